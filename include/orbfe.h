@@ -1,0 +1,191 @@
+/* orbfe.h -- C-ABI of the MI355X (gfx950) ORB front end + local-BA edge kernels.
+ *
+ * Drop-in boundary for ONE hot path of sunshanlu/ORB_SLAM2_ROS2 (all citations relative to
+ * src/ORB_SLAM2/ in that repository):
+ *
+ *   orbfe_extract*            replaces  ORBExtractor::ORBExtractor + ::extract
+ *                                       (include/ORB_SLAM2/ORBExtractor.h:107-116, src/ORBExtractor.cc:205-214, 499-508),
+ *                                       i.e. initPyramid (:278-320), extractFast (:331-387), Quadtree (:19-192),
+ *                                       getGrayCentroid (:465-487) and computeBRIEF (:397-456)
+ *   orbfe_get_pyramid         replaces  ORBExtractor::getPyramid()            (ORBExtractor.h:113)
+ *   orbfe_get_scale_factors   replaces  ORBExtractor::getScaledFactors()      (ORBExtractor.h:116)
+ *   orbfe_stereo_match        replaces  ORBMatcher::searchByStereo            (ORBMatcher.h:38, src/ORBMatcher.cc:18-81)
+ *                                       incl. createRowIndexDB (:915-932), getBestMatch (:967-990),
+ *                                       pixelSADMatch/SAD/getPitch (:841-905, :1002-1011)
+ *   orbfe_match_bruteforce    replaces  ORBMatcher::getBestMatch / descDistance loops (src/ORBMatcher.cc:941-990)
+ *   orbfe_stereo_batch_device           the same extract(L) + extract(R) + searchByStereo for a batch of stereo
+ *                                       pairs whose images are already resident in device memory
+ *                                       (Frame::Frame stereo ctor + Frame::createStereo, src/Frame.cc:85-111,
+ *                                       include/ORB_SLAM2/Frame.h:313-322)
+ *   orbfe_ba_eval_edges       replaces  the g2o edge evaluation that Optimizer::OptimizeLocalMap /
+ *                                       OptimizePoseOnly drive (src/Optimizer.cc:225-442, :33-203):
+ *                                       EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ computeError + linearizeOplus
+ *                                       + RobustKernelHuber
+ *
+ * Conventions: plain C, caller owns every host buffer, the context owns every device buffer.  No call
+ * throws or aborts; every call returns an orbfe_status and orbfe_last_error() gives the text.  Calls on
+ * distinct contexts are thread-safe; calls on one context must be serialised by the caller (the reference
+ * uses one extractor object per thread, src/Frame.cc:100-105).
+ *
+ * There is NO CPU fallback behind this interface: if no HIP device is usable, orbfe_create fails.
+ */
+#ifndef ORBFE_H_
+#define ORBFE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBFE_ABI_VERSION 1
+#define ORBFE_MAX_LEVELS 16
+#define ORBFE_DESC_BYTES 32
+
+typedef enum orbfe_status {
+  ORBFE_OK = 0,
+  ORBFE_EBADARG = 1,   /* NULL pointer, index out of range, unsupported parameter              */
+  ORBFE_EBADSIZE = 2,  /* reference: ImageSizeError (src/ORBExtractor.cc:310-314) and friends   */
+  ORBFE_EDEVICE = 3,   /* HIP runtime error / no gfx950 device                                  */
+  ORBFE_ECAPACITY = 4, /* batch larger than max_images, output buffer too small                 */
+  ORBFE_ENOMEM = 5
+} orbfe_status;
+
+/* Same memory layout as cv::KeyPoint {Point2f pt; float size, angle, response; int octave, class_id} (28 B). */
+typedef struct orbfe_keypoint {
+  float x, y;      /* level-0 coordinates: level coordinate * scale[octave] (src/ORBExtractor.cc:408-409) */
+  float size;      /* 7.0 (cv::FAST)                                                                     */
+  float angle;     /* signed degrees in (-180,180] (src/ORBExtractor.cc:407)                             */
+  float response;  /* FAST score                                                                         */
+  int32_t octave;
+  int32_t class_id; /* -1 */
+} orbfe_keypoint;
+
+typedef struct orbfe_config {
+  int32_t width, height;       /* level-0 image size (e.g. 1241x376 KITTI, 640x480 TUM)                 */
+  int32_t n_features;          /* ORBExtractor.nFeatures                                                */
+  int32_t n_levels;            /* ORBExtractor.nLevels (<= ORBFE_MAX_LEVELS)                            */
+  float scale_factor;          /* ORBExtractor.scaleFactor                                              */
+  int32_t fast_hi, fast_lo;    /* ORBExtractor.iniThFAST / minThFAST                                    */
+  const int8_t* brief_pairs;   /* 256 x {x1,y1,x2,y2}; NULL = the embedded table (config/brief_template.txt) */
+  int32_t blur_variant;        /* 0: taps {18,34,48,56,48,34,18} (default)  1: {18,34,49,55,49,34,18}    */
+  int32_t device_id;           /* HIP device ordinal                                                    */
+  int32_t max_images;          /* image slots held on the device (a stereo pair uses two)               */
+  void* stream;                /* optional hipStream_t to run on; NULL = context-owned stream           */
+} orbfe_config;
+
+typedef struct orbfe_ctx orbfe_ctx;
+
+/* Per-level geometry as the reference derives it (src/ORBExtractor.cc:283-317, 334-343). */
+typedef struct orbfe_level_info {
+  int32_t width, height;
+  float scale;                 /* mvfScaledFactors[level]                                               */
+  int32_t quota;               /* mvnFeatures[level]                                                    */
+  int32_t grid_cols, grid_rows, cell_w, cell_h; /* FAST cell grid of extractFast                        */
+} orbfe_level_info;
+
+int orbfe_abi_version(void);
+orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out);
+void orbfe_destroy(orbfe_ctx* ctx);
+const char* orbfe_last_error(const orbfe_ctx* ctx); /* ctx may be NULL: error of the last failed orbfe_create */
+
+orbfe_status orbfe_get_level_info(const orbfe_ctx* ctx, int32_t level, orbfe_level_info* out);
+orbfe_status orbfe_get_scale_factors(const orbfe_ctx* ctx, float* out, int32_t n);
+
+/* ---- extraction (host buffers) ---------------------------------------------------------------
+ * One image -> slot 0.  kps has room for n_features entries, desc for n_features*32 bytes.          */
+orbfe_status orbfe_extract(orbfe_ctx* ctx, const uint8_t* img, size_t stride_bytes, orbfe_keypoint* kps, uint8_t* desc,
+                           int32_t* n_out);
+/* n_img images -> slots 0..n_img-1; kps/desc are [n_img][n_features] arrays, n_out[n_img].           */
+orbfe_status orbfe_extract_batch(orbfe_ctx* ctx, int32_t n_img, const uint8_t* const* imgs, size_t stride_bytes,
+                                 orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out);
+/* Copy one pyramid level of a slot to the host (tight rows).  blurred=0: the planes getPyramid() returns;
+ * blurred=1: the Gaussian-blurred planes BRIEF samples (mvBriefMat).  dst needs width*height bytes.   */
+orbfe_status orbfe_get_pyramid(orbfe_ctx* ctx, int32_t slot, int32_t level, int32_t blurred, uint8_t* dst);
+
+/* ---- stereo matching over the device-resident results of the last extract --------------------
+ * right_u / depth: n_features doubles each, -1 where unmatched (mvFeatsRightU / mvDepths).
+ * best_right / best_dist (nullable, n_features int32): getBestMatch result before the thresholds
+ * (-1 where the candidate list was empty).                                                           */
+orbfe_status orbfe_stereo_match(orbfe_ctx* ctx, int32_t slot_left, int32_t slot_right, float fx, float bf, double* right_u,
+                                double* depth, int32_t* n_matches, int32_t* best_right, int32_t* best_dist);
+
+/* ---- whole stereo pairs, images already in device memory --------------------------------------
+ * d_left/d_right: device pointers to n_pairs images each, image p at base + p*image_pitch_bytes,
+ * rows stride_bytes apart.  Pair p uses slots 2p (left) and 2p+1 (right).  Asynchronous on the
+ * context stream; results stay on the device until fetched.                                          */
+orbfe_status orbfe_stereo_batch_device(orbfe_ctx* ctx, const uint8_t* d_left, const uint8_t* d_right, size_t stride_bytes,
+                                       size_t image_pitch_bytes, int32_t n_pairs, float fx, float bf);
+orbfe_status orbfe_sync(orbfe_ctx* ctx);
+/* Fetch the results of slot (keypoints/descriptors) and, for a left slot, of its pair. Any pointer may be NULL. */
+orbfe_status orbfe_fetch_features(orbfe_ctx* ctx, int32_t slot, orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out);
+orbfe_status orbfe_fetch_stereo(orbfe_ctx* ctx, int32_t pair, double* right_u, double* depth, int32_t* n_matches,
+                                int32_t* best_right, int32_t* best_dist);
+/* Device pointers of the packed per-slot results, for gathers that never touch the host
+ * (keypoints [max_images][n_features] orbfe_keypoint, descriptors [max_images][n_features][32],
+ * counts [max_images] int32, right_u/depth [max_images/2][n_features] double).                       */
+orbfe_status orbfe_device_results(orbfe_ctx* ctx, const void** d_kps, const void** d_desc, const void** d_counts,
+                                  const void** d_right_u, const void** d_depth, const void** d_nmatch);
+
+/* ---- brute-force Hamming-256 best / second-best (host buffers) --------------------------------
+ * q: nq*32 bytes, t: nt*32 bytes.  Candidate lists in CSR form: query i scans train indices
+ * cand_idx[cand_offsets[i] .. cand_offsets[i+1]) IN THAT ORDER (order matters, quirk Q6);
+ * cand_offsets == NULL means "all nt, ascending".  Outputs per query: best_idx (-1 if no candidate),
+ * best_dist, second_dist (INT32_MAX if none) exactly as ORBMatcher::getBestMatch computes them.       */
+orbfe_status orbfe_match_bruteforce(orbfe_ctx* ctx, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt,
+                                    const uint32_t* cand_offsets, const uint32_t* cand_idx, int32_t* best_idx,
+                                    int32_t* best_dist, int32_t* second_dist);
+
+/* ---- local-BA edge evaluation (fp64) ----------------------------------------------------------- */
+typedef struct orbfe_ba_problem {
+  int32_t n_poses, n_points, n_edges;
+  const double* poses;       /* [n_poses][7]  qx,qy,qz,qw, tx,ty,tz  (g2o::SE3Quat of VertexSE3Expmap)   */
+  const double* points;      /* [n_points][3] (VertexPointXYZ)                                          */
+  const int32_t* edge_pose;  /* [n_edges]                                                               */
+  const int32_t* edge_point; /* [n_edges]                                                               */
+  const double* meas;        /* [n_edges][3]  u, v, u_right (u_right ignored for mono edges)            */
+  const uint8_t* is_stereo;  /* [n_edges]     1: EdgeStereoSE3ProjectXYZ, 0: EdgeSE3ProjectXYZ           */
+  const double* info;        /* [n_edges]     information = info * I                                    */
+  const double* huber_delta; /* [n_edges]     <= 0: no robust kernel                                    */
+  double fx, fy, cx, cy, bf;
+} orbfe_ba_problem;
+
+typedef struct orbfe_ba_edge_out {
+  double* error;    /* [n_edges][3]  (3rd component 0 for mono)                                         */
+  double* chi2;     /* [n_edges]                                                                        */
+  double* rho;      /* [n_edges][2]  robustified chi2 rho(chi2), weight rho'(chi2)                      */
+  double* j_point;  /* [n_edges][3][3] d e / d point (rows 0-1 used for mono), nullable                 */
+  double* j_pose;   /* [n_edges][3][6] d e / d (omega, upsilon), nullable                               */
+  uint8_t* depth_positive; /* [n_edges] isDepthPositive(), nullable                                     */
+} orbfe_ba_edge_out;
+
+orbfe_status orbfe_ba_eval_edges(orbfe_ctx* ctx, const orbfe_ba_problem* prob, const orbfe_ba_edge_out* out);
+
+/* ---- instrumentation ---------------------------------------------------------------------------
+ * Stage timing with HIP events on the context stream.  Enable, run, then read the accumulated
+ * per-stage milliseconds and launch counts.  Stage ids: see orbfe_stage.                             */
+typedef enum orbfe_stage {
+  ORBFE_STAGE_RESIZE = 0,
+  ORBFE_STAGE_BLUR = 1,
+  ORBFE_STAGE_FAST = 2,
+  ORBFE_STAGE_QUADTREE = 3,
+  ORBFE_STAGE_BRIEF = 4,
+  ORBFE_STAGE_STEREO = 5,
+  ORBFE_STAGE_MATCH = 6,
+  ORBFE_STAGE_BA = 7,
+  ORBFE_STAGE_COUNT = 8
+} orbfe_stage;
+orbfe_status orbfe_profile_enable(orbfe_ctx* ctx, int32_t on);
+orbfe_status orbfe_profile_read(orbfe_ctx* ctx, double* ms /*[ORBFE_STAGE_COUNT]*/, int64_t* launches /*[..]*/, int32_t reset);
+const char* orbfe_stage_name(int32_t stage);
+
+/* ---- debugging / parity aids (used by tests; stable but not part of the drop-in surface) -------
+ * FAST candidates of (slot, level) in the reference's order (cell-row-major, in-cell raster), region
+ * coordinates: xyr[3*i] = x, y, response.  Returns the count through n_out even if cap is too small.  */
+orbfe_status orbfe_debug_candidates(orbfe_ctx* ctx, int32_t slot, int32_t level, float* xyr, int32_t cap, int32_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBFE_H_ */

@@ -1,0 +1,231 @@
+"""ctypes binding of the CPU oracle (oracle/liborb_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the product
+package (orb_slam2_ros2_amd) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+KP_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")]
+)
+assert KP_DTYPE.itemsize == 28
+
+
+def build(fast: bool = False, out_dir: str | None = None) -> str:
+    """Compile the oracle if needed and return the path of the .so."""
+    name = "liborb_oracle_fast.so" if fast else "liborb_oracle.so"
+    if out_dir is None:
+        subprocess.check_call(["make", "-s", "-C", _HERE, name])
+        return os.path.join(_HERE, name)
+    # out-of-tree build (bench.py builds the -march=native flavour on the box it runs on)
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, name)
+    flags = ["-O3", "-march=native"] if fast else ["-O2"]
+    cmd = ["g++", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-pthread", *flags, "-o", out,
+           os.path.join(_HERE, "orb_oracle.cpp"), os.path.join(_HERE, "ba_oracle.cpp")]
+    subprocess.check_call(cmd)
+    return out
+
+
+_u8p = C.POINTER(C.c_uint8)
+
+
+def _p(a, t=C.c_void_p):
+    return a.ctypes.data_as(t)
+
+
+class Oracle:
+    def __init__(self, path: str | None = None):
+        self.path = path or build()
+        L = self.lib = C.CDLL(self.path)
+        L.orc_extractor_create.restype = C.c_void_p
+        L.orc_extractor_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_int, C.c_int]
+        L.orc_extractor_destroy.argtypes = [C.c_void_p]
+        L.orc_extractor_level_info.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
+        L.orc_extractor_plane.restype = C.c_void_p
+        L.orc_extractor_plane.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_extractor_umax.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_extractor_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_extractor_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_extractor_splits.restype = C.c_long
+        L.orc_extractor_splits.argtypes = [C.c_void_p, C.c_int]
+        L.orc_extractor_thetas.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_gauss7_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.orc_fast9_16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_quadtree_select.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_hamming256.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_best_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
+        L.orc_match_bruteforce.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_atan2.restype = C.c_double
+        L.orc_atan2.argtypes = [C.c_double, C.c_double, C.c_int]
+        L.orc_sincos.argtypes = [C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_stereo_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                       C.c_int, C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 8
+
+    # ---- primitives ------------------------------------------------------------------------
+    def resize(self, src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dst = np.empty((dh, dw), np.uint8)
+        self.lib.orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), dw, dh, dw)
+        return dst
+
+    def gauss7(self, src: np.ndarray, variant: int = 0) -> np.ndarray:
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dst = np.empty_like(src)
+        self.lib.orc_gauss7_u8(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), src.shape[1], variant)
+        return dst
+
+    def fast(self, patch: np.ndarray, threshold: int, nonmax: bool = True) -> np.ndarray:
+        patch = np.ascontiguousarray(patch, dtype=np.uint8)
+        cap = patch.size
+        out = np.empty((cap, 3), np.int32)
+        n = self.lib.orc_fast9_16(_p(patch), patch.shape[1], patch.shape[1], patch.shape[0], threshold, int(nonmax), _p(out), cap)
+        return out[:n].copy()
+
+    def quadtree(self, w: int, h: int, xyr: np.ndarray, need: int):
+        xyr = np.ascontiguousarray(xyr, dtype=np.float32).reshape(-1, 3)
+        out = np.empty(max(need, 1) + 8, np.int32)
+        ns = C.c_int64(0)
+        n = self.lib.orc_quadtree_select(w, h, _p(xyr), xyr.shape[0], need, _p(out), C.byref(ns))
+        return out[:n].copy(), ns.value
+
+    def hamming(self, a: np.ndarray, b: np.ndarray) -> int:
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        return self.lib.orc_hamming256(_p(a), _p(b))
+
+    def best_match(self, q: np.ndarray, train: np.ndarray, cand: np.ndarray):
+        q = np.ascontiguousarray(q, np.uint8)
+        train = np.ascontiguousarray(train, np.uint8)
+        cand = np.ascontiguousarray(cand, np.int64)
+        bi, bd, sd, ratio = C.c_int64(0), C.c_int(0), C.c_int(0), C.c_float(0)
+        self.lib.orc_best_match(_p(q), _p(train), _p(cand), cand.size, C.byref(bi), C.byref(bd), C.byref(sd), C.byref(ratio))
+        return bi.value, bd.value, sd.value, ratio.value
+
+    def match_bruteforce(self, q: np.ndarray, t: np.ndarray):
+        q = np.ascontiguousarray(q, np.uint8)
+        t = np.ascontiguousarray(t, np.uint8)
+        nq, nt = q.shape[0], t.shape[0]
+        bi = np.empty(nq, np.int32)
+        bd = np.empty(nq, np.int32)
+        sd = np.empty(nq, np.int32)
+        self.lib.orc_match_bruteforce(_p(q), nq, _p(t), nt, _p(bi), _p(bd), _p(sd))
+        return bi, bd, sd
+
+    def atan2(self, y, x, mode=0):
+        return self.lib.orc_atan2(float(y), float(x), mode)
+
+    def sincos(self, t, mode=0):
+        s, c = C.c_double(0), C.c_double(0)
+        self.lib.orc_sincos(float(t), mode, C.byref(s), C.byref(c))
+        return s.value, c.value
+
+    # ---- extractor --------------------------------------------------------------------------
+    def extractor(self, img: np.ndarray, n_features=2000, n_levels=8, scale=1.2, th_hi=20, th_lo=7, pattern=None, blur_variant=0,
+                  math_mode=0) -> "OracleExtractor":
+        return OracleExtractor(self, img, n_features, n_levels, scale, th_hi, th_lo, pattern, blur_variant, math_mode)
+
+    def stereo_frame(self, left, right, n_features=2000, n_levels=8, scale=1.2, th_hi=20, th_lo=7, fx=718.856, bf=386.1448,
+                     math_mode=0, threads=2, want_outputs=True):
+        left = np.ascontiguousarray(left, np.uint8)
+        right = np.ascontiguousarray(right, np.uint8)
+        h, w = left.shape
+        if not want_outputs:
+            return self.lib.orc_stereo_frame(_p(left), _p(right), w, h, w, n_features, n_levels, scale, th_hi, th_lo, fx, bf,
+                                             math_mode, threads, *([None] * 8))
+        lk = np.zeros(n_features, KP_DTYPE)
+        rk = np.zeros(n_features, KP_DTYPE)
+        ld = np.zeros((n_features, 32), np.uint8)
+        rd = np.zeros((n_features, 32), np.uint8)
+        nl, nr = C.c_int32(0), C.c_int32(0)
+        ru = np.zeros(n_features, np.float64)
+        dp = np.zeros(n_features, np.float64)
+        m = self.lib.orc_stereo_frame(_p(left), _p(right), w, h, w, n_features, n_levels, scale, th_hi, th_lo, fx, bf, math_mode,
+                                      threads, _p(lk), _p(ld), C.byref(nl), _p(rk), _p(rd), C.byref(nr), _p(ru), _p(dp))
+        nl, nr = nl.value, nr.value
+        return dict(n_matches=m, lk=lk[:nl], ld=ld[:nl], rk=rk[:nr], rd=rd[:nr], right_u=ru[:nl], depth=dp[:nl])
+
+
+class OracleExtractor:
+    """Mirrors ORBExtractor (ORBExtractor.cc:205-214): the pyramid and blur are built in the constructor."""
+
+    def __init__(self, orc: Oracle, img, n_features, n_levels, scale, th_hi, th_lo, pattern, blur_variant, math_mode):
+        self.orc = orc
+        img = np.ascontiguousarray(img, np.uint8)
+        self.n_features, self.n_levels = n_features, n_levels
+        pat = None
+        if pattern is not None:
+            pat = np.ascontiguousarray(pattern, np.int8).reshape(256, 4)
+        self._pat = pat
+        self.h = orc.lib.orc_extractor_create(_p(img), img.shape[1], img.shape[0], img.shape[1], n_features, n_levels, scale,
+                                              th_hi, th_lo, _p(pat) if pat is not None else None, blur_variant, math_mode)
+        if not self.h:
+            raise ValueError("ImageSizeError: a pyramid level is smaller than 2*19 px")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.orc.lib.orc_extractor_destroy(self.h)
+            self.h = None
+
+    def level_info(self, level):
+        w, h, q = C.c_int(0), C.c_int(0), C.c_int(0)
+        sf = C.c_float(0)
+        self.orc.lib.orc_extractor_level_info(self.h, level, C.byref(w), C.byref(h), C.byref(sf), C.byref(q))
+        return w.value, h.value, sf.value, q.value
+
+    def plane(self, level, blurred=False) -> np.ndarray:
+        w, h, _, _ = self.level_info(level)
+        ptr = self.orc.lib.orc_extractor_plane(self.h, level, int(blurred))
+        buf = (C.c_uint8 * (w * h)).from_address(ptr)
+        return np.frombuffer(buf, np.uint8).reshape(h, w).copy()
+
+    def umax(self):
+        out = np.zeros(16, np.int32)
+        self.orc.lib.orc_extractor_umax(self.h, _p(out))
+        return out
+
+    def extract(self):
+        kps = np.zeros(self.n_features + 64, KP_DTYPE)
+        desc = np.zeros((self.n_features + 64, 32), np.uint8)
+        n = self.orc.lib.orc_extractor_extract(self.h, _p(kps), _p(desc), kps.shape[0])
+        return kps[:n].copy(), desc[:n].copy()
+
+    def candidates(self, level):
+        n = self.orc.lib.orc_extractor_candidates(self.h, level, None, 0)
+        out = np.zeros((max(n, 1), 3), np.float32)
+        self.orc.lib.orc_extractor_candidates(self.h, level, _p(out), n)
+        return out[:n]
+
+    def splits(self, level):
+        return self.orc.lib.orc_extractor_splits(self.h, level)
+
+    def thetas(self):
+        out = np.zeros(self.n_features + 64, np.float64)
+        n = self.orc.lib.orc_extractor_thetas(self.h, _p(out), out.size)
+        return out[:n]
+
+    def stereo_match(self, right: "OracleExtractor", lk, ld, rk, rd, fx, bf):
+        lk = np.ascontiguousarray(lk)
+        rk = np.ascontiguousarray(rk)
+        ld = np.ascontiguousarray(ld, np.uint8)
+        rd = np.ascontiguousarray(rd, np.uint8)
+        nl, nr = lk.shape[0], rk.shape[0]
+        ru = np.zeros(max(nl, 1), np.float64)
+        dp = np.zeros(max(nl, 1), np.float64)
+        br = np.zeros(max(nl, 1), np.int32)
+        bd = np.zeros(max(nl, 1), np.int32)
+        m = self.orc.lib.orc_stereo_match(self.h, right.h, _p(lk), _p(ld), nl, _p(rk), _p(rd), nr, fx, bf, _p(ru), _p(dp), _p(br),
+                                          _p(bd))
+        return m, ru[:nl], dp[:nl], br[:nl], bd[:nl]

@@ -1,0 +1,278 @@
+"""ctypes binding of the C-ABI in include/orbfe.h (liborbfe_hip.so).
+
+There is no fallback: if the HIP library is missing or no device is usable this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborbfe_hip.so")
+
+KP_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")]
+)
+assert KP_DTYPE.itemsize == 28
+
+ORBFE_OK = 0
+STATUS_NAMES = {0: "OK", 1: "EBADARG", 2: "EBADSIZE", 3: "EDEVICE", 4: "ECAPACITY", 5: "ENOMEM"}
+STAGE_COUNT = 8
+
+
+class OrbfeError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"orbfe {STATUS_NAMES.get(status, status)}: {msg}")
+        self.status = status
+
+
+class ImageSizeError(OrbfeError):
+    """Mirrors the reference's ImageSizeError (include/ORB_SLAM2/Error.h, thrown at ORBExtractor.cc:310-314)."""
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("n_features", C.c_int32), ("n_levels", C.c_int32),
+        ("scale_factor", C.c_float), ("fast_hi", C.c_int32), ("fast_lo", C.c_int32), ("brief_pairs", C.c_void_p),
+        ("blur_variant", C.c_int32), ("device_id", C.c_int32), ("max_images", C.c_int32), ("stream", C.c_void_p),
+    ]
+
+
+class LevelInfo(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("scale", C.c_float), ("quota", C.c_int32),
+                ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("cell_w", C.c_int32), ("cell_h", C.c_int32)]
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32), ("poses", C.c_void_p),
+                ("points", C.c_void_p), ("edge_pose", C.c_void_p), ("edge_point", C.c_void_p), ("meas", C.c_void_p),
+                ("is_stereo", C.c_void_p), ("info", C.c_void_p), ("huber_delta", C.c_void_p), ("fx", C.c_double),
+                ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double)]
+
+
+class BaEdgeOut(C.Structure):
+    _fields_ = [("error", C.c_void_p), ("chi2", C.c_void_p), ("rho", C.c_void_p), ("j_point", C.c_void_p),
+                ("j_pose", C.c_void_p), ("depth_positive", C.c_void_p)]
+
+
+EXPORTS = [
+    "orbfe_abi_version", "orbfe_create", "orbfe_destroy", "orbfe_last_error", "orbfe_get_level_info", "orbfe_get_scale_factors",
+    "orbfe_extract", "orbfe_extract_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
+    "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges",
+    "orbfe_profile_enable", "orbfe_profile_read", "orbfe_stage_name", "orbfe_debug_candidates",
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load liborbfe_hip.so (built by orb_slam2_ros2_amd/csrc/Makefile); raises if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(f"{LIB_PATH} is missing: build it with `make -C orb_slam2_ros2_amd/csrc` "
+                      "(there is no CPU fallback for the front end)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    L.orbfe_abi_version.restype = C.c_int
+    L.orbfe_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.orbfe_destroy.argtypes = [vp]
+    L.orbfe_destroy.restype = None
+    L.orbfe_last_error.argtypes = [vp]
+    L.orbfe_last_error.restype = C.c_char_p
+    L.orbfe_get_level_info.argtypes = [vp, i32, C.POINTER(LevelInfo)]
+    L.orbfe_get_scale_factors.argtypes = [vp, vp, i32]
+    L.orbfe_extract.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
+    L.orbfe_extract_batch.argtypes = [vp, i32, vp, C.c_size_t, vp, vp, vp]
+    L.orbfe_get_pyramid.argtypes = [vp, i32, i32, i32, vp]
+    L.orbfe_stereo_match.argtypes = [vp, i32, i32, f32, f32, vp, vp, vp, vp, vp]
+    L.orbfe_stereo_batch_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, i32, f32, f32]
+    L.orbfe_sync.argtypes = [vp]
+    L.orbfe_fetch_features.argtypes = [vp, i32, vp, vp, vp]
+    L.orbfe_fetch_stereo.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    L.orbfe_device_results.argtypes = [vp] + [C.POINTER(vp)] * 6
+    L.orbfe_match_bruteforce.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]
+    L.orbfe_ba_eval_edges.argtypes = [vp, C.POINTER(BaProblem), C.POINTER(BaEdgeOut)]
+    L.orbfe_profile_enable.argtypes = [vp, i32]
+    L.orbfe_profile_read.argtypes = [vp, vp, vp, i32]
+    L.orbfe_stage_name.argtypes = [i32]
+    L.orbfe_stage_name.restype = C.c_char_p
+    L.orbfe_debug_candidates.argtypes = [vp, i32, i32, vp, i32, vp]
+    _lib = L
+    return L
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """Owns one orbfe_ctx (device buffers for `max_images` image slots of one fixed geometry)."""
+
+    def __init__(self, width, height, n_features=2000, n_levels=8, scale_factor=1.2, fast_hi=20, fast_lo=7, brief_pairs=None,
+                 blur_variant=0, device_id=0, max_images=2, stream=None):
+        self.lib = load()
+        self._pairs = None
+        if brief_pairs is not None:
+            self._pairs = np.ascontiguousarray(brief_pairs, np.int8).reshape(256, 4)
+        cfg = Config(width, height, n_features, n_levels, scale_factor, fast_hi, fast_lo, ptr(self._pairs), blur_variant,
+                     device_id, max_images, stream)
+        self.cfg = cfg
+        h = C.c_void_p(None)
+        st = self.lib.orbfe_create(C.byref(cfg), C.byref(h))
+        if st != ORBFE_OK:
+            msg = self.lib.orbfe_last_error(None).decode()
+            raise (ImageSizeError if st == 2 else OrbfeError)(st, msg)
+        self.h = h
+        self.width, self.height, self.n_features, self.n_levels, self.max_images = width, height, n_features, n_levels, max_images
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.orbfe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != ORBFE_OK:
+            msg = self.lib.orbfe_last_error(self.h).decode()
+            raise (ImageSizeError if st == 2 else OrbfeError)(st, msg)
+
+    # ---- geometry ---------------------------------------------------------------------------
+    def level_info(self, level) -> LevelInfo:
+        li = LevelInfo()
+        self._check(self.lib.orbfe_get_level_info(self.h, level, C.byref(li)))
+        return li
+
+    def scale_factors(self) -> np.ndarray:
+        out = np.zeros(self.n_levels, np.float32)
+        self._check(self.lib.orbfe_get_scale_factors(self.h, ptr(out), self.n_levels))
+        return out
+
+    # ---- extraction -------------------------------------------------------------------------
+    def extract_batch(self, imgs):
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in imgs]
+        n = len(imgs)
+        for im in imgs:
+            if im.shape != (self.height, self.width):
+                raise ValueError(f"image shape {im.shape} != context geometry {(self.height, self.width)}")
+        arr = (C.c_void_p * max(n, 1))(*[im.ctypes.data for im in imgs])
+        kps = np.zeros((max(n, 1), max(self.n_features, 1)), KP_DTYPE)
+        desc = np.zeros((max(n, 1), max(self.n_features, 1), 32), np.uint8)
+        cnt = np.zeros(max(n, 1), np.int32)
+        self._check(self.lib.orbfe_extract_batch(self.h, n, arr, self.width, ptr(kps), ptr(desc), ptr(cnt)))
+        return [(kps[i, :cnt[i]].copy(), desc[i, :cnt[i]].copy()) for i in range(n)]
+
+    def extract(self, img):
+        return self.extract_batch([img])[0]
+
+    def pyramid(self, slot, level, blurred=False) -> np.ndarray:
+        li = self.level_info(level)
+        out = np.zeros((li.height, li.width), np.uint8)
+        self._check(self.lib.orbfe_get_pyramid(self.h, slot, level, int(blurred), ptr(out)))
+        return out
+
+    def debug_candidates(self, slot, level) -> np.ndarray:
+        n = C.c_int32(0)
+        self._check(self.lib.orbfe_debug_candidates(self.h, slot, level, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 3), np.float32)
+        self._check(self.lib.orbfe_debug_candidates(self.h, slot, level, ptr(out), n.value, C.byref(n)))
+        return out[:n.value]
+
+    # ---- stereo -------------------------------------------------------------------------------
+    def stereo_match(self, slot_left, slot_right, fx, bf):
+        nf = max(self.n_features, 1)
+        ru = np.zeros(nf, np.float64)
+        dp = np.zeros(nf, np.float64)
+        br = np.zeros(nf, np.int32)
+        bd = np.zeros(nf, np.int32)
+        nm = C.c_int32(0)
+        self._check(self.lib.orbfe_stereo_match(self.h, slot_left, slot_right, fx, bf, ptr(ru), ptr(dp), C.byref(nm), ptr(br), ptr(bd)))
+        return nm.value, ru, dp, br, bd
+
+    def stereo_batch_device(self, d_left_ptr, d_right_ptr, stride, image_pitch, n_pairs, fx, bf):
+        self._check(self.lib.orbfe_stereo_batch_device(self.h, d_left_ptr, d_right_ptr, stride, image_pitch, n_pairs, fx, bf))
+
+    def sync(self):
+        self._check(self.lib.orbfe_sync(self.h))
+
+    def fetch_features(self, slot):
+        nf = max(self.n_features, 1)
+        kps = np.zeros(nf, KP_DTYPE)
+        desc = np.zeros((nf, 32), np.uint8)
+        n = C.c_int32(0)
+        self._check(self.lib.orbfe_fetch_features(self.h, slot, ptr(kps), ptr(desc), C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def fetch_stereo(self, pair):
+        nf = max(self.n_features, 1)
+        ru = np.zeros(nf, np.float64)
+        dp = np.zeros(nf, np.float64)
+        br = np.zeros(nf, np.int32)
+        bd = np.zeros(nf, np.int32)
+        nm = C.c_int32(0)
+        self._check(self.lib.orbfe_fetch_stereo(self.h, pair, ptr(ru), ptr(dp), C.byref(nm), ptr(br), ptr(bd)))
+        return nm.value, ru, dp, br, bd
+
+    def device_results(self):
+        ps = [C.c_void_p(None) for _ in range(6)]
+        self._check(self.lib.orbfe_device_results(self.h, *[C.byref(p) for p in ps]))
+        return dict(zip(["kps", "desc", "counts", "right_u", "depth", "n_match"], [p.value for p in ps]))
+
+    # ---- matching -----------------------------------------------------------------------------
+    def match_bruteforce(self, q, t, cand_offsets=None, cand_idx=None):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        nq, nt = q.shape[0], t.shape[0]
+        if cand_offsets is not None:
+            cand_offsets = np.ascontiguousarray(cand_offsets, np.uint32)
+            cand_idx = np.ascontiguousarray(cand_idx if cand_idx is not None else np.zeros(0), np.uint32)
+            assert cand_offsets.size == nq + 1
+        bi = np.zeros(max(nq, 1), np.int32)
+        bd = np.zeros(max(nq, 1), np.int32)
+        sd = np.zeros(max(nq, 1), np.int32)
+        self._check(self.lib.orbfe_match_bruteforce(self.h, ptr(q), nq, ptr(t), nt, ptr(cand_offsets), ptr(cand_idx), ptr(bi), ptr(bd), ptr(sd)))
+        return bi[:nq], bd[:nq], sd[:nq]
+
+    # ---- BA -------------------------------------------------------------------------------------
+    def ba_eval_edges(self, poses, points, edge_pose, edge_point, meas, is_stereo, info, huber_delta, fx, fy, cx, cy, bf,
+                      jacobians=True):
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+        points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+        edge_pose = np.ascontiguousarray(edge_pose, np.int32)
+        edge_point = np.ascontiguousarray(edge_point, np.int32)
+        meas = np.ascontiguousarray(meas, np.float64).reshape(-1, 3)
+        is_stereo = np.ascontiguousarray(is_stereo, np.uint8)
+        info = np.ascontiguousarray(info, np.float64)
+        huber_delta = np.ascontiguousarray(huber_delta, np.float64)
+        E = edge_pose.size
+        prob = BaProblem(poses.shape[0], points.shape[0], E, ptr(poses).value, ptr(points).value, ptr(edge_pose).value,
+                         ptr(edge_point).value, ptr(meas).value, ptr(is_stereo).value, ptr(info).value, ptr(huber_delta).value,
+                         fx, fy, cx, cy, bf)
+        out = dict(error=np.zeros((E, 3)), chi2=np.zeros(E), rho=np.zeros((E, 2)), depth_positive=np.zeros(E, np.uint8))
+        if jacobians:
+            out["j_point"] = np.zeros((E, 3, 3))
+            out["j_pose"] = np.zeros((E, 3, 6))
+        o = BaEdgeOut(ptr(out["error"]).value, ptr(out["chi2"]).value, ptr(out["rho"]).value,
+                      ptr(out["j_point"]).value if jacobians else None, ptr(out["j_pose"]).value if jacobians else None,
+                      ptr(out["depth_positive"]).value)
+        self._check(self.lib.orbfe_ba_eval_edges(self.h, C.byref(prob), C.byref(o)))
+        return out
+
+    # ---- instrumentation ------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self.lib.orbfe_profile_enable(self.h, int(on)))
+
+    def profile_read(self, reset=True):
+        ms = np.zeros(STAGE_COUNT, np.float64)
+        n = np.zeros(STAGE_COUNT, np.int64)
+        self._check(self.lib.orbfe_profile_read(self.h, ptr(ms), ptr(n), int(reset)))
+        names = [self.lib.orbfe_stage_name(i).decode() for i in range(STAGE_COUNT)]
+        return {names[i]: (float(ms[i]), int(n[i])) for i in range(STAGE_COUNT)}

@@ -1,0 +1,247 @@
+// k_match.hip -- Hamming-256 best/second-best matching on gfx950: masked brute force (one wavefront per
+// query) and the stereo epipolar matcher with 11x11 SAD sub-pixel refinement (one wavefront per left
+// keypoint).
+//
+// Replaces ORBMatcher::descDistance (src/ORB_SLAM2/src/ORBMatcher.cc:941-956), getBestMatch (:967-990),
+// createRowIndexDB (:915-932), searchByStereo (:18-81), pixelSADMatch / SAD / getPitch (:841-905, :1002-1011).
+//
+// getBestMatch is order dependent (quirk Q6): when a new minimum is found the old minimum is NOT demoted
+// to second best.  Equivalent order-free form used here, evaluated 64 candidates at a time in list order:
+//   best   = first index attaining the global minimum
+//   second = min over the candidates that are not strict prefix-minimum records at their position
+// A candidate is a record iff d < min(all earlier d); the exclusive prefix-min inside a 64-chunk is a
+// 6-step wave scan, the carry between chunks is a scalar.
+#include <hip/hip_runtime.h>
+
+#include "orbfe_internal.h"
+
+namespace orbfe {
+
+#define ORB_INT_MAX 2147483647
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_excl_prefix_min(int v, int lane) {
+  // inclusive scan, then shift by one lane
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o);
+    if (lane >= o) v = min(v, t);
+  }
+  const int p = __shfl_up(v, 1);
+  return lane == 0 ? ORB_INT_MAX : p;
+}
+
+struct Best2 {
+  int min_d, second, min_idx;
+};
+
+// Fold one chunk of up to 64 candidates (lane order = list order) into the running (min, idx, second).
+// d = distance of this lane's candidate or INT_MAX if the lane holds none; idx = its train index.
+__device__ __forceinline__ void fold_chunk(Best2& b, int d, int idx, int lane) {
+  const int pre = min(b.min_d, wave_excl_prefix_min(d, lane));
+  const bool record = d < pre;
+  const int sec = wave_min_i(record ? ORB_INT_MAX : d);
+  b.second = min(b.second, sec);
+  const int cmin = wave_min_i(d);
+  if (cmin < b.min_d) {
+    const unsigned long long m = __ballot(d == cmin);
+    const int first = __ffsll((long long)m) - 1;
+    b.min_d = cmin;
+    b.min_idx = __shfl(idx, first);
+  }
+}
+
+__device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const uint8_t* __restrict__ p) {
+  const uint4 b0 = *(const uint4*)p;
+  const uint4 b1 = *(const uint4*)(p + 16);
+  return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
+         __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// ---------------------------------------------------------------------------------------------
+// brute force: query i scans cand_idx[off[i]..off[i+1]) (or 0..nt-1) in order
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_match_bruteforce(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t,
+                                                          int nt, const uint32_t* __restrict__ off,
+                                                          const uint32_t* __restrict__ cand, int32_t* __restrict__ best_idx,
+                                                          int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= nq) return;
+  const uint4 a0 = *(const uint4*)(q + (size_t)i * 32);
+  const uint4 a1 = *(const uint4*)(q + (size_t)i * 32 + 16);
+  const int begin = off ? (int)off[i] : 0;
+  const int end = off ? (int)off[i + 1] : nt;
+  Best2 b = {ORB_INT_MAX, ORB_INT_MAX, 0};
+  for (int c0 = begin; c0 < end; c0 += 64) {
+    const int c = c0 + lane;
+    int d = ORB_INT_MAX, idx = 0;
+    if (c < end) {
+      idx = off ? (int)cand[c] : c;
+      d = hamming256(a0, a1, t + (size_t)idx * 32);
+    }
+    fold_chunk(b, d, idx, lane);
+  }
+  if (lane == 0) {
+    best_idx[i] = (end > begin) ? b.min_idx : -1;
+    best_dist[i] = b.min_d;
+    second_dist[i] = b.second;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stereo: one wave per left keypoint of pair blockIdx.y
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cv_floor_f(float v) {
+  const int i = (int)v;
+  return i - (i > v);
+}
+
+__global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv, const uint8_t* __restrict__ pyr, size_t img_pitch,
+                                                const orbfe_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                const KpAux* __restrict__ aux, const int32_t* __restrict__ n_kp, int n_features,
+                                                float fx, float bf, int cols0, int mean_threshold, double* __restrict__ right_u,
+                                                double* __restrict__ depth, int32_t* __restrict__ n_match,
+                                                int32_t* __restrict__ best_right, int32_t* __restrict__ best_dist, int slot_l0,
+                                                int slot_r0, int slot_step, int pair0) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x & 63;
+  const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int pair = pair0 + blockIdx.y;
+  const int sl = slot_l0 + blockIdx.y * slot_step, sr = slot_r0 + blockIdx.y * slot_step;
+  const size_t out_i = (size_t)pair * n_features + li;
+  if (li >= n_features) return;
+  const int nl = n_kp[sl], nr = n_kp[sr];
+  if (li >= nl) {
+    if (lane == 0) {
+      right_u[out_i] = -1.0;
+      depth[out_i] = -1.0;
+      best_right[out_i] = -1;
+      best_dist[out_i] = -1;
+    }
+    return;
+  }
+  const orbfe_keypoint* LK = kps + (size_t)sl * n_features;
+  const orbfe_keypoint* RK = kps + (size_t)sr * n_features;
+  const uint8_t* LD = desc + (size_t)sl * n_features * 32;
+  const uint8_t* RD = desc + (size_t)sr * n_features * 32;
+  const KpAux* RA = aux + (size_t)sr * n_features;
+
+  const orbfe_keypoint l = LK[li];
+  const float max_u = l.x - 0;
+  const float min_u = fmaxf(0.f, l.x - fx);
+  const int row = __float2int_rn(l.y);
+  const uint4 a0 = *(const uint4*)(LD + (size_t)li * 32);
+  const uint4 a1 = *(const uint4*)(LD + (size_t)li * 32 + 16);
+
+  // candidates = rowIdxDB[row] filtered by the u-range, in ascending right index (ORBMatcher.cc:38-48)
+  Best2 b = {ORB_INT_MAX, ORB_INT_MAX, 0};
+  bool any = false;
+  for (int c0 = 0; c0 < nr; c0 += 64) {
+    const int c = c0 + lane;
+    bool pass = false;
+    if (c < nr) {
+      const KpAux a = RA[c];
+      const float rx = RK[c].x;
+      pass = row >= a.row_min && row < a.row_max && rx < max_u && rx > min_u;
+    }
+    if (__ballot(pass) == 0ull) continue;
+    any = true;
+    const int d = pass ? hamming256(a0, a1, RD + (size_t)c * 32) : ORB_INT_MAX;
+    fold_chunk(b, d, c, lane);
+  }
+  double out_u = -1.0, out_depth = -1.0;
+  int matched = 0;
+  if (any && b.min_d <= mean_threshold) {
+    const orbfe_keypoint r = RK[b.min_idx];
+    if (!(l.octave > r.octave + 1 || l.octave < r.octave - 1)) {
+      // ---- pixelSADMatch (ORBMatcher.cc:841-881): 11 SADs of centre-subtracted 11x11 patches ----
+      const LevelDev& LL = lv[l.octave];
+      const LevelDev& LR = lv[r.octave];
+      const uint8_t* IL = pyr + (size_t)sl * img_pitch + LL.plane_off;
+      const uint8_t* IR = pyr + (size_t)sr * img_pitch + LR.plane_off;
+      const int lx = cv_floor_f(l.x / LL.sf), ly = cv_floor_f(l.y / LL.sf);  // getPitch (:1004-1006)
+      const int rx = cv_floor_f(r.x / LR.sf), ry = cv_floor_f(r.y / LR.sf);
+      const int c1 = IL[(size_t)ly * LL.stride + lx];
+      const int c2 = IR[(size_t)ry * LR.stride + rx];
+      // lane = part*11 + Lidx, part 0..4 sums rows {part, part+5, (part+10 if part==0)}
+      int partial = 0;
+      if (lane < 55) {
+        const int Lidx = lane % 11, part = lane / 11;
+        const int Ls = Lidx - 5;
+        for (int rr = part; rr < 11; rr += 5) {
+          const uint8_t* pl = IL + (size_t)(ly - 5 + rr) * LL.stride + (lx - 5);
+          const uint8_t* pr = IR + (size_t)(ry - 5 + rr) * LR.stride + (rx + Ls - 5);
+#pragma unroll
+          for (int cc = 0; cc < 11; ++cc) {
+            const int dlt = ((int)pl[cc] - c1) - ((int)pr[cc] - c2);
+            partial += dlt < 0 ? -dlt : dlt;
+          }
+        }
+      }
+      int sad = partial;
+      sad += __shfl(partial, (lane + 11) & 63);
+      sad += __shfl(partial, (lane + 22) & 63);
+      sad += __shfl(partial, (lane + 33) & 63);
+      sad += __shfl(partial, (lane + 44) & 63);
+      // lanes 0..10 now hold SAD(L = lane-5); first minimum wins (strict <, :856)
+      const int mine = lane < 11 ? sad : ORB_INT_MAX;
+      const int smin = wave_min_i(mine);
+      const int best_l = __ffsll((long long)__ballot(mine == smin)) - 1;  // 0..10 == bestL + mnL
+      float delta_u = 0.f;
+      if (best_l > 0 && best_l < 10) {
+        const float s1 = (float)__shfl(sad, best_l - 1);
+        const float s2 = (float)__shfl(sad, best_l);
+        const float s3 = (float)__shfl(sad, best_l + 1);
+        delta_u = (float)(0.5 * (double)(s1 - s3) / (double)(s1 + s3 - 2 * s2));
+        if (delta_u < 1 && delta_u > -1) delta_u *= LR.sf;
+        else delta_u = 0.f;
+      }
+      float ru = r.x + delta_u;  // bestL itself is not added (quirk Q7)
+      ru = fmaxf(0.f, ru);
+      ru = fminf(ru, (float)cols0 - 1);
+      float delta = l.x - ru;
+      bool ok = true;
+      if (delta <= 0) {
+        ru = r.x;
+        delta = l.x - ru;
+        if (delta <= 0) ok = false;
+      }
+      if (ok) {
+        out_u = (double)ru;
+        out_depth = (double)(bf / (l.x - ru));
+        matched = 1;
+      }
+    }
+  }
+  if (lane == 0) {
+    right_u[out_i] = out_u;
+    depth[out_i] = out_depth;
+    best_right[out_i] = any ? b.min_idx : -1;
+    best_dist[out_i] = any ? b.min_d : -1;
+    if (matched) atomicAdd(&n_match[pair], 1);
+  }
+}
+
+void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, const uint32_t* d_off,
+                             const uint32_t* d_cand, int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second) {
+  if (nq <= 0) return;
+  hipLaunchKernelGGL(k_match_bruteforce, dim3((nq + 3) / 4), dim3(256), 0, s, d_q, nq, d_t, nt, d_off, d_cand, d_best_idx,
+                     d_best_dist, d_second);
+}
+
+void launch_stereo(hipStream_t s, const LevelDev* d_lv, const uint8_t* d_pyr, size_t img_pitch, const orbfe_keypoint* d_kps,
+                   const uint8_t* d_desc, const KpAux* d_aux, const int32_t* d_n_kp, int n_features, float fx, float bf,
+                   int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
+                   int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs) {
+  if (n_pairs <= 0 || n_features <= 0) return;
+  hipLaunchKernelGGL(k_stereo, dim3((n_features + 3) / 4, n_pairs), dim3(256), 0, s, d_lv, d_pyr, img_pitch, d_kps, d_desc,
+                     d_aux, d_n_kp, n_features, fx, bf, cols0, mean_threshold, d_right_u, d_depth, d_n_match, d_best_right,
+                     d_best_dist, slot_l0, slot_r0, slot_step, pair0);
+}
+
+}  // namespace orbfe

@@ -1,0 +1,833 @@
+// orbfe_api.hip -- host side of the C-ABI declared in include/orbfe.h: geometry tables, device buffers,
+// stream/event plumbing and the launch sequence.  No OpenCV, no torch, no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "orbfe_internal.h"
+
+namespace orbfe {
+// k_pyramid.hip
+void launch_resize(hipStream_t s, const LevelDev* d_lv, int n_levels, int total_tiles, const ResizeTap* d_taps, uint8_t* d_pyr,
+                   size_t img_pitch, int n_img);
+void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int total_tiles, const uint8_t* d_pyr, uint8_t* d_blur,
+                 size_t img_pitch, const int taps[7], int n_img);
+void launch_load_level0(hipStream_t st, const uint8_t* d_src, size_t src_stride, size_t src_pitch, uint8_t* d_pyr, size_t img_pitch,
+                        uint32_t plane_off, int dst_stride, int w, int h, int slot0, int slot_step, int n_img);
+// k_fast.hip
+void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, int n_cells_total, const uint8_t* d_pyr,
+                 size_t img_pitch, int t_hi, int t_lo, uint32_t* d_slots, size_t slots_pitch, uint16_t* d_counts, int n_img);
+// k_quadtree.hip
+size_t quadtree_lds_bytes(int node_cap, int sort_cap);
+void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint16_t* d_counts, int n_cells_total,
+                     const uint32_t* d_slots, size_t slots_pitch, uint64_t* d_scr_a, uint64_t* d_scr_b, size_t scratch_pitch,
+                     uint32_t* d_sel, int32_t* d_sel_count, int n_features, int32_t* d_n_cand, int node_cap, int sort_cap,
+                     int n_img);
+// k_brief.hip
+void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,
+                         size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
+                         const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
+                         int32_t* d_n_kp, double* d_theta, int rows0, int n_img);
+// k_match.hip
+void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, const uint32_t* d_off,
+                             const uint32_t* d_cand, int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second);
+void launch_stereo(hipStream_t s, const LevelDev* d_lv, const uint8_t* d_pyr, size_t img_pitch, const orbfe_keypoint* d_kps,
+                   const uint8_t* d_desc, const KpAux* d_aux, const int32_t* d_n_kp, int n_features, float fx, float bf,
+                   int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
+                   int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs);
+// k_ba.hip
+void launch_ba_edges(hipStream_t s, int n_edges, const double* d_poses, const double* d_points, const int32_t* d_edge_pose,
+                     const int32_t* d_edge_point, const double* d_meas, const uint8_t* d_is_stereo, const double* d_info,
+                     const double* d_delta, BaParamsDev prm, double* d_error, double* d_chi2, double* d_rho, double* d_jpoint,
+                     double* d_jpose, uint8_t* d_depth_pos);
+}  // namespace orbfe
+
+using namespace orbfe;
+
+static const int8_t kEmbeddedPattern[256][4] = {
+#include "brief_pattern.inc"
+};
+static const int kGaussTaps[2][7] = {{18, 34, 48, 56, 48, 34, 18}, {18, 34, 49, 55, 49, 34, 18}};
+static const int kMeanThreshold = 75;  // ORBMatcher::mnMeanThreshold (ORBMatcher.cc:1088)
+
+static thread_local std::string g_create_error;
+
+struct orbfe_ctx {
+  orbfe_config cfg;
+  std::string err;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+
+  // geometry (host copies)
+  std::vector<LevelDev> lv;
+  std::vector<CellDev> cells;
+  std::vector<ResizeTap> taps;
+  int umax[16];
+  int blur_taps[7];
+  int n_cells_total = 0, rs_tiles = 0, bl_tiles = 0;
+  size_t img_pitch = 0;      // bytes per image in pyr / blur
+  size_t slots_pitch = 0;    // uint32 per image
+  size_t scratch_pitch = 0;  // uint64 per image
+  int node_cap = 0, sort_cap = 0;
+
+  // device
+  LevelDev* d_lv = nullptr;
+  CellDev* d_cells = nullptr;
+  ResizeTap* d_taps = nullptr;
+  int8_t* d_pattern = nullptr;
+  uint8_t *d_pyr = nullptr, *d_blur = nullptr;
+  uint32_t* d_slots = nullptr;
+  uint16_t* d_counts = nullptr;
+  uint64_t *d_scr_a = nullptr, *d_scr_b = nullptr;
+  uint32_t* d_sel = nullptr;
+  int32_t *d_sel_count = nullptr, *d_n_cand = nullptr, *d_n_kp = nullptr;
+  orbfe_keypoint* d_kps = nullptr;
+  uint8_t* d_desc = nullptr;
+  KpAux* d_aux = nullptr;
+  double* d_theta = nullptr;
+  double *d_right_u = nullptr, *d_depth = nullptr;
+  int32_t *d_n_match = nullptr, *d_best_right = nullptr, *d_best_dist = nullptr;
+  // generic staging for match / BA calls
+  void* d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  // pinned host staging for small result reads
+  int32_t* h_counts = nullptr;
+
+  // profiling
+  bool prof = false;
+  hipEvent_t ev[2 * ORBFE_STAGE_COUNT];
+  bool ev_init = false;
+  double stage_ms[ORBFE_STAGE_COUNT];
+  int64_t stage_launches[ORBFE_STAGE_COUNT];
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+static orbfe_status fail(orbfe_ctx* c, orbfe_status st, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  else g_create_error = buf;
+  return st;
+}
+
+#define HIP_TRY(c, expr)                                                                          \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return fail((c), ORBFE_EDEVICE, "%s -> %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// ---- OpenCV rounding (cvRound = round half to even, cvFloor, cvCeil) ------------------------------
+static inline int cv_round_d(double v) { return (int)lrint(v); }
+static inline int cv_round_f(float v) { return (int)lrintf(v); }
+static inline int cv_floor_f(float v) {
+  int i = (int)v;
+  return i - (i > v);
+}
+static inline int cv_ceil_f(float v) {
+  int i = (int)v;
+  return i + (i < v);
+}
+static inline short sat_short_f(float v) { return (short)std::min(32767, std::max(-32768, cv_round_f(v))); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// cv::resize INTER_LINEAR coefficient tables for one axis (imgproc/resize.cpp, 8-bit fixed-point path)
+static void build_resize_axis(int s, int d, std::vector<ResizeTap>& out) {
+  const double scale = 1.0 / ((double)d / s);
+  for (int i = 0; i < d; ++i) {
+    float f = (float)((i + 0.5) * scale - 0.5);
+    int si = cv_floor_f(f);
+    f -= si;
+    ResizeTap t;
+    t.ofs = si;
+    t.c0 = sat_short_f((1.f - f) * 2048);
+    t.c1 = sat_short_f(f * 2048);
+    out.push_back(t);
+  }
+}
+
+// Geometry exactly as the reference derives it: ORBExtractor.cc:283-317 (scales, quotas, level sizes),
+// :334-343 (cell grid), :81-96 (root strips), :217-236 (umax).
+static orbfe_status build_geometry(orbfe_ctx* c) {
+  const orbfe_config& cfg = c->cfg;
+  const int nl = cfg.n_levels;
+  c->lv.assign(nl, LevelDev());
+  std::vector<float> sf(nl);
+  for (int l = 0; l < nl; ++l) sf[l] = (float)std::pow((double)cfg.scale_factor, (double)l);
+  std::vector<int> quota(nl, 0);
+  {
+    const float scale = 1.0f / cfg.scale_factor;
+    int sum = 0;
+    int nfeats = cv_round_d((double)(cfg.n_features * (1 - scale)) / (1 - std::pow((double)scale, (double)nl)));
+    for (int l = 0; l < nl - 1; ++l) {
+      quota[l] = nfeats;
+      sum += nfeats;
+      nfeats = cv_round_f(nfeats * scale);
+    }
+    quota[nl - 1] = std::max(0, cfg.n_features - sum);
+  }
+  size_t plane_off = 0;
+  uint32_t slot_base = 0, cand_base = 0;
+  int cell_base = 0, quota_off = 0, rs_tiles = 0, bl_tiles = 0, max_quota = 0, max_ini = 4;
+  c->cells.clear();
+  c->taps.clear();
+  for (int l = 0; l < nl; ++l) {
+    LevelDev& L = c->lv[l];
+    L.w = (l == 0) ? cfg.width : cv_round_f(cfg.width / sf[l]);
+    L.h = (l == 0) ? cfg.height : cv_round_f(cfg.height / sf[l]);
+    if (l > 0 && (L.w < 2 * ORBFE_BORDER || L.h < 2 * ORBFE_BORDER))
+      return fail(c, ORBFE_EBADSIZE, "ImageSizeError: level %d would be %dx%d (< %d px)", l, L.w, L.h, 2 * ORBFE_BORDER);
+    L.stride = (int)align_up((size_t)L.w, 16);
+    L.plane_off = (uint32_t)plane_off;
+    plane_off += align_up((size_t)L.stride * L.h, 256);
+    L.sf = sf[l];
+    L.quota = quota[l];
+    L.quota_off = quota_off;
+    quota_off += quota[l];
+    max_quota = std::max(max_quota, quota[l]);
+    // FAST grid
+    L.reg_w = L.w - 2 * ORBFE_EDGE;
+    L.reg_h = L.h - 2 * ORBFE_EDGE;
+    L.n_cols = L.reg_w / 30;
+    L.n_rows = L.reg_h / 30;
+    if (L.n_cols <= 0 || L.n_rows <= 0)
+      return fail(c, ORBFE_EBADSIZE, "level %d region %dx%d is smaller than one 30-px FAST cell", l, L.reg_w, L.reg_h);
+    L.w_cell = L.reg_w / L.n_cols;  // ceil() of an integer division is a no-op (quirk Q2)
+    L.h_cell = L.reg_h / L.n_rows;
+    if (L.w_cell + 6 > ORBFE_MAX_CELL || L.h_cell + 6 > ORBFE_MAX_CELL)
+      return fail(c, ORBFE_EBADSIZE, "level %d cell %dx%d exceeds the LDS tile bound", l, L.w_cell, L.h_cell);
+    if (L.reg_w > 4095 || L.reg_h > 4095) return fail(c, ORBFE_EBADSIZE, "level %d region exceeds 4095 px", l);
+    L.cell_base = cell_base;
+    L.cell_cap = ((L.w_cell + 1) / 2) * ((L.h_cell + 1) / 2);
+    L.slot_base = slot_base;
+    const int max_bx = L.w - ORBFE_EDGE, max_by = L.h - ORBFE_EDGE;
+    int n_cells = 0;
+    for (int idx = 0; idx < L.n_rows; ++idx) {
+      int ini_y = ORBFE_EDGE + idx * L.h_cell, max_y = ini_y + L.h_cell + 6;
+      if (ini_y >= max_by - 6) continue;
+      if (max_y > max_by) max_y = max_by;
+      for (int jdx = 0; jdx < L.n_cols; ++jdx) {
+        int ini_x = ORBFE_EDGE + jdx * L.w_cell, max_x = ini_x + L.w_cell + 6;
+        if (ini_x >= max_bx - 6) continue;
+        if (max_x > max_bx) max_x = max_bx;
+        CellDev cd;
+        cd.level = (int16_t)l;
+        cd.x0 = (int16_t)ini_x;
+        cd.y0 = (int16_t)ini_y;
+        cd.pw = (int16_t)(max_x - ini_x);
+        cd.ph = (int16_t)(max_y - ini_y);
+        cd.offx = (int16_t)(jdx * L.w_cell);
+        cd.offy = (int16_t)(idx * L.h_cell);
+        cd.pad = 0;
+        cd.slot_off = slot_base + (uint32_t)n_cells * (uint32_t)L.cell_cap;
+        c->cells.push_back(cd);
+        ++n_cells;
+      }
+    }
+    L.n_cells = n_cells;
+    cell_base += n_cells;
+    L.cand_cap = (uint32_t)n_cells * (uint32_t)L.cell_cap;
+    slot_base += L.cand_cap;
+    L.cand_base = cand_base;
+    cand_base += (uint32_t)align_up(L.cand_cap, 32);
+    // root strips (Quadtree::initSplit)
+    {
+      const double w = (double)L.reg_w, h = (double)L.reg_h;
+      const int n_ini = (int)std::round(w / h);
+      if (n_ini > ORBFE_MAX_STRIPS) return fail(c, ORBFE_EBADSIZE, "aspect ratio %d:1 exceeds %d root strips", n_ini, ORBFE_MAX_STRIPS);
+      L.n_ini = n_ini;
+      max_ini = std::max(max_ini, n_ini);
+      std::memset(L.strips, 0, sizeof L.strips);
+      if (n_ini > 0) {
+        const float hx = (float)(w / n_ini);
+        L.strips[0] = 0.0;
+        for (int i = 1; i < n_ini; ++i) L.strips[i] = (double)((float)i * hx);
+        L.strips[n_ini] = w;
+      }
+    }
+    // resize tables and launch tiles
+    L.rs_tile_base = rs_tiles;
+    L.rs_tiles_x = L.rs_tiles_y = 0;
+    L.xtab_off = L.ytab_off = 0;
+    if (l > 0) {
+      L.xtab_off = (uint32_t)c->taps.size();
+      build_resize_axis(cfg.width, L.w, c->taps);
+      L.ytab_off = (uint32_t)c->taps.size();
+      build_resize_axis(cfg.height, L.h, c->taps);
+      L.rs_tiles_x = (L.w + 63) / 64;
+      L.rs_tiles_y = (L.h + 3) / 4;
+      rs_tiles += L.rs_tiles_x * L.rs_tiles_y;
+    }
+    L.bl_tile_base = bl_tiles;
+    L.bl_tiles_x = (L.w + 63) / 64;
+    L.bl_tiles_y = (L.h + 15) / 16;
+    bl_tiles += L.bl_tiles_x * L.bl_tiles_y;
+  }
+  // horizontal taps: clamp exactly as resizeGeneric_ does (sx<0 -> 0/fx=0; sx>=sw-1 -> sw-1/fx=0)
+  for (int l = 1; l < nl; ++l) {
+    LevelDev& L = c->lv[l];
+    for (int i = 0; i < L.w; ++i) {
+      ResizeTap& t = c->taps[L.xtab_off + i];
+      if (t.ofs < 0) {
+        t.ofs = 0;
+        t.c0 = 2048;
+        t.c1 = 0;
+      }
+      if (t.ofs >= cfg.width - 1) {
+        t.ofs = cfg.width - 1;
+        t.c0 = 2048;
+        t.c1 = 0;
+      }
+    }
+  }
+  c->n_cells_total = cell_base;
+  c->rs_tiles = rs_tiles;
+  c->bl_tiles = bl_tiles;
+  c->img_pitch = align_up(plane_off, 4096);
+  c->slots_pitch = align_up(slot_base, 64);
+  c->scratch_pitch = align_up(cand_base, 64);
+  c->node_cap = max_quota + max_ini + 8;
+  int sc = 2;
+  while (sc < max_quota) sc <<= 1;
+  c->sort_cap = sc;
+  if (quadtree_lds_bytes(c->node_cap, c->sort_cap) > 150 * 1024)
+    return fail(c, ORBFE_EBADARG, "per-level quota %d needs more LDS than one CU has", max_quota);
+  // umax (ORBExtractor::initMaxU)
+  {
+    const int R = ORBFE_CENTROID_R;
+    int v, v0, vmax = cv_floor_f(R * std::sqrt(2.f) / 2 + 1);
+    int vmin = cv_ceil_f(R * std::sqrt(2.f) / 2);
+    const double hp2 = R * R;
+    for (v = 0; v <= R; ++v) c->umax[v] = 0;
+    for (v = 0; v <= vmax; ++v) c->umax[v] = cv_round_d(std::sqrt(hp2 - v * v));
+    for (v = R, v0 = 0; v >= vmin; --v) {
+      while (c->umax[v0] == c->umax[v0 + 1]) ++v0;
+      c->umax[v] = v0;
+      ++v0;
+    }
+  }
+  for (int i = 0; i < 7; ++i) c->blur_taps[i] = kGaussTaps[cfg.blur_variant ? 1 : 0][i];
+  return ORBFE_OK;
+}
+
+template <typename T>
+static orbfe_status dev_alloc(orbfe_ctx* c, T** p, size_t count) {
+  HIP_TRY(c, hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
+  return ORBFE_OK;
+}
+#define TRY(expr)                          \
+  do {                                     \
+    orbfe_status st_ = (expr);             \
+    if (st_ != ORBFE_OK) return st_;       \
+  } while (0)
+
+static orbfe_status ensure_tmp(orbfe_ctx* c, size_t bytes) {
+  if (bytes <= c->tmp_bytes) return ORBFE_OK;
+  if (c->d_tmp) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipFree(c->d_tmp));
+    c->d_tmp = nullptr;
+    c->tmp_bytes = 0;
+  }
+  bytes = align_up(bytes, 1 << 20);
+  HIP_TRY(c, hipMalloc(&c->d_tmp, bytes));
+  c->tmp_bytes = bytes;
+  return ORBFE_OK;
+}
+
+// ---- stage timing ---------------------------------------------------------------------------------
+struct StageTimer {
+  orbfe_ctx* c;
+  int stage;
+  hipEvent_t a = nullptr, b = nullptr;
+  StageTimer(orbfe_ctx* ctx, int st) : c(ctx), stage(st) {
+    if (!c->prof) return;
+    auto get = [&]() {
+      hipEvent_t e = nullptr;
+      if (!c->ev_pool.empty()) {
+        e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+      } else if (hipEventCreate(&e) != hipSuccess)
+        e = nullptr;
+      return e;
+    };
+    a = get();
+    b = get();
+    if (a) hipEventRecord(a, c->stream);
+  }
+  ~StageTimer() {
+    if (!c->prof || !a || !b) return;
+    hipEventRecord(b, c->stream);
+    c->pending.push_back({stage, {a, b}});
+  }
+};
+
+static void drain_timers(orbfe_ctx* c) {
+  for (auto& p : c->pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.second.second) == hipSuccess && hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
+      c->stage_ms[p.first] += ms;
+      c->stage_launches[p.first] += 1;
+    }
+    c->ev_pool.push_back(p.second.first);
+    c->ev_pool.push_back(p.second.second);
+  }
+  c->pending.clear();
+}
+
+// ---- the launch sequence for slots [0, n_img) ---------------------------------------------------------
+static orbfe_status run_extract(orbfe_ctx* c, int n_img) {
+  const int nl = c->cfg.n_levels;
+  {
+    StageTimer t(c, ORBFE_STAGE_RESIZE);
+    launch_resize(c->stream, c->d_lv, nl, c->rs_tiles, c->d_taps, c->d_pyr, c->img_pitch, n_img);
+  }
+  {
+    StageTimer t(c, ORBFE_STAGE_BLUR);
+    launch_blur(c->stream, c->d_lv, nl, c->bl_tiles, c->d_pyr, c->d_blur, c->img_pitch, c->blur_taps, n_img);
+  }
+  {
+    StageTimer t(c, ORBFE_STAGE_FAST);
+    launch_fast(c->stream, c->d_lv, c->d_cells, c->n_cells_total, c->d_pyr, c->img_pitch, c->cfg.fast_hi, c->cfg.fast_lo,
+                c->d_slots, c->slots_pitch, c->d_counts, n_img);
+  }
+  {
+    StageTimer t(c, ORBFE_STAGE_QUADTREE);
+    launch_quadtree(c->stream, c->d_lv, nl, c->d_counts, c->n_cells_total, c->d_slots, c->slots_pitch, c->d_scr_a, c->d_scr_b,
+                    c->scratch_pitch, c->d_sel, c->d_sel_count, c->cfg.n_features, c->d_n_cand, c->node_cap, c->sort_cap, n_img);
+  }
+  {
+    StageTimer t(c, ORBFE_STAGE_BRIEF);
+    launch_orient_brief(c->stream, c->d_lv, nl, c->d_pyr, c->d_blur, c->img_pitch, c->d_sel, c->d_sel_count, c->cfg.n_features,
+                        c->d_pattern, c->umax, c->d_kps, c->d_desc, c->d_aux, c->d_n_kp, c->d_theta, c->cfg.height, n_img);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return ORBFE_OK;
+}
+
+static orbfe_status run_stereo(orbfe_ctx* c, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs, float fx, float bf) {
+  HIP_TRY(c, hipMemsetAsync(c->d_n_match + pair0, 0, sizeof(int32_t) * n_pairs, c->stream));
+  {
+    StageTimer t(c, ORBFE_STAGE_STEREO);
+    launch_stereo(c->stream, c->d_lv, c->d_pyr, c->img_pitch, c->d_kps, c->d_desc, c->d_aux, c->d_n_kp, c->cfg.n_features, fx, bf,
+                  c->cfg.width, kMeanThreshold, c->d_right_u, c->d_depth, c->d_n_match, c->d_best_right, c->d_best_dist, slot_l0,
+                  slot_r0, slot_step, pair0, n_pairs);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return ORBFE_OK;
+}
+
+// ====================================================================================================
+extern "C" {
+
+int orbfe_abi_version(void) { return ORBFE_ABI_VERSION; }
+
+const char* orbfe_last_error(const orbfe_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+const char* orbfe_stage_name(int32_t stage) {
+  static const char* names[ORBFE_STAGE_COUNT] = {"resize", "blur", "fast", "quadtree", "orient_brief", "stereo", "match", "ba"};
+  return (stage >= 0 && stage < ORBFE_STAGE_COUNT) ? names[stage] : "?";
+}
+
+void orbfe_destroy(orbfe_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  drain_timers(c);
+  for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+  void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_pattern, c->d_pyr,     c->d_blur,  c->d_slots,
+                  c->d_counts, c->d_scr_a,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_kp,
+                  c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta,   c->d_right_u, c->d_depth, c->d_n_match,
+                  c->d_best_right, c->d_best_dist, c->d_tmp};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  if (c->h_counts) hipHostFree(c->h_counts);
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
+  if (!cfg || !out) return fail(nullptr, ORBFE_EBADARG, "orbfe_create: NULL argument");
+  *out = nullptr;
+  if (cfg->width <= 0 || cfg->height <= 0 || cfg->n_features < 0 || cfg->n_levels < 1 || cfg->n_levels > ORBFE_MAX_LEVELS ||
+      !(cfg->scale_factor > 1.0f) || cfg->max_images < 1 || cfg->max_images > 65535)
+    return fail(nullptr, ORBFE_EBADARG, "orbfe_create: bad config (w=%d h=%d nfeat=%d levels=%d scale=%g max_images=%d)", cfg->width,
+                cfg->height, cfg->n_features, cfg->n_levels, (double)cfg->scale_factor, cfg->max_images);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, ORBFE_EDEVICE, "orbfe_create: no HIP device (this library has no CPU fallback)");
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, ORBFE_EBADARG, "orbfe_create: device %d of %d", cfg->device_id, ndev);
+  orbfe_ctx* c = new orbfe_ctx();
+  c->cfg = *cfg;
+  c->cfg.fast_hi = std::min(std::max(cfg->fast_hi, 0), 255);  // cv::FAST clamps the threshold
+  c->cfg.fast_lo = std::min(std::max(cfg->fast_lo, 0), 255);
+  c->device = cfg->device_id;
+  std::memset(c->stage_ms, 0, sizeof c->stage_ms);
+  std::memset(c->stage_launches, 0, sizeof c->stage_launches);
+  auto bail = [&](orbfe_status st) {
+    g_create_error = c->err;
+    orbfe_destroy(c);
+    return st;
+  };
+  orbfe_status st = build_geometry(c);
+  if (st != ORBFE_OK) return bail(st);
+  if (hipSetDevice(c->device) != hipSuccess) {
+    fail(c, ORBFE_EDEVICE, "hipSetDevice(%d) failed", c->device);
+    return bail(ORBFE_EDEVICE);
+  }
+  if (cfg->stream) {
+    c->stream = (hipStream_t)cfg->stream;
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      fail(c, ORBFE_EDEVICE, "hipStreamCreate failed");
+      return bail(ORBFE_EDEVICE);
+    }
+    c->own_stream = true;
+  }
+  const size_t M = (size_t)cfg->max_images, NF = (size_t)std::max(cfg->n_features, 1), NL = (size_t)cfg->n_levels;
+  const size_t NP = (M + 1) / 2;
+#define ALLOC(ptr, count)                          \
+  do {                                             \
+    st = dev_alloc(c, &(ptr), (count));            \
+    if (st != ORBFE_OK) return bail(st);           \
+  } while (0)
+  ALLOC(c->d_lv, NL);
+  ALLOC(c->d_cells, c->cells.size());
+  ALLOC(c->d_taps, c->taps.size());
+  ALLOC(c->d_pattern, 1024);
+  ALLOC(c->d_pyr, M * c->img_pitch);
+  ALLOC(c->d_blur, M * c->img_pitch);
+  ALLOC(c->d_slots, M * c->slots_pitch);
+  ALLOC(c->d_counts, M * (size_t)c->n_cells_total);
+  ALLOC(c->d_scr_a, M * c->scratch_pitch);
+  ALLOC(c->d_scr_b, M * c->scratch_pitch);
+  ALLOC(c->d_sel, M * NF);
+  ALLOC(c->d_sel_count, M * NL);
+  ALLOC(c->d_n_cand, M * NL);
+  ALLOC(c->d_n_kp, M);
+  ALLOC(c->d_kps, M * NF);
+  ALLOC(c->d_desc, M * NF * 32);
+  ALLOC(c->d_aux, M * NF);
+  ALLOC(c->d_theta, M * NF);
+  ALLOC(c->d_right_u, NP * NF);
+  ALLOC(c->d_depth, NP * NF);
+  ALLOC(c->d_n_match, NP);
+  ALLOC(c->d_best_right, NP * NF);
+  ALLOC(c->d_best_dist, NP * NF);
+#undef ALLOC
+  hipError_t e = hipSuccess;
+  const int8_t* pat = cfg->brief_pairs ? cfg->brief_pairs : &kEmbeddedPattern[0][0];
+  c->cfg.brief_pairs = nullptr;  // not retained
+  if (e == hipSuccess) e = hipMemcpy(c->d_lv, c->lv.data(), sizeof(LevelDev) * NL, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(c->d_cells, c->cells.data(), sizeof(CellDev) * c->cells.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !c->taps.empty()) e = hipMemcpy(c->d_taps, c->taps.data(), sizeof(ResizeTap) * c->taps.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(c->d_pattern, pat, 1024, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(c->d_n_kp, 0, sizeof(int32_t) * M);
+  if (e == hipSuccess) e = hipMemset(c->d_sel_count, 0, sizeof(int32_t) * M * NL);
+  if (e == hipSuccess) e = hipMemset(c->d_n_match, 0, sizeof(int32_t) * NP);
+  if (e == hipSuccess) e = hipMemset(c->d_pyr, 0, M * c->img_pitch);
+  if (e == hipSuccess) e = hipMemset(c->d_blur, 0, M * c->img_pitch);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_counts, sizeof(int32_t) * std::max<size_t>(M, 64), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    fail(c, ORBFE_EDEVICE, "device initialisation failed: %s", hipGetErrorString(e));
+    return bail(ORBFE_EDEVICE);
+  }
+  *out = c;
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_get_level_info(const orbfe_ctx* c, int32_t level, orbfe_level_info* out) {
+  if (!c || !out || level < 0 || level >= c->cfg.n_levels) return ORBFE_EBADARG;
+  const LevelDev& L = c->lv[level];
+  out->width = L.w;
+  out->height = L.h;
+  out->scale = L.sf;
+  out->quota = L.quota;
+  out->grid_cols = L.n_cols;
+  out->grid_rows = L.n_rows;
+  out->cell_w = L.w_cell;
+  out->cell_h = L.h_cell;
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_get_scale_factors(const orbfe_ctx* c, float* out, int32_t n) {
+  if (!c || !out || n < c->cfg.n_levels) return ORBFE_EBADARG;
+  for (int l = 0; l < c->cfg.n_levels; ++l) out[l] = c->lv[l].sf;
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_sync(orbfe_ctx* c) {
+  if (!c) return ORBFE_EBADARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_fetch_features(orbfe_ctx* c, int32_t slot, orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out) {
+  if (!c || slot < 0 || slot >= c->cfg.max_images) return fail(c, ORBFE_EBADARG, "fetch_features: slot %d", slot);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t NF = (size_t)c->cfg.n_features;
+  int32_t n = 0;
+  HIP_TRY(c, hipMemcpyAsync(c->h_counts, c->d_n_kp + slot, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  n = c->h_counts[0];
+  if (n < 0 || (size_t)n > NF) return fail(c, ORBFE_EDEVICE, "fetch_features: corrupt count %d", n);
+  if (kps && n) HIP_TRY(c, hipMemcpyAsync(kps, c->d_kps + (size_t)slot * NF, sizeof(orbfe_keypoint) * n, hipMemcpyDeviceToHost, c->stream));
+  if (desc && n) HIP_TRY(c, hipMemcpyAsync(desc, c->d_desc + (size_t)slot * NF * 32, (size_t)32 * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  if (n_out) *n_out = n;
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_fetch_stereo(orbfe_ctx* c, int32_t pair, double* right_u, double* depth, int32_t* n_matches, int32_t* best_right,
+                                int32_t* best_dist) {
+  if (!c || pair < 0 || pair >= (c->cfg.max_images + 1) / 2) return fail(c, ORBFE_EBADARG, "fetch_stereo: pair %d", pair);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t NF = (size_t)c->cfg.n_features;
+  const size_t o = (size_t)pair * NF;
+  if (right_u && NF) HIP_TRY(c, hipMemcpyAsync(right_u, c->d_right_u + o, sizeof(double) * NF, hipMemcpyDeviceToHost, c->stream));
+  if (depth && NF) HIP_TRY(c, hipMemcpyAsync(depth, c->d_depth + o, sizeof(double) * NF, hipMemcpyDeviceToHost, c->stream));
+  if (best_right && NF) HIP_TRY(c, hipMemcpyAsync(best_right, c->d_best_right + o, sizeof(int32_t) * NF, hipMemcpyDeviceToHost, c->stream));
+  if (best_dist && NF) HIP_TRY(c, hipMemcpyAsync(best_dist, c->d_best_dist + o, sizeof(int32_t) * NF, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_counts, c->d_n_match + pair, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  if (n_matches) *n_matches = c->h_counts[0];
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_device_results(orbfe_ctx* c, const void** d_kps, const void** d_desc, const void** d_counts, const void** d_right_u,
+                                  const void** d_depth, const void** d_nmatch) {
+  if (!c) return ORBFE_EBADARG;
+  if (d_kps) *d_kps = c->d_kps;
+  if (d_desc) *d_desc = c->d_desc;
+  if (d_counts) *d_counts = c->d_n_kp;
+  if (d_right_u) *d_right_u = c->d_right_u;
+  if (d_depth) *d_depth = c->d_depth;
+  if (d_nmatch) *d_nmatch = c->d_n_match;
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* const* imgs, size_t stride, orbfe_keypoint* kps,
+                                 uint8_t* desc, int32_t* n_out) {
+  if (!c || !imgs || n_img < 0) return fail(c, ORBFE_EBADARG, "extract_batch: NULL argument");
+  if (n_img > c->cfg.max_images) return fail(c, ORBFE_ECAPACITY, "extract_batch: %d images > max_images %d", n_img, c->cfg.max_images);
+  if (stride < (size_t)c->cfg.width) return fail(c, ORBFE_EBADARG, "extract_batch: stride %zu < width %d", stride, c->cfg.width);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const LevelDev& L0 = c->lv[0];
+  for (int i = 0; i < n_img; ++i) {
+    if (!imgs[i]) return fail(c, ORBFE_EBADARG, "extract_batch: image %d is NULL", i);
+    HIP_TRY(c, hipMemcpy2DAsync(c->d_pyr + (size_t)i * c->img_pitch + L0.plane_off, L0.stride, imgs[i], stride, c->cfg.width,
+                                c->cfg.height, hipMemcpyHostToDevice, c->stream));
+  }
+  TRY(run_extract(c, n_img));
+  const size_t NF = (size_t)c->cfg.n_features;
+  for (int i = 0; i < n_img; ++i) {
+    int32_t n = 0;
+    TRY(orbfe_fetch_features(c, i, kps ? kps + (size_t)i * NF : nullptr, desc ? desc + (size_t)i * NF * 32 : nullptr, &n));
+    if (n_out) n_out[i] = n;
+  }
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_extract(orbfe_ctx* c, const uint8_t* img, size_t stride, orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out) {
+  const uint8_t* one[1] = {img};
+  return orbfe_extract_batch(c, 1, one, stride, kps, desc, n_out);
+}
+
+orbfe_status orbfe_get_pyramid(orbfe_ctx* c, int32_t slot, int32_t level, int32_t blurred, uint8_t* dst) {
+  if (!c || !dst || slot < 0 || slot >= c->cfg.max_images || level < 0 || level >= c->cfg.n_levels)
+    return fail(c, ORBFE_EBADARG, "get_pyramid: slot %d level %d", slot, level);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const LevelDev& L = c->lv[level];
+  const uint8_t* src = (blurred ? c->d_blur : c->d_pyr) + (size_t)slot * c->img_pitch + L.plane_off;
+  HIP_TRY(c, hipMemcpy2DAsync(dst, L.w, src, L.stride, L.w, L.h, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_stereo_match(orbfe_ctx* c, int32_t slot_left, int32_t slot_right, float fx, float bf, double* right_u,
+                                double* depth, int32_t* n_matches, int32_t* best_right, int32_t* best_dist) {
+  if (!c || slot_left < 0 || slot_right < 0 || slot_left >= c->cfg.max_images || slot_right >= c->cfg.max_images)
+    return fail(c, ORBFE_EBADARG, "stereo_match: slots %d/%d", slot_left, slot_right);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int pair = slot_left / 2;
+  TRY(run_stereo(c, slot_left, slot_right, 0, pair, 1, fx, bf));
+  return orbfe_fetch_stereo(c, pair, right_u, depth, n_matches, best_right, best_dist);
+}
+
+orbfe_status orbfe_stereo_batch_device(orbfe_ctx* c, const uint8_t* d_left, const uint8_t* d_right, size_t stride, size_t image_pitch,
+                                       int32_t n_pairs, float fx, float bf) {
+  if (!c || !d_left || !d_right || n_pairs < 0) return fail(c, ORBFE_EBADARG, "stereo_batch_device: NULL argument");
+  if (2 * n_pairs > c->cfg.max_images) return fail(c, ORBFE_ECAPACITY, "stereo_batch_device: %d pairs need %d slots > %d", n_pairs, 2 * n_pairs, c->cfg.max_images);
+  if (stride < (size_t)c->cfg.width || image_pitch < stride * (size_t)c->cfg.height)
+    return fail(c, ORBFE_EBADARG, "stereo_batch_device: stride/pitch too small");
+  if (n_pairs == 0) return ORBFE_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const LevelDev& L0 = c->lv[0];
+  // level 0 of slot 2p / 2p+1 <- left / right image p
+  launch_load_level0(c->stream, d_left, stride, image_pitch, c->d_pyr, c->img_pitch, L0.plane_off, L0.stride, c->cfg.width,
+                     c->cfg.height, 0, 2, n_pairs);
+  launch_load_level0(c->stream, d_right, stride, image_pitch, c->d_pyr, c->img_pitch, L0.plane_off, L0.stride, c->cfg.width,
+                     c->cfg.height, 1, 2, n_pairs);
+  TRY(run_extract(c, 2 * n_pairs));
+  TRY(run_stereo(c, 0, 1, 2, 0, n_pairs, fx, bf));
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_match_bruteforce(orbfe_ctx* c, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, const uint32_t* cand_offsets,
+                                    const uint32_t* cand_idx, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist) {
+  if (!c || nq < 0 || nt < 0 || (nq && !q) || (nt && !t) || !best_idx || !best_dist || !second_dist)
+    return fail(c, ORBFE_EBADARG, "match_bruteforce: NULL argument");
+  if (cand_offsets && !cand_idx && cand_offsets[nq] > 0) return fail(c, ORBFE_EBADARG, "match_bruteforce: cand_idx is NULL");
+  if (nq == 0) return ORBFE_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t n_cand = cand_offsets ? cand_offsets[nq] : 0;
+  if (cand_offsets)
+    for (size_t i = 0; i < n_cand; ++i)
+      if (cand_idx[i] >= (uint32_t)nt) return fail(c, ORBFE_EBADARG, "match_bruteforce: candidate %u >= nt %d", cand_idx[i], nt);
+  size_t o_q = 0, o_t = align_up((size_t)nq * 32, 256), o_off = o_t + align_up((size_t)std::max(nt, 1) * 32, 256);
+  size_t o_cand = o_off + align_up(((size_t)nq + 1) * 4, 256), o_bi = o_cand + align_up(std::max<size_t>(n_cand, 1) * 4, 256);
+  size_t o_bd = o_bi + align_up((size_t)nq * 4, 256), o_sd = o_bd + align_up((size_t)nq * 4, 256), total = o_sd + align_up((size_t)nq * 4, 256);
+  TRY(ensure_tmp(c, total));
+  uint8_t* base = (uint8_t*)c->d_tmp;
+  HIP_TRY(c, hipMemcpyAsync(base + o_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+  if (nt) HIP_TRY(c, hipMemcpyAsync(base + o_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
+  if (cand_offsets) {
+    HIP_TRY(c, hipMemcpyAsync(base + o_off, cand_offsets, ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    if (n_cand) HIP_TRY(c, hipMemcpyAsync(base + o_cand, cand_idx, n_cand * 4, hipMemcpyHostToDevice, c->stream));
+  }
+  {
+    StageTimer tm(c, ORBFE_STAGE_MATCH);
+    launch_match_bruteforce(c->stream, base + o_q, nq, base + o_t, nt, cand_offsets ? (const uint32_t*)(base + o_off) : nullptr,
+                            (const uint32_t*)(base + o_cand), (int32_t*)(base + o_bi), (int32_t*)(base + o_bd), (int32_t*)(base + o_sd));
+  }
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(best_idx, base + o_bi, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(best_dist, base + o_bd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(second_dist, base + o_sd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_ba_eval_edges(orbfe_ctx* c, const orbfe_ba_problem* p, const orbfe_ba_edge_out* o) {
+  if (!c || !p || !o) return fail(c, ORBFE_EBADARG, "ba_eval_edges: NULL argument");
+  const int E = p->n_edges;
+  if (E < 0 || p->n_poses < 0 || p->n_points < 0) return fail(c, ORBFE_EBADARG, "ba_eval_edges: negative size");
+  if (E == 0) return ORBFE_OK;
+  if (!p->poses || !p->points || !p->edge_pose || !p->edge_point || !p->meas || !p->is_stereo || !p->info || !p->huber_delta || !o->error ||
+      !o->chi2 || !o->rho)
+    return fail(c, ORBFE_EBADARG, "ba_eval_edges: NULL array");
+  for (int e = 0; e < E; ++e)
+    if (p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_poses || p->edge_point[e] < 0 || p->edge_point[e] >= p->n_points)
+      return fail(c, ORBFE_EBADARG, "ba_eval_edges: edge %d references vertex out of range", e);
+  HIP_TRY(c, hipSetDevice(c->device));
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o2 = off;
+    off += align_up(std::max<size_t>(bytes, 8), 256);
+    return o2;
+  };
+  const size_t o_pose = take((size_t)p->n_poses * 56), o_pt = take((size_t)p->n_points * 24), o_ep = take((size_t)E * 4),
+               o_et = take((size_t)E * 4), o_meas = take((size_t)E * 24), o_st = take((size_t)E), o_info = take((size_t)E * 8),
+               o_delta = take((size_t)E * 8), o_err = take((size_t)E * 24), o_chi = take((size_t)E * 8), o_rho = take((size_t)E * 16),
+               o_jpt = take((size_t)E * 72), o_jps = take((size_t)E * 144), o_dp = take((size_t)E);
+  TRY(ensure_tmp(c, off));
+  uint8_t* b = (uint8_t*)c->d_tmp;
+  HIP_TRY(c, hipMemcpyAsync(b + o_pose, p->poses, (size_t)p->n_poses * 56, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_pt, p->points, (size_t)p->n_points * 24, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_ep, p->edge_pose, (size_t)E * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_et, p->edge_point, (size_t)E * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_meas, p->meas, (size_t)E * 24, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_st, p->is_stereo, (size_t)E, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_info, p->info, (size_t)E * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_delta, p->huber_delta, (size_t)E * 8, hipMemcpyHostToDevice, c->stream));
+  BaParamsDev prm = {p->fx, p->fy, p->cx, p->cy, p->bf};
+  {
+    StageTimer tm(c, ORBFE_STAGE_BA);
+    launch_ba_edges(c->stream, E, (const double*)(b + o_pose), (const double*)(b + o_pt), (const int32_t*)(b + o_ep),
+                    (const int32_t*)(b + o_et), (const double*)(b + o_meas), b + o_st, (const double*)(b + o_info),
+                    (const double*)(b + o_delta), prm, (double*)(b + o_err), (double*)(b + o_chi), (double*)(b + o_rho),
+                    o->j_point ? (double*)(b + o_jpt) : nullptr, o->j_pose ? (double*)(b + o_jps) : nullptr,
+                    o->depth_positive ? b + o_dp : nullptr);
+  }
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(o->error, b + o_err, (size_t)E * 24, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(o->chi2, b + o_chi, (size_t)E * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(o->rho, b + o_rho, (size_t)E * 16, hipMemcpyDeviceToHost, c->stream));
+  if (o->j_point) HIP_TRY(c, hipMemcpyAsync(o->j_point, b + o_jpt, (size_t)E * 72, hipMemcpyDeviceToHost, c->stream));
+  if (o->j_pose) HIP_TRY(c, hipMemcpyAsync(o->j_pose, b + o_jps, (size_t)E * 144, hipMemcpyDeviceToHost, c->stream));
+  if (o->depth_positive) HIP_TRY(c, hipMemcpyAsync(o->depth_positive, b + o_dp, (size_t)E, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_profile_enable(orbfe_ctx* c, int32_t on) {
+  if (!c) return ORBFE_EBADARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  c->prof = on != 0;
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_profile_read(orbfe_ctx* c, double* ms, int64_t* launches, int32_t reset) {
+  if (!c) return ORBFE_EBADARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  for (int i = 0; i < ORBFE_STAGE_COUNT; ++i) {
+    if (ms) ms[i] = c->stage_ms[i];
+    if (launches) launches[i] = c->stage_launches[i];
+    if (reset) {
+      c->stage_ms[i] = 0;
+      c->stage_launches[i] = 0;
+    }
+  }
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_debug_candidates(orbfe_ctx* c, int32_t slot, int32_t level, float* xyr, int32_t cap, int32_t* n_out) {
+  if (!c || slot < 0 || slot >= c->cfg.max_images || level < 0 || level >= c->cfg.n_levels || !n_out)
+    return fail(c, ORBFE_EBADARG, "debug_candidates: bad argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const LevelDev& L = c->lv[level];
+  std::vector<uint16_t> cnt(L.n_cells);
+  std::vector<uint32_t> sl(L.cand_cap);
+  HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->d_counts + (size_t)slot * c->n_cells_total + L.cell_base, sizeof(uint16_t) * L.n_cells,
+                            hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(sl.data(), c->d_slots + (size_t)slot * c->slots_pitch + L.slot_base, sizeof(uint32_t) * L.cand_cap,
+                            hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int n = 0;
+  for (int ci = 0; ci < L.n_cells; ++ci)
+    for (int j = 0; j < cnt[ci]; ++j) {
+      const uint32_t p = sl[(size_t)ci * L.cell_cap + j];
+      if (xyr && n < cap) {
+        xyr[3 * n] = (float)ORBFE_REC_X(p);
+        xyr[3 * n + 1] = (float)ORBFE_REC_Y(p);
+        xyr[3 * n + 2] = (float)ORBFE_REC_R(p);
+      }
+      ++n;
+    }
+  *n_out = n;
+  return ORBFE_OK;
+}
+
+}  // extern "C"

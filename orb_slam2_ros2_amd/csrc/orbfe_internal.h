@@ -1,0 +1,68 @@
+// orbfe_internal.h -- structures shared by the host side of the C-ABI and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/orbfe.h"
+
+#define ORBFE_MAX_STRIPS 16  // Quadtree::initSplit root strips, round(w/h)  (ORBExtractor.cc:85)
+#define ORBFE_BORDER 19      // ORBExtractor::mnBorderSize (ORBExtractor.cc:523)
+#define ORBFE_EDGE 16        // mnBorderSize - 3: origin of the FAST region (ORBExtractor.cc:336-337)
+#define ORBFE_CENTROID_R 15  // ORBExtractor::mnCentroidR (ORBExtractor.cc:518)
+#define ORBFE_MAX_CELL 72    // largest FAST patch side (cell < 60, +6 overlap), LDS tile bound
+
+// fixed-point bilinear tap: dst(dx) = S[ofs]*c0 + S[ofs+1]*c1   (cv::resize INTER_LINEAR, 11-bit)
+struct ResizeTap {
+  int32_t ofs;
+  int16_t c0, c1;
+};
+
+// Per pyramid level, resident in device memory (one table per context).
+struct LevelDev {
+  int32_t w, h, stride;  // plane size, row pitch in bytes (multiple of 16)
+  uint32_t plane_off;    // byte offset of the plane inside one image's pyramid buffer
+  float sf;              // mvfScaledFactors[level]
+  int32_t quota;         // mvnFeatures[level]
+  int32_t quota_off;     // sum of quotas of the lower levels
+  // FAST cell grid (ORBExtractor.cc:334-343)
+  int32_t reg_w, reg_h;  // region [16, w-16) x [16, h-16)
+  int32_t n_cols, n_rows, w_cell, h_cell;
+  int32_t cell_base;     // first flattened cell id of this level
+  int32_t n_cells;
+  int32_t cell_cap;      // slots per cell (upper bound on 3x3-strict local maxima in a cell interior)
+  uint32_t slot_base;    // first slot (uint32 units) of this level inside one image's slot buffer
+  // quadtree
+  uint32_t cand_base;    // first record (uint64 units) inside one image's scratch buffer
+  uint32_t cand_cap;     // = n_cells * cell_cap
+  int32_t n_ini;         // root strips
+  double strips[ORBFE_MAX_STRIPS + 1];
+  // resize tap tables (levels >= 1): offsets into the context's tap array
+  uint32_t xtab_off, ytab_off;
+  // launch geometry
+  int32_t rs_tiles_x, rs_tiles_y, rs_tile_base;  // resize: 64x4 output tiles
+  int32_t bl_tiles_x, bl_tiles_y, bl_tile_base;  // blur:   64x16 output tiles
+};
+
+// One FAST cell (flattened over levels).  Patch = what the reference hands to cv::FAST (ORBExtractor.cc:363).
+struct CellDev {
+  int16_t level;
+  int16_t x0, y0;      // patch origin in level coordinates (iniX, iniY)
+  int16_t pw, ph;      // patch size (maxX-iniX, maxY-iniY)
+  int16_t offx, offy;  // jdx*wCell, idx*hCell  (ORBExtractor.cc:370-371)
+  int16_t pad;
+  uint32_t slot_off;   // first slot of this cell inside one image's slot buffer
+};
+
+// candidate / selected-keypoint record: x (12 bit) | y (12 bit) | response (8 bit); x,y in region coordinates
+#define ORBFE_PACK_XYR(x, y, r) ((((uint32_t)(x)) << 20) | (((uint32_t)(y)) << 8) | ((uint32_t)(r)))
+#define ORBFE_REC_X(p) (((p) >> 20) & 0xFFFu)
+#define ORBFE_REC_Y(p) (((p) >> 8) & 0xFFFu)
+#define ORBFE_REC_R(p) ((p)&0xFFu)
+
+// auxiliary per-keypoint data the stereo matcher reads (createRowIndexDB row band, ORBMatcher.cc:924-927)
+struct KpAux {
+  int16_t row_min, row_max;  // [row_min, row_max)
+};
+
+struct BaParamsDev {
+  double fx, fy, cx, cy, bf;
+};
