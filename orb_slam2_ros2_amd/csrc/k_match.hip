@@ -167,12 +167,13 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
       const int lx = cv_floor_f(l.x / LL.sf), ly = cv_floor_f(l.y / LL.sf);  // getPitch (:1004-1006)
       const int rx = cv_floor_f(r.x / LR.sf), ry = cv_floor_f(r.y / LR.sf);
       const int c1 = IL[(size_t)ly * LL.stride + lx];
-      const int c2 = IR[(size_t)ry * LR.stride + rx];
       // lane = part*11 + Lidx, part 0..4 sums rows {part, part+5, (part+10 if part==0)}
       int partial = 0;
       if (lane < 55) {
         const int Lidx = lane % 11, part = lane / 11;
         const int Ls = Lidx - 5;
+        // each shifted right patch subtracts ITS OWN centre pixel (SAD(), ORBMatcher.cc:901-903)
+        const int c2 = IR[(size_t)ry * LR.stride + rx + Ls];
         for (int rr = part; rr < 11; rr += 5) {
           const uint8_t* pl = IL + (size_t)(ly - 5 + rr) * LL.stride + (lx - 5);
           const uint8_t* pr = IR + (size_t)(ry - 5 + rr) * LR.stride + (rx + Ls - 5);
