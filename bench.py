@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo frames/sec (extract+match) on KITTI-00-shaped 1241x376 pairs, MI355X.
+
+One "step" = one pass of the hot path (pyramid+blur, FAST, quadtree, orientation+rBRIEF for the left and
+right image, then searchByStereo) over one batch of `--pairs` synthetic stereo pairs that are already
+resident in HBM when the timed region starts.  Contract: `python bench.py --gpus N --steps K --warmup W`
+prints ONE JSON line on rank 0 (see the task statement).  N>1: launched by torch.distributed.run, one
+rank per GPU, frames sharded per rank (weak scaling), one RCCL gather of the per-pair results at the end
+of the sequence inside the timed region.
+
+Extra objects in the JSON line:
+  roofline      dominant kernel: algorithmic bytes per launch / mean launch duration (HIP events on the
+                library's stream) against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (oracle/, -O3 -march=native, 2 threads exactly like Frame.cc:100-105)
+                timed on this box's host cores over a bounded sample of the same frames (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, NFEAT, NLEVELS, SCALE, TH_HI, TH_LO = 1241, 376, 2000, 8, 1.2, 20, 7
+FX, BF = 718.856, 718.856 * 0.537166  # config/kitti_config_00.yaml: Camera.fx, Camera.bl
+HBM_PEAK_GBPS = 8000.0
+
+
+def algorithmic_bytes(ctx):
+    """algorithmic bytes per image for each kernel, and per stereo pair in total."""
+    P = sum(ctx.level_info(l).width * ctx.level_info(l).height for l in range(NLEVELS))
+    S0 = W * H
+    K = NFEAT
+    per_image = {
+        "resize": S0 + (P - S0),            # read level 0, write levels 1..7
+        "blur": 2 * P,                      # read + write every plane
+        "fast": P,                          # read every plane (+ candidate records, not counted)
+        "quadtree": 0,                      # candidate records only (L2 resident), not in the 8(d) budget
+        "orient_brief": K * (749 + 512) + K * 60,
+    }
+    per_pair_match = 2 * K * 32 + 2 * K * 28 + K * 12 * 121 + K * 16
+    per_pair = 2 * sum(per_image.values()) + per_pair_match
+    return per_image, per_pair_match, per_pair
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step (per GPU)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the front end has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from orb_slam2_ros2_amd import synth
+    from orb_slam2_ros2_amd._lib import Context
+
+    B = args.pairs
+    # synthetic frames of this rank's shard: rank r owns frames [r*B, (r+1)*B) of every step (weak scaling)
+    n_unique = min(B, 16)  # generating is host work; the batch tiles n_unique distinct pairs
+    lefts, rights = [], []
+    for i in range(n_unique):
+        l, r = synth.stereo_pair(rank * n_unique + i, W, H)
+        lefts.append(l)
+        rights.append(r)
+    reps = (B + n_unique - 1) // n_unique
+    left_h = np.stack((lefts * reps)[:B])
+    right_h = np.stack((rights * reps)[:B])
+    d_left = torch.from_numpy(left_h).to(dev)
+    d_right = torch.from_numpy(right_h).to(dev)
+
+    ctx = Context(W, H, NFEAT, NLEVELS, SCALE, TH_HI, TH_LO, device_id=local_rank, max_images=2 * B)
+    per_image_bytes, match_bytes, pair_bytes = algorithmic_bytes(ctx)
+
+    def step():
+        ctx.stereo_batch_device(d_left.data_ptr(), d_right.data_ptr(), W, W * H, B, FX, BF)
+
+    def gather_results():
+        """Sequence-level exchange: per-pair summaries of this rank -> rank 0 (RCCL gather over xGMI)."""
+        if world == 1:
+            return None
+        res = ctx.device_results()
+        summary = torch.zeros(B, 4, dtype=torch.int32, device=dev)
+
+        class _Raw:  # zero-copy view of the library's device buffers
+            def __init__(self, p, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (p, False), "version": 2}
+
+        counts = torch.as_tensor(_Raw(res["counts"], 2 * B), device=dev)
+        nmatch = torch.as_tensor(_Raw(res["n_match"], B), device=dev)
+        summary[:, 0] = counts[0::2]
+        summary[:, 1] = counts[1::2]
+        summary[:, 2] = nmatch
+        summary[:, 3] = rank
+        out = [torch.empty_like(summary) for _ in range(world)] if rank == 0 else None
+        dist.gather(summary, out, dst=0)
+        return out
+
+    def sync_all():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    gathered = gather_results()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # sanity: the last batch produced features and matches
+    nm, ru, dp, _, _ = ctx.fetch_stereo(0)
+    kps, _ = ctx.fetch_features(0)
+    assert len(kps) > 0 and nm > 0, "front end produced no features/matches"
+
+    # per-stage device time (HIP events on the library stream) in a separate, untimed pass
+    ctx.profile_enable(True)
+    n_prof = max(3, min(args.steps, 10))
+    for _ in range(n_prof):
+        step()
+    ctx.sync()
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    stages = {k: (ms / n if n else 0.0) for k, (ms, n) in prof.items() if n}
+    images_per_launch = 2 * B
+    stage_bytes = {k: per_image_bytes[k] * images_per_launch for k in per_image_bytes}
+    stage_bytes["stereo"] = match_bytes * B
+    dom = max((k for k in stages if k in stage_bytes), key=lambda k: stages[k])
+    dom_ms = stages[dom]
+    achieved = stage_bytes[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+
+    total_pairs = args.steps * B * world
+    fps = total_pairs / dt
+    line = {
+        "metric": "stereo frames/sec (extract+match) KITTI-00 1241x376; HBM GB/s vs roofline",
+        "value": fps,
+        "unit": "stereo pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": "Single 1241x376 KITTI-shaped stereo pair, 8-level pyramid, 2000 FAST+rBRIEF keypoints per image, "
+                        "searchByStereo; batched",
+            "pairs_per_step_per_gpu": B,
+            "n_features": NFEAT,
+            "levels": NLEVELS,
+            "parallelism": f"frames sharded over {world} GPU(s), RCCL gather of per-pair results at sequence end",
+            "algorithmic_bytes_per_pair": pair_bytes,
+            "pipeline_hbm_GBps": pair_bytes * fps / world / 1e9,
+            "pipeline_hbm_frac": pair_bytes * fps / world / 1e9 / HBM_PEAK_GBPS,
+            "stage_ms_per_launch": {k: round(v, 4) for k, v in stages.items()},
+        },
+        "roofline": {
+            "kernel": dom,
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": stage_bytes[dom],
+            "avg_launch_ms": dom_ms,
+        },
+    }
+
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        from oracle import pyoracle
+        so = pyoracle.build(fast=True, out_dir=os.path.join("/tmp", f"orb_oracle_{os.getuid()}"))
+        orc = pyoracle.Oracle(so)
+        orc.stereo_frame(lefts[0], rights[0], want_outputs=False)  # warm-up
+        n_done, t_cpu0 = 0, time.perf_counter()
+        while True:
+            i = n_done % n_unique
+            m = orc.stereo_frame(lefts[i], rights[i], NFEAT, NLEVELS, SCALE, TH_HI, TH_LO, FX, BF, math_mode=0, threads=2,
+                                 want_outputs=False)
+            assert m >= 0
+            n_done += 1
+            if time.perf_counter() - t_cpu0 >= args.cpu_seconds or n_done >= 400:
+                break
+        t_cpu = time.perf_counter() - t_cpu0
+        line["cpu_baseline"] = {
+            "value": n_done / t_cpu,
+            "unit": "stereo pairs/s",
+            "cores": 2,
+            "kind": "port",
+            "sample": f"{n_done} synthetic 1241x376 stereo pairs, oracle/orb_oracle.cpp -O3 -march=native, L/R extract on 2 threads "
+                      f"(Frame.cc:100-105), pairs sequential; host has {os.cpu_count()} cores",
+        }
+        line["config"]["gpu_over_cpu"] = fps / (n_done / t_cpu)
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -821,6 +821,16 @@ int orc_extractor_thetas(void* h, double* out, int cap) {
   return n;
 }
 
+// orientation + descriptor of one point of one level (level coordinates), for known-answer tests
+double orc_extractor_describe(void* h, int level, float x, float y, uint8_t* desc32, int32_t* m10, int32_t* m01) {
+  auto* e = (Extractor*)h;
+  int a, b;
+  e->gray_centroid_moments(e->pyr[level], x, y, a, b);
+  if (m10) *m10 = a;
+  if (m01) *m01 = b;
+  return e->compute_brief_one(level, x, y, desc32);
+}
+
 // ---- standalone primitives (known-answer tests) ---------------------------------------------------
 void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride) {
   resize_linear_u8(src, sw, sh, sstride, dst, dw, dh, dstride);

@@ -59,6 +59,10 @@ class Oracle:
         L.orc_extractor_splits.restype = C.c_long
         L.orc_extractor_splits.argtypes = [C.c_void_p, C.c_int]
         L.orc_extractor_thetas.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_extractor_describe.restype = C.c_double
+        L.orc_extractor_describe.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_ba_eval_edges.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_double] * 5 + [C.c_void_p] * 6
+        L.orc_se3_oplus.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_gauss7_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.orc_fast9_16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -132,6 +136,31 @@ class Oracle:
         self.lib.orc_sincos(float(t), mode, C.byref(s), C.byref(c))
         return s.value, c.value
 
+    # ---- BA ------------------------------------------------------------------------------------
+    def ba_eval_edges(self, poses, points, edge_pose, edge_point, meas, is_stereo, info, huber_delta, fx, fy, cx, cy, bf):
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+        points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+        edge_pose = np.ascontiguousarray(edge_pose, np.int32)
+        edge_point = np.ascontiguousarray(edge_point, np.int32)
+        meas = np.ascontiguousarray(meas, np.float64).reshape(-1, 3)
+        is_stereo = np.ascontiguousarray(is_stereo, np.uint8)
+        info = np.ascontiguousarray(info, np.float64)
+        huber_delta = np.ascontiguousarray(huber_delta, np.float64)
+        E = edge_pose.size
+        out = dict(error=np.zeros((E, 3)), chi2=np.zeros(E), rho=np.zeros((E, 2)), j_point=np.zeros((E, 3, 3)),
+                   j_pose=np.zeros((E, 3, 6)), depth_positive=np.zeros(E, np.uint8))
+        self.lib.orc_ba_eval_edges(E, _p(poses), _p(points), _p(edge_pose), _p(edge_point), _p(meas), _p(is_stereo), _p(info),
+                                   _p(huber_delta), fx, fy, cx, cy, bf, _p(out["error"]), _p(out["chi2"]), _p(out["rho"]),
+                                   _p(out["j_point"]), _p(out["j_pose"]), _p(out["depth_positive"]))
+        return out
+
+    def se3_oplus(self, T, upd):
+        T = np.ascontiguousarray(T, np.float64)
+        upd = np.ascontiguousarray(upd, np.float64)
+        out = np.zeros(7)
+        self.lib.orc_se3_oplus(_p(T), _p(upd), _p(out))
+        return out
+
     # ---- extractor --------------------------------------------------------------------------
     def extractor(self, img: np.ndarray, n_features=2000, n_levels=8, scale=1.2, th_hi=20, th_lo=7, pattern=None, blur_variant=0,
                   math_mode=0) -> "OracleExtractor":
@@ -190,6 +219,12 @@ class OracleExtractor:
         ptr = self.orc.lib.orc_extractor_plane(self.h, level, int(blurred))
         buf = (C.c_uint8 * (w * h)).from_address(ptr)
         return np.frombuffer(buf, np.uint8).reshape(h, w).copy()
+
+    def describe(self, level, x, y):
+        desc = np.zeros(32, np.uint8)
+        m10, m01 = C.c_int32(0), C.c_int32(0)
+        th = self.orc.lib.orc_extractor_describe(self.h, level, float(x), float(y), _p(desc), C.byref(m10), C.byref(m01))
+        return th, desc, m10.value, m01.value
 
     def umax(self):
         out = np.zeros(16, np.int32)

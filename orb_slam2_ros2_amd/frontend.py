@@ -1,0 +1,156 @@
+"""Host-side mirror of the reference's operator interface for the hot path (same names, argument
+meaning and error behaviour), implemented on the C-ABI of include/orbfe.h.
+
+Reference interfaces mirrored (relative to src/ORB_SLAM2/):
+  ORBExtractor(image, nFeatures, pyramidLevels, scaleFactor, bfTemFp, maxThreshold, minThreshold) + extract()
+      include/ORB_SLAM2/ORBExtractor.h:107-116
+  ORBMatcher(ratio=0.6, checkOri=True).searchByStereo(frame) / descDistance(a, b)
+      include/ORB_SLAM2/ORBMatcher.h:32-39, 77
+  Optimizer -- the per-edge evaluation under OptimizeLocalMap            include/ORB_SLAM2/Optimizer.h:69-72
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from ._lib import Context, ImageSizeError, OrbfeError  # noqa: F401
+
+
+def load_brief_template(path: str) -> np.ndarray:
+    """Parse a BRIEF template file exactly as ORBExtractor::initBriefTemplate does (ORBExtractor.cc:242-267):
+    skip the header line, then `x1 y1 x2 y2` per line.  Raises FileNotFoundError like FileNotOpenError."""
+    rows = []
+    with open(path, "r") as f:
+        lines = f.read().split("\n")
+    for ln in lines[1:]:
+        toks = ln.split()
+        if len(toks) >= 4:
+            rows.append([int(float(t)) for t in toks[:4]])
+    if len(rows) != 256:
+        raise ValueError(f"{path}: expected 256 BRIEF pairs, found {len(rows)}")
+    return np.asarray(rows, np.int8)
+
+
+class _CtxCache:
+    """One device context per (geometry, parameters): the reference builds a new extractor per image
+    (Frame.cc:91-92); re-allocating device buffers per image would be absurd, so contexts are shared."""
+    _cache: dict = {}
+
+    @classmethod
+    def get(cls, key, **kw) -> Context:
+        ctx = cls._cache.get(key)
+        if ctx is None or ctx.h is None:
+            ctx = Context(**kw)
+            cls._cache[key] = ctx
+        return ctx
+
+    @classmethod
+    def clear(cls):
+        for c in cls._cache.values():
+            c.close()
+        cls._cache.clear()
+
+
+class ORBExtractor:
+    """Per-image extractor, same construction/extract() split as the reference: the constructor takes the
+    image (the reference builds pyramid + blur there, ORBExtractor.cc:205-214), extract() returns keypoints
+    (structured array with cv::KeyPoint's fields) and an (N, 32) uint8 descriptor matrix."""
+
+    mnBorderSize = 19  # ORBExtractor.cc:523
+
+    def __init__(self, image, nFeatures, pyramidLevels, scaleFactor, bfTemFp=None, maxThreshold=20, minThreshold=7,
+                 *, device_id=0, slot=0, max_images=2):
+        image = np.ascontiguousarray(image, np.uint8)
+        if image.ndim != 2:
+            raise ValueError("ORBExtractor needs a single-channel 8-bit image (CV_8UC1)")
+        pairs = load_brief_template(bfTemFp) if bfTemFp else None
+        h, w = image.shape
+        key = (w, h, nFeatures, pyramidLevels, float(scaleFactor), maxThreshold, minThreshold,
+               pairs.tobytes() if pairs is not None else None, device_id, max_images)
+        self.ctx = _CtxCache.get(key, width=w, height=h, n_features=nFeatures, n_levels=pyramidLevels, scale_factor=scaleFactor,
+                                 fast_hi=maxThreshold, fast_lo=minThreshold, brief_pairs=pairs, device_id=device_id,
+                                 max_images=max_images)
+        self.image = image
+        self.slot = slot
+        self.mnLevels = pyramidLevels
+        self.mfScaledFactor = float(scaleFactor)
+        self._result = None
+
+    def extract(self):
+        if self.slot == 0:
+            kps, desc = self.ctx.extract(self.image)
+        else:  # fill the lower slots with this image too; only `slot` is read back
+            kps, desc = self.ctx.extract_batch([self.image] * (self.slot + 1))[self.slot]
+        self._result = (kps, desc)
+        return kps, desc
+
+    def getPyramid(self):
+        """The 8 un-blurred level images (ORBExtractor.h:113); valid after extract()."""
+        return [self.ctx.pyramid(self.slot, l, False) for l in range(self.mnLevels)]
+
+    def getScaledFactors(self):
+        return self.ctx.scale_factors()
+
+
+class ORBMatcher:
+    mnMaxThreshold, mnMinThreshold, mnMeanThreshold = 100, 50, 75  # ORBMatcher.cc:1086-1088
+    mnW, mnL, mnBinNum, mnBinChoose, mnFarParam = 5, 5, 30, 3, 35  # ORBMatcher.cc:1089-1093
+
+    def __init__(self, ratio: float = 0.6, checkOri: bool = True):
+        self.mfRatio, self.mbCheckOri = ratio, checkOri
+
+    @staticmethod
+    def descDistance(a, b) -> int:
+        """Hamming distance of two 1x32 uint8 descriptors (ORBMatcher.cc:941-956); host-side helper for
+        single pairs -- bulk matching goes through getBestMatches()."""
+        a = np.ascontiguousarray(a, np.uint8).reshape(-1)
+        b = np.ascontiguousarray(b, np.uint8).reshape(-1)
+        if a.size != 32 or b.size != 32:
+            raise ValueError("descriptors must be 1x32 uint8")
+        return int(np.unpackbits(a ^ b).sum())
+
+    @staticmethod
+    def getBestMatches(ctx: Context, queries, train, cand_offsets=None, cand_idx=None):
+        """Batched ORBMatcher::getBestMatch (ORBMatcher.cc:967-990): per query (best_idx, best_dist,
+        second_dist) with the reference's scan-order semantics."""
+        return ctx.match_bruteforce(queries, train, cand_offsets, cand_idx)
+
+    def searchByStereo(self, frame: "StereoFrontEnd", fx: float, bf: float):
+        """ORBMatcher::searchByStereo (ORBMatcher.cc:18-81) on the device-resident features of `frame`.
+        Returns (n_matches, right_u, depth) with -1 where unmatched."""
+        nm, ru, dp, _, _ = frame.ctx.stereo_match(0, 1, fx, bf)
+        n = len(frame.left[0])
+        return nm, ru[:n], dp[:n]
+
+
+class StereoFrontEnd:
+    """Frame::Frame(stereo) + Frame::createStereo (Frame.cc:85-111, Frame.h:313-322): both extractions and
+    the stereo match for one pair, through one context."""
+
+    def __init__(self, left, right, nFeatures=2000, nLevels=8, scale=1.2, maxThresh=20, minThresh=7, fx=718.856, bf=386.1448,
+                 briefFp=None, device_id=0):
+        left = np.ascontiguousarray(left, np.uint8)
+        right = np.ascontiguousarray(right, np.uint8)
+        if left.shape != right.shape:
+            raise ValueError("left/right image sizes differ")
+        pairs = load_brief_template(briefFp) if briefFp else None
+        h, w = left.shape
+        key = (w, h, nFeatures, nLevels, float(scale), maxThresh, minThresh, pairs.tobytes() if pairs is not None else None,
+               device_id, 2)
+        self.ctx = _CtxCache.get(key, width=w, height=h, n_features=nFeatures, n_levels=nLevels, scale_factor=scale,
+                                 fast_hi=maxThresh, fast_lo=minThresh, brief_pairs=pairs, device_id=device_id, max_images=2)
+        self.left, self.right = self.ctx.extract_batch([left, right])
+        self.mnN, ru, dp = ORBMatcher().searchByStereo(self, fx, bf)
+        self.mvFeatsRightU, self.mvDepths = ru, dp
+
+
+class Optimizer:
+    """Edge evaluation of the graph Optimizer::OptimizeLocalMap builds (Optimizer.cc:296-330)."""
+    deltaMono = float(np.float32(np.sqrt(5.991)))    # Optimizer.cc:1084 (stored as float)
+    deltaStereo = float(np.float32(np.sqrt(7.815)))  # Optimizer.cc:1085
+
+    @staticmethod
+    def evalEdges(ctx: Context, poses, points, edge_pose, edge_point, meas, is_stereo, info, huber_delta, fx, fy, cx, cy, bf,
+                  jacobians=True):
+        return ctx.ba_eval_edges(poses, points, edge_pose, edge_point, meas, is_stereo, info, huber_delta, fx, fy, cx, cy, bf,
+                                 jacobians)

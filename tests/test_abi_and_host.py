@@ -1,0 +1,74 @@
+"""Host logic that needs no GPU: the C-ABI library loads and exports every symbol include/orbfe.h declares,
+fails loudly without a device, the template parser, frame sharding."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "orbfe.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(orbfe_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from orb_slam2_ros2_amd import _lib
+    syms = declared_symbols()
+    assert len(syms) >= 20 and set(syms) == set(_lib.EXPORTS)
+    lib = ctypes.CDLL(_lib.LIB_PATH)  # loading must not need a GPU
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert lib.orbfe_abi_version() == 1
+
+
+def test_no_cpu_fallback_create_fails_loudly_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    from orb_slam2_ros2_amd._lib import Context, OrbfeError
+    with pytest.raises(OrbfeError) as ei:
+        Context(1241, 376)
+    assert ei.value.status == 3 and "no CPU fallback" in str(ei.value)
+    from orb_slam2_ros2_amd import ORBExtractor
+    with pytest.raises(OrbfeError):
+        ORBExtractor(np.zeros((376, 1241), np.uint8), 2000, 8, 1.2)
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "orb_slam2_ros2_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", ".inc")) or fn == "Makefile":
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                assert "oracle" not in txt.lower(), f"{fn} mentions the oracle"
+
+
+def test_brief_template_parser(tmp_path):
+    from orb_slam2_ros2_amd.frontend import load_brief_template
+    inc = open(os.path.join(ROOT, "orb_slam2_ros2_amd", "csrc", "brief_pattern.inc")).read()
+    nums = [int(v) for v in re.findall(r"-?\d+", "\n".join(l for l in inc.split("\n") if l.lstrip().startswith("{")))]
+    pat = np.asarray(nums, np.int8).reshape(256, 4)
+    p = tmp_path / "brief_template.txt"
+    # same shape as config/brief_template.txt: header line, tab-separated, trailing tab on some lines, no final newline
+    p.write_text("x1  y1  x2  y2\n" + "\n".join("\t".join(str(v) for v in r) + ("\t" if i % 7 == 0 else "") for i, r in enumerate(pat)))
+    assert np.array_equal(load_brief_template(str(p)), pat)
+    assert pat[0].tolist() == [8, -3, 9, 5] and pat.min() == -13 and pat.max() == 12
+    with pytest.raises(FileNotFoundError):
+        load_brief_template(str(tmp_path / "missing.txt"))
+
+
+def test_frame_range_partition():
+    from orb_slam2_ros2_amd.sharding import frame_range
+    assert [frame_range(4541, r, 8) for r in range(8)][0] == (0, 568)
+    assert frame_range(4541, 7, 8) == (3976, 4541)
+    for F, Wd in ((4541, 8), (100, 3), (5, 8), (0, 2)):
+        cover = []
+        for r in range(Wd):
+            b, e = frame_range(F, r, Wd)
+            cover += list(range(b, e))
+        assert cover == list(range(F))

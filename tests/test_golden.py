@@ -1,0 +1,77 @@
+"""The oracle against the committed golden vectors (tests/golden/golden_v1.json, made by tools/make_golden.py).
+These pin the oracle + synthetic generator; the GPU parity tests compare the HIP path with the same vectors."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from orb_slam2_ros2_amd import ba_synth, synth
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_v1.json")))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("f", [0, 1, 7])
+def test_kitti_frames(orc, f):
+    g = G["frames"][f"kitti_{f}"]
+    L, R = synth.stereo_pair(f)
+    assert sha(L) == g["left_sha"] and sha(R) == g["right_sha"]
+    r = orc.stereo_frame(L, R, fx=718.856, bf=718.856 * 0.537166, math_mode=0, threads=2)
+    assert (len(r["lk"]), len(r["rk"]), r["n_matches"]) == (g["n_left"], g["n_right"], g["n_matches"])
+    assert sha(r["lk"]) == g["lk_sha"] and sha(r["ld"]) == g["ld_sha"]
+    assert sha(r["rk"]) == g["rk_sha"] and sha(r["rd"]) == g["rd_sha"]
+    assert sha(r["right_u"]) == g["right_u_sha"] and sha(r["depth"]) == g["depth_sha"]
+    assert r["ld"][:2].tolist() == g["first_desc"]
+    # deterministic-math mode gives the same bytes
+    r1 = orc.stereo_frame(L, R, fx=718.856, bf=718.856 * 0.537166, math_mode=1, threads=1)
+    assert sha(r1["lk"]) == g["lk_sha"] and sha(r1["ld"]) == g["ld_sha"] and sha(r1["right_u"]) == g["right_u_sha"]
+
+
+def test_level_geometry_matches_survey_table(orc):
+    ex = orc.extractor(np.zeros((376, 1241), np.uint8))
+    dims = [ex.level_info(l)[:2] for l in range(8)]
+    assert dims == [(1241, 376), (1034, 313), (862, 261), (718, 218), (598, 181), (499, 151), (416, 126), (346, 105)]
+    assert [ex.level_info(l)[3] for l in range(8)] == [434, 362, 302, 252, 210, 175, 146, 119]
+    ex = orc.extractor(np.zeros((480, 640), np.uint8), n_features=1000)
+    assert [list(ex.level_info(l)[:2]) for l in range(8)] == G["frames"]["tum_0"]["level_dims"]
+    assert [ex.level_info(l)[3] for l in range(8)] == G["frames"]["tum_0"]["quotas"] == [217, 181, 151, 126, 105, 88, 73, 59]
+
+
+def test_tum_frame_and_sparse_frame(orc):
+    g = G["frames"]["tum_0"]
+    img = synth.mono_image(0)
+    assert sha(img) == g["img_sha"]
+    k, d = orc.extractor(img, n_features=1000).extract()
+    assert (len(k), sha(k), sha(d)) == (g["n"], g["k_sha"], g["d_sha"])
+    gs = G["frames"]["sparse_5"]
+    Ls, _ = synth.stereo_pair(5, sparse=True)
+    ks, _ = orc.extractor(Ls).extract()
+    assert sha(Ls) == gs["img_sha"] and len(ks) == gs["n"] == 0  # quirk Q3: fewer candidates than quota => nothing
+
+
+def test_image_size_error(orc):
+    with pytest.raises(ValueError):
+        orc.extractor(np.zeros((100, 130), np.uint8))  # level 7 would be 36x28 < 38 px (ORBExtractor.cc:310-314)
+
+
+def test_cfg3_bruteforce(orc):
+    g = G["cfg3"]
+    q, t = synth.descriptors_cfg3()
+    assert sha(q) == g["q_sha"] and sha(t) == g["t_sha"]
+    bi, bd, sd = orc.match_bruteforce(q, t)
+    assert (sha(bi), sha(bd), sha(sd)) == (g["best_idx_sha"], g["best_dist_sha"], g["second_sha"])
+
+
+def test_cfg5_ba(orc):
+    g = G["cfg5_ba"]
+    p = ba_synth.make_problem()
+    assert p["edge_pose"].size == g["n_edges"] and sha(p["meas"]) == g["meas_sha"]
+    o = orc.ba_eval_edges(p["poses"], p["points"], p["edge_pose"], p["edge_point"], p["meas"], p["is_stereo"], p["info"],
+                          p["huber_delta"], p["fx"], p["fy"], p["cx"], p["cy"], p["bf"])
+    assert o["chi2"].sum() == pytest.approx(g["chi2_sum"], rel=1e-12)
+    assert np.abs(o["j_pose"]).sum() == pytest.approx(g["jpose_abs_sum"], rel=1e-12)

@@ -1,0 +1,272 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C-ABI, against the CPU
+oracle on the same seeded inputs -- bit-exact for every integer/byte/index output (pyramid planes, FAST
+candidates, keypoints, angles, descriptors, match indices, right_u/depth floats), <= 1e-9 relative for the fp64 BA
+edge outputs -- plus size-independent properties at the full batch size."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from orb_slam2_ros2_amd import ba_synth, synth
+
+pytestmark = pytest.mark.gpu
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_v1.json")))
+FX, BF = 718.856, 718.856 * 0.537166
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from orb_slam2_ros2_amd import _lib
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def kitti_ctx(lib):
+    ctx = lib.Context(1241, 376, max_images=12)
+    yield ctx
+    ctx.close()
+
+
+def assert_image_parity(ctx, slot, ex, gk, gd, n_levels, check_planes=True):
+    """every intermediate and final product of one image: GPU (ctx, slot) vs oracle extractor `ex`"""
+    ok, od = ex.extract()
+    for l in range(n_levels):
+        if check_planes:
+            for blurred in (False, True):
+                a, b = ctx.pyramid(slot, l, blurred), ex.plane(l, blurred)
+                assert a.shape == b.shape and np.array_equal(a, b), f"level {l} blurred={blurred}: {(a != b).sum()} px differ"
+        gc, oc = ctx.debug_candidates(slot, l), ex.candidates(l)
+        assert gc.shape == oc.shape and np.array_equal(gc, oc), f"level {l} FAST candidates differ ({gc.shape} vs {oc.shape})"
+    assert len(gk) == len(ok), f"keypoint count {len(gk)} vs {len(ok)}"
+    for fld in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(gk[fld].view(np.int32), ok[fld].view(np.int32)), f"keypoint field {fld}"
+    assert np.array_equal(gd, od), "descriptors"
+    return ok, od
+
+
+@pytest.mark.parametrize("f", [0, 1, 7])
+def test_kitti_stereo_frame_bit_exact_and_golden(orc, kitti_ctx, f):
+    L, R = synth.stereo_pair(f)
+    (lk, ld), (rk, rd) = kitti_ctx.extract_batch([L, R])
+    nm, ru, dp, br, bd = kitti_ctx.stereo_match(0, 1, FX, BF)
+    exl, exr = orc.extractor(L), orc.extractor(R)   # libm mode: exactly what the reference calls
+    okl, odl = assert_image_parity(kitti_ctx, 0, exl, lk, ld, 8)
+    okr, odr = assert_image_parity(kitti_ctx, 1, exr, rk, rd, 8)
+    om, oru, odp, obr, obd = exl.stereo_match(exr, okl, odl, okr, odr, FX, BF)
+    n = len(okl)
+    assert nm == om
+    assert np.array_equal(ru[:n].view(np.int64), oru.view(np.int64)) and np.array_equal(dp[:n].view(np.int64), odp.view(np.int64))
+    assert np.array_equal(br[:n], obr) and np.array_equal(bd[:n], obd)
+    g = G["frames"][f"kitti_{f}"]
+    assert (sha(lk), sha(ld), sha(rk), sha(rd)) == (g["lk_sha"], g["ld_sha"], g["rk_sha"], g["rd_sha"])
+    assert sha(ru[:n]) == g["right_u_sha"] and sha(dp[:n]) == g["depth_sha"] and nm == g["n_matches"]
+
+
+def test_tum_geometry_1000_features(orc, lib):
+    img = synth.mono_image(0)
+    ctx = lib.Context(640, 480, n_features=1000, max_images=1)
+    k, d = ctx.extract(img)
+    assert_image_parity(ctx, 0, orc.extractor(img, n_features=1000), k, d, 8)
+    g = G["frames"]["tum_0"]
+    assert (len(k), sha(k), sha(d)) == (g["n"], g["k_sha"], g["d_sha"])
+    assert [ctx.level_info(l).quota for l in range(8)] == g["quotas"]
+    ctx.close()
+
+
+@pytest.mark.parametrize("w,h,nf,nl,sc,hi,lo", [(700, 300, 500, 5, 1.3, 20, 7), (333, 257, 300, 4, 1.2, 40, 10),
+                                                (1241, 376, 2000, 8, 1.2, 7, 20), (512, 512, 1500, 6, 1.5, 25, 25),
+                                                (1000, 200, 777, 3, 1.1, 12, 3), (1241, 376, 64, 8, 1.2, 20, 7)])
+def test_other_geometries_and_thresholds(orc, lib, w, h, nf, nl, sc, hi, lo):
+    img, _ = synth.stereo_pair(11, w, h, n_rect=160)
+    ctx = lib.Context(w, h, n_features=nf, n_levels=nl, scale_factor=sc, fast_hi=hi, fast_lo=lo, max_images=1)
+    k, d = ctx.extract(img)
+    ex = orc.extractor(img, n_features=nf, n_levels=nl, scale=sc, th_hi=hi, th_lo=lo)
+    assert_image_parity(ctx, 0, ex, k, d, nl)
+    for l in range(nl):
+        li = ctx.level_info(l)
+        assert (li.width, li.height, li.quota) == (ex.level_info(l)[0], ex.level_info(l)[1], ex.level_info(l)[3])
+        assert li.scale == ex.level_info(l)[2]
+    ctx.close()
+
+
+@pytest.mark.parametrize("nf", [2000, 120, 24])
+def test_sparse_image_levels_with_fewer_candidates_than_quota_yield_nothing(orc, lib, nf):
+    img, _ = synth.stereo_pair(5, sparse=True)
+    ctx = lib.Context(1241, 376, n_features=nf, max_images=1)
+    k, d = ctx.extract(img)
+    ok, _ = assert_image_parity(ctx, 0, orc.extractor(img, n_features=nf), k, d, 8, check_planes=False)
+    if nf == 2000:
+        assert len(k) == 0   # quirk Q3 on every level
+    ctx.close()
+
+
+def test_flat_and_noise_only_images(orc, lib):
+    ctx = lib.Context(400, 300, n_features=500, n_levels=4, max_images=1)
+    for img in (np.full((300, 400), 128, np.uint8), np.random.default_rng(0).integers(120, 127, (300, 400)).astype(np.uint8),
+                np.random.default_rng(1).integers(0, 256, (300, 400)).astype(np.uint8)):
+        k, d = ctx.extract(img)
+        assert_image_parity(ctx, 0, orc.extractor(img, n_features=500, n_levels=4), k, d, 4)
+    ctx.close()
+
+
+def test_blur_variant_and_custom_template(orc, lib):
+    img, _ = synth.stereo_pair(2, 640, 360, n_rect=150)
+    r = np.random.default_rng(9)
+    pat = r.integers(-13, 13, (256, 4)).astype(np.int8)
+    ctx = lib.Context(640, 360, n_features=800, blur_variant=1, brief_pairs=pat, max_images=1)
+    k, d = ctx.extract(img)
+    assert_image_parity(ctx, 0, orc.extractor(img, n_features=800, blur_variant=1, pattern=pat), k, d, 8)
+    ctx.close()
+
+
+def test_batch_slots_are_independent_and_equal_to_single_calls(orc, kitti_ctx):
+    frames = [synth.stereo_pair(f)[s] for f in (20, 21, 22) for s in (0, 1)]
+    frames.insert(3, frames[0])  # a duplicate must give identical bytes in another slot
+    res = kitti_ctx.extract_batch(frames)
+    assert np.array_equal(res[0][0], res[3][0]) and np.array_equal(res[0][1], res[3][1])
+    for i in (1, 5):
+        ok, od = orc.extractor(frames[i]).extract()
+        assert np.array_equal(res[i][0], ok) and np.array_equal(res[i][1], od)
+    single = kitti_ctx.extract(frames[2])
+    assert np.array_equal(single[0], res[2][0]) and np.array_equal(single[1], res[2][1])
+
+
+def test_device_resident_stereo_batch_equals_host_api(orc, kitti_ctx):
+    import torch
+    pairs = [synth.stereo_pair(f) for f in (30, 31, 32, 33)]
+    dl = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
+    dr = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    kitti_ctx.stereo_batch_device(dl.data_ptr(), dr.data_ptr(), 1241, 1241 * 376, 4, FX, BF)
+    kitti_ctx.sync()
+    for p, (L, R) in enumerate(pairs):
+        lk, ld = kitti_ctx.fetch_features(2 * p)
+        rk, rd = kitti_ctx.fetch_features(2 * p + 1)
+        nm, ru, dp, br, bd = kitti_ctx.fetch_stereo(p)
+        r = orc.stereo_frame(L, R, fx=FX, bf=BF)
+        assert np.array_equal(lk, r["lk"]) and np.array_equal(ld, r["ld"]) and np.array_equal(rk, r["rk"]) and np.array_equal(rd, r["rd"])
+        n = len(lk)
+        assert nm == r["n_matches"] and np.array_equal(ru[:n], r["right_u"]) and np.array_equal(dp[:n], r["depth"])
+    # padded source rows (stride > width) give the same result
+    pad = torch.zeros((4, 376, 1280), dtype=torch.uint8, device="cuda")
+    pad[:, :, :1241] = dl
+    padr = torch.zeros_like(pad)
+    padr[:, :, :1241] = dr
+    kitti_ctx.stereo_batch_device(pad.data_ptr(), padr.data_ptr(), 1280, 1280 * 376, 4, FX, BF)
+    kitti_ctx.sync()
+    lk2, ld2 = kitti_ctx.fetch_features(6)
+    assert np.array_equal(lk2, lk) and np.array_equal(ld2, ld)
+
+
+def test_cfg3_bruteforce_2000x2000_bit_exact(orc, kitti_ctx):
+    q, t = synth.descriptors_cfg3()
+    bi, bd, sd = kitti_ctx.match_bruteforce(q, t)
+    obi, obd, osd = orc.match_bruteforce(q, t)
+    assert np.array_equal(bi, obi) and np.array_equal(bd, obd) and np.array_equal(sd, osd)
+    g = G["cfg3"]
+    assert (sha(bi), sha(bd), sha(sd)) == (g["best_idx_sha"], g["best_dist_sha"], g["second_sha"])
+
+
+def test_bruteforce_candidate_lists_order_and_edge_cases(orc, kitti_ctx):
+    r = np.random.default_rng(4)
+    t = r.integers(0, 256, (300, 32), dtype=np.uint8)
+    q = t[r.integers(0, 300, 90)] ^ (r.integers(0, 256, (90, 32), dtype=np.uint8) & r.integers(0, 2, (90, 32), dtype=np.uint8) * 3)
+    lens = r.integers(0, 200, 90)
+    lens[:6] = [0, 1, 2, 63, 64, 65]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    cand = np.concatenate([r.permutation(300)[:n] for n in lens] + [np.zeros(0, np.int64)]).astype(np.uint32)
+    bi, bd, sd = kitti_ctx.match_bruteforce(q, t, offs, cand)
+    for i in range(90):
+        c = cand[offs[i]:offs[i + 1]].astype(np.int64)
+        if len(c) == 0:
+            assert (bi[i], bd[i], sd[i]) == (-1, 2**31 - 1, 2**31 - 1)
+        else:
+            assert (bi[i], bd[i], sd[i]) == orc.best_match(q[i], t, c)[:3], i
+    # descending-distance scan: second best stays INT_MAX (quirk Q6)
+    tt = np.zeros((3, 32), np.uint8)
+    tt[0, :7] = 255
+    tt[1, :5] = 255
+    tt[2, :3] = 255
+    b = kitti_ctx.match_bruteforce(np.zeros((1, 32), np.uint8), tt)
+    assert (b[0][0], b[1][0], b[2][0]) == (2, 24, 2**31 - 1)
+    b = kitti_ctx.match_bruteforce(np.zeros((1, 32), np.uint8), tt[::-1].copy())
+    assert (b[0][0], b[1][0], b[2][0]) == (0, 24, 40)
+    e = kitti_ctx.match_bruteforce(np.zeros((2, 32), np.uint8), np.zeros((0, 32), np.uint8))
+    assert e[0].tolist() == [-1, -1]
+
+
+def test_ba_edges_match_oracle(orc, kitti_ctx):
+    p = ba_synth.make_problem()
+    out = kitti_ctx.ba_eval_edges(**p)
+    ref = orc.ba_eval_edges(**p)
+    for k in ("error", "chi2", "rho", "j_point", "j_pose"):
+        a, b = out[k], ref[k]
+        assert a.shape == b.shape
+        assert np.allclose(a, b, rtol=1e-9, atol=1e-12), k  # tolerance of north_star (BA residuals <= 1e-4) is far looser
+    assert np.array_equal(out["depth_positive"], ref["depth_positive"])
+    assert out["chi2"].sum() == pytest.approx(G["cfg5_ba"]["chi2_sum"], rel=1e-12)
+    lean = kitti_ctx.ba_eval_edges(**p, jacobians=False)
+    assert np.array_equal(lean["chi2"], out["chi2"])
+
+
+def test_error_paths(lib, kitti_ctx):
+    with pytest.raises(lib.ImageSizeError):
+        lib.Context(130, 100)           # level 7 below 38 px (ORBExtractor.cc:310-314)
+    with pytest.raises(lib.OrbfeError) as ei:
+        kitti_ctx.extract_batch([np.zeros((376, 1241), np.uint8)] * 13)
+    assert ei.value.status == 4         # ECAPACITY
+    with pytest.raises(ValueError):
+        kitti_ctx.extract(np.zeros((100, 100), np.uint8))
+    with pytest.raises(lib.OrbfeError):
+        kitti_ctx.stereo_match(0, 99, FX, BF)
+    with pytest.raises(lib.OrbfeError):
+        lib.Context(1241, 376, n_levels=0)
+
+
+def test_full_batch_properties(kitti_ctx, lib):
+    """BASELINE-size batch (64 pairs = 128 images): size-independent properties instead of an oracle run."""
+    import torch
+    base = [synth.stereo_pair(f) for f in range(40, 44)]
+    B = 64
+    ctx = lib.Context(1241, 376, max_images=2 * B)
+    dl = torch.from_numpy(np.stack([base[i % 4][0] for i in range(B)])).cuda()
+    dr = torch.from_numpy(np.stack([base[i % 4][1] for i in range(B)])).cuda()
+    ctx.stereo_batch_device(dl.data_ptr(), dr.data_ptr(), 1241, 1241 * 376, B, FX, BF)
+    ctx.sync()
+    ref = {}
+    for p in range(B):
+        lk, ld = ctx.fetch_features(2 * p)
+        nm, ru, dp, br, bd = ctx.fetch_stereo(p)
+        key = p % 4
+        if key not in ref:
+            ref[key] = (lk, ld, nm, ru, dp)
+            assert len(lk) == 2000 and np.all(np.diff(lk["octave"]) >= 0)      # level-major order
+            assert np.all(lk["size"] == 7) and np.all(lk["class_id"] == -1)
+            assert (ru[:2000] >= 0).sum() == nm and nm > 50
+            ok = ru[:2000] >= 0
+            assert np.all(lk["x"][ok] - ru[:2000][ok] > 0) and np.all(dp[:2000][ok] > 0)
+        else:  # idempotence: the same image gives the same bytes in every slot of the batch
+            r = ref[key]
+            assert np.array_equal(lk, r[0]) and np.array_equal(ld, r[1]) and nm == r[2]
+            assert np.array_equal(ru, r[3]) and np.array_equal(dp, r[4])
+    ctx.close()
+
+
+def test_frontend_mirror_classes(orc):
+    from orb_slam2_ros2_amd import ORBExtractor, ORBMatcher, StereoFrontEnd
+    L, R = synth.stereo_pair(0)
+    e = ORBExtractor(L, 2000, 8, 1.2, None, 20, 7)
+    k, d = e.extract()
+    ok, od = orc.extractor(L).extract()
+    assert np.array_equal(k, ok) and np.array_equal(d, od)
+    pyr = e.getPyramid()
+    assert len(pyr) == 8 and np.array_equal(pyr[0], L) and pyr[7].shape == (105, 346)
+    assert ORBMatcher.descDistance(d[0], d[1]) == orc.hamming(d[0], d[1])
+    fr = StereoFrontEnd(L, R, fx=FX, bf=BF)
+    assert fr.mnN == G["frames"]["kitti_0"]["n_matches"] and sha(fr.mvDepths) == G["frames"]["kitti_0"]["depth_sha"]
