@@ -75,6 +75,13 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise OSError(f"{LIB_PATH} is missing: build it with `make -C orb_slam2_ros2_amd/csrc` "
                       "(there is no CPU fallback for the front end)")
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7, and a process that
+    # loads the system runtime first and torch's second ends up with two runtimes, the second of which sees no
+    # GPU.  If torch is installed, let it load its runtime first; liborbfe_hip.so then binds to that same copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
     L.orbfe_abi_version.restype = C.c_int
