@@ -49,8 +49,18 @@ __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv,
 }
 
 // ---------------------------------------------------------------------------------------------
-// blur: 64x16 outputs per block, separable 7-tap, 8.8 fixed point, BORDER_REFLECT_101
+// blur: separable 7-tap, 8.8 fixed point, BORDER_REFLECT_101 -- register sliding window, no LDS.
+//
+// One wave owns a column strip of 62 words (248 px) and BLUR_ROWS output rows.  Per input row a lane
+// loads ONE aligned 32-bit word (4 px; a wave reads 256 contiguous bytes), takes the two neighbouring
+// words from the adjacent lanes with a DPP wave shift (lanes 0 and 63 only carry the halo), forms the
+// four horizontal 8.8 sums and pushes them into a 7-row register window; once the window is full every
+// new row yields one output row (vertical 16.16 sum, +0x8000 >> 16) stored as one 32-bit word.
+// Integer arithmetic only => bit-exact with the two-pass definition.
 // ---------------------------------------------------------------------------------------------
+#define BLUR_ROWS 32
+#define BLUR_WORDS 62
+
 struct BlurTaps {
   int t[7];
 };
@@ -61,43 +71,91 @@ __device__ __forceinline__ int reflect101(int p, int n) {
   return p;
 }
 
+__device__ __forceinline__ uint32_t mad24(uint32_t tap_uniform, uint32_t v, uint32_t acc) {
+  uint32_t d;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(tap_uniform), "v"(v), "v"(acc));
+  return d;
+}
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130, 0xf, 0xf, false); }
+
 __global__ __launch_bounds__(256) void k_blur(const LevelDev* __restrict__ lv, int n_levels, const uint8_t* __restrict__ pyr,
                                               uint8_t* __restrict__ blur, size_t img_pitch, BlurTaps taps) {
-  __shared__ uint8_t tin[22][72];
-  __shared__ uint16_t tmid[22][64];
   const int img = blockIdx.y;
   const int tile = blockIdx.x;
   int l = 0;
   while (l + 1 < n_levels && tile >= lv[l + 1].bl_tile_base) ++l;
   const LevelDev& L = lv[l];
   const int t = tile - L.bl_tile_base;
-  const int x0 = (t % L.bl_tiles_x) * 64, y0 = (t / L.bl_tiles_x) * 16;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int strip = t % L.bl_tiles_x;
+  const int y0 = ((t / L.bl_tiles_x) * 4 + wv) * BLUR_ROWS;
+  if (y0 >= L.h) return;  // wave-uniform
+  const int w = L.w, h = L.h, stride = L.stride;
+  const int x4 = (strip * BLUR_WORDS + lane - 1) * 4;  // lane 0 / 63 = left / right halo word
   const uint8_t* P = pyr + (size_t)img * img_pitch + L.plane_off;
-  for (int i = threadIdx.x; i < 22 * 70; i += 256) {
-    const int r = i / 70, c = i - r * 70;
-    const int gy = reflect101(y0 + r - 3, L.h);
-    const int gx = reflect101(x0 + c - 3, L.w);
-    tin[r][c] = P[(size_t)gy * L.stride + gx];
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 22 * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    uint32_t acc = 0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) acc += (uint32_t)taps.t[k] * tin[r][c + k];
-    tmid[r][c] = (uint16_t)min(acc, 65535u);  // ufixedpoint16 saturation (never hit when the taps sum to 256)
-  }
-  __syncthreads();
   uint8_t* D = blur + (size_t)img * img_pitch + L.plane_off;
-  for (int i = threadIdx.x; i < 16 * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    const int gx = x0 + c, gy = y0 + r;
-    if (gx >= L.w || gy >= L.h) continue;
-    uint32_t acc = 0;
+  const bool fast_word = (x4 >= 0) && (x4 + 3 < w);
+  const bool writer = (lane >= 1) && (lane <= BLUR_WORDS) && (x4 < w);
+  int rx[4];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) acc += (uint32_t)taps.t[k] * tmid[r + k][c];
-    const uint32_t v = (acc + 0x8000u) >> 16;
-    D[(size_t)gy * L.stride + gx] = (uint8_t)min(v, 255u);
+  for (int k = 0; k < 4; ++k) rx[k] = reflect101(x4 + k, w);
+  // taps are 8.8 fixed-point fractions (< 256): masking tells the compiler that 24-bit multiplies suffice
+  const uint32_t t0 = taps.t[0] & 255u, t1 = taps.t[1] & 255u, t2 = taps.t[2] & 255u, t3 = taps.t[3] & 255u, t4 = taps.t[4] & 255u,
+                 t5 = taps.t[5] & 255u, t6 = taps.t[6] & 255u;
+  const uint32_t T03 = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24), T46 = t4 | (t5 << 8) | (t6 << 16);
+
+  uint32_t win[7][4];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) win[i][j] = 0;
+
+  const int n_out = min(BLUR_ROWS, h - y0);
+  const int n_in = n_out + 6;
+  for (int r0 = 0; r0 < n_in; r0 += 7) {
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int r = r0 + u;
+      if (r < n_in) {  // wave-uniform
+        const int gy = reflect101(y0 + r - 3, h);
+        const uint8_t* row = P + (size_t)gy * stride;
+        uint32_t m;
+        if (fast_word) {
+          m = *(const uint32_t*)(row + x4);
+        } else {
+          m = (uint32_t)row[rx[0]] | ((uint32_t)row[rx[1]] << 8) | ((uint32_t)row[rx[2]] << 16) | ((uint32_t)row[rx[3]] << 24);
+        }
+        const uint32_t lw = wave_shr1(m), rw = wave_shl1(m);
+        // bytes B[0..11] = lw|m|rw; output j needs px[j-3..j+3] = B[1+j .. 7+j]: two unaligned 4-byte windows per
+        // output (v_alignbyte) fed to two v_dot4_u32_u8 against the packed taps {t0..t3} and {t4..t6,0}
+        uint32_t* hh = win[u];  // window slot (r % 7) == u because r0 is a multiple of 7
+        hh[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(m, lw, 1), T03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rw, m, 1), T46, 0u, false), false);
+        hh[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(m, lw, 2), T03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rw, m, 2), T46, 0u, false), false);
+        hh[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(m, lw, 3), T03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rw, m, 3), T46, 0u, false), false);
+        hh[3] = __builtin_amdgcn_udot4(m, T03, __builtin_amdgcn_udot4(rw, T46, 0u, false), false);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hh[j] = min(hh[j], 65535u);  // ufixedpoint16 saturation (only reachable with variant-1 taps)
+        if (r >= 6) {
+          // rows r-6 .. r live in slots (u+1)%7 .. u ; tap k multiplies row r-6+k
+          uint32_t o = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            // 8-bit tap x 16-bit row sum: 24-bit multiplies are exact
+            // 8-bit tap x 16-bit row sum: v_mad_u32_u24 is exact here (hipcc would pick the quarter-rate v_mul_lo_u32)
+            uint32_t acc = mad24(t0, win[(u + 1) % 7][j], 0x8000u);
+            acc = mad24(t1, win[(u + 2) % 7][j], acc);
+            acc = mad24(t2, win[(u + 3) % 7][j], acc);
+            acc = mad24(t3, win[(u + 4) % 7][j], acc);
+            acc = mad24(t4, win[(u + 5) % 7][j], acc);
+            acc = mad24(t5, win[(u + 6) % 7][j], acc);
+            acc = mad24(t6, win[u][j], acc);
+            o |= min(acc >> 16, 255u) << (8 * j);
+          }
+          if (writer) *(uint32_t*)(D + (size_t)(y0 + r - 6) * stride + x4) = o;
+        }
+      }
+    }
   }
 }
 

@@ -270,8 +270,8 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
       rs_tiles += L.rs_tiles_x * L.rs_tiles_y;
     }
     L.bl_tile_base = bl_tiles;
-    L.bl_tiles_x = (L.w + 63) / 64;
-    L.bl_tiles_y = (L.h + 15) / 16;
+    L.bl_tiles_x = (L.w + 247) / 248;  // k_blur: 62 words (248 px) per wave, 4 waves x 32 rows per block
+    L.bl_tiles_y = (L.h + 127) / 128;
     bl_tiles += L.bl_tiles_x * L.bl_tiles_y;
   }
   // horizontal taps: clamp exactly as resizeGeneric_ does (sx<0 -> 0/fx=0; sx>=sw-1 -> sw-1/fx=0)
