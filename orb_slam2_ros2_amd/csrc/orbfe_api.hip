@@ -23,7 +23,8 @@ void launch_load_level0(hipStream_t st, const uint8_t* d_src, size_t src_stride,
                         uint32_t plane_off, int dst_stride, int w, int h, int slot0, int slot_step, int n_img);
 // k_fast.hip
 void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, int n_cells_total, const uint8_t* d_pyr,
-                 size_t img_pitch, int t_hi, int t_lo, uint32_t* d_slots, size_t slots_pitch, uint16_t* d_counts, int n_img);
+                 size_t img_pitch, int t_hi, int t_lo, uint32_t* d_slots, size_t slots_pitch, uint16_t* d_counts, int n_img,
+                 int max_pw, int max_ph);
 // k_quadtree.hip
 size_t quadtree_lds_bytes(int node_cap, int sort_cap);
 void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint16_t* d_counts, int n_cells_total,
@@ -77,6 +78,7 @@ struct orbfe_ctx {
   size_t slots_pitch = 0;    // uint32 per image
   size_t scratch_pitch = 0;  // uint64 per image
   int node_cap = 0, sort_cap = 0;
+  int max_pw = 0, max_ph = 0;  // largest FAST cell patch (sizes the LDS of k_fast)
 
   // device
   LevelDev* d_lv = nullptr;
@@ -232,6 +234,8 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
         cd.pad = 0;
         cd.slot_off = slot_base + (uint32_t)n_cells * (uint32_t)L.cell_cap;
         c->cells.push_back(cd);
+        c->max_pw = std::max(c->max_pw, (int)cd.pw);
+        c->max_ph = std::max(c->max_ph, (int)cd.ph);
         ++n_cells;
       }
     }
@@ -400,7 +404,7 @@ static orbfe_status run_extract(orbfe_ctx* c, int n_img) {
   {
     StageTimer t(c, ORBFE_STAGE_FAST);
     launch_fast(c->stream, c->d_lv, c->d_cells, c->n_cells_total, c->d_pyr, c->img_pitch, c->cfg.fast_hi, c->cfg.fast_lo,
-                c->d_slots, c->slots_pitch, c->d_counts, n_img);
+                c->d_slots, c->slots_pitch, c->d_counts, n_img, c->max_pw, c->max_ph);
   }
   {
     StageTimer t(c, ORBFE_STAGE_QUADTREE);
