@@ -1,13 +1,14 @@
-// k_brief.hip -- intensity-centroid orientation + rotated BRIEF-256 + keypoint assembly, one wavefront
-// per keypoint.
+// k_brief.hip -- intensity-centroid orientation + rotated BRIEF-256 + keypoint assembly: three kernels
+// (moments: one wave per keypoint; orientation: one lane per keypoint; descriptor: one wave per keypoint).
 //
 // Replaces ORBExtractor::computeBRIEF (src/ORB_SLAM2/src/ORBExtractor.cc:397-456), getGrayCentroid
 // (:465-487), rotateTemplate (:534-540) and the level concatenation of ORBExtractor::extract (:499-508).
 //
 //  * IC moments: the 749-pixel disc (umax table of initMaxU, :217-236) is summed in int32 across the 64
-//    lanes (two patch rows per step) on the UN-blurred plane, then wave-reduced.
+//    lanes (two patch rows per step) on the UN-blurred plane, then wave-reduced with DPP.
 //  * theta = atan2(m01, m10), cos/sin: fp64, evaluated with the shared deterministic routines of
-//    orb_math.h (bit-identical on host and device; <= 1 ulp from libm).
+//    orb_math.h (bit-identical on host and device; <= 1 ulp from libm) -- ONE LANE per keypoint (a block
+//    owns 16 keypoints), not one wave per keypoint: the ~400 fp64 instructions are the expensive part.
 //  * 256 tests: lane l evaluates pairs l, l+64, l+128, l+192; the rotated offsets are rounded exactly as
 //    the reference does (double product -> float, float add, round-half-even); one __ballot per group of
 //    64 tests yields 8 descriptor bytes already in the reference's LSB-first order.
@@ -18,31 +19,27 @@
 
 namespace orbfe {
 
-struct UmaxTab {
-  int8_t u[16];
-};
+// umax table (initMaxU, ORBExtractor.cc:217-236) packed 4 bits per row: half-width of the IC disc at |dy|
+typedef unsigned long long UmaxPacked;
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+// full-wave integer sum (all 64 lanes active), result in every lane
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_i32<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_i32<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_i32<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_i32<0x118, 0xf>(v);  // row_shr:8
+  v += dpp_i32<0x142, 0xa>(v);  // row_bcast:15
+  v += dpp_i32<0x143, 0xc>(v);  // row_bcast:31
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
-__global__ __launch_bounds__(256) void k_orient_brief(const LevelDev* __restrict__ lv, int n_levels,
-                                                      const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
-                                                      size_t img_pitch, const uint32_t* __restrict__ sel,
-                                                      const int32_t* __restrict__ sel_count, int n_features,
-                                                      const int8_t* __restrict__ pattern, UmaxTab umax,
-                                                      orbfe_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                      KpAux* __restrict__ aux, int32_t* __restrict__ n_kp, double* __restrict__ theta_out,
-                                                      int rows0) {
-#pragma clang fp contract(off)
-  const int lane = threadIdx.x & 63;
-  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);  // output keypoint index inside the image
-  const int img = blockIdx.y;
-  // level-major concatenation (ORBExtractor.cc:501-506): find the level that owns output index k
-  const int32_t* sc = sel_count + (size_t)img * n_levels;
-  int level = -1, j = 0, acc = 0;
+// output index k of an image -> (level, index inside the level): level-major concatenation (ORBExtractor.cc:501-506)
+__device__ __forceinline__ int locate_level(const int32_t* __restrict__ sc, int n_levels, int k, int* j_out, int* total_out) {
+  int level = -1, acc = 0, j = 0;
   for (int l = 0; l < n_levels; ++l) {
     const int c = sc[l];
     if (level < 0 && k < acc + c) {
@@ -51,57 +48,157 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelDev* __restrict
     }
     acc += c;
   }
-  if (k == 0 && lane == 0) n_kp[img] = acc;
+  *j_out = j;
+  *total_out = acc;
+  return level;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1. intensity-centroid moments, one wave per keypoint.  The 31x31 window of the UN-blurred plane is
+//    read as aligned 32-bit words (5 coalesced wave loads instead of 16 byte gathers).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ic_moments(const LevelDev* __restrict__ lv, int n_levels, const uint8_t* __restrict__ pyr,
+                                                    size_t img_pitch, const uint32_t* __restrict__ sel,
+                                                    const int32_t* __restrict__ sel_count, int n_features, UmaxPacked umax,
+                                                    int2* __restrict__ moments) {
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int img = blockIdx.y;
+  int j, total;
+  const int level = locate_level(sel_count + (size_t)img * n_levels, n_levels, k, &j, &total);
   if (level < 0) return;  // wave-uniform
   const LevelDev& L = lv[level];
   const uint32_t rec = sel[(size_t)img * n_features + L.quota_off + j];
   const int x = (int)ORBFE_REC_X(rec) + ORBFE_EDGE, y = (int)ORBFE_REC_Y(rec) + ORBFE_EDGE;  // level coordinates
-  const int resp = (int)ORBFE_REC_R(rec);
   const uint8_t* I = pyr + (size_t)img * img_pitch + L.plane_off;
-  const uint8_t* W = blur + (size_t)img * img_pitch + L.plane_off;
   const int stride = L.stride;
-
-  // ---- intensity centroid (ORBExtractor.cc:465-487): m10 = sum dx*I, m01 = sum dy*I over the disc ----
+  const int xa = (x - 15) & ~3;  // first aligned word of a row of the window
   int m10 = 0, m01 = 0;
-  {
-    const int half = lane >> 5;      // two rows per step
-    const int dx = (lane & 31) - 15;  // -15..16 (16 unused)
-    for (int r = 0; r < 16; ++r) {
-      const int dy = -15 + 2 * r + half;  // -15 .. 16
-      if (dy <= 15) {
-        const int ady = dy < 0 ? -dy : dy;
-        const int d = umax.u[ady];
-        if (dx >= -d && dx <= d) {
-          const int v = I[(size_t)(y + dy) * stride + (x + dx)];
-          m10 += dx * v;
-          m01 += dy * v;
-        }
+#pragma unroll
+  for (int it = 0; it < 5; ++it) {       // 31 rows x 9 words = 279 words
+    const int idx = it * 64 + lane;
+    const int r = (idx * 7282) >> 16;     // idx / 9 for idx < 320
+    const int c = idx - r * 9;
+    if (r < 31) {
+      const int dy = r - 15;
+      const int ady = dy < 0 ? -dy : dy;
+      const int d = (int)((umax >> (4 * ady)) & 15ull);
+      const uint32_t wv = *(const uint32_t*)(I + (size_t)(y + dy) * stride + xa + 4 * c);
+      const int dx0 = xa + 4 * c - x;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int dx = dx0 + b;
+        const int v = (int)((wv >> (8 * b)) & 255u);
+        const int vv = (dx >= -d && dx <= d) ? v : 0;
+        m10 += dx * vv;
+        m01 += dy * vv;
       }
     }
   }
   m10 = wave_sum_i(m10);
   m01 = wave_sum_i(m01);
-  const double theta = orbmath::det_atan2((double)m01, (double)m10);
+  if (lane == 0) moments[(size_t)img * n_features + k] = make_int2(m10, m01);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2. orientation: ONE LANE per keypoint.  theta = atan2(m01, m10) and cos/sin in fp64 with the shared
+//    deterministic routines; assembles the cv::KeyPoint record and the stereo row band.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv, int n_levels, const uint32_t* __restrict__ sel,
+                                                const int32_t* __restrict__ sel_count, int n_features,
+                                                const int2* __restrict__ moments, double2* __restrict__ sincos,
+                                                orbfe_keypoint* __restrict__ kps, KpAux* __restrict__ aux, int32_t* __restrict__ n_kp,
+                                                double* __restrict__ theta_out, int rows0) {
+#pragma clang fp contract(off)
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int img = blockIdx.y;
+  int j, total;
+  const int level = locate_level(sel_count + (size_t)img * n_levels, n_levels, k, &j, &total);
+  if (k == 0) n_kp[img] = total;
+  if (level < 0) return;
+  const LevelDev& L = lv[level];
+  const uint32_t rec = sel[(size_t)img * n_features + L.quota_off + j];
+  const int x = (int)ORBFE_REC_X(rec) + ORBFE_EDGE, y = (int)ORBFE_REC_Y(rec) + ORBFE_EDGE;
+  const size_t o = (size_t)img * n_features + k;
+  const int2 m = moments[o];
+  const double theta = orbmath::det_atan2((double)m.y, (double)m.x);
   double sn, cs;
   orbmath::det_sincos(theta, &sn, &cs);
+  sincos[o] = make_double2(sn, cs);
+  orbfe_keypoint kp;
+  kp.x = (float)x * L.sf;  // keypoint.pt *= scale[octave] (ORBExtractor.cc:408-409)
+  kp.y = (float)y * L.sf;
+  kp.size = 7.0f;
+  kp.angle = (float)(theta / 3.14159265358979323846 * 180);  // ORBExtractor.cc:407
+  kp.response = (float)ORBFE_REC_R(rec);
+  kp.octave = level;
+  kp.class_id = -1;
+  kps[o] = kp;
+  // createRowIndexDB band (ORBMatcher.cc:924-927), stored with the keypoint for the stereo matcher
+  const float r = (float)(2.0 * (double)L.sf);
+  const unsigned row = (unsigned)__float2int_rn(kp.y);
+  KpAux a;
+  a.row_max = (int16_t)min(rows0, __float2int_rn((float)row + r + 1.0f));
+  a.row_min = (int16_t)max(0, __float2int_rn((float)row - r));
+  aux[o] = a;
+  if (theta_out) theta_out[o] = theta;
+}
 
-  // ---- rotated BRIEF on the blurred plane (ORBExtractor.cc:439-454) ----
+// ---------------------------------------------------------------------------------------------
+// 3. rotated BRIEF, one wave per keypoint.  The 37x37 window of the BLURRED plane that the rotated template
+//    can reach (|offset| <= 18) is staged in LDS with coalesced word loads; the 512 data-dependent byte reads
+//    then hit LDS instead of issuing 8 global gathers with ~64 distinct cache lines each.
+// ---------------------------------------------------------------------------------------------
+#define BRIEF_R 18
+#define BRIEF_ROWS (2 * BRIEF_R + 1)
+#define BRIEF_WORDS 11  // (3 + 37 + 3) / 4 rounded up
+
+__global__ __launch_bounds__(64) void k_brief(const LevelDev* __restrict__ lv, int n_levels, const uint8_t* __restrict__ blur,
+                                              size_t img_pitch, const uint32_t* __restrict__ sel,
+                                              const int32_t* __restrict__ sel_count, int n_features,
+                                              const int8_t* __restrict__ pattern, const double2* __restrict__ sincos,
+                                              uint8_t* __restrict__ desc) {
+#pragma clang fp contract(off)
+  __shared__ uint32_t win[BRIEF_ROWS * BRIEF_WORDS];
+  const int lane = threadIdx.x;
+  const int k = blockIdx.x;
+  const int img = blockIdx.y;
+  int j, total;
+  const int level = locate_level(sel_count + (size_t)img * n_levels, n_levels, k, &j, &total);
+  if (level < 0) return;  // block-uniform
+  const LevelDev& L = lv[level];
+  const uint32_t rec = sel[(size_t)img * n_features + L.quota_off + j];
+  const int x = (int)ORBFE_REC_X(rec) + ORBFE_EDGE, y = (int)ORBFE_REC_Y(rec) + ORBFE_EDGE;
+  const uint8_t* W = blur + (size_t)img * img_pitch + L.plane_off;
+  const int stride = L.stride;
+  const int xa = (x - BRIEF_R) & ~3;
+#pragma unroll
+  for (int it = 0; it < (BRIEF_ROWS * BRIEF_WORDS + 63) / 64; ++it) {
+    const int idx = it * 64 + lane;
+    const int r = (idx * 5958) >> 16;  // idx / 11 for idx < 448
+    const int c = idx - r * BRIEF_WORDS;
+    if (idx < BRIEF_ROWS * BRIEF_WORDS) win[idx] = *(const uint32_t*)(W + (size_t)(y - BRIEF_R + r) * stride + xa + 4 * c);
+  }
+  const double2 scv = sincos[(size_t)img * n_features + k];
+  const double sn = scv.x, cs = scv.y;
+  __syncthreads();
+  const uint8_t* wb = (const uint8_t*)win;
   const float px = (float)x, py = (float)y;
+  const int x_off = xa, y_off = y - BRIEF_R;
   unsigned long long bits[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const int pair = g * 64 + lane;
-    const int8_t* t = pattern + pair * 4;
+    const int8_t* t = pattern + (g * 64 + lane) * 4;
     const float x1 = (float)t[0], y1 = (float)t[1], x2 = (float)t[2], y2 = (float)t[3];
-    // float * double -> double, one rounding to float (rotateTemplate, :537-538)
+    // float * double -> double, one rounding to float (rotateTemplate, ORBExtractor.cc:537-538)
     const float p1x = (float)((double)x1 * cs - (double)y1 * sn);
     const float p1y = (float)((double)x1 * sn + (double)y1 * cs);
     const float p2x = (float)((double)x2 * cs - (double)y2 * sn);
     const float p2y = (float)((double)x2 * sn + (double)y2 * cs);
     const int r1 = __float2int_rn(py + p1y), c1 = __float2int_rn(px + p1x);
     const int r2 = __float2int_rn(py + p2y), c2 = __float2int_rn(px + p2x);
-    const int v1 = W[(size_t)r1 * stride + c1];
-    const int v2 = W[(size_t)r2 * stride + c2];
+    const int v1 = wb[(r1 - y_off) * (BRIEF_WORDS * 4) + (c1 - x_off)];
+    const int v2 = wb[(r2 - y_off) * (BRIEF_WORDS * 4) + (c2 - x_off)];
     bits[g] = __ballot(v1 < v2);
   }
   if (lane < 4) {
@@ -112,38 +209,21 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelDev* __restrict
     if (lane == 3) b = bits[3];
     d64[lane] = b;
   }
-  if (lane == 0) {
-    orbfe_keypoint kp;
-    kp.x = px * L.sf;  // keypoint.pt *= scale[octave] (ORBExtractor.cc:408-409)
-    kp.y = py * L.sf;
-    kp.size = 7.0f;
-    kp.angle = (float)(theta / 3.14159265358979323846 * 180);  // ORBExtractor.cc:407
-    kp.response = (float)resp;
-    kp.octave = level;
-    kp.class_id = -1;
-    kps[(size_t)img * n_features + k] = kp;
-    // createRowIndexDB band (ORBMatcher.cc:924-927), stored with the keypoint for the stereo matcher
-    const float r = (float)(2.0 * (double)L.sf);
-    const unsigned row = (unsigned)__float2int_rn(kp.y);
-    const int max_row = min(rows0, __float2int_rn((float)row + r + 1.0f));
-    const int min_row = max(0, __float2int_rn((float)row - r));
-    KpAux a;
-    a.row_min = (int16_t)min_row;
-    a.row_max = (int16_t)max_row;
-    aux[(size_t)img * n_features + k] = a;
-    if (theta_out) theta_out[(size_t)img * n_features + k] = theta;
-  }
 }
 
 void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
-                         int32_t* d_n_kp, double* d_theta, int rows0, int n_img) {
+                         int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, int rows0, int n_img) {
   if (n_img <= 0 || n_features <= 0) return;
-  UmaxTab u;
-  for (int i = 0; i < 16; ++i) u.u[i] = (int8_t)umax[i];
-  hipLaunchKernelGGL(k_orient_brief, dim3((n_features + 3) / 4, n_img), dim3(256), 0, s, d_lv, n_levels, d_pyr, d_blur,
-                     img_pitch, d_sel, d_sel_count, n_features, d_pattern, u, d_kps, d_desc, d_aux, d_n_kp, d_theta, rows0);
+  UmaxPacked u = 0;
+  for (int i = 0; i < 16; ++i) u |= (unsigned long long)(umax[i] & 15) << (4 * i);
+  hipLaunchKernelGGL(k_ic_moments, dim3((n_features + 3) / 4, n_img), dim3(256), 0, s, d_lv, n_levels, d_pyr, img_pitch, d_sel,
+                     d_sel_count, n_features, u, d_moments);
+  hipLaunchKernelGGL(k_orient, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, n_levels, d_sel, d_sel_count, n_features,
+                     d_moments, d_sincos, d_kps, d_aux, d_n_kp, d_theta, rows0);
+  hipLaunchKernelGGL(k_brief, dim3(n_features, n_img), dim3(64), 0, s, d_lv, n_levels, d_blur, img_pitch, d_sel, d_sel_count,
+                     n_features, d_pattern, d_sincos, d_desc);
 }
 
 }  // namespace orbfe

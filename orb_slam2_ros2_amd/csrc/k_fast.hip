@@ -17,47 +17,26 @@
 //   2. every interior pixel takes a 9-read necessary test (a 9-arc contains one pixel of each opposite ring
 //      pair, so min over 4 pairs of max(pair) must exceed v+t, or max of min(pair) be below v-t); survivors
 //      are appended -- in raster order -- to an LDS queue with ballot/prefix;
-//   3. the queue is processed densely: exact 16-bit arc masks, then V for the true corners, written to a
-//      zero-bordered V map;
-//   4. NMS, the hi/lo decision and the ordered compaction run over the queue only (it is already in raster
-//      order), never over the whole patch again.
+//   3. the queue is processed densely: V for both polarities at once with packed-i16 min/max (v_pk_min_i16 /
+//      v_pk_max_i16 on (d, -d) pairs), written to a zero-bordered V map;
+//   4. NMS and the hi/lo decision run over the queue only, never over the whole patch again; the kept maxima
+//      are appended to the level's candidate list (one atomic reservation per cell).
 #include <hip/hip_runtime.h>
 
 #include "orbfe_internal.h"
 
 namespace orbfe {
 
-__device__ __forceinline__ uint32_t rot16(uint32_t m, int k) { return ((m >> k) | (m << (16 - k))) & 0xFFFFu; }
-
-__device__ __forceinline__ bool has_arc9(uint32_t m) {
-  uint32_t m2 = m & rot16(m, 1);
-  uint32_t m4 = m2 & rot16(m2, 2);
-  uint32_t m8 = m4 & rot16(m4, 4);
-  return (m8 & rot16(m, 8)) != 0;
-}
-
-// max over the 16 circular windows of length 9 of the window minimum
-__device__ __forceinline__ int max_arc_min(const int (&d)[16]) {
-  int m2[16], m4[16], m8[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) m2[i] = min(d[i], d[(i + 1) & 15]);
-#pragma unroll
-  for (int i = 0; i < 16; ++i) m4[i] = min(m2[i], m2[(i + 2) & 15]);
-#pragma unroll
-  for (int i = 0; i < 16; ++i) m8[i] = min(m4[i], m4[(i + 4) & 15]);
-  int best = -1000;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) best = max(best, min(m8[i], d[(i + 8) & 15]));
-  return best;
-}
+typedef short s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2 as_s2(uint32_t u) { return __builtin_bit_cast(s2, u); }
 
 // floor(i / d) for 0 <= i < 8192, 1 <= d <= 128 with inv = ceil(2^20 / d)
 __device__ __forceinline__ int fdiv20(int i, uint32_t inv) { return (int)(((uint32_t)i * inv) >> 20); }
 
 __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, const CellDev* __restrict__ cells,
                                              const uint8_t* __restrict__ pyr, size_t img_pitch, int t_hi, int t_lo,
-                                             uint32_t* __restrict__ slots, size_t slots_pitch, uint16_t* __restrict__ counts,
-                                             int n_cells_total, int lds_v_off, int lds_q_off, int lds_f_off) {
+                                             uint32_t* __restrict__ cand, size_t cand_pitch, int32_t* __restrict__ n_cand,
+                                             int n_levels, int lds_v_off, int lds_q_off, int lds_f_off) {
   extern __shared__ uint32_t lds_w[];
   uint8_t* P = (uint8_t*)lds_w;              // patch rows, pitch = pitch_p bytes, pixel (r,c) at P[r*pitch_p + xa + c]
   uint8_t* V = (uint8_t*)lds_w + lds_v_off;  // (ih+2) x (iw+2) scores with a zero border, pixel (iy,ix) at V[(iy+1)*pv + ix+1]
@@ -144,28 +123,34 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
       ring[13] = c[1 * pitch_p - 3];
       ring[14] = c[2 * pitch_p - 2];
       ring[15] = c[3 * pitch_p - 1];
-      uint32_t dark = 0, bright = 0;
+      // V = max(A, B) for both polarities at once: lane-local packed i16 pairs (d_k, -d_k); the 16 circular
+      // 9-windows by doubling (min over 2, 4, 8, then +1), then the max over the windows.  Corner at t <=> V > t.
+      const uint32_t vhi = (uint32_t)v << 16;
+      s2 d[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        dark |= (uint32_t)(ring[k] < v - t_min) << k;
-        bright |= (uint32_t)(ring[k] > v + t_min) << k;
+        const uint32_t a = ((uint32_t)ring[k] << 16) | (uint32_t)v;  // (v, r)
+        const uint32_t b = (uint32_t)ring[k] | vhi;                  // (r, v)
+        d[k] = as_s2(a) - as_s2(b);                                  // (v - r, r - v)
       }
-      if (has_arc9(dark) || has_arc9(bright)) {
-        int d[16], nd[16];
+      s2 m2[16], m4[16], m8[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          d[k] = v - ring[k];
-          nd[k] = -d[k];
-        }
-        const int a = max_arc_min(d), b = max_arc_min(nd);
-        V[(iy + 1) * pv + ix + 1] = (uint8_t)min(255, max(a, b));  // > t_min >= 0 here
-      }
+      for (int k = 0; k < 16; ++k) m2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) m8[k] = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
+      s2 best = __builtin_elementwise_min(m8[0], d[8]);
+#pragma unroll
+      for (int k = 1; k < 16; ++k) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[k], d[(k + 8) & 15]));
+      const int vv = max((int)best.x, (int)best.y);
+      if (vv > t_min) V[(iy + 1) * pv + ix + 1] = (uint8_t)min(255, vv);
     }
   }
   __syncthreads();
 
-  // ---- 4. NMS over the queue, hi/lo decision, ordered compaction ----
-  bool any_hi = false;
+  // ---- 4. NMS over the queue, hi/lo decision, append to the level's candidate list ----
+  int n_hi = 0, n_lo = 0;
   {
     const uint32_t inv = iw > 0 ? ((1u << 20) + iw - 1) / iw : 0;
     for (int q0 = 0; q0 < nq; q0 += 64) {
@@ -183,16 +168,24 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
         }
         F[q] = (uint8_t)f;
       }
-      any_hi = any_hi || (__ballot((f & 2) != 0) != 0ull);
+      n_hi += __popcll(__ballot((f & 2) != 0));
+      n_lo += __popcll(__ballot((f & 1) != 0));
     }
   }
   __syncthreads();
   {
+    // cv::FAST(hi) result if non-empty, else cv::FAST(lo) (ORBExtractor.cc:365-367).  The list of a level is a SET:
+    // the quadtree orders candidates by (cell, y, x) recomputed from the coordinates, so cells may append in any
+    // order -- one atomic reservation per cell, then the wave writes its records.
     const uint32_t inv = iw > 0 ? ((1u << 20) + iw - 1) / iw : 0;
-    const int want = any_hi ? 2 : 1;
+    const int want = n_hi > 0 ? 2 : 1;
+    const int total = n_hi > 0 ? n_hi : n_lo;
+    if (total == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&n_cand[(size_t)img * n_levels + cell.level], total);
+    base = __builtin_amdgcn_readfirstlane(base);
+    uint32_t* out = cand + (size_t)img * cand_pitch + L.cand_base + base;
     int cnt = 0;
-    uint32_t* out = slots + (size_t)img * slots_pitch + cell.slot_off;
-    const int cap = L.cell_cap;
     for (int q0 = 0; q0 < nq; q0 += 64) {
       const int q = q0 + lane;
       const bool keep = (q < nq) && ((F[q] & want) != 0);
@@ -200,12 +193,11 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
       if (keep) {
         const int i = Q[q];
         const int iy = fdiv20(i, inv), ix = i - iy * iw;
-        const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-        if (pos < cap) out[pos] = ORBFE_PACK_XYR(ix + 3 + cell.offx, iy + 3 + cell.offy, V[(iy + 1) * pv + ix + 1] - 1);
+        out[cnt + __popcll(m & ((1ull << lane) - 1ull))] =
+            ORBFE_PACK_XYR(ix + 3 + cell.offx, iy + 3 + cell.offy, V[(iy + 1) * pv + ix + 1] - 1);
       }
       cnt += __popcll(m);
     }
-    if (lane == 0) counts[(size_t)img * n_cells_total + blockIdx.x] = (uint16_t)min(cnt, cap);
   }
 }
 
@@ -225,13 +217,13 @@ void fast_lds_layout(int max_pw, int max_ph, int* v_off, int* q_off, int* f_off,
 }
 
 void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, int n_cells_total, const uint8_t* d_pyr,
-                 size_t img_pitch, int t_hi, int t_lo, uint32_t* d_slots, size_t slots_pitch, uint16_t* d_counts, int n_img,
-                 int max_pw, int max_ph) {
+                 size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch, int32_t* d_n_cand, int n_levels,
+                 int n_img, int max_pw, int max_ph) {
   if (n_cells_total <= 0 || n_img <= 0) return;
   int v_off, q_off, f_off, total;
   fast_lds_layout(max_pw, max_ph, &v_off, &q_off, &f_off, &total);
-  hipLaunchKernelGGL(k_fast, dim3(n_cells_total, n_img), dim3(64), total, s, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo, d_slots,
-                     slots_pitch, d_counts, n_cells_total, v_off, q_off, f_off);
+  hipLaunchKernelGGL(k_fast, dim3(n_cells_total, n_img), dim3(64), total, s, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo, d_cand,
+                     cand_pitch, d_n_cand, n_levels, v_off, q_off, f_off);
 }
 
 }  // namespace orbfe

@@ -4,20 +4,45 @@
 // src/ORB_SLAM2/src/ORBExtractor.cc:19-192) as driven by extractFast (:376-386).
 //
 // The algorithm is inherently sequential (best-first expansion of a priority queue), so the parallelism
-// is (a) across the (image, level) pairs of a batch -- one wave each -- and (b) inside one expansion step:
-//   * pop  = 64-lane arg-max over the active node table in LDS, key (count desc, insertion seq asc),
-//            which is exactly std::multimap<size_t,...,greater> begin() with insertion-order ties;
-//   * split = two-pass stable 4-way partition of the node's record segment with wave ballots
-//            (records ping-pong between two scratch buffers at the same offsets, so memory is 2N);
-//   * membership is the reference's strict test against double-precision bounds (ORBExtractor.h:55-62),
-//     midpoints (b+e)/2 in fp64, so points on a split line are dropped exactly as in the reference.
-// No "single point => stop" rule, exact min(quota, nodes) truncation, per-node first-maximum response,
-// output ordered by candidate index (std::set) -- quirks Q3/Q4 of SURVEY.md.
+// is (a) across the (image, level) pairs of a batch -- one wave each -- and (b) inside one expansion step.
+// The cost that matters is the LATENCY of one pop+split (a level needs 40-150 of them, one after the
+// other), so everything a step touches lives in LDS:
+//   * node table (bounds in fp64, key = count<<32 | ~insertion_seq, segment begin) in LDS;
+//   * the candidate records (x:12 | y:12 | response:8, 4 bytes) in ONE LDS array; a node owns a contiguous
+//     segment; a node with <= 512 records is split IN PLACE through registers (8 records per lane, ballots
+//     give the stable 4-way partition); only the few big nodes near the root bounce through a global
+//     scratch buffer; levels whose candidates do not fit the LDS array fall back to global memory for
+//     everything (same code, generic pointers);
+//   * pop = arg-max of the key = std::multimap<size_t,...,greater>::begin() with insertion-order ties:
+//     7 LDS reads per lane + two 32-bit DPP wave reductions.
+// Membership is the reference's strict test against double-precision bounds (ORBExtractor.h:55-62),
+// midpoints (b+e)/2 in fp64, so points on a split line are dropped exactly as in the reference.  No
+// "single point => stop" rule, exact min(quota, nodes) truncation, per-node first-maximum response,
+// output ordered by candidate index (std::set) -- quirks Q3/Q4 of SURVEY.md.  The candidate index itself
+// is not carried: candidate order is (cell row, cell column, y, x), recomputed from the coordinates.
 #include <hip/hip_runtime.h>
 
 #include "orbfe_internal.h"
 
 namespace orbfe {
+
+#define QT_INPLACE_CHUNKS 8  // nodes up to 8*64 records are partitioned in registers
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+// full-wave max / min of a u32 (all 64 lanes active); result broadcast to every lane
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = max(v, dpp_u32<0x111, 0xf>(0u, v));  // row_shr:1
+  v = max(v, dpp_u32<0x112, 0xf>(0u, v));  // row_shr:2
+  v = max(v, dpp_u32<0x114, 0xf>(0u, v));  // row_shr:4
+  v = max(v, dpp_u32<0x118, 0xf>(0u, v));  // row_shr:8
+  v = max(v, dpp_u32<0x142, 0xa>(0u, v));  // row_bcast:15 -> rows 1,3
+  v = max(v, dpp_u32<0x143, 0xc>(0u, v));  // row_bcast:31 -> rows 2,3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #pragma unroll
@@ -27,349 +52,278 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
   }
   return v;
 }
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-  return v;
+
+__device__ __forceinline__ int quadrant_of(uint32_t p, double midx, double midy) {
+  const double x = (double)ORBFE_REC_X(p), y = (double)ORBFE_REC_Y(p);
+  const int qx = (x < midx) ? 0 : ((x > midx) ? 1 : -1);
+  const int qy = (y < midy) ? 0 : ((y > midy) ? 1 : -1);
+  return (qx >= 0 && qy >= 0) ? (qy * 2 + qx) : -1;  // rows outer, cols inner (ORBExtractor.cc:60-72)
 }
 
-struct NodeTab {
-  double* rb;
-  double* re;
-  double* cb;
-  double* ce;
-  uint32_t* cnt;
-  uint32_t* seq;
-  uint32_t* beg;
-  uint32_t* buf;
-};
-
-// Copy the records of `src[0..n)` that lie strictly inside (cb,ce) x (rb,re) to dst[0..), stable.  Wave-uniform args.
-__device__ int filter_box(const uint64_t* __restrict__ src, int n, uint64_t* __restrict__ dst, double rb, double re, double cb,
-                          double ce, int lane) {
-  int out = 0;
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    uint64_t rec = 0;
-    bool in = false;
-    if (i < n) {
-      rec = src[i];
-      const uint32_t p = (uint32_t)rec;
-      const double x = (double)ORBFE_REC_X(p), y = (double)ORBFE_REC_Y(p);
-      in = x > cb && x < ce && y > rb && y < re;
-    }
-    const unsigned long long m = __ballot(in);
-    if (in) dst[out + __popcll(m & ((1ull << lane) - 1ull))] = rec;
-    out += __popcll(m);
-  }
-  return out;
+// candidate order of the reference = (cell row, cell column, y, x): cells are visited row-major and cv::FAST emits
+// a patch in raster order (ORBExtractor.cc:346-373).  39-bit key, smaller = earlier.
+__device__ __forceinline__ unsigned long long order_key(uint32_t rec, const LevelDev& L) {
+  const uint32_t x = ORBFE_REC_X(rec), y = ORBFE_REC_Y(rec);
+  const uint32_t jdx = min(((x - 3u) * L.inv_w_cell) >> 20, (uint32_t)L.n_cols - 1u);
+  const uint32_t idx = min(((y - 3u) * L.inv_h_cell) >> 20, (uint32_t)L.n_rows - 1u);
+  return ((unsigned long long)(idx * (uint32_t)L.n_cols + jdx) << 24) | ((unsigned long long)y << 12) | (unsigned long long)x;
 }
 
-__global__ __launch_bounds__(64) void k_quadtree(const LevelDev* __restrict__ lv, int n_levels,
-                                                 const uint16_t* __restrict__ counts, int n_cells_total,
-                                                 const uint32_t* __restrict__ slots, size_t slots_pitch,
-                                                 uint64_t* __restrict__ scratch_a, uint64_t* __restrict__ scratch_b,
-                                                 size_t scratch_pitch, uint32_t* __restrict__ sel, int32_t* __restrict__ sel_count,
-                                                 int n_features, int32_t* __restrict__ n_cand, int node_cap, int sort_cap) {
-  extern __shared__ double lds[];
-  const int lane = threadIdx.x;
-  const int level = blockIdx.x, img = blockIdx.y;
-  const LevelDev& L = lv[level];
-  NodeTab T;
-  T.rb = lds;
-  T.re = T.rb + node_cap;
-  T.cb = T.re + node_cap;
-  T.ce = T.cb + node_cap;
-  uint64_t* sortbuf = (uint64_t*)(T.ce + node_cap);
-  T.cnt = (uint32_t*)(sortbuf + sort_cap);
-  T.seq = T.cnt + node_cap;
-  T.beg = T.seq + node_cap;
-  T.buf = T.beg + node_cap;
-
-  uint64_t* bufs[2] = {scratch_a + (size_t)img * scratch_pitch + L.cand_base, scratch_b + (size_t)img * scratch_pitch + L.cand_base};
-  const uint16_t* cnt = counts + (size_t)img * n_cells_total + L.cell_base;
-  const uint32_t* sl = slots + (size_t)img * slots_pitch + L.slot_base;
-  uint32_t* out_sel = sel + (size_t)img * n_features + L.quota_off;
-  const int need = L.quota;
-
-  // ---- gather the level's candidates in the reference's order (cell-row-major, in-cell raster) ----
-  int N = 0;
-  for (int c0 = 0; c0 < L.n_cells; c0 += 64) {
-    const int c = c0 + lane;
-    const int k = (c < L.n_cells) ? (int)cnt[c] : 0;
-    const int incl = wave_incl_scan(k, lane);
-    const int excl = incl - k;
-    const int total = __shfl(incl, 63);
-    const int kmax = wave_max_i(k);
-    for (int j = 0; j < kmax; ++j)
-      if (j < k) {
-        const uint32_t p = sl[(size_t)c * L.cell_cap + j];
-        const uint32_t idx = (uint32_t)(N + excl + j);
-        bufs[0][idx] = ((uint64_t)idx << 32) | p;
-      }
-    N += total;
+// root strip of a record (Quadtree::initSplit children, strict membership) or -1
+__device__ __forceinline__ int strip_of(uint32_t rec, const LevelDev& L) {
+  const double x = (double)ORBFE_REC_X(rec), y = (double)ORBFE_REC_Y(rec);
+  int s = -1;
+  if (y > 0.0 && y < (double)L.reg_h) {
+    for (int k = 0; k < L.n_ini; ++k)
+      if (x > L.strips[k] && x < L.strips[k + 1]) s = k;
   }
-  if (lane == 0) n_cand[(size_t)img * n_levels + level] = N;
-  __syncthreads();
+  return s;
+}
 
-  int n_act = 0;
-  if (need <= 1) {
-    // while (mnNodes < mnNeedNodes ...) never runs: the map holds only the root (ORBExtractor.cc:151)
-    if (need == 1 && N > 0) {
-      // root->getFeature(): first maximum response over all candidates
-      int best_r = -1;
-      uint32_t best_i = 0xFFFFFFFFu;
-      uint64_t best_rec = 0;
-      for (int i = lane; i < N; i += 64) {
-        const uint64_t rec = bufs[0][i];
-        const int r = (int)ORBFE_REC_R((uint32_t)rec);
-        if (r > best_r) {
-          best_r = r;
-          best_i = (uint32_t)(rec >> 32);
-          best_rec = rec;
-        }
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const int r2 = __shfl_xor(best_r, o);
-        const uint32_t i2 = __shfl_xor(best_i, o);
-        const uint64_t rec2 = __shfl_xor(best_rec, o);
-        if (r2 > best_r || (r2 == best_r && i2 < best_i)) {
-          best_r = r2;
-          best_i = i2;
-          best_rec = rec2;
-        }
-      }
-      if (lane == 0) {
-        out_sel[0] = (uint32_t)best_rec;
-        sel_count[(size_t)img * n_levels + level] = 1;
-      }
-    } else if (lane == 0) {
-      sel_count[(size_t)img * n_levels + level] = 0;
-    }
-    return;
-  }
-
-  // ---- first pop: the root, whose children are the initSplit strips (ORBExtractor.cc:81-96, 147-170) ----
-  uint32_t next_seq = 0;
+// Everything after the strip counts: scatter into the strip segments, best-first expansion, selection, ordering.
+// IN_LDS selects the address space of the record home H at compile time (ds_* instead of flat_* accesses: a flat access
+// costs several hundred cycles even when it lands in LDS, and a pop is a chain of dependent accesses).
+template <bool IN_LDS>
+__device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __restrict__ A, int N, uint32_t* H, uint32_t* __restrict__ T,
+                                          double* n_rb, double* n_re, double* n_cb, double* n_ce, unsigned long long* n_key,
+                                          uint32_t* n_beg, unsigned long long* sortbuf, int run, int n_act, uint32_t next_seq, int need,
+                                          int sort_cap, uint32_t* __restrict__ out_sel, int32_t* __restrict__ sel_count_out, int lane) {
   {
-    int off = 0;
-    for (int s = 0; s < L.n_ini; ++s) {
-      const int c = filter_box(bufs[0], N, bufs[1] + off, 0.0, (double)L.reg_h, L.strips[s], L.strips[s + 1], lane);
-      if (c > 0) {
-        if (lane == 0) {
-          T.rb[n_act] = 0.0;
-          T.re[n_act] = (double)L.reg_h;
-          T.cb[n_act] = L.strips[s];
-          T.ce[n_act] = L.strips[s + 1];
-          T.cnt[n_act] = (uint32_t)c;
-          T.seq[n_act] = next_seq;
-          T.beg[n_act] = (uint32_t)off;
-          T.buf[n_act] = 1u;
+    for (int b0 = 0; b0 < N; b0 += 256) {
+      uint32_t rec[4];
+      int sid[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = b0 + u * 64 + lane;
+        rec[u] = (i < N) ? A[i] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = b0 + u * 64 + lane;
+        sid[u] = (i < N) ? strip_of(rec[u], L) : -1;
+      }
+      for (int s = 0; s < L.n_ini; ++s) {
+        int base = __builtin_amdgcn_readlane(run, s);
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned long long m = __ballot(sid[u] == s);
+          if (sid[u] == s) H[base + c + __popcll(m & ((1ull << lane) - 1ull))] = rec[u];
+          c += __popcll(m);
         }
-        ++n_act;
-        ++next_seq;
-        off += c;
+        if (lane == s) run += c;
       }
     }
   }
   __syncthreads();
 
   // ---- best-first expansion ----
+  // A lone wave pays tens of cycles for every taken branch (nothing hides the instruction fetch), so the step is
+  // written as straight-line predicated code: fixed 8-way unrolled arg-max, uniform-address LDS traffic executed by
+  // all lanes instead of "if (lane == 0)" blocks, the four children written by lanes 0..3 at once.
   const long long max_iter = 80ll * (long long)N + 1024;  // each point survives < ~64 halvings (fp64); hard stop for safety
   long long iter = 0;
   while (n_act < need && n_act > 0 && iter < max_iter) {
     ++iter;
-    // pop: arg-max of (count desc, seq asc)
-    unsigned long long best_key = 0ull;
-    int best_j = -1;
-    for (int j = lane; j < n_act; j += 64) {
-      const unsigned long long key = ((unsigned long long)T.cnt[j] << 32) | (unsigned long long)(0xFFFFFFFFu - T.seq[j]);
-      if (best_j < 0 || key > best_key) {
-        best_key = key;
-        best_j = j;
-      }
-    }
+    // pop: arg-max of (count desc, seq asc) = max of the 64-bit key
+    uint32_t bc = 0, bs = 0;
+    int bj = 0;
+    for (int j0 = 0; j0 < n_act; j0 += 512) {  // one trip unless the quota exceeds 512
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const unsigned long long k2 = __shfl_xor(best_key, o);
-      const int j2 = __shfl_xor(best_j, o);
-      if (j2 >= 0 && (best_j < 0 || k2 > best_key)) {
-        best_key = k2;
-        best_j = j2;
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + u * 64 + lane;
+        const unsigned long long key = (j < n_act) ? n_key[j] : 0ull;
+        const uint32_t kc = (uint32_t)(key >> 32), ks = (uint32_t)key;
+        const bool better = kc > bc || (kc == bc && ks > bs);
+        bc = better ? kc : bc;
+        bs = better ? ks : bs;
+        bj = better ? j : bj;
       }
     }
-    const int j = best_j;
-    const double rb = T.rb[j], re = T.re[j], cb = T.cb[j], ce = T.ce[j];
-    const int n = (int)T.cnt[j];
-    const int beg = (int)T.beg[j];
-    const int sb = (int)T.buf[j];
-    __syncthreads();
-    // erase from the active table (order inside the table is irrelevant, the key decides)
+    const uint32_t mc = wave_max_u32(bc);
+    const uint32_t ms = wave_max_u32(bc == mc ? bs : 0u);
+    const unsigned long long win = __ballot(bc == mc && bs == ms);
+    const int j = __builtin_amdgcn_readlane(bj, __ffsll((long long)win) - 1);
+    const double rb = n_rb[j], re = n_re[j], cb = n_cb[j], ce = n_ce[j];
+    const int n = (int)mc;
+    const int beg = (int)n_beg[j];
+    // erase from the active table: the last entry moves into slot j (uniform addresses, every lane does the same copy)
     --n_act;
-    if (lane == 0 && j != n_act) {
-      T.rb[j] = T.rb[n_act];
-      T.re[j] = T.re[n_act];
-      T.cb[j] = T.cb[n_act];
-      T.ce[j] = T.ce[n_act];
-      T.cnt[j] = T.cnt[n_act];
-      T.seq[j] = T.seq[n_act];
-      T.beg[j] = T.beg[n_act];
-      T.buf[j] = T.buf[n_act];
+    {
+      const double t0 = n_rb[n_act], t1 = n_re[n_act], t2 = n_cb[n_act], t3 = n_ce[n_act];
+      const unsigned long long t4 = n_key[n_act];
+      const uint32_t t5 = n_beg[n_act];
+      n_rb[j] = t0;
+      n_re[j] = t1;
+      n_cb[j] = t2;
+      n_ce[j] = t3;
+      n_key[j] = t4;
+      n_beg[j] = t5;
     }
-    // split (ORBExtractor.cc:60-72): rows outer, cols inner; child q = 2*row_half + col_half
     const double midy = (rb + re) / 2, midx = (cb + ce) / 2;
-    const uint64_t* src = bufs[sb] + beg;
-    uint64_t* dst = bufs[sb ^ 1] + beg;
-    int c4[4] = {0, 0, 0, 0};
+    uint32_t* seg = H + beg;
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     if (n <= 64) {
-      uint64_t rec = 0;
-      int q = -1;
-      if (lane < n) {
-        rec = src[lane];
-        const uint32_t p = (uint32_t)rec;
-        const double x = (double)ORBFE_REC_X(p), y = (double)ORBFE_REC_Y(p);
-        const int qx = (x < midx) ? 0 : ((x > midx) ? 1 : -1);
-        const int qy = (y < midy) ? 0 : ((y > midy) ? 1 : -1);
-        q = (qx >= 0 && qy >= 0) ? (qy * 2 + qx) : -1;
-      }
-      unsigned long long m[4];
+      // the common case: one record per lane, in-place 4-way partition
+      const uint32_t rec = (lane < n) ? seg[lane] : 0u;
+      const int q = (lane < n) ? quadrant_of(rec, midx, midy) : -1;
+      const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1), m2 = __ballot(q == 2), m3 = __ballot(q == 3);
+      c0 = __popcll(m0);
+      c1 = __popcll(m1);
+      c2 = __popcll(m2);
+      c3 = __popcll(m3);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const unsigned long long mq = q == 0 ? m0 : (q == 1 ? m1 : (q == 2 ? m2 : m3));
+      const int baseq = q == 0 ? 0 : (q == 1 ? c0 : (q == 2 ? c0 + c1 : c0 + c1 + c2));
+      if (q >= 0) seg[baseq + __popcll(mq & below)] = rec;
+    } else if (n <= 64 * QT_INPLACE_CHUNKS) {
+      // up to 512 records: in place through registers
+      uint32_t rec[QT_INPLACE_CHUNKS];
+      int q[QT_INPLACE_CHUNKS];
+      int c4[4] = {0, 0, 0, 0};
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        m[c] = __ballot(q == c);
-        c4[c] = __popcll(m[c]);
+      for (int c = 0; c < QT_INPLACE_CHUNKS; ++c) {
+        const int i = c * 64 + lane;
+        rec[c] = (i < n) ? seg[i] : 0u;
+        q[c] = (i < n) ? quadrant_of(rec[c], midx, midy) : -1;
       }
-      int base = 0;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (q == c) dst[base + __popcll(m[c] & ((1ull << lane) - 1ull))] = rec;
-        base += c4[c];
-      }
+      for (int c = 0; c < QT_INPLACE_CHUNKS; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c4[k] += __popcll(__ballot(q[c] == k));
+      if (!IN_LDS) __syncthreads();  // every record is in a register before the segment is overwritten
+      int run4[4] = {0, c4[0], c4[0] + c4[1], c4[0] + c4[1] + c4[2]};
+#pragma unroll
+      for (int c = 0; c < QT_INPLACE_CHUNKS; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned long long m = __ballot(q[c] == k);
+          if (q[c] == k) seg[run4[k] + __popcll(m & ((1ull << lane) - 1ull))] = rec[c];
+          run4[k] += __popcll(m);
+        }
+      c0 = c4[0];
+      c1 = c4[1];
+      c2 = c4[2];
+      c3 = c4[3];
     } else {
+      // big node: count, scatter to the bounce buffer, copy back
+      int c4[4] = {0, 0, 0, 0};
       for (int b0 = 0; b0 < n; b0 += 64) {
         const int i = b0 + lane;
-        int q = -1;
-        if (i < n) {
-          const uint32_t p = (uint32_t)src[i];
-          const double x = (double)ORBFE_REC_X(p), y = (double)ORBFE_REC_Y(p);
-          const int qx = (x < midx) ? 0 : ((x > midx) ? 1 : -1);
-          const int qy = (y < midy) ? 0 : ((y > midy) ? 1 : -1);
-          q = (qx >= 0 && qy >= 0) ? (qy * 2 + qx) : -1;
-        }
+        const int q = (i < n) ? quadrant_of(seg[i], midx, midy) : -1;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) c4[c] += __popcll(__ballot(q == c));
+        for (int k = 0; k < 4; ++k) c4[k] += __popcll(__ballot(q == k));
       }
-      int basec[4];
-      basec[0] = 0;
-      basec[1] = c4[0];
-      basec[2] = c4[0] + c4[1];
-      basec[3] = c4[0] + c4[1] + c4[2];
-      int run[4] = {0, 0, 0, 0};
+      int run4[4] = {0, c4[0], c4[0] + c4[1], c4[0] + c4[1] + c4[2]};
+      uint32_t* tmp = T + beg;
       for (int b0 = 0; b0 < n; b0 += 64) {
         const int i = b0 + lane;
+        uint32_t rec = 0;
         int q = -1;
-        uint64_t rec = 0;
         if (i < n) {
-          rec = src[i];
-          const uint32_t p = (uint32_t)rec;
-          const double x = (double)ORBFE_REC_X(p), y = (double)ORBFE_REC_Y(p);
-          const int qx = (x < midx) ? 0 : ((x > midx) ? 1 : -1);
-          const int qy = (y < midy) ? 0 : ((y > midy) ? 1 : -1);
-          q = (qx >= 0 && qy >= 0) ? (qy * 2 + qx) : -1;
+          rec = seg[i];
+          q = quadrant_of(rec, midx, midy);
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const unsigned long long m = __ballot(q == c);
-          if (q == c) dst[basec[c] + run[c] + __popcll(m & ((1ull << lane) - 1ull))] = rec;
-          run[c] += __popcll(m);
+        for (int k = 0; k < 4; ++k) {
+          const unsigned long long m = __ballot(q == k);
+          if (q == k) tmp[run4[k] + __popcll(m & ((1ull << lane) - 1ull))] = rec;
+          run4[k] += __popcll(m);
         }
       }
+      __syncthreads();
+      const int kept = c4[0] + c4[1] + c4[2] + c4[3];
+      for (int i = lane; i < kept; i += 64) seg[i] = tmp[i];
+      c0 = c4[0];
+      c1 = c4[1];
+      c2 = c4[2];
+      c3 = c4[3];
     }
-    // insert the non-empty children in order TL, TR, BL, BR (ORBExtractor.cc:161-170)
-    int off = beg;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (c4[c] > 0) {
-        if (lane == 0) {
-          T.rb[n_act] = (c & 2) ? midy : rb;
-          T.re[n_act] = (c & 2) ? re : midy;
-          T.cb[n_act] = (c & 1) ? midx : cb;
-          T.ce[n_act] = (c & 1) ? ce : midx;
-          T.cnt[n_act] = (uint32_t)c4[c];
-          T.seq[n_act] = next_seq;
-          T.beg[n_act] = (uint32_t)off;
-          T.buf[n_act] = (uint32_t)(sb ^ 1);
-        }
-        ++n_act;
-        ++next_seq;
+    // insert the non-empty children in order TL, TR, BL, BR (ORBExtractor.cc:161-170): lane c writes child c
+    {
+      const int cc = lane == 0 ? c0 : (lane == 1 ? c1 : (lane == 2 ? c2 : c3));
+      const int offc = beg + (lane == 0 ? 0 : (lane == 1 ? c0 : (lane == 2 ? c0 + c1 : c0 + c1 + c2)));
+      const int ne0 = c0 > 0, ne1 = c1 > 0, ne2 = c2 > 0, ne3 = c3 > 0;
+      const int rank = lane == 0 ? 0 : (lane == 1 ? ne0 : (lane == 2 ? ne0 + ne1 : ne0 + ne1 + ne2));
+      if (lane < 4 && cc > 0) {
+        const int slot = n_act + rank;
+        n_rb[slot] = (lane & 2) ? midy : rb;
+        n_re[slot] = (lane & 2) ? re : midy;
+        n_cb[slot] = (lane & 1) ? midx : cb;
+        n_ce[slot] = (lane & 1) ? ce : midx;
+        n_key[slot] = ((unsigned long long)cc << 32) | (unsigned long long)(0xFFFFFFFFu - (next_seq + (uint32_t)rank));
+        n_beg[slot] = (uint32_t)offc;
       }
-      off += c4[c];
+      const int added = ne0 + ne1 + ne2 + ne3;
+      n_act += added;
+      next_seq += (uint32_t)added;
     }
-    __syncthreads();
+    if (!IN_LDS) __syncthreads();  // LDS traffic of one wave is executed in order; global needs the wait
   }
+  __syncthreads();
 
   // ---- nodes2kpoints (ORBExtractor.cc:182-192): keep the first min(need, size) nodes in map order ----
   while (n_act > need) {
-    // drop the last node in map order = arg-min of (count, then latest insertion)
-    unsigned long long worst_key = ~0ull;
-    int worst_j = -1;
+    // drop the last node in map order = arg-min of the key
+    uint32_t bc = 0xFFFFFFFFu, bs = 0xFFFFFFFFu;
+    int bj = -1;
     for (int j = lane; j < n_act; j += 64) {
-      const unsigned long long key = ((unsigned long long)T.cnt[j] << 32) | (unsigned long long)(0xFFFFFFFFu - T.seq[j]);
-      if (worst_j < 0 || key < worst_key) {
-        worst_key = key;
-        worst_j = j;
+      const unsigned long long key = n_key[j];
+      const uint32_t kc = (uint32_t)(key >> 32), ks = (uint32_t)key;
+      if (bj < 0 || kc < bc || (kc == bc && ks < bs)) {
+        bc = kc;
+        bs = ks;
+        bj = j;
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const unsigned long long k2 = __shfl_xor(worst_key, o);
-      const int j2 = __shfl_xor(worst_j, o);
-      if (j2 >= 0 && (worst_j < 0 || k2 < worst_key)) {
-        worst_key = k2;
-        worst_j = j2;
-      }
-    }
+    const uint32_t mc = wave_min_u32(bj >= 0 ? bc : 0xFFFFFFFFu);
+    const uint32_t ms = wave_min_u32((bj >= 0 && bc == mc) ? bs : 0xFFFFFFFFu);
+    const unsigned long long win = __ballot(bj >= 0 && bc == mc && bs == ms);
+    const int j = __builtin_amdgcn_readlane(bj, __ffsll((long long)win) - 1);
     __syncthreads();
     --n_act;
-    if (lane == 0 && worst_j != n_act) {
-      const int j = worst_j;
-      T.cnt[j] = T.cnt[n_act];
-      T.seq[j] = T.seq[n_act];
-      T.beg[j] = T.beg[n_act];
-      T.buf[j] = T.buf[n_act];
+    if (lane == 0 && j != n_act) {
+      n_key[j] = n_key[n_act];
+      n_beg[j] = n_beg[n_act];
     }
     __syncthreads();
   }
 
-  // per node: first maximum response (ORBExtractor.cc:103-117); records are in candidate order inside a node
+  // per node: first maximum response (ORBExtractor.cc:103-117); records keep candidate order inside a node.
+  // Sort key = candidate order recomputed from the coordinates: (cell row, cell col, y, x), then the response.
   int sc = 2;
   while (sc < need) sc <<= 1;  // need <= sort_cap by construction (host side)
   sort_cap = min(sort_cap, sc);
+  // (the sort buffer aliases the fp64 bound arrays, which are dead now; keys / begins live behind them)
   for (int j = lane; j < sort_cap; j += 64) {
-    uint64_t best_rec = ~0ull;
+    unsigned long long key = ~0ull;
     if (j < n_act) {
-      const uint64_t* p = bufs[T.buf[j]] + T.beg[j];
-      const int n = (int)T.cnt[j];
-      int best_r = -1;
-      for (int i = 0; i < n; ++i) {
-        const uint64_t rec = p[i];
-        const int r = (int)ORBFE_REC_R((uint32_t)rec);
-        if (r > best_r) {
-          best_r = r;
-          best_rec = rec;
+      const uint32_t* p = H + n_beg[j];
+      const int n = (int)(n_key[j] >> 32);
+      uint32_t best = p[0];
+      unsigned long long bk = order_key(best, L);
+      for (int i = 1; i < n; ++i) {
+        const uint32_t rec = p[i];
+        const uint32_t r = ORBFE_REC_R(rec), rb2 = ORBFE_REC_R(best);
+        if (r >= rb2) {  // maximum response; the reference keeps the FIRST maximum in candidate order
+          const unsigned long long k = order_key(rec, L);
+          if (r > rb2 || k < bk) {
+            best = rec;
+            bk = k;
+          }
         }
       }
+      key = (bk << 8) | (unsigned long long)ORBFE_REC_R(best);
     }
-    sortbuf[j] = best_rec;
+    sortbuf[j] = key;
   }
   __syncthreads();
-  // bitonic sort ascending on the candidate index (high word) = std::set<size_t> iteration order
   for (int k = 2; k <= sort_cap; k <<= 1) {
     for (int s = k >> 1; s > 0; s >>= 1) {
       for (int i = lane; i < sort_cap; i += 64) {
         const int p = i ^ s;
         if (p > i) {
-          const uint64_t a = sortbuf[i], b = sortbuf[p];
+          const unsigned long long a = sortbuf[i], b = sortbuf[p];
           const bool up = (i & k) == 0;
           if ((a > b) == up) {
             sortbuf[i] = b;
@@ -380,22 +334,148 @@ __global__ __launch_bounds__(64) void k_quadtree(const LevelDev* __restrict__ lv
       __syncthreads();
     }
   }
-  for (int j = lane; j < n_act; j += 64) out_sel[j] = (uint32_t)sortbuf[j];
-  if (lane == 0) sel_count[(size_t)img * n_levels + level] = n_act;
+  for (int j = lane; j < n_act; j += 64) {
+    const unsigned long long key = sortbuf[j];
+    const uint32_t y = (uint32_t)(key >> 20) & 0xFFFu, x = (uint32_t)(key >> 8) & 0xFFFu, r = (uint32_t)key & 0xFFu;  // key = order<<8 | r
+    out_sel[j] = ORBFE_PACK_XYR(x, y, r);
+  }
+  if (lane == 0) *sel_count_out = n_act;
 }
 
-size_t quadtree_lds_bytes(int node_cap, int sort_cap) {
-  return (size_t)node_cap * (4 * sizeof(double) + 4 * sizeof(uint32_t)) + (size_t)sort_cap * sizeof(uint64_t);
+
+__global__ __launch_bounds__(64) void k_quadtree(const LevelDev* __restrict__ lv, int n_levels, const uint32_t* __restrict__ cand,
+                                                 uint32_t* __restrict__ scratch_b, uint32_t* __restrict__ scratch_c,
+                                                 size_t scratch_pitch,
+                                                 uint32_t* __restrict__ sel, int32_t* __restrict__ sel_count, int n_features,
+                                                 const int32_t* __restrict__ n_cand, int node_cap, int sort_cap, int rec_cap) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int level = blockIdx.x, img = blockIdx.y;
+  const LevelDev& L = lv[level];
+  // LDS carve-up: 4 fp64 bound arrays | u64 keys | u32 begins | records.  The sort buffer aliases the bounds.
+  double* n_rb = lds;
+  double* n_re = n_rb + node_cap;
+  double* n_cb = n_re + node_cap;
+  double* n_ce = n_cb + node_cap;
+  unsigned long long* n_key = (unsigned long long*)(n_ce + node_cap);
+  uint32_t* n_beg = (uint32_t*)(n_key + node_cap);
+  uint32_t* lds_recs = n_beg + node_cap;
+  unsigned long long* sortbuf = (unsigned long long*)lds;
+
+  uint32_t* out_sel = sel + (size_t)img * n_features + L.quota_off;
+  const int need = L.quota;
+  // the level's candidate SET, appended by k_fast in arbitrary order
+  const uint32_t* A = cand + (size_t)img * scratch_pitch + L.cand_base;
+  const int N = min(n_cand[(size_t)img * n_levels + level], (int)L.cand_cap);
+  const bool in_lds = N <= rec_cap;
+  uint32_t* gb = scratch_b + (size_t)img * scratch_pitch + L.cand_base;
+  uint32_t* gc = scratch_c + (size_t)img * scratch_pitch + L.cand_base;
+  uint32_t* H = in_lds ? lds_recs : gb;  // home of the records
+  uint32_t* T = in_lds ? gb : gc;        // bounce buffer for the few nodes too big to split in registers
+
+  int n_act = 0;
+  int strip_run = 0;
+  if (need <= 1) {
+    // while (mnNodes < mnNeedNodes ...) never runs: the map holds only the root (ORBExtractor.cc:151)
+    if (need == 1 && N > 0) {
+      // root->getFeature(): maximum response, first in candidate order on ties
+      uint32_t br = 0;
+      unsigned long long bk = ~0ull;
+      uint32_t brec = 0;
+      for (int i = lane; i < N; i += 64) {
+        const uint32_t rec = A[i];
+        const uint32_t r = ORBFE_REC_R(rec);
+        const unsigned long long k = order_key(rec, L);
+        if (r > br || (r == br && k < bk)) {
+          br = r;
+          bk = k;
+          brec = rec;
+        }
+      }
+      const uint32_t mr = wave_max_u32(br);
+      const uint32_t khi = wave_min_u32(br == mr ? (uint32_t)(bk >> 24) : 0xFFFFFFFFu);
+      const uint32_t klo = wave_min_u32((br == mr && (uint32_t)(bk >> 24) == khi) ? (uint32_t)(bk & 0xFFFFFFu) : 0xFFFFFFFFu);
+      const unsigned long long win = __ballot(br == mr && (uint32_t)(bk >> 24) == khi && (uint32_t)(bk & 0xFFFFFFu) == klo);
+      const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)brec, __ffsll((long long)win) - 1);
+      if (lane == 0) {
+        out_sel[0] = rec;
+        sel_count[(size_t)img * n_levels + level] = 1;
+      }
+    } else if (lane == 0) {
+      sel_count[(size_t)img * n_levels + level] = 0;
+    }
+    return;
+  }
+
+  // ---- first pop: the root, whose children are the initSplit strips (ORBExtractor.cc:81-96, 147-170) ----
+  // Pass 1 counts the records of each strip (lane s keeps strip s's counter), pass 2 scatters them into the
+  // strip segments of H.  Four records per lane are in flight per step to hide the global-load latency.
+  uint32_t next_seq = 0;
+  {
+    int my_cnt = 0;
+    for (int b0 = 0; b0 < N; b0 += 256) {
+      uint32_t rec[4];
+      int sid[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = b0 + u * 64 + lane;
+        rec[u] = (i < N) ? A[i] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = b0 + u * 64 + lane;
+        sid[u] = (i < N) ? strip_of(rec[u], L) : -1;
+      }
+      for (int s = 0; s < L.n_ini; ++s) {
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c += __popcll(__ballot(sid[u] == s));
+        if (lane == s) my_cnt += c;
+      }
+    }
+    const int incl = wave_incl_scan(my_cnt, lane);  // lanes >= n_ini hold 0
+    const int run = incl - my_cnt;                   // lane s: write cursor of strip s
+    for (int s = 0; s < L.n_ini; ++s) {
+      const int c = __builtin_amdgcn_readlane(my_cnt, s);
+      const int off = __builtin_amdgcn_readlane(run, s);
+      if (c > 0) {
+        if (lane == 0) {
+          n_rb[n_act] = 0.0;
+          n_re[n_act] = (double)L.reg_h;
+          n_cb[n_act] = L.strips[s];
+          n_ce[n_act] = L.strips[s + 1];
+          n_key[n_act] = ((unsigned long long)c << 32) | (unsigned long long)(0xFFFFFFFFu - next_seq);
+          n_beg[n_act] = (uint32_t)off;
+        }
+        ++n_act;
+        ++next_seq;
+      }
+    }
+    strip_run = run;
+  }
+  if (in_lds)
+    tree_body<true>(L, A, N, lds_recs, gb, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, strip_run, n_act, next_seq, need, sort_cap, out_sel,
+                    sel_count + (size_t)img * n_levels + level, lane);
+  else
+    tree_body<false>(L, A, N, gb, gc, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, strip_run, n_act, next_seq, need, sort_cap, out_sel,
+                     sel_count + (size_t)img * n_levels + level, lane);
 }
 
-void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint16_t* d_counts, int n_cells_total,
-                     const uint32_t* d_slots, size_t slots_pitch, uint64_t* d_scr_a, uint64_t* d_scr_b, size_t scratch_pitch,
-                     uint32_t* d_sel, int32_t* d_sel_count, int n_features, int32_t* d_n_cand, int node_cap, int sort_cap,
-                     int n_img) {
+size_t quadtree_lds_bytes(int node_cap, int rec_cap) {
+  return (size_t)node_cap * (4 * sizeof(double) + sizeof(unsigned long long) + sizeof(uint32_t)) + (size_t)rec_cap * sizeof(uint32_t);
+}
+
+hipError_t quadtree_configure(size_t lds_bytes) {
+  return hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+
+void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint32_t* d_cand, uint32_t* d_scr_b, uint32_t* d_scr_c,
+                     size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
+                     int rec_cap, int n_img) {
   if (n_img <= 0) return;
-  const size_t lds = quadtree_lds_bytes(node_cap, sort_cap);
-  hipLaunchKernelGGL(k_quadtree, dim3(n_levels, n_img), dim3(64), lds, s, d_lv, n_levels, d_counts, n_cells_total, d_slots,
-                     slots_pitch, d_scr_a, d_scr_b, scratch_pitch, d_sel, d_sel_count, n_features, d_n_cand, node_cap, sort_cap);
+  const size_t lds = quadtree_lds_bytes(node_cap, rec_cap);
+  hipLaunchKernelGGL(k_quadtree, dim3(n_levels, n_img), dim3(64), lds, s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
+                     d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap);
 }
 
 }  // namespace orbfe

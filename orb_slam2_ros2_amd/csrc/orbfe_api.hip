@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -23,19 +24,19 @@ void launch_load_level0(hipStream_t st, const uint8_t* d_src, size_t src_stride,
                         uint32_t plane_off, int dst_stride, int w, int h, int slot0, int slot_step, int n_img);
 // k_fast.hip
 void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, int n_cells_total, const uint8_t* d_pyr,
-                 size_t img_pitch, int t_hi, int t_lo, uint32_t* d_slots, size_t slots_pitch, uint16_t* d_counts, int n_img,
-                 int max_pw, int max_ph);
+                 size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch, int32_t* d_n_cand, int n_levels,
+                 int n_img, int max_pw, int max_ph);
 // k_quadtree.hip
-size_t quadtree_lds_bytes(int node_cap, int sort_cap);
-void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint16_t* d_counts, int n_cells_total,
-                     const uint32_t* d_slots, size_t slots_pitch, uint64_t* d_scr_a, uint64_t* d_scr_b, size_t scratch_pitch,
-                     uint32_t* d_sel, int32_t* d_sel_count, int n_features, int32_t* d_n_cand, int node_cap, int sort_cap,
-                     int n_img);
+size_t quadtree_lds_bytes(int node_cap, int rec_cap);
+hipError_t quadtree_configure(size_t lds_bytes);
+void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint32_t* d_cand, uint32_t* d_scr_b, uint32_t* d_scr_c,
+                     size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
+                     int rec_cap, int n_img);
 // k_brief.hip
 void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
-                         int32_t* d_n_kp, double* d_theta, int rows0, int n_img);
+                         int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, int rows0, int n_img);
 // k_match.hip
 void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, const uint32_t* d_off,
                              const uint32_t* d_cand, int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second);
@@ -66,6 +67,11 @@ struct orbfe_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // side streams for the chunked batch path
+  static const int kMaxSide = 4;
+  int n_side = 0;
+  hipStream_t side[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
 
   // geometry (host copies)
   std::vector<LevelDev> lv;
@@ -75,8 +81,8 @@ struct orbfe_ctx {
   int blur_taps[7];
   int n_cells_total = 0, rs_tiles = 0, bl_tiles = 0;
   size_t img_pitch = 0;      // bytes per image in pyr / blur
-  size_t slots_pitch = 0;    // uint32 per image
-  size_t scratch_pitch = 0;  // uint64 per image
+  size_t scratch_pitch = 0;  // uint32 records per image
+  int rec_cap = 0;           // candidate records one quadtree wave keeps in LDS
   int node_cap = 0, sort_cap = 0;
   int max_pw = 0, max_ph = 0;  // largest FAST cell patch (sizes the LDS of k_fast)
 
@@ -86,15 +92,15 @@ struct orbfe_ctx {
   ResizeTap* d_taps = nullptr;
   int8_t* d_pattern = nullptr;
   uint8_t *d_pyr = nullptr, *d_blur = nullptr;
-  uint32_t* d_slots = nullptr;
-  uint16_t* d_counts = nullptr;
-  uint64_t *d_scr_a = nullptr, *d_scr_b = nullptr;
+  uint32_t *d_scr_a = nullptr, *d_scr_b = nullptr, *d_scr_c = nullptr;  // candidate lists | quadtree home / bounce buffers
   uint32_t* d_sel = nullptr;
   int32_t *d_sel_count = nullptr, *d_n_cand = nullptr, *d_n_kp = nullptr;
   orbfe_keypoint* d_kps = nullptr;
   uint8_t* d_desc = nullptr;
   KpAux* d_aux = nullptr;
   double* d_theta = nullptr;
+  int2* d_moments = nullptr;     // per keypoint (m10, m01)
+  double2* d_sincos = nullptr;   // per keypoint (sin, cos) of the orientation
   double *d_right_u = nullptr, *d_depth = nullptr;
   int32_t *d_n_match = nullptr, *d_best_right = nullptr, *d_best_dist = nullptr;
   // generic staging for match / BA calls
@@ -180,7 +186,7 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
     quota[nl - 1] = std::max(0, cfg.n_features - sum);
   }
   size_t plane_off = 0;
-  uint32_t slot_base = 0, cand_base = 0;
+  uint32_t cand_base = 0;
   int cell_base = 0, quota_off = 0, rs_tiles = 0, bl_tiles = 0, max_quota = 0, max_ini = 4;
   c->cells.clear();
   c->taps.clear();
@@ -207,12 +213,13 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
       return fail(c, ORBFE_EBADSIZE, "level %d region %dx%d is smaller than one 30-px FAST cell", l, L.reg_w, L.reg_h);
     L.w_cell = L.reg_w / L.n_cols;  // ceil() of an integer division is a no-op (quirk Q2)
     L.h_cell = L.reg_h / L.n_rows;
+    L.inv_w_cell = ((1u << 20) + L.w_cell - 1) / L.w_cell;
+    L.inv_h_cell = ((1u << 20) + L.h_cell - 1) / L.h_cell;
     if (L.w_cell + 6 > ORBFE_MAX_CELL || L.h_cell + 6 > ORBFE_MAX_CELL)
       return fail(c, ORBFE_EBADSIZE, "level %d cell %dx%d exceeds the LDS tile bound", l, L.w_cell, L.h_cell);
     if (L.reg_w > 4095 || L.reg_h > 4095) return fail(c, ORBFE_EBADSIZE, "level %d region exceeds 4095 px", l);
     L.cell_base = cell_base;
     L.cell_cap = ((L.w_cell + 1) / 2) * ((L.h_cell + 1) / 2);
-    L.slot_base = slot_base;
     const int max_bx = L.w - ORBFE_EDGE, max_by = L.h - ORBFE_EDGE;
     int n_cells = 0;
     for (int idx = 0; idx < L.n_rows; ++idx) {
@@ -232,7 +239,6 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
         cd.offx = (int16_t)(jdx * L.w_cell);
         cd.offy = (int16_t)(idx * L.h_cell);
         cd.pad = 0;
-        cd.slot_off = slot_base + (uint32_t)n_cells * (uint32_t)L.cell_cap;
         c->cells.push_back(cd);
         c->max_pw = std::max(c->max_pw, (int)cd.pw);
         c->max_ph = std::max(c->max_ph, (int)cd.ph);
@@ -242,7 +248,6 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
     L.n_cells = n_cells;
     cell_base += n_cells;
     L.cand_cap = (uint32_t)n_cells * (uint32_t)L.cell_cap;
-    slot_base += L.cand_cap;
     L.cand_base = cand_base;
     cand_base += (uint32_t)align_up(L.cand_cap, 32);
     // root strips (Quadtree::initSplit)
@@ -299,14 +304,19 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
   c->rs_tiles = rs_tiles;
   c->bl_tiles = bl_tiles;
   c->img_pitch = align_up(plane_off, 4096);
-  c->slots_pitch = align_up(slot_base, 64);
   c->scratch_pitch = align_up(cand_base, 64);
   c->node_cap = max_quota + max_ini + 8;
   int sc = 2;
   while (sc < max_quota) sc <<= 1;
   c->sort_cap = sc;
-  if (quadtree_lds_bytes(c->node_cap, c->sort_cap) > 150 * 1024)
+  if (quadtree_lds_bytes(c->node_cap, 0) > 120 * 1024)
     return fail(c, ORBFE_EBADARG, "per-level quota %d needs more LDS than one CU has", max_quota);
+  {
+    uint32_t max_cand = 0;
+    for (int l = 0; l < nl; ++l) max_cand = std::max(max_cand, c->lv[l].cand_cap);
+    const size_t budget = 150 * 1024 - quadtree_lds_bytes(c->node_cap, 0);
+    c->rec_cap = (int)std::min<size_t>(std::min<size_t>(max_cand, 8192), budget / 4);
+  }
   // umax (ORBExtractor::initMaxU)
   {
     const int R = ORBFE_CENTROID_R;
@@ -355,7 +365,8 @@ struct StageTimer {
   orbfe_ctx* c;
   int stage;
   hipEvent_t a = nullptr, b = nullptr;
-  StageTimer(orbfe_ctx* ctx, int st) : c(ctx), stage(st) {
+  hipStream_t stream;
+  StageTimer(orbfe_ctx* ctx, int st, hipStream_t s) : c(ctx), stage(st), stream(s) {
     if (!c->prof) return;
     auto get = [&]() {
       hipEvent_t e = nullptr;
@@ -368,11 +379,11 @@ struct StageTimer {
     };
     a = get();
     b = get();
-    if (a) hipEventRecord(a, c->stream);
+    if (a) (void)hipEventRecord(a, stream);
   }
   ~StageTimer() {
     if (!c->prof || !a || !b) return;
-    hipEventRecord(b, c->stream);
+    (void)hipEventRecord(b, stream);
     c->pending.push_back({stage, {a, b}});
   }
 };
@@ -391,40 +402,50 @@ static void drain_timers(orbfe_ctx* c) {
 }
 
 // ---- the launch sequence for slots [0, n_img) ---------------------------------------------------------
-static orbfe_status run_extract(orbfe_ctx* c, int n_img) {
+// Slots [img0, img0 + n_img) on stream `st`.  Every per-image array is offset on the host, so the kernels index from 0.
+static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img) {
   const int nl = c->cfg.n_levels;
+  const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
+  const size_t i0 = (size_t)img0;
+  uint8_t* pyr = c->d_pyr + i0 * c->img_pitch;
+  uint8_t* blur = c->d_blur + i0 * c->img_pitch;
+  int32_t* n_cand = c->d_n_cand + i0 * nl;
   {
-    StageTimer t(c, ORBFE_STAGE_RESIZE);
-    launch_resize(c->stream, c->d_lv, nl, c->rs_tiles, c->d_taps, c->d_pyr, c->img_pitch, n_img);
+    StageTimer t(c, ORBFE_STAGE_RESIZE, st);
+    launch_resize(st, c->d_lv, nl, c->rs_tiles, c->d_taps, pyr, c->img_pitch, n_img);
   }
   {
-    StageTimer t(c, ORBFE_STAGE_BLUR);
-    launch_blur(c->stream, c->d_lv, nl, c->bl_tiles, c->d_pyr, c->d_blur, c->img_pitch, c->blur_taps, n_img);
+    StageTimer t(c, ORBFE_STAGE_BLUR, st);
+    launch_blur(st, c->d_lv, nl, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
+  }
+  HIP_TRY(c, hipMemsetAsync(n_cand, 0, sizeof(int32_t) * (size_t)n_img * nl, st));
+  {
+    StageTimer t(c, ORBFE_STAGE_FAST, st);
+    launch_fast(st, c->d_lv, c->d_cells, c->n_cells_total, pyr, c->img_pitch, c->cfg.fast_hi, c->cfg.fast_lo,
+                c->d_scr_a + i0 * c->scratch_pitch, c->scratch_pitch, n_cand, nl, n_img, c->max_pw, c->max_ph);
   }
   {
-    StageTimer t(c, ORBFE_STAGE_FAST);
-    launch_fast(c->stream, c->d_lv, c->d_cells, c->n_cells_total, c->d_pyr, c->img_pitch, c->cfg.fast_hi, c->cfg.fast_lo,
-                c->d_slots, c->slots_pitch, c->d_counts, n_img, c->max_pw, c->max_ph);
+    StageTimer t(c, ORBFE_STAGE_QUADTREE, st);
+    launch_quadtree(st, c->d_lv, nl, c->d_scr_a + i0 * c->scratch_pitch, c->d_scr_b + i0 * c->scratch_pitch,
+                    c->d_scr_c + i0 * c->scratch_pitch, c->scratch_pitch, c->d_sel + i0 * NF, c->d_sel_count + i0 * nl,
+                    c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, c->rec_cap, n_img);
   }
   {
-    StageTimer t(c, ORBFE_STAGE_QUADTREE);
-    launch_quadtree(c->stream, c->d_lv, nl, c->d_counts, c->n_cells_total, c->d_slots, c->slots_pitch, c->d_scr_a, c->d_scr_b,
-                    c->scratch_pitch, c->d_sel, c->d_sel_count, c->cfg.n_features, c->d_n_cand, c->node_cap, c->sort_cap, n_img);
-  }
-  {
-    StageTimer t(c, ORBFE_STAGE_BRIEF);
-    launch_orient_brief(c->stream, c->d_lv, nl, c->d_pyr, c->d_blur, c->img_pitch, c->d_sel, c->d_sel_count, c->cfg.n_features,
-                        c->d_pattern, c->umax, c->d_kps, c->d_desc, c->d_aux, c->d_n_kp, c->d_theta, c->cfg.height, n_img);
+    StageTimer t(c, ORBFE_STAGE_BRIEF, st);
+    launch_orient_brief(st, c->d_lv, nl, pyr, blur, c->img_pitch, c->d_sel + i0 * NF, c->d_sel_count + i0 * nl, c->cfg.n_features,
+                        c->d_pattern, c->umax, c->d_kps + i0 * NF, c->d_desc + i0 * NF * 32, c->d_aux + i0 * NF, c->d_n_kp + i0,
+                        c->d_theta + i0 * NF, c->d_moments + i0 * NF, c->d_sincos + i0 * NF, c->cfg.height, n_img);
   }
   HIP_TRY(c, hipGetLastError());
   return ORBFE_OK;
 }
 
-static orbfe_status run_stereo(orbfe_ctx* c, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs, float fx, float bf) {
-  HIP_TRY(c, hipMemsetAsync(c->d_n_match + pair0, 0, sizeof(int32_t) * n_pairs, c->stream));
+static orbfe_status run_stereo(orbfe_ctx* c, hipStream_t st, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs, float fx,
+                               float bf) {
+  HIP_TRY(c, hipMemsetAsync(c->d_n_match + pair0, 0, sizeof(int32_t) * n_pairs, st));
   {
-    StageTimer t(c, ORBFE_STAGE_STEREO);
-    launch_stereo(c->stream, c->d_lv, c->d_pyr, c->img_pitch, c->d_kps, c->d_desc, c->d_aux, c->d_n_kp, c->cfg.n_features, fx, bf,
+    StageTimer t(c, ORBFE_STAGE_STEREO, st);
+    launch_stereo(st, c->d_lv, c->d_pyr, c->img_pitch, c->d_kps, c->d_desc, c->d_aux, c->d_n_kp, c->cfg.n_features, fx, bf,
                   c->cfg.width, kMeanThreshold, c->d_right_u, c->d_depth, c->d_n_match, c->d_best_right, c->d_best_dist, slot_l0,
                   slot_r0, slot_step, pair0, n_pairs);
   }
@@ -450,14 +471,19 @@ void orbfe_destroy(orbfe_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   drain_timers(c);
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
-  void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_pattern, c->d_pyr,     c->d_blur,  c->d_slots,
-                  c->d_counts, c->d_scr_a,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_kp,
-                  c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta,   c->d_right_u, c->d_depth, c->d_n_match,
+  void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_pattern, c->d_pyr,     c->d_blur,
+                  c->d_scr_a, c->d_scr_c,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_kp,
+                  c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos,   c->d_right_u, c->d_depth, c->d_n_match,
                   c->d_best_right, c->d_best_dist, c->d_tmp};
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (c->h_counts) hipHostFree(c->h_counts);
-  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  for (int k = 0; k < orbfe_ctx::kMaxSide; ++k) {
+    if (c->side[k]) (void)hipStreamDestroy(c->side[k]);
+    if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
+  }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -499,6 +525,21 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     }
     c->own_stream = true;
   }
+  {
+    const char* env = getenv("ORBFE_STREAMS");
+    int want = env ? atoi(env) : orbfe_ctx::kMaxSide;
+    want = std::min(std::max(want, 1), (int)orbfe_ctx::kMaxSide);
+    bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < want && ok; ++k) {
+      ok = hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) == hipSuccess;
+      if (ok) c->n_side = k + 1;
+    }
+    if (!ok) {
+      fail(c, ORBFE_EDEVICE, "cannot create side streams");
+      return bail(ORBFE_EDEVICE);
+    }
+  }
   const size_t M = (size_t)cfg->max_images, NF = (size_t)std::max(cfg->n_features, 1), NL = (size_t)cfg->n_levels;
   const size_t NP = (M + 1) / 2;
 #define ALLOC(ptr, count)                          \
@@ -512,10 +553,9 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   ALLOC(c->d_pattern, 1024);
   ALLOC(c->d_pyr, M * c->img_pitch);
   ALLOC(c->d_blur, M * c->img_pitch);
-  ALLOC(c->d_slots, M * c->slots_pitch);
-  ALLOC(c->d_counts, M * (size_t)c->n_cells_total);
   ALLOC(c->d_scr_a, M * c->scratch_pitch);
   ALLOC(c->d_scr_b, M * c->scratch_pitch);
+  ALLOC(c->d_scr_c, M * c->scratch_pitch);
   ALLOC(c->d_sel, M * NF);
   ALLOC(c->d_sel_count, M * NL);
   ALLOC(c->d_n_cand, M * NL);
@@ -524,6 +564,8 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   ALLOC(c->d_desc, M * NF * 32);
   ALLOC(c->d_aux, M * NF);
   ALLOC(c->d_theta, M * NF);
+  ALLOC(c->d_moments, M * NF);
+  ALLOC(c->d_sincos, M * NF);
   ALLOC(c->d_right_u, NP * NF);
   ALLOC(c->d_depth, NP * NF);
   ALLOC(c->d_n_match, NP);
@@ -532,6 +574,13 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
 #undef ALLOC
   hipError_t e = hipSuccess;
   const int8_t* pat = cfg->brief_pairs ? cfg->brief_pairs : &kEmbeddedPattern[0][0];
+  for (int i = 0; i < 512; ++i) {
+    const int px = pat[2 * i], py = pat[2 * i + 1];
+    if (px * px + py * py > 338) {  // 13^2 + 13^2: the rotated point must stay within 18 px (image border 19, LDS window of k_brief)
+      fail(c, ORBFE_EBADARG, "BRIEF template point (%d,%d) is farther than sqrt(338) px from the centre", px, py);
+      return bail(ORBFE_EBADARG);
+    }
+  }
   c->cfg.brief_pairs = nullptr;  // not retained
   if (e == hipSuccess) e = hipMemcpy(c->d_lv, c->lv.data(), sizeof(LevelDev) * NL, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(c->d_cells, c->cells.data(), sizeof(CellDev) * c->cells.size(), hipMemcpyHostToDevice);
@@ -546,6 +595,12 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
     fail(c, ORBFE_EDEVICE, "device initialisation failed: %s", hipGetErrorString(e));
+    return bail(ORBFE_EDEVICE);
+  }
+  e = quadtree_configure(quadtree_lds_bytes(c->node_cap, c->rec_cap));
+  if (e != hipSuccess) {
+    fail(c, ORBFE_EDEVICE, "cannot reserve %zu B of LDS for the quadtree kernel: %s", quadtree_lds_bytes(c->node_cap, c->rec_cap),
+         hipGetErrorString(e));
     return bail(ORBFE_EDEVICE);
   }
   *out = c;
@@ -638,7 +693,7 @@ orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* con
     HIP_TRY(c, hipMemcpy2DAsync(c->d_pyr + (size_t)i * c->img_pitch + L0.plane_off, L0.stride, imgs[i], stride, c->cfg.width,
                                 c->cfg.height, hipMemcpyHostToDevice, c->stream));
   }
-  TRY(run_extract(c, n_img));
+  TRY(run_extract(c, c->stream, 0, n_img));
   const size_t NF = (size_t)c->cfg.n_features;
   for (int i = 0; i < n_img; ++i) {
     int32_t n = 0;
@@ -670,7 +725,7 @@ orbfe_status orbfe_stereo_match(orbfe_ctx* c, int32_t slot_left, int32_t slot_ri
     return fail(c, ORBFE_EBADARG, "stereo_match: slots %d/%d", slot_left, slot_right);
   HIP_TRY(c, hipSetDevice(c->device));
   const int pair = slot_left / 2;
-  TRY(run_stereo(c, slot_left, slot_right, 0, pair, 1, fx, bf));
+  TRY(run_stereo(c, c->stream, slot_left, slot_right, 0, pair, 1, fx, bf));
   return orbfe_fetch_stereo(c, pair, right_u, depth, n_matches, best_right, best_dist);
 }
 
@@ -683,13 +738,28 @@ orbfe_status orbfe_stereo_batch_device(orbfe_ctx* c, const uint8_t* d_left, cons
   if (n_pairs == 0) return ORBFE_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   const LevelDev& L0 = c->lv[0];
-  // level 0 of slot 2p / 2p+1 <- left / right image p
-  launch_load_level0(c->stream, d_left, stride, image_pitch, c->d_pyr, c->img_pitch, L0.plane_off, L0.stride, c->cfg.width,
-                     c->cfg.height, 0, 2, n_pairs);
-  launch_load_level0(c->stream, d_right, stride, image_pitch, c->d_pyr, c->img_pitch, L0.plane_off, L0.stride, c->cfg.width,
-                     c->cfg.height, 1, 2, n_pairs);
-  TRY(run_extract(c, 2 * n_pairs));
-  TRY(run_stereo(c, 0, 1, 2, 0, n_pairs, fx, bf));
+  // The batch is cut into chunks that run on separate streams: the quadtree is latency-bound (one wave per
+  // image level, a few hundred dependent steps) and leaves the machine almost idle, so the streaming kernels of the
+  // other chunks fill it.  With stage timing enabled the batch runs unsplit so that each kernel is timed alone.
+  const int n_chunks = c->prof ? 1 : std::min<int>(c->n_side, std::max(1, n_pairs / 8));
+  HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+  for (int k = 0; k < n_chunks; ++k) {
+    const int p0 = (int)((long long)n_pairs * k / n_chunks), p1 = (int)((long long)n_pairs * (k + 1) / n_chunks);
+    if (p1 <= p0) continue;
+    hipStream_t st = n_chunks == 1 ? c->stream : c->side[k];
+    if (n_chunks > 1) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_fork, 0));
+    // level 0 of slot 2p / 2p+1 <- left / right image p
+    launch_load_level0(st, d_left + (size_t)p0 * image_pitch, stride, image_pitch, c->d_pyr, c->img_pitch, L0.plane_off, L0.stride,
+                       c->cfg.width, c->cfg.height, 2 * p0, 2, p1 - p0);
+    launch_load_level0(st, d_right + (size_t)p0 * image_pitch, stride, image_pitch, c->d_pyr, c->img_pitch, L0.plane_off, L0.stride,
+                       c->cfg.width, c->cfg.height, 2 * p0 + 1, 2, p1 - p0);
+    TRY(run_extract(c, st, 2 * p0, 2 * (p1 - p0)));
+    TRY(run_stereo(c, st, 2 * p0, 2 * p0 + 1, 2, p0, p1 - p0, fx, bf));
+    if (n_chunks > 1) {
+      HIP_TRY(c, hipEventRecord(c->ev_join[k], st));
+      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join[k], 0));
+    }
+  }
   return ORBFE_OK;
 }
 
@@ -716,7 +786,7 @@ orbfe_status orbfe_match_bruteforce(orbfe_ctx* c, const uint8_t* q, int32_t nq, 
     if (n_cand) HIP_TRY(c, hipMemcpyAsync(base + o_cand, cand_idx, n_cand * 4, hipMemcpyHostToDevice, c->stream));
   }
   {
-    StageTimer tm(c, ORBFE_STAGE_MATCH);
+    StageTimer tm(c, ORBFE_STAGE_MATCH, c->stream);
     launch_match_bruteforce(c->stream, base + o_q, nq, base + o_t, nt, cand_offsets ? (const uint32_t*)(base + o_off) : nullptr,
                             (const uint32_t*)(base + o_cand), (int32_t*)(base + o_bi), (int32_t*)(base + o_bd), (int32_t*)(base + o_sd));
   }
@@ -763,7 +833,7 @@ orbfe_status orbfe_ba_eval_edges(orbfe_ctx* c, const orbfe_ba_problem* p, const 
   HIP_TRY(c, hipMemcpyAsync(b + o_delta, p->huber_delta, (size_t)E * 8, hipMemcpyHostToDevice, c->stream));
   BaParamsDev prm = {p->fx, p->fy, p->cx, p->cy, p->bf};
   {
-    StageTimer tm(c, ORBFE_STAGE_BA);
+    StageTimer tm(c, ORBFE_STAGE_BA, c->stream);
     launch_ba_edges(c->stream, E, (const double*)(b + o_pose), (const double*)(b + o_pt), (const int32_t*)(b + o_ep),
                     (const int32_t*)(b + o_et), (const double*)(b + o_meas), b + o_st, (const double*)(b + o_info),
                     (const double*)(b + o_delta), prm, (double*)(b + o_err), (double*)(b + o_chi), (double*)(b + o_rho),
@@ -812,24 +882,26 @@ orbfe_status orbfe_debug_candidates(orbfe_ctx* c, int32_t slot, int32_t level, f
     return fail(c, ORBFE_EBADARG, "debug_candidates: bad argument");
   HIP_TRY(c, hipSetDevice(c->device));
   const LevelDev& L = c->lv[level];
-  std::vector<uint16_t> cnt(L.n_cells);
-  std::vector<uint32_t> sl(L.cand_cap);
-  HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->d_counts + (size_t)slot * c->n_cells_total + L.cell_base, sizeof(uint16_t) * L.n_cells,
-                            hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(sl.data(), c->d_slots + (size_t)slot * c->slots_pitch + L.slot_base, sizeof(uint32_t) * L.cand_cap,
-                            hipMemcpyDeviceToHost, c->stream));
+  int32_t n = 0;
+  HIP_TRY(c, hipMemcpyAsync(&n, c->d_n_cand + (size_t)slot * c->cfg.n_levels + level, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  int n = 0;
-  for (int ci = 0; ci < L.n_cells; ++ci)
-    for (int j = 0; j < cnt[ci]; ++j) {
-      const uint32_t p = sl[(size_t)ci * L.cell_cap + j];
-      if (xyr && n < cap) {
-        xyr[3 * n] = (float)ORBFE_REC_X(p);
-        xyr[3 * n + 1] = (float)ORBFE_REC_Y(p);
-        xyr[3 * n + 2] = (float)ORBFE_REC_R(p);
-      }
-      ++n;
-    }
+  n = std::min<int32_t>(std::max(n, 0), (int32_t)L.cand_cap);
+  std::vector<uint32_t> rec((size_t)std::max(n, 1));
+  if (n) HIP_TRY(c, hipMemcpyAsync(rec.data(), c->d_scr_a + (size_t)slot * c->scratch_pitch + L.cand_base, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // reference order = (cell row, cell col, y, x)
+  std::vector<std::pair<uint64_t, uint32_t>> keyed((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const uint32_t x = ORBFE_REC_X(rec[i]), y = ORBFE_REC_Y(rec[i]);
+    const uint32_t jdx = std::min<uint32_t>((x - 3) / L.w_cell, L.n_cols - 1), idx = std::min<uint32_t>((y - 3) / L.h_cell, L.n_rows - 1);
+    keyed[i] = {((uint64_t)(idx * L.n_cols + jdx) << 24) | ((uint64_t)y << 12) | x, rec[i]};
+  }
+  std::sort(keyed.begin(), keyed.end());
+  for (int i = 0; i < n && xyr && i < cap; ++i) {
+    xyr[3 * i] = (float)ORBFE_REC_X(keyed[i].second);
+    xyr[3 * i + 1] = (float)ORBFE_REC_Y(keyed[i].second);
+    xyr[3 * i + 2] = (float)ORBFE_REC_R(keyed[i].second);
+  }
   *n_out = n;
   return ORBFE_OK;
 }

@@ -26,12 +26,12 @@ struct LevelDev {
   // FAST cell grid (ORBExtractor.cc:334-343)
   int32_t reg_w, reg_h;  // region [16, w-16) x [16, h-16)
   int32_t n_cols, n_rows, w_cell, h_cell;
+  uint32_t inv_w_cell, inv_h_cell;  // ceil(2^20 / cell size): exact floor-division of a 12-bit coordinate by the cell size
   int32_t cell_base;     // first flattened cell id of this level
   int32_t n_cells;
-  int32_t cell_cap;      // slots per cell (upper bound on 3x3-strict local maxima in a cell interior)
-  uint32_t slot_base;    // first slot (uint32 units) of this level inside one image's slot buffer
-  // quadtree
-  uint32_t cand_base;    // first record (uint64 units) inside one image's scratch buffer
+  int32_t cell_cap;      // upper bound on 3x3-strict local maxima in one cell interior
+  // candidate list / quadtree
+  uint32_t cand_base;    // first record (uint32 units) of this level inside one image's candidate buffer
   uint32_t cand_cap;     // = n_cells * cell_cap
   int32_t n_ini;         // root strips
   double strips[ORBFE_MAX_STRIPS + 1];
@@ -49,7 +49,6 @@ struct CellDev {
   int16_t pw, ph;      // patch size (maxX-iniX, maxY-iniY)
   int16_t offx, offy;  // jdx*wCell, idx*hCell  (ORBExtractor.cc:370-371)
   int16_t pad;
-  uint32_t slot_off;   // first slot of this cell inside one image's slot buffer
 };
 
 // candidate / selected-keypoint record: x (12 bit) | y (12 bit) | response (8 bit); x,y in region coordinates
