@@ -16,6 +16,7 @@
 
 #include "orb_math.h"
 #include "orbfe_internal.h"
+#include "wave_ops.h"
 
 namespace orbfe {
 
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(256) void k_ic_moments(const LevelDev* __restrict__
 __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv, int n_levels, const uint32_t* __restrict__ sel,
                                                 const int32_t* __restrict__ sel_count, int n_features,
                                                 const int2* __restrict__ moments, double2* __restrict__ sincos,
-                                                orbfe_keypoint* __restrict__ kps, KpAux* __restrict__ aux, int32_t* __restrict__ n_kp,
+                                                orbfe_keypoint* __restrict__ kps, KpAux* __restrict__ aux, float* __restrict__ kx,
+                                                short2* __restrict__ env, int n_chunks, int32_t* __restrict__ n_kp,
                                                 double* __restrict__ theta_out, int rows0) {
 #pragma clang fp contract(off)
   const int k = blockIdx.x * 256 + threadIdx.x;
@@ -115,33 +117,43 @@ __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv,
   int j, total;
   const int level = locate_level(sel_count + (size_t)img * n_levels, n_levels, k, &j, &total);
   if (k == 0) n_kp[img] = total;
-  if (level < 0) return;
-  const LevelDev& L = lv[level];
-  const uint32_t rec = sel[(size_t)img * n_features + L.quota_off + j];
-  const int x = (int)ORBFE_REC_X(rec) + ORBFE_EDGE, y = (int)ORBFE_REC_Y(rec) + ORBFE_EDGE;
-  const size_t o = (size_t)img * n_features + k;
-  const int2 m = moments[o];
-  const double theta = orbmath::det_atan2((double)m.y, (double)m.x);
-  double sn, cs;
-  orbmath::det_sincos(theta, &sn, &cs);
-  sincos[o] = make_double2(sn, cs);
-  orbfe_keypoint kp;
-  kp.x = (float)x * L.sf;  // keypoint.pt *= scale[octave] (ORBExtractor.cc:408-409)
-  kp.y = (float)y * L.sf;
-  kp.size = 7.0f;
-  kp.angle = (float)(theta / 3.14159265358979323846 * 180);  // ORBExtractor.cc:407
-  kp.response = (float)ORBFE_REC_R(rec);
-  kp.octave = level;
-  kp.class_id = -1;
-  kps[o] = kp;
-  // createRowIndexDB band (ORBMatcher.cc:924-927), stored with the keypoint for the stereo matcher
-  const float r = (float)(2.0 * (double)L.sf);
-  const unsigned row = (unsigned)__float2int_rn(kp.y);
-  KpAux a;
-  a.row_max = (int16_t)min(rows0, __float2int_rn((float)row + r + 1.0f));
-  a.row_min = (int16_t)max(0, __float2int_rn((float)row - r));
-  aux[o] = a;
-  if (theta_out) theta_out[o] = theta;
+  int row_min = 32767, row_max = -1;
+  if (level >= 0) {
+    const LevelDev& L = lv[level];
+    const uint32_t rec = sel[(size_t)img * n_features + L.quota_off + j];
+    const int x = (int)ORBFE_REC_X(rec) + ORBFE_EDGE, y = (int)ORBFE_REC_Y(rec) + ORBFE_EDGE;
+    const size_t o = (size_t)img * n_features + k;
+    const int2 m = moments[o];
+    const double theta = orbmath::det_atan2((double)m.y, (double)m.x);
+    double sn, cs;
+    orbmath::det_sincos(theta, &sn, &cs);
+    sincos[o] = make_double2(sn, cs);
+    orbfe_keypoint kp;
+    kp.x = (float)x * L.sf;  // keypoint.pt *= scale[octave] (ORBExtractor.cc:408-409)
+    kp.y = (float)y * L.sf;
+    kp.size = 7.0f;
+    kp.angle = (float)(theta / 3.14159265358979323846 * 180);  // ORBExtractor.cc:407
+    kp.response = (float)ORBFE_REC_R(rec);
+    kp.octave = level;
+    kp.class_id = -1;
+    kps[o] = kp;
+    kx[o] = kp.x;
+    // createRowIndexDB band (ORBMatcher.cc:924-927), stored with the keypoint for the stereo matcher
+    const float r = (float)(2.0 * (double)L.sf);
+    const unsigned row = (unsigned)__float2int_rn(kp.y);
+    row_max = min(rows0, __float2int_rn((float)row + r + 1.0f));
+    row_min = max(0, __float2int_rn((float)row - r));
+    KpAux a;
+    a.row_max = (int16_t)row_max;
+    a.row_min = (int16_t)row_min;
+    aux[o] = a;
+    if (theta_out) theta_out[o] = theta;
+  }
+  // row envelope of the 64 keypoints of this wave (= one chunk of the stereo matcher's candidate scan)
+  const int emin = wave_reduce_dpp<OpMinI>(row_min);
+  const int emax = wave_reduce_dpp<OpMaxI>(row_max);
+  const int chunk = k >> 6;
+  if ((threadIdx.x & 63) == 0 && chunk < n_chunks) env[(size_t)img * n_chunks + chunk] = make_short2((short)emin, (short)emax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -214,14 +226,15 @@ __global__ __launch_bounds__(64) void k_brief(const LevelDev* __restrict__ lv, i
 void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
-                         int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, int rows0, int n_img) {
+                         int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx, short2* d_env, int n_chunks,
+                         int rows0, int n_img) {
   if (n_img <= 0 || n_features <= 0) return;
   UmaxPacked u = 0;
   for (int i = 0; i < 16; ++i) u |= (unsigned long long)(umax[i] & 15) << (4 * i);
   hipLaunchKernelGGL(k_ic_moments, dim3((n_features + 3) / 4, n_img), dim3(256), 0, s, d_lv, n_levels, d_pyr, img_pitch, d_sel,
                      d_sel_count, n_features, u, d_moments);
   hipLaunchKernelGGL(k_orient, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, n_levels, d_sel, d_sel_count, n_features,
-                     d_moments, d_sincos, d_kps, d_aux, d_n_kp, d_theta, rows0);
+                     d_moments, d_sincos, d_kps, d_aux, d_kx, d_env, n_chunks, d_n_kp, d_theta, rows0);
   hipLaunchKernelGGL(k_brief, dim3(n_features, n_img), dim3(64), 0, s, d_lv, n_levels, d_blur, img_pitch, d_sel, d_sel_count,
                      n_features, d_pattern, d_sincos, d_desc);
 }

@@ -19,21 +19,23 @@ namespace orbfe {
 
 #define ORB_INT_MAX 2147483647
 
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_min_step(int v) {
+  // lanes without a source keep INT_MAX (the identity of min)
+  return min(v, __builtin_amdgcn_update_dpp(ORB_INT_MAX, v, CTRL, ROW_MASK, 0xf, false));
+}
+// inclusive prefix-min over the 64 lanes (all lanes active): Hillis-Steele inside each row of 16 with DPP row
+// shifts, then the row totals are broadcast into the following rows.  Lane 63 holds the wave minimum.
+__device__ __forceinline__ int wave_incl_prefix_min(int v) {
+  v = dpp_min_step<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_min_step<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_min_step<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_min_step<0x118, 0xf>(v);  // row_shr:8
+  v = dpp_min_step<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+  v = dpp_min_step<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
   return v;
 }
-__device__ __forceinline__ int wave_excl_prefix_min(int v, int lane) {
-  // inclusive scan, then shift by one lane
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(v, o);
-    if (lane >= o) v = min(v, t);
-  }
-  const int p = __shfl_up(v, 1);
-  return lane == 0 ? ORB_INT_MAX : p;
-}
+__device__ __forceinline__ int wave_min_i(int v) { return __builtin_amdgcn_readlane(wave_incl_prefix_min(v), 63); }
 
 struct Best2 {
   int min_d, second, min_idx;
@@ -42,16 +44,16 @@ struct Best2 {
 // Fold one chunk of up to 64 candidates (lane order = list order) into the running (min, idx, second).
 // d = distance of this lane's candidate or INT_MAX if the lane holds none; idx = its train index.
 __device__ __forceinline__ void fold_chunk(Best2& b, int d, int idx, int lane) {
-  const int pre = min(b.min_d, wave_excl_prefix_min(d, lane));
-  const bool record = d < pre;
-  const int sec = wave_min_i(record ? ORB_INT_MAX : d);
-  b.second = min(b.second, sec);
-  const int cmin = wave_min_i(d);
+  const int incl = wave_incl_prefix_min(d);
+  const int excl = __builtin_amdgcn_update_dpp(ORB_INT_MAX, incl, 0x138, 0xf, 0xf, false);  // wave_shr:1, lane 0 <- INT_MAX
+  const int pre = min(b.min_d, excl);
+  const bool record = d < pre;  // strict prefix-minimum record: becomes the new best, never the second best
+  b.second = min(b.second, wave_min_i(record ? ORB_INT_MAX : d));
+  const int cmin = __builtin_amdgcn_readlane(incl, 63);
   if (cmin < b.min_d) {
     const unsigned long long m = __ballot(d == cmin);
-    const int first = __ffsll((long long)m) - 1;
     b.min_d = cmin;
-    b.min_idx = __shfl(idx, first);
+    b.min_idx = __builtin_amdgcn_readlane(idx, __ffsll((long long)m) - 1);
   }
 }
 
@@ -103,14 +105,16 @@ __device__ __forceinline__ int cv_floor_f(float v) {
 
 __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv, const uint8_t* __restrict__ pyr, size_t img_pitch,
                                                 const orbfe_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
-                                                const KpAux* __restrict__ aux, const int32_t* __restrict__ n_kp, int n_features,
-                                                float fx, float bf, int cols0, int mean_threshold, double* __restrict__ right_u,
-                                                double* __restrict__ depth, int32_t* __restrict__ n_match,
+                                                const KpAux* __restrict__ aux, const float* __restrict__ kx,
+                                                const short2* __restrict__ env, int n_chunks, const int32_t* __restrict__ n_kp,
+                                                int n_features, float fx, float bf, int cols0, int mean_threshold,
+                                                double* __restrict__ right_u, double* __restrict__ depth, int32_t* __restrict__ n_match,
                                                 int32_t* __restrict__ best_right, int32_t* __restrict__ best_dist, int slot_l0,
                                                 int slot_r0, int slot_step, int pair0) {
 #pragma clang fp contract(off)
-  const int lane = threadIdx.x & 63;
-  const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ uint32_t s_sad[4][11 * 4 + 11 * 7 + 7];  // per wave: left 11 rows x 4 words, right 11 rows x 7 words
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int li = blockIdx.x * 4 + wv;
   const int pair = pair0 + blockIdx.y;
   const int sl = slot_l0 + blockIdx.y * slot_step, sr = slot_r0 + blockIdx.y * slot_step;
   const size_t out_i = (size_t)pair * n_features + li;
@@ -130,6 +134,8 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
   const uint8_t* LD = desc + (size_t)sl * n_features * 32;
   const uint8_t* RD = desc + (size_t)sr * n_features * 32;
   const KpAux* RA = aux + (size_t)sr * n_features;
+  const float* RX = kx + (size_t)sr * n_features;
+  const short2* RE = env + (size_t)sr * n_chunks;
 
   const orbfe_keypoint l = LK[li];
   const float max_u = l.x - 0;
@@ -138,21 +144,35 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
   const uint4 a0 = *(const uint4*)(LD + (size_t)li * 32);
   const uint4 a1 = *(const uint4*)(LD + (size_t)li * 32 + 16);
 
-  // candidates = rowIdxDB[row] filtered by the u-range, in ascending right index (ORBMatcher.cc:38-48)
+  // candidates = rowIdxDB[row] filtered by the u-range, in ascending right index (ORBMatcher.cc:38-48).
+  // Keypoints are stored level-major / cell-row-major, so a chunk of 64 consecutive right keypoints covers a narrow
+  // band of rows: one envelope test per chunk (lane = chunk) skips most of the 32 chunks outright.
   Best2 b = {ORB_INT_MAX, ORB_INT_MAX, 0};
   bool any = false;
-  for (int c0 = 0; c0 < nr; c0 += 64) {
-    const int c = c0 + lane;
-    bool pass = false;
-    if (c < nr) {
-      const KpAux a = RA[c];
-      const float rx = RK[c].x;
-      pass = row >= a.row_min && row < a.row_max && rx < max_u && rx > min_u;
+  const int used_chunks = (nr + 63) >> 6;
+  for (int cb = 0; cb < used_chunks; cb += 64) {
+    const int ch = cb + lane;
+    bool hit = false;
+    if (ch < used_chunks) {
+      const short2 e = RE[ch];
+      hit = row >= (int)e.x && row < (int)e.y;
     }
-    if (__ballot(pass) == 0ull) continue;
-    any = true;
-    const int d = pass ? hamming256(a0, a1, RD + (size_t)c * 32) : ORB_INT_MAX;
-    fold_chunk(b, d, c, lane);
+    unsigned long long todo = __ballot(hit);
+    while (todo) {
+      const int cbit = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int c = ((cb + cbit) << 6) + lane;
+      bool pass = false;
+      if (c < nr) {
+        const KpAux a = RA[c];
+        const float rx = RX[c];
+        pass = row >= a.row_min && row < a.row_max && rx < max_u && rx > min_u;
+      }
+      if (__ballot(pass) == 0ull) continue;
+      any = true;
+      const int d = pass ? hamming256(a0, a1, RD + (size_t)c * 32) : ORB_INT_MAX;
+      fold_chunk(b, d, c, lane);
+    }
   }
   double out_u = -1.0, out_depth = -1.0;
   int matched = 0;
@@ -166,17 +186,33 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
       const uint8_t* IR = pyr + (size_t)sr * img_pitch + LR.plane_off;
       const int lx = cv_floor_f(l.x / LL.sf), ly = cv_floor_f(l.y / LL.sf);  // getPitch (:1004-1006)
       const int rx = cv_floor_f(r.x / LR.sf), ry = cv_floor_f(r.y / LR.sf);
-      const int c1 = IL[(size_t)ly * LL.stride + lx];
+      // stage the left 11x11 patch (x in [lx-5, lx+5]) and the right 11x21 window (x in [rx-10, rx+10]) in LDS as words
+      uint32_t* wl = s_sad[wv];
+      uint32_t* wr = s_sad[wv] + 44;
+      const int lxa = (lx - 5) & ~3, rxa = (rx - 10) & ~3;
+      for (int t = lane; t < 44 + 77; t += 64) {
+        if (t < 44) {
+          const int rr = t >> 2, cc = t & 3;
+          wl[t] = *(const uint32_t*)(IL + (size_t)(ly - 5 + rr) * LL.stride + lxa + 4 * cc);
+        } else {
+          const int u = t - 44;
+          const int rr = u / 7, cc = u - rr * 7;
+          wr[u] = *(const uint32_t*)(IR + (size_t)(ry - 5 + rr) * LR.stride + rxa + 4 * cc);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // LDS accesses of one wave execute in order; this only pins the compiler
+      const uint8_t* bl = (const uint8_t*)wl + ((lx - 5) - lxa);
+      const uint8_t* br = (const uint8_t*)wr + ((rx - 10) - rxa);
+      const int c1 = bl[5 * 16 + 5];
       // lane = part*11 + Lidx, part 0..4 sums rows {part, part+5, (part+10 if part==0)}
       int partial = 0;
       if (lane < 55) {
         const int Lidx = lane % 11, part = lane / 11;
-        const int Ls = Lidx - 5;
         // each shifted right patch subtracts ITS OWN centre pixel (SAD(), ORBMatcher.cc:901-903)
-        const int c2 = IR[(size_t)ry * LR.stride + rx + Ls];
+        const int c2 = br[5 * 28 + 5 + Lidx];
         for (int rr = part; rr < 11; rr += 5) {
-          const uint8_t* pl = IL + (size_t)(ly - 5 + rr) * LL.stride + (lx - 5);
-          const uint8_t* pr = IR + (size_t)(ry - 5 + rr) * LR.stride + (rx + Ls - 5);
+          const uint8_t* pl = bl + rr * 16;
+          const uint8_t* pr = br + rr * 28 + Lidx;
 #pragma unroll
           for (int cc = 0; cc < 11; ++cc) {
             const int dlt = ((int)pl[cc] - c1) - ((int)pr[cc] - c2);
@@ -236,12 +272,12 @@ void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const ui
 }
 
 void launch_stereo(hipStream_t s, const LevelDev* d_lv, const uint8_t* d_pyr, size_t img_pitch, const orbfe_keypoint* d_kps,
-                   const uint8_t* d_desc, const KpAux* d_aux, const int32_t* d_n_kp, int n_features, float fx, float bf,
-                   int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
+                   const uint8_t* d_desc, const KpAux* d_aux, const float* d_kx, const short2* d_env, int n_chunks,
+                   const int32_t* d_n_kp, int n_features, float fx, float bf, int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
                    int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs) {
   if (n_pairs <= 0 || n_features <= 0) return;
   hipLaunchKernelGGL(k_stereo, dim3((n_features + 3) / 4, n_pairs), dim3(256), 0, s, d_lv, d_pyr, img_pitch, d_kps, d_desc,
-                     d_aux, d_n_kp, n_features, fx, bf, cols0, mean_threshold, d_right_u, d_depth, d_n_match, d_best_right,
+                     d_aux, d_kx, d_env, n_chunks, d_n_kp, n_features, fx, bf, cols0, mean_threshold, d_right_u, d_depth, d_n_match, d_best_right,
                      d_best_dist, slot_l0, slot_r0, slot_step, pair0);
 }
 

@@ -15,37 +15,82 @@
 namespace orbfe {
 
 // ---------------------------------------------------------------------------------------------
-// resize: 64x4 output pixels per 256-thread block; grid.x = tiles of all levels >= 1, grid.y = image
+// resize: 64x16 output pixels per 256-thread block; grid.x = tiles of all levels >= 1, grid.y = image.
+// The level-0 footprint of the tile (<= 60 rows x 232 bytes at scale 3.58) is staged in LDS with aligned
+// 32-bit loads; every thread then produces 4 horizontally adjacent outputs from LDS bytes and stores them
+// as one word.
 // ---------------------------------------------------------------------------------------------
+#define RS_TW 64
+#define RS_TH 16
+#define RS_LDS_BYTES 16384
+
 __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv, int n_levels,
                                                 const ResizeTap* __restrict__ taps, uint8_t* __restrict__ pyr,
                                                 size_t img_pitch) {
+  __shared__ uint32_t tile[RS_LDS_BYTES / 4];
   const int img = blockIdx.y;
-  const int tile = blockIdx.x;
+  const int tl = blockIdx.x;
   int l = 1;
-  while (l + 1 < n_levels && tile >= lv[l + 1].rs_tile_base) ++l;
+  while (l + 1 < n_levels && tl >= lv[l + 1].rs_tile_base) ++l;
   const LevelDev& L = lv[l];
-  const int t = tile - L.rs_tile_base;
-  const int tx = t % L.rs_tiles_x, ty = t / L.rs_tiles_x;
-  const int dx = tx * 64 + (threadIdx.x & 63);
-  const int dy = ty * 4 + (threadIdx.x >> 6);
-  if (dx >= L.w || dy >= L.h) return;
+  const int t = tl - L.rs_tile_base;
+  const int x0 = (t % L.rs_tiles_x) * RS_TW, y0 = (t / L.rs_tiles_x) * RS_TH;
   const int sw = lv[0].w, sh = lv[0].h, sstride = lv[0].stride;
   uint8_t* base = pyr + (size_t)img * img_pitch;
   const uint8_t* S = base + lv[0].plane_off;
-  const ResizeTap ax = taps[L.xtab_off + dx];
-  const ResizeTap ay = taps[L.ytab_off + dy];
-  const int sy0 = min(max(ay.ofs, 0), sh - 1);
-  const int sy1 = min(max(ay.ofs + 1, 0), sh - 1);
-  const int sx0 = ax.ofs;
-  const int sx1 = min(ax.ofs + 1, sw - 1);  // tap c1 is 0 wherever the reference does not read S[sx+1]
-  const uint8_t* r0 = S + (size_t)sy0 * sstride;
-  const uint8_t* r1 = S + (size_t)sy1 * sstride;
-  const int h0 = r0[sx0] * ax.c0 + r0[sx1] * ax.c1;
-  const int h1 = r1[sx0] * ax.c0 + r1[sx1] * ax.c1;
-  int v = ((((int)ay.c0 * (h0 >> 4)) >> 16) + (((int)ay.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
-  v = min(255, max(0, v));
-  base[L.plane_off + (size_t)dy * L.stride + dx] = (uint8_t)v;
+  const ResizeTap* xt = taps + L.xtab_off;
+  const ResizeTap* yt = taps + L.ytab_off;
+  // level-0 footprint of the tile (taps are monotone in the output coordinate)
+  const int x1 = min(x0 + RS_TW, L.w) - 1, y1 = min(y0 + RS_TH, L.h) - 1;
+  const int sx_lo = xt[x0].ofs & ~3, sx_hi = min(xt[x1].ofs + 1, sw - 1);
+  const int sy_lo = min(max(yt[y0].ofs, 0), sh - 1), sy_hi = min(max(yt[y1].ofs + 1, 0), sh - 1);
+  const int nw = ((sx_hi - sx_lo) >> 2) + 1, nr = sy_hi - sy_lo + 1;
+  const int pitch = nw * 4;
+  const bool fits = nw * nr * 4 <= RS_LDS_BYTES;  // always true for pyramid scales; otherwise read global memory directly
+  if (fits) {
+    const uint32_t inv = ((1u << 20) + nw - 1) / nw;
+    for (int k = threadIdx.x; k < nw * nr; k += 256) {
+      const int r = (int)(((uint32_t)k * inv) >> 20), c = k - r * nw;
+      tile[k] = *(const uint32_t*)(S + (size_t)(sy_lo + r) * sstride + sx_lo + 4 * c);
+    }
+  }
+  __syncthreads();
+  const int cx = x0 + (threadIdx.x & 15) * 4;
+  const int cy = y0 + (threadIdx.x >> 4);
+  if (cx >= L.w || cy >= L.h) return;
+  const ResizeTap ay = yt[cy];
+  const int sy0 = min(max(ay.ofs, 0), sh - 1), sy1 = min(max(ay.ofs + 1, 0), sh - 1);
+  const uint8_t* tb = (const uint8_t*)tile;
+  uint32_t out = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int dx = min(cx + j, L.w - 1);
+    const ResizeTap ax = xt[dx];
+    const int sx0 = ax.ofs;
+    const int sx1 = min(ax.ofs + 1, sw - 1);  // tap c1 is 0 wherever the reference does not read S[sx+1]
+    int p00, p01, p10, p11;
+    if (fits) {
+      const uint8_t* r0 = tb + (sy0 - sy_lo) * pitch - sx_lo;
+      const uint8_t* r1 = tb + (sy1 - sy_lo) * pitch - sx_lo;
+      p00 = r0[sx0];
+      p01 = r0[sx1];
+      p10 = r1[sx0];
+      p11 = r1[sx1];
+    } else {
+      const uint8_t* r0 = S + (size_t)sy0 * sstride;
+      const uint8_t* r1 = S + (size_t)sy1 * sstride;
+      p00 = r0[sx0];
+      p01 = r0[sx1];
+      p10 = r1[sx0];
+      p11 = r1[sx1];
+    }
+    const int h0 = p00 * ax.c0 + p01 * ax.c1;
+    const int h1 = p10 * ax.c0 + p11 * ax.c1;
+    int v = ((((int)ay.c0 * (h0 >> 4)) >> 16) + (((int)ay.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    v = min(255, max(0, v));
+    out |= (uint32_t)v << (8 * j);
+  }
+  *(uint32_t*)(base + L.plane_off + (size_t)cy * L.stride + cx) = out;  // stride is a multiple of 16: the padding absorbs the tail
 }
 
 // ---------------------------------------------------------------------------------------------

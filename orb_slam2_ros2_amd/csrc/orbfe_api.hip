@@ -36,13 +36,14 @@ void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const ui
 void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
-                         int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, int rows0, int n_img);
+                         int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx, short2* d_env, int n_chunks,
+                         int rows0, int n_img);
 // k_match.hip
 void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, const uint32_t* d_off,
                              const uint32_t* d_cand, int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second);
 void launch_stereo(hipStream_t s, const LevelDev* d_lv, const uint8_t* d_pyr, size_t img_pitch, const orbfe_keypoint* d_kps,
-                   const uint8_t* d_desc, const KpAux* d_aux, const int32_t* d_n_kp, int n_features, float fx, float bf,
-                   int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
+                   const uint8_t* d_desc, const KpAux* d_aux, const float* d_kx, const short2* d_env, int n_chunks,
+                   const int32_t* d_n_kp, int n_features, float fx, float bf, int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
                    int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs);
 // k_ba.hip
 void launch_ba_edges(hipStream_t s, int n_edges, const double* d_poses, const double* d_points, const int32_t* d_edge_pose,
@@ -101,6 +102,9 @@ struct orbfe_ctx {
   double* d_theta = nullptr;
   int2* d_moments = nullptr;     // per keypoint (m10, m01)
   double2* d_sincos = nullptr;   // per keypoint (sin, cos) of the orientation
+  float* d_kx = nullptr;         // per keypoint x (level-0 coordinates), SoA copy for the stereo candidate scan
+  short2* d_env = nullptr;       // per chunk of 64 keypoints: [min row_min, max row_max) envelope
+  int n_chunks = 0;
   double *d_right_u = nullptr, *d_depth = nullptr;
   int32_t *d_n_match = nullptr, *d_best_right = nullptr, *d_best_dist = nullptr;
   // generic staging for match / BA calls
@@ -274,8 +278,8 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
       build_resize_axis(cfg.width, L.w, c->taps);
       L.ytab_off = (uint32_t)c->taps.size();
       build_resize_axis(cfg.height, L.h, c->taps);
-      L.rs_tiles_x = (L.w + 63) / 64;
-      L.rs_tiles_y = (L.h + 3) / 4;
+      L.rs_tiles_x = (L.w + 63) / 64;  // k_resize: 64x16 output tiles
+      L.rs_tiles_y = (L.h + 15) / 16;
       rs_tiles += L.rs_tiles_x * L.rs_tiles_y;
     }
     L.bl_tile_base = bl_tiles;
@@ -434,7 +438,8 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     StageTimer t(c, ORBFE_STAGE_BRIEF, st);
     launch_orient_brief(st, c->d_lv, nl, pyr, blur, c->img_pitch, c->d_sel + i0 * NF, c->d_sel_count + i0 * nl, c->cfg.n_features,
                         c->d_pattern, c->umax, c->d_kps + i0 * NF, c->d_desc + i0 * NF * 32, c->d_aux + i0 * NF, c->d_n_kp + i0,
-                        c->d_theta + i0 * NF, c->d_moments + i0 * NF, c->d_sincos + i0 * NF, c->cfg.height, n_img);
+                        c->d_theta + i0 * NF, c->d_moments + i0 * NF, c->d_sincos + i0 * NF, c->d_kx + i0 * NF,
+                        c->d_env + i0 * c->n_chunks, c->n_chunks, c->cfg.height, n_img);
   }
   HIP_TRY(c, hipGetLastError());
   return ORBFE_OK;
@@ -445,7 +450,8 @@ static orbfe_status run_stereo(orbfe_ctx* c, hipStream_t st, int slot_l0, int sl
   HIP_TRY(c, hipMemsetAsync(c->d_n_match + pair0, 0, sizeof(int32_t) * n_pairs, st));
   {
     StageTimer t(c, ORBFE_STAGE_STEREO, st);
-    launch_stereo(st, c->d_lv, c->d_pyr, c->img_pitch, c->d_kps, c->d_desc, c->d_aux, c->d_n_kp, c->cfg.n_features, fx, bf,
+    launch_stereo(st, c->d_lv, c->d_pyr, c->img_pitch, c->d_kps, c->d_desc, c->d_aux, c->d_kx, c->d_env, c->n_chunks, c->d_n_kp,
+                  c->cfg.n_features, fx, bf,
                   c->cfg.width, kMeanThreshold, c->d_right_u, c->d_depth, c->d_n_match, c->d_best_right, c->d_best_dist, slot_l0,
                   slot_r0, slot_step, pair0, n_pairs);
   }
@@ -473,7 +479,7 @@ void orbfe_destroy(orbfe_ctx* c) {
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
   void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_pattern, c->d_pyr,     c->d_blur,
                   c->d_scr_a, c->d_scr_c,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_kp,
-                  c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos,   c->d_right_u, c->d_depth, c->d_n_match,
+                  c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos, c->d_kx, c->d_env,   c->d_right_u, c->d_depth, c->d_n_match,
                   c->d_best_right, c->d_best_dist, c->d_tmp};
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -566,6 +572,9 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   ALLOC(c->d_theta, M * NF);
   ALLOC(c->d_moments, M * NF);
   ALLOC(c->d_sincos, M * NF);
+  c->n_chunks = (int)((NF + 63) / 64);
+  ALLOC(c->d_kx, M * NF);
+  ALLOC(c->d_env, M * (size_t)c->n_chunks);
   ALLOC(c->d_right_u, NP * NF);
   ALLOC(c->d_depth, NP * NF);
   ALLOC(c->d_n_match, NP);

@@ -1,0 +1,50 @@
+// wave_ops.h -- 64-lane wave reductions / scans with DPP (gfx9 row shifts + row broadcasts), no LDS traffic.
+// All 64 lanes must be active at the call site.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace orbfe {
+
+#define ORBFE_DPP_ROW_SHR(n) (0x110 + (n))
+#define ORBFE_DPP_ROW_BCAST15 0x142
+#define ORBFE_DPP_ROW_BCAST31 0x143
+#define ORBFE_DPP_WAVE_SHR1 0x138
+#define ORBFE_DPP_WAVE_SHL1 0x130
+
+struct OpMinI {
+  static __device__ __forceinline__ int id() { return 2147483647; }
+  static __device__ __forceinline__ int f(int a, int b) { return a < b ? a : b; }
+};
+struct OpMaxI {
+  static __device__ __forceinline__ int id() { return -2147483647 - 1; }
+  static __device__ __forceinline__ int f(int a, int b) { return a > b ? a : b; }
+};
+struct OpAddI {
+  static __device__ __forceinline__ int id() { return 0; }
+  static __device__ __forceinline__ int f(int a, int b) { return a + b; }
+};
+
+template <class Op, int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_step(int v) {
+  // lanes without a source lane keep the identity
+  return Op::f(v, __builtin_amdgcn_update_dpp(Op::id(), v, CTRL, ROW_MASK, 0xf, false));
+}
+
+// inclusive scan over the 64 lanes; lane 63 holds the reduction of the whole wave
+template <class Op>
+__device__ __forceinline__ int wave_incl_scan_dpp(int v) {
+  v = dpp_step<Op, ORBFE_DPP_ROW_SHR(1), 0xf>(v);
+  v = dpp_step<Op, ORBFE_DPP_ROW_SHR(2), 0xf>(v);
+  v = dpp_step<Op, ORBFE_DPP_ROW_SHR(4), 0xf>(v);
+  v = dpp_step<Op, ORBFE_DPP_ROW_SHR(8), 0xf>(v);
+  v = dpp_step<Op, ORBFE_DPP_ROW_BCAST15, 0xa>(v);
+  v = dpp_step<Op, ORBFE_DPP_ROW_BCAST31, 0xc>(v);
+  return v;
+}
+template <class Op>
+__device__ __forceinline__ int wave_reduce_dpp(int v) {
+  return __builtin_amdgcn_readlane(wave_incl_scan_dpp<Op>(v), 63);
+}
+
+}  // namespace orbfe
