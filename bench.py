@@ -32,8 +32,9 @@ FX, BF = 718.856, 718.856 * 0.537166  # config/kitti_config_00.yaml: Camera.fx, 
 HBM_PEAK_GBPS = 8000.0
 
 
-def algorithmic_bytes(ctx):
-    """algorithmic bytes per image for each kernel, and per stereo pair in total."""
+def algorithmic_bytes(ctx, n_cand_per_image):
+    """algorithmic bytes per image for each kernel, and per stereo pair in total.  The quadtree has no
+    entry in 8(d) (it only touches the candidate records): 4 B per candidate read + 4 B per selected keypoint written."""
     P = sum(ctx.level_info(l).width * ctx.level_info(l).height for l in range(NLEVELS))
     S0 = W * H
     K = NFEAT
@@ -41,7 +42,7 @@ def algorithmic_bytes(ctx):
         "resize": S0 + (P - S0),            # read level 0, write levels 1..7
         "blur": 2 * P,                      # read + write every plane
         "fast": P,                          # read every plane (+ candidate records, not counted)
-        "quadtree": 0,                      # candidate records only (L2 resident), not in the 8(d) budget
+        "quadtree": 4 * n_cand_per_image + 4 * K,
         "orient_brief": K * (749 + 512) + K * 60,
     }
     per_pair_match = 2 * K * 32 + 2 * K * 28 + K * 12 * 121 + K * 16
@@ -52,9 +53,12 @@ def algorithmic_bytes(ctx):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step (per GPU)")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--prewarm-seconds", type=float, default=1.5,
+                    help="untimed steps run before the W warm-up steps until this much wall time has passed: the GPU needs "
+                         "~0.3 s of sustained load to leave its idle clocks (measured: first 30 steps 13 %% slower)")
+    ap.add_argument("--pairs", type=int, default=128, help="stereo pairs per step (per GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     args = ap.parse_args()
 
@@ -92,28 +96,28 @@ def main():
     d_right = torch.from_numpy(right_h).to(dev)
 
     ctx = Context(W, H, NFEAT, NLEVELS, SCALE, TH_HI, TH_LO, device_id=local_rank, max_images=2 * B)
-    per_image_bytes, match_bytes, pair_bytes = algorithmic_bytes(ctx)
 
     def step():
         ctx.stereo_batch_device(d_left.data_ptr(), d_right.data_ptr(), W, W * H, B, FX, BF)
 
+    class _Raw:  # zero-copy torch view of one of the library's device buffers
+        def __init__(self, p, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (p, False), "version": 2}
+
+    res = ctx.device_results()
+    d_counts = torch.as_tensor(_Raw(res["counts"], 2 * B), device=dev)
+    d_nmatch = torch.as_tensor(_Raw(res["n_match"], B), device=dev)
+
     def gather_results():
-        """Sequence-level exchange: per-pair summaries of this rank -> rank 0 (RCCL gather over xGMI)."""
-        if world == 1:
-            return None
-        res = ctx.device_results()
-        summary = torch.zeros(B, 4, dtype=torch.int32, device=dev)
-
-        class _Raw:  # zero-copy view of the library's device buffers
-            def __init__(self, p, n):
-                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (p, False), "version": 2}
-
-        counts = torch.as_tensor(_Raw(res["counts"], 2 * B), device=dev)
-        nmatch = torch.as_tensor(_Raw(res["n_match"], B), device=dev)
-        summary[:, 0] = counts[0::2]
-        summary[:, 1] = counts[1::2]
-        summary[:, 2] = nmatch
+        """Sequence-level exchange: the per-pair records of this rank's shard -> rank 0, one RCCL gather
+        over xGMI at the end of the sequence.  Frames are independent, so nothing else crosses GPUs."""
+        summary = torch.empty(B, 4, dtype=torch.int32, device=dev)
+        summary[:, 0] = d_counts[0::2]
+        summary[:, 1] = d_counts[1::2]
+        summary[:, 2] = d_nmatch
         summary[:, 3] = rank
+        if world == 1:
+            return [summary]
         out = [torch.empty_like(summary) for _ in range(world)] if rank == 0 else None
         dist.gather(summary, out, dst=0)
         return out
@@ -125,6 +129,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm_seconds:
+        step()
+        ctx.sync()
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -140,12 +148,20 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # sanity: the last batch produced features and matches
+    # sanity: the last batch produced features and matches, and the gathered summaries agree with the fetched results
     nm, ru, dp, _, _ = ctx.fetch_stereo(0)
     kps, _ = ctx.fetch_features(0)
     assert len(kps) > 0 and nm > 0, "front end produced no features/matches"
+    if rank == 0:
+        g0 = gathered[0].cpu().numpy()
+        assert g0[0, 0] == len(kps) and g0[0, 2] == nm, "gathered summary disagrees with the fetched results"
+        assert all(int(g[:, 2].min()) > 0 for g in (t.cpu().numpy() for t in gathered)), "a rank produced a pair without matches"
 
-    # per-stage device time (HIP events on the library stream) in a separate, untimed pass
+    n_cand_img = sum(len(ctx.debug_candidates(0, l)) for l in range(NLEVELS))  # FAST candidates of one image (slot 0)
+    per_image_bytes, match_bytes, pair_bytes = algorithmic_bytes(ctx, n_cand_img)
+
+    # per-stage device time (HIP events on the library stream) in a separate, untimed pass (the batch runs unsplit
+    # there so that every kernel is timed alone; the timed region above overlaps two half-batches on two streams)
     ctx.profile_enable(True)
     n_prof = max(3, min(args.steps, 10))
     for _ in range(n_prof):
@@ -198,8 +214,23 @@ def main():
             "traffic": None,
             "algorithmic_bytes_per_launch": stage_bytes[dom],
             "avg_launch_ms": dom_ms,
+            "images_per_launch": images_per_launch,
+            "all_stages": {k: {"ms": round(stages[k], 4), "GBps": round(stage_bytes[k] / (stages[k] * 1e-3) / 1e9, 1)}
+                           for k in stages if k in stage_bytes and stages[k] > 0},
         },
     }
+
+    # HBM traffic of the dominant kernel from a committed rocprofv3 PMC pass of this same command (profiles/), if present
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            ent = tj.get("kernels", {}).get(dom)
+            if ent and tj.get("pairs_per_step") == B:
+                line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
+                line["roofline"]["traffic_source"] = tj.get("source", "profiles/pmc_traffic.json")
+        except Exception:
+            pass
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from oracle import pyoracle

@@ -69,7 +69,7 @@ struct orbfe_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   // side streams for the chunked batch path
-  static const int kMaxSide = 4;
+  static const int kMaxSide = 4;  // upper bound; ORBFE_STREAMS picks the count (default 2)
   int n_side = 0;
   hipStream_t side[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
@@ -533,7 +533,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   }
   {
     const char* env = getenv("ORBFE_STREAMS");
-    int want = env ? atoi(env) : orbfe_ctx::kMaxSide;
+    int want = env ? atoi(env) : 2;
     want = std::min(std::max(want, 1), (int)orbfe_ctx::kMaxSide);
     bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int k = 0; k < want && ok; ++k) {

@@ -72,3 +72,27 @@ def test_frame_range_partition():
             b, e = frame_range(F, r, Wd)
             cover += list(range(b, e))
         assert cover == list(range(F))
+
+
+def _build_shim(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "test_shim")
+    pkg = os.path.join(ROOT, "orb_slam2_ros2_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_shim.cpp"), "-L" + pkg,
+                           "-lorbfe_hip", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cpp_host_mirror_compiles_and_fails_loudly_without_device(tmp_path):
+    import subprocess
+
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    from orb_slam2_ros2_amd import synth
+    exe = _build_shim(tmp_path)
+    L, R = synth.stereo_pair(0, 640, 240, n_rect=100)
+    L.tofile(tmp_path / "L.raw")
+    R.tofile(tmp_path / "R.raw")
+    r = subprocess.run([exe, str(tmp_path / "L.raw"), str(tmp_path / "R.raw"), "640", "240"], capture_output=True, text=True)
+    assert r.returncode == 3 and r.stdout.strip() == "NO_DEVICE"

@@ -270,3 +270,26 @@ def test_frontend_mirror_classes(orc):
     assert ORBMatcher.descDistance(d[0], d[1]) == orc.hamming(d[0], d[1])
     fr = StereoFrontEnd(L, R, fx=FX, bf=BF)
     assert fr.mnN == G["frames"]["kitti_0"]["n_matches"] and sha(fr.mvDepths) == G["frames"]["kitti_0"]["depth_sha"]
+
+
+def test_cpp_host_mirror_matches_oracle(orc, tmp_path):
+    """The C++ classes of orb_slam2_ros2_amd/host/orbfe_shim.hpp (reference signatures over the C-ABI)."""
+    import subprocess
+    from test_abi_and_host import _build_shim
+
+    def fnv1a(b):
+        h = 1469598103934665603
+        for x in b:
+            h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+
+    exe = _build_shim(tmp_path)
+    L, R = synth.stereo_pair(0)
+    L.tofile(tmp_path / "L.raw")
+    R.tofile(tmp_path / "R.raw")
+    out = subprocess.run([exe, str(tmp_path / "L.raw"), str(tmp_path / "R.raw"), "1241", "376"], capture_output=True, text=True, check=True)
+    nl, nr, nm, hk, hd, d01 = out.stdout.split()
+    ref = orc.stereo_frame(L, R, fx=FX, bf=BF)
+    assert (int(nl), int(nr), int(nm)) == (len(ref["lk"]), len(ref["rk"]), ref["n_matches"])
+    assert int(hk, 16) == fnv1a(ref["lk"].tobytes()) and int(hd, 16) == fnv1a(ref["ld"].tobytes())
+    assert int(d01) == orc.hamming(ref["ld"][0], ref["ld"][1])
