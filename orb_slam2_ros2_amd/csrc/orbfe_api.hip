@@ -749,14 +749,16 @@ orbfe_status orbfe_stereo_batch_device(orbfe_ctx* c, const uint8_t* d_left, cons
   const LevelDev& L0 = c->lv[0];
   // The batch is cut into chunks that run on separate streams: the quadtree is latency-bound (one wave per
   // image level, a few hundred dependent steps) and leaves the machine almost idle, so the streaming kernels of the
-  // other chunks fill it.  With stage timing enabled the batch runs unsplit so that each kernel is timed alone.
-  const int n_chunks = c->prof ? 1 : std::min<int>(c->n_side, std::max(1, n_pairs / 8));
+  // other chunks fill it.  With stage timing enabled the same chunks run one after the other on the main stream, so
+  // that every kernel is timed alone with the launch shape of the production path.
+  const int n_chunks = std::min<int>(c->n_side, std::max(1, n_pairs / 8));
+  const bool serial = c->prof || n_chunks == 1;
   HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
   for (int k = 0; k < n_chunks; ++k) {
     const int p0 = (int)((long long)n_pairs * k / n_chunks), p1 = (int)((long long)n_pairs * (k + 1) / n_chunks);
     if (p1 <= p0) continue;
-    hipStream_t st = n_chunks == 1 ? c->stream : c->side[k];
-    if (n_chunks > 1) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_fork, 0));
+    hipStream_t st = serial ? c->stream : c->side[k];
+    if (!serial) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_fork, 0));
     // level 0 of slot 2p / 2p+1 <- left / right image p
     launch_load_level0(st, d_left + (size_t)p0 * image_pitch, stride, image_pitch, c->d_pyr, c->img_pitch, L0.plane_off, L0.stride,
                        c->cfg.width, c->cfg.height, 2 * p0, 2, p1 - p0);
@@ -764,7 +766,7 @@ orbfe_status orbfe_stereo_batch_device(orbfe_ctx* c, const uint8_t* d_left, cons
                        c->cfg.width, c->cfg.height, 2 * p0 + 1, 2, p1 - p0);
     TRY(run_extract(c, st, 2 * p0, 2 * (p1 - p0)));
     TRY(run_stereo(c, st, 2 * p0, 2 * p0 + 1, 2, p0, p1 - p0, fx, bf));
-    if (n_chunks > 1) {
+    if (!serial) {
       HIP_TRY(c, hipEventRecord(c->ev_join[k], st));
       HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join[k], 0));
     }
