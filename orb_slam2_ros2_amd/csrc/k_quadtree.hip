@@ -53,10 +53,23 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
   return v;
 }
 
-__device__ __forceinline__ int quadrant_of(uint32_t p, double midx, double midy) {
-  const double x = (double)ORBFE_REC_X(p), y = (double)ORBFE_REC_Y(p);
-  const int qx = (x < midx) ? 0 : ((x > midx) ? 1 : -1);
-  const int qy = (y < midy) ? 0 : ((y > midy) ? 1 : -1);
+// Integer form of the strict fp64 membership test: coordinates are integers, so  x < mid  <=>  x <= ceil(mid) - 1  and
+// x > mid  <=>  x >= floor(mid) + 1  (a point with x == mid, possible only for an integral mid, belongs to neither child).
+struct SplitInt {
+  int x_lt, x_gt, y_lt, y_gt;  // x <= x_lt: left child; x >= x_gt: right child (likewise rows)
+};
+__device__ __forceinline__ SplitInt make_split(double midx, double midy) {
+  SplitInt s;
+  s.x_lt = (int)ceil(midx) - 1;
+  s.x_gt = (int)floor(midx) + 1;
+  s.y_lt = (int)ceil(midy) - 1;
+  s.y_gt = (int)floor(midy) + 1;
+  return s;
+}
+__device__ __forceinline__ int quadrant_of(uint32_t p, const SplitInt& s) {
+  const int x = (int)ORBFE_REC_X(p), y = (int)ORBFE_REC_Y(p);
+  const int qx = (x <= s.x_lt) ? 0 : ((x >= s.x_gt) ? 1 : -1);
+  const int qy = (y <= s.y_lt) ? 0 : ((y >= s.y_gt) ? 1 : -1);
   return (qx >= 0 && qy >= 0) ? (qy * 2 + qx) : -1;  // rows outer, cols inner (ORBExtractor.cc:60-72)
 }
 
@@ -161,12 +174,13 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       n_beg[j] = t5;
     }
     const double midy = (rb + re) / 2, midx = (cb + ce) / 2;
+    const SplitInt sp = make_split(midx, midy);
     uint32_t* seg = H + beg;
     int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     if (n <= 64) {
       // the common case: one record per lane, in-place 4-way partition
       const uint32_t rec = (lane < n) ? seg[lane] : 0u;
-      const int q = (lane < n) ? quadrant_of(rec, midx, midy) : -1;
+      const int q = (lane < n) ? quadrant_of(rec, sp) : -1;
       const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1), m2 = __ballot(q == 2), m3 = __ballot(q == 3);
       c0 = __popcll(m0);
       c1 = __popcll(m1);
@@ -185,7 +199,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       for (int c = 0; c < QT_INPLACE_CHUNKS; ++c) {
         const int i = c * 64 + lane;
         rec[c] = (i < n) ? seg[i] : 0u;
-        q[c] = (i < n) ? quadrant_of(rec[c], midx, midy) : -1;
+        q[c] = (i < n) ? quadrant_of(rec[c], sp) : -1;
       }
 #pragma unroll
       for (int c = 0; c < QT_INPLACE_CHUNKS; ++c)
@@ -210,7 +224,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       int c4[4] = {0, 0, 0, 0};
       for (int b0 = 0; b0 < n; b0 += 64) {
         const int i = b0 + lane;
-        const int q = (i < n) ? quadrant_of(seg[i], midx, midy) : -1;
+        const int q = (i < n) ? quadrant_of(seg[i], sp) : -1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) c4[k] += __popcll(__ballot(q == k));
       }
@@ -222,7 +236,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         int q = -1;
         if (i < n) {
           rec = seg[i];
-          q = quadrant_of(rec, midx, midy);
+          q = quadrant_of(rec, sp);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

@@ -69,7 +69,7 @@ struct orbfe_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   // side streams for the chunked batch path
-  static const int kMaxSide = 4;  // upper bound; ORBFE_STREAMS picks the count (default 2)
+  static const int kMaxSide = 4;  // upper bound; ORBFE_STREAMS picks the count (default 1)
   int n_side = 0;
   hipStream_t side[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
@@ -83,7 +83,8 @@ struct orbfe_ctx {
   int n_cells_total = 0, rs_tiles = 0, bl_tiles = 0;
   size_t img_pitch = 0;      // bytes per image in pyr / blur
   size_t scratch_pitch = 0;  // uint32 records per image
-  int rec_cap = 0;           // candidate records one quadtree wave keeps in LDS
+  int rec_cap = 0;           // upper bound of candidate records one quadtree wave keeps in LDS (launch picks <= this)
+  int n_cu = 256;            // compute units of the device
   int node_cap = 0, sort_cap = 0;
   int max_pw = 0, max_ph = 0;  // largest FAST cell patch (sizes the LDS of k_fast)
 
@@ -320,6 +321,7 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
     for (int l = 0; l < nl; ++l) max_cand = std::max(max_cand, c->lv[l].cand_cap);
     const size_t budget = 150 * 1024 - quadtree_lds_bytes(c->node_cap, 0);
     c->rec_cap = (int)std::min<size_t>(std::min<size_t>(max_cand, 8192), budget / 4);
+    if (const char* env = getenv("ORBFE_QT_REC_CAP")) c->rec_cap = std::max(0, std::min(c->rec_cap, atoi(env)));
   }
   // umax (ORBExtractor::initMaxU)
   {
@@ -430,9 +432,19 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   }
   {
     StageTimer t(c, ORBFE_STAGE_QUADTREE, st);
+    // LDS residency of the candidate records is traded against concurrency: the kernel is latency-bound (one wave per
+    // tree, 40-150 dependent steps), so what matters most is that EVERY tree of the launch is resident at once; the
+    // records go to LDS only as far as that still holds (measured at 1024 trees: 4 trees/CU 0.59 ms, 3 trees/CU 0.96 ms).
+    const int trees = nl * n_img;
+    const int per_cu = (trees + c->n_cu - 1) / c->n_cu;
+    const size_t lds_cu = 160 * 1024 - 2048;
+    const size_t node_bytes = quadtree_lds_bytes(c->node_cap, 0);
+    size_t budget = lds_cu / (size_t)std::max(per_cu, 1);
+    budget -= budget % 512;
+    const int rec_cap = budget > node_bytes ? (int)std::min<size_t>((budget - node_bytes) / 4, (size_t)c->rec_cap) : 0;
     launch_quadtree(st, c->d_lv, nl, c->d_scr_a + i0 * c->scratch_pitch, c->d_scr_b + i0 * c->scratch_pitch,
                     c->d_scr_c + i0 * c->scratch_pitch, c->scratch_pitch, c->d_sel + i0 * NF, c->d_sel_count + i0 * nl,
-                    c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, c->rec_cap, n_img);
+                    c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img);
   }
   {
     StageTimer t(c, ORBFE_STAGE_BRIEF, st);
@@ -522,6 +534,10 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     fail(c, ORBFE_EDEVICE, "hipSetDevice(%d) failed", c->device);
     return bail(ORBFE_EDEVICE);
   }
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && ncu > 0) c->n_cu = ncu;
+  }
   if (cfg->stream) {
     c->stream = (hipStream_t)cfg->stream;
   } else {
@@ -533,7 +549,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   }
   {
     const char* env = getenv("ORBFE_STREAMS");
-    int want = env ? atoi(env) : 2;
+    int want = env ? atoi(env) : 1;
     want = std::min(std::max(want, 1), (int)orbfe_ctx::kMaxSide);
     bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int k = 0; k < want && ok; ++k) {
