@@ -55,22 +55,44 @@ __device__ __forceinline__ int locate_level(const int32_t* __restrict__ sc, int 
 }
 
 // ---------------------------------------------------------------------------------------------
+// 0. level-major keypoint list: one lane per output index.  Every later kernel starts from ONE load of this list
+//    instead of the count-prefix / level-table / selection-record chain of dependent loads.
+//    entry = {x | y << 16 (level coordinates), level | response << 8}; x == 0xFFFF marks "no keypoint".
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_kplist(const LevelDev* __restrict__ lv, int n_levels, const uint32_t* __restrict__ sel,
+                                                const int32_t* __restrict__ sel_count, int n_features, uint2* __restrict__ kpl,
+                                                int32_t* __restrict__ n_kp) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int img = blockIdx.y;
+  if (k >= n_features) return;
+  int j, total;
+  const int level = locate_level(sel_count + (size_t)img * n_levels, n_levels, k, &j, &total);
+  if (k == 0) n_kp[img] = total;
+  uint2 e = make_uint2(0xFFFFu, 0u);
+  if (level >= 0) {
+    const LevelDev& L = lv[level];
+    const uint32_t rec = sel[(size_t)img * n_features + L.quota_off + j];
+    e.x = (ORBFE_REC_X(rec) + ORBFE_EDGE) | ((ORBFE_REC_Y(rec) + ORBFE_EDGE) << 16);
+    e.y = (uint32_t)level | (ORBFE_REC_R(rec) << 8);
+  }
+  kpl[(size_t)img * n_features + k] = e;
+}
+
+// ---------------------------------------------------------------------------------------------
 // 1. intensity-centroid moments, one wave per keypoint.  The 31x31 window of the UN-blurred plane is
 //    read as aligned 32-bit words (5 coalesced wave loads instead of 16 byte gathers).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ic_moments(const LevelDev* __restrict__ lv, int n_levels, const uint8_t* __restrict__ pyr,
-                                                    size_t img_pitch, const uint32_t* __restrict__ sel,
-                                                    const int32_t* __restrict__ sel_count, int n_features, UmaxPacked umax,
+__global__ __launch_bounds__(256) void k_ic_moments(const LevelDev* __restrict__ lv, const uint8_t* __restrict__ pyr,
+                                                    size_t img_pitch, const uint2* __restrict__ kpl, int n_features, UmaxPacked umax,
                                                     int2* __restrict__ moments) {
   const int lane = threadIdx.x & 63;
   const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int img = blockIdx.y;
-  int j, total;
-  const int level = locate_level(sel_count + (size_t)img * n_levels, n_levels, k, &j, &total);
-  if (level < 0) return;  // wave-uniform
-  const LevelDev& L = lv[level];
-  const uint32_t rec = sel[(size_t)img * n_features + L.quota_off + j];
-  const int x = (int)ORBFE_REC_X(rec) + ORBFE_EDGE, y = (int)ORBFE_REC_Y(rec) + ORBFE_EDGE;  // level coordinates
+  if (k >= n_features) return;
+  const uint2 e = kpl[(size_t)img * n_features + k];
+  if ((e.x & 0xFFFFu) == 0xFFFFu) return;  // wave-uniform
+  const LevelDev& L = lv[e.y & 0xFFu];
+  const int x = (int)(e.x & 0xFFFFu), y = (int)(e.x >> 16);  // level coordinates
   const uint8_t* I = pyr + (size_t)img * img_pitch + L.plane_off;
   const int stride = L.stride;
   const int xa = (x - 15) & ~3;  // first aligned word of a row of the window
@@ -105,23 +127,19 @@ __global__ __launch_bounds__(256) void k_ic_moments(const LevelDev* __restrict__
 // 2. orientation: ONE LANE per keypoint.  theta = atan2(m01, m10) and cos/sin in fp64 with the shared
 //    deterministic routines; assembles the cv::KeyPoint record and the stereo row band.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv, int n_levels, const uint32_t* __restrict__ sel,
-                                                const int32_t* __restrict__ sel_count, int n_features,
+__global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv, const uint2* __restrict__ kpl, int n_features,
                                                 const int2* __restrict__ moments, double2* __restrict__ sincos,
                                                 orbfe_keypoint* __restrict__ kps, KpAux* __restrict__ aux, float* __restrict__ kx,
-                                                short2* __restrict__ env, int n_chunks, int32_t* __restrict__ n_kp,
-                                                double* __restrict__ theta_out, int rows0) {
+                                                short2* __restrict__ env, int n_chunks, double* __restrict__ theta_out, int rows0) {
 #pragma clang fp contract(off)
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int img = blockIdx.y;
-  int j, total;
-  const int level = locate_level(sel_count + (size_t)img * n_levels, n_levels, k, &j, &total);
-  if (k == 0) n_kp[img] = total;
+  const uint2 e = (k < n_features) ? kpl[(size_t)img * n_features + k] : make_uint2(0xFFFFu, 0u);
   int row_min = 32767, row_max = -1;
-  if (level >= 0) {
+  if ((e.x & 0xFFFFu) != 0xFFFFu) {
+    const int level = (int)(e.y & 0xFFu);
     const LevelDev& L = lv[level];
-    const uint32_t rec = sel[(size_t)img * n_features + L.quota_off + j];
-    const int x = (int)ORBFE_REC_X(rec) + ORBFE_EDGE, y = (int)ORBFE_REC_Y(rec) + ORBFE_EDGE;
+    const int x = (int)(e.x & 0xFFFFu), y = (int)(e.x >> 16);
     const size_t o = (size_t)img * n_features + k;
     const int2 m = moments[o];
     const double theta = orbmath::det_atan2((double)m.y, (double)m.x);
@@ -133,7 +151,7 @@ __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv,
     kp.y = (float)y * L.sf;
     kp.size = 7.0f;
     kp.angle = (float)(theta / 3.14159265358979323846 * 180);  // ORBExtractor.cc:407
-    kp.response = (float)ORBFE_REC_R(rec);
+    kp.response = (float)((e.y >> 8) & 0xFFu);
     kp.octave = level;
     kp.class_id = -1;
     kps[o] = kp;
@@ -165,22 +183,20 @@ __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv,
 #define BRIEF_ROWS (2 * BRIEF_R + 1)
 #define BRIEF_WORDS 11  // (3 + 37 + 3) / 4 rounded up
 
-__global__ __launch_bounds__(64) void k_brief(const LevelDev* __restrict__ lv, int n_levels, const uint8_t* __restrict__ blur,
-                                              size_t img_pitch, const uint32_t* __restrict__ sel,
-                                              const int32_t* __restrict__ sel_count, int n_features,
-                                              const int8_t* __restrict__ pattern, const double2* __restrict__ sincos,
-                                              uint8_t* __restrict__ desc) {
+__global__ __launch_bounds__(256) void k_brief(const LevelDev* __restrict__ lv, const uint8_t* __restrict__ blur, size_t img_pitch,
+                                              const uint2* __restrict__ kpl, int n_features, const int8_t* __restrict__ pattern,
+                                              const double2* __restrict__ sincos, uint8_t* __restrict__ desc) {
 #pragma clang fp contract(off)
-  __shared__ uint32_t win[BRIEF_ROWS * BRIEF_WORDS];
-  const int lane = threadIdx.x;
-  const int k = blockIdx.x;
+  __shared__ uint32_t win_all[4][BRIEF_ROWS * BRIEF_WORDS + 1];  // one window per wave; the waves never synchronise
+  const int lane = threadIdx.x & 63;
+  uint32_t* win = win_all[threadIdx.x >> 6];
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int img = blockIdx.y;
-  int j, total;
-  const int level = locate_level(sel_count + (size_t)img * n_levels, n_levels, k, &j, &total);
-  if (level < 0) return;  // block-uniform
-  const LevelDev& L = lv[level];
-  const uint32_t rec = sel[(size_t)img * n_features + L.quota_off + j];
-  const int x = (int)ORBFE_REC_X(rec) + ORBFE_EDGE, y = (int)ORBFE_REC_Y(rec) + ORBFE_EDGE;
+  if (k >= n_features) return;
+  const uint2 e = kpl[(size_t)img * n_features + k];
+  if ((e.x & 0xFFFFu) == 0xFFFFu) return;  // wave-uniform
+  const LevelDev& L = lv[e.y & 0xFFu];
+  const int x = (int)(e.x & 0xFFFFu), y = (int)(e.x >> 16);
   const uint8_t* W = blur + (size_t)img * img_pitch + L.plane_off;
   const int stride = L.stride;
   const int xa = (x - BRIEF_R) & ~3;
@@ -193,7 +209,10 @@ __global__ __launch_bounds__(64) void k_brief(const LevelDev* __restrict__ lv, i
   }
   const double2 scv = sincos[(size_t)img * n_features + k];
   const double sn = scv.x, cs = scv.y;
-  __syncthreads();
+  // the LDS accesses of one wave execute in order, so the window written above is visible to every lane of this wave;
+  // the fence only pins the compiler
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   const uint8_t* wb = (const uint8_t*)win;
   const float px = (float)x, py = (float)y;
   const int x_off = xa, y_off = y - BRIEF_R;
@@ -227,16 +246,18 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
                          int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx, short2* d_env, int n_chunks,
-                         int rows0, int n_img) {
+                         uint2* d_kpl, int rows0, int n_img) {
   if (n_img <= 0 || n_features <= 0) return;
   UmaxPacked u = 0;
   for (int i = 0; i < 16; ++i) u |= (unsigned long long)(umax[i] & 15) << (4 * i);
-  hipLaunchKernelGGL(k_ic_moments, dim3((n_features + 3) / 4, n_img), dim3(256), 0, s, d_lv, n_levels, d_pyr, img_pitch, d_sel,
-                     d_sel_count, n_features, u, d_moments);
-  hipLaunchKernelGGL(k_orient, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, n_levels, d_sel, d_sel_count, n_features,
-                     d_moments, d_sincos, d_kps, d_aux, d_kx, d_env, n_chunks, d_n_kp, d_theta, rows0);
-  hipLaunchKernelGGL(k_brief, dim3(n_features, n_img), dim3(64), 0, s, d_lv, n_levels, d_blur, img_pitch, d_sel, d_sel_count,
-                     n_features, d_pattern, d_sincos, d_desc);
+  hipLaunchKernelGGL(k_kplist, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, n_levels, d_sel, d_sel_count, n_features,
+                     d_kpl, d_n_kp);
+  hipLaunchKernelGGL(k_ic_moments, dim3((n_features + 3) / 4, n_img), dim3(256), 0, s, d_lv, d_pyr, img_pitch, d_kpl, n_features, u,
+                     d_moments);
+  hipLaunchKernelGGL(k_orient, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, d_kpl, n_features, d_moments, d_sincos,
+                     d_kps, d_aux, d_kx, d_env, n_chunks, d_theta, rows0);
+  hipLaunchKernelGGL(k_brief, dim3((n_features + 3) / 4, n_img), dim3(256), 0, s, d_lv, d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos,
+                     d_desc);
 }
 
 }  // namespace orbfe

@@ -36,16 +36,27 @@ __device__ __forceinline__ int fdiv20(int i, uint32_t inv) { return (int)(((uint
 __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, const CellDev* __restrict__ cells,
                                              const uint8_t* __restrict__ pyr, size_t img_pitch, int t_hi, int t_lo,
                                              uint32_t* __restrict__ cand, size_t cand_pitch, int32_t* __restrict__ n_cand,
-                                             int n_levels, int lds_v_off, int lds_q_off, int lds_f_off) {
-  extern __shared__ uint32_t lds_w[];
+                                             int n_levels, int n_cells_total, int lds_v_off, int lds_q_off, int lds_f_off, int lds_wave_bytes) {
+  extern __shared__ uint32_t lds_all[];
+  // one cell per single-wave workgroup (four cells per workgroup measured 10 % slower: the LDS of a workgroup stays
+  // allocated until its slowest cell is done).  WAVE_SYNC: the LDS accesses of one wave execute in order, the fence only
+  // pins the compiler -- no s_barrier needed.
+#define WAVE_SYNC()                                          \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                         \
+  } while (0)
+  uint32_t* lds_w = lds_all;
   uint8_t* P = (uint8_t*)lds_w;              // patch rows, pitch = pitch_p bytes, pixel (r,c) at P[r*pitch_p + xa + c]
   uint8_t* V = (uint8_t*)lds_w + lds_v_off;  // (ih+2) x (iw+2) scores with a zero border, pixel (iy,ix) at V[(iy+1)*pv + ix+1]
   uint16_t* Q = (uint16_t*)((uint8_t*)lds_w + lds_q_off);  // survivors: interior index i = iy*iw + ix, raster order
   uint8_t* F = (uint8_t*)lds_w + lds_f_off;  // per queue entry: bit0 = max & V>lo, bit1 = max & V>hi
 
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int img = blockIdx.y;
-  const CellDev cell = cells[blockIdx.x];
+  const int cell_id = blockIdx.x;
+  if (cell_id >= n_cells_total) return;
+  const CellDev cell = cells[cell_id];
   const LevelDev& L = lv[cell.level];
   const int pw = cell.pw, ph = cell.ph;
   const int iw = pw - 6, ih = ph - 6;  // interior cv::FAST scans: rows/cols 3 .. size-4
@@ -72,7 +83,7 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
     uint32_t* V32 = (uint32_t*)V;
     for (int k = lane; k < vwords; k += 64) V32[k] = 0;
   }
-  __syncthreads();
+  WAVE_SYNC();
 
   // ---- 2. necessary test on every interior pixel, survivors -> queue (raster order) ----
   int nq = 0;
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
       nq += __popcll(m);
     }
   }
-  __syncthreads();
+  WAVE_SYNC();
 
   // ---- 3. exact test + score for the survivors ----
   {
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
       if (vv > t_min) V[(iy + 1) * pv + ix + 1] = (uint8_t)min(255, vv);
     }
   }
-  __syncthreads();
+  WAVE_SYNC();
 
   // ---- 4. NMS over the queue, hi/lo decision, append to the level's candidate list ----
   int n_hi = 0, n_lo = 0;
@@ -172,7 +183,7 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
       n_lo += __popcll(__ballot((f & 1) != 0));
     }
   }
-  __syncthreads();
+  WAVE_SYNC();
   {
     // cv::FAST(hi) result if non-empty, else cv::FAST(lo) (ORBExtractor.cc:365-367).  The list of a level is a SET:
     // the quadtree orders candidates by (cell, y, x) recomputed from the coordinates, so cells may append in any
@@ -222,8 +233,9 @@ void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, in
   if (n_cells_total <= 0 || n_img <= 0) return;
   int v_off, q_off, f_off, total;
   fast_lds_layout(max_pw, max_ph, &v_off, &q_off, &f_off, &total);
-  hipLaunchKernelGGL(k_fast, dim3(n_cells_total, n_img), dim3(64), total, s, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo, d_cand,
-                     cand_pitch, d_n_cand, n_levels, v_off, q_off, f_off);
+  total = (total + 15) & ~15;
+  hipLaunchKernelGGL(k_fast, dim3(n_cells_total, n_img), dim3(64), total, s, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo,
+                     d_cand, cand_pitch, d_n_cand, n_levels, n_cells_total, v_off, q_off, f_off, total);
 }
 
 }  // namespace orbfe

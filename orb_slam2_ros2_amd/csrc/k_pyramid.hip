@@ -159,18 +159,28 @@ __global__ __launch_bounds__(256) void k_blur(const LevelDev* __restrict__ lv, i
   const int n_out = min(BLUR_ROWS, h - y0);
   const int n_in = n_out + 6;
   for (int r0 = 0; r0 < n_in; r0 += 7) {
+    // issue the (up to) seven row loads of this group back to back: seven requests in flight per lane hide the
+    // memory latency that a load-use-load-use chain would expose 38 times per wave
+    uint32_t mrow[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int r = r0 + u;
+      mrow[u] = 0;
+      if (r < n_in) {  // wave-uniform
+        const int gy = reflect101(y0 + r - 3, h);
+        const uint8_t* row = P + (size_t)gy * stride;
+        if (fast_word) {
+          mrow[u] = *(const uint32_t*)(row + x4);
+        } else {
+          mrow[u] = (uint32_t)row[rx[0]] | ((uint32_t)row[rx[1]] << 8) | ((uint32_t)row[rx[2]] << 16) | ((uint32_t)row[rx[3]] << 24);
+        }
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 7; ++u) {
       const int r = r0 + u;
       if (r < n_in) {  // wave-uniform
-        const int gy = reflect101(y0 + r - 3, h);
-        const uint8_t* row = P + (size_t)gy * stride;
-        uint32_t m;
-        if (fast_word) {
-          m = *(const uint32_t*)(row + x4);
-        } else {
-          m = (uint32_t)row[rx[0]] | ((uint32_t)row[rx[1]] << 8) | ((uint32_t)row[rx[2]] << 16) | ((uint32_t)row[rx[3]] << 24);
-        }
+        const uint32_t m = mrow[u];
         const uint32_t lw = wave_shr1(m), rw = wave_shl1(m);
         // bytes B[0..11] = lw|m|rw; output j needs px[j-3..j+3] = B[1+j .. 7+j]: two unaligned 4-byte windows per
         // output (v_alignbyte) fed to two v_dot4_u32_u8 against the packed taps {t0..t3} and {t4..t6,0}
