@@ -119,7 +119,20 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
   const int sl = slot_l0 + blockIdx.y * slot_step, sr = slot_r0 + blockIdx.y * slot_step;
   const size_t out_i = (size_t)pair * n_features + li;
   if (li >= n_features) return;
+  const orbfe_keypoint* LK = kps + (size_t)sl * n_features;
+  const orbfe_keypoint* RK = kps + (size_t)sr * n_features;
+  const uint8_t* LD = desc + (size_t)sl * n_features * 32;
+  const uint8_t* RD = desc + (size_t)sr * n_features * 32;
+  const KpAux* RA = aux + (size_t)sr * n_features;
+  const float* RX = kx + (size_t)sr * n_features;
+  const short2* RE = env + (size_t)sr * n_chunks;
+  // first round trip: counts, the left keypoint, its descriptor and the chunk envelopes are all independent loads
+  // (slot li always exists in the buffers; whether it holds a keypoint is decided after the loads are in flight)
   const int nl = n_kp[sl], nr = n_kp[sr];
+  const orbfe_keypoint l = LK[li];
+  const uint4 a0 = *(const uint4*)(LD + (size_t)li * 32);
+  const uint4 a1 = *(const uint4*)(LD + (size_t)li * 32 + 16);
+  const short2 env0 = (lane < n_chunks) ? RE[lane] : make_short2(0, 0);
   if (li >= nl) {
     if (lane == 0) {
       right_u[out_i] = -1.0;
@@ -129,20 +142,9 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
     }
     return;
   }
-  const orbfe_keypoint* LK = kps + (size_t)sl * n_features;
-  const orbfe_keypoint* RK = kps + (size_t)sr * n_features;
-  const uint8_t* LD = desc + (size_t)sl * n_features * 32;
-  const uint8_t* RD = desc + (size_t)sr * n_features * 32;
-  const KpAux* RA = aux + (size_t)sr * n_features;
-  const float* RX = kx + (size_t)sr * n_features;
-  const short2* RE = env + (size_t)sr * n_chunks;
-
-  const orbfe_keypoint l = LK[li];
   const float max_u = l.x - 0;
   const float min_u = fmaxf(0.f, l.x - fx);
   const int row = __float2int_rn(l.y);
-  const uint4 a0 = *(const uint4*)(LD + (size_t)li * 32);
-  const uint4 a1 = *(const uint4*)(LD + (size_t)li * 32 + 16);
 
   // candidates = rowIdxDB[row] filtered by the u-range, in ascending right index (ORBMatcher.cc:38-48).
   // Keypoints are stored level-major / cell-row-major, so a chunk of 64 consecutive right keypoints covers a narrow
@@ -154,24 +156,45 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
     const int ch = cb + lane;
     bool hit = false;
     if (ch < used_chunks) {
-      const short2 e = RE[ch];
+      const short2 e = (cb == 0) ? env0 : RE[ch];
       hit = row >= (int)e.x && row < (int)e.y;
     }
     unsigned long long todo = __ballot(hit);
+    // four hit chunks per step: their filter loads, then their descriptor loads, are issued together (two dependent
+    // memory round trips per four chunks instead of eight); the order-dependent fold then runs chunk by chunk
     while (todo) {
-      const int cbit = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      const int c = ((cb + cbit) << 6) + lane;
-      bool pass = false;
-      if (c < nr) {
-        const KpAux a = RA[c];
-        const float rx = RX[c];
-        pass = row >= a.row_min && row < a.row_max && rx < max_u && rx > min_u;
+      int cid[4];
+      bool pass[4];
+      int d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        cid[u] = -1;
+        if (todo) {
+          cid[u] = cb + (__ffsll((long long)todo) - 1);
+          todo &= todo - 1;
+        }
       }
-      if (__ballot(pass) == 0ull) continue;
-      any = true;
-      const int d = pass ? hamming256(a0, a1, RD + (size_t)c * 32) : ORB_INT_MAX;
-      fold_chunk(b, d, c, lane);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        pass[u] = false;
+        const int c = (cid[u] << 6) + lane;
+        if (cid[u] >= 0 && c < nr) {
+          const KpAux a = RA[c];
+          const float rx = RX[c];
+          pass[u] = row >= a.row_min && row < a.row_max && rx < max_u && rx > min_u;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = (cid[u] << 6) + lane;
+        d[u] = pass[u] ? hamming256(a0, a1, RD + (size_t)c * 32) : ORB_INT_MAX;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (cid[u] < 0 || __ballot(pass[u]) == 0ull) continue;  // wave-uniform
+        any = true;
+        fold_chunk(b, d[u], (cid[u] << 6) + lane, lane);
+      }
     }
   }
   double out_u = -1.0, out_depth = -1.0;
