@@ -162,6 +162,20 @@ typedef struct orbfe_ba_edge_out {
 
 orbfe_status orbfe_ba_eval_edges(orbfe_ctx* ctx, const orbfe_ba_problem* prob, const orbfe_ba_edge_out* out);
 
+/* Normal-equation blocks of one linearisation, laid out like g2o's BlockSolver_6_3 (src/Optimizer.h:49-54): replaces
+ * BaseBinaryEdge::constructQuadraticForm over all edges (what optimizer.optimize() runs per LM iteration under
+ * Optimizer::OptimizeLocalMap, src/Optimizer.cc:336,361).  W = rho'(chi2) * info * I per edge (Huber as configured);
+ * pose_fixed[k] != 0 => vertex k gets no blocks (setFixed, Optimizer.cc:248,288); points are the marginalised set.  */
+typedef struct orbfe_ba_system_out {
+  double* Hpp;  /* [n_poses][6][6]  sum B^T W B            (zero for fixed poses)                         */
+  double* bp;   /* [n_poses][6]     - sum B^T W e                                                          */
+  double* Hll;  /* [n_points][3][3] sum A^T W A                                                            */
+  double* bl;   /* [n_points][3]    - sum A^T W e                                                          */
+  double* Hpl;  /* [n_edges][6][3]  B^T W A of the edge (zero if its pose is fixed), nullable              */
+} orbfe_ba_system_out;
+orbfe_status orbfe_ba_build_system(orbfe_ctx* ctx, const orbfe_ba_problem* prob, const uint8_t* pose_fixed /*[n_poses], nullable*/,
+                                   const orbfe_ba_system_out* out);
+
 /* ---- instrumentation ---------------------------------------------------------------------------
  * Stage timing with HIP events on the context stream.  Enable, run, then read the accumulated
  * per-stage milliseconds and launch counts.  Stage ids: see orbfe_stage.                             */

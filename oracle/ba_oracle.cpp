@@ -141,6 +141,63 @@ void orc_ba_eval_edges(int n_edges, const double* poses, const double* points, c
   }
 }
 
+// g2o BaseBinaryEdge::constructQuadraticForm for every active edge, accumulated the way BlockSolver_6_3 lays the system out:
+// vertex 0 = point (Xi, Jacobian A), vertex 1 = pose (Xj, Jacobian B).  With Omega = info*I and w = rho'(chi2) (Huber) or 1:
+//   b_point -= A^T (w Omega) e        H_ll += A^T (w Omega) A
+//   b_pose  -= B^T (w Omega) e        H_pp += B^T (w Omega) B        H_pl(e) = B^T (w Omega) A      (pose not fixed)
+// Points are never fixed in the local BA (they are the marginalised set, Optimizer.cc:265); fixed poses get no blocks.
+void orc_ba_build_system(int n_poses, int n_points, int n_edges, const double* poses, const double* points, const int32_t* edge_pose,
+                         const int32_t* edge_point, const double* meas, const uint8_t* is_stereo, const double* info, const double* delta,
+                         double fx, double fy, double cx, double cy, double bf, const uint8_t* pose_fixed, double* Hpp, double* bp,
+                         double* Hll, double* bl, double* Hpl, double* chi2_robust_sum) {
+  std::vector<double> err((size_t)n_edges * 3), chi2(n_edges), rho((size_t)n_edges * 2), jp((size_t)n_edges * 9), jx((size_t)n_edges * 18);
+  orc_ba_eval_edges(n_edges, poses, points, edge_pose, edge_point, meas, is_stereo, info, delta, fx, fy, cx, cy, bf, err.data(),
+                    chi2.data(), rho.data(), jp.data(), jx.data(), nullptr);
+  std::memset(Hpp, 0, sizeof(double) * 36 * n_poses);
+  std::memset(bp, 0, sizeof(double) * 6 * n_poses);
+  std::memset(Hll, 0, sizeof(double) * 9 * n_points);
+  std::memset(bl, 0, sizeof(double) * 3 * n_points);
+  double total = 0;
+  for (int e = 0; e < n_edges; ++e) {
+    const int rows = is_stereo[e] ? 3 : 2;
+    const double w = rho[(size_t)e * 2 + 1] * info[e];
+    const double* A = &jp[(size_t)e * 9];
+    const double* B = &jx[(size_t)e * 18];
+    const double* er = &err[(size_t)e * 3];
+    const int pi = edge_point[e], ki = edge_pose[e];
+    total += rho[(size_t)e * 2];
+    for (int a = 0; a < 3; ++a) {
+      double s = 0;
+      for (int r = 0; r < rows; ++r) s += A[3 * r + a] * (w * er[r]);
+      bl[(size_t)pi * 3 + a] -= s;
+      for (int c = 0; c < 3; ++c) {
+        double h = 0;
+        for (int r = 0; r < rows; ++r) h += A[3 * r + a] * w * A[3 * r + c];
+        Hll[(size_t)pi * 9 + 3 * a + c] += h;
+      }
+    }
+    if (Hpl) std::memset(Hpl + (size_t)e * 18, 0, sizeof(double) * 18);
+    if (pose_fixed && pose_fixed[ki]) continue;
+    for (int a = 0; a < 6; ++a) {
+      double s = 0;
+      for (int r = 0; r < rows; ++r) s += B[6 * r + a] * (w * er[r]);
+      bp[(size_t)ki * 6 + a] -= s;
+      for (int c = 0; c < 6; ++c) {
+        double h = 0;
+        for (int r = 0; r < rows; ++r) h += B[6 * r + a] * w * B[6 * r + c];
+        Hpp[(size_t)ki * 36 + 6 * a + c] += h;
+      }
+      if (Hpl)
+        for (int c = 0; c < 3; ++c) {
+          double h = 0;
+          for (int r = 0; r < rows; ++r) h += B[6 * r + a] * w * A[3 * r + c];
+          Hpl[(size_t)e * 18 + 3 * a + c] = h;
+        }
+    }
+  }
+  if (chi2_robust_sum) *chi2_robust_sum = total;
+}
+
 // SE3Quat::exp(update) * T  -- VertexSE3Expmap::oplusImpl; update = (omega, upsilon).  Used by the
 // finite-difference Jacobian check in tests.
 void orc_se3_oplus(const double* T, const double* upd, double* out) {

@@ -63,6 +63,7 @@ class Oracle:
         L.orc_extractor_describe.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_ba_eval_edges.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_double] * 5 + [C.c_void_p] * 6
         L.orc_se3_oplus.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_ba_build_system.argtypes = [C.c_int] * 3 + [C.c_void_p] * 8 + [C.c_double] * 5 + [C.c_void_p] * 7
         L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_gauss7_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.orc_fast9_16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -152,6 +153,25 @@ class Oracle:
         self.lib.orc_ba_eval_edges(E, _p(poses), _p(points), _p(edge_pose), _p(edge_point), _p(meas), _p(is_stereo), _p(info),
                                    _p(huber_delta), fx, fy, cx, cy, bf, _p(out["error"]), _p(out["chi2"]), _p(out["rho"]),
                                    _p(out["j_point"]), _p(out["j_pose"]), _p(out["depth_positive"]))
+        return out
+
+    def ba_build_system(self, poses, points, edge_pose, edge_point, meas, is_stereo, info, huber_delta, fx, fy, cx, cy, bf, pose_fixed):
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+        points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+        edge_pose = np.ascontiguousarray(edge_pose, np.int32)
+        edge_point = np.ascontiguousarray(edge_point, np.int32)
+        meas = np.ascontiguousarray(meas, np.float64).reshape(-1, 3)
+        is_stereo = np.ascontiguousarray(is_stereo, np.uint8)
+        info = np.ascontiguousarray(info, np.float64)
+        huber_delta = np.ascontiguousarray(huber_delta, np.float64)
+        pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8)
+        nk, npt, E = poses.shape[0], points.shape[0], edge_pose.size
+        out = dict(Hpp=np.zeros((nk, 6, 6)), bp=np.zeros((nk, 6)), Hll=np.zeros((npt, 3, 3)), bl=np.zeros((npt, 3)), Hpl=np.zeros((E, 6, 3)))
+        tot = C.c_double(0)
+        self.lib.orc_ba_build_system(nk, npt, E, _p(poses), _p(points), _p(edge_pose), _p(edge_point), _p(meas), _p(is_stereo), _p(info),
+                                     _p(huber_delta), fx, fy, cx, cy, bf, _p(pose_fixed), _p(out["Hpp"]), _p(out["bp"]), _p(out["Hll"]),
+                                     _p(out["bl"]), _p(out["Hpl"]), C.byref(tot))
+        out["chi2_robust"] = tot.value
         return out
 
     def se3_oplus(self, T, upd):

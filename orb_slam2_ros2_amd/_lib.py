@@ -52,6 +52,10 @@ class BaProblem(C.Structure):
                 ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double)]
 
 
+class BaSystemOut(C.Structure):
+    _fields_ = [("Hpp", C.c_void_p), ("bp", C.c_void_p), ("Hll", C.c_void_p), ("bl", C.c_void_p), ("Hpl", C.c_void_p)]
+
+
 class BaEdgeOut(C.Structure):
     _fields_ = [("error", C.c_void_p), ("chi2", C.c_void_p), ("rho", C.c_void_p), ("j_point", C.c_void_p),
                 ("j_pose", C.c_void_p), ("depth_positive", C.c_void_p)]
@@ -60,7 +64,7 @@ class BaEdgeOut(C.Structure):
 EXPORTS = [
     "orbfe_abi_version", "orbfe_create", "orbfe_destroy", "orbfe_last_error", "orbfe_get_level_info", "orbfe_get_scale_factors",
     "orbfe_extract", "orbfe_extract_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
-    "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges",
+    "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system",
     "orbfe_profile_enable", "orbfe_profile_read", "orbfe_stage_name", "orbfe_debug_candidates",
 ]
 
@@ -103,6 +107,7 @@ def load() -> C.CDLL:
     L.orbfe_device_results.argtypes = [vp] + [C.POINTER(vp)] * 6
     L.orbfe_match_bruteforce.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]
     L.orbfe_ba_eval_edges.argtypes = [vp, C.POINTER(BaProblem), C.POINTER(BaEdgeOut)]
+    L.orbfe_ba_build_system.argtypes = [vp, C.POINTER(BaProblem), vp, C.POINTER(BaSystemOut)]
     L.orbfe_profile_enable.argtypes = [vp, i32]
     L.orbfe_profile_read.argtypes = [vp, vp, vp, i32]
     L.orbfe_stage_name.argtypes = [i32]
@@ -271,6 +276,28 @@ class Context:
                       ptr(out["j_point"]).value if jacobians else None, ptr(out["j_pose"]).value if jacobians else None,
                       ptr(out["depth_positive"]).value)
         self._check(self.lib.orbfe_ba_eval_edges(self.h, C.byref(prob), C.byref(o)))
+        return out
+
+    def ba_build_system(self, poses, points, edge_pose, edge_point, meas, is_stereo, info, huber_delta, fx, fy, cx, cy, bf,
+                        pose_fixed=None, want_hpl=True):
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+        points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+        edge_pose = np.ascontiguousarray(edge_pose, np.int32)
+        edge_point = np.ascontiguousarray(edge_point, np.int32)
+        meas = np.ascontiguousarray(meas, np.float64).reshape(-1, 3)
+        is_stereo = np.ascontiguousarray(is_stereo, np.uint8)
+        info = np.ascontiguousarray(info, np.float64)
+        huber_delta = np.ascontiguousarray(huber_delta, np.float64)
+        fixed = None if pose_fixed is None else np.ascontiguousarray(pose_fixed, np.uint8)
+        nk, npt, E = poses.shape[0], points.shape[0], edge_pose.size
+        prob = BaProblem(nk, npt, E, ptr(poses).value, ptr(points).value, ptr(edge_pose).value, ptr(edge_point).value,
+                         ptr(meas).value, ptr(is_stereo).value, ptr(info).value, ptr(huber_delta).value, fx, fy, cx, cy, bf)
+        out = dict(Hpp=np.zeros((nk, 6, 6)), bp=np.zeros((nk, 6)), Hll=np.zeros((npt, 3, 3)), bl=np.zeros((npt, 3)))
+        if want_hpl:
+            out["Hpl"] = np.zeros((E, 6, 3))
+        o = BaSystemOut(ptr(out["Hpp"]).value, ptr(out["bp"]).value, ptr(out["Hll"]).value, ptr(out["bl"]).value,
+                        ptr(out["Hpl"]).value if want_hpl else None)
+        self._check(self.lib.orbfe_ba_build_system(self.h, C.byref(prob), ptr(fixed), C.byref(o)))
         return out
 
     # ---- instrumentation ------------------------------------------------------------------------

@@ -50,6 +50,11 @@ void launch_ba_edges(hipStream_t s, int n_edges, const double* d_poses, const do
                      const int32_t* d_edge_point, const double* d_meas, const uint8_t* d_is_stereo, const double* d_info,
                      const double* d_delta, BaParamsDev prm, double* d_error, double* d_chi2, double* d_rho, double* d_jpoint,
                      double* d_jpose, uint8_t* d_depth_pos);
+void launch_ba_system(hipStream_t s, int n_poses, int n_points, int n_edges, const double* poses, const double* points,
+                      const int32_t* edge_pose, const int32_t* edge_point, const double* meas, const uint8_t* is_stereo,
+                      const double* info, const double* delta, BaParamsDev prm, const uint8_t* pose_fixed, const int32_t* pt_off,
+                      const int32_t* pt_edges, const int32_t* ps_off, const int32_t* ps_edges, double* Hpp, double* bp, double* Hll,
+                      double* bl, double* Hpl);
 }  // namespace orbfe
 
 using namespace orbfe;
@@ -876,6 +881,84 @@ orbfe_status orbfe_ba_eval_edges(orbfe_ctx* c, const orbfe_ba_problem* p, const 
   if (o->j_point) HIP_TRY(c, hipMemcpyAsync(o->j_point, b + o_jpt, (size_t)E * 72, hipMemcpyDeviceToHost, c->stream));
   if (o->j_pose) HIP_TRY(c, hipMemcpyAsync(o->j_pose, b + o_jps, (size_t)E * 144, hipMemcpyDeviceToHost, c->stream));
   if (o->depth_positive) HIP_TRY(c, hipMemcpyAsync(o->depth_positive, b + o_dp, (size_t)E, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_ba_build_system(orbfe_ctx* c, const orbfe_ba_problem* p, const uint8_t* pose_fixed, const orbfe_ba_system_out* o) {
+  if (!c || !p || !o) return fail(c, ORBFE_EBADARG, "ba_build_system: NULL argument");
+  const int E = p->n_edges, NK = p->n_poses, NP = p->n_points;
+  if (E < 0 || NK < 0 || NP < 0) return fail(c, ORBFE_EBADARG, "ba_build_system: negative size");
+  if (!o->Hpp || !o->bp || !o->Hll || !o->bl) return fail(c, ORBFE_EBADARG, "ba_build_system: NULL output");
+  if (E && (!p->poses || !p->points || !p->edge_pose || !p->edge_point || !p->meas || !p->is_stereo || !p->info || !p->huber_delta))
+    return fail(c, ORBFE_EBADARG, "ba_build_system: NULL array");
+  for (int e = 0; e < E; ++e)
+    if (p->edge_pose[e] < 0 || p->edge_pose[e] >= NK || p->edge_point[e] < 0 || p->edge_point[e] >= NP)
+      return fail(c, ORBFE_EBADARG, "ba_build_system: edge %d references vertex out of range", e);
+  HIP_TRY(c, hipSetDevice(c->device));
+  // vertex -> edges lists, edges in ascending index (counting sort): the summation order of the segmented reductions
+  std::vector<int32_t> pt_off(NP + 1, 0), ps_off(NK + 1, 0), pt_edges(std::max(E, 1)), ps_edges(std::max(E, 1));
+  for (int e = 0; e < E; ++e) {
+    ++pt_off[p->edge_point[e] + 1];
+    ++ps_off[p->edge_pose[e] + 1];
+  }
+  for (int i = 0; i < NP; ++i) pt_off[i + 1] += pt_off[i];
+  for (int i = 0; i < NK; ++i) ps_off[i + 1] += ps_off[i];
+  {
+    std::vector<int32_t> pc(pt_off.begin(), pt_off.end() - 1), kc(ps_off.begin(), ps_off.end() - 1);
+    for (int e = 0; e < E; ++e) {
+      pt_edges[pc[p->edge_point[e]]++] = e;
+      ps_edges[kc[p->edge_pose[e]]++] = e;
+    }
+  }
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o2 = off;
+    off += align_up(std::max<size_t>(bytes, 8), 256);
+    return o2;
+  };
+  const size_t o_pose = take((size_t)NK * 56), o_pt = take((size_t)NP * 24), o_ep = take((size_t)E * 4), o_et = take((size_t)E * 4),
+               o_meas = take((size_t)E * 24), o_st = take((size_t)E), o_info = take((size_t)E * 8), o_delta = take((size_t)E * 8),
+               o_fix = take((size_t)NK), o_pto = take((size_t)(NP + 1) * 4), o_pte = take((size_t)E * 4), o_pso = take((size_t)(NK + 1) * 4),
+               o_pse = take((size_t)E * 4), o_hpp = take((size_t)NK * 288), o_bp = take((size_t)NK * 48), o_hll = take((size_t)NP * 72),
+               o_bl = take((size_t)NP * 24), o_hpl = take((size_t)E * 144);
+  TRY(ensure_tmp(c, off));
+  uint8_t* b = (uint8_t*)c->d_tmp;
+  auto up = [&](size_t o2, const void* src, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpyAsync(b + o2, src, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+  };
+  HIP_TRY(c, up(o_pose, p->poses, (size_t)NK * 56));
+  HIP_TRY(c, up(o_pt, p->points, (size_t)NP * 24));
+  HIP_TRY(c, up(o_ep, p->edge_pose, (size_t)E * 4));
+  HIP_TRY(c, up(o_et, p->edge_point, (size_t)E * 4));
+  HIP_TRY(c, up(o_meas, p->meas, (size_t)E * 24));
+  HIP_TRY(c, up(o_st, p->is_stereo, (size_t)E));
+  HIP_TRY(c, up(o_info, p->info, (size_t)E * 8));
+  HIP_TRY(c, up(o_delta, p->huber_delta, (size_t)E * 8));
+  if (pose_fixed) HIP_TRY(c, up(o_fix, pose_fixed, (size_t)NK));
+  HIP_TRY(c, up(o_pto, pt_off.data(), (size_t)(NP + 1) * 4));
+  HIP_TRY(c, up(o_pte, pt_edges.data(), (size_t)E * 4));
+  HIP_TRY(c, up(o_pso, ps_off.data(), (size_t)(NK + 1) * 4));
+  HIP_TRY(c, up(o_pse, ps_edges.data(), (size_t)E * 4));
+  BaParamsDev prm = {p->fx, p->fy, p->cx, p->cy, p->bf};
+  {
+    StageTimer tm(c, ORBFE_STAGE_BA, c->stream);
+    launch_ba_system(c->stream, NK, NP, E, (const double*)(b + o_pose), (const double*)(b + o_pt), (const int32_t*)(b + o_ep),
+                     (const int32_t*)(b + o_et), (const double*)(b + o_meas), b + o_st, (const double*)(b + o_info),
+                     (const double*)(b + o_delta), prm, pose_fixed ? b + o_fix : nullptr, (const int32_t*)(b + o_pto),
+                     (const int32_t*)(b + o_pte), (const int32_t*)(b + o_pso), (const int32_t*)(b + o_pse), (double*)(b + o_hpp),
+                     (double*)(b + o_bp), (double*)(b + o_hll), (double*)(b + o_bl), o->Hpl ? (double*)(b + o_hpl) : nullptr);
+  }
+  HIP_TRY(c, hipGetLastError());
+  auto down = [&](void* dst, size_t o2, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpyAsync(dst, b + o2, bytes, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
+  };
+  HIP_TRY(c, down(o->Hpp, o_hpp, (size_t)NK * 288));
+  HIP_TRY(c, down(o->bp, o_bp, (size_t)NK * 48));
+  HIP_TRY(c, down(o->Hll, o_hll, (size_t)NP * 72));
+  HIP_TRY(c, down(o->bl, o_bl, (size_t)NP * 24));
+  if (o->Hpl) HIP_TRY(c, down(o->Hpl, o_hpl, (size_t)E * 144));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_timers(c);
   return ORBFE_OK;

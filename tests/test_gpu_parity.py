@@ -215,6 +215,24 @@ def test_ba_edges_match_oracle(orc, kitti_ctx):
     assert np.array_equal(lean["chi2"], out["chi2"])
 
 
+def test_ba_normal_equation_blocks_match_oracle(orc, kitti_ctx):
+    p = ba_synth.make_problem()
+    nk = p["poses"].shape[0]
+    fixed = np.zeros(nk, np.uint8)
+    fixed[0] = 1
+    fixed[30:] = 1          # 29 free keyframes + KF0 fixed + 30 fixed observers
+    out = kitti_ctx.ba_build_system(**p, pose_fixed=fixed)
+    ref = orc.ba_build_system(**p, pose_fixed=fixed)
+    for k in ("Hpp", "bp", "Hll", "bl", "Hpl"):
+        scale = np.abs(ref[k]).max()
+        assert np.allclose(out[k], ref[k], rtol=1e-9, atol=1e-12 * scale), k
+    assert not out["Hpp"][0].any() and not out["Hpp"][30:].any() and out["Hpp"][1:30].any()
+    again = kitti_ctx.ba_build_system(**p, pose_fixed=fixed)
+    assert all(np.array_equal(out[k], again[k]) for k in out)   # segmented sums, no atomics: run-to-run identical
+    free = kitti_ctx.ba_build_system(**p, pose_fixed=None, want_hpl=False)
+    assert free["Hpp"][45].any() and "Hpl" not in free
+
+
 def test_error_paths(lib, kitti_ctx):
     with pytest.raises(lib.ImageSizeError):
         lib.Context(130, 100)           # level 7 below 38 px (ORBExtractor.cc:310-314)

@@ -91,3 +91,37 @@ def test_depth_positive_flag(orc, prob):
     pts = prob["points"].copy()
     pts[:, 2] -= 100.0
     assert not _eval(orc, prob, points=pts)["depth_positive"].any()
+
+
+def test_normal_equation_blocks_are_consistent_with_the_edge_outputs(orc, prob):
+    """H/b of constructQuadraticForm restated two ways: the oracle's accumulation vs numpy einsum over its edge outputs."""
+    nk = prob["poses"].shape[0]
+    fixed = np.zeros(nk, np.uint8)
+    fixed[0] = 1
+    fixed[nk // 2:] = 1
+    s = orc.ba_build_system(**prob, pose_fixed=fixed)
+    o = _eval(orc, prob)
+    w = o["rho"][:, 1] * prob["info"]
+    E = w.size
+    Hll = np.zeros_like(s["Hll"])
+    bl = np.zeros_like(s["bl"])
+    Hpp = np.zeros_like(s["Hpp"])
+    bp = np.zeros_like(s["bp"])
+    for e in range(E):
+        A, B, er = o["j_point"][e], o["j_pose"][e], o["error"][e]
+        p, k = prob["edge_point"][e], prob["edge_pose"][e]
+        Hll[p] += w[e] * A.T @ A
+        bl[p] -= w[e] * A.T @ er
+        if not fixed[k]:
+            Hpp[k] += w[e] * B.T @ B
+            bp[k] -= w[e] * B.T @ er
+            assert np.allclose(s["Hpl"][e], w[e] * B.T @ A, rtol=1e-12, atol=1e-9)
+        else:
+            assert not s["Hpl"][e].any()
+    for a, b in ((s["Hll"], Hll), (s["bl"], bl), (s["Hpp"], Hpp), (s["bp"], bp)):
+        assert np.allclose(a, b, rtol=1e-11, atol=1e-7)
+    assert not s["Hpp"][0].any() and s["Hpp"][1].any()
+    assert s["chi2_robust"] == pytest.approx(o["rho"][:, 0].sum(), rel=1e-13)
+    # Schur-reducible: every H_ll block of an observed point is symmetric positive definite
+    obs = np.unique(prob["edge_point"])
+    assert np.all(np.linalg.eigvalsh(s["Hll"][obs]) > 0)
