@@ -119,6 +119,8 @@ struct orbfe_ctx {
   size_t tmp_bytes = 0;
   // pinned host staging for small result reads
   int32_t* h_counts = nullptr;
+  uint8_t* h_stage = nullptr;  // pinned staging of the host-pointer API
+  size_t h_stage_bytes = 0;
 
   // profiling
   bool prof = false;
@@ -372,6 +374,22 @@ static orbfe_status ensure_tmp(orbfe_ctx* c, size_t bytes) {
   return ORBFE_OK;
 }
 
+// Pinned staging for the host-pointer API, grown on demand.  Layout per image: level-0 plane with the device row pitch
+// (one contiguous DMA instead of a pageable 2-D copy), then the full keypoint and descriptor arrays.
+static orbfe_status ensure_stage(orbfe_ctx* c, size_t bytes) {
+  if (bytes <= c->h_stage_bytes) return ORBFE_OK;
+  if (c->h_stage) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipHostFree(c->h_stage));
+    c->h_stage = nullptr;
+    c->h_stage_bytes = 0;
+  }
+  bytes = align_up(bytes, 1 << 20);
+  HIP_TRY(c, hipHostMalloc((void**)&c->h_stage, bytes, hipHostMallocDefault));
+  c->h_stage_bytes = bytes;
+  return ORBFE_OK;
+}
+
 // ---- stage timing ---------------------------------------------------------------------------------
 struct StageTimer {
   orbfe_ctx* c;
@@ -501,7 +519,8 @@ void orbfe_destroy(orbfe_ctx* c) {
                   c->d_best_right, c->d_best_dist, c->d_tmp};
   for (void* p : ptrs)
     if (p) hipFree(p);
-  if (c->h_counts) hipHostFree(c->h_counts);
+  if (c->h_counts) (void)hipHostFree(c->h_counts);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (int k = 0; k < orbfe_ctx::kMaxSide; ++k) {
     if (c->side[k]) (void)hipStreamDestroy(c->side[k]);
     if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
@@ -690,14 +709,22 @@ orbfe_status orbfe_fetch_stereo(orbfe_ctx* c, int32_t pair, double* right_u, dou
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t NF = (size_t)c->cfg.n_features;
   const size_t o = (size_t)pair * NF;
-  if (right_u && NF) HIP_TRY(c, hipMemcpyAsync(right_u, c->d_right_u + o, sizeof(double) * NF, hipMemcpyDeviceToHost, c->stream));
-  if (depth && NF) HIP_TRY(c, hipMemcpyAsync(depth, c->d_depth + o, sizeof(double) * NF, hipMemcpyDeviceToHost, c->stream));
-  if (best_right && NF) HIP_TRY(c, hipMemcpyAsync(best_right, c->d_best_right + o, sizeof(int32_t) * NF, hipMemcpyDeviceToHost, c->stream));
-  if (best_dist && NF) HIP_TRY(c, hipMemcpyAsync(best_dist, c->d_best_dist + o, sizeof(int32_t) * NF, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_counts, c->d_n_match + pair, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  const size_t o_ru = 0, o_dp = align_up(NF * 8, 256), o_br = o_dp + align_up(NF * 8, 256), o_bd = o_br + align_up(NF * 4, 256),
+               o_nm = o_bd + align_up(NF * 4, 256), total = o_nm + 256;
+  TRY(ensure_stage(c, total));
+  uint8_t* h = c->h_stage;
+  if (right_u && NF) HIP_TRY(c, hipMemcpyAsync(h + o_ru, c->d_right_u + o, sizeof(double) * NF, hipMemcpyDeviceToHost, c->stream));
+  if (depth && NF) HIP_TRY(c, hipMemcpyAsync(h + o_dp, c->d_depth + o, sizeof(double) * NF, hipMemcpyDeviceToHost, c->stream));
+  if (best_right && NF) HIP_TRY(c, hipMemcpyAsync(h + o_br, c->d_best_right + o, sizeof(int32_t) * NF, hipMemcpyDeviceToHost, c->stream));
+  if (best_dist && NF) HIP_TRY(c, hipMemcpyAsync(h + o_bd, c->d_best_dist + o, sizeof(int32_t) * NF, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(h + o_nm, c->d_n_match + pair, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_timers(c);
-  if (n_matches) *n_matches = c->h_counts[0];
+  if (right_u && NF) std::memcpy(right_u, h + o_ru, sizeof(double) * NF);
+  if (depth && NF) std::memcpy(depth, h + o_dp, sizeof(double) * NF);
+  if (best_right && NF) std::memcpy(best_right, h + o_br, sizeof(int32_t) * NF);
+  if (best_dist && NF) std::memcpy(best_dist, h + o_bd, sizeof(int32_t) * NF);
+  if (n_matches) std::memcpy(n_matches, h + o_nm, sizeof(int32_t));
   return ORBFE_OK;
 }
 
@@ -718,18 +745,34 @@ orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* con
   if (!c || !imgs || n_img < 0) return fail(c, ORBFE_EBADARG, "extract_batch: NULL argument");
   if (n_img > c->cfg.max_images) return fail(c, ORBFE_ECAPACITY, "extract_batch: %d images > max_images %d", n_img, c->cfg.max_images);
   if (stride < (size_t)c->cfg.width) return fail(c, ORBFE_EBADARG, "extract_batch: stride %zu < width %d", stride, c->cfg.width);
+  if (n_img == 0) return ORBFE_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   const LevelDev& L0 = c->lv[0];
+  const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
+  const size_t plane = align_up((size_t)L0.stride * L0.h, 256);
+  const size_t o_kps = (size_t)n_img * plane, o_desc = o_kps + align_up((size_t)n_img * NF * sizeof(orbfe_keypoint), 256);
+  const size_t o_cnt = o_desc + align_up((size_t)n_img * NF * 32, 256), total = o_cnt + align_up((size_t)n_img * 4, 256);
+  TRY(ensure_stage(c, total));
   for (int i = 0; i < n_img; ++i) {
     if (!imgs[i]) return fail(c, ORBFE_EBADARG, "extract_batch: image %d is NULL", i);
-    HIP_TRY(c, hipMemcpy2DAsync(c->d_pyr + (size_t)i * c->img_pitch + L0.plane_off, L0.stride, imgs[i], stride, c->cfg.width,
-                                c->cfg.height, hipMemcpyHostToDevice, c->stream));
+    uint8_t* dst = c->h_stage + (size_t)i * plane;
+    for (int y = 0; y < L0.h; ++y) std::memcpy(dst + (size_t)y * L0.stride, imgs[i] + (size_t)y * stride, (size_t)c->cfg.width);
+    HIP_TRY(c, hipMemcpyAsync(c->d_pyr + (size_t)i * c->img_pitch + L0.plane_off, dst, (size_t)L0.stride * L0.h, hipMemcpyHostToDevice,
+                              c->stream));
   }
   TRY(run_extract(c, c->stream, 0, n_img));
-  const size_t NF = (size_t)c->cfg.n_features;
+  // one batch of D2H copies (full arrays: the counts are not known on the host yet), ONE synchronisation
+  HIP_TRY(c, hipMemcpyAsync(c->h_stage + o_cnt, c->d_n_kp, sizeof(int32_t) * n_img, hipMemcpyDeviceToHost, c->stream));
+  if (kps) HIP_TRY(c, hipMemcpyAsync(c->h_stage + o_kps, c->d_kps, (size_t)n_img * NF * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, c->stream));
+  if (desc) HIP_TRY(c, hipMemcpyAsync(c->h_stage + o_desc, c->d_desc, (size_t)n_img * NF * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  const int32_t* cnt = (const int32_t*)(c->h_stage + o_cnt);
   for (int i = 0; i < n_img; ++i) {
-    int32_t n = 0;
-    TRY(orbfe_fetch_features(c, i, kps ? kps + (size_t)i * NF : nullptr, desc ? desc + (size_t)i * NF * 32 : nullptr, &n));
+    const int32_t n = cnt[i];
+    if (n < 0 || (size_t)n > NF) return fail(c, ORBFE_EDEVICE, "extract_batch: corrupt count %d for image %d", n, i);
+    if (kps) std::memcpy(kps + (size_t)i * NF, c->h_stage + o_kps + (size_t)i * NF * sizeof(orbfe_keypoint), sizeof(orbfe_keypoint) * n);
+    if (desc) std::memcpy(desc + (size_t)i * NF * 32, c->h_stage + o_desc + (size_t)i * NF * 32, (size_t)32 * n);
     if (n_out) n_out[i] = n;
   }
   return ORBFE_OK;
