@@ -64,7 +64,9 @@ typedef struct orbfe_keypoint {
 
 typedef struct orbfe_config {
   int32_t width, height;       /* level-0 image size (e.g. 1241x376 KITTI, 640x480 TUM)                 */
-  int32_t n_features;          /* ORBExtractor.nFeatures                                                */
+  int32_t n_features;          /* ORBExtractor.nFeatures.  Capacity limit: the largest per-level quota (level 0) must
+                                  stay below ~2700 keypoints (its quadtree node table lives in one CU's LDS), i.e.
+                                  nFeatures <= ~12000 for 8 levels at scale 1.2; larger values fail with ORBFE_EBADARG */
   int32_t n_levels;            /* ORBExtractor.nLevels (<= ORBFE_MAX_LEVELS)                            */
   float scale_factor;          /* ORBExtractor.scaleFactor                                              */
   int32_t fast_hi, fast_lo;    /* ORBExtractor.iniThFAST / minThFAST                                    */

@@ -96,6 +96,39 @@ def test_other_geometries_and_thresholds(orc, lib, w, h, nf, nl, sc, hi, lo):
     ctx.close()
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzzed_geometries(orc, lib, seed):
+    """random image sizes / feature counts / pyramid shapes / thresholds: every LDS layout, tile edge and quota path"""
+    r = np.random.default_rng(1000 + seed)
+    nl = int(r.integers(1, 9))
+    sc = float(r.choice([1.1, 1.2, 1.25, 1.5, 2.0]))
+    # smallest level must keep a FAST region of >= 30 px (and the reference's own 38-px check)
+    min_side = int(np.ceil(70 * sc ** (nl - 1))) + 2
+    w = int(r.integers(max(min_side, 80), max(min_side, 80) + 1300))
+    h = int(r.integers(max(min_side, 80), max(min_side, 80) + 600))
+    w, h = min(w, 2400), min(h, 1400)
+    nf = int(r.choice([50, 300, 1000, 2500, 6000]))
+    hi = int(r.integers(5, 60))
+    lo = int(r.integers(0, 30))
+    img, _ = synth.stereo_pair(200 + seed, w, h, n_rect=int(r.integers(20, 400)))
+    try:
+        ex = orc.extractor(img, n_features=nf, n_levels=nl, scale=sc, th_hi=hi, th_lo=lo)
+    except ValueError:
+        with pytest.raises(lib.ImageSizeError):
+            lib.Context(w, h, n_features=nf, n_levels=nl, scale_factor=sc, fast_hi=hi, fast_lo=lo, max_images=1)
+        return
+    max_quota = max(ex.level_info(l)[3] for l in range(nl))
+    if max_quota > 2700:  # documented capacity limit: the quadtree node table of one level must fit one CU's LDS
+        with pytest.raises(lib.OrbfeError) as ei:
+            lib.Context(w, h, n_features=nf, n_levels=nl, scale_factor=sc, fast_hi=hi, fast_lo=lo, max_images=1)
+        assert ei.value.status == 1 and "quota" in str(ei.value)
+        return
+    ctx = lib.Context(w, h, n_features=nf, n_levels=nl, scale_factor=sc, fast_hi=hi, fast_lo=lo, max_images=1)
+    k, d = ctx.extract(img)
+    assert_image_parity(ctx, 0, ex, k, d, nl)
+    ctx.close()
+
+
 @pytest.mark.parametrize("nf", [2000, 120, 24])
 def test_sparse_image_levels_with_fewer_candidates_than_quota_yield_nothing(orc, lib, nf):
     img, _ = synth.stereo_pair(5, sparse=True)
