@@ -26,7 +26,7 @@
 
 namespace orbfe {
 
-#define QT_INPLACE_CHUNKS 8  // nodes up to 8*64 records are partitioned in registers
+#define QT_INPLACE_CHUNKS 4  // nodes up to QT_INPLACE_CHUNKS*64 records are partitioned in registers
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v) {
@@ -141,9 +141,9 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     // pop: arg-max of (count desc, seq asc) = max of the 64-bit key
     uint32_t bc = 0, bs = 0;
     int bj = 0;
-    for (int j0 = 0; j0 < n_act; j0 += 512) {  // one trip unless the quota exceeds 512
+    for (int j0 = 0; j0 < n_act; j0 += 128) {  // two table rows per trip; the table is short for most of a tree's life
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 2; ++u) {
         const int j = j0 + u * 64 + lane;
         const unsigned long long key = (j < n_act) ? n_key[j] : 0ull;
         const uint32_t kc = (uint32_t)(key >> 32), ks = (uint32_t)key;
