@@ -178,6 +178,19 @@ typedef struct orbfe_ba_system_out {
 orbfe_status orbfe_ba_build_system(orbfe_ctx* ctx, const orbfe_ba_problem* prob, const uint8_t* pose_fixed /*[n_poses], nullable*/,
                                    const orbfe_ba_system_out* out);
 
+/* ---- pose-only optimisation of one frame (fp64), entirely on the device -------------------------------------------
+ * Replaces the g2o part of Optimizer::OptimizePoseOnly (include/ORB_SLAM2/Optimizer.h:72, src/Optimizer.cc:33-178): one SE3 pose
+ * vertex, one unary edge per observed map point -- EdgeSE3ProjectXYZOnlyPose when u_right < 0 (Optimizer.cc:77), else
+ * EdgeStereoSE3ProjectXYZOnlyPose -- information info[i]*I (the caller passes getScaledFactorInv2(octave), :85,:106), Huber
+ * sqrt(5.991)/sqrt(7.815); 4 rounds x optimize(10) from the initial pose with the re-classification chi2 > 5.991*sigma2[i] /
+ * 7.815*sigma2[i] (sigma2 = getScaledFactor2(octave), :136,:157) and the kernels dropped in the third round (:149,:170).
+ * Outputs the optimised pose (qx qy qz qw tx ty tz), the inlier flag of every edge and `edges - nBad` of the last round.
+ * The projection post-check of Optimizer.cc:180-190 (Frame::project2UV with the frame's float pose) stays with the caller.  */
+orbfe_status orbfe_pose_only_optimize(orbfe_ctx* ctx, int32_t n, const double* xw /*[n][3]*/, const double* meas /*[n][3] u v uR*/,
+                                      const double* info /*[n]*/, const float* sigma2 /*[n]*/, const double* pose_in /*[7]*/,
+                                      double fx, double fy, double cx, double cy, double bf, double* pose_out /*[7]*/,
+                                      uint8_t* inlier_out /*[n], nullable*/, int32_t* n_good);
+
 /* ---- instrumentation ---------------------------------------------------------------------------
  * Stage timing with HIP events on the context stream.  Enable, run, then read the accumulated
  * per-stage milliseconds and launch counts.  Stage ids: see orbfe_stage.                             */

@@ -30,7 +30,7 @@ def build(fast: bool = False, out_dir: str | None = None) -> str:
     out = os.path.join(out_dir, name)
     flags = ["-O3", "-march=native"] if fast else ["-O2"]
     cmd = ["g++", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-pthread", *flags, "-o", out,
-           os.path.join(_HERE, "orb_oracle.cpp"), os.path.join(_HERE, "ba_oracle.cpp")]
+           os.path.join(_HERE, "orb_oracle.cpp"), os.path.join(_HERE, "ba_oracle.cpp"), os.path.join(_HERE, "pose_oracle.cpp")]
     subprocess.check_call(cmd)
     return out
 
@@ -63,6 +63,7 @@ class Oracle:
         L.orc_extractor_describe.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_ba_eval_edges.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_double] * 5 + [C.c_void_p] * 6
         L.orc_se3_oplus.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_pose_only_optimize.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_double] * 5 + [C.c_void_p] * 2
         L.orc_ba_build_system.argtypes = [C.c_int] * 3 + [C.c_void_p] * 8 + [C.c_double] * 5 + [C.c_void_p] * 7
         L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_gauss7_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
@@ -173,6 +174,18 @@ class Oracle:
                                      _p(out["bl"]), _p(out["Hpl"]), C.byref(tot))
         out["chi2_robust"] = tot.value
         return out
+
+    def pose_only_optimize(self, Xw, meas, info, sigma2, pose, fx, fy, cx, cy, bf):
+        Xw = np.ascontiguousarray(Xw, np.float64).reshape(-1, 3)
+        meas = np.ascontiguousarray(meas, np.float64).reshape(-1, 3)
+        info = np.ascontiguousarray(info, np.float64)
+        sigma2 = np.ascontiguousarray(sigma2, np.float32)
+        pose = np.ascontiguousarray(pose, np.float64)
+        n = Xw.shape[0]
+        out = np.zeros(7)
+        inl = np.zeros(max(n, 1), np.uint8)
+        r = self.lib.orc_pose_only_optimize(n, _p(Xw), _p(meas), _p(info), _p(sigma2), _p(pose), fx, fy, cx, cy, bf, _p(out), _p(inl))
+        return r, out, inl[:n].astype(bool)
 
     def se3_oplus(self, T, upd):
         T = np.ascontiguousarray(T, np.float64)

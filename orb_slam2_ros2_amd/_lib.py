@@ -64,7 +64,7 @@ class BaEdgeOut(C.Structure):
 EXPORTS = [
     "orbfe_abi_version", "orbfe_create", "orbfe_destroy", "orbfe_last_error", "orbfe_get_level_info", "orbfe_get_scale_factors",
     "orbfe_extract", "orbfe_extract_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
-    "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system",
+    "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_pose_only_optimize",
     "orbfe_profile_enable", "orbfe_profile_read", "orbfe_stage_name", "orbfe_debug_candidates",
 ]
 
@@ -108,6 +108,7 @@ def load() -> C.CDLL:
     L.orbfe_match_bruteforce.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]
     L.orbfe_ba_eval_edges.argtypes = [vp, C.POINTER(BaProblem), C.POINTER(BaEdgeOut)]
     L.orbfe_ba_build_system.argtypes = [vp, C.POINTER(BaProblem), vp, C.POINTER(BaSystemOut)]
+    L.orbfe_pose_only_optimize.argtypes = [vp, i32, vp, vp, vp, vp, vp] + [C.c_double] * 5 + [vp, vp, vp]
     L.orbfe_profile_enable.argtypes = [vp, i32]
     L.orbfe_profile_read.argtypes = [vp, vp, vp, i32]
     L.orbfe_stage_name.argtypes = [i32]
@@ -299,6 +300,20 @@ class Context:
                         ptr(out["Hpl"]).value if want_hpl else None)
         self._check(self.lib.orbfe_ba_build_system(self.h, C.byref(prob), ptr(fixed), C.byref(o)))
         return out
+
+    def pose_only_optimize(self, Xw, meas, info, sigma2, pose, fx, fy, cx, cy, bf):
+        Xw = np.ascontiguousarray(Xw, np.float64).reshape(-1, 3)
+        meas = np.ascontiguousarray(meas, np.float64).reshape(-1, 3)
+        info = np.ascontiguousarray(info, np.float64)
+        sigma2 = np.ascontiguousarray(sigma2, np.float32)
+        pose = np.ascontiguousarray(pose, np.float64)
+        n = Xw.shape[0]
+        out = np.zeros(7)
+        inl = np.zeros(max(n, 1), np.uint8)
+        ng = C.c_int32(0)
+        self._check(self.lib.orbfe_pose_only_optimize(self.h, n, ptr(Xw), ptr(meas), ptr(info), ptr(sigma2), ptr(pose), fx, fy, cx, cy,
+                                                      bf, ptr(out), ptr(inl), C.byref(ng)))
+        return ng.value, out, inl[:n].astype(bool)
 
     # ---- instrumentation ------------------------------------------------------------------------
     def profile_enable(self, on=True):

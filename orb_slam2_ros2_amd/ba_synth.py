@@ -91,3 +91,39 @@ def make_problem(seed=42, n_kf=60, n_pt=3000, scale_factor=1.2, n_levels=8):
     return dict(poses=poses_est, points=points_est, edge_pose=np.asarray(e_pose, np.int32), edge_point=np.asarray(e_pt, np.int32),
                 meas=np.asarray(meas, np.float64), is_stereo=np.asarray(stereo, np.uint8), info=np.asarray(info, np.float64),
                 huber_delta=np.asarray(delta, np.float64), fx=FX, fy=FY, cx=CX, cy=CY, bf=BF)
+
+
+def make_pose_problem(seed=7, n=1000, scale_factor=1.2, n_levels=8, outlier_every=12):
+    """One frame for Optimizer::OptimizePoseOnly (Optimizer.cc:33-203): n map points seen by a camera whose initial pose is a
+    perturbed version of the truth; 70 % stereo / 30 % mono observations with octave-scaled noise, every `outlier_every`-th
+    observation a gross outlier.  Returns the arrays of the C-ABI call."""
+    idx = np.arange(n)
+    X = np.stack([(_u(seed, 1, idx) - 0.5) * 8.0, (_u(seed, 2, idx) - 0.5) * 4.0, 3.0 + _u(seed, 3, idx) * 9.0], 1)
+    q_true = np.array([0.02, -0.03, 0.01, 0.0])
+    q_true[3] = np.sqrt(1 - (q_true[:3] ** 2).sum())
+    t_true = np.array([0.10, -0.05, 0.20])
+
+    def rot(q, v):
+        qv, qw = q[:3], q[3]
+        uv = 2 * np.cross(qv, v)
+        return v + qw * uv + np.cross(qv, uv)
+
+    Pc = rot(q_true, X) + t_true
+    u = FX * Pc[:, 0] / Pc[:, 2] + CX
+    v = FY * Pc[:, 1] / Pc[:, 2] + CY
+    ur = u - BF / Pc[:, 2]
+    octave = (hash_u64(seed, 4, idx) % np.uint64(n_levels)).astype(np.int64)
+    sig = (np.float32(scale_factor) ** octave.astype(np.float32)).astype(np.float32)
+    nz = np.stack([_irwin_hall(seed, 10, idx), _irwin_hall(seed, 30, idx), _irwin_hall(seed, 50, idx)], 1) * sig[:, None]
+    out = (idx % outlier_every) == 0
+    nz[out] += np.array([40.0, -33.0, 36.0])
+    stereo = (hash_u64(seed, 5, idx) % np.uint64(10)) < np.uint64(7)
+    meas = np.stack([np.float32(u + nz[:, 0]), np.float32(v + nz[:, 1]), np.where(stereo, np.float32(ur + nz[:, 2]), -1.0)], 1).astype(np.float64)
+    inv_s = (np.float32(1.0) / sig).astype(np.float32)
+    info = (inv_s.astype(np.float32) ** 2).astype(np.float64)   # getScaledFactorInv2 (float pow), both edge kinds (Optimizer.cc:85,106)
+    sigma2 = (sig ** 2).astype(np.float32)                        # getScaledFactor2
+    q0 = q_true + np.array([0.004, -0.003, 0.002, 0.0])
+    q0 /= np.linalg.norm(q0)
+    pose0 = np.concatenate([q0, t_true + np.array([0.05, -0.04, 0.06])])
+    return dict(Xw=X, meas=meas, info=info, sigma2=sigma2, pose=pose0, fx=FX, fy=FY, cx=CX, cy=CY, bf=BF,
+                truth=np.concatenate([q_true, t_true]), outlier=out)

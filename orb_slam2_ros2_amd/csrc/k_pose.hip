@@ -1,0 +1,393 @@
+// k_pose.hip -- Optimizer::OptimizePoseOnly on the device: one workgroup runs the whole optimisation of one frame.
+//
+// Replaces src/ORB_SLAM2/src/Optimizer.cc:33-203 (the g2o part): one VertexSE3Expmap, EdgeSE3ProjectXYZOnlyPose /
+// EdgeStereoSE3ProjectXYZOnlyPose per observed map point (mono when rightU < 0), information invSigma2(octave), Huber
+// sqrt(5.991)/sqrt(7.815); four rounds of optimize(10), each restarting from the initial pose, edges re-classified with
+// chi2 > 5.991*sigma2 / 7.815*sigma2 after every round, robust kernels dropped in the third round; g2o's Levenberg-Marquardt
+// control (tau 1e-5, gain ratio, lambda *= max(1/3, min(2/3, 1-(2rho-1)^3)), ni doubling, <= 10 trials per iteration).
+// A single 6-DoF vertex makes every iteration: evaluate <= 2000 edges in parallel, reduce 21+6+1 doubles over the workgroup
+// (fixed tree => deterministic), solve a 6x6 system on one lane.  No host round trip per iteration.
+#include <hip/hip_runtime.h>
+
+#include "orbfe_internal.h"
+
+namespace orbfe {
+
+#define POSE_THREADS 256
+
+struct PoseDev {
+  double q[4], t[3];
+};
+
+__device__ __forceinline__ void quat_rotate(const double* q, const double* v, double* out) {
+  const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+  double ux = qy * v[2] - qz * v[1], uy = qz * v[0] - qx * v[2], uz = qx * v[1] - qy * v[0];
+  ux += ux;
+  uy += uy;
+  uz += uz;
+  out[0] = v[0] + qw * ux + (qy * uz - qz * uy);
+  out[1] = v[1] + qw * uy + (qz * ux - qx * uz);
+  out[2] = v[2] + qw * uz + (qx * uy - qy * ux);
+}
+
+// SE3Quat::exp(update) * T, normalizeRotation (g2o se3quat.h); update = (omega, upsilon)
+__device__ void pose_oplus(const PoseDev& T, const double* upd, PoseDev& out) {
+  const double wx = upd[0], wy = upd[1], wz = upd[2];
+  const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+  const double Om[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
+  double Om2[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += Om[i][k] * Om[k][j];
+      Om2[i][j] = a;
+    }
+  double R[3][3], V[3][3];
+  const double st = sin(theta), ct = cos(theta);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const double I = (i == j) ? 1.0 : 0.0;
+      if (theta < 0.00001) {
+        R[i][j] = I + Om[i][j] + 0.5 * Om2[i][j];
+        V[i][j] = I + 0.5 * Om[i][j] + (1. / 6.) * Om2[i][j];
+      } else {
+        R[i][j] = I + st / theta * Om[i][j] + (1 - ct) / (theta * theta) * Om2[i][j];
+        V[i][j] = I + (1 - ct) / (theta * theta) * Om[i][j] + (theta - st) / (theta * theta * theta) * Om2[i][j];
+      }
+    }
+  double q[4];
+  const double tr = R[0][0] + R[1][1] + R[2][2];
+  if (tr > 0) {
+    double t = sqrt(tr + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[2][1] - R[1][2]) * t;
+    q[1] = (R[0][2] - R[2][0]) * t;
+    q[2] = (R[1][0] - R[0][1]) * t;
+  } else {
+    int i = 0;
+    if (R[1][1] > R[0][0]) i = 1;
+    if (R[2][2] > R[i][i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = sqrt(R[i][i] - R[j][j] - R[k][k] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (R[k][j] - R[j][k]) * t;
+    q[j] = (R[j][i] + R[i][j]) * t;
+    q[k] = (R[k][i] + R[i][k]) * t;
+  }
+  double te[3];
+  for (int i = 0; i < 3; ++i) te[i] = V[i][0] * upd[3] + V[i][1] * upd[4] + V[i][2] * upd[5];
+  const double ax = q[0], ay = q[1], az = q[2], aw = q[3];
+  const double bx = T.q[0], by = T.q[1], bz = T.q[2], bw = T.q[3];
+  out.q[3] = aw * bw - ax * bx - ay * by - az * bz;
+  out.q[0] = aw * bx + ax * bw + ay * bz - az * by;
+  out.q[1] = aw * by + ay * bw + az * bx - ax * bz;
+  out.q[2] = aw * bz + az * bw + ax * by - ay * bx;
+  double rt[3];
+  quat_rotate(q, T.t, rt);
+  for (int i = 0; i < 3; ++i) out.t[i] = te[i] + rt[i];
+  if (out.q[3] < 0)
+    for (int i = 0; i < 4; ++i) out.q[i] = -out.q[i];
+  const double n = sqrt(out.q[0] * out.q[0] + out.q[1] * out.q[1] + out.q[2] * out.q[2] + out.q[3] * out.q[3]);
+  for (int i = 0; i < 4; ++i) out.q[i] /= n;
+}
+
+__device__ bool solve6(const double* A /*6x6 row-major*/, const double* b, double* x) {
+  double L[36];
+  for (int i = 0; i < 36; ++i) L[i] = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = A[6 * i + j];
+      for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
+      if (i == j) {
+        if (!(s > 0)) return false;
+        L[6 * i + i] = sqrt(s);
+      } else
+        L[6 * i + j] = s / L[6 * j + j];
+    }
+  double y[6];
+  for (int i = 0; i < 6; ++i) {
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k];
+    y[i] = s / L[6 * i + i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double s = y[i];
+    for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k];
+    x[i] = s / L[6 * i + i];
+  }
+  return true;
+}
+
+struct PoseShared {
+  PoseDev T, T0, backup;
+  double H[36], b[6], x[6];
+  double red[28][POSE_THREADS / 64];
+  double lambda, ni, current_chi, temp_chi, rho;
+  int qmax, cont_inner, stop_outer, any_active, n_bad;
+};
+
+// sum of v over the workgroup, result in every thread (fixed order: wave butterfly, then waves 0..3)
+__device__ __forceinline__ double block_sum(double v, double (*slot)[POSE_THREADS / 64], int row) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) slot[row][threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0;
+#pragma unroll
+  for (int w = 0; w < POSE_THREADS / 64; ++w) s += slot[row][w];
+  __syncthreads();
+  return s;
+}
+
+__global__ __launch_bounds__(POSE_THREADS) void k_pose_only(int n, const double* __restrict__ Xw, const double* __restrict__ meas,
+                                                            const double* __restrict__ info, const float* __restrict__ sigma2,
+                                                            const double* __restrict__ pose_in, BaParamsDev prm, double d_mono,
+                                                            double d_stereo, double* __restrict__ err, uint8_t* __restrict__ level,
+                                                            uint8_t* __restrict__ robust, uint8_t* __restrict__ inlier,
+                                                            double* __restrict__ pose_out, int32_t* __restrict__ n_good) {
+#pragma clang fp contract(off)
+  __shared__ PoseShared S;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    for (int i = 0; i < 4; ++i) S.T0.q[i] = pose_in[i];
+    for (int i = 0; i < 3; ++i) S.T0.t[i] = pose_in[4 + i];
+    S.T = S.T0;
+  }
+  for (int i = tid; i < n; i += POSE_THREADS) {
+    level[i] = 0;
+    robust[i] = 1;
+    inlier[i] = 1;
+  }
+  __syncthreads();
+
+  auto edge_error = [&](int i, const PoseDev& T, double* e) {
+    double p[3];
+    quat_rotate(T.q, Xw + 3 * i, p);
+    const double x = p[0] + T.t[0], y = p[1] + T.t[1], z = p[2] + T.t[2];
+    const double* m = meas + 3 * i;
+    const double u = x / z * prm.fx + prm.cx, v = y / z * prm.fy + prm.cy;
+    e[0] = m[0] - u;
+    e[1] = m[1] - v;
+    e[2] = (m[2] < 0) ? 0.0 : m[2] - (u - prm.bf / z);
+  };
+  auto edge_chi2 = [&](int i, const double* e) {
+    const double w = info[i];
+    double c = e[0] * (w * e[0]) + e[1] * (w * e[1]);
+    if (!(meas[3 * i + 2] < 0)) c += e[2] * (w * e[2]);
+    return c;
+  };
+  // computeActiveErrors + activeRobustChi2 at the current S.T
+  auto eval_chi = [&]() {
+    const PoseDev T = S.T;
+    double part = 0;
+    for (int i = tid; i < n; i += POSE_THREADS) {
+      if (level[i] != 0) continue;
+      double e[3];
+      edge_error(i, T, e);
+      err[3 * i] = e[0];
+      err[3 * i + 1] = e[1];
+      err[3 * i + 2] = e[2];
+      const double c = edge_chi2(i, e);
+      if (robust[i]) {
+        const double dl = (meas[3 * i + 2] < 0) ? d_mono : d_stereo;
+        const double dsqr = dl * dl;
+        part += (c <= dsqr) ? c : (2 * sqrt(c) * dl - dsqr);
+      } else
+        part += c;
+    }
+    return block_sum(part, S.red, 27);
+  };
+  // linearizeOplus + constructQuadraticForm of every active edge at S.T (errors of the last evaluation)
+  auto build_system = [&]() {
+    const PoseDev T = S.T;
+    double acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = 0;
+    for (int i = tid; i < n; i += POSE_THREADS) {
+      if (level[i] != 0) continue;
+      double p[3];
+      quat_rotate(T.q, Xw + 3 * i, p);
+      const double x = p[0] + T.t[0], y = p[1] + T.t[1], z = p[2] + T.t[2];
+      const double invz = 1.0 / z, invz_2 = invz * invz;
+      const bool st = !(meas[3 * i + 2] < 0);
+      double J[3][6];
+      J[0][0] = x * y * invz_2 * prm.fx;
+      J[0][1] = -(1 + (x * x * invz_2)) * prm.fx;
+      J[0][2] = y * invz * prm.fx;
+      J[0][3] = -invz * prm.fx;
+      J[0][4] = 0;
+      J[0][5] = x * invz_2 * prm.fx;
+      J[1][0] = (1 + y * y * invz_2) * prm.fy;
+      J[1][1] = -x * y * invz_2 * prm.fy;
+      J[1][2] = -x * invz * prm.fy;
+      J[1][3] = 0;
+      J[1][4] = -invz * prm.fy;
+      J[1][5] = y * invz_2 * prm.fy;
+      J[2][0] = st ? J[0][0] - prm.bf * y * invz_2 : 0.0;
+      J[2][1] = st ? J[0][1] + prm.bf * x * invz_2 : 0.0;
+      J[2][2] = st ? J[0][2] : 0.0;
+      J[2][3] = st ? J[0][3] : 0.0;
+      J[2][4] = 0;
+      J[2][5] = st ? J[0][5] - prm.bf * invz_2 : 0.0;
+      const double e[3] = {err[3 * i], err[3 * i + 1], st ? err[3 * i + 2] : 0.0};
+      const double w = info[i];
+      double r1 = 1.0;
+      if (robust[i]) {
+        const double c = edge_chi2(i, e);
+        const double dl = st ? d_stereo : d_mono;
+        if (c > dl * dl) r1 = dl / sqrt(c);
+      }
+      int k = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        acc[21 + a] -= r1 * (J[0][a] * (w * e[0]) + J[1][a] * (w * e[1]) + J[2][a] * (w * e[2]));
+#pragma unroll
+        for (int c2 = a; c2 < 6; ++c2) acc[k++] += J[0][a] * (r1 * w) * J[0][c2] + J[1][a] * (r1 * w) * J[1][c2] + J[2][a] * (r1 * w) * J[2][c2];
+      }
+    }
+    double tot[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) tot[k] = block_sum(acc[k], S.red, k);
+    if (tid == 0) {
+      int k = 0;
+      for (int a = 0; a < 6; ++a)
+        for (int c2 = a; c2 < 6; ++c2) {
+          S.H[6 * a + c2] = tot[k];
+          S.H[6 * c2 + a] = tot[k];
+          ++k;
+        }
+      for (int a = 0; a < 6; ++a) S.b[a] = tot[21 + a];
+    }
+    __syncthreads();
+  };
+
+  // edge->computeError() at construction (Optimizer.cc:90,111)
+  for (int i = tid; i < n; i += POSE_THREADS) {
+    double e[3];
+    edge_error(i, S.T0, e);
+    err[3 * i] = e[0];
+    err[3 * i + 1] = e[1];
+    err[3 * i + 2] = e[2];
+  }
+  __syncthreads();
+
+  for (int round = 0; round < 4; ++round) {
+    if (tid == 0) {
+      S.T = S.T0;  // every round restarts from the initial pose (Optimizer.cc:127)
+      S.n_bad = 0;
+      S.any_active = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += POSE_THREADS)
+      if (level[i] == 0) S.any_active = 1;  // benign race: every writer stores 1
+    __syncthreads();
+    if (S.any_active) {
+      // ---- SparseOptimizer::optimize(10) with OptimizationAlgorithmLevenberg ----
+      for (int it = 0; it < 10; ++it) {
+        const double chi = eval_chi();
+        build_system();
+        if (tid == 0) {
+          S.current_chi = chi;
+          if (it == 0) {
+            double md = 0;
+            for (int j = 0; j < 6; ++j) md = fmax(fabs(S.H[7 * j]), md);
+            S.lambda = 1e-5 * md;
+            S.ni = 2;
+          }
+          S.rho = 0;
+          S.qmax = 0;
+          S.stop_outer = 0;
+        }
+        __syncthreads();
+        for (int trial = 0; trial < 10; ++trial) {
+          if (tid == 0) {
+            S.backup = S.T;
+            double Hl[36];
+            for (int j = 0; j < 36; ++j) Hl[j] = S.H[j];
+            for (int j = 0; j < 6; ++j) Hl[7 * j] += S.lambda;
+            for (int j = 0; j < 6; ++j) S.x[j] = 0;
+            S.cont_inner = solve6(Hl, S.b, S.x) ? 1 : 0;  // ok2
+            PoseDev Tn;
+            pose_oplus(S.T, S.x, Tn);
+            S.T = Tn;
+          }
+          __syncthreads();
+          const double tchi = eval_chi();
+          if (tid == 0) {
+            double temp_chi = S.cont_inner ? tchi : 1.7976931348623157e308;
+            double rho = S.current_chi - temp_chi;
+            double scale = 0;
+            for (int j = 0; j < 6; ++j) scale += S.x[j] * (S.lambda * S.x[j] + S.b[j]);
+            scale += 1e-3;
+            rho /= scale;
+            bool finite_lambda = true;
+            if (rho > 0 && isfinite(temp_chi)) {
+              double alpha = 1. - pow((2 * rho - 1), 3);
+              alpha = fmin(alpha, 2. / 3.);
+              S.lambda *= fmax(1. / 3., alpha);
+              S.ni = 2;
+              S.current_chi = temp_chi;
+            } else {
+              S.lambda *= S.ni;
+              S.ni *= 2;
+              S.T = S.backup;
+              finite_lambda = isfinite(S.lambda);
+            }
+            S.rho = rho;
+            S.qmax += 1;
+            S.cont_inner = (finite_lambda && rho < 0 && S.qmax < 10) ? 1 : 0;
+            if (!S.cont_inner) S.stop_outer = (S.qmax == 10 || rho == 0 || !isfinite(S.lambda)) ? 1 : 0;
+          }
+          __syncthreads();
+          if (!S.cont_inner) break;
+        }
+        if (S.stop_outer) break;
+      }
+    }
+    // ---- re-classification (Optimizer.cc:132-177): mono edges, then stereo edges; counts only ----
+    {
+      const PoseDev T = S.T;
+      int bad = 0;
+      for (int i = tid; i < n; i += POSE_THREADS) {
+        const bool st = !(meas[3 * i + 2] < 0);
+        double e[3] = {err[3 * i], err[3 * i + 1], err[3 * i + 2]};
+        if (!inlier[i]) {
+          edge_error(i, T, e);
+          err[3 * i] = e[0];
+          err[3 * i + 1] = e[1];
+          err[3 * i + 2] = e[2];
+        }
+        const double c = edge_chi2(i, e);
+        const double th = (st ? 7.815 : 5.991) * (double)sigma2[i];
+        if (c > th) {
+          inlier[i] = 0;
+          level[i] = 1;
+          ++bad;
+        } else {
+          inlier[i] = 1;
+          level[i] = 0;
+        }
+        if (round == 2) robust[i] = 0;
+      }
+      const double tb = block_sum((double)bad, S.red, 27);
+      if (tid == 0) S.n_bad = (int)tb;
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    for (int i = 0; i < 4; ++i) pose_out[i] = S.T.q[i];
+    for (int i = 0; i < 3; ++i) pose_out[4 + i] = S.T.t[i];
+    *n_good = n - S.n_bad;
+  }
+}
+
+void launch_pose_only(hipStream_t s, int n, const double* Xw, const double* meas, const double* info, const float* sigma2,
+                      const double* pose_in, BaParamsDev prm, double d_mono, double d_stereo, double* err, uint8_t* level,
+                      uint8_t* robust, uint8_t* inlier, double* pose_out, int32_t* n_good) {
+  hipLaunchKernelGGL(k_pose_only, dim3(1), dim3(POSE_THREADS), 0, s, n, Xw, meas, info, sigma2, pose_in, prm, d_mono, d_stereo, err,
+                     level, robust, inlier, pose_out, n_good);
+}
+
+}  // namespace orbfe

@@ -55,6 +55,9 @@ void launch_ba_system(hipStream_t s, int n_poses, int n_points, int n_edges, con
                       const double* info, const double* delta, BaParamsDev prm, const uint8_t* pose_fixed, const int32_t* pt_off,
                       const int32_t* pt_edges, const int32_t* ps_off, const int32_t* ps_edges, double* Hpp, double* bp, double* Hll,
                       double* bl, double* Hpl);
+void launch_pose_only(hipStream_t s, int n, const double* Xw, const double* meas, const double* info, const float* sigma2,
+                      const double* pose_in, BaParamsDev prm, double d_mono, double d_stereo, double* err, uint8_t* level,
+                      uint8_t* robust, uint8_t* inlier, double* pose_out, int32_t* n_good);
 }  // namespace orbfe
 
 using namespace orbfe;
@@ -1002,6 +1005,46 @@ orbfe_status orbfe_ba_build_system(orbfe_ctx* c, const orbfe_ba_problem* p, cons
   HIP_TRY(c, down(o->Hll, o_hll, (size_t)NP * 72));
   HIP_TRY(c, down(o->bl, o_bl, (size_t)NP * 24));
   if (o->Hpl) HIP_TRY(c, down(o->Hpl, o_hpl, (size_t)E * 144));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_pose_only_optimize(orbfe_ctx* c, int32_t n, const double* xw, const double* meas, const double* info, const float* sigma2,
+                                      const double* pose_in, double fx, double fy, double cx, double cy, double bf, double* pose_out,
+                                      uint8_t* inlier_out, int32_t* n_good) {
+  if (!c || n < 0 || !pose_in || !pose_out || !n_good || (n && (!xw || !meas || !info || !sigma2)))
+    return fail(c, ORBFE_EBADARG, "pose_only_optimize: NULL argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t N = (size_t)std::max(n, 1);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o2 = off;
+    off += align_up(std::max<size_t>(bytes, 8), 256);
+    return o2;
+  };
+  const size_t o_x = take(N * 24), o_m = take(N * 24), o_i = take(N * 8), o_s = take(N * 4), o_p = take(56), o_e = take(N * 24),
+               o_l = take(N), o_r = take(N), o_in = take(N), o_po = take(56), o_ng = take(8);
+  TRY(ensure_tmp(c, off));
+  uint8_t* b = (uint8_t*)c->d_tmp;
+  if (n) {
+    HIP_TRY(c, hipMemcpyAsync(b + o_x, xw, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(b + o_m, meas, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(b + o_i, info, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(b + o_s, sigma2, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  }
+  HIP_TRY(c, hipMemcpyAsync(b + o_p, pose_in, 56, hipMemcpyHostToDevice, c->stream));
+  BaParamsDev prm = {fx, fy, cx, cy, bf};
+  {
+    StageTimer tm(c, ORBFE_STAGE_BA, c->stream);
+    launch_pose_only(c->stream, n, (const double*)(b + o_x), (const double*)(b + o_m), (const double*)(b + o_i), (const float*)(b + o_s),
+                     (const double*)(b + o_p), prm, (double)(float)std::sqrt(5.991), (double)(float)std::sqrt(7.815), (double*)(b + o_e),
+                     b + o_l, b + o_r, b + o_in, (double*)(b + o_po), (int32_t*)(b + o_ng));
+  }
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(pose_out, b + o_po, 56, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(n_good, b + o_ng, 4, hipMemcpyDeviceToHost, c->stream));
+  if (inlier_out && n) HIP_TRY(c, hipMemcpyAsync(inlier_out, b + o_in, (size_t)n, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_timers(c);
   return ORBFE_OK;

@@ -150,6 +150,11 @@ class Optimizer:
     deltaStereo = float(np.float32(np.sqrt(7.815)))  # Optimizer.cc:1085
 
     @staticmethod
+    def OptimizePoseOnly(ctx: Context, Xw, meas, info, sigma2, pose, fx, fy, cx, cy, bf):
+        """The g2o part of Optimizer::OptimizePoseOnly (Optimizer.cc:33-178) on the device: returns (edges - nBad, pose, inliers)."""
+        return ctx.pose_only_optimize(Xw, meas, info, sigma2, pose, fx, fy, cx, cy, bf)
+
+    @staticmethod
     def evalEdges(ctx: Context, poses, points, edge_pose, edge_point, meas, is_stereo, info, huber_delta, fx, fy, cx, cy, bf,
                   jacobians=True):
         return ctx.ba_eval_edges(poses, points, edge_pose, edge_point, meas, is_stereo, info, huber_delta, fx, fy, cx, cy, bf,
