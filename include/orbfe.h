@@ -178,6 +178,20 @@ typedef struct orbfe_ba_system_out {
 orbfe_status orbfe_ba_build_system(orbfe_ctx* ctx, const orbfe_ba_problem* prob, const uint8_t* pose_fixed /*[n_poses], nullable*/,
                                    const orbfe_ba_system_out* out);
 
+/* ---- grid-guided matching against the features of one slot ---------------------------------------------------------
+ * Replaces VirtualFrame::initGrid + findFeaturesInArea (src/Frame.cc:53-69, 286-311) + ORBMatcher::getBestMatch
+ * (src/ORBMatcher.cc:967-990), the core of the guided searches (ORBMatcher::searchByProjection, src/ORBMatcher.cc:265-347 and
+ * :561-612): query i searches the 64x48-px grid cells overlapping [x-r, x+r] x [y-r, y+r] around qxy[i] with r = radius[i] (the
+ * caller multiplies by getScaledFactor2(octave), Frame.cc:289), cells rows-outer / columns-inner, a cell's features in index
+ * order, keeps octaves in [min_level[i], max_level[i]] and features with exclude[idx] == 0 (nullable: e.g. "already has a
+ * map point", ORBMatcher.cc:322-332), and applies the reference's order-dependent best / second-best scan.  Outputs as
+ * orbfe_match_bruteforce plus the candidate count; best_idx = -1 when the list is empty.  Cell indices are clamped to the
+ * grid (the reference indexes one column past the grid when the box touches x == width and width is a multiple of 64).      */
+orbfe_status orbfe_search_in_area(orbfe_ctx* ctx, int32_t slot, int32_t nq, const float* qxy /*[nq][2]*/, const float* radius,
+                                  const int8_t* min_level, const int8_t* max_level, const uint8_t* q_desc /*[nq][32]*/,
+                                  const uint8_t* exclude /*[n_features], nullable*/, int32_t* best_idx, int32_t* best_dist,
+                                  int32_t* second_dist, int32_t* n_cand);
+
 /* ---- pose-only optimisation of one frame (fp64), entirely on the device -------------------------------------------
  * Replaces the g2o part of Optimizer::OptimizePoseOnly (include/ORB_SLAM2/Optimizer.h:72, src/Optimizer.cc:33-178): one SE3 pose
  * vertex, one unary edge per observed map point -- EdgeSE3ProjectXYZOnlyPose when u_right < 0 (Optimizer.cc:77), else

@@ -939,3 +939,51 @@ int orc_stereo_frame(const uint8_t* left, const uint8_t* right, int w, int h, in
 }
 
 }  // extern "C"
+
+// ---- guided matching: VirtualFrame::initGrid + findFeaturesInArea (src/Frame.cc:53-69, 286-311) + getBestMatch -------------
+// The core every guided search of the reference shares (searchByProjection frame-to-frame, ORBMatcher.cc:265-347; map points to
+// frame, :561-612): candidates = the features of the 64x48-px grid cells overlapping the box [x-r, x+r] x [y-r, y+r]
+// (r = radius * getScaledFactor2(octave)), rows outer, columns inner, features of a cell in index order, filtered by octave
+// range and by the caller's exclusion mask; then the order-dependent best / second-best scan.
+// One deviation: the reference indexes mGrids[row][col] with col == cols when maxX == width is a multiple of 64 (undefined
+// behaviour); cell indices are clamped to the grid here.
+extern "C" void orc_search_in_area(const orc_keypoint* kps, const uint8_t* desc, int n, int width, int height, int nq, const float* qxy,
+                                   const float* radius, const int8_t* min_level, const int8_t* max_level, const uint8_t* q_desc,
+                                   const uint8_t* exclude, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
+                                   int32_t* n_cand) {
+  const int GW = 64, GH = 48;
+  const int rows = cv_ceil((float)height / GH), cols = cv_ceil((float)width / GW);
+  std::vector<std::vector<int64_t>> grid((size_t)rows * cols);
+  for (int i = 0; i < n; ++i) {
+    const int r = std::min(rows - 1, cv_floor(kps[i].y / GH)), c = std::min(cols - 1, cv_floor(kps[i].x / GW));
+    grid[(size_t)r * cols + c].push_back(i);
+  }
+  for (int q = 0; q < nq; ++q) {
+    const float x = qxy[2 * q], y = qxy[2 * q + 1], rad = radius[q];
+    const int min_x = std::max(0, cv_round(x - rad)), max_x = std::min(width, cv_round(x + rad));
+    const int min_y = std::max(0, cv_round(y - rad)), max_y = std::min(height, cv_round(y + rad));
+    const int c0 = std::min(cols - 1, cv_floor((float)min_x / GW)), c1 = std::min(cols - 1, cv_floor((float)max_x / GW));
+    const int r0 = std::min(rows - 1, cv_floor((float)min_y / GH)), r1 = std::min(rows - 1, cv_floor((float)max_y / GH));
+    std::vector<int64_t> cand;
+    for (int r = r0; r <= r1; ++r)
+      for (int c = c0; c <= c1; ++c)
+        for (int64_t id : grid[(size_t)r * cols + c]) {
+          const int oc = kps[id].octave;
+          if (oc <= max_level[q] && oc >= min_level[q] && !(exclude && exclude[id])) cand.push_back(id);
+        }
+    n_cand[q] = (int32_t)cand.size();
+    if (cand.empty()) {
+      best_idx[q] = -1;
+      best_dist[q] = INT_MAX;
+      second_dist[q] = INT_MAX;
+      continue;
+    }
+    int64_t bi;
+    int bd, sd;
+    float ratio;
+    best_match(q_desc + (size_t)q * 32, desc, cand.data(), (int)cand.size(), &bi, &bd, &sd, &ratio);
+    best_idx[q] = (int32_t)bi;
+    best_dist[q] = bd;
+    second_dist[q] = sd;
+  }
+}

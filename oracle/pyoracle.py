@@ -63,6 +63,7 @@ class Oracle:
         L.orc_extractor_describe.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_ba_eval_edges.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_double] * 5 + [C.c_void_p] * 6
         L.orc_se3_oplus.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_search_in_area.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10
         L.orc_pose_only_optimize.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_double] * 5 + [C.c_void_p] * 2
         L.orc_ba_build_system.argtypes = [C.c_int] * 3 + [C.c_void_p] * 8 + [C.c_double] * 5 + [C.c_void_p] * 7
         L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -137,6 +138,21 @@ class Oracle:
         s, c = C.c_double(0), C.c_double(0)
         self.lib.orc_sincos(float(t), mode, C.byref(s), C.byref(c))
         return s.value, c.value
+
+    def search_in_area(self, kps, desc, width, height, qxy, radius, min_level, max_level, q_desc, exclude=None):
+        kps = np.ascontiguousarray(kps)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        qxy = np.ascontiguousarray(qxy, np.float32).reshape(-1, 2)
+        nq = qxy.shape[0]
+        radius = np.ascontiguousarray(radius, np.float32)
+        min_level = np.ascontiguousarray(min_level, np.int8)
+        max_level = np.ascontiguousarray(max_level, np.int8)
+        q_desc = np.ascontiguousarray(q_desc, np.uint8).reshape(-1, 32)
+        ex = None if exclude is None else np.ascontiguousarray(exclude, np.uint8)
+        out = [np.zeros(max(nq, 1), np.int32) for _ in range(4)]
+        self.lib.orc_search_in_area(_p(kps), _p(desc), kps.shape[0], width, height, nq, _p(qxy), _p(radius), _p(min_level), _p(max_level),
+                                    _p(q_desc), _p(ex) if ex is not None else None, *[_p(o) for o in out])
+        return tuple(o[:nq] for o in out)
 
     # ---- BA ------------------------------------------------------------------------------------
     def ba_eval_edges(self, poses, points, edge_pose, edge_point, meas, is_stereo, info, huber_delta, fx, fy, cx, cy, bf):

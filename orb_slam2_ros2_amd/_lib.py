@@ -64,7 +64,7 @@ class BaEdgeOut(C.Structure):
 EXPORTS = [
     "orbfe_abi_version", "orbfe_create", "orbfe_destroy", "orbfe_last_error", "orbfe_get_level_info", "orbfe_get_scale_factors",
     "orbfe_extract", "orbfe_extract_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
-    "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_pose_only_optimize",
+    "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_pose_only_optimize", "orbfe_search_in_area",
     "orbfe_profile_enable", "orbfe_profile_read", "orbfe_stage_name", "orbfe_debug_candidates",
 ]
 
@@ -109,6 +109,7 @@ def load() -> C.CDLL:
     L.orbfe_ba_eval_edges.argtypes = [vp, C.POINTER(BaProblem), C.POINTER(BaEdgeOut)]
     L.orbfe_ba_build_system.argtypes = [vp, C.POINTER(BaProblem), vp, C.POINTER(BaSystemOut)]
     L.orbfe_pose_only_optimize.argtypes = [vp, i32, vp, vp, vp, vp, vp] + [C.c_double] * 5 + [vp, vp, vp]
+    L.orbfe_search_in_area.argtypes = [vp, i32, i32] + [vp] * 10
     L.orbfe_profile_enable.argtypes = [vp, i32]
     L.orbfe_profile_read.argtypes = [vp, vp, vp, i32]
     L.orbfe_stage_name.argtypes = [i32]
@@ -253,6 +254,22 @@ class Context:
         sd = np.zeros(max(nq, 1), np.int32)
         self._check(self.lib.orbfe_match_bruteforce(self.h, ptr(q), nq, ptr(t), nt, ptr(cand_offsets), ptr(cand_idx), ptr(bi), ptr(bd), ptr(sd)))
         return bi[:nq], bd[:nq], sd[:nq]
+
+    def search_in_area(self, slot, qxy, radius, min_level, max_level, q_desc, exclude=None):
+        qxy = np.ascontiguousarray(qxy, np.float32).reshape(-1, 2)
+        nq = qxy.shape[0]
+        radius = np.ascontiguousarray(radius, np.float32)
+        min_level = np.ascontiguousarray(min_level, np.int8)
+        max_level = np.ascontiguousarray(max_level, np.int8)
+        q_desc = np.ascontiguousarray(q_desc, np.uint8).reshape(-1, 32)
+        ex = None
+        if exclude is not None:
+            ex = np.zeros(max(self.n_features, 1), np.uint8)
+            ex[:len(exclude)] = np.asarray(exclude, np.uint8)
+        out = [np.zeros(max(nq, 1), np.int32) for _ in range(4)]
+        self._check(self.lib.orbfe_search_in_area(self.h, slot, nq, ptr(qxy), ptr(radius), ptr(min_level), ptr(max_level), ptr(q_desc),
+                                                  ptr(ex), *[ptr(o) for o in out]))
+        return tuple(o[:nq] for o in out)
 
     # ---- BA -------------------------------------------------------------------------------------
     def ba_eval_edges(self, poses, points, edge_pose, edge_point, meas, is_stereo, info, huber_delta, fx, fy, cx, cy, bf,

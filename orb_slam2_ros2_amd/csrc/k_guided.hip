@@ -1,0 +1,186 @@
+// k_guided.hip -- grid-guided descriptor matching against the device-resident features of one image slot.
+//
+// Replaces VirtualFrame::initGrid (src/ORB_SLAM2/src/Frame.cc:53-69) + VirtualFrame::findFeaturesInArea (:286-311) +
+// ORBMatcher::getBestMatch (src/ORBMatcher.cc:967-990) as used by the guided searches (searchByProjection frame-to-frame
+// ORBMatcher.cc:265-347, map points to frame :561-612): candidates of a query = the features of the 64x48-px grid cells that
+// overlap its search box, rows outer / columns inner / index order inside a cell, filtered by octave range and an exclusion
+// mask, scanned with the reference's order-dependent best / second-best rule.  SURVEY 8f, row f1.
+#include <hip/hip_runtime.h>
+
+#include "orbfe_internal.h"
+#include "wave_ops.h"
+
+namespace orbfe {
+
+#define GRID_W 64
+#define GRID_H 48
+#define ORB_INT_MAX 2147483647
+
+__device__ __forceinline__ int cvfloor_f(float v) {
+  const int i = (int)v;
+  return i - (i > v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// grid build: one workgroup per call.  cell_off[ncells+1], cell_feat[n] (features of a cell in ascending index).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grid_build(const orbfe_keypoint* __restrict__ kps, const int32_t* __restrict__ n_kp_ptr,
+                                                    int rows, int cols, int32_t* __restrict__ cell_off, int32_t* __restrict__ cell_feat) {
+  extern __shared__ int32_t l_grid[];  // [ncells + 1] offsets, then [ncells] fill cursors
+  const int n = *n_kp_ptr;
+  const int ncells = rows * cols;
+  int32_t* l_off = l_grid;
+  int32_t* l_cur = l_grid + ncells + 1;
+  for (int c = threadIdx.x; c <= ncells; c += 256) {
+    l_off[c] = 0;
+    if (c < ncells) l_cur[c] = 0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int r = min(rows - 1, cvfloor_f(kps[i].y / (float)GRID_H)), c = min(cols - 1, cvfloor_f(kps[i].x / (float)GRID_W));
+    atomicAdd(&l_off[r * cols + c + 1], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // exclusive prefix (a few hundred cells)
+    int acc = 0;
+    for (int c = 0; c < ncells; ++c) {
+      const int k = l_off[c + 1];
+      l_off[c] = acc;
+      acc += k;
+    }
+    l_off[ncells] = acc;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c <= ncells; c += 256) cell_off[c] = l_off[c];
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int r = min(rows - 1, cvfloor_f(kps[i].y / (float)GRID_H)), c = min(cols - 1, cvfloor_f(kps[i].x / (float)GRID_W));
+    const int cell = r * cols + c;
+    cell_feat[l_off[cell] + atomicAdd(&l_cur[cell], 1)] = i;
+  }
+  __syncthreads();
+  // the reference pushes indices in ascending order (Frame.cc:61-68): sort every (short) cell list
+  for (int c = threadIdx.x; c < ncells; c += 256) {
+    int32_t* L = cell_feat + l_off[c];
+    const int k = l_off[c + 1] - l_off[c];
+    for (int a = 1; a < k; ++a) {
+      const int32_t v = L[a];
+      int b = a - 1;
+      while (b >= 0 && L[b] > v) {
+        L[b + 1] = L[b];
+        --b;
+      }
+      L[b + 1] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// search: one wave per query
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int hamming256w(const uint4 a0, const uint4 a1, const uint8_t* __restrict__ p) {
+  const uint4 b0 = *(const uint4*)p;
+  const uint4 b1 = *(const uint4*)(p + 16);
+  return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
+         __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+struct Best2g {
+  int min_d, second, min_idx;
+};
+__device__ __forceinline__ void fold_chunk_g(Best2g& b, int d, int idx) {
+  const int incl = wave_incl_scan_dpp<OpMinI>(d);
+  const int excl = __builtin_amdgcn_update_dpp(ORB_INT_MAX, incl, ORBFE_DPP_WAVE_SHR1, 0xf, 0xf, false);
+  const int pre = min(b.min_d, excl);
+  const bool record = d < pre;
+  b.second = min(b.second, wave_reduce_dpp<OpMinI>(record ? ORB_INT_MAX : d));
+  const int cmin = __builtin_amdgcn_readlane(incl, 63);
+  if (cmin < b.min_d) {
+    const unsigned long long m = __ballot(d == cmin);
+    b.min_d = cmin;
+    b.min_idx = __builtin_amdgcn_readlane(idx, __ffsll((long long)m) - 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_search_area(const uint2* __restrict__ kpl, const uint8_t* __restrict__ desc, int width,
+                                                     int height, int rows, int cols, const int32_t* __restrict__ cell_off,
+                                                     const int32_t* __restrict__ cell_feat, int nq, const float* __restrict__ qxy,
+                                                     const float* __restrict__ radius, const int8_t* __restrict__ min_level,
+                                                     const int8_t* __restrict__ max_level, const uint8_t* __restrict__ q_desc,
+                                                     const uint8_t* __restrict__ exclude, int32_t* __restrict__ best_idx,
+                                                     int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist,
+                                                     int32_t* __restrict__ n_cand) {
+  __shared__ int32_t stage_all[4][128];  // per wave: filtered candidates waiting to fill a 64-lane chunk (order preserved)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int32_t* stage = stage_all[wv];
+  const int q = blockIdx.x * 4 + wv;
+  if (q >= nq) return;
+  const float x = qxy[2 * q], y = qxy[2 * q + 1], rad = radius[q];
+  const int lo = min_level[q], hi = max_level[q];
+  const int min_x = max(0, __float2int_rn(x - rad)), max_x = min(width, __float2int_rn(x + rad));
+  const int min_y = max(0, __float2int_rn(y - rad)), max_y = min(height, __float2int_rn(y + rad));
+  const int c0 = min(cols - 1, cvfloor_f((float)min_x / (float)GRID_W)), c1 = min(cols - 1, cvfloor_f((float)max_x / (float)GRID_W));
+  const int r0 = min(rows - 1, cvfloor_f((float)min_y / (float)GRID_H)), r1 = min(rows - 1, cvfloor_f((float)max_y / (float)GRID_H));
+  const uint4 a0 = *(const uint4*)(q_desc + (size_t)q * 32);
+  const uint4 a1 = *(const uint4*)(q_desc + (size_t)q * 32 + 16);
+  Best2g b = {ORB_INT_MAX, ORB_INT_MAX, 0};
+  int staged = 0, total = 0;
+  auto flush = [&](int count) {  // process stage[0..count) (count <= 64) as one chunk
+    const int idx = (lane < count) ? stage[lane] : 0;
+    const int d = (lane < count) ? hamming256w(a0, a1, desc + (size_t)idx * 32) : ORB_INT_MAX;
+    fold_chunk_g(b, d, idx);
+  };
+  for (int r = r0; r <= r1; ++r)
+    for (int c = c0; c <= c1; ++c) {
+      const int beg = cell_off[r * cols + c], end = cell_off[r * cols + c + 1];
+      for (int i0 = beg; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        int id = 0;
+        bool pass = false;
+        if (i < end) {
+          id = cell_feat[i];
+          const int oc = (int)(kpl[id].y & 0xFFu);
+          pass = oc <= hi && oc >= lo && !(exclude && exclude[id]);
+        }
+        const unsigned long long m = __ballot(pass);
+        if (pass) stage[staged + __popcll(m & ((1ull << lane) - 1ull))] = id;
+        staged += __popcll(m);
+        total += __popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (staged >= 64) {
+          flush(64);
+          const int keep = (lane < staged - 64) ? stage[64 + lane] : 0;
+          __builtin_amdgcn_wave_barrier();
+          if (lane < staged - 64) stage[lane] = keep;
+          staged -= 64;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+  if (staged > 0) flush(staged);
+  if (lane == 0) {
+    n_cand[q] = total;
+    best_idx[q] = total ? b.min_idx : -1;
+    best_dist[q] = b.min_d;
+    second_dist[q] = b.second;
+  }
+}
+
+void launch_grid_build(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, int rows, int cols, int32_t* d_cell_off,
+                       int32_t* d_cell_feat) {
+  const size_t lds = (size_t)(2 * rows * cols + 1) * sizeof(int32_t);
+  hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), lds, s, d_kps, d_n_kp, rows, cols, d_cell_off, d_cell_feat);
+}
+
+void launch_search_area(hipStream_t s, const uint2* d_kpl, const uint8_t* d_desc, int width, int height, int rows, int cols,
+                        const int32_t* d_cell_off, const int32_t* d_cell_feat, int nq, const float* d_qxy, const float* d_radius,
+                        const int8_t* d_min_level, const int8_t* d_max_level, const uint8_t* d_q_desc, const uint8_t* d_exclude,
+                        int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second, int32_t* d_n_cand) {
+  if (nq <= 0) return;
+  hipLaunchKernelGGL(k_search_area, dim3((nq + 3) / 4), dim3(256), 0, s, d_kpl, d_desc, width, height, rows, cols, d_cell_off,
+                     d_cell_feat, nq, d_qxy, d_radius, d_min_level, d_max_level, d_q_desc, d_exclude, d_best_idx, d_best_dist, d_second,
+                     d_n_cand);
+}
+
+}  // namespace orbfe

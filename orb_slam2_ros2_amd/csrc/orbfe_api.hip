@@ -55,6 +55,12 @@ void launch_ba_system(hipStream_t s, int n_poses, int n_points, int n_edges, con
                       const double* info, const double* delta, BaParamsDev prm, const uint8_t* pose_fixed, const int32_t* pt_off,
                       const int32_t* pt_edges, const int32_t* ps_off, const int32_t* ps_edges, double* Hpp, double* bp, double* Hll,
                       double* bl, double* Hpl);
+void launch_grid_build(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, int rows, int cols, int32_t* d_cell_off,
+                       int32_t* d_cell_feat);
+void launch_search_area(hipStream_t s, const uint2* d_kpl, const uint8_t* d_desc, int width, int height, int rows, int cols,
+                        const int32_t* d_cell_off, const int32_t* d_cell_feat, int nq, const float* d_qxy, const float* d_radius,
+                        const int8_t* d_min_level, const int8_t* d_max_level, const uint8_t* d_q_desc, const uint8_t* d_exclude,
+                        int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second, int32_t* d_n_cand);
 void launch_pose_only(hipStream_t s, int n, const double* Xw, const double* meas, const double* info, const float* sigma2,
                       const double* pose_in, BaParamsDev prm, double d_mono, double d_stereo, double* err, uint8_t* level,
                       uint8_t* robust, uint8_t* inlier, double* pose_out, int32_t* n_good);
@@ -1005,6 +1011,53 @@ orbfe_status orbfe_ba_build_system(orbfe_ctx* c, const orbfe_ba_problem* p, cons
   HIP_TRY(c, down(o->Hll, o_hll, (size_t)NP * 72));
   HIP_TRY(c, down(o->bl, o_bl, (size_t)NP * 24));
   if (o->Hpl) HIP_TRY(c, down(o->Hpl, o_hpl, (size_t)E * 144));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_search_in_area(orbfe_ctx* c, int32_t slot, int32_t nq, const float* qxy, const float* radius, const int8_t* min_level,
+                                  const int8_t* max_level, const uint8_t* q_desc, const uint8_t* exclude, int32_t* best_idx,
+                                  int32_t* best_dist, int32_t* second_dist, int32_t* n_cand) {
+  if (!c || slot < 0 || slot >= c->cfg.max_images || nq < 0) return fail(c, ORBFE_EBADARG, "search_in_area: bad slot / count");
+  if (nq && (!qxy || !radius || !min_level || !max_level || !q_desc || !best_idx || !best_dist || !second_dist || !n_cand))
+    return fail(c, ORBFE_EBADARG, "search_in_area: NULL argument");
+  if (nq == 0) return ORBFE_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
+  const int rows = (c->cfg.height + 47) / 48, cols = (c->cfg.width + 63) / 64;  // cvCeil((float)(max-min)/grid), Frame.cc:55-56
+  const size_t ncells = (size_t)rows * cols;
+  if ((2 * ncells + 1) * 4 > 60 * 1024) return fail(c, ORBFE_EBADSIZE, "search_in_area: %zu grid cells exceed the LDS counters", ncells);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o2 = off;
+    off += align_up(std::max<size_t>(bytes, 8), 256);
+    return o2;
+  };
+  const size_t o_co = take((ncells + 1) * 4), o_cf = take(NF * 4), o_q = take((size_t)nq * 8), o_r = take((size_t)nq * 4),
+               o_lo = take((size_t)nq), o_hi = take((size_t)nq), o_d = take((size_t)nq * 32), o_ex = take(NF), o_bi = take((size_t)nq * 4),
+               o_bd = take((size_t)nq * 4), o_sd = take((size_t)nq * 4), o_nc = take((size_t)nq * 4);
+  TRY(ensure_tmp(c, off));
+  uint8_t* b = (uint8_t*)c->d_tmp;
+  HIP_TRY(c, hipMemcpyAsync(b + o_q, qxy, (size_t)nq * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_r, radius, (size_t)nq * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_lo, min_level, (size_t)nq, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_hi, max_level, (size_t)nq, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_d, q_desc, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+  if (exclude) HIP_TRY(c, hipMemcpyAsync(b + o_ex, exclude, (size_t)c->cfg.n_features, hipMemcpyHostToDevice, c->stream));
+  {
+    StageTimer tm(c, ORBFE_STAGE_MATCH, c->stream);
+    launch_grid_build(c->stream, c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, rows, cols, (int32_t*)(b + o_co), (int32_t*)(b + o_cf));
+    launch_search_area(c->stream, c->d_kpl + (size_t)slot * NF, c->d_desc + (size_t)slot * NF * 32, c->cfg.width, c->cfg.height, rows, cols,
+                       (const int32_t*)(b + o_co), (const int32_t*)(b + o_cf), nq, (const float*)(b + o_q), (const float*)(b + o_r),
+                       (const int8_t*)(b + o_lo), (const int8_t*)(b + o_hi), b + o_d, exclude ? b + o_ex : nullptr, (int32_t*)(b + o_bi),
+                       (int32_t*)(b + o_bd), (int32_t*)(b + o_sd), (int32_t*)(b + o_nc));
+  }
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(best_idx, b + o_bi, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(best_dist, b + o_bd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(second_dist, b + o_sd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(n_cand, b + o_nc, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_timers(c);
   return ORBFE_OK;

@@ -115,6 +115,12 @@ class ORBMatcher:
         second_dist) with the reference's scan-order semantics."""
         return ctx.match_bruteforce(queries, train, cand_offsets, cand_idx)
 
+    @staticmethod
+    def searchInArea(ctx: Context, slot, qxy, radius, min_level, max_level, q_desc, exclude=None):
+        """Batched VirtualFrame::findFeaturesInArea + getBestMatch (Frame.cc:286-311, ORBMatcher.cc:967-990): the core of
+        ORBMatcher::searchByProjection (ORBMatcher.cc:265-347, 561-612) against the device-resident features of `slot`."""
+        return ctx.search_in_area(slot, qxy, radius, min_level, max_level, q_desc, exclude)
+
     def searchByStereo(self, frame: "StereoFrontEnd", fx: float, bf: float):
         """ORBMatcher::searchByStereo (ORBMatcher.cc:18-81) on the device-resident features of `frame`.
         Returns (n_matches, right_u, depth) with -1 where unmatched."""
