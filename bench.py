@@ -222,6 +222,9 @@ def main():
             "algorithmic_bytes_per_launch": stage_bytes[dom],
             "avg_launch_ms": dom_ms,
             "images_per_launch": images_per_launch,
+            # k_fast runs once per pyramid level (per-level LDS carve-up): the "launch" priced here is the level sweep of one
+            # batch, i.e. NLEVELS back-to-back k_fast launches; rocprofv3's per-launch average x NLEVELS is the same figure
+            "kernel_launches_per_step": {"fast": NLEVELS, "orient_brief": 4, "resize": 1, "blur": 1, "quadtree": 1, "stereo": 1}[dom],
             "all_stages": {k: {"ms": round(stages[k], 4), "GBps": round(stage_bytes[k] / (stages[k] * 1e-3) / 1e9, 1)}
                            for k in stages if k in stage_bytes and stages[k] > 0},
         },

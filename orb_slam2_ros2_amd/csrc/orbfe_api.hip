@@ -23,9 +23,9 @@ void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int total_ti
 void launch_load_level0(hipStream_t st, const uint8_t* d_src, size_t src_stride, size_t src_pitch, uint8_t* d_pyr, size_t img_pitch,
                         uint32_t plane_off, int dst_stride, int w, int h, int slot0, int slot_step, int n_img);
 // k_fast.hip
-void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, int n_cells_total, const uint8_t* d_pyr,
-                 size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch, int32_t* d_n_cand, int n_levels,
-                 int n_img, int max_pw, int max_ph);
+void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, const LevelDev* h_lv, const int* lvl_max_pw,
+                 const int* lvl_max_ph, const uint8_t* d_pyr, size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch,
+                 int32_t* d_n_cand, int n_levels, int n_img);
 // k_quadtree.hip
 size_t quadtree_lds_bytes(int node_cap, int rec_cap);
 hipError_t quadtree_configure(size_t lds_bytes);
@@ -100,7 +100,7 @@ struct orbfe_ctx {
   int rec_cap = 0;           // upper bound of candidate records one quadtree wave keeps in LDS (launch picks <= this)
   int n_cu = 256;            // compute units of the device
   int node_cap = 0, sort_cap = 0;
-  int max_pw = 0, max_ph = 0;  // largest FAST cell patch (sizes the LDS of k_fast)
+  int lvl_max_pw[ORBFE_MAX_LEVELS] = {0}, lvl_max_ph[ORBFE_MAX_LEVELS] = {0};  // largest FAST cell patch per level (sizes the LDS of k_fast)
 
   // device
   LevelDev* d_lv = nullptr;
@@ -262,8 +262,8 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
         cd.offy = (int16_t)(idx * L.h_cell);
         cd.pad = 0;
         c->cells.push_back(cd);
-        c->max_pw = std::max(c->max_pw, (int)cd.pw);
-        c->max_ph = std::max(c->max_ph, (int)cd.ph);
+        c->lvl_max_pw[l] = std::max(c->lvl_max_pw[l], (int)cd.pw);
+        c->lvl_max_ph[l] = std::max(c->lvl_max_ph[l], (int)cd.ph);
         ++n_cells;
       }
     }
@@ -442,7 +442,7 @@ static void drain_timers(orbfe_ctx* c) {
 
 // ---- the launch sequence for slots [0, n_img) ---------------------------------------------------------
 // Slots [img0, img0 + n_img) on stream `st`.  Every per-image array is offset on the host, so the kernels index from 0.
-static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img) {
+static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, int lds_share = 1) {
   const int nl = c->cfg.n_levels;
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
   const size_t i0 = (size_t)img0;
@@ -460,8 +460,8 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   HIP_TRY(c, hipMemsetAsync(n_cand, 0, sizeof(int32_t) * (size_t)n_img * nl, st));
   {
     StageTimer t(c, ORBFE_STAGE_FAST, st);
-    launch_fast(st, c->d_lv, c->d_cells, c->n_cells_total, pyr, c->img_pitch, c->cfg.fast_hi, c->cfg.fast_lo,
-                c->d_scr_a + i0 * c->scratch_pitch, c->scratch_pitch, n_cand, nl, n_img, c->max_pw, c->max_ph);
+    launch_fast(st, c->d_lv, c->d_cells, c->lv.data(), c->lvl_max_pw, c->lvl_max_ph, pyr, c->img_pitch, c->cfg.fast_hi, c->cfg.fast_lo,
+                c->d_scr_a + i0 * c->scratch_pitch, c->scratch_pitch, n_cand, nl, n_img);
   }
   {
     StageTimer t(c, ORBFE_STAGE_QUADTREE, st);
@@ -470,7 +470,9 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     // records go to LDS only as far as that still holds (measured at 1024 trees: 4 trees/CU 0.59 ms, 3 trees/CU 0.96 ms).
     const int trees = nl * n_img;
     const int per_cu = (trees + c->n_cu - 1) / c->n_cu;
-    const size_t lds_cu = 160 * 1024 - 2048;
+    // lds_share > 1: that many chunks run side by side on their own streams; each quadtree launch leaves the rest of the
+    // CU's LDS to the other chunks' kernels so that they can fill the SIMDs the tree waves leave idle.
+    const size_t lds_cu = (160 * 1024 - 2048) / (size_t)std::max(lds_share, 1);
     const size_t node_bytes = quadtree_lds_bytes(c->node_cap, 0);
     size_t budget = lds_cu / (size_t)std::max(per_cu, 1);
     budget -= budget % 512;
@@ -839,7 +841,7 @@ orbfe_status orbfe_stereo_batch_device(orbfe_ctx* c, const uint8_t* d_left, cons
                        c->cfg.width, c->cfg.height, 2 * p0, 2, p1 - p0);
     launch_load_level0(st, d_right + (size_t)p0 * image_pitch, stride, image_pitch, c->d_pyr, c->img_pitch, L0.plane_off, L0.stride,
                        c->cfg.width, c->cfg.height, 2 * p0 + 1, 2, p1 - p0);
-    TRY(run_extract(c, st, 2 * p0, 2 * (p1 - p0)));
+    TRY(run_extract(c, st, 2 * p0, 2 * (p1 - p0), serial ? 1 : n_chunks));
     TRY(run_stereo(c, st, 2 * p0, 2 * p0 + 1, 2, p0, p1 - p0, fx, bf));
     if (!serial) {
       HIP_TRY(c, hipEventRecord(c->ev_join[k], st));

@@ -143,7 +143,11 @@ def test_sparse_image_levels_with_fewer_candidates_than_quota_yield_nothing(orc,
 def test_flat_and_noise_only_images(orc, lib):
     ctx = lib.Context(400, 300, n_features=500, n_levels=4, max_images=1)
     for img in (np.full((300, 400), 128, np.uint8), np.random.default_rng(0).integers(120, 127, (300, 400)).astype(np.uint8),
-                np.random.default_rng(1).integers(0, 256, (300, 400)).astype(np.uint8)):
+                np.random.default_rng(1).integers(0, 256, (300, 400)).astype(np.uint8),
+                # salt and pepper / a checkerboard with jitter: almost every pixel passes FAST's necessary test for BOTH
+                # polarities (stresses the dual-polarity list of k_fast and its overflow path)
+                (np.random.default_rng(2).integers(0, 2, (300, 400)) * 255).astype(np.uint8),
+                ((np.indices((300, 400)).sum(0) & 1) * 200 + np.random.default_rng(3).integers(0, 40, (300, 400))).astype(np.uint8)):
         k, d = ctx.extract(img)
         assert_image_parity(ctx, 0, orc.extractor(img, n_features=500, n_levels=4), k, d, 4)
     ctx.close()

@@ -14,7 +14,7 @@ def collect(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        name = r["Kernel_Name"].split("(")[0].split("::")[-1]
+        name = r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]  # k_fast<48, 40> -> k_fast
         tot[name] += float(r["Counter_Value"])
         n[name] += 1
     return tot, n
@@ -26,10 +26,12 @@ def main():
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py`, see profiles/",
            "pairs_per_step": int(sys.argv[3]), "images_per_launch": int(sys.argv[5]), "kernels": {}, "per_kernel": {}}
     stage = collections.defaultdict(lambda: [0.0, 0.0, 0])
+    # a "launch" of a stage = one batched step (k_fast runs once per pyramid level, k_load_level0 once per eye): average per step
+    steps_f, steps_w = max(nf["k_quadtree"], 1), max(nw["k_quadtree"], 1)
     for k in sorted(set(fetch) | set(write)):
-        f = fetch[k] / max(nf[k], 1) * 1024.0
-        w = write[k] / max(nw[k], 1) * 1024.0
-        out["per_kernel"][k] = {"launches": nf[k], "fetch_bytes_raw": f, "fetch_bytes_corrected": 2 * f, "write_bytes": w}
+        f = fetch[k] / steps_f * 1024.0
+        w = write[k] / steps_w * 1024.0
+        out["per_kernel"][k] = {"launches_per_step": nf[k] / steps_f, "fetch_bytes_raw": f, "fetch_bytes_corrected": 2 * f, "write_bytes": w}
         if k in STAGE:
             stage[STAGE[k]][0] += 2 * f
             stage[STAGE[k]][1] += w
