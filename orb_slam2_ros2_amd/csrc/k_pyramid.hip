@@ -15,82 +15,87 @@
 namespace orbfe {
 
 // ---------------------------------------------------------------------------------------------
-// resize: 64x16 output pixels per 256-thread block; grid.x = tiles of all levels >= 1, grid.y = image.
-// The level-0 footprint of the tile (<= 60 rows x 232 bytes at scale 3.58) is staged in LDS with aligned
-// 32-bit loads; every thread then produces 4 horizontally adjacent outputs from LDS bytes and stores them
-// as one word.
+// resize: 64 x RS_TH output pixels per 256-thread block; grid.x = tiles of all levels >= 1 (host-built descriptors: no
+// level search, no division, no dependent tap loads before the footprint is known), grid.y = image.
+// The level-0 footprint of the tile (<= 60 rows x 240 bytes at scale 3.58) and the tile's 64 + RS_TH taps are staged in
+// LDS in ONE round trip; every thread then produces 4 horizontally adjacent outputs per row from LDS bytes and stores
+// them as one word.
 // ---------------------------------------------------------------------------------------------
-#define RS_TW 64
-#define RS_TH 16
-#define RS_LDS_BYTES 16384
-
-__global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv, int n_levels,
+__global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv, const RsTile* __restrict__ tiles,
                                                 const ResizeTap* __restrict__ taps, uint8_t* __restrict__ pyr,
                                                 size_t img_pitch) {
-  __shared__ uint32_t tile[RS_LDS_BYTES / 4];
+  __shared__ __attribute__((aligned(16))) uint32_t tile[RS_LDS_BYTES / 4];
+  __shared__ ResizeTap xs[RS_TW];
+  __shared__ ResizeTap ys[RS_TH];
   const int img = blockIdx.y;
-  const int tl = blockIdx.x;
-  int l = 1;
-  while (l + 1 < n_levels && tl >= lv[l + 1].rs_tile_base) ++l;
-  const LevelDev& L = lv[l];
-  const int t = tl - L.rs_tile_base;
-  const int x0 = (t % L.rs_tiles_x) * RS_TW, y0 = (t / L.rs_tiles_x) * RS_TH;
+  const RsTile T = tiles[blockIdx.x];
+  const LevelDev& L = lv[T.level];
+  const int x0 = T.x0, y0 = T.y0;
   const int sw = lv[0].w, sh = lv[0].h, sstride = lv[0].stride;
   uint8_t* base = pyr + (size_t)img * img_pitch;
   const uint8_t* S = base + lv[0].plane_off;
-  const ResizeTap* xt = taps + L.xtab_off;
-  const ResizeTap* yt = taps + L.ytab_off;
-  // level-0 footprint of the tile (taps are monotone in the output coordinate)
-  const int x1 = min(x0 + RS_TW, L.w) - 1, y1 = min(y0 + RS_TH, L.h) - 1;
-  const int sx_lo = xt[x0].ofs & ~3, sx_hi = min(xt[x1].ofs + 1, sw - 1);
-  const int sy_lo = min(max(yt[y0].ofs, 0), sh - 1), sy_hi = min(max(yt[y1].ofs + 1, 0), sh - 1);
-  const int nw = ((sx_hi - sx_lo) >> 2) + 1, nr = sy_hi - sy_lo + 1;
-  const int pitch = nw * 4;
-  const bool fits = nw * nr * 4 <= RS_LDS_BYTES;  // always true for pyramid scales; otherwise read global memory directly
-  if (fits) {
-    const uint32_t inv = ((1u << 20) + nw - 1) / nw;
-    for (int k = threadIdx.x; k < nw * nr; k += 256) {
-      const int r = (int)(((uint32_t)k * inv) >> 20), c = k - r * nw;
-      tile[k] = *(const uint32_t*)(S + (size_t)(sy_lo + r) * sstride + sx_lo + 4 * c);
+  const int sx_lo = T.sx_lo, sy_lo = T.sy_lo, nw = T.nw, nr = T.nr;
+  const bool fits = nw > 0;  // always true for pyramid scales; otherwise read global memory directly
+  {
+    const ResizeTap* xt = taps + L.xtab_off;
+    const ResizeTap* yt = taps + L.ytab_off;
+    const int k = threadIdx.x;
+    if (k < RS_TW)
+      xs[k] = xt[min(x0 + k, L.w - 1)];
+    else if (k < RS_TW + RS_TH)
+      ys[k - RS_TW] = yt[min(y0 + k - RS_TW, L.h - 1)];
+  }
+  if (fits) {  // footprint rows start at a multiple of 16 bytes and are a whole number of 16-byte quads
+    const int nq = nw >> 2;
+    const uint32_t inv = ((1u << 20) + nq - 1) / nq;
+    const uint8_t* src = S + (size_t)sy_lo * sstride + sx_lo;
+    uint4* tile4 = (uint4*)tile;
+    for (int k = threadIdx.x; k < nq * nr; k += 256) {
+      const int r = (int)(((uint32_t)k * inv) >> 20), c = k - r * nq;
+      tile4[k] = *(const uint4*)(src + (uint32_t)(r * sstride + 16 * c));
     }
   }
   __syncthreads();
-  const int cx = x0 + (threadIdx.x & 15) * 4;
-  const int cy = y0 + (threadIdx.x >> 4);
-  if (cx >= L.w || cy >= L.h) return;
-  const ResizeTap ay = yt[cy];
-  const int sy0 = min(max(ay.ofs, 0), sh - 1), sy1 = min(max(ay.ofs + 1, 0), sh - 1);
-  const uint8_t* tb = (const uint8_t*)tile;
-  uint32_t out = 0;
+  const int tx = (threadIdx.x & 15) * 4;
+  const int cx = x0 + tx;
+  if (cx >= L.w) return;
+  const int pitch = nw * 4;
+  // explicit address spaces keep the staged path on ds_read (a merged pointer would turn every byte read into a flat load)
+  typedef const __attribute__((address_space(3))) uint8_t* lds_bytes_t;
+  lds_bytes_t tb = (lds_bytes_t)tile;
+  ResizeTap ax[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int dx = min(cx + j, L.w - 1);
-    const ResizeTap ax = xt[dx];
-    const int sx0 = ax.ofs;
-    const int sx1 = min(ax.ofs + 1, sw - 1);  // tap c1 is 0 wherever the reference does not read S[sx+1]
-    int p00, p01, p10, p11;
-    if (fits) {
-      const uint8_t* r0 = tb + (sy0 - sy_lo) * pitch - sx_lo;
-      const uint8_t* r1 = tb + (sy1 - sy_lo) * pitch - sx_lo;
-      p00 = r0[sx0];
-      p01 = r0[sx1];
-      p10 = r1[sx0];
-      p11 = r1[sx1];
-    } else {
-      const uint8_t* r0 = S + (size_t)sy0 * sstride;
-      const uint8_t* r1 = S + (size_t)sy1 * sstride;
-      p00 = r0[sx0];
-      p01 = r0[sx1];
-      p10 = r1[sx0];
-      p11 = r1[sx1];
+  for (int j = 0; j < 4; ++j) ax[j] = xs[tx + j];
+#pragma unroll
+  for (int rr = 0; rr < RS_TH / 16; ++rr) {
+    const int ty = (threadIdx.x >> 4) + 16 * rr;
+    const int cy = y0 + ty;
+    if (cy >= L.h) break;
+    const ResizeTap ay = ys[ty];
+    const int sy0 = min(max(ay.ofs, 0), sh - 1), sy1 = min(max(ay.ofs + 1, 0), sh - 1);
+    // (two code paths, not one pointer select: an LDS address minus sx_lo is not a valid flat address)
+    const int o0 = (sy0 - sy_lo) * pitch - sx_lo, o1 = (sy1 - sy_lo) * pitch - sx_lo;
+    const uint8_t* g0 = S + (size_t)sy0 * sstride;
+    const uint8_t* g1 = S + (size_t)sy1 * sstride;
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int sx0 = ax[j].ofs;
+      const int sx1 = min(ax[j].ofs + 1, sw - 1);  // tap c1 is 0 wherever the reference does not read S[sx+1]
+      int p00, p01, p10, p11;
+      if (fits) {
+        p00 = tb[o0 + sx0], p01 = tb[o0 + sx1], p10 = tb[o1 + sx0], p11 = tb[o1 + sx1];
+      } else {
+        p00 = g0[sx0], p01 = g0[sx1], p10 = g1[sx0], p11 = g1[sx1];
+      }
+      const int h0 = p00 * ax[j].c0 + p01 * ax[j].c1;
+      const int h1 = p10 * ax[j].c0 + p11 * ax[j].c1;
+      int v = ((((int)ay.c0 * (h0 >> 4)) >> 16) + (((int)ay.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      v = min(255, max(0, v));
+      out |= (uint32_t)v << (8 * j);
     }
-    const int h0 = p00 * ax.c0 + p01 * ax.c1;
-    const int h1 = p10 * ax.c0 + p11 * ax.c1;
-    int v = ((((int)ay.c0 * (h0 >> 4)) >> 16) + (((int)ay.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
-    v = min(255, max(0, v));
-    out |= (uint32_t)v << (8 * j);
+    *(uint32_t*)(base + L.plane_off + (size_t)cy * L.stride + cx) = out;  // stride is a multiple of 16: the padding absorbs the tail
   }
-  *(uint32_t*)(base + L.plane_off + (size_t)cy * L.stride + cx) = out;  // stride is a multiple of 16: the padding absorbs the tail
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -245,10 +250,10 @@ void launch_load_level0(hipStream_t st, const uint8_t* d_src, size_t src_stride,
 // ---------------------------------------------------------------------------------------------
 // launchers (called from the C-ABI layer)
 // ---------------------------------------------------------------------------------------------
-void launch_resize(hipStream_t s, const LevelDev* d_lv, int n_levels, int total_tiles, const ResizeTap* d_taps, uint8_t* d_pyr,
+void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, int total_tiles, const ResizeTap* d_taps, uint8_t* d_pyr,
                    size_t img_pitch, int n_img) {
   if (total_tiles <= 0 || n_img <= 0) return;
-  hipLaunchKernelGGL(k_resize, dim3(total_tiles, n_img), dim3(256), 0, s, d_lv, n_levels, d_taps, d_pyr, img_pitch);
+  hipLaunchKernelGGL(k_resize, dim3(total_tiles, n_img), dim3(256), 0, s, d_lv, d_tiles, d_taps, d_pyr, img_pitch);
 }
 
 void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int total_tiles, const uint8_t* d_pyr, uint8_t* d_blur,

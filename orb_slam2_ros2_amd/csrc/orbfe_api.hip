@@ -16,7 +16,7 @@
 
 namespace orbfe {
 // k_pyramid.hip
-void launch_resize(hipStream_t s, const LevelDev* d_lv, int n_levels, int total_tiles, const ResizeTap* d_taps, uint8_t* d_pyr,
+void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, int total_tiles, const ResizeTap* d_taps, uint8_t* d_pyr,
                    size_t img_pitch, int n_img);
 void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int total_tiles, const uint8_t* d_pyr, uint8_t* d_blur,
                  size_t img_pitch, const int taps[7], int n_img);
@@ -92,6 +92,8 @@ struct orbfe_ctx {
   std::vector<LevelDev> lv;
   std::vector<CellDev> cells;
   std::vector<ResizeTap> taps;
+  std::vector<RsTile> rs_tile_tab;
+  RsTile* d_rs_tiles = nullptr;
   int umax[16];
   int blur_taps[7];
   int n_cells_total = 0, rs_tiles = 0, bl_tiles = 0;
@@ -296,8 +298,8 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
       build_resize_axis(cfg.width, L.w, c->taps);
       L.ytab_off = (uint32_t)c->taps.size();
       build_resize_axis(cfg.height, L.h, c->taps);
-      L.rs_tiles_x = (L.w + 63) / 64;  // k_resize: 64x16 output tiles
-      L.rs_tiles_y = (L.h + 15) / 16;
+      L.rs_tiles_x = (L.w + RS_TW - 1) / RS_TW;  // k_resize output tiles
+      L.rs_tiles_y = (L.h + RS_TH - 1) / RS_TH;
       rs_tiles += L.rs_tiles_x * L.rs_tiles_y;
     }
     L.bl_tile_base = bl_tiles;
@@ -322,6 +324,27 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
       }
     }
   }
+  // resize work items: output tile + the level-0 footprint it reads (taps are monotone in the output coordinate)
+  c->rs_tile_tab.clear();
+  for (int l = 1; l < nl; ++l) {
+    const LevelDev& L = c->lv[l];
+    const ResizeTap* xt = c->taps.data() + L.xtab_off;
+    const ResizeTap* yt = c->taps.data() + L.ytab_off;
+    for (int ty = 0; ty < L.rs_tiles_y; ++ty)
+      for (int tx = 0; tx < L.rs_tiles_x; ++tx) {
+        const int x0 = tx * RS_TW, y0 = ty * RS_TH;
+        const int x1 = std::min(x0 + RS_TW, (int)L.w) - 1, y1 = std::min(y0 + RS_TH, (int)L.h) - 1;
+        const int sx_lo = xt[x0].ofs & ~15, sx_hi = std::min(xt[x1].ofs + 1, cfg.width - 1);
+        const int sy_lo = std::min(std::max(yt[y0].ofs, 0), cfg.height - 1), sy_hi = std::min(std::max(yt[y1].ofs + 1, 0), cfg.height - 1);
+        const int nw = (((sx_hi - sx_lo) >> 4) + 1) * 4, nr = sy_hi - sy_lo + 1;  // whole 16-byte quads (rows are padded to 16 B)
+        RsTile t;
+        t.level = (int16_t)l, t.x0 = (int16_t)x0, t.y0 = (int16_t)y0, t.sx_lo = (int16_t)sx_lo, t.sy_lo = (int16_t)sy_lo;
+        t.nw = (int16_t)((nw * nr * 4 <= RS_LDS_BYTES) ? nw : 0);
+        t.nr = (int16_t)nr, t.pad = 0;
+        c->rs_tile_tab.push_back(t);
+      }
+  }
+  if ((int)c->rs_tile_tab.size() != rs_tiles) return fail(c, ORBFE_EDEVICE, "internal: resize tile count");
   c->n_cells_total = cell_base;
   c->rs_tiles = rs_tiles;
   c->bl_tiles = bl_tiles;
@@ -451,7 +474,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   int32_t* n_cand = c->d_n_cand + i0 * nl;
   {
     StageTimer t(c, ORBFE_STAGE_RESIZE, st);
-    launch_resize(st, c->d_lv, nl, c->rs_tiles, c->d_taps, pyr, c->img_pitch, n_img);
+    launch_resize(st, c->d_lv, c->d_rs_tiles, c->rs_tiles, c->d_taps, pyr, c->img_pitch, n_img);
   }
   {
     StageTimer t(c, ORBFE_STAGE_BLUR, st);
@@ -524,7 +547,7 @@ void orbfe_destroy(orbfe_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   drain_timers(c);
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
-  void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_pattern, c->d_pyr,     c->d_blur,
+  void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_rs_tiles, c->d_pattern, c->d_pyr,     c->d_blur,
                   c->d_scr_a, c->d_scr_c,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_kp,
                   c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos, c->d_kx, c->d_env, c->d_kpl,   c->d_right_u, c->d_depth, c->d_n_match,
                   c->d_best_right, c->d_best_dist, c->d_tmp};
@@ -608,6 +631,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   ALLOC(c->d_lv, NL);
   ALLOC(c->d_cells, c->cells.size());
   ALLOC(c->d_taps, c->taps.size());
+  ALLOC(c->d_rs_tiles, c->rs_tile_tab.size());
   ALLOC(c->d_pattern, 1024);
   ALLOC(c->d_pyr, M * c->img_pitch);
   ALLOC(c->d_blur, M * c->img_pitch);
@@ -647,6 +671,8 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   if (e == hipSuccess) e = hipMemcpy(c->d_lv, c->lv.data(), sizeof(LevelDev) * NL, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(c->d_cells, c->cells.data(), sizeof(CellDev) * c->cells.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess && !c->taps.empty()) e = hipMemcpy(c->d_taps, c->taps.data(), sizeof(ResizeTap) * c->taps.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !c->rs_tile_tab.empty())
+    e = hipMemcpy(c->d_rs_tiles, c->rs_tile_tab.data(), sizeof(RsTile) * c->rs_tile_tab.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(c->d_pattern, pat, 1024, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(c->d_n_kp, 0, sizeof(int32_t) * M);
   if (e == hipSuccess) e = hipMemset(c->d_sel_count, 0, sizeof(int32_t) * M * NL);

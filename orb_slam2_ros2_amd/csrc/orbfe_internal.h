@@ -16,6 +16,17 @@ struct ResizeTap {
   int16_t c0, c1;
 };
 
+// k_resize work item: RS_TW x RS_TH output pixels of one level and the level-0 footprint they read
+#define RS_TW 64
+#define RS_TH 16
+#define RS_LDS_BYTES 16384
+struct RsTile {
+  int16_t level, x0, y0;  // output tile origin
+  int16_t sx_lo, nw;      // footprint: first level-0 column (multiple of 16), 32-bit words per row (multiple of 4); nw == 0: does not fit the LDS
+  int16_t sy_lo, nr;      // first level-0 row, rows
+  int16_t pad;
+};
+
 // Per pyramid level, resident in device memory (one table per context).
 struct LevelDev {
   int32_t w, h, stride;  // plane size, row pitch in bytes (multiple of 16)
