@@ -103,6 +103,9 @@ __device__ __forceinline__ int cv_floor_f(float v) {
   return i - (i > v);
 }
 
+#ifndef ST_STEP
+#define ST_STEP 8  // hit chunks per step of the candidate scan (a 1241x376 frame has ~5 per left keypoint)
+#endif
 __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv, const uint8_t* __restrict__ pyr, size_t img_pitch,
                                                 const orbfe_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
                                                 const KpAux* __restrict__ aux, const float* __restrict__ kx,
@@ -113,7 +116,9 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
                                                 int slot_r0, int slot_step, int pair0) {
 #pragma clang fp contract(off)
   __shared__ uint32_t s_sad[4][11 * 4 + 11 * 7 + 7];  // per wave: left 11 rows x 4 words, right 11 rows x 7 words
+  __shared__ uint16_t s_clist[4][ST_STEP * 64];         // per wave: right indices of the step's candidates, list order
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint16_t* clist = s_clist[wv];
   const int li = blockIdx.x * 4 + wv;
   const int pair = pair0 + blockIdx.y;
   const int sl = slot_l0 + blockIdx.y * slot_step, sr = slot_r0 + blockIdx.y * slot_step;
@@ -160,14 +165,18 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
       hit = row >= (int)e.x && row < (int)e.y;
     }
     unsigned long long todo = __ballot(hit);
-    // four hit chunks per step: their filter loads, then their descriptor loads, are issued together (two dependent
-    // memory round trips per four chunks instead of eight); the order-dependent fold then runs chunk by chunk
+    // ST_STEP hit chunks per step, two dependent memory round trips per step: (a) the filter records of ALL the step's
+    // chunks are requested before the first is looked at (clamped indices, so the loads are unconditional); (b) the
+    // candidates that pass -- a few per chunk -- are compacted in list order through LDS, so that one lane holds one
+    // candidate, one batch of descriptor loads serves the whole step and the order-dependent fold runs once per 64
+    // candidates instead of once per chunk.  (Measured: with each chunk's loads consumed inside its own branch the step
+    // size made no difference at all; with per-chunk descriptor registers 8 chunks per step cost half the occupancy.)
     while (todo) {
-      int cid[4];
-      bool pass[4];
-      int d[4];
+      int cid[ST_STEP];
+      KpAux ra[ST_STEP];
+      float rxv[ST_STEP];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < ST_STEP; ++u) {
         cid[u] = -1;
         if (todo) {
           cid[u] = cb + (__ffsll((long long)todo) - 1);
@@ -175,26 +184,31 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        pass[u] = false;
-        const int c = (cid[u] << 6) + lane;
-        if (cid[u] >= 0 && c < nr) {
-          const KpAux a = RA[c];
-          const float rx = RX[c];
-          pass[u] = row >= a.row_min && row < a.row_max && rx < max_u && rx > min_u;
-        }
+      for (int u = 0; u < ST_STEP; ++u) {
+        const int c = min((max(cid[u], 0) << 6) + lane, nr - 1);
+        ra[u] = RA[c];
+        rxv[u] = RX[c];
       }
+      int total = 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < ST_STEP; ++u) {
         const int c = (cid[u] << 6) + lane;
-        d[u] = pass[u] ? hamming256(a0, a1, RD + (size_t)c * 32) : ORB_INT_MAX;
+        const bool pass = cid[u] >= 0 && c < nr && row >= ra[u].row_min && row < ra[u].row_max && rxv[u] < max_u && rxv[u] > min_u;
+        const unsigned long long m = __ballot(pass);
+        if (pass) clist[total + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)c;
+        total += __popcll(m);
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (cid[u] < 0 || __ballot(pass[u]) == 0ull) continue;  // wave-uniform
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int g = 0; g < total; g += 64) {
+        const bool has = g + lane < total;
+        const int idx = has ? (int)clist[g + lane] : 0;
+        const int d = has ? hamming256(a0, a1, RD + (size_t)idx * 32) : ORB_INT_MAX;
         any = true;
-        fold_chunk(b, d[u], (cid[u] << 6) + lane, lane);
+        fold_chunk(b, d, idx, lane);
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
   double out_u = -1.0, out_depth = -1.0;
