@@ -60,7 +60,7 @@ __device__ __forceinline__ int locate_level(const int32_t* __restrict__ sc, int 
 //    entry = {x | y << 16 (level coordinates), level | response << 8}; x == 0xFFFF marks "no keypoint".
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_kplist(const LevelDev* __restrict__ lv, int n_levels, const uint32_t* __restrict__ sel,
-                                                const int32_t* __restrict__ sel_count, int n_features, uint2* __restrict__ kpl,
+                                                const int32_t* __restrict__ sel_count, int n_features, uint4* __restrict__ kpl,
                                                 int32_t* __restrict__ n_kp) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int img = blockIdx.y;
@@ -68,12 +68,14 @@ __global__ __launch_bounds__(256) void k_kplist(const LevelDev* __restrict__ lv,
   int j, total;
   const int level = locate_level(sel_count + (size_t)img * n_levels, n_levels, k, &j, &total);
   if (k == 0) n_kp[img] = total;
-  uint2 e = make_uint2(0xFFFFu, 0u);
+  uint4 e = make_uint4(0xFFFFu, 0u, 0u, 0u);
   if (level >= 0) {
     const LevelDev& L = lv[level];
     const uint32_t rec = sel[(size_t)img * n_features + L.quota_off + j];
     e.x = (ORBFE_REC_X(rec) + ORBFE_EDGE) | ((ORBFE_REC_Y(rec) + ORBFE_EDGE) << 16);
     e.y = (uint32_t)level | (ORBFE_REC_R(rec) << 8);
+    e.z = L.plane_off;  // the consumers address the plane straight from the entry: no dependent level-table lookup
+    e.w = (uint32_t)L.stride;
   }
   kpl[(size_t)img * n_features + k] = e;
 }
@@ -82,36 +84,42 @@ __global__ __launch_bounds__(256) void k_kplist(const LevelDev* __restrict__ lv,
 // 1. intensity-centroid moments, one wave per keypoint.  The 31x31 window of the UN-blurred plane is
 //    read as aligned 32-bit words (5 coalesced wave loads instead of 16 byte gathers).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ic_moments(const LevelDev* __restrict__ lv, const uint8_t* __restrict__ pyr,
-                                                    size_t img_pitch, const uint2* __restrict__ kpl, int n_features, UmaxPacked umax,
-                                                    int2* __restrict__ moments) {
+__global__ __launch_bounds__(256) void k_ic_moments(const uint8_t* __restrict__ pyr, size_t img_pitch, const uint4* __restrict__ kpl,
+                                                    int n_features, UmaxPacked umax, int2* __restrict__ moments) {
   const int lane = threadIdx.x & 63;
   const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int img = blockIdx.y;
   if (k >= n_features) return;
-  const uint2 e = kpl[(size_t)img * n_features + k];
+  // two dependent memory round trips per wave: the list entry (position, plane offset, stride), then all five window words
+  const uint4 e = kpl[(size_t)img * n_features + k];
   if ((e.x & 0xFFFFu) == 0xFFFFu) return;  // wave-uniform
-  const LevelDev& L = lv[e.y & 0xFFu];
   const int x = (int)(e.x & 0xFFFFu), y = (int)(e.x >> 16);  // level coordinates
-  const uint8_t* I = pyr + (size_t)img * img_pitch + L.plane_off;
-  const int stride = L.stride;
+  const uint8_t* I = pyr + (size_t)img * img_pitch + e.z;
+  const int stride = (int)e.w;
   const int xa = (x - 15) & ~3;  // first aligned word of a row of the window
+  uint32_t wv[5];
+#pragma unroll
+  for (int it = 0; it < 5; ++it) {        // 31 rows x 9 words = 279 words; indices past the end re-read the last word
+    const int idx = min(it * 64 + lane, 31 * 9 - 1);
+    const int r = (idx * 7282) >> 16;      // idx / 9 for idx < 320
+    const int c = idx - r * 9;
+    wv[it] = *(const uint32_t*)(I + (size_t)(y + r - 15) * stride + xa + 4 * c);
+  }
   int m10 = 0, m01 = 0;
 #pragma unroll
-  for (int it = 0; it < 5; ++it) {       // 31 rows x 9 words = 279 words
+  for (int it = 0; it < 5; ++it) {
     const int idx = it * 64 + lane;
-    const int r = (idx * 7282) >> 16;     // idx / 9 for idx < 320
+    const int r = (idx * 7282) >> 16;
     const int c = idx - r * 9;
     if (r < 31) {
       const int dy = r - 15;
       const int ady = dy < 0 ? -dy : dy;
       const int d = (int)((umax >> (4 * ady)) & 15ull);
-      const uint32_t wv = *(const uint32_t*)(I + (size_t)(y + dy) * stride + xa + 4 * c);
       const int dx0 = xa + 4 * c - x;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int dx = dx0 + b;
-        const int v = (int)((wv >> (8 * b)) & 255u);
+        const int v = (int)((wv[it] >> (8 * b)) & 255u);
         const int vv = (dx >= -d && dx <= d) ? v : 0;
         m10 += dx * vv;
         m01 += dy * vv;
@@ -127,14 +135,14 @@ __global__ __launch_bounds__(256) void k_ic_moments(const LevelDev* __restrict__
 // 2. orientation: ONE LANE per keypoint.  theta = atan2(m01, m10) and cos/sin in fp64 with the shared
 //    deterministic routines; assembles the cv::KeyPoint record and the stereo row band.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv, const uint2* __restrict__ kpl, int n_features,
+__global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv, const uint4* __restrict__ kpl, int n_features,
                                                 const int2* __restrict__ moments, double2* __restrict__ sincos,
                                                 orbfe_keypoint* __restrict__ kps, KpAux* __restrict__ aux, float* __restrict__ kx,
                                                 short2* __restrict__ env, int n_chunks, double* __restrict__ theta_out, int rows0) {
 #pragma clang fp contract(off)
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int img = blockIdx.y;
-  const uint2 e = (k < n_features) ? kpl[(size_t)img * n_features + k] : make_uint2(0xFFFFu, 0u);
+  const uint4 e = (k < n_features) ? kpl[(size_t)img * n_features + k] : make_uint4(0xFFFFu, 0u, 0u, 0u);
   int row_min = 32767, row_max = -1;
   if ((e.x & 0xFFFFu) != 0xFFFFu) {
     const int level = (int)(e.y & 0xFFu);
@@ -183,8 +191,8 @@ __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv,
 #define BRIEF_ROWS (2 * BRIEF_R + 1)
 #define BRIEF_WORDS 11  // (3 + 37 + 3) / 4 rounded up
 
-__global__ __launch_bounds__(256) void k_brief(const LevelDev* __restrict__ lv, const uint8_t* __restrict__ blur, size_t img_pitch,
-                                              const uint2* __restrict__ kpl, int n_features, const int8_t* __restrict__ pattern,
+__global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blur, size_t img_pitch,
+                                              const uint4* __restrict__ kpl, int n_features, const int8_t* __restrict__ pattern,
                                               const double2* __restrict__ sincos, uint8_t* __restrict__ desc) {
 #pragma clang fp contract(off)
   __shared__ uint32_t win_all[4][BRIEF_ROWS * BRIEF_WORDS + 1];  // one window per wave; the waves never synchronise
@@ -193,21 +201,32 @@ __global__ __launch_bounds__(256) void k_brief(const LevelDev* __restrict__ lv, 
   const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int img = blockIdx.y;
   if (k >= n_features) return;
-  const uint2 e = kpl[(size_t)img * n_features + k];
+  // two dependent memory round trips per wave: the list entry, then the whole window + sin/cos + the lane's four template
+  // pairs, all requested before anything is consumed (window indices past the end re-read the last word)
+  const uint4 e = kpl[(size_t)img * n_features + k];
   if ((e.x & 0xFFFFu) == 0xFFFFu) return;  // wave-uniform
-  const LevelDev& L = lv[e.y & 0xFFu];
   const int x = (int)(e.x & 0xFFFFu), y = (int)(e.x >> 16);
-  const uint8_t* W = blur + (size_t)img * img_pitch + L.plane_off;
-  const int stride = L.stride;
+  const uint8_t* W = blur + (size_t)img * img_pitch + e.z;
+  const int stride = (int)e.w;
   const int xa = (x - BRIEF_R) & ~3;
+  constexpr int NW = BRIEF_ROWS * BRIEF_WORDS, NIT = (NW + 63) / 64;
+  uint32_t wv[NIT];
 #pragma unroll
-  for (int it = 0; it < (BRIEF_ROWS * BRIEF_WORDS + 63) / 64; ++it) {
-    const int idx = it * 64 + lane;
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = min(it * 64 + lane, NW - 1);
     const int r = (idx * 5958) >> 16;  // idx / 11 for idx < 448
     const int c = idx - r * BRIEF_WORDS;
-    if (idx < BRIEF_ROWS * BRIEF_WORDS) win[idx] = *(const uint32_t*)(W + (size_t)(y - BRIEF_R + r) * stride + xa + 4 * c);
+    wv[it] = *(const uint32_t*)(W + (size_t)(y - BRIEF_R + r) * stride + xa + 4 * c);
   }
   const double2 scv = sincos[(size_t)img * n_features + k];
+  uint32_t tp[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) tp[g] = *(const uint32_t*)(pattern + (g * 64 + lane) * 4);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = it * 64 + lane;
+    if (idx < NW) win[idx] = wv[it];
+  }
   const double sn = scv.x, cs = scv.y;
   // the LDS accesses of one wave execute in order, so the window written above is visible to every lane of this wave;
   // the fence only pins the compiler
@@ -219,8 +238,8 @@ __global__ __launch_bounds__(256) void k_brief(const LevelDev* __restrict__ lv, 
   unsigned long long bits[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const int8_t* t = pattern + (g * 64 + lane) * 4;
-    const float x1 = (float)t[0], y1 = (float)t[1], x2 = (float)t[2], y2 = (float)t[3];
+    const float x1 = (float)(int8_t)(tp[g] & 255u), y1 = (float)(int8_t)((tp[g] >> 8) & 255u);
+    const float x2 = (float)(int8_t)((tp[g] >> 16) & 255u), y2 = (float)(int8_t)(tp[g] >> 24);
     // float * double -> double, one rounding to float (rotateTemplate, ORBExtractor.cc:537-538)
     const float p1x = (float)((double)x1 * cs - (double)y1 * sn);
     const float p1y = (float)((double)x1 * sn + (double)y1 * cs);
@@ -246,17 +265,17 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
                          int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx, short2* d_env, int n_chunks,
-                         uint2* d_kpl, int rows0, int n_img) {
+                         uint4* d_kpl, int rows0, int n_img) {
   if (n_img <= 0 || n_features <= 0) return;
   UmaxPacked u = 0;
   for (int i = 0; i < 16; ++i) u |= (unsigned long long)(umax[i] & 15) << (4 * i);
   hipLaunchKernelGGL(k_kplist, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, n_levels, d_sel, d_sel_count, n_features,
                      d_kpl, d_n_kp);
-  hipLaunchKernelGGL(k_ic_moments, dim3((n_features + 3) / 4, n_img), dim3(256), 0, s, d_lv, d_pyr, img_pitch, d_kpl, n_features, u,
+  hipLaunchKernelGGL(k_ic_moments, dim3((n_features + 3) / 4, n_img), dim3(256), 0, s, d_pyr, img_pitch, d_kpl, n_features, u,
                      d_moments);
   hipLaunchKernelGGL(k_orient, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, d_kpl, n_features, d_moments, d_sincos,
                      d_kps, d_aux, d_kx, d_env, n_chunks, d_theta, rows0);
-  hipLaunchKernelGGL(k_brief, dim3((n_features + 3) / 4, n_img), dim3(256), 0, s, d_lv, d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos,
+  hipLaunchKernelGGL(k_brief, dim3((n_features + 3) / 4, n_img), dim3(256), 0, s, d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos,
                      d_desc);
 }
 

@@ -120,8 +120,24 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
     const int c = lane & (LW - 1);
     const uint8_t* src = pyr + (size_t)img * img_pitch + L.plane_off + (size_t)cell.y0 * L.stride + (cell.x0 - xa);
     const uint32_t stride = (uint32_t)L.stride;
-    if (c < nwords)
-      for (int r = lane / LW; r < ph; r += RPI) lds_w[r * (PP / 4) + c] = *(const uint32_t*)(src + (r * stride + 4u * (uint32_t)c));
+    // all rows of a lane are requested before the first is parked in LDS (rows clamped, so the loads are unconditional
+    // and no wait lands inside a branch): one memory round trip for the 30-px grid's patches (<= 48 rows)
+    constexpr int BATCH = 12;
+    if (c < nwords) {
+      for (int rb = lane / LW; rb < ph; rb += RPI * BATCH) {
+        uint32_t wv[BATCH];
+#pragma unroll
+        for (int it = 0; it < BATCH; ++it) {
+          const int r = min(rb + RPI * it, ph - 1);
+          wv[it] = *(const uint32_t*)(src + (r * stride + 4u * (uint32_t)c));
+        }
+#pragma unroll
+        for (int it = 0; it < BATCH; ++it) {
+          const int r = rb + RPI * it;
+          if (r < ph) lds_w[r * (PP / 4) + c] = wv[it];
+        }
+      }
+    }
   }
   // ---- zero the V map (with border) ----
   {

@@ -101,7 +101,7 @@ __device__ __forceinline__ void fold_chunk_g(Best2g& b, int d, int idx) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_search_area(const uint2* __restrict__ kpl, const uint8_t* __restrict__ desc, int width,
+__global__ __launch_bounds__(256) void k_search_area(const uint4* __restrict__ kpl, const uint8_t* __restrict__ desc, int width,
                                                      int height, int rows, int cols, const int32_t* __restrict__ cell_off,
                                                      const int32_t* __restrict__ cell_feat, int nq, const float* __restrict__ qxy,
                                                      const float* __restrict__ radius, const int8_t* __restrict__ min_level,
@@ -173,7 +173,7 @@ void launch_grid_build(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t
   hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), lds, s, d_kps, d_n_kp, rows, cols, d_cell_off, d_cell_feat);
 }
 
-void launch_search_area(hipStream_t s, const uint2* d_kpl, const uint8_t* d_desc, int width, int height, int rows, int cols,
+void launch_search_area(hipStream_t s, const uint4* d_kpl, const uint8_t* d_desc, int width, int height, int rows, int cols,
                         const int32_t* d_cell_off, const int32_t* d_cell_feat, int nq, const float* d_qxy, const float* d_radius,
                         const int8_t* d_min_level, const int8_t* d_max_level, const uint8_t* d_q_desc, const uint8_t* d_exclude,
                         int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second, int32_t* d_n_cand) {

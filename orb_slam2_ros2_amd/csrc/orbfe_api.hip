@@ -37,7 +37,7 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
                          int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx, short2* d_env, int n_chunks,
-                         uint2* d_kpl, int rows0, int n_img);
+                         uint4* d_kpl, int rows0, int n_img);
 // k_match.hip
 void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, const uint32_t* d_off,
                              const uint32_t* d_cand, int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second);
@@ -57,7 +57,7 @@ void launch_ba_system(hipStream_t s, int n_poses, int n_points, int n_edges, con
                       double* bl, double* Hpl);
 void launch_grid_build(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, int rows, int cols, int32_t* d_cell_off,
                        int32_t* d_cell_feat);
-void launch_search_area(hipStream_t s, const uint2* d_kpl, const uint8_t* d_desc, int width, int height, int rows, int cols,
+void launch_search_area(hipStream_t s, const uint4* d_kpl, const uint8_t* d_desc, int width, int height, int rows, int cols,
                         const int32_t* d_cell_off, const int32_t* d_cell_feat, int nq, const float* d_qxy, const float* d_radius,
                         const int8_t* d_min_level, const int8_t* d_max_level, const uint8_t* d_q_desc, const uint8_t* d_exclude,
                         int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second, int32_t* d_n_cand);
@@ -117,7 +117,7 @@ struct orbfe_ctx {
   uint8_t* d_desc = nullptr;
   KpAux* d_aux = nullptr;
   double* d_theta = nullptr;
-  uint2* d_kpl = nullptr;        // level-major keypoint list {x | y<<16, level | response<<8}
+  uint4* d_kpl = nullptr;        // level-major keypoint list {x | y<<16, level | response<<8, plane offset, row stride}
   int2* d_moments = nullptr;     // per keypoint (m10, m01)
   double2* d_sincos = nullptr;   // per keypoint (sin, cos) of the orientation
   float* d_kx = nullptr;         // per keypoint x (level-0 coordinates), SoA copy for the stereo candidate scan
