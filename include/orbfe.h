@@ -178,6 +178,25 @@ typedef struct orbfe_ba_system_out {
 orbfe_status orbfe_ba_build_system(orbfe_ctx* ctx, const orbfe_ba_problem* prob, const uint8_t* pose_fixed /*[n_poses], nullable*/,
                                    const orbfe_ba_system_out* out);
 
+/* The g2o part of Optimizer::OptimizeLocalMap (include/ORB_SLAM2/Optimizer.h:69, src/Optimizer.cc:336-391) on the graph the
+ * caller built (:232-330): optimize(iters_first = 5) with the problem's Huber deltas, then every edge with chi2 > 5.991 (mono) /
+ * 7.815 (stereo) or non-positive depth goes to level 1 and ALL robust kernels are dropped (:338-359), optimize(iters_second = 10)
+ * on level 0, final computeError() + the same test on every edge (:364-391).  BlockSolver_6_3 + OptimizationAlgorithmLevenberg
+ * semantics (lambda0 = 1e-5 max diag, gain ratio, <= 10 trials per iteration, points marginalised by Schur complement); the
+ * reduced system is factorised densely, so at most 170 non-fixed keyframes.  stop_flag (nullable) is polled like g2o's
+ * forceStopFlag (Optimizer.cc:230).  The map bookkeeping of :393-441 stays with the caller.                               */
+typedef struct orbfe_ba_optimize_out {
+  double* poses;         /* [n_poses][7]  optimised estimates (fixed poses unchanged)                          */
+  double* points;        /* [n_points][3]                                                                     */
+  uint8_t* level;        /* [n_edges] 1: excluded from the second round (setLevel(1)), nullable                 */
+  double* chi2;          /* [n_edges] chi2 at the final estimates, nullable                                    */
+  uint8_t* bad;          /* [n_edges] final chi2 / depth test failed (the vToProcess candidates), nullable       */
+  int32_t* iterations;   /* [2] Levenberg iterations run by the two optimize() calls, nullable                  */
+} orbfe_ba_optimize_out;
+orbfe_status orbfe_ba_local_optimize(orbfe_ctx* ctx, const orbfe_ba_problem* prob, const uint8_t* pose_fixed /*[n_poses], nullable*/,
+                                     int32_t iters_first, int32_t iters_second, const volatile int32_t* stop_flag,
+                                     const orbfe_ba_optimize_out* out);
+
 /* ---- grid-guided matching against the features of one slot ---------------------------------------------------------
  * Replaces VirtualFrame::initGrid + findFeaturesInArea (src/Frame.cc:53-69, 286-311) + ORBMatcher::getBestMatch
  * (src/ORBMatcher.cc:967-990), the core of the guided searches (ORBMatcher::searchByProjection, src/ORBMatcher.cc:265-347 and

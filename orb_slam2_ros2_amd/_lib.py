@@ -56,6 +56,11 @@ class BaSystemOut(C.Structure):
     _fields_ = [("Hpp", C.c_void_p), ("bp", C.c_void_p), ("Hll", C.c_void_p), ("bl", C.c_void_p), ("Hpl", C.c_void_p)]
 
 
+class BaOptimizeOut(C.Structure):
+    _fields_ = [("poses", C.c_void_p), ("points", C.c_void_p), ("level", C.c_void_p), ("chi2", C.c_void_p), ("bad", C.c_void_p),
+                ("iterations", C.c_void_p)]
+
+
 class BaEdgeOut(C.Structure):
     _fields_ = [("error", C.c_void_p), ("chi2", C.c_void_p), ("rho", C.c_void_p), ("j_point", C.c_void_p),
                 ("j_pose", C.c_void_p), ("depth_positive", C.c_void_p)]
@@ -64,7 +69,7 @@ class BaEdgeOut(C.Structure):
 EXPORTS = [
     "orbfe_abi_version", "orbfe_create", "orbfe_destroy", "orbfe_last_error", "orbfe_get_level_info", "orbfe_get_scale_factors",
     "orbfe_extract", "orbfe_extract_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
-    "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_pose_only_optimize", "orbfe_search_in_area",
+    "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area",
     "orbfe_profile_enable", "orbfe_profile_read", "orbfe_stage_name", "orbfe_debug_candidates",
 ]
 
@@ -108,6 +113,7 @@ def load() -> C.CDLL:
     L.orbfe_match_bruteforce.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]
     L.orbfe_ba_eval_edges.argtypes = [vp, C.POINTER(BaProblem), C.POINTER(BaEdgeOut)]
     L.orbfe_ba_build_system.argtypes = [vp, C.POINTER(BaProblem), vp, C.POINTER(BaSystemOut)]
+    L.orbfe_ba_local_optimize.argtypes = [vp, C.POINTER(BaProblem), vp, i32, i32, vp, C.POINTER(BaOptimizeOut)]
     L.orbfe_pose_only_optimize.argtypes = [vp, i32, vp, vp, vp, vp, vp] + [C.c_double] * 5 + [vp, vp, vp]
     L.orbfe_search_in_area.argtypes = [vp, i32, i32] + [vp] * 10
     L.orbfe_profile_enable.argtypes = [vp, i32]
@@ -316,6 +322,27 @@ class Context:
         o = BaSystemOut(ptr(out["Hpp"]).value, ptr(out["bp"]).value, ptr(out["Hll"]).value, ptr(out["bl"]).value,
                         ptr(out["Hpl"]).value if want_hpl else None)
         self._check(self.lib.orbfe_ba_build_system(self.h, C.byref(prob), ptr(fixed), C.byref(o)))
+        return out
+
+    def ba_local_optimize(self, prob, pose_fixed=None, iters_first=5, iters_second=10):
+        """prob: dict with the orbfe_ba_problem arrays (see ba_synth.make_problem) -> dict(poses, points, level, chi2, bad, iters)"""
+        f64 = lambda a, shape: np.ascontiguousarray(a, np.float64).reshape(shape)
+        poses, points, meas = f64(prob["poses"], (-1, 7)), f64(prob["points"], (-1, 3)), f64(prob["meas"], (-1, 3))
+        info, delta = f64(prob["info"], -1), f64(prob["huber_delta"], -1)
+        ek = np.ascontiguousarray(prob["edge_pose"], np.int32)
+        ep = np.ascontiguousarray(prob["edge_point"], np.int32)
+        st = np.ascontiguousarray(prob["is_stereo"], np.uint8)
+        fixed = None if pose_fixed is None else np.ascontiguousarray(pose_fixed, np.uint8)
+        nk, npt, E = poses.shape[0], points.shape[0], ek.size
+        bp = BaProblem(nk, npt, E, ptr(poses).value, ptr(points).value, ptr(ek).value, ptr(ep).value, ptr(meas).value, ptr(st).value,
+                       ptr(info).value, ptr(delta).value, prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"])
+        out = dict(poses=np.zeros((nk, 7)), points=np.zeros((npt, 3)), level=np.zeros(max(E, 1), np.uint8), chi2=np.zeros(max(E, 1)),
+                   bad=np.zeros(max(E, 1), np.uint8), iters=np.zeros(2, np.int32))
+        o = BaOptimizeOut(ptr(out["poses"]).value, ptr(out["points"]).value, ptr(out["level"]).value, ptr(out["chi2"]).value,
+                          ptr(out["bad"]).value, ptr(out["iters"]).value)
+        self._check(self.lib.orbfe_ba_local_optimize(self.h, C.byref(bp), ptr(fixed), iters_first, iters_second, None, C.byref(o)))
+        for k in ("level", "chi2", "bad"):
+            out[k] = out[k][:E]
         return out
 
     def pose_only_optimize(self, Xw, meas, info, sigma2, pose, fx, fy, cx, cy, bf):

@@ -90,7 +90,7 @@ def make_problem(seed=42, n_kf=60, n_pt=3000, scale_factor=1.2, n_levels=8):
     points_est = points + 0.03 * np.stack([_irwin_hall(seed, 90, pid), _irwin_hall(seed, 110, pid), _irwin_hall(seed, 130, pid)], 1)
     return dict(poses=poses_est, points=points_est, edge_pose=np.asarray(e_pose, np.int32), edge_point=np.asarray(e_pt, np.int32),
                 meas=np.asarray(meas, np.float64), is_stereo=np.asarray(stereo, np.uint8), info=np.asarray(info, np.float64),
-                huber_delta=np.asarray(delta, np.float64), fx=FX, fy=FY, cx=CX, cy=CY, bf=BF)
+                huber_delta=np.asarray(delta, np.float64), fx=FX, fy=FY, cx=CX, cy=CY, bf=BF, poses_true=poses, points_true=points)
 
 
 def make_pose_problem(seed=7, n=1000, scale_factor=1.2, n_levels=8, outlier_every=12):

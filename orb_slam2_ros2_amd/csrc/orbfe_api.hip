@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <limits>
 #include <vector>
 
 #include "orbfe_internal.h"
@@ -45,6 +46,18 @@ void launch_stereo(hipStream_t s, const LevelDev* d_lv, const uint8_t* d_pyr, si
                    const uint8_t* d_desc, const KpAux* d_aux, const float* d_kx, const short2* d_env, int n_chunks,
                    const int32_t* d_n_kp, int n_features, float fx, float bf, int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
                    int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs);
+// k_lba.hip
+void launch_lba_chi2_sum(hipStream_t s, int n_edges, const double* chi2, const double* rho, const uint8_t* level, double* chi2_last,
+                         double* out);
+void launch_lba_maxdiag(hipStream_t s, int n_poses, int n_points, const double* Hpp, const double* Hll, const uint8_t* fixed, double* out);
+void launch_lba_solve(hipStream_t s, int n_poses, int n_points, int n_edges, int nf, const int32_t* free_pose, const int32_t* pose_slot,
+                      const int32_t* pair_off, const int2* pairs, const int32_t* ps_off, const int32_t* ps_edges, const int32_t* pt_off,
+                      const int32_t* pt_edges, const int32_t* edge_pose, const int32_t* edge_point, const uint8_t* fixed, const double* Hpp,
+                      const double* bp, const double* Hll, const double* bl, const double* Hpl, const double* lambda_p, double* Dinv, double* W,
+                      double* S, double* rhs, double* x, int* ok, double* poses, double* points, double* dxp, double* dxl, double* scale_out);
+void launch_lba_classify(hipStream_t s, int n_edges, const double* chi2_last, const uint8_t* depth_pos, const uint8_t* is_stereo,
+                         uint8_t* level, double* info_eff, double* delta_eff);
+void launch_lba_final(hipStream_t s, int n_edges, const double* chi2, const uint8_t* depth_pos, const uint8_t* is_stereo, uint8_t* bad);
 // k_ba.hip
 void launch_ba_edges(hipStream_t s, int n_edges, const double* d_poses, const double* d_points, const int32_t* d_edge_pose,
                      const int32_t* d_edge_point, const double* d_meas, const uint8_t* d_is_stereo, const double* d_info,
@@ -1041,6 +1054,232 @@ orbfe_status orbfe_ba_build_system(orbfe_ctx* c, const orbfe_ba_problem* p, cons
   if (o->Hpl) HIP_TRY(c, down(o->Hpl, o_hpl, (size_t)E * 144));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_timers(c);
+  return ORBFE_OK;
+}
+
+// Optimizer::OptimizeLocalMap's two optimize() calls (Optimizer.cc:336-362) with g2o's Levenberg-Marquardt control on the host
+// (a handful of scalars per trial) and every vertex / edge / block operation on the device.
+orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, const uint8_t* pose_fixed, int32_t iters_first,
+                                     int32_t iters_second, const volatile int32_t* stop_flag, const orbfe_ba_optimize_out* o) {
+  if (!c || !p || !o) return fail(c, ORBFE_EBADARG, "ba_local_optimize: NULL argument");
+  const int E = p->n_edges, NK = p->n_poses, NP = p->n_points;
+  if (E < 0 || NK < 0 || NP < 0 || iters_first < 0 || iters_second < 0) return fail(c, ORBFE_EBADARG, "ba_local_optimize: negative size");
+  if (!o->poses || !o->points) return fail(c, ORBFE_EBADARG, "ba_local_optimize: NULL output");
+  if ((NK && !p->poses) || (NP && !p->points) ||
+      (E && (!p->edge_pose || !p->edge_point || !p->meas || !p->is_stereo || !p->info || !p->huber_delta)))
+    return fail(c, ORBFE_EBADARG, "ba_local_optimize: NULL array");
+  for (int e = 0; e < E; ++e)
+    if (p->edge_pose[e] < 0 || p->edge_pose[e] >= NK || p->edge_point[e] < 0 || p->edge_point[e] >= NP)
+      return fail(c, ORBFE_EBADARG, "ba_local_optimize: edge %d references vertex out of range", e);
+  // free poses, vertex -> edges lists (ascending edge index), pose-pair lists of the Schur complement
+  std::vector<int32_t> slot(std::max(NK, 1), -1), free_pose;
+  for (int k = 0; k < NK; ++k)
+    if (!(pose_fixed && pose_fixed[k])) {
+      slot[k] = (int32_t)free_pose.size();
+      free_pose.push_back(k);
+    }
+  const int nf = (int)free_pose.size();
+  if (6 * nf > 1024) return fail(c, ORBFE_EBADSIZE, "ba_local_optimize: %d free keyframes exceed the 170 the reduced solver takes", nf);
+  std::vector<int32_t> pt_off(NP + 1, 0), ps_off(NK + 1, 0), pt_edges(std::max(E, 1)), ps_edges(std::max(E, 1));
+  for (int e = 0; e < E; ++e) {
+    ++pt_off[p->edge_point[e] + 1];
+    ++ps_off[p->edge_pose[e] + 1];
+  }
+  for (int i = 0; i < NP; ++i) pt_off[i + 1] += pt_off[i];
+  for (int i = 0; i < NK; ++i) ps_off[i + 1] += ps_off[i];
+  {
+    std::vector<int32_t> pc(pt_off.begin(), pt_off.end() - 1), kc(ps_off.begin(), ps_off.end() - 1);
+    for (int e = 0; e < E; ++e) {
+      pt_edges[pc[p->edge_point[e]]++] = e;
+      ps_edges[kc[p->edge_pose[e]]++] = e;
+    }
+  }
+  std::vector<int32_t> pair_off((size_t)nf * nf + 1, 0);
+  std::vector<int2> pairs;
+  {
+    for (int pt = 0; pt < NP; ++pt)
+      for (int a = pt_off[pt]; a < pt_off[pt + 1]; ++a) {
+        const int i = slot[p->edge_pose[pt_edges[a]]];
+        if (i < 0) continue;
+        for (int b2 = pt_off[pt]; b2 < pt_off[pt + 1]; ++b2) {
+          const int j = slot[p->edge_pose[pt_edges[b2]]];
+          if (j >= 0) ++pair_off[(size_t)i * nf + j + 1];
+        }
+      }
+    for (size_t q = 0; q < (size_t)nf * nf; ++q) pair_off[q + 1] += pair_off[q];
+    pairs.resize(std::max<size_t>(pair_off.back(), 1));
+    std::vector<int32_t> cur(pair_off.begin(), pair_off.end() - 1);
+    for (int pt = 0; pt < NP; ++pt)
+      for (int a = pt_off[pt]; a < pt_off[pt + 1]; ++a) {
+        const int e1 = pt_edges[a], i = slot[p->edge_pose[e1]];
+        if (i < 0) continue;
+        for (int b2 = pt_off[pt]; b2 < pt_off[pt + 1]; ++b2) {
+          const int e2 = pt_edges[b2], j = slot[p->edge_pose[e2]];
+          if (j >= 0) pairs[cur[(size_t)i * nf + j]++] = make_int2(e1, e2);
+        }
+      }
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o2 = off;
+    off += align_up(std::max<size_t>(bytes, 8), 256);
+    return o2;
+  };
+  const size_t n = (size_t)6 * nf;
+  const size_t o_pose = take((size_t)NK * 56), o_pt = take((size_t)NP * 24), o_pose_bk = take((size_t)NK * 56), o_pt_bk = take((size_t)NP * 24),
+               o_ep = take((size_t)E * 4), o_et = take((size_t)E * 4), o_meas = take((size_t)E * 24), o_st = take((size_t)E),
+               o_info = take((size_t)E * 8), o_info_eff = take((size_t)E * 8), o_delta = take((size_t)E * 8), o_fix = take((size_t)NK),
+               o_pto = take((size_t)(NP + 1) * 4), o_pte = take((size_t)E * 4), o_pso = take((size_t)(NK + 1) * 4), o_pse = take((size_t)E * 4),
+               o_free = take((size_t)nf * 4), o_slot = take((size_t)NK * 4), o_pairoff = take(pair_off.size() * 4),
+               o_pairs = take(pairs.size() * 8), o_hpp = take((size_t)NK * 288), o_bp = take((size_t)NK * 48), o_hll = take((size_t)NP * 72),
+               o_bl = take((size_t)NP * 24), o_hpl = take((size_t)E * 144), o_dinv = take((size_t)NP * 72), o_w = take((size_t)E * 144),
+               o_s = take(n * n * 8), o_rhs = take(n * 8), o_x = take(n * 8), o_dxp = take((size_t)NK * 48), o_dxl = take((size_t)NP * 24),
+               o_err = take((size_t)E * 24), o_chi2 = take((size_t)E * 8), o_rho = take((size_t)E * 16), o_last = take((size_t)E * 8),
+               o_level = take((size_t)E), o_depth = take((size_t)E), o_bad = take((size_t)E), o_sc = take(64);
+  TRY(ensure_tmp(c, off));
+  uint8_t* b = (uint8_t*)c->d_tmp;
+  hipStream_t st = c->stream;
+  auto up = [&](size_t o2, const void* src, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpyAsync(b + o2, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess;
+  };
+  std::vector<uint8_t> fixed_h(std::max(NK, 1), 0);
+  if (pose_fixed) std::memcpy(fixed_h.data(), pose_fixed, NK);
+  HIP_TRY(c, up(o_pose, p->poses, (size_t)NK * 56));
+  HIP_TRY(c, up(o_pt, p->points, (size_t)NP * 24));
+  HIP_TRY(c, up(o_ep, p->edge_pose, (size_t)E * 4));
+  HIP_TRY(c, up(o_et, p->edge_point, (size_t)E * 4));
+  HIP_TRY(c, up(o_meas, p->meas, (size_t)E * 24));
+  HIP_TRY(c, up(o_st, p->is_stereo, (size_t)E));
+  HIP_TRY(c, up(o_info, p->info, (size_t)E * 8));
+  HIP_TRY(c, up(o_info_eff, p->info, (size_t)E * 8));
+  HIP_TRY(c, up(o_delta, p->huber_delta, (size_t)E * 8));
+  HIP_TRY(c, up(o_fix, fixed_h.data(), (size_t)NK));
+  HIP_TRY(c, up(o_pto, pt_off.data(), (size_t)(NP + 1) * 4));
+  HIP_TRY(c, up(o_pte, pt_edges.data(), (size_t)E * 4));
+  HIP_TRY(c, up(o_pso, ps_off.data(), (size_t)(NK + 1) * 4));
+  HIP_TRY(c, up(o_pse, ps_edges.data(), (size_t)E * 4));
+  HIP_TRY(c, up(o_free, free_pose.data(), (size_t)nf * 4));
+  HIP_TRY(c, up(o_slot, slot.data(), (size_t)NK * 4));
+  HIP_TRY(c, up(o_pairoff, pair_off.data(), pair_off.size() * 4));
+  HIP_TRY(c, up(o_pairs, pairs.data(), pairs.size() * 8));
+  HIP_TRY(c, hipMemsetAsync(b + o_level, 0, std::max(E, 1), st));
+  HIP_TRY(c, hipMemsetAsync(b + o_last, 0, (size_t)std::max(E, 1) * 8, st));
+  HIP_TRY(c, hipStreamSynchronize(st));  // the host vectors above go out of use only now
+
+  const BaParamsDev prm = {p->fx, p->fy, p->cx, p->cy, p->bf};
+  double* d_poses = (double*)(b + o_pose);
+  double* d_points = (double*)(b + o_pt);
+  const int32_t* d_ek = (const int32_t*)(b + o_ep);
+  const int32_t* d_ep = (const int32_t*)(b + o_et);
+  double* d_sc = (double*)(b + o_sc);  // [0] robust chi2, [1] max diagonal, [2] lambda, [3] ok (int), [4] scale
+  struct HostScalars {
+    double chi, maxdiag, lambda;
+    int32_t ok, pad;
+    double scale;
+  };
+  auto evaluate = [&](const double* d_info) {  // computeActiveErrors + activeRobustChi2
+    launch_ba_edges(st, E, d_poses, d_points, d_ek, d_ep, (const double*)(b + o_meas), b + o_st, d_info, (const double*)(b + o_delta), prm,
+                    (double*)(b + o_err), (double*)(b + o_chi2), (double*)(b + o_rho), nullptr, nullptr, b + o_depth);
+    launch_lba_chi2_sum(st, E, (const double*)(b + o_chi2), (const double*)(b + o_rho), b + o_level, (double*)(b + o_last), d_sc);
+  };
+  auto read_scalars = [&](HostScalars& h) -> hipError_t {
+    hipError_t e = hipMemcpyAsync(&h, d_sc, sizeof h, hipMemcpyDeviceToHost, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+  };
+  auto stopped = [&]() { return stop_flag && *stop_flag; };
+  StageTimer tm(c, ORBFE_STAGE_BA, st);
+  auto optimize = [&](int iterations, int32_t& done) -> orbfe_status {  // SparseOptimizer::optimize + OptimizationAlgorithmLevenberg::solve
+    done = 0;
+    if (E == 0) return ORBFE_OK;
+    double lambda = 0, ni = 2;
+    for (int it = 0; it < iterations; ++it) {
+      if (stopped()) break;
+      ++done;
+      evaluate((const double*)(b + o_info_eff));
+      launch_ba_system(st, NK, NP, E, d_poses, d_points, d_ek, d_ep, (const double*)(b + o_meas), b + o_st, (const double*)(b + o_info_eff),
+                       (const double*)(b + o_delta), prm, b + o_fix, (const int32_t*)(b + o_pto), (const int32_t*)(b + o_pte),
+                       (const int32_t*)(b + o_pso), (const int32_t*)(b + o_pse), (double*)(b + o_hpp), (double*)(b + o_bp),
+                       (double*)(b + o_hll), (double*)(b + o_bl), (double*)(b + o_hpl));
+      if (it == 0) launch_lba_maxdiag(st, NK, NP, (const double*)(b + o_hpp), (const double*)(b + o_hll), b + o_fix, d_sc + 1);
+      HostScalars h;
+      HIP_TRY(c, read_scalars(h));
+      double current_chi = h.chi;
+      if (it == 0) {
+        lambda = 1e-5 * h.maxdiag;  // computeLambdaInit, tau = 1e-5
+        ni = 2;
+      }
+      double rho = 0;
+      int qmax = 0;
+      do {
+        HIP_TRY(c, hipMemcpyAsync(b + o_pose_bk, d_poses, (size_t)NK * 56, hipMemcpyDeviceToDevice, st));  // push()
+        HIP_TRY(c, hipMemcpyAsync(b + o_pt_bk, d_points, (size_t)NP * 24, hipMemcpyDeviceToDevice, st));
+        struct {
+          double lambda;
+          int32_t ok, pad;
+        } upv = {lambda, 1, 0};
+        HIP_TRY(c, hipMemcpyAsync(d_sc + 2, &upv, sizeof upv, hipMemcpyHostToDevice, st));
+        launch_lba_solve(st, NK, NP, E, nf, (const int32_t*)(b + o_free), (const int32_t*)(b + o_slot), (const int32_t*)(b + o_pairoff),
+                         (const int2*)(b + o_pairs), (const int32_t*)(b + o_pso), (const int32_t*)(b + o_pse), (const int32_t*)(b + o_pto),
+                         (const int32_t*)(b + o_pte), d_ek, d_ep, b + o_fix, (const double*)(b + o_hpp), (const double*)(b + o_bp),
+                         (const double*)(b + o_hll), (const double*)(b + o_bl), (const double*)(b + o_hpl), d_sc + 2, (double*)(b + o_dinv),
+                         (double*)(b + o_w), (double*)(b + o_s), (double*)(b + o_rhs), (double*)(b + o_x), (int*)(d_sc + 3), d_poses, d_points,
+                         (double*)(b + o_dxp), (double*)(b + o_dxl), d_sc + 4);
+        evaluate((const double*)(b + o_info_eff));
+        HIP_TRY(c, read_scalars(h));
+        const bool ok2 = h.ok != 0;
+        const double temp_chi = ok2 ? h.chi : std::numeric_limits<double>::max();
+        rho = (current_chi - temp_chi) / (h.scale + 1e-3);
+        if (!ok2) rho = -1.0;  // the linear solver failed: the trial is rejected whatever its step looked like
+        if (rho > 0 && std::isfinite(temp_chi)) {
+          double alpha = 1. - std::pow((2 * rho - 1), 3);
+          alpha = std::min(alpha, 2. / 3.);
+          lambda *= std::max(1. / 3., alpha);
+          ni = 2;
+          current_chi = temp_chi;
+        } else {
+          lambda *= ni;
+          ni *= 2;
+          HIP_TRY(c, hipMemcpyAsync(d_poses, b + o_pose_bk, (size_t)NK * 56, hipMemcpyDeviceToDevice, st));  // pop()
+          HIP_TRY(c, hipMemcpyAsync(d_points, b + o_pt_bk, (size_t)NP * 24, hipMemcpyDeviceToDevice, st));
+          if (!std::isfinite(lambda)) break;
+        }
+        ++qmax;
+      } while (rho < 0 && qmax < 10 && !stopped());
+      if (qmax == 10 || rho == 0 || !std::isfinite(lambda)) break;  // OptimizationAlgorithm::Terminate
+    }
+    return ORBFE_OK;
+  };
+  int32_t it1 = 0, it2 = 0;
+  TRY(optimize(iters_first, it1));
+  if (!stopped()) {
+    // edge->chi2() is the chi2 of the last evaluated trial; isDepthPositive() reads the current estimates (Optimizer.cc:338-359)
+    launch_ba_edges(st, E, d_poses, d_points, d_ek, d_ep, (const double*)(b + o_meas), b + o_st, (const double*)(b + o_info),
+                    (const double*)(b + o_delta), prm, (double*)(b + o_err), (double*)(b + o_chi2), (double*)(b + o_rho), nullptr, nullptr,
+                    b + o_depth);
+    launch_lba_classify(st, E, (const double*)(b + o_last), b + o_depth, b + o_st, b + o_level, (double*)(b + o_info_eff),
+                        (double*)(b + o_delta));
+    TRY(optimize(iters_second, it2));
+  }
+  // final computeError() on every edge with the final estimates (Optimizer.cc:364-391)
+  launch_ba_edges(st, E, d_poses, d_points, d_ek, d_ep, (const double*)(b + o_meas), b + o_st, (const double*)(b + o_info),
+                  (const double*)(b + o_delta), prm, (double*)(b + o_err), (double*)(b + o_chi2), (double*)(b + o_rho), nullptr, nullptr,
+                  b + o_depth);
+  launch_lba_final(st, E, (const double*)(b + o_chi2), b + o_depth, b + o_st, b + o_bad);
+  HIP_TRY(c, hipGetLastError());
+  auto down = [&](void* dst, size_t o2, size_t bytes) -> hipError_t {
+    return (bytes && dst) ? hipMemcpyAsync(dst, b + o2, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
+  };
+  HIP_TRY(c, down(o->poses, o_pose, (size_t)NK * 56));
+  HIP_TRY(c, down(o->points, o_pt, (size_t)NP * 24));
+  HIP_TRY(c, down(o->level, o_level, (size_t)E));
+  HIP_TRY(c, down(o->chi2, o_chi2, (size_t)E * 8));
+  HIP_TRY(c, down(o->bad, o_bad, (size_t)E));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  if (o->iterations) {
+    o->iterations[0] = it1;
+    o->iterations[1] = it2;
+  }
   return ORBFE_OK;
 }
 

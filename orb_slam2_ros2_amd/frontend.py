@@ -161,6 +161,13 @@ class Optimizer:
         return ctx.pose_only_optimize(Xw, meas, info, sigma2, pose, fx, fy, cx, cy, bf)
 
     @staticmethod
+    def OptimizeLocalMap(ctx: Context, problem, pose_fixed=None, iters_first=5, iters_second=10):
+        """The g2o part of Optimizer::OptimizeLocalMap (Optimizer.cc:336-391) on the graph `problem` describes (the arrays of
+        orbfe_ba_problem): optimize(5) with Huber, level-1 / kernel-off re-classification, optimize(10), final chi2 test.
+        Returns dict(poses, points, level, chi2, bad, iters); the map bookkeeping of :393-441 stays with the caller."""
+        return ctx.ba_local_optimize(problem, pose_fixed, iters_first, iters_second)
+
+    @staticmethod
     def evalEdges(ctx: Context, poses, points, edge_pose, edge_point, meas, is_stereo, info, huber_delta, fx, fy, cx, cy, bf,
                   jacobians=True):
         return ctx.ba_eval_edges(poses, points, edge_pose, edge_point, meas, is_stereo, info, huber_delta, fx, fy, cx, cy, bf,

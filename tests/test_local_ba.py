@@ -1,0 +1,94 @@
+"""The g2o part of Optimizer::OptimizeLocalMap (Optimizer.cc:336-391): oracle known answers (CPU) and the device solver against the
+oracle (GPU).  north_star asks for 1e-4 on BA pose residuals; device and oracle run the same Levenberg-Marquardt trajectory and
+differ by summation order only, so 1e-7 is asserted on poses and points."""
+import numpy as np
+import pytest
+
+from orb_slam2_ros2_amd import ba_synth
+
+
+def _problem(seed, n_kf, n_pt, n_fixed=2):
+    pr = ba_synth.make_problem(seed=seed, n_kf=n_kf, n_pt=n_pt)
+    fixed = np.zeros(n_kf, np.uint8)
+    fixed[:n_fixed] = 1
+    pr["poses"][:n_fixed] = pr["poses_true"][:n_fixed]      # the gauge: fixed keyframes sit at their true poses
+    return pr, fixed
+
+
+def _pose_dist(a, b):
+    """max abs difference of (q, t) with the quaternion sign fixed"""
+    s = np.sign((a[:, :4] * b[:, :4]).sum(1, keepdims=True))
+    return max(np.abs(a[:, :4] - s * b[:, :4]).max(), np.abs(a[:, 4:] - b[:, 4:]).max())
+
+
+def test_oracle_local_ba_converges_and_excludes_the_planted_outliers(orc):
+    pr, fixed = _problem(3, 12, 400)
+    r = orc.ba_local_optimize(pr, fixed)
+    assert tuple(r["iters"]) == (5, 10)
+    assert _pose_dist(r["poses"], pr["poses_true"]) < 0.75 * _pose_dist(pr["poses"], pr["poses_true"])
+    assert np.median(np.abs(r["points"] - pr["points_true"])) < 0.75 * np.median(np.abs(pr["points"] - pr["points_true"]))
+    assert np.array_equal(r["poses"][:2], pr["poses"][:2])                    # setFixed(true)
+    e0 = orc.ba_eval_edges(pr["poses"], pr["points"], pr["edge_pose"], pr["edge_point"], pr["meas"], pr["is_stereo"], pr["info"],
+                           pr["huber_delta"], pr["fx"], pr["fy"], pr["cx"], pr["cy"], pr["bf"])
+    assert np.median(r["chi2"]) < 0.2 * np.median(e0["chi2"])
+    # level 1 = the edges the first round could not explain; every surviving gross outlier (35 px) is among them
+    th = np.where(pr["is_stereo"] != 0, 7.815, 5.991)
+    assert r["level"].sum() > 0 and (r["chi2"][r["level"] == 0] > 50 * th[r["level"] == 0]).sum() == 0
+    assert np.array_equal(r["bad"].astype(bool), (r["chi2"] > th) | (r["bad"].astype(bool) & (r["chi2"] <= th)))
+    assert np.allclose(np.linalg.norm(r["poses"][:, :4], axis=1), 1, atol=1e-12) and (r["poses"][:, 3] >= 0).all()
+
+
+def test_oracle_local_ba_degenerate_inputs(orc):
+    pr, fixed = _problem(4, 6, 60)
+    # zero iterations: nothing moves, but the classification and the final test still run
+    r = orc.ba_local_optimize(pr, fixed, iters1=0, iters2=0)
+    assert np.array_equal(r["poses"], pr["poses"]) and np.array_equal(r["points"], pr["points"]) and tuple(r["iters"]) == (0, 0)
+    # every keyframe fixed: only the points move (structure-only BA)
+    allf = np.ones(6, np.uint8)
+    r = orc.ba_local_optimize(pr, allf)
+    assert np.array_equal(r["poses"], pr["poses"]) and not np.array_equal(r["points"], pr["points"])
+    # no edges at all
+    e = dict(pr)
+    for k in ("edge_pose", "edge_point", "is_stereo", "info", "huber_delta"):
+        e[k] = pr[k][:0]
+    e["meas"] = pr["meas"][:0]
+    r = orc.ba_local_optimize(e, fixed)
+    assert np.array_equal(r["poses"], pr["poses"]) and np.array_equal(r["points"], pr["points"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_kf,n_pt,n_fixed", [(3, 12, 400, 2), (5, 30, 1500, 5), (6, 60, 3000, 20), (7, 8, 100, 8)])
+def test_device_local_ba_matches_oracle(orc, seed, n_kf, n_pt, n_fixed):
+    from orb_slam2_ros2_amd._lib import Context
+    from orb_slam2_ros2_amd import Optimizer
+    pr, fixed = _problem(seed, n_kf, n_pt, n_fixed)
+    ctx = Context(640, 480, n_features=500, max_images=1)
+    g = Optimizer.OptimizeLocalMap(ctx, pr, fixed)
+    o = orc.ba_local_optimize(pr, fixed)
+    assert tuple(g["iters"]) == tuple(o["iters"])
+    assert _pose_dist(g["poses"], o["poses"]) < 1e-7 and np.abs(g["points"] - o["points"]).max() < 1e-7
+    assert np.array_equal(g["poses"][:n_fixed], pr["poses"][:n_fixed])
+    assert (g["level"] != o["level"]).sum() <= 1 and (g["bad"] != o["bad"]).sum() <= 1   # an edge exactly on a threshold may flip
+    assert np.allclose(g["chi2"], o["chi2"], rtol=1e-6, atol=1e-9)
+    again = ctx.ba_local_optimize(pr, fixed)
+    assert all(np.array_equal(again[k], g[k]) for k in ("poses", "points", "level", "chi2", "bad"))   # fixed summation orders
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_device_local_ba_edge_cases(orc):
+    from orb_slam2_ros2_amd._lib import Context, OrbfeError
+    pr, fixed = _problem(4, 6, 60)
+    ctx = Context(640, 480, n_features=500, max_images=1)
+    g = ctx.ba_local_optimize(pr, fixed, 0, 0)
+    o = orc.ba_local_optimize(pr, fixed, iters1=0, iters2=0)
+    assert np.array_equal(g["poses"], pr["poses"]) and np.array_equal(g["level"], o["level"]) and np.array_equal(g["bad"], o["bad"])
+    allf = np.ones(6, np.uint8)
+    g, o = ctx.ba_local_optimize(pr, allf), orc.ba_local_optimize(pr, allf)
+    assert np.array_equal(g["poses"], pr["poses"]) and np.abs(g["points"] - o["points"]).max() < 1e-7
+    bad = dict(pr)
+    bad["edge_pose"] = pr["edge_pose"].copy()
+    bad["edge_pose"][3] = 99
+    with pytest.raises(OrbfeError):
+        ctx.ba_local_optimize(bad, fixed)
+    ctx.close()
