@@ -183,7 +183,7 @@ orbfe_status orbfe_ba_build_system(orbfe_ctx* ctx, const orbfe_ba_problem* prob,
  * 7.815 (stereo) or non-positive depth goes to level 1 and ALL robust kernels are dropped (:338-359), optimize(iters_second = 10)
  * on level 0, final computeError() + the same test on every edge (:364-391).  BlockSolver_6_3 + OptimizationAlgorithmLevenberg
  * semantics (lambda0 = 1e-5 max diag, gain ratio, <= 10 trials per iteration, points marginalised by Schur complement); the
- * reduced system is factorised densely, so at most 170 non-fixed keyframes.  stop_flag (nullable) is polled like g2o's
+ * reduced system is factorised densely by one workgroup: at most 100 non-fixed keyframes (ORBFE_EBADSIZE beyond).  stop_flag (nullable) is polled like g2o's
  * forceStopFlag (Optimizer.cc:230).  The map bookkeeping of :393-441 stays with the caller.                               */
 typedef struct orbfe_ba_optimize_out {
   double* poses;         /* [n_poses][7]  optimised estimates (fixed poses unchanged)                          */

@@ -1079,7 +1079,8 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
       free_pose.push_back(k);
     }
   const int nf = (int)free_pose.size();
-  if (6 * nf > 1024) return fail(c, ORBFE_EBADSIZE, "ba_local_optimize: %d free keyframes exceed the 170 the reduced solver takes", nf);
+  if (nf > LBA_MAX_FREE)
+    return fail(c, ORBFE_EBADSIZE, "ba_local_optimize: %d non-fixed keyframes exceed the %d the reduced solver takes", nf, LBA_MAX_FREE);
   std::vector<int32_t> pt_off(NP + 1, 0), ps_off(NK + 1, 0), pt_edges(std::max(E, 1)), ps_edges(std::max(E, 1));
   for (int e = 0; e < E; ++e) {
     ++pt_off[p->edge_point[e] + 1];

@@ -73,6 +73,9 @@ struct KpAux {
   int16_t row_min, row_max;  // [row_min, row_max)
 };
 
+// local BA: non-fixed keyframes the dense reduced solver takes (its panel, right-hand side and diagonal blocks live in 64 KB of LDS)
+#define LBA_MAX_FREE 100
+
 struct BaParamsDev {
   double fx, fy, cx, cy, bf;
 };
