@@ -30,7 +30,7 @@ def _quat_from_yaw(yaw):
     return np.stack([np.zeros_like(yaw), np.sin(yaw / 2), np.zeros_like(yaw), np.cos(yaw / 2)], 1)  # rotation about y
 
 
-def make_problem(seed=42, n_kf=60, n_pt=3000, scale_factor=1.2, n_levels=8):
+def make_problem(seed=42, n_kf=60, n_pt=3000, scale_factor=1.2, n_levels=8, with_truth=False):
     # camera centres on an arc of radius 3 m looking roughly along +z
     ang = np.linspace(-0.5, 0.5, n_kf)
     centres = np.stack([3.0 * np.sin(ang), 0.05 * np.cos(7 * ang), 3.0 * (1 - np.cos(ang))], 1)
@@ -88,9 +88,12 @@ def make_problem(seed=42, n_kf=60, n_pt=3000, scale_factor=1.2, n_levels=8):
     poses_est = poses.copy()
     poses_est[:, 4:] += 0.02 * np.stack([_irwin_hall(seed, 30, kid), _irwin_hall(seed, 50, kid), _irwin_hall(seed, 70, kid)], 1)
     points_est = points + 0.03 * np.stack([_irwin_hall(seed, 90, pid), _irwin_hall(seed, 110, pid), _irwin_hall(seed, 130, pid)], 1)
-    return dict(poses=poses_est, points=points_est, edge_pose=np.asarray(e_pose, np.int32), edge_point=np.asarray(e_pt, np.int32),
-                meas=np.asarray(meas, np.float64), is_stereo=np.asarray(stereo, np.uint8), info=np.asarray(info, np.float64),
-                huber_delta=np.asarray(delta, np.float64), fx=FX, fy=FY, cx=CX, cy=CY, bf=BF, poses_true=poses, points_true=points)
+    out = dict(poses=poses_est, points=points_est, edge_pose=np.asarray(e_pose, np.int32), edge_point=np.asarray(e_pt, np.int32),
+               meas=np.asarray(meas, np.float64), is_stereo=np.asarray(stereo, np.uint8), info=np.asarray(info, np.float64),
+               huber_delta=np.asarray(delta, np.float64), fx=FX, fy=FY, cx=CX, cy=CY, bf=BF)
+    if with_truth:  # the noise-free vertices the measurements were generated from
+        out.update(poses_true=poses, points_true=points)
+    return out
 
 
 def make_pose_problem(seed=7, n=1000, scale_factor=1.2, n_levels=8, outlier_every=12):

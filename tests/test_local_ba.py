@@ -8,7 +8,7 @@ from orb_slam2_ros2_amd import ba_synth
 
 
 def _problem(seed, n_kf, n_pt, n_fixed=2):
-    pr = ba_synth.make_problem(seed=seed, n_kf=n_kf, n_pt=n_pt)
+    pr = ba_synth.make_problem(seed=seed, n_kf=n_kf, n_pt=n_pt, with_truth=True)
     fixed = np.zeros(n_kf, np.uint8)
     fixed[:n_fixed] = 1
     pr["poses"][:n_fixed] = pr["poses_true"][:n_fixed]      # the gauge: fixed keyframes sit at their true poses

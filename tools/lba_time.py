@@ -6,7 +6,7 @@ import numpy as np
 from orb_slam2_ros2_amd import ba_synth
 from orb_slam2_ros2_amd._lib import Context
 from oracle import pyoracle
-pr = ba_synth.make_problem(seed=42, n_kf=60, n_pt=3000)
+pr = ba_synth.make_problem(seed=42, n_kf=60, n_pt=3000, with_truth=True)
 fixed = np.zeros(60, np.uint8); fixed[:20] = 1
 pr["poses"][:20] = pr["poses_true"][:20]
 ctx = Context(640, 480, n_features=500, max_images=1)
