@@ -17,6 +17,7 @@
 // FileNotOpenError, everything else -> std::runtime_error with orbfe_last_error().
 #pragma once
 #include <array>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <fstream>
@@ -186,9 +187,65 @@ class ORBMatcher {
     return n;
   }
 
+  // The matching core of ORBMatcher::searchByProjection (src/ORBMatcher.cc:265-347, 561-612): for every projected point
+  // Frame::findFeaturesInArea (src/Frame.cc:286-311) + getBestMatch (:967-990) against the features of `slot`.  The caller
+  // projects, picks radius / octave window and applies mnMinThreshold, the ratio test and verifyAngle as the reference does.
+  struct AreaMatch {
+    std::vector<int32_t> bestIdx, bestDist, secondDist, nCand;
+  };
+  AreaMatch searchInArea(orbfe_ctx* ctx, int slot, const std::vector<float>& uv /*[n][2]*/, const std::vector<float>& radius,
+                         const std::vector<int8_t>& minLevel, const std::vector<int8_t>& maxLevel,
+                         const std::vector<Descriptor>& desc, const std::vector<uint8_t>* exclude = nullptr) const {
+    const int32_t n = (int32_t)radius.size();
+    AreaMatch m;
+    m.bestIdx.resize(n), m.bestDist.resize(n), m.secondDist.resize(n), m.nCand.resize(n);
+    check(ctx, orbfe_search_in_area(ctx, slot, n, uv.data(), radius.data(), minLevel.data(), maxLevel.data(),
+                                    n ? desc[0].data() : nullptr, exclude ? exclude->data() : nullptr, m.bestIdx.data(),
+                                    m.bestDist.data(), m.secondDist.data(), m.nCand.data()));
+    return m;
+  }
+
  private:
   float mfRatio;
   bool mbCheckOri;
+};
+
+// Mirror of the reference's Optimizer (include/ORB_SLAM2/Optimizer.h:69-72): the g2o parts run on the device, graph
+// construction and map bookkeeping stay in the caller.
+class Optimizer {
+ public:
+  static inline const float deltaMono = std::sqrt(5.991f), deltaStereo = std::sqrt(7.815f);  // src/Optimizer.cc:1084-1085
+
+  struct LocalMapResult {
+    std::vector<double> poses, points, chi2;  // [nPoses][7] qx qy qz qw tx ty tz, [nPoints][3], [nEdges]
+    std::vector<uint8_t> level, bad;           // setLevel(1) after the first round; final chi2 / depth test
+    int32_t iterations[2] = {0, 0};
+  };
+  // Optimizer::OptimizeLocalMap (src/Optimizer.cc:336-391) on the graph `prob` describes
+  static LocalMapResult OptimizeLocalMap(orbfe_ctx* ctx, const orbfe_ba_problem& prob, const std::vector<uint8_t>& poseFixed,
+                                         const volatile int32_t* isStop = nullptr) {
+    LocalMapResult r;
+    r.poses.resize((size_t)prob.n_poses * 7), r.points.resize((size_t)prob.n_points * 3);
+    r.chi2.resize((size_t)std::max(prob.n_edges, 1)), r.level.resize(r.chi2.size()), r.bad.resize(r.chi2.size());
+    orbfe_ba_optimize_out o = {r.poses.data(), r.points.data(), r.level.data(), r.chi2.data(), r.bad.data(), r.iterations};
+    check(ctx, orbfe_ba_local_optimize(ctx, &prob, poseFixed.empty() ? nullptr : poseFixed.data(), 5, 10, isStop, &o));
+    r.chi2.resize(prob.n_edges), r.level.resize(prob.n_edges), r.bad.resize(prob.n_edges);
+    return r;
+  }
+  // the g2o part of Optimizer::OptimizePoseOnly (src/Optimizer.cc:33-178); returns edges - nBad, pose and inlier flags in place
+  static int OptimizePoseOnly(orbfe_ctx* ctx, const std::vector<double>& pointsWorld, const std::vector<double>& meas /*u v uR*/,
+                              const std::vector<double>& invSigma2, const std::vector<float>& sigma2, double fx, double fy, double cx,
+                              double cy, double bf, double pose[7], std::vector<uint8_t>& inlier) {
+    const int32_t n = (int32_t)invSigma2.size();
+    inlier.assign((size_t)std::max(n, 1), 0);
+    int32_t good = 0;
+    double out[7];
+    check(ctx, orbfe_pose_only_optimize(ctx, n, pointsWorld.data(), meas.data(), invSigma2.data(), sigma2.data(), pose, fx, fy, cx, cy, bf,
+                                        out, inlier.data(), &good));
+    for (int i = 0; i < 7; ++i) pose[i] = out[i];
+    inlier.resize(n);
+    return good;
+  }
 };
 
 }  // namespace orbfe

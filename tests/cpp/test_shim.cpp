@@ -1,6 +1,8 @@
 // Compile-and-run check of the C++ host mirror (orb_slam2_ros2_amd/host/orbfe_shim.hpp).
 // Usage: test_shim <image.raw> <w> <h>   prints "n_left n_right n_matches fnv1a(keypoints) fnv1a(descriptors)" or
 //        "NO_DEVICE" (exit 3) when no HIP device is usable -- there is no CPU fallback to run instead.
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -43,8 +45,57 @@ int main(int argc, char** argv) {
     orbfe::check(el.context(), orbfe_extract_batch(el.context(), 2, imgs, w, kk.data(), dd.data(), cnt));
     std::vector<double> ru, dp;
     const int nm = orbfe::ORBMatcher().searchByStereo(el.context(), 2000, (int)kl.size(), 718.856f, 718.856f * 0.537166f, ru, dp);
-    printf("%zu %zu %d %016llx %016llx %d\n", kl.size(), kr.size(), nm, (unsigned long long)fnv1a(kl.data(), kl.size() * sizeof(orbfe_keypoint)),
+    printf("%zu %zu %d %016llx %016llx %d", kl.size(), kr.size(), nm, (unsigned long long)fnv1a(kl.data(), kl.size() * sizeof(orbfe_keypoint)),
            (unsigned long long)fnv1a(dl.data(), dl.size() * 32), orbfe::ORBMatcher::descDistance(dl[0], dl[1]));
+    // guided search: every left keypoint looks for itself in slot 0 (radius 3 px, its own octave): best = itself at distance 0
+    {
+      const size_t n = std::min<size_t>(kl.size(), 200);
+      std::vector<float> uv(2 * n), rad(n, 3.0f);
+      std::vector<int8_t> lo(n), hi(n);
+      std::vector<orbfe::Descriptor> qd(dl.begin(), dl.begin() + n);
+      for (size_t i = 0; i < n; ++i) {
+        uv[2 * i] = kl[i].x, uv[2 * i + 1] = kl[i].y;
+        lo[i] = hi[i] = (int8_t)kl[i].octave;
+      }
+      const auto m = orbfe::ORBMatcher().searchInArea(el.context(), 0, uv, rad, lo, hi, qd);
+      int self = 0;
+      for (size_t i = 0; i < n; ++i) self += (m.bestDist[i] == 0 && m.nCand[i] >= 1);
+      printf(" %d/%zu", self, n);
+    }
+    // local BA through the Optimizer mirror: 4 keyframes (2 fixed) looking at a 5x4x2 grid of points, exact stereo
+    // measurements, perturbed free poses and points -> the optimum is the truth
+    {
+      const int NK = 4, NP = 40;
+      std::vector<double> poses(NK * 7, 0.0), truth, points(NP * 3), pts_true, meas;
+      std::vector<int32_t> ek, ep;
+      for (int k = 0; k < NK; ++k) poses[7 * k + 3] = 1.0, poses[7 * k + 4] = -0.3 * k;  // identity rotation, camera at x = 0.3 k
+      for (int p = 0; p < NP; ++p) {
+        points[3 * p] = -1.0 + 0.5 * (p % 5), points[3 * p + 1] = -0.6 + 0.4 * ((p / 5) % 4), points[3 * p + 2] = 4.0 + 1.5 * (p / 20);
+      }
+      truth = poses, pts_true = points;
+      const double fx = 520.9, fy = 521.0, cx = 325.1, cy = 249.7, bf = 40.0;
+      for (int p = 0; p < NP; ++p)
+        for (int k = 0; k < NK; ++k) {
+          const double x = points[3 * p] + poses[7 * k + 4], y = points[3 * p + 1], z = points[3 * p + 2];
+          const double u = fx * x / z + cx;
+          meas.insert(meas.end(), {u, fy * y / z + cy, u - bf / z});
+          ek.push_back(k), ep.push_back(p);
+        }
+      const int E = (int)ek.size();
+      std::vector<uint8_t> st(E, 1), fixed = {1, 1, 0, 0};
+      std::vector<double> info(E, 1.0), delta(E, (double)orbfe::Optimizer::deltaStereo);
+      poses[7 * 2 + 4] += 0.03, poses[7 * 3 + 5] -= 0.02, poses[7 * 3 + 6] += 0.025;
+      for (int p = 0; p < NP; ++p) points[3 * p + (p % 3)] += 0.04 * ((p % 2) ? 1 : -1);
+      orbfe_ba_problem prob = {NK, NP, E, poses.data(), points.data(), ek.data(), ep.data(), meas.data(), st.data(), info.data(),
+                               delta.data(), fx, fy, cx, cy, bf};
+      const auto r = orbfe::Optimizer::OptimizeLocalMap(el.context(), prob, fixed);
+      double err = 0;
+      for (size_t i = 0; i < truth.size(); ++i) err = std::max(err, std::fabs(r.poses[i] - truth[i]));
+      for (size_t i = 0; i < pts_true.size(); ++i) err = std::max(err, std::fabs(r.points[i] - pts_true[i]));
+      int nbad = 0;
+      for (uint8_t b : r.bad) nbad += b;
+      printf(" %.3e %d %d\n", err, nbad, r.iterations[0] + r.iterations[1]);
+    }
   } catch (const std::exception& e) {
     if (std::string(e.what()).find("no HIP device") != std::string::npos) {
       printf("NO_DEVICE\n");

@@ -343,7 +343,10 @@ def test_cpp_host_mirror_matches_oracle(orc, tmp_path):
     L.tofile(tmp_path / "L.raw")
     R.tofile(tmp_path / "R.raw")
     out = subprocess.run([exe, str(tmp_path / "L.raw"), str(tmp_path / "R.raw"), "1241", "376"], capture_output=True, text=True, check=True)
-    nl, nr, nm, hk, hd, d01 = out.stdout.split()
+    nl, nr, nm, hk, hd, d01, self_found, ba_err, ba_bad, ba_iters = out.stdout.split()
+    found, asked = map(int, self_found.split("/"))
+    assert found == asked == 200                                   # ORBMatcher::searchInArea: every keypoint finds itself
+    assert float(ba_err) < 1e-6 and int(ba_bad) == 0 and 2 <= int(ba_iters) <= 15   # Optimizer::OptimizeLocalMap reaches the truth
     ref = orc.stereo_frame(L, R, fx=FX, bf=BF)
     assert (int(nl), int(nr), int(nm)) == (len(ref["lk"]), len(ref["rk"]), ref["n_matches"])
     assert int(hk, 16) == fnv1a(ref["lk"].tobytes()) and int(hd, 16) == fnv1a(ref["ld"].tobytes())
