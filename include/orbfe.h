@@ -224,6 +224,28 @@ orbfe_status orbfe_pose_only_optimize(orbfe_ctx* ctx, int32_t n, const double* x
                                       double fx, double fy, double cx, double cy, double bf, double* pose_out /*[7]*/,
                                       uint8_t* inlier_out /*[n], nullable*/, int32_t* n_good);
 
+/* ---- frame-level glue either side of the ORB path -----------------------------------------------------
+ * orbfe_extract_color: Tracking::grabFrame's cv::cvtColor(COLOR_RGB2GRAY / COLOR_BGR2GRAY) (src/Tracking.cc:55-68) fused in front of
+ * orbfe_extract (slot 0): img is 8-bit 3-channel interleaved, color_order 1 = RGB, 2 = BGR (the reference's Camera.Color values);
+ * the grey image becomes level 0 of the pyramid (orbfe_get_pyramid(ctx, 0, 0, 0, ..) returns it).
+ * orbfe_frame_rgbd: for the keypoints of `slot`, Camera::undistortPoints (src/Camera.cc:29-39; no-op when k1 == 0) IN PLACE on the
+ * device-resident keypoints -- so the feature grid of orbfe_search_in_area sees undistorted positions as VirtualFrame::initGrid does
+ * (Frame.cc:108,148) -- and, when depth != NULL, the RGB-D tail of Frame::Frame (src/Frame.cc:136-158): depth read at the
+ * DISTORTED keypoint with truncated indices, divided by depth_scale in float, depth_out = d and right_u_out = x_undist - bf / d
+ * where d > 0, else -1.  depth_type 0: uint16 image, 1: float image; rows depth_stride_bytes apart (host memory).
+ * Outputs [n_features] (entries past the keypoint count are -1), any may be NULL.  Stereo rigs are taken as rectified (k1 == 0,
+ * the reference's only stereo configuration): orbfe_stereo_match does not undistort.                                          */
+typedef struct orbfe_camera {
+  float fx, fy, cx, cy;      /* Camera::mK as the reference stores it (float)                    */
+  float k1, k2, p1, p2, k3;  /* Camera::mDistCoeff                                                */
+  float bf;                  /* Camera::mfBf                                                      */
+} orbfe_camera;
+orbfe_status orbfe_extract_color(orbfe_ctx* ctx, const uint8_t* img, size_t stride_bytes, int32_t color_order, orbfe_keypoint* kps,
+                                 uint8_t* desc, int32_t* n_out);
+orbfe_status orbfe_frame_rgbd(orbfe_ctx* ctx, int32_t slot, const orbfe_camera* cam, const void* depth, int32_t depth_type,
+                              size_t depth_stride_bytes, float depth_scale, orbfe_keypoint* kps_undistorted, double* depth_out,
+                              double* right_u_out);
+
 /* ---- instrumentation ---------------------------------------------------------------------------
  * Stage timing with HIP events on the context stream.  Enable, run, then read the accumulated
  * per-stage milliseconds and launch counts.  Stage ids: see orbfe_stage.                             */

@@ -31,7 +31,7 @@ def build(fast: bool = False, out_dir: str | None = None) -> str:
     flags = ["-O3", "-march=native"] if fast else ["-O2"]
     cmd = ["g++", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-pthread", *flags, "-o", out,
            os.path.join(_HERE, "orb_oracle.cpp"), os.path.join(_HERE, "ba_oracle.cpp"), os.path.join(_HERE, "pose_oracle.cpp"),
-           os.path.join(_HERE, "lba_oracle.cpp")]
+           os.path.join(_HERE, "lba_oracle.cpp"), os.path.join(_HERE, "glue_oracle.cpp")]
     subprocess.check_call(cmd)
     return out
 
@@ -66,6 +66,10 @@ class Oracle:
         L.orc_se3_oplus.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_search_in_area.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10
         L.orc_pose_only_optimize.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_double] * 5 + [C.c_void_p] * 2
+        L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_undistort_points.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_rgbd_lookup.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p,
+                                      C.c_void_p]
         L.orc_ba_local_optimize.argtypes = [C.c_int] * 3 + [C.c_void_p] * 8 + [C.c_double] * 5 + [C.c_void_p] + [C.c_int] * 2 + [C.c_void_p] * 6
         L.orc_ba_build_system.argtypes = [C.c_int] * 3 + [C.c_void_p] * 8 + [C.c_double] * 5 + [C.c_void_p] * 7
         L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -204,6 +208,32 @@ class Oracle:
         inl = np.zeros(max(n, 1), np.uint8)
         r = self.lib.orc_pose_only_optimize(n, _p(Xw), _p(meas), _p(info), _p(sigma2), _p(pose), fx, fy, cx, cy, bf, _p(out), _p(inl))
         return r, out, inl[:n].astype(bool)
+
+    # ---- frame glue -------------------------------------------------------------------------
+    def cvt_gray(self, img: np.ndarray, order: int) -> np.ndarray:
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w, _ = img.shape
+        out = np.empty((h, w), np.uint8)
+        self.lib.orc_cvt_gray(_p(img), w, h, 3 * w, order, _p(out), w)
+        return out
+
+    def undistort_points(self, xy, K, D):
+        xy = np.array(xy, np.float32).reshape(-1, 2).copy()
+        K = np.ascontiguousarray(K, np.float32)
+        D = np.ascontiguousarray(D, np.float32)
+        self.lib.orc_undistort_points(xy.shape[0], _p(xy), _p(K), _p(D))
+        return xy
+
+    def rgbd_lookup(self, xy, xy_u, depth, depth_scale, bf):
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        xy_u = np.ascontiguousarray(xy_u, np.float32).reshape(-1, 2)
+        depth = np.ascontiguousarray(depth)
+        assert depth.dtype in (np.uint16, np.float32)
+        n = xy.shape[0]
+        d, ru = np.zeros(max(n, 1)), np.zeros(max(n, 1))
+        self.lib.orc_rgbd_lookup(n, _p(xy), _p(xy_u), _p(depth), 0 if depth.dtype == np.uint16 else 1, depth.strides[0], depth_scale, bf,
+                                 _p(d), _p(ru))
+        return d[:n], ru[:n]
 
     def ba_local_optimize(self, prob, pose_fixed=None, iters1=5, iters2=10):
         """prob: dict as orb_slam2_ros2_amd.ba_synth.make_problem -> dict(poses, points, level, chi2, bad, iters)"""

@@ -4,6 +4,6 @@ ORBExtractor / ORBMatcher / Optimizer call shapes.  See include/orbfe.h for the 
 Importing this package does not load the HIP library; constructing any of the classes does, and raises
 if the library or a device is missing (there is no CPU fallback).
 """
-from .frontend import ORBExtractor, ORBMatcher, Optimizer, StereoFrontEnd  # noqa: F401
+from .frontend import Frame, ORBExtractor, ORBMatcher, Optimizer, StereoFrontEnd  # noqa: F401
 
-__all__ = ["ORBExtractor", "ORBMatcher", "Optimizer", "StereoFrontEnd"]
+__all__ = ["Frame", "ORBExtractor", "ORBMatcher", "Optimizer", "StereoFrontEnd"]

@@ -56,6 +56,11 @@ class BaSystemOut(C.Structure):
     _fields_ = [("Hpp", C.c_void_p), ("bp", C.c_void_p), ("Hll", C.c_void_p), ("bl", C.c_void_p), ("Hpl", C.c_void_p)]
 
 
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("k1", C.c_float), ("k2", C.c_float),
+                ("p1", C.c_float), ("p2", C.c_float), ("k3", C.c_float), ("bf", C.c_float)]
+
+
 class BaOptimizeOut(C.Structure):
     _fields_ = [("poses", C.c_void_p), ("points", C.c_void_p), ("level", C.c_void_p), ("chi2", C.c_void_p), ("bad", C.c_void_p),
                 ("iterations", C.c_void_p)]
@@ -69,7 +74,7 @@ class BaEdgeOut(C.Structure):
 EXPORTS = [
     "orbfe_abi_version", "orbfe_create", "orbfe_destroy", "orbfe_last_error", "orbfe_get_level_info", "orbfe_get_scale_factors",
     "orbfe_extract", "orbfe_extract_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
-    "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area",
+    "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_extract_color", "orbfe_frame_rgbd",
     "orbfe_profile_enable", "orbfe_profile_read", "orbfe_stage_name", "orbfe_debug_candidates",
 ]
 
@@ -116,6 +121,8 @@ def load() -> C.CDLL:
     L.orbfe_ba_local_optimize.argtypes = [vp, C.POINTER(BaProblem), vp, i32, i32, vp, C.POINTER(BaOptimizeOut)]
     L.orbfe_pose_only_optimize.argtypes = [vp, i32, vp, vp, vp, vp, vp] + [C.c_double] * 5 + [vp, vp, vp]
     L.orbfe_search_in_area.argtypes = [vp, i32, i32] + [vp] * 10
+    L.orbfe_extract_color.argtypes = [vp, vp, C.c_size_t, i32, vp, vp, vp]
+    L.orbfe_frame_rgbd.argtypes = [vp, i32, C.POINTER(Camera), vp, i32, C.c_size_t, f32, vp, vp, vp]
     L.orbfe_profile_enable.argtypes = [vp, i32]
     L.orbfe_profile_read.argtypes = [vp, vp, vp, i32]
     L.orbfe_stage_name.argtypes = [i32]
@@ -358,6 +365,31 @@ class Context:
         self._check(self.lib.orbfe_pose_only_optimize(self.h, n, ptr(Xw), ptr(meas), ptr(info), ptr(sigma2), ptr(pose), fx, fy, cx, cy,
                                                       bf, ptr(out), ptr(inl), C.byref(ng)))
         return ng.value, out, inl[:n].astype(bool)
+
+    # ---- frame glue ------------------------------------------------------------------------------
+    def extract_color(self, img: np.ndarray, order: int):
+        """img: (h, w, 3) uint8, order 1 = RGB / 2 = BGR -> (keypoints, descriptors) of slot 0"""
+        img = np.ascontiguousarray(img, np.uint8)
+        assert img.shape == (self.height, self.width, 3)
+        kps = np.zeros(max(self.n_features, 1), KP_DTYPE)
+        desc = np.zeros((max(self.n_features, 1), 32), np.uint8)
+        n = C.c_int32(0)
+        self._check(self.lib.orbfe_extract_color(self.h, ptr(img), img.strides[0], order, ptr(kps), ptr(desc), C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def frame_rgbd(self, slot, cam: dict, depth=None, depth_scale=1.0):
+        """cam: dict(fx fy cx cy k1 k2 p1 p2 k3 bf) -> (undistorted keypoints, depth, right_u); depth None: undistortion only"""
+        cm = Camera(*[float(cam[k]) for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "bf")])
+        nf = max(self.n_features, 1)
+        kps = np.zeros(nf, KP_DTYPE)
+        d, ru = np.zeros(nf), np.zeros(nf)
+        dtype, stride = 0, 0
+        if depth is not None:
+            depth = np.ascontiguousarray(depth)
+            assert depth.dtype in (np.uint16, np.float32) and depth.shape == (self.height, self.width)
+            dtype, stride = (0 if depth.dtype == np.uint16 else 1), depth.strides[0]
+        self._check(self.lib.orbfe_frame_rgbd(self.h, slot, C.byref(cm), ptr(depth), dtype, stride, depth_scale, ptr(kps), ptr(d), ptr(ru)))
+        return kps, d, ru   # [n_features] each; entries past the slot's keypoint count are zero (kps) / -1
 
     # ---- instrumentation ------------------------------------------------------------------------
     def profile_enable(self, on=True):

@@ -1,0 +1,100 @@
+// k_glue.hip -- the frame-level steps either side of the ORB path.
+//
+// Replaces cv::cvtColor(COLOR_RGB2GRAY / COLOR_BGR2GRAY) of Tracking::grabFrame (src/ORB_SLAM2/src/Tracking.cc:55-68),
+// Camera::undistortPoints (src/Camera.cc:29-39, cv::undistortPoints with P = K: 5 fixed iterations in fp64) and the RGB-D tail
+// of Frame::Frame (src/Frame.cc:136-158: depth lookup at the distorted keypoint with truncated indices, rightU = x_u - bf / d).
+// Byte arithmetic and fp64 without FMA contraction: bit-identical to an un-contracted x86-64 build of the same formulas.
+#include <hip/hip_runtime.h>
+
+#include "orbfe_internal.h"
+
+namespace orbfe {
+
+// 4 pixels (12 source bytes as 3 aligned words) -> one destination word.  order 1: RGB, 2: BGR.
+__global__ __launch_bounds__(256) void k_cvt_gray(const uint8_t* __restrict__ src, size_t src_stride, uint8_t* __restrict__ dst,
+                                                  int dst_stride, int w, int order) {
+  const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int y = blockIdx.y;
+  if (x4 >= w) return;
+  const uint32_t* s = (const uint32_t*)(src + (size_t)y * src_stride + 3 * (size_t)x4);  // rows and 12-byte groups are 4-aligned
+  const uint32_t w0 = s[0], w1 = s[1], w2 = s[2];
+  const uint32_t c[12] = {w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u, w0 >> 24, w1 & 255u, (w1 >> 8) & 255u,
+                          (w1 >> 16) & 255u, w1 >> 24, w2 & 255u, (w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24};
+  const uint32_t c0 = order == 1 ? 4899u : 1868u, c2 = order == 1 ? 1868u : 4899u;  // R2Y / B2Y on the first / third channel
+  uint32_t out = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t g = (c[3 * j] * c0 + c[3 * j + 1] * 9617u + c[3 * j + 2] * c2 + (1u << 13)) >> 14;
+    out |= g << (8 * j);
+  }
+  *(uint32_t*)(dst + (size_t)y * dst_stride + x4) = out;  // the row padding absorbs the tail
+}
+
+// one lane per keypoint of the slot: depth lookup at the distorted position, undistortion in place, rightU
+__global__ __launch_bounds__(256) void k_frame_rgbd(orbfe_keypoint* __restrict__ kps, const int32_t* __restrict__ n_kp_ptr, int n_features,
+                                                    orbfe_camera cam, const uint8_t* __restrict__ depth, int depth_type, size_t depth_stride,
+                                                    float depth_scale, double* __restrict__ depth_out, double* __restrict__ right_u_out) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_features) return;
+  const int n = *n_kp_ptr;
+  if (i >= n) {
+    depth_out[i] = -1.0;
+    right_u_out[i] = -1.0;
+    return;
+  }
+  const float px = kps[i].x, py = kps[i].y;
+  float xu = px, yu = py;
+  if (cam.k1 != 0.0f) {  // Camera.cc:31
+    const double fx = cam.fx, fy = cam.fy, cx = cam.cx, cy = cam.cy;
+    const double ifx = 1. / fx, ify = 1. / fy;
+    const double k0 = cam.k1, k1 = cam.k2, k2 = cam.p1, k3 = cam.p2, k4 = cam.k3;
+    double x = px, y = py;
+    const double u = x, v = y;
+    x = (x - cx) * ifx;
+    y = (y - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; ++j) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);
+      if (icdist < 0) {
+        x = (u - cx) * ifx;
+        y = (v - cy) * ify;
+        break;
+      }
+      const double dx = 2 * k2 * x * y + k3 * (r2 + 2 * x * x) + 0 * r2 + 0 * r2 * r2;
+      const double dy = k2 * (r2 + 2 * y * y) + 2 * k3 * x * y + 0 * r2 + 0 * r2 * r2;
+      x = (x0 - dx) * icdist;
+      y = (y0 - dy) * icdist;
+    }
+    const double xx = fx * x + 0 * y + cx, yy = 0 * x + fy * y + cy, ww = 1. / (0 * x + 0 * y + 1);
+    xu = (float)(xx * ww);
+    yu = (float)(yy * ww);
+    kps[i].x = xu;
+    kps[i].y = yu;
+  }
+  double d_out = -1.0, ru_out = -1.0;
+  if (depth) {
+    const int ix = (int)px, iy = (int)py;  // Mat::at<float>(float, float): truncated indices (quirk Q10)
+    const uint8_t* row = depth + (size_t)iy * depth_stride;
+    const float raw = depth_type == 0 ? (float)((const uint16_t*)row)[ix] : ((const float*)row)[ix];
+    const float d = raw / depth_scale;
+    if (d > 0) {
+      d_out = (double)d;
+      ru_out = (double)(xu - cam.bf / d);
+    }
+  }
+  depth_out[i] = d_out;
+  right_u_out[i] = ru_out;
+}
+
+void launch_cvt_gray(hipStream_t s, const uint8_t* d_src, size_t src_stride, uint8_t* d_dst, int dst_stride, int w, int h, int order) {
+  hipLaunchKernelGGL(k_cvt_gray, dim3((w + 1023) / 1024, h), dim3(256), 0, s, d_src, src_stride, d_dst, dst_stride, w, order);
+}
+void launch_frame_rgbd(hipStream_t s, orbfe_keypoint* d_kps, const int32_t* d_n_kp, int n_features, const orbfe_camera& cam,
+                       const uint8_t* d_depth, int depth_type, size_t depth_stride, float depth_scale, double* d_depth_out, double* d_right_u) {
+  hipLaunchKernelGGL(k_frame_rgbd, dim3((n_features + 255) / 256), dim3(256), 0, s, d_kps, d_n_kp, n_features, cam, d_depth, depth_type,
+                     depth_stride, depth_scale, d_depth_out, d_right_u);
+}
+
+}  // namespace orbfe

@@ -46,6 +46,10 @@ void launch_stereo(hipStream_t s, const LevelDev* d_lv, const uint8_t* d_pyr, si
                    const uint8_t* d_desc, const KpAux* d_aux, const float* d_kx, const short2* d_env, int n_chunks,
                    const int32_t* d_n_kp, int n_features, float fx, float bf, int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
                    int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs);
+// k_glue.hip
+void launch_cvt_gray(hipStream_t s, const uint8_t* d_src, size_t src_stride, uint8_t* d_dst, int dst_stride, int w, int h, int order);
+void launch_frame_rgbd(hipStream_t s, orbfe_keypoint* d_kps, const int32_t* d_n_kp, int n_features, const orbfe_camera& cam,
+                       const uint8_t* d_depth, int depth_type, size_t depth_stride, float depth_scale, double* d_depth_out, double* d_right_u);
 // k_lba.hip
 void launch_lba_chi2_sum(hipStream_t s, int n_edges, const double* chi2, const double* rho, const uint8_t* level, double* chi2_last,
                          double* out);
@@ -790,6 +794,27 @@ orbfe_status orbfe_device_results(orbfe_ctx* c, const void** d_kps, const void**
   return ORBFE_OK;
 }
 
+// results of slots 0..n_img-1 to the host through the pinned staging buffer: one batch of D2H copies (full arrays: the counts
+// are not known on the host yet), ONE synchronisation
+static orbfe_status fetch_extract_results(orbfe_ctx* c, int n_img, size_t o_kps, size_t o_desc, size_t o_cnt, orbfe_keypoint* kps,
+                                          uint8_t* desc, int32_t* n_out) {
+  const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
+  HIP_TRY(c, hipMemcpyAsync(c->h_stage + o_cnt, c->d_n_kp, sizeof(int32_t) * n_img, hipMemcpyDeviceToHost, c->stream));
+  if (kps) HIP_TRY(c, hipMemcpyAsync(c->h_stage + o_kps, c->d_kps, (size_t)n_img * NF * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, c->stream));
+  if (desc) HIP_TRY(c, hipMemcpyAsync(c->h_stage + o_desc, c->d_desc, (size_t)n_img * NF * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  const int32_t* cnt = (const int32_t*)(c->h_stage + o_cnt);
+  for (int i = 0; i < n_img; ++i) {
+    const int32_t n = cnt[i];
+    if (n < 0 || (size_t)n > NF) return fail(c, ORBFE_EDEVICE, "extract: corrupt count %d for image %d", n, i);
+    if (kps) std::memcpy(kps + (size_t)i * NF, c->h_stage + o_kps + (size_t)i * NF * sizeof(orbfe_keypoint), sizeof(orbfe_keypoint) * n);
+    if (desc) std::memcpy(desc + (size_t)i * NF * 32, c->h_stage + o_desc + (size_t)i * NF * 32, (size_t)32 * n);
+    if (n_out) n_out[i] = n;
+  }
+  return ORBFE_OK;
+}
+
 orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* const* imgs, size_t stride, orbfe_keypoint* kps,
                                  uint8_t* desc, int32_t* n_out) {
   if (!c || !imgs || n_img < 0) return fail(c, ORBFE_EBADARG, "extract_batch: NULL argument");
@@ -811,26 +836,62 @@ orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* con
                               c->stream));
   }
   TRY(run_extract(c, c->stream, 0, n_img));
-  // one batch of D2H copies (full arrays: the counts are not known on the host yet), ONE synchronisation
-  HIP_TRY(c, hipMemcpyAsync(c->h_stage + o_cnt, c->d_n_kp, sizeof(int32_t) * n_img, hipMemcpyDeviceToHost, c->stream));
-  if (kps) HIP_TRY(c, hipMemcpyAsync(c->h_stage + o_kps, c->d_kps, (size_t)n_img * NF * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, c->stream));
-  if (desc) HIP_TRY(c, hipMemcpyAsync(c->h_stage + o_desc, c->d_desc, (size_t)n_img * NF * 32, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  drain_timers(c);
-  const int32_t* cnt = (const int32_t*)(c->h_stage + o_cnt);
-  for (int i = 0; i < n_img; ++i) {
-    const int32_t n = cnt[i];
-    if (n < 0 || (size_t)n > NF) return fail(c, ORBFE_EDEVICE, "extract_batch: corrupt count %d for image %d", n, i);
-    if (kps) std::memcpy(kps + (size_t)i * NF, c->h_stage + o_kps + (size_t)i * NF * sizeof(orbfe_keypoint), sizeof(orbfe_keypoint) * n);
-    if (desc) std::memcpy(desc + (size_t)i * NF * 32, c->h_stage + o_desc + (size_t)i * NF * 32, (size_t)32 * n);
-    if (n_out) n_out[i] = n;
-  }
-  return ORBFE_OK;
+  return fetch_extract_results(c, n_img, o_kps, o_desc, o_cnt, kps, desc, n_out);
 }
 
 orbfe_status orbfe_extract(orbfe_ctx* c, const uint8_t* img, size_t stride, orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out) {
   const uint8_t* one[1] = {img};
   return orbfe_extract_batch(c, 1, one, stride, kps, desc, n_out);
+}
+
+orbfe_status orbfe_extract_color(orbfe_ctx* c, const uint8_t* img, size_t stride, int32_t color_order, orbfe_keypoint* kps, uint8_t* desc,
+                                 int32_t* n_out) {
+  if (!c || !img) return fail(c, ORBFE_EBADARG, "extract_color: NULL argument");
+  if (color_order != 1 && color_order != 2) return fail(c, ORBFE_EBADARG, "extract_color: color_order %d (1 = RGB, 2 = BGR)", color_order);
+  if (stride < (size_t)c->cfg.width * 3) return fail(c, ORBFE_EBADARG, "extract_color: stride %zu < 3 * width", stride);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const LevelDev& L0 = c->lv[0];
+  const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
+  const size_t row = align_up((size_t)c->cfg.width * 3, 16) + 16;  // 4-aligned rows with room for the last 12-byte group
+  const size_t plane = align_up(row * (size_t)L0.h, 256);
+  const size_t o_kps = plane, o_desc = o_kps + align_up(NF * sizeof(orbfe_keypoint), 256), o_cnt = o_desc + align_up(NF * 32, 256),
+               total = o_cnt + 256;
+  TRY(ensure_stage(c, total));
+  TRY(ensure_tmp(c, plane));
+  for (int y = 0; y < L0.h; ++y) std::memcpy(c->h_stage + (size_t)y * row, img + (size_t)y * stride, (size_t)c->cfg.width * 3);
+  HIP_TRY(c, hipMemcpyAsync(c->d_tmp, c->h_stage, row * (size_t)L0.h, hipMemcpyHostToDevice, c->stream));
+  launch_cvt_gray(c->stream, (const uint8_t*)c->d_tmp, row, c->d_pyr + L0.plane_off, L0.stride, c->cfg.width, c->cfg.height, color_order);
+  TRY(run_extract(c, c->stream, 0, 1));
+  return fetch_extract_results(c, 1, o_kps, o_desc, o_cnt, kps, desc, n_out);
+}
+
+orbfe_status orbfe_frame_rgbd(orbfe_ctx* c, int32_t slot, const orbfe_camera* cam, const void* depth, int32_t depth_type,
+                              size_t depth_stride, float depth_scale, orbfe_keypoint* kps_out, double* depth_out, double* right_u_out) {
+  if (!c || !cam || slot < 0 || slot >= c->cfg.max_images) return fail(c, ORBFE_EBADARG, "frame_rgbd: bad slot / NULL camera");
+  const size_t px = depth_type == 0 ? 2 : 4;
+  if (depth && (depth_type < 0 || depth_type > 1 || depth_stride < (size_t)c->cfg.width * px || !(depth_scale > 0)))
+    return fail(c, ORBFE_EBADARG, "frame_rgbd: depth type %d stride %zu scale %g", depth_type, depth_stride, (double)depth_scale);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
+  const size_t d_bytes = depth ? depth_stride * (size_t)c->cfg.height : 0;
+  const size_t o_img = 0, o_d = align_up(d_bytes, 256), o_ru = o_d + align_up(NF * 8, 256), total = o_ru + align_up(NF * 8, 256);
+  TRY(ensure_tmp(c, total));
+  uint8_t* b = (uint8_t*)c->d_tmp;
+  if (depth) HIP_TRY(c, hipMemcpyAsync(b + o_img, depth, d_bytes, hipMemcpyHostToDevice, c->stream));
+  launch_frame_rgbd(c->stream, c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, (int)NF, *cam, depth ? b + o_img : nullptr, depth_type,
+                    depth_stride, depth_scale, (double*)(b + o_d), (double*)(b + o_ru));
+  HIP_TRY(c, hipGetLastError());
+  int32_t n = 0;
+  HIP_TRY(c, hipMemcpyAsync(&n, c->d_n_kp + slot, 4, hipMemcpyDeviceToHost, c->stream));
+  if (depth_out) HIP_TRY(c, hipMemcpyAsync(depth_out, b + o_d, NF * 8, hipMemcpyDeviceToHost, c->stream));
+  if (right_u_out) HIP_TRY(c, hipMemcpyAsync(right_u_out, b + o_ru, NF * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (kps_out && n > 0) {
+    HIP_TRY(c, hipMemcpyAsync(kps_out, c->d_kps + (size_t)slot * NF, sizeof(orbfe_keypoint) * (size_t)std::min<int64_t>(n, (int64_t)NF),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  return ORBFE_OK;
 }
 
 orbfe_status orbfe_get_pyramid(orbfe_ctx* c, int32_t slot, int32_t level, int32_t blurred, uint8_t* dst) {

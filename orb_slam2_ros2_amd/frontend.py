@@ -150,6 +150,20 @@ class StereoFrontEnd:
         self.mvFeatsRightU, self.mvDepths = ru, dp
 
 
+class Frame:
+    """The steps Frame::Frame / Tracking::grabFrame run either side of the extractor (src/Frame.cc:91-159, src/Tracking.cc:55-68)."""
+
+    @staticmethod
+    def grabColor(ctx: Context, img, color_type: int):
+        """cv::cvtColor(COLOR_RGB2GRAY if Camera.Color == 1 else COLOR_BGR2GRAY) + ORBExtractor::extract on slot 0"""
+        return ctx.extract_color(img, color_type)
+
+    @staticmethod
+    def finishRGBD(ctx: Context, slot: int, camera: dict, depth, depth_scale: float):
+        """Camera::undistortPoints + the depth / rightU lookup of the RGB-D constructor (Frame.cc:145-158)"""
+        return ctx.frame_rgbd(slot, camera, depth, depth_scale)
+
+
 class Optimizer:
     """Edge evaluation of the graph Optimizer::OptimizeLocalMap builds (Optimizer.cc:296-330)."""
     deltaMono = float(np.float32(np.sqrt(5.991)))    # Optimizer.cc:1084 (stored as float)
