@@ -121,6 +121,130 @@ class ORBMatcher:
         ORBMatcher::searchByProjection (ORBMatcher.cc:265-347, 561-612) against the device-resident features of `slot`."""
         return ctx.search_in_area(slot, qxy, radius, min_level, max_level, q_desc, exclude)
 
+    # ---- the guided searches (host logic of the reference around the batched device calls) -------------------------------
+    # Map state enters as plain arrays (which features already carry a good map point, which map points are usable ...);
+    # the side effects on the map (setMapPoints, addMatchInTrack, ...) are returned as data and stay with the caller.
+    # `area_search` / `best_match` default to the device calls; they are parameters so that this logic can be exercised on its own.
+
+    def searchByProjectionFrames(self, ctx, slot1, scale_factors2, kps2, desc2, valid2, has_mp1, th, z, bl, bFuse=False, in_vision=None,
+                                 area_search=None):
+        """ORBMatcher::searchByProjection(pFrame1, pFrame2, matches, th, bFuse) (ORBMatcher.cc:265-347): every feature idx of frame 2
+        that carries a usable map point (valid2[idx]) searches frame 1 (device slot `slot1`) around ITS OWN position with radius
+        th * scale2[octave] (Frame.cc:289); octave window by the motion along z (`z` = tlc.z, `bl` = Camera::mfBl, :274-282).
+        !bFuse: candidates that already have a good map point in frame 1 (has_mp1) are skipped (:316-330; the caller bumps
+        addMatchInTrack for them).  Returns [(queryIdx in frame 1, trainIdx = idx, distance)] in idx order."""
+        search = area_search or (lambda *a: ctx.search_in_area(slot1, *a))
+        kps2 = np.asarray(kps2)
+        idx = np.flatnonzero(np.asarray(valid2, bool) & (np.ones(len(kps2), bool) if not bFuse or in_vision is None else np.asarray(in_vision, bool)))
+        if idx.size == 0:
+            return []
+        up, down = (abs(z) > bl and z > 0), (abs(z) > bl and not z > 0)
+        octv = kps2["octave"][idx].astype(np.int32)
+        lo = np.where(up, octv, np.where(down, 0, np.maximum(0, octv - 1))).astype(np.int8)
+        hi = np.where(up, 7, np.where(down, octv, np.minimum(octv + 1, 7))).astype(np.int8)   # the reference hard-codes 7 (:302,:311)
+        sf2 = np.asarray(scale_factors2, np.float32) ** 2             # getScaledFactor2(octave)
+        radius = (np.float32(th) * sf2[octv]).astype(np.float32)
+        qxy = np.stack([kps2["x"][idx], kps2["y"][idx]], 1).astype(np.float32)
+        excl = None if bFuse else np.ascontiguousarray(has_mp1, np.uint8)
+        bi, bd, sd, nc = search(qxy, radius, lo, hi, np.asarray(desc2)[idx], excl)
+        ratio = bd.astype(np.float32) / sd.astype(np.float32)
+        ok = (nc > 0) & (ratio < np.float32(self.mfRatio)) & (bd < self.mnMinThreshold)
+        return [(int(bi[k]), int(idx[k]), int(bd[k])) for k in np.flatnonzero(ok)]
+
+    def searchByProjectionMapPoints(self, ctx, slot, uv, level, cos_theta, mp_desc, usable, th, frame_has_good_mp, bFuse=False, n_levels=8,
+                                    scale_factors=None, area_search=None):
+        """ORBMatcher::searchByProjection(pframe, mapPoints, th, matches, bFuse) (ORBMatcher.cc:561-612).  Per map point the caller
+        supplies what MapPoint::isInVision / predictLevel produced (MapPoint.cc:141-201): projection uv, predicted level, cosTheta and
+        usable = in map, not bad, in vision.  Radius (2.5 if cos > 0.998 else 4.0) * th * scale2[level], levels level-1..level+1.
+        bFuse: returns (matches [(featIdx, mapPointIdx, dist)], nMatches).  Otherwise: (assignments [(featIdx, mapPointIdx)] the caller
+        applies with setMapPoint / addMatchInTrack -- first map point wins a feature, features with a good map point are left alone
+        (:588-594) --, nMatches including the frame's existing good map points (:566-572))."""
+        search = area_search or (lambda *a: ctx.search_in_area(slot, *a))
+        has = np.array(frame_has_good_mp, bool).copy()
+        n_matches = 0 if bFuse else int(has.sum())
+        idx = np.flatnonzero(np.asarray(usable, bool))
+        if idx.size == 0:
+            return [], n_matches
+        lvl = np.asarray(level, np.int32)[idx]
+        sf2 = np.asarray(scale_factors if scale_factors is not None else ctx.scale_factors(), np.float32) ** 2
+        base = np.where(np.asarray(cos_theta, np.float32)[idx] > np.float32(0.998), np.float32(2.5), np.float32(4.0))
+        radius = ((base * np.float32(th)).astype(np.float32) * sf2[lvl]).astype(np.float32)
+        lo = np.maximum(0, lvl - 1).astype(np.int8)
+        hi = np.minimum(n_levels - 1, lvl + 1).astype(np.int8)
+        bi, bd, sd, nc = search(np.asarray(uv, np.float32)[idx], radius, lo, hi, np.asarray(mp_desc)[idx], None)
+        ratio = bd.astype(np.float32) / sd.astype(np.float32)
+        ok = (nc > 0) & (bd < self.mnMinThreshold) & (ratio < np.float32(self.mfRatio))
+        out = []
+        for k in np.flatnonzero(ok):
+            f = int(bi[k])
+            if bFuse:
+                out.append((f, int(idx[k]), int(bd[k])))
+                n_matches += 1
+            elif not has[f]:
+                has[f] = True                                           # pframe->setMapPoint(bestMatch.first, pMp)
+                out.append((f, int(idx[k])))
+                n_matches += 1
+        return out, n_matches
+
+    def searchByBow(self, ctx, desc_f, desc_kf, featvec_f, featvec_kf, good_f, inmap_f, good_kf, inmap_kf, angles_f=None, angles_kf=None,
+                    bAddMPs=False, bLoop=False, best_match=None):
+        """ORBMatcher::searchByBow (ORBMatcher.cc:170-253) given the two DBoW feature vectors as {node id: [feature ids]} (the BoW
+        transform itself stays with DBoW3).  good_* = map point non-null and not bad, inmap_* = isInMap().  Returns the matches
+        [(frame idx, keyframe idx, distance)] after the threshold / ratio test and verifyAngle (if mbCheckOri)."""
+        match = best_match or (lambda q, t, off, cand: ctx.match_bruteforce(q, t, off, cand))
+        good_f, inmap_f, good_kf, inmap_kf = (np.asarray(a, bool) for a in (good_f, inmap_f, good_kf, inmap_kf))
+        q_ids, offs, cands = [], [0], []
+        for node in sorted(set(featvec_f) & set(featvec_kf)):            # the merge walk over the two ordered maps (:183-189)
+            if bAddMPs:
+                cf = [p for p in featvec_f[node] if not (good_f[p] and inmap_f[p])]
+            elif bLoop:
+                cf = list(featvec_f[node])
+            else:
+                cf = [p for p in featvec_f[node] if not good_f[p]]
+            for pk in featvec_kf[node]:
+                g = good_kf[pk]
+                if bAddMPs:
+                    if g and inmap_kf[pk]:
+                        continue
+                elif not bLoop and not g:
+                    continue
+                if not cf:
+                    continue
+                q_ids.append(pk)
+                cands += cf
+                offs.append(len(cands))
+        if not q_ids:
+            return []
+        bi, bd, sd = match(np.asarray(desc_kf)[q_ids], np.asarray(desc_f), np.asarray(offs, np.uint32), np.asarray(cands, np.uint32))
+        ratio = bd.astype(np.float32) / sd.astype(np.float32)
+        keep = ~((bd > self.mnMinThreshold) | (ratio > np.float32(self.mfRatio)))
+        matches = [(int(bi[k]), int(q_ids[k]), int(bd[k])) for k in np.flatnonzero(keep)]
+        if self.mbCheckOri and angles_f is not None and angles_kf is not None:
+            matches = self.verifyAngle(matches, angles_f, angles_kf)
+        return matches
+
+    @classmethod
+    def verifyAngle(cls, matches, angles1, angles2):
+        """ORBMatcher::verifyAngle (ORBMatcher.cc:1013-1051): 30-bin histogram of angle differences (float arithmetic), the three
+        largest bins survive (first maximum wins ties, empty bins never chosen); output ordered by bin id, then input order."""
+        hist = [[] for _ in range(cls.mnBinNum)]
+        for m in matches:
+            diff = np.float32(angles1[m[0]]) - np.float32(angles2[m[1]])
+            diff = diff if diff >= 0 else np.float32(360) + diff
+            b = int(diff / np.float32(360 // cls.mnBinNum))             # 360 / mnBinNum is an int division (= 12)
+            if b == 30:
+                b = 0
+            hist[b].append(m)
+        good = set()
+        for _ in range(cls.mnBinChoose):
+            best, best_id = 0, None
+            for i, h in enumerate(hist):
+                if i not in good and len(h) > best:
+                    best, best_id = len(h), i
+            if best_id is not None:
+                good.add(best_id)
+        return [m for i in sorted(good) for m in hist[i]]
+
     def searchByStereo(self, frame: "StereoFrontEnd", fx: float, bf: float):
         """ORBMatcher::searchByStereo (ORBMatcher.cc:18-81) on the device-resident features of `frame`.
         Returns (n_matches, right_u, depth) with -1 where unmatched."""

@@ -205,6 +205,170 @@ class ORBMatcher {
     return m;
   }
 
+  struct DMatch {  // cv::DMatch fields the reference uses
+    int queryIdx, trainIdx;
+    int distance;
+    bool operator==(const DMatch& o) const { return queryIdx == o.queryIdx && trainIdx == o.trainIdx && distance == o.distance; }
+  };
+  static constexpr int mnBinNum = 30, mnBinChoose = 3;  // ORBMatcher.cc:1091-1092
+
+  // ORBMatcher::searchByProjection(pFrame1, pFrame2, matches, th, bFuse) (src/ORBMatcher.cc:265-347).  Frame 1 = the features of
+  // `slot1` on the device; frame 2 enters as arrays.  valid2[idx]: map point of feature idx non-null and not bad (and, for
+  // bFuse, in vision of frame 1); hasMp1[i]: feature i of frame 1 already carries a good map point (skipped unless bFuse; the
+  // caller bumps addMatchInTrack and applies setMapPoints).  z = tlc.z (:274-276), bl = Camera::mfBl.
+  std::vector<DMatch> searchByProjection(orbfe_ctx* ctx, int slot1, const std::vector<float>& scaleFactors2,
+                                         const std::vector<orbfe_keypoint>& kps2, const std::vector<Descriptor>& desc2,
+                                         const std::vector<uint8_t>& valid2, const std::vector<uint8_t>& hasMp1, float th, float z, float bl,
+                                         bool bFuse) const {
+    const bool up = std::abs(z) > bl && z > 0, down = std::abs(z) > bl && !(z > 0);
+    std::vector<int> idx;
+    std::vector<float> uv, radius;
+    std::vector<int8_t> lo, hi;
+    std::vector<Descriptor> qd;
+    for (size_t i = 0; i < kps2.size(); ++i) {
+      if (!valid2[i]) continue;
+      const int o = kps2[i].octave;
+      idx.push_back((int)i);
+      uv.push_back(kps2[i].x), uv.push_back(kps2[i].y);
+      radius.push_back(th * (scaleFactors2[o] * scaleFactors2[o]));  // findFeaturesInArea: radius * getScaledFactor2(octave)
+      lo.push_back((int8_t)(up ? o : down ? 0 : std::max(0, o - 1)));
+      hi.push_back((int8_t)(up ? 7 : down ? o : std::min(o + 1, 7)));
+      qd.push_back(desc2[i]);
+    }
+    std::vector<DMatch> out;
+    if (idx.empty()) return out;
+    const AreaMatch m = searchInArea(ctx, slot1, uv, radius, lo, hi, qd, bFuse ? nullptr : &hasMp1);
+    for (size_t k = 0; k < idx.size(); ++k) {
+      if (m.nCand[k] <= 0) continue;
+      const float ratio = (float)m.bestDist[k] / (float)m.secondDist[k];
+      if (ratio < mfRatio && m.bestDist[k] < mnMinThreshold) out.push_back({m.bestIdx[k], idx[k], m.bestDist[k]});
+    }
+    return out;
+  }
+
+  // ORBMatcher::searchByProjection(pframe, mapPoints, th, matches, bFuse) (src/ORBMatcher.cc:561-612).  Per map point the caller
+  // supplies the outputs of MapPoint::isInVision / predictLevel (uv, level, cosTheta) and usable = in map, not bad, in vision.
+  // bFuse: matches (featIdx, mapPointIdx, distance).  Otherwise `matches` holds the assignments the caller applies with
+  // setMapPoint / addMatchInTrack (first map point wins a feature, features with a good map point are left alone); returns nMatches.
+  int searchByProjection(orbfe_ctx* ctx, int slot, const std::vector<float>& scaleFactors, int nLevels, const std::vector<float>& uv,
+                         const std::vector<int>& level, const std::vector<float>& cosTheta, const std::vector<Descriptor>& mpDesc,
+                         const std::vector<uint8_t>& usable, float th, std::vector<uint8_t> frameHasGoodMp, std::vector<DMatch>& matches,
+                         bool bFuse) const {
+    matches.clear();
+    int nMatches = 0;
+    if (!bFuse)
+      for (uint8_t h : frameHasGoodMp) nMatches += h ? 1 : 0;
+    std::vector<int> idx;
+    std::vector<float> q, radius;
+    std::vector<int8_t> lo, hi;
+    std::vector<Descriptor> qd;
+    for (size_t i = 0; i < usable.size(); ++i) {
+      if (!usable[i]) continue;
+      const int l = level[i];
+      idx.push_back((int)i);
+      q.push_back(uv[2 * i]), q.push_back(uv[2 * i + 1]);
+      radius.push_back(((cosTheta[i] > 0.998f ? 2.5f : 4.0f) * th) * (scaleFactors[l] * scaleFactors[l]));
+      lo.push_back((int8_t)std::max(0, l - 1));
+      hi.push_back((int8_t)std::min(nLevels - 1, l + 1));
+      qd.push_back(mpDesc[i]);
+    }
+    if (idx.empty()) return nMatches;
+    const AreaMatch m = searchInArea(ctx, slot, q, radius, lo, hi, qd, nullptr);
+    for (size_t k = 0; k < idx.size(); ++k) {
+      if (m.nCand[k] <= 0) continue;
+      const float ratio = (float)m.bestDist[k] / (float)m.secondDist[k];
+      if (!(m.bestDist[k] < mnMinThreshold && ratio < mfRatio)) continue;
+      const int f = m.bestIdx[k];
+      if (bFuse) {
+        matches.push_back({f, idx[k], m.bestDist[k]});
+        ++nMatches;
+      } else if (!frameHasGoodMp[f]) {
+        frameHasGoodMp[f] = 1;  // pframe->setMapPoint(bestMatch.first, pMp)
+        matches.push_back({f, idx[k], m.bestDist[k]});
+        ++nMatches;
+      }
+    }
+    return nMatches;
+  }
+
+  // ORBMatcher::searchByBow (src/ORBMatcher.cc:170-253) given the two DBoW feature vectors (node id -> feature ids, ordered maps
+  // like DBoW3::FeatureVector); the BoW transform stays with DBoW3.  good* = map point non-null and not bad, inMap* = isInMap().
+  std::vector<DMatch> searchByBow(orbfe_ctx* ctx, const std::vector<Descriptor>& descF, const std::vector<Descriptor>& descKF,
+                                  const std::map<unsigned, std::vector<unsigned>>& featVecF,
+                                  const std::map<unsigned, std::vector<unsigned>>& featVecKF, const std::vector<uint8_t>& goodF,
+                                  const std::vector<uint8_t>& inMapF, const std::vector<uint8_t>& goodKF, const std::vector<uint8_t>& inMapKF,
+                                  const std::vector<float>& anglesF, const std::vector<float>& anglesKF, bool bAddMPs, bool bLoop) const {
+    std::vector<int> qIds;
+    std::vector<uint32_t> off{0}, cand;
+    std::vector<Descriptor> qd;
+    auto f = featVecF.begin();
+    auto k = featVecKF.begin();
+    while (f != featVecF.end() && k != featVecKF.end()) {
+      if (f->first > k->first) {
+        ++k;
+      } else if (f->first < k->first) {
+        ++f;
+      } else {
+        std::vector<uint32_t> cf;
+        for (unsigned p : f->second) {
+          const bool g = goodF[p];
+          if (bAddMPs ? !(g && inMapF[p]) : (bLoop || !g)) cf.push_back(p);
+        }
+        for (unsigned pk : k->second) {
+          const bool g = goodKF[pk];
+          if (bAddMPs) {
+            if (g && inMapKF[pk]) continue;
+          } else if (!bLoop && !g) {
+            continue;
+          }
+          if (cf.empty()) continue;
+          qIds.push_back((int)pk);
+          qd.push_back(descKF[pk]);
+          cand.insert(cand.end(), cf.begin(), cf.end());
+          off.push_back((uint32_t)cand.size());
+        }
+        ++f;
+        ++k;
+      }
+    }
+    std::vector<DMatch> matches;
+    if (qIds.empty()) return matches;
+    const int32_t nq = (int32_t)qIds.size();
+    std::vector<int32_t> bi(nq), bd(nq), sd(nq);
+    check(ctx, orbfe_match_bruteforce(ctx, qd[0].data(), nq, descF.empty() ? nullptr : descF[0].data(), (int32_t)descF.size(), off.data(),
+                                      cand.data(), bi.data(), bd.data(), sd.data()));
+    for (int32_t i = 0; i < nq; ++i) {
+      const float ratio = (float)bd[i] / (float)sd[i];
+      if (bd[i] > mnMinThreshold || ratio > mfRatio) continue;
+      matches.push_back({bi[i], qIds[i], bd[i]});
+    }
+    if (mbCheckOri) verifyAngle(matches, anglesF, anglesKF);
+    return matches;
+  }
+
+  // ORBMatcher::verifyAngle (src/ORBMatcher.cc:1013-1051)
+  static void verifyAngle(std::vector<DMatch>& matches, const std::vector<float>& angles1, const std::vector<float>& angles2) {
+    std::vector<std::vector<DMatch>> hist(mnBinNum);
+    for (const DMatch& m : matches) {
+      float diff = angles1[m.queryIdx] - angles2[m.trainIdx];
+      diff = diff >= 0 ? diff : 360 + diff;
+      int bin = diff / (360 / mnBinNum);
+      if (bin == 30) bin = 0;
+      hist[bin].push_back(m);
+    }
+    std::vector<bool> good(mnBinNum, false);
+    for (int c = 0; c < mnBinChoose; ++c) {
+      int maxSize = 0, maxId = -1;
+      for (int id = 0; id < mnBinNum; ++id)
+        if (!good[id] && (int)hist[id].size() > maxSize) maxId = id, maxSize = (int)hist[id].size();
+      if (maxId >= 0) good[maxId] = true;
+    }
+    std::vector<DMatch> ret;
+    for (int id = 0; id < mnBinNum; ++id)
+      if (good[id]) ret.insert(ret.end(), hist[id].begin(), hist[id].end());
+    matches.swap(ret);
+  }
+
  private:
   float mfRatio;
   bool mbCheckOri;

@@ -61,6 +61,19 @@ int main(int argc, char** argv) {
       int self = 0;
       for (size_t i = 0; i < n; ++i) self += (m.bestDist[i] == 0 && m.nCand[i] >= 1);
       printf(" %d/%zu", self, n);
+      // ORBMatcher::searchByProjection(frame, frame): with ratio 1 every keypoint whose own cell neighbourhood holds no closer
+      // descriptor matches itself at distance 0; verifyAngle keeps them all (angle difference 0 -> one bin)
+      std::vector<float> sf(8);
+      orbfe::check(el.context(), orbfe_get_scale_factors(el.context(), sf.data(), 8));
+      std::vector<uint8_t> valid(kl.size(), 1), none(kl.size(), 0);
+      auto mm = orbfe::ORBMatcher(1.0f).searchByProjection(el.context(), 0, sf, kl, dl, valid, none, 3.0f, 0.f, 0.5f, false);
+      int selfm = 0;
+      for (const auto& d : mm) selfm += (d.queryIdx == d.trainIdx && d.distance == 0);
+      std::vector<float> ang(kl.size());
+      for (size_t i = 0; i < kl.size(); ++i) ang[i] = kl[i].angle;
+      const size_t before = mm.size();
+      orbfe::ORBMatcher::verifyAngle(mm, ang, ang);
+      printf(" %d/%zu/%zu", selfm, before, mm.size());
     }
     // local BA through the Optimizer mirror: 4 keyframes (2 fixed) looking at a 5x4x2 grid of points, exact stereo
     // measurements, perturbed free poses and points -> the optimum is the truth

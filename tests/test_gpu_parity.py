@@ -343,9 +343,11 @@ def test_cpp_host_mirror_matches_oracle(orc, tmp_path):
     L.tofile(tmp_path / "L.raw")
     R.tofile(tmp_path / "R.raw")
     out = subprocess.run([exe, str(tmp_path / "L.raw"), str(tmp_path / "R.raw"), "1241", "376"], capture_output=True, text=True, check=True)
-    nl, nr, nm, hk, hd, d01, self_found, ba_err, ba_bad, ba_iters = out.stdout.split()
+    nl, nr, nm, hk, hd, d01, self_found, proj, ba_err, ba_bad, ba_iters = out.stdout.split()
     found, asked = map(int, self_found.split("/"))
     assert found == asked == 200                                   # ORBMatcher::searchInArea: every keypoint finds itself
+    selfm, n_proj, n_kept = map(int, proj.split("/"))
+    assert selfm == n_proj == n_kept and n_proj > 0.9 * int(nl)     # ORBMatcher::searchByProjection(frame, frame) + verifyAngle
     assert float(ba_err) < 1e-6 and int(ba_bad) == 0 and 2 <= int(ba_iters) <= 15   # Optimizer::OptimizeLocalMap reaches the truth
     ref = orc.stereo_frame(L, R, fx=FX, bf=BF)
     assert (int(nl), int(nr), int(nm)) == (len(ref["lk"]), len(ref["rk"]), ref["n_matches"])
