@@ -265,7 +265,7 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
                          int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx, short2* d_env, int n_chunks,
-                         uint4* d_kpl, int rows0, int n_img) {
+                         uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief) {
   if (n_img <= 0 || n_features <= 0) return;
   UmaxPacked u = 0;
   for (int i = 0; i < 16; ++i) u |= (unsigned long long)(umax[i] & 15) << (4 * i);
@@ -275,6 +275,7 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                      d_moments);
   hipLaunchKernelGGL(k_orient, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, d_kpl, n_features, d_moments, d_sincos,
                      d_kps, d_aux, d_kx, d_env, n_chunks, d_theta, rows0);
+  if (before_brief) (void)hipStreamWaitEvent(s, before_brief, 0);  // the blurred planes come from another stream
   hipLaunchKernelGGL(k_brief, dim3((n_features + 3) / 4, n_img), dim3(256), 0, s, d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos,
                      d_desc);
 }

@@ -38,7 +38,7 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
                          int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx, short2* d_env, int n_chunks,
-                         uint4* d_kpl, int rows0, int n_img);
+                         uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief);
 // k_match.hip
 void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, const uint32_t* d_off,
                              const uint32_t* d_cand, int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second);
@@ -104,6 +104,9 @@ struct orbfe_ctx {
   int n_side = 0;
   hipStream_t side[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
+  // the blur of a batch runs on its own stream under the (latency-bound, LDS-hungry, SIMD-idle) quadtree of the same batch
+  hipStream_t blur_stream = nullptr;
+  hipEvent_t ev_blur_go = nullptr, ev_blur_done = nullptr;
 
   // geometry (host copies)
   std::vector<LevelDev> lv;
@@ -493,7 +496,12 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     StageTimer t(c, ORBFE_STAGE_RESIZE, st);
     launch_resize(st, c->d_lv, c->d_rs_tiles, c->rs_tiles, c->d_taps, pyr, c->img_pitch, n_img);
   }
-  {
+  // Only the descriptors read the blurred planes, so the blur need not sit between resize and FAST: it is issued on a second
+  // stream once FAST is done and runs UNDER the quadtree, which keeps 8 waves per CU busy with dependent LDS steps and leaves
+  // the SIMDs idle (the blur uses no LDS, the quadtree all of it).  With stage timing on, or when several chunks share the
+  // context, the blur stays in line.
+  const bool overlap_blur = c->blur_stream && !c->prof && lds_share == 1;
+  if (!overlap_blur) {
     StageTimer t(c, ORBFE_STAGE_BLUR, st);
     launch_blur(st, c->d_lv, nl, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
   }
@@ -502,6 +510,12 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     StageTimer t(c, ORBFE_STAGE_FAST, st);
     launch_fast(st, c->d_lv, c->d_cells, c->lv.data(), c->lvl_max_pw, c->lvl_max_ph, pyr, c->img_pitch, c->cfg.fast_hi, c->cfg.fast_lo,
                 c->d_scr_a + i0 * c->scratch_pitch, c->scratch_pitch, n_cand, nl, n_img);
+  }
+  if (overlap_blur) {
+    HIP_TRY(c, hipEventRecord(c->ev_blur_go, st));
+    HIP_TRY(c, hipStreamWaitEvent(c->blur_stream, c->ev_blur_go, 0));
+    launch_blur(c->blur_stream, c->d_lv, nl, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
+    HIP_TRY(c, hipEventRecord(c->ev_blur_done, c->blur_stream));
   }
   {
     StageTimer t(c, ORBFE_STAGE_QUADTREE, st);
@@ -526,7 +540,8 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     launch_orient_brief(st, c->d_lv, nl, pyr, blur, c->img_pitch, c->d_sel + i0 * NF, c->d_sel_count + i0 * nl, c->cfg.n_features,
                         c->d_pattern, c->umax, c->d_kps + i0 * NF, c->d_desc + i0 * NF * 32, c->d_aux + i0 * NF, c->d_n_kp + i0,
                         c->d_theta + i0 * NF, c->d_moments + i0 * NF, c->d_sincos + i0 * NF, c->d_kx + i0 * NF,
-                        c->d_env + i0 * c->n_chunks, c->n_chunks, c->d_kpl + i0 * NF, c->cfg.height, n_img);
+                        c->d_env + i0 * c->n_chunks, c->n_chunks, c->d_kpl + i0 * NF, c->cfg.height, n_img,
+                        overlap_blur ? c->ev_blur_done : nullptr);
   }
   HIP_TRY(c, hipGetLastError());
   return ORBFE_OK;
@@ -577,6 +592,9 @@ void orbfe_destroy(orbfe_ctx* c) {
     if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_blur_go) (void)hipEventDestroy(c->ev_blur_go);
+  if (c->ev_blur_done) (void)hipEventDestroy(c->ev_blur_done);
+  if (c->blur_stream) (void)hipStreamDestroy(c->blur_stream);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -636,6 +654,15 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     if (!ok) {
       fail(c, ORBFE_EDEVICE, "cannot create side streams");
       return bail(ORBFE_EDEVICE);
+    }
+    const char* ov = getenv("ORBFE_OVERLAP_BLUR");
+    if (!ov || atoi(ov) != 0) {
+      if (hipStreamCreateWithFlags(&c->blur_stream, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&c->ev_blur_go, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&c->ev_blur_done, hipEventDisableTiming) != hipSuccess) {
+        fail(c, ORBFE_EDEVICE, "cannot create the blur stream");
+        return bail(ORBFE_EDEVICE);
+      }
     }
   }
   const size_t M = (size_t)cfg->max_images, NF = (size_t)std::max(cfg->n_features, 1), NL = (size_t)cfg->n_levels;
