@@ -81,34 +81,36 @@ __global__ __launch_bounds__(256) void k_kplist(const LevelDev* __restrict__ lv,
 }
 
 // ---------------------------------------------------------------------------------------------
-// 1. intensity-centroid moments, one wave per keypoint.  The 31x31 window of the UN-blurred plane is
-//    read as aligned 32-bit words (5 coalesced wave loads instead of 16 byte gathers).
+// 1. intensity-centroid moments: FOUR keypoints per wave, one DPP row of 16 lanes each.  The 31x31 window of the
+//    UN-blurred plane is read as aligned 32-bit words (31 rows x 9 words = 18 loads per lane, all requested at once).
+//    The kernel is two dependent memory round trips (list entry, window) at full occupancy, so packing four independent
+//    keypoints into a wave is what raises its throughput (one keypoint per wave: 0.215 ms per 256 images).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ic_moments(const uint8_t* __restrict__ pyr, size_t img_pitch, const uint4* __restrict__ kpl,
                                                     int n_features, UmaxPacked umax, int2* __restrict__ moments) {
-  const int lane = threadIdx.x & 63;
-  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, sub = lane & 15;
+  const int k = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
   const int img = blockIdx.y;
-  if (k >= n_features) return;
-  // two dependent memory round trips per wave: the list entry (position, plane offset, stride), then all five window words
-  const uint4 e = kpl[(size_t)img * n_features + k];
-  if ((e.x & 0xFFFFu) == 0xFFFFu) return;  // wave-uniform
-  const int x = (int)(e.x & 0xFFFFu), y = (int)(e.x >> 16);  // level coordinates
-  const uint8_t* I = pyr + (size_t)img * img_pitch + e.z;
-  const int stride = (int)e.w;
+  const bool in_range = k < n_features;
+  const uint4 e = in_range ? kpl[(size_t)img * n_features + k] : make_uint4(0xFFFFu, 0u, 0u, 0u);
+  const bool valid = (e.x & 0xFFFFu) != 0xFFFFu;
+  const int x = valid ? (int)(e.x & 0xFFFFu) : 16, y = valid ? (int)(e.x >> 16) : 16;  // level coordinates (a safe spot if unused)
+  const uint8_t* I = pyr + (size_t)img * img_pitch + (valid ? e.z : 0u);
+  const int stride = valid ? (int)e.w : 64;
   const int xa = (x - 15) & ~3;  // first aligned word of a row of the window
-  uint32_t wv[5];
+  constexpr int NIT = (31 * 9 + 15) / 16;
+  uint32_t wv[NIT];
 #pragma unroll
-  for (int it = 0; it < 5; ++it) {        // 31 rows x 9 words = 279 words; indices past the end re-read the last word
-    const int idx = min(it * 64 + lane, 31 * 9 - 1);
-    const int r = (idx * 7282) >> 16;      // idx / 9 for idx < 320
+  for (int it = 0; it < NIT; ++it) {  // indices past the end re-read the last word
+    const int idx = min(it * 16 + sub, 31 * 9 - 1);
+    const int r = (idx * 7282) >> 16;  // idx / 9 for idx < 320
     const int c = idx - r * 9;
     wv[it] = *(const uint32_t*)(I + (size_t)(y + r - 15) * stride + xa + 4 * c);
   }
   int m10 = 0, m01 = 0;
 #pragma unroll
-  for (int it = 0; it < 5; ++it) {
-    const int idx = it * 64 + lane;
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = it * 16 + sub;
     const int r = (idx * 7282) >> 16;
     const int c = idx - r * 9;
     if (r < 31) {
@@ -126,9 +128,13 @@ __global__ __launch_bounds__(256) void k_ic_moments(const uint8_t* __restrict__ 
       }
     }
   }
-  m10 = wave_sum_i(m10);
-  m01 = wave_sum_i(m01);
-  if (lane == 0) moments[(size_t)img * n_features + k] = make_int2(m10, m01);
+  // sum over the 16 lanes of the row: lane 15 of each row ends up with the total
+#pragma unroll
+  for (int sh = 0; sh < 4; ++sh) {
+    m10 += (sh == 0) ? dpp_i32<0x111, 0xf>(m10) : (sh == 1) ? dpp_i32<0x112, 0xf>(m10) : (sh == 2) ? dpp_i32<0x114, 0xf>(m10) : dpp_i32<0x118, 0xf>(m10);
+    m01 += (sh == 0) ? dpp_i32<0x111, 0xf>(m01) : (sh == 1) ? dpp_i32<0x112, 0xf>(m01) : (sh == 2) ? dpp_i32<0x114, 0xf>(m01) : dpp_i32<0x118, 0xf>(m01);
+  }
+  if (sub == 15 && valid) moments[(size_t)img * n_features + k] = make_int2(m10, m01);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -271,7 +277,7 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
   for (int i = 0; i < 16; ++i) u |= (unsigned long long)(umax[i] & 15) << (4 * i);
   hipLaunchKernelGGL(k_kplist, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, n_levels, d_sel, d_sel_count, n_features,
                      d_kpl, d_n_kp);
-  hipLaunchKernelGGL(k_ic_moments, dim3((n_features + 3) / 4, n_img), dim3(256), 0, s, d_pyr, img_pitch, d_kpl, n_features, u,
+  hipLaunchKernelGGL(k_ic_moments, dim3((n_features + 15) / 16, n_img), dim3(256), 0, s, d_pyr, img_pitch, d_kpl, n_features, u,
                      d_moments);
   hipLaunchKernelGGL(k_orient, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, d_kpl, n_features, d_moments, d_sincos,
                      d_kps, d_aux, d_kx, d_env, n_chunks, d_theta, rows0);

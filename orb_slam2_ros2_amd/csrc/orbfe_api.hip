@@ -499,7 +499,9 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   // Only the descriptors read the blurred planes, so the blur need not sit between resize and FAST: it is issued on a second
   // stream once FAST is done and runs UNDER the quadtree, which keeps 8 waves per CU busy with dependent LDS steps and leaves
   // the SIMDs idle (the blur uses no LDS, the quadtree all of it).  With stage timing on, or when several chunks share the
-  // context, the blur stays in line.
+  // context, the blur stays in line.  (Measured and dropped: starting each level's quadtree under FAST of the smaller levels on
+  // a third stream -- the tree waves then share their SIMDs with a VALU-saturating kernel and the dependent chain stretches:
+  // 3.04 -> 4.6 ms per 128 pairs.)
   const bool overlap_blur = c->blur_stream && !c->prof && lds_share == 1;
   if (!overlap_blur) {
     StageTimer t(c, ORBFE_STAGE_BLUR, st);
