@@ -61,9 +61,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=128, help="stereo pairs per step (per GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--streams", type=int, default=1,
-                    help="side streams the library may split a batch over (library default 2, +4 %% throughput at 128 pairs). "
-                         "The bench default is 1 so that every kernel runs alone: its HIP-event duration, the rocprofv3 "
-                         "kernel-trace average and the PMC traffic then describe the same launches")
+                    help="half-batch streams the library may split a batch over (1 = none, the library default and the fastest "
+                         "setting measured; the blur-under-quadtree overlap inside a batch is independent of this)")
     args = ap.parse_args()
 
     import torch

@@ -221,30 +221,32 @@ __global__ __launch_bounds__(256) void k_blur(const LevelDev* __restrict__ lv, i
 
 // ---------------------------------------------------------------------------------------------
 // level 0 <- caller's device images (ORBExtractor.cc:304 image.copyTo(mvPyramids[0])): slot
-// slot0 + i*slot_step takes image i.  4 pixels per thread, one aligned 32-bit store.
+// slot0 + i*slot_step takes image i.  16 pixels per thread: one (unaligned) 16-byte load from the caller's rows, one aligned
+// 16-byte store into the padded plane (4 bytes per thread ran at 2 TB/s).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_load_level0(const uint8_t* __restrict__ src, size_t src_stride, size_t src_pitch,
                                                      uint8_t* __restrict__ pyr, size_t img_pitch, uint32_t plane_off, int dst_stride,
                                                      int w, int h, int slot0, int slot_step) {
   const int i = blockIdx.z;
-  const int y = blockIdx.y;
-  const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (x4 >= w || y >= h) return;
-  const uint8_t* s = src + (size_t)i * src_pitch + (size_t)y * src_stride + x4;
-  uint8_t* d = pyr + (size_t)(slot0 + i * slot_step) * img_pitch + plane_off + (size_t)y * dst_stride + x4;
-  if (x4 + 3 < w) {
-    const uint32_t v = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
-    *(uint32_t*)d = v;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  const int x16 = (blockIdx.x * 64 + threadIdx.x) * 16;
+  if (x16 >= w || y >= h) return;
+  const uint8_t* s = src + (size_t)i * src_pitch + (size_t)y * src_stride + x16;
+  uint8_t* d = pyr + (size_t)(slot0 + i * slot_step) * img_pitch + plane_off + (size_t)y * dst_stride + x16;
+  if (x16 + 15 < w) {
+    uint4 v;
+    __builtin_memcpy(&v, s, 16);
+    *(uint4*)d = v;
   } else {
-    for (int k = 0; x4 + k < w; ++k) d[k] = s[k];
+    for (int k = 0; x16 + k < w; ++k) d[k] = s[k];
   }
 }
 
 void launch_load_level0(hipStream_t st, const uint8_t* d_src, size_t src_stride, size_t src_pitch, uint8_t* d_pyr, size_t img_pitch,
                         uint32_t plane_off, int dst_stride, int w, int h, int slot0, int slot_step, int n_img) {
   if (n_img <= 0) return;
-  hipLaunchKernelGGL(k_load_level0, dim3((w + 1023) / 1024, h, n_img), dim3(256), 0, st, d_src, src_stride, src_pitch, d_pyr,
-                     img_pitch, plane_off, dst_stride, w, h, slot0, slot_step);
+  hipLaunchKernelGGL(k_load_level0, dim3((w + 1023) / 1024, (h + 3) / 4, n_img), dim3(64, 4), 0, st, d_src, src_stride, src_pitch,
+                     d_pyr, img_pitch, plane_off, dst_stride, w, h, slot0, slot_step);
 }
 
 // ---------------------------------------------------------------------------------------------
