@@ -139,6 +139,8 @@ def main():
         ctx.sync()
     for _ in range(args.warmup):
         step()
+    ctx.sync()
+    gather_results()  # warm-up of the exchange too: the first torch indexing / RCCL call initialises lazily (tens of ms)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -197,14 +197,17 @@ __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv,
 #define BRIEF_ROWS (2 * BRIEF_R + 1)
 #define BRIEF_WORDS 11  // (3 + 37 + 3) / 4 rounded up
 
-__global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blur, size_t img_pitch,
+#ifndef BRIEF_WAVES
+#define BRIEF_WAVES 4
+#endif
+__global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __restrict__ blur, size_t img_pitch,
                                               const uint4* __restrict__ kpl, int n_features, const int8_t* __restrict__ pattern,
                                               const double2* __restrict__ sincos, uint8_t* __restrict__ desc) {
 #pragma clang fp contract(off)
-  __shared__ uint32_t win_all[4][BRIEF_ROWS * BRIEF_WORDS + 1];  // one window per wave; the waves never synchronise
+  __shared__ uint32_t win_all[BRIEF_WAVES][BRIEF_ROWS * BRIEF_WORDS + 1];  // one window per wave; the waves never synchronise
   const int lane = threadIdx.x & 63;
   uint32_t* win = win_all[threadIdx.x >> 6];
-  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int k = blockIdx.x * BRIEF_WAVES + (threadIdx.x >> 6);
   const int img = blockIdx.y;
   if (k >= n_features) return;
   // two dependent memory round trips per wave: the list entry, then the whole window + sin/cos + the lane's four template
@@ -282,7 +285,7 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
   hipLaunchKernelGGL(k_orient, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, d_kpl, n_features, d_moments, d_sincos,
                      d_kps, d_aux, d_kx, d_env, n_chunks, d_theta, rows0);
   if (before_brief) (void)hipStreamWaitEvent(s, before_brief, 0);  // the blurred planes come from another stream
-  hipLaunchKernelGGL(k_brief, dim3((n_features + 3) / 4, n_img), dim3(256), 0, s, d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos,
+  hipLaunchKernelGGL(k_brief, dim3((n_features + BRIEF_WAVES - 1) / BRIEF_WAVES, n_img), dim3(64 * BRIEF_WAVES), 0, s, d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos,
                      d_desc);
 }
 
