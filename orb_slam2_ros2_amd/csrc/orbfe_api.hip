@@ -502,7 +502,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   // context, the blur stays in line.  (Measured and dropped: starting each level's quadtree under FAST of the smaller levels on
   // a third stream -- the tree waves then share their SIMDs with a VALU-saturating kernel and the dependent chain stretches:
   // 3.04 -> 4.6 ms per 128 pairs.)
-  const bool overlap_blur = c->blur_stream && !c->prof && lds_share == 1;
+  const bool overlap_blur = c->blur_stream && !c->prof && lds_share == 1 && n_img >= 32;  // a frame or two: nothing to hide, only event latency to add
   if (!overlap_blur) {
     StageTimer t(c, ORBFE_STAGE_BLUR, st);
     launch_blur(st, c->d_lv, nl, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
