@@ -93,15 +93,175 @@ __device__ __forceinline__ int strip_of(uint32_t rec, const LevelDev& L) {
   return s;
 }
 
+// ---- pre-partition of the top three tree levels -------------------------------------------------------------------
+// The first pops of a level split nodes of hundreds to thousands of records, one wave moving 64 records per step: measured,
+// these partitions are half (records in LDS) to three quarters (records in global memory) of a tree's time.  But WHICH
+// child a record falls into does not depend on the pop order, only on the midpoints, which are fixed by the strip bounds.
+// So the records are scattered ONCE, in parallel, into the layout three levels of splitting would produce:
+//   node segment = [child 0 | child 1 | child 2 | child 3 | records on its split lines]   (recursively, three levels deep)
+// and popping a strip, a child or a grandchild only reads four precomputed totals.  A node that is never popped keeps its
+// whole segment, split-line records included, exactly like the reference's un-split node.  The order of the records
+// inside a segment is irrelevant (the per-node winner is the maximum response with ties broken by a key recomputed from
+// the coordinates).  Group index inside a strip (layout order): leaf (q1,q2,q3) = 21 q1 + 5 q2 + q3, lines of (q1,q2) =
+// 21 q1 + 5 q2 + 4, lines of (q1) = 21 q1 + 20, lines of the strip = 84.  Internal node index: (q1,q2) = 4 q1 + q2,
+// (q1) = 16 + q1, strip = 20.  Totals index: (q1) = q1, (q1,q2) = 4 + 4 q1 + q2, (q1,q2,q3) = 20 + 16 q1 + 4 q2 + q3.
+#define QT_PP_GROUPS 85
+#define QT_PP_INTERNAL 21
+#define QT_PP_TOTALS 84
+#define QT_PP_MAX_STRIPS 4
+#define QT_BEG_MASK 0xFFFFFFu  // n_beg = segment begin | pre-partition code << 24 (0: a node split the ordinary way)
+
+__device__ __forceinline__ void descend(double& rb, double& re, double& cb, double& ce, int q) {
+  const double midy = (rb + re) / 2, midx = (cb + ce) / 2;
+  if (q & 2) rb = midy; else re = midy;
+  if (q & 1) cb = midx; else ce = midx;
+}
+__device__ __forceinline__ SplitInt load_split(const int* t) {
+  SplitInt s;
+  s.x_lt = t[0], s.x_gt = t[1], s.y_lt = t[2], s.y_gt = t[3];
+  return s;
+}
+// group of a record (global index strip * 85 + local) or -1 if it lies in no strip
+__device__ __forceinline__ int pp_group(uint32_t rec, const LevelDev& L, const int* sp_tab) {
+  const int s = strip_of(rec, L);
+  if (s < 0) return -1;
+  const int* t = sp_tab + s * (QT_PP_INTERNAL * 4);
+  const int base = s * QT_PP_GROUPS;
+  const int q1 = quadrant_of(rec, load_split(t + 20 * 4));
+  if (q1 < 0) return base + 84;
+  const int q2 = quadrant_of(rec, load_split(t + (16 + q1) * 4));
+  if (q2 < 0) return base + q1 * 21 + 20;
+  const int q3 = quadrant_of(rec, load_split(t + (q1 * 4 + q2) * 4));
+  return base + q1 * 21 + q2 * 5 + (q3 < 0 ? 4 : q3);
+}
+
 // Everything after the strip counts: scatter into the strip segments, best-first expansion, selection, ordering.
 // IN_LDS selects the address space of the record home H at compile time (ds_* instead of flat_* accesses: a flat access
 // costs several hundred cycles even when it lands in LDS, and a pop is a chain of dependent accesses).
 template <bool IN_LDS>
 __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __restrict__ A, int N, uint32_t* H, uint32_t* __restrict__ T,
                                           double* n_rb, double* n_re, double* n_cb, double* n_ce, unsigned long long* n_key,
-                                          uint32_t* n_beg, unsigned long long* sortbuf, int run, int n_act, uint32_t next_seq, int need,
+                                          uint32_t* n_beg, unsigned long long* sortbuf, int node_cap, int need,
                                           int sort_cap, uint32_t* __restrict__ out_sel, int32_t* __restrict__ sel_count_out, int lane) {
-  {
+  int n_act = 0;
+  uint32_t next_seq = 0;
+  // ---- first pop: the root, whose children are the initSplit strips (ORBExtractor.cc:81-96, 147-170) ----
+  const int ns = L.n_ini;
+  const int n_tot = (ns * QT_PP_TOTALS + 3) & ~3;
+  uint16_t* tot = (uint16_t*)(n_rb + node_cap) - n_tot;      // the totals live in the tail of the (still empty) node table ...
+  const int pp_limit = node_cap - (n_tot * 2 + 7) / 8;       // ... and are abandoned when the table grows into them
+  bool pp_ok = N <= 65535 && ns <= QT_PP_MAX_STRIPS && node_cap >= 176;
+  if (pp_ok) {
+    const int ng = ns * QT_PP_GROUPS;
+    int* sp_tab = (int*)n_re;         // split thresholds of the 21 internal nodes of every strip   (scratch: the node table
+    uint32_t* cur = (uint32_t*)n_cb;  // group sizes, then group cursors                              is not in use yet)
+    for (int g = lane; g < ng; g += 64) cur[g] = 0;
+    for (int t = lane; t < ns * QT_PP_INTERNAL; t += 64) {
+      const int st = t / QT_PP_INTERNAL, k = t - QT_PP_INTERNAL * st;
+      double rb = 0.0, re = (double)L.reg_h, cb = L.strips[st], ce = L.strips[st + 1];
+      if (k != 20) {
+        descend(rb, re, cb, ce, k >= 16 ? k - 16 : (k >> 2));
+        if (k < 16) descend(rb, re, cb, ce, k & 3);
+      }
+      const SplitInt sp = make_split((cb + ce) / 2, (rb + re) / 2);
+      sp_tab[4 * t + 0] = sp.x_lt;
+      sp_tab[4 * t + 1] = sp.x_gt;
+      sp_tab[4 * t + 2] = sp.y_lt;
+      sp_tab[4 * t + 3] = sp.y_gt;
+    }
+    __syncthreads();
+    // pass 1: group sizes
+    for (int b0 = 0; b0 < N; b0 += 256) {
+      uint32_t rec[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = b0 + u * 64 + lane;
+        rec[u] = (i < N) ? A[i] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = b0 + u * 64 + lane;
+        const int g = (i < N) ? pp_group(rec[u], L, sp_tab) : -1;
+        if (g >= 0) atomicAdd(&cur[g], 1u);  // LDS atomic; lanes of one group serialise, a chunk spans a handful of groups
+      }
+    }
+    __syncthreads();
+    // totals of the 84 nodes below every strip, then sizes -> cursors (exclusive prefix in layout order)
+    for (int t = lane; t < ns * QT_PP_TOTALS; t += 64) {
+      const int st = t / QT_PP_TOTALS, k = t - QT_PP_TOTALS * st;
+      const uint32_t* c = cur + st * QT_PP_GROUPS;
+      uint32_t v = 0;
+      if (k < 4) {
+        for (int i = 0; i < 21; ++i) v += c[k * 21 + i];
+      } else if (k < 20) {
+        const int q1 = (k - 4) >> 2, q2 = (k - 4) & 3;
+        for (int i = 0; i < 5; ++i) v += c[q1 * 21 + q2 * 5 + i];
+      } else {
+        const int m = k - 20;
+        v = c[(m >> 4) * 21 + ((m >> 2) & 3) * 5 + (m & 3)];
+      }
+      tot[t] = (uint16_t)v;
+    }
+    __syncthreads();
+    int carry = 0, strip_base = 0, strip_cnt = 0;  // lane st keeps the segment of strip st
+    for (int g0 = 0; g0 < ng; g0 += 64) {
+      const int g = g0 + lane;
+      const int v = (g < ng) ? (int)cur[g] : 0;
+      const int incl = wave_incl_scan(v, lane);
+      const int excl = carry + incl - v;
+      __syncthreads();
+      if (g < ng) cur[g] = (uint32_t)excl;
+      for (int st = 0; st < ns; ++st) {  // strip st starts at group 85 st and ends where strip st + 1 starts
+        const int first = st * QT_PP_GROUPS, last = first + QT_PP_GROUPS - 1;
+        if (first >= g0 && first < g0 + 64) {
+          const int b = __builtin_amdgcn_readlane(excl, first - g0);
+          if (lane == st) strip_base = b;
+        }
+        if (last >= g0 && last < g0 + 64) {
+          const int e = __builtin_amdgcn_readlane(excl + v, last - g0);
+          if (lane == st) strip_cnt = e;
+        }
+      }
+      carry += __builtin_amdgcn_readlane(incl, 63);
+    }
+    strip_cnt -= strip_base;
+    __syncthreads();
+    // pass 2: scatter
+    for (int b0 = 0; b0 < N; b0 += 256) {
+      uint32_t rec[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = b0 + u * 64 + lane;
+        rec[u] = (i < N) ? A[i] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = b0 + u * 64 + lane;
+        const int g = (i < N) ? pp_group(rec[u], L, sp_tab) : -1;
+        if (g >= 0) H[atomicAdd(&cur[g], 1u)] = rec[u];  // the order inside a group is irrelevant (see above)
+      }
+    }
+    __syncthreads();
+    for (int st = 0; st < ns; ++st) {
+      const int c = __builtin_amdgcn_readlane(strip_cnt, st);
+      const int off = __builtin_amdgcn_readlane(strip_base, st);
+      if (c > 0) {
+        if (lane == 0) {
+          n_rb[n_act] = 0.0;
+          n_re[n_act] = (double)L.reg_h;
+          n_cb[n_act] = L.strips[st];
+          n_ce[n_act] = L.strips[st + 1];
+          n_key[n_act] = ((unsigned long long)c << 32) | (unsigned long long)(0xFFFFFFFFu - next_seq);
+          n_beg[n_act] = (uint32_t)off | ((uint32_t)(1 + st * QT_PP_INTERNAL + 20) << 24);
+        }
+        ++n_act;
+        ++next_seq;
+      }
+    }
+  } else {
+    // Pass 1 counts the records of each strip (lane s keeps strip s's counter), pass 2 scatters them into the
+    // strip segments of H.  Four records per lane are in flight per step to hide the global-load latency.
+    int my_cnt = 0;
     for (int b0 = 0; b0 < N; b0 += 256) {
       uint32_t rec[4];
       int sid[4];
@@ -115,16 +275,54 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         const int i = b0 + u * 64 + lane;
         sid[u] = (i < N) ? strip_of(rec[u], L) : -1;
       }
-      for (int s = 0; s < L.n_ini; ++s) {
-        int base = __builtin_amdgcn_readlane(run, s);
+      for (int st = 0; st < L.n_ini; ++st) {
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c += __popcll(__ballot(sid[u] == st));
+        if (lane == st) my_cnt += c;
+      }
+    }
+    const int incl = wave_incl_scan(my_cnt, lane);  // lanes >= n_ini hold 0
+    int run = incl - my_cnt;                         // lane s: write cursor of strip s
+    for (int st = 0; st < L.n_ini; ++st) {
+      const int c = __builtin_amdgcn_readlane(my_cnt, st);
+      const int off = __builtin_amdgcn_readlane(run, st);
+      if (c > 0) {
+        if (lane == 0) {
+          n_rb[n_act] = 0.0;
+          n_re[n_act] = (double)L.reg_h;
+          n_cb[n_act] = L.strips[st];
+          n_ce[n_act] = L.strips[st + 1];
+          n_key[n_act] = ((unsigned long long)c << 32) | (unsigned long long)(0xFFFFFFFFu - next_seq);
+          n_beg[n_act] = (uint32_t)off;
+        }
+        ++n_act;
+        ++next_seq;
+      }
+    }
+    for (int b0 = 0; b0 < N; b0 += 256) {
+      uint32_t rec[4];
+      int sid[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = b0 + u * 64 + lane;
+        rec[u] = (i < N) ? A[i] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = b0 + u * 64 + lane;
+        sid[u] = (i < N) ? strip_of(rec[u], L) : -1;
+      }
+      for (int st = 0; st < L.n_ini; ++st) {
+        int base = __builtin_amdgcn_readlane(run, st);
         int c = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const unsigned long long m = __ballot(sid[u] == s);
-          if (sid[u] == s) H[base + c + __popcll(m & ((1ull << lane) - 1ull))] = rec[u];
+          const unsigned long long m = __ballot(sid[u] == st);
+          if (sid[u] == st) H[base + c + __popcll(m & ((1ull << lane) - 1ull))] = rec[u];
           c += __popcll(m);
         }
-        if (lane == s) run += c;
+        if (lane == st) run += c;
       }
     }
   }
@@ -159,7 +357,8 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     const int j = __builtin_amdgcn_readlane(bj, __ffsll((long long)win) - 1);
     const double rb = n_rb[j], re = n_re[j], cb = n_cb[j], ce = n_ce[j];
     const int n = (int)mc;
-    const int beg = (int)n_beg[j];
+    const uint32_t beg_raw = n_beg[j];
+    const int beg = (int)(beg_raw & QT_BEG_MASK), code = (int)(beg_raw >> 24);
     // erase from the active table: the last entry moves into slot j (uniform addresses, every lane does the same copy)
     --n_act;
     {
@@ -177,7 +376,23 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     const SplitInt sp = make_split(midx, midy);
     uint32_t* seg = H + beg;
     int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    if (n <= 64) {
+    int child_code = 0;  // pre-partition code of child 0 (children q get child_code + q), 0: none
+    if (pp_ok && code != 0) {
+      // a strip, a child or a grandchild whose records were laid out by the pre-partition: nothing moves
+      const int st = (code - 1) / QT_PP_INTERNAL, k = (code - 1) - QT_PP_INTERNAL * st;
+      const uint16_t* t = tot + st * QT_PP_TOTALS;
+      int ti;
+      if (k == 20) {
+        ti = 0;
+        child_code = 1 + st * QT_PP_INTERNAL + 16;
+      } else if (k >= 16) {
+        ti = 4 + (k - 16) * 4;
+        child_code = 1 + st * QT_PP_INTERNAL + (k - 16) * 4;
+      } else {
+        ti = 20 + k * 4;
+      }
+      c0 = t[ti], c1 = t[ti + 1], c2 = t[ti + 2], c3 = t[ti + 3];
+    } else if (n <= 64) {
       // the common case: one record per lane, in-place 4-way partition
       const uint32_t rec = (lane < n) ? seg[lane] : 0u;
       const int q = (lane < n) ? quadrant_of(rec, sp) : -1;
@@ -259,6 +474,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       const int offc = beg + (lane == 0 ? 0 : (lane == 1 ? c0 : (lane == 2 ? c0 + c1 : c0 + c1 + c2)));
       const int ne0 = c0 > 0, ne1 = c1 > 0, ne2 = c2 > 0, ne3 = c3 > 0;
       const int rank = lane == 0 ? 0 : (lane == 1 ? ne0 : (lane == 2 ? ne0 + ne1 : ne0 + ne1 + ne2));
+      if (n_act + 4 > pp_limit) pp_ok = false;  // the table reaches the totals parked in its tail: split the ordinary way from now on
       if (lane < 4 && cc > 0) {
         const int slot = n_act + rank;
         n_rb[slot] = (lane & 2) ? midy : rb;
@@ -266,7 +482,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         n_cb[slot] = (lane & 1) ? midx : cb;
         n_ce[slot] = (lane & 1) ? ce : midx;
         n_key[slot] = ((unsigned long long)cc << 32) | (unsigned long long)(0xFFFFFFFFu - (next_seq + (uint32_t)rank));
-        n_beg[slot] = (uint32_t)offc;
+        n_beg[slot] = (uint32_t)offc | ((uint32_t)(child_code ? child_code + lane : 0) << 24);
       }
       const int added = ne0 + ne1 + ne2 + ne3;
       n_act += added;
@@ -312,7 +528,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
   for (int j = lane; j < sort_cap; j += 64) {
     unsigned long long key = ~0ull;
     if (j < n_act) {
-      const uint32_t* p = H + n_beg[j];
+      const uint32_t* p = H + (n_beg[j] & QT_BEG_MASK);
       const int n = (int)(n_key[j] >> 32);
       uint32_t best = p[0];
       unsigned long long bk = order_key(best, L);
@@ -384,11 +600,7 @@ __global__ __launch_bounds__(64) void k_quadtree(const LevelDev* __restrict__ lv
   const bool in_lds = N <= rec_cap;
   uint32_t* gb = scratch_b + (size_t)img * scratch_pitch + L.cand_base;
   uint32_t* gc = scratch_c + (size_t)img * scratch_pitch + L.cand_base;
-  uint32_t* H = in_lds ? lds_recs : gb;  // home of the records
-  uint32_t* T = in_lds ? gb : gc;        // bounce buffer for the few nodes too big to split in registers
 
-  int n_act = 0;
-  int strip_run = 0;
   if (need <= 1) {
     // while (mnNodes < mnNeedNodes ...) never runs: the map holds only the root (ORBExtractor.cc:151)
     if (need == 1 && N > 0) {
@@ -421,57 +633,11 @@ __global__ __launch_bounds__(64) void k_quadtree(const LevelDev* __restrict__ lv
     return;
   }
 
-  // ---- first pop: the root, whose children are the initSplit strips (ORBExtractor.cc:81-96, 147-170) ----
-  // Pass 1 counts the records of each strip (lane s keeps strip s's counter), pass 2 scatters them into the
-  // strip segments of H.  Four records per lane are in flight per step to hide the global-load latency.
-  uint32_t next_seq = 0;
-  {
-    int my_cnt = 0;
-    for (int b0 = 0; b0 < N; b0 += 256) {
-      uint32_t rec[4];
-      int sid[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = b0 + u * 64 + lane;
-        rec[u] = (i < N) ? A[i] : 0u;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = b0 + u * 64 + lane;
-        sid[u] = (i < N) ? strip_of(rec[u], L) : -1;
-      }
-      for (int s = 0; s < L.n_ini; ++s) {
-        int c = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) c += __popcll(__ballot(sid[u] == s));
-        if (lane == s) my_cnt += c;
-      }
-    }
-    const int incl = wave_incl_scan(my_cnt, lane);  // lanes >= n_ini hold 0
-    const int run = incl - my_cnt;                   // lane s: write cursor of strip s
-    for (int s = 0; s < L.n_ini; ++s) {
-      const int c = __builtin_amdgcn_readlane(my_cnt, s);
-      const int off = __builtin_amdgcn_readlane(run, s);
-      if (c > 0) {
-        if (lane == 0) {
-          n_rb[n_act] = 0.0;
-          n_re[n_act] = (double)L.reg_h;
-          n_cb[n_act] = L.strips[s];
-          n_ce[n_act] = L.strips[s + 1];
-          n_key[n_act] = ((unsigned long long)c << 32) | (unsigned long long)(0xFFFFFFFFu - next_seq);
-          n_beg[n_act] = (uint32_t)off;
-        }
-        ++n_act;
-        ++next_seq;
-      }
-    }
-    strip_run = run;
-  }
   if (in_lds)
-    tree_body<true>(L, A, N, lds_recs, gb, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, strip_run, n_act, next_seq, need, sort_cap, out_sel,
+    tree_body<true>(L, A, N, lds_recs, gb, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, node_cap, need, sort_cap, out_sel,
                     sel_count + (size_t)img * n_levels + level, lane);
   else
-    tree_body<false>(L, A, N, gb, gc, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, strip_run, n_act, next_seq, need, sort_cap, out_sel,
+    tree_body<false>(L, A, N, gb, gc, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, node_cap, need, sort_cap, out_sel,
                      sel_count + (size_t)img * n_levels + level, lane);
 }
 
