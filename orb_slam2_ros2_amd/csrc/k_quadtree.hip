@@ -359,19 +359,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     const int n = (int)mc;
     const uint32_t beg_raw = n_beg[j];
     const int beg = (int)(beg_raw & QT_BEG_MASK), code = (int)(beg_raw >> 24);
-    // erase from the active table: the last entry moves into slot j (uniform addresses, every lane does the same copy)
-    --n_act;
-    {
-      const double t0 = n_rb[n_act], t1 = n_re[n_act], t2 = n_cb[n_act], t3 = n_ce[n_act];
-      const unsigned long long t4 = n_key[n_act];
-      const uint32_t t5 = n_beg[n_act];
-      n_rb[j] = t0;
-      n_re[j] = t1;
-      n_cb[j] = t2;
-      n_ce[j] = t3;
-      n_key[j] = t4;
-      n_beg[j] = t5;
-    }
+    // (the popped node's slot is reused by its first child below: no erase-and-compact round trip through the table)
     const double midy = (rb + re) / 2, midx = (cb + ce) / 2;
     const SplitInt sp = make_split(midx, midy);
     uint32_t* seg = H + beg;
@@ -474,9 +462,9 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       const int offc = beg + (lane == 0 ? 0 : (lane == 1 ? c0 : (lane == 2 ? c0 + c1 : c0 + c1 + c2)));
       const int ne0 = c0 > 0, ne1 = c1 > 0, ne2 = c2 > 0, ne3 = c3 > 0;
       const int rank = lane == 0 ? 0 : (lane == 1 ? ne0 : (lane == 2 ? ne0 + ne1 : ne0 + ne1 + ne2));
-      if (n_act + 4 > pp_limit) pp_ok = false;  // the table reaches the totals parked in its tail: split the ordinary way from now on
+      if (n_act + 3 > pp_limit) pp_ok = false;  // the table reaches the totals parked in its tail: split the ordinary way from now on
       if (lane < 4 && cc > 0) {
-        const int slot = n_act + rank;
+        const int slot = rank == 0 ? j : n_act + rank - 1;  // first child into the popped node's slot, the others appended
         n_rb[slot] = (lane & 2) ? midy : rb;
         n_re[slot] = (lane & 2) ? re : midy;
         n_cb[slot] = (lane & 1) ? midx : cb;
@@ -485,7 +473,20 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         n_beg[slot] = (uint32_t)offc | ((uint32_t)(child_code ? child_code + lane : 0) << 24);
       }
       const int added = ne0 + ne1 + ne2 + ne3;
-      n_act += added;
+      if (added == 0) {  // every record sat on a split line: the node disappears, the last entry fills its slot
+        --n_act;
+        const double t0 = n_rb[n_act], t1 = n_re[n_act], t2 = n_cb[n_act], t3 = n_ce[n_act];
+        const unsigned long long t4 = n_key[n_act];
+        const uint32_t t5 = n_beg[n_act];
+        n_rb[j] = t0;
+        n_re[j] = t1;
+        n_cb[j] = t2;
+        n_ce[j] = t3;
+        n_key[j] = t4;
+        n_beg[j] = t5;
+      } else {
+        n_act += added - 1;
+      }
       next_seq += (uint32_t)added;
     }
     if (!IN_LDS) __syncthreads();  // LDS traffic of one wave is executed in order; global needs the wait
