@@ -111,28 +111,62 @@ __device__ __forceinline__ int strip_of(uint32_t rec, const LevelDev& L) {
 #define QT_PP_MAX_STRIPS 4
 #define QT_BEG_MASK 0xFFFFFFu  // n_beg = segment begin | pre-partition code << 24 (0: a node split the ordinary way)
 
-__device__ __forceinline__ void descend(double& rb, double& re, double& cb, double& ce, int q) {
-  const double midy = (rb + re) / 2, midx = (cb + ce) / 2;
-  if (q & 2) rb = midy; else re = midy;
-  if (q & 1) cb = midx; else ce = midx;
+// Integer thresholds of the pre-partition.  The x and the y splits of a node are independent, and all strips share the rows
+// (0, reg_h): seven y thresholds (1 + 2 + 4 midpoints) are uniform, seven x thresholds per strip sit in LDS.
+struct Thr {
+  int lt, gt;  // v <= lt: first half, v >= gt: second half, else on the line
+};
+__device__ __forceinline__ Thr make_thr(double mid) {
+  Thr t;
+  t.lt = (int)ceil(mid) - 1;
+  t.gt = (int)floor(mid) + 1;
+  return t;
 }
-__device__ __forceinline__ SplitInt load_split(const int* t) {
-  SplitInt s;
-  s.x_lt = t[0], s.x_gt = t[1], s.y_lt = t[2], s.y_gt = t[3];
-  return s;
+// the seven midpoints of three halvings of (lo, hi): index 0 | 1 + b1 | 3 + 2 b1 + b2   (same fp64 operations as the pop loop)
+__device__ __forceinline__ void thr7(double lo, double hi, Thr* out) {
+  const double m1 = (lo + hi) / 2;
+  out[0] = make_thr(m1);
+#pragma unroll
+  for (int b1 = 0; b1 < 2; ++b1) {
+    const double l1 = b1 ? m1 : lo, h1 = b1 ? hi : m1;
+    const double m2 = (l1 + h1) / 2;
+    out[1 + b1] = make_thr(m2);
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) {
+      const double l2 = b2 ? m2 : l1, h2 = b2 ? h1 : m2;
+      out[3 + 2 * b1 + b2] = make_thr((l2 + h2) / 2);
+    }
+  }
 }
+__device__ __forceinline__ int half_of(int v, const Thr& t) { return v <= t.lt ? 0 : (v >= t.gt ? 1 : -1); }
+
+struct PpGeom {
+  int ns, y_max;
+  int s_lo[QT_PP_MAX_STRIPS], s_hi[QT_PP_MAX_STRIPS];  // integer form of the strict strip membership
+  Thr yt[7];
+};
 // group of a record (global index strip * 85 + local) or -1 if it lies in no strip
-__device__ __forceinline__ int pp_group(uint32_t rec, const LevelDev& L, const int* sp_tab) {
-  const int s = strip_of(rec, L);
-  if (s < 0) return -1;
-  const int* t = sp_tab + s * (QT_PP_INTERNAL * 4);
-  const int base = s * QT_PP_GROUPS;
-  const int q1 = quadrant_of(rec, load_split(t + 20 * 4));
-  if (q1 < 0) return base + 84;
-  const int q2 = quadrant_of(rec, load_split(t + (16 + q1) * 4));
-  if (q2 < 0) return base + q1 * 21 + 20;
-  const int q3 = quadrant_of(rec, load_split(t + (q1 * 4 + q2) * 4));
-  return base + q1 * 21 + q2 * 5 + (q3 < 0 ? 4 : q3);
+__device__ __forceinline__ int pp_group(uint32_t rec, const PpGeom& G, const Thr* xt /*LDS: [ns][7]*/) {
+  const int x = (int)ORBFE_REC_X(rec), y = (int)ORBFE_REC_Y(rec);
+  if (y < 1 || y > G.y_max) return -1;
+  int st = -1;
+#pragma unroll
+  for (int k = 0; k < QT_PP_MAX_STRIPS; ++k)
+    if (k < G.ns && x >= G.s_lo[k] && x <= G.s_hi[k]) st = k;
+  if (st < 0) return -1;
+  const Thr* t = xt + st * 7;
+  const int base = st * QT_PP_GROUPS;
+  const int bx1 = half_of(x, t[0]), by1 = half_of(y, G.yt[0]);
+  if (bx1 < 0 || by1 < 0) return base + 84;
+  const int q1 = by1 * 2 + bx1;  // rows outer, cols inner (ORBExtractor.cc:60-72)
+  const Thr y2 = by1 ? G.yt[2] : G.yt[1];
+  const int bx2 = half_of(x, t[1 + bx1]), by2 = half_of(y, y2);
+  if (bx2 < 0 || by2 < 0) return base + q1 * 21 + 20;
+  const int q2 = by2 * 2 + bx2;
+  const Thr y3a = by2 ? G.yt[4] : G.yt[3], y3b = by2 ? G.yt[6] : G.yt[5];
+  const Thr y3 = by1 ? y3b : y3a;
+  const int bx3 = half_of(x, t[3 + 2 * bx1 + bx2]), by3 = half_of(y, y3);
+  return base + q1 * 21 + q2 * 5 + ((bx3 < 0 || by3 < 0) ? 4 : by3 * 2 + bx3);
 }
 
 // Everything after the strip counts: scatter into the strip segments, best-first expansion, selection, ordering.
@@ -153,35 +187,33 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
   bool pp_ok = N <= 65535 && ns <= QT_PP_MAX_STRIPS && node_cap >= 176;
   if (pp_ok) {
     const int ng = ns * QT_PP_GROUPS;
-    int* sp_tab = (int*)n_re;         // split thresholds of the 21 internal nodes of every strip   (scratch: the node table
+    Thr* xt = (Thr*)n_re;             // x thresholds of every strip                                  (scratch: the node table
     uint32_t* cur = (uint32_t*)n_cb;  // group sizes, then group cursors                              is not in use yet)
     for (int g = lane; g < ng; g += 64) cur[g] = 0;
-    for (int t = lane; t < ns * QT_PP_INTERNAL; t += 64) {
-      const int st = t / QT_PP_INTERNAL, k = t - QT_PP_INTERNAL * st;
-      double rb = 0.0, re = (double)L.reg_h, cb = L.strips[st], ce = L.strips[st + 1];
-      if (k != 20) {
-        descend(rb, re, cb, ce, k >= 16 ? k - 16 : (k >> 2));
-        if (k < 16) descend(rb, re, cb, ce, k & 3);
-      }
-      const SplitInt sp = make_split((cb + ce) / 2, (rb + re) / 2);
-      sp_tab[4 * t + 0] = sp.x_lt;
-      sp_tab[4 * t + 1] = sp.x_gt;
-      sp_tab[4 * t + 2] = sp.y_lt;
-      sp_tab[4 * t + 3] = sp.y_gt;
+    PpGeom G;
+    G.ns = ns;
+    G.y_max = (int)ceil((double)L.reg_h) - 1;  // y > 0 && y < reg_h
+    thr7(0.0, (double)L.reg_h, G.yt);
+#pragma unroll
+    for (int k = 0; k < QT_PP_MAX_STRIPS; ++k) {
+      const double lo = L.strips[k < ns ? k : 0], hi = L.strips[k < ns ? k + 1 : 1];
+      G.s_lo[k] = (int)floor(lo) + 1;  // x > lo
+      G.s_hi[k] = (int)ceil(hi) - 1;   // x < hi
+      if (lane == k && k < ns) thr7(lo, hi, xt + 7 * k);
     }
     __syncthreads();
-    // pass 1: group sizes
-    for (int b0 = 0; b0 < N; b0 += 256) {
-      uint32_t rec[4];
+    // pass 1: group sizes (sixteen records per lane are in flight per trip: a lone wave sees every global round trip)
+    for (int b0 = 0; b0 < N; b0 += 1024) {
+      uint32_t rec[16];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int i = b0 + u * 64 + lane;
         rec[u] = (i < N) ? A[i] : 0u;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int i = b0 + u * 64 + lane;
-        const int g = (i < N) ? pp_group(rec[u], L, sp_tab) : -1;
+        const int g = (i < N) ? pp_group(rec[u], G, xt) : -1;
         if (g >= 0) atomicAdd(&cur[g], 1u);  // LDS atomic; lanes of one group serialise, a chunk spans a handful of groups
       }
     }
@@ -227,17 +259,17 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     strip_cnt -= strip_base;
     __syncthreads();
     // pass 2: scatter
-    for (int b0 = 0; b0 < N; b0 += 256) {
-      uint32_t rec[4];
+    for (int b0 = 0; b0 < N; b0 += 1024) {
+      uint32_t rec[16];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int i = b0 + u * 64 + lane;
         rec[u] = (i < N) ? A[i] : 0u;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int i = b0 + u * 64 + lane;
-        const int g = (i < N) ? pp_group(rec[u], L, sp_tab) : -1;
+        const int g = (i < N) ? pp_group(rec[u], G, xt) : -1;
         if (g >= 0) H[atomicAdd(&cur[g], 1u)] = rec[u];  // the order inside a group is irrelevant (see above)
       }
     }
