@@ -552,55 +552,111 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     __syncthreads();
   }
 
-  // per node: first maximum response (ORBExtractor.cc:103-117); records keep candidate order inside a node.
-  // Sort key = candidate order recomputed from the coordinates: (cell row, cell col, y, x), then the response.
+  // per node: first maximum response (ORBExtractor.cc:103-117).  Sort key = candidate order recomputed from the coordinates:
+  // (cell row, cell col, y, x), then the response.  One lane per node, eight records requested per trip (with the records in
+  // global memory every trip is a round trip the lone wave waits for).
   int sc = 2;
   while (sc < need) sc <<= 1;  // need <= sort_cap by construction (host side)
   sort_cap = min(sort_cap, sc);
-  // (the sort buffer aliases the fp64 bound arrays, which are dead now; keys / begins live behind them)
-  for (int j = lane; j < sort_cap; j += 64) {
-    unsigned long long key = ~0ull;
-    if (j < n_act) {
-      const uint32_t* p = H + (n_beg[j] & QT_BEG_MASK);
-      const int n = (int)(n_key[j] >> 32);
-      uint32_t best = p[0];
-      unsigned long long bk = order_key(best, L);
-      for (int i = 1; i < n; ++i) {
-        const uint32_t rec = p[i];
-        const uint32_t r = ORBFE_REC_R(rec), rb2 = ORBFE_REC_R(best);
-        if (r >= rb2) {  // maximum response; the reference keeps the FIRST maximum in candidate order
-          const unsigned long long k = order_key(rec, L);
-          if (r > rb2 || k < bk) {
-            best = rec;
+  auto node_key = [&](int j) -> unsigned long long {
+    if (j >= n_act) return ~0ull;
+    const uint32_t* p = H + (n_beg[j] & QT_BEG_MASK);
+    const int n = (int)(n_key[j] >> 32);
+    uint32_t best = 0, br = 0;
+    unsigned long long bk = ~0ull;
+    for (int i0 = 0; i0 < n; i0 += 8) {
+      uint32_t rec[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rec[u] = p[min(i0 + u, n - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t r = ORBFE_REC_R(rec[u]);
+        if (i0 + u < n && (bk == ~0ull || r >= br)) {  // maximum response; the reference keeps the FIRST maximum in candidate order
+          const unsigned long long k = order_key(rec[u], L);
+          if (bk == ~0ull || r > br || k < bk) {
+            best = rec[u];
+            br = r;
             bk = k;
           }
         }
       }
-      key = (bk << 8) | (unsigned long long)ORBFE_REC_R(best);
     }
-    sortbuf[j] = key;
-  }
-  __syncthreads();
-  for (int k = 2; k <= sort_cap; k <<= 1) {
-    for (int s = k >> 1; s > 0; s >>= 1) {
-      for (int i = lane; i < sort_cap; i += 64) {
-        const int p = i ^ s;
-        if (p > i) {
-          const unsigned long long a = sortbuf[i], b = sortbuf[p];
-          const bool up = (i & k) == 0;
-          if ((a > b) == up) {
-            sortbuf[i] = b;
-            sortbuf[p] = a;
+    return (bk << 8) | (unsigned long long)ORBFE_REC_R(best);
+  };
+  if (sort_cap <= 512) {
+    // bitonic sort of up to 512 keys IN REGISTERS, key index = r * 64 + lane: strides >= 64 pair two registers of a lane,
+    // smaller strides exchange with lane ^ stride (a first version through LDS with a barrier per stage took 94 k cycles,
+    // a quarter of the pop loop)
+    unsigned long long key[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) key[r] = (r * 64 < sort_cap) ? node_key(r * 64 + lane) : ~0ull;
+    for (int k = 2; k <= sort_cap; k <<= 1) {
+      for (int st = k >> 1; st > 0; st >>= 1) {
+        if (st >= 64) {
+          const int rs = st >> 6;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+#pragma unroll
+            for (int q = 1; q <= 4; q <<= 1) {
+              if (rs == q && (r & q) == 0) {
+                const bool up = ((r * 64) & k) == 0;
+                const unsigned long long a = key[r], b2 = key[r | q];
+                const bool sw = (a > b2) == up;
+                key[r] = sw ? b2 : a;
+                key[r | q] = sw ? a : b2;
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)key[r], st), hi = (uint32_t)__shfl_xor((int)(uint32_t)(key[r] >> 32), st);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            const bool up = (((r * 64) + lane) & k) == 0;
+            const bool take_min = ((lane & st) == 0) == up;
+            const unsigned long long mn = key[r] < other ? key[r] : other, mx = key[r] < other ? other : key[r];
+            key[r] = take_min ? mn : mx;
           }
         }
       }
-      __syncthreads();
     }
-  }
-  for (int j = lane; j < n_act; j += 64) {
-    const unsigned long long key = sortbuf[j];
-    const uint32_t y = (uint32_t)(key >> 20) & 0xFFFu, x = (uint32_t)(key >> 8) & 0xFFFu, r = (uint32_t)key & 0xFFu;  // key = order<<8 | r
-    out_sel[j] = ORBFE_PACK_XYR(x, y, r);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int j = r * 64 + lane;
+      if (j < n_act) {
+        const uint32_t y = (uint32_t)(key[r] >> 20) & 0xFFFu, x = (uint32_t)(key[r] >> 8) & 0xFFFu, rr = (uint32_t)key[r] & 0xFFu;  // key = order<<8 | r
+        out_sel[j] = ORBFE_PACK_XYR(x, y, rr);
+      }
+    }
+  } else {
+    // (the sort buffer aliases the fp64 bound arrays, which are dead now; keys / begins live behind them)
+    for (int j = lane; j < sort_cap; j += 64) {
+      const unsigned long long key = node_key(j);
+      __syncthreads();
+      sortbuf[j] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= sort_cap; k <<= 1) {
+      for (int st = k >> 1; st > 0; st >>= 1) {
+        for (int i = lane; i < sort_cap; i += 64) {
+          const int p = i ^ st;
+          if (p > i) {
+            const unsigned long long a = sortbuf[i], b2 = sortbuf[p];
+            const bool up = (i & k) == 0;
+            if ((a > b2) == up) {
+              sortbuf[i] = b2;
+              sortbuf[p] = a;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int j = lane; j < n_act; j += 64) {
+      const unsigned long long key = sortbuf[j];
+      const uint32_t y = (uint32_t)(key >> 20) & 0xFFFu, x = (uint32_t)(key >> 8) & 0xFFFu, r = (uint32_t)key & 0xFFu;  // key = order<<8 | r
+      out_sel[j] = ORBFE_PACK_XYR(x, y, r);
+    }
   }
   if (lane == 0) *sel_count_out = n_act;
 }
