@@ -195,11 +195,16 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
   }
   WAVE_SYNC();
 
-  // ---- 3. exact test + score for the survivors, two queue entries per lane (each 16-bit half scores one entry) ----
+  // ---- 3. exact test + score for the survivors, two queue entries per lane (each 16-bit half scores one entry).  Only about
+  //         half of the survivors are corners: those (and the dual-tagged entries, whose second polarity is still to come) are
+  //         compacted in place at the front of Q, so that the NMS and the output pass touch no entry that cannot matter.
+  int nc = 0;
   {
     const uint32_t* Q32 = (const uint32_t*)Q;
     const int n_ep = (nq + 1) >> 1;
-    for (int j = lane; j < n_ep; j += 64) {
+    for (int j0 = 0; j0 < n_ep; j0 += 64) {
+      const bool act = j0 + lane < n_ep;
+      const int j = min(j0 + lane, n_ep - 1);
       const uint32_t w = Q32[j];
       const bool has1 = 2 * j + 1 < nq;
       const uint32_t q0 = w & 0xFFFFu, q1 = has1 ? (w >> 16) : q0;
@@ -208,10 +213,18 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
       sgn.x = (q0 & Q_BRIGHT) ? (short)-1 : (short)1;
       sgn.y = (q1 & Q_BRIGHT) ? (short)-1 : (short)1;
       const s2 A = arc_score2<PP>(P + iy0 * PP + xa + ix0, P + iy1 * PP + xa + ix1, sgn);
-      if (A.x > t_min) V[(iy0 + 1) * PV + ix0 + 1] = (uint8_t)min(255, (int)A.x);
-      if (has1 && A.y > t_min) V[(iy1 + 1) * PV + ix1 + 1] = (uint8_t)min(255, (int)A.y);
+      const bool c0 = act && A.x > t_min, c1 = act && has1 && A.y > t_min;
+      if (c0) V[(iy0 + 1) * PV + ix0 + 1] = (uint8_t)min(255, (int)A.x);
+      if (c1) V[(iy1 + 1) * PV + ix1 + 1] = (uint8_t)min(255, (int)A.y);
+      const bool k0 = c0 || (act && (q0 & Q_DUAL)), k1 = c1 || (act && has1 && (q1 & Q_DUAL));
+      const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+      const int pos = nc + mbcnt64(m1, mbcnt64(m0, 0));  // lane order, entry 0 before entry 1: the list order is kept
+      if (k0) Q[pos] = (uint16_t)q0;  // (in place: this trip's entries were all read above, later trips read further back)
+      if (k1) Q[pos + (k0 ? 1 : 0)] = (uint16_t)q1;
+      nc += __popcll(m0) + __popcll(m1);
     }
   }
+  nq = nc;
   if (nd > 0 || d_overflow) {
     WAVE_SYNC();
     const s2 bright = {(short)-1, (short)-1};
