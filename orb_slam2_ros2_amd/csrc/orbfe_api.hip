@@ -105,6 +105,16 @@ struct orbfe_ctx {
   hipStream_t side[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
   // the blur of a batch runs on its own stream under the (latency-bound, LDS-hungry, SIMD-idle) quadtree of the same batch
+  // the host-pointer path for one or two images (the drop-in call shape) is launch-bound: its copy-in / kernels / copy-out
+  // sequence is captured once into a hipGraph per (image count, outputs wanted) and replayed
+  struct GraphEntry {
+    int n_img;
+    bool want_kps, want_desc;
+    const uint8_t* stage;
+    hipGraphExec_t exec;
+  };
+  std::vector<GraphEntry> graphs;
+  bool use_graphs = true;
   hipStream_t blur_stream = nullptr;
   hipEvent_t ev_blur_go = nullptr, ev_blur_done = nullptr;
 
@@ -593,6 +603,8 @@ void orbfe_destroy(orbfe_ctx* c) {
     if (c->side[k]) (void)hipStreamDestroy(c->side[k]);
     if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
   }
+  for (auto& ge : c->graphs) (void)hipGraphExecDestroy(ge.exec);
+  c->graphs.clear();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_blur_go) (void)hipEventDestroy(c->ev_blur_go);
   if (c->ev_blur_done) (void)hipEventDestroy(c->ev_blur_done);
@@ -657,6 +669,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
       fail(c, ORBFE_EDEVICE, "cannot create side streams");
       return bail(ORBFE_EDEVICE);
     }
+    if (const char* gr = getenv("ORBFE_GRAPHS")) c->use_graphs = atoi(gr) != 0;
     const char* ov = getenv("ORBFE_OVERLAP_BLUR");
     if (!ov || atoi(ov) != 0) {
       if (hipStreamCreateWithFlags(&c->blur_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -825,12 +838,17 @@ orbfe_status orbfe_device_results(orbfe_ctx* c, const void** d_kps, const void**
 
 // results of slots 0..n_img-1 to the host through the pinned staging buffer: one batch of D2H copies (full arrays: the counts
 // are not known on the host yet), ONE synchronisation
-static orbfe_status fetch_extract_results(orbfe_ctx* c, int n_img, size_t o_kps, size_t o_desc, size_t o_cnt, orbfe_keypoint* kps,
-                                          uint8_t* desc, int32_t* n_out) {
+static orbfe_status enqueue_fetch(orbfe_ctx* c, int n_img, size_t o_kps, size_t o_desc, size_t o_cnt, bool want_kps, bool want_desc) {
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
   HIP_TRY(c, hipMemcpyAsync(c->h_stage + o_cnt, c->d_n_kp, sizeof(int32_t) * n_img, hipMemcpyDeviceToHost, c->stream));
-  if (kps) HIP_TRY(c, hipMemcpyAsync(c->h_stage + o_kps, c->d_kps, (size_t)n_img * NF * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, c->stream));
-  if (desc) HIP_TRY(c, hipMemcpyAsync(c->h_stage + o_desc, c->d_desc, (size_t)n_img * NF * 32, hipMemcpyDeviceToHost, c->stream));
+  if (want_kps)
+    HIP_TRY(c, hipMemcpyAsync(c->h_stage + o_kps, c->d_kps, (size_t)n_img * NF * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, c->stream));
+  if (want_desc) HIP_TRY(c, hipMemcpyAsync(c->h_stage + o_desc, c->d_desc, (size_t)n_img * NF * 32, hipMemcpyDeviceToHost, c->stream));
+  return ORBFE_OK;
+}
+static orbfe_status finish_fetch(orbfe_ctx* c, int n_img, size_t o_kps, size_t o_desc, size_t o_cnt, orbfe_keypoint* kps, uint8_t* desc,
+                                 int32_t* n_out) {
+  const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_timers(c);
   const int32_t* cnt = (const int32_t*)(c->h_stage + o_cnt);
@@ -842,6 +860,11 @@ static orbfe_status fetch_extract_results(orbfe_ctx* c, int n_img, size_t o_kps,
     if (n_out) n_out[i] = n;
   }
   return ORBFE_OK;
+}
+static orbfe_status fetch_extract_results(orbfe_ctx* c, int n_img, size_t o_kps, size_t o_desc, size_t o_cnt, orbfe_keypoint* kps,
+                                          uint8_t* desc, int32_t* n_out) {
+  TRY(enqueue_fetch(c, n_img, o_kps, o_desc, o_cnt, kps != nullptr, desc != nullptr));
+  return finish_fetch(c, n_img, o_kps, o_desc, o_cnt, kps, desc, n_out);
 }
 
 orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* const* imgs, size_t stride, orbfe_keypoint* kps,
@@ -861,11 +884,47 @@ orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* con
     if (!imgs[i]) return fail(c, ORBFE_EBADARG, "extract_batch: image %d is NULL", i);
     uint8_t* dst = c->h_stage + (size_t)i * plane;
     for (int y = 0; y < L0.h; ++y) std::memcpy(dst + (size_t)y * L0.stride, imgs[i] + (size_t)y * stride, (size_t)c->cfg.width);
-    HIP_TRY(c, hipMemcpyAsync(c->d_pyr + (size_t)i * c->img_pitch + L0.plane_off, dst, (size_t)L0.stride * L0.h, hipMemcpyHostToDevice,
-                              c->stream));
   }
-  TRY(run_extract(c, c->stream, 0, n_img));
-  return fetch_extract_results(c, n_img, o_kps, o_desc, o_cnt, kps, desc, n_out);
+  auto enqueue_all = [&]() -> orbfe_status {
+    for (int i = 0; i < n_img; ++i)
+      HIP_TRY(c, hipMemcpyAsync(c->d_pyr + (size_t)i * c->img_pitch + L0.plane_off, c->h_stage + (size_t)i * plane, (size_t)L0.stride * L0.h,
+                                hipMemcpyHostToDevice, c->stream));
+    TRY(run_extract(c, c->stream, 0, n_img));
+    return enqueue_fetch(c, n_img, o_kps, o_desc, o_cnt, kps != nullptr, desc != nullptr);
+  };
+  if (c->use_graphs && !c->prof && n_img <= 2) {
+    hipGraphExec_t exec = nullptr;
+    for (auto it = c->graphs.begin(); it != c->graphs.end();) {
+      if (it->stage != c->h_stage) {  // the staging buffer was re-allocated: the captured addresses are stale
+        (void)hipGraphExecDestroy(it->exec);
+        it = c->graphs.erase(it);
+        continue;
+      }
+      if (it->n_img == n_img && it->want_kps == (kps != nullptr) && it->want_desc == (desc != nullptr)) exec = it->exec;
+      ++it;
+    }
+    if (!exec) {
+      hipGraph_t g = nullptr;
+      bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      const orbfe_status st = ok ? enqueue_all() : ORBFE_EDEVICE;
+      if (ok) ok = hipStreamEndCapture(c->stream, &g) == hipSuccess && st == ORBFE_OK && g;
+      if (ok) ok = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess;
+      if (g) (void)hipGraphDestroy(g);
+      if (ok) {
+        c->graphs.push_back({n_img, kps != nullptr, desc != nullptr, c->h_stage, exec});
+      } else {
+        (void)hipGetLastError();
+        exec = nullptr;
+        c->use_graphs = false;  // this runtime cannot capture the sequence: plain launches from now on
+      }
+    }
+    if (exec) {
+      HIP_TRY(c, hipGraphLaunch(exec, c->stream));
+      return finish_fetch(c, n_img, o_kps, o_desc, o_cnt, kps, desc, n_out);
+    }
+  }
+  TRY(enqueue_all());
+  return finish_fetch(c, n_img, o_kps, o_desc, o_cnt, kps, desc, n_out);
 }
 
 orbfe_status orbfe_extract(orbfe_ctx* c, const uint8_t* img, size_t stride, orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out) {
