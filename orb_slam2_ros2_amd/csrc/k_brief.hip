@@ -118,14 +118,15 @@ __global__ __launch_bounds__(256) void k_ic_moments(const uint8_t* __restrict__ 
       const int ady = dy < 0 ? -dy : dy;
       const int d = (int)((umax >> (4 * ady)) & 15ull);
       const int dx0 = xa + 4 * c - x;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int dx = dx0 + b;
-        const int v = (int)((wv[it] >> (8 * b)) & 255u);
-        const int vv = (dx >= -d && dx <= d) ? v : 0;
-        m10 += dx * vv;
-        m01 += dy * vv;
-      }
+      // bytes lo..hi of the word lie inside the disc row |dx| <= d: mask them, then two dot products give the byte sum and the
+      // position-weighted byte sum (sum dx_b v_b = dx0 sum v_b + sum b v_b)
+      const int lo = max(0, -d - dx0), hi = min(3, d - dx0);
+      const uint32_t mask = (hi >= lo) ? ((0xFFFFFFFFu >> (8 * (3 - hi))) & (0xFFFFFFFFu << (8 * lo))) : 0u;
+      const uint32_t w = wv[it] & mask;
+      const int sum = (int)__builtin_amdgcn_udot4(w, 0x01010101u, 0u, false);
+      const int wsum = (int)__builtin_amdgcn_udot4(w, 0x03020100u, 0u, false);
+      m10 += dx0 * sum + wsum;
+      m01 += dy * sum;
     }
   }
   // sum over the 16 lanes of the row: lane 15 of each row ends up with the total
