@@ -117,3 +117,21 @@ def test_device_rgbd_tail_matches_oracle(orc, depth_dtype):
     ku0, d0, _ = ctx.frame_rgbd(0, flat, depth, scale)
     assert np.array_equal(ku0["x"][:n], k["x"]) and np.array_equal(d0[:n], od)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_device_glue_error_paths():
+    from orb_slam2_ros2_amd._lib import Context, OrbfeError
+    ctx = Context(640, 480, n_features=500, max_images=1)
+    img = np.zeros((480, 640, 3), np.uint8)
+    with pytest.raises(OrbfeError):
+        ctx.extract_color(img, 3)                                   # Camera.Color is 1 (RGB) or 2 (BGR)
+    k, d = ctx.extract_color(img, 1)
+    assert len(k) == 0                                              # a flat image has no corners, and that is not an error
+    with pytest.raises(OrbfeError):
+        ctx.frame_rgbd(5, TUM)                                      # slot out of range
+    with pytest.raises(OrbfeError):
+        ctx.frame_rgbd(0, TUM, np.zeros((480, 640), np.uint16), depth_scale=0.0)
+    ku, dd, ru = ctx.frame_rgbd(0, TUM, np.zeros((480, 640), np.uint16), depth_scale=5000.0)
+    assert (dd == -1).all() and (ru == -1).all()                    # no keypoints: every entry is "no depth"
+    ctx.close()
