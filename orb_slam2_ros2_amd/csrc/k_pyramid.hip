@@ -15,18 +15,22 @@
 namespace orbfe {
 
 // ---------------------------------------------------------------------------------------------
-// resize: 64 x RS_TH output pixels per 256-thread block; grid.x = tiles of all levels >= 1 (host-built descriptors: no
+// resize: 64 x TH output pixels per 256-thread block; grid.x = tiles of all levels >= 1 (host-built descriptors: no
 // level search, no division, no dependent tap loads before the footprint is known), grid.y = image.
-// The level-0 footprint of the tile (<= 60 rows x 240 bytes at scale 3.58) and the tile's 64 + RS_TH taps are staged in
+// The level-0 footprint of the tile (<= 60 rows x 240 bytes at scale 3.58) and the tile's 64 + TH taps are staged in
 // LDS in ONE round trip; every thread then produces 4 horizontally adjacent outputs per row from LDS bytes and stores
 // them as one word.
 // ---------------------------------------------------------------------------------------------
+// TH = 64 / 32 / 16 rows per tile: every level takes the tallest tile whose level-0 footprint fits RS_LDS_BYTES (four / two / one
+// rows per thread: more work per memory round trip of a wave); the LDS of a launch is sized to its largest footprint.
+template <int TH>
 __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv, const RsTile* __restrict__ tiles,
                                                 const ResizeTap* __restrict__ taps, uint8_t* __restrict__ pyr,
-                                                size_t img_pitch) {
-  __shared__ __attribute__((aligned(16))) uint32_t tile[RS_LDS_BYTES / 4];
-  __shared__ ResizeTap xs[RS_TW];
-  __shared__ ResizeTap ys[RS_TH];
+                                                size_t img_pitch, int tile_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t rs_lds[];
+  uint32_t* tile = rs_lds;
+  ResizeTap* xs = (ResizeTap*)(rs_lds + tile_bytes / 4);
+  ResizeTap* ys = xs + RS_TW;
   const int img = blockIdx.y;
   const RsTile T = tiles[blockIdx.x];
   const LevelDev& L = lv[T.level];
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv,
     const int k = threadIdx.x;
     if (k < RS_TW)
       xs[k] = xt[min(x0 + k, L.w - 1)];
-    else if (k < RS_TW + RS_TH)
+    else if (k < RS_TW + TH)
       ys[k - RS_TW] = yt[min(y0 + k - RS_TW, L.h - 1)];
   }
   if (fits) {  // footprint rows start at a multiple of 16 bytes and are a whole number of 16-byte quads
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv,
 #pragma unroll
   for (int j = 0; j < 4; ++j) ax[j] = xs[tx + j];
 #pragma unroll
-  for (int rr = 0; rr < RS_TH / 16; ++rr) {
+  for (int rr = 0; rr < TH / 16; ++rr) {
     const int ty = (threadIdx.x >> 4) + 16 * rr;
     const int cy = y0 + ty;
     if (cy >= L.h) break;
@@ -252,10 +256,23 @@ void launch_load_level0(hipStream_t st, const uint8_t* d_src, size_t src_stride,
 // ---------------------------------------------------------------------------------------------
 // launchers (called from the C-ABI layer)
 // ---------------------------------------------------------------------------------------------
-void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, int total_tiles, const ResizeTap* d_taps, uint8_t* d_pyr,
-                   size_t img_pitch, int n_img) {
-  if (total_tiles <= 0 || n_img <= 0) return;
-  hipLaunchKernelGGL(k_resize, dim3(total_tiles, n_img), dim3(256), 0, s, d_lv, d_tiles, d_taps, d_pyr, img_pitch);
+// n_tiles / lds_bytes: the 64x64, 64x32 and 64x16 tile classes, stored in this order in d_tiles
+void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, const int* n_tiles, const int* lds_bytes,
+                   const ResizeTap* d_taps, uint8_t* d_pyr, size_t img_pitch, int n_img) {
+  if (n_img <= 0) return;
+  const size_t extra = (RS_TW + 64) * sizeof(ResizeTap);
+  const RsTile* t = d_tiles;
+  if (n_tiles[0] > 0)
+    hipLaunchKernelGGL((k_resize<64>), dim3(n_tiles[0], n_img), dim3(256), (size_t)lds_bytes[0] + extra, s, d_lv, t, d_taps, d_pyr, img_pitch,
+                       lds_bytes[0]);
+  t += n_tiles[0];
+  if (n_tiles[1] > 0)
+    hipLaunchKernelGGL((k_resize<32>), dim3(n_tiles[1], n_img), dim3(256), (size_t)lds_bytes[1] + extra, s, d_lv, t, d_taps, d_pyr, img_pitch,
+                       lds_bytes[1]);
+  t += n_tiles[1];
+  if (n_tiles[2] > 0)
+    hipLaunchKernelGGL((k_resize<16>), dim3(n_tiles[2], n_img), dim3(256), (size_t)lds_bytes[2] + extra, s, d_lv, t, d_taps, d_pyr, img_pitch,
+                       lds_bytes[2]);
 }
 
 void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int total_tiles, const uint8_t* d_pyr, uint8_t* d_blur,

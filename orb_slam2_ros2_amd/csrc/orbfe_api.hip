@@ -17,7 +17,8 @@
 
 namespace orbfe {
 // k_pyramid.hip
-void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, int total_tiles, const ResizeTap* d_taps, uint8_t* d_pyr,
+void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, const int* n_tiles, const int* lds_bytes,
+                   const ResizeTap* d_taps, uint8_t* d_pyr,
                    size_t img_pitch, int n_img);
 void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int total_tiles, const uint8_t* d_pyr, uint8_t* d_blur,
                  size_t img_pitch, const int taps[7], int n_img);
@@ -127,6 +128,7 @@ struct orbfe_ctx {
   int umax[16];
   int blur_taps[7];
   int n_cells_total = 0, rs_tiles = 0, bl_tiles = 0;
+  int rs_n[3] = {0, 0, 0}, rs_bytes[3] = {0, 0, 0};  // resize tiles of 64x64 / 64x32 / 64x16 outputs (in this order) and their LDS
   size_t img_pitch = 0;      // bytes per image in pyr / blur
   size_t scratch_pitch = 0;  // uint32 records per image
   int rec_cap = 0;           // upper bound of candidate records one quadtree wave keeps in LDS (launch picks <= this)
@@ -328,9 +330,8 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
       build_resize_axis(cfg.width, L.w, c->taps);
       L.ytab_off = (uint32_t)c->taps.size();
       build_resize_axis(cfg.height, L.h, c->taps);
-      L.rs_tiles_x = (L.w + RS_TW - 1) / RS_TW;  // k_resize output tiles
-      L.rs_tiles_y = (L.h + RS_TH - 1) / RS_TH;
-      rs_tiles += L.rs_tiles_x * L.rs_tiles_y;
+      L.rs_tiles_x = (L.w + RS_TW - 1) / RS_TW;  // k_resize output tiles (rows: decided below, 16 or 32 per tile)
+      L.rs_tiles_y = 0;
     }
     L.bl_tile_base = bl_tiles;
     L.bl_tiles_x = (L.w + 247) / 248;  // k_blur: 62 words (248 px) per wave, 4 waves x 32 rows per block
@@ -354,27 +355,53 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
       }
     }
   }
-  // resize work items: output tile + the level-0 footprint it reads (taps are monotone in the output coordinate)
+  // resize work items: output tile + the level-0 footprint it reads (taps are monotone in the output coordinate).  Levels whose
+  // 64x32 tiles all stage <= RS_TALL_LDS_BYTES use those ("tall", listed first), the coarser levels 64x16 tiles.
   c->rs_tile_tab.clear();
+  std::vector<RsTile> cls[3];
+  for (int k = 0; k < 3; ++k) c->rs_n[k] = c->rs_bytes[k] = 0;
   for (int l = 1; l < nl; ++l) {
-    const LevelDev& L = c->lv[l];
+    LevelDev& L = c->lv[l];
     const ResizeTap* xt = c->taps.data() + L.xtab_off;
     const ResizeTap* yt = c->taps.data() + L.ytab_off;
-    for (int ty = 0; ty < L.rs_tiles_y; ++ty)
-      for (int tx = 0; tx < L.rs_tiles_x; ++tx) {
-        const int x0 = tx * RS_TW, y0 = ty * RS_TH;
-        const int x1 = std::min(x0 + RS_TW, (int)L.w) - 1, y1 = std::min(y0 + RS_TH, (int)L.h) - 1;
-        const int sx_lo = xt[x0].ofs & ~15, sx_hi = std::min(xt[x1].ofs + 1, cfg.width - 1);
-        const int sy_lo = std::min(std::max(yt[y0].ofs, 0), cfg.height - 1), sy_hi = std::min(std::max(yt[y1].ofs + 1, 0), cfg.height - 1);
-        const int nw = (((sx_hi - sx_lo) >> 4) + 1) * 4, nr = sy_hi - sy_lo + 1;  // whole 16-byte quads (rows are padded to 16 B)
-        RsTile t;
-        t.level = (int16_t)l, t.x0 = (int16_t)x0, t.y0 = (int16_t)y0, t.sx_lo = (int16_t)sx_lo, t.sy_lo = (int16_t)sy_lo;
-        t.nw = (int16_t)((nw * nr * 4 <= RS_LDS_BYTES) ? nw : 0);
-        t.nr = (int16_t)nr, t.pad = 0;
-        c->rs_tile_tab.push_back(t);
+    auto make_tiles = [&](int th, std::vector<RsTile>& out, int& max_bytes) {
+      max_bytes = 0;
+      const int tys = (L.h + th - 1) / th;
+      for (int ty = 0; ty < tys; ++ty)
+        for (int tx = 0; tx < L.rs_tiles_x; ++tx) {
+          const int x0 = tx * RS_TW, y0 = ty * th;
+          const int x1 = std::min(x0 + RS_TW, (int)L.w) - 1, y1 = std::min(y0 + th, (int)L.h) - 1;
+          const int sx_lo = xt[x0].ofs & ~15, sx_hi = std::min(xt[x1].ofs + 1, cfg.width - 1);
+          const int sy_lo = std::min(std::max(yt[y0].ofs, 0), cfg.height - 1), sy_hi = std::min(std::max(yt[y1].ofs + 1, 0), cfg.height - 1);
+          const int nw = (((sx_hi - sx_lo) >> 4) + 1) * 4, nr = sy_hi - sy_lo + 1;  // whole 16-byte quads (rows are padded to 16 B)
+          RsTile t;
+          t.level = (int16_t)l, t.x0 = (int16_t)x0, t.y0 = (int16_t)y0, t.sx_lo = (int16_t)sx_lo, t.sy_lo = (int16_t)sy_lo;
+          t.nw = (int16_t)((nw * nr * 4 <= RS_LDS_BYTES) ? nw : 0);
+          t.nr = (int16_t)nr, t.pad = 0;
+          max_bytes = std::max(max_bytes, nw * nr * 4);
+          out.push_back(t);
+        }
+      return tys;
+    };
+    for (int k = 0; k < 3; ++k) {  // the tallest tile whose footprint still fits
+      const int th = 64 >> k;
+      std::vector<RsTile> cand;
+      int bytes = 0;
+      const int tys = make_tiles(th, cand, bytes);
+      if (bytes <= RS_LDS_BYTES || k == 2) {
+        cls[k].insert(cls[k].end(), cand.begin(), cand.end());
+        c->rs_bytes[k] = std::max(c->rs_bytes[k], std::min(bytes, RS_LDS_BYTES));
+        L.rs_tiles_y = tys;
+        break;
       }
+    }
   }
-  if ((int)c->rs_tile_tab.size() != rs_tiles) return fail(c, ORBFE_EDEVICE, "internal: resize tile count");
+  for (int k = 0; k < 3; ++k) {
+    c->rs_n[k] = (int)cls[k].size();
+    c->rs_bytes[k] = (int)align_up((size_t)std::max(c->rs_bytes[k], 16), 16);
+    c->rs_tile_tab.insert(c->rs_tile_tab.end(), cls[k].begin(), cls[k].end());
+  }
+  rs_tiles = (int)c->rs_tile_tab.size();
   c->n_cells_total = cell_base;
   c->rs_tiles = rs_tiles;
   c->bl_tiles = bl_tiles;
@@ -504,7 +531,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   int32_t* n_cand = c->d_n_cand + i0 * nl;
   {
     StageTimer t(c, ORBFE_STAGE_RESIZE, st);
-    launch_resize(st, c->d_lv, c->d_rs_tiles, c->rs_tiles, c->d_taps, pyr, c->img_pitch, n_img);
+    launch_resize(st, c->d_lv, c->d_rs_tiles, c->rs_n, c->rs_bytes, c->d_taps, pyr, c->img_pitch, n_img);
   }
   // Only the descriptors read the blurred planes, so the blur need not sit between resize and FAST: it is issued on a second
   // stream once FAST is done and runs UNDER the quadtree, which keeps 8 waves per CU busy with dependent LDS steps and leaves

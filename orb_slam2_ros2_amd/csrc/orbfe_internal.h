@@ -18,8 +18,7 @@ struct ResizeTap {
 
 // k_resize work item: RS_TW x RS_TH output pixels of one level and the level-0 footprint they read
 #define RS_TW 64
-#define RS_TH 16
-#define RS_LDS_BYTES 16384
+#define RS_LDS_BYTES 16384  // largest footprint a tile may stage
 struct RsTile {
   int16_t level, x0, y0;  // output tile origin
   int16_t sx_lo, nw;      // footprint: first level-0 column (multiple of 16), 32-bit words per row (multiple of 4); nw == 0: does not fit the LDS
