@@ -92,3 +92,49 @@ def test_device_local_ba_edge_cases(orc):
     with pytest.raises(OrbfeError):
         ctx.ba_local_optimize(bad, fixed)
     ctx.close()
+
+
+def _mutate(pr, fixed, kind, rng):
+    """structural corner cases of the graph the reference can produce"""
+    pr = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in pr.items()}
+    fixed = fixed.copy()
+    E = len(pr["edge_pose"])
+    if kind == "mono_only":
+        pr["is_stereo"][:] = 0
+        pr["meas"][:, 2] = -1.0
+        pr["info"][:] = np.sqrt(pr["info"])                      # quirk Q9: mono edges carry invSigma
+        pr["huber_delta"][:] = float(np.float32(np.sqrt(5.991)))
+    elif kind == "free_pose_without_edges":
+        k = int(np.flatnonzero(fixed == 0)[0])
+        keep = pr["edge_pose"] != k
+        for name in ("edge_pose", "edge_point", "meas", "is_stereo", "info", "huber_delta"):
+            pr[name] = pr[name][keep]
+    elif kind == "points_seen_by_fixed_poses_only":
+        # make some points fixed-only by removing their free-pose edges
+        victims = np.unique(pr["edge_point"])[:25]
+        keep = ~(np.isin(pr["edge_point"], victims) & (fixed[pr["edge_pose"]] == 0))
+        for name in ("edge_pose", "edge_point", "meas", "is_stereo", "info", "huber_delta"):
+            pr[name] = pr[name][keep]
+    elif kind == "duplicate_edges":
+        dup = rng.integers(0, E, 50)
+        for name in ("edge_pose", "edge_point", "meas", "is_stereo", "info", "huber_delta"):
+            pr[name] = np.concatenate([pr[name], pr[name][dup]])
+    elif kind == "far_start":
+        pr["poses"][fixed == 0, 4:] += rng.normal(0, 0.15, ((fixed == 0).sum(), 3))     # several rejected LM trials
+    return pr, fixed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["mono_only", "free_pose_without_edges", "points_seen_by_fixed_poses_only", "duplicate_edges", "far_start"])
+def test_device_local_ba_structural_cases(orc, kind):
+    from orb_slam2_ros2_amd._lib import Context
+    rng = np.random.default_rng(11)
+    pr, fixed = _problem(9, 10, 300, 3)
+    pr, fixed = _mutate(pr, fixed, kind, rng)
+    ctx = Context(640, 480, n_features=500, max_images=1)
+    g = ctx.ba_local_optimize(pr, fixed)
+    o = orc.ba_local_optimize(pr, fixed)
+    assert tuple(g["iters"]) == tuple(o["iters"]), kind
+    assert _pose_dist(g["poses"], o["poses"]) < 1e-7 and np.abs(g["points"] - o["points"]).max() < 1e-7, kind
+    assert (g["level"] != o["level"]).sum() <= 1 and (g["bad"] != o["bad"]).sum() <= 1
+    ctx.close()
