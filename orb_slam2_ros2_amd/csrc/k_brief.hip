@@ -205,7 +205,8 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __res
                                               const uint4* __restrict__ kpl, int n_features, const int8_t* __restrict__ pattern,
                                               const double2* __restrict__ sincos, uint8_t* __restrict__ desc) {
 #pragma clang fp contract(off)
-  __shared__ uint32_t win_all[BRIEF_WAVES][BRIEF_ROWS * BRIEF_WORDS + 1];  // one window per wave; the waves never synchronise
+  __shared__ uint32_t win_all[BRIEF_WAVES][BRIEF_ROWS * BRIEF_WORDS + 1];
+  __shared__ double2 rot_all[BRIEF_WAVES][2 * BRIEF_R + 1];  // per wave: (v cos, v sin) for every template coordinate v in [-18, 18]  // one window per wave; the waves never synchronise
   const int lane = threadIdx.x & 63;
   uint32_t* win = win_all[threadIdx.x >> 6];
   const int k = blockIdx.x * BRIEF_WAVES + (threadIdx.x >> 6);
@@ -238,8 +239,16 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __res
     if (idx < NW) win[idx] = wv[it];
   }
   const double sn = scv.x, cs = scv.y;
-  // the LDS accesses of one wave execute in order, so the window written above is visible to every lane of this wave;
-  // the fence only pins the compiler
+  // The rotation needs x cos, x sin, y cos, y sin in fp64 for 512 template points, but the coordinates are small integers:
+  // 37 lanes form the products once ((double)v * cs is exactly what the per-point expression computes), every point then
+  // takes two LDS reads and one fp64 add per coordinate instead of two fp64 multiplies and a conversion.
+  double2* rot = rot_all[threadIdx.x >> 6];
+  if (lane <= 2 * BRIEF_R) {
+    const double v = (double)(float)(lane - BRIEF_R);
+    rot[lane] = make_double2(v * cs, v * sn);
+  }
+  // the LDS accesses of one wave execute in order, so the window and the table written above are visible to every lane of this
+  // wave; the fence only pins the compiler
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const uint8_t* wb = (const uint8_t*)win;
@@ -248,13 +257,14 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __res
   unsigned long long bits[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const float x1 = (float)(int8_t)(tp[g] & 255u), y1 = (float)(int8_t)((tp[g] >> 8) & 255u);
-    const float x2 = (float)(int8_t)((tp[g] >> 16) & 255u), y2 = (float)(int8_t)(tp[g] >> 24);
+    const int x1 = (int)(int8_t)(tp[g] & 255u), y1 = (int)(int8_t)((tp[g] >> 8) & 255u);
+    const int x2 = (int)(int8_t)((tp[g] >> 16) & 255u), y2 = (int)(int8_t)(tp[g] >> 24);
+    const double2 rx1 = rot[x1 + BRIEF_R], ry1 = rot[y1 + BRIEF_R], rx2 = rot[x2 + BRIEF_R], ry2 = rot[y2 + BRIEF_R];
     // float * double -> double, one rounding to float (rotateTemplate, ORBExtractor.cc:537-538)
-    const float p1x = (float)((double)x1 * cs - (double)y1 * sn);
-    const float p1y = (float)((double)x1 * sn + (double)y1 * cs);
-    const float p2x = (float)((double)x2 * cs - (double)y2 * sn);
-    const float p2y = (float)((double)x2 * sn + (double)y2 * cs);
+    const float p1x = (float)(rx1.x - ry1.y);  // x1 cos - y1 sin
+    const float p1y = (float)(rx1.y + ry1.x);  // x1 sin + y1 cos
+    const float p2x = (float)(rx2.x - ry2.y);
+    const float p2y = (float)(rx2.y + ry2.x);
     const int r1 = __float2int_rn(py + p1y), c1 = __float2int_rn(px + p1x);
     const int r2 = __float2int_rn(py + p2y), c2 = __float2int_rn(px + p2x);
     const int v1 = wb[(r1 - y_off) * (BRIEF_WORDS * 4) + (c1 - x_off)];
