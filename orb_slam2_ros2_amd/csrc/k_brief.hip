@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void k_ic_moments(const uint8_t* __restrict__ 
   const uint4 e = in_range ? kpl[(size_t)img * n_features + k] : make_uint4(0xFFFFu, 0u, 0u, 0u);
   const bool valid = (e.x & 0xFFFFu) != 0xFFFFu;
   const int x = valid ? (int)(e.x & 0xFFFFu) : 16, y = valid ? (int)(e.x >> 16) : 16;  // level coordinates (a safe spot if unused)
-  const uint8_t* I = pyr + (size_t)img * img_pitch + (valid ? e.z : 0u);
+  const uint8_t* I = pyr + (size_t)img * img_pitch;  // wave-uniform base; the rest of the address is a 32-bit offset
+  const uint32_t plane = valid ? e.z : 0u;
   const int stride = valid ? (int)e.w : 64;
   const int xa = (x - 15) & ~3;  // first aligned word of a row of the window
   constexpr int NIT = (31 * 9 + 15) / 16;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void k_ic_moments(const uint8_t* __restrict__ 
     const int idx = min(it * 16 + sub, 31 * 9 - 1);
     const int r = (idx * 7282) >> 16;  // idx / 9 for idx < 320
     const int c = idx - r * 9;
-    wv[it] = *(const uint32_t*)(I + (size_t)(y + r - 15) * stride + xa + 4 * c);
+    wv[it] = *(const uint32_t*)(I + (plane + (uint32_t)((y + r - 15) * stride + xa + 4 * c)));
   }
   int m10 = 0, m01 = 0;
 #pragma unroll
@@ -217,7 +218,8 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __res
   const uint4 e = kpl[(size_t)img * n_features + k];
   if ((e.x & 0xFFFFu) == 0xFFFFu) return;  // wave-uniform
   const int x = (int)(e.x & 0xFFFFu), y = (int)(e.x >> 16);
-  const uint8_t* W = blur + (size_t)img * img_pitch + e.z;
+  const uint8_t* W = blur + (size_t)img * img_pitch;  // wave-uniform base; the rest of the address is a 32-bit offset
+  const uint32_t plane = e.z;
   const int stride = (int)e.w;
   const int xa = (x - BRIEF_R) & ~3;
   constexpr int NW = BRIEF_ROWS * BRIEF_WORDS, NIT = (NW + 63) / 64;
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __res
     const int idx = min(it * 64 + lane, NW - 1);
     const int r = (idx * 5958) >> 16;  // idx / 11 for idx < 448
     const int c = idx - r * BRIEF_WORDS;
-    wv[it] = *(const uint32_t*)(W + (size_t)(y - BRIEF_R + r) * stride + xa + 4 * c);
+    wv[it] = *(const uint32_t*)(W + (plane + (uint32_t)((y - BRIEF_R + r) * stride + xa + 4 * c)));
   }
   const double2 scv = sincos[(size_t)img * n_features + k];
   uint32_t tp[4];
