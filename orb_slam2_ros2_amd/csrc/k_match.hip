@@ -186,8 +186,8 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
 #pragma unroll
       for (int u = 0; u < ST_STEP; ++u) {
         const int c = min((max(cid[u], 0) << 6) + lane, nr - 1);
-        ra[u] = RA[c];
-        rxv[u] = RX[c];
+        ra[u] = RA[(uint32_t)c];  // (unsigned indices: scalar base + 32-bit offset addressing)
+        rxv[u] = RX[(uint32_t)c];
       }
       int total = 0;
 #pragma unroll
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
       for (int g = 0; g < total; g += 64) {
         const bool has = g + lane < total;
         const int idx = has ? (int)clist[g + lane] : 0;
-        const int d = has ? hamming256(a0, a1, RD + (size_t)idx * 32) : ORB_INT_MAX;
+        const int d = has ? hamming256(a0, a1, RD + ((uint32_t)idx << 5)) : ORB_INT_MAX;
         any = true;
         fold_chunk(b, d, idx, lane);
       }
