@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "orbfe_internal.h"
+#include "wave_ops.h"
 
 namespace orbfe {
 
@@ -92,9 +93,10 @@ __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv,
       } else {
         p00 = g0[sx0], p01 = g0[sx1], p10 = g1[sx0], p11 = g1[sx1];
       }
-      const int h0 = p00 * ax[j].c0 + p01 * ax[j].c1;
-      const int h1 = p10 * ax[j].c0 + p11 * ax[j].c1;
-      int v = ((((int)ay.c0 * (h0 >> 4)) >> 16) + (((int)ay.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      // (pixels < 2^8, taps <= 2^11, h >> 4 < 2^15: every product fits the full-rate 24-bit multiplier)
+      const int h0 = mad24u(p00, ax[j].c0, mul24u(p01, ax[j].c1));
+      const int h1 = mad24u(p10, ax[j].c0, mul24u(p11, ax[j].c1));
+      int v = ((mul24u((int)ay.c0, h0 >> 4) >> 16) + (mul24u((int)ay.c1, h1 >> 4) >> 16) + 2) >> 2;
       v = min(255, max(0, v));
       out |= (uint32_t)v << (8 * j);
     }

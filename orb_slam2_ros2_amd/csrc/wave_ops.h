@@ -12,6 +12,18 @@ namespace orbfe {
 #define ORBFE_DPP_WAVE_SHR1 0x138
 #define ORBFE_DPP_WAVE_SHL1 0x130
 
+// Full-rate 24-bit integer multiplies.  hipcc lowers an int product whose operand ranges it cannot prove to the quarter-rate
+// v_mul_lo_u32 (and __mul24 back to a plain product): where the operands are known to fit 24 bits, spell the instruction out.
+__device__ __forceinline__ int mul24u(int a, int b) {
+  int d;
+  asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ int mad24u(int a, int b, int c) {
+  int d;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 struct OpMinI {
   static __device__ __forceinline__ int id() { return 2147483647; }
   static __device__ __forceinline__ int f(int a, int b) { return a < b ? a : b; }
