@@ -160,6 +160,9 @@ __global__ __launch_bounds__(256) void k_blur(const LevelDev* __restrict__ lv, i
   const uint32_t t0 = taps.t[0] & 255u, t1 = taps.t[1] & 255u, t2 = taps.t[2] & 255u, t3 = taps.t[3] & 255u, t4 = taps.t[4] & 255u,
                  t5 = taps.t[5] & 255u, t6 = taps.t[6] & 255u;
   const uint32_t T03 = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24), T46 = t4 | (t5 << 8) | (t6 << 16);
+  // taps that sum to <= 256 (variant 0) can reach neither the 16-bit saturation of the row pass (255 * 256 < 65536) nor the
+  // 8-bit one of the column pass (256 * 65280 + 0x8000 < 2^24 + 2^16): the clamps and the byte-by-byte packing are skipped
+  const bool no_sat = t0 + t1 + t2 + t3 + t4 + t5 + t6 <= 256u;
 
   uint32_t win[7][4];
 #pragma unroll
@@ -200,14 +203,15 @@ __global__ __launch_bounds__(256) void k_blur(const LevelDev* __restrict__ lv, i
         hh[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(m, lw, 2), T03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rw, m, 2), T46, 0u, false), false);
         hh[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(m, lw, 3), T03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rw, m, 3), T46, 0u, false), false);
         hh[3] = __builtin_amdgcn_udot4(m, T03, __builtin_amdgcn_udot4(rw, T46, 0u, false), false);
+        if (!no_sat) {  // wave-uniform
 #pragma unroll
-        for (int j = 0; j < 4; ++j) hh[j] = min(hh[j], 65535u);  // ufixedpoint16 saturation (only reachable with variant-1 taps)
+          for (int j = 0; j < 4; ++j) hh[j] = min(hh[j], 65535u);  // ufixedpoint16 saturation (only reachable with variant-1 taps)
+        }
         if (r >= 6) {
           // rows r-6 .. r live in slots (u+1)%7 .. u ; tap k multiplies row r-6+k
-          uint32_t o = 0;
+          uint32_t acc4[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            // 8-bit tap x 16-bit row sum: 24-bit multiplies are exact
             // 8-bit tap x 16-bit row sum: v_mad_u32_u24 is exact here (hipcc would pick the quarter-rate v_mul_lo_u32)
             uint32_t acc = mad24(t0, win[(u + 1) % 7][j], 0x8000u);
             acc = mad24(t1, win[(u + 2) % 7][j], acc);
@@ -215,8 +219,17 @@ __global__ __launch_bounds__(256) void k_blur(const LevelDev* __restrict__ lv, i
             acc = mad24(t3, win[(u + 4) % 7][j], acc);
             acc = mad24(t4, win[(u + 5) % 7][j], acc);
             acc = mad24(t5, win[(u + 6) % 7][j], acc);
-            acc = mad24(t6, win[u][j], acc);
-            o |= min(acc >> 16, 255u) << (8 * j);
+            acc4[j] = mad24(t6, win[u][j], acc);
+          }
+          uint32_t o;
+          if (no_sat) {  // wave-uniform: byte 2 of each accumulator is the pixel, three v_perm_b32 pack them
+            const uint32_t lo = __builtin_amdgcn_perm(acc4[1], acc4[0], 0x0c0c0602u);  // (0, 0, acc1.b2, acc0.b2)
+            const uint32_t hi = __builtin_amdgcn_perm(acc4[3], acc4[2], 0x06020c0cu);  // (acc3.b2, acc2.b2, 0, 0)
+            o = lo | hi;
+          } else {
+            o = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o |= min(acc4[j] >> 16, 255u) << (8 * j);
           }
           if (writer) *(uint32_t*)(D + (size_t)(y0 + r - 6) * stride + x4) = o;
         }
