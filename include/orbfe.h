@@ -94,6 +94,11 @@ const char* orbfe_last_error(const orbfe_ctx* ctx); /* ctx may be NULL: error of
 
 orbfe_status orbfe_get_level_info(const orbfe_ctx* ctx, int32_t level, orbfe_level_info* out);
 orbfe_status orbfe_get_scale_factors(const orbfe_ctx* ctx, float* out, int32_t n);
+/* Keypoints one image can yield = the stride of every per-image array of this API ("[n_features]" below means this number).
+ * It equals n_features for every configuration the reference ships; it is larger only where the reference itself returns more
+ * than nFeatures keypoints: its per-level quotas are rounded level by level and only the last level absorbs the difference
+ * (src/ORBExtractor.cc:292-300), so e.g. nFeatures = 7 at 8 levels x 1.2 asks for 2 keypoints on each of seven levels.          */
+int32_t orbfe_get_capacity(const orbfe_ctx* ctx);
 
 /* ---- extraction (host buffers) ---------------------------------------------------------------
  * One image -> slot 0.  kps has room for n_features entries, desc for n_features*32 bytes.          */

@@ -73,6 +73,7 @@ class BaEdgeOut(C.Structure):
 
 EXPORTS = [
     "orbfe_abi_version", "orbfe_create", "orbfe_destroy", "orbfe_last_error", "orbfe_get_level_info", "orbfe_get_scale_factors",
+    "orbfe_get_capacity",
     "orbfe_extract", "orbfe_extract_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
     "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_extract_color", "orbfe_frame_rgbd",
     "orbfe_profile_enable", "orbfe_profile_read", "orbfe_stage_name", "orbfe_debug_candidates",
@@ -106,6 +107,8 @@ def load() -> C.CDLL:
     L.orbfe_last_error.restype = C.c_char_p
     L.orbfe_get_level_info.argtypes = [vp, i32, C.POINTER(LevelInfo)]
     L.orbfe_get_scale_factors.argtypes = [vp, vp, i32]
+    L.orbfe_get_capacity.argtypes = [vp]
+    L.orbfe_get_capacity.restype = i32
     L.orbfe_extract.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
     L.orbfe_extract_batch.argtypes = [vp, i32, vp, C.c_size_t, vp, vp, vp]
     L.orbfe_get_pyramid.argtypes = [vp, i32, i32, i32, vp]
@@ -154,7 +157,9 @@ class Context:
             msg = self.lib.orbfe_last_error(None).decode()
             raise (ImageSizeError if st == 2 else OrbfeError)(st, msg)
         self.h = h
-        self.width, self.height, self.n_features, self.n_levels, self.max_images = width, height, n_features, n_levels, max_images
+        self.width, self.height, self.n_levels, self.max_images = width, height, n_levels, max_images
+        self.requested_features = n_features
+        self.n_features = int(self.lib.orbfe_get_capacity(h))   # stride of every per-image array (>= the requested count)
 
     def close(self):
         if getattr(self, "h", None):

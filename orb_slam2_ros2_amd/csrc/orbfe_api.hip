@@ -128,6 +128,7 @@ struct orbfe_ctx {
   int umax[16];
   int blur_taps[7];
   int n_cells_total = 0, rs_tiles = 0, bl_tiles = 0;
+  int kp_cap = 0;  // keypoints one image can yield = stride of every per-image array (>= n_features, see build_geometry)
   int rs_n[3] = {0, 0, 0}, rs_bytes[3] = {0, 0, 0};  // resize tiles of 64x64 / 64x32 / 64x16 outputs (in this order) and their LDS
   size_t img_pitch = 0;      // bytes per image in pyr / blur
   size_t scratch_pitch = 0;  // uint32 records per image
@@ -240,6 +241,11 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
       nfeats = cv_round_f(nfeats * scale);
     }
     quota[nl - 1] = std::max(0, cfg.n_features - sum);
+    // The reference's quotas are rounded per level and only the LAST level absorbs the difference (ORBExtractor.cc:292-300): for
+    // small nFeatures (< 60 at 8 levels x 1.2) the first levels alone already exceed it and an image yields MORE than nFeatures
+    // keypoints.  Every per-image array is therefore sized by the capacity max(nFeatures, sum of quotas), which the caller can
+    // query (orbfe_get_capacity); it equals nFeatures for every configuration the reference ships.
+    c->kp_cap = std::max(cfg.n_features, sum + quota[nl - 1]);
   }
   size_t plane_off = 0;
   uint32_t cand_base = 0;
@@ -665,6 +671,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   };
   orbfe_status st = build_geometry(c);
   if (st != ORBFE_OK) return bail(st);
+  c->cfg.n_features = c->kp_cap;  // from here on n_features is the per-image array stride (the quotas keep the requested value)
   if (hipSetDevice(c->device) != hipSuccess) {
     fail(c, ORBFE_EDEVICE, "hipSetDevice(%d) failed", c->device);
     return bail(ORBFE_EDEVICE);
@@ -707,7 +714,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
       }
     }
   }
-  const size_t M = (size_t)cfg->max_images, NF = (size_t)std::max(cfg->n_features, 1), NL = (size_t)cfg->n_levels;
+  const size_t M = (size_t)cfg->max_images, NF = (size_t)std::max(c->cfg.n_features, 1), NL = (size_t)cfg->n_levels;
   const size_t NP = (M + 1) / 2;
 #define ALLOC(ptr, count)                          \
   do {                                             \
@@ -800,6 +807,8 @@ orbfe_status orbfe_get_scale_factors(const orbfe_ctx* c, float* out, int32_t n) 
   for (int l = 0; l < c->cfg.n_levels; ++l) out[l] = c->lv[l].sf;
   return ORBFE_OK;
 }
+
+int32_t orbfe_get_capacity(const orbfe_ctx* c) { return c ? c->kp_cap : 0; }
 
 orbfe_status orbfe_sync(orbfe_ctx* c) {
   if (!c) return ORBFE_EBADARG;

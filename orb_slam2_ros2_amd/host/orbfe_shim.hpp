@@ -16,6 +16,7 @@
 // Error mapping (include/ORB_SLAM2/Error.h): ORBFE_EBADSIZE -> ImageSizeError, a missing template file ->
 // FileNotOpenError, everything else -> std::runtime_error with orbfe_last_error().
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -120,6 +121,7 @@ class ORBExtractor {
       : mImage(image), mnFeats(nFeatures), mnLevels(pyramidLevels), mSlot(slot) {
     if (!image.data || image.cols <= 0 || image.rows <= 0) throw std::invalid_argument("ORBExtractor: empty image");
     mCtx = ContextPool::get(image.cols, image.rows, nFeatures, pyramidLevels, scaleFactor, maxThreshold, minThreshold, bfTemFp);
+    mnFeats = orbfe_get_capacity(mCtx);  // array stride: nFeatures, or more where the reference's rounded quotas exceed it
     mScales.resize(pyramidLevels);
     check(mCtx, orbfe_get_scale_factors(mCtx, mScales.data(), pyramidLevels));
   }
@@ -179,7 +181,8 @@ class ORBMatcher {
   // fills mvFeatsRightU / mvDepths (-1 where unmatched) and returns the match count (Frame::mnN).
   int searchByStereo(orbfe_ctx* ctx, int nFeatures, int nLeft, float fx, float bf, std::vector<double>& rightU,
                      std::vector<double>& depths) const {
-    std::vector<double> ru((size_t)std::max(nFeatures, 1)), dp((size_t)std::max(nFeatures, 1));
+    const int cap = std::max(std::max(nFeatures, (int)orbfe_get_capacity(ctx)), 1);
+    std::vector<double> ru((size_t)cap), dp((size_t)cap);
     int32_t n = 0;
     check(ctx, orbfe_stereo_match(ctx, 0, 1, fx, bf, ru.data(), dp.data(), &n, nullptr, nullptr));
     rightU.assign(ru.begin(), ru.begin() + nLeft);
@@ -199,8 +202,13 @@ class ORBMatcher {
     const int32_t n = (int32_t)radius.size();
     AreaMatch m;
     m.bestIdx.resize(n), m.bestDist.resize(n), m.secondDist.resize(n), m.nCand.resize(n);
+    std::vector<uint8_t> ex;  // the ABI reads one flag per possible feature of the slot
+    if (exclude) {
+      ex.assign((size_t)std::max<int>(orbfe_get_capacity(ctx), (int)exclude->size()), 0);
+      std::copy(exclude->begin(), exclude->end(), ex.begin());
+    }
     check(ctx, orbfe_search_in_area(ctx, slot, n, uv.data(), radius.data(), minLevel.data(), maxLevel.data(),
-                                    n ? desc[0].data() : nullptr, exclude ? exclude->data() : nullptr, m.bestIdx.data(),
+                                    n ? desc[0].data() : nullptr, exclude ? ex.data() : nullptr, m.bestIdx.data(),
                                     m.bestDist.data(), m.secondDist.data(), m.nCand.data()));
     return m;
   }

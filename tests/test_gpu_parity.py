@@ -353,3 +353,17 @@ def test_cpp_host_mirror_matches_oracle(orc, tmp_path):
     assert (int(nl), int(nr), int(nm)) == (len(ref["lk"]), len(ref["rk"]), ref["n_matches"])
     assert int(hk, 16) == fnv1a(ref["lk"].tobytes()) and int(hd, 16) == fnv1a(ref["ld"].tobytes())
     assert int(d01) == orc.hamming(ref["ld"][0], ref["ld"][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nf", [7, 13, 58])
+def test_tiny_nfeatures_can_yield_more_keypoints_than_asked(orc, lib, nf):
+    """ORBExtractor.cc:292-300 rounds the quota of every level and lets only the last one absorb the difference: for small nFeatures
+    the first seven levels alone ask for more (nFeatures = 7 -> 2 per level = 14).  The arrays are sized by orbfe_get_capacity."""
+    img = synth.stereo_pair(2)[0]
+    ctx = lib.Context(1241, 376, n_features=nf, max_images=1)
+    assert ctx.n_features >= nf and ctx.requested_features == nf
+    k, d = ctx.extract(img)
+    ok, _ = assert_image_parity(ctx, 0, orc.extractor(img, n_features=nf), k, d, 8, check_planes=False)
+    assert len(ok) > nf and len(ok) <= ctx.n_features
+    ctx.close()
