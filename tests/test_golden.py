@@ -75,3 +75,65 @@ def test_cfg5_ba(orc):
                           p["huber_delta"], p["fx"], p["fy"], p["cx"], p["cy"], p["bf"])
     assert o["chi2"].sum() == pytest.approx(g["chi2_sum"], rel=1e-12)
     assert np.abs(o["j_pose"]).sum() == pytest.approx(g["jpose_abs_sum"], rel=1e-12)
+
+
+# ---- golden_v2: the widened rows (local BA, pose-only, frame glue) ----------------------------------------------------------
+G2 = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_v2.json")))
+TUM = dict(fx=520.908620, fy=521.007327, cx=325.141442, cy=249.701764, k1=0.231222, k2=-0.784899, p1=-0.003257, p2=-0.000105, k3=0.917205, bf=40.0)
+
+
+def _lba_problem():
+    pr = ba_synth.make_problem(seed=3, n_kf=12, n_pt=400, with_truth=True)
+    fixed = np.zeros(12, np.uint8)
+    fixed[:2] = 1
+    pr["poses"][:2] = pr["poses_true"][:2]
+    return pr, fixed
+
+
+def _color_image(seed, w=640, h=480):
+    g = synth.mono_image(seed, w, h)
+    rng = np.random.default_rng(seed)
+    img = np.stack([g, np.roll(g, 3, 1), (255 - g)], 2).astype(np.int32) + rng.integers(-6, 7, (h, w, 3))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def _check_lba(r):
+    g = G2["lba"]
+    assert r["iters"].tolist() == g["iters"] and int(r["level"].sum()) == g["n_level1"] and int(r["bad"].sum()) == g["n_bad"]
+    assert np.allclose(r["poses"].ravel(), g["poses"], rtol=0, atol=1e-8) and np.allclose(r["points"][:20].ravel(), g["points_head"], rtol=0, atol=1e-8)
+    assert abs(r["chi2"].sum() - g["chi2_sum"]) < 1e-6 * g["chi2_sum"]
+
+
+def test_v2_oracle_local_ba_pose_only_and_glue(orc):
+    pr, fixed = _lba_problem()
+    r = orc.ba_local_optimize(pr, fixed)
+    _check_lba(r)
+    assert sha(r["level"]) == G2["lba"]["level_sha"] and sha(r["bad"]) == G2["lba"]["bad_sha"]
+    p = ba_synth.make_pose_problem()
+    n_good, pose, inl = orc.pose_only_optimize(p["Xw"], p["meas"], p["info"], p["sigma2"], p["pose"], p["fx"], p["fy"], p["cx"], p["cy"], p["bf"])
+    assert n_good == G2["pose_only"]["n_good"] and np.allclose(pose, G2["pose_only"]["pose"], rtol=0, atol=1e-9)
+    assert sha(inl.astype(np.uint8)) == G2["pose_only"]["inlier_sha"]
+    img = _color_image(3)
+    assert sha(img) == G2["glue"]["img_sha"]
+    assert sha(orc.cvt_gray(img, 1)) == G2["glue"]["gray_rgb_sha"] and sha(orc.cvt_gray(img, 2)) == G2["glue"]["gray_bgr_sha"]
+    K = np.array([TUM[q] for q in ("fx", "fy", "cx", "cy")], np.float32)
+    D = np.array([TUM[q] for q in ("k1", "k2", "p1", "p2", "k3")], np.float32)
+    pts = np.stack([np.linspace(30, 610, 40), np.linspace(25, 455, 40)[::-1]], 1).astype(np.float32)
+    assert sha(orc.undistort_points(pts, K, D)) == G2["glue"]["undistort_sha"]
+
+
+@pytest.mark.gpu
+def test_v2_device_against_golden():
+    from orb_slam2_ros2_amd._lib import Context
+    ctx = Context(640, 480, n_features=1000, max_images=1)
+    pr, fixed = _lba_problem()
+    _check_lba(ctx.ba_local_optimize(pr, fixed))
+    p = ba_synth.make_pose_problem()
+    n_good, pose, inl = ctx.pose_only_optimize(p["Xw"], p["meas"], p["info"], p["sigma2"], p["pose"], p["fx"], p["fy"], p["cx"], p["cy"], p["bf"])
+    assert abs(n_good - G2["pose_only"]["n_good"]) <= 1 and np.allclose(pose, G2["pose_only"]["pose"], rtol=0, atol=1e-6)
+    img = _color_image(3)
+    ctx.extract_color(img, 1)
+    assert sha(ctx.pyramid(0, 0, False)) == G2["glue"]["gray_rgb_sha"]
+    ctx.extract_color(img, 2)
+    assert sha(ctx.pyramid(0, 0, False)) == G2["glue"]["gray_bgr_sha"]
+    ctx.close()
