@@ -265,6 +265,8 @@ typedef enum orbfe_stage {
   ORBFE_STAGE_BA = 7,
   ORBFE_STAGE_COUNT = 8
 } orbfe_stage;
+/* on = 0: off.  on = 1: every stage timed ALONE (the overlaps between streams and the graph replay are switched off, kernels run in
+ * line).  on = 2 + stage: only that stage is timed, inside the production schedule (what rocprofv3 sees for its kernels).            */
 orbfe_status orbfe_profile_enable(orbfe_ctx* ctx, int32_t on);
 orbfe_status orbfe_profile_read(orbfe_ctx* ctx, double* ms /*[ORBFE_STAGE_COUNT]*/, int64_t* launches /*[..]*/, int32_t reset);
 const char* orbfe_stage_name(int32_t stage);

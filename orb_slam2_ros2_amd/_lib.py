@@ -398,6 +398,7 @@ class Context:
 
     # ---- instrumentation ------------------------------------------------------------------------
     def profile_enable(self, on=True):
+        """False / 0: off, True / 1: every stage timed alone, 2 + stage id: that stage only, in the production schedule"""
         self._check(self.lib.orbfe_profile_enable(self.h, int(on)))
 
     def profile_read(self, reset=True):

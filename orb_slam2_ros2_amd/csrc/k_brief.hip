@@ -287,10 +287,11 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
                          int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx, short2* d_env, int n_chunks,
-                         uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief) {
+                         uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief, hipEvent_t before_lists) {
   if (n_img <= 0 || n_features <= 0) return;
   UmaxPacked u = 0;
   for (int i = 0; i < 16; ++i) u |= (unsigned long long)(umax[i] & 15) << (4 * i);
+  if (before_lists) (void)hipStreamWaitEvent(s, before_lists, 0);  // the previous batch's stereo match still reads these arrays
   hipLaunchKernelGGL(k_kplist, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, n_levels, d_sel, d_sel_count, n_features,
                      d_kpl, d_n_kp);
   hipLaunchKernelGGL(k_ic_moments, dim3((n_features + 15) / 16, n_img), dim3(256), 0, s, d_pyr, img_pitch, d_kpl, n_features, u,

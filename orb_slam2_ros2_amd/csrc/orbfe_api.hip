@@ -39,7 +39,7 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
                          int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx, short2* d_env, int n_chunks,
-                         uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief);
+                         uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief, hipEvent_t before_lists);
 // k_match.hip
 void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, const uint32_t* d_off,
                              const uint32_t* d_cand, int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second);
@@ -116,6 +116,12 @@ struct orbfe_ctx {
   };
   std::vector<GraphEntry> graphs;
   bool use_graphs = true;
+  // the stereo match of a device-resident batch runs on its own stream: it is latency-bound and reads only the keypoint /
+  // descriptor arrays and the pyramid, so the NEXT batch's copy-in, resize and FAST (second pyramid buffer) run under it
+  uint8_t* d_pyr_alt = nullptr;
+  hipStream_t stereo_stream = nullptr;
+  hipEvent_t ev_brief_done = nullptr, ev_stereo_done = nullptr;
+  bool stereo_pending = false, pipeline_stereo = true;
   hipStream_t blur_stream = nullptr;
   hipEvent_t ev_blur_go = nullptr, ev_blur_done = nullptr;
 
@@ -167,7 +173,7 @@ struct orbfe_ctx {
   size_t h_stage_bytes = 0;
 
   // profiling
-  bool prof = false;
+  int prof = 0;  // 0 off | 1 every stage timed alone (overlaps and graphs off) | 2..: only stage (prof - 2) timed, in the production schedule
   hipEvent_t ev[2 * ORBFE_STAGE_COUNT];
   bool ev_init = false;
   double stage_ms[ORBFE_STAGE_COUNT];
@@ -486,13 +492,15 @@ static orbfe_status ensure_stage(orbfe_ctx* c, size_t bytes) {
 }
 
 // ---- stage timing ---------------------------------------------------------------------------------
+static inline bool timed(const orbfe_ctx* c, int stage) { return c->prof == 1 || c->prof == stage + 2; }
+
 struct StageTimer {
   orbfe_ctx* c;
   int stage;
   hipEvent_t a = nullptr, b = nullptr;
   hipStream_t stream;
   StageTimer(orbfe_ctx* ctx, int st, hipStream_t s) : c(ctx), stage(st), stream(s) {
-    if (!c->prof) return;
+    if (!timed(c, st)) return;
     auto get = [&]() {
       hipEvent_t e = nullptr;
       if (!c->ev_pool.empty()) {
@@ -507,7 +515,7 @@ struct StageTimer {
     if (a) (void)hipEventRecord(a, stream);
   }
   ~StageTimer() {
-    if (!c->prof || !a || !b) return;
+    if (!a || !b) return;
     (void)hipEventRecord(b, stream);
     c->pending.push_back({stage, {a, b}});
   }
@@ -526,9 +534,21 @@ static void drain_timers(orbfe_ctx* c) {
   c->pending.clear();
 }
 
+// make the context stream wait for a stereo match still running on the stereo stream (every entry point that reads or
+// rewrites per-slot data calls this first; the pipelined batch call places the wait later, see run_extract)
+static orbfe_status join_stereo(orbfe_ctx* c) {
+  if (c->stereo_pending) {
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_stereo_done, 0));
+    c->stereo_pending = false;
+  }
+  return ORBFE_OK;
+}
+
 // ---- the launch sequence for slots [0, n_img) ---------------------------------------------------------
 // Slots [img0, img0 + n_img) on stream `st`.  Every per-image array is offset on the host, so the kernels index from 0.
-static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, int lds_share = 1) {
+static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, int lds_share = 1, hipEvent_t before_lists = nullptr) {
+  // before_lists: event the keypoint-list / orientation / descriptor kernels must wait for (the previous batch's stereo match still
+  // reads the arrays they rewrite); callers that do not pipeline have joined the stereo stream already
   const int nl = c->cfg.n_levels;
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
   const size_t i0 = (size_t)img0;
@@ -545,7 +565,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   // context, the blur stays in line.  (Measured and dropped: starting each level's quadtree under FAST of the smaller levels on
   // a third stream -- the tree waves then share their SIMDs with a VALU-saturating kernel and the dependent chain stretches:
   // 3.04 -> 4.6 ms per 128 pairs.)
-  const bool overlap_blur = c->blur_stream && !c->prof && lds_share == 1 && n_img >= 32;  // a frame or two: nothing to hide, only event latency to add
+  const bool overlap_blur = c->blur_stream && c->prof != 1 && lds_share == 1 && n_img >= 32;  // a frame or two: nothing to hide, only event latency to add
   if (!overlap_blur) {
     StageTimer t(c, ORBFE_STAGE_BLUR, st);
     launch_blur(st, c->d_lv, nl, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
@@ -559,7 +579,10 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   if (overlap_blur) {
     HIP_TRY(c, hipEventRecord(c->ev_blur_go, st));
     HIP_TRY(c, hipStreamWaitEvent(c->blur_stream, c->ev_blur_go, 0));
-    launch_blur(c->blur_stream, c->d_lv, nl, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
+    {
+      StageTimer t(c, ORBFE_STAGE_BLUR, c->blur_stream);  // (events on the stream the kernel is launched on)
+      launch_blur(c->blur_stream, c->d_lv, nl, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
+    }
     HIP_TRY(c, hipEventRecord(c->ev_blur_done, c->blur_stream));
   }
   {
@@ -586,7 +609,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
                         c->d_pattern, c->umax, c->d_kps + i0 * NF, c->d_desc + i0 * NF * 32, c->d_aux + i0 * NF, c->d_n_kp + i0,
                         c->d_theta + i0 * NF, c->d_moments + i0 * NF, c->d_sincos + i0 * NF, c->d_kx + i0 * NF,
                         c->d_env + i0 * c->n_chunks, c->n_chunks, c->d_kpl + i0 * NF, c->cfg.height, n_img,
-                        overlap_blur ? c->ev_blur_done : nullptr);
+                        overlap_blur ? c->ev_blur_done : nullptr, before_lists);
   }
   HIP_TRY(c, hipGetLastError());
   return ORBFE_OK;
@@ -594,6 +617,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
 
 static orbfe_status run_stereo(orbfe_ctx* c, hipStream_t st, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs, float fx,
                                float bf) {
+  // (c->d_pyr is read here, at launch time: a later swap of the pyramid buffers does not affect a launch already queued)
   HIP_TRY(c, hipMemsetAsync(c->d_n_match + pair0, 0, sizeof(int32_t) * n_pairs, st));
   {
     StageTimer t(c, ORBFE_STAGE_STEREO, st);
@@ -621,6 +645,8 @@ const char* orbfe_stage_name(int32_t stage) {
 void orbfe_destroy(orbfe_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
+  if (c->stereo_stream) (void)hipStreamSynchronize(c->stereo_stream);
+  if (c->blur_stream) (void)hipStreamSynchronize(c->blur_stream);
   if (c->stream) hipStreamSynchronize(c->stream);
   drain_timers(c);
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
@@ -642,6 +668,10 @@ void orbfe_destroy(orbfe_ctx* c) {
   if (c->ev_blur_go) (void)hipEventDestroy(c->ev_blur_go);
   if (c->ev_blur_done) (void)hipEventDestroy(c->ev_blur_done);
   if (c->blur_stream) (void)hipStreamDestroy(c->blur_stream);
+  if (c->stereo_stream) (void)hipStreamDestroy(c->stereo_stream);
+  if (c->ev_brief_done) (void)hipEventDestroy(c->ev_brief_done);
+  if (c->ev_stereo_done) (void)hipEventDestroy(c->ev_stereo_done);
+  if (c->d_pyr_alt) (void)hipFree(c->d_pyr_alt);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -704,6 +734,17 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
       return bail(ORBFE_EDEVICE);
     }
     if (const char* gr = getenv("ORBFE_GRAPHS")) c->use_graphs = atoi(gr) != 0;
+    {
+      const char* ps = getenv("ORBFE_PIPELINE_STEREO");
+      c->pipeline_stereo = !ps || atoi(ps) != 0;
+      if (c->pipeline_stereo &&
+          (hipStreamCreateWithFlags(&c->stereo_stream, hipStreamNonBlocking) != hipSuccess ||
+           hipEventCreateWithFlags(&c->ev_brief_done, hipEventDisableTiming) != hipSuccess ||
+           hipEventCreateWithFlags(&c->ev_stereo_done, hipEventDisableTiming) != hipSuccess)) {
+        fail(c, ORBFE_EDEVICE, "cannot create the stereo stream");
+        return bail(ORBFE_EDEVICE);
+      }
+    }
     const char* ov = getenv("ORBFE_OVERLAP_BLUR");
     if (!ov || atoi(ov) != 0) {
       if (hipStreamCreateWithFlags(&c->blur_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -813,6 +854,7 @@ int32_t orbfe_get_capacity(const orbfe_ctx* c) { return c ? c->kp_cap : 0; }
 orbfe_status orbfe_sync(orbfe_ctx* c) {
   if (!c) return ORBFE_EBADARG;
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_timers(c);
   return ORBFE_OK;
@@ -821,6 +863,7 @@ orbfe_status orbfe_sync(orbfe_ctx* c) {
 orbfe_status orbfe_fetch_features(orbfe_ctx* c, int32_t slot, orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out) {
   if (!c || slot < 0 || slot >= c->cfg.max_images) return fail(c, ORBFE_EBADARG, "fetch_features: slot %d", slot);
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
   const size_t NF = (size_t)c->cfg.n_features;
   int32_t n = 0;
   HIP_TRY(c, hipMemcpyAsync(c->h_counts, c->d_n_kp + slot, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -839,6 +882,7 @@ orbfe_status orbfe_fetch_stereo(orbfe_ctx* c, int32_t pair, double* right_u, dou
                                 int32_t* best_dist) {
   if (!c || pair < 0 || pair >= (c->cfg.max_images + 1) / 2) return fail(c, ORBFE_EBADARG, "fetch_stereo: pair %d", pair);
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
   const size_t NF = (size_t)c->cfg.n_features;
   const size_t o = (size_t)pair * NF;
   const size_t o_ru = 0, o_dp = align_up(NF * 8, 256), o_br = o_dp + align_up(NF * 8, 256), o_bd = o_br + align_up(NF * 4, 256),
@@ -910,6 +954,7 @@ orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* con
   if (stride < (size_t)c->cfg.width) return fail(c, ORBFE_EBADARG, "extract_batch: stride %zu < width %d", stride, c->cfg.width);
   if (n_img == 0) return ORBFE_OK;
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
   const LevelDev& L0 = c->lv[0];
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
   const size_t plane = align_up((size_t)L0.stride * L0.h, 256);
@@ -928,7 +973,7 @@ orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* con
     TRY(run_extract(c, c->stream, 0, n_img));
     return enqueue_fetch(c, n_img, o_kps, o_desc, o_cnt, kps != nullptr, desc != nullptr);
   };
-  if (c->use_graphs && !c->prof && n_img <= 2) {
+  if (c->use_graphs && c->prof == 0 && n_img <= 2) {
     hipGraphExec_t exec = nullptr;
     for (auto it = c->graphs.begin(); it != c->graphs.end();) {
       if (it->stage != c->h_stage) {  // the staging buffer was re-allocated: the captured addresses are stale
@@ -974,6 +1019,7 @@ orbfe_status orbfe_extract_color(orbfe_ctx* c, const uint8_t* img, size_t stride
   if (color_order != 1 && color_order != 2) return fail(c, ORBFE_EBADARG, "extract_color: color_order %d (1 = RGB, 2 = BGR)", color_order);
   if (stride < (size_t)c->cfg.width * 3) return fail(c, ORBFE_EBADARG, "extract_color: stride %zu < 3 * width", stride);
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
   const LevelDev& L0 = c->lv[0];
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
   const size_t row = align_up((size_t)c->cfg.width * 3, 16) + 16;  // 4-aligned rows with room for the last 12-byte group
@@ -996,6 +1042,7 @@ orbfe_status orbfe_frame_rgbd(orbfe_ctx* c, int32_t slot, const orbfe_camera* ca
   if (depth && (depth_type < 0 || depth_type > 1 || depth_stride < (size_t)c->cfg.width * px || !(depth_scale > 0)))
     return fail(c, ORBFE_EBADARG, "frame_rgbd: depth type %d stride %zu scale %g", depth_type, depth_stride, (double)depth_scale);
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
   const size_t d_bytes = depth ? depth_stride * (size_t)c->cfg.height : 0;
   const size_t o_img = 0, o_d = align_up(d_bytes, 256), o_ru = o_d + align_up(NF * 8, 256), total = o_ru + align_up(NF * 8, 256);
@@ -1022,6 +1069,7 @@ orbfe_status orbfe_get_pyramid(orbfe_ctx* c, int32_t slot, int32_t level, int32_
   if (!c || !dst || slot < 0 || slot >= c->cfg.max_images || level < 0 || level >= c->cfg.n_levels)
     return fail(c, ORBFE_EBADARG, "get_pyramid: slot %d level %d", slot, level);
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
   const LevelDev& L = c->lv[level];
   const uint8_t* src = (blurred ? c->d_blur : c->d_pyr) + (size_t)slot * c->img_pitch + L.plane_off;
   HIP_TRY(c, hipMemcpy2DAsync(dst, L.w, src, L.stride, L.w, L.h, hipMemcpyDeviceToHost, c->stream));
@@ -1034,6 +1082,7 @@ orbfe_status orbfe_stereo_match(orbfe_ctx* c, int32_t slot_left, int32_t slot_ri
   if (!c || slot_left < 0 || slot_right < 0 || slot_left >= c->cfg.max_images || slot_right >= c->cfg.max_images)
     return fail(c, ORBFE_EBADARG, "stereo_match: slots %d/%d", slot_left, slot_right);
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
   const int pair = slot_left / 2;
   TRY(run_stereo(c, c->stream, slot_left, slot_right, 0, pair, 1, fx, bf));
   return orbfe_fetch_stereo(c, pair, right_u, depth, n_matches, best_right, best_dist);
@@ -1053,7 +1102,26 @@ orbfe_status orbfe_stereo_batch_device(orbfe_ctx* c, const uint8_t* d_left, cons
   // other chunks fill it.  With stage timing enabled the same chunks run one after the other on the main stream, so
   // that every kernel is timed alone with the launch shape of the production path.
   const int n_chunks = std::min<int>(c->n_side, std::max(1, n_pairs / 8));
-  const bool serial = c->prof || n_chunks == 1;
+  const bool serial = c->prof == 1 || n_chunks == 1;
+  // One chunk (the default): the stereo match goes to its own stream and this call returns with it still queued; the next call
+  // starts its copy-in / resize / FAST on the context stream right away, into the OTHER pyramid buffer, and only its keypoint-list
+  // kernels wait for the match (they rewrite what it reads).  Every other entry point joins the stereo stream first.
+  const bool pipe = c->pipeline_stereo && c->stereo_stream && c->prof != 1 && n_chunks == 1 && n_pairs >= 16;
+  if (pipe) {
+    if (!c->d_pyr_alt) {
+      if (hipMalloc((void**)&c->d_pyr_alt, (size_t)c->cfg.max_images * c->img_pitch) != hipSuccess ||
+          hipMemset(c->d_pyr_alt, 0, (size_t)c->cfg.max_images * c->img_pitch) != hipSuccess) {
+        (void)hipGetLastError();
+        c->d_pyr_alt = nullptr;
+        c->pipeline_stereo = false;  // no room for the second pyramid: plain in-order execution
+      }
+    }
+  }
+  const bool piped = pipe && c->d_pyr_alt;
+  if (piped)
+    std::swap(c->d_pyr, c->d_pyr_alt);
+  else
+    TRY(join_stereo(c));
   HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
   for (int k = 0; k < n_chunks; ++k) {
     const int p0 = (int)((long long)n_pairs * k / n_chunks), p1 = (int)((long long)n_pairs * (k + 1) / n_chunks);
@@ -1065,8 +1133,16 @@ orbfe_status orbfe_stereo_batch_device(orbfe_ctx* c, const uint8_t* d_left, cons
                        c->cfg.width, c->cfg.height, 2 * p0, 2, p1 - p0);
     launch_load_level0(st, d_right + (size_t)p0 * image_pitch, stride, image_pitch, c->d_pyr, c->img_pitch, L0.plane_off, L0.stride,
                        c->cfg.width, c->cfg.height, 2 * p0 + 1, 2, p1 - p0);
-    TRY(run_extract(c, st, 2 * p0, 2 * (p1 - p0), serial ? 1 : n_chunks));
-    TRY(run_stereo(c, st, 2 * p0, 2 * p0 + 1, 2, p0, p1 - p0, fx, bf));
+    TRY(run_extract(c, st, 2 * p0, 2 * (p1 - p0), serial ? 1 : n_chunks, (piped && c->stereo_pending) ? c->ev_stereo_done : nullptr));
+    if (piped) {
+      HIP_TRY(c, hipEventRecord(c->ev_brief_done, st));
+      HIP_TRY(c, hipStreamWaitEvent(c->stereo_stream, c->ev_brief_done, 0));
+      TRY(run_stereo(c, c->stereo_stream, 2 * p0, 2 * p0 + 1, 2, p0, p1 - p0, fx, bf));
+      HIP_TRY(c, hipEventRecord(c->ev_stereo_done, c->stereo_stream));
+      c->stereo_pending = true;
+    } else {
+      TRY(run_stereo(c, st, 2 * p0, 2 * p0 + 1, 2, p0, p1 - p0, fx, bf));
+    }
     if (!serial) {
       HIP_TRY(c, hipEventRecord(c->ev_join[k], st));
       HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join[k], 0));
@@ -1082,6 +1158,7 @@ orbfe_status orbfe_match_bruteforce(orbfe_ctx* c, const uint8_t* q, int32_t nq, 
   if (cand_offsets && !cand_idx && cand_offsets[nq] > 0) return fail(c, ORBFE_EBADARG, "match_bruteforce: cand_idx is NULL");
   if (nq == 0) return ORBFE_OK;
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
   const size_t n_cand = cand_offsets ? cand_offsets[nq] : 0;
   if (cand_offsets)
     for (size_t i = 0; i < n_cand; ++i)
@@ -1123,6 +1200,7 @@ orbfe_status orbfe_ba_eval_edges(orbfe_ctx* c, const orbfe_ba_problem* p, const 
     if (p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_poses || p->edge_point[e] < 0 || p->edge_point[e] >= p->n_points)
       return fail(c, ORBFE_EBADARG, "ba_eval_edges: edge %d references vertex out of range", e);
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o2 = off;
@@ -1175,6 +1253,7 @@ orbfe_status orbfe_ba_build_system(orbfe_ctx* c, const orbfe_ba_problem* p, cons
     if (p->edge_pose[e] < 0 || p->edge_pose[e] >= NK || p->edge_point[e] < 0 || p->edge_point[e] >= NP)
       return fail(c, ORBFE_EBADARG, "ba_build_system: edge %d references vertex out of range", e);
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
   // vertex -> edges lists, edges in ascending index (counting sort): the summation order of the segmented reductions
   std::vector<int32_t> pt_off(NP + 1, 0), ps_off(NK + 1, 0), pt_edges(std::max(E, 1)), ps_edges(std::max(E, 1));
   for (int e = 0; e < E; ++e) {
@@ -1306,6 +1385,7 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
       }
   }
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o2 = off;
@@ -1477,6 +1557,7 @@ orbfe_status orbfe_search_in_area(orbfe_ctx* c, int32_t slot, int32_t nq, const 
     return fail(c, ORBFE_EBADARG, "search_in_area: NULL argument");
   if (nq == 0) return ORBFE_OK;
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
   const int rows = (c->cfg.height + 47) / 48, cols = (c->cfg.width + 63) / 64;  // cvCeil((float)(max-min)/grid), Frame.cc:55-56
   const size_t ncells = (size_t)rows * cols;
@@ -1522,6 +1603,7 @@ orbfe_status orbfe_pose_only_optimize(orbfe_ctx* c, int32_t n, const double* xw,
   if (!c || n < 0 || !pose_in || !pose_out || !n_good || (n && (!xw || !meas || !info || !sigma2)))
     return fail(c, ORBFE_EBADARG, "pose_only_optimize: NULL argument");
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
   const size_t N = (size_t)std::max(n, 1);
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -1559,15 +1641,17 @@ orbfe_status orbfe_pose_only_optimize(orbfe_ctx* c, int32_t n, const double* xw,
 orbfe_status orbfe_profile_enable(orbfe_ctx* c, int32_t on) {
   if (!c) return ORBFE_EBADARG;
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_timers(c);
-  c->prof = on != 0;
+  c->prof = on < 0 ? 0 : on;
   return ORBFE_OK;
 }
 
 orbfe_status orbfe_profile_read(orbfe_ctx* c, double* ms, int64_t* launches, int32_t reset) {
   if (!c) return ORBFE_EBADARG;
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_timers(c);
   for (int i = 0; i < ORBFE_STAGE_COUNT; ++i) {
@@ -1585,6 +1669,7 @@ orbfe_status orbfe_debug_candidates(orbfe_ctx* c, int32_t slot, int32_t level, f
   if (!c || slot < 0 || slot >= c->cfg.max_images || level < 0 || level >= c->cfg.n_levels || !n_out)
     return fail(c, ORBFE_EBADARG, "debug_candidates: bad argument");
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
   const LevelDev& L = c->lv[level];
   int32_t n = 0;
   HIP_TRY(c, hipMemcpyAsync(&n, c->d_n_cand + (size_t)slot * c->cfg.n_levels + level, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));

@@ -367,3 +367,42 @@ def test_tiny_nfeatures_can_yield_more_keypoints_than_asked(orc, lib, nf):
     ok, _ = assert_image_parity(ctx, 0, orc.extractor(img, n_features=nf), k, d, 8, check_planes=False)
     assert len(ok) > nf and len(ok) <= ctx.n_features
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_back_to_back_device_batches_overlap_safely(orc, lib):
+    """Consecutive orbfe_stereo_batch_device calls are pipelined (the stereo match of batch k runs on its own stream under the front
+    of batch k+1, two pyramid buffers): the results of the LAST batch must be those of that batch alone, whatever ran before, and
+    every other entry point must see a quiesced context."""
+    import torch
+    B = 16
+    sets = [[synth.stereo_pair(4 * s + i) for i in range(4)] for s in range(3)]
+
+    def dev(pairs):
+        l = torch.from_numpy(np.stack([pairs[i % 4][0] for i in range(B)])).cuda()
+        r = torch.from_numpy(np.stack([pairs[i % 4][1] for i in range(B)])).cuda()
+        return l, r
+    bufs = [dev(p) for p in sets]
+    ctx = lib.Context(1241, 376, max_images=2 * B)
+    for _ in range(2):                                          # twice: both pyramid buffers get used in both roles
+        for l, r in bufs:                                       # three batches back to back, no synchronisation in between
+            ctx.stereo_batch_device(l.data_ptr(), r.data_ptr(), 1241, 1241 * 376, B, FX, BF)
+        for i in (0, 3, B - 1):                                 # the last batch (sets[2]) is what the slots hold
+            ref = orc.stereo_frame(*sets[2][i % 4], fx=FX, bf=BF)
+            k, d = ctx.fetch_features(2 * i)
+            nm, ru, dp, _, _ = ctx.fetch_stereo(i)
+            n = len(ref["lk"])
+            assert np.array_equal(k, ref["lk"]) and np.array_equal(d, ref["ld"]) and nm == ref["n_matches"]
+            assert np.array_equal(ru[:n], ref["right_u"]) and np.array_equal(dp[:n], ref["depth"])
+            assert np.array_equal(ctx.pyramid(2 * i, 1, False), orc.extractor(sets[2][i % 4][0]).plane(1, False))
+    # a host-pointer call right after a queued batch (joins the stereo stream first), then another batch
+    l, r = bufs[0]
+    ctx.stereo_batch_device(l.data_ptr(), r.data_ptr(), 1241, 1241 * 376, B, FX, BF)
+    (k0, d0), (k1, d1) = ctx.extract_batch([sets[1][0][0], sets[1][0][1]])
+    ref = orc.stereo_frame(*sets[1][0], fx=FX, bf=BF)
+    assert np.array_equal(k0, ref["lk"]) and np.array_equal(d1, ref["rd"])
+    nm, ru, dp, _, _ = ctx.stereo_match(0, 1, FX, BF)
+    assert nm == ref["n_matches"]
+    nm5 = ctx.fetch_stereo(5)[0]
+    assert nm5 == orc.stereo_frame(*sets[0][5 % 4], fx=FX, bf=BF)["n_matches"]   # pair 5 of the batch is untouched by the host call
+    ctx.close()
