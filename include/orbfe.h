@@ -251,6 +251,60 @@ orbfe_status orbfe_frame_rgbd(orbfe_ctx* ctx, int32_t slot, const orbfe_camera* 
                               size_t depth_stride_bytes, float depth_scale, orbfe_keypoint* kps_undistorted, double* depth_out,
                               double* right_u_out);
 
+/* ---- map.pb: the reference's on-disk map, and a local bundle adjustment on it -------------------------------
+ * `orbslam2.MapData` as Map::saveToProtobuf writes it (src/Map.cc:200-250; proto/Map.proto, Keyframe.proto,
+ * MapPoint.proto), read and written without libprotobuf (host/map_pb.hpp).  The first three calls are host-only
+ * (no context, no device).  Output buffers follow the "size query" convention: *out_len receives the size needed;
+ * with out == NULL or cap too small nothing is written and ORBFE_ECAPACITY is returned (ORBFE_OK for out == NULL). */
+typedef struct orbfe_map_summary {
+  uint64_t next_id;        /* KeyFrameList.next_id (KeyFrame::mnNextId)                                   */
+  int32_t n_scale_factors; /* KeyFrameList.scale_factors (KeyFrame::mvfScaledFactors)                     */
+  int32_t n_keyframes, n_mappoints;
+  int64_t n_keypoints;     /* over all keyframes                                                          */
+  int64_t n_observations;  /* keypoints that carry a map point id (map_points[i] != -1)                   */
+} orbfe_map_summary;
+/* Map::loadFromProtobuf's parse (src/Map.cc:263-267); ORBFE_EBADARG for a malformed file                  */
+orbfe_status orbfe_map_pb_summary(const uint8_t* pb, size_t len, orbfe_map_summary* out);
+/* parse + serialise: the canonical encoding libprotobuf's C++ serialiser produces for the same content    */
+orbfe_status orbfe_map_pb_reencode(const uint8_t* pb, size_t len, uint8_t* out, size_t cap, size_t* out_len);
+
+/* The graph Optimizer::OptimizeLocalMap builds around keyframe kf_id (src/Optimizer.cc:232-330): vertices =
+ * [covisible keyframes (weight > 15, descending) + kf_id | fixed observers], map points of the free group in
+ * ascending id, one edge per observation (stereo iff right_u > 0; information getScaledFactorInv2 / Inv, quirk Q9).
+ * sizes[4] = {n_poses, n_group, n_points, n_edges}; every array pointer may be NULL (size query), else it must
+ * hold the counts a previous call returned.                                                                  */
+typedef struct orbfe_map_graph {
+  uint64_t* pose_kf_id;  /* [n_poses]                                                                       */
+  uint8_t* pose_fixed;   /* [n_poses]  setFixed                                                             */
+  double* poses;         /* [n_poses][7] Converter::ConvertTcw2SE3                                          */
+  uint64_t* point_id;    /* [n_points]                                                                      */
+  double* points;        /* [n_points][3]                                                                   */
+  int32_t* edge_pose;    /* [n_edges] vertex index                                                          */
+  int32_t* edge_point;   /* [n_edges] point index                                                           */
+  int32_t* edge_feat;    /* [n_edges] keypoint index inside the observing keyframe                          */
+  double* meas;          /* [n_edges][3]                                                                    */
+  uint8_t* is_stereo;    /* [n_edges]                                                                       */
+  double* info;          /* [n_edges]                                                                       */
+  double* huber_delta;   /* [n_edges]                                                                       */
+} orbfe_map_graph;
+orbfe_status orbfe_map_local_graph(const uint8_t* pb, size_t len, uint64_t kf_id, int32_t sizes[4], const orbfe_map_graph* out);
+
+/* Optimizer::OptimizeLocalMap(kf, isStop) (src/Optimizer.cc:225-441) on a map file: graph as above, the two
+ * optimize() rounds on the device (orbfe_ba_local_optimize), then the reference's write-back policy (:363-441):
+ * outlier observations erased and poses / points stored as float unless more than 20 % of the affected keyframes
+ * would lose more than 30 % of their map points.  Camera::mfFx.. come from `cam` (fx fy cx cy bf).  Output: the
+ * updated map.pb.  MapPoint::updateDescriptor / updateNormalAndDepth and KeyFrame::updateConnections (:436-440)
+ * are map bookkeeping and are NOT applied.                                                                   */
+typedef struct orbfe_map_ba_report {
+  int32_t n_poses, n_group, n_points, n_edges;
+  int32_t n_outlier_edges, n_keyframes_hit, n_bad_keyframes, written;
+  int32_t iterations[2];
+  double chi2_before, chi2_after; /* sum of robustified-free chi2 over all edges at the initial / final estimates */
+} orbfe_map_ba_report;
+orbfe_status orbfe_map_local_ba(orbfe_ctx* ctx, const uint8_t* pb, size_t len, uint64_t kf_id, const orbfe_camera* cam,
+                                const volatile int32_t* stop_flag, uint8_t* out, size_t cap, size_t* out_len,
+                                orbfe_map_ba_report* report);
+
 /* ---- instrumentation ---------------------------------------------------------------------------
  * Stage timing with HIP events on the context stream.  Enable, run, then read the accumulated
  * per-stage milliseconds and launch counts.  Stage ids: see orbfe_stage.                             */

@@ -66,6 +66,22 @@ class BaOptimizeOut(C.Structure):
                 ("iterations", C.c_void_p)]
 
 
+class MapSummary(C.Structure):
+    _fields_ = [("next_id", C.c_uint64), ("n_scale_factors", C.c_int32), ("n_keyframes", C.c_int32), ("n_mappoints", C.c_int32),
+                ("n_keypoints", C.c_int64), ("n_observations", C.c_int64)]
+
+
+class MapGraph(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("pose_kf_id", "pose_fixed", "poses", "point_id", "points", "edge_pose", "edge_point",
+                                          "edge_feat", "meas", "is_stereo", "info", "huber_delta")]
+
+
+class MapBaReport(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("n_poses", "n_group", "n_points", "n_edges", "n_outlier_edges", "n_keyframes_hit",
+                                         "n_bad_keyframes", "written")] + [("iterations", C.c_int32 * 2),
+                                                                           ("chi2_before", C.c_double), ("chi2_after", C.c_double)]
+
+
 class BaEdgeOut(C.Structure):
     _fields_ = [("error", C.c_void_p), ("chi2", C.c_void_p), ("rho", C.c_void_p), ("j_point", C.c_void_p),
                 ("j_pose", C.c_void_p), ("depth_positive", C.c_void_p)]
@@ -76,6 +92,7 @@ EXPORTS = [
     "orbfe_get_capacity",
     "orbfe_extract", "orbfe_extract_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
     "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_extract_color", "orbfe_frame_rgbd",
+    "orbfe_map_pb_summary", "orbfe_map_pb_reencode", "orbfe_map_local_graph", "orbfe_map_local_ba",
     "orbfe_profile_enable", "orbfe_profile_read", "orbfe_stage_name", "orbfe_debug_candidates",
 ]
 
@@ -126,6 +143,11 @@ def load() -> C.CDLL:
     L.orbfe_search_in_area.argtypes = [vp, i32, i32] + [vp] * 10
     L.orbfe_extract_color.argtypes = [vp, vp, C.c_size_t, i32, vp, vp, vp]
     L.orbfe_frame_rgbd.argtypes = [vp, i32, C.POINTER(Camera), vp, i32, C.c_size_t, f32, vp, vp, vp]
+    L.orbfe_map_pb_summary.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(MapSummary)]
+    L.orbfe_map_pb_reencode.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.orbfe_map_local_graph.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.POINTER(i32 * 4), C.POINTER(MapGraph)]
+    L.orbfe_map_local_ba.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_uint64, C.POINTER(Camera), vp, vp, C.c_size_t,
+                                     C.POINTER(C.c_size_t), C.POINTER(MapBaReport)]
     L.orbfe_profile_enable.argtypes = [vp, i32]
     L.orbfe_profile_read.argtypes = [vp, vp, vp, i32]
     L.orbfe_stage_name.argtypes = [i32]
@@ -137,6 +159,43 @@ def load() -> C.CDLL:
 
 def ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---- map.pb (host-only entry points: no context, no device) ------------------------------------------
+def _status(st, what):
+    if st != 0:
+        raise RuntimeError(f"{what}: orbfe status {st}")
+
+
+def map_pb_summary(pb: bytes) -> dict:
+    """Counts of an `orbslam2.MapData` file as Map::loadFromProtobuf would read it (src/Map.cc:252-313)."""
+    s = MapSummary()
+    _status(load().orbfe_map_pb_summary(pb, len(pb), C.byref(s)), "map_pb_summary")
+    return {k: getattr(s, k) for k, _ in MapSummary._fields_}
+
+
+def map_pb_reencode(pb: bytes) -> bytes:
+    """Parse + serialise: the canonical libprotobuf encoding of the same content."""
+    L, n = load(), C.c_size_t(0)
+    _status(L.orbfe_map_pb_reencode(pb, len(pb), None, 0, C.byref(n)), "map_pb_reencode")
+    out = np.zeros(max(n.value, 1), np.uint8)
+    _status(L.orbfe_map_pb_reencode(pb, len(pb), ptr(out), out.size, C.byref(n)), "map_pb_reencode")
+    return out[:n.value].tobytes()
+
+
+def map_local_graph(pb: bytes, kf_id: int) -> dict:
+    """The graph Optimizer::OptimizeLocalMap builds around keyframe kf_id (src/Optimizer.cc:232-330)."""
+    L, sizes = load(), (C.c_int32 * 4)()
+    _status(L.orbfe_map_local_graph(pb, len(pb), kf_id, C.byref(sizes), None), "map_local_graph")
+    n_poses, n_group, n_points, n_edges = list(sizes)
+    g = dict(pose_kf_id=np.zeros(n_poses, np.uint64), pose_fixed=np.zeros(n_poses, np.uint8), poses=np.zeros((n_poses, 7)),
+             point_id=np.zeros(n_points, np.uint64), points=np.zeros((n_points, 3)), edge_pose=np.zeros(n_edges, np.int32),
+             edge_point=np.zeros(n_edges, np.int32), edge_feat=np.zeros(n_edges, np.int32), meas=np.zeros((n_edges, 3)),
+             is_stereo=np.zeros(n_edges, np.uint8), info=np.zeros(n_edges), huber_delta=np.zeros(n_edges))
+    mg = MapGraph(*[ptr(g[k]).value if g[k].size else None for k, _ in MapGraph._fields_])
+    _status(L.orbfe_map_local_graph(pb, len(pb), kf_id, C.byref(sizes), C.byref(mg)), "map_local_graph")
+    g["n_group"] = n_group
+    return g
 
 
 class Context:
@@ -356,6 +415,20 @@ class Context:
         for k in ("level", "chi2", "bad"):
             out[k] = out[k][:E]
         return out
+
+    def map_local_ba(self, pb: bytes, kf_id: int, fx, fy, cx, cy, bf):
+        """Optimizer::OptimizeLocalMap around keyframe kf_id of a map.pb -> (updated map.pb bytes, report dict)"""
+        cam = Camera(fx, fy, cx, cy, 0, 0, 0, 0, 0, bf)
+        n, rep = C.c_size_t(0), MapBaReport()
+        out = np.zeros(len(pb) + 4096, np.uint8)  # the result never grows: observations are only erased (-1 takes more bytes than an id, hence the slack)
+        st = self.lib.orbfe_map_local_ba(self.h, pb, len(pb), kf_id, C.byref(cam), None, ptr(out), out.size, C.byref(n), C.byref(rep))
+        if st == 4:  # ORBFE_ECAPACITY
+            out = np.zeros(n.value, np.uint8)
+            st = self.lib.orbfe_map_local_ba(self.h, pb, len(pb), kf_id, C.byref(cam), None, ptr(out), out.size, C.byref(n), C.byref(rep))
+        self._check(st)
+        r = {k: getattr(rep, k) for k, _ in MapBaReport._fields_ if k != "iterations"}
+        r["iterations"] = list(rep.iterations)
+        return out[:n.value].tobytes(), r
 
     def pose_only_optimize(self, Xw, meas, info, sigma2, pose, fx, fy, cx, cy, bf):
         Xw = np.ascontiguousarray(Xw, np.float64).reshape(-1, 3)

@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "../../include/orbfe.h"
+#include "map_pb.hpp"
 
 namespace orbfe {
 
@@ -403,6 +404,21 @@ class Optimizer {
     check(ctx, orbfe_ba_local_optimize(ctx, &prob, poseFixed.empty() ? nullptr : poseFixed.data(), 5, 10, isStop, &o));
     r.chi2.resize(prob.n_edges), r.level.resize(prob.n_edges), r.bad.resize(prob.n_edges);
     return r;
+  }
+  // Optimizer::OptimizeLocalMap(pkframe, isStop) (src/Optimizer.cc:225-441) on a map loaded from map.pb: graph construction,
+  // the two optimize() rounds on the device, the write-back policy; `map` is updated in place
+  static mappb::LocalBaReport OptimizeLocalMap(orbfe_ctx* ctx, mappb::MapRec& map, uint64_t kfId, const orbfe_camera& cam,
+                                               const volatile int32_t* isStop = nullptr) {
+    mappb::LocalGraph g;
+    if (!mappb::build_local_graph(map, kfId, g)) throw std::runtime_error("OptimizeLocalMap: keyframe id is not in the map");
+    orbfe_ba_problem p{};
+    p.n_poses = (int32_t)g.pose_kf_id.size(), p.n_points = (int32_t)g.point_id.size(), p.n_edges = (int32_t)g.edge_pose.size();
+    if (p.n_edges == 0) return mappb::LocalBaReport{p.n_poses, g.n_group, p.n_points, 0, 0, 0, 0, 0};
+    p.poses = g.poses.data(), p.points = g.points.data(), p.edge_pose = g.edge_pose.data(), p.edge_point = g.edge_point.data();
+    p.meas = g.meas.data(), p.is_stereo = g.is_stereo.data(), p.info = g.info.data(), p.huber_delta = g.huber.data();
+    p.fx = cam.fx, p.fy = cam.fy, p.cx = cam.cx, p.cy = cam.cy, p.bf = cam.bf;
+    const LocalMapResult r = OptimizeLocalMap(ctx, p, g.pose_fixed, isStop);
+    return mappb::apply_local_ba(map, g, r.poses.data(), r.points.data(), r.bad.data());
   }
   // the g2o part of Optimizer::OptimizePoseOnly (src/Optimizer.cc:33-178); returns edges - nBad, pose and inlier flags in place
   static int OptimizePoseOnly(orbfe_ctx* ctx, const std::vector<double>& pointsWorld, const std::vector<double>& meas /*u v uR*/,

@@ -107,8 +107,25 @@ int main(int argc, char** argv) {
       for (size_t i = 0; i < pts_true.size(); ++i) err = std::max(err, std::fabs(r.points[i] - pts_true[i]));
       int nbad = 0;
       for (uint8_t b : r.bad) nbad += b;
-      printf(" %.3e %d %d\n", err, nbad, r.iterations[0] + r.iterations[1]);
+      printf(" %.3e %d %d", err, nbad, r.iterations[0] + r.iterations[1]);
     }
+    if (argc >= 8) {  // <map.pb in> <keyframe id> <map.pb out>: Optimizer::OptimizeLocalMap on a map file through host/map_pb.hpp
+      std::vector<uint8_t> bytes;
+      FILE* mf = fopen(argv[5], "rb");
+      if (!mf) return 2;
+      for (int c; (c = fgetc(mf)) != EOF;) bytes.push_back((uint8_t)c);
+      fclose(mf);
+      orbfe::mappb::MapRec map;
+      if (!orbfe::mappb::parse(bytes.data(), bytes.size(), map)) return 2;
+      const orbfe_camera cam = {520.908620f, 521.007327f, 325.141442f, 249.701764f, 0, 0, 0, 0, 0, (float)(520.908620 * 0.0767889)};
+      const auto rep = orbfe::Optimizer::OptimizeLocalMap(el.context(), map, (uint64_t)atoll(argv[6]), cam);
+      const std::string out = orbfe::mappb::serialize(map);
+      mf = fopen(argv[7], "wb");
+      if (!mf || fwrite(out.data(), 1, out.size(), mf) != out.size()) return 2;
+      fclose(mf);
+      printf(" %d/%d/%d/%d/%d", rep.n_group, rep.n_points, rep.n_edges, rep.n_outlier_edges, rep.written);
+    }
+    printf("\n");
   } catch (const std::exception& e) {
     if (std::string(e.what()).find("no HIP device") != std::string::npos) {
       printf("NO_DEVICE\n");
