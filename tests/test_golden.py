@@ -78,6 +78,7 @@ def test_cfg5_ba(orc):
 
 
 # ---- golden_v2: the widened rows (local BA, pose-only, frame glue) ----------------------------------------------------------
+GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
 G2 = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_v2.json")))
 TUM = dict(fx=520.908620, fy=521.007327, cx=325.141442, cy=249.701764, k1=0.231222, k2=-0.784899, p1=-0.003257, p2=-0.000105, k3=0.917205, bf=40.0)
 
@@ -137,3 +138,24 @@ def test_v2_device_against_golden():
     ctx.extract_color(img, 2)
     assert sha(ctx.pyramid(0, 0, False)) == G2["glue"]["gray_bgr_sha"]
     ctx.close()
+
+
+def test_golden_map_pb_written_by_libprotobuf():
+    """tests/golden/map_small.pb was serialised by the real protobuf runtime (tools/make_golden_map.py): host/map_pb.hpp must read
+    it, write it back byte for byte, and build the local-map graph recorded next to it.  No protobuf import here."""
+    import hashlib
+
+    from orb_slam2_ros2_amd import _lib
+    pb = open(os.path.join(GOLDEN_DIR, "map_small.pb"), "rb").read()
+    meta = json.load(open(os.path.join(GOLDEN_DIR, "map_small.json")))
+    assert hashlib.sha256(pb).hexdigest() == meta["sha256"]
+    assert _lib.map_pb_summary(pb) == meta["summary"]
+    assert _lib.map_pb_reencode(pb) == pb
+    g = _lib.map_local_graph(pb, meta["graph_kf_id"])
+    for key, want in meta["graph"].items():
+        if key == "n_group":
+            assert g[key] == want
+        elif key in ("poses",):
+            assert np.abs(np.asarray(g[key]) - np.asarray(want)).max() < 1e-15
+        else:
+            assert (np.asarray(g[key]) == np.asarray(want, dtype=np.asarray(g[key]).dtype)).all(), key
