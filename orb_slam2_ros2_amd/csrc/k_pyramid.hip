@@ -105,85 +105,6 @@ __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv,
 }
 
 // ---------------------------------------------------------------------------------------------
-// resize, all levels in one pass over level 0: cv::resize takes every level from level 0 (quirk Q1), so a level-0 tile
-// staged once in LDS serves the outputs of ALL levels whose top-left source tap falls into it.  One block = one level-0 tile
-// of tw x th px (+ PF_HALO columns, + 1 row) and the x / y taps of its output ranges, requested in ONE round trip; the
-// outputs of the levels form one flattened list of words (4 px) that the 256 threads stride over, so the small levels do not
-// leave lanes idle.  Level 0 is read once instead of once per level (k_resize: 7x, the launch was fabric-bandwidth bound).
-// Same arithmetic as k_resize: bit-exact with it.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_resize_fused(const LevelDev* __restrict__ lv, const PfTile* __restrict__ tiles,
-                                                      const PfPart* __restrict__ parts, const ResizeTap* __restrict__ taps,
-                                                      uint8_t* __restrict__ pyr, size_t img_pitch, int nf, int tw, int th,
-                                                      int xt_cap) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t pf_lds[];
-  const int pitch = tw + PF_HALO;  // bytes per staged row (multiple of 16)
-  const int nq = pitch >> 4;
-  uint32_t* tile = pf_lds;
-  ResizeTap* xs = (ResizeTap*)(pf_lds + (pitch * (th + 1)) / 4);
-  ResizeTap* ys = xs + xt_cap;
-  __shared__ PfPart s_part[PF_MAX_PARTS];
-  const int img = blockIdx.y;
-  const PfTile T = tiles[blockIdx.x];
-  const PfPart* pp = parts + (size_t)blockIdx.x * nf;
-  const int sw = lv[0].w, sh = lv[0].h, sstride = lv[0].stride;
-  uint8_t* base = pyr + (size_t)img * img_pitch;
-  const uint8_t* S = base + lv[0].plane_off;
-  const int x0 = T.x0, y0 = T.y0;
-  // ---- stage: tile quads, taps, part table -- every load is issued before the one barrier ----
-  {
-    const uint32_t inv = ((1u << 20) + nq - 1) / nq;
-    const int q0 = x0 >> 4, q_last = (sstride >> 4) - 1;
-    uint4* tile4 = (uint4*)tile;
-    const int n_quads = nq * (th + 1);
-    for (int k = threadIdx.x; k < n_quads; k += 256) {
-      const int r = (int)(((uint32_t)k * inv) >> 20), c = k - r * nq;
-      const int sr = min(y0 + r, sh - 1), sq = min(q0 + c, q_last);
-      tile4[k] = *(const uint4*)(S + ((uint32_t)(sr * sstride) + 16u * (uint32_t)sq));
-    }
-    for (int q = 0; q < nf; ++q) {  // uniform loop: the part fields come through scalar loads
-      const PfPart P = pp[q];
-      const LevelDev& L = lv[q + 1];
-      const ResizeTap* xt = taps + L.xtab_off;
-      const ResizeTap* yt = taps + L.ytab_off;
-      for (int e = threadIdx.x; e < 4 * P.n_words; e += 256) xs[P.xt0 + e] = xt[min(P.dx0 + e, L.w - 1)];
-      for (int e = threadIdx.x; e < P.n_rows; e += 256) ys[P.yt0 + e] = yt[min(P.dy0 + e, L.h - 1)];
-    }
-    if ((int)threadIdx.x < nf) s_part[threadIdx.x] = pp[threadIdx.x];
-  }
-  __syncthreads();
-  typedef const __attribute__((address_space(3))) uint8_t* lds_bytes_t;
-  lds_bytes_t tb = (lds_bytes_t)tile;
-  int p = 0;
-  const int n_items = T.n_items;
-  for (int i = threadIdx.x; i < n_items; i += 256) {
-    while (p + 1 < nf && i >= (int)s_part[p + 1].item0) ++p;
-    const PfPart P = s_part[p];
-    const LevelDev& L = lv[p + 1];
-    const int local = i - (int)P.item0;
-    const int row = (int)(((uint32_t)local * P.inv_words) >> 20), word = local - row * P.n_words;
-    const ResizeTap ay = ys[P.yt0 + row];
-    const ResizeTap* ax = xs + P.xt0 + 4 * word;
-    const int sy0 = min(max(ay.ofs, 0), sh - 1), sy1 = min(max(ay.ofs + 1, 0), sh - 1);
-    const int o0 = (sy0 - y0) * pitch - x0, o1 = (sy1 - y0) * pitch - x0;
-    uint32_t out = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const ResizeTap a = ax[j];
-      const int sx0 = a.ofs;
-      const int sx1 = min(a.ofs + 1, sw - 1);  // tap c1 is 0 wherever the reference does not read S[sx+1]
-      const int p00 = tb[o0 + sx0], p01 = tb[o0 + sx1], p10 = tb[o1 + sx0], p11 = tb[o1 + sx1];
-      const int h0 = mad24u(p00, a.c0, mul24u(p01, a.c1));
-      const int h1 = mad24u(p10, a.c0, mul24u(p11, a.c1));
-      int v = ((mul24u((int)ay.c0, h0 >> 4) >> 16) + (mul24u((int)ay.c1, h1 >> 4) >> 16) + 2) >> 2;
-      v = min(255, max(0, v));
-      out |= (uint32_t)v << (8 * j);
-    }
-    *(uint32_t*)(base + L.plane_off + (size_t)(P.dy0 + row) * L.stride + (P.dx0 + 4 * word)) = out;  // row padding absorbs the tail
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // blur: separable 7-tap, 8.8 fixed point, BORDER_REFLECT_101 -- register sliding window, no LDS.
 //
 // One wave owns a column strip of 62 words (248 px) and BLUR_ROWS output rows.  Per input row a lane
@@ -367,14 +288,6 @@ void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, c
   if (n_tiles[2] > 0)
     hipLaunchKernelGGL((k_resize<16>), dim3(n_tiles[2], n_img), dim3(256), (size_t)lds_bytes[2] + extra, s, d_lv, t, d_taps, d_pyr, img_pitch,
                        lds_bytes[2]);
-}
-
-void launch_resize_fused(hipStream_t s, const LevelDev* d_lv, const PfTile* d_tiles, const PfPart* d_parts, int n_tiles, int nf, int tw,
-                         int th, int xt_cap, int yt_cap, const ResizeTap* d_taps, uint8_t* d_pyr, size_t img_pitch, int n_img) {
-  if (n_img <= 0 || n_tiles <= 0 || nf <= 0) return;
-  const size_t lds = (size_t)(tw + PF_HALO) * (th + 1) + (size_t)(xt_cap + yt_cap) * sizeof(ResizeTap);
-  hipLaunchKernelGGL(k_resize_fused, dim3(n_tiles, n_img), dim3(256), lds, s, d_lv, d_tiles, d_parts, d_taps, d_pyr, img_pitch, nf, tw, th,
-                     xt_cap);
 }
 
 void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int total_tiles, const uint8_t* d_pyr, uint8_t* d_blur,

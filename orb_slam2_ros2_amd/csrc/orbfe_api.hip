@@ -20,8 +20,6 @@ namespace orbfe {
 void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, const int* n_tiles, const int* lds_bytes,
                    const ResizeTap* d_taps, uint8_t* d_pyr,
                    size_t img_pitch, int n_img);
-void launch_resize_fused(hipStream_t s, const LevelDev* d_lv, const PfTile* d_tiles, const PfPart* d_parts, int n_tiles, int nf, int tw,
-                         int th, int xt_cap, int yt_cap, const ResizeTap* d_taps, uint8_t* d_pyr, size_t img_pitch, int n_img);
 void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int total_tiles, const uint8_t* d_pyr, uint8_t* d_blur,
                  size_t img_pitch, const int taps[7], int n_img);
 void launch_load_level0(hipStream_t st, const uint8_t* d_src, size_t src_stride, size_t src_pitch, uint8_t* d_pyr, size_t img_pitch,
@@ -133,12 +131,6 @@ struct orbfe_ctx {
   std::vector<ResizeTap> taps;
   std::vector<RsTile> rs_tile_tab;
   RsTile* d_rs_tiles = nullptr;
-  // fused resize (k_resize_fused): levels 1..pf_nf from one pass over level 0; the levels above (if any) go through k_resize
-  std::vector<PfTile> pf_tile_tab;
-  std::vector<PfPart> pf_part_tab;
-  PfTile* d_pf_tiles = nullptr;
-  PfPart* d_pf_parts = nullptr;
-  int pf_nf = 0, pf_tw = 0, pf_th = 0, pf_xt_cap = 0, pf_yt_cap = 0;
   int umax[16];
   int blur_taps[7];
   int n_cells_total = 0, rs_tiles = 0, bl_tiles = 0;
@@ -375,89 +367,12 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
       }
     }
   }
-  // fused resize: level-0 tiles of pf_tw x pf_th px; per tile and level the outputs whose top-left source tap lies in the tile,
-  // column boundaries moved up to multiples of 4 (whole output words).  A level is fused if every one of its parts finds its
-  // source pixels inside the staged tile (+ PF_HALO columns, + 1 row): true up to scale ~4.6, i.e. all levels of an 8 x 1.2 pyramid.
-  c->pf_tile_tab.clear(), c->pf_part_tab.clear();
-  c->pf_nf = 0;
-  {
-    const char* ef = getenv("ORBFE_FUSED_RESIZE");
-    const bool want = !ef || atoi(ef) != 0;
-    const char* etw = getenv("ORBFE_PF_TW");
-    const char* eth = getenv("ORBFE_PF_TH");
-    const int W = cfg.width, H = cfg.height;
-    const int ncols = (W + 127) / 128, nrows = (H + 31) / 32;
-    int tw = (int)align_up((size_t)((W + ncols - 1) / ncols), 16), th = (H + nrows - 1) / nrows;
-    if (etw && atoi(etw) >= 16) tw = (int)align_up((size_t)atoi(etw), 16);
-    if (eth && atoi(eth) >= 4) th = atoi(eth);
-    const int ntc = (W + tw - 1) / tw, ntr = (H + th - 1) / th;
-    c->pf_tw = tw, c->pf_th = th;
-    // per level: column / row boundaries
-    std::vector<std::vector<int>> colB(nl), rowB(nl);
-    int nf = 0;
-    for (int l = 1; l < nl && want && l <= PF_MAX_PARTS; ++l) {
-      const LevelDev& L = c->lv[l];
-      const ResizeTap* xt = c->taps.data() + L.xtab_off;
-      const ResizeTap* yt = c->taps.data() + L.ytab_off;
-      auto sy_of = [&](int dy) { return std::min(std::max(yt[dy].ofs, 0), H - 1); };
-      std::vector<int>&cb = colB[l], &rb = rowB[l];
-      cb.assign(ntc + 1, 0), rb.assign(ntr + 1, 0);
-      for (int tc = 1, dx = 0; tc < ntc; ++tc) {
-        while (dx < L.w && xt[dx].ofs < tc * tw) ++dx;
-        cb[tc] = std::max(cb[tc - 1], (int)align_up((size_t)dx, 4));
-      }
-      cb[ntc] = std::max(cb[ntc - 1], (int)align_up((size_t)L.w, 4));
-      for (int tc = 1; tc < ntc; ++tc) cb[tc] = std::min(cb[tc], cb[ntc]);
-      for (int tr = 1, dy = 0; tr < ntr; ++tr) {
-        while (dy < L.h && sy_of(dy) < tr * th) ++dy;
-        rb[tr] = dy;
-      }
-      rb[ntr] = L.h;
-      bool ok = true;
-      for (int tc = 0; tc < ntc && ok; ++tc)
-        for (int dx = cb[tc]; dx < cb[tc + 1]; ++dx) {
-          const int sx0 = xt[std::min(dx, (int)L.w - 1)].ofs, sx1 = std::min(sx0 + 1, W - 1);
-          if (sx0 < tc * tw || sx1 >= tc * tw + tw + PF_HALO) ok = false;
-        }
-      for (int tr = 0; tr < ntr && ok; ++tr)
-        for (int dy = rb[tr]; dy < rb[tr + 1]; ++dy) {
-          const int sy0 = sy_of(dy), sy1 = std::min(std::max(yt[dy].ofs + 1, 0), H - 1);
-          if (sy0 < tr * th || sy1 > tr * th + th) ok = false;
-        }
-      if ((cb[ntc] / 4) * (size_t)L.h >= 60000) ok = false;  // (item indices are 16-bit per tile; never close for real geometries)
-      if (!ok) break;
-      nf = l;
-    }
-    c->pf_nf = nf;
-    c->pf_xt_cap = c->pf_yt_cap = 0;
-    if (nf > 0) {
-      for (int tr = 0; tr < ntr; ++tr)
-        for (int tc = 0; tc < ntc; ++tc) {
-          PfTile T{};
-          T.x0 = (int16_t)(tc * tw), T.y0 = (int16_t)(tr * th);
-          int items = 0, nxt = 0, nyt = 0;
-          for (int l = 1; l <= nf; ++l) {
-            PfPart P{};
-            P.dx0 = (int16_t)colB[l][tc], P.n_words = (int16_t)((colB[l][tc + 1] - colB[l][tc]) / 4);
-            P.dy0 = (int16_t)rowB[l][tr], P.n_rows = (int16_t)(rowB[l][tr + 1] - rowB[l][tr]);
-            P.inv_words = P.n_words > 0 ? (uint32_t)(((1u << 20) + P.n_words - 1) / P.n_words) : 0u;
-            P.item0 = (uint16_t)items, P.xt0 = (uint16_t)nxt, P.yt0 = (uint16_t)nyt;
-            items += P.n_words * P.n_rows, nxt += 4 * P.n_words, nyt += P.n_rows;
-            c->pf_part_tab.push_back(P);
-          }
-          T.n_items = (int16_t)items, T.n_xt = (int16_t)nxt, T.n_yt = (int16_t)nyt;
-          c->pf_xt_cap = std::max(c->pf_xt_cap, nxt), c->pf_yt_cap = std::max(c->pf_yt_cap, nyt);
-          c->pf_tile_tab.push_back(T);
-        }
-      c->pf_xt_cap = (int)align_up((size_t)c->pf_xt_cap, 2), c->pf_yt_cap = (int)align_up((size_t)std::max(c->pf_yt_cap, 1), 2);
-    }
-  }
   // resize work items: output tile + the level-0 footprint it reads (taps are monotone in the output coordinate).  Levels whose
   // 64x32 tiles all stage <= RS_TALL_LDS_BYTES use those ("tall", listed first), the coarser levels 64x16 tiles.
   c->rs_tile_tab.clear();
   std::vector<RsTile> cls[3];
   for (int k = 0; k < 3; ++k) c->rs_n[k] = c->rs_bytes[k] = 0;
-  for (int l = c->pf_nf + 1; l < nl; ++l) {  // the levels k_resize_fused does not take
+  for (int l = 1; l < nl; ++l) {
     LevelDev& L = c->lv[l];
     const ResizeTap* xt = c->taps.data() + L.xtab_off;
     const ResizeTap* yt = c->taps.data() + L.ytab_off;
@@ -642,8 +557,6 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   int32_t* n_cand = c->d_n_cand + i0 * nl;
   {
     StageTimer t(c, ORBFE_STAGE_RESIZE, st);
-    launch_resize_fused(st, c->d_lv, c->d_pf_tiles, c->d_pf_parts, (int)c->pf_tile_tab.size(), c->pf_nf, c->pf_tw, c->pf_th, c->pf_xt_cap,
-                        c->pf_yt_cap, c->d_taps, pyr, c->img_pitch, n_img);
     launch_resize(st, c->d_lv, c->d_rs_tiles, c->rs_n, c->rs_bytes, c->d_taps, pyr, c->img_pitch, n_img);
   }
   // Only the descriptors read the blurred planes, so the blur need not sit between resize and FAST: it is issued on a second
@@ -737,7 +650,7 @@ void orbfe_destroy(orbfe_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   drain_timers(c);
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
-  void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_rs_tiles, c->d_pf_tiles, c->d_pf_parts, c->d_pattern, c->d_pyr,     c->d_blur,
+  void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_rs_tiles, c->d_pattern, c->d_pyr,     c->d_blur,
                   c->d_scr_a, c->d_scr_c,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_kp,
                   c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos, c->d_kx, c->d_env, c->d_kpl,   c->d_right_u, c->d_depth, c->d_n_match,
                   c->d_best_right, c->d_best_dist, c->d_tmp};
@@ -853,8 +766,6 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   ALLOC(c->d_cells, c->cells.size());
   ALLOC(c->d_taps, c->taps.size());
   ALLOC(c->d_rs_tiles, c->rs_tile_tab.size());
-  ALLOC(c->d_pf_tiles, c->pf_tile_tab.size());
-  ALLOC(c->d_pf_parts, c->pf_part_tab.size());
   ALLOC(c->d_pattern, 1024);
   ALLOC(c->d_pyr, M * c->img_pitch);
   ALLOC(c->d_blur, M * c->img_pitch);
@@ -896,10 +807,6 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   if (e == hipSuccess && !c->taps.empty()) e = hipMemcpy(c->d_taps, c->taps.data(), sizeof(ResizeTap) * c->taps.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess && !c->rs_tile_tab.empty())
     e = hipMemcpy(c->d_rs_tiles, c->rs_tile_tab.data(), sizeof(RsTile) * c->rs_tile_tab.size(), hipMemcpyHostToDevice);
-  if (e == hipSuccess && !c->pf_tile_tab.empty())
-    e = hipMemcpy(c->d_pf_tiles, c->pf_tile_tab.data(), sizeof(PfTile) * c->pf_tile_tab.size(), hipMemcpyHostToDevice);
-  if (e == hipSuccess && !c->pf_part_tab.empty())
-    e = hipMemcpy(c->d_pf_parts, c->pf_part_tab.data(), sizeof(PfPart) * c->pf_part_tab.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(c->d_pattern, pat, 1024, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(c->d_n_kp, 0, sizeof(int32_t) * M);
   if (e == hipSuccess) e = hipMemset(c->d_sel_count, 0, sizeof(int32_t) * M * NL);

@@ -26,23 +26,6 @@ struct RsTile {
   int16_t pad;
 };
 
-// k_resize_fused work item: one level-0 tile and, per fused level, the output pixels whose top-left source tap lies in the tile
-// (column ranges moved to multiples of 4 so that every output word is stored whole; the tile is staged with PF_HALO extra columns)
-#define PF_HALO 16
-#define PF_MAX_PARTS 15
-struct PfPart {
-  int16_t dx0, n_words;  // output columns [dx0, dx0 + 4 n_words), dx0 % 4 == 0
-  int16_t dy0, n_rows;   // output rows [dy0, dy0 + n_rows)
-  uint32_t inv_words;    // ceil(2^20 / n_words): exact division of an item index < 2^12 by n_words
-  uint16_t item0;        // first work item (one output word) of this level in the tile's flattened item list
-  uint16_t xt0, yt0;     // first staged x / y tap of this level
-  uint16_t pad;
-};
-struct PfTile {
-  int16_t x0, y0;        // level-0 origin (x0 a multiple of 16)
-  int16_t n_items, n_xt, n_yt, pad;
-};
-
 // Per pyramid level, resident in device memory (one table per context).
 struct LevelDev {
   int32_t w, h, stride;  // plane size, row pitch in bytes (multiple of 16)
