@@ -251,6 +251,21 @@ orbfe_status orbfe_frame_rgbd(orbfe_ctx* ctx, int32_t slot, const orbfe_camera* 
                               size_t depth_stride_bytes, float depth_scale, orbfe_keypoint* kps_undistorted, double* depth_out,
                               double* right_u_out);
 
+/* MapPoint::isInVision + MapPoint::predictLevel (src/MapPoint.cc:141-201) for n map points against one frame -- the per-point
+ * preamble of ORBMatcher::searchByProjection(frame, mapPoints, ...) (src/ORBMatcher.cc:575-580), whose outputs feed
+ * orbfe_search_in_area.  pose: Rcw row-major + tcw as the reference's float cv::Mat; bounds: VirtualFrame::mfMinU, mfMaxU, mfMinV,
+ * mfMaxV (Frame.h:259-264).  Outputs per point: projection uv, camera-centre distance, cosTheta, predicted level (clamped to
+ * [0, 7] like the reference) and visible = isInVision's return value; a point that fails a test keeps visible = 0 and the
+ * values computed up to that test.  Float arithmetic in the reference's order (documented in csrc/k_guided.hip).              */
+typedef struct orbfe_frame_pose {
+  float Rcw[9], tcw[3];
+  float min_u, max_u, min_v, max_v;
+} orbfe_frame_pose;
+orbfe_status orbfe_project_map_points(orbfe_ctx* ctx, int32_t n, const float* pos /*[n][3]*/, const float* view_dir /*[n][3]*/,
+                                      const float* max_dist /*[n]*/, const float* min_dist /*[n]*/, const orbfe_frame_pose* pose,
+                                      const orbfe_camera* cam, float* uv /*[n][2]*/, float* distance /*[n]*/, float* cos_theta /*[n]*/,
+                                      int8_t* level /*[n]*/, uint8_t* visible /*[n]*/);
+
 /* ---- map.pb: the reference's on-disk map, and a local bundle adjustment on it -------------------------------
  * `orbslam2.MapData` as Map::saveToProtobuf writes it (src/Map.cc:200-250; proto/Map.proto, Keyframe.proto,
  * MapPoint.proto), read and written without libprotobuf (host/map_pb.hpp).  The first three calls are host-only

@@ -79,3 +79,46 @@ void orc_rgbd_lookup(int n, const float* xy, const float* xy_u, const void* dept
 }
 
 }  // extern "C"
+
+// ---- MapPoint::isInVision + MapPoint::predictLevel (src/MapPoint.cc:141-201) ----------------------------------------------------
+// cv::Mat arithmetic restated (OpenCV 4.x core, not in the reference tree -- a documented decision, parity unpinned):
+//   Rcw * X + tcw : MatExpr GEMM; the 3x3 * 3x1 CV_32F fast path of gemmImpl forms float s = a0*b0 + a1*b1 + a2*b2 and stores
+//                   (float)(s*alpha + c*beta) with alpha = beta = 1.0 (double)
+//   cv::norm(NORM_L2), Mat::dot on CV_32F: double accumulation of float elements
+// R: row-major 3x3 (Rcw), t: tcw, cam: fx fy cx cy, bounds: minU maxU minV maxV.  Outputs as documented in include/orbfe.h.
+extern "C" void orc_project_map_points(int n, const float* pos, const float* vdir, const float* max_dist, const float* min_dist, const float* R,
+                                       const float* t, const float* cam, const float* bounds, float scale_factor, float* uv, float* dist_out,
+                                       float* cos_out, int8_t* level_out, uint8_t* visible) {
+  const float log_sf = std::log(scale_factor);  // std::log(float) (MapPoint.cc:195)
+  for (int i = 0; i < n; ++i) {
+    float pc[3];
+    for (int r = 0; r < 3; ++r) {
+      const float s = R[3 * r] * pos[3 * i] + R[3 * r + 1] * pos[3 * i + 1] + R[3 * r + 2] * pos[3 * i + 2];
+      pc[r] = (float)((double)s * 1.0 + (double)t[r] * 1.0);
+    }
+    float u = 0.f, v = 0.f, distance = 0.f, cos_theta = 0.f;
+    int level = 0;
+    uint8_t vis = 0;
+    do {
+      if (pc[2] < 0) break;                                                                        // :151
+      const float x = pc[0], y = pc[1], z = pc[2];
+      distance = std::sqrt(x * x + y * y + z * z);                                                 // :155
+      if (!(distance < max_dist[i] && distance > min_dist[i])) break;                              // MapPoint.h:150-156
+      u = x / z * cam[0] + cam[2];                                                                 // :159-160
+      v = y / z * cam[1] + cam[3];
+      if (!(u < bounds[1] && v < bounds[3] && u > bounds[0] && v > bounds[2])) break;              // Frame.h:259-264
+      float vd[3];
+      for (int r = 0; r < 3; ++r) vd[r] = R[3 * r] * vdir[3 * i] + R[3 * r + 1] * vdir[3 * i + 1] + R[3 * r + 2] * vdir[3 * i + 2];
+      double nn = 0.0, dot = 0.0;
+      for (int r = 0; r < 3; ++r) nn += (double)vd[r] * (double)vd[r];
+      const float vabs = (float)std::sqrt(nn);                                                     // :166
+      for (int r = 0; r < 3; ++r) dot += (double)vd[r] * (double)pc[r];
+      cos_theta = (float)(dot / (double)(distance * vabs));                                        // :167
+      if (cos_theta < 0.5) break;
+      vis = 1;
+      level = (int)std::nearbyint(std::log(max_dist[i] / distance) / log_sf);                      // cvRound (:195)
+      level = level < 0 ? 0 : (level > 7 ? 7 : level);
+    } while (false);
+    uv[2 * i] = u, uv[2 * i + 1] = v, dist_out[i] = distance, cos_out[i] = cos_theta, level_out[i] = (int8_t)level, visible[i] = vis;
+  }
+}

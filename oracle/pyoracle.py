@@ -235,6 +235,23 @@ class Oracle:
                                  _p(d), _p(ru))
         return d[:n], ru[:n]
 
+    def project_map_points(self, pos, view_dir, max_dist, min_dist, Rcw, tcw, cam, bounds, scale_factor=1.2):
+        """MapPoint::isInVision + predictLevel (MapPoint.cc:141-201): cam = fx fy cx cy, bounds = minU maxU minV maxV
+        -> dict(uv, distance, cos_theta, level, visible)"""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        pos, view_dir, max_dist, min_dist = f32(pos).reshape(-1, 3), f32(view_dir).reshape(-1, 3), f32(max_dist), f32(min_dist)
+        R, t, cam, bounds = f32(Rcw).reshape(9), f32(tcw).reshape(3), f32(cam), f32(bounds)
+        n = pos.shape[0]
+        m = max(n, 1)
+        out = dict(uv=np.zeros((m, 2), np.float32), distance=np.zeros(m, np.float32), cos_theta=np.zeros(m, np.float32),
+                   level=np.zeros(m, np.int8), visible=np.zeros(m, np.uint8))
+        self.lib.orc_project_map_points.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_float] + [C.c_void_p] * 5
+        self.lib.orc_project_map_points.restype = None
+        self.lib.orc_project_map_points(n, _p(pos), _p(view_dir), _p(max_dist), _p(min_dist), _p(R), _p(t), _p(cam), _p(bounds),
+                                        float(np.float32(scale_factor)), _p(out["uv"]), _p(out["distance"]), _p(out["cos_theta"]),
+                                        _p(out["level"]), _p(out["visible"]))
+        return {k: v[:n] for k, v in out.items()}
+
     def ba_local_optimize(self, prob, pose_fixed=None, iters1=5, iters2=10):
         """prob: dict as orb_slam2_ros2_amd.ba_synth.make_problem -> dict(poses, points, level, chi2, bad, iters)"""
         f64 = lambda a: np.ascontiguousarray(a, np.float64)

@@ -66,6 +66,11 @@ class BaOptimizeOut(C.Structure):
                 ("iterations", C.c_void_p)]
 
 
+class FramePose(C.Structure):
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("min_u", C.c_float), ("max_u", C.c_float), ("min_v", C.c_float),
+                ("max_v", C.c_float)]
+
+
 class MapSummary(C.Structure):
     _fields_ = [("next_id", C.c_uint64), ("n_scale_factors", C.c_int32), ("n_keyframes", C.c_int32), ("n_mappoints", C.c_int32),
                 ("n_keypoints", C.c_int64), ("n_observations", C.c_int64)]
@@ -91,7 +96,7 @@ EXPORTS = [
     "orbfe_abi_version", "orbfe_create", "orbfe_destroy", "orbfe_last_error", "orbfe_get_level_info", "orbfe_get_scale_factors",
     "orbfe_get_capacity",
     "orbfe_extract", "orbfe_extract_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
-    "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_extract_color", "orbfe_frame_rgbd",
+    "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_extract_color", "orbfe_frame_rgbd", "orbfe_project_map_points",
     "orbfe_map_pb_summary", "orbfe_map_pb_reencode", "orbfe_map_local_graph", "orbfe_map_local_ba",
     "orbfe_profile_enable", "orbfe_profile_read", "orbfe_stage_name", "orbfe_debug_candidates",
 ]
@@ -143,6 +148,7 @@ def load() -> C.CDLL:
     L.orbfe_search_in_area.argtypes = [vp, i32, i32] + [vp] * 10
     L.orbfe_extract_color.argtypes = [vp, vp, C.c_size_t, i32, vp, vp, vp]
     L.orbfe_frame_rgbd.argtypes = [vp, i32, C.POINTER(Camera), vp, i32, C.c_size_t, f32, vp, vp, vp]
+    L.orbfe_project_map_points.argtypes = [vp, i32, vp, vp, vp, vp, C.POINTER(FramePose), C.POINTER(Camera), vp, vp, vp, vp, vp]
     L.orbfe_map_pb_summary.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(MapSummary)]
     L.orbfe_map_pb_reencode.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.orbfe_map_local_graph.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.POINTER(i32 * 4), C.POINTER(MapGraph)]
@@ -415,6 +421,22 @@ class Context:
         for k in ("level", "chi2", "bad"):
             out[k] = out[k][:E]
         return out
+
+    def project_map_points(self, pos, view_dir, max_dist, min_dist, Rcw, tcw, cam, bounds):
+        """MapPoint::isInVision + predictLevel for n map points (MapPoint.cc:141-201); cam = (fx, fy, cx, cy), bounds = (minU, maxU,
+        minV, maxV) -> dict(uv, distance, cos_theta, level, visible)"""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        pos, view_dir, max_dist, min_dist = f32(pos).reshape(-1, 3), f32(view_dir).reshape(-1, 3), f32(max_dist), f32(min_dist)
+        n = pos.shape[0]
+        m = max(n, 1)
+        out = dict(uv=np.zeros((m, 2), np.float32), distance=np.zeros(m, np.float32), cos_theta=np.zeros(m, np.float32),
+                   level=np.zeros(m, np.int8), visible=np.zeros(m, np.uint8))
+        fp = FramePose((C.c_float * 9)(*f32(Rcw).reshape(9)), (C.c_float * 3)(*f32(tcw).reshape(3)), *[float(np.float32(b)) for b in bounds])
+        cm = Camera(*[float(np.float32(v)) for v in cam], 0, 0, 0, 0, 0, 0)
+        self._check(self.lib.orbfe_project_map_points(self.h, n, ptr(pos), ptr(view_dir), ptr(max_dist), ptr(min_dist), C.byref(fp),
+                                                      C.byref(cm), ptr(out["uv"]), ptr(out["distance"]), ptr(out["cos_theta"]),
+                                                      ptr(out["level"]), ptr(out["visible"])))
+        return {k: v[:n] for k, v in out.items()}
 
     def map_local_ba(self, pb: bytes, kf_id: int, fx, fy, cx, cy, bf):
         """Optimizer::OptimizeLocalMap around keyframe kf_id of a map.pb -> (updated map.pb bytes, report dict)"""

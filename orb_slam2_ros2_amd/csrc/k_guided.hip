@@ -167,6 +167,82 @@ __global__ __launch_bounds__(256) void k_search_area(const uint4* __restrict__ k
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MapPoint::isInVision + MapPoint::predictLevel (src/MapPoint.cc:141-201) for n map points against one frame: what
+// ORBMatcher::searchByProjection(frame, mapPoints) evaluates per point before the area search (src/ORBMatcher.cc:575-580).
+// One thread per map point; the float / double mix follows the cv::Mat expressions of the reference:
+//   Rcw * X + tcw      3x3 * 3x1 gemm: float products summed left to right, then (float)(s * 1.0 + c * 1.0) in double
+//   cv::norm, Mat::dot double accumulation of float elements
+// Early exits keep the reference's order (z < 0, distance range, image bounds, cos < 0.5); a point that fails leaves visible = 0.
+// ---------------------------------------------------------------------------------------------
+struct ProjectParams {
+  float R[9], t[3];
+  float fx, fy, cx, cy;
+  float min_u, max_u, min_v, max_v;
+  float log_sf;  // std::log(ORBExtractor::mfScaledFactor) as float
+  int max_level;
+};
+
+__global__ __launch_bounds__(256) void k_project_map_points(int n, const float* __restrict__ pos, const float* __restrict__ vdir,
+                                                            const float* __restrict__ max_dist, const float* __restrict__ min_dist,
+                                                            ProjectParams P, float* __restrict__ uv, float* __restrict__ dist_out,
+                                                            float* __restrict__ cos_out, int8_t* __restrict__ level_out,
+                                                            uint8_t* __restrict__ visible) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float X0 = pos[3 * i], X1 = pos[3 * i + 1], X2 = pos[3 * i + 2];
+  float pc[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float s = P.R[3 * r] * X0 + P.R[3 * r + 1] * X1 + P.R[3 * r + 2] * X2;
+    pc[r] = (float)((double)s + (double)P.t[r]);
+  }
+  uint8_t vis = 0;
+  float u = 0.f, v = 0.f, distance = 0.f, cos_theta = 0.f;
+  int level = 0;
+  do {
+    if (pc[2] < 0.f) break;
+    const float x = pc[0], y = pc[1], z = pc[2];
+    distance = sqrtf(x * x + y * y + z * z);  // (correctly rounded; __fsqrt_rn maps to the native approximation)
+    if (!(distance < max_dist[i] && distance > min_dist[i])) break;  // isGoodDistance
+    u = x / z * P.fx + P.cx;
+    v = y / z * P.fy + P.cy;
+    if (!(u < P.max_u && v < P.max_v && u > P.min_u && v > P.min_v)) break;  // VirtualFrame::isInImage
+    const float D0 = vdir[3 * i], D1 = vdir[3 * i + 1], D2 = vdir[3 * i + 2];
+    float vd[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) vd[r] = P.R[3 * r] * D0 + P.R[3 * r + 1] * D1 + P.R[3 * r + 2] * D2;
+    const double nn = (double)vd[0] * (double)vd[0] + (double)vd[1] * (double)vd[1] + (double)vd[2] * (double)vd[2];
+    const float vabs = (float)sqrt(nn);
+    const double dot = (double)vd[0] * (double)pc[0] + (double)vd[1] * (double)pc[1] + (double)vd[2] * (double)pc[2];
+    cos_theta = (float)(dot / (double)(distance * vabs));
+    if (cos_theta < 0.5f) break;
+    vis = 1;
+    // predictLevel: cvRound(std::log(nMaxDis / distance) / std::log(mfScaledFactor)), clamped to [0, 7] in the reference (max_level here)
+    const float lr = (float)log((double)(max_dist[i] / distance));
+    level = __float2int_rn(lr / P.log_sf);
+    level = level < 0 ? 0 : (level > P.max_level ? P.max_level : level);
+  } while (false);
+  uv[2 * i] = u, uv[2 * i + 1] = v;
+  dist_out[i] = distance, cos_out[i] = cos_theta;
+  level_out[i] = (int8_t)level;
+  visible[i] = vis;
+}
+
+void launch_project_map_points(hipStream_t s, int n, const float* d_pos, const float* d_vdir, const float* d_max, const float* d_min,
+                               const float* R, const float* t, const float* cam4, const float* bounds4, float log_sf, int max_level,
+                               float* d_uv, float* d_dist, float* d_cos, int8_t* d_level, uint8_t* d_vis) {
+  if (n <= 0) return;
+  ProjectParams P;
+  for (int k = 0; k < 9; ++k) P.R[k] = R[k];
+  for (int k = 0; k < 3; ++k) P.t[k] = t[k];
+  P.fx = cam4[0], P.fy = cam4[1], P.cx = cam4[2], P.cy = cam4[3];
+  P.min_u = bounds4[0], P.max_u = bounds4[1], P.min_v = bounds4[2], P.max_v = bounds4[3];
+  P.log_sf = log_sf, P.max_level = max_level;
+  hipLaunchKernelGGL(k_project_map_points, dim3((n + 255) / 256), dim3(256), 0, s, n, d_pos, d_vdir, d_max, d_min, P, d_uv, d_dist, d_cos,
+                     d_level, d_vis);
+}
+
 void launch_grid_build(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, int rows, int cols, int32_t* d_cell_off,
                        int32_t* d_cell_feat) {
   const size_t lds = (size_t)(2 * rows * cols + 1) * sizeof(int32_t);

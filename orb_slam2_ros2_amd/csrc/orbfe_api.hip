@@ -73,6 +73,9 @@ void launch_ba_system(hipStream_t s, int n_poses, int n_points, int n_edges, con
                       const double* info, const double* delta, BaParamsDev prm, const uint8_t* pose_fixed, const int32_t* pt_off,
                       const int32_t* pt_edges, const int32_t* ps_off, const int32_t* ps_edges, double* Hpp, double* bp, double* Hll,
                       double* bl, double* Hpl);
+void launch_project_map_points(hipStream_t s, int n, const float* d_pos, const float* d_vdir, const float* d_max, const float* d_min,
+                               const float* R, const float* t, const float* cam4, const float* bounds4, float log_sf, int max_level,
+                               float* d_uv, float* d_dist, float* d_cos, int8_t* d_level, uint8_t* d_vis);
 void launch_grid_build(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, int rows, int cols, int32_t* d_cell_off,
                        int32_t* d_cell_feat);
 void launch_search_area(hipStream_t s, const uint4* d_kpl, const uint8_t* d_desc, int width, int height, int rows, int cols,
@@ -1592,6 +1595,50 @@ orbfe_status orbfe_search_in_area(orbfe_ctx* c, int32_t slot, int32_t nq, const 
   HIP_TRY(c, hipMemcpyAsync(best_dist, b + o_bd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(second_dist, b + o_sd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(n_cand, b + o_nc, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_project_map_points(orbfe_ctx* c, int32_t n, const float* pos, const float* view_dir, const float* max_dist,
+                                      const float* min_dist, const orbfe_frame_pose* pose, const orbfe_camera* cam, float* uv,
+                                      float* distance, float* cos_theta, int8_t* level, uint8_t* visible) {
+  if (!c || n < 0 || !pose || !cam) return fail(c, ORBFE_EBADARG, "project_map_points: NULL argument");
+  if (n && (!pos || !view_dir || !max_dist || !min_dist || !uv || !distance || !cos_theta || !level || !visible))
+    return fail(c, ORBFE_EBADARG, "project_map_points: NULL argument");
+  if (n == 0) return ORBFE_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
+  const size_t N = (size_t)n;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o2 = off;
+    off += align_up(std::max<size_t>(bytes, 8), 256);
+    return o2;
+  };
+  const size_t o_p = take(N * 12), o_v = take(N * 12), o_mx = take(N * 4), o_mn = take(N * 4), o_uv = take(N * 8), o_d = take(N * 4),
+               o_c = take(N * 4), o_l = take(N), o_s = take(N);
+  TRY(ensure_tmp(c, off));
+  uint8_t* b = (uint8_t*)c->d_tmp;
+  HIP_TRY(c, hipMemcpyAsync(b + o_p, pos, N * 12, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_v, view_dir, N * 12, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_mx, max_dist, N * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_mn, min_dist, N * 4, hipMemcpyHostToDevice, c->stream));
+  const float cam4[4] = {cam->fx, cam->fy, cam->cx, cam->cy};
+  const float bounds4[4] = {pose->min_u, pose->max_u, pose->min_v, pose->max_v};
+  {
+    StageTimer tm(c, ORBFE_STAGE_MATCH, c->stream);
+    // std::log(ORBExtractor::mfScaledFactor): float argument, float result
+    launch_project_map_points(c->stream, n, (const float*)(b + o_p), (const float*)(b + o_v), (const float*)(b + o_mx),
+                              (const float*)(b + o_mn), pose->Rcw, pose->tcw, cam4, bounds4, std::log(c->cfg.scale_factor), 7,
+                              (float*)(b + o_uv), (float*)(b + o_d), (float*)(b + o_c), (int8_t*)(b + o_l), b + o_s);
+  }
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(uv, b + o_uv, N * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(distance, b + o_d, N * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(cos_theta, b + o_c, N * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(level, b + o_l, N, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(visible, b + o_s, N, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_timers(c);
   return ORBFE_OK;

@@ -151,6 +151,12 @@ class ORBMatcher:
         ok = (nc > 0) & (ratio < np.float32(self.mfRatio)) & (bd < self.mnMinThreshold)
         return [(int(bi[k]), int(idx[k]), int(bd[k])) for k in np.flatnonzero(ok)]
 
+    @staticmethod
+    def projectMapPoints(ctx, pos, view_dir, max_dist, min_dist, Rcw, tcw, cam, bounds):
+        """MapPoint::isInVision + predictLevel (MapPoint.cc:141-201) for all candidate map points in one device call: returns
+        dict(uv, distance, cos_theta, level, visible) -- the inputs searchByProjectionMapPoints takes (usable = visible & in map & not bad)."""
+        return ctx.project_map_points(pos, view_dir, max_dist, min_dist, Rcw, tcw, cam, bounds)
+
     def searchByProjectionMapPoints(self, ctx, slot, uv, level, cos_theta, mp_desc, usable, th, frame_has_good_mp, bFuse=False, n_levels=8,
                                     scale_factors=None, area_search=None):
         """ORBMatcher::searchByProjection(pframe, mapPoints, th, matches, bFuse) (ORBMatcher.cc:561-612).  Per map point the caller

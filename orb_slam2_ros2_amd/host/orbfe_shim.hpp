@@ -255,6 +255,25 @@ class ORBMatcher {
     return out;
   }
 
+  // MapPoint::isInVision + predictLevel (src/MapPoint.cc:141-201) for all candidate map points of a frame in one call: the per-point
+  // preamble of searchByProjection(pframe, mapPoints, ...) (src/ORBMatcher.cc:575-580).  pos / viewDir: [n][3] floats.
+  struct Vision {
+    std::vector<float> uv, distance, cosTheta;
+    std::vector<int8_t> level;
+    std::vector<uint8_t> visible;
+  };
+  static Vision projectMapPoints(orbfe_ctx* ctx, const std::vector<float>& pos, const std::vector<float>& viewDir,
+                                 const std::vector<float>& maxDist, const std::vector<float>& minDist, const orbfe_frame_pose& pose,
+                                 const orbfe_camera& cam) {
+    const int32_t n = (int32_t)maxDist.size();
+    Vision v;
+    const size_t m = (size_t)std::max(n, 1);
+    v.uv.resize(2 * m), v.distance.resize(m), v.cosTheta.resize(m), v.level.resize(m), v.visible.resize(m);
+    check(ctx, orbfe_project_map_points(ctx, n, pos.data(), viewDir.data(), maxDist.data(), minDist.data(), &pose, &cam, v.uv.data(),
+                                        v.distance.data(), v.cosTheta.data(), v.level.data(), v.visible.data()));
+    v.uv.resize(2 * (size_t)n), v.distance.resize(n), v.cosTheta.resize(n), v.level.resize(n), v.visible.resize(n);
+    return v;
+  }
   // ORBMatcher::searchByProjection(pframe, mapPoints, th, matches, bFuse) (src/ORBMatcher.cc:561-612).  Per map point the caller
   // supplies the outputs of MapPoint::isInVision / predictLevel (uv, level, cosTheta) and usable = in map, not bad, in vision.
   // bFuse: matches (featIdx, mapPointIdx, distance).  Otherwise `matches` holds the assignments the caller applies with

@@ -188,3 +188,63 @@ def test_device_guided_wrappers_match_the_oracle_path(orc, kitti_pair):
     ref = m.searchByBow(None, d1, d2, fv1, fv2, *g, k1["angle"], k2["angle"], best_match=_csr_match(orc))
     assert dev == ref and len(dev) > 5
     ctx.close()
+
+
+# ---- MapPoint::isInVision / predictLevel (src/MapPoint.cc:141-201) ----------------------------------------------------------------
+def _vision_case(n=4000, seed=5):
+    rng = np.random.default_rng(seed)
+    ang = 0.3
+    Rcw = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+    tcw = np.array([0.2, -0.1, 0.4], np.float32)
+    pos = np.stack([rng.uniform(-6, 6, n), rng.uniform(-3, 3, n), rng.uniform(-2, 12, n)], 1).astype(np.float32)  # some behind the camera
+    vd = rng.normal(size=(n, 3)).astype(np.float32)
+    vd[: n // 2] = (pos[: n // 2] * rng.uniform(0.5, 1.5, (n // 2, 1))).astype(np.float32)  # half of them roughly along the viewing ray
+    ref = np.linalg.norm(pos, axis=1).astype(np.float32)
+    max_d = (ref * rng.uniform(0.7, 3.0, n)).astype(np.float32)
+    min_d = (ref * rng.uniform(0.1, 1.1, n)).astype(np.float32)
+    cam = (520.9086, 521.0073, 325.1414, 249.7018)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    return pos, vd, max_d, min_d, Rcw, tcw, cam, bounds
+
+
+def test_is_in_vision_restatement_against_definition():
+    from oracle import pyoracle
+    orc = pyoracle.Oracle(pyoracle.build())
+    pos, vd, max_d, min_d, Rcw, tcw, cam, bounds = _vision_case()
+    r = orc.project_map_points(pos, vd, max_d, min_d, Rcw, tcw, cam, bounds)
+    # fp64 evaluation of the five conditions: the float restatement may only differ within rounding of a boundary
+    pc = pos.astype(np.float64) @ Rcw.astype(np.float64).T + tcw
+    d = np.linalg.norm(pc, axis=1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u, v = pc[:, 0] / pc[:, 2] * cam[0] + cam[2], pc[:, 1] / pc[:, 2] * cam[1] + cam[3]
+        w = vd.astype(np.float64) @ Rcw.astype(np.float64).T
+        cos = (w * pc).sum(1) / (d * np.linalg.norm(w, axis=1))
+    vis = (pc[:, 2] >= 0) & (d < max_d) & (d > min_d) & (u > 0) & (u < 640) & (v > 0) & (v < 480) & (cos >= 0.5)
+    margin = np.minimum.reduce([np.abs(d - max_d), np.abs(d - min_d), np.abs(u), np.abs(640 - u), np.abs(v), np.abs(480 - v),
+                                np.abs(cos - 0.5) * 100, np.abs(pc[:, 2]) * 100])
+    clear = margin > 1e-3
+    assert (r["visible"][clear].astype(bool) == vis[clear]).all() and 0.02 * len(vis) < vis.sum() < 0.5 * len(vis)
+    k = r["visible"].astype(bool)
+    assert np.abs(r["uv"][k, 0] - u[k]).max() < 1e-3 and np.abs(r["distance"][k] - d[k]).max() < 1e-5
+    assert np.abs(r["cos_theta"][k] - cos[k]).max() < 1e-6
+    lvl = np.clip(np.rint(np.log(max_d[k].astype(np.float64) / d[k]) / np.log(1.2)), 0, 7)
+    assert (r["level"][k] != lvl).mean() < 0.002 and set(np.unique(r["level"][k])) <= set(range(8))
+
+
+@pytest.mark.gpu
+def test_project_map_points_matches_restatement():
+    from oracle import pyoracle
+    from orb_slam2_ros2_amd._lib import Context
+    orc = pyoracle.Oracle(pyoracle.build())
+    ctx = Context(640, 480, 1000, 8, 1.2, 20, 7, max_images=1)
+    for seed, n in ((5, 4000), (6, 1), (7, 257)):
+        args = _vision_case(n, seed)
+        got, want = ctx.project_map_points(*args), orc.project_map_points(*args)
+        assert (got["visible"] == want["visible"]).all()
+        k = want["visible"].astype(bool)
+        for key in ("uv", "distance", "cos_theta", "level"):  # bit-exact float results where the reference defines them
+            assert (got[key][k] == want[key][k]).all(), key
+    empty = ctx.project_map_points(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0), np.zeros(0), np.eye(3), np.zeros(3),
+                                   (500, 500, 320, 240), (0, 640, 0, 480))
+    assert len(empty["visible"]) == 0
+    ctx.close()
