@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--prewarm-seconds", type=float, default=1.5,
                     help="untimed steps run before the W warm-up steps until this much wall time has passed: the GPU needs "
                          "~0.3 s of sustained load to leave its idle clocks (measured: first 30 steps 13 %% slower)")
-    ap.add_argument("--pairs", type=int, default=256, help="stereo pairs per step (per GPU)")
+    ap.add_argument("--pairs", type=int, default=512, help="stereo pairs per step (per GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--streams", type=int, default=1,
                     help="half-batch streams the library may split a batch over (1 = none, the library default and the fastest "
