@@ -43,6 +43,26 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
+// full-wave sum (the row_shr steps leave a row's total in its lane 15, the broadcasts chain the rows)
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+  v += dpp_u32<0x111, 0xf>(0u, v);
+  v += dpp_u32<0x112, 0xf>(0u, v);
+  v += dpp_u32<0x114, 0xf>(0u, v);
+  v += dpp_u32<0x118, 0xf>(0u, v);
+  v += dpp_u32<0x142, 0xa>(0u, v);
+  v += dpp_u32<0x143, 0xc>(0u, v);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// max over the lanes BELOW this one (0 for lane 0)
+__device__ __forceinline__ int wave_excl_max(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o);
+    if (lane >= o) v = max(v, t);
+  }
+  const int prev = __shfl_up(v, 1);
+  return lane > 0 ? prev : 0;
+}
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #pragma unroll
@@ -145,28 +165,60 @@ struct PpGeom {
   int s_lo[QT_PP_MAX_STRIPS], s_hi[QT_PP_MAX_STRIPS];  // integer form of the strict strip membership
   Thr yt[7];
 };
-// group of a record (global index strip * 85 + local) or -1 if it lies in no strip
+// group of a record (global index strip * 85 + local) or -1 if it lies in no strip.  Straight-line code: all three levels are
+// evaluated with clamped indices and the result is selected at the end -- a lone wave pays tens of cycles for every branch it
+// takes, and the sixteen records a lane classifies per trip can only overlap their threshold reads without branches between them.
 __device__ __forceinline__ int pp_group(uint32_t rec, const PpGeom& G, const Thr* xt /*LDS: [ns][7]*/) {
   const int x = (int)ORBFE_REC_X(rec), y = (int)ORBFE_REC_Y(rec);
-  if (y < 1 || y > G.y_max) return -1;
   int st = -1;
 #pragma unroll
-  for (int k = 0; k < QT_PP_MAX_STRIPS; ++k)
-    if (k < G.ns && x >= G.s_lo[k] && x <= G.s_hi[k]) st = k;
-  if (st < 0) return -1;
-  const Thr* t = xt + st * 7;
-  const int base = st * QT_PP_GROUPS;
-  const int bx1 = half_of(x, t[0]), by1 = half_of(y, G.yt[0]);
-  if (bx1 < 0 || by1 < 0) return base + 84;
-  const int q1 = by1 * 2 + bx1;  // rows outer, cols inner (ORBExtractor.cc:60-72)
-  const Thr y2 = by1 ? G.yt[2] : G.yt[1];
-  const int bx2 = half_of(x, t[1 + bx1]), by2 = half_of(y, y2);
-  if (bx2 < 0 || by2 < 0) return base + q1 * 21 + 20;
-  const int q2 = by2 * 2 + bx2;
-  const Thr y3a = by2 ? G.yt[4] : G.yt[3], y3b = by2 ? G.yt[6] : G.yt[5];
-  const Thr y3 = by1 ? y3b : y3a;
-  const int bx3 = half_of(x, t[3 + 2 * bx1 + bx2]), by3 = half_of(y, y3);
-  return base + q1 * 21 + q2 * 5 + ((bx3 < 0 || by3 < 0) ? 4 : by3 * 2 + bx3);
+  for (int k = 0; k < QT_PP_MAX_STRIPS; ++k) st = (k < G.ns && x >= G.s_lo[k] && x <= G.s_hi[k]) ? k : st;
+  const bool inside = y >= 1 && y <= G.y_max && st >= 0;
+  const int st0 = max(st, 0);
+  const Thr* t = xt + st0 * 7;
+  const Thr x1 = t[0];
+  const int bx1 = half_of(x, x1), by1 = half_of(y, G.yt[0]);
+  const bool ok1 = bx1 >= 0 && by1 >= 0;
+  const int cx1 = max(bx1, 0), cy1 = max(by1, 0);
+  const Thr x2 = t[1 + cx1];
+  const Thr y2 = cy1 ? G.yt[2] : G.yt[1];
+  const int bx2 = half_of(x, x2), by2 = half_of(y, y2);
+  const bool ok2 = bx2 >= 0 && by2 >= 0;
+  const int cx2 = max(bx2, 0), cy2 = max(by2, 0);
+  const Thr x3 = t[3 + 2 * cx1 + cx2];
+  const Thr y3a = cy2 ? G.yt[4] : G.yt[3], y3b = cy2 ? G.yt[6] : G.yt[5];
+  const Thr y3 = cy1 ? y3b : y3a;
+  const int bx3 = half_of(x, x3), by3 = half_of(y, y3);
+  const bool ok3 = bx3 >= 0 && by3 >= 0;
+  const int q1 = cy1 * 2 + cx1, q2 = cy2 * 2 + cx2;  // rows outer, cols inner (ORBExtractor.cc:60-72)
+  const int leaf = ok3 ? by3 * 2 + bx3 : 4;
+  const int l2 = ok2 ? q2 * 5 + leaf : 20;
+  const int l1 = ok1 ? q1 * 21 + l2 : 84;
+  return inside ? st0 * QT_PP_GROUPS + l1 : -1;
+}
+
+// The x and the y halves of pp_group are functions of ONE coordinate each, so they are tabulated once per tree (a few hundred
+// entries) and a record costs two independent LDS byte reads plus a dozen integer operations instead of ~70 with three dependent
+// threshold reads.  Code byte: bit 7 = inside, bits 5-6 = strip (x table only), bits 3-4 = number of levels the coordinate
+// passes without sitting on a split line (0..3), bits 0-2 = the halves taken (level 1 in bit 2).
+__device__ __forceinline__ uint32_t pp_axis_code(int v, const Thr& t0, const Thr* t12 /*[2]*/, const Thr* t3 /*[4]*/) {
+  const int b1 = half_of(v, t0);
+  const int c1 = max(b1, 0);
+  const int b2 = half_of(v, t12[c1]);
+  const int c2 = max(b2, 0);
+  const int b3 = half_of(v, t3[2 * c1 + c2]);
+  const int nv = b1 < 0 ? 0 : (b2 < 0 ? 1 : (b3 < 0 ? 2 : 3));
+  return (uint32_t)(nv << 3) | (uint32_t)(c1 << 2) | (uint32_t)(c2 << 1) | (uint32_t)max(b3, 0);
+}
+__device__ __forceinline__ int pp_group_tab(uint32_t rec, const uint8_t* xtab, const uint8_t* ytab) {
+  const uint32_t cx = xtab[ORBFE_REC_X(rec)], cy = ytab[ORBFE_REC_Y(rec)];
+  const int nv = (int)min((cx >> 3) & 3u, (cy >> 3) & 3u);
+  const int q1 = (int)(((cy >> 2) & 1u) * 2u + ((cx >> 2) & 1u));  // rows outer, cols inner (ORBExtractor.cc:60-72)
+  const int q2 = (int)(((cy >> 1) & 1u) * 2u + ((cx >> 1) & 1u));
+  const int q3 = (int)((cy & 1u) * 2u + (cx & 1u));
+  const int l2 = nv >= 2 ? q2 * 5 + (nv >= 3 ? q3 : 4) : 20;
+  const int l1 = nv >= 1 ? q1 * 21 + l2 : 84;
+  return ((cx & cy) & 0x80u) ? (int)((cx >> 5) & 3u) * QT_PP_GROUPS + l1 : -1;
 }
 
 // Everything after the strip counts: scatter into the strip segments, best-first expansion, selection, ordering.
@@ -175,10 +227,15 @@ __device__ __forceinline__ int pp_group(uint32_t rec, const PpGeom& G, const Thr
 template <bool IN_LDS>
 __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __restrict__ A, int N, uint32_t* H, uint32_t* __restrict__ T,
                                           double* n_rb, double* n_re, double* n_cb, double* n_ce, unsigned long long* n_key,
-                                          uint32_t* n_beg, unsigned long long* sortbuf, int node_cap, int need,
+                                          uint32_t* n_beg, unsigned long long* sortbuf, unsigned long long* bkey, uint32_t* bj,
+                                          int batch_on, int node_cap, int need,
                                           int sort_cap, uint32_t* __restrict__ out_sel, int32_t* __restrict__ sel_count_out, int lane) {
   int n_act = 0;
   uint32_t next_seq = 0;
+#ifdef QT_PROFILE
+  const long long tp0 = __builtin_readcyclecounter();
+  int prof_batches = 0, prof_batched_pops = 0, prof_single = 0;
+#endif
   // ---- first pop: the root, whose children are the initSplit strips (ORBExtractor.cc:81-96, 147-170) ----
   const int ns = L.n_ini;
   const int n_tot = (ns * QT_PP_TOTALS + 3) & ~3;
@@ -202,22 +259,70 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       if (lane == k && k < ns) thr7(lo, hi, xt + 7 * k);
     }
     __syncthreads();
-    // pass 1: group sizes (sixteen records per lane are in flight per trip: a lone wave sees every global round trip)
-    for (int b0 = 0; b0 < N; b0 += 1024) {
-      uint32_t rec[16];
+    // coordinate -> code tables in the (still unused) n_ce array: x in [0, 4096) would not fit, the region is reg_w x reg_h
+    const int tab_w = (int)ceil(L.strips[ns]) + 1, tab_h = (int)ceil((double)L.reg_h) + 1;
+    uint8_t* xtab = (uint8_t*)n_ce;
+    uint8_t* ytab = xtab + ((tab_w + 3) & ~3);
+    const bool use_tab = ((tab_w + 3) & ~3) + tab_h <= node_cap * 8 && tab_w <= 4096 && tab_h <= 4096;
+    if (use_tab) {
+      for (int x = lane; x < tab_w; x += 64) xtab[x] = 0;  // columns on a strip boundary or outside the region: bit 7 clear
+      __syncthreads();
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int i = b0 + u * 64 + lane;
-        rec[u] = (i < N) ? A[i] : 0u;
+      for (int k = 0; k < QT_PP_MAX_STRIPS; ++k) {  // strip by strip: its seven thresholds are wave-uniform (no dependent reads per entry)
+        if (k < ns) {
+          Thr t[7];
+#pragma unroll
+          for (int q = 0; q < 7; ++q) t[q] = xt[7 * k + q];
+          for (int x = max(G.s_lo[k], 0) + lane; x <= G.s_hi[k] && x < tab_w; x += 64)
+            xtab[x] = (uint8_t)(0x80u | ((uint32_t)k << 5) | pp_axis_code(x, t[0], t + 1, t + 3));
+        }
       }
+      for (int y = lane; y < tab_h; y += 64)
+        ytab[y] = (uint8_t)(((y >= 1 && y <= G.y_max) ? 0x80u : 0u) | pp_axis_code(y, G.yt[0], G.yt + 1, G.yt + 3));
+      __syncthreads();
+    }
+    auto group_of = [&](uint32_t r) -> int {
+      if (use_tab) {
+        const uint32_t x = min(ORBFE_REC_X(r), (uint32_t)tab_w - 1u), y = min(ORBFE_REC_Y(r), (uint32_t)tab_h - 1u);  // (candidates lie inside the region; the clamp only guards the table)
+        return pp_group_tab(ORBFE_PACK_XYR(x, y, 0), xtab, ytab);
+      }
+      return pp_group(r, G, xt);
+    };
+#ifdef QT_PROFILE
+    const long long tb0 = __builtin_readcyclecounter();
+#endif
+    // pass 1: group sizes.  Sixteen records per lane per trip, and the next trip's records are requested before this trip's are
+    // classified: a lone wave sees every global round trip, so the loads of trip k+1 fly under the work of trip k.
+    auto load16 = [&](int b0, uint32_t* r) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int i = b0 + u * 64 + lane;
-        const int g = (i < N) ? pp_group(rec[u], G, xt) : -1;
-        if (g >= 0) atomicAdd(&cur[g], 1u);  // LDS atomic; lanes of one group serialise, a chunk spans a handful of groups
+        r[u] = A[max(min(i, N - 1), 0)];  // (clamped: unconditional loads, validity is checked when the record is used)
+      }
+    };
+    {
+      uint32_t nxt[16];
+      load16(0, nxt);
+      for (int b0 = 0; b0 < N; b0 += 1024) {
+        uint32_t rec[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) rec[u] = nxt[u];
+        if (b0 + 1024 < N) load16(b0 + 1024, nxt);
+        int g[16];  // (all groups first, then the atomics: the table reads must not queue behind the atomics they may alias)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int i = b0 + u * 64 + lane;
+          g[u] = (i < N) ? group_of(rec[u]) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (g[u] >= 0) atomicAdd(&cur[g[u]], 1u);  // LDS atomic; lanes of one group serialise, a chunk spans a handful of groups
       }
     }
     __syncthreads();
+#ifdef QT_PROFILE
+    const long long tb1 = __builtin_readcyclecounter();
+#endif
     // totals of the 84 nodes below every strip, then sizes -> cursors (exclusive prefix in layout order)
     for (int t = lane; t < ns * QT_PP_TOTALS; t += 64) {
       const int st = t / QT_PP_TOTALS, k = t - QT_PP_TOTALS * st;
@@ -258,22 +363,38 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     }
     strip_cnt -= strip_base;
     __syncthreads();
+#ifdef QT_PROFILE
+    const long long tb2 = __builtin_readcyclecounter();
+#endif
     // pass 2: scatter
-    for (int b0 = 0; b0 < N; b0 += 1024) {
-      uint32_t rec[16];
+    {
+      uint32_t nxt[16];
+      load16(0, nxt);
+      for (int b0 = 0; b0 < N; b0 += 1024) {
+        uint32_t rec[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int i = b0 + u * 64 + lane;
-        rec[u] = (i < N) ? A[i] : 0u;
-      }
+        for (int u = 0; u < 16; ++u) rec[u] = nxt[u];
+        if (b0 + 1024 < N) load16(b0 + 1024, nxt);
+        int g[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int i = b0 + u * 64 + lane;
-        const int g = (i < N) ? pp_group(rec[u], G, xt) : -1;
-        if (g >= 0) H[atomicAdd(&cur[g], 1u)] = rec[u];  // the order inside a group is irrelevant (see above)
+        for (int u = 0; u < 16; ++u) {
+          const int i = b0 + u * 64 + lane;
+          g[u] = (i < N) ? group_of(rec[u]) : -1;
+        }
+        uint32_t pos[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) pos[u] = (g[u] >= 0) ? atomicAdd(&cur[g[u]], 1u) : 0u;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (g[u] >= 0) H[pos[u]] = rec[u];  // the order inside a group is irrelevant (see above)
       }
     }
     __syncthreads();
+#ifdef QT_PROFILE
+    if (lane == 0 && blockIdx.y == 0)
+      printf("qt build level-block %d: setup %lld pass1 %lld totals+prefix %lld pass2 %lld\n", (int)blockIdx.x, tb0 - tp0, tb1 - tb0, tb2 - tb1,
+             (long long)__builtin_readcyclecounter() - tb2);
+#endif
     for (int st = 0; st < ns; ++st) {
       const int c = __builtin_amdgcn_readlane(strip_cnt, st);
       const int off = __builtin_amdgcn_readlane(strip_base, st);
@@ -360,6 +481,9 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
   }
   __syncthreads();
 
+#ifdef QT_PROFILE
+  const long long tp1 = __builtin_readcyclecounter();
+#endif
   // ---- best-first expansion ----
   // A lone wave pays tens of cycles for every taken branch (nothing hides the instruction fetch), so the step is
   // written as straight-line predicated code: fixed 8-way unrolled arg-max, uniform-address LDS traffic executed by
@@ -368,6 +492,207 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
   long long iter = 0;
   while (n_act < need && n_act > 0 && iter < max_iter) {
     ++iter;
+    // ---- batched pops ------------------------------------------------------------------------------------------------------
+    // Pops come in non-increasing count order (a child never outnumbers its parent), so the next pops are simply the head of the
+    // table sorted by key -- as long as no child created on the way outnumbers a later member of that head (it would have to be
+    // popped first).  One lane takes one node: the up-to-64 nodes with the largest keys are sorted into pop order, every lane
+    // splits its node (four precomputed totals, or the node's <= 64 records held in registers), and a prefix scan finds how many
+    // of these pops the reference would really make in this order: up to the first member outnumbered by an earlier member's
+    // child, up to the pop that reaches the quota, and never across a node that vanishes (the table would need compacting) or
+    // holds more than 64 records; those take the one-node path below.  Sequence numbers and table slots are handed out in pop
+    // order, so the table afterwards is exactly what the same pops made one at a time leave behind.  (A level needs 40-150
+    // pops; measured on the synthetic frames the valid prefix is almost always the whole head: ~10 batches per tree.)
+    if (batch_on && n_act <= 512) {
+      unsigned long long lk[8];
+      uint32_t lmax = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        lk[u] = 0ull;
+        if (u * 64 < n_act) {
+          const int jj = u * 64 + lane;
+          lk[u] = (jj < n_act) ? n_key[jj] : 0ull;
+        }
+        lmax = max(lmax, (uint32_t)(lk[u] >> 32));
+      }
+      const uint32_t mc = wave_max_u32(lmax);
+      uint32_t C = (mc >> 1) + 1;  // the head = every node with count >= C: a prefix of the pop order whatever C is
+      int B;
+      for (;;) {
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cnt += ((uint32_t)(lk[u] >> 32) >= C) ? 1u : 0u;
+        B = (int)wave_sum_u32(cnt);
+        if (B <= 64 || C >= mc) break;
+        C = (C + mc + 1) >> 1;
+      }
+      if (B <= 64) {
+        // members -> dense list (table order), then one member per lane, sorted into pop order (key descending)
+        int base = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (u * 64 < n_act) {
+            const bool mem = (uint32_t)(lk[u] >> 32) >= C;
+            const unsigned long long m = __ballot(mem);
+            if (mem) {
+              const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
+              bkey[idx] = lk[u];
+              bj[idx] = (uint32_t)(u * 64 + lane);
+            }
+            base += __popcll(m);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // pop order = keys descending.  Rank by counting (the B keys are read back with wave-uniform addresses, all reads
+        // independent) instead of a 64-lane bitonic network (21 dependent cross-lane exchanges of ~100 cycles each).
+        unsigned long long mykey = (lane < B) ? bkey[lane] : 0ull;
+        uint32_t myj = (lane < B) ? bj[lane] : 0u;
+        {
+          int rank = 0;
+          for (int i = 0; i < B; i += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const unsigned long long o = (i + u < B) ? bkey[i + u] : 0ull;
+              rank += o > mykey;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if (lane < B) {
+            bkey[rank] = mykey;  // keys are distinct (unique sequence numbers): the ranks are a permutation
+            bj[rank] = myj;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          mykey = (lane < B) ? bkey[lane] : 0ull;
+          myj = (lane < B) ? bj[lane] : 0u;
+        }
+        const bool act = lane < B;
+        const int j = (int)myj;
+        const int n = (int)(mykey >> 32);
+        const double rb = n_rb[j], re = n_re[j], cb = n_cb[j], ce = n_ce[j];
+        const uint32_t beg_raw = n_beg[j];
+        const int beg = (int)(beg_raw & QT_BEG_MASK), code = (int)(beg_raw >> 24);
+        const double midy = (rb + re) / 2, midx = (cb + ce) / 2;
+        const SplitInt sp = make_split(midx, midy);
+        const bool is_pp = pp_ok && code != 0;
+        const unsigned long long big = __ballot(act && !is_pp && n > 64);
+        const int b_eff = big ? min(B, __ffsll((long long)big) - 1) : B;
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0, child_code = 0;
+        if (is_pp) {
+          const int st = (code - 1) / QT_PP_INTERNAL, k = (code - 1) - QT_PP_INTERNAL * st;
+          const uint16_t* t = tot + st * QT_PP_TOTALS;
+          int ti;
+          if (k == 20) {
+            ti = 0;
+            child_code = 1 + st * QT_PP_INTERNAL + 16;
+          } else if (k >= 16) {
+            ti = 4 + (k - 16) * 4;
+            child_code = 1 + st * QT_PP_INTERNAL + (k - 16) * 4;
+          } else {
+            ti = 20 + k * 4;
+          }
+          c0 = t[ti], c1 = t[ti + 1], c2 = t[ti + 2], c3 = t[ti + 3];
+        }
+        // the ordinary members: all records of a node into the registers of its lane (one round trip for the whole head)
+        const bool ld = lane < b_eff && !is_pp;
+        const int nmax = (int)wave_max_u32(ld ? (uint32_t)n : 0u);
+        uint32_t* seg = H + beg;
+        uint32_t rec[64];
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+          if (c8 * 8 < nmax) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int i = c8 * 8 + u;
+              rec[i] = (ld && i < n) ? seg[i] : 0u;
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rec[c8 * 8 + u] = 0u;
+          }
+        }
+        if (ld) {
+          int k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+#pragma unroll
+          for (int c8 = 0; c8 < 8; ++c8) {
+            if (c8 * 8 < nmax) {
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const int i = c8 * 8 + u;
+                const int q = (i < n) ? quadrant_of(rec[i], sp) : -1;
+                k0 += q == 0, k1 += q == 1, k2 += q == 2, k3 += q == 3;
+              }
+            }
+          }
+          c0 = k0, c1 = k1, c2 = k2, c3 = k3;
+        }
+        const int ne0 = c0 > 0, ne1 = c1 > 0, ne2 = c2 > 0, ne3 = c3 > 0;
+        const int added = ne0 + ne1 + ne2 + ne3;
+        const bool in = lane < b_eff;
+        const int d = in ? added - 1 : 0;
+        const int incl = wave_incl_scan(d, lane);              // growth of the table up to and including this pop
+        const int em = wave_excl_max(in ? max(max(c0, c1), max(c2, c3)) : 0, lane);
+        const unsigned long long bad = __ballot(in && (em > n || added == 0));   // a child of an earlier member comes first | the node vanishes
+        const unsigned long long stop = __ballot(in && (n_act + incl >= need));  // the quota is reached by this pop
+        int v = b_eff;
+        if (bad) v = min(v, __ffsll((long long)bad) - 1);
+        if (stop) v = min(v, __ffsll((long long)stop));
+        if (v > 0) {
+          const bool cm = lane < v;
+          const int ex = incl - d;  // table growth of the earlier pops = (children of the earlier pops) - (earlier pops)
+          const uint32_t seq0 = next_seq + (uint32_t)(ex + lane);
+          const int slot0 = n_act + ex;
+          if (cm) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int cc = q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3));
+              const int offc = beg + (q == 0 ? 0 : (q == 1 ? c0 : (q == 2 ? c0 + c1 : c0 + c1 + c2)));
+              const int rank = q == 0 ? 0 : (q == 1 ? ne0 : (q == 2 ? ne0 + ne1 : ne0 + ne1 + ne2));
+              if (cc > 0) {
+                const int slot = rank == 0 ? j : slot0 + rank - 1;  // first child into the popped node's slot, the others appended
+                n_rb[slot] = (q & 2) ? midy : rb;
+                n_re[slot] = (q & 2) ? re : midy;
+                n_cb[slot] = (q & 1) ? midx : cb;
+                n_ce[slot] = (q & 1) ? ce : midx;
+                n_key[slot] = ((unsigned long long)cc << 32) | (unsigned long long)(0xFFFFFFFFu - (seq0 + (uint32_t)rank));
+                n_beg[slot] = (uint32_t)offc | ((uint32_t)(child_code ? child_code + q : 0) << 24);
+              }
+            }
+            if (!is_pp) {  // in-place 4-way partition straight from the registers (the node's segment belongs to this lane alone)
+              int p0 = 0, p1 = c0, p2 = c0 + c1, p3 = c0 + c1 + c2;
+#pragma unroll
+              for (int c8 = 0; c8 < 8; ++c8) {
+                if (c8 * 8 < nmax) {
+#pragma unroll
+                  for (int u = 0; u < 8; ++u) {
+                    const int i = c8 * 8 + u;
+                    const int q = (i < n) ? quadrant_of(rec[i], sp) : -1;
+                    if (q >= 0) {
+                      const int pos = q == 0 ? p0 : (q == 1 ? p1 : (q == 2 ? p2 : p3));
+                      seg[pos] = rec[i];
+                      p0 += q == 0, p1 += q == 1, p2 += q == 2, p3 += q == 3;
+                    }
+                  }
+                }
+              }
+            }
+          }
+          const int grow = __builtin_amdgcn_readlane(incl, v - 1);
+          n_act += grow;
+          next_seq += (uint32_t)(grow + v);
+#ifdef QT_PROFILE
+          ++prof_batches, prof_batched_pops += v;
+#endif
+          if (n_act + 3 > pp_limit) pp_ok = false;  // the table has reached the totals parked in its tail
+          if (!IN_LDS) __syncthreads();
+          continue;
+        }
+      }
+    }
+#ifdef QT_PROFILE
+    ++prof_single;
+#endif
     // pop: arg-max of (count desc, seq asc) = max of the 64-bit key
     uint32_t bc = 0, bs = 0;
     int bj = 0;
@@ -525,6 +850,9 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
   }
   __syncthreads();
 
+#ifdef QT_PROFILE
+  const long long tp2 = __builtin_readcyclecounter();
+#endif
   // ---- nodes2kpoints (ORBExtractor.cc:182-192): keep the first min(need, size) nodes in map order ----
   while (n_act > need) {
     // drop the last node in map order = arg-min of the key
@@ -659,6 +987,12 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     }
   }
   if (lane == 0) *sel_count_out = n_act;
+#ifdef QT_PROFILE
+  const long long tp3 = __builtin_readcyclecounter();
+  if (lane == 0 && blockIdx.y == 0)
+    printf("qt level-block %d N %d need %d: build %lld expand %lld (batches %d pops %d single %d) select %lld cycles(100MHz)\n", (int)blockIdx.x, N, need,
+           tp1 - tp0, tp2 - tp1, prof_batches, prof_batched_pops, prof_single, tp3 - tp2);
+#endif
 }
 
 
@@ -666,7 +1000,7 @@ __global__ __launch_bounds__(64) void k_quadtree(const LevelDev* __restrict__ lv
                                                  uint32_t* __restrict__ scratch_b, uint32_t* __restrict__ scratch_c,
                                                  size_t scratch_pitch,
                                                  uint32_t* __restrict__ sel, int32_t* __restrict__ sel_count, int n_features,
-                                                 const int32_t* __restrict__ n_cand, int node_cap, int sort_cap, int rec_cap) {
+                                                 const int32_t* __restrict__ n_cand, int node_cap, int sort_cap, int rec_cap, int batch) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
   const int level = blockIdx.x, img = blockIdx.y;
@@ -678,7 +1012,9 @@ __global__ __launch_bounds__(64) void k_quadtree(const LevelDev* __restrict__ lv
   double* n_ce = n_cb + node_cap;
   unsigned long long* n_key = (unsigned long long*)(n_ce + node_cap);
   uint32_t* n_beg = (uint32_t*)(n_key + node_cap);
-  uint32_t* lds_recs = n_beg + node_cap;
+  unsigned long long* bkey = (unsigned long long*)(n_beg + ((node_cap + 1) & ~1));  // head list of the batched pops: 64 keys + 64 slots
+  uint32_t* bj = (uint32_t*)(bkey + 64);
+  uint32_t* lds_recs = bj + 64;
   unsigned long long* sortbuf = (unsigned long long*)lds;
 
   uint32_t* out_sel = sel + (size_t)img * n_features + L.quota_off;
@@ -723,15 +1059,16 @@ __global__ __launch_bounds__(64) void k_quadtree(const LevelDev* __restrict__ lv
   }
 
   if (in_lds)
-    tree_body<true>(L, A, N, lds_recs, gb, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, node_cap, need, sort_cap, out_sel,
+    tree_body<true>(L, A, N, lds_recs, gb, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, bkey, bj, batch, node_cap, need, sort_cap, out_sel,
                     sel_count + (size_t)img * n_levels + level, lane);
   else
-    tree_body<false>(L, A, N, gb, gc, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, node_cap, need, sort_cap, out_sel,
+    tree_body<false>(L, A, N, gb, gc, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, bkey, bj, batch, node_cap, need, sort_cap, out_sel,
                      sel_count + (size_t)img * n_levels + level, lane);
 }
 
 size_t quadtree_lds_bytes(int node_cap, int rec_cap) {
-  return (size_t)node_cap * (4 * sizeof(double) + sizeof(unsigned long long) + sizeof(uint32_t)) + (size_t)rec_cap * sizeof(uint32_t);
+  return (size_t)node_cap * (4 * sizeof(double) + sizeof(unsigned long long) + sizeof(uint32_t)) + 8 + 64 * (sizeof(unsigned long long) + sizeof(uint32_t)) +
+         (size_t)rec_cap * sizeof(uint32_t);
 }
 
 hipError_t quadtree_configure(size_t lds_bytes) {
@@ -740,11 +1077,11 @@ hipError_t quadtree_configure(size_t lds_bytes) {
 
 void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint32_t* d_cand, uint32_t* d_scr_b, uint32_t* d_scr_c,
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
-                     int rec_cap, int n_img) {
+                     int rec_cap, int n_img, int batch) {
   if (n_img <= 0) return;
   const size_t lds = quadtree_lds_bytes(node_cap, rec_cap);
   hipLaunchKernelGGL(k_quadtree, dim3(n_levels, n_img), dim3(64), lds, s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
-                     d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap);
+                     d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch);
 }
 
 }  // namespace orbfe
