@@ -26,6 +26,7 @@
 
 namespace orbfe {
 
+#define QT_HEAD 32           // batched pops: nodes taken per step (the valid prefix is rarely longer than 16)
 #define QT_INPLACE_CHUNKS 4  // nodes up to QT_INPLACE_CHUNKS*64 records are partitioned in registers
 
 template <int CTRL, int ROW_MASK>
@@ -232,10 +233,6 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
                                           int sort_cap, uint32_t* __restrict__ out_sel, int32_t* __restrict__ sel_count_out, int lane) {
   int n_act = 0;
   uint32_t next_seq = 0;
-#ifdef QT_PROFILE
-  const long long tp0 = __builtin_readcyclecounter();
-  int prof_batches = 0, prof_batched_pops = 0, prof_single = 0;
-#endif
   // ---- first pop: the root, whose children are the initSplit strips (ORBExtractor.cc:81-96, 147-170) ----
   const int ns = L.n_ini;
   const int n_tot = (ns * QT_PP_TOTALS + 3) & ~3;
@@ -288,9 +285,6 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       }
       return pp_group(r, G, xt);
     };
-#ifdef QT_PROFILE
-    const long long tb0 = __builtin_readcyclecounter();
-#endif
     // pass 1: group sizes.  Sixteen records per lane per trip, and the next trip's records are requested before this trip's are
     // classified: a lone wave sees every global round trip, so the loads of trip k+1 fly under the work of trip k.
     auto load16 = [&](int b0, uint32_t* r) {
@@ -320,9 +314,6 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       }
     }
     __syncthreads();
-#ifdef QT_PROFILE
-    const long long tb1 = __builtin_readcyclecounter();
-#endif
     // totals of the 84 nodes below every strip, then sizes -> cursors (exclusive prefix in layout order)
     for (int t = lane; t < ns * QT_PP_TOTALS; t += 64) {
       const int st = t / QT_PP_TOTALS, k = t - QT_PP_TOTALS * st;
@@ -363,9 +354,6 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     }
     strip_cnt -= strip_base;
     __syncthreads();
-#ifdef QT_PROFILE
-    const long long tb2 = __builtin_readcyclecounter();
-#endif
     // pass 2: scatter
     {
       uint32_t nxt[16];
@@ -390,11 +378,6 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       }
     }
     __syncthreads();
-#ifdef QT_PROFILE
-    if (lane == 0 && blockIdx.y == 0)
-      printf("qt build level-block %d: setup %lld pass1 %lld totals+prefix %lld pass2 %lld\n", (int)blockIdx.x, tb0 - tp0, tb1 - tb0, tb2 - tb1,
-             (long long)__builtin_readcyclecounter() - tb2);
-#endif
     for (int st = 0; st < ns; ++st) {
       const int c = __builtin_amdgcn_readlane(strip_cnt, st);
       const int off = __builtin_amdgcn_readlane(strip_base, st);
@@ -481,9 +464,6 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
   }
   __syncthreads();
 
-#ifdef QT_PROFILE
-  const long long tp1 = __builtin_readcyclecounter();
-#endif
   // ---- best-first expansion ----
   // A lone wave pays tens of cycles for every taken branch (nothing hides the instruction fetch), so the step is
   // written as straight-line predicated code: fixed 8-way unrolled arg-max, uniform-address LDS traffic executed by
@@ -522,10 +502,10 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
 #pragma unroll
         for (int u = 0; u < 8; ++u) cnt += ((uint32_t)(lk[u] >> 32) >= C) ? 1u : 0u;
         B = (int)wave_sum_u32(cnt);
-        if (B <= 64 || C >= mc) break;
+        if (B <= QT_HEAD || C >= mc) break;
         C = (C + mc + 1) >> 1;
       }
-      if (B <= 64) {
+      if (B <= QT_HEAD) {
         // members -> dense list (table order), then one member per lane, sorted into pop order (key descending)
         int base = 0;
 #pragma unroll
@@ -549,11 +529,16 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         uint32_t myj = (lane < B) ? bj[lane] : 0u;
         {
           int rank = 0;
-          for (int i = 0; i < B; i += 4) {
+          const uint32_t mh = (uint32_t)(mykey >> 32), ml = (uint32_t)mykey;
+          const uint4* bk4 = (const uint4*)bkey;  // two keys per read, wave-uniform addresses
+          for (int i = 0; i < B; i += 8) {
+            uint4 k4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) k4[u] = bk4[min((i >> 1) + u, QT_HEAD / 2 - 1)];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-              const unsigned long long o = (i + u < B) ? bkey[i + u] : 0ull;
-              rank += o > mykey;
+              const bool g0 = k4[u].y > mh || (k4[u].y == mh && k4[u].x > ml), g1 = k4[u].w > mh || (k4[u].w == mh && k4[u].z > ml);
+              rank += (i + 2 * u < B && g0) + (i + 2 * u + 1 < B && g1);
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -599,14 +584,12 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         const int nmax = (int)wave_max_u32(ld ? (uint32_t)n : 0u);
         uint32_t* seg = H + beg;
         uint32_t rec[64];
+        const int nld = ld ? n : 1;  // (clamped indices: unconditional loads, no branch per record; lanes without an ordinary node re-read one word)
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8) {
           if (c8 * 8 < nmax) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int i = c8 * 8 + u;
-              rec[i] = (ld && i < n) ? seg[i] : 0u;
-            }
+            for (int u = 0; u < 8; ++u) rec[c8 * 8 + u] = seg[min(c8 * 8 + u, nld - 1)];
           } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) rec[c8 * 8 + u] = 0u;
@@ -668,11 +651,11 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
                   for (int u = 0; u < 8; ++u) {
                     const int i = c8 * 8 + u;
                     const int q = (i < n) ? quadrant_of(rec[i], sp) : -1;
-                    if (q >= 0) {
-                      const int pos = q == 0 ? p0 : (q == 1 ? p1 : (q == 2 ? p2 : p3));
-                      seg[pos] = rec[i];
-                      p0 += q == 0, p1 += q == 1, p2 += q == 2, p3 += q == 3;
-                    }
+                    // a record on a split line goes to the last slot of the segment, which lies behind the children whenever
+                    // such a record exists: one predicated store per record, no position-dependent branch
+                    const int pos = q == 0 ? p0 : (q == 1 ? p1 : (q == 2 ? p2 : (q == 3 ? p3 : n - 1)));
+                    if (i < n) seg[pos] = rec[i];
+                    p0 += q == 0, p1 += q == 1, p2 += q == 2, p3 += q == 3;
                   }
                 }
               }
@@ -681,18 +664,12 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
           const int grow = __builtin_amdgcn_readlane(incl, v - 1);
           n_act += grow;
           next_seq += (uint32_t)(grow + v);
-#ifdef QT_PROFILE
-          ++prof_batches, prof_batched_pops += v;
-#endif
           if (n_act + 3 > pp_limit) pp_ok = false;  // the table has reached the totals parked in its tail
           if (!IN_LDS) __syncthreads();
           continue;
         }
       }
     }
-#ifdef QT_PROFILE
-    ++prof_single;
-#endif
     // pop: arg-max of (count desc, seq asc) = max of the 64-bit key
     uint32_t bc = 0, bs = 0;
     int bj = 0;
@@ -850,9 +827,6 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
   }
   __syncthreads();
 
-#ifdef QT_PROFILE
-  const long long tp2 = __builtin_readcyclecounter();
-#endif
   // ---- nodes2kpoints (ORBExtractor.cc:182-192): keep the first min(need, size) nodes in map order ----
   while (n_act > need) {
     // drop the last node in map order = arg-min of the key
@@ -987,12 +961,6 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     }
   }
   if (lane == 0) *sel_count_out = n_act;
-#ifdef QT_PROFILE
-  const long long tp3 = __builtin_readcyclecounter();
-  if (lane == 0 && blockIdx.y == 0)
-    printf("qt level-block %d N %d need %d: build %lld expand %lld (batches %d pops %d single %d) select %lld cycles(100MHz)\n", (int)blockIdx.x, N, need,
-           tp1 - tp0, tp2 - tp1, prof_batches, prof_batched_pops, prof_single, tp3 - tp2);
-#endif
 }
 
 

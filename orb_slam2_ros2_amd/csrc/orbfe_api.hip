@@ -1114,8 +1114,10 @@ orbfe_status orbfe_stereo_batch_device(orbfe_ctx* c, const uint8_t* d_left, cons
   const bool pipe = c->pipeline_stereo && c->stereo_stream && c->prof != 1 && n_chunks == 1 && n_pairs >= 16;
   if (pipe) {
     if (!c->d_pyr_alt) {
+      // (cleared ON THE CONTEXT STREAM: a null-stream hipMemset returns before the device has run it and is not ordered with this
+      //  non-blocking stream -- it was seen zeroing rows of the first batch's level 0 after k_load_level0 had written them)
       if (hipMalloc((void**)&c->d_pyr_alt, (size_t)c->cfg.max_images * c->img_pitch) != hipSuccess ||
-          hipMemset(c->d_pyr_alt, 0, (size_t)c->cfg.max_images * c->img_pitch) != hipSuccess) {
+          hipMemsetAsync(c->d_pyr_alt, 0, (size_t)c->cfg.max_images * c->img_pitch, c->stream) != hipSuccess) {
         (void)hipGetLastError();
         c->d_pyr_alt = nullptr;
         c->pipeline_stereo = false;  // no room for the second pyramid: plain in-order execution
