@@ -26,7 +26,6 @@
 
 namespace orbfe {
 
-#define QT_HEAD 32           // batched pops: nodes taken per step (the valid prefix is rarely longer than 16)
 #define QT_INPLACE_CHUNKS 4  // nodes up to QT_INPLACE_CHUNKS*64 records are partitioned in registers
 
 template <int CTRL, int ROW_MASK>
@@ -502,10 +501,10 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
 #pragma unroll
         for (int u = 0; u < 8; ++u) cnt += ((uint32_t)(lk[u] >> 32) >= C) ? 1u : 0u;
         B = (int)wave_sum_u32(cnt);
-        if (B <= QT_HEAD || C >= mc) break;
+        if (B <= 64 || C >= mc) break;
         C = (C + mc + 1) >> 1;
       }
-      if (B <= QT_HEAD) {
+      if (B <= 64) {
         // members -> dense list (table order), then one member per lane, sorted into pop order (key descending)
         int base = 0;
 #pragma unroll
@@ -529,16 +528,11 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         uint32_t myj = (lane < B) ? bj[lane] : 0u;
         {
           int rank = 0;
-          const uint32_t mh = (uint32_t)(mykey >> 32), ml = (uint32_t)mykey;
-          const uint4* bk4 = (const uint4*)bkey;  // two keys per read, wave-uniform addresses
-          for (int i = 0; i < B; i += 8) {
-            uint4 k4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) k4[u] = bk4[min((i >> 1) + u, QT_HEAD / 2 - 1)];
+          for (int i = 0; i < B; i += 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-              const bool g0 = k4[u].y > mh || (k4[u].y == mh && k4[u].x > ml), g1 = k4[u].w > mh || (k4[u].w == mh && k4[u].z > ml);
-              rank += (i + 2 * u < B && g0) + (i + 2 * u + 1 < B && g1);
+              const unsigned long long o = (i + u < B) ? bkey[i + u] : 0ull;
+              rank += o > mykey;
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -584,12 +578,14 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         const int nmax = (int)wave_max_u32(ld ? (uint32_t)n : 0u);
         uint32_t* seg = H + beg;
         uint32_t rec[64];
-        const int nld = ld ? n : 1;  // (clamped indices: unconditional loads, no branch per record; lanes without an ordinary node re-read one word)
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8) {
           if (c8 * 8 < nmax) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) rec[c8 * 8 + u] = seg[min(c8 * 8 + u, nld - 1)];
+            for (int u = 0; u < 8; ++u) {
+              const int i = c8 * 8 + u;
+              rec[i] = (ld && i < n) ? seg[i] : 0u;
+            }
           } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) rec[c8 * 8 + u] = 0u;
@@ -651,11 +647,11 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
                   for (int u = 0; u < 8; ++u) {
                     const int i = c8 * 8 + u;
                     const int q = (i < n) ? quadrant_of(rec[i], sp) : -1;
-                    // a record on a split line goes to the last slot of the segment, which lies behind the children whenever
-                    // such a record exists: one predicated store per record, no position-dependent branch
-                    const int pos = q == 0 ? p0 : (q == 1 ? p1 : (q == 2 ? p2 : (q == 3 ? p3 : n - 1)));
-                    if (i < n) seg[pos] = rec[i];
-                    p0 += q == 0, p1 += q == 1, p2 += q == 2, p3 += q == 3;
+                    if (q >= 0) {
+                      const int pos = q == 0 ? p0 : (q == 1 ? p1 : (q == 2 ? p2 : p3));
+                      seg[pos] = rec[i];
+                      p0 += q == 0, p1 += q == 1, p2 += q == 2, p3 += q == 3;
+                    }
                   }
                 }
               }
