@@ -243,29 +243,45 @@ __global__ __launch_bounds__(256) void k_blur(const LevelDev* __restrict__ lv, i
 // slot0 + i*slot_step takes image i.  16 pixels per thread: one (unaligned) 16-byte load from the caller's rows, one aligned
 // 16-byte store into the padded plane (4 bytes per thread ran at 2 TB/s).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_load_level0(const uint8_t* __restrict__ src, size_t src_stride, size_t src_pitch,
-                                                     uint8_t* __restrict__ pyr, size_t img_pitch, uint32_t plane_off, int dst_stride,
-                                                     int w, int h, int slot0, int slot_step) {
-  const int i = blockIdx.z;
-  const int y = blockIdx.y * 4 + threadIdx.y;
-  const int x16 = (blockIdx.x * 64 + threadIdx.x) * 16;
-  if (x16 >= w || y >= h) return;
-  const uint8_t* s = src + (size_t)i * src_pitch + (size_t)y * src_stride + x16;
-  uint8_t* d = pyr + (size_t)(slot0 + i * slot_step) * img_pitch + plane_off + (size_t)y * dst_stride + x16;
-  if (x16 + 15 < w) {
-    uint4 v;
-    __builtin_memcpy(&v, s, 16);
-    *(uint4*)d = v;
-  } else {
-    for (int k = 0; x16 + k < w; ++k) d[k] = s[k];
+// One image row = ceil(w / 16) units of 16 bytes; the units of an image are numbered row-major and a thread takes two of them
+// (rows are not a multiple of the block width: a 2-D block over (x, y) left 40 % of its lanes idle at w = 1241).  src_b (nullable):
+// a second source whose image i goes to slot slot0 + i * slot_step + 1 -- left and right eyes of a stereo batch in one launch.
+__global__ __launch_bounds__(256) void k_load_level0(const uint8_t* __restrict__ src_a, const uint8_t* __restrict__ src_b, size_t src_stride,
+                                                     size_t src_pitch, uint8_t* __restrict__ pyr, size_t img_pitch, uint32_t plane_off,
+                                                     int dst_stride, int w, int h, int slot0, int slot_step, int units_per_row,
+                                                     uint32_t inv_upr) {
+  const int z = blockIdx.y;
+  const int i = src_b ? (z >> 1) : z;
+  const uint8_t* src = (src_b && (z & 1)) ? src_b : src_a;
+  const int slot = slot0 + i * slot_step + ((src_b && (z & 1)) ? 1 : 0);
+  const uint8_t* sbase = src + (size_t)i * src_pitch;
+  uint8_t* dbase = pyr + (size_t)slot * img_pitch + plane_off;
+  const int n_units = units_per_row * h;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int u = (blockIdx.x * 2 + k) * 256 + threadIdx.x;
+    if (u >= n_units) return;
+    const int y = (int)(((unsigned long long)(uint32_t)u * inv_upr) >> 32), x16 = (u - y * units_per_row) * 16;
+    const uint8_t* s = sbase + (size_t)y * src_stride + x16;
+    uint8_t* d = dbase + (size_t)y * dst_stride + x16;
+    if (x16 + 15 < w) {
+      uint4 v;
+      __builtin_memcpy(&v, s, 16);
+      *(uint4*)d = v;
+    } else {
+      for (int b = 0; x16 + b < w; ++b) d[b] = s[b];
+    }
   }
 }
 
-void launch_load_level0(hipStream_t st, const uint8_t* d_src, size_t src_stride, size_t src_pitch, uint8_t* d_pyr, size_t img_pitch,
-                        uint32_t plane_off, int dst_stride, int w, int h, int slot0, int slot_step, int n_img) {
+void launch_load_level0(hipStream_t st, const uint8_t* d_src, const uint8_t* d_src_b, size_t src_stride, size_t src_pitch, uint8_t* d_pyr,
+                        size_t img_pitch, uint32_t plane_off, int dst_stride, int w, int h, int slot0, int slot_step, int n_img) {
   if (n_img <= 0) return;
-  hipLaunchKernelGGL(k_load_level0, dim3((w + 1023) / 1024, (h + 3) / 4, n_img), dim3(64, 4), 0, st, d_src, src_stride, src_pitch,
-                     d_pyr, img_pitch, plane_off, dst_stride, w, h, slot0, slot_step);
+  const int upr = (w + 15) / 16;
+  const uint32_t inv = (uint32_t)(((1ull << 32) + upr - 1) / upr);  // exact floor(u / upr) for u < 2^20 (u * (inv * upr - 2^32) < 2^32)
+  const int n_units = upr * h;
+  hipLaunchKernelGGL(k_load_level0, dim3((n_units + 511) / 512, d_src_b ? 2 * n_img : n_img), dim3(256), 0, st, d_src, d_src_b, src_stride,
+                     src_pitch, d_pyr, img_pitch, plane_off, dst_stride, w, h, slot0, slot_step, upr, inv);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -22,8 +22,8 @@ void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, c
                    size_t img_pitch, int n_img);
 void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int total_tiles, const uint8_t* d_pyr, uint8_t* d_blur,
                  size_t img_pitch, const int taps[7], int n_img);
-void launch_load_level0(hipStream_t st, const uint8_t* d_src, size_t src_stride, size_t src_pitch, uint8_t* d_pyr, size_t img_pitch,
-                        uint32_t plane_off, int dst_stride, int w, int h, int slot0, int slot_step, int n_img);
+void launch_load_level0(hipStream_t st, const uint8_t* d_src, const uint8_t* d_src_b, size_t src_stride, size_t src_pitch, uint8_t* d_pyr,
+                        size_t img_pitch, uint32_t plane_off, int dst_stride, int w, int h, int slot0, int slot_step, int n_img);
 // k_fast.hip
 void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, const LevelDev* h_lv, const int* lvl_max_pw,
                  const int* lvl_max_ph, const uint8_t* d_pyr, size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch,
@@ -1136,10 +1136,8 @@ orbfe_status orbfe_stereo_batch_device(orbfe_ctx* c, const uint8_t* d_left, cons
     hipStream_t st = serial ? c->stream : c->side[k];
     if (!serial) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_fork, 0));
     // level 0 of slot 2p / 2p+1 <- left / right image p
-    launch_load_level0(st, d_left + (size_t)p0 * image_pitch, stride, image_pitch, c->d_pyr, c->img_pitch, L0.plane_off, L0.stride,
-                       c->cfg.width, c->cfg.height, 2 * p0, 2, p1 - p0);
-    launch_load_level0(st, d_right + (size_t)p0 * image_pitch, stride, image_pitch, c->d_pyr, c->img_pitch, L0.plane_off, L0.stride,
-                       c->cfg.width, c->cfg.height, 2 * p0 + 1, 2, p1 - p0);
+    launch_load_level0(st, d_left + (size_t)p0 * image_pitch, d_right + (size_t)p0 * image_pitch, stride, image_pitch, c->d_pyr, c->img_pitch,
+                       L0.plane_off, L0.stride, c->cfg.width, c->cfg.height, 2 * p0, 2, p1 - p0);
     TRY(run_extract(c, st, 2 * p0, 2 * (p1 - p0), serial ? 1 : n_chunks, (piped && c->stereo_pending) ? c->ev_stereo_done : nullptr));
     if (piped) {
       HIP_TRY(c, hipEventRecord(c->ev_brief_done, st));
