@@ -320,7 +320,9 @@ void fast_lds_layout(int max_pw, int max_ph, int pp, int pv, int* v_off, int* q_
 // levels 0..3 into one launch with their common carve-up (31 waves) is 5 % slower than the four separate launches.
 void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, const LevelDev* h_lv, const int* lvl_max_pw,
                  const int* lvl_max_ph, const uint8_t* d_pyr, size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch,
-                 int32_t* d_n_cand, int n_levels, int n_img) {
+                 int32_t* d_n_cand, int n_levels, int n_img, hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, int side_from) {
+  // side (nullable): the launches of levels >= side_from go to this stream (after ev_go, recorded on s here; ev_done joins them
+  // back into s): the small levels do not fill the machine and their waves run in the tails the large levels' launches leave
   if (n_img <= 0) return;
   // a frame or two (the drop-in path): the whole sweep fits the machine at once, and eight back-to-back launches would each
   // cost a full wave lifetime (~18 us): one launch with the common carve-up instead (0.144 -> 0.03 ms for one stereo pair)
@@ -342,18 +344,28 @@ void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, co
                          cand_pitch, d_n_cand, n_levels, 0, total_cells, v_off, q_off, q_cap);
     return;
   }
+  const bool split = side && ev_go && ev_done && side_from > 0 && side_from < n_levels;
+  if (split) {
+    (void)hipEventRecord(ev_go, s);
+    (void)hipStreamWaitEvent(side, ev_go, 0);
+  }
   for (int l = 0; l < n_levels; ++l) {
     const int n_cells = h_lv[l].n_cells;
     if (n_cells <= 0 || lvl_max_pw[l] <= 6 || lvl_max_ph[l] <= 6) continue;
+    hipStream_t s_l = (split && l >= side_from) ? side : s;
     const bool small = lvl_max_pw[l] <= 44;
     int v_off, q_off, q_cap, total;
     fast_lds_layout(lvl_max_pw[l], lvl_max_ph[l], small ? 48 : 80, small ? 40 : 72, &v_off, &q_off, &q_cap, &total);
     if (small)
-      hipLaunchKernelGGL((k_fast<48, 40>), dim3(n_cells, n_img), dim3(64), total, s, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo,
+      hipLaunchKernelGGL((k_fast<48, 40>), dim3(n_cells, n_img), dim3(64), total, s_l, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo,
                          d_cand, cand_pitch, d_n_cand, n_levels, (int)h_lv[l].cell_base, n_cells, v_off, q_off, q_cap);
     else
-      hipLaunchKernelGGL((k_fast<80, 72>), dim3(n_cells, n_img), dim3(64), total, s, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo,
+      hipLaunchKernelGGL((k_fast<80, 72>), dim3(n_cells, n_img), dim3(64), total, s_l, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo,
                          d_cand, cand_pitch, d_n_cand, n_levels, (int)h_lv[l].cell_base, n_cells, v_off, q_off, q_cap);
+  }
+  if (split) {
+    (void)hipEventRecord(ev_done, side);
+    (void)hipStreamWaitEvent(s, ev_done, 0);
   }
 }
 

@@ -27,7 +27,7 @@ void launch_load_level0(hipStream_t st, const uint8_t* d_src, const uint8_t* d_s
 // k_fast.hip
 void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, const LevelDev* h_lv, const int* lvl_max_pw,
                  const int* lvl_max_ph, const uint8_t* d_pyr, size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch,
-                 int32_t* d_n_cand, int n_levels, int n_img);
+                 int32_t* d_n_cand, int n_levels, int n_img, hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, int side_from);
 // k_quadtree.hip
 size_t quadtree_lds_bytes(int node_cap, int rec_cap);
 hipError_t quadtree_configure(size_t lds_bytes);
@@ -126,7 +126,8 @@ struct orbfe_ctx {
   hipEvent_t ev_brief_done = nullptr, ev_stereo_done = nullptr;
   bool stereo_pending = false, pipeline_stereo = true;
   hipStream_t blur_stream = nullptr;
-  hipEvent_t ev_blur_go = nullptr, ev_blur_done = nullptr;
+  hipEvent_t ev_blur_go = nullptr, ev_blur_done = nullptr, ev_fast_go = nullptr, ev_fast_done = nullptr;
+  int fast_side_from = 4;  // k_fast launches of levels >= this run on the blur stream beside the large levels (ORBFE_FAST_SIDE_FROM; 0: off)
 
   // geometry (host copies)
   std::vector<LevelDev> lv;
@@ -436,6 +437,7 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
     c->rec_cap = (int)std::min<size_t>(std::min<size_t>(max_cand, 8192), budget / 4);
     if (const char* env = getenv("ORBFE_QT_REC_CAP")) c->rec_cap = std::max(0, std::min(c->rec_cap, atoi(env)));
     if (const char* env = getenv("ORBFE_QT_BATCH")) c->qt_batch = atoi(env) != 0;
+    if (const char* env = getenv("ORBFE_FAST_SIDE_FROM")) c->fast_side_from = atoi(env);
   }
   // umax (ORBExtractor::initMaxU)
   {
@@ -579,7 +581,8 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   {
     StageTimer t(c, ORBFE_STAGE_FAST, st);
     launch_fast(st, c->d_lv, c->d_cells, c->lv.data(), c->lvl_max_pw, c->lvl_max_ph, pyr, c->img_pitch, c->cfg.fast_hi, c->cfg.fast_lo,
-                c->d_scr_a + i0 * c->scratch_pitch, c->scratch_pitch, n_cand, nl, n_img);
+                c->d_scr_a + i0 * c->scratch_pitch, c->scratch_pitch, n_cand, nl, n_img, overlap_blur ? c->blur_stream : nullptr,
+                c->ev_fast_go, c->ev_fast_done, c->fast_side_from);
   }
   if (overlap_blur) {
     HIP_TRY(c, hipEventRecord(c->ev_blur_go, st));
@@ -672,6 +675,8 @@ void orbfe_destroy(orbfe_ctx* c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_blur_go) (void)hipEventDestroy(c->ev_blur_go);
   if (c->ev_blur_done) (void)hipEventDestroy(c->ev_blur_done);
+  if (c->ev_fast_go) (void)hipEventDestroy(c->ev_fast_go);
+  if (c->ev_fast_done) (void)hipEventDestroy(c->ev_fast_done);
   if (c->blur_stream) (void)hipStreamDestroy(c->blur_stream);
   if (c->stereo_stream) (void)hipStreamDestroy(c->stereo_stream);
   if (c->ev_brief_done) (void)hipEventDestroy(c->ev_brief_done);
@@ -754,7 +759,9 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     if (!ov || atoi(ov) != 0) {
       if (hipStreamCreateWithFlags(&c->blur_stream, hipStreamNonBlocking) != hipSuccess ||
           hipEventCreateWithFlags(&c->ev_blur_go, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&c->ev_blur_done, hipEventDisableTiming) != hipSuccess) {
+          hipEventCreateWithFlags(&c->ev_blur_done, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&c->ev_fast_go, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&c->ev_fast_done, hipEventDisableTiming) != hipSuccess) {
         fail(c, ORBFE_EDEVICE, "cannot create the blur stream");
         return bail(ORBFE_EDEVICE);
       }
