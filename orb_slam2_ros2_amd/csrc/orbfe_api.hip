@@ -318,6 +318,22 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
         ++n_cells;
       }
     }
+    // XCD-aware order: the workgroups of a launch go round-robin to the 8 XCDs, each with its own L2, and neighbouring patches
+    // share 6 of their ~36 columns / rows -- in row-major order every neighbour pair sits on two different L2s and the shared lines
+    // are fetched twice (or more).  Cells are regrouped into 8 vertical strips, strip x on table positions = x (mod 8), so that one
+    // XCD walks one strip of the image top to bottom.  (The candidate list of a level is a set: the cell order is free.)
+    if (n_cells >= 16 && !getenv("ORBFE_NO_XCD_ORDER")) {
+      std::vector<CellDev> strip[8];
+      const size_t first = c->cells.size() - (size_t)n_cells;
+      for (size_t i = first; i < c->cells.size(); ++i) {
+        const int jdx = c->cells[i].offx / std::max((int)L.w_cell, 1);
+        strip[std::min(7, jdx * 8 / std::max((int)L.n_cols, 1))].push_back(c->cells[i]);
+      }
+      size_t w = first;
+      for (size_t i = 0; w < c->cells.size(); ++i)
+        for (int x = 0; x < 8; ++x)
+          if (i < strip[x].size()) c->cells[w++] = strip[x][i];
+    }
     L.n_cells = n_cells;
     cell_base += n_cells;
     L.cand_cap = (uint32_t)n_cells * (uint32_t)L.cell_cap;
@@ -413,6 +429,21 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
       }
     }
   }
+  // XCD-aware order inside a class (one launch): workgroups go round-robin to the 8 XCDs, so the tiles are regrouped into 8 vertical
+  // strips of level 0 -- strip x on positions = x (mod 8), top to bottom, the levels of the class interleaved by source row -- and one
+  // XCD's L2 then serves its strip of level 0 to every level instead of each L2 fetching the whole plane for each level.
+  if (!getenv("ORBFE_NO_XCD_ORDER"))
+    for (int k = 0; k < 3; ++k) {
+      if (cls[k].size() < 16) continue;
+      std::vector<RsTile> strip[8];
+      for (const RsTile& t : cls[k]) strip[std::min(7, std::max(0, (int)t.sx_lo * 8 / std::max(cfg.width, 1)))].push_back(t);
+      for (auto& v : strip)
+        std::stable_sort(v.begin(), v.end(), [](const RsTile& a, const RsTile& b) { return a.sy_lo < b.sy_lo; });
+      size_t w = 0;
+      for (size_t i = 0; w < cls[k].size(); ++i)
+        for (int x = 0; x < 8; ++x)
+          if (i < strip[x].size()) cls[k][w++] = strip[x][i];
+    }
   for (int k = 0; k < 3; ++k) {
     c->rs_n[k] = (int)cls[k].size();
     c->rs_bytes[k] = (int)align_up((size_t)std::max(c->rs_bytes[k], 16), 16);
