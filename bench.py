@@ -236,9 +236,12 @@ def main():
             "avg_launch_ms": dom_ms,
             "images_per_launch": images_per_launch,
             # k_fast runs once per pyramid level (per-level LDS carve-up): the "launch" priced here is the level sweep of one
-            # batch, i.e. NLEVELS back-to-back k_fast launches; rocprofv3's per-launch average x NLEVELS is the same figure
+            # batch, i.e. NLEVELS k_fast launches, the small levels on a second stream BESIDE the large ones.  Their rocprofv3
+            # durations therefore overlap: the matching trace figure is the union of the launches' intervals per step (column
+            # UnionNs / steps of profiles/*_kernel_stats.csv, tools/kernel_stats_from_db.py), not average x NLEVELS
             "kernel_launches_per_step": {"fast": NLEVELS, "orient_brief": 4, "resize": 1, "blur": 1, "quadtree": 1, "stereo": 1}[dom],
             "avg_launch_ms_alone": stages_inline[dom],
+            "rocprof_match": "union of the overlapping k_fast launches per step (UnionNs / steps in profiles/r1_v13_kernel_stats.csv)",
             "all_stages": {k: {"ms": round(stages_inline[k], 4), "GBps": round(stage_bytes[k] / (stages_inline[k] * 1e-3) / 1e9, 1)}
                            for k in stages_inline if k in stage_bytes and stages_inline[k] > 0},
         },

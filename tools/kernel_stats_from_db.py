@@ -1,12 +1,30 @@
 #!/usr/bin/env python3
-"""Per-kernel summary (the `--stats` table) from a rocprofv3 rocpd database: tools/kernel_stats_from_db.py results.db > out.csv"""
+"""Per-kernel summary (the `--stats` table) from a rocprofv3 rocpd database: tools/kernel_stats_from_db.py results.db > out.csv
+Extra column UnionNs: the time during which AT LEAST ONE launch of the kernel was running.  For a kernel whose launches overlap
+(k_fast: the small pyramid levels run on a second stream beside the large ones) TotalDurationNs counts the overlapped time once per
+launch, UnionNs once; UnionNs / steps (steps = calls of k_quadtree, one per batched step) is the wall time of the stage per step --
+the figure bench.py measures with HIP events."""
 import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
-rows = db.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name "
-                  "order by 3 desc").fetchall()
-tot = sum(r[2] for r in rows) or 1
-print('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"')
-for n, c, t, a, mn, mx in rows:
-    print(f'"{n}",{c},{t},{a:.3f},{100.0 * t / tot:.2f},{mn},{mx}')
+names = [r[0] for r in db.execute("select distinct name from kernels")]
+rows = []
+for n in names:
+    iv = db.execute("select start, end from kernels where name = ? order by start", (n,)).fetchall()
+    tot = sum(e - s for s, e in iv)
+    union, cs, ce = 0, iv[0][0], iv[0][1]
+    for s, e in iv[1:]:
+        if s > ce:
+            union += ce - cs
+            cs, ce = s, e
+        else:
+            ce = max(ce, e)
+    union += ce - cs
+    d = [e - s for s, e in iv]
+    rows.append((n, len(iv), tot, tot / len(iv), min(d), max(d), union))
+rows.sort(key=lambda r: -r[2])
+total = sum(r[2] for r in rows) or 1
+print('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","UnionNs"')
+for n, c, t, a, mn, mx, u in rows:
+    print(f'"{n}",{c},{t},{a:.3f},{100.0 * t / total:.2f},{mn},{mx},{u}')
