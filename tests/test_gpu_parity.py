@@ -406,3 +406,40 @@ def test_back_to_back_device_batches_overlap_safely(orc, lib):
     nm5 = ctx.fetch_stereo(5)[0]
     assert nm5 == orc.stereo_frame(*sets[0][5 % 4], fx=FX, bf=BF)["n_matches"]   # pair 5 of the batch is untouched by the host call
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nf", [2000, 600])
+def test_clustered_corner_distributions_for_the_batched_quadtree(orc, lib, nf):
+    """Corner distributions that bend the quadtree's pop order: texture confined to one corner of the frame (a child of an early pop
+    outnumbers every other node: the batched pops must cut their head there), two clusters of very different density, a dense
+    column on a strip boundary, and isolated dots (single-point nodes that are halved until they vanish, ties everywhere).
+    Selection, order, angles and descriptors must equal the CPU restatement's; with ORBFE_QT_BATCH=0 the same holds."""
+    W, H = 1241, 376
+    rng = np.random.default_rng(21)
+    noise = lambda h, w, a=0, b=256: rng.integers(a, b, (h, w)).astype(np.uint8)
+    imgs = []
+    a = np.full((H, W), 110, np.uint8)
+    a[40:200, 60:360] = noise(160, 300)                      # everything in the first root strip, upper half
+    imgs.append(a)
+    b = np.full((H, W), 90, np.uint8)
+    b[30:340, 700:1200] = noise(310, 500)                    # dense cluster on the right ...
+    b[60:120, 40:400:7] = 255                                # ... and a sparse comb of bright columns on the left
+    imgs.append(b)
+    c = np.full((H, W), 128, np.uint8)
+    c[20:356, 300:322] = noise(336, 22)                      # a dense column around the boundary of the first two root strips
+    c[180:196, 30:1210] = noise(16, 1180)                    # and a dense row through the middle (the first horizontal split line)
+    imgs.append(c)
+    d = np.full((H, W), 100, np.uint8)
+    ys, xs = rng.integers(30, H - 30, 2600), rng.integers(30, W - 30, 2600)
+    for y, x in zip(ys, xs):                                  # isolated 3x3 dots: FAST corners a few pixels apart at most
+        d[y - 1:y + 2, x - 1:x + 2] = 230
+    imgs.append(d)
+    ctx = lib.Context(W, H, n_features=nf, max_images=1)
+    total = 0
+    for img in imgs:
+        k, dsc = ctx.extract(img)
+        ok, _ = assert_image_parity(ctx, 0, orc.extractor(img, n_features=nf), k, dsc, 8, check_planes=False)
+        total += len(ok)
+    assert total > nf  # the cases do select keypoints (not four empty results)
+    ctx.close()
