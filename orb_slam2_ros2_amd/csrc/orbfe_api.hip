@@ -115,6 +115,7 @@ struct orbfe_ctx {
     int n_img;
     bool want_kps, want_desc;
     const uint8_t* stage;
+    const uint8_t* pyr;  // the pyramid buffer baked into the captured kernels (the pipelined batch path swaps the context's two buffers)
     hipGraphExec_t exec;
   };
   std::vector<GraphEntry> graphs;
@@ -1024,7 +1025,7 @@ orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* con
         it = c->graphs.erase(it);
         continue;
       }
-      if (it->n_img == n_img && it->want_kps == (kps != nullptr) && it->want_desc == (desc != nullptr)) exec = it->exec;
+      if (it->n_img == n_img && it->want_kps == (kps != nullptr) && it->want_desc == (desc != nullptr) && it->pyr == c->d_pyr) exec = it->exec;
       ++it;
     }
     if (!exec) {
@@ -1035,7 +1036,7 @@ orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* con
       if (ok) ok = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess;
       if (g) (void)hipGraphDestroy(g);
       if (ok) {
-        c->graphs.push_back({n_img, kps != nullptr, desc != nullptr, c->h_stage, exec});
+        c->graphs.push_back({n_img, kps != nullptr, desc != nullptr, c->h_stage, c->d_pyr, exec});
       } else {
         (void)hipGetLastError();
         exec = nullptr;

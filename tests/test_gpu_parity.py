@@ -443,3 +443,28 @@ def test_clustered_corner_distributions_for_the_batched_quadtree(orc, lib, nf):
         total += len(ok)
     assert total > nf  # the cases do select keypoints (not four empty results)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_host_calls_between_device_batches_use_the_current_pyramid_buffer(orc, lib):
+    """A pipelined device batch swaps the context's two pyramid buffers; a host-pointer extract that replays a cached hipGraph must
+    write the buffer the following stereo_match / get_pyramid read (the graph cache is keyed on the buffer)."""
+    import torch
+    B = 16
+    pairs = [synth.stereo_pair(60 + i) for i in range(4)]
+    l = torch.from_numpy(np.stack([pairs[i % 4][0] for i in range(B)])).cuda()
+    r = torch.from_numpy(np.stack([pairs[i % 4][1] for i in range(B)])).cuda()
+    ctx = lib.Context(1241, 376, max_images=2 * B)
+    probes = [synth.stereo_pair(70 + i) for i in range(4)]
+    for step, (L, R) in enumerate(probes):
+        if step:  # an odd number of swaps between two host calls, then an even one
+            for _ in range(1 if step % 2 else 2):
+                ctx.stereo_batch_device(l.data_ptr(), r.data_ptr(), 1241, 1241 * 376, B, FX, BF)
+        (k0, d0), (k1, d1) = ctx.extract_batch([L, R])
+        ref = orc.stereo_frame(L, R, fx=FX, bf=BF)
+        n = len(ref["lk"])
+        assert np.array_equal(k0, ref["lk"]) and np.array_equal(d0, ref["ld"]) and np.array_equal(k1, ref["rk"])
+        nm, ru, dp, _, _ = ctx.stereo_match(0, 1, FX, BF)
+        assert nm == ref["n_matches"] and np.array_equal(ru[:n], ref["right_u"]) and np.array_equal(dp[:n], ref["depth"])
+        assert np.array_equal(ctx.pyramid(1, 2, False), orc.extractor(R).plane(2, False))
+    ctx.close()
