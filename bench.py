@@ -76,10 +76,19 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the front end has no CPU fallback)")
+    # test hooks (a 1-GPU box cannot run RCCL with two ranks): ORBFE_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # ORBFE_BENCH_BACKEND=gloo exchanges through host memory -- same control flow, used only to rehearse the N > 1 path
+    backend = os.environ.get("ORBFE_BENCH_BACKEND", "nccl")
+    if os.environ.get("ORBFE_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    xdev = dev if backend == "nccl" else torch.device("cpu")  # where the tensors of the collectives live
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     os.environ["ORBFE_STREAMS"] = str(max(1, args.streams))
     from orb_slam2_ros2_amd import synth
@@ -122,6 +131,7 @@ def main():
         summary[:, 3] = rank
         if world == 1:
             return [summary]
+        summary = summary.to(xdev)
         out = [torch.empty_like(summary) for _ in range(world)] if rank == 0 else None
         dist.gather(summary, out, dst=0)
         return out
@@ -176,7 +186,7 @@ def main():
     live = ctx.profile_read()
     ctx.profile_enable(0)
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
