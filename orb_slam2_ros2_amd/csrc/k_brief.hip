@@ -210,7 +210,13 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __res
   __shared__ double2 rot_all[BRIEF_WAVES][2 * BRIEF_R + 1];  // per wave: (v cos, v sin) for every template coordinate v in [-18, 18]  // one window per wave; the waves never synchronise
   const int lane = threadIdx.x & 63;
   uint32_t* win = win_all[threadIdx.x >> 6];
-  const int k = blockIdx.x * BRIEF_WAVES + (threadIdx.x >> 6);
+  // XCD-aware block order: workgroups go round-robin to the 8 XCDs (own L2 each) and consecutive keypoints are spatial neighbours
+  // (candidate order) whose 37x37 windows overlap; block b of the grid takes keypoint block (b % 8) * (grid / 8) + b / 8, so one XCD
+  // works through one contiguous eighth of the list (gridDim.x is a multiple of 8).  Fetched bytes 2.69 -> 0.85 GB per 1024 images;
+  // the time does not change (same-box A/B: 8.86 vs 8.87 ms per 512 pairs) -- the kernel is bound by the L1 fill rate.
+  const int per_xcd = (int)gridDim.x >> 3;
+  const int kb = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  const int k = kb * BRIEF_WAVES + (threadIdx.x >> 6);
   const int img = blockIdx.y;
   if (k >= n_features) return;
   // two dependent memory round trips per wave: the list entry, then the whole window + sin/cos + the lane's four template
@@ -299,7 +305,7 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
   hipLaunchKernelGGL(k_orient, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, d_kpl, n_features, d_moments, d_sincos,
                      d_kps, d_aux, d_kx, d_env, n_chunks, d_theta, rows0);
   if (before_brief) (void)hipStreamWaitEvent(s, before_brief, 0);  // the blurred planes come from another stream
-  hipLaunchKernelGGL(k_brief, dim3((n_features + BRIEF_WAVES - 1) / BRIEF_WAVES, n_img), dim3(64 * BRIEF_WAVES), 0, s, d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos,
+  hipLaunchKernelGGL(k_brief, dim3((((n_features + BRIEF_WAVES - 1) / BRIEF_WAVES) + 7) & ~7, n_img), dim3(64 * BRIEF_WAVES), 0, s, d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos,
                      d_desc);
 }
 
