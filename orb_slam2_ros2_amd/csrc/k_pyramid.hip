@@ -114,7 +114,6 @@ __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv,
 // new row yields one output row (vertical 16.16 sum, +0x8000 >> 16) stored as one 32-bit word.
 // Integer arithmetic only => bit-exact with the two-pass definition.
 // ---------------------------------------------------------------------------------------------
-#define BLUR_ROWS 32
 #define BLUR_WORDS 62
 
 struct BlurTaps {

@@ -16,6 +16,11 @@ struct ResizeTap {
   int16_t c0, c1;
 };
 
+// k_blur: output rows per wave (a block = 4 waves stacked vertically); the host sizes the tile grid with it
+#ifndef BLUR_ROWS
+#define BLUR_ROWS 32
+#endif
+
 // k_resize work item: RS_TW x RS_TH output pixels of one level and the level-0 footprint they read
 #define RS_TW 64
 #define RS_LDS_BYTES 16384  // largest footprint a tile may stage
