@@ -221,3 +221,23 @@ def test_cpp_shim_runs_local_ba_on_a_map_file(small_map, tmp_path):
     ctx.close()
     assert (n_group, n_points, n_edges, n_out, written) == (rep["n_group"], rep["n_points"], rep["n_edges"], rep["n_outlier_edges"], 1)
     assert (tmp_path / "out.pb").read_bytes() == want
+
+
+def test_c_abi_argument_checks_of_the_host_only_entry_points(small_map):
+    """NULL / size-query conventions of orbfe_map_pb_* and orbfe_map_local_graph (no device needed)."""
+    import ctypes as C
+    L = _lib.load()
+    _, _, pb = small_map
+    n = C.c_size_t(0)
+    assert L.orbfe_map_pb_summary(pb, len(pb), None) == 1                      # ORBFE_EBADARG
+    assert L.orbfe_map_pb_reencode(pb, len(pb), None, 0, None) == 1
+    assert L.orbfe_map_pb_reencode(pb, len(pb), None, 0, C.byref(n)) == 0 and n.value == len(pb)   # size query
+    small = (C.c_uint8 * 16)()
+    assert L.orbfe_map_pb_reencode(pb, len(pb), small, 16, C.byref(n)) == 4 and n.value == len(pb)  # ORBFE_ECAPACITY, size reported
+    sizes = (C.c_int32 * 4)()
+    assert L.orbfe_map_local_graph(pb, len(pb), 10, None, None) == 1
+    assert L.orbfe_map_local_graph(pb, len(pb), 10, C.byref(sizes), None) == 0 and sizes[0] >= sizes[1] > 0 and sizes[3] > 0
+    assert L.orbfe_map_local_graph(pb, len(pb), 11, C.byref(sizes), None) == 1  # no such keyframe
+    assert L.orbfe_map_local_graph(pb[: len(pb) // 2], len(pb) // 2, 10, C.byref(sizes), None) == 1  # truncated file
+    # the device entry point refuses NULL context / camera before touching anything
+    assert L.orbfe_map_local_ba(None, pb, len(pb), 10, None, None, None, 0, C.byref(n), None) == 1
