@@ -255,16 +255,22 @@ class Context:
 
     # ---- extraction -------------------------------------------------------------------------
     def extract_batch(self, imgs):
-        imgs = [np.ascontiguousarray(im, np.uint8) for im in imgs]
+        imgs = [np.asarray(im) for im in imgs]
         n = len(imgs)
         for im in imgs:
             if im.shape != (self.height, self.width):
                 raise ValueError(f"image shape {im.shape} != context geometry {(self.height, self.width)}")
+        # views with padded rows (a cv::Mat ROI / a row-padded camera buffer) go through as they are if they share one row stride
+        strides = {im.strides[0] for im in imgs}
+        if not (len(strides) == 1 and all(im.dtype == np.uint8 and im.strides[1] == 1 and im.strides[0] >= self.width for im in imgs)):
+            imgs = [np.ascontiguousarray(im, np.uint8) for im in imgs]
+            strides = {self.width}
+        stride = strides.pop() if n else self.width
         arr = (C.c_void_p * max(n, 1))(*[im.ctypes.data for im in imgs])
         kps = np.zeros((max(n, 1), max(self.n_features, 1)), KP_DTYPE)
         desc = np.zeros((max(n, 1), max(self.n_features, 1), 32), np.uint8)
         cnt = np.zeros(max(n, 1), np.int32)
-        self._check(self.lib.orbfe_extract_batch(self.h, n, arr, self.width, ptr(kps), ptr(desc), ptr(cnt)))
+        self._check(self.lib.orbfe_extract_batch(self.h, n, arr, stride, ptr(kps), ptr(desc), ptr(cnt)))
         return [(kps[i, :cnt[i]].copy(), desc[i, :cnt[i]].copy()) for i in range(n)]
 
     def extract(self, img):

@@ -468,3 +468,19 @@ def test_host_calls_between_device_batches_use_the_current_pyramid_buffer(orc, l
         assert nm == ref["n_matches"] and np.array_equal(ru[:n], ref["right_u"]) and np.array_equal(dp[:n], ref["depth"])
         assert np.array_equal(ctx.pyramid(1, 2, False), orc.extractor(R).plane(2, False))
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_host_images_with_padded_rows(orc, lib):
+    """orbfe_extract_batch takes the caller's row stride: a view into a wider buffer (a cv::Mat ROI) gives the result of the packed image."""
+    L, R = synth.stereo_pair(9)
+    big = np.random.default_rng(0).integers(0, 256, (376 + 6, 1241 + 123), dtype=np.uint8)
+    big2 = big.copy()
+    big[3:379, 50:1291] = L
+    big2[3:379, 50:1291] = R
+    ctx = lib.Context(1241, 376, max_images=2)
+    (k0, d0), (k1, d1) = ctx.extract_batch([big[3:379, 50:1291], big2[3:379, 50:1291]])
+    ref = orc.stereo_frame(L, R, fx=FX, bf=BF)
+    assert np.array_equal(k0, ref["lk"]) and np.array_equal(d0, ref["ld"]) and np.array_equal(k1, ref["rk"]) and np.array_equal(d1, ref["rd"])
+    assert ctx.stereo_match(0, 1, FX, BF)[0] == ref["n_matches"]
+    ctx.close()
