@@ -113,23 +113,29 @@ __device__ __forceinline__ int strip_of(uint32_t rec, const LevelDev& L) {
   return s;
 }
 
-// ---- pre-partition of the top three tree levels -------------------------------------------------------------------
+// ---- pre-partition of the top four tree levels ----------------------------------------------------------------------
 // The first pops of a level split nodes of hundreds to thousands of records, one wave moving 64 records per step: measured,
 // these partitions are half (records in LDS) to three quarters (records in global memory) of a tree's time.  But WHICH
 // child a record falls into does not depend on the pop order, only on the midpoints, which are fixed by the strip bounds.
-// So the records are scattered ONCE, in parallel, into the layout three levels of splitting would produce:
-//   node segment = [child 0 | child 1 | child 2 | child 3 | records on its split lines]   (recursively, three levels deep)
-// and popping a strip, a child or a grandchild only reads four precomputed totals.  A node that is never popped keeps its
-// whole segment, split-line records included, exactly like the reference's un-split node.  The order of the records
+// So the records are scattered ONCE, in parallel, into the layout four levels of splitting would produce:
+//   node segment = [child 0 | child 1 | child 2 | child 3 | records on its split lines]   (recursively, four levels deep)
+// and popping a strip or one of its descendants down to the great-grandchildren only reads four precomputed totals (a level of
+// 1241x376 with quota 434 never pops deeper: its pops are 4 + 16 + 64 + ~60 of those nodes).  A node that is never popped keeps
+// its whole segment, split-line records included, exactly like the reference's un-split node.  The order of the records
 // inside a segment is irrelevant (the per-node winner is the maximum response with ties broken by a key recomputed from
-// the coordinates).  Group index inside a strip (layout order): leaf (q1,q2,q3) = 21 q1 + 5 q2 + q3, lines of (q1,q2) =
-// 21 q1 + 5 q2 + 4, lines of (q1) = 21 q1 + 20, lines of the strip = 84.  Internal node index: (q1,q2) = 4 q1 + q2,
-// (q1) = 16 + q1, strip = 20.  Totals index: (q1) = q1, (q1,q2) = 4 + 4 q1 + q2, (q1,q2,q3) = 20 + 16 q1 + 4 q2 + q3.
-#define QT_PP_GROUPS 85
-#define QT_PP_INTERNAL 21
-#define QT_PP_TOTALS 84
+// the coordinates).  Group index inside a strip (layout order): leaf (q1,q2,q3,q4) = 85 q1 + 21 q2 + 5 q3 + q4, lines of
+// (q1,q2,q3) = 85 q1 + 21 q2 + 5 q3 + 4, lines of (q1,q2) = 85 q1 + 21 q2 + 20, lines of (q1) = 85 q1 + 84, lines of the strip
+// = 340.  Internal node index: (q1,q2,q3) = 16 q1 + 4 q2 + q3, (q1,q2) = 64 + 4 q1 + q2, (q1) = 80 + q1, strip = 84.  Totals in LDS
+// (parked in the node table's tail): (q1) = q1, (q1,q2) = 4 + 4 q1 + q2, (q1,q2,q3) = 20 + 16 q1 + 4 q2 + q3; the 256 totals of the
+// fourth level, (q1,q2,q3,q4) = 4 (16 q1 + 4 q2 + q3) + q4, live in global memory behind the level's bounce buffer (a batch of pops
+// reads them in one round trip).
+#define QT_PP_GROUPS 341
+#define QT_PP_INTERNAL 85
+#define QT_PP_TOTALS 84    // levels 1-3, LDS
+#define QT_PP_TOTALS4 256  // level 4, global memory
 #define QT_PP_MAX_STRIPS 4
-#define QT_BEG_MASK 0xFFFFFFu  // n_beg = segment begin | pre-partition code << 24 (0: a node split the ordinary way)
+#define QT_CODE_SHIFT 22
+#define QT_BEG_MASK 0x3FFFFFu  // n_beg = segment begin | pre-partition code << 22 (0: a node split the ordinary way)
 
 // Integer thresholds of the pre-partition.  The x and the y splits of a node are independent, and all strips share the rows
 // (0, reg_h): seven y thresholds (1 + 2 + 4 midpoints) are uniform, seven x thresholds per strip sit in LDS.
@@ -142,8 +148,9 @@ __device__ __forceinline__ Thr make_thr(double mid) {
   t.gt = (int)floor(mid) + 1;
   return t;
 }
-// the seven midpoints of three halvings of (lo, hi): index 0 | 1 + b1 | 3 + 2 b1 + b2   (same fp64 operations as the pop loop)
-__device__ __forceinline__ void thr7(double lo, double hi, Thr* out) {
+// the fifteen midpoints of four halvings of (lo, hi): index 0 | 1 + b1 | 3 + 2 b1 + b2 | 7 + 4 b1 + 2 b2 + b3   (same fp64 operations
+// as the pop loop)
+__device__ __forceinline__ void thr15(double lo, double hi, Thr* out) {
   const double m1 = (lo + hi) / 2;
   out[0] = make_thr(m1);
 #pragma unroll
@@ -154,7 +161,13 @@ __device__ __forceinline__ void thr7(double lo, double hi, Thr* out) {
 #pragma unroll
     for (int b2 = 0; b2 < 2; ++b2) {
       const double l2 = b2 ? m2 : l1, h2 = b2 ? h1 : m2;
-      out[3 + 2 * b1 + b2] = make_thr((l2 + h2) / 2);
+      const double m3 = (l2 + h2) / 2;
+      out[3 + 2 * b1 + b2] = make_thr(m3);
+#pragma unroll
+      for (int b3 = 0; b3 < 2; ++b3) {
+        const double l3 = b3 ? m3 : l2, h3 = b3 ? h2 : m3;
+        out[7 + 4 * b1 + 2 * b2 + b3] = make_thr((l3 + h3) / 2);
+      }
     }
   }
 }
@@ -163,62 +176,34 @@ __device__ __forceinline__ int half_of(int v, const Thr& t) { return v <= t.lt ?
 struct PpGeom {
   int ns, y_max;
   int s_lo[QT_PP_MAX_STRIPS], s_hi[QT_PP_MAX_STRIPS];  // integer form of the strict strip membership
-  Thr yt[7];
 };
-// group of a record (global index strip * 85 + local) or -1 if it lies in no strip.  Straight-line code: all three levels are
-// evaluated with clamped indices and the result is selected at the end -- a lone wave pays tens of cycles for every branch it
-// takes, and the sixteen records a lane classifies per trip can only overlap their threshold reads without branches between them.
-__device__ __forceinline__ int pp_group(uint32_t rec, const PpGeom& G, const Thr* xt /*LDS: [ns][7]*/) {
-  const int x = (int)ORBFE_REC_X(rec), y = (int)ORBFE_REC_Y(rec);
-  int st = -1;
-#pragma unroll
-  for (int k = 0; k < QT_PP_MAX_STRIPS; ++k) st = (k < G.ns && x >= G.s_lo[k] && x <= G.s_hi[k]) ? k : st;
-  const bool inside = y >= 1 && y <= G.y_max && st >= 0;
-  const int st0 = max(st, 0);
-  const Thr* t = xt + st0 * 7;
-  const Thr x1 = t[0];
-  const int bx1 = half_of(x, x1), by1 = half_of(y, G.yt[0]);
-  const bool ok1 = bx1 >= 0 && by1 >= 0;
-  const int cx1 = max(bx1, 0), cy1 = max(by1, 0);
-  const Thr x2 = t[1 + cx1];
-  const Thr y2 = cy1 ? G.yt[2] : G.yt[1];
-  const int bx2 = half_of(x, x2), by2 = half_of(y, y2);
-  const bool ok2 = bx2 >= 0 && by2 >= 0;
-  const int cx2 = max(bx2, 0), cy2 = max(by2, 0);
-  const Thr x3 = t[3 + 2 * cx1 + cx2];
-  const Thr y3a = cy2 ? G.yt[4] : G.yt[3], y3b = cy2 ? G.yt[6] : G.yt[5];
-  const Thr y3 = cy1 ? y3b : y3a;
-  const int bx3 = half_of(x, x3), by3 = half_of(y, y3);
-  const bool ok3 = bx3 >= 0 && by3 >= 0;
-  const int q1 = cy1 * 2 + cx1, q2 = cy2 * 2 + cx2;  // rows outer, cols inner (ORBExtractor.cc:60-72)
-  const int leaf = ok3 ? by3 * 2 + bx3 : 4;
-  const int l2 = ok2 ? q2 * 5 + leaf : 20;
-  const int l1 = ok1 ? q1 * 21 + l2 : 84;
-  return inside ? st0 * QT_PP_GROUPS + l1 : -1;
-}
 
-// The x and the y halves of pp_group are functions of ONE coordinate each, so they are tabulated once per tree (a few hundred
-// entries) and a record costs two independent LDS byte reads plus a dozen integer operations instead of ~70 with three dependent
-// threshold reads.  Code byte: bit 7 = inside, bits 5-6 = strip (x table only), bits 3-4 = number of levels the coordinate
-// passes without sitting on a split line (0..3), bits 0-2 = the halves taken (level 1 in bit 2).
-__device__ __forceinline__ uint32_t pp_axis_code(int v, const Thr& t0, const Thr* t12 /*[2]*/, const Thr* t3 /*[4]*/) {
-  const int b1 = half_of(v, t0);
+// The x and the y halves of a record's group are functions of ONE coordinate each, so they are tabulated once per tree (a few
+// hundred entries) and a record costs two independent LDS reads plus a dozen integer operations instead of ~90 with four
+// dependent threshold reads.  Code (16 bits): bit 15 = inside, bits 12-13 = strip (x table only), bits 4-6 = number of levels the
+// coordinate passes without sitting on a split line (0..4), bits 0-3 = the halves taken (level 1 in bit 3).
+__device__ __forceinline__ uint32_t pp_axis_code(int v, const Thr* t /*[15]*/) {
+  const int b1 = half_of(v, t[0]);
   const int c1 = max(b1, 0);
-  const int b2 = half_of(v, t12[c1]);
+  const int b2 = half_of(v, t[1 + c1]);
   const int c2 = max(b2, 0);
-  const int b3 = half_of(v, t3[2 * c1 + c2]);
-  const int nv = b1 < 0 ? 0 : (b2 < 0 ? 1 : (b3 < 0 ? 2 : 3));
-  return (uint32_t)(nv << 3) | (uint32_t)(c1 << 2) | (uint32_t)(c2 << 1) | (uint32_t)max(b3, 0);
+  const int b3 = half_of(v, t[3 + 2 * c1 + c2]);
+  const int c3 = max(b3, 0);
+  const int b4 = half_of(v, t[7 + 4 * c1 + 2 * c2 + c3]);
+  const int nv = b1 < 0 ? 0 : (b2 < 0 ? 1 : (b3 < 0 ? 2 : (b4 < 0 ? 3 : 4)));
+  return (uint32_t)(nv << 4) | (uint32_t)(c1 << 3) | (uint32_t)(c2 << 2) | (uint32_t)(c3 << 1) | (uint32_t)max(b4, 0);
 }
-__device__ __forceinline__ int pp_group_tab(uint32_t rec, const uint8_t* xtab, const uint8_t* ytab) {
-  const uint32_t cx = xtab[ORBFE_REC_X(rec)], cy = ytab[ORBFE_REC_Y(rec)];
-  const int nv = (int)min((cx >> 3) & 3u, (cy >> 3) & 3u);
-  const int q1 = (int)(((cy >> 2) & 1u) * 2u + ((cx >> 2) & 1u));  // rows outer, cols inner (ORBExtractor.cc:60-72)
-  const int q2 = (int)(((cy >> 1) & 1u) * 2u + ((cx >> 1) & 1u));
-  const int q3 = (int)((cy & 1u) * 2u + (cx & 1u));
-  const int l2 = nv >= 2 ? q2 * 5 + (nv >= 3 ? q3 : 4) : 20;
-  const int l1 = nv >= 1 ? q1 * 21 + l2 : 84;
-  return ((cx & cy) & 0x80u) ? (int)((cx >> 5) & 3u) * QT_PP_GROUPS + l1 : -1;
+__device__ __forceinline__ int pp_group_tab(uint32_t x, uint32_t y, const uint16_t* xtab, const uint16_t* ytab) {
+  const uint32_t cx = xtab[x], cy = ytab[y];
+  const int nv = (int)min((cx >> 4) & 7u, (cy >> 4) & 7u);
+  const int q1 = (int)(((cy >> 3) & 1u) * 2u + ((cx >> 3) & 1u));  // rows outer, cols inner (ORBExtractor.cc:60-72)
+  const int q2 = (int)(((cy >> 2) & 1u) * 2u + ((cx >> 2) & 1u));
+  const int q3 = (int)(((cy >> 1) & 1u) * 2u + ((cx >> 1) & 1u));
+  const int q4 = (int)((cy & 1u) * 2u + (cx & 1u));
+  const int l3 = nv >= 3 ? q3 * 5 + (nv >= 4 ? q4 : 4) : 20;
+  const int l2 = nv >= 2 ? q2 * 21 + l3 : 84;
+  const int l1 = nv >= 1 ? q1 * 85 + l2 : 340;
+  return ((cx & cy) & 0x8000u) ? (int)((cx >> 12) & 3u) * QT_PP_GROUPS + l1 : -1;
 }
 
 // Everything after the strip counts: scatter into the strip segments, best-first expansion, selection, ordering.
@@ -235,54 +220,52 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
   // ---- first pop: the root, whose children are the initSplit strips (ORBExtractor.cc:81-96, 147-170) ----
   const int ns = L.n_ini;
   const int n_tot = (ns * QT_PP_TOTALS + 3) & ~3;
-  uint16_t* tot = (uint16_t*)(n_rb + node_cap) - n_tot;      // the totals live in the tail of the (still empty) node table ...
+  uint16_t* tot = (uint16_t*)(n_rb + node_cap) - n_tot;      // the totals of levels 1-3 live in the tail of the (still empty) node table ...
   const int pp_limit = node_cap - (n_tot * 2 + 7) / 8;       // ... and are abandoned when the table grows into them
-  bool pp_ok = N <= 65535 && ns <= QT_PP_MAX_STRIPS && node_cap >= 176;
+  const int n4_off = (N + 3) & ~3;                           // the fourth level's totals: global, behind the records of the bounce buffer
+  uint16_t* tot4 = (uint16_t*)(T + n4_off);
+  // coordinate -> code tables (uint16) in the n_key array, cursors across n_cb | n_ce, x thresholds in n_re: the node table is not in use yet
+  const int tab_w = (int)ceil(L.strips[ns]) + 1, tab_h = (int)ceil((double)L.reg_h) + 1;
+  const int tab_w2 = (tab_w + 1) & ~1;
+  bool pp_ok = N > 0 && N <= 65535 && ns <= QT_PP_MAX_STRIPS && node_cap >= 176 && tab_w <= 4096 && tab_h <= 4096 &&
+               (tab_w2 + tab_h) * 2 <= node_cap * 8 && ns * QT_PP_GROUPS * 4 <= node_cap * 16 && ns * 15 * 8 <= node_cap * 8 &&
+               n4_off + ns * (QT_PP_TOTALS4 / 2) <= (int)L.cand_cap;
   if (pp_ok) {
     const int ng = ns * QT_PP_GROUPS;
-    Thr* xt = (Thr*)n_re;             // x thresholds of every strip                                  (scratch: the node table
-    uint32_t* cur = (uint32_t*)n_cb;  // group sizes, then group cursors                              is not in use yet)
+    Thr* xt = (Thr*)n_re;             // x thresholds of every strip
+    uint32_t* cur = (uint32_t*)n_cb;  // group sizes, then group cursors (runs on into n_ce)
+    uint16_t* xtab = (uint16_t*)n_key;
+    uint16_t* ytab = xtab + tab_w2;
     for (int g = lane; g < ng; g += 64) cur[g] = 0;
+    for (int x = lane; x < tab_w; x += 64) xtab[x] = 0;  // columns on a strip boundary or outside the region: bit 15 clear
     PpGeom G;
     G.ns = ns;
     G.y_max = (int)ceil((double)L.reg_h) - 1;  // y > 0 && y < reg_h
-    thr7(0.0, (double)L.reg_h, G.yt);
+    Thr yt[15];
+    thr15(0.0, (double)L.reg_h, yt);
 #pragma unroll
     for (int k = 0; k < QT_PP_MAX_STRIPS; ++k) {
       const double lo = L.strips[k < ns ? k : 0], hi = L.strips[k < ns ? k + 1 : 1];
       G.s_lo[k] = (int)floor(lo) + 1;  // x > lo
       G.s_hi[k] = (int)ceil(hi) - 1;   // x < hi
-      if (lane == k && k < ns) thr7(lo, hi, xt + 7 * k);
+      if (lane == k && k < ns) thr15(lo, hi, xt + 15 * k);
     }
     __syncthreads();
-    // coordinate -> code tables in the (still unused) n_ce array: x in [0, 4096) would not fit, the region is reg_w x reg_h
-    const int tab_w = (int)ceil(L.strips[ns]) + 1, tab_h = (int)ceil((double)L.reg_h) + 1;
-    uint8_t* xtab = (uint8_t*)n_ce;
-    uint8_t* ytab = xtab + ((tab_w + 3) & ~3);
-    const bool use_tab = ((tab_w + 3) & ~3) + tab_h <= node_cap * 8 && tab_w <= 4096 && tab_h <= 4096;
-    if (use_tab) {
-      for (int x = lane; x < tab_w; x += 64) xtab[x] = 0;  // columns on a strip boundary or outside the region: bit 7 clear
-      __syncthreads();
 #pragma unroll
-      for (int k = 0; k < QT_PP_MAX_STRIPS; ++k) {  // strip by strip: its seven thresholds are wave-uniform (no dependent reads per entry)
-        if (k < ns) {
-          Thr t[7];
+    for (int k = 0; k < QT_PP_MAX_STRIPS; ++k) {  // strip by strip: its fifteen thresholds are wave-uniform (no dependent reads per entry)
+      if (k < ns) {
+        Thr t[15];
 #pragma unroll
-          for (int q = 0; q < 7; ++q) t[q] = xt[7 * k + q];
-          for (int x = max(G.s_lo[k], 0) + lane; x <= G.s_hi[k] && x < tab_w; x += 64)
-            xtab[x] = (uint8_t)(0x80u | ((uint32_t)k << 5) | pp_axis_code(x, t[0], t + 1, t + 3));
-        }
+        for (int q = 0; q < 15; ++q) t[q] = xt[15 * k + q];
+        for (int x = max(G.s_lo[k], 0) + lane; x <= G.s_hi[k] && x < tab_w; x += 64)
+          xtab[x] = (uint16_t)(0x8000u | ((uint32_t)k << 12) | pp_axis_code(x, t));
       }
-      for (int y = lane; y < tab_h; y += 64)
-        ytab[y] = (uint8_t)(((y >= 1 && y <= G.y_max) ? 0x80u : 0u) | pp_axis_code(y, G.yt[0], G.yt + 1, G.yt + 3));
-      __syncthreads();
     }
+    for (int y = lane; y < tab_h; y += 64) ytab[y] = (uint16_t)(((y >= 1 && y <= G.y_max) ? 0x8000u : 0u) | pp_axis_code(y, yt));
+    __syncthreads();
     auto group_of = [&](uint32_t r) -> int {
-      if (use_tab) {
-        const uint32_t x = min(ORBFE_REC_X(r), (uint32_t)tab_w - 1u), y = min(ORBFE_REC_Y(r), (uint32_t)tab_h - 1u);  // (candidates lie inside the region; the clamp only guards the table)
-        return pp_group_tab(ORBFE_PACK_XYR(x, y, 0), xtab, ytab);
-      }
-      return pp_group(r, G, xt);
+      // (candidates lie inside the region; the clamp only guards the table)
+      return pp_group_tab(min(ORBFE_REC_X(r), (uint32_t)tab_w - 1u), min(ORBFE_REC_Y(r), (uint32_t)tab_h - 1u), xtab, ytab);
     };
     // pass 1: group sizes.  Sixteen records per lane per trip, and the next trip's records are requested before this trip's are
     // classified: a lone wave sees every global round trip, so the loads of trip k+1 fly under the work of trip k.
@@ -313,21 +296,25 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       }
     }
     __syncthreads();
-    // totals of the 84 nodes below every strip, then sizes -> cursors (exclusive prefix in layout order)
+    // totals of the 84 + 256 nodes below every strip, then sizes -> cursors (exclusive prefix in layout order)
     for (int t = lane; t < ns * QT_PP_TOTALS; t += 64) {
       const int st = t / QT_PP_TOTALS, k = t - QT_PP_TOTALS * st;
       const uint32_t* c = cur + st * QT_PP_GROUPS;
       uint32_t v = 0;
       if (k < 4) {
-        for (int i = 0; i < 21; ++i) v += c[k * 21 + i];
+        for (int i = 0; i < 85; ++i) v += c[k * 85 + i];
       } else if (k < 20) {
         const int q1 = (k - 4) >> 2, q2 = (k - 4) & 3;
-        for (int i = 0; i < 5; ++i) v += c[q1 * 21 + q2 * 5 + i];
+        for (int i = 0; i < 21; ++i) v += c[q1 * 85 + q2 * 21 + i];
       } else {
         const int m = k - 20;
-        v = c[(m >> 4) * 21 + ((m >> 2) & 3) * 5 + (m & 3)];
+        for (int i = 0; i < 5; ++i) v += c[(m >> 4) * 85 + ((m >> 2) & 3) * 21 + (m & 3) * 5 + i];
       }
       tot[t] = (uint16_t)v;
+    }
+    for (int t = lane; t < ns * QT_PP_TOTALS4; t += 64) {
+      const int st = t / QT_PP_TOTALS4, m = t - QT_PP_TOTALS4 * st;  // m = 64 q1 + 16 q2 + 4 q3 + q4
+      tot4[t] = (uint16_t)cur[st * QT_PP_GROUPS + (m >> 6) * 85 + ((m >> 4) & 3) * 21 + ((m >> 2) & 3) * 5 + (m & 3)];
     }
     __syncthreads();
     int carry = 0, strip_base = 0, strip_cnt = 0;  // lane st keeps the segment of strip st
@@ -338,7 +325,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       const int excl = carry + incl - v;
       __syncthreads();
       if (g < ng) cur[g] = (uint32_t)excl;
-      for (int st = 0; st < ns; ++st) {  // strip st starts at group 85 st and ends where strip st + 1 starts
+      for (int st = 0; st < ns; ++st) {  // strip st starts at group 341 st and ends where strip st + 1 starts
         const int first = st * QT_PP_GROUPS, last = first + QT_PP_GROUPS - 1;
         if (first >= g0 && first < g0 + 64) {
           const int b = __builtin_amdgcn_readlane(excl, first - g0);
@@ -387,7 +374,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
           n_cb[n_act] = L.strips[st];
           n_ce[n_act] = L.strips[st + 1];
           n_key[n_act] = ((unsigned long long)c << 32) | (unsigned long long)(0xFFFFFFFFu - next_seq);
-          n_beg[n_act] = (uint32_t)off | ((uint32_t)(1 + st * QT_PP_INTERNAL + 20) << 24);
+          n_beg[n_act] = (uint32_t)off | ((uint32_t)(1 + st * QT_PP_INTERNAL + 84) << QT_CODE_SHIFT);
         }
         ++n_act;
         ++next_seq;
@@ -551,7 +538,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         const int n = (int)(mykey >> 32);
         const double rb = n_rb[j], re = n_re[j], cb = n_cb[j], ce = n_ce[j];
         const uint32_t beg_raw = n_beg[j];
-        const int beg = (int)(beg_raw & QT_BEG_MASK), code = (int)(beg_raw >> 24);
+        const int beg = (int)(beg_raw & QT_BEG_MASK), code = (int)(beg_raw >> QT_CODE_SHIFT);
         const double midy = (rb + re) / 2, midx = (cb + ce) / 2;
         const SplitInt sp = make_split(midx, midy);
         const bool is_pp = pp_ok && code != 0;
@@ -560,18 +547,25 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         int c0 = 0, c1 = 0, c2 = 0, c3 = 0, child_code = 0;
         if (is_pp) {
           const int st = (code - 1) / QT_PP_INTERNAL, k = (code - 1) - QT_PP_INTERNAL * st;
-          const uint16_t* t = tot + st * QT_PP_TOTALS;
-          int ti;
-          if (k == 20) {
-            ti = 0;
-            child_code = 1 + st * QT_PP_INTERNAL + 16;
-          } else if (k >= 16) {
-            ti = 4 + (k - 16) * 4;
-            child_code = 1 + st * QT_PP_INTERNAL + (k - 16) * 4;
-          } else {
-            ti = 20 + k * 4;
+          if (k >= 64) {  // strip, child, grandchild: totals in LDS
+            const uint16_t* t = tot + st * QT_PP_TOTALS;
+            int ti;
+            if (k == 84) {
+              ti = 0;
+              child_code = 1 + st * QT_PP_INTERNAL + 80;
+            } else if (k >= 80) {
+              ti = 4 + (k - 80) * 4;
+              child_code = 1 + st * QT_PP_INTERNAL + 64 + (k - 80) * 4;
+            } else {
+              ti = 20 + (k - 64) * 4;
+              child_code = 1 + st * QT_PP_INTERNAL + (k - 64) * 4;
+            }
+            c0 = t[ti], c1 = t[ti + 1], c2 = t[ti + 2], c3 = t[ti + 3];
+          } else {  // great-grandchild: its four leaf totals come from global memory, its children are ordinary nodes
+            const uint32_t* t4 = (const uint32_t*)(tot4 + st * QT_PP_TOTALS4 + 4 * k);  // (the buffer is only 4-byte aligned)
+            const uint32_t ta = t4[0], tb = t4[1];
+            c0 = (int)(ta & 0xFFFFu), c1 = (int)(ta >> 16), c2 = (int)(tb & 0xFFFFu), c3 = (int)(tb >> 16);
           }
-          c0 = t[ti], c1 = t[ti + 1], c2 = t[ti + 2], c3 = t[ti + 3];
         }
         // the ordinary members: all records of a node into the registers of its lane (one round trip for the whole head)
         const bool ld = lane < b_eff && !is_pp;
@@ -635,7 +629,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
                 n_cb[slot] = (q & 1) ? midx : cb;
                 n_ce[slot] = (q & 1) ? ce : midx;
                 n_key[slot] = ((unsigned long long)cc << 32) | (unsigned long long)(0xFFFFFFFFu - (seq0 + (uint32_t)rank));
-                n_beg[slot] = (uint32_t)offc | ((uint32_t)(child_code ? child_code + q : 0) << 24);
+                n_beg[slot] = (uint32_t)offc | ((uint32_t)(child_code ? child_code + q : 0) << QT_CODE_SHIFT);
               }
             }
             if (!is_pp) {  // in-place 4-way partition straight from the registers (the node's segment belongs to this lane alone)
@@ -688,7 +682,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     const double rb = n_rb[j], re = n_re[j], cb = n_cb[j], ce = n_ce[j];
     const int n = (int)mc;
     const uint32_t beg_raw = n_beg[j];
-    const int beg = (int)(beg_raw & QT_BEG_MASK), code = (int)(beg_raw >> 24);
+    const int beg = (int)(beg_raw & QT_BEG_MASK), code = (int)(beg_raw >> QT_CODE_SHIFT);
     // (the popped node's slot is reused by its first child below: no erase-and-compact round trip through the table)
     const double midy = (rb + re) / 2, midx = (cb + ce) / 2;
     const SplitInt sp = make_split(midx, midy);
@@ -698,18 +692,25 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     if (pp_ok && code != 0) {
       // a strip, a child or a grandchild whose records were laid out by the pre-partition: nothing moves
       const int st = (code - 1) / QT_PP_INTERNAL, k = (code - 1) - QT_PP_INTERNAL * st;
-      const uint16_t* t = tot + st * QT_PP_TOTALS;
-      int ti;
-      if (k == 20) {
-        ti = 0;
-        child_code = 1 + st * QT_PP_INTERNAL + 16;
-      } else if (k >= 16) {
-        ti = 4 + (k - 16) * 4;
-        child_code = 1 + st * QT_PP_INTERNAL + (k - 16) * 4;
+      if (k >= 64) {
+        const uint16_t* t = tot + st * QT_PP_TOTALS;
+        int ti;
+        if (k == 84) {
+          ti = 0;
+          child_code = 1 + st * QT_PP_INTERNAL + 80;
+        } else if (k >= 80) {
+          ti = 4 + (k - 80) * 4;
+          child_code = 1 + st * QT_PP_INTERNAL + 64 + (k - 80) * 4;
+        } else {
+          ti = 20 + (k - 64) * 4;
+          child_code = 1 + st * QT_PP_INTERNAL + (k - 64) * 4;
+        }
+        c0 = t[ti], c1 = t[ti + 1], c2 = t[ti + 2], c3 = t[ti + 3];
       } else {
-        ti = 20 + k * 4;
+        const uint32_t* t4 = (const uint32_t*)(tot4 + st * QT_PP_TOTALS4 + 4 * k);
+        const uint32_t ta = t4[0], tb = t4[1];
+        c0 = (int)(ta & 0xFFFFu), c1 = (int)(ta >> 16), c2 = (int)(tb & 0xFFFFu), c3 = (int)(tb >> 16);
       }
-      c0 = t[ti], c1 = t[ti + 1], c2 = t[ti + 2], c3 = t[ti + 3];
     } else if (n <= 64) {
       // the common case: one record per lane, in-place 4-way partition
       const uint32_t rec = (lane < n) ? seg[lane] : 0u;
@@ -800,7 +801,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         n_cb[slot] = (lane & 1) ? midx : cb;
         n_ce[slot] = (lane & 1) ? ce : midx;
         n_key[slot] = ((unsigned long long)cc << 32) | (unsigned long long)(0xFFFFFFFFu - (next_seq + (uint32_t)rank));
-        n_beg[slot] = (uint32_t)offc | ((uint32_t)(child_code ? child_code + lane : 0) << 24);
+        n_beg[slot] = (uint32_t)offc | ((uint32_t)(child_code ? child_code + lane : 0) << QT_CODE_SHIFT);
       }
       const int added = ne0 + ne1 + ne2 + ne3;
       if (added == 0) {  // every record sat on a split line: the node disappears, the last entry fills its slot
