@@ -36,8 +36,6 @@ namespace orbfe {
 #ifndef FAST_U
 #define FAST_U 1
 #endif
-typedef short s2 __attribute__((ext_vector_type(2)));
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
 // queue entry: interior column | interior row << 7 | polarity to score | dual marker
 #define Q_IX(e) ((int)((e)&0x7Fu))
@@ -50,38 +48,35 @@ __device__ __forceinline__ int mbcnt64(unsigned long long m, int acc) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)acc));
 }
 
-// A = max over the 16 arcs of 9 contiguous ring pixels of min(sgn * (v - ring)) for TWO pixels at once (one per 16-bit half):
-// sgn = +1 scores the dark-ring polarity (A of the header), sgn = -1 the bright-ring one (B).  a0 / a1 point at the top-left
-// corner of each pixel's 7x7 window in the LDS patch (compile-time pitch PP, so all 17 reads are immediate offsets of one
-// address register).  The 16 circular 9-windows by doubling (min over 2, 4, 8, then +1), then the max over the windows.
+// A = max over the 16 arcs of 9 contiguous ring pixels of min(sgn * (v - ring)): sgn = +1 scores the dark-ring polarity (A of the
+// header), sgn = -1 the bright-ring one (B).  `a` points at the top-left corner of the pixel's 7x7 window in the LDS patch (compile-time
+// pitch PP, so all 17 reads are immediate offsets of one address register).  One pixel per lane in 32-bit registers: the 16 circular
+// 9-windows as 3 x 3 (min over 3 neighbours, then over three of those at distance 3), which the three-operand v_min3_i32 /
+// v_max3_i32 cover in 16 + 16 + 8 instructions.  (Until r1_v15 two pixels per lane in packed 16-bit halves with the doubling
+// scheme 2-4-8-9: 16 x 4 v_pk_min + 15 v_pk_max + 17 byte -> half packs per PAIR, i.e. no fewer instructions per pixel, and a
+// trip of 128 entries: a cell's ~150 survivors took two expensive trips, the second mostly empty, instead of three cheap ones.)
 template <int PP>
-__device__ __forceinline__ s2 arc_score2(const uint8_t* a0, const uint8_t* a1, s2 sgn) {
+__device__ __forceinline__ int arc_score1(const uint8_t* a, int sgn) {
   constexpr int off[16] = {6 * PP + 3, 6 * PP + 4, 5 * PP + 5, 4 * PP + 6, 3 * PP + 6, 2 * PP + 6, 1 * PP + 5, 0 * PP + 4,
                            0 * PP + 3, 0 * PP + 2, 1 * PP + 1, 2 * PP + 0, 3 * PP + 0, 4 * PP + 0, 5 * PP + 1, 6 * PP + 2};
-  us2 v;
-  v.x = a0[3 * PP + 3];
-  v.y = a1[3 * PP + 3];
-  const s2 vs = __builtin_bit_cast(s2, v) * sgn;
-  const s2 negs = -sgn;
-  s2 d[16];
+  int r[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    us2 r;
-    r.x = a0[off[k]];
-    r.y = a1[off[k]];
-    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d[k]) : "v"(__builtin_bit_cast(s2, r)), "v"(negs), "v"(vs));  // sgn * (v - r)
-  }
-  s2 m2[16], m4[16], m8[16];
+  for (int k = 0; k < 16; ++k) r[k] = a[off[k]];
+  const int v = a[3 * PP + 3];
+  int vs, d[16];
+  asm("v_mul_i32_i24 %0, %1, %2" : "=v"(vs) : "v"(v), "v"(sgn));
+  const int negs = -sgn;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) m2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
+  for (int k = 0; k < 16; ++k) asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d[k]) : "v"(r[k]), "v"(negs), "v"(vs));  // sgn * (v - r)
+  int m3[16], m9[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+  for (int k = 0; k < 16; ++k) asm("v_min3_i32 %0, %1, %2, %3" : "=v"(m3[k]) : "v"(d[k]), "v"(d[(k + 1) & 15]), "v"(d[(k + 2) & 15]));
 #pragma unroll
-  for (int k = 0; k < 16; ++k) m8[k] = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
-  s2 best = __builtin_elementwise_min(m8[0], d[8]);
-#pragma unroll
-  for (int k = 1; k < 16; ++k) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[k], d[(k + 8) & 15]));
-  return best;
+  for (int k = 0; k < 16; ++k)  // (spelled out: left to itself the compiler re-associates the 32 three-way minima into 24 + 14 two-way ones)
+    asm("v_min3_i32 %0, %1, %2, %3" : "=v"(m9[k]) : "v"(m3[k]), "v"(m3[(k + 3) & 15]), "v"(m3[(k + 6) & 15]));
+  const int a0 = max(max(m9[0], m9[1]), m9[2]), a1 = max(max(m9[3], m9[4]), m9[5]), a2 = max(max(m9[6], m9[7]), m9[8]);
+  const int a3 = max(max(m9[9], m9[10]), m9[11]), a4 = max(max(m9[12], m9[13]), m9[14]);
+  return max(max(max(a0, a1), a2), max(max(a3, a4), m9[15]));
 }
 
 // PP / PV: compile-time pitches of the LDS patch and of the score map (48 / 40 for patches up to 44 px wide -- every
@@ -218,45 +213,27 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
   //         half of the survivors are corners: those (and the dual-tagged entries, whose second polarity is still to come) are
   //         compacted in place at the front of Q, so that the NMS and the output pass touch no entry that cannot matter.
   int nc = 0;
-  {
-    const uint32_t* Q32 = (const uint32_t*)Q;
-    const int n_ep = (nq + 1) >> 1;
-    for (int j0 = 0; j0 < n_ep; j0 += 64) {
-      const bool act = j0 + lane < n_ep;
-      const int j = min(j0 + lane, n_ep - 1);
-      const uint32_t w = Q32[j];
-      const bool has1 = 2 * j + 1 < nq;
-      const uint32_t q0 = w & 0xFFFFu, q1 = has1 ? (w >> 16) : q0;
-      const int ix0 = Q_IX(q0), iy0 = Q_IY(q0), ix1 = Q_IX(q1), iy1 = Q_IY(q1);
-      s2 sgn;
-      sgn.x = (q0 & Q_BRIGHT) ? (short)-1 : (short)1;
-      sgn.y = (q1 & Q_BRIGHT) ? (short)-1 : (short)1;
-      const s2 A = arc_score2<PP>(P + iy0 * PP + xa + ix0, P + iy1 * PP + xa + ix1, sgn);
-      const bool c0 = act && A.x > t_min, c1 = act && has1 && A.y > t_min;
-      if (c0) V[(iy0 + 1) * PV + ix0 + 1] = (uint8_t)min(255, (int)A.x);
-      if (c1) V[(iy1 + 1) * PV + ix1 + 1] = (uint8_t)min(255, (int)A.y);
-      const bool k0 = c0 || (act && (q0 & Q_DUAL)), k1 = c1 || (act && has1 && (q1 & Q_DUAL));
-      const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
-      const int pos = nc + mbcnt64(m1, mbcnt64(m0, 0));  // lane order, entry 0 before entry 1: the list order is kept
-      if (k0) Q[pos] = (uint16_t)q0;  // (in place: this trip's entries were all read above, later trips read further back)
-      if (k1) Q[pos + (k0 ? 1 : 0)] = (uint16_t)q1;
-      nc += __popcll(m0) + __popcll(m1);
-    }
+  for (int j0 = 0; j0 < nq; j0 += 64) {
+    const bool act = j0 + lane < nq;
+    const uint32_t q = Q[min(j0 + lane, nq - 1)];
+    const int ix = Q_IX(q), iy = Q_IY(q);
+    const int A = arc_score1<PP>(P + iy * PP + xa + ix, (q & Q_BRIGHT) ? -1 : 1);
+    const bool c = act && A > t_min;
+    if (c) V[(iy + 1) * PV + ix + 1] = (uint8_t)min(255, A);
+    const bool keep = c || (act && (q & Q_DUAL));
+    const unsigned long long m = __ballot(keep);
+    if (keep) Q[nc + mbcnt64(m, 0)] = (uint16_t)q;  // (in place: this trip's entries were all read above, later trips read further back)
+    nc += __popcll(m);
   }
   nq = nc;
   if (nd > 0 || d_overflow) {
     WAVE_SYNC();
-    const s2 bright = {(short)-1, (short)-1};
-    const int n_dp = (nd + 1) >> 1;
-    for (int j = lane; j < n_dp; j += 64) {  // the back list, two entries per lane: V = max(A, B)
-      const bool has1 = 2 * j + 1 < nd;
-      const uint32_t q0 = Q[q_cap - 1 - 2 * j], q1 = has1 ? Q[q_cap - 2 - 2 * j] : q0;
-      const int ix0 = Q_IX(q0), iy0 = Q_IY(q0), ix1 = Q_IX(q1), iy1 = Q_IY(q1);
-      const s2 B = arc_score2<PP>(P + iy0 * PP + xa + ix0, P + iy1 * PP + xa + ix1, bright);
-      uint8_t* v0 = V + (iy0 + 1) * PV + ix0 + 1;
-      uint8_t* v1 = V + (iy1 + 1) * PV + ix1 + 1;
-      if (B.x > t_min) *v0 = (uint8_t)max((int)*v0, min(255, (int)B.x));
-      if (has1 && B.y > t_min) *v1 = (uint8_t)max((int)*v1, min(255, (int)B.y));
+    for (int j = lane; j < nd; j += 64) {  // the back list: V = max(A, B)
+      const uint32_t q = Q[q_cap - 1 - j];
+      const int ix = Q_IX(q), iy = Q_IY(q);
+      const int B = arc_score1<PP>(P + iy * PP + xa + ix, -1);
+      uint8_t* vp = V + (iy + 1) * PV + ix + 1;
+      if (B > t_min) *vp = (uint8_t)max((int)*vp, min(255, B));
     }
     if (d_overflow) {  // entries that did not fit the back list (max is idempotent, so re-scoring listed ones is harmless)
       for (int q = lane; q < nq; q += 64) {
@@ -264,9 +241,9 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
         if (e & Q_DUAL) {
           const int ix = Q_IX(e), iy = Q_IY(e);
           const uint8_t* a = P + iy * PP + xa + ix;
-          const s2 B = arc_score2<PP>(a, a, bright);
+          const int B = arc_score1<PP>(a, -1);
           uint8_t* vp = V + (iy + 1) * PV + ix + 1;
-          if (B.x > t_min) *vp = (uint8_t)max((int)*vp, min(255, (int)B.x));
+          if (B > t_min) *vp = (uint8_t)max((int)*vp, min(255, B));
         }
       }
     }
