@@ -30,12 +30,8 @@
 
 namespace orbfe {
 
-// row steps of the necessary test per loop trip.  Measured on one box, per 128 pairs: 1 -> 2.252 ms, 2 -> 2.278, 4 -> 2.287 (the reads
-// of the extra pixels only lengthen the trip: eight waves per SIMD already cover the LDS latency); 1 with unconditional reads and
-// selects instead of the guarded block of the first version: 2.286 vs 2.302
-#ifndef FAST_U
-#define FAST_U 1
-#endif
+// (the necessary test takes one row step per loop trip.  Measured on one box, per 128 pairs: 1 -> 2.252 ms, 2 -> 2.278, 4 -> 2.287: the
+// reads of the extra pixels only lengthen the trip, eight waves per SIMD already cover the LDS latency)
 
 // queue entry: interior column | interior row << 7 | polarity to score | dual marker
 #define Q_IX(e) ((int)((e)&0x7Fu))
@@ -160,47 +156,41 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
     const int lx = lane & (lw - 1), ly = lane >> shift;
     for (int x0 = 0; x0 < iw; x0 += lw) {
       const int ix = x0 + lx;
-      const bool xin = ix < iw;
-      const uint8_t* a = P + ly * PP + xa + ix;  // top-left corner of the pixel's 7x7 window
-      uint32_t e = (uint32_t)ix | ((uint32_t)ly << 7);
-      // FAST_U row steps per trip: the LDS reads of all FAST_U pixels are issued before any test, so a wave has FAST_U independent
-      // chains in flight (the kernel is VALU-bound with dependency stalls that eight waves per SIMD do not fully cover)
-      for (int y0 = 0; y0 < ih; y0 += FAST_U * rpi, a += FAST_U * rpi * PP, e += (uint32_t)(FAST_U * rpi) << 7) {
-        bool b0[FAST_U], d0[FAST_U];
-        int v[FAST_U], r0[FAST_U], r8[FAST_U], r4[FAST_U], r12[FAST_U], r2[FAST_U], r10[FAST_U], r6[FAST_U], r14[FAST_U];
-#pragma unroll
-        for (int h = 0; h < FAST_U; ++h) {
-          const uint8_t* ah = a + h * rpi * PP;  // (rows past the interior are read but not used: they lie inside the LDS carve-up of this wave)
-          v[h] = ah[3 * PP + 3];
-          r0[h] = ah[6 * PP + 3], r8[h] = ah[3], r4[h] = ah[3 * PP + 6], r12[h] = ah[3 * PP];
-          r2[h] = ah[5 * PP + 5], r10[h] = ah[PP + 1], r6[h] = ah[PP + 5], r14[h] = ah[5 * PP + 1];
-        }
-#pragma unroll
-        for (int h = 0; h < FAST_U; ++h) {
-          const int lo_of_hi = min(min(max(r0[h], r8[h]), max(r4[h], r12[h])), min(max(r2[h], r10[h]), max(r6[h], r14[h])));
-          const int hi_of_lo = max(max(min(r0[h], r8[h]), min(r4[h], r12[h])), max(min(r2[h], r10[h]), min(r6[h], r14[h])));
-          const bool in = xin && y0 + h * rpi + ly < ih;
-          b0[h] = in && lo_of_hi > v[h] + t_min;  // every opposite pair has a pixel brighter than v + t
-          d0[h] = in && hi_of_lo < v[h] - t_min;  // ... darker than v - t
-        }
-#pragma unroll
-        for (int h = 0; h < FAST_U; ++h) {
-          const uint32_t eh = e + ((uint32_t)(h * rpi) << 7);
-          const unsigned long long m = __ballot(b0[h] || d0[h]);
-          if (b0[h] || d0[h]) Q[nq + mbcnt64(m, 0)] = (uint16_t)(eh | (d0[h] ? 0u : Q_BRIGHT) | ((b0[h] && d0[h]) ? Q_DUAL : 0u));
-          nq += __popcll(m);
-          const unsigned long long m2 = __ballot(b0[h] && d0[h]);
-          if (m2) {  // both polarities passed: the main entry scores the dark one, the list at the back of Q the bright one
-            const int k = __popcll(m2);
-            if (nq + nd + k <= q_cap) {
-              if (b0[h] && d0[h]) Q[q_cap - 1 - (nd + mbcnt64(m2, 0))] = (uint16_t)eh;
-              nd += k;
-            } else {
-              d_overflow = true;  // (pathological cell) the tagged entries are re-scanned one by one below
-            }
+      const uint8_t* a0 = P + ly * PP + xa + ix;  // top-left corner of the pixel's 7x7 window
+      const uint32_t e_lane = (uint32_t)ix | ((uint32_t)ly << 7);
+      const int thr_x = ix < iw ? t_min : 0x7FFF;
+      const uint8_t* a = a0;
+      // every predicate is ONE vector compare whose lane mask feeds the ballot and the branch directly (a predicate built from
+      // several masks is expanded to 0 / 1 per lane and compared again before a ballot: two more VALU instructions each)
+      auto trip = [&](const int y0, const int thr) __attribute__((always_inline)) {
+        const int v = a[3 * PP + 3];
+        const int r0 = a[6 * PP + 3], r8 = a[3], r4 = a[3 * PP + 6], r12 = a[3 * PP];
+        const int r2 = a[5 * PP + 5], r10 = a[PP + 1], r6 = a[PP + 5], r14 = a[5 * PP + 1];
+        const int lo_of_hi = min(min(max(r0, r8), max(r4, r12)), min(max(r2, r10), max(r6, r14)));
+        const int hi_of_lo = max(max(min(r0, r8), min(r4, r12)), max(min(r2, r10), min(r6, r14)));
+        const int sb = lo_of_hi - v;  // > t: every opposite pair has a pixel brighter than v + t
+        const int sd = v - hi_of_lo;  // > t: ... darker than v - t
+        const bool any = max(sb, sd) > thr, dual = min(sb, sd) > thr;
+        const unsigned long long m = __ballot(any), m2 = __ballot(dual);
+        const uint32_t eh = e_lane + ((uint32_t)y0 << 7);
+        if (any) Q[nq + mbcnt64(m, 0)] = (uint16_t)(eh | (sd > thr ? 0u : Q_BRIGHT) | (dual ? Q_DUAL : 0u));
+        nq += __popcll(m);
+        if (m2) {  // both polarities passed: the main entry scores the dark one, the list at the back of Q the bright one
+          const int k = __popcll(m2);
+          if (nq + nd + k <= q_cap) {
+            if (dual) Q[q_cap - 1 - (nd + mbcnt64(m2, 0))] = (uint16_t)eh;
+            nd += k;
+          } else {
+            d_overflow = true;  // (pathological cell) the tagged entries are re-scanned one by one below
           }
         }
-      }
+      };
+      // lanes right of the interior can never pass (thr_x), so the column test costs nothing per trip; the row test is only needed in
+      // the last, partial trip of a column block (its rows past the interior are read -- they lie inside this wave's carve-up -- but
+      // cannot pass either)
+      int y0 = 0;
+      for (; y0 + rpi <= ih; y0 += rpi, a += rpi * PP) trip(y0, thr_x);
+      if (y0 < ih) trip(y0, y0 + ly < ih ? thr_x : 0x7FFF);
     }
   }
   if (nq + nd > q_cap) {  // the front grew into the back list after it was written: drop the list, re-scan instead
