@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_ic_moments(const uint8_t* __restrict__ 
     const int idx = min(it * 16 + sub, 31 * 9 - 1);
     const int r = (idx * 7282) >> 16;  // idx / 9 for idx < 320
     const int c = idx - r * 9;
-    wv[it] = *(const uint32_t*)(I + (plane + (uint32_t)((y + r - 15) * stride + xa + 4 * c)));
+    wv[it] = *(const uint32_t*)(I + (plane + (uint32_t)mad24u(y + r - 15, stride, xa + 4 * c)));  // rows and strides < 2^13
   }
   int m10 = 0, m01 = 0;
 #pragma unroll
@@ -126,6 +126,9 @@ __global__ __launch_bounds__(256) void k_ic_moments(const uint8_t* __restrict__ 
       const uint32_t w = wv[it] & mask;
       const int sum = (int)__builtin_amdgcn_udot4(w, 0x01010101u, 0u, false);
       const int wsum = (int)__builtin_amdgcn_udot4(w, 0x03020100u, 0u, false);
+      // (plain products on purpose: `sum` comes out of v_dot4, and on gfx950 another VALU instruction may read a dot result only
+      // three wait states later -- the compiler inserts them for its own instructions but does not look inside an asm statement:
+      // the inline-asm v_mad_i32_i24 tried here read stale sums, different from run to run)
       m10 += dx0 * sum + wsum;
       m01 += dy * sum;
     }
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __res
     const int idx = min(it * 64 + lane, NW - 1);
     const int r = (idx * 5958) >> 16;  // idx / 11 for idx < 448
     const int c = idx - r * BRIEF_WORDS;
-    wv[it] = *(const uint32_t*)(W + (plane + (uint32_t)((y - BRIEF_R + r) * stride + xa + 4 * c)));
+    wv[it] = *(const uint32_t*)(W + (plane + (uint32_t)mad24u(y - BRIEF_R + r, stride, xa + 4 * c)));
   }
   const double2 scv = sincos[(size_t)img * n_features + k];
   uint32_t tp[4];
@@ -275,8 +278,8 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __res
     const float p2y = (float)(rx2.y + ry2.x);
     const int r1 = __float2int_rn(py + p1y), c1 = __float2int_rn(px + p1x);
     const int r2 = __float2int_rn(py + p2y), c2 = __float2int_rn(px + p2x);
-    const int v1 = wb[(r1 - y_off) * (BRIEF_WORDS * 4) + (c1 - x_off)];
-    const int v2 = wb[(r2 - y_off) * (BRIEF_WORDS * 4) + (c2 - x_off)];
+    const int v1 = wb[mad24u(r1 - y_off, BRIEF_WORDS * 4, c1 - x_off)];
+    const int v2 = wb[mad24u(r2 - y_off, BRIEF_WORDS * 4, c2 - x_off)];
     bits[g] = __ballot(v1 < v2);
   }
   if (lane < 4) {

@@ -27,6 +27,7 @@
 #include <algorithm>
 
 #include "orbfe_internal.h"
+#include "wave_ops.h"
 
 namespace orbfe {
 
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
 #pragma unroll
         for (int it = 0; it < BATCH; ++it) {
           const int r = min(rb + RPI * it, ph - 1);
-          wv[it] = *(const uint32_t*)(src + (r * stride + 4u * (uint32_t)c));
+          wv[it] = *(const uint32_t*)(src + (uint32_t)mad24u(r, (int)stride, 4 * c));  // full-rate 24-bit product: rows and strides < 2^13
         }
 #pragma unroll
         for (int it = 0; it < BATCH; ++it) {

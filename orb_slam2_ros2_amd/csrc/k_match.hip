@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "orbfe_internal.h"
+#include "wave_ops.h"
 
 namespace orbfe {
 
@@ -230,11 +231,11 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
       for (int t = lane; t < 44 + 77; t += 64) {
         if (t < 44) {
           const int rr = t >> 2, cc = t & 3;
-          wl[t] = *(const uint32_t*)(IL + (size_t)(ly - 5 + rr) * LL.stride + lxa + 4 * cc);
+          wl[t] = *(const uint32_t*)(IL + (uint32_t)mad24u(ly - 5 + rr, LL.stride, lxa + 4 * cc));
         } else {
           const int u = t - 44;
           const int rr = u / 7, cc = u - rr * 7;
-          wr[u] = *(const uint32_t*)(IR + (size_t)(ry - 5 + rr) * LR.stride + rxa + 4 * cc);
+          wr[u] = *(const uint32_t*)(IR + (uint32_t)mad24u(ry - 5 + rr, LR.stride, rxa + 4 * cc));
         }
       }
       __builtin_amdgcn_wave_barrier();  // LDS accesses of one wave execute in order; this only pins the compiler

@@ -56,8 +56,9 @@ __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv,
     const uint8_t* src = S + (size_t)sy_lo * sstride + sx_lo;
     uint4* tile4 = (uint4*)tile;
     for (int k = threadIdx.x; k < nq * nr; k += 256) {
-      const int r = (int)(((uint32_t)k * inv) >> 20), c = k - r * nq;
-      tile4[k] = *(const uint4*)(src + (uint32_t)(r * sstride + 16 * c));
+      // (k < 2^14, inv <= 2^20, rows / strides < 2^13: full-rate 24-bit products; the plain ones compile to the quarter-rate v_mul_lo_u32)
+      const int r = (int)((uint32_t)mul24u(k, (int)inv) >> 20), c = k - mul24u(r, nq);
+      tile4[k] = *(const uint4*)(src + (uint32_t)mad24u(r, sstride, 16 * c));
     }
   }
   __syncthreads();
@@ -79,9 +80,7 @@ __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv,
     const ResizeTap ay = ys[ty];
     const int sy0 = min(max(ay.ofs, 0), sh - 1), sy1 = min(max(ay.ofs + 1, 0), sh - 1);
     // (two code paths, not one pointer select: an LDS address minus sx_lo is not a valid flat address)
-    const int o0 = (sy0 - sy_lo) * pitch - sx_lo, o1 = (sy1 - sy_lo) * pitch - sx_lo;
-    const uint8_t* g0 = S + (size_t)sy0 * sstride;
-    const uint8_t* g1 = S + (size_t)sy1 * sstride;
+    const int o0 = mad24s(sy0 - sy_lo, pitch, -sx_lo), o1 = mad24s(sy1 - sy_lo, pitch, -sx_lo);
     uint32_t out = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -91,7 +90,8 @@ __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv,
       if (fits) {
         p00 = tb[o0 + sx0], p01 = tb[o0 + sx1], p10 = tb[o1 + sx0], p11 = tb[o1 + sx1];
       } else {
-        p00 = g0[sx0], p01 = g0[sx1], p10 = g1[sx0], p11 = g1[sx1];
+        const uint32_t g0 = (uint32_t)mul24u(sy0, sstride), g1 = (uint32_t)mul24u(sy1, sstride);  // 32-bit offsets from the uniform base
+        p00 = S[g0 + sx0], p01 = S[g0 + sx1], p10 = S[g1 + sx0], p11 = S[g1 + sx1];
       }
       // (pixels < 2^8, taps <= 2^11, h >> 4 < 2^15: every product fits the full-rate 24-bit multiplier)
       const int h0 = mad24u(p00, ax[j].c0, mul24u(p01, ax[j].c1));
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv,
       v = min(255, max(0, v));
       out |= (uint32_t)v << (8 * j);
     }
-    *(uint32_t*)(base + L.plane_off + (size_t)cy * L.stride + cx) = out;  // stride is a multiple of 16: the padding absorbs the tail
+    *(uint32_t*)(base + (L.plane_off + (uint32_t)mad24u(cy, L.stride, cx))) = out;  // stride is a multiple of 16: the padding absorbs the tail
   }
 }
 
@@ -142,7 +142,9 @@ __global__ __launch_bounds__(256) void k_blur(const LevelDev* __restrict__ lv, i
   while (l + 1 < n_levels && tile >= lv[l + 1].bl_tile_base) ++l;
   const LevelDev& L = lv[l];
   const int t = tile - L.bl_tile_base;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // (the wave index is uniform, but only a readfirstlane tells the compiler: the row arithmetic below -- reflections, row * stride --
+  // then runs on the scalar unit instead of as quarter-rate 64-bit vector multiplies)
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int strip = t % L.bl_tiles_x;
   const int y0 = ((t / L.bl_tiles_x) * 4 + wv) * BLUR_ROWS;
   if (y0 >= L.h) return;  // wave-uniform
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void k_blur(const LevelDev* __restrict__ lv, i
 #pragma unroll
             for (int j = 0; j < 4; ++j) o |= min(acc4[j] >> 16, 255u) << (8 * j);
           }
-          if (writer) *(uint32_t*)(D + (size_t)(y0 + r - 6) * stride + x4) = o;
+          if (writer) *(uint32_t*)(D + (uint32_t)(mul24u(y0 + r - 6, stride) + x4)) = o;
         }
       }
     }

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include "orbfe_internal.h"
+#include "wave_ops.h"
 
 namespace orbfe {
 
@@ -97,9 +98,11 @@ __device__ __forceinline__ int quadrant_of(uint32_t p, const SplitInt& s) {
 // a patch in raster order (ORBExtractor.cc:346-373).  39-bit key, smaller = earlier.
 __device__ __forceinline__ unsigned long long order_key(uint32_t rec, const LevelDev& L) {
   const uint32_t x = ORBFE_REC_X(rec), y = ORBFE_REC_Y(rec);
-  const uint32_t jdx = min(((x - 3u) * L.inv_w_cell) >> 20, (uint32_t)L.n_cols - 1u);
-  const uint32_t idx = min(((y - 3u) * L.inv_h_cell) >> 20, (uint32_t)L.n_rows - 1u);
-  return ((unsigned long long)(idx * (uint32_t)L.n_cols + jdx) << 24) | ((unsigned long long)y << 12) | (unsigned long long)x;
+  // (coordinates are >= 3 and < 2^12, the reciprocals <= 2^20, cell counts < 2^8: full-rate 24-bit products; the plain ones compile
+  // to the quarter-rate v_mul_lo_u32 / v_mad_u64_u32 -- this function sits in the winner scan of every node)
+  const uint32_t jdx = min((uint32_t)mul24u((int)(x - 3u), (int)L.inv_w_cell) >> 20, (uint32_t)L.n_cols - 1u);
+  const uint32_t idx = min((uint32_t)mul24u((int)(y - 3u), (int)L.inv_h_cell) >> 20, (uint32_t)L.n_rows - 1u);
+  return ((unsigned long long)(uint32_t)mad24u((int)idx, L.n_cols, (int)jdx) << 24) | ((unsigned long long)y << 12) | (unsigned long long)x;
 }
 
 // root strip of a record (Quadtree::initSplit children, strict membership) or -1

@@ -12,6 +12,10 @@ namespace orbfe {
 #define ORBFE_DPP_WAVE_SHR1 0x138
 #define ORBFE_DPP_WAVE_SHL1 0x130
 
+// NOTE on the inline-asm helpers below: the compiler's hazard recogniser does not look inside an asm statement.  Their INPUTS must
+// not come straight out of a v_dot* instruction (gfx950: three wait states before another VALU instruction may read a dot result),
+// and their RESULT must not be the direct input of a DPP / readlane instruction (two wait states): pass such values through a
+// compiler-generated instruction first.  (k_ic_moments: sums of v_dot4 fed to an asm v_mad_i32_i24 gave garbage moments.)
 // Full-rate 24-bit integer multiplies.  hipcc lowers an int product whose operand ranges it cannot prove to the quarter-rate
 // v_mul_lo_u32 (and __mul24 back to a plain product): where the operands are known to fit 24 bits, spell the instruction out.
 __device__ __forceinline__ int mul24u(int a, int b) {
@@ -22,6 +26,12 @@ __device__ __forceinline__ int mul24u(int a, int b) {
 __device__ __forceinline__ int mad24u(int a, int b, int c) {
   int d;
   asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// signed variant (|a|, |b| < 2^23)
+__device__ __forceinline__ int mad24s(int a, int b, int c) {
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
 struct OpMinI {
