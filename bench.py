@@ -251,7 +251,7 @@ def main():
             # UnionNs / steps of profiles/*_kernel_stats.csv, tools/kernel_stats_from_db.py), not average x NLEVELS
             "kernel_launches_per_step": {"fast": NLEVELS, "orient_brief": 4, "resize": 1, "blur": 1, "quadtree": 1, "stereo": 1}[dom],
             "avg_launch_ms_alone": stages_inline[dom],
-            "rocprof_match": "union of the overlapping k_fast launches per step (UnionNs / steps in profiles/r1_v15_kernel_stats.csv)",
+            "rocprof_match": "union of the overlapping k_fast launches per step (UnionNs / steps in profiles/r1_v16_kernel_stats.csv)",
             "all_stages": {k: {"ms": round(stages_inline[k], 4), "GBps": round(stage_bytes[k] / (stages_inline[k] * 1e-3) / 1e9, 1)}
                            for k in stages_inline if k in stage_bytes and stages_inline[k] > 0},
         },
@@ -293,6 +293,28 @@ def main():
                       f"(Frame.cc:100-105), pairs sequential; host has {os.cpu_count()} cores",
         }
         line["config"]["gpu_over_cpu"] = fps / (n_done / t_cpu)
+        # (ii) of SURVEY 8d, the throughput-fair figure: pairs distributed over the host cores of this box's share (one pair per
+        # thread, L/R extraction sequential inside it), same oracle, same inputs; reported beside the reference-shaped one
+        from concurrent.futures import ThreadPoolExecutor
+        n_thr = max(1, min(len(os.sched_getaffinity(0)), 16))
+        t_all0 = time.perf_counter()
+        t_end = t_all0 + max(2.0, args.cpu_seconds / 2)
+
+        def _worker(w):
+            n = 0
+            while time.perf_counter() < t_end:
+                i = (w + n) % n_unique
+                assert orc.stereo_frame(lefts[i], rights[i], NFEAT, NLEVELS, SCALE, TH_HI, TH_LO, FX, BF, math_mode=0, threads=1,
+                                        want_outputs=False) >= 0
+                n += 1
+            return n
+
+        with ThreadPoolExecutor(n_thr) as pool:
+            n_all = sum(pool.map(_worker, range(n_thr)))
+        t_all = time.perf_counter() - t_all0
+        line["cpu_baseline"]["all_cores"] = {"value": n_all / t_all, "unit": "stereo pairs/s", "cores": n_thr,
+                                             "sample": f"{n_all} pairs over {n_thr} threads, one pair per thread"}
+        line["config"]["gpu_over_cpu_all_cores"] = fps / (n_all / t_all)
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
