@@ -17,9 +17,8 @@
 //   2. every interior pixel takes a 9-read necessary test (a 9-arc contains one pixel of each opposite ring
 //      pair, so min over 4 pairs of max(pair) must exceed v+t, or max of min(pair) be below v-t); survivors are
 //      appended -- in raster order, one entry per polarity that passed -- to an LDS queue with ballot/prefix;
-//   3. the queue is processed densely, two entries per lane: each 16-bit half scores its entry's polarity
-//      (v_pk_mad_i16 applies the sign, v_pk_min_i16 / v_pk_max_i16 the arcs) into a zero-bordered V map,
-//      V = max(A, B) where both polarities were queued;
+//   3. the queue is processed densely, one entry per lane: the entry's polarity is scored in 32-bit registers (v_mad_i32_i24 applies
+//      the sign, v_min3_i32 / v_max3_i32 the arcs) into a zero-bordered V map, V = max(A, B) where both polarities were queued;
 //   4. NMS and the hi/lo decision run over the queue only, never over the whole patch again; the kept maxima
 //      are appended to the level's candidate list (one atomic reservation per cell).
 #include <hip/hip_runtime.h>
@@ -200,7 +199,7 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
   }
   WAVE_SYNC();
 
-  // ---- 3. exact test + score for the survivors, two queue entries per lane (each 16-bit half scores one entry).  Only about
+  // ---- 3. exact test + score for the survivors, one queue entry per lane (trips of 64).  Only about
   //         half of the survivors are corners: those (and the dual-tagged entries, whose second polarity is still to come) are
   //         compacted in place at the front of Q, so that the NMS and the output pass touch no entry that cannot matter.
   int nc = 0;
