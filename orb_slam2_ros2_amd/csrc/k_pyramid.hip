@@ -115,6 +115,9 @@ __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv,
 // Integer arithmetic only => bit-exact with the two-pass definition.
 // ---------------------------------------------------------------------------------------------
 #define BLUR_WORDS 62
+#ifndef BLUR_DOT2
+#define BLUR_DOT2 1
+#endif
 
 struct BlurTaps {
   int t[7];
@@ -170,6 +173,14 @@ __global__ __launch_bounds__(256) void k_blur(const LevelDev* __restrict__ lv, i
   for (int i = 0; i < 7; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) win[i][j] = 0;
+#if BLUR_DOT2
+  // column pass on PAIRS of rows: slot r % 7 holds (row sum r-1 | row sum r << 16) -- the row sums fit 16 bits (ufixedpoint16) -- and
+  // v_dot2_u32_u16 takes two taps per instruction: 1 pack + 4 dot2 per output pixel instead of 7 v_mad_u32_u24
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  uint32_t hprev[4] = {0u, 0u, 0u, 0u};
+  const us2 T01 = {(unsigned short)t0, (unsigned short)t1}, T23 = {(unsigned short)t2, (unsigned short)t3},
+            T45 = {(unsigned short)t4, (unsigned short)t5}, T6 = {(unsigned short)0, (unsigned short)t6};
+#endif
 
   const int n_out = min(BLUR_ROWS, h - y0);
   const int n_in = n_out + 6;
@@ -199,7 +210,11 @@ __global__ __launch_bounds__(256) void k_blur(const LevelDev* __restrict__ lv, i
         const uint32_t lw = wave_shr1(m), rw = wave_shl1(m);
         // bytes B[0..11] = lw|m|rw; output j needs px[j-3..j+3] = B[1+j .. 7+j]: two unaligned 4-byte windows per
         // output (v_alignbyte) fed to two v_dot4_u32_u8 against the packed taps {t0..t3} and {t4..t6,0}
+#if BLUR_DOT2
+        uint32_t hh[4];
+#else
         uint32_t* hh = win[u];  // window slot (r % 7) == u because r0 is a multiple of 7
+#endif
         hh[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(m, lw, 1), T03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rw, m, 1), T46, 0u, false), false);
         hh[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(m, lw, 2), T03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rw, m, 2), T46, 0u, false), false);
         hh[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(m, lw, 3), T03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rw, m, 3), T46, 0u, false), false);
@@ -208,11 +223,25 @@ __global__ __launch_bounds__(256) void k_blur(const LevelDev* __restrict__ lv, i
 #pragma unroll
           for (int j = 0; j < 4; ++j) hh[j] = min(hh[j], 65535u);  // ufixedpoint16 saturation (only reachable with variant-1 taps)
         }
+#if BLUR_DOT2
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          win[u][j] = hprev[j] | (hh[j] << 16);
+          hprev[j] = hh[j];
+        }
+#endif
         if (r >= 6) {
           // rows r-6 .. r live in slots (u+1)%7 .. u ; tap k multiplies row r-6+k
           uint32_t acc4[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
+#if BLUR_DOT2
+            // pairs (r-6, r-5), (r-4, r-3), (r-2, r-1) and (r-1, r) with tap 6 on its upper half
+            uint32_t acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, win[(u + 2) % 7][j]), T01, 0x8000u, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, win[(u + 4) % 7][j]), T23, acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, win[(u + 6) % 7][j]), T45, acc, false);
+            acc4[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, win[u][j]), T6, acc, false);
+#else
             // 8-bit tap x 16-bit row sum: v_mad_u32_u24 is exact here (hipcc would pick the quarter-rate v_mul_lo_u32)
             uint32_t acc = mad24(t0, win[(u + 1) % 7][j], 0x8000u);
             acc = mad24(t1, win[(u + 2) % 7][j], acc);
@@ -221,6 +250,7 @@ __global__ __launch_bounds__(256) void k_blur(const LevelDev* __restrict__ lv, i
             acc = mad24(t4, win[(u + 5) % 7][j], acc);
             acc = mad24(t5, win[(u + 6) % 7][j], acc);
             acc4[j] = mad24(t6, win[u][j], acc);
+#endif
           }
           uint32_t o;
           if (no_sat) {  // wave-uniform: byte 2 of each accumulator is the pixel, three v_perm_b32 pack them
