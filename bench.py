@@ -50,6 +50,30 @@ def algorithmic_bytes(ctx, n_cand_per_image):
     return per_image, per_pair_match, per_pair
 
 
+def spawn_ranks(n: int) -> int:
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return max(1, max(abs(rc) for _, rc in bad) & 0xFF)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,12 +89,19 @@ def main():
                          "setting measured; the blur-under-quadtree overlap inside a batch is independent of this)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) as CHILD processes -- before anything in this process
+        # has touched the GPU -- relay rank 0's JSON line and exit with the worst child status
+        raise SystemExit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -199,6 +230,24 @@ def main():
         assert g0[0, 0] == len(kps) and g0[0, 2] == nm, "gathered summary disagrees with the fetched results"
         assert all(int(g[:, 2].min()) > 0 for g in (t.cpu().numpy() for t in gathered)), "a rank produced a pair without matches"
 
+    # every pair of the last timed batch against the committed digests (tests/golden/golden_v1.json: sha256 of keypoints, descriptors,
+    # right_u, depth and match count per frame, made by the oracle): no oracle needed here, a fraction of a second, outside the clock
+    from orb_slam2_ros2_amd.digest import batch_digests
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v1.json")))["bench_pairs"]
+    kps_all, desc_all, cnt_all = ctx.fetch_batch(0, 2 * B)
+    ru_all, dp_all, nm_all = ctx.fetch_stereo_batch(0, B)
+    digests = batch_digests(kps_all, desc_all, cnt_all, ru_all, dp_all, nm_all)
+    want = [gold.get(str(rank * n_unique + (p % n_unique))) for p in range(B)]
+    wrong = [p for p in range(B) if want[p] is not None and digests[p] != want[p]]
+    if wrong:
+        raise SystemExit(f"bench.py: rank {rank}: {len(wrong)} of {B} pairs differ from the golden digests (first: pair {wrong[0]})")
+    verified = sum(w is not None for w in want)
+    if world > 1:
+        v = torch.tensor([verified], dtype=torch.int64, device=xdev)
+        dist.all_reduce(v)
+        verified = int(v.item())
+    del kps_all, desc_all, ru_all, dp_all
+
     live_ms, live_n = live[dom]
     stages_inline = dict(stages)
     if live_n:
@@ -221,9 +270,11 @@ def main():
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
+        "verified_pairs": verified,   # pairs of the last timed batch (all ranks) whose results equal the committed golden digests
         "config": {
             "workload": "Single 1241x376 KITTI-shaped stereo pair, 8-level pyramid, 2000 FAST+rBRIEF keypoints per image, "
                         "searchByStereo; batched",
+            "io": "device-resident",   # images are in HBM when the clock starts, results stay there (see host_io for the PCIe-inclusive rate)
             "pairs_per_step_per_gpu": B,
             "streams": args.streams,
             "n_features": NFEAT,

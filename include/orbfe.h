@@ -23,9 +23,12 @@
  *                                       + RobustKernelHuber
  *
  * Conventions: plain C, caller owns every host buffer, the context owns every device buffer.  No call
- * throws or aborts; every call returns an orbfe_status and orbfe_last_error() gives the text.  Calls on
- * distinct contexts are thread-safe; calls on one context must be serialised by the caller (the reference
- * uses one extractor object per thread, src/Frame.cc:100-105).
+ * throws or aborts; every call returns an orbfe_status and orbfe_last_error() gives the text of the calling
+ * THREAD's last failed call.  Threading: calls on distinct contexts are thread-safe.  Calls on one context must
+ * be serialised by the caller, with ONE exception made for the reference's call pattern -- Frame::Frame runs
+ * the left and the right ORBExtractor::extract on two std::threads (src/Frame.cc:100-105): orbfe_extract_slot
+ * calls on DIFFERENT slots of one context may run concurrently (each slot has its own stream, pinned staging
+ * and launch graph); they must not overlap with any other kind of call on that context.
  *
  * There is NO CPU fallback behind this interface: if no HIP device is usable, orbfe_create fails.
  */
@@ -39,7 +42,7 @@
 extern "C" {
 #endif
 
-#define ORBFE_ABI_VERSION 1
+#define ORBFE_ABI_VERSION 2
 #define ORBFE_MAX_LEVELS 16
 #define ORBFE_DESC_BYTES 32
 
@@ -107,6 +110,11 @@ orbfe_status orbfe_extract(orbfe_ctx* ctx, const uint8_t* img, size_t stride_byt
 /* n_img images -> slots 0..n_img-1; kps/desc are [n_img][n_features] arrays, n_out[n_img].           */
 orbfe_status orbfe_extract_batch(orbfe_ctx* ctx, int32_t n_img, const uint8_t* const* imgs, size_t stride_bytes,
                                  orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out);
+/* One image -> slot `slot` (0 <= slot < max_images), otherwise like orbfe_extract.  The drop-in for ORBExtractor::extract as
+ * Frame::Frame calls it (src/Frame.cc:100-105): two extractor objects, two threads -- give each object its own slot; the results
+ * stay resident in the slot for orbfe_stereo_match(ctx, slot_left, slot_right, ..) / orbfe_get_pyramid / orbfe_search_in_area.   */
+orbfe_status orbfe_extract_slot(orbfe_ctx* ctx, int32_t slot, const uint8_t* img, size_t stride_bytes, orbfe_keypoint* kps,
+                                uint8_t* desc, int32_t* n_out);
 /* Copy one pyramid level of a slot to the host (tight rows).  blurred=0: the planes getPyramid() returns;
  * blurred=1: the Gaussian-blurred planes BRIEF samples (mvBriefMat).  dst needs width*height bytes.   */
 orbfe_status orbfe_get_pyramid(orbfe_ctx* ctx, int32_t slot, int32_t level, int32_t blurred, uint8_t* dst);
@@ -129,6 +137,12 @@ orbfe_status orbfe_sync(orbfe_ctx* ctx);
 orbfe_status orbfe_fetch_features(orbfe_ctx* ctx, int32_t slot, orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out);
 orbfe_status orbfe_fetch_stereo(orbfe_ctx* ctx, int32_t pair, double* right_u, double* depth, int32_t* n_matches,
                                 int32_t* best_right, int32_t* best_dist);
+/* The packed results of slots [slot0, slot0 + n_slots) / pairs [pair0, pair0 + n_pairs) in one copy per array, full strides:
+ * kps [n_slots][n_features], desc [n_slots][n_features][32], counts [n_slots]; right_u / depth [n_pairs][n_features], n_matches
+ * [n_pairs].  Entries past a slot's count are stale.  Any pointer may be NULL.                                                */
+orbfe_status orbfe_fetch_batch(orbfe_ctx* ctx, int32_t slot0, int32_t n_slots, orbfe_keypoint* kps, uint8_t* desc, int32_t* counts);
+orbfe_status orbfe_fetch_stereo_batch(orbfe_ctx* ctx, int32_t pair0, int32_t n_pairs, double* right_u, double* depth,
+                                      int32_t* n_matches);
 /* Device pointers of the packed per-slot results, for gathers that never touch the host
  * (keypoints [max_images][n_features] orbfe_keypoint, descriptors [max_images][n_features][32],
  * counts [max_images] int32, right_u/depth [max_images/2][n_features] double).                       */
@@ -189,7 +203,8 @@ orbfe_status orbfe_ba_build_system(orbfe_ctx* ctx, const orbfe_ba_problem* prob,
  * on level 0, final computeError() + the same test on every edge (:364-391).  BlockSolver_6_3 + OptimizationAlgorithmLevenberg
  * semantics (lambda0 = 1e-5 max diag, gain ratio, <= 10 trials per iteration, points marginalised by Schur complement); the
  * reduced system is factorised densely by one workgroup: at most 100 non-fixed keyframes (ORBFE_EBADSIZE beyond).  stop_flag (nullable) is polled like g2o's
- * forceStopFlag (Optimizer.cc:230).  The map bookkeeping of :393-441 stays with the caller.                               */
+ * forceStopFlag (Optimizer.cc:230): it points at ONE BYTE, the reference's `bool mbAbortBA` (include/ORB_SLAM2/LocalMapping.h:185) passed as
+ * `bool& isStop` (Optimizer.h:69) -- only that byte is read, non-zero = stop.  The map bookkeeping of :393-441 stays with the caller.                               */
 typedef struct orbfe_ba_optimize_out {
   double* poses;         /* [n_poses][7]  optimised estimates (fixed poses unchanged)                          */
   double* points;        /* [n_points][3]                                                                     */
@@ -199,7 +214,7 @@ typedef struct orbfe_ba_optimize_out {
   int32_t* iterations;   /* [2] Levenberg iterations run by the two optimize() calls, nullable                  */
 } orbfe_ba_optimize_out;
 orbfe_status orbfe_ba_local_optimize(orbfe_ctx* ctx, const orbfe_ba_problem* prob, const uint8_t* pose_fixed /*[n_poses], nullable*/,
-                                     int32_t iters_first, int32_t iters_second, const volatile int32_t* stop_flag,
+                                     int32_t iters_first, int32_t iters_second, const volatile uint8_t* stop_flag,
                                      const orbfe_ba_optimize_out* out);
 
 /* ---- grid-guided matching against the features of one slot ---------------------------------------------------------
@@ -317,7 +332,7 @@ typedef struct orbfe_map_ba_report {
   double chi2_before, chi2_after; /* sum of robustified-free chi2 over all edges at the initial / final estimates */
 } orbfe_map_ba_report;
 orbfe_status orbfe_map_local_ba(orbfe_ctx* ctx, const uint8_t* pb, size_t len, uint64_t kf_id, const orbfe_camera* cam,
-                                const volatile int32_t* stop_flag, uint8_t* out, size_t cap, size_t* out_len,
+                                const volatile uint8_t* stop_flag, uint8_t* out, size_t cap, size_t* out_len,
                                 orbfe_map_ba_report* report);
 
 /* ---- instrumentation ---------------------------------------------------------------------------

@@ -95,7 +95,7 @@ class BaEdgeOut(C.Structure):
 EXPORTS = [
     "orbfe_abi_version", "orbfe_create", "orbfe_destroy", "orbfe_last_error", "orbfe_get_level_info", "orbfe_get_scale_factors",
     "orbfe_get_capacity",
-    "orbfe_extract", "orbfe_extract_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
+    "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_slot", "orbfe_fetch_batch", "orbfe_fetch_stereo_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
     "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_extract_color", "orbfe_frame_rgbd", "orbfe_project_map_points",
     "orbfe_map_pb_summary", "orbfe_map_pb_reencode", "orbfe_map_local_graph", "orbfe_map_local_ba",
     "orbfe_profile_enable", "orbfe_profile_read", "orbfe_stage_name", "orbfe_debug_candidates",
@@ -133,6 +133,9 @@ def load() -> C.CDLL:
     L.orbfe_get_capacity.restype = i32
     L.orbfe_extract.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
     L.orbfe_extract_batch.argtypes = [vp, i32, vp, C.c_size_t, vp, vp, vp]
+    L.orbfe_extract_slot.argtypes = [vp, i32, vp, C.c_size_t, vp, vp, vp]
+    L.orbfe_fetch_batch.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.orbfe_fetch_stereo_batch.argtypes = [vp, i32, i32, vp, vp, vp]
     L.orbfe_get_pyramid.argtypes = [vp, i32, i32, i32, vp]
     L.orbfe_stereo_match.argtypes = [vp, i32, i32, f32, f32, vp, vp, vp, vp, vp]
     L.orbfe_stereo_batch_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, i32, f32, f32]
@@ -275,6 +278,38 @@ class Context:
 
     def extract(self, img):
         return self.extract_batch([img])[0]
+
+    def extract_slot(self, slot, img):
+        """one image -> slot `slot` on the slot's own stream (calls on different slots may run on different threads at once)"""
+        img = np.asarray(img)
+        if img.shape != (self.height, self.width):
+            raise ValueError(f"image shape {img.shape} != context geometry {(self.height, self.width)}")
+        if not (img.dtype == np.uint8 and img.strides[1] == 1 and img.strides[0] >= self.width):
+            img = np.ascontiguousarray(img, np.uint8)
+        nf = max(self.n_features, 1)
+        kps = np.zeros(nf, KP_DTYPE)
+        desc = np.zeros((nf, 32), np.uint8)
+        n = C.c_int32(0)
+        self._check(self.lib.orbfe_extract_slot(self.h, slot, img.ctypes.data, img.strides[0], ptr(kps), ptr(desc), C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def fetch_batch(self, slot0, n_slots):
+        """packed results of slots [slot0, slot0 + n_slots): (kps [n][NF], desc [n][NF][32], counts [n])"""
+        nf = max(self.n_features, 1)
+        kps = np.zeros((n_slots, nf), KP_DTYPE)
+        desc = np.zeros((n_slots, nf, 32), np.uint8)
+        cnt = np.zeros(n_slots, np.int32)
+        self._check(self.lib.orbfe_fetch_batch(self.h, slot0, n_slots, ptr(kps), ptr(desc), ptr(cnt)))
+        return kps, desc, cnt
+
+    def fetch_stereo_batch(self, pair0, n_pairs):
+        """packed stereo results of pairs [pair0, pair0 + n_pairs): (right_u [n][NF], depth [n][NF], n_matches [n])"""
+        nf = max(self.n_features, 1)
+        ru = np.zeros((n_pairs, nf), np.float64)
+        dp = np.zeros((n_pairs, nf), np.float64)
+        nm = np.zeros(n_pairs, np.int32)
+        self._check(self.lib.orbfe_fetch_stereo_batch(self.h, pair0, n_pairs, ptr(ru), ptr(dp), ptr(nm)))
+        return ru, dp, nm
 
     def pyramid(self, slot, level, blurred=False) -> np.ndarray:
         li = self.level_info(level)

@@ -22,6 +22,8 @@
 // is not carried: candidate order is (cell row, cell column, y, x), recomputed from the coordinates.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "orbfe_internal.h"
 #include "wave_ops.h"
 
@@ -1039,8 +1041,21 @@ size_t quadtree_lds_bytes(int node_cap, int rec_cap) {
          (size_t)rec_cap * sizeof(uint32_t);
 }
 
+// The dynamic-LDS limit of a kernel is state of the process and the device, not of a context: contexts of different geometries come
+// and go (on several threads), so the limit is only ever RAISED, under a lock -- a later, smaller context must not lower it under an
+// earlier one whose launches still ask for more.
 hipError_t quadtree_configure(size_t lds_bytes) {
-  return hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  static std::mutex mu;
+  static size_t current[64] = {0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(mu);
+  const int slot = dev >= 0 && dev < 64 ? dev : 63;
+  if (lds_bytes <= current[slot]) return hipSuccess;
+  e = hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e == hipSuccess) current[slot] = lds_bytes;
+  return e;
 }
 
 void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint32_t* d_cand, uint32_t* d_scr_b, uint32_t* d_scr_c,

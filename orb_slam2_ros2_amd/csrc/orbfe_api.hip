@@ -11,6 +11,7 @@
 #include <mutex>
 #include <string>
 #include <limits>
+#include <memory>
 #include <vector>
 
 #include "orbfe_internal.h"
@@ -95,11 +96,11 @@ static const int8_t kEmbeddedPattern[256][4] = {
 static const int kGaussTaps[2][7] = {{18, 34, 48, 56, 48, 34, 18}, {18, 34, 49, 55, 49, 34, 18}};
 static const int kMeanThreshold = 75;  // ORBMatcher::mnMeanThreshold (ORBMatcher.cc:1088)
 
-static thread_local std::string g_create_error;
+// The text of the last failed call is kept PER THREAD (like dlerror): slot calls of one context run on several threads at once.
+static thread_local std::string g_last_error;
 
 struct orbfe_ctx {
   orbfe_config cfg;
-  std::string err;
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -112,13 +113,28 @@ struct orbfe_ctx {
   // the host-pointer path for one or two images (the drop-in call shape) is launch-bound: its copy-in / kernels / copy-out
   // sequence is captured once into a hipGraph per (image count, outputs wanted) and replayed
   struct GraphEntry {
-    int n_img;
+    int slot0, n_img;
     bool want_kps, want_desc;
     const uint8_t* stage;
     const uint8_t* pyr;  // the pyramid buffer baked into the captured kernels (the pipelined batch path swaps the context's two buffers)
     hipGraphExec_t exec;
   };
-  std::vector<GraphEntry> graphs;
+  // One in-order host-pointer pipeline: a stream, its pinned staging buffer and the hipGraphs captured on it.  The context has a main
+  // lane (its own stream) and, created on first use, one lane per image slot for orbfe_extract_slot: the reference extracts the left
+  // and the right image on two threads (src/Frame.cc:100-105), so two slots of one context must be usable at the same time.
+  struct Lane {
+    std::mutex mu;  // serialises the calls on this lane
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev_main = nullptr;  // slot lanes: "the context stream has got this far" (work queued by asynchronous batch calls)
+    uint8_t* h_stage = nullptr;
+    size_t h_stage_bytes = 0;
+    std::vector<GraphEntry> graphs;
+    bool use_graphs = true;
+  };
+  Lane main;
+  std::vector<std::unique_ptr<Lane>> slot_lane;  // [max_images], entries created lazily under slot_lane_mu
+  std::mutex slot_lane_mu;
   bool use_graphs = true;
   // the stereo match of a device-resident batch runs on its own stream: it is latency-bound and reads only the keypoint /
   // descriptor arrays and the pyramid, so the NEXT batch's copy-in, resize and FAST (second pyramid buffer) run under it
@@ -175,8 +191,6 @@ struct orbfe_ctx {
   size_t tmp_bytes = 0;
   // pinned host staging for small result reads
   int32_t* h_counts = nullptr;
-  uint8_t* h_stage = nullptr;  // pinned staging of the host-pointer API
-  size_t h_stage_bytes = 0;
 
   // profiling
   int prof = 0;  // 0 off | 1 every stage timed alone (overlaps and graphs off) | 2..: only stage (prof - 2) timed, in the production schedule
@@ -194,8 +208,8 @@ static orbfe_status fail(orbfe_ctx* c, orbfe_status st, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  if (c) c->err = buf;
-  else g_create_error = buf;
+  (void)c;
+  g_last_error = buf;
   return st;
 }
 
@@ -516,19 +530,20 @@ static orbfe_status ensure_tmp(orbfe_ctx* c, size_t bytes) {
 
 // Pinned staging for the host-pointer API, grown on demand.  Layout per image: level-0 plane with the device row pitch
 // (one contiguous DMA instead of a pageable 2-D copy), then the full keypoint and descriptor arrays.
-static orbfe_status ensure_stage(orbfe_ctx* c, size_t bytes) {
-  if (bytes <= c->h_stage_bytes) return ORBFE_OK;
-  if (c->h_stage) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipHostFree(c->h_stage));
-    c->h_stage = nullptr;
-    c->h_stage_bytes = 0;
+static orbfe_status ensure_stage(orbfe_ctx* c, orbfe_ctx::Lane& ln, size_t bytes) {
+  if (bytes <= ln.h_stage_bytes) return ORBFE_OK;
+  if (ln.h_stage) {
+    HIP_TRY(c, hipStreamSynchronize(ln.stream));
+    HIP_TRY(c, hipHostFree(ln.h_stage));
+    ln.h_stage = nullptr;
+    ln.h_stage_bytes = 0;
   }
   bytes = align_up(bytes, 1 << 20);
-  HIP_TRY(c, hipHostMalloc((void**)&c->h_stage, bytes, hipHostMallocDefault));
-  c->h_stage_bytes = bytes;
+  HIP_TRY(c, hipHostMalloc((void**)&ln.h_stage, bytes, hipHostMallocDefault));
+  ln.h_stage_bytes = bytes;
   return ORBFE_OK;
 }
+static orbfe_status ensure_stage(orbfe_ctx* c, size_t bytes) { return ensure_stage(c, c->main, bytes); }
 
 // ---- stage timing ---------------------------------------------------------------------------------
 static inline bool timed(const orbfe_ctx* c, int stage) { return c->prof == 1 || c->prof == stage + 2; }
@@ -538,8 +553,8 @@ struct StageTimer {
   int stage;
   hipEvent_t a = nullptr, b = nullptr;
   hipStream_t stream;
-  StageTimer(orbfe_ctx* ctx, int st, hipStream_t s) : c(ctx), stage(st), stream(s) {
-    if (!timed(c, st)) return;
+  StageTimer(orbfe_ctx* ctx, int st, hipStream_t s, bool enabled = true) : c(ctx), stage(st), stream(s) {
+    if (!enabled || !timed(c, st)) return;
     auto get = [&]() {
       hipEvent_t e = nullptr;
       if (!c->ev_pool.empty()) {
@@ -585,7 +600,10 @@ static orbfe_status join_stereo(orbfe_ctx* c) {
 
 // ---- the launch sequence for slots [0, n_img) ---------------------------------------------------------
 // Slots [img0, img0 + n_img) on stream `st`.  Every per-image array is offset on the host, so the kernels index from 0.
-static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, int lds_share = 1, hipEvent_t before_lists = nullptr) {
+static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, int lds_share = 1, hipEvent_t before_lists = nullptr,
+                                bool timing = true) {
+  // timing = false: a slot lane (orbfe_extract_slot) -- several of them run at once, so nothing shared by the context is touched:
+  // no stage timers (their event lists belong to the main lane), no second stream
   // before_lists: event the keypoint-list / orientation / descriptor kernels must wait for (the previous batch's stereo match still
   // reads the arrays they rewrite); callers that do not pipeline have joined the stereo stream already
   const int nl = c->cfg.n_levels;
@@ -595,7 +613,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   uint8_t* blur = c->d_blur + i0 * c->img_pitch;
   int32_t* n_cand = c->d_n_cand + i0 * nl;
   {
-    StageTimer t(c, ORBFE_STAGE_RESIZE, st);
+    StageTimer t(c, ORBFE_STAGE_RESIZE, st, timing);
     launch_resize(st, c->d_lv, c->d_rs_tiles, c->rs_n, c->rs_bytes, c->d_taps, pyr, c->img_pitch, n_img);
   }
   // Only the descriptors read the blurred planes, so the blur need not sit between resize and FAST: it is issued on a second
@@ -604,14 +622,14 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   // context, the blur stays in line.  (Measured and dropped: starting each level's quadtree under FAST of the smaller levels on
   // a third stream -- the tree waves then share their SIMDs with a VALU-saturating kernel and the dependent chain stretches:
   // 3.04 -> 4.6 ms per 128 pairs.)
-  const bool overlap_blur = c->blur_stream && c->prof != 1 && lds_share == 1 && n_img >= 32;  // a frame or two: nothing to hide, only event latency to add
+  const bool overlap_blur = timing && c->blur_stream && c->prof != 1 && lds_share == 1 && n_img >= 32;  // a frame or two: nothing to hide, only event latency to add
   if (!overlap_blur) {
-    StageTimer t(c, ORBFE_STAGE_BLUR, st);
+    StageTimer t(c, ORBFE_STAGE_BLUR, st, timing);
     launch_blur(st, c->d_lv, nl, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
   }
   HIP_TRY(c, hipMemsetAsync(n_cand, 0, sizeof(int32_t) * (size_t)n_img * nl, st));
   {
-    StageTimer t(c, ORBFE_STAGE_FAST, st);
+    StageTimer t(c, ORBFE_STAGE_FAST, st, timing);
     launch_fast(st, c->d_lv, c->d_cells, c->lv.data(), c->lvl_max_pw, c->lvl_max_ph, pyr, c->img_pitch, c->cfg.fast_hi, c->cfg.fast_lo,
                 c->d_scr_a + i0 * c->scratch_pitch, c->scratch_pitch, n_cand, nl, n_img, overlap_blur ? c->blur_stream : nullptr,
                 c->ev_fast_go, c->ev_fast_done, c->fast_side_from);
@@ -626,7 +644,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     HIP_TRY(c, hipEventRecord(c->ev_blur_done, c->blur_stream));
   }
   {
-    StageTimer t(c, ORBFE_STAGE_QUADTREE, st);
+    StageTimer t(c, ORBFE_STAGE_QUADTREE, st, timing);
     // LDS residency of the candidate records is traded against concurrency: the kernel is latency-bound (one wave per
     // tree, 40-150 dependent steps), so what matters most is that EVERY tree of the launch is resident at once; the
     // records go to LDS only as far as that still holds (measured at 1024 trees: 4 trees/CU 0.59 ms, 3 trees/CU 0.96 ms).
@@ -644,7 +662,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
                     c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img, c->qt_batch);
   }
   {
-    StageTimer t(c, ORBFE_STAGE_BRIEF, st);
+    StageTimer t(c, ORBFE_STAGE_BRIEF, st, timing);
     launch_orient_brief(st, c->d_lv, nl, pyr, blur, c->img_pitch, c->d_sel + i0 * NF, c->d_sel_count + i0 * nl, c->cfg.n_features,
                         c->d_pattern, c->umax, c->d_kps + i0 * NF, c->d_desc + i0 * NF * 32, c->d_aux + i0 * NF, c->d_n_kp + i0,
                         c->d_theta + i0 * NF, c->d_moments + i0 * NF, c->d_sincos + i0 * NF, c->d_kx + i0 * NF,
@@ -675,7 +693,7 @@ extern "C" {
 
 int orbfe_abi_version(void) { return ORBFE_ABI_VERSION; }
 
-const char* orbfe_last_error(const orbfe_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char* orbfe_last_error(const orbfe_ctx*) { return g_last_error.c_str(); }
 
 const char* orbfe_stage_name(int32_t stage) {
   static const char* names[ORBFE_STAGE_COUNT] = {"resize", "blur", "fast", "quadtree", "orient_brief", "stereo", "match", "ba"};
@@ -697,13 +715,22 @@ void orbfe_destroy(orbfe_ctx* c) {
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
-  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  for (auto& sl : c->slot_lane)
+    if (sl) {
+      if (sl->stream) (void)hipStreamSynchronize(sl->stream);
+      for (auto& ge : sl->graphs) (void)hipGraphExecDestroy(ge.exec);
+      if (sl->h_stage) (void)hipHostFree(sl->h_stage);
+      if (sl->ev_main) (void)hipEventDestroy(sl->ev_main);
+      if (sl->stream) (void)hipStreamDestroy(sl->stream);
+    }
+  c->slot_lane.clear();
+  if (c->main.h_stage) (void)hipHostFree(c->main.h_stage);
   for (int k = 0; k < orbfe_ctx::kMaxSide; ++k) {
     if (c->side[k]) (void)hipStreamDestroy(c->side[k]);
     if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
   }
-  for (auto& ge : c->graphs) (void)hipGraphExecDestroy(ge.exec);
-  c->graphs.clear();
+  for (auto& ge : c->main.graphs) (void)hipGraphExecDestroy(ge.exec);
+  c->main.graphs.clear();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_blur_go) (void)hipEventDestroy(c->ev_blur_go);
   if (c->ev_blur_done) (void)hipEventDestroy(c->ev_blur_done);
@@ -737,8 +764,9 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   std::memset(c->stage_ms, 0, sizeof c->stage_ms);
   std::memset(c->stage_launches, 0, sizeof c->stage_launches);
   auto bail = [&](orbfe_status st) {
-    g_create_error = c->err;
+    const std::string keep = g_last_error;
     orbfe_destroy(c);
+    g_last_error = keep;
     return st;
   };
   orbfe_status st = build_geometry(c);
@@ -761,6 +789,8 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     }
     c->own_stream = true;
   }
+  c->main.stream = c->stream;
+  c->slot_lane.resize((size_t)cfg->max_images);
   {
     const char* env = getenv("ORBFE_STREAMS");
     int want = env ? atoi(env) : 1;
@@ -932,7 +962,7 @@ orbfe_status orbfe_fetch_stereo(orbfe_ctx* c, int32_t pair, double* right_u, dou
   const size_t o_ru = 0, o_dp = align_up(NF * 8, 256), o_br = o_dp + align_up(NF * 8, 256), o_bd = o_br + align_up(NF * 4, 256),
                o_nm = o_bd + align_up(NF * 4, 256), total = o_nm + 256;
   TRY(ensure_stage(c, total));
-  uint8_t* h = c->h_stage;
+  uint8_t* h = c->main.h_stage;
   if (right_u && NF) HIP_TRY(c, hipMemcpyAsync(h + o_ru, c->d_right_u + o, sizeof(double) * NF, hipMemcpyDeviceToHost, c->stream));
   if (depth && NF) HIP_TRY(c, hipMemcpyAsync(h + o_dp, c->d_depth + o, sizeof(double) * NF, hipMemcpyDeviceToHost, c->stream));
   if (best_right && NF) HIP_TRY(c, hipMemcpyAsync(h + o_br, c->d_best_right + o, sizeof(int32_t) * NF, hipMemcpyDeviceToHost, c->stream));
@@ -948,6 +978,36 @@ orbfe_status orbfe_fetch_stereo(orbfe_ctx* c, int32_t pair, double* right_u, dou
   return ORBFE_OK;
 }
 
+// Bulk fetches: the packed result arrays of a range of slots / pairs in one copy each (full [n_features] strides), one synchronisation.
+orbfe_status orbfe_fetch_batch(orbfe_ctx* c, int32_t slot0, int32_t n_slots, orbfe_keypoint* kps, uint8_t* desc, int32_t* counts) {
+  if (!c || slot0 < 0 || n_slots < 0 || slot0 + n_slots > c->cfg.max_images) return fail(c, ORBFE_EBADARG, "fetch_batch: slots [%d, %d)", slot0, slot0 + n_slots);
+  if (n_slots == 0) return ORBFE_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
+  const size_t NF = (size_t)std::max(c->cfg.n_features, 1), s0 = (size_t)slot0, n = (size_t)n_slots;
+  if (counts) HIP_TRY(c, hipMemcpyAsync(counts, c->d_n_kp + s0, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+  if (kps) HIP_TRY(c, hipMemcpyAsync(kps, c->d_kps + s0 * NF, sizeof(orbfe_keypoint) * n * NF, hipMemcpyDeviceToHost, c->stream));
+  if (desc) HIP_TRY(c, hipMemcpyAsync(desc, c->d_desc + s0 * NF * 32, n * NF * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_fetch_stereo_batch(orbfe_ctx* c, int32_t pair0, int32_t n_pairs, double* right_u, double* depth, int32_t* n_matches) {
+  if (!c || pair0 < 0 || n_pairs < 0 || pair0 + n_pairs > (c->cfg.max_images + 1) / 2)
+    return fail(c, ORBFE_EBADARG, "fetch_stereo_batch: pairs [%d, %d)", pair0, pair0 + n_pairs);
+  if (n_pairs == 0) return ORBFE_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
+  const size_t NF = (size_t)std::max(c->cfg.n_features, 1), p0 = (size_t)pair0, n = (size_t)n_pairs;
+  if (right_u) HIP_TRY(c, hipMemcpyAsync(right_u, c->d_right_u + p0 * NF, sizeof(double) * n * NF, hipMemcpyDeviceToHost, c->stream));
+  if (depth) HIP_TRY(c, hipMemcpyAsync(depth, c->d_depth + p0 * NF, sizeof(double) * n * NF, hipMemcpyDeviceToHost, c->stream));
+  if (n_matches) HIP_TRY(c, hipMemcpyAsync(n_matches, c->d_n_match + p0, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  return ORBFE_OK;
+}
+
 orbfe_status orbfe_device_results(orbfe_ctx* c, const void** d_kps, const void** d_desc, const void** d_counts, const void** d_right_u,
                                   const void** d_depth, const void** d_nmatch) {
   if (!c) return ORBFE_EBADARG;
@@ -960,35 +1020,97 @@ orbfe_status orbfe_device_results(orbfe_ctx* c, const void** d_kps, const void**
   return ORBFE_OK;
 }
 
-// results of slots 0..n_img-1 to the host through the pinned staging buffer: one batch of D2H copies (full arrays: the counts
-// are not known on the host yet), ONE synchronisation
-static orbfe_status enqueue_fetch(orbfe_ctx* c, int n_img, size_t o_kps, size_t o_desc, size_t o_cnt, bool want_kps, bool want_desc) {
-  const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
-  HIP_TRY(c, hipMemcpyAsync(c->h_stage + o_cnt, c->d_n_kp, sizeof(int32_t) * n_img, hipMemcpyDeviceToHost, c->stream));
+// results of slots slot0..slot0+n_img-1 to the host through the lane's pinned staging buffer: one batch of D2H copies (full arrays:
+// the counts are not known on the host yet), ONE synchronisation
+static orbfe_status enqueue_fetch(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, int n_img, size_t o_kps, size_t o_desc, size_t o_cnt,
+                                  bool want_kps, bool want_desc) {
+  const size_t NF = (size_t)std::max(c->cfg.n_features, 1), s0 = (size_t)slot0;
+  HIP_TRY(c, hipMemcpyAsync(ln.h_stage + o_cnt, c->d_n_kp + s0, sizeof(int32_t) * n_img, hipMemcpyDeviceToHost, ln.stream));
   if (want_kps)
-    HIP_TRY(c, hipMemcpyAsync(c->h_stage + o_kps, c->d_kps, (size_t)n_img * NF * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, c->stream));
-  if (want_desc) HIP_TRY(c, hipMemcpyAsync(c->h_stage + o_desc, c->d_desc, (size_t)n_img * NF * 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(ln.h_stage + o_kps, c->d_kps + s0 * NF, (size_t)n_img * NF * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost,
+                              ln.stream));
+  if (want_desc)
+    HIP_TRY(c, hipMemcpyAsync(ln.h_stage + o_desc, c->d_desc + s0 * NF * 32, (size_t)n_img * NF * 32, hipMemcpyDeviceToHost, ln.stream));
   return ORBFE_OK;
 }
-static orbfe_status finish_fetch(orbfe_ctx* c, int n_img, size_t o_kps, size_t o_desc, size_t o_cnt, orbfe_keypoint* kps, uint8_t* desc,
-                                 int32_t* n_out) {
+static orbfe_status finish_fetch(orbfe_ctx* c, orbfe_ctx::Lane& ln, int n_img, size_t o_kps, size_t o_desc, size_t o_cnt,
+                                 orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out, bool timing) {
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  drain_timers(c);
-  const int32_t* cnt = (const int32_t*)(c->h_stage + o_cnt);
+  HIP_TRY(c, hipStreamSynchronize(ln.stream));
+  if (timing) drain_timers(c);
+  const int32_t* cnt = (const int32_t*)(ln.h_stage + o_cnt);
   for (int i = 0; i < n_img; ++i) {
     const int32_t n = cnt[i];
     if (n < 0 || (size_t)n > NF) return fail(c, ORBFE_EDEVICE, "extract: corrupt count %d for image %d", n, i);
-    if (kps) std::memcpy(kps + (size_t)i * NF, c->h_stage + o_kps + (size_t)i * NF * sizeof(orbfe_keypoint), sizeof(orbfe_keypoint) * n);
-    if (desc) std::memcpy(desc + (size_t)i * NF * 32, c->h_stage + o_desc + (size_t)i * NF * 32, (size_t)32 * n);
+    if (kps) std::memcpy(kps + (size_t)i * NF, ln.h_stage + o_kps + (size_t)i * NF * sizeof(orbfe_keypoint), sizeof(orbfe_keypoint) * n);
+    if (desc) std::memcpy(desc + (size_t)i * NF * 32, ln.h_stage + o_desc + (size_t)i * NF * 32, (size_t)32 * n);
     if (n_out) n_out[i] = n;
   }
   return ORBFE_OK;
 }
 static orbfe_status fetch_extract_results(orbfe_ctx* c, int n_img, size_t o_kps, size_t o_desc, size_t o_cnt, orbfe_keypoint* kps,
                                           uint8_t* desc, int32_t* n_out) {
-  TRY(enqueue_fetch(c, n_img, o_kps, o_desc, o_cnt, kps != nullptr, desc != nullptr));
-  return finish_fetch(c, n_img, o_kps, o_desc, o_cnt, kps, desc, n_out);
+  TRY(enqueue_fetch(c, c->main, 0, n_img, o_kps, o_desc, o_cnt, kps != nullptr, desc != nullptr));
+  return finish_fetch(c, c->main, n_img, o_kps, o_desc, o_cnt, kps, desc, n_out, true);
+}
+
+// Host images -> slots [slot0, slot0 + n_img) on lane `ln`: copy-in, the launch sequence, results back, one synchronisation.  One or
+// two images (the drop-in call shape) are launch-bound: the whole sequence is captured once per lane into a hipGraph and replayed.
+static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, int n_img, const uint8_t* const* imgs, size_t stride,
+                                 orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out, bool timing) {
+  const LevelDev& L0 = c->lv[0];
+  const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
+  const size_t plane = align_up((size_t)L0.stride * L0.h, 256);
+  const size_t o_kps = (size_t)n_img * plane, o_desc = o_kps + align_up((size_t)n_img * NF * sizeof(orbfe_keypoint), 256);
+  const size_t o_cnt = o_desc + align_up((size_t)n_img * NF * 32, 256), total = o_cnt + align_up((size_t)n_img * 4, 256);
+  TRY(ensure_stage(c, ln, total));
+  for (int i = 0; i < n_img; ++i) {
+    if (!imgs[i]) return fail(c, ORBFE_EBADARG, "extract: image %d is NULL", i);
+    uint8_t* dst = ln.h_stage + (size_t)i * plane;
+    for (int y = 0; y < L0.h; ++y) std::memcpy(dst + (size_t)y * L0.stride, imgs[i] + (size_t)y * stride, (size_t)c->cfg.width);
+  }
+  uint8_t* const pyr_now = c->d_pyr;
+  auto enqueue_all = [&]() -> orbfe_status {
+    for (int i = 0; i < n_img; ++i)
+      HIP_TRY(c, hipMemcpyAsync(pyr_now + (size_t)(slot0 + i) * c->img_pitch + L0.plane_off, ln.h_stage + (size_t)i * plane,
+                                (size_t)L0.stride * L0.h, hipMemcpyHostToDevice, ln.stream));
+    TRY(run_extract(c, ln.stream, slot0, n_img, 1, nullptr, timing));
+    return enqueue_fetch(c, ln, slot0, n_img, o_kps, o_desc, o_cnt, kps != nullptr, desc != nullptr);
+  };
+  if (c->use_graphs && ln.use_graphs && c->prof == 0 && n_img <= 2) {
+    hipGraphExec_t exec = nullptr;
+    for (auto it = ln.graphs.begin(); it != ln.graphs.end();) {
+      if (it->stage != ln.h_stage) {  // the staging buffer was re-allocated: the captured addresses are stale
+        (void)hipGraphExecDestroy(it->exec);
+        it = ln.graphs.erase(it);
+        continue;
+      }
+      if (it->slot0 == slot0 && it->n_img == n_img && it->want_kps == (kps != nullptr) && it->want_desc == (desc != nullptr) && it->pyr == pyr_now)
+        exec = it->exec;
+      ++it;
+    }
+    if (!exec) {
+      hipGraph_t g = nullptr;
+      bool ok = hipStreamBeginCapture(ln.stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      const orbfe_status st = ok ? enqueue_all() : ORBFE_EDEVICE;
+      if (ok) ok = hipStreamEndCapture(ln.stream, &g) == hipSuccess && st == ORBFE_OK && g;
+      if (ok) ok = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess;
+      if (g) (void)hipGraphDestroy(g);
+      if (ok) {
+        ln.graphs.push_back({slot0, n_img, kps != nullptr, desc != nullptr, ln.h_stage, pyr_now, exec});
+      } else {
+        (void)hipGetLastError();
+        exec = nullptr;
+        ln.use_graphs = false;  // this runtime cannot capture the sequence: plain launches on this lane from now on
+      }
+    }
+    if (exec) {
+      HIP_TRY(c, hipGraphLaunch(exec, ln.stream));
+      return finish_fetch(c, ln, n_img, o_kps, o_desc, o_cnt, kps, desc, n_out, timing);
+    }
+  }
+  TRY(enqueue_all());
+  return finish_fetch(c, ln, n_img, o_kps, o_desc, o_cnt, kps, desc, n_out, timing);
 }
 
 orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* const* imgs, size_t stride, orbfe_keypoint* kps,
@@ -999,57 +1121,40 @@ orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* con
   if (n_img == 0) return ORBFE_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
-  const LevelDev& L0 = c->lv[0];
-  const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
-  const size_t plane = align_up((size_t)L0.stride * L0.h, 256);
-  const size_t o_kps = (size_t)n_img * plane, o_desc = o_kps + align_up((size_t)n_img * NF * sizeof(orbfe_keypoint), 256);
-  const size_t o_cnt = o_desc + align_up((size_t)n_img * NF * 32, 256), total = o_cnt + align_up((size_t)n_img * 4, 256);
-  TRY(ensure_stage(c, total));
-  for (int i = 0; i < n_img; ++i) {
-    if (!imgs[i]) return fail(c, ORBFE_EBADARG, "extract_batch: image %d is NULL", i);
-    uint8_t* dst = c->h_stage + (size_t)i * plane;
-    for (int y = 0; y < L0.h; ++y) std::memcpy(dst + (size_t)y * L0.stride, imgs[i] + (size_t)y * stride, (size_t)c->cfg.width);
-  }
-  auto enqueue_all = [&]() -> orbfe_status {
-    for (int i = 0; i < n_img; ++i)
-      HIP_TRY(c, hipMemcpyAsync(c->d_pyr + (size_t)i * c->img_pitch + L0.plane_off, c->h_stage + (size_t)i * plane, (size_t)L0.stride * L0.h,
-                                hipMemcpyHostToDevice, c->stream));
-    TRY(run_extract(c, c->stream, 0, n_img));
-    return enqueue_fetch(c, n_img, o_kps, o_desc, o_cnt, kps != nullptr, desc != nullptr);
-  };
-  if (c->use_graphs && c->prof == 0 && n_img <= 2) {
-    hipGraphExec_t exec = nullptr;
-    for (auto it = c->graphs.begin(); it != c->graphs.end();) {
-      if (it->stage != c->h_stage) {  // the staging buffer was re-allocated: the captured addresses are stale
-        (void)hipGraphExecDestroy(it->exec);
-        it = c->graphs.erase(it);
-        continue;
+  return extract_lane(c, c->main, 0, n_img, imgs, stride, kps, desc, n_out, true);
+}
+
+// One image -> slot `slot` on that slot's own lane.  Calls on DIFFERENT slots may run at the same time on different threads.
+orbfe_status orbfe_extract_slot(orbfe_ctx* c, int32_t slot, const uint8_t* img, size_t stride, orbfe_keypoint* kps, uint8_t* desc,
+                                int32_t* n_out) {
+  if (!c || !img) return fail(c, ORBFE_EBADARG, "extract_slot: NULL argument");
+  if (slot < 0 || slot >= c->cfg.max_images) return fail(c, ORBFE_EBADARG, "extract_slot: slot %d of %d", slot, c->cfg.max_images);
+  if (stride < (size_t)c->cfg.width) return fail(c, ORBFE_EBADARG, "extract_slot: stride %zu < width %d", stride, c->cfg.width);
+  HIP_TRY(c, hipSetDevice(c->device));
+  orbfe_ctx::Lane* ln = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(c->slot_lane_mu);
+    if (!c->slot_lane[(size_t)slot]) {
+      std::unique_ptr<orbfe_ctx::Lane> fresh(new orbfe_ctx::Lane());
+      HIP_TRY(c, hipStreamCreateWithFlags(&fresh->stream, hipStreamNonBlocking));
+      fresh->own_stream = true;
+      if (hipEventCreateWithFlags(&fresh->ev_main, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(fresh->stream);
+        return fail(c, ORBFE_EDEVICE, "extract_slot: cannot create the lane event");
       }
-      if (it->n_img == n_img && it->want_kps == (kps != nullptr) && it->want_desc == (desc != nullptr) && it->pyr == c->d_pyr) exec = it->exec;
-      ++it;
+      c->slot_lane[(size_t)slot] = std::move(fresh);
     }
-    if (!exec) {
-      hipGraph_t g = nullptr;
-      bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-      const orbfe_status st = ok ? enqueue_all() : ORBFE_EDEVICE;
-      if (ok) ok = hipStreamEndCapture(c->stream, &g) == hipSuccess && st == ORBFE_OK && g;
-      if (ok) ok = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess;
-      if (g) (void)hipGraphDestroy(g);
-      if (ok) {
-        c->graphs.push_back({n_img, kps != nullptr, desc != nullptr, c->h_stage, c->d_pyr, exec});
-      } else {
-        (void)hipGetLastError();
-        exec = nullptr;
-        c->use_graphs = false;  // this runtime cannot capture the sequence: plain launches from now on
-      }
-    }
-    if (exec) {
-      HIP_TRY(c, hipGraphLaunch(exec, c->stream));
-      return finish_fetch(c, n_img, o_kps, o_desc, o_cnt, kps, desc, n_out);
-    }
+    ln = c->slot_lane[(size_t)slot].get();
   }
-  TRY(enqueue_all());
-  return finish_fetch(c, n_img, o_kps, o_desc, o_cnt, kps, desc, n_out);
+  std::lock_guard<std::mutex> lk(ln->mu);
+  // a stereo match of an earlier device batch may still be reading the slot arrays (the flag is only read here: the calls that
+  // change it must not overlap with slot calls)
+  if (c->stereo_pending) HIP_TRY(c, hipStreamWaitEvent(ln->stream, c->ev_stereo_done, 0));
+  // ... and an asynchronous batch call may have left work on the context stream that still writes this slot
+  HIP_TRY(c, hipEventRecord(ln->ev_main, c->stream));
+  HIP_TRY(c, hipStreamWaitEvent(ln->stream, ln->ev_main, 0));
+  const uint8_t* one[1] = {img};
+  return extract_lane(c, *ln, slot, 1, one, stride, kps, desc, n_out, false);
 }
 
 orbfe_status orbfe_extract(orbfe_ctx* c, const uint8_t* img, size_t stride, orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out) {
@@ -1072,8 +1177,8 @@ orbfe_status orbfe_extract_color(orbfe_ctx* c, const uint8_t* img, size_t stride
                total = o_cnt + 256;
   TRY(ensure_stage(c, total));
   TRY(ensure_tmp(c, plane));
-  for (int y = 0; y < L0.h; ++y) std::memcpy(c->h_stage + (size_t)y * row, img + (size_t)y * stride, (size_t)c->cfg.width * 3);
-  HIP_TRY(c, hipMemcpyAsync(c->d_tmp, c->h_stage, row * (size_t)L0.h, hipMemcpyHostToDevice, c->stream));
+  for (int y = 0; y < L0.h; ++y) std::memcpy(c->main.h_stage + (size_t)y * row, img + (size_t)y * stride, (size_t)c->cfg.width * 3);
+  HIP_TRY(c, hipMemcpyAsync(c->d_tmp, c->main.h_stage, row * (size_t)L0.h, hipMemcpyHostToDevice, c->stream));
   launch_cvt_gray(c->stream, (const uint8_t*)c->d_tmp, row, c->d_pyr + L0.plane_off, L0.stride, c->cfg.width, c->cfg.height, color_order);
   TRY(run_extract(c, c->stream, 0, 1));
   return fetch_extract_results(c, 1, o_kps, o_desc, o_cnt, kps, desc, n_out);
@@ -1368,7 +1473,7 @@ orbfe_status orbfe_ba_build_system(orbfe_ctx* c, const orbfe_ba_problem* p, cons
 // Optimizer::OptimizeLocalMap's two optimize() calls (Optimizer.cc:336-362) with g2o's Levenberg-Marquardt control on the host
 // (a handful of scalars per trial) and every vertex / edge / block operation on the device.
 orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, const uint8_t* pose_fixed, int32_t iters_first,
-                                     int32_t iters_second, const volatile int32_t* stop_flag, const orbfe_ba_optimize_out* o) {
+                                     int32_t iters_second, const volatile uint8_t* stop_flag, const orbfe_ba_optimize_out* o) {
   if (!c || !p || !o) return fail(c, ORBFE_EBADARG, "ba_local_optimize: NULL argument");
   const int E = p->n_edges, NK = p->n_poses, NP = p->n_points;
   if (E < 0 || NK < 0 || NP < 0 || iters_first < 0 || iters_second < 0) return fail(c, ORBFE_EBADARG, "ba_local_optimize: negative size");

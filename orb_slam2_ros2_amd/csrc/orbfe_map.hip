@@ -61,7 +61,7 @@ orbfe_status orbfe_map_local_graph(const uint8_t* pb, size_t len, uint64_t kf_id
 }
 
 orbfe_status orbfe_map_local_ba(orbfe_ctx* ctx, const uint8_t* pb, size_t len, uint64_t kf_id, const orbfe_camera* cam,
-                                const volatile int32_t* stop_flag, uint8_t* out, size_t cap, size_t* out_len,
+                                const volatile uint8_t* stop_flag, uint8_t* out, size_t cap, size_t* out_len,
                                 orbfe_map_ba_report* report) {
   if (!ctx || (!pb && len) || !cam || !out_len) return ORBFE_EBADARG;
   MapRec map;

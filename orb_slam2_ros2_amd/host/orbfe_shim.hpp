@@ -415,19 +415,19 @@ class Optimizer {
   };
   // Optimizer::OptimizeLocalMap (src/Optimizer.cc:336-391) on the graph `prob` describes
   static LocalMapResult OptimizeLocalMap(orbfe_ctx* ctx, const orbfe_ba_problem& prob, const std::vector<uint8_t>& poseFixed,
-                                         const volatile int32_t* isStop = nullptr) {
+                                         const volatile bool* isStop = nullptr) {
     LocalMapResult r;
     r.poses.resize((size_t)prob.n_poses * 7), r.points.resize((size_t)prob.n_points * 3);
     r.chi2.resize((size_t)std::max(prob.n_edges, 1)), r.level.resize(r.chi2.size()), r.bad.resize(r.chi2.size());
     orbfe_ba_optimize_out o = {r.poses.data(), r.points.data(), r.level.data(), r.chi2.data(), r.bad.data(), r.iterations};
-    check(ctx, orbfe_ba_local_optimize(ctx, &prob, poseFixed.empty() ? nullptr : poseFixed.data(), 5, 10, isStop, &o));
+    check(ctx, orbfe_ba_local_optimize(ctx, &prob, poseFixed.empty() ? nullptr : poseFixed.data(), 5, 10, (const volatile uint8_t*)isStop, &o));
     r.chi2.resize(prob.n_edges), r.level.resize(prob.n_edges), r.bad.resize(prob.n_edges);
     return r;
   }
   // Optimizer::OptimizeLocalMap(pkframe, isStop) (src/Optimizer.cc:225-441) on a map loaded from map.pb: graph construction,
   // the two optimize() rounds on the device, the write-back policy; `map` is updated in place
   static mappb::LocalBaReport OptimizeLocalMap(orbfe_ctx* ctx, mappb::MapRec& map, uint64_t kfId, const orbfe_camera& cam,
-                                               const volatile int32_t* isStop = nullptr) {
+                                               const volatile bool* isStop = nullptr) {
     mappb::LocalGraph g;
     if (!mappb::build_local_graph(map, kfId, g)) throw std::runtime_error("OptimizeLocalMap: keyframe id is not in the map");
     orbfe_ba_problem p{};
