@@ -8,7 +8,14 @@ prints ONE JSON line on rank 0 (see the task statement).  N>1: launched by torch
 rank per GPU, frames sharded per rank (weak scaling), one RCCL gather of the per-pair results at the end
 of the sequence inside the timed region.
 
+`--sequence F` runs BASELINE config 4 instead: a sequence of F stereo pairs cut into contiguous blocks per rank (sharding.frame_range),
+each rank streaming its block from page-locked host memory through orbfe_stream_submit in batches of <= --pairs, and ONE gather of
+the per-frame records (left keypoints + descriptors + right_u + depth, 152 KB per frame) to rank 0 over RCCL, inside the timed region.
+
 Extra objects in the JSON line:
+  host_io       the same step fed from page-locked HOST memory and delivering its results to host memory (orbfe_stream_submit:
+                upload of batch k+1 and download of batch k-1 under the compute of batch k) -- the PCIe-inclusive rate; `value`
+                itself is device-resident
   roofline      dominant kernel: algorithmic bytes per launch / mean launch duration (HIP events on the
                 library's stream) against the 8 TB/s HBM peak
   cpu_baseline  the CPU oracle (oracle/, -O3 -march=native, 2 threads exactly like Frame.cc:100-105)
@@ -74,6 +81,154 @@ def spawn_ranks(n: int) -> int:
     return 0
 
 
+def host_io_leg(ctx, left_h, right_h, B, steps, want, world, sync_all, dist, torch, xdev):
+    """The step fed from page-locked host memory, results delivered to page-locked host memory (transfers included).
+    Two input buffers and two result sets alternate; at most two batches are outstanding."""
+    from orb_slam2_ros2_amd._lib import PinnedArray
+    from orb_slam2_ros2_amd.digest import batch_digests
+    pins = []
+    for _ in range(2):
+        l, r = PinnedArray(left_h.shape, np.uint8), PinnedArray(right_h.shape, np.uint8)
+        l.array[...] = left_h
+        r.array[...] = right_h
+        pins.append((l, r))
+    outs = [ctx.alloc_batch_results(B, pinned=True) for _ in range(2)]
+
+    def run(n):
+        last = None
+        for k in range(n):
+            t = ctx.stream_submit(pins[k % 2][0].array, pins[k % 2][1].array, B, FX, BF, outs[k % 2])
+            if last is not None:
+                ctx.stream_wait(last)
+            last = t
+        ctx.stream_wait(last)
+    run(4)
+    sync_all()
+    t0 = time.perf_counter()
+    run(steps)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ok = 0
+    for o in outs:   # the last two batches, as delivered to the host
+        dig = batch_digests(o["kps"], o["desc"], o["counts"], o["right_u"], o["depth"], o["n_matches"])
+        bad = [p for p in range(B) if want[p] is not None and dig[p] != want[p]]
+        if bad:
+            raise SystemExit(f"bench.py: host_io leg: {len(bad)} of {B} pairs differ from the golden digests (first: pair {bad[0]})")
+        ok += sum(w is not None for w in want)
+    in_bytes = left_h.nbytes + right_h.nbytes
+    out_bytes = sum(o[k].nbytes for k in ("kps", "desc", "counts", "right_u", "depth", "n_matches") for o in outs[:1])
+    res = {
+        "pairs_per_s": steps * B * world / dt,
+        "ms_per_step": dt / steps * 1e3,
+        "steps": steps,
+        "h2d_GBps": in_bytes * steps / dt / 1e9,          # per GPU
+        "d2h_GBps": out_bytes * steps / dt / 1e9,         # per GPU
+        "h2d_bytes_per_pair": in_bytes // B,
+        "d2h_bytes_per_pair": out_bytes // B,
+        "verified_pairs": ok,
+        "what": "page-locked host images -> orbfe_stream_submit (upload k+1 / compute k / download k-1 overlapped) -> full result "
+                "arrays (keypoints, descriptors, right_u, depth, counts of both images) in page-locked host memory",
+    }
+    for o in outs:
+        for pa in o["_pinned"]:
+            pa.free()
+    for l, r in pins:
+        l.free()
+        r.free()
+    return res
+
+
+def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend):
+    """BASELINE config 4: a whole sequence (KittiStereo.cc:28-37) sharded over the ranks, records gathered on rank 0."""
+    import torch
+    import torch.distributed as dist
+
+    from orb_slam2_ros2_amd import synth
+    from orb_slam2_ros2_amd._lib import Context
+    from orb_slam2_ros2_amd.digest import pair_digest  # noqa: F401  (records are checked field by field below)
+    from orb_slam2_ros2_amd.sequence import DeviceSequenceProcessor, record_bytes, run_sequence, unpack_record
+    from orb_slam2_ros2_amd.sharding import frame_range
+
+    F, B, U = args.sequence, args.pairs, max(1, min(args.sequence_unique, 128))
+    b, e = frame_range(F, rank, world)
+    B = max(1, min(B, max(e - b, 1)))
+    ctx = Context(W, H, NFEAT, NLEVELS, SCALE, TH_HI, TH_LO, device_id=local_rank, max_images=2 * B)
+    proc = DeviceSequenceProcessor(ctx, lambda f: synth.stereo_pair(f % U, W, H), B, FX, BF, dev)
+    proc.prepare(range(b, e))   # page-locked batches of this rank's block, built before the clock starts
+
+    def to_xdev(t):
+        return t if backend == "nccl" else t.cpu()
+
+    def collect(h):
+        return to_xdev(proc.collect(h))
+
+    def sync_all():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # warm-up: one pass over (at most) two batches, including the exchange
+    run_sequence(min(F, 2 * B * world), rank, world, B, proc.submit, collect)
+    sync_all()
+    t0 = time.perf_counter()
+    rec, n_local = run_sequence(F, rank, world, B, proc.submit, collect)
+    rec_host = rec.cpu() if rank == 0 else None     # the sequence-level result, on the host of rank 0
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    line = None
+    if rank == 0:
+        # every frame's record against the record of the first frame with the same content (frames repeat with period U), and the
+        # distinct ones against a host-pointer run of the same library (whose digests the GPU suite pins to the golden fixtures)
+        r = rec_host.numpy()
+        assert r.shape == (F, record_bytes(ctx.n_features))
+        for f in range(min(U, F), F):
+            if not np.array_equal(r[f], r[f % U]):
+                raise SystemExit(f"bench.py --sequence: record of frame {f} differs from frame {f % U} (same image)")
+        checked = 0
+        for f in range(min(U, F, 8)):
+            u = unpack_record(r[f], ctx.n_features)
+            (lk, ld), _ = ctx.extract_batch(list(synth.stereo_pair(f % U, W, H)))
+            nm, ru, dp, _, _ = ctx.stereo_match(0, 1, FX, BF)
+            n = len(lk)
+            if not (u["n"] == n and u["n_matches"] == nm and np.array_equal(u["kps"], lk) and np.array_equal(u["desc"], ld)
+                    and np.array_equal(u["right_u"], ru[:n]) and np.array_equal(u["depth"], dp[:n])):
+                raise SystemExit(f"bench.py --sequence: record of frame {f} differs from the host-pointer path")
+            checked += 1
+        n_batches = (max(e - b, 1) + B - 1) // B
+        line = {
+            "metric": "stereo frames/sec (extract+match) KITTI-00 1241x376; HBM GB/s vs roofline",
+            "value": F / dt, "unit": "stereo pairs/s", "n_gpus": world, "steps": n_batches, "warmup": 1,
+            "ms_per_step": dt / n_batches * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"Full KITTI-00-shaped sequence ({F} stereo pairs, {U} distinct synthetic frames) frame-sharded across "
+                            f"{world} GPU(s), gather of the per-frame records to rank 0",
+                "io": "page-locked host images -> device (upload overlapped with compute); records packed on the device, gathered "
+                      "over " + ("RCCL" if backend == "nccl" else backend) + ", copied to the host of rank 0 -- all inside the timed region",
+                "gathered_payload": "per frame: n, n_matches, left keypoints [2000 x 28 B], left descriptors [2000 x 32 B], right_u and "
+                                    "depth [2000 x f64]",
+                "record_bytes": record_bytes(ctx.n_features), "gathered_bytes": int(F) * record_bytes(ctx.n_features),
+                "pairs_per_batch": B, "frames_rank0": n_local, "records_checked_against_host_path": checked,
+                "records_checked_for_repeat_consistency": max(0, F - min(U, F)),
+                "parallelism": f"frame_range blocks over {world} GPU(s)",
+            },
+            "roofline": None, "cpu_baseline": None,
+            "seconds": dt,
+        }
+    ctx.close()
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +239,11 @@ def main():
                          "~0.3 s of sustained load to leave its idle clocks (measured: first 30 steps 13 %% slower)")
     ap.add_argument("--pairs", type=int, default=512, help="stereo pairs per step (per GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--host-io-steps", type=int, default=-1, help="steps of the host_io leg (-1: as --steps, 0: skip)")
+    ap.add_argument("--sequence", type=int, default=0,
+                    help="run a whole sequence of this many stereo pairs (BASELINE config 4: 4541), sharded over the ranks, instead of the "
+                         "fixed-batch step loop")
+    ap.add_argument("--sequence-unique", type=int, default=64, help="distinct synthetic frames behind the sequence (frame f = f mod this)")
     ap.add_argument("--streams", type=int, default=1,
                     help="half-batch streams the library may split a batch over (1 = none, the library default and the fastest "
                          "setting measured; the blur-under-quadtree overlap inside a batch is independent of this)")
@@ -124,6 +284,14 @@ def main():
     os.environ["ORBFE_STREAMS"] = str(max(1, args.streams))
     from orb_slam2_ros2_amd import synth
     from orb_slam2_ros2_amd._lib import Context
+
+    if args.sequence > 0:
+        line = run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend)
+        if rank == 0:
+            print(json.dumps(line))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     B = args.pairs
     # synthetic frames of this rank's shard: rank r owns frames [r*B, (r+1)*B) of every step (weak scaling)
@@ -248,6 +416,11 @@ def main():
         verified = int(v.item())
     del kps_all, desc_all, ru_all, dp_all
 
+    host_io = None
+    hio_steps = args.steps if args.host_io_steps < 0 else args.host_io_steps
+    if hio_steps > 0:
+        host_io = host_io_leg(ctx, left_h, right_h, B, hio_steps, want, world, sync_all, dist, torch, xdev)
+
     live_ms, live_n = live[dom]
     stages_inline = dict(stages)
     if live_n:
@@ -271,6 +444,7 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "verified_pairs": verified,   # pairs of the last timed batch (all ranks) whose results equal the committed golden digests
+        "host_io": host_io,
         "config": {
             "workload": "Single 1241x376 KITTI-shaped stereo pair, 8-level pyramid, 2000 FAST+rBRIEF keypoints per image, "
                         "searchByStereo; batched",

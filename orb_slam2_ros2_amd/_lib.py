@@ -87,6 +87,10 @@ class MapBaReport(C.Structure):
                                                                            ("chi2_before", C.c_double), ("chi2_after", C.c_double)]
 
 
+class BatchResults(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("kps", "desc", "counts", "right_u", "depth", "n_matches")]
+
+
 class BaEdgeOut(C.Structure):
     _fields_ = [("error", C.c_void_p), ("chi2", C.c_void_p), ("rho", C.c_void_p), ("j_point", C.c_void_p),
                 ("j_pose", C.c_void_p), ("depth_positive", C.c_void_p)]
@@ -96,6 +100,7 @@ EXPORTS = [
     "orbfe_abi_version", "orbfe_create", "orbfe_destroy", "orbfe_last_error", "orbfe_get_level_info", "orbfe_get_scale_factors",
     "orbfe_get_capacity",
     "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_slot", "orbfe_fetch_batch", "orbfe_fetch_stereo_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
+    "orbfe_host_alloc", "orbfe_host_free", "orbfe_stream_submit", "orbfe_stream_wait", "orbfe_stream_device_results",
     "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_extract_color", "orbfe_frame_rgbd", "orbfe_project_map_points",
     "orbfe_map_pb_summary", "orbfe_map_pb_reencode", "orbfe_map_local_graph", "orbfe_map_local_ba",
     "orbfe_profile_enable", "orbfe_profile_read", "orbfe_stage_name", "orbfe_debug_candidates",
@@ -140,6 +145,13 @@ def load() -> C.CDLL:
     L.orbfe_stereo_match.argtypes = [vp, i32, i32, f32, f32, vp, vp, vp, vp, vp]
     L.orbfe_stereo_batch_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, i32, f32, f32]
     L.orbfe_sync.argtypes = [vp]
+    L.orbfe_host_alloc.argtypes = [C.c_size_t]
+    L.orbfe_host_alloc.restype = vp
+    L.orbfe_host_free.argtypes = [vp]
+    L.orbfe_host_free.restype = None
+    L.orbfe_stream_submit.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, i32, f32, f32, C.POINTER(BatchResults), C.POINTER(C.c_int64)]
+    L.orbfe_stream_wait.argtypes = [vp, C.c_int64]
+    L.orbfe_stream_device_results.argtypes = [vp, C.c_int64, i32] + [C.POINTER(vp)] * 6
     L.orbfe_fetch_features.argtypes = [vp, i32, vp, vp, vp]
     L.orbfe_fetch_stereo.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.orbfe_device_results.argtypes = [vp] + [C.POINTER(vp)] * 6
@@ -168,6 +180,31 @@ def load() -> C.CDLL:
 
 def ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class PinnedArray:
+    """numpy view of page-locked host memory from orbfe_host_alloc (freed with the object)"""
+
+    def __init__(self, shape, dtype):
+        self.lib = load()
+        self.dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * self.dtype.itemsize
+        self.p = self.lib.orbfe_host_alloc(max(n, 1))
+        if not self.p:
+            raise MemoryError(f"orbfe_host_alloc({n}) failed")
+        self.array = np.frombuffer((C.c_uint8 * max(n, 1)).from_address(self.p), dtype=self.dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if getattr(self, "p", None):
+            self.array = None
+            self.lib.orbfe_host_free(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 # ---- map.pb (host-only entry points: no context, no device) ------------------------------------------
@@ -340,6 +377,44 @@ class Context:
 
     def sync(self):
         self._check(self.lib.orbfe_sync(self.h))
+
+    # ---- host-image stream -----------------------------------------------------------------------
+    def alloc_batch_results(self, n_pairs, pinned=True):
+        """result arrays of one batch for stream_submit: dict of numpy arrays (page-locked unless pinned=False)"""
+        nf = max(self.n_features, 1)
+        spec = dict(kps=((2 * n_pairs, nf), KP_DTYPE), desc=((2 * n_pairs, nf, 32), np.uint8), counts=((2 * n_pairs,), np.int32),
+                    right_u=((n_pairs, nf), np.float64), depth=((n_pairs, nf), np.float64), n_matches=((n_pairs,), np.int32))
+        out, keep = {}, []
+        for k, (shape, dt) in spec.items():
+            if pinned:
+                pa = PinnedArray(shape, dt)
+                keep.append(pa)
+                out[k] = pa.array
+            else:
+                out[k] = np.zeros(shape, dt)
+        out["_pinned"] = keep
+        return out
+
+    def stream_submit(self, left, right, n_pairs, fx, bf, out, stride=None, image_pitch=None):
+        """left / right: uint8 arrays [n_pairs, H, W] (C-contiguous; page-locked for true overlap) -> ticket"""
+        stride = stride or self.width
+        image_pitch = image_pitch or stride * self.height
+        out = out or {}
+        res = BatchResults(*[out[k].ctypes.data if out.get(k) is not None else None
+                             for k in ("kps", "desc", "counts", "right_u", "depth", "n_matches")])
+        t = C.c_int64(-1)
+        self._check(self.lib.orbfe_stream_submit(self.h, left.ctypes.data, right.ctypes.data, stride, image_pitch, n_pairs, fx, bf,
+                                                 C.byref(res), C.byref(t)))
+        return t.value
+
+    def stream_wait(self, ticket):
+        self._check(self.lib.orbfe_stream_wait(self.h, ticket))
+
+    def stream_device_results(self, ticket, n_pairs):
+        """device pointers (ints) of the packed results of a live ticket: dict kps, desc, counts, right_u, depth, n_match"""
+        ps = [C.c_void_p(None) for _ in range(6)]
+        self._check(self.lib.orbfe_stream_device_results(self.h, ticket, n_pairs, *[C.byref(p) for p in ps]))
+        return dict(zip(["kps", "desc", "counts", "right_u", "depth", "n_match"], [p.value for p in ps]))
 
     def fetch_features(self, slot):
         nf = max(self.n_features, 1)

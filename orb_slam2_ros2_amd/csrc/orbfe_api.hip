@@ -132,6 +132,19 @@ struct orbfe_ctx {
     std::vector<GraphEntry> graphs;
     bool use_graphs = true;
   };
+  // Host-image stream (orbfe_stream_submit / _wait): batch k+1 is uploaded and the packed results of batch k-1 are downloaded while
+  // batch k is computed.  Two input and two result buffers on the device, one copy stream per direction.
+  struct HostStream {
+    bool init = false;
+    hipStream_t h2d = nullptr, d2h = nullptr;
+    uint8_t* d_in[2] = {nullptr, nullptr};   // [left images | right images] of one batch
+    size_t in_bytes = 0;
+    uint8_t* d_out[2] = {nullptr, nullptr};  // packed results of one batch: kps | desc | counts | right_u | depth | n_match
+    size_t out_bytes = 0;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_in_free[2] = {nullptr, nullptr}, ev_out_ready[2] = {nullptr, nullptr},
+               ev_done[2] = {nullptr, nullptr};
+    int64_t next_ticket = 0;
+  } hs;
   Lane main;
   std::vector<std::unique_ptr<Lane>> slot_lane;  // [max_images], entries created lazily under slot_lane_mu
   std::mutex slot_lane_mu;
@@ -702,19 +715,36 @@ const char* orbfe_stage_name(int32_t stage) {
 
 void orbfe_destroy(orbfe_ctx* c) {
   if (!c) return;
-  hipSetDevice(c->device);
+  (void)hipSetDevice(c->device);
+  // every stream that may still touch the buffers freed below
+  if (c->hs.h2d) (void)hipStreamSynchronize(c->hs.h2d);
+  for (auto& sl : c->slot_lane)
+    if (sl && sl->stream) (void)hipStreamSynchronize(sl->stream);
   if (c->stereo_stream) (void)hipStreamSynchronize(c->stereo_stream);
   if (c->blur_stream) (void)hipStreamSynchronize(c->blur_stream);
-  if (c->stream) hipStreamSynchronize(c->stream);
+  for (int k = 0; k < orbfe_ctx::kMaxSide; ++k)
+    if (c->side[k]) (void)hipStreamSynchronize(c->side[k]);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->hs.d2h) (void)hipStreamSynchronize(c->hs.d2h);
   drain_timers(c);
-  for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_rs_tiles, c->d_pattern, c->d_pyr,     c->d_blur,
                   c->d_scr_a, c->d_scr_c,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_kp,
                   c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos, c->d_kx, c->d_env, c->d_kpl,   c->d_right_u, c->d_depth, c->d_n_match,
                   c->d_best_right, c->d_best_dist, c->d_tmp};
   for (void* p : ptrs)
-    if (p) hipFree(p);
+    if (p) (void)hipFree(p);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
+  if (c->hs.h2d) (void)hipStreamSynchronize(c->hs.h2d);
+  if (c->hs.d2h) (void)hipStreamSynchronize(c->hs.d2h);
+  for (int b = 0; b < 2; ++b) {
+    if (c->hs.d_in[b]) (void)hipFree(c->hs.d_in[b]);
+    if (c->hs.d_out[b]) (void)hipFree(c->hs.d_out[b]);
+    for (hipEvent_t e : {c->hs.ev_h2d[b], c->hs.ev_in_free[b], c->hs.ev_out_ready[b], c->hs.ev_done[b]})
+      if (e) (void)hipEventDestroy(e);
+  }
+  if (c->hs.h2d) (void)hipStreamDestroy(c->hs.h2d);
+  if (c->hs.d2h) (void)hipStreamDestroy(c->hs.d2h);
   for (auto& sl : c->slot_lane)
     if (sl) {
       if (sl->stream) (void)hipStreamSynchronize(sl->stream);
@@ -1237,14 +1267,31 @@ orbfe_status orbfe_stereo_match(orbfe_ctx* c, int32_t slot_left, int32_t slot_ri
   return orbfe_fetch_stereo(c, pair, right_u, depth, n_matches, best_right, best_dist);
 }
 
-orbfe_status orbfe_stereo_batch_device(orbfe_ctx* c, const uint8_t* d_left, const uint8_t* d_right, size_t stride, size_t image_pitch,
-                                       int32_t n_pairs, float fx, float bf) {
-  if (!c || !d_left || !d_right || n_pairs < 0) return fail(c, ORBFE_EBADARG, "stereo_batch_device: NULL argument");
-  if (2 * n_pairs > c->cfg.max_images) return fail(c, ORBFE_ECAPACITY, "stereo_batch_device: %d pairs need %d slots > %d", n_pairs, 2 * n_pairs, c->cfg.max_images);
-  if (stride < (size_t)c->cfg.width || image_pitch < stride * (size_t)c->cfg.height)
-    return fail(c, ORBFE_EBADARG, "stereo_batch_device: stride/pitch too small");
-  if (n_pairs == 0) return ORBFE_OK;
-  HIP_TRY(c, hipSetDevice(c->device));
+// Where the packed results of a batch go on the device (host-image stream), and the events around that copy.
+struct PackDst {
+  uint8_t* base;
+  hipEvent_t wait_free;  // the buffer's previous contents have been downloaded
+  hipEvent_t ready;      // recorded once the results are in the buffer
+  hipEvent_t in_free;    // recorded once the input images have been consumed (level 0 of every pyramid written)
+};
+struct PackLayout {
+  size_t o_kps, o_desc, o_cnt, o_ru, o_dp, o_nm, total;
+};
+static PackLayout pack_layout(const orbfe_ctx* c, int n_pairs) {
+  const size_t NF = (size_t)std::max(c->cfg.n_features, 1), n = (size_t)n_pairs;
+  PackLayout l;
+  l.o_kps = 0;
+  l.o_desc = l.o_kps + align_up(2 * n * NF * sizeof(orbfe_keypoint), 256);
+  l.o_cnt = l.o_desc + align_up(2 * n * NF * 32, 256);
+  l.o_ru = l.o_cnt + align_up(2 * n * 4, 256);
+  l.o_dp = l.o_ru + align_up(n * NF * 8, 256);
+  l.o_nm = l.o_dp + align_up(n * NF * 8, 256);
+  l.total = l.o_nm + align_up(n * 4, 256);
+  return l;
+}
+
+static orbfe_status batch_device_core(orbfe_ctx* c, const uint8_t* d_left, const uint8_t* d_right, size_t stride, size_t image_pitch,
+                                      int32_t n_pairs, float fx, float bf, const PackDst* pack) {
   const LevelDev& L0 = c->lv[0];
   // The batch is cut into chunks that run on separate streams: the quadtree is latency-bound (one wave per
   // image level, a few hundred dependent steps) and leaves the machine almost idle, so the streaming kernels of the
@@ -1282,13 +1329,12 @@ orbfe_status orbfe_stereo_batch_device(orbfe_ctx* c, const uint8_t* d_left, cons
     // level 0 of slot 2p / 2p+1 <- left / right image p
     launch_load_level0(st, d_left + (size_t)p0 * image_pitch, d_right + (size_t)p0 * image_pitch, stride, image_pitch, c->d_pyr, c->img_pitch,
                        L0.plane_off, L0.stride, c->cfg.width, c->cfg.height, 2 * p0, 2, p1 - p0);
+    if (pack && pack->in_free && serial && k == n_chunks - 1) HIP_TRY(c, hipEventRecord(pack->in_free, st));  // the images may be overwritten
     TRY(run_extract(c, st, 2 * p0, 2 * (p1 - p0), serial ? 1 : n_chunks, (piped && c->stereo_pending) ? c->ev_stereo_done : nullptr));
     if (piped) {
       HIP_TRY(c, hipEventRecord(c->ev_brief_done, st));
       HIP_TRY(c, hipStreamWaitEvent(c->stereo_stream, c->ev_brief_done, 0));
       TRY(run_stereo(c, c->stereo_stream, 2 * p0, 2 * p0 + 1, 2, p0, p1 - p0, fx, bf));
-      HIP_TRY(c, hipEventRecord(c->ev_stereo_done, c->stereo_stream));
-      c->stereo_pending = true;
     } else {
       TRY(run_stereo(c, st, 2 * p0, 2 * p0 + 1, 2, p0, p1 - p0, fx, bf));
     }
@@ -1297,6 +1343,153 @@ orbfe_status orbfe_stereo_batch_device(orbfe_ctx* c, const uint8_t* d_left, cons
       HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join[k], 0));
     }
   }
+  if (pack) {
+    // the packed results of this batch -> the stream's result buffer (device to device: ~0.1 ms for 512 pairs), on the stream the
+    // match ran on, BEFORE the next batch may rewrite the per-slot arrays; the download then runs beside the next batch
+    hipStream_t ps = piped ? c->stereo_stream : c->stream;
+    if (pack->in_free && !serial) HIP_TRY(c, hipEventRecord(pack->in_free, c->stream));
+    const PackLayout l = pack_layout(c, n_pairs);
+    const size_t NF = (size_t)std::max(c->cfg.n_features, 1), n = (size_t)n_pairs;
+    HIP_TRY(c, hipStreamWaitEvent(ps, pack->wait_free, 0));
+    HIP_TRY(c, hipMemcpyAsync(pack->base + l.o_kps, c->d_kps, 2 * n * NF * sizeof(orbfe_keypoint), hipMemcpyDeviceToDevice, ps));
+    HIP_TRY(c, hipMemcpyAsync(pack->base + l.o_desc, c->d_desc, 2 * n * NF * 32, hipMemcpyDeviceToDevice, ps));
+    HIP_TRY(c, hipMemcpyAsync(pack->base + l.o_cnt, c->d_n_kp, 2 * n * 4, hipMemcpyDeviceToDevice, ps));
+    HIP_TRY(c, hipMemcpyAsync(pack->base + l.o_ru, c->d_right_u, n * NF * 8, hipMemcpyDeviceToDevice, ps));
+    HIP_TRY(c, hipMemcpyAsync(pack->base + l.o_dp, c->d_depth, n * NF * 8, hipMemcpyDeviceToDevice, ps));
+    HIP_TRY(c, hipMemcpyAsync(pack->base + l.o_nm, c->d_n_match, n * 4, hipMemcpyDeviceToDevice, ps));
+    HIP_TRY(c, hipEventRecord(pack->ready, ps));
+  }
+  if (piped) {
+    HIP_TRY(c, hipEventRecord(c->ev_stereo_done, c->stereo_stream));
+    c->stereo_pending = true;
+  }
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_stereo_batch_device(orbfe_ctx* c, const uint8_t* d_left, const uint8_t* d_right, size_t stride, size_t image_pitch,
+                                       int32_t n_pairs, float fx, float bf) {
+  if (!c || !d_left || !d_right || n_pairs < 0) return fail(c, ORBFE_EBADARG, "stereo_batch_device: NULL argument");
+  if (2 * n_pairs > c->cfg.max_images) return fail(c, ORBFE_ECAPACITY, "stereo_batch_device: %d pairs need %d slots > %d", n_pairs, 2 * n_pairs, c->cfg.max_images);
+  if (stride < (size_t)c->cfg.width || image_pitch < stride * (size_t)c->cfg.height)
+    return fail(c, ORBFE_EBADARG, "stereo_batch_device: stride/pitch too small");
+  if (n_pairs == 0) return ORBFE_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  return batch_device_core(c, d_left, d_right, stride, image_pitch, n_pairs, fx, bf, nullptr);
+}
+
+// ---- host-image stream ---------------------------------------------------------------------------------------------------------
+void* orbfe_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+void orbfe_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
+orbfe_status orbfe_stream_submit(orbfe_ctx* c, const uint8_t* left, const uint8_t* right, size_t stride, size_t image_pitch, int32_t n_pairs,
+                                 float fx, float bf, const orbfe_batch_results* out, int64_t* ticket) {
+  if (!c || !left || !right || !out || !ticket || n_pairs <= 0) return fail(c, ORBFE_EBADARG, "stream_submit: NULL argument / no pairs");
+  if (2 * n_pairs > c->cfg.max_images) return fail(c, ORBFE_ECAPACITY, "stream_submit: %d pairs need %d slots > %d", n_pairs, 2 * n_pairs, c->cfg.max_images);
+  if (stride < (size_t)c->cfg.width || image_pitch < stride * (size_t)c->cfg.height)
+    return fail(c, ORBFE_EBADARG, "stream_submit: stride/pitch too small");
+  HIP_TRY(c, hipSetDevice(c->device));
+  orbfe_ctx::HostStream& hs = c->hs;
+  if (!hs.init) {
+    HIP_TRY(c, hipStreamCreateWithFlags(&hs.h2d, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&hs.d2h, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+      HIP_TRY(c, hipEventCreateWithFlags(&hs.ev_h2d[b], hipEventDisableTiming));
+      HIP_TRY(c, hipEventCreateWithFlags(&hs.ev_in_free[b], hipEventDisableTiming));
+      HIP_TRY(c, hipEventCreateWithFlags(&hs.ev_out_ready[b], hipEventDisableTiming));
+      HIP_TRY(c, hipEventCreateWithFlags(&hs.ev_done[b], hipEventDisableTiming));
+    }
+    hs.init = true;
+  }
+  const size_t eye = image_pitch * (size_t)n_pairs;
+  const PackLayout l = pack_layout(c, n_pairs);
+  if (2 * eye > hs.in_bytes || l.total > hs.out_bytes) {  // (re)size the device buffers: quiesce everything first
+    TRY(join_stereo(c));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(hs.h2d));
+    HIP_TRY(c, hipStreamSynchronize(hs.d2h));
+    const size_t in_bytes = std::max(hs.in_bytes, align_up(2 * eye, 1 << 20));
+    const PackLayout lmax = pack_layout(c, c->cfg.max_images / 2);
+    const size_t out_bytes = std::max(hs.out_bytes, lmax.total);
+    for (int b = 0; b < 2; ++b) {
+      if (in_bytes != hs.in_bytes) {
+        if (hs.d_in[b]) HIP_TRY(c, hipFree(hs.d_in[b]));
+        hs.d_in[b] = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&hs.d_in[b], in_bytes));
+      }
+      if (out_bytes != hs.out_bytes) {
+        if (hs.d_out[b]) HIP_TRY(c, hipFree(hs.d_out[b]));
+        hs.d_out[b] = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&hs.d_out[b], out_bytes));
+      }
+    }
+    hs.in_bytes = in_bytes;
+    hs.out_bytes = out_bytes;
+  }
+  const int b = (int)(hs.next_ticket & 1);
+  // the ticket that last used this pair of buffers must have been collected: its `out` arrays and its images are the caller's again
+  // only then, and "at most two outstanding" is what makes two buffers enough
+  if (hs.next_ticket >= 2 && hipEventQuery(hs.ev_done[b]) != hipSuccess) {
+    (void)hipGetLastError();
+    HIP_TRY(c, hipEventSynchronize(hs.ev_done[b]));
+  }
+  // upload: after the batch that last read this input buffer has consumed it
+  HIP_TRY(c, hipStreamWaitEvent(hs.h2d, hs.ev_in_free[b], 0));
+  HIP_TRY(c, hipMemcpyAsync(hs.d_in[b], left, eye, hipMemcpyHostToDevice, hs.h2d));
+  HIP_TRY(c, hipMemcpyAsync(hs.d_in[b] + eye, right, eye, hipMemcpyHostToDevice, hs.h2d));
+  HIP_TRY(c, hipEventRecord(hs.ev_h2d[b], hs.h2d));
+  // compute: the device-batch schedule, results packed into this ticket's result buffer
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, hs.ev_h2d[b], 0));
+  const PackDst pack = {hs.d_out[b], hs.ev_done[b], hs.ev_out_ready[b], hs.ev_in_free[b]};
+  TRY(batch_device_core(c, hs.d_in[b], hs.d_in[b] + eye, stride, image_pitch, n_pairs, fx, bf, &pack));
+  // download
+  const size_t NF = (size_t)std::max(c->cfg.n_features, 1), n = (size_t)n_pairs;
+  HIP_TRY(c, hipStreamWaitEvent(hs.d2h, hs.ev_out_ready[b], 0));
+  const uint8_t* src = hs.d_out[b];
+  if (out->kps) HIP_TRY(c, hipMemcpyAsync(out->kps, src + l.o_kps, 2 * n * NF * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, hs.d2h));
+  if (out->desc) HIP_TRY(c, hipMemcpyAsync(out->desc, src + l.o_desc, 2 * n * NF * 32, hipMemcpyDeviceToHost, hs.d2h));
+  if (out->counts) HIP_TRY(c, hipMemcpyAsync(out->counts, src + l.o_cnt, 2 * n * 4, hipMemcpyDeviceToHost, hs.d2h));
+  if (out->right_u) HIP_TRY(c, hipMemcpyAsync(out->right_u, src + l.o_ru, n * NF * 8, hipMemcpyDeviceToHost, hs.d2h));
+  if (out->depth) HIP_TRY(c, hipMemcpyAsync(out->depth, src + l.o_dp, n * NF * 8, hipMemcpyDeviceToHost, hs.d2h));
+  if (out->n_matches) HIP_TRY(c, hipMemcpyAsync(out->n_matches, src + l.o_nm, n * 4, hipMemcpyDeviceToHost, hs.d2h));
+  HIP_TRY(c, hipEventRecord(hs.ev_done[b], hs.d2h));
+  *ticket = hs.next_ticket++;
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_stream_wait(orbfe_ctx* c, int64_t ticket) {
+  if (!c) return ORBFE_EBADARG;
+  orbfe_ctx::HostStream& hs = c->hs;
+  if (!hs.init || ticket < 0 || ticket >= hs.next_ticket) return fail(c, ORBFE_EBADARG, "stream_wait: ticket %lld was never issued", (long long)ticket);
+  if (ticket + 2 < hs.next_ticket) return ORBFE_OK;  // its buffers have been re-used since: that download finished long ago
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipEventSynchronize(hs.ev_done[ticket & 1]));
+  return ORBFE_OK;
+}
+
+orbfe_status orbfe_stream_device_results(orbfe_ctx* c, int64_t ticket, int32_t n_pairs, const void** d_kps, const void** d_desc,
+                                         const void** d_counts, const void** d_right_u, const void** d_depth, const void** d_nmatch) {
+  if (!c) return ORBFE_EBADARG;
+  orbfe_ctx::HostStream& hs = c->hs;
+  if (!hs.init || ticket < 0 || ticket >= hs.next_ticket || ticket + 2 < hs.next_ticket || n_pairs <= 0 || 2 * n_pairs > c->cfg.max_images)
+    return fail(c, ORBFE_EBADARG, "stream_device_results: ticket %lld is not live (next %lld) or bad pair count %d", (long long)ticket,
+                (long long)hs.next_ticket, n_pairs);
+  const PackLayout l = pack_layout(c, n_pairs);
+  const uint8_t* b = hs.d_out[ticket & 1];
+  if (d_kps) *d_kps = b + l.o_kps;
+  if (d_desc) *d_desc = b + l.o_desc;
+  if (d_counts) *d_counts = b + l.o_cnt;
+  if (d_right_u) *d_right_u = b + l.o_ru;
+  if (d_depth) *d_depth = b + l.o_dp;
+  if (d_nmatch) *d_nmatch = b + l.o_nm;
   return ORBFE_OK;
 }
 

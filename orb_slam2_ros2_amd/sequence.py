@@ -1,0 +1,136 @@
+"""Sequence-level driver: the loop of example/Stereo/KittiStereo.cc:28-37 over F stereo pairs, cut into contiguous blocks per rank
+(sharding.frame_range), each rank working through its block in batches, and ONE exchange at the end: the per-frame records of every
+rank gathered on rank 0 (sharding.gather_frames; RCCL on the GPUs, gloo in the CPU tests).
+
+A frame record is what Frame::createStereo leaves behind for the tracker -- left keypoints, left descriptors, right_u, depth and the
+counts -- padded to n_features so that every frame has the same size:
+
+    int32 n_keypoints | int32 n_matches | 8 bytes pad | kps [NF] x 28 B | desc [NF] x 32 B | right_u [NF] f64 | depth [NF] f64
+"""
+from __future__ import annotations
+
+from typing import Callable, Sequence
+
+import numpy as np
+
+from .sharding import frame_range, gather_frames
+
+KP_BYTES, DESC_BYTES, HEAD_BYTES = 28, 32, 16
+
+
+def record_bytes(n_features: int) -> int:
+    return HEAD_BYTES + n_features * (KP_BYTES + DESC_BYTES + 8 + 8)
+
+
+def pack_records(kps, desc, counts, right_u, depth, n_matches):
+    """Packed batch results -> uint8 records [n_pairs, record_bytes] (torch tensors in, on whatever device they live on).
+
+    kps: uint8 [2P, NF, 28], desc: uint8 [2P, NF, 32], counts: int32 [2P], right_u / depth: float64 [P, NF], n_matches: int32 [P].
+    Only the LEFT image's features go into a record (slots 2p); entries past the count are zeroed so that records are canonical."""
+    import torch
+    P, NF = right_u.shape[0], right_u.shape[1]
+    rec = torch.zeros((P, record_bytes(NF)), dtype=torch.uint8, device=kps.device)
+    if P == 0:
+        return rec
+    n = counts[0::2].to(torch.int32)
+    head = torch.stack([n, n_matches.to(torch.int32), torch.zeros_like(n), torch.zeros_like(n)], dim=1).contiguous()
+    rec[:, :HEAD_BYTES] = head.view(torch.uint8).reshape(P, HEAD_BYTES)
+    live = (torch.arange(NF, device=kps.device)[None, :] < n[:, None])          # [P, NF]
+    o = HEAD_BYTES
+    rec[:, o:o + NF * KP_BYTES] = (kps[0::2] * live[:, :, None]).reshape(P, NF * KP_BYTES)
+    o += NF * KP_BYTES
+    rec[:, o:o + NF * DESC_BYTES] = (desc[0::2] * live[:, :, None]).reshape(P, NF * DESC_BYTES)
+    o += NF * DESC_BYTES
+    rec[:, o:o + NF * 8] = (right_u.contiguous().view(torch.uint8).reshape(P, NF, 8) * live[:, :, None]).reshape(P, NF * 8)
+    o += NF * 8
+    rec[:, o:o + NF * 8] = (depth.contiguous().view(torch.uint8).reshape(P, NF, 8) * live[:, :, None]).reshape(P, NF * 8)
+    return rec
+
+
+def unpack_record(rec: np.ndarray, n_features: int) -> dict:
+    """One record (uint8 [record_bytes]) -> dict(n, n_matches, kps, desc, right_u, depth) trimmed to n keypoints."""
+    from ._lib import KP_DTYPE
+    rec = np.ascontiguousarray(rec, np.uint8)
+    n, nm = (int(v) for v in rec[:8].view(np.int32))
+    o = HEAD_BYTES
+    kps = rec[o:o + n_features * KP_BYTES].view(KP_DTYPE)[:n]
+    o += n_features * KP_BYTES
+    desc = rec[o:o + n_features * DESC_BYTES].reshape(n_features, 32)[:n]
+    o += n_features * DESC_BYTES
+    ru = rec[o:o + n_features * 8].view(np.float64)[:n]
+    o += n_features * 8
+    dp = rec[o:o + n_features * 8].view(np.float64)[:n]
+    return dict(n=n, n_matches=nm, kps=kps, desc=desc, right_u=ru, depth=dp)
+
+
+def run_sequence(n_frames: int, rank: int, world: int, batch_pairs: int, submit: Callable[[Sequence[int]], object],
+                 collect: Callable[[object], "object"], depth: int = 2, dst: int = 0):
+    """Process this rank's block of the sequence in batches of <= batch_pairs frames, `depth` batches in flight, and gather all
+    records on `dst`.
+
+    submit(frame_ids) -> handle starts a batch (host images -> device, extraction, stereo match); collect(handle) -> uint8 tensor
+    [len(frame_ids), record_bytes] on the device the collective runs on, in frame order.  Batches are collected in submission order.
+    Returns (records [n_frames, record_bytes] on dst / None elsewhere, number of frames this rank processed)."""
+    import torch
+    b, e = frame_range(n_frames, rank, world)
+    chunks, flight = [], []
+    for s in range(b, e, max(1, batch_pairs)):
+        flight.append(submit(range(s, min(e, s + batch_pairs))))
+        if len(flight) >= max(1, depth):
+            chunks.append(collect(flight.pop(0)))
+    while flight:
+        chunks.append(collect(flight.pop(0)))
+    if chunks:
+        local = torch.cat(chunks, dim=0) if len(chunks) > 1 else chunks[0]
+    else:  # an empty block (more ranks than frames): shape and device from a zero-frame batch
+        local = collect(submit(range(0, 0)))[:0]
+    return gather_frames(local, n_frames, rank, world, dst), e - b
+
+
+class DeviceSequenceProcessor:
+    """submit / collect for run_sequence on one GPU: host images -> orbfe_stream_submit (upload overlapped with the compute of the
+    batch before) -> records packed ON THE DEVICE from the stream's result buffers (no download), ready for the RCCL gather.
+
+    make_pair(frame_id) -> (left, right) uint8 images; prepare() builds the page-locked batch buffers of this rank's frames before
+    the clock starts (a camera driver or an image decoder would write there directly)."""
+
+    def __init__(self, ctx, make_pair, batch_pairs, fx, bf, device):
+        self.ctx, self.make_pair, self.batch, self.fx, self.bf, self.device = ctx, make_pair, batch_pairs, fx, bf, device
+        self.pinned = {}
+
+    def prepare(self, frame_ids):
+        from ._lib import PinnedArray
+        ids = list(frame_ids)
+        H, W = self.ctx.height, self.ctx.width
+        cache = {}
+        for s in range(0, len(ids), self.batch):
+            chunk = ids[s:s + self.batch]
+            l, r = PinnedArray((len(chunk), H, W), np.uint8), PinnedArray((len(chunk), H, W), np.uint8)
+            for i, f in enumerate(chunk):
+                if f not in cache and len(cache) < 256:
+                    cache[f] = self.make_pair(f)
+                l.array[i], r.array[i] = cache[f] if f in cache else self.make_pair(f)
+            self.pinned[(chunk[0], len(chunk))] = (l, r)
+
+    def submit(self, frame_ids):
+        ids = list(frame_ids)
+        if not ids:
+            return None
+        key = (ids[0], len(ids))
+        if key not in self.pinned:
+            self.prepare(ids)
+        l, r = self.pinned[key]
+        return (self.ctx.stream_submit(l.array, r.array, len(ids), self.fx, self.bf, None), len(ids))
+
+    def collect(self, handle):
+        import torch
+        from .torch_views import batch_result_views
+        nf = self.ctx.n_features
+        if handle is None:
+            return torch.zeros((0, record_bytes(nf)), dtype=torch.uint8, device=self.device)
+        ticket, n = handle
+        self.ctx.stream_wait(ticket)   # the packed results of this ticket are in the stream's device buffer
+        views = batch_result_views(self.ctx.stream_device_results(ticket, n), n, nf, self.device)
+        rec = pack_records(*views)
+        torch.cuda.current_stream(self.device).synchronize()   # the buffer may be re-used by the submit after next
+        return rec

@@ -69,3 +69,82 @@ def test_two_rank_gather_equals_single_process_sequence(n_frames):
     ref = _records(range(n_frames)).numpy()
     assert got.shape == ref.shape and np.array_equal(got, ref)
     assert (got[:, 0, 0] > 0).all()
+
+
+# ---- the sequence driver bench.py --sequence uses (orb_slam2_ros2_amd/sequence.py), world size 2 over gloo ---------------------------
+NF_SMALL = 100
+
+
+def _small_frame_processor():
+    """submit / collect for run_sequence on the CPU: the oracle produces a frame's results on small images, packed with the same
+    pack_records the device path uses (CPU tensors, so gloo can gather them)."""
+    import torch
+    from oracle.pyoracle import Oracle
+    from orb_slam2_ros2_amd import synth
+    from orb_slam2_ros2_amd._lib import KP_DTYPE
+    from orb_slam2_ros2_amd.sequence import pack_records
+    orc = Oracle()
+
+    def submit(frame_ids):
+        return list(frame_ids)
+
+    def collect(ids):
+        P = len(ids)
+        kps = np.zeros((2 * P, NF_SMALL), KP_DTYPE)
+        desc = np.zeros((2 * P, NF_SMALL, 32), np.uint8)
+        cnt = np.zeros(2 * P, np.int32)
+        ru = np.full((P, NF_SMALL), -1.0)
+        dp = np.full((P, NF_SMALL), -1.0)
+        nm = np.zeros(P, np.int32)
+        for i, f in enumerate(ids):
+            L, R = synth.stereo_pair(f, 320, 200, n_rect=60)
+            r = orc.stereo_frame(L, R, n_features=NF_SMALL, n_levels=3, fx=300.0, bf=120.0)
+            nl, nr = len(r["lk"]), len(r["rk"])
+            kps[2 * i, :nl], desc[2 * i, :nl], kps[2 * i + 1, :nr], desc[2 * i + 1, :nr] = r["lk"], r["ld"], r["rk"], r["rd"]
+            kps[2 * i, nl:]["x"] = 123.0   # stale entries past the count, as the device arrays hold them: a record must not carry them
+            cnt[2 * i], cnt[2 * i + 1], nm[i] = nl, nr, r["n_matches"]
+            ru[i, :nl], dp[i, :nl] = r["right_u"], r["depth"]
+        t = torch.from_numpy
+        return pack_records(t(kps.view(np.uint8).reshape(2 * P, NF_SMALL, 28)), t(desc), t(cnt), t(ru), t(dp), t(nm))
+    return submit, collect
+
+
+def _seq_worker(rank, world, port, n_frames, batch, q):
+    import torch.distributed as dist
+    from orb_slam2_ros2_amd.sequence import run_sequence
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    submit, collect = _small_frame_processor()
+    rec, n_local = run_sequence(n_frames, rank, world, batch, submit, collect)
+    if rank == 0:
+        q.put((rec.numpy(), n_local))
+    else:
+        assert rec is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames,batch", [(7, 2), (1, 4)])
+def test_sequence_driver_two_ranks_equals_one_rank(n_frames, batch):
+    """run_sequence (frame_range per rank, batches in flight, the gather of the per-frame RECORDS) with two gloo ranks against the same
+    function with one; n_frames = 1 leaves rank 1 with an empty block."""
+    import torch.multiprocessing as mp
+    from orb_slam2_ros2_amd.sequence import record_bytes, run_sequence, unpack_record
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seq_worker, args=(r, 2, port, n_frames, batch, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, n0 = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    submit, collect = _small_frame_processor()
+    ref, n_all = run_sequence(n_frames, 0, 1, batch, submit, collect)
+    ref = ref.numpy()
+    assert n_all == n_frames and n0 == (n_frames + 1) // 2
+    assert got.shape == ref.shape == (n_frames, record_bytes(NF_SMALL)) and np.array_equal(got, ref)
+    u = unpack_record(got[0], NF_SMALL)
+    assert u["n"] > 10 and (u["kps"]["size"] == 7).all() and u["n_matches"] == int((u["right_u"] >= 0).sum())

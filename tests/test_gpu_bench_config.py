@@ -47,6 +47,7 @@ def test_bench_batch_of_512_pairs_equals_the_oracle(orc):
     assert all(dig[p] == G["bench_pairs"][str(p % U)] for p in range(B))
     # the per-level FAST candidate sets of a slot deep in the batch (global-record quadtree input), frame 13
     ex = orc.extractor(frames[13][0])
+    ex.extract()
     slot = 2 * (13 + 16 * 20)
     for l in range(8):
         assert np.array_equal(ctx.debug_candidates(slot, l), ex.candidates(l)), f"level {l} candidates of slot {slot}"

@@ -1,0 +1,118 @@
+"""GPU tests of the host-image stream (orbfe_stream_submit / _wait): batches from host memory, results to host memory, three
+batches in flight at different stages -- every pair against the committed digests (tests/golden/golden_v1.json, made by the oracle) --
+and of the sequence driver on top of it."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from orb_slam2_ros2_amd import synth
+from orb_slam2_ros2_amd.digest import batch_digests, pair_digest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v1.json")))["bench_pairs"]
+FX, BF = 718.856, 718.856 * 0.537166
+W, H = 1241, 376
+
+
+def _batches(n_batches, n_pairs, pinned):
+    """batch k holds frames k, k+1, ... (mod 32): every batch differs from its neighbours"""
+    from orb_slam2_ros2_amd._lib import PinnedArray
+    frames = {f: synth.stereo_pair(f) for f in range(32)}
+    ids, bufs = [], []
+    for k in range(n_batches):
+        fid = [(3 * k + i) % 32 for i in range(n_pairs)]
+        if pinned:
+            l, r = PinnedArray((n_pairs, H, W), np.uint8), PinnedArray((n_pairs, H, W), np.uint8)
+            la, ra = l.array, r.array
+        else:
+            l = r = None
+            la, ra = np.zeros((n_pairs, H, W), np.uint8), np.zeros((n_pairs, H, W), np.uint8)
+        for i, f in enumerate(fid):
+            la[i], ra[i] = frames[f]
+        ids.append(fid)
+        bufs.append((la, ra, l, r))
+    return ids, bufs
+
+
+@pytest.mark.parametrize("n_pairs,pinned", [(24, True), (24, False), (5, True)])
+def test_stream_batches_equal_golden_digests(n_pairs, pinned):
+    from orb_slam2_ros2_amd._lib import Context
+    n_batches = 7
+    ids, bufs = _batches(n_batches, n_pairs, pinned)
+    ctx = Context(W, H, max_images=2 * n_pairs)
+    outs = [ctx.alloc_batch_results(n_pairs, pinned) for _ in range(2)]
+    tickets = []
+
+    def check(k):
+        ctx.stream_wait(tickets[k])
+        o = outs[k % 2]
+        dig = batch_digests(o["kps"], o["desc"], o["counts"], o["right_u"], o["depth"], o["n_matches"])
+        bad = [i for i in range(n_pairs) if dig[i] != GOLD[str(ids[k][i])]]
+        assert not bad, f"batch {k}: pairs {bad} differ"
+
+    for k in range(n_batches):
+        if k >= 2:
+            check(k - 2)           # its result arrays are about to be handed to batch k
+        la, ra = bufs[k][0], bufs[k][1]
+        tickets.append(ctx.stream_submit(la, ra, n_pairs, FX, BF, outs[k % 2]))
+    check(n_batches - 2)
+    check(n_batches - 1)
+    assert tickets == list(range(n_batches))
+    # the slots hold the newest batch; the other entry points see a quiesced context
+    lk, ld = ctx.fetch_features(0)
+    rk, rd = ctx.fetch_features(1)
+    nm, ru, dp, _, _ = ctx.fetch_stereo(0)
+    assert pair_digest(lk, ld, rk, rd, ru, dp, nm) == GOLD[str(ids[-1][0])]
+    # a device batch and a host-pointer call after the stream
+    (k0, d0), (k1, d1) = ctx.extract_batch(list(synth.stereo_pair(4)))
+    m, r, d, _, _ = ctx.stereo_match(0, 1, FX, BF)
+    assert pair_digest(k0, d0, k1, d1, r, d, m) == GOLD["4"]
+    ctx.close()
+
+
+def test_stream_argument_checks():
+    from orb_slam2_ros2_amd import _lib
+    ctx = _lib.Context(W, H, max_images=4)
+    l = np.zeros((2, H, W), np.uint8)
+    with pytest.raises(_lib.OrbfeError) as ei:
+        ctx.stream_submit(l, l, 3, FX, BF, {})          # 3 pairs need 6 slots
+    assert ei.value.status == 4
+    with pytest.raises(_lib.OrbfeError):
+        ctx.stream_wait(0)                              # never issued
+    with pytest.raises(_lib.OrbfeError):
+        ctx.stream_submit(l, l, 2, FX, BF, {}, stride=100)
+    ctx.close()
+
+
+def test_sequence_driver_on_the_device_equals_golden():
+    """sequence.run_sequence with the device processor bench.py uses (world size 1): 70 frames in batches of 16 + a ragged tail, records
+    packed on the device from the stream's result buffers; every record against the digest of its frame."""
+    import torch
+    from orb_slam2_ros2_amd._lib import Context
+    from orb_slam2_ros2_amd.sequence import DeviceSequenceProcessor, record_bytes, run_sequence, unpack_record
+    n_frames, batch = 70, 16
+    ctx = Context(W, H, max_images=2 * batch)
+    proc = DeviceSequenceProcessor(ctx, lambda f: synth.stereo_pair(f % 32), batch, FX, BF, torch.device("cuda", 0))
+    proc.prepare(range(n_frames))
+    rec, n_local = run_sequence(n_frames, 0, 1, batch, proc.submit, proc.collect)
+    assert n_local == n_frames and tuple(rec.shape) == (n_frames, record_bytes(ctx.n_features))
+    rec = rec.cpu().numpy()
+    ref = {}
+    for f in range(n_frames):
+        u = unpack_record(rec[f], ctx.n_features)
+        if f % 32 not in ref:
+            # the right image's features are not part of a record: compare the left half + stereo outputs with the oracle-made fixture
+            # through a full fetch of the same frame on the host-pointer path
+            (lk, ld), (rk, rd) = ctx.extract_batch(list(synth.stereo_pair(f % 32)))
+            m, r, d, _, _ = ctx.stereo_match(0, 1, FX, BF)
+            assert pair_digest(lk, ld, rk, rd, r, d, m) == GOLD[str(f % 32)]
+            ref[f % 32] = (lk, ld, r[:len(lk)], d[:len(lk)], m)
+        lk, ld, r, d, m = ref[f % 32]
+        assert u["n"] == len(lk) and u["n_matches"] == m
+        assert np.array_equal(u["kps"], lk) and np.array_equal(u["desc"], ld)
+        assert np.array_equal(u["right_u"], r) and np.array_equal(u["depth"], d)
+    ctx.close()
