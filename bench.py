@@ -70,38 +70,55 @@ def spawn_ranks(n: int) -> int:
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0 or "")
+    # poll: when one rank dies (a missing GPU, a failed rendezvous) the others would wait in the collective init for ever -- end them
+    import threading
+    buf = []
+    rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            time.sleep(2.0)   # let the others fail by themselves with their own message first
+            for r, p in enumerate(procs):
+                if p.poll() is None:
+                    p.kill()   # exactly the children started above
+            rcs = [p.wait() for p in procs]
+            break
+        time.sleep(0.05)
+    rd.join(timeout=10)
+    sys.stdout.write("".join(x or "" for x in buf))
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
         print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
-        return max(1, max(abs(rc) for _, rc in bad) & 0xFF)
+        return 1
     return 0
 
 
 def host_io_leg(ctx, left_h, right_h, B, steps, want, world, sync_all, dist, torch, xdev):
     """The step fed from page-locked host memory, results delivered to page-locked host memory (transfers included).
-    Two input buffers and two result sets alternate; at most two batches are outstanding."""
+    Three input buffers and three result sets rotate: batch k-2 is collected after batch k has been submitted."""
     from orb_slam2_ros2_amd._lib import PinnedArray
     from orb_slam2_ros2_amd.digest import batch_digests
     pins = []
-    for _ in range(2):
+    for _ in range(3):
         l, r = PinnedArray(left_h.shape, np.uint8), PinnedArray(right_h.shape, np.uint8)
         l.array[...] = left_h
         r.array[...] = right_h
         pins.append((l, r))
-    outs = [ctx.alloc_batch_results(B, pinned=True) for _ in range(2)]
+    outs = [ctx.alloc_batch_results(B, pinned=True) for _ in range(3)]
 
     def run(n):
-        last = None
+        tickets = []
         for k in range(n):
-            t = ctx.stream_submit(pins[k % 2][0].array, pins[k % 2][1].array, B, FX, BF, outs[k % 2])
-            if last is not None:
-                ctx.stream_wait(last)
-            last = t
-        ctx.stream_wait(last)
+            tickets.append(ctx.stream_submit(pins[k % 3][0].array, pins[k % 3][1].array, B, FX, BF, outs[k % 3]))
+            if k >= 2:
+                ctx.stream_wait(tickets[k - 2])
+        for t in tickets[-2:]:
+            ctx.stream_wait(t)
     run(4)
     sync_all()
     t0 = time.perf_counter()
@@ -113,7 +130,7 @@ def host_io_leg(ctx, left_h, right_h, B, steps, want, world, sync_all, dist, tor
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ok = 0
-    for o in outs:   # the last two batches, as delivered to the host
+    for o in outs:   # the last three batches, as delivered to the host
         dig = batch_digests(o["kps"], o["desc"], o["counts"], o["right_u"], o["depth"], o["n_matches"])
         bad = [p for p in range(B) if want[p] is not None and dig[p] != want[p]]
         if bad:

@@ -136,10 +136,10 @@ orbfe_status orbfe_sync(orbfe_ctx* ctx);
 
 /* ---- whole stereo pairs from HOST memory, copies overlapped with compute ------------------------
  * The loop of example/Stereo/KittiStereo.cc:28-37 (imread x2 -> Frame::createStereo) as a three-stage pipeline over batches: while
- * batch k is computed, batch k+1 is uploaded and the packed results of batch k-1 are downloaded (two input and two result buffers
+ * batch k is computed, batch k+1 is uploaded and the packed results of batch k-1 are downloaded (three input and three result buffers
  * on the device, one copy stream per direction).  left / right: n_pairs images each, image p at base + p * image_pitch_bytes, rows
  * stride_bytes apart.  orbfe_stream_submit returns at once with a ticket; the images must stay untouched, and `out` is not
- * valid, until orbfe_stream_wait(ticket) has returned.  At most TWO tickets may be outstanding.  Host memory from
+ * valid, until orbfe_stream_wait(ticket) has returned.  At most THREE tickets may be outstanding (a fourth submit waits for the oldest).  Host memory from
  * orbfe_host_alloc (page-locked) makes both copies asynchronous DMA; ordinary memory works but the runtime stages it and the
  * overlap is lost.  The slots of the context hold the results of the newest submitted batch (pair p in slots 2p / 2p+1).
  * `out` arrays: kps [2 n_pairs][n_features], desc [2 n_pairs][n_features][32], counts [2 n_pairs] (slot order); right_u / depth
@@ -159,7 +159,7 @@ orbfe_status orbfe_stream_submit(orbfe_ctx* ctx, const uint8_t* left, const uint
                                  int64_t* ticket);
 orbfe_status orbfe_stream_wait(orbfe_ctx* ctx, int64_t ticket);
 /* Device pointers of the packed results of `ticket` (same arrays and strides as orbfe_batch_results), for consumers that stay on
- * the device (a gather over RCCL): complete once orbfe_stream_wait(ticket) has returned, valid until ticket + 2 is submitted.      */
+ * the device (a gather over RCCL): complete once orbfe_stream_wait(ticket) has returned, valid until ticket + 3 is submitted.      */
 orbfe_status orbfe_stream_device_results(orbfe_ctx* ctx, int64_t ticket, int32_t n_pairs, const void** d_kps, const void** d_desc,
                                          const void** d_counts, const void** d_right_u, const void** d_depth, const void** d_nmatch);
 /* Fetch the results of slot (keypoints/descriptors) and, for a left slot, of its pair. Any pointer may be NULL. */

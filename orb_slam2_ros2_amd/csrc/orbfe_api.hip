@@ -135,14 +135,18 @@ struct orbfe_ctx {
   // Host-image stream (orbfe_stream_submit / _wait): batch k+1 is uploaded and the packed results of batch k-1 are downloaded while
   // batch k is computed.  Two input and two result buffers on the device, one copy stream per direction.
   struct HostStream {
+    // Ring depth 3: with two buffers the caller's "collect k-1, then submit k+1" makes the upload of k+1 wait for the DOWNLOAD of
+    // k-1, and a step costs (compute + download + upload) / 2 instead of max(compute, upload): measured 11.6 ms against 8.2 ms of
+    // compute and 8.7 ms of upload per 512 pairs.
+    static const int kDepth = 3;
     bool init = false;
     hipStream_t h2d = nullptr, d2h = nullptr;
-    uint8_t* d_in[2] = {nullptr, nullptr};   // [left images | right images] of one batch
+    uint8_t* d_in[kDepth] = {nullptr, nullptr, nullptr};   // [left images | right images] of one batch
     size_t in_bytes = 0;
-    uint8_t* d_out[2] = {nullptr, nullptr};  // packed results of one batch: kps | desc | counts | right_u | depth | n_match
+    uint8_t* d_out[kDepth] = {nullptr, nullptr, nullptr};  // packed results of one batch: kps | desc | counts | right_u | depth | n_match
     size_t out_bytes = 0;
-    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_in_free[2] = {nullptr, nullptr}, ev_out_ready[2] = {nullptr, nullptr},
-               ev_done[2] = {nullptr, nullptr};
+    hipEvent_t ev_h2d[kDepth] = {nullptr, nullptr, nullptr}, ev_in_free[kDepth] = {nullptr, nullptr, nullptr},
+               ev_out_ready[kDepth] = {nullptr, nullptr, nullptr}, ev_done[kDepth] = {nullptr, nullptr, nullptr};
     int64_t next_ticket = 0;
   } hs;
   Lane main;
@@ -737,7 +741,7 @@ void orbfe_destroy(orbfe_ctx* c) {
   if (c->h_counts) (void)hipHostFree(c->h_counts);
   if (c->hs.h2d) (void)hipStreamSynchronize(c->hs.h2d);
   if (c->hs.d2h) (void)hipStreamSynchronize(c->hs.d2h);
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < orbfe_ctx::HostStream::kDepth; ++b) {
     if (c->hs.d_in[b]) (void)hipFree(c->hs.d_in[b]);
     if (c->hs.d_out[b]) (void)hipFree(c->hs.d_out[b]);
     for (hipEvent_t e : {c->hs.ev_h2d[b], c->hs.ev_in_free[b], c->hs.ev_out_ready[b], c->hs.ev_done[b]})
@@ -1401,7 +1405,7 @@ orbfe_status orbfe_stream_submit(orbfe_ctx* c, const uint8_t* left, const uint8_
   if (!hs.init) {
     HIP_TRY(c, hipStreamCreateWithFlags(&hs.h2d, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&hs.d2h, hipStreamNonBlocking));
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < orbfe_ctx::HostStream::kDepth; ++b) {
       HIP_TRY(c, hipEventCreateWithFlags(&hs.ev_h2d[b], hipEventDisableTiming));
       HIP_TRY(c, hipEventCreateWithFlags(&hs.ev_in_free[b], hipEventDisableTiming));
       HIP_TRY(c, hipEventCreateWithFlags(&hs.ev_out_ready[b], hipEventDisableTiming));
@@ -1419,7 +1423,7 @@ orbfe_status orbfe_stream_submit(orbfe_ctx* c, const uint8_t* left, const uint8_
     const size_t in_bytes = std::max(hs.in_bytes, align_up(2 * eye, 1 << 20));
     const PackLayout lmax = pack_layout(c, c->cfg.max_images / 2);
     const size_t out_bytes = std::max(hs.out_bytes, lmax.total);
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < orbfe_ctx::HostStream::kDepth; ++b) {
       if (in_bytes != hs.in_bytes) {
         if (hs.d_in[b]) HIP_TRY(c, hipFree(hs.d_in[b]));
         hs.d_in[b] = nullptr;
@@ -1434,10 +1438,10 @@ orbfe_status orbfe_stream_submit(orbfe_ctx* c, const uint8_t* left, const uint8_
     hs.in_bytes = in_bytes;
     hs.out_bytes = out_bytes;
   }
-  const int b = (int)(hs.next_ticket & 1);
-  // the ticket that last used this pair of buffers must have been collected: its `out` arrays and its images are the caller's again
-  // only then, and "at most two outstanding" is what makes two buffers enough
-  if (hs.next_ticket >= 2 && hipEventQuery(hs.ev_done[b]) != hipSuccess) {
+  const int D = orbfe_ctx::HostStream::kDepth;
+  const int b = (int)(hs.next_ticket % D);
+  // the ticket that last used this set of buffers must be complete ("at most three outstanding" is what makes three sets enough)
+  if (hs.next_ticket >= D && hipEventQuery(hs.ev_done[b]) != hipSuccess) {
     (void)hipGetLastError();
     HIP_TRY(c, hipEventSynchronize(hs.ev_done[b]));
   }
@@ -1469,9 +1473,10 @@ orbfe_status orbfe_stream_wait(orbfe_ctx* c, int64_t ticket) {
   if (!c) return ORBFE_EBADARG;
   orbfe_ctx::HostStream& hs = c->hs;
   if (!hs.init || ticket < 0 || ticket >= hs.next_ticket) return fail(c, ORBFE_EBADARG, "stream_wait: ticket %lld was never issued", (long long)ticket);
-  if (ticket + 2 < hs.next_ticket) return ORBFE_OK;  // its buffers have been re-used since: that download finished long ago
+  const int D = orbfe_ctx::HostStream::kDepth;
+  if (ticket + D < hs.next_ticket) return ORBFE_OK;  // ticket + D has been submitted since, and that submit waited for this one
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipEventSynchronize(hs.ev_done[ticket & 1]));
+  HIP_TRY(c, hipEventSynchronize(hs.ev_done[ticket % D]));
   return ORBFE_OK;
 }
 
@@ -1479,11 +1484,12 @@ orbfe_status orbfe_stream_device_results(orbfe_ctx* c, int64_t ticket, int32_t n
                                          const void** d_counts, const void** d_right_u, const void** d_depth, const void** d_nmatch) {
   if (!c) return ORBFE_EBADARG;
   orbfe_ctx::HostStream& hs = c->hs;
-  if (!hs.init || ticket < 0 || ticket >= hs.next_ticket || ticket + 2 < hs.next_ticket || n_pairs <= 0 || 2 * n_pairs > c->cfg.max_images)
+  if (!hs.init || ticket < 0 || ticket >= hs.next_ticket || ticket + orbfe_ctx::HostStream::kDepth < hs.next_ticket || n_pairs <= 0 ||
+      2 * n_pairs > c->cfg.max_images)
     return fail(c, ORBFE_EBADARG, "stream_device_results: ticket %lld is not live (next %lld) or bad pair count %d", (long long)ticket,
                 (long long)hs.next_ticket, n_pairs);
   const PackLayout l = pack_layout(c, n_pairs);
-  const uint8_t* b = hs.d_out[ticket & 1];
+  const uint8_t* b = hs.d_out[ticket % orbfe_ctx::HostStream::kDepth];
   if (d_kps) *d_kps = b + l.o_kps;
   if (d_desc) *d_desc = b + l.o_desc;
   if (d_counts) *d_counts = b + l.o_cnt;

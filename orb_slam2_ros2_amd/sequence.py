@@ -64,7 +64,7 @@ def unpack_record(rec: np.ndarray, n_features: int) -> dict:
 
 
 def run_sequence(n_frames: int, rank: int, world: int, batch_pairs: int, submit: Callable[[Sequence[int]], object],
-                 collect: Callable[[object], "object"], depth: int = 2, dst: int = 0):
+                 collect: Callable[[object], "object"], depth: int = 3, dst: int = 0):
     """Process this rank's block of the sequence in batches of <= batch_pairs frames, `depth` batches in flight, and gather all
     records on `dst`.
 
@@ -132,5 +132,5 @@ class DeviceSequenceProcessor:
         self.ctx.stream_wait(ticket)   # the packed results of this ticket are in the stream's device buffer
         views = batch_result_views(self.ctx.stream_device_results(ticket, n), n, nf, self.device)
         rec = pack_records(*views)
-        torch.cuda.current_stream(self.device).synchronize()   # the buffer may be re-used by the submit after next
+        torch.cuda.current_stream(self.device).synchronize()   # the buffer is re-used three submits later
         return rec

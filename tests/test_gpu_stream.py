@@ -44,23 +44,23 @@ def test_stream_batches_equal_golden_digests(n_pairs, pinned):
     n_batches = 7
     ids, bufs = _batches(n_batches, n_pairs, pinned)
     ctx = Context(W, H, max_images=2 * n_pairs)
-    outs = [ctx.alloc_batch_results(n_pairs, pinned) for _ in range(2)]
+    outs = [ctx.alloc_batch_results(n_pairs, pinned) for _ in range(3)]
     tickets = []
 
     def check(k):
         ctx.stream_wait(tickets[k])
-        o = outs[k % 2]
+        o = outs[k % 3]
         dig = batch_digests(o["kps"], o["desc"], o["counts"], o["right_u"], o["depth"], o["n_matches"])
         bad = [i for i in range(n_pairs) if dig[i] != GOLD[str(ids[k][i])]]
         assert not bad, f"batch {k}: pairs {bad} differ"
 
     for k in range(n_batches):
-        if k >= 2:
-            check(k - 2)           # its result arrays are about to be handed to batch k
+        if k >= 3:
+            check(k - 3)           # its result arrays are about to be handed to batch k
         la, ra = bufs[k][0], bufs[k][1]
-        tickets.append(ctx.stream_submit(la, ra, n_pairs, FX, BF, outs[k % 2]))
-    check(n_batches - 2)
-    check(n_batches - 1)
+        tickets.append(ctx.stream_submit(la, ra, n_pairs, FX, BF, outs[k % 3]))
+    for k in range(n_batches - 3, n_batches):
+        check(k)
     assert tickets == list(range(n_batches))
     # the slots hold the newest batch; the other entry points see a quiesced context
     lk, ld = ctx.fetch_features(0)
