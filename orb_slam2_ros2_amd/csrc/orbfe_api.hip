@@ -1,8 +1,10 @@
 // orbfe_api.hip -- host side of the C-ABI declared in include/orbfe.h: geometry tables, device buffers,
 // stream/event plumbing and the launch sequence.  No OpenCV, no torch, no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -830,7 +832,9 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     int want = env ? atoi(env) : 1;
     want = std::min(std::max(want, 1), (int)orbfe_ctx::kMaxSide);
     bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
-    for (int k = 0; k < want && ok; ++k) {
+    // (streams are not free: HIP multiplexes all of a process's streams onto 4 hardware queues, and two busy streams on one queue
+    //  serialise -- none is created that the chosen schedule does not use)
+    for (int k = 0; k < want && want > 1 && ok; ++k) {
       ok = hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking) == hipSuccess &&
            hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) == hipSuccess;
       if (ok) c->n_side = k + 1;
@@ -1301,7 +1305,7 @@ static orbfe_status batch_device_core(orbfe_ctx* c, const uint8_t* d_left, const
   // image level, a few hundred dependent steps) and leaves the machine almost idle, so the streaming kernels of the
   // other chunks fill it.  With stage timing enabled the same chunks run one after the other on the main stream, so
   // that every kernel is timed alone with the launch shape of the production path.
-  const int n_chunks = std::min<int>(c->n_side, std::max(1, n_pairs / 8));
+  const int n_chunks = std::max(1, std::min<int>(c->n_side, std::max(1, n_pairs / 8)));
   const bool serial = c->prof == 1 || n_chunks == 1;
   // One chunk (the default): the stereo match goes to its own stream and this call returns with it still queued; the next call
   // starts its copy-in / resize / FAST on the context stream right away, into the OTHER pyramid buffer, and only its keypoint-list
@@ -1382,12 +1386,58 @@ orbfe_status orbfe_stereo_batch_device(orbfe_ctx* c, const uint8_t* d_left, cons
 }
 
 // ---- host-image stream ---------------------------------------------------------------------------------------------------------
+// CPUs of the NUMA node the current HIP device hangs off (sysfs local_cpulist of its PCI function); empty set if unknown.
+static bool device_local_cpus(cpu_set_t* set) {
+  int dev = 0;
+  char bus[64] = {0};
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, sizeof bus, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  for (char* q = bus; *q; ++q) *q = (char)tolower(*q);
+  char path[160];
+  snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bus);
+  FILE* f = fopen(path, "r");
+  if (!f) return false;
+  char line[1024] = {0};
+  const bool got = fgets(line, sizeof line, f) != nullptr;
+  fclose(f);
+  if (!got) return false;
+  CPU_ZERO(set);
+  int n = 0;
+  for (char* tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+    int a = 0, b = 0;
+    const int k = sscanf(tok, "%d-%d", &a, &b);
+    if (k == 1) b = a;
+    if (k < 1) continue;
+    for (int c = a; c <= b && c < CPU_SETSIZE; ++c) {
+      CPU_SET(c, set);
+      ++n;
+    }
+  }
+  return n > 0;
+}
+
+// Page-locked host memory ON THE NUMA NODE OF THE DEVICE: the pages are placed where the allocating thread runs, and a buffer on the
+// other socket is read by the DMA engines across the inter-socket link (measured on a two-socket MI355X host: 41 GB/s instead of
+// 57 GB/s host to device).  The calling thread is moved to the device's local CPUs for the allocation and the first touch, then back.
 void* orbfe_host_alloc(size_t bytes) {
+  cpu_set_t old_set, local;
+  const bool have_old = sched_getaffinity(0, sizeof old_set, &old_set) == 0;
+  bool moved = false;
+  if (have_old && !getenv("ORBFE_NO_NUMA_PIN") && device_local_cpus(&local)) {
+    cpu_set_t both;
+    CPU_AND(&both, &local, &old_set);  // stay inside what this process is allowed to use
+    if (CPU_COUNT(&both) > 0) moved = sched_setaffinity(0, sizeof both, &both) == 0;
+  }
   void* p = nullptr;
   if (hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) {
     (void)hipGetLastError();
-    return nullptr;
+    p = nullptr;
+  } else if (moved) {
+    for (size_t o = 0; o < bytes; o += 4096) ((volatile uint8_t*)p)[o] = 0;  // first touch, should the driver place lazily
   }
+  if (moved) (void)sched_setaffinity(0, sizeof old_set, &old_set);
   return p;
 }
 void orbfe_host_free(void* p) {
@@ -1456,15 +1506,22 @@ orbfe_status orbfe_stream_submit(orbfe_ctx* c, const uint8_t* left, const uint8_
   TRY(batch_device_core(c, hs.d_in[b], hs.d_in[b] + eye, stride, image_pitch, n_pairs, fx, bf, &pack));
   // download
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1), n = (size_t)n_pairs;
-  HIP_TRY(c, hipStreamWaitEvent(hs.d2h, hs.ev_out_ready[b], 0));
+  // (measured and dropped: writing the results into the page-locked arrays with a copy KERNEL through their device mapping instead of
+  //  the DMA engine -- 16 to 1024 workgroups, four 16-byte loads in flight per lane: the step takes 11.7 ms against 9.1 ms.)
+  // The download goes onto the stream the pack ran on.  In the pipelined schedule that is the stereo stream, which has nothing else
+  // to do until the next batch's match ~8 ms later -- a stream of its own would be one more hardware queue, and HIP multiplexes all
+  // streams of a process onto 4 of them (GPU_MAX_HW_QUEUES): a download that shares its queue with the uploads or with the compute
+  // stream serialises with them (measured: 9.1 -> 11.8 ms per 512-pair step, depending on what the process had created before).
+  hipStream_t ds = c->stereo_pending ? c->stereo_stream : hs.d2h;
+  if (ds == hs.d2h) HIP_TRY(c, hipStreamWaitEvent(hs.d2h, hs.ev_out_ready[b], 0));
   const uint8_t* src = hs.d_out[b];
-  if (out->kps) HIP_TRY(c, hipMemcpyAsync(out->kps, src + l.o_kps, 2 * n * NF * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, hs.d2h));
-  if (out->desc) HIP_TRY(c, hipMemcpyAsync(out->desc, src + l.o_desc, 2 * n * NF * 32, hipMemcpyDeviceToHost, hs.d2h));
-  if (out->counts) HIP_TRY(c, hipMemcpyAsync(out->counts, src + l.o_cnt, 2 * n * 4, hipMemcpyDeviceToHost, hs.d2h));
-  if (out->right_u) HIP_TRY(c, hipMemcpyAsync(out->right_u, src + l.o_ru, n * NF * 8, hipMemcpyDeviceToHost, hs.d2h));
-  if (out->depth) HIP_TRY(c, hipMemcpyAsync(out->depth, src + l.o_dp, n * NF * 8, hipMemcpyDeviceToHost, hs.d2h));
-  if (out->n_matches) HIP_TRY(c, hipMemcpyAsync(out->n_matches, src + l.o_nm, n * 4, hipMemcpyDeviceToHost, hs.d2h));
-  HIP_TRY(c, hipEventRecord(hs.ev_done[b], hs.d2h));
+  if (out->kps) HIP_TRY(c, hipMemcpyAsync(out->kps, src + l.o_kps, 2 * n * NF * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, ds));
+  if (out->desc) HIP_TRY(c, hipMemcpyAsync(out->desc, src + l.o_desc, 2 * n * NF * 32, hipMemcpyDeviceToHost, ds));
+  if (out->counts) HIP_TRY(c, hipMemcpyAsync(out->counts, src + l.o_cnt, 2 * n * 4, hipMemcpyDeviceToHost, ds));
+  if (out->right_u) HIP_TRY(c, hipMemcpyAsync(out->right_u, src + l.o_ru, n * NF * 8, hipMemcpyDeviceToHost, ds));
+  if (out->depth) HIP_TRY(c, hipMemcpyAsync(out->depth, src + l.o_dp, n * NF * 8, hipMemcpyDeviceToHost, ds));
+  if (out->n_matches) HIP_TRY(c, hipMemcpyAsync(out->n_matches, src + l.o_nm, n * 4, hipMemcpyDeviceToHost, ds));
+  HIP_TRY(c, hipEventRecord(hs.ev_done[b], ds));
   *ticket = hs.next_ticket++;
   return ORBFE_OK;
 }
