@@ -386,8 +386,7 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.sync()
-    gather_results()
-    _probe("after gather_results")  # warm-up of the exchange too: the first torch indexing / RCCL call initialises lazily (tens of ms)
+    gather_results()  # warm-up of the exchange too: the first torch indexing / RCCL call initialises lazily (tens of ms)
     sync_all()
     # the timed region runs the production schedule (blur under the quadtree, stereo match of a batch under the front of the next);
     # the dominant stage alone carries HIP events on the stream it is launched on, so its duration is measured LIVE in this region --
