@@ -661,7 +661,9 @@ inline LocalBaReport apply_local_ba(MapRec& map, const LocalGraph& g, const doub
   for (const auto& item : to_process) {
     int n_good = 0;
     for (int64_t mp : map.keyframes[item.first].map_points) n_good += mp >= 0;
-    if ((float)item.second.size() / (float)n_good > 0.3f) ++r.n_bad_keyframes;  // size_t / float in the reference: float division
+    // `item.second.size() / (float)nGoodMp > 0.3` (:400): a FLOAT quotient compared with the DOUBLE literal 0.3 -- at exactly 30 % (3 of 10)
+    // the float 0.3f, widened, exceeds 0.3 and the keyframe counts as bad
+    if ((double)((float)item.second.size() / (float)n_good) > 0.3) ++r.n_bad_keyframes;
   }
   r.written = !((double)r.n_bad_keyframes / ((double)to_process.size() + 1e-5) > 0.2);
   if (!r.written) return r;

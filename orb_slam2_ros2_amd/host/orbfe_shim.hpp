@@ -4,14 +4,8 @@
 // Two layers:
 //   namespace orbfe              OpenCV-free classes (ImageView / std::vector) with the reference's names, argument
 //                                order and error behaviour.  Always available.
-//   namespace ORB_SLAM2_ROS2     the drop-in classes with the reference's exact signatures (cv::Mat, cv::KeyPoint),
-//                                compiled only when ORBFE_WITH_OPENCV is defined, i.e. inside the reference's build:
-//                                  ORBExtractor(const cv::Mat&, int, int, float, const std::string&, int, int)
-//                                  void extract(std::vector<cv::KeyPoint>&, std::vector<cv::Mat>&)
-//                                  const std::vector<cv::Mat>& getPyramid() const
-//                                  static const std::vector<float>& getScaledFactors()
-//                                (include/ORB_SLAM2/ORBExtractor.h:107-116) and the stereo-match entry used by
-//                                Frame::createStereo (include/ORB_SLAM2/Frame.h:316-319).
+//   namespace ORB_SLAM2_ROS2     (orbfe_dropin.hpp) the drop-in classes with the reference's exact signatures (cv::Mat, cv::KeyPoint,
+//                                Frame::SharedPtr, KeyFrame::SharedPtr), for the reference's own build.
 //
 // Error mapping (include/ORB_SLAM2/Error.h): ORBFE_EBADSIZE -> ImageSizeError, a missing template file ->
 // FileNotOpenError, everything else -> std::runtime_error with orbfe_last_error().
@@ -79,19 +73,26 @@ inline std::vector<int8_t> loadBriefTemplate(const std::string& path) {
   return out;
 }
 
-// One device context per (geometry, parameters, device); the reference constructs an extractor per image
-// (src/Frame.cc:91-92) -- the device buffers behind it are shared and re-used.
+// One device context per (geometry, parameters, device); the reference constructs an extractor per image (src/Frame.cc:91-92,
+// :132) -- the device buffers behind them are shared and re-used.  Every extractor object takes one image SLOT of that context when
+// it extracts: slots are handed out round-robin, so the left and the right extractor of a frame (two objects, two threads,
+// Frame.cc:100-105) always work in different slots, through orbfe_extract_slot, which is safe for exactly that.  A slot keeps its
+// results on the device until it is handed out again (kSlots extractions later); a generation counter tells an object whether the
+// slot still holds ITS results.
 class ContextPool {
  public:
+  static constexpr int kSlots = 4;  // two stereo frames' worth: the frame being built and the one before it
   using Key = std::tuple<int, int, int, int, float, int, int, std::string, int, int>;
+  struct Lease {
+    int slot = -1;
+    uint64_t generation = 0;
+  };
   static orbfe_ctx* get(int w, int h, int nFeatures, int nLevels, float scale, int maxTh, int minTh, const std::string& tplPath,
-                        int device = 0, int maxImages = 2) {
-    static std::mutex mu;
-    static std::map<Key, std::shared_ptr<orbfe_ctx>> pool;
-    std::lock_guard<std::mutex> lk(mu);
+                        int device = 0, int maxImages = kSlots) {
+    std::lock_guard<std::mutex> lk(mu());
     Key key{w, h, nFeatures, nLevels, scale, maxTh, minTh, tplPath, device, maxImages};
-    auto it = pool.find(key);
-    if (it != pool.end()) return it->second.get();
+    auto it = pool().find(key);
+    if (it != pool().end()) return it->second.get();
     std::vector<int8_t> tpl;
     if (!tplPath.empty()) tpl = loadBriefTemplate(tplPath);
     orbfe_config cfg{};
@@ -107,8 +108,44 @@ class ContextPool {
     cfg.max_images = maxImages;
     orbfe_ctx* ctx = nullptr;
     check(nullptr, orbfe_create(&cfg, &ctx));
-    pool[key] = std::shared_ptr<orbfe_ctx>(ctx, orbfe_destroy);
+    pool()[key] = std::shared_ptr<orbfe_ctx>(ctx, orbfe_destroy);
+    slots()[ctx] = SlotTable{0, std::vector<uint64_t>((size_t)maxImages, 0)};
     return ctx;
+  }
+  // the next slot of the context, and the generation its new content carries
+  static Lease acquire(orbfe_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(mu());
+    SlotTable& t = slots()[ctx];
+    if (t.generation.empty()) t.generation.assign(kSlots, 0);
+    Lease l;
+    l.slot = t.next;
+    t.next = (t.next + 1) % (int)t.generation.size();
+    l.generation = ++t.generation[(size_t)l.slot];
+    return l;
+  }
+  static bool current(orbfe_ctx* ctx, const Lease& l) {
+    std::lock_guard<std::mutex> lk(mu());
+    auto it = slots().find(ctx);
+    return l.slot >= 0 && it != slots().end() && (size_t)l.slot < it->second.generation.size() &&
+           it->second.generation[(size_t)l.slot] == l.generation;
+  }
+
+ private:
+  struct SlotTable {
+    int next = 0;
+    std::vector<uint64_t> generation;
+  };
+  static std::mutex& mu() {
+    static std::mutex m;
+    return m;
+  }
+  static std::map<Key, std::shared_ptr<orbfe_ctx>>& pool() {
+    static std::map<Key, std::shared_ptr<orbfe_ctx>> p;
+    return p;
+  }
+  static std::map<orbfe_ctx*, SlotTable>& slots() {
+    static std::map<orbfe_ctx*, SlotTable> s;
+    return s;
   }
 };
 
@@ -118,8 +155,8 @@ class ORBExtractor {
   static constexpr int mnBorderSize = 19;  // src/ORBExtractor.cc:523
 
   ORBExtractor(const ImageView& image, int nFeatures, int pyramidLevels, float scaleFactor, const std::string& bfTemFp,
-               int maxThreshold, int minThreshold, int slot = 0)
-      : mImage(image), mnFeats(nFeatures), mnLevels(pyramidLevels), mSlot(slot) {
+               int maxThreshold, int minThreshold)
+      : mImage(image), mnFeats(nFeatures), mnLevels(pyramidLevels) {
     if (!image.data || image.cols <= 0 || image.rows <= 0) throw std::invalid_argument("ORBExtractor: empty image");
     mCtx = ContextPool::get(image.cols, image.rows, nFeatures, pyramidLevels, scaleFactor, maxThreshold, minThreshold, bfTemFp);
     mnFeats = orbfe_get_capacity(mCtx);  // array stride: nFeatures, or more where the reference's rounded quotas exceed it
@@ -127,43 +164,47 @@ class ORBExtractor {
     check(mCtx, orbfe_get_scale_factors(mCtx, mScales.data(), pyramidLevels));
   }
 
+  // ORBExtractor::extract (src/ORBExtractor.cc:499-508).  Thread-safe against extract() of OTHER objects (Frame.cc:100-105).
   void extract(std::vector<orbfe_keypoint>& keyPoints, std::vector<Descriptor>& descriptors) {
     keyPoints.resize(mnFeats);
     descriptors.resize(mnFeats);
     int32_t n = 0;
-    if (mSlot == 0) {
-      check(mCtx, orbfe_extract(mCtx, mImage.data, mImage.step, keyPoints.data(), descriptors.data()->data(), &n));
-    } else {  // left/right of a stereo frame live in slots 0/1 of one context
-      std::vector<const uint8_t*> imgs(mSlot + 1, mImage.data);
-      std::vector<orbfe_keypoint> k((size_t)(mSlot + 1) * mnFeats);
-      std::vector<uint8_t> d((size_t)(mSlot + 1) * mnFeats * 32);
-      std::vector<int32_t> cnt(mSlot + 1);
-      check(mCtx, orbfe_extract_batch(mCtx, mSlot + 1, imgs.data(), mImage.step, k.data(), d.data(), cnt.data()));
-      n = cnt[mSlot];
-      std::memcpy(keyPoints.data(), k.data() + (size_t)mSlot * mnFeats, sizeof(orbfe_keypoint) * n);
-      std::memcpy(descriptors.data(), d.data() + (size_t)mSlot * mnFeats * 32, (size_t)32 * n);
-    }
+    mLease = ContextPool::acquire(mCtx);
+    check(mCtx, orbfe_extract_slot(mCtx, mLease.slot, mImage.data, mImage.step, keyPoints.data(), descriptors.data()->data(), &n));
     keyPoints.resize(n);
     descriptors.resize(n);
+    mnKeyPoints = n;
   }
 
-  // level `l` of the un-blurred pyramid, tight rows (what getPyramid()[l] holds in the reference)
-  std::vector<uint8_t> getPyramidLevel(int l, int* w = nullptr, int* h = nullptr) const {
+  // level `l` of the un-blurred pyramid, tight rows (what getPyramid()[l] holds in the reference).  Read from the device on demand:
+  // if the slot has been handed to another extractor since, the pyramid is rebuilt from the image this object still refers to
+  // (like the reference's pyramid, it lives as long as the image does).
+  std::vector<uint8_t> getPyramidLevel(int l, int* w = nullptr, int* h = nullptr) {
     orbfe_level_info li{};
     check(mCtx, orbfe_get_level_info(mCtx, l, &li));
+    if (!resident()) {
+      std::vector<orbfe_keypoint> k;
+      std::vector<Descriptor> d;
+      extract(k, d);
+    }
     std::vector<uint8_t> out((size_t)li.width * li.height);
-    check(mCtx, orbfe_get_pyramid(mCtx, mSlot, l, 0, out.data()));
+    check(mCtx, orbfe_get_pyramid(mCtx, mLease.slot, l, 0, out.data()));
     if (w) *w = li.width;
     if (h) *h = li.height;
     return out;
   }
   const std::vector<float>& getScaledFactors() const { return mScales; }
   orbfe_ctx* context() const { return mCtx; }
+  int slot() const { return mLease.slot; }                                 // -1 before the first extract()
+  bool resident() const { return ContextPool::current(mCtx, mLease); }    // the slot still holds this object's results
+  int keyPointCount() const { return mnKeyPoints; }
+  int levels() const { return mnLevels; }
 
  private:
   ImageView mImage;
-  int mnFeats, mnLevels, mSlot;
+  int mnFeats, mnLevels, mnKeyPoints = 0;
   orbfe_ctx* mCtx = nullptr;
+  ContextPool::Lease mLease;
   std::vector<float> mScales;
 };
 
@@ -178,16 +219,22 @@ class ORBMatcher {
     for (int i = 0; i < 32; ++i) d += __builtin_popcount((unsigned)(a[i] ^ b[i]));
     return d;
   }
-  // ORBMatcher::searchByStereo (src/ORBMatcher.cc:18-81) over the features extracted into slots 0 (left) / 1 (right);
-  // fills mvFeatsRightU / mvDepths (-1 where unmatched) and returns the match count (Frame::mnN).
-  int searchByStereo(orbfe_ctx* ctx, int nFeatures, int nLeft, float fx, float bf, std::vector<double>& rightU,
+  // ORBMatcher::searchByStereo (src/ORBMatcher.cc:18-81) over the device-resident results of the frame's two extractors (what
+  // Frame::createStereo does right after Frame::Frame, include/ORB_SLAM2/Frame.h:313-322); fills mvFeatsRightU / mvDepths
+  // (-1 where unmatched) and returns the match count (Frame::mnN).
+  int searchByStereo(const ORBExtractor& left, const ORBExtractor& right, float fx, float bf, std::vector<double>& rightU,
                      std::vector<double>& depths) const {
-    const int cap = std::max(std::max(nFeatures, (int)orbfe_get_capacity(ctx)), 1);
+    if (left.context() != right.context()) throw std::logic_error("searchByStereo: the two extractors differ in geometry / parameters");
+    if (!left.resident() || !right.resident())
+      throw std::logic_error("searchByStereo: the extractors' device results have been overwritten (more than "
+                             "ContextPool::kSlots extractions since); match right after Frame construction as the reference does");
+    orbfe_ctx* ctx = left.context();
+    const int cap = std::max((int)orbfe_get_capacity(ctx), 1);
     std::vector<double> ru((size_t)cap), dp((size_t)cap);
     int32_t n = 0;
-    check(ctx, orbfe_stereo_match(ctx, 0, 1, fx, bf, ru.data(), dp.data(), &n, nullptr, nullptr));
-    rightU.assign(ru.begin(), ru.begin() + nLeft);
-    depths.assign(dp.begin(), dp.begin() + nLeft);
+    check(ctx, orbfe_stereo_match(ctx, left.slot(), right.slot(), fx, bf, ru.data(), dp.data(), &n, nullptr, nullptr));
+    rightU.assign(ru.begin(), ru.begin() + left.keyPointCount());
+    depths.assign(dp.begin(), dp.begin() + left.keyPointCount());
     return n;
   }
 
@@ -457,47 +504,5 @@ class Optimizer {
 
 }  // namespace orbfe
 
-#ifdef ORBFE_WITH_OPENCV
-#include <opencv2/core.hpp>
-namespace ORB_SLAM2_ROS2 {
-// Drop-in for include/ORB_SLAM2/ORBExtractor.h:100-160 -- same constructor, extract(), getPyramid(), statics.
-class ORBExtractor {
- public:
-  typedef std::shared_ptr<ORBExtractor> SharedPtr;
-  ORBExtractor(const cv::Mat& image, int nFeatures, int pyramidLevels, float scaleFactor, const std::string& bfTemFp, int maxThreshold,
-               int minThreshold)
-      : mImpl(orbfe::ImageView{image.data, image.cols, image.rows, image.step}, nFeatures, pyramidLevels, scaleFactor, bfTemFp,
-              maxThreshold, minThreshold) {
-    CV_Assert(image.type() == CV_8UC1);
-    mnLevels = pyramidLevels;
-    mfScaledFactor = scaleFactor;
-    mvfScaledFactors = mImpl.getScaledFactors();
-  }
-  void extract(std::vector<cv::KeyPoint>& keyPoints, std::vector<cv::Mat>& descriptors) {
-    std::vector<orbfe_keypoint> k;
-    std::vector<orbfe::Descriptor> d;
-    mImpl.extract(k, d);
-    static_assert(sizeof(cv::KeyPoint) == sizeof(orbfe_keypoint), "cv::KeyPoint layout");
-    keyPoints.resize(k.size());
-    std::memcpy((void*)keyPoints.data(), k.data(), sizeof(orbfe_keypoint) * k.size());
-    descriptors.clear();
-    for (auto& row : d) descriptors.push_back(cv::Mat(1, 32, CV_8U, row.data()).clone());  // one 1x32 Mat per keypoint (:402-412)
-    mvPyramids.clear();
-    for (int l = 0; l < mnLevels; ++l) {
-      int w, h;
-      auto buf = mImpl.getPyramidLevel(l, &w, &h);
-      mvPyramids.push_back(cv::Mat(h, w, CV_8U, buf.data()).clone());
-    }
-  }
-  const std::vector<cv::Mat>& getPyramid() const { return mvPyramids; }
-  static const std::vector<float>& getScaledFactors() { return mvfScaledFactors; }
-  static inline int mnLevels = 0, mnBorderSize = 19;
-  static inline float mfScaledFactor = 0.f;
-
- private:
-  orbfe::ORBExtractor mImpl;
-  std::vector<cv::Mat> mvPyramids;
-  static inline std::vector<float> mvfScaledFactors;
-};
-}  // namespace ORB_SLAM2_ROS2
-#endif  // ORBFE_WITH_OPENCV
+// The drop-in classes with the reference's exact signatures (cv::Mat, cv::KeyPoint, Frame::SharedPtr, KeyFrame::SharedPtr) are in
+// orbfe_dropin.hpp (needs <opencv2/core.hpp>, i.e. the reference's build).

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "../../orb_slam2_ros2_amd/host/orbfe_shim.hpp"
@@ -30,21 +31,18 @@ int main(int argc, char** argv) {
   if (!f || fread(R.data(), 1, R.size(), f) != R.size()) return 2;
   fclose(f);
   try {
-    orbfe::ORBExtractor el({L.data(), w, h, (size_t)w}, 2000, 8, 1.2f, "", 20, 7, 0);
-    orbfe::ORBExtractor er({R.data(), w, h, (size_t)w}, 2000, 8, 1.2f, "", 20, 7, 1);
+    orbfe::ORBExtractor el({L.data(), w, h, (size_t)w}, 2000, 8, 1.2f, "", 20, 7);
+    orbfe::ORBExtractor er({R.data(), w, h, (size_t)w}, 2000, 8, 1.2f, "", 20, 7);
     std::vector<orbfe_keypoint> kl, kr;
     std::vector<orbfe::Descriptor> dl, dr;
-    // slot 1 first: extracting slot 1 also refills slot 0 with the right image, the left extract then restores slot 0
-    er.extract(kr, dr);
-    el.extract(kl, dl);
-    // put the right image back into slot 1 for the stereo match (slot 0 keeps the left features)
-    const uint8_t* imgs[2] = {L.data(), R.data()};
-    std::vector<orbfe_keypoint> kk(4000);
-    std::vector<uint8_t> dd(4000 * 32);
-    int32_t cnt[2];
-    orbfe::check(el.context(), orbfe_extract_batch(el.context(), 2, imgs, w, kk.data(), dd.data(), cnt));
+    // Frame::Frame (src/Frame.cc:100-105): the two extractions on two threads, each object in its own slot of the shared context
+    {
+      std::thread tl([&] { el.extract(kl, dl); }), tr([&] { er.extract(kr, dr); });
+      tl.join();
+      tr.join();
+    }
     std::vector<double> ru, dp;
-    const int nm = orbfe::ORBMatcher().searchByStereo(el.context(), 2000, (int)kl.size(), 718.856f, 718.856f * 0.537166f, ru, dp);
+    const int nm = orbfe::ORBMatcher().searchByStereo(el, er, 718.856f, 718.856f * 0.537166f, ru, dp);
     printf("%zu %zu %d %016llx %016llx %d", kl.size(), kr.size(), nm, (unsigned long long)fnv1a(kl.data(), kl.size() * sizeof(orbfe_keypoint)),
            (unsigned long long)fnv1a(dl.data(), dl.size() * 32), orbfe::ORBMatcher::descDistance(dl[0], dl[1]));
     // guided search: every left keypoint looks for itself in slot 0 (radius 3 px, its own octave): best = itself at distance 0
@@ -57,7 +55,7 @@ int main(int argc, char** argv) {
         uv[2 * i] = kl[i].x, uv[2 * i + 1] = kl[i].y;
         lo[i] = hi[i] = (int8_t)kl[i].octave;
       }
-      const auto m = orbfe::ORBMatcher().searchInArea(el.context(), 0, uv, rad, lo, hi, qd);
+      const auto m = orbfe::ORBMatcher().searchInArea(el.context(), el.slot(), uv, rad, lo, hi, qd);
       int self = 0;
       for (size_t i = 0; i < n; ++i) self += (m.bestDist[i] == 0 && m.nCand[i] >= 1);
       printf(" %d/%zu", self, n);
@@ -66,7 +64,7 @@ int main(int argc, char** argv) {
       std::vector<float> sf(8);
       orbfe::check(el.context(), orbfe_get_scale_factors(el.context(), sf.data(), 8));
       std::vector<uint8_t> valid(kl.size(), 1), none(kl.size(), 0);
-      auto mm = orbfe::ORBMatcher(1.0f).searchByProjection(el.context(), 0, sf, kl, dl, valid, none, 3.0f, 0.f, 0.5f, false);
+      auto mm = orbfe::ORBMatcher(1.0f).searchByProjection(el.context(), el.slot(), sf, kl, dl, valid, none, 3.0f, 0.f, 0.5f, false);
       int selfm = 0;
       for (const auto& d : mm) selfm += (d.queryIdx == d.trainIdx && d.distance == 0);
       std::vector<float> ang(kl.size());

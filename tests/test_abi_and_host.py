@@ -79,7 +79,19 @@ def _build_shim(tmp_path):
     exe = str(tmp_path / "test_shim")
     pkg = os.path.join(ROOT, "orb_slam2_ros2_amd")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_shim.cpp"), "-L" + pkg,
-                           "-lorbfe_hip", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
+                           "-lorbfe_hip", "-pthread", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def _build_dropin(tmp_path):
+    """tests/cpp/test_dropin.cpp: the cv::Mat drop-in classes and the templated Frame / KeyFrame adapters (host/orbfe_dropin.hpp) against the
+    stand-in opencv2/core.hpp of tests/cpp/stubs -- a compile-and-logic check; it pins nothing about OpenCV."""
+    import subprocess
+    exe = str(tmp_path / "test_dropin")
+    pkg = os.path.join(ROOT, "orb_slam2_ros2_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "tests", "cpp", "stubs"), "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"), "-L" + pkg, "-lorbfe_hip", "-pthread",
+                           "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
 
@@ -95,4 +107,18 @@ def test_cpp_host_mirror_compiles_and_fails_loudly_without_device(tmp_path):
     L.tofile(tmp_path / "L.raw")
     R.tofile(tmp_path / "R.raw")
     r = subprocess.run([exe, str(tmp_path / "L.raw"), str(tmp_path / "R.raw"), "640", "240"], capture_output=True, text=True)
+    assert r.returncode == 3 and r.stdout.strip() == "NO_DEVICE"
+
+
+def test_dropin_header_compiles_against_the_stand_in_opencv_and_fails_loudly_without_device(tmp_path):
+    """host/orbfe_dropin.hpp (cv::Mat ORBExtractor, the templated bodies of searchByStereo(FramePtr), OptimizePoseOnly(FramePtr),
+    OptimizeLocalMap(KeyFramePtr, bool&)) goes through g++ with -Wall against tests/cpp/stubs/opencv2/core.hpp.  A compile check of the
+    adapters' use of the reference's accessors; it pins nothing about OpenCV."""
+    import subprocess
+
+    import torch
+    exe = _build_dropin(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a device is present: the run-time half is tests/test_gpu_dropin.py")
+    r = subprocess.run([exe, "poseonly"], capture_output=True, text=True)
     assert r.returncode == 3 and r.stdout.strip() == "NO_DEVICE"
