@@ -109,38 +109,47 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
   if (iw <= 0 || ih <= 0) return;
   const int t_min = min(t_hi, t_lo);
 
-  // ---- 1. patch -> LDS (aligned words; 16 or 32 lanes per patch row, no index division) ----
+  // ---- 1. patch -> LDS: 16-byte units (PP / 16 per row: 3 for the 30-px grid's patches), 21 rows per pass, every pass of a lane
+  //         requested before the first is parked (rows clamped, so the loads are unconditional): two loads and two stores per lane
+  //         for a 36-row patch where 32-bit words took nine of each plus their address arithmetic (~ 60 of the kernel's ~1080 VALU
+  //         instructions per wave).  The global address is only 4-byte aligned (x0 - xa); gfx950 takes that for dwordx4.
   const int xa = cell.x0 & 3;
   {
-    constexpr int LW = (PP / 4 <= 16) ? 16 : 32, RPI = 64 / LW;
-    const int nwords = (xa + pw + 3) >> 2;
-    const int c = lane & (LW - 1);
+    constexpr int UPR = PP / 16;                    // 16-byte units per LDS row
+    constexpr int RPP = 64 / UPR;                   // rows per pass
+    constexpr int MUL = (128 + UPR - 1) / UPR;      // lane / UPR == (lane * MUL) >> 7 for lane < 64 (UPR = 3: 43, UPR = 5: 26)
+    static_assert(PP % 16 == 0 && (UPR == 3 || UPR == 5), "patch pitch");
+    const int row0 = (lane * MUL) >> 7, part = lane - row0 * UPR;
+    const int nbytes = (xa + pw + 3) & ~3;          // bytes of a patch row that are needed
     const uint8_t* src = pyr + (size_t)img * img_pitch + L.plane_off + (size_t)cell.y0 * L.stride + (cell.x0 - xa);
     const uint32_t stride = (uint32_t)L.stride;
-    // all rows of a lane are requested before the first is parked in LDS (rows clamped, so the loads are unconditional
-    // and no wait lands inside a branch): one memory round trip for the 30-px grid's patches (<= 48 rows)
-    constexpr int BATCH = 12;
-    if (c < nwords) {
-      for (int rb = lane / LW; rb < ph; rb += RPI * BATCH) {
-        uint32_t wv[BATCH];
+    uint4* lds_q = (uint4*)lds_all;
+    constexpr int BATCH = 2;
+    if (row0 < RPP && 16 * part < nbytes) {         // (a unit that starts past the needed bytes is never read: it may lie past the row)
+      for (int rb = row0; rb < ph; rb += RPP * BATCH) {
+        uint4 wv[BATCH];
 #pragma unroll
         for (int it = 0; it < BATCH; ++it) {
-          const int r = min(rb + RPI * it, ph - 1);
-          wv[it] = *(const uint32_t*)(src + (uint32_t)mad24u(r, (int)stride, 4 * c));  // full-rate 24-bit product: rows and strides < 2^13
+          const int r = min(rb + RPP * it, ph - 1);
+          wv[it] = *(const uint4*)(src + (uint32_t)mad24u(r, (int)stride, 16 * part));  // full-rate 24-bit product: rows and strides < 2^13
         }
+        // both passes in flight before the first is consumed (left alone, the compiler sinks the second load into the branch that
+        // guards its store and the wave pays two memory round trips)
+#pragma unroll
+        for (int it = 0; it < BATCH; ++it) asm volatile("" : "+v"(wv[it].x), "+v"(wv[it].y), "+v"(wv[it].z), "+v"(wv[it].w));
 #pragma unroll
         for (int it = 0; it < BATCH; ++it) {
-          const int r = rb + RPI * it;
-          if (r < ph) lds_w[r * (PP / 4) + c] = wv[it];
+          const int r = rb + RPP * it;
+          if (r < ph) lds_q[r * UPR + part] = wv[it];
         }
       }
     }
   }
-  // ---- zero the V map (with border) ----
+  // ---- zero the V map (with border), 16 bytes per store (its carve-up is rounded to 16) ----
   {
-    const int vwords = ((ih + 2) * PV + 3) >> 2;
-    uint32_t* V32 = (uint32_t*)V;
-    for (int k = lane; k < vwords; k += 64) V32[k] = 0;
+    const int vq = ((ih + 2) * PV + 3 + 15) >> 4;
+    uint4* V128 = (uint4*)V;
+    for (int k = lane; k < vq; k += 64) V128[k] = make_uint4(0u, 0u, 0u, 0u);
   }
   WAVE_SYNC();
 
