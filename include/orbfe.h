@@ -74,7 +74,11 @@ typedef struct orbfe_config {
   float scale_factor;          /* ORBExtractor.scaleFactor                                              */
   int32_t fast_hi, fast_lo;    /* ORBExtractor.iniThFAST / minThFAST                                    */
   const int8_t* brief_pairs;   /* 256 x {x1,y1,x2,y2}; NULL = the embedded table (config/brief_template.txt) */
-  int32_t blur_variant;        /* 0: taps {18,34,48,56,48,34,18} (default)  1: {18,34,49,55,49,34,18}    */
+  int32_t blur_variant;        /* cv::GaussianBlur 7x7 sigma 2, 8.8 fixed-point taps (un-vendored OpenCV):
+                                  0: {18,34,48,56,48,34,18} (OpenCV >= 4.3, default)  1: {18,34,49,55,49,34,18}          */
+  int32_t gray_variant;        /* cv::cvtColor RGB/BGR -> gray fixed-point coefficients (orbfe_extract_color only):
+                                  0: 14-bit R 4899 G 9617 B 1868, (sum + 2^13) >> 14 (default)
+                                  1: 15-bit R 9798 G 19235 B 3735, (sum + 2^14) >> 15 (newer OpenCV 4.x builds)           */
   int32_t device_id;           /* HIP device ordinal                                                    */
   int32_t max_images;          /* image slots held on the device (a stereo pair uses two)               */
   void* stream;                /* optional hipStream_t to run on; NULL = context-owned stream           */

@@ -18,6 +18,17 @@
 extern "C" {
 
 // order: 1 = RGB, 2 = BGR (the reference's Camera.Color values, Tracking.cc:56,63); src rows stride bytes apart, 3 bytes per pixel
+// variant 0: the 14-bit coefficients (R 4899, G 9617, B 1868, >> 14), variant 1: the 15-bit ones of newer OpenCV 4.x builds (9798, 19235,
+// 3735, >> 15).  cv::cvtColor is un-vendored third-party arithmetic: which one the reference's OpenCV uses could not be checked here.
+void orc_cvt_gray_v(const uint8_t* src, int w, int h, int stride, int order, int variant, uint8_t* dst, int dst_stride) {
+  const int cr = variant ? 9798 : 4899, cg = variant ? 19235 : 9617, cb = variant ? 3735 : 1868, sh = variant ? 15 : 14;
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const uint8_t* p = src + (size_t)y * stride + 3 * x;
+      const int r = order == 1 ? p[0] : p[2], g = p[1], b = order == 1 ? p[2] : p[0];
+      dst[(size_t)y * dst_stride + x] = (uint8_t)((r * cr + g * cg + b * cb + (1 << (sh - 1))) >> sh);
+    }
+}
 void orc_cvt_gray(const uint8_t* src, int w, int h, int stride, int order, uint8_t* dst, int dst_stride) {
   for (int y = 0; y < h; ++y)
     for (int x = 0; x < w; ++x) {

@@ -67,6 +67,7 @@ class Oracle:
         L.orc_search_in_area.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10
         L.orc_pose_only_optimize.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_double] * 5 + [C.c_void_p] * 2
         L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_cvt_gray_v.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orc_undistort_points.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_rgbd_lookup.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p,
                                       C.c_void_p]
@@ -210,11 +211,12 @@ class Oracle:
         return r, out, inl[:n].astype(bool)
 
     # ---- frame glue -------------------------------------------------------------------------
-    def cvt_gray(self, img: np.ndarray, order: int) -> np.ndarray:
+    def cvt_gray(self, img: np.ndarray, order: int, variant: int = 0) -> np.ndarray:
+        """variant 0: 14-bit coefficients (default), 1: the 15-bit ones of newer OpenCV 4.x builds"""
         img = np.ascontiguousarray(img, np.uint8)
         h, w, _ = img.shape
         out = np.empty((h, w), np.uint8)
-        self.lib.orc_cvt_gray(_p(img), w, h, 3 * w, order, _p(out), w)
+        self.lib.orc_cvt_gray_v(_p(img), w, h, 3 * w, order, variant, _p(out), w)
         return out
 
     def undistort_points(self, xy, K, D):

@@ -36,7 +36,7 @@ class Config(C.Structure):
     _fields_ = [
         ("width", C.c_int32), ("height", C.c_int32), ("n_features", C.c_int32), ("n_levels", C.c_int32),
         ("scale_factor", C.c_float), ("fast_hi", C.c_int32), ("fast_lo", C.c_int32), ("brief_pairs", C.c_void_p),
-        ("blur_variant", C.c_int32), ("device_id", C.c_int32), ("max_images", C.c_int32), ("stream", C.c_void_p),
+        ("blur_variant", C.c_int32), ("gray_variant", C.c_int32), ("device_id", C.c_int32), ("max_images", C.c_int32), ("stream", C.c_void_p),
     ]
 
 
@@ -248,13 +248,13 @@ class Context:
     """Owns one orbfe_ctx (device buffers for `max_images` image slots of one fixed geometry)."""
 
     def __init__(self, width, height, n_features=2000, n_levels=8, scale_factor=1.2, fast_hi=20, fast_lo=7, brief_pairs=None,
-                 blur_variant=0, device_id=0, max_images=2, stream=None):
+                 blur_variant=0, device_id=0, max_images=2, stream=None, gray_variant=0):
         self.lib = load()
         self._pairs = None
         if brief_pairs is not None:
             self._pairs = np.ascontiguousarray(brief_pairs, np.int8).reshape(256, 4)
         cfg = Config(width, height, n_features, n_levels, scale_factor, fast_hi, fast_lo, ptr(self._pairs), blur_variant,
-                     device_id, max_images, stream)
+                     gray_variant, device_id, max_images, stream)
         self.cfg = cfg
         h = C.c_void_p(None)
         st = self.lib.orbfe_create(C.byref(cfg), C.byref(h))

@@ -12,7 +12,7 @@ namespace orbfe {
 
 // 4 pixels (12 source bytes as 3 aligned words) -> one destination word.  order 1: RGB, 2: BGR.
 __global__ __launch_bounds__(256) void k_cvt_gray(const uint8_t* __restrict__ src, size_t src_stride, uint8_t* __restrict__ dst,
-                                                  int dst_stride, int w, int order) {
+                                                  int dst_stride, int w, int order, int variant) {
   const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
   const int y = blockIdx.y;
   if (x4 >= w) return;
@@ -20,11 +20,14 @@ __global__ __launch_bounds__(256) void k_cvt_gray(const uint8_t* __restrict__ sr
   const uint32_t w0 = s[0], w1 = s[1], w2 = s[2];
   const uint32_t c[12] = {w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u, w0 >> 24, w1 & 255u, (w1 >> 8) & 255u,
                           (w1 >> 16) & 255u, w1 >> 24, w2 & 255u, (w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24};
-  const uint32_t c0 = order == 1 ? 4899u : 1868u, c2 = order == 1 ? 1868u : 4899u;  // R2Y / B2Y on the first / third channel
+  // variant 0: 14-bit coefficients 4899 / 9617 / 1868, variant 1: 15-bit 9798 / 19235 / 3735 (un-vendored OpenCV: a selectable decision)
+  const uint32_t cr = variant ? 9798u : 4899u, cg = variant ? 19235u : 9617u, cb = variant ? 3735u : 1868u;
+  const uint32_t shift = variant ? 15u : 14u, half = 1u << (shift - 1);
+  const uint32_t c0 = order == 1 ? cr : cb, c2 = order == 1 ? cb : cr;  // R2Y / B2Y on the first / third channel
   uint32_t out = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const uint32_t g = (c[3 * j] * c0 + c[3 * j + 1] * 9617u + c[3 * j + 2] * c2 + (1u << 13)) >> 14;
+    const uint32_t g = (c[3 * j] * c0 + c[3 * j + 1] * cg + c[3 * j + 2] * c2 + half) >> shift;
     out |= g << (8 * j);
   }
   *(uint32_t*)(dst + (size_t)y * dst_stride + x4) = out;  // the row padding absorbs the tail
@@ -88,8 +91,9 @@ __global__ __launch_bounds__(256) void k_frame_rgbd(orbfe_keypoint* __restrict__
   right_u_out[i] = ru_out;
 }
 
-void launch_cvt_gray(hipStream_t s, const uint8_t* d_src, size_t src_stride, uint8_t* d_dst, int dst_stride, int w, int h, int order) {
-  hipLaunchKernelGGL(k_cvt_gray, dim3((w + 1023) / 1024, h), dim3(256), 0, s, d_src, src_stride, d_dst, dst_stride, w, order);
+void launch_cvt_gray(hipStream_t s, const uint8_t* d_src, size_t src_stride, uint8_t* d_dst, int dst_stride, int w, int h, int order,
+                     int variant) {
+  hipLaunchKernelGGL(k_cvt_gray, dim3((w + 1023) / 1024, h), dim3(256), 0, s, d_src, src_stride, d_dst, dst_stride, w, order, variant);
 }
 void launch_frame_rgbd(hipStream_t s, orbfe_keypoint* d_kps, const int32_t* d_n_kp, int n_features, const orbfe_camera& cam,
                        const uint8_t* d_depth, int depth_type, size_t depth_stride, float depth_scale, double* d_depth_out, double* d_right_u) {

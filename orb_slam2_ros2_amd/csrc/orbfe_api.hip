@@ -51,7 +51,8 @@ void launch_stereo(hipStream_t s, const LevelDev* d_lv, const uint8_t* d_pyr, si
                    const int32_t* d_n_kp, int n_features, float fx, float bf, int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
                    int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs);
 // k_glue.hip
-void launch_cvt_gray(hipStream_t s, const uint8_t* d_src, size_t src_stride, uint8_t* d_dst, int dst_stride, int w, int h, int order);
+void launch_cvt_gray(hipStream_t s, const uint8_t* d_src, size_t src_stride, uint8_t* d_dst, int dst_stride, int w, int h, int order,
+                     int variant);
 void launch_frame_rgbd(hipStream_t s, orbfe_keypoint* d_kps, const int32_t* d_n_kp, int n_features, const orbfe_camera& cam,
                        const uint8_t* d_depth, int depth_type, size_t depth_stride, float depth_scale, double* d_depth_out, double* d_right_u);
 // k_lba.hip
@@ -1217,7 +1218,8 @@ orbfe_status orbfe_extract_color(orbfe_ctx* c, const uint8_t* img, size_t stride
   TRY(ensure_tmp(c, plane));
   for (int y = 0; y < L0.h; ++y) std::memcpy(c->main.h_stage + (size_t)y * row, img + (size_t)y * stride, (size_t)c->cfg.width * 3);
   HIP_TRY(c, hipMemcpyAsync(c->d_tmp, c->main.h_stage, row * (size_t)L0.h, hipMemcpyHostToDevice, c->stream));
-  launch_cvt_gray(c->stream, (const uint8_t*)c->d_tmp, row, c->d_pyr + L0.plane_off, L0.stride, c->cfg.width, c->cfg.height, color_order);
+  launch_cvt_gray(c->stream, (const uint8_t*)c->d_tmp, row, c->d_pyr + L0.plane_off, L0.stride, c->cfg.width, c->cfg.height, color_order,
+                  c->cfg.gray_variant ? 1 : 0);
   TRY(run_extract(c, c->stream, 0, 1));
   return fetch_extract_results(c, 1, o_kps, o_desc, o_cnt, kps, desc, n_out);
 }

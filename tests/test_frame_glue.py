@@ -35,6 +35,15 @@ def test_oracle_cvt_gray_known_answers_and_numpy(orc):
     px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 20, 30]]], np.uint8)
     assert orc.cvt_gray(px, 1)[0].tolist() == [255, 0, 76, 150, 29, 18]     # 0.299 / 0.587 / 0.114 in 14-bit fixed point
     assert orc.cvt_gray(px, 2)[0].tolist() == [255, 0, 29, 150, 76, 22]
+    # variant 1: the 15-bit coefficients (9798 / 19235 / 3735, >> 15) -- a selectable decision like the blur taps
+    for order in (1, 2):
+        r, g, b = (img[..., 0], img[..., 1], img[..., 2]) if order == 1 else (img[..., 2], img[..., 1], img[..., 0])
+        want = ((r.astype(np.int64) * 9798 + g.astype(np.int64) * 19235 + b.astype(np.int64) * 3735 + 16384) >> 15).astype(np.uint8)
+        assert np.array_equal(orc.cvt_gray(img, order, 1), want)
+    assert orc.cvt_gray(px, 1, 1)[0].tolist() == [255, 0, 76, 150, 29, 18]
+    big = _color_image(5, 320, 240)
+    assert (orc.cvt_gray(big, 1, 0) != orc.cvt_gray(big, 1, 1)).any()        # the two do differ on real data (by one grey level)
+    assert np.abs(orc.cvt_gray(big, 1, 0).astype(int) - orc.cvt_gray(big, 1, 1).astype(int)).max() <= 1
 
 
 def test_oracle_undistort_inverts_the_distortion_model(orc):
@@ -67,14 +76,14 @@ def test_oracle_rgbd_lookup_truncates_indices_and_marks_missing_depth(orc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("order", [1, 2])
-def test_device_color_frame_matches_oracle(orc, order):
+@pytest.mark.parametrize("order,variant", [(1, 0), (2, 0), (1, 1), (2, 1)])
+def test_device_color_frame_matches_oracle(orc, order, variant):
     from orb_slam2_ros2_amd import Frame
     from orb_slam2_ros2_amd._lib import Context
     img = _color_image(3)
-    ctx = Context(640, 480, n_features=1000, max_images=1)
+    ctx = Context(640, 480, n_features=1000, max_images=1, gray_variant=variant)
     k, d = Frame.grabColor(ctx, img, order)
-    gray = orc.cvt_gray(img, order)
+    gray = orc.cvt_gray(img, order, variant)
     assert np.array_equal(ctx.pyramid(0, 0, False), gray)
     ok, od = orc.extractor(gray, n_features=1000).extract()
     assert len(k) == len(ok) and np.array_equal(d, od)
