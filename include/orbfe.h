@@ -235,7 +235,8 @@ orbfe_status orbfe_ba_build_system(orbfe_ctx* ctx, const orbfe_ba_problem* prob,
  * 7.815 (stereo) or non-positive depth goes to level 1 and ALL robust kernels are dropped (:338-359), optimize(iters_second = 10)
  * on level 0, final computeError() + the same test on every edge (:364-391).  BlockSolver_6_3 + OptimizationAlgorithmLevenberg
  * semantics (lambda0 = 1e-5 max diag, gain ratio, <= 10 trials per iteration, points marginalised by Schur complement); the
- * reduced system is factorised densely by one workgroup: at most 100 non-fixed keyframes (ORBFE_EBADSIZE beyond).  stop_flag (nullable) is polled like g2o's
+ * reduced system is factorised densely (6x6-blocked Cholesky: by one workgroup out of LDS up to 100 non-fixed keyframes, by a multi-workgroup
+ * path beyond -- no bound on their number, as Optimizer.cc:232 has none).  stop_flag (nullable) is polled like g2o's
  * forceStopFlag (Optimizer.cc:230): it points at ONE BYTE, the reference's `bool mbAbortBA` (include/ORB_SLAM2/LocalMapping.h:185) passed as
  * `bool& isStop` (Optimizer.h:69) -- only that byte is read, non-zero = stop.  The map bookkeeping of :393-441 stays with the caller.                               */
 typedef struct orbfe_ba_optimize_out {

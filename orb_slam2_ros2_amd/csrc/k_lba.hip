@@ -260,6 +260,117 @@ __global__ __launch_bounds__(1024) void k_lba_chol_solve(int n, double* __restri
   if (t < n) x[t] = yv[t];
 }
 
+// ---- the same factorisation for reduced systems past the LDS-resident solver (more than LBA_MAX_FREE free keyframes) --------------
+// Optimizer::OptimizeLocalMap takes ALL keyframes covisible with the current one (getConnectedKfs(0), src/Optimizer.cc:232) -- there is
+// no bound on their number, so the reduced system must not have one either.  Same right-looking 6x6-blocked algorithm, with the
+// panel, the diagonal blocks and the right-hand side in global memory and one block column per pair of launches: the panel step by
+// one workgroup (the dependent part: a 6x6 factorisation and n - c0 independent row solves), the trailing update by as many
+// workgroups as it has columns / 16 -- that update is where the n^3 / 3 flops are, and a single CU would take ~40 ms for it at
+// 300 keyframes.  A failed pivot clears *ok; every later launch of the factorisation then returns at once.
+__global__ __launch_bounds__(1024) void k_lba_chol_panel(int n, int kb, double* __restrict__ S, double* __restrict__ Pg,
+                                                         double* __restrict__ Ldg, double* __restrict__ yg, int* __restrict__ ok) {
+#pragma clang fp contract(off)
+  __shared__ double Lk[36];
+  __shared__ int s_ok;
+  const int t = threadIdx.x, c0 = 6 * kb;
+  if (*ok == 0) return;  // uniform
+  if (t < 36) Lk[t] = S[(size_t)(c0 + t / 6) + (size_t)(c0 + t % 6) * n];
+  if (t == 0) s_ok = 1;
+  __syncthreads();
+  if (t == 0) {
+    for (int j = 0; j < 6; ++j) {
+      double d = Lk[7 * j];
+      for (int k = 0; k < j; ++k) d -= Lk[6 * j + k] * Lk[6 * j + k];
+      if (!(d > 0) || !isfinite(d)) {
+        s_ok = 0;
+        break;
+      }
+      d = sqrt(d);
+      Lk[7 * j] = d;
+      for (int i = j + 1; i < 6; ++i) {
+        double v = Lk[6 * i + j];
+        for (int k = 0; k < j; ++k) v -= Lk[6 * i + k] * Lk[6 * j + k];
+        Lk[6 * i + j] = v / d;
+      }
+    }
+  }
+  __syncthreads();
+  if (!s_ok) {
+    if (t == 0) *ok = 0;
+    return;
+  }
+  if (t < 36) Ldg[(size_t)kb * 36 + t] = Lk[t];
+  for (int r = c0 + 6 + t; r <= n; r += 1024) {  // rows below the diagonal block, and the right-hand-side row r == n
+    double v[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double sv = (r < n) ? S[(size_t)r + (size_t)(c0 + c) * n] : yg[c0 + c];
+      for (int m = 0; m < c; ++m) sv -= v[m] * Lk[6 * c + m];
+      v[c] = sv / Lk[7 * c];
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      Pg[(size_t)r * 6 + c] = v[c];
+      if (r < n) {
+        S[(size_t)r + (size_t)(c0 + c) * n] = v[c];  // L
+        S[(size_t)(c0 + c) + (size_t)r * n] = v[c];  // L^T, for the backward substitution
+      } else {
+        yg[c0 + c] = v[c];  // y of this block
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_lba_chol_trail(int n, int kb, double* __restrict__ S, const double* __restrict__ Pg,
+                                                         double* __restrict__ yg, const int* __restrict__ ok) {
+#pragma clang fp contract(off)
+  if (*ok == 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = 6 * kb + 6 + (int)blockIdx.x * 16 + wave;  // one wave per column of the trailing matrix, lanes over its rows
+  if (c >= n) return;
+  const double* pc = Pg + (size_t)c * 6;
+  const double p0 = pc[0], p1 = pc[1], p2 = pc[2], p3 = pc[3], p4 = pc[4], p5 = pc[5];
+  for (int r = c + lane; r <= n; r += 64) {
+    const double* pr = Pg + (size_t)r * 6;
+    const double sv = pr[0] * p0 + pr[1] * p1 + pr[2] * p2 + pr[3] * p3 + pr[4] * p4 + pr[5] * p5;
+    if (r < n)
+      S[(size_t)r + (size_t)c * n] -= sv;
+    else
+      yg[c] -= sv;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_lba_chol_back(int n, const double* __restrict__ S, const double* __restrict__ Ldg,
+                                                        double* __restrict__ yg, double* __restrict__ x, const int* __restrict__ ok) {
+#pragma clang fp contract(off)
+  const int t = threadIdx.x;
+  if (*ok == 0) {
+    for (int i = t; i < n; i += 1024) x[i] = 0.0;
+    return;
+  }
+  const int nb = n / 6;
+  for (int kb = nb - 1; kb >= 0; --kb) {  // L^T x = y, block by block from the bottom
+    const int c0 = 6 * kb;
+    const double* Lk = Ldg + (size_t)kb * 36;
+    if (t == 0) {
+      for (int a = 5; a >= 0; --a) {
+        double v = yg[c0 + a];
+        for (int m = a + 1; m < 6; ++m) v -= Lk[6 * m + a] * yg[c0 + m];
+        yg[c0 + a] = v / Lk[7 * a];
+      }
+    }
+    __syncthreads();  // (one workgroup: its own global writes are visible to it after the barrier)
+    for (int r = t; r < c0; r += 1024) {
+      double v = yg[r];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) v -= S[(size_t)r + (size_t)(c0 + a) * n] * yg[c0 + a];
+      yg[r] = v;
+    }
+    __syncthreads();
+  }
+  for (int i = t; i < n; i += 1024) x[i] = yg[i];
+}
+
 // SparseOptimizer::update: poses <- exp(dx) * pose (free poses), points <- point + Dinv (bl - sum Hpl^T dxp)
 __global__ __launch_bounds__(256) void k_lba_update(int n_poses, int n_points, const int32_t* __restrict__ pose_slot,
                                                     const double* __restrict__ x, const int32_t* __restrict__ pt_off,
@@ -363,13 +474,28 @@ void launch_lba_solve(hipStream_t s, int n_poses, int n_points, int n_edges, int
                       const int32_t* pair_off, const int2* pairs, const int32_t* ps_off, const int32_t* ps_edges, const int32_t* pt_off,
                       const int32_t* pt_edges, const int32_t* edge_pose, const int32_t* edge_point, const uint8_t* fixed, const double* Hpp,
                       const double* bp, const double* Hll, const double* bl, const double* Hpl, const double* lambda_p, double* Dinv, double* W,
-                      double* S, double* rhs, double* x, int* ok, double* poses, double* points, double* dxp, double* dxl, double* scale_out) {
+                      double* S, double* rhs, double* x, int* ok, double* poses, double* points, double* dxp, double* dxl, double* scale_out,
+                      double* big_scratch) {
   if (n_points > 0) hipLaunchKernelGGL(k_lba_point_inv, dim3((n_points + 255) / 256), dim3(256), 0, s, n_points, Hll, lambda_p, Dinv, ok);
   if (n_edges > 0) hipLaunchKernelGGL(k_lba_edge_w, dim3((n_edges + 255) / 256), dim3(256), 0, s, n_edges, edge_point, Hpl, Dinv, W);
   if (nf > 0) {
     hipLaunchKernelGGL(k_lba_schur, dim3(nf, nf), dim3(64), 0, s, nf, free_pose, pair_off, pairs, ps_off, ps_edges, edge_point, Hpp, bp, bl,
                        Hpl, W, lambda_p, S, rhs);
-    hipLaunchKernelGGL(k_lba_chol_solve, dim3(1), dim3(1024), 0, s, 6 * nf, S, rhs, x, ok);
+    if (nf <= LBA_MAX_FREE) {
+      hipLaunchKernelGGL(k_lba_chol_solve, dim3(1), dim3(1024), 0, s, 6 * nf, S, rhs, x, ok);
+    } else {  // big_scratch: panel [(n + 1) * 6] | diagonal blocks [nf * 36] | right-hand side [n]
+      const int n = 6 * nf;
+      double* Pg = big_scratch;
+      double* Ldg = Pg + (size_t)(n + 1) * 6;
+      double* yg = Ldg + (size_t)nf * 36;
+      (void)hipMemcpyAsync(yg, rhs, sizeof(double) * n, hipMemcpyDeviceToDevice, s);
+      for (int kb = 0; kb < nf; ++kb) {
+        hipLaunchKernelGGL(k_lba_chol_panel, dim3(1), dim3(1024), 0, s, n, kb, S, Pg, Ldg, yg, ok);
+        const int cols = n - 6 * kb - 6;
+        if (cols > 0) hipLaunchKernelGGL(k_lba_chol_trail, dim3((cols + 15) / 16), dim3(1024), 0, s, n, kb, S, Pg, yg, ok);
+      }
+      hipLaunchKernelGGL(k_lba_chol_back, dim3(1), dim3(1024), 0, s, n, S, Ldg, yg, x, ok);
+    }
   }
   const int nt = n_points + n_poses;
   if (nt > 0)

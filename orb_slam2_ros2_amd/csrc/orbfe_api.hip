@@ -63,7 +63,8 @@ void launch_lba_solve(hipStream_t s, int n_poses, int n_points, int n_edges, int
                       const int32_t* pair_off, const int2* pairs, const int32_t* ps_off, const int32_t* ps_edges, const int32_t* pt_off,
                       const int32_t* pt_edges, const int32_t* edge_pose, const int32_t* edge_point, const uint8_t* fixed, const double* Hpp,
                       const double* bp, const double* Hll, const double* bl, const double* Hpl, const double* lambda_p, double* Dinv, double* W,
-                      double* S, double* rhs, double* x, int* ok, double* poses, double* points, double* dxp, double* dxl, double* scale_out);
+                      double* S, double* rhs, double* x, int* ok, double* poses, double* points, double* dxp, double* dxl, double* scale_out,
+                      double* big_scratch);
 void launch_lba_classify(hipStream_t s, int n_edges, const double* chi2_last, const uint8_t* depth_pos, const uint8_t* is_stereo,
                          uint8_t* level, double* info_eff, double* delta_eff);
 void launch_lba_final(hipStream_t s, int n_edges, const double* chi2, const uint8_t* depth_pos, const uint8_t* is_stereo, uint8_t* bad);
@@ -1750,8 +1751,8 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
       free_pose.push_back(k);
     }
   const int nf = (int)free_pose.size();
-  if (nf > LBA_MAX_FREE)
-    return fail(c, ORBFE_EBADSIZE, "ba_local_optimize: %d non-fixed keyframes exceed the %d the reduced solver takes", nf, LBA_MAX_FREE);
+  // (no bound on nf: up to LBA_MAX_FREE free keyframes the reduced system is factorised by one workgroup out of LDS, beyond that by the
+  //  multi-workgroup path of k_lba.hip with its panel in global memory)
   std::vector<int32_t> pt_off(NP + 1, 0), ps_off(NK + 1, 0), pt_edges(std::max(E, 1)), ps_edges(std::max(E, 1));
   for (int e = 0; e < E; ++e) {
     ++pt_off[p->edge_point[e] + 1];
@@ -1809,7 +1810,8 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
                o_bl = take((size_t)NP * 24), o_hpl = take((size_t)E * 144), o_dinv = take((size_t)NP * 72), o_w = take((size_t)E * 144),
                o_s = take(n * n * 8), o_rhs = take(n * 8), o_x = take(n * 8), o_dxp = take((size_t)NK * 48), o_dxl = take((size_t)NP * 24),
                o_err = take((size_t)E * 24), o_chi2 = take((size_t)E * 8), o_rho = take((size_t)E * 16), o_last = take((size_t)E * 8),
-               o_level = take((size_t)E), o_depth = take((size_t)E), o_bad = take((size_t)E), o_sc = take(64);
+               o_level = take((size_t)E), o_depth = take((size_t)E), o_bad = take((size_t)E), o_sc = take(64),
+               o_big = take(nf > LBA_MAX_FREE ? ((n + 1) * 6 + (size_t)nf * 36 + n) * 8 : 8);
   TRY(ensure_tmp(c, off));
   uint8_t* b = (uint8_t*)c->d_tmp;
   hipStream_t st = c->stream;
@@ -1897,7 +1899,7 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
                          (const int32_t*)(b + o_pte), d_ek, d_ep, b + o_fix, (const double*)(b + o_hpp), (const double*)(b + o_bp),
                          (const double*)(b + o_hll), (const double*)(b + o_bl), (const double*)(b + o_hpl), d_sc + 2, (double*)(b + o_dinv),
                          (double*)(b + o_w), (double*)(b + o_s), (double*)(b + o_rhs), (double*)(b + o_x), (int*)(d_sc + 3), d_poses, d_points,
-                         (double*)(b + o_dxp), (double*)(b + o_dxl), d_sc + 4);
+                         (double*)(b + o_dxp), (double*)(b + o_dxl), d_sc + 4, (double*)(b + o_big));
         evaluate((const double*)(b + o_info_eff));
         HIP_TRY(c, read_scalars(h));
         const bool ok2 = h.ok != 0;

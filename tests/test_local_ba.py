@@ -76,6 +76,26 @@ def test_device_local_ba_matches_oracle(orc, seed, n_kf, n_pt, n_fixed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_kf,n_pt,n_fixed", [(11, 155, 2500, 5), (12, 101, 1500, 0), (13, 310, 4000, 10)])
+def test_device_local_ba_beyond_100_free_keyframes(orc, seed, n_kf, n_pt, n_fixed):
+    """Optimizer::OptimizeLocalMap takes every keyframe covisible with the current one (getConnectedKfs(0), Optimizer.cc:232): no bound.
+    Past 100 free keyframes the reduced system is factorised by the multi-workgroup path (panel in global memory): 150, 101 (the first
+    size past the LDS-resident solver, no fixed frame: the gauge is free, as g2o would run it) and 300 free keyframes."""
+    from orb_slam2_ros2_amd._lib import Context
+    pr, fixed = _problem(seed, n_kf, n_pt, n_fixed)
+    assert (fixed == 0).sum() > 100
+    ctx = Context(640, 480, n_features=500, max_images=1)
+    g = ctx.ba_local_optimize(pr, fixed)
+    o = orc.ba_local_optimize(pr, fixed)
+    assert tuple(g["iters"]) == tuple(o["iters"])
+    assert _pose_dist(g["poses"], o["poses"]) < 1e-7 and np.abs(g["points"] - o["points"]).max() < 1e-7
+    assert (g["level"] != o["level"]).sum() <= 1 and (g["bad"] != o["bad"]).sum() <= 1
+    again = ctx.ba_local_optimize(pr, fixed)
+    assert all(np.array_equal(again[k], g[k]) for k in ("poses", "points", "level", "chi2", "bad"))
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_device_local_ba_edge_cases(orc):
     from orb_slam2_ros2_amd._lib import Context, OrbfeError
     pr, fixed = _problem(4, 6, 60)
