@@ -72,6 +72,49 @@ __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv,
   ResizeTap ax[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) ax[j] = xs[tx + j];
+  if (fits) {
+    // Instruction diet (the kernel is VALU-bound: ~24 instructions per output pixel before, ~13 now):
+    //  * H << 4 = S[sx] (a0 << 4) + S[sx + 1] (a1 << 4) is ONE v_dot2_u32_u16 on the byte pair spread to 16-bit halves and the two
+    //    taps packed in one register (a << 4 <= 2^15 fits the unsigned half; H << 4 < 2^24);
+    //  * ((b (H >> 4)) >> 16) is ONE v_mul_hi_u32_u24 of (b << 8) and ((H >> 4) << 8) = (H << 4) & ~0xFF: both below 2^24, and the
+    //    high half of the 48-bit product is exactly the reference's floor;
+    //  * S[sx + 1] is read at offset 1 of the same address (where the reference clamps sx + 1 its tap is 0, and the byte read instead
+    //    lies inside the staged tile's 16-byte row padding), no min(), no second address;
+    //  * saturate_cast<uchar> cannot fire: b0 + b1 <= 2049 and H >> 4 <= 32640 give (..) + 2 >> 2 <= 255.
+    typedef unsigned short __attribute__((ext_vector_type(2))) us2;
+    us2 taps2[4];
+    int sxo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      taps2[j] = __builtin_bit_cast(us2, ((uint32_t)(uint16_t)ax[j].c0 << 4) | ((uint32_t)(uint16_t)ax[j].c1 << 20));
+      sxo[j] = ax[j].ofs - sx_lo;
+    }
+#pragma unroll
+    for (int rr = 0; rr < TH / 16; ++rr) {
+      const int ty = (threadIdx.x >> 4) + 16 * rr;
+      const int cy = y0 + ty;
+      if (cy >= L.h) break;
+      const ResizeTap ay = ys[ty];
+      const int sy0 = min(max(ay.ofs, 0), sh - 1), sy1 = min(max(ay.ofs + 1, 0), sh - 1);
+      const int o0 = mul24u(sy0 - sy_lo, pitch), o1 = mul24u(sy1 - sy_lo, pitch);
+      const uint32_t b0 = (uint32_t)(uint16_t)ay.c0 << 8, b1 = (uint32_t)(uint16_t)ay.c1 << 8;
+      uint32_t v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lds_bytes_t r0 = tb + (o0 + sxo[j]), r1 = tb + (o1 + sxo[j]);
+        const uint32_t q0 = (uint32_t)r0[0] | ((uint32_t)r0[1] << 16), q1 = (uint32_t)r1[0] | ((uint32_t)r1[1] << 16);
+        const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, q0), taps2[j], 0u, false) & 0xFFFFFF00u;
+        const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, q1), taps2[j], 0u, false) & 0xFFFFFF00u;
+        uint32_t m0, m1;  // (their inputs come from the compiler's own v_and, not straight from the dot: see wave_ops.h)
+        asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(m0) : "v"(b0), "v"(h0));
+        asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(m1) : "v"(b1), "v"(h1));
+        v[j] = (m0 + m1 + 2u) >> 2;
+      }
+      *(uint32_t*)(base + (L.plane_off + (uint32_t)mad24u(cy, L.stride, cx))) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+    }
+    return;
+  }
+  // footprint too large for the LDS (never for pyramid scales): the reference formula straight from global memory
 #pragma unroll
   for (int rr = 0; rr < TH / 16; ++rr) {
     const int ty = (threadIdx.x >> 4) + 16 * rr;
@@ -79,20 +122,13 @@ __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv,
     if (cy >= L.h) break;
     const ResizeTap ay = ys[ty];
     const int sy0 = min(max(ay.ofs, 0), sh - 1), sy1 = min(max(ay.ofs + 1, 0), sh - 1);
-    // (two code paths, not one pointer select: an LDS address minus sx_lo is not a valid flat address)
-    const int o0 = mad24s(sy0 - sy_lo, pitch, -sx_lo), o1 = mad24s(sy1 - sy_lo, pitch, -sx_lo);
     uint32_t out = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int sx0 = ax[j].ofs;
       const int sx1 = min(ax[j].ofs + 1, sw - 1);  // tap c1 is 0 wherever the reference does not read S[sx+1]
-      int p00, p01, p10, p11;
-      if (fits) {
-        p00 = tb[o0 + sx0], p01 = tb[o0 + sx1], p10 = tb[o1 + sx0], p11 = tb[o1 + sx1];
-      } else {
-        const uint32_t g0 = (uint32_t)mul24u(sy0, sstride), g1 = (uint32_t)mul24u(sy1, sstride);  // 32-bit offsets from the uniform base
-        p00 = S[g0 + sx0], p01 = S[g0 + sx1], p10 = S[g1 + sx0], p11 = S[g1 + sx1];
-      }
+      const uint32_t g0 = (uint32_t)mul24u(sy0, sstride), g1 = (uint32_t)mul24u(sy1, sstride);  // 32-bit offsets from the uniform base
+      const int p00 = S[g0 + sx0], p01 = S[g0 + sx1], p10 = S[g1 + sx0], p11 = S[g1 + sx1];
       // (pixels < 2^8, taps <= 2^11, h >> 4 < 2^15: every product fits the full-rate 24-bit multiplier)
       const int h0 = mad24u(p00, ax[j].c0, mul24u(p01, ax[j].c1));
       const int h1 = mad24u(p10, ax[j].c0, mul24u(p11, ax[j].c1));
