@@ -499,6 +499,25 @@ def main():
         },
     }
 
+    # The same kernel against its VALU ISSUE ceiling: FAST is integer work on bytes and sits far below the HBM roofline because it is
+    # instruction-bound, so the HBM fraction alone says little about it.  wave-instructions per second = waves per launch x VALU
+    # instructions per wave (committed rocprofv3 SQ_* counter pass, profiles/) / the launch duration measured live above; peak = 256 CUs
+    # x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction.
+    sq_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_sq_counters.json"))
+    kern_of = {"fast": "k_fast", "blur": "k_blur", "quadtree": "k_quadtree", "stereo": "k_stereo", "resize": "k_resize"}
+    if sq_files and dom in kern_of:
+        try:
+            sq = json.load(open(os.path.join(ROOT, "profiles", sq_files[-1])))
+            ent = sq["kernels"].get(kern_of[dom])
+            if ent and sq.get("pairs_per_step") == B and dom_ms > 0:
+                peak = 256 * 4 * 2.4e9 / 4
+                ach = ent["waves_per_step"] * ent["valu_per_wave"] / (dom_ms * 1e-3)
+                line["roofline_valu"] = {"kernel": dom, "bound": "valu", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s",
+                                         "frac": ach / peak, "valu_per_wave": ent["valu_per_wave"], "waves_per_launch": ent["waves_per_step"],
+                                         "source": "profiles/" + sq_files[-1]}
+        except Exception:
+            pass
+
     # HBM traffic of the dominant kernel from a committed rocprofv3 PMC pass of this same command (profiles/), if present
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):

@@ -15,7 +15,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     if r["Counter_Name"] == "SQ_WAVES":
         n[k] += 1
 steps = max(n["k_quadtree"], 1)
-out = {"source": sys.argv[3], "kernels": {}}
+out = {"source": sys.argv[3], "pairs_per_step": int(sys.argv[4]) if len(sys.argv) > 4 else None, "kernels": {}}
 for k, c in sorted(tot.items()):
     w = max(c["SQ_WAVES"], 1.0)
     wc = max(c["SQ_WAVE_CYCLES"], 1.0)
