@@ -265,6 +265,15 @@ orbfe_status orbfe_search_in_area(orbfe_ctx* ctx, int32_t slot, int32_t nq, cons
                                   const uint8_t* exclude /*[n_features], nullable*/, int32_t* best_idx, int32_t* best_dist,
                                   int32_t* second_dist, int32_t* n_cand);
 
+/* The same search against a feature set the CALLER supplies -- a KeyFrame's mvFeatsLeft / descriptors: keyframes are not resident in a
+ * slot.  This is the core of the remaining guided searches, ORBMatcher::searchBySim3 x2 (src/ORBMatcher.cc:370-559, via
+ * KeyFrame::findFeaturesInArea), and of searchByProjection / fuse when the target is a KeyFrame (:561-734).  t_kps: x, y, octave are
+ * read; exclude: [nt] flags, nullable; the grid is the context's width x height.                                                  */
+orbfe_status orbfe_search_in_area_features(orbfe_ctx* ctx, int32_t nt, const orbfe_keypoint* t_kps, const uint8_t* t_desc /*[nt][32]*/,
+                                           int32_t nq, const float* qxy /*[nq][2]*/, const float* radius, const int8_t* min_level,
+                                           const int8_t* max_level, const uint8_t* q_desc /*[nq][32]*/, const uint8_t* exclude,
+                                           int32_t* best_idx, int32_t* best_dist, int32_t* second_dist, int32_t* n_cand);
+
 /* ---- pose-only optimisation of one frame (fp64), entirely on the device -------------------------------------------
  * Replaces the g2o part of Optimizer::OptimizePoseOnly (include/ORB_SLAM2/Optimizer.h:72, src/Optimizer.cc:33-178): one SE3 pose
  * vertex, one unary edge per observed map point -- EdgeSE3ProjectXYZOnlyPose when u_right < 0 (Optimizer.cc:77), else

@@ -1958,6 +1958,56 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
   return ORBFE_OK;
 }
 
+// The grid-guided search against a feature set on the device: the features of an image slot (orbfe_search_in_area) or a set the caller
+// uploaded (orbfe_search_in_area_features: a KeyFrame's keypoints and descriptors -- keyframes are not resident in a slot).
+static orbfe_status search_area_core(orbfe_ctx* c, const char* who, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, const uint4* d_kpl,
+                                     const uint8_t* d_desc, size_t n_target, size_t tmp_used, int32_t nq, const float* qxy,
+                                     const float* radius, const int8_t* min_level, const int8_t* max_level, const uint8_t* q_desc,
+                                     const uint8_t* exclude, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist, int32_t* n_cand) {
+  const int rows = (c->cfg.height + 47) / 48, cols = (c->cfg.width + 63) / 64;  // cvCeil((float)(max-min)/grid), Frame.cc:55-56
+  const size_t ncells = (size_t)rows * cols;
+  if ((2 * ncells + 1) * 4 > 60 * 1024) return fail(c, ORBFE_EBADSIZE, "%s: %zu grid cells exceed the LDS counters", who, ncells);
+  const size_t NT = std::max<size_t>(n_target, 1);
+  size_t off = tmp_used;
+  auto take = [&](size_t bytes) {
+    size_t o2 = off;
+    off += align_up(std::max<size_t>(bytes, 8), 256);
+    return o2;
+  };
+  const size_t o_co = take((ncells + 1) * 4), o_cf = take(NT * 4), o_q = take((size_t)nq * 8), o_r = take((size_t)nq * 4),
+               o_lo = take((size_t)nq), o_hi = take((size_t)nq), o_d = take((size_t)nq * 32), o_ex = take(NT), o_bi = take((size_t)nq * 4),
+               o_bd = take((size_t)nq * 4), o_sd = take((size_t)nq * 4), o_nc = take((size_t)nq * 4);
+  if (off > c->tmp_bytes) return fail(c, ORBFE_ENOMEM, "%s: scratch not reserved", who);  // (the callers reserve before they upload)
+  uint8_t* b = (uint8_t*)c->d_tmp;
+  HIP_TRY(c, hipMemcpyAsync(b + o_q, qxy, (size_t)nq * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_r, radius, (size_t)nq * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_lo, min_level, (size_t)nq, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_hi, max_level, (size_t)nq, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b + o_d, q_desc, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+  if (exclude) HIP_TRY(c, hipMemcpyAsync(b + o_ex, exclude, n_target, hipMemcpyHostToDevice, c->stream));
+  {
+    StageTimer tm(c, ORBFE_STAGE_MATCH, c->stream);
+    launch_grid_build(c->stream, d_kps, d_n_kp, rows, cols, (int32_t*)(b + o_co), (int32_t*)(b + o_cf));
+    launch_search_area(c->stream, d_kpl, d_desc, c->cfg.width, c->cfg.height, rows, cols, (const int32_t*)(b + o_co),
+                       (const int32_t*)(b + o_cf), nq, (const float*)(b + o_q), (const float*)(b + o_r), (const int8_t*)(b + o_lo),
+                       (const int8_t*)(b + o_hi), b + o_d, exclude ? b + o_ex : nullptr, (int32_t*)(b + o_bi), (int32_t*)(b + o_bd),
+                       (int32_t*)(b + o_sd), (int32_t*)(b + o_nc));
+  }
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(best_idx, b + o_bi, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(best_dist, b + o_bd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(second_dist, b + o_sd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(n_cand, b + o_nc, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  return ORBFE_OK;
+}
+// scratch the core needs beyond `tmp_used`
+static size_t search_area_scratch(const orbfe_ctx* c, size_t n_target, int32_t nq) {
+  const size_t ncells = (size_t)((c->cfg.height + 47) / 48) * ((c->cfg.width + 63) / 64), NT = std::max<size_t>(n_target, 1);
+  return ((ncells + 1) * 4 + NT * 5 + (size_t)nq * (8 + 4 + 1 + 1 + 32 + 16)) + 12 * 256 + 4096;
+}
+
 orbfe_status orbfe_search_in_area(orbfe_ctx* c, int32_t slot, int32_t nq, const float* qxy, const float* radius, const int8_t* min_level,
                                   const int8_t* max_level, const uint8_t* q_desc, const uint8_t* exclude, int32_t* best_idx,
                                   int32_t* best_dist, int32_t* second_dist, int32_t* n_cand) {
@@ -1968,42 +2018,40 @@ orbfe_status orbfe_search_in_area(orbfe_ctx* c, int32_t slot, int32_t nq, const 
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
-  const int rows = (c->cfg.height + 47) / 48, cols = (c->cfg.width + 63) / 64;  // cvCeil((float)(max-min)/grid), Frame.cc:55-56
-  const size_t ncells = (size_t)rows * cols;
-  if ((2 * ncells + 1) * 4 > 60 * 1024) return fail(c, ORBFE_EBADSIZE, "search_in_area: %zu grid cells exceed the LDS counters", ncells);
-  size_t off = 0;
-  auto take = [&](size_t bytes) {
-    size_t o2 = off;
-    off += align_up(std::max<size_t>(bytes, 8), 256);
-    return o2;
-  };
-  const size_t o_co = take((ncells + 1) * 4), o_cf = take(NF * 4), o_q = take((size_t)nq * 8), o_r = take((size_t)nq * 4),
-               o_lo = take((size_t)nq), o_hi = take((size_t)nq), o_d = take((size_t)nq * 32), o_ex = take(NF), o_bi = take((size_t)nq * 4),
-               o_bd = take((size_t)nq * 4), o_sd = take((size_t)nq * 4), o_nc = take((size_t)nq * 4);
-  TRY(ensure_tmp(c, off));
+  TRY(ensure_tmp(c, search_area_scratch(c, NF, nq)));
+  return search_area_core(c, "search_in_area", c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, c->d_kpl + (size_t)slot * NF,
+                          c->d_desc + (size_t)slot * NF * 32, NF, 0, nq, qxy, radius, min_level, max_level, q_desc, exclude, best_idx,
+                          best_dist, second_dist, n_cand);
+}
+
+orbfe_status orbfe_search_in_area_features(orbfe_ctx* c, int32_t nt, const orbfe_keypoint* t_kps, const uint8_t* t_desc, int32_t nq,
+                                           const float* qxy, const float* radius, const int8_t* min_level, const int8_t* max_level,
+                                           const uint8_t* q_desc, const uint8_t* exclude, int32_t* best_idx, int32_t* best_dist,
+                                           int32_t* second_dist, int32_t* n_cand) {
+  if (!c || nt < 0 || nq < 0 || (nt && (!t_kps || !t_desc))) return fail(c, ORBFE_EBADARG, "search_in_area_features: bad count / NULL features");
+  if (nq && (!qxy || !radius || !min_level || !max_level || !q_desc || !best_idx || !best_dist || !second_dist || !n_cand))
+    return fail(c, ORBFE_EBADARG, "search_in_area_features: NULL argument");
+  if (nq == 0) return ORBFE_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
+  const size_t NT = (size_t)std::max(nt, 1);
+  // the uploaded feature set at the front of the scratch: keypoints | octave list in the layout of the slot arrays | descriptors | count
+  const size_t o_k = 0, o_l = o_k + align_up(NT * sizeof(orbfe_keypoint), 256), o_d = o_l + align_up(NT * sizeof(uint4), 256),
+               o_n = o_d + align_up(NT * 32, 256), used = o_n + 256;
+  TRY(ensure_tmp(c, used + search_area_scratch(c, NT, nq)));
   uint8_t* b = (uint8_t*)c->d_tmp;
-  HIP_TRY(c, hipMemcpyAsync(b + o_q, qxy, (size_t)nq * 8, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_r, radius, (size_t)nq * 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_lo, min_level, (size_t)nq, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_hi, max_level, (size_t)nq, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_d, q_desc, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
-  if (exclude) HIP_TRY(c, hipMemcpyAsync(b + o_ex, exclude, (size_t)c->cfg.n_features, hipMemcpyHostToDevice, c->stream));
-  {
-    StageTimer tm(c, ORBFE_STAGE_MATCH, c->stream);
-    launch_grid_build(c->stream, c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, rows, cols, (int32_t*)(b + o_co), (int32_t*)(b + o_cf));
-    launch_search_area(c->stream, c->d_kpl + (size_t)slot * NF, c->d_desc + (size_t)slot * NF * 32, c->cfg.width, c->cfg.height, rows, cols,
-                       (const int32_t*)(b + o_co), (const int32_t*)(b + o_cf), nq, (const float*)(b + o_q), (const float*)(b + o_r),
-                       (const int8_t*)(b + o_lo), (const int8_t*)(b + o_hi), b + o_d, exclude ? b + o_ex : nullptr, (int32_t*)(b + o_bi),
-                       (int32_t*)(b + o_bd), (int32_t*)(b + o_sd), (int32_t*)(b + o_nc));
+  std::vector<uint4> kpl(NT, make_uint4(0u, 0u, 0u, 0u));
+  for (int i = 0; i < nt; ++i) kpl[(size_t)i].y = (uint32_t)(t_kps[i].octave & 0xFF);  // the search reads the octave from here
+  if (nt) {
+    HIP_TRY(c, hipMemcpyAsync(b + o_k, t_kps, (size_t)nt * sizeof(orbfe_keypoint), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(b + o_l, kpl.data(), (size_t)nt * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(b + o_d, t_desc, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
   }
-  HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(best_idx, b + o_bi, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(best_dist, b + o_bd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(second_dist, b + o_sd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(n_cand, b + o_nc, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  drain_timers(c);
-  return ORBFE_OK;
+  HIP_TRY(c, hipMemcpyAsync(b + o_n, &nt, 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // (kpl and nt live on this frame)
+  return search_area_core(c, "search_in_area_features", (const orbfe_keypoint*)(b + o_k), (const int32_t*)(b + o_n), (const uint4*)(b + o_l),
+                          b + o_d, (size_t)nt, used, nq, qxy, radius, min_level, max_level, q_desc, exclude, best_idx, best_dist,
+                          second_dist, n_cand);
 }
 
 orbfe_status orbfe_project_map_points(orbfe_ctx* c, int32_t n, const float* pos, const float* view_dir, const float* max_dist,

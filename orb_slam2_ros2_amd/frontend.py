@@ -31,6 +31,8 @@ def load_brief_template(path: str) -> np.ndarray:
     return np.asarray(rows, np.int8)
 
 
+from .matcher_ext import MatcherExt  # searchBySim3 x2, processFuseMps, the epipolar half of searchForTriangulation
+
 class _CtxCache:
     """One device context per (geometry, parameters): the reference builds a new extractor per image
     (Frame.cc:91-92); re-allocating device buffers per image would be absurd, so contexts are shared."""
@@ -92,7 +94,7 @@ class ORBExtractor:
         return self.ctx.scale_factors()
 
 
-class ORBMatcher:
+class ORBMatcher(MatcherExt):
     mnMaxThreshold, mnMinThreshold, mnMeanThreshold = 100, 50, 75  # ORBMatcher.cc:1086-1088
     mnW, mnL, mnBinNum, mnBinChoose, mnFarParam = 5, 5, 30, 3, 35  # ORBMatcher.cc:1089-1093
 

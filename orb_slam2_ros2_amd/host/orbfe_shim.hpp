@@ -421,6 +421,145 @@ class ORBMatcher {
     return matches;
   }
 
+  // ---- the remaining callers of getBestMatch (include/ORB_SLAM2/ORBMatcher.h:41-75) --------------------------------------------------
+  // Their targets are KeyFrames, whose features are not resident in a slot: the feature set is uploaded with the call
+  // (orbfe_search_in_area_features).  Map state enters as arrays, map side effects come back as data.  Float arithmetic follows the
+  // reference's expressions; where it multiplies cv::Mat objects (cv::gemm, un-vendored) the convention of csrc/k_guided.hip applies: a
+  // product element is the float sum a0 b0 + a1 b1 + a2 b2 taken left to right, `alpha A x + t` is (float)((double)alpha * sum + t).
+  struct KeyFrameView {                       // what the searches read of a KeyFrame
+    std::vector<orbfe_keypoint> kps;          // mvFeatsLeft
+    std::vector<Descriptor> desc;             // mvLeftDescriptor
+    std::vector<float> pos;                   // [n][3] world position of the feature's map point (ignored where !good)
+    std::vector<uint8_t> good, inMap;         // map point non-null and not bad / isInMap()
+    std::vector<float> maxDist, minDist;      // MapPoint::getDistance
+  };
+  struct Sim3 {                               // Sim3Ret (include/ORB_SLAM2/Sim3Solver.h:14-48): p_q = s R p_p + t
+    float s = 1.f;
+    float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+    Sim3 inv() const {                        // Sim3Ret::inv (:36-43)
+      Sim3 o;
+      o.s = 1.0f / s;
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) o.R[3 * r + c] = R[3 * c + r];
+      float rt[3];
+      matVec(o.R, t, rt);
+      for (int r = 0; r < 3; ++r) o.t[r] = -o.s * rt[r];
+      return o;
+    }
+  };
+  static void matVec(const float* R, const float* x, float* out) {
+    for (int r = 0; r < 3; ++r) out[r] = R[3 * r] * x[0] + R[3 * r + 1] * x[1] + R[3 * r + 2] * x[2];
+  }
+  static void affine(float alpha, const float* R, const float* x, const float* t, float* out) {
+    float sm[3];
+    matVec(R, x, sm);
+    for (int r = 0; r < 3; ++r) out[r] = (float)((double)alpha * (double)sm[r] + (double)t[r]);
+  }
+  // MapPoint::predictLevel (src/MapPoint.cc:188-199)
+  static int predictLevel(float maxDist, float d, float logScale) {
+    const int level = (int)std::lrintf(std::log(maxDist / d) / logScale);
+    return level < 0 ? 0 : (level > 7 ? 7 : level);
+  }
+  AreaMatch searchInAreaFeatures(orbfe_ctx* ctx, const std::vector<orbfe_keypoint>& tKps, const std::vector<Descriptor>& tDesc,
+                                 const std::vector<float>& uv, const std::vector<float>& radius, const std::vector<int8_t>& minLevel,
+                                 const std::vector<int8_t>& maxLevel, const std::vector<Descriptor>& desc,
+                                 const std::vector<uint8_t>* exclude = nullptr) const {
+    const int32_t n = (int32_t)radius.size();
+    AreaMatch m;
+    m.bestIdx.resize(n), m.bestDist.resize(n), m.secondDist.resize(n), m.nCand.resize(n);
+    check(ctx, orbfe_search_in_area_features(ctx, (int32_t)tKps.size(), tKps.data(), tDesc.empty() ? nullptr : tDesc[0].data(), n, uv.data(),
+                                             radius.data(), minLevel.data(), maxLevel.data(), n ? desc[0].data() : nullptr,
+                                             exclude ? exclude->data() : nullptr, m.bestIdx.data(), m.bestDist.data(), m.secondDist.data(),
+                                             m.nCand.data()));
+    return m;
+  }
+  struct Intrinsics {
+    float fx, fy, cx, cy, minU, maxU, minV, maxV;  // Camera::mfFx.. and the frame's undistorted bounds (VirtualFrame::isInImage)
+  };
+  // ORBMatcher::SIM3Project (src/ORBMatcher.cc:370-414) for the points `ids` of `src` into `dst`: best feature of dst per point, -1 = no match
+  std::vector<int> sim3Project(orbfe_ctx* ctx, const KeyFrameView& src, const std::vector<int>& ids, const float* Rcw, const float* tcw,
+                               const Sim3& S, const KeyFrameView& dst, float th, const Intrinsics& K, const std::vector<float>& scaleFactors) const {
+    std::vector<int> out(ids.size(), -1), who;
+    std::vector<float> uv, radius;
+    std::vector<int8_t> lo, hi;
+    std::vector<Descriptor> qd;
+    const float logScale = std::log(scaleFactors.size() > 1 ? scaleFactors[1] : 1.2f);
+    for (size_t k = 0; k < ids.size(); ++k) {
+      const int i = ids[k];
+      float pc[3], pm[3];
+      if (Rcw)
+        affine(1.0f, Rcw, &src.pos[3 * (size_t)i], tcw, pc);
+      else
+        for (int a = 0; a < 3; ++a) pc[a] = src.pos[3 * (size_t)i + a];
+      affine(S.s, S.R, pc, S.t, pm);
+      if (pm[2] <= 0) continue;
+      const float u = K.fx * (pm[0] / pm[2]) + K.cx, v = K.fy * (pm[1] / pm[2]) + K.cy;  // Camera::project (src/Camera.cc:14-22)
+      if (!(u < K.maxU && v < K.maxV && u > K.minU && v > K.minV)) continue;
+      const float d = std::sqrt(pm[0] * pm[0] + pm[1] * pm[1] + pm[2] * pm[2]) / S.s;
+      if (!(d < src.maxDist[i] && d > src.minDist[i])) continue;
+      const int o = predictLevel(src.maxDist[i], d, logScale);
+      who.push_back((int)k);
+      uv.push_back(u), uv.push_back(v);
+      radius.push_back(th * (scaleFactors[o] * scaleFactors[o]));
+      lo.push_back((int8_t)(o - 1)), hi.push_back((int8_t)(o + 1));
+      qd.push_back(src.desc[i]);
+    }
+    if (who.empty()) return out;
+    std::vector<uint8_t> ex(dst.kps.size());
+    for (size_t j = 0; j < ex.size(); ++j) ex[j] = !(dst.good[j] && dst.inMap[j]);  // vGoodIndices (:396-405)
+    const AreaMatch m = searchInAreaFeatures(ctx, dst.kps, dst.desc, uv, radius, lo, hi, qd, &ex);
+    for (size_t k = 0; k < who.size(); ++k) {
+      if (m.nCand[k] <= 0) continue;
+      const float ratio = (float)m.bestDist[k] / (float)m.secondDist[k];
+      if (m.bestDist[k] <= mnMinThreshold && ratio <= mfRatio) out[who[k]] = m.bestIdx[k];
+    }
+    return out;
+  }
+  // ORBMatcher::searchBySim3(mpCurr, mpMatch, matches, g2oScm, th) (src/ORBMatcher.cc:424-484); matches: (queryIdx in C, trainIdx in M)
+  int searchBySim3(orbfe_ctx* ctx, const KeyFrameView& C, const KeyFrameView& M, std::vector<std::pair<int, int>>& matches, const Sim3& Scm,
+                   const float* RcwC, const float* tcwC, const float* RcwM, const float* tcwM, float th, const Intrinsics& K,
+                   const std::vector<float>& scaleFactors) const {
+    std::vector<uint8_t> flagC(C.kps.size(), 1), flagM(M.kps.size(), 1);
+    for (const auto& m : matches) flagC[m.first] = 0, flagM[m.second] = 0;
+    std::vector<int> idsC, idsM;
+    for (size_t i = 0; i < C.kps.size(); ++i)
+      if (flagC[i] && C.good[i] && C.inMap[i]) idsC.push_back((int)i);
+    for (size_t i = 0; i < M.kps.size(); ++i)
+      if (flagM[i] && M.good[i]) idsM.push_back((int)i);
+    std::map<int, int> fresh;
+    const std::vector<int> a = sim3Project(ctx, C, idsC, RcwC, tcwC, Scm.inv(), M, th, K, scaleFactors);
+    for (size_t k = 0; k < idsC.size(); ++k)
+      if (a[k] >= 0) fresh.insert({idsC[k], a[k]});
+    const std::vector<int> b = sim3Project(ctx, M, idsM, RcwM, tcwM, Scm, C, th, K, scaleFactors);
+    for (size_t k = 0; k < idsM.size(); ++k)
+      if (b[k] >= 0) fresh.insert({b[k], idsM[k]});
+    for (const auto& m : fresh) matches.push_back(m);
+    return (int)matches.size();
+  }
+  // ORBMatcher::processFuseMps (src/ORBMatcher.cc:623-661): the decision per match; the caller applies it to its map
+  struct FuseAction {
+    enum Kind { Add, Replace } kind;
+    long a, b;  // Add: feature index, map point index; Replace: identity kept, identity dropped
+  };
+  static int processFuseMps(const std::vector<DMatch>& matches, const std::vector<uint8_t>& fGood, const std::vector<long>& fId,
+                            const std::vector<int>& fObs, const std::vector<uint8_t>& vGood, const std::vector<long>& vId,
+                            const std::vector<int>& vObs, bool bLoop, std::vector<FuseAction>& actions) {
+    int nFuse = 0;
+    for (const DMatch& m : matches) {
+      const int q = m.queryIdx, t = m.trainIdx;
+      if (!vGood[t]) continue;
+      if (!fGood[q]) {
+        actions.push_back({FuseAction::Add, q, t});
+        ++nFuse;
+      } else if (fId[q] != vId[t]) {
+        const bool keepV = bLoop || fObs[q] < vObs[t];
+        actions.push_back({FuseAction::Replace, keepV ? vId[t] : fId[q], keepV ? fId[q] : vId[t]});
+        ++nFuse;
+      }
+    }
+    return nFuse;
+  }
+
   // ORBMatcher::verifyAngle (src/ORBMatcher.cc:1013-1051)
   static void verifyAngle(std::vector<DMatch>& matches, const std::vector<float>& angles1, const std::vector<float>& angles2) {
     std::vector<std::vector<DMatch>> hist(mnBinNum);

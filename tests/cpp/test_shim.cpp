@@ -73,6 +73,30 @@ int main(int argc, char** argv) {
       orbfe::ORBMatcher::verifyAngle(mm, ang, ang);
       printf(" %d/%zu/%zu", selfm, before, mm.size());
     }
+    // ORBMatcher::searchBySim3 with the identity similarity between a keyframe and a copy of itself (uploaded feature sets): every
+    // map point projects onto its own feature and must match it
+    {
+      orbfe::ORBMatcher::KeyFrameView kf;
+      kf.kps = kl, kf.desc = dl;
+      const size_t n = kl.size();
+      kf.pos.resize(3 * n), kf.good.assign(n, 1), kf.inMap.assign(n, 1), kf.maxDist.assign(n, 0.f), kf.minDist.assign(n, 0.f);
+      const float fx = 718.856f, cx = 607.1928f, cy = 185.2157f;
+      std::vector<float> sf(8);
+      orbfe::check(el.context(), orbfe_get_scale_factors(el.context(), sf.data(), 8));
+      for (size_t i = 0; i < n; ++i) {
+        const float z = 10.f;
+        kf.pos[3 * i] = (kl[i].x - cx) / fx * z, kf.pos[3 * i + 1] = (kl[i].y - cy) / fx * z, kf.pos[3 * i + 2] = z;
+        const float d = std::sqrt(kf.pos[3 * i] * kf.pos[3 * i] + kf.pos[3 * i + 1] * kf.pos[3 * i + 1] + z * z);
+        kf.maxDist[i] = d * sf[kl[i].octave] * 1.01f, kf.minDist[i] = 0.5f * d;   // predictLevel(d) == the feature's own octave
+      }
+      const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, zero[3] = {0, 0, 0};
+      std::vector<std::pair<int, int>> mm = {{0, 0}};
+      const orbfe::ORBMatcher::Intrinsics K = {fx, fx, cx, cy, 0.f, (float)w, 0.f, (float)h};
+      orbfe::ORBMatcher(1.0f).searchBySim3(el.context(), kf, kf, mm, orbfe::ORBMatcher::Sim3(), I, zero, I, zero, 7.5f, K, sf);
+      size_t self = 0;
+      for (const auto& m : mm) self += m.first == m.second;
+      printf(" %zu/%zu", self, mm.size());
+    }
     // local BA through the Optimizer mirror: 4 keyframes (2 fixed) looking at a 5x4x2 grid of points, exact stereo
     // measurements, perturbed free poses and points -> the optimum is the truth
     {

@@ -343,7 +343,9 @@ def test_cpp_host_mirror_matches_oracle(orc, tmp_path):
     L.tofile(tmp_path / "L.raw")
     R.tofile(tmp_path / "R.raw")
     out = subprocess.run([exe, str(tmp_path / "L.raw"), str(tmp_path / "R.raw"), "1241", "376"], capture_output=True, text=True, check=True)
-    nl, nr, nm, hk, hd, d01, self_found, proj, ba_err, ba_bad, ba_iters = out.stdout.split()
+    nl, nr, nm, hk, hd, d01, self_found, proj, sim3, ba_err, ba_bad, ba_iters = out.stdout.split()
+    s_self, s_all = map(int, sim3.split("/"))
+    assert s_self == s_all and s_all > 0.85 * int(nl)             # ORBMatcher::searchBySim3 (uploaded keyframe features): self matches
     found, asked = map(int, self_found.split("/"))
     assert found == asked == 200                                   # ORBMatcher::searchInArea: every keypoint finds itself
     selfm, n_proj, n_kept = map(int, proj.split("/"))
