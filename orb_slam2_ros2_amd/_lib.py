@@ -100,7 +100,7 @@ EXPORTS = [
     "orbfe_abi_version", "orbfe_create", "orbfe_destroy", "orbfe_last_error", "orbfe_get_level_info", "orbfe_get_scale_factors",
     "orbfe_get_capacity",
     "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_slot", "orbfe_fetch_batch", "orbfe_fetch_stereo_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
-    "orbfe_host_alloc", "orbfe_host_free", "orbfe_stream_submit", "orbfe_stream_wait", "orbfe_stream_device_results",
+    "orbfe_host_alloc", "orbfe_host_free", "orbfe_stream_submit", "orbfe_stream_wait", "orbfe_stream_device_results", "orbfe_record_bytes", "orbfe_stream_pack_records",
     "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_search_in_area_features", "orbfe_extract_color", "orbfe_frame_rgbd", "orbfe_project_map_points",
     "orbfe_map_pb_summary", "orbfe_map_pb_reencode", "orbfe_map_local_graph", "orbfe_map_local_ba",
     "orbfe_profile_enable", "orbfe_profile_read", "orbfe_stage_name", "orbfe_debug_candidates",
@@ -152,6 +152,9 @@ def load() -> C.CDLL:
     L.orbfe_stream_submit.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, i32, f32, f32, C.POINTER(BatchResults), C.POINTER(C.c_int64)]
     L.orbfe_stream_wait.argtypes = [vp, C.c_int64]
     L.orbfe_stream_device_results.argtypes = [vp, C.c_int64, i32] + [C.POINTER(vp)] * 6
+    L.orbfe_record_bytes.argtypes = [vp]
+    L.orbfe_record_bytes.restype = C.c_size_t
+    L.orbfe_stream_pack_records.argtypes = [vp, C.c_int64, i32, vp]
     L.orbfe_fetch_features.argtypes = [vp, i32, vp, vp, vp]
     L.orbfe_fetch_stereo.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.orbfe_device_results.argtypes = [vp] + [C.POINTER(vp)] * 6
@@ -410,6 +413,13 @@ class Context:
 
     def stream_wait(self, ticket):
         self._check(self.lib.orbfe_stream_wait(self.h, ticket))
+
+    def record_bytes(self) -> int:
+        return int(self.lib.orbfe_record_bytes(self.h))
+
+    def stream_pack_records(self, ticket, n_pairs, d_records_ptr):
+        """frame records of a live ticket -> device memory at d_records_ptr (n_pairs * record_bytes() bytes); returns when complete"""
+        self._check(self.lib.orbfe_stream_pack_records(self.h, ticket, n_pairs, d_records_ptr))
 
     def stream_device_results(self, ticket, n_pairs):
         """device pointers (ints) of the packed results of a live ticket: dict kps, desc, counts, right_u, depth, n_match"""

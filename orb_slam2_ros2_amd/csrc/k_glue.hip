@@ -91,6 +91,38 @@ __global__ __launch_bounds__(256) void k_frame_rgbd(orbfe_keypoint* __restrict__
   right_u_out[i] = ru_out;
 }
 
+// Frame records for the sequence-level gather: what Frame::createStereo leaves behind for the tracker, one fixed-size
+// record per stereo pair, packed from the stream's result buffer:
+//   int32 n_keypoints | int32 n_matches | 8 bytes pad | left keypoints [NF x 28 B] | left descriptors [NF x 32 B] | right_u [NF] f64 | depth [NF] f64
+// Entries past the keypoint count are zeroed, so a record depends on nothing but its frame.  One workgroup per pair, 4-byte units
+// (every section starts on a multiple of 4: 16, 16 + 28 NF, ...); a pure copy, HBM-bound.
+__global__ __launch_bounds__(256) void k_pack_records(const uint8_t* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                      const int32_t* __restrict__ counts, const uint8_t* __restrict__ right_u,
+                                                      const uint8_t* __restrict__ depth, const int32_t* __restrict__ n_match, int nf,
+                                                      uint32_t* __restrict__ out, size_t rec_words) {
+  const int p = blockIdx.x;
+  const int n = min(max(counts[2 * p], 0), nf);  // the LEFT image of pair p sits in slot 2p
+  uint32_t* rec = out + (size_t)p * rec_words;
+  if (threadIdx.x < 4) rec[threadIdx.x] = threadIdx.x == 0 ? (uint32_t)n : (threadIdx.x == 1 ? (uint32_t)n_match[p] : 0u);
+  const uint32_t* src[4] = {(const uint32_t*)(kps + (size_t)(2 * p) * nf * 28), (const uint32_t*)(desc + (size_t)(2 * p) * nf * 32),
+                            (const uint32_t*)(right_u + (size_t)p * nf * 8), (const uint32_t*)(depth + (size_t)p * nf * 8)};
+  const int wpe[4] = {7, 8, 2, 2};  // words per entry
+  size_t o = 4;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int live = n * wpe[s], total = nf * wpe[s];
+    for (int i = threadIdx.x; i < total; i += 256) rec[o + i] = i < live ? src[s][i] : 0u;
+    o += (size_t)total;
+  }
+}
+
+void launch_pack_records(hipStream_t s, const uint8_t* d_kps, const uint8_t* d_desc, const int32_t* d_counts, const uint8_t* d_ru,
+                         const uint8_t* d_dp, const int32_t* d_nm, int nf, int n_pairs, void* d_out) {
+  if (n_pairs <= 0) return;
+  const size_t rec_words = 4 + (size_t)nf * (7 + 8 + 2 + 2);
+  hipLaunchKernelGGL(k_pack_records, dim3(n_pairs), dim3(256), 0, s, d_kps, d_desc, d_counts, d_ru, d_dp, d_nm, nf, (uint32_t*)d_out, rec_words);
+}
+
 void launch_cvt_gray(hipStream_t s, const uint8_t* d_src, size_t src_stride, uint8_t* d_dst, int dst_stride, int w, int h, int order,
                      int variant) {
   hipLaunchKernelGGL(k_cvt_gray, dim3((w + 1023) / 1024, h), dim3(256), 0, s, d_src, src_stride, d_dst, dst_stride, w, order, variant);

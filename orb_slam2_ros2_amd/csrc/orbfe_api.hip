@@ -55,6 +55,8 @@ void launch_cvt_gray(hipStream_t s, const uint8_t* d_src, size_t src_stride, uin
                      int variant);
 void launch_frame_rgbd(hipStream_t s, orbfe_keypoint* d_kps, const int32_t* d_n_kp, int n_features, const orbfe_camera& cam,
                        const uint8_t* d_depth, int depth_type, size_t depth_stride, float depth_scale, double* d_depth_out, double* d_right_u);
+void launch_pack_records(hipStream_t s, const uint8_t* d_kps, const uint8_t* d_desc, const int32_t* d_counts, const uint8_t* d_ru,
+                         const uint8_t* d_dp, const int32_t* d_nm, int nf, int n_pairs, void* d_out);
 // k_lba.hip
 void launch_lba_chi2_sum(hipStream_t s, int n_edges, const double* chi2, const double* rho, const uint8_t* level, double* chi2_last,
                          double* out);
@@ -1556,6 +1558,31 @@ orbfe_status orbfe_stream_device_results(orbfe_ctx* c, int64_t ticket, int32_t n
   if (d_right_u) *d_right_u = b + l.o_ru;
   if (d_depth) *d_depth = b + l.o_dp;
   if (d_nmatch) *d_nmatch = b + l.o_nm;
+  return ORBFE_OK;
+}
+
+// Frame records of a ticket (layout: k_glue.hip, k_pack_records) into caller-provided DEVICE memory, for the sequence-level gather.
+size_t orbfe_record_bytes(const orbfe_ctx* c) { return c ? 16 + (size_t)std::max(c->cfg.n_features, 1) * (28 + 32 + 8 + 8) : 0; }
+
+orbfe_status orbfe_stream_pack_records(orbfe_ctx* c, int64_t ticket, int32_t n_pairs, void* d_records) {
+  if (!c || !d_records) return fail(c, ORBFE_EBADARG, "stream_pack_records: NULL argument");
+  orbfe_ctx::HostStream& hs = c->hs;
+  if (!hs.init || ticket < 0 || ticket >= hs.next_ticket || ticket + orbfe_ctx::HostStream::kDepth < hs.next_ticket || n_pairs <= 0 ||
+      2 * n_pairs > c->cfg.max_images)
+    return fail(c, ORBFE_EBADARG, "stream_pack_records: ticket %lld is not live (next %lld) or bad pair count %d", (long long)ticket,
+                (long long)hs.next_ticket, n_pairs);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int b = (int)(ticket % orbfe_ctx::HostStream::kDepth);
+  const PackLayout l = pack_layout(c, n_pairs);
+  const uint8_t* src = hs.d_out[b];
+  // on the download stream, behind the ticket's own completion: ordered after the results are in the buffer and before the
+  // buffer is handed to ticket + 3 (whose pack waits for the event recorded here)
+  HIP_TRY(c, hipStreamWaitEvent(hs.d2h, hs.ev_done[b], 0));
+  launch_pack_records(hs.d2h, src + l.o_kps, src + l.o_desc, (const int32_t*)(src + l.o_cnt), src + l.o_ru, src + l.o_dp,
+                      (const int32_t*)(src + l.o_nm), std::max(c->cfg.n_features, 1), n_pairs, d_records);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipEventRecord(hs.ev_done[b], hs.d2h));
+  HIP_TRY(c, hipEventSynchronize(hs.ev_done[b]));
   return ORBFE_OK;
 }
 

@@ -94,9 +94,9 @@ class DeviceSequenceProcessor:
     make_pair(frame_id) -> (left, right) uint8 images; prepare() builds the page-locked batch buffers of this rank's frames before
     the clock starts (a camera driver or an image decoder would write there directly)."""
 
-    def __init__(self, ctx, make_pair, batch_pairs, fx, bf, device):
+    def __init__(self, ctx, make_pair, batch_pairs, fx, bf, device, torch_pack=False):
         self.ctx, self.make_pair, self.batch, self.fx, self.bf, self.device = ctx, make_pair, batch_pairs, fx, bf, device
-        self.pinned = {}
+        self.pinned, self.torch_pack = {}, torch_pack
 
     def prepare(self, frame_ids):
         from ._lib import PinnedArray
@@ -129,8 +129,13 @@ class DeviceSequenceProcessor:
         if handle is None:
             return torch.zeros((0, record_bytes(nf)), dtype=torch.uint8, device=self.device)
         ticket, n = handle
-        self.ctx.stream_wait(ticket)   # the packed results of this ticket are in the stream's device buffer
-        views = batch_result_views(self.ctx.stream_device_results(ticket, n), n, nf, self.device)
-        rec = pack_records(*views)
-        torch.cuda.current_stream(self.device).synchronize()   # the buffer is re-used three submits later
+        if self.torch_pack:   # the same records with torch ops on views of the stream's result buffer (kept as the checker of the kernel)
+            self.ctx.stream_wait(ticket)
+            views = batch_result_views(self.ctx.stream_device_results(ticket, n), n, nf, self.device)
+            rec = pack_records(*views)
+            torch.cuda.current_stream(self.device).synchronize()   # the buffer is re-used three submits later
+            return rec
+        rec = torch.empty((n, self.ctx.record_bytes()), dtype=torch.uint8, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()       # (the allocation is visible to the library's stream)
+        self.ctx.stream_pack_records(ticket, n, rec.data_ptr())    # the library's pack kernel, straight into the tensor
         return rec

@@ -101,6 +101,11 @@ def test_sequence_driver_on_the_device_equals_golden():
     rec, n_local = run_sequence(n_frames, 0, 1, batch, proc.submit, proc.collect)
     assert n_local == n_frames and tuple(rec.shape) == (n_frames, record_bytes(ctx.n_features))
     rec = rec.cpu().numpy()
+    # the library's pack kernel against the same records assembled with torch ops from the stream's result buffer
+    proc_t = DeviceSequenceProcessor(ctx, lambda f: synth.stereo_pair(f % 32), batch, FX, BF, torch.device("cuda", 0), torch_pack=True)
+    proc_t.pinned = proc.pinned
+    rec_t, _ = run_sequence(n_frames, 0, 1, batch, proc_t.submit, proc_t.collect)
+    assert np.array_equal(rec_t.cpu().numpy(), rec)
     ref = {}
     for f in range(n_frames):
         u = unpack_record(rec[f], ctx.n_features)
