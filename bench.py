@@ -174,7 +174,7 @@ def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend):
     b, e = frame_range(F, rank, world)
     B = max(1, min(B, max(e - b, 1)))
     ctx = Context(W, H, NFEAT, NLEVELS, SCALE, TH_HI, TH_LO, device_id=local_rank, max_images=2 * B)
-    proc = DeviceSequenceProcessor(ctx, lambda f: synth.stereo_pair(f % U, W, H), B, FX, BF, dev)
+    proc = DeviceSequenceProcessor(ctx, lambda f: synth.stereo_pair(f % U, W, H), B, FX, BF, dev, content_key=lambda f: f % U)
     proc.prepare(range(b, e))   # page-locked batches of this rank's block, built before the clock starts
 
     def to_xdev(t):
