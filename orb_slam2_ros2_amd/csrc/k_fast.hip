@@ -19,8 +19,12 @@
 //      appended -- in raster order, one entry per polarity that passed -- to an LDS queue with ballot/prefix;
 //   3. the queue is processed densely, one entry per lane: the entry's polarity is scored in 32-bit registers (v_mad_i32_i24 applies
 //      the sign, v_min3_i32 / v_max3_i32 the arcs) into a zero-bordered V map, V = max(A, B) where both polarities were queued;
-//   4. NMS and the hi/lo decision run over the queue only, never over the whole patch again; the kept maxima
-//      are appended to the level's candidate list (one atomic reservation per cell).
+//   4. NMS runs over the queue only, never over the whole patch again; the kept maxima are appended to the level's
+//      candidate list (one atomic reservation per cell).
+// Steps 2-4 run with the HIGH threshold first: a pixel with V <= hi can never suppress one with V > hi (V(p) > hi >= V(q)), so the
+// map of the hi-survivors alone gives cv::FAST(hi) exactly -- and only a cell where that comes out empty (4 % of the cells of level
+// 0 on the synthetic frames, none on the coarse levels) repeats them with the LOW threshold (ORBExtractor.cc:365-367).  The test at
+// hi passes 13 ... 37 % of the pixels against 16 ... 47 % at lo: 3.4 instead of 4.45 scoring trips per cell.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
   uint8_t* V = (uint8_t*)lds_w + lds_v_off;  // (ih+2) rows of scores with a zero border, pitch PV, pixel (iy,ix) at V[(iy+1)*PV + ix+1]
   uint16_t* Q = (uint16_t*)((uint8_t*)lds_w + lds_q_off);  // [q_cap] survivors from the front; pixels that need the second
                                                            // polarity too are listed again from the back
-  uint8_t* F = P;  // per queue entry: bit0 = max & V>lo, bit1 = max & V>hi; the patch is dead by then (nq <= iw*ih < patch bytes)
+  // (the NMS verdict of a queue entry goes into bit 14 of the entry itself: its polarity / dual tags are spent by then)
 
   const int lane = threadIdx.x & 63;
   const int img = blockIdx.y;
@@ -107,8 +111,6 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
   const int pw = cell.pw, ph = cell.ph;
   const int iw = pw - 6, ih = ph - 6;  // interior cv::FAST scans: rows/cols 3 .. size-4
   if (iw <= 0 || ih <= 0) return;
-  const int t_min = min(t_hi, t_lo);
-
   // ---- 1. patch -> LDS: 16-byte units (PP / 16 per row: 3 for the 30-px grid's patches), 21 rows per pass, every pass of a lane
   //         requested before the first is parked (rows clamped, so the loads are unconditional): two loads and two stores per lane
   //         for a 36-row patch where 32-bit words took nine of each plus their address arithmetic (~ 60 of the kernel's ~1080 VALU
@@ -153,130 +155,134 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
   }
   WAVE_SYNC();
 
-  // ---- 2. necessary test on every interior pixel; survivors -> queue, tagged with the polarity to score.  The wave covers
-  //         a (64/lw rows) x (lw columns) tile per step, lw = 16/32/64 by cell width, so addresses advance by a constant.
-  //         (The queue order is free: NMS does not depend on it and the candidate list of a level is a set.  Two pixels
-  //         per lane in packed halves would need unaligned 16-bit LDS reads: measured ~20 cycles each on gfx950.)
-  int nq = 0, nd = 0;
-  bool d_overflow = false;
-  {
-    const int shift = iw <= 16 ? 4 : (iw <= 32 ? 5 : 6);
-    const int lw = 1 << shift, rpi = 64 >> shift;
-    const int lx = lane & (lw - 1), ly = lane >> shift;
-    for (int x0 = 0; x0 < iw; x0 += lw) {
-      const int ix = x0 + lx;
-      const uint8_t* a0 = P + ly * PP + xa + ix;  // top-left corner of the pixel's 7x7 window
-      const uint32_t e_lane = (uint32_t)ix | ((uint32_t)ly << 7);
-      const int thr_x = ix < iw ? t_min : 0x7FFF;
-      const uint8_t* a = a0;
-      // every predicate is ONE vector compare whose lane mask feeds the ballot and the branch directly (a predicate built from
-      // several masks is expanded to 0 / 1 per lane and compared again before a ballot: two more VALU instructions each)
-      auto trip = [&](const int y0, const int thr) __attribute__((always_inline)) {
-        const int v = a[3 * PP + 3];
-        const int r0 = a[6 * PP + 3], r8 = a[3], r4 = a[3 * PP + 6], r12 = a[3 * PP];
-        const int r2 = a[5 * PP + 5], r10 = a[PP + 1], r6 = a[PP + 5], r14 = a[5 * PP + 1];
-        const int lo_of_hi = min(min(max(r0, r8), max(r4, r12)), min(max(r2, r10), max(r6, r14)));
-        const int hi_of_lo = max(max(min(r0, r8), min(r4, r12)), max(min(r2, r10), min(r6, r14)));
-        const int sb = lo_of_hi - v;  // > t: every opposite pair has a pixel brighter than v + t
-        const int sd = v - hi_of_lo;  // > t: ... darker than v - t
-        const bool any = max(sb, sd) > thr, dual = min(sb, sd) > thr;
-        const unsigned long long m = __ballot(any), m2 = __ballot(dual);
-        const uint32_t eh = e_lane + ((uint32_t)y0 << 7);
-        if (any) Q[nq + mbcnt64(m, 0)] = (uint16_t)(eh | (sd > thr ? 0u : Q_BRIGHT) | (dual ? Q_DUAL : 0u));
-        nq += __popcll(m);
-        if (m2) {  // both polarities passed: the main entry scores the dark one, the list at the back of Q the bright one
-          const int k = __popcll(m2);
-          if (nq + nd + k <= q_cap) {
-            if (dual) Q[q_cap - 1 - (nd + mbcnt64(m2, 0))] = (uint16_t)eh;
-            nd += k;
-          } else {
-            d_overflow = true;  // (pathological cell) the tagged entries are re-scanned one by one below
+  int nq = 0, n_keep = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int t_pass = pass == 0 ? t_hi : t_lo;  // cv::FAST(patch, hi); if that yields nothing: cv::FAST(patch, lo)
+    if (pass == 1) {
+      if (t_lo >= t_hi) break;  // the second call could only return a subset of the (empty) first
+      const int vq = ((ih + 2) * PV + 3 + 15) >> 4;
+      uint4* V128 = (uint4*)V;
+      for (int k = lane; k < vq; k += 64) V128[k] = make_uint4(0u, 0u, 0u, 0u);
+      WAVE_SYNC();
+    }
+    // ---- 2. necessary test on every interior pixel; survivors -> queue, tagged with the polarity to score.  The wave covers
+    //         a (64/lw rows) x (lw columns) tile per step, lw = 16/32/64 by cell width, so addresses advance by a constant.
+    //         (The queue order is free: NMS does not depend on it and the candidate list of a level is a set.  Two pixels
+    //         per lane in packed halves would need unaligned 16-bit LDS reads: measured ~20 cycles each on gfx950.)
+    nq = 0;
+    int nd = 0;
+    bool d_overflow = false;
+    {
+      const int shift = iw <= 16 ? 4 : (iw <= 32 ? 5 : 6);
+      const int lw = 1 << shift, rpi = 64 >> shift;
+      const int lx = lane & (lw - 1), ly = lane >> shift;
+      for (int x0 = 0; x0 < iw; x0 += lw) {
+        const int ix = x0 + lx;
+        const uint8_t* a0 = P + ly * PP + xa + ix;  // top-left corner of the pixel's 7x7 window
+        const uint32_t e_lane = (uint32_t)ix | ((uint32_t)ly << 7);
+        const int thr_x = ix < iw ? t_pass : 0x7FFF;
+        const uint8_t* a = a0;
+        // every predicate is ONE vector compare whose lane mask feeds the ballot and the branch directly (a predicate built from
+        // several masks is expanded to 0 / 1 per lane and compared again before a ballot: two more VALU instructions each)
+        auto trip = [&](const int y0, const int thr) __attribute__((always_inline)) {
+          const int v = a[3 * PP + 3];
+          const int r0 = a[6 * PP + 3], r8 = a[3], r4 = a[3 * PP + 6], r12 = a[3 * PP];
+          const int r2 = a[5 * PP + 5], r10 = a[PP + 1], r6 = a[PP + 5], r14 = a[5 * PP + 1];
+          const int lo_of_hi = min(min(max(r0, r8), max(r4, r12)), min(max(r2, r10), max(r6, r14)));
+          const int hi_of_lo = max(max(min(r0, r8), min(r4, r12)), max(min(r2, r10), min(r6, r14)));
+          const int sb = lo_of_hi - v;  // > t: every opposite pair has a pixel brighter than v + t
+          const int sd = v - hi_of_lo;  // > t: ... darker than v - t
+          const bool any = max(sb, sd) > thr, dual = min(sb, sd) > thr;
+          const unsigned long long m = __ballot(any), m2 = __ballot(dual);
+          const uint32_t eh = e_lane + ((uint32_t)y0 << 7);
+          if (any) Q[nq + mbcnt64(m, 0)] = (uint16_t)(eh | (sd > thr ? 0u : Q_BRIGHT) | (dual ? Q_DUAL : 0u));
+          nq += __popcll(m);
+          if (m2) {  // both polarities passed: the main entry scores the dark one, the list at the back of Q the bright one
+            const int k = __popcll(m2);
+            if (nq + nd + k <= q_cap) {
+              if (dual) Q[q_cap - 1 - (nd + mbcnt64(m2, 0))] = (uint16_t)eh;
+              nd += k;
+            } else {
+              d_overflow = true;  // (pathological cell) the tagged entries are re-scanned one by one below
+            }
           }
-        }
-      };
-      // lanes right of the interior can never pass (thr_x), so the column test costs nothing per trip; the row test is only needed in
-      // the last, partial trip of a column block (its rows past the interior are read -- they lie inside this wave's carve-up -- but
-      // cannot pass either)
-      int y0 = 0;
-      for (; y0 + rpi <= ih; y0 += rpi, a += rpi * PP) trip(y0, thr_x);
-      if (y0 < ih) trip(y0, y0 + ly < ih ? thr_x : 0x7FFF);
+        };
+        // lanes right of the interior can never pass (thr_x), so the column test costs nothing per trip; the row test is only needed in
+        // the last, partial trip of a column block (its rows past the interior are read -- they lie inside this wave's carve-up -- but
+        // cannot pass either)
+        int y0 = 0;
+        for (; y0 + rpi <= ih; y0 += rpi, a += rpi * PP) trip(y0, thr_x);
+        if (y0 < ih) trip(y0, y0 + ly < ih ? thr_x : 0x7FFF);
+      }
     }
-  }
-  if (nq + nd > q_cap) {  // the front grew into the back list after it was written: drop the list, re-scan instead
-    nd = 0;
-    d_overflow = true;
-  }
-  WAVE_SYNC();
-
-  // ---- 3. exact test + score for the survivors, one queue entry per lane (trips of 64).  Only about
-  //         half of the survivors are corners: those (and the dual-tagged entries, whose second polarity is still to come) are
-  //         compacted in place at the front of Q, so that the NMS and the output pass touch no entry that cannot matter.
-  int nc = 0;
-  for (int j0 = 0; j0 < nq; j0 += 64) {
-    const bool act = j0 + lane < nq;
-    const uint32_t q = Q[min(j0 + lane, nq - 1)];
-    const int ix = Q_IX(q), iy = Q_IY(q);
-    const int A = arc_score1<PP>(P + iy * PP + xa + ix, (q & Q_BRIGHT) ? -1 : 1);
-    const bool c = act && A > t_min;
-    if (c) V[(iy + 1) * PV + ix + 1] = (uint8_t)min(255, A);
-    const bool keep = c || (act && (q & Q_DUAL));
-    const unsigned long long m = __ballot(keep);
-    if (keep) Q[nc + mbcnt64(m, 0)] = (uint16_t)q;  // (in place: this trip's entries were all read above, later trips read further back)
-    nc += __popcll(m);
-  }
-  nq = nc;
-  if (nd > 0 || d_overflow) {
+    if (nq + nd > q_cap) {  // the front grew into the back list after it was written: drop the list, re-scan instead
+      nd = 0;
+      d_overflow = true;
+    }
     WAVE_SYNC();
-    for (int j = lane; j < nd; j += 64) {  // the back list: V = max(A, B)
-      const uint32_t q = Q[q_cap - 1 - j];
+
+    // ---- 3. exact test + score for the survivors, one queue entry per lane (trips of 64).  Only about
+    //         half of the survivors are corners: those (and the dual-tagged entries, whose second polarity is still to come) are
+    //         compacted in place at the front of Q, so that the NMS and the output pass touch no entry that cannot matter.
+    int nc = 0;
+    for (int j0 = 0; j0 < nq; j0 += 64) {
+      const bool act = j0 + lane < nq;
+      const uint32_t q = Q[min(j0 + lane, nq - 1)];
       const int ix = Q_IX(q), iy = Q_IY(q);
-      const int B = arc_score1<PP>(P + iy * PP + xa + ix, -1);
-      uint8_t* vp = V + (iy + 1) * PV + ix + 1;
-      if (B > t_min) *vp = (uint8_t)max((int)*vp, min(255, B));
+      const int A = arc_score1<PP>(P + iy * PP + xa + ix, (q & Q_BRIGHT) ? -1 : 1);
+      const bool c = act && A > t_pass;
+      if (c) V[(iy + 1) * PV + ix + 1] = (uint8_t)min(255, A);
+      const bool keep = c || (act && (q & Q_DUAL));
+      const unsigned long long m = __ballot(keep);
+      if (keep) Q[nc + mbcnt64(m, 0)] = (uint16_t)q;  // (in place: this trip's entries were all read above, later trips read further back)
+      nc += __popcll(m);
     }
-    if (d_overflow) {  // entries that did not fit the back list (max is idempotent, so re-scoring listed ones is harmless)
-      for (int q = lane; q < nq; q += 64) {
-        const uint32_t e = Q[q];
-        if (e & Q_DUAL) {
-          const int ix = Q_IX(e), iy = Q_IY(e);
-          const uint8_t* a = P + iy * PP + xa + ix;
-          const int B = arc_score1<PP>(a, -1);
-          uint8_t* vp = V + (iy + 1) * PV + ix + 1;
-          if (B > t_min) *vp = (uint8_t)max((int)*vp, min(255, B));
+    nq = nc;
+    if (nd > 0 || d_overflow) {
+      WAVE_SYNC();
+      for (int j = lane; j < nd; j += 64) {  // the back list: V = max(A, B)
+        const uint32_t q = Q[q_cap - 1 - j];
+        const int ix = Q_IX(q), iy = Q_IY(q);
+        const int B = arc_score1<PP>(P + iy * PP + xa + ix, -1);
+        uint8_t* vp = V + (iy + 1) * PV + ix + 1;
+        if (B > t_pass) *vp = (uint8_t)max((int)*vp, min(255, B));
+      }
+      if (d_overflow) {  // entries that did not fit the back list (max is idempotent, so re-scoring listed ones is harmless)
+        for (int q = lane; q < nq; q += 64) {
+          const uint32_t e = Q[q];
+          if (e & Q_DUAL) {
+            const int ix = Q_IX(e), iy = Q_IY(e);
+            const uint8_t* a = P + iy * PP + xa + ix;
+            const int B = arc_score1<PP>(a, -1);
+            uint8_t* vp = V + (iy + 1) * PV + ix + 1;
+            if (B > t_pass) *vp = (uint8_t)max((int)*vp, min(255, B));
+          }
         }
       }
     }
-  }
-  WAVE_SYNC();
+    WAVE_SYNC();
 
-  // ---- 4. NMS over the queue, hi/lo decision, append to the level's candidate list ----
-  int n_hi = 0, n_lo = 0;
-  {
+    // ---- 4. NMS over the queue: an entry is kept iff its score beats its 8 neighbours' (0 where nothing was scored) ----
+    n_keep = 0;
     for (int q0 = 0; q0 < nq; q0 += 64) {
       const int q = q0 + lane;
-      int f = 0;
+      bool is_max = false;
       if (q < nq) {
         const uint32_t e = Q[q];
         const uint8_t* c = V + Q_IY(e) * PV + Q_IX(e);  // top-left corner of the 3x3 neighbourhood
         const int v = c[PV + 1];
-        if (v != 0) {
-          const bool is_max = v > c[0] && v > c[1] && v > c[2] && v > c[PV] && v > c[PV + 2] && v > c[2 * PV] && v > c[2 * PV + 1] &&
-                              v > c[2 * PV + 2];
-          if (is_max) f = ((v > t_hi) ? 2 : 0) | ((v > t_lo) ? 1 : 0);
-        }
-        F[q] = (uint8_t)f;
+        is_max = v != 0 && v > c[0] && v > c[1] && v > c[2] && v > c[PV] && v > c[PV + 2] && v > c[2 * PV] && v > c[2 * PV + 1] && v > c[2 * PV + 2];
+        Q[q] = (uint16_t)(Q_XY(e) | (is_max ? Q_BRIGHT : 0u));  // (scores in the map are > t_pass by construction)
       }
-      n_hi += __popcll(__ballot((f & 2) != 0));
-      n_lo += __popcll(__ballot((f & 1) != 0));
+      n_keep += __popcll(__ballot(is_max));
     }
+    WAVE_SYNC();
+    if (n_keep > 0) break;
   }
-  WAVE_SYNC();
   {
-    // cv::FAST(hi) result if non-empty, else cv::FAST(lo) (ORBExtractor.cc:365-367).  The list of a level is a SET:
-    // the quadtree orders candidates by (cell, y, x) recomputed from the coordinates, so cells may append in any
-    // order -- one atomic reservation per cell, then the wave writes its records.
-    const int want = n_hi > 0 ? 2 : 1;
-    const int total = n_hi > 0 ? n_hi : n_lo;
+    // The list of a level is a SET: the quadtree orders candidates by (cell, y, x) recomputed from the coordinates, so cells may
+    // append in any order -- one atomic reservation per cell, then the wave writes its records.
+    const int total = n_keep;
     if (total == 0) return;
     int base = 0;
     if (lane == 0) base = atomicAdd(&n_cand[(size_t)img * n_levels + cell.level], total);
@@ -285,10 +291,10 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
     int cnt = 0;
     for (int q0 = 0; q0 < nq; q0 += 64) {
       const int q = q0 + lane;
-      const bool keep = (q < nq) && ((F[q] & want) != 0);
+      const uint32_t e = q < nq ? (uint32_t)Q[q] : 0u;
+      const bool keep = (e & Q_BRIGHT) != 0;
       const unsigned long long m = __ballot(keep);
       if (keep) {
-        const uint32_t e = Q[q];
         const int ix = Q_IX(e), iy = Q_IY(e);
         out[cnt + mbcnt64(m, 0)] = ORBFE_PACK_XYR(ix + 3 + cell.offx, iy + 3 + cell.offy, V[(iy + 1) * PV + ix + 1] - 1);
       }
