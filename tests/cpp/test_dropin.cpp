@@ -344,10 +344,44 @@ static int mode_poseonly() {
   return (pose_diff == 0 && kept == good && inlier_marks == kept && good <= good_arrays && good > 250 && err < 0.02) ? 0 : 1;
 }
 
+// host-only: the write-back policy of Optimizer.cc:391-404 at EXACTLY 30 % -- `size / (float)nGoodMp > 0.3` compares a float quotient with
+// a double literal: 3 / 10 = 0.3f widens to 0.30000001192..., which IS greater than 0.3, so the keyframe counts as bad
+static int mode_policy() {
+  using namespace orbfe::mappb;
+  MapRec map;
+  map.scale_factors = {1.f};
+  KeyFrameRec k;
+  k.id = 1;
+  k.rotation = {1, 0, 0, 0, 1, 0, 0, 0, 1}, k.translation = {0, 0, 0};
+  for (int i = 0; i < 10; ++i) {
+    k.keypoints.push_back(KeyPointRec{(float)(10 * i), 5.f, 0, 0.f});
+    k.right_u.push_back(-1.f);
+    k.map_points.push_back(i);
+    MapPointRec m;
+    m.id = (uint64_t)i;
+    m.position[2] = 5.f;
+    map.mappoints.push_back(m);
+  }
+  map.keyframes.push_back(k);
+  LocalGraph g;
+  if (!build_local_graph(map, 1, g) || g.edge_pose.size() != 10) return 1;
+  std::vector<uint8_t> bad(10, 0);
+  bad[0] = bad[4] = bad[7] = 1;  // 3 of 10
+  MapRec m3 = map;
+  const LocalBaReport r3 = apply_local_ba(m3, g, g.poses.data(), g.points.data(), bad.data());
+  bad[7] = 0;  // 2 of 10
+  MapRec m2 = map;
+  const LocalBaReport r2 = apply_local_ba(m2, g, g.poses.data(), g.points.data(), bad.data());
+  printf("POLICY_OK %d %d %d %d\n", r3.n_bad_keyframes, r3.written, r2.n_bad_keyframes, r2.written);
+  // 30 %: the one affected keyframe is bad -> 1 / (1 + 1e-5) > 0.2 -> nothing is written; 20 %: written
+  return (r3.n_bad_keyframes == 1 && r3.written == 0 && r2.n_bad_keyframes == 0 && r2.written == 1) ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
   try {
     const std::string mode = argv[1];
+    if (mode == "policy") return mode_policy();
     if (mode == "threads") return mode_threads(argc, argv);
     if (mode == "localba") return mode_localba(argc, argv);
     if (mode == "poseonly") return mode_poseonly();

@@ -118,6 +118,9 @@ def test_dropin_header_compiles_against_the_stand_in_opencv_and_fails_loudly_wit
 
     import torch
     exe = _build_dropin(tmp_path)
+    # host-only mode: the write-back policy of OptimizeLocalMap at exactly 30 % outliers in a keyframe (float quotient vs double 0.3)
+    pol = subprocess.run([exe, "policy"], capture_output=True, text=True)
+    assert pol.returncode == 0 and pol.stdout.split() == ["POLICY_OK", "1", "0", "0", "1"], pol.stdout + pol.stderr
     if torch.cuda.is_available():
         pytest.skip("a device is present: the run-time half is tests/test_gpu_dropin.py")
     r = subprocess.run([exe, "poseonly"], capture_output=True, text=True)
