@@ -250,14 +250,14 @@ def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--prewarm-seconds", type=float, default=1.5,
                     help="untimed steps run before the W warm-up steps until this much wall time has passed: the GPU needs "
                          "~0.3 s of sustained load to leave its idle clocks (measured: first 30 steps 13 %% slower)")
     ap.add_argument("--pairs", type=int, default=512, help="stereo pairs per step (per GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--host-io-steps", type=int, default=-1, help="steps of the host_io leg (-1: as --steps, 0: skip)")
+    ap.add_argument("--host-io-steps", type=int, default=-1, help="steps of the host_io leg (-1: min(--steps, 200), 0: skip)")
     ap.add_argument("--sequence", type=int, default=0,
                     help="run a whole sequence of this many stereo pairs (BASELINE config 4: 4541), sharded over the ranks, instead of the "
                          "fixed-batch step loop")
@@ -435,7 +435,7 @@ def main():
     del kps_all, desc_all, ru_all, dp_all
 
     host_io = None
-    hio_steps = args.steps if args.host_io_steps < 0 else args.host_io_steps
+    hio_steps = min(args.steps, 200) if args.host_io_steps < 0 else args.host_io_steps
     if hio_steps > 0:
         host_io = host_io_leg(ctx, left_h, right_h, B, hio_steps, want, world, sync_all, dist, torch, xdev)
 
@@ -551,6 +551,9 @@ def main():
             "unit": "stereo pairs/s",
             "cores": 2,
             "kind": "port",
+            "caveat": "a scalar C++ restatement of the reference's algorithm (oracle/): no OpenCV SIMD paths (resize / blur / FAST), so the real "
+                      "reference would be faster on the same cores and gpu_over_cpu overstates the gap; the >= 30x target holds under any "
+                      "reasonable correction, the kernel-quality figure is roofline / roofline_valu, not this ratio",
             "sample": f"{n_done} synthetic 1241x376 stereo pairs, oracle/orb_oracle.cpp -O3 -march=native, L/R extract on 2 threads "
                       f"(Frame.cc:100-105), pairs sequential; host has {os.cpu_count()} cores",
         }

@@ -69,7 +69,10 @@ typedef struct orbfe_config {
   int32_t width, height;       /* level-0 image size (e.g. 1241x376 KITTI, 640x480 TUM)                 */
   int32_t n_features;          /* ORBExtractor.nFeatures.  Capacity limit: the largest per-level quota (level 0) must
                                   stay below ~2700 keypoints (its quadtree node table lives in one CU's LDS), i.e.
-                                  nFeatures <= ~12000 for 8 levels at scale 1.2; larger values fail with ORBFE_EBADARG */
+                                  nFeatures <= ~12000 for 8 levels at scale 1.2; larger values fail with ORBFE_EBADARG.
+                                  (One more deviation, harmless: the quadtree's split loop is capped at 80 N + 1024 steps for N
+                                  candidates; the reference's degenerate case -- fewer candidates than the quota, quirk Q3 -- ends
+                                  by itself after ~50 halvings per point, far below the cap.)                              */
   int32_t n_levels;            /* ORBExtractor.nLevels (<= ORBFE_MAX_LEVELS)                            */
   float scale_factor;          /* ORBExtractor.scaleFactor                                              */
   int32_t fast_hi, fast_lo;    /* ORBExtractor.iniThFAST / minThFAST                                    */
