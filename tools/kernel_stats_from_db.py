@@ -28,3 +28,18 @@ total = sum(r[2] for r in rows) or 1
 print('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","UnionNs"')
 for n, c, t, a, mn, mx, u in rows:
     print(f'"{n}",{c},{t},{a:.3f},{100.0 * t / total:.2f},{mn},{mx},{u}')
+
+# how much of the run the GPU had at least one kernel in flight (all kernels, all streams): wall span of the trace vs union of the
+# kernel intervals -- the difference is launch / dependency gaps, not kernel time
+iv = db.execute("select start, end from kernels order by start").fetchall()
+if iv:
+    union, cs, ce = 0, iv[0][0], iv[0][1]
+    for s_, e_ in iv[1:]:
+        if s_ > ce:
+            union += ce - cs
+            cs, ce = s_, e_
+        else:
+            ce = max(ce, e_)
+    union += ce - cs
+    span = max(e_ for _, e_ in iv) - iv[0][0]
+    print(f'"# all kernels: union busy ns {union}, trace span ns {span}, idle fraction inside the span {1 - union / span:.4f}"')
