@@ -494,7 +494,7 @@ def main():
             # UnionNs / steps of profiles/*_kernel_stats.csv, tools/kernel_stats_from_db.py), not average x NLEVELS
             "kernel_launches_per_step": {"fast": NLEVELS, "orient_brief": 4, "resize": 1, "blur": 1, "quadtree": 1, "stereo": 1}[dom],
             "avg_launch_ms_alone": stages_inline[dom],
-            "rocprof_match": "union of the overlapping k_fast launches per step (UnionNs / steps in profiles/r1_v17_kernel_stats.csv)",
+            "rocprof_match": "union of the overlapping k_fast launches per step (UnionNs / steps in profiles/r2_v3_kernel_stats.csv)",
             "all_stages": {k: {"ms": round(stages_inline[k], 4), "GBps": round(stage_bytes[k] / (stages_inline[k] * 1e-3) / 1e9, 1)}
                            for k in stages_inline if k in stage_bytes and stages_inline[k] > 0},
         },
