@@ -159,29 +159,24 @@ def host_io_leg(ctx, left_h, right_h, B, steps, want, world, sync_all, dist, tor
     return res
 
 
-def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend):
-    """BASELINE config 4: a whole sequence (KittiStereo.cc:28-37) sharded over the ranks, records gathered on rank 0."""
+def sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend):
+    """One timed sequence: F stereo pairs (frame f = synthetic frame f mod U) cut into blocks per rank, each rank streaming its block from
+    page-locked host memory in batches of <= B, records packed on the device, gathered on rank 0 (RCCL / the test backend) and copied to
+    page-locked host memory -- then every record checked.  Returns (seconds, frames of this rank, records checked against the host path)."""
     import torch
     import torch.distributed as dist
 
     from orb_slam2_ros2_amd import synth
-    from orb_slam2_ros2_amd._lib import Context
-    from orb_slam2_ros2_amd.digest import pair_digest  # noqa: F401  (records are checked field by field below)
     from orb_slam2_ros2_amd.sequence import DeviceSequenceProcessor, record_bytes, run_sequence, unpack_record
     from orb_slam2_ros2_amd.sharding import frame_range
 
-    F, B, U = args.sequence, args.pairs, max(1, min(args.sequence_unique, 128))
     b, e = frame_range(F, rank, world)
-    B = max(1, min(B, max(e - b, 1)))
-    ctx = Context(W, H, NFEAT, NLEVELS, SCALE, TH_HI, TH_LO, device_id=local_rank, max_images=2 * B)
     proc = DeviceSequenceProcessor(ctx, lambda f: synth.stereo_pair(f % U, W, H), B, FX, BF, dev, content_key=lambda f: f % U)
     proc.prepare(range(b, e))   # page-locked batches of this rank's block, built before the clock starts
 
-    def to_xdev(t):
-        return t if backend == "nccl" else t.cpu()
-
     def collect(h):
-        return to_xdev(proc.collect(h))
+        t = proc.collect(h)
+        return t if backend == "nccl" else t.cpu()
 
     def sync_all():
         ctx.sync()
@@ -203,7 +198,7 @@ def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend):
         tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    line = None
+    checked = 0
     if rank == 0:
         # every frame's record against the record of the first frame with the same content (frames repeat with period U), and the
         # distinct ones against a host-pointer run of the same library (whose digests the GPU suite pins to the golden fixtures)
@@ -211,8 +206,7 @@ def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend):
         assert r.shape == (F, record_bytes(ctx.n_features))
         for f in range(min(U, F), F):
             if not np.array_equal(r[f], r[f % U]):
-                raise SystemExit(f"bench.py --sequence: record of frame {f} differs from frame {f % U} (same image)")
-        checked = 0
+                raise SystemExit(f"bench.py: sequence: record of frame {f} differs from frame {f % U} (same image)")
         for f in range(min(U, F, 8)):
             u = unpack_record(r[f], ctx.n_features)
             (lk, ld), _ = ctx.extract_batch(list(synth.stereo_pair(f % U, W, H)))
@@ -220,8 +214,32 @@ def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend):
             n = len(lk)
             if not (u["n"] == n and u["n_matches"] == nm and np.array_equal(u["kps"], lk) and np.array_equal(u["desc"], ld)
                     and np.array_equal(u["right_u"], ru[:n]) and np.array_equal(u["depth"], dp[:n])):
-                raise SystemExit(f"bench.py --sequence: record of frame {f} differs from the host-pointer path")
+                raise SystemExit(f"bench.py: sequence: record of frame {f} differs from the host-pointer path")
             checked += 1
+    for l, r_ in set(proc.pinned.values()):
+        l.free()
+        r_.free()
+    return dt, n_local, checked
+
+
+def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend):
+    """BASELINE config 4: a whole sequence (KittiStereo.cc:28-37) sharded over the ranks, records gathered on rank 0."""
+    import torch
+    import torch.distributed as dist
+
+    from orb_slam2_ros2_amd import synth
+    from orb_slam2_ros2_amd._lib import Context
+    from orb_slam2_ros2_amd.digest import pair_digest  # noqa: F401  (records are checked field by field below)
+    from orb_slam2_ros2_amd.sequence import DeviceSequenceProcessor, record_bytes, run_sequence, unpack_record
+    from orb_slam2_ros2_amd.sharding import frame_range
+
+    F, B, U = args.sequence, args.pairs, max(1, min(args.sequence_unique, 128))
+    b, e = frame_range(F, rank, world)
+    B = max(1, min(B, max(e - b, 1)))
+    ctx = Context(W, H, NFEAT, NLEVELS, SCALE, TH_HI, TH_LO, device_id=local_rank, max_images=2 * B)
+    dt, n_local, checked = sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend)
+    line = None
+    if rank == 0:
         n_batches = (max(e - b, 1) + B - 1) // B
         line = {
             "metric": "stereo frames/sec (extract+match) KITTI-00 1241x376; HBM GB/s vs roofline",
@@ -262,6 +280,9 @@ def main():
                     help="run a whole sequence of this many stereo pairs (BASELINE config 4: 4541), sharded over the ranks, instead of the "
                          "fixed-batch step loop")
     ap.add_argument("--sequence-unique", type=int, default=64, help="distinct synthetic frames behind the sequence (frame f = f mod this)")
+    ap.add_argument("--sequence-leg", type=int, default=1024,
+                    help="frames PER RANK of the short sequence job reported beside the step loop (`sequence` object: blocks per rank, records "
+                         "gathered on rank 0 -- over RCCL when N > 1); 0 skips it")
     ap.add_argument("--streams", type=int, default=1,
                     help="half-batch streams the library may split a batch over (1 = none, the library default and the fastest "
                          "setting measured; the blur-under-quadtree overlap inside a batch is independent of this)")
@@ -439,6 +460,17 @@ def main():
     if hio_steps > 0:
         host_io = host_io_leg(ctx, left_h, right_h, B, hio_steps, want, world, sync_all, dist, torch, xdev)
 
+    seq_leg = None
+    if args.sequence_leg > 0:
+        F_leg = args.sequence_leg * world
+        t_seq, _, n_chk = sequence_job(ctx, F_leg, B, max(1, min(args.sequence_unique, 128)), rank, world, dev, xdev, backend)
+        seq_leg = {"frames": F_leg, "pairs_per_s": F_leg / t_seq, "seconds": t_seq, "gathered_bytes": F_leg * ctx.record_bytes(),
+                   "records_checked_against_host_path": n_chk, "records_checked_for_repeat_consistency": max(0, F_leg - 64),
+                   "what": "BASELINE config 4 in small: contiguous blocks of frames per rank, page-locked host images -> extraction + stereo match "
+                           "-> per-frame records packed on the device -> ONE gather to rank 0 (" + ("RCCL" if backend == "nccl" and world > 1 else
+                                                                                                     ("none: single rank" if world == 1 else backend)) +
+                           ") -> page-locked host memory, all inside the timed region; `python bench.py --sequence 4541` runs the full one"}
+
     live_ms, live_n = live[dom]
     stages_inline = dict(stages)
     if live_n:
@@ -463,6 +495,7 @@ def main():
         "data": "synthetic",
         "verified_pairs": verified,   # pairs of the last timed batch (all ranks) whose results equal the committed golden digests
         "host_io": host_io,
+        "sequence": seq_leg,
         "config": {
             "workload": "Single 1241x376 KITTI-shaped stereo pair, 8-level pyramid, 2000 FAST+rBRIEF keypoints per image, "
                         "searchByStereo; batched",
