@@ -129,8 +129,11 @@ __global__ __launch_bounds__(256) void k_ic_moments(const uint8_t* __restrict__ 
       // (plain products on purpose: `sum` comes out of v_dot4, and on gfx950 another VALU instruction may read a dot result only
       // three wait states later -- the compiler inserts them for its own instructions but does not look inside an asm statement:
       // the inline-asm v_mad_i32_i24 tried here read stale sums, different from run to run)
-      m10 += dx0 * sum + wsum;
-      m01 += dy * sum;
+      // (and with ranges the compiler can see -- sum < 2^16, |dx0| < 2^7 -- so that it picks the full-rate 24-bit multiply itself: the
+      //  plain 32-bit product is v_mul_lo_u32, a quarter-rate instruction, twice per word)
+      const int sum16 = sum & 0xFFFF, dx8 = (int)(int8_t)dx0;
+      m10 += dx8 * sum16 + wsum;
+      m01 += dy * sum16;
     }
   }
   // sum over the 16 lanes of the row: lane 15 of each row ends up with the total
@@ -231,23 +234,29 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __res
   const uint32_t plane = e.z;
   const int stride = (int)e.w;
   const int xa = (x - BRIEF_R) & ~3;
-  constexpr int NW = BRIEF_ROWS * BRIEF_WORDS, NIT = (NW + 63) / 64;
+  // window load: 5 rows x 11 words per pass over lanes 0..54 (lane = 11 r0 + c0), 8 passes; a pass adds a wave-uniform 5 * stride to
+  // one address and parks its words at lane + 55 * pass -- one v_add per load where the flat index -> (row, word) split cost five
+  // (the kernel is VALU-bound: ~260 instructions per keypoint)
+  constexpr int NIT = (BRIEF_ROWS + 4) / 5;
+  const int ll = min(lane, 54);
+  const int r0 = (ll * 373) >> 12, c0 = ll - r0 * BRIEF_WORDS;  // ll / 11 for ll < 64
+  const uint32_t step = 5u * (uint32_t)__builtin_amdgcn_readfirstlane(stride);
+  const uint32_t a0 = plane + (uint32_t)mad24u(y - BRIEF_R + r0, stride, xa + 4 * c0);
   uint32_t wv[NIT];
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int idx = min(it * 64 + lane, NW - 1);
-    const int r = (idx * 5958) >> 16;  // idx / 11 for idx < 448
-    const int c = idx - r * BRIEF_WORDS;
-    wv[it] = *(const uint32_t*)(W + (plane + (uint32_t)mad24u(y - BRIEF_R + r, stride, xa + 4 * c)));
+  for (int it = 0; it < NIT - 1; ++it) wv[it] = *(const uint32_t*)(W + (a0 + (uint32_t)it * step));
+  {  // last pass: rows 35, 36 exist, the lanes of rows 37..39 re-read row 36
+    const int r = min(r0 + 5 * (NIT - 1), BRIEF_ROWS - 1);
+    wv[NIT - 1] = *(const uint32_t*)(W + (plane + (uint32_t)mad24u(y - BRIEF_R + r, stride, xa + 4 * c0)));
   }
   const double2 scv = sincos[(size_t)img * n_features + k];
   uint32_t tp[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) tp[g] = *(const uint32_t*)(pattern + (g * 64 + lane) * 4);
+  if (lane < 55) {
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int idx = it * 64 + lane;
-    if (idx < NW) win[idx] = wv[it];
+    for (int it = 0; it < NIT - 1; ++it) win[lane + 55 * it] = wv[it];
+    if (r0 + 5 * (NIT - 1) < BRIEF_ROWS) win[lane + 55 * (NIT - 1)] = wv[NIT - 1];
   }
   const double sn = scv.x, cs = scv.y;
   // The rotation needs x cos, x sin, y cos, y sin in fp64 for 512 template points, but the coordinates are small integers:
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __res
   __builtin_amdgcn_wave_barrier();
   const uint8_t* wb = (const uint8_t*)win;
   const float px = (float)x, py = (float)y;
-  const int x_off = xa, y_off = y - BRIEF_R;
+  const int xbias = 0x4B400000 + xa, ybias = 0x4B400000 + (y - BRIEF_R);  // bit pattern of 1.5 * 2^23 + the window origin
   unsigned long long bits[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -276,10 +285,14 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __res
     const float p1y = (float)(rx1.y + ry1.x);  // x1 sin + y1 cos
     const float p2x = (float)(rx2.x - ry2.y);
     const float p2y = (float)(rx2.y + ry2.x);
-    const int r1 = __float2int_rn(py + p1y), c1 = __float2int_rn(px + p1x);
-    const int r2 = __float2int_rn(py + p2y), c2 = __float2int_rn(px + p2x);
-    const int v1 = wb[mad24u(r1 - y_off, BRIEF_WORDS * 4, c1 - x_off)];
-    const int v2 = wb[mad24u(r2 - y_off, BRIEF_WORDS * 4, c2 - x_off)];
+    // cvRound(float sum) minus the window origin in two instructions instead of four (v_rndne, v_cvt, v_sub after the add): adding
+    // 1.5 * 2^23 rounds the sum to an integer with ties to even -- the unit in the last place of the result is 1 -- and leaves that
+    // integer in the low mantissa bits, so one integer subtraction removes the constant's bit pattern AND the origin.  Exact for
+    // |sum| < 2^22 (coordinates are < 2^12); the two float additions are not contracted or re-associated (fp contract off, no fast-math).
+    const int r1o = __float_as_int((py + p1y) + 12582912.0f) - ybias, c1o = __float_as_int((px + p1x) + 12582912.0f) - xbias;
+    const int r2o = __float_as_int((py + p2y) + 12582912.0f) - ybias, c2o = __float_as_int((px + p2x) + 12582912.0f) - xbias;
+    const int v1 = wb[mad24u(r1o, BRIEF_WORDS * 4, c1o)];
+    const int v2 = wb[mad24u(r2o, BRIEF_WORDS * 4, c2o)];
     bits[g] = __ballot(v1 < v2);
   }
   if (lane < 4) {
