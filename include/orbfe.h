@@ -351,6 +351,15 @@ orbfe_status orbfe_map_pb_summary(const uint8_t* pb, size_t len, orbfe_map_summa
 /* parse + serialise: the canonical encoding libprotobuf's C++ serialiser produces for the same content    */
 orbfe_status orbfe_map_pb_reencode(const uint8_t* pb, size_t len, uint8_t* out, size_t cap, size_t* out_len);
 
+/* The reference's other on-disk format, the TEXT map of Map::saveToTxtFile / loadFromTxtFile (src/Map.cc:82-165): `KeyFrames.txt`
+ * (one header line + 10 lines per keyframe, KeyFrame.cc:400-530) and `MapPoints.txt` (3 lines per map point, MapPoint.cc:538-596), as
+ * conversions to and from map.pb (host/map_txt.hpp; numbers formatted by iostreams exactly like the reference: 6 significant digits,
+ * so the text form is lossy).  Size-query convention as above, for both outputs.                                                  */
+orbfe_status orbfe_map_pb_to_txt(const uint8_t* pb, size_t len, char* kf_out, size_t kf_cap, size_t* kf_len, char* mp_out, size_t mp_cap,
+                                 size_t* mp_len);
+orbfe_status orbfe_map_txt_to_pb(const char* kf_txt, size_t kf_len, const char* mp_txt, size_t mp_len, uint8_t* out, size_t cap,
+                                 size_t* out_len);
+
 /* The graph Optimizer::OptimizeLocalMap builds around keyframe kf_id (src/Optimizer.cc:232-330): vertices =
  * [covisible keyframes (weight > 15, descending) + kf_id | fixed observers], map points of the free group in
  * ascending id, one edge per observation (stereo iff right_u > 0; information getScaledFactorInv2 / Inv, quirk Q9).

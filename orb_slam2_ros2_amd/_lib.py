@@ -102,7 +102,7 @@ EXPORTS = [
     "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_slot", "orbfe_fetch_batch", "orbfe_fetch_stereo_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
     "orbfe_host_alloc", "orbfe_host_free", "orbfe_stream_submit", "orbfe_stream_wait", "orbfe_stream_device_results", "orbfe_record_bytes", "orbfe_stream_pack_records",
     "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_search_in_area_features", "orbfe_extract_color", "orbfe_frame_rgbd", "orbfe_project_map_points",
-    "orbfe_map_pb_summary", "orbfe_map_pb_reencode", "orbfe_map_local_graph", "orbfe_map_local_ba",
+    "orbfe_map_pb_summary", "orbfe_map_pb_reencode", "orbfe_map_pb_to_txt", "orbfe_map_txt_to_pb", "orbfe_map_local_graph", "orbfe_map_local_ba",
     "orbfe_profile_enable", "orbfe_profile_read", "orbfe_stage_name", "orbfe_debug_candidates",
 ]
 
@@ -170,6 +170,8 @@ def load() -> C.CDLL:
     L.orbfe_project_map_points.argtypes = [vp, i32, vp, vp, vp, vp, C.POINTER(FramePose), C.POINTER(Camera), vp, vp, vp, vp, vp]
     L.orbfe_map_pb_summary.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(MapSummary)]
     L.orbfe_map_pb_reencode.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.orbfe_map_pb_to_txt.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.orbfe_map_txt_to_pb.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.orbfe_map_local_graph.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.POINTER(i32 * 4), C.POINTER(MapGraph)]
     L.orbfe_map_local_ba.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_uint64, C.POINTER(Camera), vp, vp, C.c_size_t,
                                      C.POINTER(C.c_size_t), C.POINTER(MapBaReport)]
@@ -230,6 +232,25 @@ def map_pb_reencode(pb: bytes) -> bytes:
     _status(L.orbfe_map_pb_reencode(pb, len(pb), None, 0, C.byref(n)), "map_pb_reencode")
     out = np.zeros(max(n.value, 1), np.uint8)
     _status(L.orbfe_map_pb_reencode(pb, len(pb), ptr(out), out.size, C.byref(n)), "map_pb_reencode")
+    return out[:n.value].tobytes()
+
+
+def map_pb_to_txt(pb: bytes):
+    """map.pb -> (KeyFrames.txt, MapPoints.txt) as Map::saveToTxtFile writes them (src/Map.cc:82-110)"""
+    L, nk, nm = load(), C.c_size_t(0), C.c_size_t(0)
+    _status(L.orbfe_map_pb_to_txt(pb, len(pb), None, 0, C.byref(nk), None, 0, C.byref(nm)), "map_pb_to_txt")
+    kf, mp = np.zeros(max(nk.value, 1), np.uint8), np.zeros(max(nm.value, 1), np.uint8)
+    _status(L.orbfe_map_pb_to_txt(pb, len(pb), ptr(kf), kf.size, C.byref(nk), ptr(mp), mp.size, C.byref(nm)), "map_pb_to_txt")
+    return kf[:nk.value].tobytes().decode(), mp[:nm.value].tobytes().decode()
+
+
+def map_txt_to_pb(keyframes_txt: str, mappoints_txt: str) -> bytes:
+    """(KeyFrames.txt, MapPoints.txt) -> map.pb: Map::loadFromTxtFile's readers (src/Map.cc:117-165), canonical protobuf encoding"""
+    L, n = load(), C.c_size_t(0)
+    k, m = keyframes_txt.encode(), mappoints_txt.encode()
+    _status(L.orbfe_map_txt_to_pb(k, len(k), m, len(m), None, 0, C.byref(n)), "map_txt_to_pb")
+    out = np.zeros(max(n.value, 1), np.uint8)
+    _status(L.orbfe_map_txt_to_pb(k, len(k), m, len(m), ptr(out), out.size, C.byref(n)), "map_txt_to_pb")
     return out[:n.value].tobytes()
 
 

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "../host/map_pb.hpp"
+#include "../host/map_txt.hpp"
 #include "orbfe.h"
 
 using namespace orbfe::mappb;
@@ -39,6 +40,26 @@ orbfe_status orbfe_map_pb_reencode(const uint8_t* pb, size_t len, uint8_t* out, 
   if (!pb && len) return ORBFE_EBADARG;
   MapRec map;
   if (!parse(pb, len, map)) return ORBFE_EBADARG;
+  return emit(serialize(map), out, cap, out_len);
+}
+
+// Map::saveToTxtFile / loadFromTxtFile (src/Map.cc:82-165) as conversions to and from map.pb: host only
+orbfe_status orbfe_map_pb_to_txt(const uint8_t* pb, size_t len, char* kf_out, size_t kf_cap, size_t* kf_len, char* mp_out, size_t mp_cap,
+                                 size_t* mp_len) {
+  if ((!pb && len) || !kf_len || !mp_len) return ORBFE_EBADARG;
+  MapRec map;
+  if (!parse(pb, len, map)) return ORBFE_EBADARG;
+  std::string kf, mp;
+  serialize_txt(map, kf, mp);
+  const orbfe_status a = emit(kf, (uint8_t*)kf_out, kf_cap, kf_len), b = emit(mp, (uint8_t*)mp_out, mp_cap, mp_len);
+  return a != ORBFE_OK ? a : b;
+}
+
+orbfe_status orbfe_map_txt_to_pb(const char* kf_txt, size_t kf_len, const char* mp_txt, size_t mp_len, uint8_t* out, size_t cap,
+                                 size_t* out_len) {
+  if ((!kf_txt && kf_len) || (!mp_txt && mp_len)) return ORBFE_EBADARG;
+  MapRec map;
+  if (!parse_txt(std::string(kf_txt ? kf_txt : "", kf_len), std::string(mp_txt ? mp_txt : "", mp_len), map)) return ORBFE_EBADARG;
   return emit(serialize(map), out, cap, out_len);
 }
 

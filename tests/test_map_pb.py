@@ -241,3 +241,75 @@ def test_c_abi_argument_checks_of_the_host_only_entry_points(small_map):
     assert L.orbfe_map_local_graph(pb[: len(pb) // 2], len(pb) // 2, 10, C.byref(sizes), None) == 1  # truncated file
     # the device entry point refuses NULL context / camera before touching anything
     assert L.orbfe_map_local_ba(None, pb, len(pb), 10, None, None, None, 0, C.byref(n), None) == 1
+
+
+# ---- the TEXT map format (Map::saveToTxtFile / loadFromTxtFile, src/Map.cc:82-165) ----------------------------------------------------
+def _g(v):
+    return "%g" % v            # what `std::ostream << float / double` prints by default: 6 significant digits
+
+
+def _txt_of(md):
+    """KeyFrames.txt / MapPoints.txt written line by line after operator<<(KeyFrame) (src/KeyFrame.cc:400-530) and operator<<(MapPoint)
+    (src/MapPoint.cc:538-565) from the protobuf message"""
+    k_out = [str(md.keyframes.next_id) + " " + "".join(_g(s) + " " for s in md.keyframes.scale_factors)]
+    for k in md.keyframes.keyframes:
+        k_out.append(f"{k.id} {_g(k.max_u)} {_g(k.max_v)} {_g(k.min_u)} {_g(k.min_v)}")
+        k_out.append("".join(f"{_g(kp.x)} {_g(kp.y)} {kp.octave} {_g(kp.angle)} {_g(k.right_u[i])} {_g(k.depths[i])} " for i, kp in enumerate(k.keypoints)))
+        k_out.append("".join(f"{b} " for d in k.descriptors for b in d.data))
+        k_out.append("".join(f"{w} {_g(v)} " for w, v in sorted(k.bow_vector.words.items())))
+        k_out.append("".join(f"{n.node_id} {len(n.feature_ids)} " + "".join(f"{i} " for i in n.feature_ids) for n in k.feature_vector.nodes))
+        k_out.append("".join(_g(v) + " " for v in list(k.pose.rotation) + list(k.pose.translation)))
+        k_out.append("".join(f"{c.id} {c.weight} " for c in sorted(k.connected_kfs, key=lambda c: c.id)))
+        k_out.append("".join(f"{c} " for c in k.children_ids))
+        k_out.append("".join(f"{c} " for c in k.loop_edges))
+        k_out.append("".join(f"{m} " for m in k.map_points))
+    m_out = []
+    for m in md.mappoints.mappoints:
+        m_out.append(f"{m.id} {_g(m.max_distance)} {_g(m.min_distance)} {m.ref_kf_id} {m.ref_feat_id} {m.matches_in_track} {m.inliers_in_track}")
+        m_out.append(f"{_g(m.position.x)} {_g(m.position.y)} {_g(m.position.z)} {_g(m.view_direction.x)} {_g(m.view_direction.y)} {_g(m.view_direction.z)}")
+        m_out.append("".join(f"{b} " for b in m.desc.data))
+    return "\n".join(k_out) + "\n", ("\n".join(m_out) + "\n" if m_out else "")
+
+
+def test_text_map_is_what_the_reference_writes_and_reads_back(small_map):
+    md, _, pb = small_map
+    kf_txt, mp_txt = _lib.map_pb_to_txt(pb)
+    want_k, want_m = _txt_of(md)
+    assert kf_txt == want_k and mp_txt == want_m
+    assert kf_txt.count("\n") == 1 + 10 * len(md.keyframes.keyframes) and mp_txt.count("\n") == 3 * len(md.mappoints.mappoints)
+    # reading it back (loadFromTxtFile): every number is what the 6-digit text says, as float32; integers and descriptors are exact
+    back = MD()
+    back.ParseFromString(_lib.map_txt_to_pb(kf_txt, mp_txt))
+    assert back.keyframes.next_id == md.keyframes.next_id and len(back.keyframes.keyframes) == len(md.keyframes.keyframes)
+    f32 = lambda v: float(np.float32(float(_g(v))))
+    for a, b in zip(md.keyframes.keyframes, back.keyframes.keyframes):
+        assert a.id == b.id and list(a.map_points) == list(b.map_points) and list(a.children_ids) == list(b.children_ids)
+        assert list(a.loop_edges) == list(b.loop_edges) and [d.data for d in a.descriptors] == [d.data for d in b.descriptors]
+        assert [(kp.octave, f32(kp.x), f32(kp.y), f32(kp.angle)) for kp in a.keypoints] == [(kp.octave, kp.x, kp.y, kp.angle) for kp in b.keypoints]
+        assert [f32(v) for v in a.right_u] == list(b.right_u) and [f32(v) for v in a.depths] == list(b.depths)
+        assert [f32(v) for v in a.pose.rotation] == list(b.pose.rotation) and [f32(v) for v in a.pose.translation] == list(b.pose.translation)
+        assert sorted((c.id, c.weight) for c in a.connected_kfs) == [(c.id, c.weight) for c in b.connected_kfs]
+        assert {w: float(_g(v)) for w, v in a.bow_vector.words.items()} == dict(b.bow_vector.words)
+        assert [(n.node_id, list(n.feature_ids)) for n in a.feature_vector.nodes] == [(n.node_id, list(n.feature_ids)) for n in b.feature_vector.nodes]
+    for a, b in zip(md.mappoints.mappoints, back.mappoints.mappoints):
+        assert (a.id, a.ref_kf_id, a.ref_feat_id, a.matches_in_track, a.inliers_in_track, a.desc.data) == \
+               (b.id, b.ref_kf_id, b.ref_feat_id, b.matches_in_track, b.inliers_in_track, b.desc.data)
+        assert (f32(a.position.x), f32(a.position.y), f32(a.position.z), f32(a.max_distance)) == (b.position.x, b.position.y, b.position.z, b.max_distance)
+    # text -> pb -> text is a fixed point (the second text form loses nothing more)
+    k2, m2 = _lib.map_pb_to_txt(_lib.map_txt_to_pb(kf_txt, mp_txt))
+    assert (k2, m2) == (kf_txt, mp_txt)
+    # empty map, and a keyframe without keypoints / connections (empty lines)
+    assert _lib.map_pb_to_txt(b"\x0a\x00\x12\x00") == ("0 \n", "")
+    e = MD()
+    e.keyframes.next_id = 3
+    e.keyframes.scale_factors.extend([1.0, 1.2])
+    k = e.keyframes.keyframes.add()
+    k.id = 2
+    k.pose.rotation.extend([1, 0, 0, 0, 1, 0, 0, 0, 1])
+    k.pose.translation.extend([0.5, 0, -2])
+    e.mappoints.SetInParent()
+    kt, mt = _lib.map_pb_to_txt(e.SerializeToString())
+    assert kt == "3 1 1.2 \n2 0 0 0 0\n\n\n\n\n1 0 0 0 1 0 0 0 1 0.5 0 -2 \n\n\n\n\n" and mt == ""
+    eb = MD()
+    eb.ParseFromString(_lib.map_txt_to_pb(kt, mt))
+    assert eb.keyframes.keyframes[0].id == 2 and list(eb.keyframes.keyframes[0].pose.translation) == [0.5, 0.0, -2.0]
