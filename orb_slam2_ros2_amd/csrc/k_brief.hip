@@ -212,10 +212,23 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __res
                                               const uint4* __restrict__ kpl, int n_features, const int8_t* __restrict__ pattern,
                                               const double2* __restrict__ sincos, uint8_t* __restrict__ desc) {
 #pragma clang fp contract(off)
-  __shared__ uint32_t win_all[BRIEF_WAVES][BRIEF_ROWS * BRIEF_WORDS + 1];
-  __shared__ double2 rot_all[BRIEF_WAVES][2 * BRIEF_R + 1];  // per wave: (v cos, v sin) for every template coordinate v in [-18, 18]  // one window per wave; the waves never synchronise
+  // per wave (the waves never synchronise): the window, and v cos / v sin for every template coordinate v in [-18, 18] as two
+  // arrays of doubles.  The kernel is bound by LDS cycles, most of them the table look-ups: as 16-byte (cos, sin) entries read by
+  // ds_read_b128 a 256-byte bank sweep holds 16 entries, so the lanes' 27 distinct coordinates collided two to three deep on every
+  // read; 8-byte entries read by ds_read_b64 put 32 to a sweep -- the coordinates -13 ... 13 of the standard template never collide
+  // (equal addresses broadcast).  The window lies BETWEEN the two arrays so that no ds_read2_b64 can reach from one to the other:
+  // that instruction takes twice the cycles of two single reads and banks 16 entries to the sweep again.
+  struct __attribute__((aligned(16))) Lds {
+    double rc[BRIEF_WAVES][40];
+    uint32_t win[BRIEF_WAVES][BRIEF_ROWS * BRIEF_WORDS + 1];
+    double rs[BRIEF_WAVES][40];
+  };
+  static_assert(sizeof(double) * 40 * BRIEF_WAVES + sizeof(uint32_t) * (BRIEF_ROWS * BRIEF_WORDS + 1) * BRIEF_WAVES > 255 * 8 &&
+                    (sizeof(double) * 40 * BRIEF_WAVES + sizeof(uint32_t) * (BRIEF_ROWS * BRIEF_WORDS + 1) * BRIEF_WAVES) % 512 != 0,
+                "rc[w] and rs[w] must not be reachable by one ds_read2(st64)_b64");
+  __shared__ Lds lds;
   const int lane = threadIdx.x & 63;
-  uint32_t* win = win_all[threadIdx.x >> 6];
+  uint32_t* win = lds.win[threadIdx.x >> 6];
   // XCD-aware block order: workgroups go round-robin to the 8 XCDs (own L2 each) and consecutive keypoints are spatial neighbours
   // (candidate order) whose 37x37 windows overlap; block b of the grid takes keypoint block (b % 8) * (grid / 8) + b / 8, so one XCD
   // works through one contiguous eighth of the list (gridDim.x is a multiple of 8).  Fetched bytes 2.69 -> 0.85 GB per 1024 images;
@@ -262,10 +275,12 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __res
   // The rotation needs x cos, x sin, y cos, y sin in fp64 for 512 template points, but the coordinates are small integers:
   // 37 lanes form the products once ((double)v * cs is exactly what the per-point expression computes), every point then
   // takes two LDS reads and one fp64 add per coordinate instead of two fp64 multiplies and a conversion.
-  double2* rot = rot_all[threadIdx.x >> 6];
+  double* rc = lds.rc[threadIdx.x >> 6];
+  double* rs = lds.rs[threadIdx.x >> 6];
   if (lane <= 2 * BRIEF_R) {
     const double v = (double)(float)(lane - BRIEF_R);
-    rot[lane] = make_double2(v * cs, v * sn);
+    rc[lane] = v * cs;
+    rs[lane] = v * sn;
   }
   // the LDS accesses of one wave execute in order, so the window and the table written above are visible to every lane of this
   // wave; the fence only pins the compiler
@@ -279,12 +294,11 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __res
   for (int g = 0; g < 4; ++g) {
     const int x1 = (int)(int8_t)(tp[g] & 255u), y1 = (int)(int8_t)((tp[g] >> 8) & 255u);
     const int x2 = (int)(int8_t)((tp[g] >> 16) & 255u), y2 = (int)(int8_t)(tp[g] >> 24);
-    const double2 rx1 = rot[x1 + BRIEF_R], ry1 = rot[y1 + BRIEF_R], rx2 = rot[x2 + BRIEF_R], ry2 = rot[y2 + BRIEF_R];
     // float * double -> double, one rounding to float (rotateTemplate, ORBExtractor.cc:537-538)
-    const float p1x = (float)(rx1.x - ry1.y);  // x1 cos - y1 sin
-    const float p1y = (float)(rx1.y + ry1.x);  // x1 sin + y1 cos
-    const float p2x = (float)(rx2.x - ry2.y);
-    const float p2y = (float)(rx2.y + ry2.x);
+    const float p1x = (float)(rc[x1 + BRIEF_R] - rs[y1 + BRIEF_R]);  // x1 cos - y1 sin
+    const float p1y = (float)(rs[x1 + BRIEF_R] + rc[y1 + BRIEF_R]);  // x1 sin + y1 cos
+    const float p2x = (float)(rc[x2 + BRIEF_R] - rs[y2 + BRIEF_R]);
+    const float p2y = (float)(rs[x2 + BRIEF_R] + rc[y2 + BRIEF_R]);
     // cvRound(float sum) minus the window origin in two instructions instead of four (v_rndne, v_cvt, v_sub after the add): adding
     // 1.5 * 2^23 rounds the sum to an integer with ties to even -- the unit in the last place of the result is 1 -- and leaves that
     // integer in the low mantissa bits, so one integer subtraction removes the constant's bit pattern AND the origin.  Exact for

@@ -104,22 +104,74 @@ __device__ __forceinline__ int cv_floor_f(float v) {
   return i - (i > v);
 }
 
-#ifndef ST_STEP
-#define ST_STEP 8  // hit chunks per step of the candidate scan (a 1241x376 frame has ~5 per left keypoint)
-#endif
-__global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv, const uint8_t* __restrict__ pyr, size_t img_pitch,
+// ---------------------------------------------------------------------------------------------
+// row table of one right image (createRowIndexDB, ORBMatcher.cc:915-932): for every image row the right keypoints whose band
+// [row_min, row_max) holds it, as offsets[rows + 1] + one flat list (counting sort in LDS, one workgroup per image).  The order
+// inside a row is whatever the atomics produce: the matcher below reduces (distance, index) keys, which does not depend on it.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rowtable(const KpAux* __restrict__ aux, const int32_t* __restrict__ n_kp, int n_features, int rows,
+                                                  int list_cap, uint32_t* __restrict__ rowoff, uint16_t* __restrict__ rowlist, int slot_r0,
+                                                  int slot_step, int pair0) {
+  extern __shared__ uint32_t s_rt[];  // cnt[rows] | part[256]
+  uint32_t* cnt = s_rt;
+  uint32_t* part = s_rt + rows;
+  const int tid = threadIdx.x;
+  const int slot = slot_r0 + blockIdx.x * slot_step;
+  const int pair = pair0 + blockIdx.x;
+  const KpAux* A = aux + (size_t)slot * n_features;
+  uint32_t* RO = rowoff + (size_t)pair * (rows + 1);
+  uint16_t* RL = rowlist + (size_t)pair * list_cap;
+  const int nr = min(n_kp[slot], n_features);
+  for (int y = tid; y < rows; y += 256) cnt[y] = 0;
+  __syncthreads();
+  for (int i = tid; i < nr; i += 256) {
+    const KpAux a = A[i];
+    for (int y = a.row_min; y < a.row_max; ++y) atomicAdd(&cnt[y], 1u);  // (k_orient clips the band to [0, rows])
+  }
+  __syncthreads();
+  // exclusive prefix sum over the rows: a run of rows per thread, the 256 run totals scanned in LDS
+  const int per = (rows + 255) >> 8;
+  const int y0 = tid * per, y1 = min(y0 + per, rows);
+  uint32_t sum = 0;
+  for (int y = y0; y < y1; ++y) sum += cnt[y];
+  part[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const uint32_t v = tid >= d ? part[tid - d] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - sum;
+  for (int y = y0; y < y1; ++y) {
+    const uint32_t c = cnt[y];
+    cnt[y] = run;  // from here on: the row's write cursor
+    RO[y] = run;
+    run += c;
+  }
+  if (tid == 255) RO[rows] = part[255];
+  __syncthreads();
+  for (int i = tid; i < nr; i += 256) {
+    const KpAux a = A[i];
+    for (int y = a.row_min; y < a.row_max; ++y) {
+      const uint32_t p = atomicAdd(&cnt[y], 1u);
+      if (p < (uint32_t)list_cap) RL[p] = (uint16_t)i;  // (list_cap = n_features x the widest band: always true)
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv, int n_levels, const uint8_t* __restrict__ pyr, size_t img_pitch,
                                                 const orbfe_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
-                                                const KpAux* __restrict__ aux, const float* __restrict__ kx,
-                                                const short2* __restrict__ env, int n_chunks, const int32_t* __restrict__ n_kp,
+                                                const float* __restrict__ kx, const uint32_t* __restrict__ rowoff,
+                                                const uint16_t* __restrict__ rowlist, int rows, int list_cap,
+                                                const int32_t* __restrict__ n_kp,
                                                 int n_features, float fx, float bf, int cols0, int mean_threshold,
                                                 double* __restrict__ right_u, double* __restrict__ depth, int32_t* __restrict__ n_match,
                                                 int32_t* __restrict__ best_right, int32_t* __restrict__ best_dist, int slot_l0,
                                                 int slot_r0, int slot_step, int pair0) {
 #pragma clang fp contract(off)
   __shared__ uint32_t s_sad[4][11 * 4 + 11 * 7 + 7];  // per wave: left 11 rows x 4 words, right 11 rows x 7 words
-  __shared__ uint16_t s_clist[4][ST_STEP * 64];         // per wave: right indices of the step's candidates, list order
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  uint16_t* clist = s_clist[wv];
   const int li = blockIdx.x * 4 + wv;
   const int pair = pair0 + blockIdx.y;
   const int sl = slot_l0 + blockIdx.y * slot_step, sr = slot_r0 + blockIdx.y * slot_step;
@@ -129,16 +181,20 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
   const orbfe_keypoint* RK = kps + (size_t)sr * n_features;
   const uint8_t* LD = desc + (size_t)sl * n_features * 32;
   const uint8_t* RD = desc + (size_t)sr * n_features * 32;
-  const KpAux* RA = aux + (size_t)sr * n_features;
   const float* RX = kx + (size_t)sr * n_features;
-  const short2* RE = env + (size_t)sr * n_chunks;
-  // first round trip: counts, the left keypoint, its descriptor and the chunk envelopes are all independent loads
+  const uint32_t* RO = rowoff + (size_t)pair * (rows + 1);
+  const uint16_t* RL = rowlist + (size_t)pair * list_cap;
+  // first round trip: the count, the left keypoint, its descriptor and -- lane = level -- the three per-level constants the SAD
+  // stage will want for the two octaves it does not know yet
   // (slot li always exists in the buffers; whether it holds a keypoint is decided after the loads are in flight)
-  const int nl = n_kp[sl], nr = n_kp[sr];
+  const int nl = n_kp[sl];
   const orbfe_keypoint l = LK[li];
   const uint4 a0 = *(const uint4*)(LD + (size_t)li * 32);
   const uint4 a1 = *(const uint4*)(LD + (size_t)li * 32 + 16);
-  const short2 env0 = (lane < n_chunks) ? RE[lane] : make_short2(0, 0);
+  const LevelDev& Lmine = lv[min(lane, n_levels - 1)];
+  const float lv_sf = Lmine.sf;
+  const uint32_t lv_off = Lmine.plane_off;
+  const int lv_stride = Lmine.stride;
   if (li >= nl) {
     if (lane == 0) {
       right_u[out_i] = -1.0;
@@ -150,80 +206,42 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
   }
   const float max_u = l.x - 0;
   const float min_u = fmaxf(0.f, l.x - fx);
-  const int row = __float2int_rn(l.y);
+  const int row = __builtin_amdgcn_readfirstlane(__float2int_rn(l.y));
 
-  // candidates = rowIdxDB[row] filtered by the u-range, in ascending right index (ORBMatcher.cc:38-48).
-  // Keypoints are stored level-major / cell-row-major, so a chunk of 64 consecutive right keypoints covers a narrow
-  // band of rows: one envelope test per chunk (lane = chunk) skips most of the 32 chunks outright.
-  Best2 b = {ORB_INT_MAX, ORB_INT_MAX, 0};
-  bool any = false;
-  const int used_chunks = (nr + 63) >> 6;
-  for (int cb = 0; cb < used_chunks; cb += 64) {
-    const int ch = cb + lane;
-    bool hit = false;
-    if (ch < used_chunks) {
-      const short2 e = (cb == 0) ? env0 : RE[ch];
-      hit = row >= (int)e.x && row < (int)e.y;
-    }
-    unsigned long long todo = __ballot(hit);
-    // ST_STEP hit chunks per step, two dependent memory round trips per step: (a) the filter records of ALL the step's
-    // chunks are requested before the first is looked at (clamped indices, so the loads are unconditional); (b) the
-    // candidates that pass -- a few per chunk -- are compacted in list order through LDS, so that one lane holds one
-    // candidate, one batch of descriptor loads serves the whole step and the order-dependent fold runs once per 64
-    // candidates instead of once per chunk.  (Measured: with each chunk's loads consumed inside its own branch the step
-    // size made no difference at all; with per-chunk descriptor registers 8 chunks per step cost half the occupancy.)
-    while (todo) {
-      int cid[ST_STEP];
-      KpAux ra[ST_STEP];
-      float rxv[ST_STEP];
-#pragma unroll
-      for (int u = 0; u < ST_STEP; ++u) {
-        cid[u] = -1;
-        if (todo) {
-          cid[u] = cb + (__ffsll((long long)todo) - 1);
-          todo &= todo - 1;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < ST_STEP; ++u) {
-        const int c = min((max(cid[u], 0) << 6) + lane, nr - 1);
-        ra[u] = RA[(uint32_t)c];  // (unsigned indices: scalar base + 32-bit offset addressing)
-        rxv[u] = RX[(uint32_t)c];
-      }
-      int total = 0;
-#pragma unroll
-      for (int u = 0; u < ST_STEP; ++u) {
-        const int c = (cid[u] << 6) + lane;
-        const bool pass = cid[u] >= 0 && c < nr && row >= ra[u].row_min && row < ra[u].row_max && rxv[u] < max_u && rxv[u] > min_u;
-        const unsigned long long m = __ballot(pass);
-        if (pass) clist[total + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)c;
-        total += __popcll(m);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      for (int g = 0; g < total; g += 64) {
-        const bool has = g + lane < total;
-        const int idx = has ? (int)clist[g + lane] : 0;
-        const int d = has ? hamming256(a0, a1, RD + ((uint32_t)idx << 5)) : ORB_INT_MAX;
-        any = true;
-        fold_chunk(b, d, idx, lane);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+  // candidates = rowIdxDB[row] filtered by the u-range (ORBMatcher.cc:38-48); the reference takes the FIRST minimum of the list,
+  // which is in ascending right index: the minimum of (distance << 16 | index) over the candidates, in any order.  A lane keeps the
+  // minimum of the candidates it has seen (one per 64 list entries); one wave reduction after the loop.
+  int key = ORB_INT_MAX;
+  if ((unsigned)row < (unsigned)rows) {
+    const int beg = (int)RO[row], end = (int)RO[row + 1];
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int g = beg; g < end; g += 64) {
+      const int c = g + lane;
+      const bool has = c < end;
+      const uint32_t idx = RL[has ? c : beg];
+      const float x = RX[idx];
+      const int d = hamming256(a0, a1, RD + (idx << 5));
+      const bool pass = has && x < max_u && x > min_u;
+      key = min(key, pass ? (int)(((uint32_t)d << 16) | idx) : ORB_INT_MAX);
     }
   }
+  key = wave_min_i(key);
+  const bool any = key != ORB_INT_MAX;
+  Best2 b = {key >> 16, ORB_INT_MAX, key & 0xFFFF};
   double out_u = -1.0, out_depth = -1.0;
   int matched = 0;
   if (any && b.min_d <= mean_threshold) {
     const orbfe_keypoint r = RK[b.min_idx];
     if (!(l.octave > r.octave + 1 || l.octave < r.octave - 1)) {
       // ---- pixelSADMatch (ORBMatcher.cc:841-881): 11 SADs of centre-subtracted 11x11 patches ----
-      const LevelDev& LL = lv[l.octave];
-      const LevelDev& LR = lv[r.octave];
-      const uint8_t* IL = pyr + (size_t)sl * img_pitch + LL.plane_off;
-      const uint8_t* IR = pyr + (size_t)sr * img_pitch + LR.plane_off;
-      const int lx = cv_floor_f(l.x / LL.sf), ly = cv_floor_f(l.y / LL.sf);  // getPitch (:1004-1006)
-      const int rx = cv_floor_f(r.x / LR.sf), ry = cv_floor_f(r.y / LR.sf);
+      const int ol = __builtin_amdgcn_readfirstlane(l.octave), orr = __builtin_amdgcn_readfirstlane(r.octave);
+      const float sf_l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lv_sf), ol));
+      const float sf_r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lv_sf), orr));
+      const int stride_l = __builtin_amdgcn_readlane(lv_stride, ol), stride_r = __builtin_amdgcn_readlane(lv_stride, orr);
+      const uint8_t* IL = pyr + (size_t)sl * img_pitch + (uint32_t)__builtin_amdgcn_readlane((int)lv_off, ol);
+      const uint8_t* IR = pyr + (size_t)sr * img_pitch + (uint32_t)__builtin_amdgcn_readlane((int)lv_off, orr);
+      const int lx = cv_floor_f(l.x / sf_l), ly = cv_floor_f(l.y / sf_l);  // getPitch (:1004-1006)
+      const int rx = cv_floor_f(r.x / sf_r), ry = cv_floor_f(r.y / sf_r);
       // stage the left 11x11 patch (x in [lx-5, lx+5]) and the right 11x21 window (x in [rx-10, rx+10]) in LDS as words
       uint32_t* wl = s_sad[wv];
       uint32_t* wr = s_sad[wv] + 44;
@@ -231,11 +249,11 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
       for (int t = lane; t < 44 + 77; t += 64) {
         if (t < 44) {
           const int rr = t >> 2, cc = t & 3;
-          wl[t] = *(const uint32_t*)(IL + (uint32_t)mad24u(ly - 5 + rr, LL.stride, lxa + 4 * cc));
+          wl[t] = *(const uint32_t*)(IL + (uint32_t)mad24u(ly - 5 + rr, stride_l, lxa + 4 * cc));
         } else {
           const int u = t - 44;
           const int rr = u / 7, cc = u - rr * 7;
-          wr[u] = *(const uint32_t*)(IR + (uint32_t)mad24u(ry - 5 + rr, LR.stride, rxa + 4 * cc));
+          wr[u] = *(const uint32_t*)(IR + (uint32_t)mad24u(ry - 5 + rr, stride_r, rxa + 4 * cc));
         }
       }
       __builtin_amdgcn_wave_barrier();  // LDS accesses of one wave execute in order; this only pins the compiler
@@ -273,7 +291,7 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
         const float s2 = (float)__shfl(sad, best_l);
         const float s3 = (float)__shfl(sad, best_l + 1);
         delta_u = (float)(0.5 * (double)(s1 - s3) / (double)(s1 + s3 - 2 * s2));
-        if (delta_u < 1 && delta_u > -1) delta_u *= LR.sf;
+        if (delta_u < 1 && delta_u > -1) delta_u *= sf_r;
         else delta_u = 0.f;
       }
       float ru = r.x + delta_u;  // bestL itself is not added (quirk Q7)
@@ -309,13 +327,15 @@ void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const ui
                      d_best_dist, d_second);
 }
 
-void launch_stereo(hipStream_t s, const LevelDev* d_lv, const uint8_t* d_pyr, size_t img_pitch, const orbfe_keypoint* d_kps,
-                   const uint8_t* d_desc, const KpAux* d_aux, const float* d_kx, const short2* d_env, int n_chunks,
+void launch_stereo(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, size_t img_pitch, const orbfe_keypoint* d_kps,
+                   const uint8_t* d_desc, const KpAux* d_aux, const float* d_kx, uint32_t* d_rowoff, uint16_t* d_rowlist, int rows, int list_cap,
                    const int32_t* d_n_kp, int n_features, float fx, float bf, int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
                    int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs) {
   if (n_pairs <= 0 || n_features <= 0) return;
-  hipLaunchKernelGGL(k_stereo, dim3((n_features + 3) / 4, n_pairs), dim3(256), 0, s, d_lv, d_pyr, img_pitch, d_kps, d_desc,
-                     d_aux, d_kx, d_env, n_chunks, d_n_kp, n_features, fx, bf, cols0, mean_threshold, d_right_u, d_depth, d_n_match, d_best_right,
+  hipLaunchKernelGGL(k_rowtable, dim3(n_pairs), dim3(256), (size_t)(rows + 256) * sizeof(uint32_t), s, d_aux, d_n_kp, n_features, rows, list_cap,
+                     d_rowoff, d_rowlist, slot_r0, slot_step, pair0);
+  hipLaunchKernelGGL(k_stereo, dim3((n_features + 3) / 4, n_pairs), dim3(256), 0, s, d_lv, n_levels, d_pyr, img_pitch, d_kps, d_desc,
+                     d_kx, d_rowoff, d_rowlist, rows, list_cap, d_n_kp, n_features, fx, bf, cols0, mean_threshold, d_right_u, d_depth, d_n_match, d_best_right,
                      d_best_dist, slot_l0, slot_r0, slot_step, pair0);
 }
 

@@ -46,8 +46,8 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
 // k_match.hip
 void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, const uint32_t* d_off,
                              const uint32_t* d_cand, int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second);
-void launch_stereo(hipStream_t s, const LevelDev* d_lv, const uint8_t* d_pyr, size_t img_pitch, const orbfe_keypoint* d_kps,
-                   const uint8_t* d_desc, const KpAux* d_aux, const float* d_kx, const short2* d_env, int n_chunks,
+void launch_stereo(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, size_t img_pitch, const orbfe_keypoint* d_kps,
+                   const uint8_t* d_desc, const KpAux* d_aux, const float* d_kx, uint32_t* d_rowoff, uint16_t* d_rowlist, int rows, int list_cap,
                    const int32_t* d_n_kp, int n_features, float fx, float bf, int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
                    int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs);
 // k_glue.hip
@@ -207,6 +207,9 @@ struct orbfe_ctx {
   float* d_kx = nullptr;         // per keypoint x (level-0 coordinates), SoA copy for the stereo candidate scan
   short2* d_env = nullptr;       // per chunk of 64 keypoints: [min row_min, max row_max) envelope
   int n_chunks = 0;
+  uint32_t* d_rowoff = nullptr;  // per pair: offsets[height + 1] of the right image's row table (createRowIndexDB)
+  uint16_t* d_rowlist = nullptr; // per pair: the table's entries, row_list_cap = n_features x the widest band
+  int row_list_cap = 0;
   double *d_right_u = nullptr, *d_depth = nullptr;
   int32_t *d_n_match = nullptr, *d_best_right = nullptr, *d_best_dist = nullptr;
   // generic staging for match / BA calls
@@ -702,7 +705,8 @@ static orbfe_status run_stereo(orbfe_ctx* c, hipStream_t st, int slot_l0, int sl
   HIP_TRY(c, hipMemsetAsync(c->d_n_match + pair0, 0, sizeof(int32_t) * n_pairs, st));
   {
     StageTimer t(c, ORBFE_STAGE_STEREO, st);
-    launch_stereo(st, c->d_lv, c->d_pyr, c->img_pitch, c->d_kps, c->d_desc, c->d_aux, c->d_kx, c->d_env, c->n_chunks, c->d_n_kp,
+    launch_stereo(st, c->d_lv, c->cfg.n_levels, c->d_pyr, c->img_pitch, c->d_kps, c->d_desc, c->d_aux, c->d_kx, c->d_rowoff, c->d_rowlist,
+                  c->cfg.height, c->row_list_cap, c->d_n_kp,
                   c->cfg.n_features, fx, bf,
                   c->cfg.width, kMeanThreshold, c->d_right_u, c->d_depth, c->d_n_match, c->d_best_right, c->d_best_dist, slot_l0,
                   slot_r0, slot_step, pair0, n_pairs);
@@ -741,7 +745,7 @@ void orbfe_destroy(orbfe_ctx* c) {
   void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_rs_tiles, c->d_pattern, c->d_pyr,     c->d_blur,
                   c->d_scr_a, c->d_scr_c,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_kp,
                   c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos, c->d_kx, c->d_env, c->d_kpl,   c->d_right_u, c->d_depth, c->d_n_match,
-                  c->d_best_right, c->d_best_dist, c->d_tmp};
+                  c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -902,6 +906,14 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   c->n_chunks = (int)((NF + 63) / 64);
   ALLOC(c->d_kx, M * NF);
   ALLOC(c->d_env, M * (size_t)c->n_chunks);
+  {
+    // widest band of createRowIndexDB: rows rn(y - r) .. rn(y + r + 1) - 1 with r = 2 * scale of the coarsest level
+    float sf_max = 1.f;
+    for (int l = 0; l < NL; ++l) sf_max = std::max(sf_max, c->lv[l].sf);
+    c->row_list_cap = (int)NF * ((int)(4.0f * sf_max) + 4);
+  }
+  ALLOC(c->d_rowoff, NP * (size_t)(c->cfg.height + 1));
+  ALLOC(c->d_rowlist, NP * (size_t)c->row_list_cap);
   ALLOC(c->d_right_u, NP * NF);
   ALLOC(c->d_depth, NP * NF);
   ALLOC(c->d_n_match, NP);
