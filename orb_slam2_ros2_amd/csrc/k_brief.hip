@@ -152,12 +152,11 @@ __global__ __launch_bounds__(256) void k_ic_moments(const uint8_t* __restrict__ 
 __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv, const uint4* __restrict__ kpl, int n_features,
                                                 const int2* __restrict__ moments, double2* __restrict__ sincos,
                                                 orbfe_keypoint* __restrict__ kps, KpAux* __restrict__ aux, float* __restrict__ kx,
-                                                short2* __restrict__ env, int n_chunks, double* __restrict__ theta_out, int rows0) {
+                                                double* __restrict__ theta_out, int rows0) {
 #pragma clang fp contract(off)
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int img = blockIdx.y;
   const uint4 e = (k < n_features) ? kpl[(size_t)img * n_features + k] : make_uint4(0xFFFFu, 0u, 0u, 0u);
-  int row_min = 32767, row_max = -1;
   if ((e.x & 0xFFFFu) != 0xFFFFu) {
     const int level = (int)(e.y & 0xFFu);
     const LevelDev& L = lv[level];
@@ -181,19 +180,12 @@ __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv,
     // createRowIndexDB band (ORBMatcher.cc:924-927), stored with the keypoint for the stereo matcher
     const float r = (float)(2.0 * (double)L.sf);
     const unsigned row = (unsigned)__float2int_rn(kp.y);
-    row_max = min(rows0, __float2int_rn((float)row + r + 1.0f));
-    row_min = max(0, __float2int_rn((float)row - r));
     KpAux a;
-    a.row_max = (int16_t)row_max;
-    a.row_min = (int16_t)row_min;
+    a.row_max = (int16_t)min(rows0, __float2int_rn((float)row + r + 1.0f));
+    a.row_min = (int16_t)max(0, __float2int_rn((float)row - r));
     aux[o] = a;
     if (theta_out) theta_out[o] = theta;
   }
-  // row envelope of the 64 keypoints of this wave (= one chunk of the stereo matcher's candidate scan)
-  const int emin = wave_reduce_dpp<OpMinI>(row_min);
-  const int emax = wave_reduce_dpp<OpMaxI>(row_max);
-  const int chunk = k >> 6;
-  if ((threadIdx.x & 63) == 0 && chunk < n_chunks) env[(size_t)img * n_chunks + chunk] = make_short2((short)emin, (short)emax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -322,7 +314,7 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __res
 void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
-                         int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx, short2* d_env, int n_chunks,
+                         int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx,
                          uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief, hipEvent_t before_lists) {
   if (n_img <= 0 || n_features <= 0) return;
   UmaxPacked u = 0;
@@ -333,7 +325,7 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
   hipLaunchKernelGGL(k_ic_moments, dim3((n_features + 15) / 16, n_img), dim3(256), 0, s, d_pyr, img_pitch, d_kpl, n_features, u,
                      d_moments);
   hipLaunchKernelGGL(k_orient, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, d_kpl, n_features, d_moments, d_sincos,
-                     d_kps, d_aux, d_kx, d_env, n_chunks, d_theta, rows0);
+                     d_kps, d_aux, d_kx, d_theta, rows0);
   if (before_brief) (void)hipStreamWaitEvent(s, before_brief, 0);  // the blurred planes come from another stream
   hipLaunchKernelGGL(k_brief, dim3((((n_features + BRIEF_WAVES - 1) / BRIEF_WAVES) + 7) & ~7, n_img), dim3(64 * BRIEF_WAVES), 0, s, d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos,
                      d_desc);

@@ -265,16 +265,16 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
       if (lane < 55) {
         const int Lidx = lane % 11, part = lane / 11;
         // each shifted right patch subtracts ITS OWN centre pixel (SAD(), ORBMatcher.cc:901-903)
-        const int c2 = br[5 * 28 + 5 + Lidx];
+        const uint32_t c2 = br[5 * 28 + 5 + Lidx];
+        uint32_t acc = 0;
         for (int rr = part; rr < 11; rr += 5) {
           const uint8_t* pl = bl + rr * 16;
           const uint8_t* pr = br + rr * 28 + Lidx;
 #pragma unroll
-          for (int cc = 0; cc < 11; ++cc) {
-            const int dlt = ((int)pl[cc] - c1) - ((int)pr[cc] - c2);
-            partial += dlt < 0 ? -dlt : dlt;
-          }
+          for (int cc = 0; cc < 11; ++cc)  // |(pl - c1) - (pr - c2)| = |(pl + c2) - (pr + c1)|, both sides non-negative: one v_sad_u32
+            acc = __builtin_amdgcn_sad_u16((uint32_t)pl[cc] + c2, (uint32_t)pr[cc] + (uint32_t)c1, acc);
         }
+        partial = (int)acc;
       }
       int sad = partial;
       sad += __shfl(partial, (lane + 11) & 63);

@@ -41,7 +41,7 @@ void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const ui
 void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
-                         int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx, short2* d_env, int n_chunks,
+                         int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx,
                          uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief, hipEvent_t before_lists);
 // k_match.hip
 void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, const uint32_t* d_off,
@@ -205,8 +205,6 @@ struct orbfe_ctx {
   int2* d_moments = nullptr;     // per keypoint (m10, m01)
   double2* d_sincos = nullptr;   // per keypoint (sin, cos) of the orientation
   float* d_kx = nullptr;         // per keypoint x (level-0 coordinates), SoA copy for the stereo candidate scan
-  short2* d_env = nullptr;       // per chunk of 64 keypoints: [min row_min, max row_max) envelope
-  int n_chunks = 0;
   uint32_t* d_rowoff = nullptr;  // per pair: offsets[height + 1] of the right image's row table (createRowIndexDB)
   uint16_t* d_rowlist = nullptr; // per pair: the table's entries, row_list_cap = n_features x the widest band
   int row_list_cap = 0;
@@ -692,7 +690,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     launch_orient_brief(st, c->d_lv, nl, pyr, blur, c->img_pitch, c->d_sel + i0 * NF, c->d_sel_count + i0 * nl, c->cfg.n_features,
                         c->d_pattern, c->umax, c->d_kps + i0 * NF, c->d_desc + i0 * NF * 32, c->d_aux + i0 * NF, c->d_n_kp + i0,
                         c->d_theta + i0 * NF, c->d_moments + i0 * NF, c->d_sincos + i0 * NF, c->d_kx + i0 * NF,
-                        c->d_env + i0 * c->n_chunks, c->n_chunks, c->d_kpl + i0 * NF, c->cfg.height, n_img,
+                        c->d_kpl + i0 * NF, c->cfg.height, n_img,
                         overlap_blur ? c->ev_blur_done : nullptr, before_lists);
   }
   HIP_TRY(c, hipGetLastError());
@@ -744,7 +742,7 @@ void orbfe_destroy(orbfe_ctx* c) {
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_rs_tiles, c->d_pattern, c->d_pyr,     c->d_blur,
                   c->d_scr_a, c->d_scr_c,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_kp,
-                  c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos, c->d_kx, c->d_env, c->d_kpl,   c->d_right_u, c->d_depth, c->d_n_match,
+                  c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos, c->d_kx, c->d_kpl,   c->d_right_u, c->d_depth, c->d_n_match,
                   c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -903,9 +901,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   ALLOC(c->d_moments, M * NF);
   ALLOC(c->d_kpl, M * NF);
   ALLOC(c->d_sincos, M * NF);
-  c->n_chunks = (int)((NF + 63) / 64);
   ALLOC(c->d_kx, M * NF);
-  ALLOC(c->d_env, M * (size_t)c->n_chunks);
   {
     // widest band of createRowIndexDB: rows rn(y - r) .. rn(y + r + 1) - 1 with r = 2 * scale of the coarsest level
     float sf_max = 1.f;
