@@ -813,6 +813,10 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   };
   orbfe_status st = build_geometry(c);
   if (st != ORBFE_OK) return bail(st);
+  if (c->kp_cap > 65535) {  // the stereo matcher's row table and its (distance, index) keys hold a keypoint index in 16 bits
+    fail(c, ORBFE_EBADSIZE, "orbfe_create: %d keypoints per image exceed 65535", c->kp_cap);
+    return bail(ORBFE_EBADSIZE);
+  }
   c->cfg.n_features = c->kp_cap;  // from here on n_features is the per-image array stride (the quotas keep the requested value)
   if (hipSetDevice(c->device) != hipSuccess) {
     fail(c, ORBFE_EDEVICE, "hipSetDevice(%d) failed", c->device);

@@ -486,3 +486,36 @@ def test_host_images_with_padded_rows(orc, lib):
     assert np.array_equal(k0, ref["lk"]) and np.array_equal(d0, ref["ld"]) and np.array_equal(k1, ref["rk"]) and np.array_equal(d1, ref["rd"])
     assert ctx.stereo_match(0, 1, FX, BF)[0] == ref["n_matches"]
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_stereo_row_table_edge_cases(orc, lib):
+    """searchByStereo on inputs that stress the right image's row table (createRowIndexDB, ORBMatcher.cc:915-932): every keypoint
+    inside one narrow horizontal band (rows with hundreds of candidates, most rows empty), an empty right or left image, and a right
+    image whose content lies to the RIGHT of the left one (every candidate fails the u-range)."""
+    W, H, NF, NL = 640, 240, 800, 6
+    rng = np.random.default_rng(11)
+    tex = rng.integers(0, 256, (H, W + 64)).astype(np.uint8)
+    band = np.full((H, W + 64), 90, np.uint8)
+    band[100:150] = tex[100:150]                                  # texture in 50 rows only
+    blank = np.full((H, W), 77, np.uint8)
+    cases = [(band[:, 20:20 + W], band[:, 32:32 + W]),           # dense band, disparity 12
+             (tex[:, 0:W], tex[:, 9:9 + W]),                      # texture everywhere, disparity 9
+             (band[:, 20:20 + W], blank), (blank, band[:, 20:20 + W]),
+             (tex[:, 40:40 + W], tex[:, 0:W])]                    # negative disparity: nothing may match
+    ctx = lib.Context(W, H, n_features=NF, n_levels=NL, max_images=2)
+    for ci, (L, R) in enumerate(cases):
+        L, R = np.ascontiguousarray(L), np.ascontiguousarray(R)
+        (lk, ld), (rk, rd) = ctx.extract_batch([L, R])
+        nm, ru, dp, br, bd = ctx.stereo_match(0, 1, 500.0, 50.0)
+        assert (nm > 50) if ci < 2 else (nm == 0), (ci, nm)
+        exl, exr = orc.extractor(L, n_features=NF, n_levels=NL), orc.extractor(R, n_features=NF, n_levels=NL)
+        okl, odl = exl.extract()
+        okr, odr = exr.extract()
+        assert len(lk) == len(okl) and len(rk) == len(okr)
+        om, oru, odp, obr, obd = exl.stereo_match(exr, okl, odl, okr, odr, 500.0, 50.0)
+        n = len(okl)
+        assert nm == om
+        assert np.array_equal(ru[:n].view(np.int64), oru.view(np.int64)) and np.array_equal(dp[:n].view(np.int64), odp.view(np.int64))
+        assert np.array_equal(br[:n], obr) and np.array_equal(bd[:n], obd)
+    ctx.close()
