@@ -200,7 +200,10 @@ __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv,
 #ifndef BRIEF_WAVES
 #define BRIEF_WAVES 4
 #endif
-__global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __restrict__ blur, size_t img_pitch,
+#ifndef BRIEF_KPW
+#define BRIEF_KPW 2  // consecutive keypoints per wave (measured: 2 and 3 equal, 4 and 8 slower -- fewer, longer waves balance worse)
+#endif
+__global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_brief(const uint8_t* __restrict__ blur, size_t img_pitch,
                                               const uint4* __restrict__ kpl, int n_features, const int8_t* __restrict__ pattern,
                                               const double2* __restrict__ sincos, uint8_t* __restrict__ desc) {
 #pragma clang fp contract(off)
@@ -221,93 +224,124 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) void k_brief(const uint8_t* __res
   __shared__ Lds lds;
   const int lane = threadIdx.x & 63;
   uint32_t* win = lds.win[threadIdx.x >> 6];
+  double* rc = lds.rc[threadIdx.x >> 6];
+  double* rs = lds.rs[threadIdx.x >> 6];
   // XCD-aware block order: workgroups go round-robin to the 8 XCDs (own L2 each) and consecutive keypoints are spatial neighbours
   // (candidate order) whose 37x37 windows overlap; block b of the grid takes keypoint block (b % 8) * (grid / 8) + b / 8, so one XCD
-  // works through one contiguous eighth of the list (gridDim.x is a multiple of 8).  Fetched bytes 2.69 -> 0.85 GB per 1024 images;
-  // the time does not change (same-box A/B: 8.86 vs 8.87 ms per 512 pairs) -- the kernel is bound by the L1 fill rate.
+  // works through one contiguous eighth of the list (gridDim.x is a multiple of 8).  Fetched bytes 2.69 -> 0.85 GB per 1024 images.
   const int per_xcd = (int)gridDim.x >> 3;
   const int kb = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-  const int k = kb * BRIEF_WAVES + (threadIdx.x >> 6);
+  const int k0 = (kb * BRIEF_WAVES + (threadIdx.x >> 6)) * BRIEF_KPW;
   const int img = blockIdx.y;
-  if (k >= n_features) return;
-  // two dependent memory round trips per wave: the list entry, then the whole window + sin/cos + the lane's four template
-  // pairs, all requested before anything is consumed (window indices past the end re-read the last word)
-  const uint4 e = kpl[(size_t)img * n_features + k];
-  if ((e.x & 0xFFFFu) == 0xFFFFu) return;  // wave-uniform
-  const int x = (int)(e.x & 0xFFFFu), y = (int)(e.x >> 16);
+  if (k0 >= n_features) return;
+  // A wave with one keypoint spent two thirds of its life parked at s_waitcnt: list entry -> window -> tests are dependent round
+  // trips, and eight waves per SIMD do not cover them.  A wave now works through BRIEF_KPW consecutive keypoints as a three-stage
+  // pipeline: while keypoint i is tested, the window and sin / cos of keypoint i + 1 are in flight (parked in registers) and so is
+  // the list entry of keypoint i + 2; the lane's template pairs are fetched once.
+  const uint4* list = kpl + (size_t)img * n_features;
+  const double2* sc = sincos + (size_t)img * n_features;
   const uint8_t* W = blur + (size_t)img * img_pitch;  // wave-uniform base; the rest of the address is a 32-bit offset
-  const uint32_t plane = e.z;
-  const int stride = (int)e.w;
-  const int xa = (x - BRIEF_R) & ~3;
-  // window load: 5 rows x 11 words per pass over lanes 0..54 (lane = 11 r0 + c0), 8 passes; a pass adds a wave-uniform 5 * stride to
-  // one address and parks its words at lane + 55 * pass -- one v_add per load where the flat index -> (row, word) split cost five
-  // (the kernel is VALU-bound: ~260 instructions per keypoint)
-  constexpr int NIT = (BRIEF_ROWS + 4) / 5;
-  const int ll = min(lane, 54);
-  const int r0 = (ll * 373) >> 12, c0 = ll - r0 * BRIEF_WORDS;  // ll / 11 for ll < 64
-  const uint32_t step = 5u * (uint32_t)__builtin_amdgcn_readfirstlane(stride);
-  const uint32_t a0 = plane + (uint32_t)mad24u(y - BRIEF_R + r0, stride, xa + 4 * c0);
-  uint32_t wv[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT - 1; ++it) wv[it] = *(const uint32_t*)(W + (a0 + (uint32_t)it * step));
-  {  // last pass: rows 35, 36 exist, the lanes of rows 37..39 re-read row 36
-    const int r = min(r0 + 5 * (NIT - 1), BRIEF_ROWS - 1);
-    wv[NIT - 1] = *(const uint32_t*)(W + (plane + (uint32_t)mad24u(y - BRIEF_R + r, stride, xa + 4 * c0)));
-  }
-  const double2 scv = sincos[(size_t)img * n_features + k];
+  const int k_last = min(k0 + BRIEF_KPW, n_features) - 1;
   uint32_t tp[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) tp[g] = *(const uint32_t*)(pattern + (g * 64 + lane) * 4);
-  if (lane < 55) {
+  // window load: 5 rows x 11 words per pass over lanes 0..54 (lane = 11 r0 + c0), 8 passes; a pass adds a wave-uniform 5 * stride to
+  // one address and parks its words at lane + 55 * pass -- one v_add per load where the flat index -> (row, word) split cost five
+  constexpr int NIT = (BRIEF_ROWS + 4) / 5;
+  const int ll = min(lane, 54);
+  const int r0 = (ll * 373) >> 12, c0 = ll - r0 * BRIEF_WORDS;  // ll / 11 for ll < 64
+  const int r_last = min(r0 + 5 * (NIT - 1), BRIEF_ROWS - 1);    // last pass: rows 35, 36 exist, the lanes of rows 37..39 re-read row 36
+  struct Stage {
+    uint32_t wv[NIT];
+    double2 scv;
+  };
+  // requests the window and sin / cos of the keypoint in entry e (an unused slot -- x = 0xFFFF -- reads row 0 of plane 0: harmless)
+  auto request = [&](const uint4 e, int k, Stage& st) __attribute__((always_inline)) {
+    const bool used = (e.x & 0xFFFFu) != 0xFFFFu;
+    const int x = used ? (int)(e.x & 0xFFFFu) : BRIEF_R, y = used ? (int)(e.x >> 16) : BRIEF_R;
+    const uint32_t plane = used ? e.z : 0u;
+    const int stride = used ? (int)e.w : 0;
+    const int xa = (x - BRIEF_R) & ~3;
+    const uint32_t step = 5u * (uint32_t)__builtin_amdgcn_readfirstlane(stride);
+    const uint32_t a0 = plane + (uint32_t)mad24u(y - BRIEF_R + r0, stride, xa + 4 * c0);
 #pragma unroll
-    for (int it = 0; it < NIT - 1; ++it) win[lane + 55 * it] = wv[it];
-    if (r0 + 5 * (NIT - 1) < BRIEF_ROWS) win[lane + 55 * (NIT - 1)] = wv[NIT - 1];
-  }
-  const double sn = scv.x, cs = scv.y;
-  // The rotation needs x cos, x sin, y cos, y sin in fp64 for 512 template points, but the coordinates are small integers:
-  // 37 lanes form the products once ((double)v * cs is exactly what the per-point expression computes), every point then
-  // takes two LDS reads and one fp64 add per coordinate instead of two fp64 multiplies and a conversion.
-  double* rc = lds.rc[threadIdx.x >> 6];
-  double* rs = lds.rs[threadIdx.x >> 6];
-  if (lane <= 2 * BRIEF_R) {
-    const double v = (double)(float)(lane - BRIEF_R);
-    rc[lane] = v * cs;
-    rs[lane] = v * sn;
-  }
-  // the LDS accesses of one wave execute in order, so the window and the table written above are visible to every lane of this
-  // wave; the fence only pins the compiler
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  const uint8_t* wb = (const uint8_t*)win;
-  const float px = (float)x, py = (float)y;
-  const int xbias = 0x4B400000 + xa, ybias = 0x4B400000 + (y - BRIEF_R);  // bit pattern of 1.5 * 2^23 + the window origin
-  unsigned long long bits[4];
+    for (int it = 0; it < NIT - 1; ++it) st.wv[it] = *(const uint32_t*)(W + (a0 + (uint32_t)it * step));
+    st.wv[NIT - 1] = *(const uint32_t*)(W + (plane + (uint32_t)mad24u(y - BRIEF_R + r_last, stride, xa + 4 * c0)));
+    st.scv = sc[k];
+  };
+  uint4 e_cur = list[k0];
+  uint4 e_nxt = list[min(k0 + 1, k_last)];
+  Stage st_cur;
+  request(e_cur, k0, st_cur);
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int x1 = (int)(int8_t)(tp[g] & 255u), y1 = (int)(int8_t)((tp[g] >> 8) & 255u);
-    const int x2 = (int)(int8_t)((tp[g] >> 16) & 255u), y2 = (int)(int8_t)(tp[g] >> 24);
-    // float * double -> double, one rounding to float (rotateTemplate, ORBExtractor.cc:537-538)
-    const float p1x = (float)(rc[x1 + BRIEF_R] - rs[y1 + BRIEF_R]);  // x1 cos - y1 sin
-    const float p1y = (float)(rs[x1 + BRIEF_R] + rc[y1 + BRIEF_R]);  // x1 sin + y1 cos
-    const float p2x = (float)(rc[x2 + BRIEF_R] - rs[y2 + BRIEF_R]);
-    const float p2y = (float)(rs[x2 + BRIEF_R] + rc[y2 + BRIEF_R]);
-    // cvRound(float sum) minus the window origin in two instructions instead of four (v_rndne, v_cvt, v_sub after the add): adding
-    // 1.5 * 2^23 rounds the sum to an integer with ties to even -- the unit in the last place of the result is 1 -- and leaves that
-    // integer in the low mantissa bits, so one integer subtraction removes the constant's bit pattern AND the origin.  Exact for
-    // |sum| < 2^22 (coordinates are < 2^12); the two float additions are not contracted or re-associated (fp contract off, no fast-math).
-    const int r1o = __float_as_int((py + p1y) + 12582912.0f) - ybias, c1o = __float_as_int((px + p1x) + 12582912.0f) - xbias;
-    const int r2o = __float_as_int((py + p2y) + 12582912.0f) - ybias, c2o = __float_as_int((px + p2x) + 12582912.0f) - xbias;
-    const int v1 = wb[mad24u(r1o, BRIEF_WORDS * 4, c1o)];
-    const int v2 = wb[mad24u(r2o, BRIEF_WORDS * 4, c2o)];
-    bits[g] = __ballot(v1 < v2);
-  }
-  if (lane < 4) {
-    unsigned long long* d64 = (unsigned long long*)(desc + ((size_t)img * n_features + k) * 32);
-    unsigned long long b = bits[0];
-    if (lane == 1) b = bits[1];
-    if (lane == 2) b = bits[2];
-    if (lane == 3) b = bits[3];
-    d64[lane] = b;
+  for (int i = 0; i < BRIEF_KPW; ++i) {
+    const int k = k0 + i;
+    if (k > k_last) break;  // wave-uniform
+    // stage 1 / 2 for the keypoints behind this one
+    const uint4 e_nn = list[min(k + 2, k_last)];
+    Stage st_nxt;
+    if (i + 1 < BRIEF_KPW) request(e_nxt, min(k + 1, k_last), st_nxt);
+    if ((e_cur.x & 0xFFFFu) != 0xFFFFu) {  // wave-uniform
+      const int x = (int)(e_cur.x & 0xFFFFu), y = (int)(e_cur.x >> 16);
+      const int xa = (x - BRIEF_R) & ~3;
+      if (lane < 55) {
+#pragma unroll
+        for (int it = 0; it < NIT - 1; ++it) win[lane + 55 * it] = st_cur.wv[it];
+        if (r0 + 5 * (NIT - 1) < BRIEF_ROWS) win[lane + 55 * (NIT - 1)] = st_cur.wv[NIT - 1];
+      }
+      const double sn = st_cur.scv.x, cs = st_cur.scv.y;
+      // The rotation needs x cos, x sin, y cos, y sin in fp64 for 512 template points, but the coordinates are small integers:
+      // 37 lanes form the products once ((double)v * cs is exactly what the per-point expression computes), every point then
+      // takes two LDS reads and one fp64 add per coordinate instead of two fp64 multiplies and a conversion.
+      if (lane <= 2 * BRIEF_R) {
+        const double v = (double)(float)(lane - BRIEF_R);
+        rc[lane] = v * cs;
+        rs[lane] = v * sn;
+      }
+      // the LDS accesses of one wave execute in order, so the window and the table written above are visible to every lane of this
+      // wave; the fence only pins the compiler
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const uint8_t* wb = (const uint8_t*)win;
+      const float px = (float)x, py = (float)y;
+      const int xbias = 0x4B400000 + xa, ybias = 0x4B400000 + (y - BRIEF_R);  // bit pattern of 1.5 * 2^23 + the window origin
+      unsigned long long bits[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int x1 = (int)(int8_t)(tp[g] & 255u), y1 = (int)(int8_t)((tp[g] >> 8) & 255u);
+        const int x2 = (int)(int8_t)((tp[g] >> 16) & 255u), y2 = (int)(int8_t)(tp[g] >> 24);
+        // float * double -> double, one rounding to float (rotateTemplate, ORBExtractor.cc:537-538)
+        const float p1x = (float)(rc[x1 + BRIEF_R] - rs[y1 + BRIEF_R]);  // x1 cos - y1 sin
+        const float p1y = (float)(rs[x1 + BRIEF_R] + rc[y1 + BRIEF_R]);  // x1 sin + y1 cos
+        const float p2x = (float)(rc[x2 + BRIEF_R] - rs[y2 + BRIEF_R]);
+        const float p2y = (float)(rs[x2 + BRIEF_R] + rc[y2 + BRIEF_R]);
+        // cvRound(float sum) minus the window origin in two instructions instead of four (v_rndne, v_cvt, v_sub after the add): adding
+        // 1.5 * 2^23 rounds the sum to an integer with ties to even -- the unit in the last place of the result is 1 -- and leaves that
+        // integer in the low mantissa bits, so one integer subtraction removes the constant's bit pattern AND the origin.  Exact for
+        // |sum| < 2^22 (coordinates are < 2^12); the two float additions are not contracted or re-associated (fp contract off, no fast-math).
+        const int r1o = __float_as_int((py + p1y) + 12582912.0f) - ybias, c1o = __float_as_int((px + p1x) + 12582912.0f) - xbias;
+        const int r2o = __float_as_int((py + p2y) + 12582912.0f) - ybias, c2o = __float_as_int((px + p2x) + 12582912.0f) - xbias;
+        const int v1 = wb[mad24u(r1o, BRIEF_WORDS * 4, c1o)];
+        const int v2 = wb[mad24u(r2o, BRIEF_WORDS * 4, c2o)];
+        bits[g] = __ballot(v1 < v2);
+      }
+      if (lane < 4) {
+        unsigned long long* d64 = (unsigned long long*)(desc + ((size_t)img * n_features + k) * 32);
+        unsigned long long b = bits[0];
+        if (lane == 1) b = bits[1];
+        if (lane == 2) b = bits[2];
+        if (lane == 3) b = bits[3];
+        d64[lane] = b;
+      }
+      // every lane has read what it needs of this window and table before the next keypoint's are parked over them
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (i + 1 < BRIEF_KPW) {
+      e_cur = e_nxt;
+      e_nxt = e_nn;
+      st_cur = st_nxt;
+    }
   }
 }
 
@@ -327,8 +361,8 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
   hipLaunchKernelGGL(k_orient, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, d_kpl, n_features, d_moments, d_sincos,
                      d_kps, d_aux, d_kx, d_theta, rows0);
   if (before_brief) (void)hipStreamWaitEvent(s, before_brief, 0);  // the blurred planes come from another stream
-  hipLaunchKernelGGL(k_brief, dim3((((n_features + BRIEF_WAVES - 1) / BRIEF_WAVES) + 7) & ~7, n_img), dim3(64 * BRIEF_WAVES), 0, s, d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos,
-                     d_desc);
+  hipLaunchKernelGGL(k_brief, dim3((((n_features + BRIEF_WAVES * BRIEF_KPW - 1) / (BRIEF_WAVES * BRIEF_KPW)) + 7) & ~7, n_img), dim3(64 * BRIEF_WAVES), 0, s,
+                     d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos, d_desc);
 }
 
 }  // namespace orbfe
