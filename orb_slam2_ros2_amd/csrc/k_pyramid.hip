@@ -173,7 +173,7 @@ __device__ __forceinline__ uint32_t mad24(uint32_t tap_uniform, uint32_t v, uint
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ uint32_t wave_shl1(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130, 0xf, 0xf, false); }
 
-__global__ __launch_bounds__(256) void k_blur(const LevelDev* __restrict__ lv, int n_levels, const uint8_t* __restrict__ pyr,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur(const LevelDev* __restrict__ lv, int n_levels, const uint8_t* __restrict__ pyr,
                                               uint8_t* __restrict__ blur, size_t img_pitch, BlurTaps taps) {
   const int img = blockIdx.y;
   const int tile = blockIdx.x;
@@ -220,29 +220,26 @@ __global__ __launch_bounds__(256) void k_blur(const LevelDev* __restrict__ lv, i
 
   const int n_out = min(BLUR_ROWS, h - y0);
   const int n_in = n_out + 6;
-  for (int r0 = 0; r0 < n_in; r0 += 7) {
-    // issue the (up to) seven row loads of this group back to back: seven requests in flight per lane hide the
-    // memory latency that a load-use-load-use chain would expose 38 times per wave
-    uint32_t mrow[7];
+  // Seven row loads are always in flight per lane: the slot of a row is refilled with the row seven further down BEFORE the row is
+  // worked on (a rotating window in registers; the unrolled body keeps the slot indices static).  Loading a group of seven, working
+  // through it and only then requesting the next group left one exposed memory round trip per group -- six per wave, and the
+  // kernel's waves spent two thirds of their time at s_waitcnt.
+  auto load_row = [&](int r) __attribute__((always_inline)) -> uint32_t {
+    const int gy = reflect101(y0 + r - 3, h);
+    const uint8_t* row = P + (size_t)gy * stride;
+    if (fast_word) return *(const uint32_t*)(row + x4);
+    return (uint32_t)row[rx[0]] | ((uint32_t)row[rx[1]] << 8) | ((uint32_t)row[rx[2]] << 16) | ((uint32_t)row[rx[3]] << 24);
+  };
+  uint32_t mrow[7];
 #pragma unroll
-    for (int u = 0; u < 7; ++u) {
-      const int r = r0 + u;
-      mrow[u] = 0;
-      if (r < n_in) {  // wave-uniform
-        const int gy = reflect101(y0 + r - 3, h);
-        const uint8_t* row = P + (size_t)gy * stride;
-        if (fast_word) {
-          mrow[u] = *(const uint32_t*)(row + x4);
-        } else {
-          mrow[u] = (uint32_t)row[rx[0]] | ((uint32_t)row[rx[1]] << 8) | ((uint32_t)row[rx[2]] << 16) | ((uint32_t)row[rx[3]] << 24);
-        }
-      }
-    }
+  for (int u = 0; u < 7; ++u) mrow[u] = (u < n_in) ? load_row(u) : 0u;  // (n_in >= 7)
+  for (int r0 = 0; r0 < n_in; r0 += 7) {
 #pragma unroll
     for (int u = 0; u < 7; ++u) {
       const int r = r0 + u;
       if (r < n_in) {  // wave-uniform
         const uint32_t m = mrow[u];
+        if (r + 7 < n_in) mrow[u] = load_row(r + 7);  // wave-uniform
         const uint32_t lw = wave_shr1(m), rw = wave_shl1(m);
         // bytes B[0..11] = lw|m|rw; output j needs px[j-3..j+3] = B[1+j .. 7+j]: two unaligned 4-byte windows per
         // output (v_alignbyte) fed to two v_dot4_u32_u8 against the packed taps {t0..t3} and {t4..t6,0}
