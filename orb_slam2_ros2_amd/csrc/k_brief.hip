@@ -81,13 +81,35 @@ __global__ __launch_bounds__(256) void k_kplist(const LevelDev* __restrict__ lv,
 }
 
 // ---------------------------------------------------------------------------------------------
-// 1. intensity-centroid moments: FOUR keypoints per wave, one DPP row of 16 lanes each.  The 31x31 window of the
-//    UN-blurred plane is read as aligned 32-bit words (31 rows x 9 words = 18 loads per lane, all requested at once).
-//    The kernel is two dependent memory round trips (list entry, window) at full occupancy, so packing four independent
-//    keypoints into a wave is what raises its throughput (one keypoint per wave: 0.215 ms per 256 images).
+// 1. intensity-centroid moments: FOUR keypoints per wave, one DPP row of 16 lanes each.  The 31x31 disc of the UN-blurred plane is
+//    read as 32 rows x 8 words that start AT x - 15 (byte-aligned dword loads: gfx950 takes them), so what a lane does with its
+//    16 words no longer depends on the keypoint: lane `sub` of a row owns word sub & 7 of the rows (sub >> 3) + 2 it, it = 0..15
+//    -- one address, advanced by two image rows per load -- and its column offset dx = 4 (sub & 7) - 15 is a constant.  The disc
+//    mask of a word depends on (it, sub) only: the 256 masks are computed once per workgroup (one per thread) and read back from LDS.
+//    Per word that leaves one AND and three dot products that accumulate in place:
+//        S += sum of the bytes,  W += sum of byte position x byte,  T += it x sum of the bytes
+//    m10 = sum dx v = dx S + W;   m01 = sum dy v = (sub >> 3 - 15) S + 2 T       (then summed over the 16 lanes)
+//    (Before: aligned words, 9 per row, and ~35 instructions per word to rebuild row, column, disc width and mask from the flat
+//    index for every keypoint: 669 vector instructions per wave, now ~170.)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ic_moments(const uint8_t* __restrict__ pyr, size_t img_pitch, const uint4* __restrict__ kpl,
                                                     int n_features, UmaxPacked umax, int2* __restrict__ moments) {
+  __shared__ uint32_t s_mask[256];
+  {
+    const int it = threadIdx.x >> 4, sb = threadIdx.x & 15;
+    const int dy = (sb >> 3) + 2 * it - 15;
+    const int ady = dy < 0 ? -dy : dy;
+    uint32_t mask = 0u;
+    if (ady <= 15) {
+      const int d = (int)((umax >> (4 * ady)) & 15ull);
+      const int dx0 = 4 * (sb & 7) - 15;
+      // bytes lo..hi of the word lie inside the disc row |dx| <= d
+      const int lo = max(0, -d - dx0), hi = min(3, d - dx0);
+      mask = (hi >= lo) ? ((0xFFFFFFFFu >> (8 * (3 - hi))) & (0xFFFFFFFFu << (8 * lo))) : 0u;
+    }
+    s_mask[threadIdx.x] = mask;
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63, sub = lane & 15;
   const int k = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
   const int img = blockIdx.y;
@@ -98,44 +120,29 @@ __global__ __launch_bounds__(256) void k_ic_moments(const uint8_t* __restrict__ 
   const uint8_t* I = pyr + (size_t)img * img_pitch;  // wave-uniform base; the rest of the address is a 32-bit offset
   const uint32_t plane = valid ? e.z : 0u;
   const int stride = valid ? (int)e.w : 64;
-  const int xa = (x - 15) & ~3;  // first aligned word of a row of the window
-  constexpr int NIT = (31 * 9 + 15) / 16;
+  constexpr int NIT = 16;
+  const uint32_t a0 = plane + (uint32_t)mad24u(y - 15 + (sub >> 3), stride, x - 15 + 4 * (sub & 7));  // rows and strides < 2^13
+  const uint32_t step = 2u * (uint32_t)stride;
   uint32_t wv[NIT];
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {  // indices past the end re-read the last word
-    const int idx = min(it * 16 + sub, 31 * 9 - 1);
-    const int r = (idx * 7282) >> 16;  // idx / 9 for idx < 320
-    const int c = idx - r * 9;
-    wv[it] = *(const uint32_t*)(I + (plane + (uint32_t)mad24u(y + r - 15, stride, xa + 4 * c)));  // rows and strides < 2^13
+  for (int it = 0; it < NIT; ++it) {  // (the last load of the upper half-row is row y + 16: masked out, inside the image -- the border is 19)
+    uint32_t w;
+    __builtin_memcpy(&w, I + (a0 + (uint32_t)it * step), 4);
+    wv[it] = w;
   }
-  int m10 = 0, m01 = 0;
+  uint32_t S = 0u, Wp = 0u, T = 0u;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int idx = it * 16 + sub;
-    const int r = (idx * 7282) >> 16;
-    const int c = idx - r * 9;
-    if (r < 31) {
-      const int dy = r - 15;
-      const int ady = dy < 0 ? -dy : dy;
-      const int d = (int)((umax >> (4 * ady)) & 15ull);
-      const int dx0 = xa + 4 * c - x;
-      // bytes lo..hi of the word lie inside the disc row |dx| <= d: mask them, then two dot products give the byte sum and the
-      // position-weighted byte sum (sum dx_b v_b = dx0 sum v_b + sum b v_b)
-      const int lo = max(0, -d - dx0), hi = min(3, d - dx0);
-      const uint32_t mask = (hi >= lo) ? ((0xFFFFFFFFu >> (8 * (3 - hi))) & (0xFFFFFFFFu << (8 * lo))) : 0u;
-      const uint32_t w = wv[it] & mask;
-      const int sum = (int)__builtin_amdgcn_udot4(w, 0x01010101u, 0u, false);
-      const int wsum = (int)__builtin_amdgcn_udot4(w, 0x03020100u, 0u, false);
-      // (plain products on purpose: `sum` comes out of v_dot4, and on gfx950 another VALU instruction may read a dot result only
-      // three wait states later -- the compiler inserts them for its own instructions but does not look inside an asm statement:
-      // the inline-asm v_mad_i32_i24 tried here read stale sums, different from run to run)
-      // (and with ranges the compiler can see -- sum < 2^16, |dx0| < 2^7 -- so that it picks the full-rate 24-bit multiply itself: the
-      //  plain 32-bit product is v_mul_lo_u32, a quarter-rate instruction, twice per word)
-      const int sum16 = sum & 0xFFFF, dx8 = (int)(int8_t)dx0;
-      m10 += dx8 * sum16 + wsum;
-      m01 += dy * sum16;
-    }
+    const uint32_t w = wv[it] & s_mask[it * 16 + sub];
+    S = __builtin_amdgcn_udot4(w, 0x01010101u, S, false);
+    Wp = __builtin_amdgcn_udot4(w, 0x03020100u, Wp, false);
+    T = __builtin_amdgcn_udot4(w, 0x01010101u * (uint32_t)it, T, false);
   }
+  // (S < 2^18, |dx|, |dy| <= 15: plain products, the compiler sees the ranges and takes the 24-bit multiplier; its own instructions
+  //  also get the wait states a dot result needs before another instruction may read it -- an asm statement would not: wave_ops.h)
+  const int S18 = (int)(S & 0x3FFFFu);
+  int m10 = (4 * (sub & 7) - 15) * S18 + (int)Wp;
+  int m01 = ((sub >> 3) - 15) * S18 + 2 * (int)T;
   // sum over the 16 lanes of the row: lane 15 of each row ends up with the total
 #pragma unroll
   for (int sh = 0; sh < 4; ++sh) {
