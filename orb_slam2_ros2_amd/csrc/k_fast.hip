@@ -192,10 +192,14 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
           const int hi_of_lo = max(max(min(r0, r8), min(r4, r12)), max(min(r2, r10), min(r6, r14)));
           const int sb = lo_of_hi - v;  // > t: every opposite pair has a pixel brighter than v + t
           const int sd = v - hi_of_lo;  // > t: ... darker than v - t
-          const bool any = max(sb, sd) > thr, dual = min(sb, sd) > thr;
-          const unsigned long long m = __ballot(any), m2 = __ballot(dual);
+          // two compares; their lane masks are combined on the SCALAR unit and handed back as lane predicates (inverse ballot: the
+          // mask register is used as it is) -- max / min of the two margins and a compare each were four vector instructions
+          const bool pd = sd > thr;
+          const unsigned long long mb = __ballot(sb > thr), md = __ballot(pd);
+          const unsigned long long m = mb | md, m2 = mb & md;
+          const bool any = __builtin_amdgcn_inverse_ballot_w64(m), dual = __builtin_amdgcn_inverse_ballot_w64(m2);
           const uint32_t eh = e_lane + ((uint32_t)y0 << 7);
-          if (any) Q[nq + mbcnt64(m, 0)] = (uint16_t)(eh | (sd > thr ? 0u : Q_BRIGHT) | (dual ? Q_DUAL : 0u));
+          if (any) Q[nq + mbcnt64(m, 0)] = (uint16_t)(eh | (pd ? 0u : Q_BRIGHT) | (dual ? Q_DUAL : 0u));
           nq += __popcll(m);
           if (m2) {  // both polarities passed: the main entry scores the dark one, the list at the back of Q the bright one
             const int k = __popcll(m2);
