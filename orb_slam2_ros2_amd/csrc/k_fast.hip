@@ -274,8 +274,11 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
       if (q < nq) {
         const uint32_t e = Q[q];
         const uint8_t* c = V + Q_IY(e) * PV + Q_IX(e);  // top-left corner of the 3x3 neighbourhood
+        // all nine reads requested at once, one compare against the largest neighbour (v > max >= 0 also says v != 0): written as a
+        // chain of && the compiler made nine dependent LDS round trips of it, each behind its own branch
         const int v = c[PV + 1];
-        is_max = v != 0 && v > c[0] && v > c[1] && v > c[2] && v > c[PV] && v > c[PV + 2] && v > c[2 * PV] && v > c[2 * PV + 1] && v > c[2 * PV + 2];
+        const int n0 = c[0], n1 = c[1], n2 = c[2], n3 = c[PV], n4 = c[PV + 2], n5 = c[2 * PV], n6 = c[2 * PV + 1], n7 = c[2 * PV + 2];
+        is_max = v > max(max(max(n0, n1), n2), max(max(max(n3, n4), n5), max(n6, n7)));
         Q[q] = (uint16_t)(Q_XY(e) | (is_max ? Q_BRIGHT : 0u));  // (scores in the map are > t_pass by construction)
       }
       n_keep += __popcll(__ballot(is_max));
