@@ -141,6 +141,104 @@ __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv,
 }
 
 // ---------------------------------------------------------------------------------------------
+// resize, region-driven (r2): one workgroup stages ONE block of level 0 (RG_W x RG_H pixels + the halo its taps reach) and writes
+// the output words of ALL levels whose first source pixel lies in the block -- the reference resizes every level from level 0
+// (quirk Q1), and with one launch per tile class above each level staged its own copy of the plane: 3.9 GB through the L2 per
+// 1024 images, 0.72 ms of the 1.11 ms the three launches took with the arithmetic removed.  Here level 0 is staged once (plus halo).
+// The arithmetic is k_resize's; the taps of the region's words are staged in LDS already in the form the inner loop wants
+// (x: byte offset inside the staged tile and the two pre-shifted coefficients packed for v_dot2; y: the two row offsets and the two
+// coefficients << 8), so a word costs one 16-byte and two 16-byte LDS reads of taps, not their unpacking.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize_regions(const LevelDev* __restrict__ lv, int n_levels, const RsRegion* __restrict__ regions,
+                                                        const RgXTap* __restrict__ xtaps, const RgYTap* __restrict__ ytaps,
+                                                        uint8_t* __restrict__ pyr, size_t img_pitch, int tile_bytes, int xt_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t rs_lds[];
+  uint32_t* tile = rs_lds;
+  RgXTap* xs = (RgXTap*)(rs_lds + tile_bytes / 4);
+  RgYTap* ys = (RgYTap*)(rs_lds + (tile_bytes + xt_bytes) / 4);
+  const int img = blockIdx.y;
+  const RsRegion& R = regions[blockIdx.x];
+  const int sstride = lv[0].stride;
+  uint8_t* base = pyr + (size_t)img * img_pitch;
+  const uint8_t* S = base + lv[0].plane_off;
+  const int nq = R.nq, nr = R.nr;
+  {
+    // ONE memory round trip for everything the workgroup reads: the tile's 16-byte units and the two tap tables (already in their LDS
+    // layout) are all requested before the first is parked -- as loops of load-then-store the compiler serialised them
+    const uint32_t inv = R.inv_nq;
+    const uint8_t* src = S + (size_t)R.sy0 * sstride + R.sx0;
+    uint4* tile4 = (uint4*)tile;
+    const uint4* xsrc = (const uint4*)(xtaps + R.xt_off);
+    const uint4* ysrc = (const uint4*)(ytaps + R.yt_off);
+    const int n_tile = nq * nr, n_x = R.n_xt >> 1, n_y = R.n_yt;
+    constexpr int U = 3;  // units of one kind per thread and sweep (a 1241x376 region: 588 tile units, ~290 + ~155 of taps)
+    for (int b0 = 0; b0 < max(n_tile, max(n_x, n_y)); b0 += 256 * U) {
+      uint4 tq[U], xq[U], yq[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = b0 + u * 256 + threadIdx.x;
+        const int kt = min(k, n_tile - 1);
+        const int r = (int)((uint32_t)mul24u(kt, (int)inv) >> 20), c = kt - mul24u(r, nq);
+        tq[u] = *(const uint4*)(src + (uint32_t)mad24u(r, sstride, 16 * c));
+        xq[u] = xsrc[min(k, max(n_x - 1, 0))];
+        yq[u] = ysrc[min(k, max(n_y - 1, 0))];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = b0 + u * 256 + threadIdx.x;
+        if (k < n_tile) tile4[k] = tq[u];
+        if (k < n_x) ((uint4*)xs)[k] = xq[u];
+        if (k < n_y) ((uint4*)ys)[k] = yq[u];
+      }
+    }
+  }
+  __syncthreads();
+  typedef const __attribute__((address_space(3))) uint8_t* lds_bytes_t;
+  lds_bytes_t tb = (lds_bytes_t)tile;
+  typedef unsigned short __attribute__((ext_vector_type(2))) us2;
+  const uint4* lds4 = (const uint4*)rs_lds;
+  for (int l = 1; l < n_levels; ++l) {
+    const RsRegionLevel& G = R.lev[l - 1];
+    const LevelDev& L = lv[l];
+    const int nwx = G.nwx, n_words = nwx * G.noy;
+    const uint32_t inv = G.inv_nwx;
+    // (indexed in 16-byte units from the 16-byte aligned base: what the compiler needs to see to emit ds_read_b128 -- through the
+    //  struct pointers it split every tap read into 4-byte pairs, and at the x taps' 32-byte lane stride those ran 8 deep into the banks)
+    const uint4* xl = lds4 + ((tile_bytes >> 4) + (G.xt_lds >> 1));
+    const uint4* yl = lds4 + (((tile_bytes + xt_bytes) >> 4) + G.yt_lds);
+    if (n_words == 0) continue;  // wave-uniform
+    uint8_t* out = base + L.plane_off + (size_t)G.oy0 * L.stride + 4 * G.wx0;
+    for (int idx = threadIdx.x; idx < n_words; idx += 256) {
+      const int r = (int)((uint32_t)mul24u(idx, (int)inv) >> 20), c = idx - mul24u(r, nwx);
+      const uint4 ayq = yl[r];
+      const struct { int o0, o1; uint32_t b0, b1; } ay = {(int)ayq.x, (int)ayq.y, ayq.z, ayq.w};
+      // (spelled out: the compiler splits these two 16-byte reads into four ds_read2_b32 however their address is formed)
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 xa, xb;
+      {
+        const uint32_t xaddr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint4*)(xl + 2 * c);
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(xa), "=&v"(xb) : "v"(xaddr) : "memory");
+      }
+      const int sxo[4] = {(int)xa.x, (int)xa.z, (int)xb.x, (int)xb.z};
+      const uint32_t t2[4] = {xa.y, xa.w, xb.y, xb.w};
+      uint32_t v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // (k_resize's inner loop: see the comments there)
+        lds_bytes_t r0 = tb + (ay.o0 + sxo[j]), r1 = tb + (ay.o1 + sxo[j]);
+        const uint32_t q0 = (uint32_t)r0[0] | ((uint32_t)r0[1] << 16), q1 = (uint32_t)r1[0] | ((uint32_t)r1[1] << 16);
+        const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, q0), __builtin_bit_cast(us2, t2[j]), 0u, false) & 0xFFFFFF00u;
+        const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, q1), __builtin_bit_cast(us2, t2[j]), 0u, false) & 0xFFFFFF00u;
+        uint32_t m0, m1;
+        asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(m0) : "v"(ay.b0), "v"(h0));
+        asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(m1) : "v"(ay.b1), "v"(h1));
+        v[j] = (m0 + m1 + 2u) >> 2;
+      }
+      *(uint32_t*)(out + (uint32_t)mad24u(r, L.stride, 4 * c)) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // blur: separable 7-tap, 8.8 fixed point, BORDER_REFLECT_101 -- register sliding window, no LDS.
 //
 // One wave owns a column strip of 62 words (248 px) and BLUR_ROWS output rows.  Per input row a lane
@@ -368,6 +466,13 @@ void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, c
   if (n_tiles[2] > 0)
     hipLaunchKernelGGL((k_resize<16>), dim3(n_tiles[2], n_img), dim3(256), (size_t)lds_bytes[2] + extra, s, d_lv, t, d_taps, d_pyr, img_pitch,
                        lds_bytes[2]);
+}
+
+void launch_resize_regions(hipStream_t s, const LevelDev* d_lv, int n_levels, const RsRegion* d_regions, int n_regions, int tile_bytes,
+                           int xt_bytes, int yt_bytes, const RgXTap* d_xtaps, const RgYTap* d_ytaps, uint8_t* d_pyr, size_t img_pitch, int n_img) {
+  if (n_img <= 0 || n_regions <= 0) return;
+  hipLaunchKernelGGL(k_resize_regions, dim3(n_regions, n_img), dim3(256), (size_t)(tile_bytes + xt_bytes + yt_bytes), s, d_lv, n_levels,
+                     d_regions, d_xtaps, d_ytaps, d_pyr, img_pitch, tile_bytes, xt_bytes);
 }
 
 void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int total_tiles, const uint8_t* d_pyr, uint8_t* d_blur,

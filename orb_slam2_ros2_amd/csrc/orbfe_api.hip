@@ -23,6 +23,8 @@ namespace orbfe {
 void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, const int* n_tiles, const int* lds_bytes,
                    const ResizeTap* d_taps, uint8_t* d_pyr,
                    size_t img_pitch, int n_img);
+void launch_resize_regions(hipStream_t s, const LevelDev* d_lv, int n_levels, const RsRegion* d_regions, int n_regions, int tile_bytes,
+                           int xt_bytes, int yt_bytes, const RgXTap* d_xtaps, const RgYTap* d_ytaps, uint8_t* d_pyr, size_t img_pitch, int n_img);
 void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int total_tiles, const uint8_t* d_pyr, uint8_t* d_blur,
                  size_t img_pitch, const int taps[7], int n_img);
 void launch_load_level0(hipStream_t st, const uint8_t* d_src, const uint8_t* d_src_b, size_t src_stride, size_t src_pitch, uint8_t* d_pyr,
@@ -179,6 +181,14 @@ struct orbfe_ctx {
   int blur_taps[7];
   int n_cells_total = 0, rs_tiles = 0, bl_tiles = 0;
   int kp_cap = 0;  // keypoints one image can yield = stride of every per-image array (>= n_features, see build_geometry)
+  std::vector<RsRegion> rs_regions;  // region-driven resize (k_resize_regions): level 0 staged once for all levels
+  RsRegion* d_rs_regions = nullptr;
+  std::vector<RgXTap> rg_xtaps;
+  std::vector<RgYTap> rg_ytaps;
+  RgXTap* d_rg_xtaps = nullptr;
+  RgYTap* d_rg_ytaps = nullptr;
+  int rg_tile_bytes = 0, rg_xt_bytes = 0, rg_yt_bytes = 0;
+  bool resize_regions = true;        // ORBFE_RESIZE_REGIONS=0: the per-class tile launches instead
   int rs_n[3] = {0, 0, 0}, rs_bytes[3] = {0, 0, 0};  // resize tiles of 64x64 / 64x32 / 64x16 outputs (in this order) and their LDS
   size_t img_pitch = 0;      // bytes per image in pyr / blur
   size_t scratch_pitch = 0;  // uint32 records per image
@@ -488,6 +498,90 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
     c->rs_bytes[k] = (int)align_up((size_t)std::max(c->rs_bytes[k], 16), 16);
     c->rs_tile_tab.insert(c->rs_tile_tab.end(), cls[k].begin(), cls[k].end());
   }
+  // region-driven resize: per block of level 0 and level, the rectangle of output words (4 px) x rows whose first source pixel /
+  // source row lies in the block (taps are monotone, so these are ranges), the level-0 rectangle they read, and where the
+  // level's taps sit in the workgroup's LDS tables
+  c->rs_regions.clear();
+  c->rg_xtaps.clear();
+  c->rg_ytaps.clear();
+  c->rg_tile_bytes = c->rg_xt_bytes = c->rg_yt_bytes = 0;
+  if (nl > 1) {
+    const int nrx = (cfg.width + RG_W - 1) / RG_W, nry = (cfg.height + RG_H - 1) / RG_H;
+    bool ok = true;
+    for (int j = 0; j < nry && ok; ++j)
+      for (int i = 0; i < nrx && ok; ++i) {
+        RsRegion R;
+        std::memset(&R, 0, sizeof R);
+        int x_hi = -1, y_lo = 1 << 30, y_hi = -1, n_xt = 0, n_yt = 0;
+        for (int l = 1; l < nl; ++l) {
+          const LevelDev& L = c->lv[l];
+          const ResizeTap* xt = c->taps.data() + L.xtab_off;
+          const ResizeTap* yt = c->taps.data() + L.ytab_off;
+          auto reg_of = [](int v, int step, int n) { return std::min(v / step, n - 1); };
+          const int nw = (L.w + 3) / 4;
+          int wx0 = -1, wx1 = -1, oy0 = -1, oy1 = -1;
+          for (int wx = 0; wx < nw; ++wx)
+            if (reg_of(xt[4 * wx].ofs, RG_W, nrx) == i) {
+              if (wx0 < 0) wx0 = wx;
+              wx1 = wx + 1;
+            }
+          for (int oy = 0; oy < L.h; ++oy)
+            if (reg_of(std::min(std::max(yt[oy].ofs, 0), cfg.height - 1), RG_H, nry) == j) {
+              if (oy0 < 0) oy0 = oy;
+              oy1 = oy + 1;
+            }
+          RsRegionLevel& G = R.lev[l - 1];
+          if (wx0 < 0 || oy0 < 0) continue;  // nothing of this level starts in the block
+          G.wx0 = (int16_t)wx0, G.nwx = (int16_t)(wx1 - wx0), G.oy0 = (int16_t)oy0, G.noy = (int16_t)(oy1 - oy0);
+          G.inv_nwx = ((1u << 20) + G.nwx - 1) / G.nwx;
+          G.xt_lds = (uint16_t)n_xt, G.yt_lds = (uint16_t)n_yt;
+          n_xt += 4 * G.nwx, n_yt += G.noy;
+          for (int px = 4 * wx0; px < 4 * wx1; ++px) x_hi = std::max(x_hi, xt[std::min(px, (int)L.w - 1)].ofs + 1);
+          for (int oy = oy0; oy < oy1; ++oy) {
+            y_lo = std::min(y_lo, std::min(std::max(yt[oy].ofs, 0), cfg.height - 1));
+            y_hi = std::max(y_hi, std::min(std::max(yt[oy].ofs + 1, 0), cfg.height - 1));
+          }
+          if ((long long)G.nwx * G.noy >= (1 << 20) / 256 * 256) ok = false;  // (never: a region holds a few thousand words)
+        }
+        if (x_hi < 0) continue;  // no level starts a word here
+        R.sx0 = (int16_t)(i * RG_W), R.sy0 = (int16_t)y_lo;
+        R.nq = (int16_t)(((x_hi - R.sx0) >> 4) + 1), R.nr = (int16_t)(y_hi - y_lo + 1);
+        R.inv_nq = ((1u << 20) + R.nq - 1) / R.nq;
+        R.n_xt = (uint16_t)n_xt, R.n_yt = (uint16_t)n_yt;
+        if (R.nq * R.nr >= (1 << 20) / 512 || n_xt > 65535 || n_yt > 65535) ok = false;
+        // the region's taps in their LDS layout
+        R.xt_off = (uint32_t)c->rg_xtaps.size(), R.yt_off = (uint32_t)c->rg_ytaps.size();
+        for (int l = 1; l < nl; ++l) {
+          const LevelDev& L = c->lv[l];
+          const RsRegionLevel& G = R.lev[l - 1];
+          const ResizeTap* xt = c->taps.data() + L.xtab_off;
+          const ResizeTap* yt = c->taps.data() + L.ytab_off;
+          for (int k = 0; k < 4 * G.nwx; ++k) {
+            const ResizeTap t = xt[std::min(4 * G.wx0 + k, (int)L.w - 1)];
+            RgXTap o;
+            o.sxo = t.ofs - R.sx0;
+            o.taps2 = ((uint32_t)(uint16_t)t.c0 << 4) | ((uint32_t)(uint16_t)t.c1 << 20);
+            c->rg_xtaps.push_back(o);
+          }
+          for (int k = 0; k < G.noy; ++k) {
+            const ResizeTap t = yt[G.oy0 + k];
+            const int r0 = std::min(std::max(t.ofs, 0), cfg.height - 1), r1 = std::min(std::max(t.ofs + 1, 0), cfg.height - 1);
+            RgYTap o;
+            o.o0 = (r0 - R.sy0) * R.nq * 16;
+            o.o1 = (r1 - R.sy0) * R.nq * 16;
+            o.b0 = (uint32_t)(uint16_t)t.c0 << 8;
+            o.b1 = (uint32_t)(uint16_t)t.c1 << 8;
+            c->rg_ytaps.push_back(o);
+          }
+        }
+        c->rg_tile_bytes = std::max(c->rg_tile_bytes, R.nq * 16 * R.nr);
+        c->rg_xt_bytes = std::max(c->rg_xt_bytes, n_xt * 8);
+        c->rg_yt_bytes = std::max(c->rg_yt_bytes, n_yt * 16);
+        c->rs_regions.push_back(R);
+      }
+    c->rg_xt_bytes = (int)align_up((size_t)c->rg_xt_bytes, 16);
+    if (!ok || c->rg_tile_bytes + c->rg_xt_bytes + c->rg_yt_bytes > 60 * 1024) c->rs_regions.clear();  // fall back to the tile classes
+  }
   rs_tiles = (int)c->rs_tile_tab.size();
   c->n_cells_total = cell_base;
   c->rs_tiles = rs_tiles;
@@ -638,7 +732,11 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   int32_t* n_cand = c->d_n_cand + i0 * nl;
   {
     StageTimer t(c, ORBFE_STAGE_RESIZE, st, timing);
-    launch_resize(st, c->d_lv, c->d_rs_tiles, c->rs_n, c->rs_bytes, c->d_taps, pyr, c->img_pitch, n_img);
+    if (c->resize_regions && !c->rs_regions.empty())
+      launch_resize_regions(st, c->d_lv, nl, c->d_rs_regions, (int)c->rs_regions.size(), c->rg_tile_bytes, c->rg_xt_bytes, c->rg_yt_bytes,
+                            c->d_rg_xtaps, c->d_rg_ytaps, pyr, c->img_pitch, n_img);
+    else
+      launch_resize(st, c->d_lv, c->d_rs_tiles, c->rs_n, c->rs_bytes, c->d_taps, pyr, c->img_pitch, n_img);
   }
   // Only the descriptors read the blurred planes, so the blur need not sit between resize and FAST: it is issued on a second
   // stream once FAST is done and runs UNDER the quadtree, which keeps 8 waves per CU busy with dependent LDS steps and leaves
@@ -743,7 +841,7 @@ void orbfe_destroy(orbfe_ctx* c) {
   void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_rs_tiles, c->d_pattern, c->d_pyr,     c->d_blur,
                   c->d_scr_a, c->d_scr_c,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_kp,
                   c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos, c->d_kx, c->d_kpl,   c->d_right_u, c->d_depth, c->d_n_match,
-                  c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist};
+                  c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist, c->d_rs_regions, c->d_rg_xtaps, c->d_rg_ytaps};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -865,6 +963,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
         return bail(ORBFE_EDEVICE);
       }
     }
+    if (const char* rr = getenv("ORBFE_RESIZE_REGIONS")) c->resize_regions = atoi(rr) != 0;
     const char* ov = getenv("ORBFE_OVERLAP_BLUR");
     if (!ov || atoi(ov) != 0) {
       if (hipStreamCreateWithFlags(&c->blur_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -888,6 +987,9 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   ALLOC(c->d_cells, c->cells.size());
   ALLOC(c->d_taps, c->taps.size());
   ALLOC(c->d_rs_tiles, c->rs_tile_tab.size());
+  ALLOC(c->d_rs_regions, std::max<size_t>(c->rs_regions.size(), 1));
+  ALLOC(c->d_rg_xtaps, std::max<size_t>(c->rg_xtaps.size(), 2));
+  ALLOC(c->d_rg_ytaps, std::max<size_t>(c->rg_ytaps.size(), 1));
   ALLOC(c->d_pattern, 1024);
   ALLOC(c->d_pyr, M * c->img_pitch);
   ALLOC(c->d_blur, M * c->img_pitch);
@@ -935,6 +1037,12 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   if (e == hipSuccess && !c->taps.empty()) e = hipMemcpy(c->d_taps, c->taps.data(), sizeof(ResizeTap) * c->taps.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess && !c->rs_tile_tab.empty())
     e = hipMemcpy(c->d_rs_tiles, c->rs_tile_tab.data(), sizeof(RsTile) * c->rs_tile_tab.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !c->rs_regions.empty())
+    e = hipMemcpy(c->d_rs_regions, c->rs_regions.data(), sizeof(RsRegion) * c->rs_regions.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !c->rg_xtaps.empty())
+    e = hipMemcpy(c->d_rg_xtaps, c->rg_xtaps.data(), sizeof(RgXTap) * c->rg_xtaps.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !c->rg_ytaps.empty())
+    e = hipMemcpy(c->d_rg_ytaps, c->rg_ytaps.data(), sizeof(RgYTap) * c->rg_ytaps.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(c->d_pattern, pat, 1024, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(c->d_n_kp, 0, sizeof(int32_t) * M);
   if (e == hipSuccess) e = hipMemset(c->d_sel_count, 0, sizeof(int32_t) * M * NL);

@@ -31,6 +31,34 @@ struct RsTile {
   int16_t pad;
 };
 
+// k_resize_regions work item: a block of level 0 staged ONCE and the output words of EVERY level whose first source pixel lies in it.
+// RG_W x RG_H level-0 pixels per region (plus the halo the bilinear taps of its last words reach into).
+#define RG_W 176
+#define RG_H 47
+struct RsRegionLevel {
+  int16_t wx0, nwx;        // output words (4 px) of the level: first, count
+  int16_t oy0, noy;        // output rows: first, count
+  uint16_t xt_lds, yt_lds; // first x tap (8-byte units) / y tap (16-byte units) of the level in the workgroup's LDS tables
+  uint32_t inv_nwx;        // ceil(2^20 / nwx): word index -> row without a division
+};
+// taps as the inner loop wants them, laid out per region exactly as they sit in LDS (the workgroup copies them, 16 bytes at a time)
+struct RgXTap {
+  int32_t sxo;     // byte offset of the tap's first source pixel inside a staged row
+  uint32_t taps2;  // (c0 << 4) | (c1 << 20): the two coefficients, pre-shifted, as the halves v_dot2_u32_u16 multiplies
+};
+struct RgYTap {
+  int32_t o0, o1;   // byte offsets of the two source rows inside the staged tile
+  uint32_t b0, b1;  // the two coefficients << 8
+};
+struct RsRegion {
+  int16_t sx0, sy0;        // first staged level-0 column (multiple of 16) / row
+  int16_t nq, nr;          // staged 16-byte quads per row, rows
+  uint32_t inv_nq;         // ceil(2^20 / nq)
+  uint16_t n_xt, n_yt;     // taps of all levels (n_xt is a multiple of 4)
+  uint32_t xt_off, yt_off; // first entry of the region in the context's RgXTap / RgYTap arrays
+  RsRegionLevel lev[ORBFE_MAX_LEVELS - 1];
+};
+
 // Per pyramid level, resident in device memory (one table per context).
 struct LevelDev {
   int32_t w, h, stride;  // plane size, row pitch in bytes (multiple of 16)
