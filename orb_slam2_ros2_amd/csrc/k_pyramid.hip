@@ -162,6 +162,9 @@ __global__ __launch_bounds__(256) void k_resize_regions(const LevelDev* __restri
   uint8_t* base = pyr + (size_t)img * img_pitch;
   const uint8_t* S = base + lv[0].plane_off;
   const int nq = R.nq, nr = R.nr;
+  // the level descriptors of the region, lane = level: requested with everything else, handed out by v_readlane (as scalar
+  // loads at the top of each level's loop they were seven dependent memory round trips per workgroup)
+  const uint4 gq = *(const uint4*)&R.lev[min((int)(threadIdx.x & 63), ORBFE_MAX_LEVELS - 2)];
   {
     // ONE memory round trip for everything the workgroup reads: the tile's 16-byte units and the two tap tables (already in their LDS
     // layout) are all requested before the first is parked -- as loops of load-then-store the compiler serialised them
@@ -198,7 +201,17 @@ __global__ __launch_bounds__(256) void k_resize_regions(const LevelDev* __restri
   typedef unsigned short __attribute__((ext_vector_type(2))) us2;
   const uint4* lds4 = (const uint4*)rs_lds;
   for (int l = 1; l < n_levels; ++l) {
-    const RsRegionLevel& G = R.lev[l - 1];
+    struct {
+      int wx0, nwx, oy0, noy, xt_lds, yt_lds;
+      uint32_t inv_nwx;
+    } G;
+    {
+      const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)gq.x, l - 1), g1 = (uint32_t)__builtin_amdgcn_readlane((int)gq.y, l - 1);
+      const uint32_t g2 = (uint32_t)__builtin_amdgcn_readlane((int)gq.z, l - 1);
+      G.wx0 = (int)(int16_t)(g0 & 0xFFFFu), G.nwx = (int)(g0 >> 16), G.oy0 = (int)(int16_t)(g1 & 0xFFFFu), G.noy = (int)(g1 >> 16);
+      G.xt_lds = (int)(g2 & 0xFFFFu), G.yt_lds = (int)(g2 >> 16);
+      G.inv_nwx = (uint32_t)__builtin_amdgcn_readlane((int)gq.w, l - 1);
+    }
     const LevelDev& L = lv[l];
     const int nwx = G.nwx, n_words = nwx * G.noy;
     const uint32_t inv = G.inv_nwx;
@@ -216,8 +229,9 @@ __global__ __launch_bounds__(256) void k_resize_regions(const LevelDev* __restri
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
       u32x4 xa, xb;
       {
-        const uint32_t xaddr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint4*)(xl + 2 * c);
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(xa), "=&v"(xb) : "v"(xaddr) : "memory");
+        // (the taps of words c's pixels 0, 1 and 2, 3 sit in two arrays of nwx 16-byte units each: a 16-byte lane stride, no bank conflict)
+        const uint32_t xaddr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint4*)(xl + c);
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(xa), "=&v"(xb) : "v"(xaddr), "v"(xaddr + 16u * (uint32_t)nwx) : "memory");
       }
       const int sxo[4] = {(int)xa.x, (int)xa.z, (int)xb.x, (int)xb.z};
       const uint32_t t2[4] = {xa.y, xa.w, xb.y, xb.w};

@@ -556,7 +556,9 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
           const RsRegionLevel& G = R.lev[l - 1];
           const ResizeTap* xt = c->taps.data() + L.xtab_off;
           const ResizeTap* yt = c->taps.data() + L.ytab_off;
-          for (int k = 0; k < 4 * G.nwx; ++k) {
+          for (int kk = 0; kk < 4 * G.nwx; ++kk) {
+            // LDS order: the taps of pixels 0, 1 of every word, then those of pixels 2, 3 (two arrays of 16-byte units)
+            const int half = kk / (2 * G.nwx), cw = (kk % (2 * G.nwx)) / 2, k = 4 * cw + 2 * half + (kk & 1);
             const ResizeTap t = xt[std::min(4 * G.wx0 + k, (int)L.w - 1)];
             RgXTap o;
             o.sxo = t.ofs - R.sx0;
