@@ -527,7 +527,7 @@ def main():
             # UnionNs / steps of profiles/*_kernel_stats.csv, tools/kernel_stats_from_db.py), not average x NLEVELS
             "kernel_launches_per_step": {"fast": NLEVELS, "orient_brief": 4, "resize": 1, "blur": 1, "quadtree": 1, "stereo": 1}[dom],
             "avg_launch_ms_alone": stages_inline[dom],
-            "rocprof_match": "union of the overlapping k_fast launches per step (UnionNs / steps in profiles/r2_v3_kernel_stats.csv)",
+            "rocprof_match": "union of the overlapping k_fast launches per step (UnionNs / steps in the newest profiles/r2_*_kernel_stats.csv)",
             "all_stages": {k: {"ms": round(stages_inline[k], 4), "GBps": round(stage_bytes[k] / (stages_inline[k] * 1e-3) / 1e9, 1)}
                            for k in stages_inline if k in stage_bytes and stages_inline[k] > 0},
         },
@@ -538,7 +538,7 @@ def main():
     # instructions per wave (committed rocprofv3 SQ_* counter pass, profiles/) / the launch duration measured live above; peak = 256 CUs
     # x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction.
     sq_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_sq_counters.json"))
-    kern_of = {"fast": "k_fast", "blur": "k_blur", "quadtree": "k_quadtree", "stereo": "k_stereo", "resize": "k_resize"}
+    kern_of = {"fast": "k_fast", "blur": "k_blur", "quadtree": "k_quadtree", "stereo": "k_stereo", "resize": "k_resize_regions"}
     if sq_files and dom in kern_of:
         try:
             sq = json.load(open(os.path.join(ROOT, "profiles", sq_files[-1])))

@@ -300,14 +300,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const int y0 = ((t / L.bl_tiles_x) * 4 + wv) * BLUR_ROWS;
   if (y0 >= L.h) return;  // wave-uniform
   const int w = L.w, h = L.h, stride = L.stride;
-  const int x4 = (strip * BLUR_WORDS + lane - 1) * 4;  // lane 0 / 63 = left / right halo word
+  // Words of a row: n_words hold at least one pixel, the last one (W) q of them.  The last strip of a row is RIGHT-ALIGNED (it starts at
+  // word n_words - 62 and recomputes a few words of its left neighbour: the same values) so that word W sits at lane 62 with the
+  // three words before it in the same wave; a row narrower than a strip is one strip from word 0.
+  const int n_words = (w + 3) >> 2, W = n_words - 1, q = w - 4 * W;
+  const int o = min(strip * BLUR_WORDS, max(0, n_words - BLUR_WORDS));
+  const int x4 = (o + lane - 1) * 4;  // lane 0 / 63 = left / right halo word
   const uint8_t* P = pyr + (size_t)img * img_pitch + L.plane_off;
   uint8_t* D = blur + (size_t)img * img_pitch + L.plane_off;
-  const bool fast_word = (x4 >= 0) && (x4 + 3 < w);
   const bool writer = (lane >= 1) && (lane <= BLUR_WORDS) && (x4 < w);
-  int rx[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) rx[k] = reflect101(x4 + k, w);
+  // BORDER_REFLECT_101 in x without a single per-byte load: every lane loads an aligned word (address clamped into the row) and the
+  // two or three lanes that hold pixels outside the image rebuild their word from their neighbours' with one v_perm_b32 --
+  //   left  (strips that start at word 0): lane 0 = pixels -4..-1 = pixels 4, 3, 2, 1: bytes 3, 2, 1 of lane 1's word (byte 0 feeds nothing);
+  //   right (strips that hold word W at lane lw <= 62): pixel w - 1 + k = pixel w - 1 - k, i.e. byte j of word W + d is byte
+  //         2 q - 2 - 4 d - j counted from byte 0 of word W: lane lw takes it from (W - 1 | W), lane lw + 1 from (W - 1 | W) when q >= 3
+  //         and from (W - 2 | W - 1) otherwise; the words to the left come by three DPP wave shifts.
+  // (The per-byte path -- four byte loads for every lane of a border wave, a third of all waves -- cost a quarter of the kernel.)
+  const int x4c = min(max(x4, 0), stride - 4);
+  const bool fix_l = o == 0;
+  const int lw = W - o + 1;           // lane of word W (>= 2: rows are at least 10 words wide)
+  const bool fix_r = lw <= BLUR_WORDS + 1;  // (lw = 63: word W is this strip's right halo lane -- its pixels past the border still feed lane 62's outputs)
+  const bool lane_l = lane == 0, lane_r = lane == lw || lane == lw + 1, lane_w = lane == lw;
+  const bool q_hi = q >= 3;
+  uint32_t sel_r;
+  {
+    const uint32_t sel_a = q == 1 ? 0x01020304u : q == 2 ? 0x03040504u : q == 3 ? 0x05060504u : 0x07060504u;
+    const uint32_t sel_b = (q & 1) ? 0x01020304u : 0x03040506u;
+    sel_r = lane_w ? sel_a : sel_b;
+  }
   // taps are 8.8 fixed-point fractions (< 256): masking tells the compiler that 24-bit multiplies suffice
   const uint32_t t0 = taps.t[0] & 255u, t1 = taps.t[1] & 255u, t2 = taps.t[2] & 255u, t3 = taps.t[3] & 255u, t4 = taps.t[4] & 255u,
                  t5 = taps.t[5] & 255u, t6 = taps.t[6] & 255u;
@@ -339,8 +359,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   auto load_row = [&](int r) __attribute__((always_inline)) -> uint32_t {
     const int gy = reflect101(y0 + r - 3, h);
     const uint8_t* row = P + (size_t)gy * stride;
-    if (fast_word) return *(const uint32_t*)(row + x4);
-    return (uint32_t)row[rx[0]] | ((uint32_t)row[rx[1]] << 8) | ((uint32_t)row[rx[2]] << 16) | ((uint32_t)row[rx[3]] << 24);
+    return *(const uint32_t*)(row + x4c);
   };
   uint32_t mrow[7];
 #pragma unroll
@@ -350,8 +369,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     for (int u = 0; u < 7; ++u) {
       const int r = r0 + u;
       if (r < n_in) {  // wave-uniform
-        const uint32_t m = mrow[u];
+        uint32_t m = mrow[u];
         if (r + 7 < n_in) mrow[u] = load_row(r + 7);  // wave-uniform
+        if (fix_l) {  // wave-uniform
+          const uint32_t n1 = wave_shl1(m);
+          m = lane_l ? __builtin_amdgcn_perm(n1, n1, 0x01020300u) : m;
+        }
+        if (fix_r) {  // wave-uniform
+          const uint32_t a = wave_shr1(m), b = wave_shr1(a), c = wave_shr1(b);
+          const uint32_t hi = lane_w ? m : (q_hi ? a : b), lo = lane_w ? a : (q_hi ? b : c);
+          m = lane_r ? __builtin_amdgcn_perm(hi, lo, sel_r) : m;
+        }
         const uint32_t lw = wave_shr1(m), rw = wave_shl1(m);
         // bytes B[0..11] = lw|m|rw; output j needs px[j-3..j+3] = B[1+j .. 7+j]: two unaligned 4-byte windows per
         // output (v_alignbyte) fed to two v_dot4_u32_u8 against the packed taps {t0..t3} and {t4..t6,0}

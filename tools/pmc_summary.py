@@ -5,7 +5,7 @@ FETCH_SIZE / WRITE_SIZE are in KiB (x1024).  MI355X_MICROARCH.md: on gfx950 FETC
 a wide coalesced read stream, so reads are doubled ("corrected"); both raw and corrected figures are kept."""
 import collections, csv, json, sys
 
-STAGE = {"k_resize": "resize", "k_resize_fused": "resize", "k_blur": "blur", "k_fast": "fast", "k_quadtree": "quadtree", "k_ic_moments": "orient_brief",
+STAGE = {"k_resize": "resize", "k_resize_fused": "resize", "k_resize_regions": "resize", "k_rowtable": "stereo", "k_kplist": "orient_brief", "k_blur": "blur", "k_fast": "fast", "k_quadtree": "quadtree", "k_ic_moments": "orient_brief",
          "k_orient": "orient_brief", "k_brief": "orient_brief", "k_stereo": "stereo", "k_load_level0": "load_level0"}
 
 
