@@ -60,14 +60,12 @@ __device__ __forceinline__ int locate_level(const int32_t* __restrict__ sc, int 
 //    entry = {x | y << 16 (level coordinates), level | response << 8}; x == 0xFFFF marks "no keypoint".
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_kplist(const LevelDev* __restrict__ lv, int n_levels, const uint32_t* __restrict__ sel,
-                                                const int32_t* __restrict__ sel_count, int n_features, uint4* __restrict__ kpl,
-                                                int32_t* __restrict__ n_kp) {
+                                                const int32_t* __restrict__ sel_count, int n_features, uint4* __restrict__ kpl) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int img = blockIdx.y;
   if (k >= n_features) return;
   int j, total;
   const int level = locate_level(sel_count + (size_t)img * n_levels, n_levels, k, &j, &total);
-  if (k == 0) n_kp[img] = total;
   uint4 e = make_uint4(0xFFFFu, 0u, 0u, 0u);
   if (level >= 0) {
     const LevelDev& L = lv[level];
@@ -159,10 +157,17 @@ __global__ __launch_bounds__(256) void k_ic_moments(const uint8_t* __restrict__ 
 __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv, const uint4* __restrict__ kpl, int n_features,
                                                 const int2* __restrict__ moments, double2* __restrict__ sincos,
                                                 orbfe_keypoint* __restrict__ kps, KpAux* __restrict__ aux, float* __restrict__ kx,
-                                                double* __restrict__ theta_out, int rows0) {
+                                                double* __restrict__ theta_out, int rows0, const int32_t* __restrict__ sel_count, int n_levels,
+                                                int32_t* __restrict__ n_kp) {
 #pragma clang fp contract(off)
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int img = blockIdx.y;
+  if (k == 0) {  // the image's keypoint count is published HERE, with the arrays it counts: the pipelined stereo match of the previous
+                 // batch reads count, keypoints and descriptors of the same slots, and only this kernel and k_brief wait for it
+    int total = 0;
+    for (int l = 0; l < n_levels; ++l) total += sel_count[(size_t)img * n_levels + l];
+    n_kp[img] = total;
+  }
   const uint4 e = (k < n_features) ? kpl[(size_t)img * n_features + k] : make_uint4(0xFFFFu, 0u, 0u, 0u);
   if ((e.x & 0xFFFFu) != 0xFFFFu) {
     const int level = (int)(e.y & 0xFFu);
@@ -360,13 +365,15 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
   if (n_img <= 0 || n_features <= 0) return;
   UmaxPacked u = 0;
   for (int i = 0; i < 16; ++i) u |= (unsigned long long)(umax[i] & 15) << (4 * i);
-  if (before_lists) (void)hipStreamWaitEvent(s, before_lists, 0);  // the previous batch's stereo match still reads these arrays
   hipLaunchKernelGGL(k_kplist, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, n_levels, d_sel, d_sel_count, n_features,
-                     d_kpl, d_n_kp);
+                     d_kpl);
   hipLaunchKernelGGL(k_ic_moments, dim3((n_features + 15) / 16, n_img), dim3(256), 0, s, d_pyr, img_pitch, d_kpl, n_features, u,
                      d_moments);
+  // the previous batch's stereo match still reads counts, keypoints, row bands and descriptors: the list and the moments (private to
+  // this batch) do not wait for it, only the kernels that rewrite those arrays do -- the match has the whole front of this batch to finish
+  if (before_lists) (void)hipStreamWaitEvent(s, before_lists, 0);
   hipLaunchKernelGGL(k_orient, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, d_kpl, n_features, d_moments, d_sincos,
-                     d_kps, d_aux, d_kx, d_theta, rows0);
+                     d_kps, d_aux, d_kx, d_theta, rows0, d_sel_count, n_levels, d_n_kp);
   if (before_brief) (void)hipStreamWaitEvent(s, before_brief, 0);  // the blurred planes come from another stream
   hipLaunchKernelGGL(k_brief, dim3((((n_features + BRIEF_WAVES * BRIEF_KPW - 1) / (BRIEF_WAVES * BRIEF_KPW)) + 7) & ~7, n_img), dim3(64 * BRIEF_WAVES), 0, s,
                      d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos, d_desc);

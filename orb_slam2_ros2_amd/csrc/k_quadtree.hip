@@ -970,10 +970,17 @@ __global__ __launch_bounds__(64) void k_quadtree(const LevelDev* __restrict__ lv
                                                  uint32_t* __restrict__ scratch_b, uint32_t* __restrict__ scratch_c,
                                                  size_t scratch_pitch,
                                                  uint32_t* __restrict__ sel, int32_t* __restrict__ sel_count, int n_features,
-                                                 const int32_t* __restrict__ n_cand, int node_cap, int sort_cap, int rec_cap, int batch) {
+                                                 const int32_t* __restrict__ n_cand, int node_cap, int sort_cap, int rec_cap, int batch,
+                                                 QtGroups groups) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
-  const int level = blockIdx.x, img = blockIdx.y;
+  const int img = blockIdx.y;
+  // One wave works through the trees of a GROUP of levels, one after the other (blockIdx.x = group; the host balances the groups by
+  // quota: the level-0 tree alone, the small levels together).  With one wave per level a 1024-image launch filled every wave slot
+  // of the chip with tree waves (8 levels x 1024 images = 8 per SIMD) that mostly wait, and the blur issued beside it on the second
+  // stream could only start as trees finished: the two kernels ran back to back, not side by side (timeline).
+  for (uint32_t todo = groups.mask[blockIdx.x]; todo; todo &= todo - 1) {
+  const int level = __builtin_ctz(todo);
   const LevelDev& L = lv[level];
   // LDS carve-up: 4 fp64 bound arrays | u64 keys | u32 begins | records.  The sort buffer aliases the bounds.
   double* n_rb = lds;
@@ -1025,7 +1032,7 @@ __global__ __launch_bounds__(64) void k_quadtree(const LevelDev* __restrict__ lv
     } else if (lane == 0) {
       sel_count[(size_t)img * n_levels + level] = 0;
     }
-    return;
+    continue;
   }
 
   if (in_lds)
@@ -1034,6 +1041,10 @@ __global__ __launch_bounds__(64) void k_quadtree(const LevelDev* __restrict__ lv
   else
     tree_body<false>(L, A, N, gb, gc, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, bkey, bj, batch, node_cap, need, sort_cap, out_sel,
                      sel_count + (size_t)img * n_levels + level, lane);
+  // the next tree reuses the LDS: the accesses of one wave execute in order, the fence only pins the compiler
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  }
 }
 
 size_t quadtree_lds_bytes(int node_cap, int rec_cap) {
@@ -1060,11 +1071,11 @@ hipError_t quadtree_configure(size_t lds_bytes) {
 
 void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint32_t* d_cand, uint32_t* d_scr_b, uint32_t* d_scr_c,
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
-                     int rec_cap, int n_img, int batch) {
+                     int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups) {
   if (n_img <= 0) return;
   const size_t lds = quadtree_lds_bytes(node_cap, rec_cap);
-  hipLaunchKernelGGL(k_quadtree, dim3(n_levels, n_img), dim3(64), lds, s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
-                     d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch);
+  hipLaunchKernelGGL(k_quadtree, dim3(n_groups, n_img), dim3(64), lds, s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
+                     d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups);
 }
 
 }  // namespace orbfe

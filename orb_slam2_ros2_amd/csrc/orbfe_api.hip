@@ -38,7 +38,7 @@ size_t quadtree_lds_bytes(int node_cap, int rec_cap);
 hipError_t quadtree_configure(size_t lds_bytes);
 void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint32_t* d_cand, uint32_t* d_scr_b, uint32_t* d_scr_c,
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
-                     int rec_cap, int n_img, int batch);
+                     int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups);
 // k_brief.hip
 void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
@@ -192,6 +192,8 @@ struct orbfe_ctx {
   int rs_n[3] = {0, 0, 0}, rs_bytes[3] = {0, 0, 0};  // resize tiles of 64x64 / 64x32 / 64x16 outputs (in this order) and their LDS
   size_t img_pitch = 0;      // bytes per image in pyr / blur
   size_t scratch_pitch = 0;  // uint32 records per image
+  QtGroups qt_groups;        // levels per quadtree wave (balanced by quota), qt_n_groups waves per image (ORBFE_QT_GROUPS)
+  int qt_n_groups = 0;
   int rec_cap = 0;           // upper bound of candidate records one quadtree wave keeps in LDS (launch picks <= this)
   int qt_batch = 1;          // k_quadtree: several pops per step (ORBFE_QT_BATCH=0: one at a time)
   int n_cu = 256;            // compute units of the device
@@ -602,6 +604,24 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
     const size_t budget = 150 * 1024 - quadtree_lds_bytes(c->node_cap, 0);
     c->rec_cap = (int)std::min<size_t>(std::min<size_t>(max_cand, 8192), budget / 4);
     if (const char* env = getenv("ORBFE_QT_REC_CAP")) c->rec_cap = std::max(0, std::min(c->rec_cap, atoi(env)));
+    {
+      // levels -> waves: longest-processing-time first on the quotas (a tree's work grows with its quota and candidate count)
+      int ng = std::min(nl, 4);
+      if (const char* env = getenv("ORBFE_QT_GROUPS")) ng = std::max(1, std::min(nl, atoi(env)));
+      std::memset(&c->qt_groups, 0, sizeof c->qt_groups);
+      std::vector<double> load(ng, 0.0);
+      std::vector<int> order(nl);
+      for (int l = 0; l < nl; ++l) order[l] = l;
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return c->lv[a].quota > c->lv[b].quota; });
+      for (int l : order) {
+        int g = 0;
+        for (int k = 1; k < ng; ++k)
+          if (load[k] < load[g]) g = k;
+        load[g] += (double)c->lv[l].quota + 1.0;
+        c->qt_groups.mask[g] |= 1u << l;
+      }
+      c->qt_n_groups = ng;
+    }
     if (const char* env = getenv("ORBFE_QT_BATCH")) c->qt_batch = atoi(env) != 0;
     if (const char* env = getenv("ORBFE_FAST_SIDE_FROM")) c->fast_side_from = atoi(env);
   }
@@ -772,7 +792,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     // LDS residency of the candidate records is traded against concurrency: the kernel is latency-bound (one wave per
     // tree, 40-150 dependent steps), so what matters most is that EVERY tree of the launch is resident at once; the
     // records go to LDS only as far as that still holds (measured at 1024 trees: 4 trees/CU 0.59 ms, 3 trees/CU 0.96 ms).
-    const int trees = nl * n_img;
+    const int trees = c->qt_n_groups * n_img;
     const int per_cu = (trees + c->n_cu - 1) / c->n_cu;
     // lds_share > 1: that many chunks run side by side on their own streams; each quadtree launch leaves the rest of the
     // CU's LDS to the other chunks' kernels so that they can fill the SIMDs the tree waves leave idle.
@@ -783,7 +803,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     const int rec_cap = budget > node_bytes ? (int)std::min<size_t>((budget - node_bytes) / 4, (size_t)c->rec_cap) : 0;
     launch_quadtree(st, c->d_lv, nl, c->d_scr_a + i0 * c->scratch_pitch, c->d_scr_b + i0 * c->scratch_pitch,
                     c->d_scr_c + i0 * c->scratch_pitch, c->scratch_pitch, c->d_sel + i0 * NF, c->d_sel_count + i0 * nl,
-                    c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img, c->qt_batch);
+                    c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img, c->qt_batch, c->qt_groups, c->qt_n_groups);
   }
   {
     StageTimer t(c, ORBFE_STAGE_BRIEF, st, timing);

@@ -59,6 +59,11 @@ struct RsRegion {
   RsRegionLevel lev[ORBFE_MAX_LEVELS - 1];
 };
 
+// k_quadtree: the levels whose trees one wave works through, as bit masks (one per blockIdx.x)
+struct QtGroups {
+  uint32_t mask[ORBFE_MAX_LEVELS];
+};
+
 // Per pyramid level, resident in device memory (one table per context).
 struct LevelDev {
   int32_t w, h, stride;  // plane size, row pitch in bytes (multiple of 16)

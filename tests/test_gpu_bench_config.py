@@ -59,6 +59,8 @@ KNOBS = [
     {"ORBFE_QT_REC_CAP": "0"},            # quadtree: records in global memory + bounce buffer (what 1024 images per launch use)
     {"ORBFE_QT_REC_CAP": "600"},          # ... and a partial LDS cache
     {"ORBFE_QT_BATCH": "0"},              # one pop per step
+    {"ORBFE_QT_GROUPS": "8"},             # one quadtree wave per level (default: the levels of an image dealt to 4 waves)
+    {"ORBFE_QT_GROUPS": "1"},             # ... and all levels of an image in one wave
     {"ORBFE_PIPELINE_STEREO": "0"},       # stereo match in line
     {"ORBFE_OVERLAP_BLUR": "0"},          # blur in line, no second stream
     {"ORBFE_FAST_SIDE_FROM": "0"},        # every k_fast launch on the context stream
