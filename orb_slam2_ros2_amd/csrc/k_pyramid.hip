@@ -308,7 +308,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const int x4 = (o + lane - 1) * 4;  // lane 0 / 63 = left / right halo word
   const uint8_t* P = pyr + (size_t)img * img_pitch + L.plane_off;
   uint8_t* D = blur + (size_t)img * img_pitch + L.plane_off;
-  const bool writer = (lane >= 1) && (lane <= BLUR_WORDS) && (x4 < w);
+  // (the right-aligned last strip computes the words it shares with its left neighbour but leaves their stores to that strip)
+  const bool writer = (lane >= 1) && (lane <= BLUR_WORDS) && (x4 < w) && (o + lane - 1 >= strip * BLUR_WORDS);
   // BORDER_REFLECT_101 in x without a single per-byte load: every lane loads an aligned word (address clamped into the row) and the
   // two or three lanes that hold pixels outside the image rebuild their word from their neighbours' with one v_perm_b32 --
   //   left  (strips that start at word 0): lane 0 = pixels -4..-1 = pixels 4, 3, 2, 1: bytes 3, 2, 1 of lane 1's word (byte 0 feeds nothing);
