@@ -134,22 +134,23 @@ __global__ __launch_bounds__(256) void k_rowtable(const KpAux* __restrict__ aux,
   const int y0 = tid * per, y1 = min(y0 + per, rows);
   uint32_t sum = 0;
   for (int y = y0; y < y1; ++y) sum += cnt[y];
-  part[tid] = sum;
+  // inclusive scan of the 256 run totals: DPP scan inside each wave, the four wave totals through LDS (two barriers, not sixteen)
+  const uint32_t incl_w = (uint32_t)wave_incl_scan_dpp<OpAddI>((int)sum);
+  if ((tid & 63) == 63) part[tid >> 6] = incl_w;
   __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
-    const uint32_t v = tid >= d ? part[tid - d] : 0u;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  uint32_t run = part[tid] - sum;
+  uint32_t wave_base = 0;
+  for (int k = 0; k < (tid >> 6); ++k) wave_base += part[k];
+  const uint32_t incl = wave_base + incl_w;
+  const uint32_t total_all = part[0] + part[1] + part[2] + part[3];
+  __syncthreads();
+  uint32_t run = incl - sum;
   for (int y = y0; y < y1; ++y) {
     const uint32_t c = cnt[y];
     cnt[y] = run;  // from here on: the row's write cursor
     RO[y] = run;
     run += c;
   }
-  if (tid == 255) RO[rows] = part[255];
+  if (tid == 255) RO[rows] = total_all;
   __syncthreads();
   for (int i = tid; i < nr; i += 256) {
     const KpAux a = A[i];

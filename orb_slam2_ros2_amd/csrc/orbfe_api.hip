@@ -193,7 +193,9 @@ struct orbfe_ctx {
   size_t img_pitch = 0;      // bytes per image in pyr / blur
   size_t scratch_pitch = 0;  // uint32 records per image
   QtGroups qt_groups;        // levels per quadtree wave (balanced by quota), qt_n_groups waves per image (ORBFE_QT_GROUPS)
+  QtGroups qt_single;        // one level per wave: launches too small to fill the wave slots (a frame or two: the chain of several trees in one wave would only add latency)
   int qt_n_groups = 0;
+  bool qt_groups_forced = false;
   int rec_cap = 0;           // upper bound of candidate records one quadtree wave keeps in LDS (launch picks <= this)
   int qt_batch = 1;          // k_quadtree: several pops per step (ORBFE_QT_BATCH=0: one at a time)
   int n_cu = 256;            // compute units of the device
@@ -607,7 +609,12 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
     {
       // levels -> waves: longest-processing-time first on the quotas (a tree's work grows with its quota and candidate count)
       int ng = std::min(nl, 4);
-      if (const char* env = getenv("ORBFE_QT_GROUPS")) ng = std::max(1, std::min(nl, atoi(env)));
+      if (const char* env = getenv("ORBFE_QT_GROUPS")) {
+        ng = std::max(1, std::min(nl, atoi(env)));
+        c->qt_groups_forced = true;
+      }
+      std::memset(&c->qt_single, 0, sizeof c->qt_single);
+      for (int l = 0; l < nl; ++l) c->qt_single.mask[l] = 1u << l;
       std::memset(&c->qt_groups, 0, sizeof c->qt_groups);
       std::vector<double> load(ng, 0.0);
       std::vector<int> order(nl);
@@ -792,7 +799,10 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     // LDS residency of the candidate records is traded against concurrency: the kernel is latency-bound (one wave per
     // tree, 40-150 dependent steps), so what matters most is that EVERY tree of the launch is resident at once; the
     // records go to LDS only as far as that still holds (measured at 1024 trees: 4 trees/CU 0.59 ms, 3 trees/CU 0.96 ms).
-    const int trees = c->qt_n_groups * n_img;
+    // several levels per wave only where one wave per level would fill more than half of the chip's wave slots (8 per SIMD)
+    const bool grouped = c->qt_groups_forced || (long long)nl * n_img > (long long)c->n_cu * 16;
+    const int n_groups = grouped ? c->qt_n_groups : nl;
+    const int trees = n_groups * n_img;
     const int per_cu = (trees + c->n_cu - 1) / c->n_cu;
     // lds_share > 1: that many chunks run side by side on their own streams; each quadtree launch leaves the rest of the
     // CU's LDS to the other chunks' kernels so that they can fill the SIMDs the tree waves leave idle.
@@ -803,7 +813,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     const int rec_cap = budget > node_bytes ? (int)std::min<size_t>((budget - node_bytes) / 4, (size_t)c->rec_cap) : 0;
     launch_quadtree(st, c->d_lv, nl, c->d_scr_a + i0 * c->scratch_pitch, c->d_scr_b + i0 * c->scratch_pitch,
                     c->d_scr_c + i0 * c->scratch_pitch, c->scratch_pitch, c->d_sel + i0 * NF, c->d_sel_count + i0 * nl,
-                    c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img, c->qt_batch, c->qt_groups, c->qt_n_groups);
+                    c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img, c->qt_batch, grouped ? c->qt_groups : c->qt_single, n_groups);
   }
   {
     StageTimer t(c, ORBFE_STAGE_BRIEF, st, timing);
