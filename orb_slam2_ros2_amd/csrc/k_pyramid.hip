@@ -286,9 +286,9 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return __builtin_amd
 __device__ __forceinline__ uint32_t wave_shl1(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130, 0xf, 0xf, false); }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur(const LevelDev* __restrict__ lv, int n_levels, const uint8_t* __restrict__ pyr,
-                                              uint8_t* __restrict__ blur, size_t img_pitch, BlurTaps taps) {
+                                              uint8_t* __restrict__ blur, size_t img_pitch, BlurTaps taps, int tile_first) {
   const int img = blockIdx.y;
-  const int tile = blockIdx.x;
+  const int tile = blockIdx.x + tile_first;
   int l = 0;
   while (l + 1 < n_levels && tile >= lv[l + 1].bl_tile_base) ++l;
   const LevelDev& L = lv[l];
@@ -518,12 +518,13 @@ void launch_resize_regions(hipStream_t s, const LevelDev* d_lv, int n_levels, co
                      d_regions, d_xtaps, d_ytaps, d_pyr, img_pitch, tile_bytes, xt_bytes);
 }
 
-void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int total_tiles, const uint8_t* d_pyr, uint8_t* d_blur,
+// tiles [tile_first, tile_first + n_tiles) of the per-image tile list (level-major: a range of tiles is a range of levels)
+void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int tile_first, int n_tiles, const uint8_t* d_pyr, uint8_t* d_blur,
                  size_t img_pitch, const int taps[7], int n_img) {
-  if (total_tiles <= 0 || n_img <= 0) return;
+  if (n_tiles <= 0 || n_img <= 0) return;
   BlurTaps bt;
   for (int i = 0; i < 7; ++i) bt.t[i] = taps[i];
-  hipLaunchKernelGGL(k_blur, dim3(total_tiles, n_img), dim3(256), 0, s, d_lv, n_levels, d_pyr, d_blur, img_pitch, bt);
+  hipLaunchKernelGGL(k_blur, dim3(n_tiles, n_img), dim3(256), 0, s, d_lv, n_levels, d_pyr, d_blur, img_pitch, bt, tile_first);
 }
 
 }  // namespace orbfe

@@ -25,7 +25,7 @@ void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, c
                    size_t img_pitch, int n_img);
 void launch_resize_regions(hipStream_t s, const LevelDev* d_lv, int n_levels, const RsRegion* d_regions, int n_regions, int tile_bytes,
                            int xt_bytes, int yt_bytes, const RgXTap* d_xtaps, const RgYTap* d_ytaps, uint8_t* d_pyr, size_t img_pitch, int n_img);
-void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int total_tiles, const uint8_t* d_pyr, uint8_t* d_blur,
+void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int tile_first, int n_tiles, const uint8_t* d_pyr, uint8_t* d_blur,
                  size_t img_pitch, const int taps[7], int n_img);
 void launch_load_level0(hipStream_t st, const uint8_t* d_src, const uint8_t* d_src_b, size_t src_stride, size_t src_pitch, uint8_t* d_pyr,
                         size_t img_pitch, uint32_t plane_off, int dst_stride, int w, int h, int slot0, int slot_step, int n_img);
@@ -759,6 +759,16 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   uint8_t* pyr = c->d_pyr + i0 * c->img_pitch;
   uint8_t* blur = c->d_blur + i0 * c->img_pitch;
   int32_t* n_cand = c->d_n_cand + i0 * nl;
+  const bool overlap_blur = timing && c->blur_stream && c->prof != 1 && lds_share == 1 && n_img >= 32;  // a frame or two: nothing to hide, only event latency to add
+  // the blur of LEVEL 0 needs nothing but the copy-in: it starts beside the resize (a third of the blur's work out of the way of the
+  // moments, which are as memory-bound as it is and take the sum of the two times when they meet)
+  static const bool blur_l0_early = !(getenv("ORBFE_BLUR_L0_EARLY") && atoi(getenv("ORBFE_BLUR_L0_EARLY")) == 0);
+  const int l0_tiles = (overlap_blur && blur_l0_early && nl > 1) ? c->lv[1].bl_tile_base : 0;
+  if (l0_tiles > 0) {
+    HIP_TRY(c, hipEventRecord(c->ev_blur_go, st));
+    HIP_TRY(c, hipStreamWaitEvent(c->blur_stream, c->ev_blur_go, 0));
+    launch_blur(c->blur_stream, c->d_lv, nl, 0, l0_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
+  }
   {
     StageTimer t(c, ORBFE_STAGE_RESIZE, st, timing);
     if (c->resize_regions && !c->rs_regions.empty())
@@ -767,16 +777,15 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     else
       launch_resize(st, c->d_lv, c->d_rs_tiles, c->rs_n, c->rs_bytes, c->d_taps, pyr, c->img_pitch, n_img);
   }
-  // Only the descriptors read the blurred planes, so the blur need not sit between resize and FAST: it is issued on a second
-  // stream once FAST is done and runs UNDER the quadtree, which keeps 8 waves per CU busy with dependent LDS steps and leaves
+  // Only the descriptors read the blurred planes, so the blur need not sit between resize and FAST: the levels above 0 are issued on a second
+  // stream once FAST is done (beside FAST, which saturates the vector units, they cost more than they hide: +2 %) and runs UNDER the quadtree, which keeps 8 waves per CU busy with dependent LDS steps and leaves
   // the SIMDs idle (the blur uses no LDS, the quadtree all of it).  With stage timing on, or when several chunks share the
   // context, the blur stays in line.  (Measured and dropped: starting each level's quadtree under FAST of the smaller levels on
   // a third stream -- the tree waves then share their SIMDs with a VALU-saturating kernel and the dependent chain stretches:
   // 3.04 -> 4.6 ms per 128 pairs.)
-  const bool overlap_blur = timing && c->blur_stream && c->prof != 1 && lds_share == 1 && n_img >= 32;  // a frame or two: nothing to hide, only event latency to add
   if (!overlap_blur) {
     StageTimer t(c, ORBFE_STAGE_BLUR, st, timing);
-    launch_blur(st, c->d_lv, nl, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
+    launch_blur(st, c->d_lv, nl, 0, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
   }
   HIP_TRY(c, hipMemsetAsync(n_cand, 0, sizeof(int32_t) * (size_t)n_img * nl, st));
   {
@@ -790,7 +799,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     HIP_TRY(c, hipStreamWaitEvent(c->blur_stream, c->ev_blur_go, 0));
     {
       StageTimer t(c, ORBFE_STAGE_BLUR, c->blur_stream);  // (events on the stream the kernel is launched on)
-      launch_blur(c->blur_stream, c->d_lv, nl, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
+      launch_blur(c->blur_stream, c->d_lv, nl, l0_tiles, c->bl_tiles - l0_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
     }
     HIP_TRY(c, hipEventRecord(c->ev_blur_done, c->blur_stream));
   }
