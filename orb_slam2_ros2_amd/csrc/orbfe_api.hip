@@ -189,6 +189,7 @@ struct orbfe_ctx {
   RgYTap* d_rg_ytaps = nullptr;
   int rg_tile_bytes = 0, rg_xt_bytes = 0, rg_yt_bytes = 0;
   bool resize_regions = true;        // ORBFE_RESIZE_REGIONS=0: the per-class tile launches instead
+  bool blur_l0_early = true;         // ORBFE_BLUR_L0_EARLY=0: the whole blur after FAST
   int rs_n[3] = {0, 0, 0}, rs_bytes[3] = {0, 0, 0};  // resize tiles of 64x64 / 64x32 / 64x16 outputs (in this order) and their LDS
   size_t img_pitch = 0;      // bytes per image in pyr / blur
   size_t scratch_pitch = 0;  // uint32 records per image
@@ -762,8 +763,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   const bool overlap_blur = timing && c->blur_stream && c->prof != 1 && lds_share == 1 && n_img >= 32;  // a frame or two: nothing to hide, only event latency to add
   // the blur of LEVEL 0 needs nothing but the copy-in: it starts beside the resize (a third of the blur's work out of the way of the
   // moments, which are as memory-bound as it is and take the sum of the two times when they meet)
-  static const bool blur_l0_early = !(getenv("ORBFE_BLUR_L0_EARLY") && atoi(getenv("ORBFE_BLUR_L0_EARLY")) == 0);
-  const int l0_tiles = (overlap_blur && blur_l0_early && nl > 1) ? c->lv[1].bl_tile_base : 0;
+  const int l0_tiles = (overlap_blur && c->blur_l0_early && nl > 1) ? c->lv[1].bl_tile_base : 0;
   if (l0_tiles > 0) {
     HIP_TRY(c, hipEventRecord(c->ev_blur_go, st));
     HIP_TRY(c, hipStreamWaitEvent(c->blur_stream, c->ev_blur_go, 0));
@@ -1005,6 +1005,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
       }
     }
     if (const char* rr = getenv("ORBFE_RESIZE_REGIONS")) c->resize_regions = atoi(rr) != 0;
+    if (const char* be = getenv("ORBFE_BLUR_L0_EARLY")) c->blur_l0_early = atoi(be) != 0;
     const char* ov = getenv("ORBFE_OVERLAP_BLUR");
     if (!ov || atoi(ov) != 0) {
       if (hipStreamCreateWithFlags(&c->blur_stream, hipStreamNonBlocking) != hipSuccess ||
