@@ -282,8 +282,8 @@ __device__ __forceinline__ uint32_t mad24(uint32_t tap_uniform, uint32_t v, uint
   asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(tap_uniform), "v"(v), "v"(acc));
   return d;
 }
-__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ uint32_t wave_shl1(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, true); }  // (bound_ctrl: the lane without a source reads 0, no "old" value to set up)
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130, 0xf, 0xf, true); }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur(const LevelDev* __restrict__ lv, int n_levels, const uint8_t* __restrict__ pyr,
                                               uint8_t* __restrict__ blur, size_t img_pitch, BlurTaps taps, int tile_first) {
