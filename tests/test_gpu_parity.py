@@ -519,3 +519,17 @@ def test_stereo_row_table_edge_cases(orc, lib):
         assert np.array_equal(ru[:n].view(np.int64), oru.view(np.int64)) and np.array_equal(dp[:n].view(np.int64), odp.view(np.int64))
         assert np.array_equal(br[:n], obr) and np.array_equal(bd[:n], obd)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w", [80, 81, 82, 83, 245, 246, 247, 248, 249, 250, 251, 252, 253, 309, 495, 496, 497, 498, 499, 744, 745, 1237, 1238, 1239, 1240])
+def test_row_widths_around_the_blur_strip_and_word_boundaries(orc, lib, w):
+    """k_blur rebuilds the pixels past the image border from neighbouring lanes (BORDER_REFLECT_101): every residue of the width
+    mod 4, rows narrower than one 62-word strip, rows that end exactly at / one word past a strip boundary (the right-aligned last
+    strip), and the resize regions' last column for the same widths; every plane of every level against the oracle."""
+    h, nl = (96 if w < 1000 else 160), (2 if w < 100 else 3)  # (the coarsest level must keep one 30-px FAST cell; at most 16 root strips)
+    img, _ = synth.stereo_pair(300 + w, w, h, n_rect=60)
+    ctx = lib.Context(w, h, n_features=300, n_levels=nl, max_images=1)
+    k, d = ctx.extract(img)
+    assert_image_parity(ctx, 0, orc.extractor(img, n_features=300, n_levels=nl), k, d, nl)
+    ctx.close()
