@@ -151,16 +151,21 @@ __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv,
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_resize_regions(const LevelDev* __restrict__ lv, int n_levels, const RsRegion* __restrict__ regions,
                                                         const RgXTap* __restrict__ xtaps, const RgYTap* __restrict__ ytaps,
-                                                        uint8_t* __restrict__ pyr, size_t img_pitch, int tile_bytes, int xt_bytes) {
+                                                        uint8_t* __restrict__ pyr, size_t img_pitch, int tile_bytes, int xt_bytes,
+                                                        const uint8_t* __restrict__ src_a, const uint8_t* __restrict__ src_b, size_t src_pitch,
+                                                        int sstride, uint32_t src_bytes) {
+  // level 0 is read from (src_a, src_b, src_pitch, sstride): the pyramid's own level-0 planes (src_b null: image i at src_a + i src_pitch),
+  // or -- device batches -- the CALLER's left / right images (image i = eye i & 1 of pair i >> 1), so that the resize does not wait
+  // for the copy-in but runs beside it.  src_bytes: size of one source image; a 16-byte unit that would end past it (the last unit
+  // of the last row when the rows are not padded) is put together from single bytes.
   extern __shared__ __attribute__((aligned(16))) uint32_t rs_lds[];
   uint32_t* tile = rs_lds;
   RgXTap* xs = (RgXTap*)(rs_lds + tile_bytes / 4);
   RgYTap* ys = (RgYTap*)(rs_lds + (tile_bytes + xt_bytes) / 4);
   const int img = blockIdx.y;
   const RsRegion& R = regions[blockIdx.x];
-  const int sstride = lv[0].stride;
   uint8_t* base = pyr + (size_t)img * img_pitch;
-  const uint8_t* S = base + lv[0].plane_off;
+  const uint8_t* S = src_b ? ((img & 1) ? src_b : src_a) + (size_t)(img >> 1) * src_pitch : src_a + (size_t)img * src_pitch;
   const int nq = R.nq, nr = R.nr;
   // the level descriptors of the region, lane = level: requested with everything else, handed out by v_readlane (as scalar
   // loads at the top of each level's loop they were seven dependent memory round trips per workgroup)
@@ -182,7 +187,15 @@ __global__ __launch_bounds__(256) void k_resize_regions(const LevelDev* __restri
         const int k = b0 + u * 256 + threadIdx.x;
         const int kt = min(k, n_tile - 1);
         const int r = (int)((uint32_t)mul24u(kt, (int)inv) >> 20), c = kt - mul24u(r, nq);
-        tq[u] = *(const uint4*)(src + (uint32_t)mad24u(r, sstride, 16 * c));
+        const uint32_t off = (uint32_t)mad24u(r, sstride, 16 * c);
+        const uint32_t end = (uint32_t)mad24u(R.sy0, sstride, R.sx0) + off + 16u;  // offset past the unit, from the start of the image
+        if (end <= src_bytes) {
+          __builtin_memcpy(&tq[u], src + off, 16);  // (byte-aligned 16-byte load: the caller's rows are not padded)
+        } else {
+          uint32_t w4[4] = {0u, 0u, 0u, 0u};
+          for (uint32_t b = 0; b < 16u && end - 16u + b < src_bytes; ++b) w4[b >> 2] |= (uint32_t)src[off + b] << (8 * (b & 3));
+          tq[u] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
         xq[u] = xsrc[min(k, max(n_x - 1, 0))];
         yq[u] = ysrc[min(k, max(n_y - 1, 0))];
       }
@@ -512,10 +525,11 @@ void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, c
 }
 
 void launch_resize_regions(hipStream_t s, const LevelDev* d_lv, int n_levels, const RsRegion* d_regions, int n_regions, int tile_bytes,
-                           int xt_bytes, int yt_bytes, const RgXTap* d_xtaps, const RgYTap* d_ytaps, uint8_t* d_pyr, size_t img_pitch, int n_img) {
+                           int xt_bytes, int yt_bytes, const RgXTap* d_xtaps, const RgYTap* d_ytaps, uint8_t* d_pyr, size_t img_pitch, int n_img,
+                           const uint8_t* src_a, const uint8_t* src_b, size_t src_pitch, int src_stride, uint32_t src_bytes) {
   if (n_img <= 0 || n_regions <= 0) return;
   hipLaunchKernelGGL(k_resize_regions, dim3(n_regions, n_img), dim3(256), (size_t)(tile_bytes + xt_bytes + yt_bytes), s, d_lv, n_levels,
-                     d_regions, d_xtaps, d_ytaps, d_pyr, img_pitch, tile_bytes, xt_bytes);
+                     d_regions, d_xtaps, d_ytaps, d_pyr, img_pitch, tile_bytes, xt_bytes, src_a, src_b, src_pitch, src_stride, src_bytes);
 }
 
 // tiles [tile_first, tile_first + n_tiles) of the per-image tile list (level-major: a range of tiles is a range of levels)

@@ -24,7 +24,8 @@ void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, c
                    const ResizeTap* d_taps, uint8_t* d_pyr,
                    size_t img_pitch, int n_img);
 void launch_resize_regions(hipStream_t s, const LevelDev* d_lv, int n_levels, const RsRegion* d_regions, int n_regions, int tile_bytes,
-                           int xt_bytes, int yt_bytes, const RgXTap* d_xtaps, const RgYTap* d_ytaps, uint8_t* d_pyr, size_t img_pitch, int n_img);
+                           int xt_bytes, int yt_bytes, const RgXTap* d_xtaps, const RgYTap* d_ytaps, uint8_t* d_pyr, size_t img_pitch, int n_img,
+                           const uint8_t* src_a, const uint8_t* src_b, size_t src_pitch, int src_stride, uint32_t src_bytes);
 void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int tile_first, int n_tiles, const uint8_t* d_pyr, uint8_t* d_blur,
                  size_t img_pitch, const int taps[7], int n_img);
 void launch_load_level0(hipStream_t st, const uint8_t* d_src, const uint8_t* d_src_b, size_t src_stride, size_t src_pitch, uint8_t* d_pyr,
@@ -190,6 +191,8 @@ struct orbfe_ctx {
   int rg_tile_bytes = 0, rg_xt_bytes = 0, rg_yt_bytes = 0;
   bool resize_regions = true;        // ORBFE_RESIZE_REGIONS=0: the per-class tile launches instead
   bool blur_l0_early = true;         // ORBFE_BLUR_L0_EARLY=0: the whole blur after FAST
+  bool ext_level0 = true;            // ORBFE_EXT_LEVEL0=0: device batches copy level 0 in first, then resize from the copy
+  hipEvent_t ev_loaded = nullptr;
   int rs_n[3] = {0, 0, 0}, rs_bytes[3] = {0, 0, 0};  // resize tiles of 64x64 / 64x32 / 64x16 outputs (in this order) and their LDS
   size_t img_pitch = 0;      // bytes per image in pyr / blur
   size_t scratch_pitch = 0;  // uint32 records per image
@@ -748,8 +751,17 @@ static orbfe_status join_stereo(orbfe_ctx* c) {
 
 // ---- the launch sequence for slots [0, n_img) ---------------------------------------------------------
 // Slots [img0, img0 + n_img) on stream `st`.  Every per-image array is offset on the host, so the kernels index from 0.
+// level 0 read straight from the caller's images by the resize (device batches): see k_resize_regions
+struct ExtLevel0 {
+  const uint8_t *left, *right;  // image p of the batch at left / right + p * pitch
+  size_t pitch;
+  int stride;
+  uint32_t bytes;               // size of one image
+  hipEvent_t loaded;            // level 0 of the pyramid is complete (the copy-in runs on the second stream): FAST waits for it
+  hipEvent_t inputs_free;       // nullable: recorded once resize AND copy-in are done with the caller's images
+};
 static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, int lds_share = 1, hipEvent_t before_lists = nullptr,
-                                bool timing = true) {
+                                bool timing = true, const ExtLevel0* ext = nullptr) {
   // timing = false: a slot lane (orbfe_extract_slot) -- several of them run at once, so nothing shared by the context is touched:
   // no stage timers (their event lists belong to the main lane), no second stream
   // before_lists: event the keypoint-list / orientation / descriptor kernels must wait for (the previous batch's stereo match still
@@ -773,9 +785,15 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     StageTimer t(c, ORBFE_STAGE_RESIZE, st, timing);
     if (c->resize_regions && !c->rs_regions.empty())
       launch_resize_regions(st, c->d_lv, nl, c->d_rs_regions, (int)c->rs_regions.size(), c->rg_tile_bytes, c->rg_xt_bytes, c->rg_yt_bytes,
-                            c->d_rg_xtaps, c->d_rg_ytaps, pyr, c->img_pitch, n_img);
+                            c->d_rg_xtaps, c->d_rg_ytaps, pyr, c->img_pitch, n_img, ext ? ext->left : pyr + c->lv[0].plane_off,
+                            ext ? ext->right : nullptr, ext ? ext->pitch : c->img_pitch, ext ? ext->stride : c->lv[0].stride,
+                            ext ? ext->bytes : 0xFFFFFFFFu);
     else
       launch_resize(st, c->d_lv, c->d_rs_tiles, c->rs_n, c->rs_bytes, c->d_taps, pyr, c->img_pitch, n_img);
+  }
+  if (ext) {  // everything below reads level 0 of the pyramid
+    HIP_TRY(c, hipStreamWaitEvent(st, ext->loaded, 0));
+    if (ext->inputs_free) HIP_TRY(c, hipEventRecord(ext->inputs_free, st));
   }
   // Only the descriptors read the blurred planes, so the blur need not sit between resize and FAST: the levels above 0 are issued on a second
   // stream once FAST is done (beside FAST, which saturates the vector units, they cost more than they hide: +2 %) and runs UNDER the quadtree, which keeps 8 waves per CU busy with dependent LDS steps and leaves
@@ -914,6 +932,7 @@ void orbfe_destroy(orbfe_ctx* c) {
   c->main.graphs.clear();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_blur_go) (void)hipEventDestroy(c->ev_blur_go);
+  if (c->ev_loaded) (void)hipEventDestroy(c->ev_loaded);
   if (c->ev_blur_done) (void)hipEventDestroy(c->ev_blur_done);
   if (c->ev_fast_go) (void)hipEventDestroy(c->ev_fast_go);
   if (c->ev_fast_done) (void)hipEventDestroy(c->ev_fast_done);
@@ -1006,10 +1025,12 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     }
     if (const char* rr = getenv("ORBFE_RESIZE_REGIONS")) c->resize_regions = atoi(rr) != 0;
     if (const char* be = getenv("ORBFE_BLUR_L0_EARLY")) c->blur_l0_early = atoi(be) != 0;
+    if (const char* xl = getenv("ORBFE_EXT_LEVEL0")) c->ext_level0 = atoi(xl) != 0;
     const char* ov = getenv("ORBFE_OVERLAP_BLUR");
     if (!ov || atoi(ov) != 0) {
       if (hipStreamCreateWithFlags(&c->blur_stream, hipStreamNonBlocking) != hipSuccess ||
           hipEventCreateWithFlags(&c->ev_blur_go, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&c->ev_loaded, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&c->ev_blur_done, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&c->ev_fast_go, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&c->ev_fast_done, hipEventDisableTiming) != hipSuccess) {
@@ -1501,11 +1522,28 @@ static orbfe_status batch_device_core(orbfe_ctx* c, const uint8_t* d_left, const
     if (p1 <= p0) continue;
     hipStream_t st = serial ? c->stream : c->side[k];
     if (!serial) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_fork, 0));
-    // level 0 of slot 2p / 2p+1 <- left / right image p
-    launch_load_level0(st, d_left + (size_t)p0 * image_pitch, d_right + (size_t)p0 * image_pitch, stride, image_pitch, c->d_pyr, c->img_pitch,
-                       L0.plane_off, L0.stride, c->cfg.width, c->cfg.height, 2 * p0, 2, p1 - p0);
-    if (pack && pack->in_free && serial && k == n_chunks - 1) HIP_TRY(c, hipEventRecord(pack->in_free, st));  // the images may be overwritten
-    TRY(run_extract(c, st, 2 * p0, 2 * (p1 - p0), serial ? 1 : n_chunks, (piped && c->stereo_pending) ? c->ev_stereo_done : nullptr));
+    // level 0 of slot 2p / 2p+1 <- left / right image p.  One chunk of >= 32 images with the second stream available: the copy-in goes to
+    // that stream and the resize reads the caller's images itself, so the two run side by side instead of one after the other at the
+    // head of the critical path (the blur of level 0 follows the copy-in on its stream, FAST waits for it)
+    const bool ext0 = serial && k == 0 && c->ext_level0 && c->blur_stream && c->ev_loaded && c->prof != 1 && c->resize_regions && !c->rs_regions.empty() &&
+                      2 * (p1 - p0) >= 32 && (size_t)stride * c->cfg.height <= 0xFFFFFFF0u;
+    ExtLevel0 ext;
+    if (ext0) {
+      HIP_TRY(c, hipStreamWaitEvent(c->blur_stream, c->ev_fork, 0));
+      launch_load_level0(c->blur_stream, d_left + (size_t)p0 * image_pitch, d_right + (size_t)p0 * image_pitch, stride, image_pitch, c->d_pyr,
+                         c->img_pitch, L0.plane_off, L0.stride, c->cfg.width, c->cfg.height, 2 * p0, 2, p1 - p0);
+      HIP_TRY(c, hipEventRecord(c->ev_loaded, c->blur_stream));
+      ext.left = d_left + (size_t)p0 * image_pitch, ext.right = d_right + (size_t)p0 * image_pitch;
+      ext.pitch = image_pitch, ext.stride = (int)stride, ext.bytes = (uint32_t)((size_t)stride * (c->cfg.height - 1) + c->cfg.width);
+      ext.loaded = c->ev_loaded;
+      ext.inputs_free = (pack && pack->in_free) ? pack->in_free : nullptr;
+    } else {
+      launch_load_level0(st, d_left + (size_t)p0 * image_pitch, d_right + (size_t)p0 * image_pitch, stride, image_pitch, c->d_pyr, c->img_pitch,
+                         L0.plane_off, L0.stride, c->cfg.width, c->cfg.height, 2 * p0, 2, p1 - p0);
+      if (pack && pack->in_free && serial && k == n_chunks - 1) HIP_TRY(c, hipEventRecord(pack->in_free, st));  // the images may be overwritten
+    }
+    TRY(run_extract(c, st, 2 * p0, 2 * (p1 - p0), serial ? 1 : n_chunks, (piped && c->stereo_pending) ? c->ev_stereo_done : nullptr, true,
+                    ext0 ? &ext : nullptr));
     if (piped) {
       HIP_TRY(c, hipEventRecord(c->ev_brief_done, st));
       HIP_TRY(c, hipStreamWaitEvent(c->stereo_stream, c->ev_brief_done, 0));

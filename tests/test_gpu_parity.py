@@ -533,3 +533,33 @@ def test_row_widths_around_the_blur_strip_and_word_boundaries(orc, lib, w):
     k, d = ctx.extract(img)
     assert_image_parity(ctx, 0, orc.extractor(img, n_features=300, n_levels=nl), k, d, nl)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_device_batch_whose_resize_reads_the_callers_images(orc, lib):
+    """Batches of >= 32 images: k_resize_regions reads level 0 straight from the caller's device images while the copy-in runs beside it.
+    Exact-size contiguous buffers (the last 16-byte unit of the last row of the last image must not be read past the buffer's end),
+    rows padded to an odd stride, and a pitch with spare rows between the images; first, middle and last pair against the oracle."""
+    import torch
+    B = 16
+    pairs = [synth.stereo_pair(400 + (f % 5)) for f in range(B)]
+    ref = {f: orc.stereo_frame(*pairs[f], fx=FX, bf=BF) for f in (0, 7, B - 1)}
+    ctx = lib.Context(1241, 376, max_images=2 * B)
+    layouts = [(1241, 376 * 1241), (1244, 376 * 1244), (1251, 380 * 1251)]
+    for stride, pitch in layouts:
+        buf_l = torch.full((B * pitch,), 201, dtype=torch.uint8, device="cuda")
+        buf_r = torch.full((B * pitch,), 202, dtype=torch.uint8, device="cuda")
+        for p, (L, R) in enumerate(pairs):
+            for buf, img in ((buf_l, L), (buf_r, R)):
+                view = buf[p * pitch:p * pitch + 376 * stride].view(376, stride)
+                view[:, :1241] = torch.from_numpy(img).cuda()
+        ctx.stereo_batch_device(buf_l.data_ptr(), buf_r.data_ptr(), stride, pitch, B, FX, BF)
+        ctx.sync()
+        for f, r in ref.items():
+            lk, ld = ctx.fetch_features(2 * f)
+            rk, rd = ctx.fetch_features(2 * f + 1)
+            nm, ru, dp, br, bd = ctx.fetch_stereo(f)
+            assert np.array_equal(lk, r["lk"]) and np.array_equal(ld, r["ld"]) and np.array_equal(rk, r["rk"]) and np.array_equal(rd, r["rd"]), (stride, f)
+            n = len(lk)
+            assert nm == r["n_matches"] and np.array_equal(ru[:n], r["right_u"]) and np.array_equal(dp[:n], r["depth"]), (stride, f)
+    ctx.close()
