@@ -170,7 +170,8 @@ struct orbfe_ctx {
   bool stereo_pending = false, pipeline_stereo = true;
   hipStream_t blur_stream = nullptr;
   hipEvent_t ev_blur_go = nullptr, ev_blur_done = nullptr, ev_fast_go = nullptr, ev_fast_done = nullptr;
-  int fast_side_from = 3;  // k_fast launches of levels >= this run on the blur stream beside the large levels (ORBFE_FAST_SIDE_FROM; 0: off)
+  int fast_side_from = 0;  // k_fast launches of levels >= this run on the blur stream beside the large levels (ORBFE_FAST_SIDE_FROM; 0: off -- the default
+                           // since the level-0 blur occupies that stream until well into FAST: the small levels queued behind it, 3 / 5 / 0: 5.75 / 5.72 / 5.71 ms)
 
   // geometry (host copies)
   std::vector<LevelDev> lv;

@@ -65,7 +65,7 @@ KNOBS = [
     {"ORBFE_OVERLAP_BLUR": "0"},          # blur in line, no second stream
     {"ORBFE_BLUR_L0_EARLY": "0"},         # the whole blur after FAST (default: level 0 beside the resize)
     {"ORBFE_EXT_LEVEL0": "0"},            # copy level 0 in first, then resize from the copy (default: the resize reads the caller's images beside the copy-in)
-    {"ORBFE_FAST_SIDE_FROM": "0"},        # every k_fast launch on the context stream
+    {"ORBFE_FAST_SIDE_FROM": "3"},        # the k_fast launches of levels >= 3 on the second stream
     {"ORBFE_FAST_SIDE_FROM": "5"},
     {"ORBFE_NO_XCD_ORDER": "1"},          # row-major cell / tile tables
     {"ORBFE_RESIZE_REGIONS": "0"},        # resize by the per-class output tiles instead of the region-driven single pass
