@@ -525,9 +525,11 @@ def main():
             # batch, i.e. NLEVELS k_fast launches, the small levels on a second stream BESIDE the large ones.  Their rocprofv3
             # durations therefore overlap: the matching trace figure is the union of the launches' intervals per step (column
             # UnionNs / steps of profiles/*_kernel_stats.csv, tools/kernel_stats_from_db.py), not average x NLEVELS
-            "kernel_launches_per_step": {"fast": NLEVELS, "orient_brief": 4, "resize": 1, "blur": 1, "quadtree": 1, "stereo": 1}[dom],
+            "kernel_launches_per_step": {"fast": NLEVELS, "orient_brief": 4, "resize": 1, "blur": 2, "quadtree": 1, "stereo": 2}[dom],
             "avg_launch_ms_alone": stages_inline[dom],
-            "rocprof_match": "union of the overlapping k_fast launches per step (UnionNs / steps in the newest profiles/r2_*_kernel_stats.csv)",
+            "rocprof_match": ("union of the k_fast launches of a step (UnionNs / steps in the newest profiles/r2_*_kernel_stats.csv); LIVE figure of the "
+                              "production schedule: the level-0 blur runs beside FAST on the second stream (avg_launch_ms_alone: nothing beside it)")
+                             if dom == "fast" else "sum of the stage's kernels per step in the newest profiles/r2_*_kernel_stats.csv",
             "all_stages": {k: {"ms": round(stages_inline[k], 4), "GBps": round(stage_bytes[k] / (stages_inline[k] * 1e-3) / 1e9, 1)}
                            for k in stages_inline if k in stage_bytes and stages_inline[k] > 0},
         },
