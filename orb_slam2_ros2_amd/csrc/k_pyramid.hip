@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_resize_regions(const LevelDev* __restri
                                                         const RgXTap* __restrict__ xtaps, const RgYTap* __restrict__ ytaps,
                                                         uint8_t* __restrict__ pyr, size_t img_pitch, int tile_bytes, int xt_bytes,
                                                         const uint8_t* __restrict__ src_a, const uint8_t* __restrict__ src_b, size_t src_pitch,
-                                                        int sstride, uint32_t src_bytes) {
+                                                        int sstride, uint32_t src_bytes, int copy_l0) {
   // level 0 is read from (src_a, src_b, src_pitch, sstride): the pyramid's own level-0 planes (src_b null: image i at src_a + i src_pitch),
   // or -- device batches -- the CALLER's left / right images (image i = eye i & 1 of pair i >> 1), so that the resize does not wait
   // for the copy-in but runs beside it.  src_bytes: size of one source image; a 16-byte unit that would end past it (the last unit
@@ -209,6 +209,19 @@ __global__ __launch_bounds__(256) void k_resize_regions(const LevelDev* __restri
     }
   }
   __syncthreads();
+  if (copy_l0) {
+    // level 0 of the pyramid <- the block of the source this region owns, straight from the staged tile (device batches: this IS the
+    // copy-in; the columns start at sx0, a multiple of 16, and the plane rows are 16-byte aligned: aligned 16-byte stores)
+    const int cq = R.cq, n_u = cq * R.ch;
+    const uint32_t inv = ((1u << 20) + cq - 1) / cq;
+    const uint4* t4 = (const uint4*)tile;
+    uint8_t* dst = base + lv[0].plane_off + (size_t)R.cy0 * lv[0].stride + R.sx0;
+    const int r_off = (R.cy0 - R.sy0) * nq;
+    for (int k = threadIdx.x; k < n_u; k += 256) {
+      const int r = (int)((uint32_t)mul24u(k, (int)inv) >> 20), cu = k - mul24u(r, cq);
+      *(uint4*)(dst + (uint32_t)mad24u(r, lv[0].stride, 16 * cu)) = t4[r_off + mul24u(r, nq) + cu];
+    }
+  }
   typedef const __attribute__((address_space(3))) uint8_t* lds_bytes_t;
   lds_bytes_t tb = (lds_bytes_t)tile;
   typedef unsigned short __attribute__((ext_vector_type(2))) us2;
@@ -526,10 +539,10 @@ void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, c
 
 void launch_resize_regions(hipStream_t s, const LevelDev* d_lv, int n_levels, const RsRegion* d_regions, int n_regions, int tile_bytes,
                            int xt_bytes, int yt_bytes, const RgXTap* d_xtaps, const RgYTap* d_ytaps, uint8_t* d_pyr, size_t img_pitch, int n_img,
-                           const uint8_t* src_a, const uint8_t* src_b, size_t src_pitch, int src_stride, uint32_t src_bytes) {
+                           const uint8_t* src_a, const uint8_t* src_b, size_t src_pitch, int src_stride, uint32_t src_bytes, int copy_l0) {
   if (n_img <= 0 || n_regions <= 0) return;
   hipLaunchKernelGGL(k_resize_regions, dim3(n_regions, n_img), dim3(256), (size_t)(tile_bytes + xt_bytes + yt_bytes), s, d_lv, n_levels,
-                     d_regions, d_xtaps, d_ytaps, d_pyr, img_pitch, tile_bytes, xt_bytes, src_a, src_b, src_pitch, src_stride, src_bytes);
+                     d_regions, d_xtaps, d_ytaps, d_pyr, img_pitch, tile_bytes, xt_bytes, src_a, src_b, src_pitch, src_stride, src_bytes, copy_l0);
 }
 
 // tiles [tile_first, tile_first + n_tiles) of the per-image tile list (level-major: a range of tiles is a range of levels)

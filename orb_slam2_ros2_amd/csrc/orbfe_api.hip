@@ -25,7 +25,7 @@ void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, c
                    size_t img_pitch, int n_img);
 void launch_resize_regions(hipStream_t s, const LevelDev* d_lv, int n_levels, const RsRegion* d_regions, int n_regions, int tile_bytes,
                            int xt_bytes, int yt_bytes, const RgXTap* d_xtaps, const RgYTap* d_ytaps, uint8_t* d_pyr, size_t img_pitch, int n_img,
-                           const uint8_t* src_a, const uint8_t* src_b, size_t src_pitch, int src_stride, uint32_t src_bytes);
+                           const uint8_t* src_a, const uint8_t* src_b, size_t src_pitch, int src_stride, uint32_t src_bytes, int copy_l0);
 void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int tile_first, int n_tiles, const uint8_t* d_pyr, uint8_t* d_blur,
                  size_t img_pitch, const int taps[7], int n_img);
 void launch_load_level0(hipStream_t st, const uint8_t* d_src, const uint8_t* d_src_b, size_t src_stride, size_t src_pitch, uint8_t* d_pyr,
@@ -552,7 +552,12 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
           }
           if ((long long)G.nwx * G.noy >= (1 << 20) / 256 * 256) ok = false;  // (never: a region holds a few thousand words)
         }
-        if (x_hi < 0) continue;  // no level starts a word here
+        // the block of level 0 this region owns is staged whether a level needs all of it or not (see RsRegion::cy0)
+        {
+          const int bx1 = std::min((i + 1) * RG_W, cfg.width) - 1, by0 = j * RG_H, by1 = std::min((j + 1) * RG_H, cfg.height) - 1;
+          x_hi = std::max(x_hi, bx1), y_lo = std::min(y_lo, by0), y_hi = std::max(y_hi, by1);
+          R.cy0 = (int16_t)by0, R.ch = (int16_t)(by1 - by0 + 1), R.cq = (int16_t)((bx1 - i * RG_W) / 16 + 1), R.pad_ = 0;
+        }
         R.sx0 = (int16_t)(i * RG_W), R.sy0 = (int16_t)y_lo;
         R.nq = (int16_t)(((x_hi - R.sx0) >> 4) + 1), R.nr = (int16_t)(y_hi - y_lo + 1);
         R.inv_nq = ((1u << 20) + R.nq - 1) / R.nq;
@@ -758,8 +763,7 @@ struct ExtLevel0 {
   size_t pitch;
   int stride;
   uint32_t bytes;               // size of one image
-  hipEvent_t loaded;            // level 0 of the pyramid is complete (the copy-in runs on the second stream): FAST waits for it
-  hipEvent_t inputs_free;       // nullable: recorded once resize AND copy-in are done with the caller's images
+  hipEvent_t inputs_free;       // nullable: recorded once the resize (which also writes level 0 of the pyramid) is done with the caller's images
 };
 static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, int lds_share = 1, hipEvent_t before_lists = nullptr,
                                 bool timing = true, const ExtLevel0* ext = nullptr) {
@@ -777,7 +781,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   // the blur of LEVEL 0 needs nothing but the copy-in: it starts beside the resize (a third of the blur's work out of the way of the
   // moments, which are as memory-bound as it is and take the sum of the two times when they meet)
   const int l0_tiles = (overlap_blur && c->blur_l0_early && nl > 1) ? c->lv[1].bl_tile_base : 0;
-  if (l0_tiles > 0) {
+  if (l0_tiles > 0 && !ext) {
     HIP_TRY(c, hipEventRecord(c->ev_blur_go, st));
     HIP_TRY(c, hipStreamWaitEvent(c->blur_stream, c->ev_blur_go, 0));
     launch_blur(c->blur_stream, c->d_lv, nl, 0, l0_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
@@ -788,13 +792,17 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
       launch_resize_regions(st, c->d_lv, nl, c->d_rs_regions, (int)c->rs_regions.size(), c->rg_tile_bytes, c->rg_xt_bytes, c->rg_yt_bytes,
                             c->d_rg_xtaps, c->d_rg_ytaps, pyr, c->img_pitch, n_img, ext ? ext->left : pyr + c->lv[0].plane_off,
                             ext ? ext->right : nullptr, ext ? ext->pitch : c->img_pitch, ext ? ext->stride : c->lv[0].stride,
-                            ext ? ext->bytes : 0xFFFFFFFFu);
+                            ext ? ext->bytes : 0xFFFFFFFFu, ext ? 1 : 0);
     else
       launch_resize(st, c->d_lv, c->d_rs_tiles, c->rs_n, c->rs_bytes, c->d_taps, pyr, c->img_pitch, n_img);
   }
-  if (ext) {  // everything below reads level 0 of the pyramid
-    HIP_TRY(c, hipStreamWaitEvent(st, ext->loaded, 0));
+  if (ext) {  // the resize has also written level 0 of the pyramid (its blocks of the caller's images): the images are free, the level-0 blur may start
     if (ext->inputs_free) HIP_TRY(c, hipEventRecord(ext->inputs_free, st));
+    if (l0_tiles > 0) {
+      HIP_TRY(c, hipEventRecord(c->ev_blur_go, st));
+      HIP_TRY(c, hipStreamWaitEvent(c->blur_stream, c->ev_blur_go, 0));
+      launch_blur(c->blur_stream, c->d_lv, nl, 0, l0_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
+    }
   }
   // Only the descriptors read the blurred planes, so the blur need not sit between resize and FAST: the levels above 0 are issued on a second
   // stream once FAST is done (beside FAST, which saturates the vector units, they cost more than they hide: +2 %) and runs UNDER the quadtree, which keeps 8 waves per CU busy with dependent LDS steps and leaves
@@ -1523,20 +1531,14 @@ static orbfe_status batch_device_core(orbfe_ctx* c, const uint8_t* d_left, const
     if (p1 <= p0) continue;
     hipStream_t st = serial ? c->stream : c->side[k];
     if (!serial) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_fork, 0));
-    // level 0 of slot 2p / 2p+1 <- left / right image p.  One chunk of >= 32 images with the second stream available: the copy-in goes to
-    // that stream and the resize reads the caller's images itself, so the two run side by side instead of one after the other at the
-    // head of the critical path (the blur of level 0 follows the copy-in on its stream, FAST waits for it)
+    // level 0 of slot 2p / 2p+1 <- left / right image p.  One chunk of >= 32 images: the resize reads the caller's images itself and every
+    // workgroup writes its block of level 0 into the pyramid from the tile it has staged anyway -- no copy-in kernel, half its traffic
     const bool ext0 = serial && k == 0 && c->ext_level0 && c->blur_stream && c->ev_loaded && c->prof != 1 && c->resize_regions && !c->rs_regions.empty() &&
                       2 * (p1 - p0) >= 32 && (size_t)stride * c->cfg.height <= 0xFFFFFFF0u;
     ExtLevel0 ext;
     if (ext0) {
-      HIP_TRY(c, hipStreamWaitEvent(c->blur_stream, c->ev_fork, 0));
-      launch_load_level0(c->blur_stream, d_left + (size_t)p0 * image_pitch, d_right + (size_t)p0 * image_pitch, stride, image_pitch, c->d_pyr,
-                         c->img_pitch, L0.plane_off, L0.stride, c->cfg.width, c->cfg.height, 2 * p0, 2, p1 - p0);
-      HIP_TRY(c, hipEventRecord(c->ev_loaded, c->blur_stream));
       ext.left = d_left + (size_t)p0 * image_pitch, ext.right = d_right + (size_t)p0 * image_pitch;
       ext.pitch = image_pitch, ext.stride = (int)stride, ext.bytes = (uint32_t)((size_t)stride * (c->cfg.height - 1) + c->cfg.width);
-      ext.loaded = c->ev_loaded;
       ext.inputs_free = (pack && pack->in_free) ? pack->in_free : nullptr;
     } else {
       launch_load_level0(st, d_left + (size_t)p0 * image_pitch, d_right + (size_t)p0 * image_pitch, stride, image_pitch, c->d_pyr, c->img_pitch,

@@ -55,6 +55,8 @@ struct RsRegion {
   int16_t nq, nr;          // staged 16-byte quads per row, rows
   uint32_t inv_nq;         // ceil(2^20 / nq)
   uint16_t n_xt, n_yt;     // taps of all levels (n_xt is a multiple of 4)
+  int16_t cy0, ch, cq;     // the block of level 0 the region OWNS: rows [cy0, cy0 + ch), cq 16-byte units from column sx0 (always staged: the
+  int16_t pad_;            // region kernel can write level 0 of the pyramid from its tile, which replaces the copy-in of device batches)
   uint32_t xt_off, yt_off; // first entry of the region in the context's RgXTap / RgYTap arrays
   RsRegionLevel lev[ORBFE_MAX_LEVELS - 1];
 };

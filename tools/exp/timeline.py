@@ -4,10 +4,10 @@ Prints every kernel launch between two consecutive k_quadtree starts: name, star
 import re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
-q = [s for n, s, e in rows if "k_load_level0" in n]
+q = [s for n, s, e in rows if "k_resize_regions" in n] or [s for n, s, e in rows if "k_load_level0" in n]
 i = int(sys.argv[2]) if len(sys.argv) > 2 else len(q) // 2
 t0, t1 = q[i], q[i + 1]
-print(f"step {i}: {1e-3 * (t1 - t0):.1f} us between two copy-ins")
+print(f"step {i}: {1e-3 * (t1 - t0):.1f} us between the starts of two steps")
 for n, s, e in rows:
     if s >= t0 - 1500000 and s < t1:
         m = re.search(r"(k_\w+)", n)
