@@ -314,9 +314,19 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_e
       // wave; the fence only pins the compiler
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      const uint8_t* wb = (const uint8_t*)win;
       const float px = (float)x, py = (float)y;
-      const int xbias = 0x4B400000 + xa, ybias = 0x4B400000 + (y - BRIEF_R);  // bit pattern of 1.5 * 2^23 + the window origin
+      // cvRound(float sum) and the window address without a subtraction.  Adding 1.5 * 2^23 rounds a float sum to an integer with ties to
+      // even -- the unit in the last place of the result is 1 -- and leaves that integer in the low mantissa bits (0x4B400000 + n).  An
+      // EVEN integer folded into the constant (exact in a float below 2^24) moves n without touching the rounding, ties included (the
+      // parity of the candidates is unchanged): the row constant carries minus the window's first row rounded down to even, the column
+      // constant minus the window's first column (a multiple of 4) plus the LDS byte address of the wave's window, less one window row
+      // where the first row is odd.  v_mad_u32_u24 then reads the row in the low 24 bits of its first operand (0x400000 + row) and adds
+      // the whole second float: 44 row + column + address + 0x56400000, whose low 16 bits are the address.  Exact for |sum| < 2^21;
+      // the float additions are neither contracted nor re-associated (fp contract off, no fast-math).
+      typedef const __attribute__((address_space(3))) uint8_t* lds_bytes_t;
+      const int y0w = y - BRIEF_R;
+      const float magic_y = (float)(12582912 - (y0w & ~1));
+      const float magic_x = (float)(12582912 - xa + (int)(uint32_t)(uintptr_t)(lds_bytes_t)(const uint8_t*)win - (y0w & 1) * (BRIEF_WORDS * 4));
       unsigned long long bits[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -327,14 +337,10 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_e
         const float p1y = (float)(rs[x1 + BRIEF_R] + rc[y1 + BRIEF_R]);  // x1 sin + y1 cos
         const float p2x = (float)(rc[x2 + BRIEF_R] - rs[y2 + BRIEF_R]);
         const float p2y = (float)(rs[x2 + BRIEF_R] + rc[y2 + BRIEF_R]);
-        // cvRound(float sum) minus the window origin in two instructions instead of four (v_rndne, v_cvt, v_sub after the add): adding
-        // 1.5 * 2^23 rounds the sum to an integer with ties to even -- the unit in the last place of the result is 1 -- and leaves that
-        // integer in the low mantissa bits, so one integer subtraction removes the constant's bit pattern AND the origin.  Exact for
-        // |sum| < 2^22 (coordinates are < 2^12); the two float additions are not contracted or re-associated (fp contract off, no fast-math).
-        const int r1o = __float_as_int((py + p1y) + 12582912.0f) - ybias, c1o = __float_as_int((px + p1x) + 12582912.0f) - xbias;
-        const int r2o = __float_as_int((py + p2y) + 12582912.0f) - ybias, c2o = __float_as_int((px + p2x) + 12582912.0f) - xbias;
-        const int v1 = wb[mad24u(r1o, BRIEF_WORDS * 4, c1o)];
-        const int v2 = wb[mad24u(r2o, BRIEF_WORDS * 4, c2o)];
+        const uint32_t a1 = (uint32_t)mad24u(__float_as_int((py + p1y) + magic_y), BRIEF_WORDS * 4, __float_as_int((px + p1x) + magic_x)) & 0xFFFFu;
+        const uint32_t a2 = (uint32_t)mad24u(__float_as_int((py + p2y) + magic_y), BRIEF_WORDS * 4, __float_as_int((px + p2x) + magic_x)) & 0xFFFFu;
+        const int v1 = *(lds_bytes_t)(uintptr_t)a1;
+        const int v2 = *(lds_bytes_t)(uintptr_t)a2;
         bits[g] = __ballot(v1 < v2);
       }
       if (lane < 4) {
