@@ -539,7 +539,10 @@ def main():
     # instruction-bound, so the HBM fraction alone says little about it.  wave-instructions per second = waves per launch x VALU
     # instructions per wave (committed rocprofv3 SQ_* counter pass, profiles/) / the launch duration measured live above; peak = 256 CUs
     # x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction.
-    sq_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_sq_counters.json"))
+    import re as _re
+    def _round_key(f):  # r2_v10 after r2_v9
+        return [int(x) for x in _re.findall(r"\d+", f)]
+    sq_files = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_sq_counters.json")), key=_round_key)
     kern_of = {"fast": "k_fast", "blur": "k_blur", "quadtree": "k_quadtree", "stereo": "k_stereo", "resize": "k_resize_regions"}
     if sq_files and dom in kern_of:
         try:
