@@ -193,7 +193,6 @@ struct orbfe_ctx {
   bool resize_regions = true;        // ORBFE_RESIZE_REGIONS=0: the per-class tile launches instead
   bool blur_l0_early = true;         // ORBFE_BLUR_L0_EARLY=0: the whole blur after FAST
   bool ext_level0 = true;            // ORBFE_EXT_LEVEL0=0: device batches copy level 0 in first, then resize from the copy
-  hipEvent_t ev_loaded = nullptr;
   int rs_n[3] = {0, 0, 0}, rs_bytes[3] = {0, 0, 0};  // resize tiles of 64x64 / 64x32 / 64x16 outputs (in this order) and their LDS
   size_t img_pitch = 0;      // bytes per image in pyr / blur
   size_t scratch_pitch = 0;  // uint32 records per image
@@ -941,7 +940,6 @@ void orbfe_destroy(orbfe_ctx* c) {
   c->main.graphs.clear();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_blur_go) (void)hipEventDestroy(c->ev_blur_go);
-  if (c->ev_loaded) (void)hipEventDestroy(c->ev_loaded);
   if (c->ev_blur_done) (void)hipEventDestroy(c->ev_blur_done);
   if (c->ev_fast_go) (void)hipEventDestroy(c->ev_fast_go);
   if (c->ev_fast_done) (void)hipEventDestroy(c->ev_fast_done);
@@ -1039,7 +1037,6 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     if (!ov || atoi(ov) != 0) {
       if (hipStreamCreateWithFlags(&c->blur_stream, hipStreamNonBlocking) != hipSuccess ||
           hipEventCreateWithFlags(&c->ev_blur_go, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&c->ev_loaded, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&c->ev_blur_done, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&c->ev_fast_go, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&c->ev_fast_done, hipEventDisableTiming) != hipSuccess) {
@@ -1533,7 +1530,7 @@ static orbfe_status batch_device_core(orbfe_ctx* c, const uint8_t* d_left, const
     if (!serial) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_fork, 0));
     // level 0 of slot 2p / 2p+1 <- left / right image p.  One chunk of >= 32 images: the resize reads the caller's images itself and every
     // workgroup writes its block of level 0 into the pyramid from the tile it has staged anyway -- no copy-in kernel, half its traffic
-    const bool ext0 = serial && k == 0 && c->ext_level0 && c->blur_stream && c->ev_loaded && c->prof != 1 && c->resize_regions && !c->rs_regions.empty() &&
+    const bool ext0 = serial && k == 0 && c->ext_level0 && c->blur_stream && c->prof != 1 && c->resize_regions && !c->rs_regions.empty() &&
                       2 * (p1 - p0) >= 32 && (size_t)stride * c->cfg.height <= 0xFFFFFFF0u;
     ExtLevel0 ext;
     if (ext0) {
