@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv,
 }
 
 // ---------------------------------------------------------------------------------------------
-// resize, region-driven (r2): one workgroup stages ONE block of level 0 (RG_W x RG_H pixels + the halo its taps reach) and writes
+// resize, region-driven (r2): one workgroup stages ONE block of level 0 (about 200 x 50 pixels, chosen per geometry, + the halo its taps reach) and writes
 // the output words of ALL levels whose first source pixel lies in the block -- the reference resizes every level from level 0
 // (quirk Q1), and with one launch per tile class above each level staged its own copy of the plane: 3.9 GB through the L2 per
 // 1024 images, 0.72 ms of the 1.11 ms the three launches took with the arithmetic removed.  Here level 0 is staged once (plus halo).
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_resize_regions(const LevelDev* __restri
   const RsRegion& R = regions[blockIdx.x];
   uint8_t* base = pyr + (size_t)img * img_pitch;
   const uint8_t* S = src_b ? ((img & 1) ? src_b : src_a) + (size_t)(img >> 1) * src_pitch : src_a + (size_t)img * src_pitch;
-  const int nq = R.nq, nr = R.nr;
+  const int nq = R.nq, nr = R.nr, pq = R.pq;  // units loaded per row, rows, LDS row pitch in units (odd: see RsRegion)
   // the level descriptors of the region, lane = level: requested with everything else, handed out by v_readlane (as scalar
   // loads at the top of each level's loop they were seven dependent memory round trips per workgroup)
   const uint4 gq = *(const uint4*)&R.lev[min((int)(threadIdx.x & 63), ORBFE_MAX_LEVELS - 2)];
@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void k_resize_regions(const LevelDev* __restri
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int k = b0 + u * 256 + threadIdx.x;
-        if (k < n_tile) tile4[k] = tq[u];
+        const int r = (int)((uint32_t)mul24u(min(k, n_tile - 1), (int)inv) >> 20);
+        if (k < n_tile) tile4[k + mul24u(r, pq - nq)] = tq[u];  // row r of the tile starts at unit r * pq
         if (k < n_x) ((uint4*)xs)[k] = xq[u];
         if (k < n_y) ((uint4*)ys)[k] = yq[u];
       }
@@ -216,10 +217,10 @@ __global__ __launch_bounds__(256) void k_resize_regions(const LevelDev* __restri
     const uint32_t inv = ((1u << 20) + cq - 1) / cq;
     const uint4* t4 = (const uint4*)tile;
     uint8_t* dst = base + lv[0].plane_off + (size_t)R.cy0 * lv[0].stride + R.sx0;
-    const int r_off = (R.cy0 - R.sy0) * nq;
+    const int r_off = (R.cy0 - R.sy0) * pq;
     for (int k = threadIdx.x; k < n_u; k += 256) {
       const int r = (int)((uint32_t)mul24u(k, (int)inv) >> 20), cu = k - mul24u(r, cq);
-      *(uint4*)(dst + (uint32_t)mad24u(r, lv[0].stride, 16 * cu)) = t4[r_off + mul24u(r, nq) + cu];
+      *(uint4*)(dst + (uint32_t)mad24u(r, lv[0].stride, 16 * cu)) = t4[r_off + mul24u(r, pq) + cu];
     }
   }
   typedef const __attribute__((address_space(3))) uint8_t* lds_bytes_t;

@@ -514,6 +514,20 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
   c->rg_ytaps.clear();
   c->rg_tile_bytes = c->rg_xt_bytes = c->rg_yt_bytes = 0;
   if (nl > 1) {
+    int RG_W = 176, RG_H = 47;
+    {
+      double best = -1.0;
+      for (int hh : {47, 63})
+        for (int ww = 128; ww <= 256; ww += 16) {
+          const int nx = (cfg.width + ww - 1) / ww, ny = (cfg.height + hh - 1) / hh;
+          const double fill = ((double)cfg.width / (nx * ww)) * ((double)cfg.height / (ny * hh));
+          if (fill > best + 1e-9 || (fill > best - 1e-9 && ww * hh > RG_W * RG_H)) best = std::max(best, fill), RG_W = ww, RG_H = hh;
+        }
+      if (const char* e = getenv("ORBFE_RG")) {  // "W,H" (tuning / tests)
+        int ww = 0, hh = 0;
+        if (sscanf(e, "%d,%d", &ww, &hh) == 2 && ww >= 64 && ww <= 1024 && ww % 16 == 0 && hh >= 8 && hh <= 255) RG_W = ww, RG_H = hh;
+      }
+    }
     const int nrx = (cfg.width + RG_W - 1) / RG_W, nry = (cfg.height + RG_H - 1) / RG_H;
     bool ok = true;
     for (int j = 0; j < nry && ok; ++j)
@@ -555,11 +569,12 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
         {
           const int bx1 = std::min((i + 1) * RG_W, cfg.width) - 1, by0 = j * RG_H, by1 = std::min((j + 1) * RG_H, cfg.height) - 1;
           x_hi = std::max(x_hi, bx1), y_lo = std::min(y_lo, by0), y_hi = std::max(y_hi, by1);
-          R.cy0 = (int16_t)by0, R.ch = (int16_t)(by1 - by0 + 1), R.cq = (int16_t)((bx1 - i * RG_W) / 16 + 1), R.pad_ = 0;
+          R.cy0 = (int16_t)by0, R.ch = (int16_t)(by1 - by0 + 1), R.cq = (int16_t)((bx1 - i * RG_W) / 16 + 1), R.pq = 0;
         }
         R.sx0 = (int16_t)(i * RG_W), R.sy0 = (int16_t)y_lo;
         R.nq = (int16_t)(((x_hi - R.sx0) >> 4) + 1), R.nr = (int16_t)(y_hi - y_lo + 1);
         R.inv_nq = ((1u << 20) + R.nq - 1) / R.nq;
+        R.pq = (int16_t)(R.nq | 1);
         R.n_xt = (uint16_t)n_xt, R.n_yt = (uint16_t)n_yt;
         if (R.nq * R.nr >= (1 << 20) / 512 || n_xt > 65535 || n_yt > 65535) ok = false;
         // the region's taps in their LDS layout
@@ -582,14 +597,14 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
             const ResizeTap t = yt[G.oy0 + k];
             const int r0 = std::min(std::max(t.ofs, 0), cfg.height - 1), r1 = std::min(std::max(t.ofs + 1, 0), cfg.height - 1);
             RgYTap o;
-            o.o0 = (r0 - R.sy0) * R.nq * 16;
-            o.o1 = (r1 - R.sy0) * R.nq * 16;
+            o.o0 = (r0 - R.sy0) * R.pq * 16;
+            o.o1 = (r1 - R.sy0) * R.pq * 16;
             o.b0 = (uint32_t)(uint16_t)t.c0 << 8;
             o.b1 = (uint32_t)(uint16_t)t.c1 << 8;
             c->rg_ytaps.push_back(o);
           }
         }
-        c->rg_tile_bytes = std::max(c->rg_tile_bytes, R.nq * 16 * R.nr);
+        c->rg_tile_bytes = std::max(c->rg_tile_bytes, R.pq * 16 * R.nr);
         c->rg_xt_bytes = std::max(c->rg_xt_bytes, n_xt * 8);
         c->rg_yt_bytes = std::max(c->rg_yt_bytes, n_yt * 16);
         c->rs_regions.push_back(R);

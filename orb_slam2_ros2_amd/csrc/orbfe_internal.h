@@ -32,9 +32,9 @@ struct RsTile {
 };
 
 // k_resize_regions work item: a block of level 0 staged ONCE and the output words of EVERY level whose first source pixel lies in it.
-// RG_W x RG_H level-0 pixels per region (plus the halo the bilinear taps of its last words reach into).
-#define RG_W 176
-#define RG_H 47
+// rg_w x rg_h level-0 pixels per region (plus the halo the bilinear taps of its last words reach into), chosen per geometry: the block
+// width (a multiple of 16 from 128 to 256) and height (47 or 63) that tile the image with the least waste -- a last column of a few
+// pixels is a workgroup in eight that stages a tile and walks seven levels for almost nothing (1241 px: 176 -> 0.79 ms, 208 or 256 -> 0.66).
 struct RsRegionLevel {
   int16_t wx0, nwx;        // output words (4 px) of the level: first, count
   int16_t oy0, noy;        // output rows: first, count
@@ -56,7 +56,9 @@ struct RsRegion {
   uint32_t inv_nq;         // ceil(2^20 / nq)
   uint16_t n_xt, n_yt;     // taps of all levels (n_xt is a multiple of 4)
   int16_t cy0, ch, cq;     // the block of level 0 the region OWNS: rows [cy0, cy0 + ch), cq 16-byte units from column sx0 (always staged: the
-  int16_t pad_;            // region kernel can write level 0 of the pyramid from its tile, which replaces the copy-in of device batches)
+  int16_t pq;              // region kernel can write level 0 of the pyramid from its tile, which replaces the copy-in of device batches)
+                           // pq: LDS row pitch of the tile in 16-byte units, ODD (a pitch of 128 / 192 / 256 bytes puts the rows a wave reads on the
+                           // same banks: region widths 112 / 176 / 240 ran 15 % slower than 96 / 128 / 144 / 160 until the pitch was padded)
   uint32_t xt_off, yt_off; // first entry of the region in the context's RgXTap / RgYTap arrays
   RsRegionLevel lev[ORBFE_MAX_LEVELS - 1];
 };

@@ -69,6 +69,8 @@ KNOBS = [
     {"ORBFE_FAST_SIDE_FROM": "5"},
     {"ORBFE_NO_XCD_ORDER": "1"},          # row-major cell / tile tables
     {"ORBFE_RESIZE_REGIONS": "0"},        # resize by the per-class output tiles instead of the region-driven single pass
+    {"ORBFE_RG": "176,47"},               # resize regions of a fixed size (default: the size that tiles the image best, 208 x 47 here)
+    {"ORBFE_RG": "112,31"},
     {"ORBFE_GRAPHS": "0"},                # no hipGraph replay on the host-pointer path
     {"ORBFE_STREAMS": "2"},               # two half-batches on their own streams
     {"ORBFE_QT_REC_CAP": "0", "ORBFE_QT_BATCH": "0", "ORBFE_PIPELINE_STEREO": "0", "ORBFE_OVERLAP_BLUR": "0", "ORBFE_GRAPHS": "0"},
