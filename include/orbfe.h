@@ -138,8 +138,8 @@ orbfe_status orbfe_stereo_match(orbfe_ctx* ctx, int32_t slot_left, int32_t slot_
  * rows stride_bytes apart.  Pair p uses slots 2p (left) and 2p+1 (right).  Asynchronous on the
  * context stream; results stay on the device until fetched.  The images must be complete when the call
  * is made and stay unchanged until the call's first kernels have run (the resize reads them directly and
- * writes level 0 of the pyramid from them): orbfe_sync, any fetch, or the NEXT batch call having returned
- * AND the device having started it are sufficient; reusing the same buffers call after call is fine.   */
+ * writes level 0 of the pyramid from them): do not overwrite them before orbfe_sync or a fetch of this
+ * batch's results has returned (the host-image stream entry points manage their own ring of buffers). */
 orbfe_status orbfe_stereo_batch_device(orbfe_ctx* ctx, const uint8_t* d_left, const uint8_t* d_right, size_t stride_bytes,
                                        size_t image_pitch_bytes, int32_t n_pairs, float fx, float bf);
 orbfe_status orbfe_sync(orbfe_ctx* ctx);
