@@ -159,10 +159,19 @@ def host_io_leg(ctx, left_h, right_h, B, steps, want, world, sync_all, dist, tor
     return res
 
 
-def sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend):
+def sequence_batch(block_frames, max_pairs):
+    """Pairs per batch of a sequence job: at least FOUR batches per rank, so that the upload of batch k + 1 and the gather / drain of
+    batch k - 1 run under the compute of batch k (one batch of 512 + a tail of 56, as a block of 568 frames at 8 ranks used to be cut,
+    overlaps nothing), capped by --pairs."""
+    return max(1, min(max_pairs, (max(block_frames, 1) + 3) // 4))
+
+
+def sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend, collective, window=1):
     """One timed sequence: F stereo pairs (frame f = synthetic frame f mod U) cut into blocks per rank, each rank streaming its block from
-    page-locked host memory in batches of <= B, records packed on the device, gathered on rank 0 (RCCL / the test backend) and copied to
-    page-locked host memory -- then every record checked.  Returns (seconds, frames of this rank, records checked against the host path)."""
+    page-locked host memory in batches of <= B, records packed on the device straight into the send buffer of the batch's WINDOW, every
+    window gathered on rank 0 (RCCL / the test backend) while the next one is computed and drained from there to page-locked host memory
+    -- then every record checked.  collective: take the gather through the process group even with one rank.
+    Returns (seconds, frames of this rank, records checked against the host path)."""
     import torch
     import torch.distributed as dist
 
@@ -174,9 +183,11 @@ def sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend):
     proc = DeviceSequenceProcessor(ctx, lambda f: synth.stereo_pair(f % U, W, H), B, FX, BF, dev, content_key=lambda f: f % U)
     proc.prepare(range(b, e))   # page-locked batches of this rank's block, built before the clock starts
 
+    on_device = backend == "nccl"
+
     def collect(h):
         t = proc.collect(h)
-        return t if backend == "nccl" else t.cpu()
+        return t if on_device else t.cpu()
 
     def sync_all():
         ctx.sync()
@@ -185,13 +196,19 @@ def sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend):
             dist.barrier()
             torch.cuda.synchronize()
 
-    # warm-up: one pass over (at most) two batches, including the exchange
-    run_sequence(min(F, 2 * B * world), rank, world, B, proc.submit, collect)
     host_out = torch.empty((F, record_bytes(ctx.n_features)), dtype=torch.uint8).pin_memory() if rank == 0 else None  # where the result lands
+
+    def sink(first, t):   # rank 0: one rank's part of a finished window -> page-locked host memory, behind the gather on torch's stream
+        host_out[first:first + t.shape[0]].copy_(t, non_blocking=True)
+
+    kw = dict(window=window, sink=sink if rank == 0 else None, collect_into=proc.collect_into if on_device else None,
+              force_collective=collective)
+    # warm-up: one pass over (at most) two batches per rank, including the exchange
+    run_sequence(min(F, 2 * B * world), rank, world, B, proc.submit, collect, **kw)
     sync_all()
     t0 = time.perf_counter()
-    rec, n_local = run_sequence(F, rank, world, B, proc.submit, collect)
-    rec_host = host_out.copy_(rec) if rank == 0 else None     # the sequence-level result, on the host of rank 0 (page-locked)
+    _, n_local = run_sequence(F, rank, world, B, proc.submit, collect, **kw)
+    rec_host = host_out
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -222,7 +239,7 @@ def sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend):
     return dt, n_local, checked
 
 
-def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend):
+def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend, collective):
     """BASELINE config 4: a whole sequence (KittiStereo.cc:28-37) sharded over the ranks, records gathered on rank 0."""
     import torch
     import torch.distributed as dist
@@ -235,9 +252,9 @@ def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend):
 
     F, B, U = args.sequence, args.pairs, max(1, min(args.sequence_unique, 128))
     b, e = frame_range(F, rank, world)
-    B = max(1, min(B, max(e - b, 1)))
+    B = sequence_batch((F + world - 1) // world, B)   # from the per-rank block size, the same on every rank
     ctx = Context(W, H, NFEAT, NLEVELS, SCALE, TH_HI, TH_LO, device_id=local_rank, max_images=2 * B)
-    dt, n_local, checked = sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend)
+    dt, n_local, checked = sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend, collective, window=max(1, args.sequence_window))
     line = None
     if rank == 0:
         n_batches = (max(e - b, 1) + B - 1) // B
@@ -249,13 +266,15 @@ def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend):
             "config": {
                 "workload": f"Full KITTI-00-shaped sequence ({F} stereo pairs, {U} distinct synthetic frames) frame-sharded across "
                             f"{world} GPU(s), gather of the per-frame records to rank 0",
-                "io": "page-locked host images -> device (upload overlapped with compute); records packed on the device, gathered "
-                      "over " + ("RCCL" if backend == "nccl" else backend) + ", copied to the host of rank 0 -- all inside the timed region",
+                "io": "page-locked host images -> device (upload overlapped with compute); records packed on the device, gathered per "
+                      f"window of {max(1, args.sequence_window)} batch(es) over " + (("RCCL" if collective else "no collective (single rank)") if backend == "nccl" else backend) +
+                      " while the next window is computed, drained to page-locked host memory of rank 0 -- all inside the timed region",
                 "gathered_payload": "per frame: n, n_matches, left keypoints [2000 x 28 B], left descriptors [2000 x 32 B], right_u and "
                                     "depth [2000 x f64]",
                 "record_bytes": record_bytes(ctx.n_features), "gathered_bytes": int(F) * record_bytes(ctx.n_features),
-                "pairs_per_batch": B, "frames_rank0": n_local, "records_checked_against_host_path": checked,
-                "records_checked_for_repeat_consistency": max(0, F - min(U, F)),
+                "pairs_per_batch": B, "batches_per_window": max(1, args.sequence_window), "frames_rank0": n_local,
+                "records_checked_against_host_path": checked, "records_checked_for_repeat_consistency": max(0, F - min(U, F)),
+                "collective_executed": bool(collective),
                 "parallelism": f"frame_range blocks over {world} GPU(s)",
             },
             "roofline": None, "cpu_baseline": None,
@@ -263,6 +282,206 @@ def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend):
         }
     ctx.close()
     return line
+
+
+# ---- the rest of north_star beside the stereo step: config 3, the BA half (config 5), the reference's own call shape -----------------
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _stats_ms(f, n, warm=5):
+    for _ in range(warm):
+        f()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        f()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    a = np.sort(np.array(ts))
+    return {"median_ms": float(np.median(a)), "p99_ms": float(a[min(len(a) - 1, int(0.99 * len(a)))]), "n": n}
+
+
+def _kernel_us(ctx, stage, f, n=30):
+    """mean device time of the kernels of one call (HIP events on the library's stream around the kernels only: inputs already
+    uploaded, results not yet downloaded -- the device-resident figure)"""
+    f()
+    ctx.profile_enable(1)
+    ctx.profile_read()
+    for _ in range(n):
+        f()
+    ms, k = ctx.profile_read()[stage]
+    ctx.profile_enable(0)
+    return (ms / n) * 1e3 if k else None
+
+
+def _oracle_fast():
+    from oracle import pyoracle   # the CPU checker, timed beside the device on ONE host core (kind: "port")
+    return pyoracle.Oracle(pyoracle.build(fast=True, out_dir=os.path.join("/tmp", f"orb_oracle_{os.getuid()}")))
+
+
+def _cpu_ms(f, budget_s=1.5, max_n=5):
+    f()
+    ts = []
+    t_end = time.perf_counter() + budget_s
+    while len(ts) < max_n and (not ts or time.perf_counter() < t_end):
+        t0 = time.perf_counter()
+        f()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
+
+
+def cfg3_leg(device_id):
+    """BASELINE config 3: 2000 x 2000 Hamming-256 brute force (ORBMatcher::getBestMatch over all train descriptors,
+    src/ORBMatcher.cc:941-990), results bit-exact against tests/golden/golden_v1.json before any number is reported."""
+    from orb_slam2_ros2_amd import synth
+    from orb_slam2_ros2_amd._lib import Context
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v1.json")))["cfg3"]
+    ctx = Context(W, H, NFEAT, NLEVELS, SCALE, TH_HI, TH_LO, device_id=device_id, max_images=2)
+    q, t = synth.descriptors_cfg3()
+    bi, bd, sd = ctx.match_bruteforce(q, t)
+    if (_sha(bi), _sha(bd), _sha(sd)) != (gold["best_idx_sha"], gold["best_dist_sha"], gold["second_sha"]):
+        raise SystemExit("bench.py: cfg3 leg: results differ from the golden vectors")
+    us = _kernel_us(ctx, "match", lambda: ctx.match_bruteforce(q, t))
+    host = _stats_ms(lambda: ctx.match_bruteforce(q, t), 50)
+    orc = _oracle_fast()
+    cand = np.arange(t.shape[0], dtype=np.uint32)
+    t0 = time.perf_counter()
+    for i in range(100):
+        orc.best_match(q[i], t, cand)
+    cpu_ms = (time.perf_counter() - t0) / 100 * q.shape[0] * 1e3
+    ctx.close()
+    alg = 2 * 2000 * 32 + 2000 * 12   # SURVEY 8(d)
+    pairs = q.shape[0] * t.shape[0]
+    return {"workload": "2000 x 2000 Hamming-256 brute force, best / second best per query (quirk Q6), bit-exact vs golden_v1",
+            "verified": True, "kernel_us": us, "Gpair_per_s": pairs / (us * 1e-6) / 1e9 if us else None,
+            "algorithmic_bytes": alg, "GBps": alg / (us * 1e-6) / 1e9 if us else None,
+            "bound": "neither HBM (152 KB) nor issue: one launch of 500 workgroups, latency of a single wave pass",
+            "host_call": dict(host, what="host descriptors in, host results out (PCIe both ways included)"),
+            "cpu_baseline": {"ms": cpu_ms, "cores": 1, "kind": "port"}}
+
+
+def ba_leg(device_id):
+    """The BA half of north_star on the BASELINE config-5 problem (60 keyframes, 3000 points, 15 597 edges): g2o edge
+    evaluation (src/Optimizer.cc:296-330 set-up, computeError / linearizeOplus / Huber), the normal-equation build, the local BA
+    (Optimizer.cc:336-361: optimize(5) + optimize(10)) and OptimizePoseOnly (:33-178) -- each checked against the golden vectors first."""
+    from orb_slam2_ros2_amd import ba_synth
+    from orb_slam2_ros2_amd._lib import Context
+    g1 = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v1.json")))["cfg5_ba"]
+    g2 = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v2.json")))["pose_only"]
+    g3 = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v3.json")))
+    ctx = Context(640, 480, n_features=1000, device_id=device_id, max_images=1)
+    orc = _oracle_fast()
+    out = {"workload": "BASELINE config 5: synthetic local map, 60 keyframes / 3000 points / 15 597 edges (80 % stereo), TUM intrinsics"}
+    # edge evaluation
+    p = ba_synth.make_problem()
+    E = int(p["edge_pose"].size)
+    r = ctx.ba_eval_edges(**p)
+    if E != g1["n_edges"] or abs(r["chi2"].sum() - g1["chi2_sum"]) > 1e-12 * g1["chi2_sum"] or \
+            abs(np.abs(r["j_pose"]).sum() - g1["jpose_abs_sum"]) > 1e-10 * g1["jpose_abs_sum"]:
+        raise SystemExit("bench.py: ba leg: edge evaluation differs from the golden vectors")
+    alg = 304 * E + p["poses"].shape[0] * 56 + p["points"].shape[0] * 24
+    us = _kernel_us(ctx, "ba", lambda: ctx.ba_eval_edges(**p))
+    out["edge_eval"] = {"edges": E, "kernel_us": us, "algorithmic_bytes": alg, "GBps": alg / (us * 1e-6) / 1e9 if us else None,
+                        "hbm_frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS if us else None,
+                        "host_call": dict(_stats_ms(lambda: ctx.ba_eval_edges(**p), 30), what="host arrays in, 4.8 MB of results out over PCIe"),
+                        "cpu_baseline": {"ms": _cpu_ms(lambda: orc.ba_eval_edges(**p)), "cores": 1, "kind": "port"}, "verified": True}
+    # normal equations
+    fx = np.zeros(p["poses"].shape[0], np.uint8)
+    fx[0] = 1
+    fx[30:] = 1
+    sysd = ctx.ba_build_system(**p, pose_fixed=fx)
+    for k, want in g3["cfg5_system"].items():
+        if abs(np.abs(np.asarray(sysd[k], np.float64)).sum() - want) > 1e-9 * want:
+            raise SystemExit(f"bench.py: ba leg: normal-equation block {k} differs from the golden vectors")
+    out["build_system"] = {"kernel_us": _kernel_us(ctx, "ba", lambda: ctx.ba_build_system(**p, pose_fixed=fx)),
+                           "host_call": _stats_ms(lambda: ctx.ba_build_system(**p, pose_fixed=fx), 30),
+                           "cpu_baseline": {"ms": _cpu_ms(lambda: orc.ba_build_system(**p, pose_fixed=fx)), "cores": 1, "kind": "port"},
+                           "verified": True}
+    # local BA
+    pr = ba_synth.make_problem(seed=42, n_kf=60, n_pt=3000, with_truth=True)
+    fixed = np.zeros(60, np.uint8)
+    fixed[:20] = 1
+    pr["poses"][:20] = pr["poses_true"][:20]
+    r = ctx.ba_local_optimize(pr, fixed)
+    gl = g3["cfg5_lba"]
+    if r["iters"].tolist() != gl["iters"] or not np.allclose(r["poses"].ravel(), gl["poses"], rtol=0, atol=1e-7) or \
+            abs(r["chi2"].sum() - gl["chi2_sum"]) > 1e-6 * gl["chi2_sum"] or abs(int(r["bad"].sum()) - gl["n_bad"]) > 1:
+        raise SystemExit("bench.py: ba leg: local BA differs from the golden vectors")
+    out["local_optimize"] = dict(_stats_ms(lambda: ctx.ba_local_optimize(pr, fixed), 20, warm=2),
+                                 what="orbfe_ba_local_optimize: optimize(5) + re-classification + optimize(10), 40 free keyframes, host arrays "
+                                      "in, host results out", iterations=gl["iters"],
+                                 cpu_baseline={"ms": _cpu_ms(lambda: orc.ba_local_optimize(pr, fixed), 2.0, 3), "cores": 1, "kind": "port"},
+                                 verified=True)
+    # the same with 300 free keyframes (multi-workgroup Cholesky); checked against the oracle in the GPU suite, timed here
+    big = ba_synth.make_problem(seed=13, n_kf=310, n_pt=4000, with_truth=True)
+    fb = np.zeros(310, np.uint8)
+    fb[:10] = 1
+    big["poses"][:10] = big["poses_true"][:10]
+    out["local_optimize_300_free_keyframes"] = dict(_stats_ms(lambda: ctx.ba_local_optimize(big, fb), 5, warm=1), edges=int(big["edge_pose"].size))
+    # pose only
+    pp = ba_synth.make_pose_problem()
+    a = (pp["Xw"], pp["meas"], pp["info"], pp["sigma2"], pp["pose"], pp["fx"], pp["fy"], pp["cx"], pp["cy"], pp["bf"])
+    n_good, pose, _ = ctx.pose_only_optimize(*a)
+    if abs(n_good - g2["n_good"]) > 1 or not np.allclose(pose, g2["pose"], rtol=0, atol=1e-6):
+        raise SystemExit("bench.py: ba leg: pose-only optimisation differs from the golden vectors")
+    out["pose_only"] = dict(_stats_ms(lambda: ctx.pose_only_optimize(*a), 50), edges=int(len(pp["info"])),
+                            what="orbfe_pose_only_optimize: 4 x optimize(10) on one SE3 vertex, host arrays in and out",
+                            cpu_baseline={"ms": _cpu_ms(lambda: orc.pose_only_optimize(*a)), "cores": 1, "kind": "port"}, verified=True)
+    ctx.close()
+    return out
+
+
+def latency_leg(device_id, n=500):
+    """One stereo pair from host images to host results, in the two call shapes a caller has: (a) one batched call for both eyes +
+    the match; (b) the reference's own -- Frame::Frame builds two ORBExtractor objects and runs extract() on two std::threads
+    (src/Frame.cc:91-105), then Frame::createStereo calls searchByStereo (include/ORB_SLAM2/Frame.h:316-319) -- through the C++
+    drop-in classes (tests/cpp/test_dropin.cpp, mode `latency`; no Python in that number)."""
+    import subprocess
+    import tempfile
+
+    from orb_slam2_ros2_amd import synth
+    from orb_slam2_ros2_amd._lib import Context
+    from orb_slam2_ros2_amd.digest import pair_digest
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v1.json")))["bench_pairs"]
+    L, R = synth.stereo_pair(0, W, H)
+    ctx = Context(W, H, NFEAT, NLEVELS, SCALE, TH_HI, TH_LO, device_id=device_id, max_images=2)
+    (lk, ld), (rk, rd) = ctx.extract_batch([L, R])
+    nm, ru, dp, _, _ = ctx.stereo_match(0, 1, FX, BF)
+    if pair_digest(lk, ld, rk, rd, ru, dp, nm) != gold["0"]:
+        raise SystemExit("bench.py: latency leg: the single-pair path differs from the golden digest")
+
+    def one():
+        ctx.extract_batch([L, R])
+        ctx.stereo_match(0, 1, FX, BF)
+    out = {"pair": "synthetic KITTI-shaped frame 0, 1241x376, 2000 features per image", "verified": True,
+           "extract_batch_plus_match": dict(_stats_ms(one, n, warm=30), what="orbfe_extract_batch([L, R]) + orbfe_stereo_match, host to host, from Python")}
+    ctx.close()
+    # (b) the C++ drop-in
+    tmp = tempfile.mkdtemp(prefix="orbfe_lat_")
+    exe = os.path.join(tmp, "test_dropin")
+    pkg = os.path.join(ROOT, "orb_slam2_ros2_amd")
+    try:
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "tests", "cpp", "stubs"), "-o", exe,
+                               os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"), "-L" + pkg, "-lorbfe_hip", "-pthread",
+                               "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
+        L.tofile(os.path.join(tmp, "L.raw"))
+        R.tofile(os.path.join(tmp, "R.raw"))
+        r = subprocess.run([exe, "latency", os.path.join(tmp, "L.raw"), os.path.join(tmp, "R.raw"), str(W), str(H), str(n)],
+                           capture_output=True, text=True, timeout=300)
+        f = r.stdout.split()
+        if r.returncode != 0 or not f or f[0] != "LATENCY_OK":
+            raise RuntimeError((r.stdout + r.stderr)[-400:])
+        if int(f[8]) != len(lk) or int(f[9]) != nm:
+            raise SystemExit("bench.py: latency leg: the drop-in frame differs from the verified single-pair result")
+        out["two_threads_extract_slot_plus_match"] = {
+            "median_ms": float(f[2]) / 1e3, "p99_ms": float(f[3]) / 1e3, "extract_median_ms": float(f[4]) / 1e3, "n": int(f[1]),
+            "what": "ORB_SLAM2_ROS2::ORBExtractor x 2 on two std::threads (orbfe_extract_slot each, thread start / join included as in "
+                    "Frame::Frame) + searchByStereo, C++ drop-in, host cv::Mat in, std::vector<cv::KeyPoint> / cv::Mat descriptors out"}
+        out["same_objects_one_thread"] = {"median_ms": float(f[5]) / 1e3, "p99_ms": float(f[6]) / 1e3, "extract_median_ms": float(f[7]) / 1e3}
+    except (subprocess.CalledProcessError, RuntimeError, OSError) as ex:
+        out["two_threads_extract_slot_plus_match"] = {"error": f"{type(ex).__name__}: {ex}"}
+    return out
 
 
 def main():
@@ -283,6 +502,10 @@ def main():
     ap.add_argument("--sequence-leg", type=int, default=1024,
                     help="frames PER RANK of the short sequence job reported beside the step loop (`sequence` object: blocks per rank, records "
                          "gathered on rank 0 -- over RCCL when N > 1); 0 skips it")
+    ap.add_argument("--sequence-window", type=int, default=1, help="batches per gather window of the sequence job (sharding.WindowGather)")
+    ap.add_argument("--legs", default="cfg3,ba,latency", help="comma-separated extra legs of the default line (north_star beyond the stereo step): "
+                    "cfg3 (2000x2000 Hamming), ba (config-5 edge evaluation / normal equations / local BA / pose-only), latency (one pair, host "
+                    "to host, in the reference's call shape); '' skips them")
     ap.add_argument("--streams", type=int, default=1,
                     help="half-batch streams the library may split a batch over (1 = none, the library default and the fastest "
                          "setting measured; the blur-under-quadtree overlap inside a batch is independent of this)")
@@ -314,21 +537,44 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     xdev = dev if backend == "nccl" else torch.device("cpu")  # where the tensors of the collectives live
+    # The process group is initialised with ONE rank too (backend nccl = RCCL): the sequence-level gather then really goes through
+    # RCCL on every box this runs on, and torch's bundled RCCL is known to live with liborbfe_hip.so in one process before an 8-GPU
+    # node ever sees the pair.  A failure to initialise with one rank is reported in the line (`rccl`), not fatal.
+    collective, rccl_note = world > 1, None
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    elif backend == "nccl" and os.environ.get("ORBFE_BENCH_NO_PG") != "1":
+        try:
+            import socket
+            if "MASTER_PORT" not in os.environ:
+                sk = socket.socket()
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+                sk.close()
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            probe = torch.ones(4, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            collective, rccl_note = True, "process group of 1 rank over RCCL: the gathers of this run executed as RCCL collectives"
+        except Exception as ex:   # noqa: BLE001 -- reported, the single-rank path needs no collective
+            rccl_note = f"init_process_group('nccl', world_size=1) failed: {type(ex).__name__}: {ex}"
+            collective = False
 
     os.environ["ORBFE_STREAMS"] = str(max(1, args.streams))
     from orb_slam2_ros2_amd import synth
     from orb_slam2_ros2_amd._lib import Context
 
     if args.sequence > 0:
-        line = run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend)
+        line = run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend, collective)
         if rank == 0:
+            line["rccl"] = rccl_note
             print(json.dumps(line))
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
 
@@ -367,7 +613,7 @@ def main():
         summary[:, 1] = d_counts[1::2]
         summary[:, 2] = d_nmatch
         summary[:, 3] = rank
-        if world == 1:
+        if not collective:
             return [summary]
         summary = summary.to(xdev)
         out = [torch.empty_like(summary) for _ in range(world)] if rank == 0 else None
@@ -463,13 +709,17 @@ def main():
     seq_leg = None
     if args.sequence_leg > 0:
         F_leg = args.sequence_leg * world
-        t_seq, _, n_chk = sequence_job(ctx, F_leg, B, max(1, min(args.sequence_unique, 128)), rank, world, dev, xdev, backend)
+        U_leg = max(1, min(args.sequence_unique, 128))
+        B_leg = sequence_batch(args.sequence_leg, B)
+        t_seq, _, n_chk = sequence_job(ctx, F_leg, B_leg, U_leg, rank, world, dev, xdev, backend, collective, window=max(1, args.sequence_window))
         seq_leg = {"frames": F_leg, "pairs_per_s": F_leg / t_seq, "seconds": t_seq, "gathered_bytes": F_leg * ctx.record_bytes(),
-                   "records_checked_against_host_path": n_chk, "records_checked_for_repeat_consistency": max(0, F_leg - 64),
+                   "pairs_per_batch": B_leg, "batches_per_window": max(1, args.sequence_window), "collective_executed": bool(collective),
+                   "records_checked_against_host_path": n_chk, "records_checked_for_repeat_consistency": max(0, F_leg - min(U_leg, F_leg)),
                    "what": "BASELINE config 4 in small: contiguous blocks of frames per rank, page-locked host images -> extraction + stereo match "
-                           "-> per-frame records packed on the device -> ONE gather to rank 0 (" + ("RCCL" if backend == "nccl" and world > 1 else
-                                                                                                     ("none: single rank" if world == 1 else backend)) +
-                           ") -> page-locked host memory, all inside the timed region; `python bench.py --sequence 4541` runs the full one"}
+                           "-> per-frame records packed on the device -> a gather per window to rank 0 (" +
+                           (("RCCL" if collective else "none: single rank, no process group") if backend == "nccl" else backend) +
+                           ") under the next window's compute -> page-locked host memory, all inside the timed region; "
+                           "`python bench.py --sequence 4541` runs the full one"}
 
     live_ms, live_n = live[dom]
     stages_inline = dict(stages)
@@ -618,11 +868,22 @@ def main():
         line["cpu_baseline"]["all_cores"] = {"value": n_all / t_all, "unit": "stereo pairs/s", "cores": n_thr,
                                              "sample": f"{n_all} pairs over {n_thr} threads, one pair per thread"}
         line["config"]["gpu_over_cpu_all_cores"] = fps / (n_all / t_all)
+    line["rccl"] = rccl_note
+    ctx.close()
+    if rank == 0 and world == 1:
+        legs = [x for x in args.legs.split(",") if x]
+        t_legs = time.perf_counter()
+        if "cfg3" in legs:
+            line["cfg3"] = cfg3_leg(local_rank)
+        if "ba" in legs:
+            line["ba"] = ba_leg(local_rank)
+        if "latency" in legs:
+            line["latency"] = latency_leg(local_rank)
+        line["legs_seconds"] = time.perf_counter() - t_legs
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
-    ctx.close()
 
 
 if __name__ == "__main__":

@@ -24,11 +24,15 @@
  *
  * Conventions: plain C, caller owns every host buffer, the context owns every device buffer.  No call
  * throws or aborts; every call returns an orbfe_status and orbfe_last_error() gives the text of the calling
- * THREAD's last failed call.  Threading: calls on distinct contexts are thread-safe.  Calls on one context must
- * be serialised by the caller, with ONE exception made for the reference's call pattern -- Frame::Frame runs
- * the left and the right ORBExtractor::extract on two std::threads (src/Frame.cc:100-105): orbfe_extract_slot
- * calls on DIFFERENT slots of one context may run concurrently (each slot has its own stream, pinned staging
- * and launch graph); they must not overlap with any other kind of call on that context.
+ * THREAD's last failed call.  Threading: calls on distinct contexts are thread-safe.  Calls on ONE context are
+ * serialised by the library (a per-context lock every entry point takes -- the reference's matchers are called
+ * from the Tracking, LocalMapping and LoopClosing threads), with one exception made for the reference's call
+ * pattern -- Frame::Frame runs the left and the right ORBExtractor::extract on two std::threads
+ * (src/Frame.cc:100-105): orbfe_extract_slot calls on DIFFERENT slots of one context run concurrently with each
+ * other and with the other entry points (each slot has its own stream, pinned staging and launch graph); the
+ * caller only has to keep a slot call away from calls that read or rewrite THAT slot (a stereo match on it, a
+ * batch call over it).  A context used from several threads serves them one at a time: give every thread role
+ * its own context where they should not wait for each other (host/orbfe_shim.hpp: matcherContext, solverContext).
  *
  * There is NO CPU fallback behind this interface: if no HIP device is usable, orbfe_create fails.
  */
@@ -163,6 +167,9 @@ typedef struct orbfe_batch_results {
   int32_t* n_matches;
 } orbfe_batch_results;
 void* orbfe_host_alloc(size_t bytes); /* page-locked host memory (NULL on failure); release with orbfe_host_free */
+/* ... placed on the NUMA node of HIP device `device_id` (< 0: the calling thread's current device, = orbfe_host_alloc): what a
+ * multi-rank job calls with its own device, so that ranks which never called hipSetDevice do not all pin to GPU 0's node          */
+void* orbfe_host_alloc_on(int32_t device_id, size_t bytes);
 void orbfe_host_free(void* p);
 orbfe_status orbfe_stream_submit(orbfe_ctx* ctx, const uint8_t* left, const uint8_t* right, size_t stride_bytes,
                                  size_t image_pitch_bytes, int32_t n_pairs, float fx, float bf, const orbfe_batch_results* out,

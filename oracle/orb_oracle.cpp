@@ -945,8 +945,15 @@ int orc_stereo_frame(const uint8_t* left, const uint8_t* right, int w, int h, in
 // frame, :561-612): candidates = the features of the 64x48-px grid cells overlapping the box [x-r, x+r] x [y-r, y+r]
 // (r = radius * getScaledFactor2(octave)), rows outer, columns inner, features of a cell in index order, filtered by octave
 // range and by the caller's exclusion mask; then the order-dependent best / second-best scan.
-// One deviation: the reference indexes mGrids[row][col] with col == cols when maxX == width is a multiple of 64 (undefined
-// behaviour); cell indices are clamped to the grid here.
+// One deviation: the reference indexes mGrids[row][col] unchecked -- col == cols when maxX == width is a multiple of 64, and a
+// negative / too large / non-finite undistorted keypoint coordinate in initGrid (Frame.cc:64-65) -- which is undefined behaviour
+// there; cell indices are clamped to the grid at both ends here (non-finite -> cell 0), like csrc/k_guided.hip::grid_cell.
+static int grid_cell(float v, int size, int n) {
+  const float q = v / size;
+  if (!(q > 0.0f)) return 0;
+  if (q >= (float)(n - 1)) return n - 1;
+  return cv_floor(q);
+}
 extern "C" void orc_search_in_area(const orc_keypoint* kps, const uint8_t* desc, int n, int width, int height, int nq, const float* qxy,
                                    const float* radius, const int8_t* min_level, const int8_t* max_level, const uint8_t* q_desc,
                                    const uint8_t* exclude, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
@@ -955,15 +962,15 @@ extern "C" void orc_search_in_area(const orc_keypoint* kps, const uint8_t* desc,
   const int rows = cv_ceil((float)height / GH), cols = cv_ceil((float)width / GW);
   std::vector<std::vector<int64_t>> grid((size_t)rows * cols);
   for (int i = 0; i < n; ++i) {
-    const int r = std::min(rows - 1, cv_floor(kps[i].y / GH)), c = std::min(cols - 1, cv_floor(kps[i].x / GW));
+    const int r = grid_cell(kps[i].y, GH, rows), c = grid_cell(kps[i].x, GW, cols);
     grid[(size_t)r * cols + c].push_back(i);
   }
   for (int q = 0; q < nq; ++q) {
     const float x = qxy[2 * q], y = qxy[2 * q + 1], rad = radius[q];
     const int min_x = std::max(0, cv_round(x - rad)), max_x = std::min(width, cv_round(x + rad));
     const int min_y = std::max(0, cv_round(y - rad)), max_y = std::min(height, cv_round(y + rad));
-    const int c0 = std::min(cols - 1, cv_floor((float)min_x / GW)), c1 = std::min(cols - 1, cv_floor((float)max_x / GW));
-    const int r0 = std::min(rows - 1, cv_floor((float)min_y / GH)), r1 = std::min(rows - 1, cv_floor((float)max_y / GH));
+    const int c0 = std::max(0, std::min(cols - 1, cv_floor((float)min_x / GW))), c1 = std::min(cols - 1, cv_floor((float)max_x / GW));
+    const int r0 = std::max(0, std::min(rows - 1, cv_floor((float)min_y / GH))), r1 = std::min(rows - 1, cv_floor((float)max_y / GH));
     std::vector<int64_t> cand;
     for (int r = r0; r <= r1; ++r)
       for (int c = c0; c <= c1; ++c)

@@ -100,7 +100,7 @@ EXPORTS = [
     "orbfe_abi_version", "orbfe_create", "orbfe_destroy", "orbfe_last_error", "orbfe_get_level_info", "orbfe_get_scale_factors",
     "orbfe_get_capacity",
     "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_slot", "orbfe_fetch_batch", "orbfe_fetch_stereo_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
-    "orbfe_host_alloc", "orbfe_host_free", "orbfe_stream_submit", "orbfe_stream_wait", "orbfe_stream_device_results", "orbfe_record_bytes", "orbfe_stream_pack_records",
+    "orbfe_host_alloc", "orbfe_host_alloc_on", "orbfe_host_free", "orbfe_stream_submit", "orbfe_stream_wait", "orbfe_stream_device_results", "orbfe_record_bytes", "orbfe_stream_pack_records",
     "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_search_in_area_features", "orbfe_extract_color", "orbfe_frame_rgbd", "orbfe_project_map_points",
     "orbfe_map_pb_summary", "orbfe_map_pb_reencode", "orbfe_map_pb_to_txt", "orbfe_map_txt_to_pb", "orbfe_map_local_graph", "orbfe_map_local_ba",
     "orbfe_profile_enable", "orbfe_profile_read", "orbfe_stage_name", "orbfe_debug_candidates",
@@ -147,6 +147,8 @@ def load() -> C.CDLL:
     L.orbfe_sync.argtypes = [vp]
     L.orbfe_host_alloc.argtypes = [C.c_size_t]
     L.orbfe_host_alloc.restype = vp
+    L.orbfe_host_alloc_on.argtypes = [i32, C.c_size_t]
+    L.orbfe_host_alloc_on.restype = vp
     L.orbfe_host_free.argtypes = [vp]
     L.orbfe_host_free.restype = None
     L.orbfe_stream_submit.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, i32, f32, f32, C.POINTER(BatchResults), C.POINTER(C.c_int64)]
@@ -191,11 +193,12 @@ def ptr(a):
 class PinnedArray:
     """numpy view of page-locked host memory from orbfe_host_alloc (freed with the object)"""
 
-    def __init__(self, shape, dtype):
+    def __init__(self, shape, dtype, device_id=-1):
+        """device_id: the HIP device whose NUMA node the pages go to (-1: the calling thread's current device)"""
         self.lib = load()
         self.dtype = np.dtype(dtype)
         n = int(np.prod(shape)) * self.dtype.itemsize
-        self.p = self.lib.orbfe_host_alloc(max(n, 1))
+        self.p = self.lib.orbfe_host_alloc_on(int(device_id), max(n, 1))
         if not self.p:
             raise MemoryError(f"orbfe_host_alloc({n}) failed")
         self.array = np.frombuffer((C.c_uint8 * max(n, 1)).from_address(self.p), dtype=self.dtype, count=int(np.prod(shape))).reshape(shape)

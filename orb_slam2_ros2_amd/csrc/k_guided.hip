@@ -21,6 +21,16 @@ __device__ __forceinline__ int cvfloor_f(float v) {
   return i - (i > v);
 }
 
+// cell of a coordinate: cvFloor(v / size) as Frame.cc:64-65, clamped to the grid at BOTH ends.  The reference indexes its vector of
+// cells unchecked (a negative or too large undistorted coordinate is undefined behaviour there); here such a feature lands in the
+// border cell, and a non-finite coordinate in cell 0, so that no index leaves the LDS counters or the scratch lists.
+__device__ __forceinline__ int grid_cell(float v, int size, int n) {
+  const float q = v / (float)size;
+  if (!(q > 0.0f)) return 0;          // negative, -0, NaN
+  if (q >= (float)(n - 1)) return n - 1;  // beyond the last cell, +inf
+  return cvfloor_f(q);
+}
+
 // ---------------------------------------------------------------------------------------------
 // grid build: one workgroup per call.  cell_off[ncells+1], cell_feat[n] (features of a cell in ascending index).
 // ---------------------------------------------------------------------------------------------
@@ -37,7 +47,7 @@ __global__ __launch_bounds__(256) void k_grid_build(const orbfe_keypoint* __rest
   }
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += 256) {
-    const int r = min(rows - 1, cvfloor_f(kps[i].y / (float)GRID_H)), c = min(cols - 1, cvfloor_f(kps[i].x / (float)GRID_W));
+    const int r = grid_cell(kps[i].y, GRID_H, rows), c = grid_cell(kps[i].x, GRID_W, cols);
     atomicAdd(&l_off[r * cols + c + 1], 1);
   }
   __syncthreads();
@@ -53,7 +63,7 @@ __global__ __launch_bounds__(256) void k_grid_build(const orbfe_keypoint* __rest
   __syncthreads();
   for (int c = threadIdx.x; c <= ncells; c += 256) cell_off[c] = l_off[c];
   for (int i = threadIdx.x; i < n; i += 256) {
-    const int r = min(rows - 1, cvfloor_f(kps[i].y / (float)GRID_H)), c = min(cols - 1, cvfloor_f(kps[i].x / (float)GRID_W));
+    const int r = grid_cell(kps[i].y, GRID_H, rows), c = grid_cell(kps[i].x, GRID_W, cols);
     const int cell = r * cols + c;
     cell_feat[l_off[cell] + atomicAdd(&l_cur[cell], 1)] = i;
   }
@@ -118,8 +128,8 @@ __global__ __launch_bounds__(256) void k_search_area(const uint4* __restrict__ k
   const int lo = min_level[q], hi = max_level[q];
   const int min_x = max(0, __float2int_rn(x - rad)), max_x = min(width, __float2int_rn(x + rad));
   const int min_y = max(0, __float2int_rn(y - rad)), max_y = min(height, __float2int_rn(y + rad));
-  const int c0 = min(cols - 1, cvfloor_f((float)min_x / (float)GRID_W)), c1 = min(cols - 1, cvfloor_f((float)max_x / (float)GRID_W));
-  const int r0 = min(rows - 1, cvfloor_f((float)min_y / (float)GRID_H)), r1 = min(rows - 1, cvfloor_f((float)max_y / (float)GRID_H));
+  const int c0 = max(0, min(cols - 1, cvfloor_f((float)min_x / (float)GRID_W))), c1 = min(cols - 1, cvfloor_f((float)max_x / (float)GRID_W));
+  const int r0 = max(0, min(rows - 1, cvfloor_f((float)min_y / (float)GRID_H))), r1 = min(rows - 1, cvfloor_f((float)max_y / (float)GRID_H));
   const uint4 a0 = *(const uint4*)(q_desc + (size_t)q * 32);
   const uint4 a1 = *(const uint4*)(q_desc + (size_t)q * 32 + 16);
   Best2g b = {ORB_INT_MAX, ORB_INT_MAX, 0};

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <limits>
@@ -109,6 +110,10 @@ static const int kMeanThreshold = 75;  // ORBMatcher::mnMeanThreshold (ORBMatche
 static thread_local std::string g_last_error;
 
 struct orbfe_ctx {
+  // Every entry point except orbfe_extract_slot takes this lock: the context's stream, scratch buffer, staging and timers serve one
+  // call at a time, whichever threads the calls come from (the reference's matchers run on three threads: Tracking, LocalMapping,
+  // LoopClosing).  Slot calls touch only their own lane and may overlap with anything but a call that rewrites their slot.
+  std::recursive_mutex api_mu;
   orbfe_config cfg;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -142,7 +147,7 @@ struct orbfe_ctx {
     bool use_graphs = true;
   };
   // Host-image stream (orbfe_stream_submit / _wait): batch k+1 is uploaded and the packed results of batch k-1 are downloaded while
-  // batch k is computed.  Two input and two result buffers on the device, one copy stream per direction.
+  // batch k is computed.  kDepth (three) input and result buffers on the device, one copy stream per direction.
   struct HostStream {
     // Ring depth 3: with two buffers the caller's "collect k-1, then submit k+1" makes the upload of k+1 wait for the DOWNLOAD of
     // k-1, and a step costs (compute + download + upload) / 2 instead of max(compute, upload): measured 11.6 ms against 8.2 ms of
@@ -157,6 +162,7 @@ struct orbfe_ctx {
     hipEvent_t ev_h2d[kDepth] = {nullptr, nullptr, nullptr}, ev_in_free[kDepth] = {nullptr, nullptr, nullptr},
                ev_out_ready[kDepth] = {nullptr, nullptr, nullptr}, ev_done[kDepth] = {nullptr, nullptr, nullptr};
     int64_t next_ticket = 0;
+    int32_t n_pairs_of[kDepth] = {0, 0, 0};  // pairs of the ticket that last used buffer set b: the packed layout depends on it
   } hs;
   Lane main;
   std::vector<std::unique_ptr<Lane>> slot_lane;  // [max_images], entries created lazily under slot_lane_mu
@@ -167,7 +173,8 @@ struct orbfe_ctx {
   uint8_t* d_pyr_alt = nullptr;
   hipStream_t stereo_stream = nullptr;
   hipEvent_t ev_brief_done = nullptr, ev_stereo_done = nullptr;
-  bool stereo_pending = false, pipeline_stereo = true;
+  std::atomic<bool> stereo_pending{false};  // (read by slot calls on other threads)
+  bool pipeline_stereo = true;
   hipStream_t blur_stream = nullptr;
   hipEvent_t ev_blur_go = nullptr, ev_blur_done = nullptr, ev_fast_go = nullptr, ev_fast_done = nullptr;
   int fast_side_from = 0;  // k_fast launches of levels >= this run on the blur stream beside the large levels (ORBFE_FAST_SIDE_FROM; 0: off -- the default
@@ -242,6 +249,13 @@ struct orbfe_ctx {
   int64_t stage_launches[ORBFE_STAGE_COUNT];
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
   std::vector<hipEvent_t> ev_pool;
+};
+
+struct ApiLock {
+  std::unique_lock<std::recursive_mutex> lk;
+  explicit ApiLock(orbfe_ctx* c) {
+    if (c) lk = std::unique_lock<std::recursive_mutex>(c->api_mu);
+  }
 };
 
 static orbfe_status fail(orbfe_ctx* c, orbfe_status st, const char* fmt, ...) {
@@ -1181,6 +1195,7 @@ orbfe_status orbfe_get_scale_factors(const orbfe_ctx* c, float* out, int32_t n) 
 int32_t orbfe_get_capacity(const orbfe_ctx* c) { return c ? c->kp_cap : 0; }
 
 orbfe_status orbfe_sync(orbfe_ctx* c) {
+  ApiLock api_lk(c);
   if (!c) return ORBFE_EBADARG;
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
@@ -1190,6 +1205,7 @@ orbfe_status orbfe_sync(orbfe_ctx* c) {
 }
 
 orbfe_status orbfe_fetch_features(orbfe_ctx* c, int32_t slot, orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out) {
+  ApiLock api_lk(c);
   if (!c || slot < 0 || slot >= c->cfg.max_images) return fail(c, ORBFE_EBADARG, "fetch_features: slot %d", slot);
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
@@ -1209,6 +1225,7 @@ orbfe_status orbfe_fetch_features(orbfe_ctx* c, int32_t slot, orbfe_keypoint* kp
 
 orbfe_status orbfe_fetch_stereo(orbfe_ctx* c, int32_t pair, double* right_u, double* depth, int32_t* n_matches, int32_t* best_right,
                                 int32_t* best_dist) {
+  ApiLock api_lk(c);
   if (!c || pair < 0 || pair >= (c->cfg.max_images + 1) / 2) return fail(c, ORBFE_EBADARG, "fetch_stereo: pair %d", pair);
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
@@ -1235,6 +1252,7 @@ orbfe_status orbfe_fetch_stereo(orbfe_ctx* c, int32_t pair, double* right_u, dou
 
 // Bulk fetches: the packed result arrays of a range of slots / pairs in one copy each (full [n_features] strides), one synchronisation.
 orbfe_status orbfe_fetch_batch(orbfe_ctx* c, int32_t slot0, int32_t n_slots, orbfe_keypoint* kps, uint8_t* desc, int32_t* counts) {
+  ApiLock api_lk(c);
   if (!c || slot0 < 0 || n_slots < 0 || slot0 + n_slots > c->cfg.max_images) return fail(c, ORBFE_EBADARG, "fetch_batch: slots [%d, %d)", slot0, slot0 + n_slots);
   if (n_slots == 0) return ORBFE_OK;
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1249,6 +1267,7 @@ orbfe_status orbfe_fetch_batch(orbfe_ctx* c, int32_t slot0, int32_t n_slots, orb
 }
 
 orbfe_status orbfe_fetch_stereo_batch(orbfe_ctx* c, int32_t pair0, int32_t n_pairs, double* right_u, double* depth, int32_t* n_matches) {
+  ApiLock api_lk(c);
   if (!c || pair0 < 0 || n_pairs < 0 || pair0 + n_pairs > (c->cfg.max_images + 1) / 2)
     return fail(c, ORBFE_EBADARG, "fetch_stereo_batch: pairs [%d, %d)", pair0, pair0 + n_pairs);
   if (n_pairs == 0) return ORBFE_OK;
@@ -1265,6 +1284,7 @@ orbfe_status orbfe_fetch_stereo_batch(orbfe_ctx* c, int32_t pair0, int32_t n_pai
 
 orbfe_status orbfe_device_results(orbfe_ctx* c, const void** d_kps, const void** d_desc, const void** d_counts, const void** d_right_u,
                                   const void** d_depth, const void** d_nmatch) {
+  ApiLock api_lk(c);
   if (!c) return ORBFE_EBADARG;
   if (d_kps) *d_kps = c->d_kps;
   if (d_desc) *d_desc = c->d_desc;
@@ -1370,6 +1390,7 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
 
 orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* const* imgs, size_t stride, orbfe_keypoint* kps,
                                  uint8_t* desc, int32_t* n_out) {
+  ApiLock api_lk(c);
   if (!c || !imgs || n_img < 0) return fail(c, ORBFE_EBADARG, "extract_batch: NULL argument");
   if (n_img > c->cfg.max_images) return fail(c, ORBFE_ECAPACITY, "extract_batch: %d images > max_images %d", n_img, c->cfg.max_images);
   if (stride < (size_t)c->cfg.width) return fail(c, ORBFE_EBADARG, "extract_batch: stride %zu < width %d", stride, c->cfg.width);
@@ -1419,6 +1440,7 @@ orbfe_status orbfe_extract(orbfe_ctx* c, const uint8_t* img, size_t stride, orbf
 
 orbfe_status orbfe_extract_color(orbfe_ctx* c, const uint8_t* img, size_t stride, int32_t color_order, orbfe_keypoint* kps, uint8_t* desc,
                                  int32_t* n_out) {
+  ApiLock api_lk(c);
   if (!c || !img) return fail(c, ORBFE_EBADARG, "extract_color: NULL argument");
   if (color_order != 1 && color_order != 2) return fail(c, ORBFE_EBADARG, "extract_color: color_order %d (1 = RGB, 2 = BGR)", color_order);
   if (stride < (size_t)c->cfg.width * 3) return fail(c, ORBFE_EBADARG, "extract_color: stride %zu < 3 * width", stride);
@@ -1442,6 +1464,7 @@ orbfe_status orbfe_extract_color(orbfe_ctx* c, const uint8_t* img, size_t stride
 
 orbfe_status orbfe_frame_rgbd(orbfe_ctx* c, int32_t slot, const orbfe_camera* cam, const void* depth, int32_t depth_type,
                               size_t depth_stride, float depth_scale, orbfe_keypoint* kps_out, double* depth_out, double* right_u_out) {
+  ApiLock api_lk(c);
   if (!c || !cam || slot < 0 || slot >= c->cfg.max_images) return fail(c, ORBFE_EBADARG, "frame_rgbd: bad slot / NULL camera");
   const size_t px = depth_type == 0 ? 2 : 4;
   if (depth && (depth_type < 0 || depth_type > 1 || depth_stride < (size_t)c->cfg.width * px || !(depth_scale > 0)))
@@ -1471,6 +1494,7 @@ orbfe_status orbfe_frame_rgbd(orbfe_ctx* c, int32_t slot, const orbfe_camera* ca
 }
 
 orbfe_status orbfe_get_pyramid(orbfe_ctx* c, int32_t slot, int32_t level, int32_t blurred, uint8_t* dst) {
+  ApiLock api_lk(c);
   if (!c || !dst || slot < 0 || slot >= c->cfg.max_images || level < 0 || level >= c->cfg.n_levels)
     return fail(c, ORBFE_EBADARG, "get_pyramid: slot %d level %d", slot, level);
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1484,6 +1508,7 @@ orbfe_status orbfe_get_pyramid(orbfe_ctx* c, int32_t slot, int32_t level, int32_
 
 orbfe_status orbfe_stereo_match(orbfe_ctx* c, int32_t slot_left, int32_t slot_right, float fx, float bf, double* right_u,
                                 double* depth, int32_t* n_matches, int32_t* best_right, int32_t* best_dist) {
+  ApiLock api_lk(c);
   if (!c || slot_left < 0 || slot_right < 0 || slot_left >= c->cfg.max_images || slot_right >= c->cfg.max_images)
     return fail(c, ORBFE_EBADARG, "stereo_match: slots %d/%d", slot_left, slot_right);
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1605,6 +1630,7 @@ static orbfe_status batch_device_core(orbfe_ctx* c, const uint8_t* d_left, const
 
 orbfe_status orbfe_stereo_batch_device(orbfe_ctx* c, const uint8_t* d_left, const uint8_t* d_right, size_t stride, size_t image_pitch,
                                        int32_t n_pairs, float fx, float bf) {
+  ApiLock api_lk(c);
   if (!c || !d_left || !d_right || n_pairs < 0) return fail(c, ORBFE_EBADARG, "stereo_batch_device: NULL argument");
   if (2 * n_pairs > c->cfg.max_images) return fail(c, ORBFE_ECAPACITY, "stereo_batch_device: %d pairs need %d slots > %d", n_pairs, 2 * n_pairs, c->cfg.max_images);
   if (stride < (size_t)c->cfg.width || image_pitch < stride * (size_t)c->cfg.height)
@@ -1616,10 +1642,9 @@ orbfe_status orbfe_stereo_batch_device(orbfe_ctx* c, const uint8_t* d_left, cons
 
 // ---- host-image stream ---------------------------------------------------------------------------------------------------------
 // CPUs of the NUMA node the current HIP device hangs off (sysfs local_cpulist of its PCI function); empty set if unknown.
-static bool device_local_cpus(cpu_set_t* set) {
-  int dev = 0;
+static bool device_local_cpus(int dev, cpu_set_t* set) {
   char bus[64] = {0};
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, sizeof bus, dev) != hipSuccess) {
+  if ((dev < 0 && hipGetDevice(&dev) != hipSuccess) || hipDeviceGetPCIBusId(bus, sizeof bus, dev) != hipSuccess) {
     (void)hipGetLastError();
     return false;
   }
@@ -1634,7 +1659,8 @@ static bool device_local_cpus(cpu_set_t* set) {
   if (!got) return false;
   CPU_ZERO(set);
   int n = 0;
-  for (char* tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+  char* save = nullptr;  // (strtok_r: allocations may come from several threads at once)
+  for (char* tok = strtok_r(line, ",\n", &save); tok; tok = strtok_r(nullptr, ",\n", &save)) {
     int a = 0, b = 0;
     const int k = sscanf(tok, "%d-%d", &a, &b);
     if (k == 1) b = a;
@@ -1650,11 +1676,15 @@ static bool device_local_cpus(cpu_set_t* set) {
 // Page-locked host memory ON THE NUMA NODE OF THE DEVICE: the pages are placed where the allocating thread runs, and a buffer on the
 // other socket is read by the DMA engines across the inter-socket link (measured on a two-socket MI355X host: 41 GB/s instead of
 // 57 GB/s host to device).  The calling thread is moved to the device's local CPUs for the allocation and the first touch, then back.
-void* orbfe_host_alloc(size_t bytes) {
+void* orbfe_host_alloc(size_t bytes) { return orbfe_host_alloc_on(-1, bytes); }
+
+// device_id < 0: the calling thread's current HIP device; a multi-rank job passes its own device so that ranks that never called
+// hipSetDevice do not all pin to GPU 0's node.
+void* orbfe_host_alloc_on(int32_t device_id, size_t bytes) {
   cpu_set_t old_set, local;
   const bool have_old = sched_getaffinity(0, sizeof old_set, &old_set) == 0;
   bool moved = false;
-  if (have_old && !getenv("ORBFE_NO_NUMA_PIN") && device_local_cpus(&local)) {
+  if (have_old && !getenv("ORBFE_NO_NUMA_PIN") && device_local_cpus(device_id, &local)) {
     cpu_set_t both;
     CPU_AND(&both, &local, &old_set);  // stay inside what this process is allowed to use
     if (CPU_COUNT(&both) > 0) moved = sched_setaffinity(0, sizeof both, &both) == 0;
@@ -1666,7 +1696,8 @@ void* orbfe_host_alloc(size_t bytes) {
   } else if (moved) {
     for (size_t o = 0; o < bytes; o += 4096) ((volatile uint8_t*)p)[o] = 0;  // first touch, should the driver place lazily
   }
-  if (moved) (void)sched_setaffinity(0, sizeof old_set, &old_set);
+  if (moved && sched_setaffinity(0, sizeof old_set, &old_set) != 0 && sched_setaffinity(0, sizeof old_set, &old_set) != 0)
+    g_last_error = "orbfe_host_alloc: the calling thread's CPU affinity could not be restored (it stays on the device's NUMA node)";
   return p;
 }
 void orbfe_host_free(void* p) {
@@ -1675,6 +1706,7 @@ void orbfe_host_free(void* p) {
 
 orbfe_status orbfe_stream_submit(orbfe_ctx* c, const uint8_t* left, const uint8_t* right, size_t stride, size_t image_pitch, int32_t n_pairs,
                                  float fx, float bf, const orbfe_batch_results* out, int64_t* ticket) {
+  ApiLock api_lk(c);
   if (!c || !left || !right || !out || !ticket || n_pairs <= 0) return fail(c, ORBFE_EBADARG, "stream_submit: NULL argument / no pairs");
   if (2 * n_pairs > c->cfg.max_images) return fail(c, ORBFE_ECAPACITY, "stream_submit: %d pairs need %d slots > %d", n_pairs, 2 * n_pairs, c->cfg.max_images);
   if (stride < (size_t)c->cfg.width || image_pitch < stride * (size_t)c->cfg.height)
@@ -1751,29 +1783,37 @@ orbfe_status orbfe_stream_submit(orbfe_ctx* c, const uint8_t* left, const uint8_
   if (out->depth) HIP_TRY(c, hipMemcpyAsync(out->depth, src + l.o_dp, n * NF * 8, hipMemcpyDeviceToHost, ds));
   if (out->n_matches) HIP_TRY(c, hipMemcpyAsync(out->n_matches, src + l.o_nm, n * 4, hipMemcpyDeviceToHost, ds));
   HIP_TRY(c, hipEventRecord(hs.ev_done[b], ds));
+  hs.n_pairs_of[b] = n_pairs;
   *ticket = hs.next_ticket++;
   return ORBFE_OK;
 }
 
 orbfe_status orbfe_stream_wait(orbfe_ctx* c, int64_t ticket) {
+  ApiLock api_lk(c);
   if (!c) return ORBFE_EBADARG;
   orbfe_ctx::HostStream& hs = c->hs;
   if (!hs.init || ticket < 0 || ticket >= hs.next_ticket) return fail(c, ORBFE_EBADARG, "stream_wait: ticket %lld was never issued", (long long)ticket);
   const int D = orbfe_ctx::HostStream::kDepth;
   if (ticket + D < hs.next_ticket) return ORBFE_OK;  // ticket + D has been submitted since, and that submit waited for this one
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipEventSynchronize(hs.ev_done[ticket % D]));
+  hipEvent_t done = hs.ev_done[ticket % D];
+  api_lk.lk.unlock();  // the wait itself needs nothing of the context: another thread may submit meanwhile
+  HIP_TRY(c, hipEventSynchronize(done));
   return ORBFE_OK;
 }
 
 orbfe_status orbfe_stream_device_results(orbfe_ctx* c, int64_t ticket, int32_t n_pairs, const void** d_kps, const void** d_desc,
                                          const void** d_counts, const void** d_right_u, const void** d_depth, const void** d_nmatch) {
+  ApiLock api_lk(c);
   if (!c) return ORBFE_EBADARG;
   orbfe_ctx::HostStream& hs = c->hs;
   if (!hs.init || ticket < 0 || ticket >= hs.next_ticket || ticket + orbfe_ctx::HostStream::kDepth < hs.next_ticket || n_pairs <= 0 ||
       2 * n_pairs > c->cfg.max_images)
     return fail(c, ORBFE_EBADARG, "stream_device_results: ticket %lld is not live (next %lld) or bad pair count %d", (long long)ticket,
                 (long long)hs.next_ticket, n_pairs);
+  if (n_pairs != hs.n_pairs_of[ticket % orbfe_ctx::HostStream::kDepth])
+    return fail(c, ORBFE_EBADARG, "stream_device_results: ticket %lld was submitted with %d pairs, not %d (the packed layout depends on it)",
+                (long long)ticket, hs.n_pairs_of[ticket % orbfe_ctx::HostStream::kDepth], n_pairs);
   const PackLayout l = pack_layout(c, n_pairs);
   const uint8_t* b = hs.d_out[ticket % orbfe_ctx::HostStream::kDepth];
   if (d_kps) *d_kps = b + l.o_kps;
@@ -1789,12 +1829,16 @@ orbfe_status orbfe_stream_device_results(orbfe_ctx* c, int64_t ticket, int32_t n
 size_t orbfe_record_bytes(const orbfe_ctx* c) { return c ? 16 + (size_t)std::max(c->cfg.n_features, 1) * (28 + 32 + 8 + 8) : 0; }
 
 orbfe_status orbfe_stream_pack_records(orbfe_ctx* c, int64_t ticket, int32_t n_pairs, void* d_records) {
+  ApiLock api_lk(c);
   if (!c || !d_records) return fail(c, ORBFE_EBADARG, "stream_pack_records: NULL argument");
   orbfe_ctx::HostStream& hs = c->hs;
   if (!hs.init || ticket < 0 || ticket >= hs.next_ticket || ticket + orbfe_ctx::HostStream::kDepth < hs.next_ticket || n_pairs <= 0 ||
       2 * n_pairs > c->cfg.max_images)
     return fail(c, ORBFE_EBADARG, "stream_pack_records: ticket %lld is not live (next %lld) or bad pair count %d", (long long)ticket,
                 (long long)hs.next_ticket, n_pairs);
+  if (n_pairs != hs.n_pairs_of[ticket % orbfe_ctx::HostStream::kDepth])
+    return fail(c, ORBFE_EBADARG, "stream_pack_records: ticket %lld was submitted with %d pairs, not %d (the packed layout depends on it)",
+                (long long)ticket, hs.n_pairs_of[ticket % orbfe_ctx::HostStream::kDepth], n_pairs);
   HIP_TRY(c, hipSetDevice(c->device));
   const int b = (int)(ticket % orbfe_ctx::HostStream::kDepth);
   const PackLayout l = pack_layout(c, n_pairs);
@@ -1812,6 +1856,7 @@ orbfe_status orbfe_stream_pack_records(orbfe_ctx* c, int64_t ticket, int32_t n_p
 
 orbfe_status orbfe_match_bruteforce(orbfe_ctx* c, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, const uint32_t* cand_offsets,
                                     const uint32_t* cand_idx, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist) {
+  ApiLock api_lk(c);
   if (!c || nq < 0 || nt < 0 || (nq && !q) || (nt && !t) || !best_idx || !best_dist || !second_dist)
     return fail(c, ORBFE_EBADARG, "match_bruteforce: NULL argument");
   if (cand_offsets && !cand_idx && cand_offsets[nq] > 0) return fail(c, ORBFE_EBADARG, "match_bruteforce: cand_idx is NULL");
@@ -1848,6 +1893,7 @@ orbfe_status orbfe_match_bruteforce(orbfe_ctx* c, const uint8_t* q, int32_t nq, 
 }
 
 orbfe_status orbfe_ba_eval_edges(orbfe_ctx* c, const orbfe_ba_problem* p, const orbfe_ba_edge_out* o) {
+  ApiLock api_lk(c);
   if (!c || !p || !o) return fail(c, ORBFE_EBADARG, "ba_eval_edges: NULL argument");
   const int E = p->n_edges;
   if (E < 0 || p->n_poses < 0 || p->n_points < 0) return fail(c, ORBFE_EBADARG, "ba_eval_edges: negative size");
@@ -1902,6 +1948,7 @@ orbfe_status orbfe_ba_eval_edges(orbfe_ctx* c, const orbfe_ba_problem* p, const 
 }
 
 orbfe_status orbfe_ba_build_system(orbfe_ctx* c, const orbfe_ba_problem* p, const uint8_t* pose_fixed, const orbfe_ba_system_out* o) {
+  ApiLock api_lk(c);
   if (!c || !p || !o) return fail(c, ORBFE_EBADARG, "ba_build_system: NULL argument");
   const int E = p->n_edges, NK = p->n_poses, NP = p->n_points;
   if (E < 0 || NK < 0 || NP < 0) return fail(c, ORBFE_EBADARG, "ba_build_system: negative size");
@@ -1984,6 +2031,7 @@ orbfe_status orbfe_ba_build_system(orbfe_ctx* c, const orbfe_ba_problem* p, cons
 // (a handful of scalars per trial) and every vertex / edge / block operation on the device.
 orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, const uint8_t* pose_fixed, int32_t iters_first,
                                      int32_t iters_second, const volatile uint8_t* stop_flag, const orbfe_ba_optimize_out* o) {
+  ApiLock api_lk(c);
   if (!c || !p || !o) return fail(c, ORBFE_EBADARG, "ba_local_optimize: NULL argument");
   const int E = p->n_edges, NK = p->n_poses, NP = p->n_points;
   if (E < 0 || NK < 0 || NP < 0 || iters_first < 0 || iters_second < 0) return fail(c, ORBFE_EBADARG, "ba_local_optimize: negative size");
@@ -2262,6 +2310,7 @@ static size_t search_area_scratch(const orbfe_ctx* c, size_t n_target, int32_t n
 orbfe_status orbfe_search_in_area(orbfe_ctx* c, int32_t slot, int32_t nq, const float* qxy, const float* radius, const int8_t* min_level,
                                   const int8_t* max_level, const uint8_t* q_desc, const uint8_t* exclude, int32_t* best_idx,
                                   int32_t* best_dist, int32_t* second_dist, int32_t* n_cand) {
+  ApiLock api_lk(c);
   if (!c || slot < 0 || slot >= c->cfg.max_images || nq < 0) return fail(c, ORBFE_EBADARG, "search_in_area: bad slot / count");
   if (nq && (!qxy || !radius || !min_level || !max_level || !q_desc || !best_idx || !best_dist || !second_dist || !n_cand))
     return fail(c, ORBFE_EBADARG, "search_in_area: NULL argument");
@@ -2279,6 +2328,7 @@ orbfe_status orbfe_search_in_area_features(orbfe_ctx* c, int32_t nt, const orbfe
                                            const float* qxy, const float* radius, const int8_t* min_level, const int8_t* max_level,
                                            const uint8_t* q_desc, const uint8_t* exclude, int32_t* best_idx, int32_t* best_dist,
                                            int32_t* second_dist, int32_t* n_cand) {
+  ApiLock api_lk(c);
   if (!c || nt < 0 || nq < 0 || (nt && (!t_kps || !t_desc))) return fail(c, ORBFE_EBADARG, "search_in_area_features: bad count / NULL features");
   if (nq && (!qxy || !radius || !min_level || !max_level || !q_desc || !best_idx || !best_dist || !second_dist || !n_cand))
     return fail(c, ORBFE_EBADARG, "search_in_area_features: NULL argument");
@@ -2292,7 +2342,13 @@ orbfe_status orbfe_search_in_area_features(orbfe_ctx* c, int32_t nt, const orbfe
   TRY(ensure_tmp(c, used + search_area_scratch(c, NT, nq)));
   uint8_t* b = (uint8_t*)c->d_tmp;
   std::vector<uint4> kpl(NT, make_uint4(0u, 0u, 0u, 0u));
-  for (int i = 0; i < nt; ++i) kpl[(size_t)i].y = (uint32_t)(t_kps[i].octave & 0xFF);  // the search reads the octave from here
+  for (int i = 0; i < nt; ++i) {
+    // caller-supplied features (a KeyFrame's undistorted mvFeatsLeft): coordinates may lie outside the image or be non-finite -- the grid
+    // kernel clamps them into the border cells; the octave must be one a pyramid can have (it is compared as an unsigned byte)
+    if (t_kps[i].octave < 0 || t_kps[i].octave >= ORBFE_MAX_LEVELS)
+      return fail(c, ORBFE_EBADARG, "search_in_area_features: feature %d has octave %d (0..%d expected)", i, t_kps[i].octave, ORBFE_MAX_LEVELS - 1);
+    kpl[(size_t)i].y = (uint32_t)t_kps[i].octave;  // the search reads the octave from here
+  }
   if (nt) {
     HIP_TRY(c, hipMemcpyAsync(b + o_k, t_kps, (size_t)nt * sizeof(orbfe_keypoint), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(b + o_l, kpl.data(), (size_t)nt * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
@@ -2308,6 +2364,7 @@ orbfe_status orbfe_search_in_area_features(orbfe_ctx* c, int32_t nt, const orbfe
 orbfe_status orbfe_project_map_points(orbfe_ctx* c, int32_t n, const float* pos, const float* view_dir, const float* max_dist,
                                       const float* min_dist, const orbfe_frame_pose* pose, const orbfe_camera* cam, float* uv,
                                       float* distance, float* cos_theta, int8_t* level, uint8_t* visible) {
+  ApiLock api_lk(c);
   if (!c || n < 0 || !pose || !cam) return fail(c, ORBFE_EBADARG, "project_map_points: NULL argument");
   if (n && (!pos || !view_dir || !max_dist || !min_dist || !uv || !distance || !cos_theta || !level || !visible))
     return fail(c, ORBFE_EBADARG, "project_map_points: NULL argument");
@@ -2352,6 +2409,7 @@ orbfe_status orbfe_project_map_points(orbfe_ctx* c, int32_t n, const float* pos,
 orbfe_status orbfe_pose_only_optimize(orbfe_ctx* c, int32_t n, const double* xw, const double* meas, const double* info, const float* sigma2,
                                       const double* pose_in, double fx, double fy, double cx, double cy, double bf, double* pose_out,
                                       uint8_t* inlier_out, int32_t* n_good) {
+  ApiLock api_lk(c);
   if (!c || n < 0 || !pose_in || !pose_out || !n_good || (n && (!xw || !meas || !info || !sigma2)))
     return fail(c, ORBFE_EBADARG, "pose_only_optimize: NULL argument");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -2391,6 +2449,7 @@ orbfe_status orbfe_pose_only_optimize(orbfe_ctx* c, int32_t n, const double* xw,
 }
 
 orbfe_status orbfe_profile_enable(orbfe_ctx* c, int32_t on) {
+  ApiLock api_lk(c);
   if (!c) return ORBFE_EBADARG;
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
@@ -2401,6 +2460,7 @@ orbfe_status orbfe_profile_enable(orbfe_ctx* c, int32_t on) {
 }
 
 orbfe_status orbfe_profile_read(orbfe_ctx* c, double* ms, int64_t* launches, int32_t reset) {
+  ApiLock api_lk(c);
   if (!c) return ORBFE_EBADARG;
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
@@ -2418,6 +2478,7 @@ orbfe_status orbfe_profile_read(orbfe_ctx* c, double* ms, int64_t* launches, int
 }
 
 orbfe_status orbfe_debug_candidates(orbfe_ctx* c, int32_t slot, int32_t level, float* xyr, int32_t cap, int32_t* n_out) {
+  ApiLock api_lk(c);
   if (!c || slot < 0 || slot >= c->cfg.max_images || level < 0 || level >= c->cfg.n_levels || !n_out)
     return fail(c, ORBFE_EBADARG, "debug_candidates: bad argument");
   HIP_TRY(c, hipSetDevice(c->device));

@@ -64,27 +64,67 @@ def unpack_record(rec: np.ndarray, n_features: int) -> dict:
 
 
 def run_sequence(n_frames: int, rank: int, world: int, batch_pairs: int, submit: Callable[[Sequence[int]], object],
-                 collect: Callable[[object], "object"], depth: int = 3, dst: int = 0):
+                 collect: Callable[[object], "object"], depth: int = 3, dst: int = 0, window: int = 0, sink=None, collect_into=None,
+                 force_collective: bool = False):
     """Process this rank's block of the sequence in batches of <= batch_pairs frames, `depth` batches in flight, and gather all
     records on `dst`.
 
     submit(frame_ids) -> handle starts a batch (host images -> device, extraction, stereo match); collect(handle) -> uint8 tensor
     [len(frame_ids), record_bytes] on the device the collective runs on, in frame order.  Batches are collected in submission order.
-    Returns (records [n_frames, record_bytes] on dst / None elsewhere, number of frames this rank processed)."""
+
+    window = 0: ONE gather at the end of the sequence (sharding.gather_frames).  window = W > 0: a gather per W batches
+    (sharding.WindowGather) that runs while the next window is computed; on dst every finished part goes to sink(first_frame, tensor)
+    (e.g. a non-blocking copy to page-locked host memory) or, without a sink, is kept and returned assembled.  collect_into(handle,
+    out) packs a batch straight into a slice of the window's send buffer (no intermediate tensor).
+    Returns (records [n_frames, record_bytes] on dst / None elsewhere or when a sink took them, number of frames this rank processed)."""
     import torch
     b, e = frame_range(n_frames, rank, world)
-    chunks, flight = [], []
-    for s in range(b, e, max(1, batch_pairs)):
-        flight.append(submit(range(s, min(e, s + batch_pairs))))
-        if len(flight) >= max(1, depth):
+    B = max(1, batch_pairs)
+    if window <= 0:
+        chunks, flight = [], []
+        for s in range(b, e, B):
+            flight.append(submit(range(s, min(e, s + B))))
+            if len(flight) >= max(1, depth):
+                chunks.append(collect(flight.pop(0)))
+        while flight:
             chunks.append(collect(flight.pop(0)))
-    while flight:
-        chunks.append(collect(flight.pop(0)))
-    if chunks:
-        local = torch.cat(chunks, dim=0) if len(chunks) > 1 else chunks[0]
-    else:  # an empty block (more ranks than frames): shape and device from a zero-frame batch
-        local = collect(submit(range(0, 0)))[:0]
-    return gather_frames(local, n_frames, rank, world, dst), e - b
+        if chunks:
+            local = torch.cat(chunks, dim=0) if len(chunks) > 1 else chunks[0]
+        else:  # an empty block (more ranks than frames): shape and device from a zero-frame batch
+            local = collect(submit(range(0, 0)))[:0]
+        return gather_frames(local, n_frames, rank, world, dst, force_collective), e - b
+
+    from .sharding import WindowGather
+    proto = collect(submit(range(0, 0)))   # zero-frame batch: record shape, dtype and device
+    win = window * B
+    wg = WindowGather(n_frames, rank, world, win, tuple(proto.shape[1:]), proto.dtype, proto.device, dst, sink, force_collective)
+    starts = list(range(b, e, B))
+    flight, nxt = [], 0
+
+    def top_up():
+        nonlocal nxt
+        while nxt < len(starts) and len(flight) < max(1, depth):
+            s = starts[nxt]
+            flight.append((s, min(e, s + B), submit(range(s, min(e, s + B)))))
+            nxt += 1
+
+    top_up()
+    for w in range(wg.n_windows):
+        lo, hi = wg.local_rows(w)           # block-relative frames of this window
+        buf = wg.buffer(w)
+        done = lo
+        while done < hi:
+            s, t, h = flight.pop(0)
+            assert s - b == done and t - b <= hi, "batches do not tile the window"
+            out = buf[s - b - lo:t - b - lo]
+            if collect_into is not None:
+                collect_into(h, out)
+            else:
+                out.copy_(collect(h))
+            done = t - b
+            top_up()
+        wg.push(w)
+    return wg.finish(), e - b
 
 
 class DeviceSequenceProcessor:
@@ -111,7 +151,8 @@ class DeviceSequenceProcessor:
             if ck is not None and ck in self._by_content:
                 self.pinned[(chunk[0], len(chunk))] = self._by_content[ck]
                 continue
-            l, r = PinnedArray((len(chunk), H, W), np.uint8), PinnedArray((len(chunk), H, W), np.uint8)
+            dv = int(self.ctx.cfg.device_id)
+            l, r = PinnedArray((len(chunk), H, W), np.uint8, dv), PinnedArray((len(chunk), H, W), np.uint8, dv)
             for i, f in enumerate(chunk):
                 k = self.content_key(f) if self.content_key else f
                 if k not in cache and len(cache) < 256:
@@ -148,3 +189,12 @@ class DeviceSequenceProcessor:
         torch.cuda.current_stream(self.device).synchronize()       # (the allocation is visible to the library's stream)
         self.ctx.stream_pack_records(ticket, n, rec.data_ptr())    # the library's pack kernel, straight into the tensor
         return rec
+
+    def collect_into(self, handle, out):
+        """Pack the records of a batch straight into `out` ([n, record_bytes] uint8, contiguous, on this device; e.g. a slice of a window's
+        send buffer whose previous use is known to be complete).  Returns when the records are in place."""
+        if handle is None:
+            return
+        ticket, n = handle
+        assert out.is_contiguous() and tuple(out.shape) == (n, self.ctx.record_bytes())
+        self.ctx.stream_pack_records(ticket, n, out.data_ptr())

@@ -7,6 +7,7 @@
 //                                             every result compared with a single-threaded run           -> "THREADS_OK ..."
 //   localba <map.pb> <kf id>                  the KeyFrame adapter against the array-level path on the same map -> "LOCALBA_OK ..."
 //   poseonly                                  the Frame adapter against the array-level call              -> "POSEONLY_OK ..."
+//   latency <L.raw> <R.raw> <w> <h> <iters>   timing of Frame::Frame (two threads) + searchByStereo per pair, host to host -> "LATENCY_OK ..."
 // Exit 3 + "NO_DEVICE" when no HIP device is usable (there is no CPU fallback).
 #include <cmath>
 #include <cstdio>
@@ -179,6 +180,48 @@ static int mode_threads(int argc, char** argv) {
          (unsigned long long)fnv1a(base->mvFeatsLeft.data(), base->mvFeatsLeft.size() * sizeof(cv::KeyPoint)), (int)pyr_ok, (int)stale_refused,
          ORB_SLAM2_ROS2::ORBExtractor::mnLevels);
   return (pyr_ok && stale_refused) ? 0 : 1;
+}
+
+// Timing mode (bench.py's `latency` object): the reference's own call shape -- Frame::Frame builds two extractor objects and runs their
+// extract() on two std::threads (src/Frame.cc:91-105), then Frame::createStereo calls searchByStereo (Frame.h:316-319) -- from host
+// images to host results, per stereo pair.  Thread creation and join are part of Frame::Frame and are inside the number; every
+// iteration's result is compared with the first one's.
+#include <chrono>
+static int mode_latency(int argc, char** argv) {
+  if (argc < 7) return 2;
+  const int w = atoi(argv[4]), h = atoi(argv[5]), iters = atoi(argv[6]);
+  std::vector<uint8_t> L, R;
+  if (!read_file(argv[2], L) || !read_file(argv[3], R) || L.size() != (size_t)w * h || R.size() != L.size()) return 2;
+  cv::Mat ml(h, w, CV_8UC1, L.data()), mr(h, w, CV_8UC1, R.data());
+  using clk = std::chrono::steady_clock;
+  auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+  uint64_t want = 0;
+  size_t nl = 0;
+  int nm = 0;
+  std::vector<double> total[2], ext[2];
+  for (int threaded = 1; threaded >= 0; --threaded) {
+    for (int it = -30; it < iters; ++it) {  // 30 untimed warm-up frames (graphs captured, clocks up)
+      const auto t0 = clk::now();
+      auto f = std::make_shared<ref::Frame>(ml, mr, threaded != 0);
+      const auto t1 = clk::now();
+      f->mnN = orbfe::dropin::searchByStereo<ref::Camera>(f);
+      const auto t2 = clk::now();
+      const uint64_t hsh = frame_hash(*f);
+      if (!want) want = hsh, nl = f->mvFeatsLeft.size(), nm = f->mnN;
+      if (hsh != want) {
+        fprintf(stderr, "latency: iteration %d (threaded %d) differs from the first frame\n", it, threaded);
+        return 1;
+      }
+      if (it >= 0) total[threaded].push_back(us(t0, t2)), ext[threaded].push_back(us(t0, t1));
+    }
+  }
+  auto pct = [](std::vector<double> v, double q) {
+    std::sort(v.begin(), v.end());
+    return v.empty() ? 0.0 : v[std::min(v.size() - 1, (size_t)(q * v.size()))];
+  };
+  printf("LATENCY_OK %d %.1f %.1f %.1f %.1f %.1f %.1f %zu %d %016llx\n", iters, pct(total[1], 0.5), pct(total[1], 0.99), pct(ext[1], 0.5),
+         pct(total[0], 0.5), pct(total[0], 0.99), pct(ext[0], 0.5), nl, nm, (unsigned long long)want);
+  return 0;
 }
 
 static int mode_localba(int argc, char** argv) {
@@ -383,6 +426,7 @@ int main(int argc, char** argv) {
     const std::string mode = argv[1];
     if (mode == "policy") return mode_policy();
     if (mode == "threads") return mode_threads(argc, argv);
+    if (mode == "latency") return mode_latency(argc, argv);
     if (mode == "localba") return mode_localba(argc, argv);
     if (mode == "poseonly") return mode_poseonly();
     return 2;

@@ -148,3 +148,74 @@ def test_sequence_driver_two_ranks_equals_one_rank(n_frames, batch):
     assert got.shape == ref.shape == (n_frames, record_bytes(NF_SMALL)) and np.array_equal(got, ref)
     u = unpack_record(got[0], NF_SMALL)
     assert u["n"] > 10 and (u["kps"]["size"] == 7).all() and u["n_matches"] == int((u["right_u"] >= 0).sum())
+
+
+# ---- the windowed gather (SURVEY 8e "per window of W frames"): a gather per window while the next one is computed -------------------
+def _win_worker(rank, world, port, n_frames, batch, window, use_sink, q):
+    import torch
+    import torch.distributed as dist
+    from orb_slam2_ros2_amd.sequence import record_bytes, run_sequence
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    submit, collect = _small_frame_processor()
+    host = torch.full((n_frames, record_bytes(NF_SMALL)), 0xEE, dtype=torch.uint8)
+    calls = []
+
+    def sink(first, t):
+        calls.append((first, t.shape[0]))
+        host[first:first + t.shape[0]].copy_(t)
+
+    rec, n_local = run_sequence(n_frames, rank, world, batch, submit, collect, window=window, sink=sink if use_sink else None,
+                                force_collective=(world == 1))
+    if rank == 0:
+        q.put(((host if use_sink else rec).numpy(), n_local, calls))
+    else:
+        assert rec is None and not calls
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames,batch,window,use_sink", [(2, 7, 2, 1, True),    # per 4: two windows of 2, rank 1 ends in a ragged one
+                                                                 (2, 9, 2, 2, False),   # per 5: windows of 4, rank 1 has nothing in the second
+                                                                 (2, 1, 4, 1, True),    # rank 1 has an empty block
+                                                                 (1, 5, 2, 1, True)])   # one rank THROUGH the collective (force_collective)
+def test_windowed_gather_equals_single_gather(world, n_frames, batch, window, use_sink):
+    import torch.multiprocessing as mp
+    from orb_slam2_ros2_amd.sequence import record_bytes, run_sequence
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_win_worker, args=(r, world, port, n_frames, batch, window, use_sink, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, n0, calls = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    submit, collect = _small_frame_processor()
+    ref, _ = run_sequence(n_frames, 0, 1, batch, submit, collect)
+    assert got.shape == (n_frames, record_bytes(NF_SMALL)) and np.array_equal(got, ref.numpy())
+    assert n0 == (n_frames + world - 1) // world
+    if use_sink:   # every frame delivered exactly once
+        seen = sorted(f for first, n in calls for f in range(first, first + n))
+        assert seen == list(range(n_frames))
+
+
+def test_window_gather_rejects_out_of_order_and_unfinished_windows():
+    import torch
+    from orb_slam2_ros2_amd.sharding import WindowGather
+    wg = WindowGather(5, 0, 1, 2, (3,), torch.uint8, torch.device("cpu"))
+    assert wg.n_windows == 3 and wg.local_rows(2) == (4, 5)
+    with pytest.raises(ValueError):
+        wg.push(1)
+    wg.buffer(0)[:] = 1
+    wg.push(0)
+    with pytest.raises(ValueError):
+        wg.finish()
+    wg.buffer(1)[:] = 2
+    wg.push(1)
+    wg.buffer(2)[:] = 3
+    wg.push(2)
+    out = wg.finish()
+    assert out.shape == (5, 3) and out[:, 0].tolist() == [1, 1, 2, 2, 3]

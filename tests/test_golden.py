@@ -159,3 +159,54 @@ def test_golden_map_pb_written_by_libprotobuf():
             assert np.abs(np.asarray(g[key]) - np.asarray(want)).max() < 1e-15
         else:
             assert (np.asarray(g[key]) == np.asarray(want, dtype=np.asarray(g[key]).dtype)).all(), key
+
+
+# ---- golden_v3: the BASELINE config-5 problem the bench's `ba` leg times -----------------------------------------------------------
+G3 = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_v3.json")))
+
+
+def cfg5_local_ba_problem():
+    pr = ba_synth.make_problem(seed=42, n_kf=60, n_pt=3000, with_truth=True)
+    fixed = np.zeros(60, np.uint8)
+    fixed[:20] = 1
+    pr["poses"][:20] = pr["poses_true"][:20]
+    return pr, fixed
+
+
+def check_cfg5_lba(r, atol=1e-8):
+    g = G3["cfg5_lba"]
+    assert r["iters"].tolist() == g["iters"] and abs(int(r["level"].sum()) - g["n_level1"]) <= 1 and abs(int(r["bad"].sum()) - g["n_bad"]) <= 1
+    assert np.allclose(r["poses"].ravel(), g["poses"], rtol=0, atol=atol) and np.allclose(r["points"][:20].ravel(), g["points_head"], rtol=0, atol=atol)
+    assert abs(r["chi2"].sum() - g["chi2_sum"]) < 1e-6 * g["chi2_sum"]
+
+
+def check_cfg5_system(s):
+    for k, want in G3["cfg5_system"].items():
+        assert np.abs(np.asarray(s[k], np.float64)).sum() == pytest.approx(want, rel=1e-9), k
+
+
+def _cfg5_system_args():
+    p = ba_synth.make_problem()
+    fx = np.zeros(p["poses"].shape[0], np.uint8)
+    fx[0] = 1
+    fx[30:] = 1
+    return p, fx
+
+
+def test_v3_oracle_cfg5_local_ba_and_system(orc):
+    pr, fixed = cfg5_local_ba_problem()
+    assert pr["edge_pose"].size == G3["cfg5_lba"]["n_edges"]
+    check_cfg5_lba(orc.ba_local_optimize(pr, fixed))
+    p, fx = _cfg5_system_args()
+    check_cfg5_system(orc.ba_build_system(**p, pose_fixed=fx))
+
+
+@pytest.mark.gpu
+def test_v3_device_cfg5_local_ba_and_system():
+    from orb_slam2_ros2_amd._lib import Context
+    ctx = Context(640, 480, n_features=1000, max_images=1)
+    pr, fixed = cfg5_local_ba_problem()
+    check_cfg5_lba(ctx.ba_local_optimize(pr, fixed), atol=1e-7)
+    p, fx = _cfg5_system_args()
+    check_cfg5_system(ctx.ba_build_system(**p, pose_fixed=fx))
+    ctx.close()

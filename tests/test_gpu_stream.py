@@ -85,6 +85,18 @@ def test_stream_argument_checks():
         ctx.stream_wait(0)                              # never issued
     with pytest.raises(_lib.OrbfeError):
         ctx.stream_submit(l, l, 2, FX, BF, {}, stride=100)
+    # the packed layout of a ticket depends on ITS pair count: asking with another one (the shorter last batch of a sequence) is refused
+    t = ctx.stream_submit(l, l, 2, FX, BF, {})
+    ctx.stream_wait(t)
+    assert ctx.stream_device_results(t, 2) is not None
+    with pytest.raises(_lib.OrbfeError):
+        ctx.stream_device_results(t, 1)
+    import torch
+    rec = torch.empty((2, ctx.record_bytes()), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.OrbfeError):
+        ctx.stream_pack_records(t, 1, rec.data_ptr())
+    ctx.stream_pack_records(t, 2, rec.data_ptr())
     ctx.close()
 
 

@@ -245,6 +245,26 @@ def test_device_sim3_and_fuse_equal_the_injected_oracle_path(orc, kfs):
     cpu_f = m.fuseFrames(None, kfC, st1, kfM["kps"], kfM["desc"], st2, inv, 0.0, 0.54, SF,
                          search_in=lambda *a: orc.search_in_area(kfC["kps"], kfC["desc"], W, H, *a))
     assert dev_f == cpu_f and dev_f[1] > 5
+    # undistorted KeyFrame features may leave the image (Frame.cc:106) or be non-finite: the grid kernel must clamp them into the border
+    # cells instead of writing outside its LDS counters / scratch lists (the reference indexes its cell vector unchecked there)
+    wild = kfC["kps"].copy()
+    wild["x"][::7] -= F32(200.0)
+    wild["y"][::11] -= F32(90.0)
+    wild["x"][3::13] += F32(W)
+    wild["y"][5::17] += F32(2 * H)
+    wild["x"][1::97] = np.nan
+    wild["y"][2::101] = np.inf
+    wild["x"][4::103] = -np.inf
+    a = ctx.search_in_area_features(wild, kfC["desc"], qxy, rad * 3, lo, hi, kfM["desc"][q], ex)
+    b = orc.search_in_area(wild, kfC["desc"], W, H, qxy, rad * 3, lo, hi, kfM["desc"][q], ex)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and (a[3] > 0).sum() > 100
+    again = ctx.search_in_area_features(kfC["kps"], kfC["desc"], qxy, rad, lo, hi, kfM["desc"][q], ex)   # nothing was corrupted
+    assert all(np.array_equal(x, y) for x, y in zip(again, orc.search_in_area(kfC["kps"], kfC["desc"], W, H, qxy, rad, lo, hi, kfM["desc"][q], ex)))
+    from orb_slam2_ros2_amd._lib import OrbfeError
+    neg = kfC["kps"].copy()
+    neg["octave"][10] = -1
+    with pytest.raises(OrbfeError):
+        ctx.search_in_area_features(neg, kfC["desc"], qxy[:4], rad[:4], lo[:4], hi[:4], kfM["desc"][q[:4]])
     # an empty feature set and an empty query list are fine
     e = ctx.search_in_area_features(kfC["kps"][:0], kfC["desc"][:0], qxy[:4], rad[:4], lo[:4], hi[:4], kfM["desc"][q[:4]])
     assert e[0].tolist() == [-1] * 4 and e[3].tolist() == [0] * 4
