@@ -57,6 +57,23 @@ def algorithmic_bytes(ctx, n_cand_per_image):
     return per_image, per_pair_match, per_pair
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on file descriptor 1 when its first communicator comes up; the contract is ONE JSON line on stdout.
+    While this is active, everything written to fd 1 -- by Python or by a native library -- goes to stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def spawn_ranks(n: int) -> int:
     import socket
     import subprocess
@@ -519,6 +536,16 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # ONE JSON line on stdout is the contract, and native libraries write there too (RCCL's version banner when its first communicator
+    # comes up): from here on file descriptor 1 points at stderr, and the line goes to the saved descriptor at the very end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -542,10 +569,14 @@ def main():
     # node ever sees the pair.  A failure to initialise with one rank is reported in the line (`rccl`), not fatal.
     collective, rccl_note = world > 1, None
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        with _StdoutToStderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                probe = torch.ones(4, device=dev)
+                dist.all_reduce(probe)   # the communicator (and its banner) comes up here, not inside a timed region
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
     elif backend == "nccl" and os.environ.get("ORBFE_BENCH_NO_PG") != "1":
         try:
             import socket
@@ -556,10 +587,11 @@ def main():
                 sk.close()
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-            probe = torch.ones(4, device=dev)
-            dist.all_reduce(probe)
-            torch.cuda.synchronize()
+            with _StdoutToStderr():
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                probe = torch.ones(4, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
             collective, rccl_note = True, "process group of 1 rank over RCCL: the gathers of this run executed as RCCL collectives"
         except Exception as ex:   # noqa: BLE001 -- reported, the single-rank path needs no collective
             rccl_note = f"init_process_group('nccl', world_size=1) failed: {type(ex).__name__}: {ex}"
@@ -573,7 +605,7 @@ def main():
         line = run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend, collective)
         if rank == 0:
             line["rccl"] = rccl_note
-            print(json.dumps(line))
+            emit(line)
         if dist.is_initialized():
             dist.destroy_process_group()
         return
@@ -881,7 +913,7 @@ def main():
             line["latency"] = latency_leg(local_rank)
         line["legs_seconds"] = time.perf_counter() - t_legs
     if rank == 0:
-        print(json.dumps(line))
+        emit(line)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -293,6 +293,17 @@ orbfe_status orbfe_search_in_area_features(orbfe_ctx* ctx, int32_t nt, const orb
                                            int32_t nq, const float* qxy /*[nq][2]*/, const float* radius, const int8_t* min_level,
                                            const int8_t* max_level, const uint8_t* q_desc /*[nq][32]*/, const uint8_t* exclude,
                                            int32_t* best_idx, int32_t* best_dist, int32_t* second_dist, int32_t* n_cand);
+/* ... with the two things the frame-level searchByProjection (src/ORBMatcher.cc:265-347) needs besides: `bounds` = {min_u, max_u, min_v,
+ * max_v}, the target frame's undistorted image bounds (VirtualFrame::mfMinU..mfMaxV, include/ORB_SLAM2/Frame.h:33-43): initGrid sizes the
+ * grid from them and findFeaturesInArea clips the search box at (int)max_u / (int)max_v (src/Frame.cc:55-56, :289-293); NULL = the image,
+ * i.e. a camera without distortion.  `excluded_hits` [nt], nullable: for every EXCLUDED feature how many queries had it inside their
+ * window and octave range -- the reference calls MapPoint::addMatchInTrack once per such occurrence while it drops the feature from
+ * the candidate list (ORBMatcher.cc:321-331); entries of features that are not excluded are 0.                                        */
+orbfe_status orbfe_search_in_area_features_ex(orbfe_ctx* ctx, int32_t nt, const orbfe_keypoint* t_kps, const uint8_t* t_desc /*[nt][32]*/,
+                                              const float* bounds /*[4], nullable*/, int32_t nq, const float* qxy /*[nq][2]*/,
+                                              const float* radius, const int8_t* min_level, const int8_t* max_level,
+                                              const uint8_t* q_desc /*[nq][32]*/, const uint8_t* exclude, int32_t* best_idx,
+                                              int32_t* best_dist, int32_t* second_dist, int32_t* n_cand, int32_t* excluded_hits);
 
 /* ---- pose-only optimisation of one frame (fp64), entirely on the device -------------------------------------------
  * Replaces the g2o part of Optimizer::OptimizePoseOnly (include/ORB_SLAM2/Optimizer.h:72, src/Optimizer.cc:33-178): one SE3 pose

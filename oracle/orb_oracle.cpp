@@ -954,12 +954,18 @@ static int grid_cell(float v, int size, int n) {
   if (q >= (float)(n - 1)) return n - 1;
   return cv_floor(q);
 }
-extern "C" void orc_search_in_area(const orc_keypoint* kps, const uint8_t* desc, int n, int width, int height, int nq, const float* qxy,
-                                   const float* radius, const int8_t* min_level, const int8_t* max_level, const uint8_t* q_desc,
-                                   const uint8_t* exclude, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
-                                   int32_t* n_cand) {
+// bounds = {mfMinU, mfMaxU, mfMinV, mfMaxV} of the target frame (Frame.h:33-43): grid size as initGrid (Frame.cc:55-56), box clipped at
+// (int)mfMaxU / (int)mfMaxV (:291-293).  excluded_hits[n] (nullable): occurrences of an excluded feature in a query's window -- what
+// the copy_if of searchByProjection (ORBMatcher.cc:321-331) turns into addMatchInTrack calls.
+extern "C" void orc_search_in_area_ex(const orc_keypoint* kps, const uint8_t* desc, int n, const float* bounds, int nq, const float* qxy,
+                                      const float* radius, const int8_t* min_level, const int8_t* max_level, const uint8_t* q_desc,
+                                      const uint8_t* exclude, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
+                                      int32_t* n_cand, int32_t* excluded_hits) {
   const int GW = 64, GH = 48;
-  const int rows = cv_ceil((float)height / GH), cols = cv_ceil((float)width / GW);
+  const int rows = cv_ceil((float)(bounds[3] - bounds[2]) / GH), cols = cv_ceil((float)(bounds[1] - bounds[0]) / GW);
+  const int width = (int)bounds[1], height = (int)bounds[3];
+  if (excluded_hits)
+    for (int i = 0; i < n; ++i) excluded_hits[i] = 0;
   std::vector<std::vector<int64_t>> grid((size_t)rows * cols);
   for (int i = 0; i < n; ++i) {
     const int r = grid_cell(kps[i].y, GH, rows), c = grid_cell(kps[i].x, GW, cols);
@@ -976,7 +982,12 @@ extern "C" void orc_search_in_area(const orc_keypoint* kps, const uint8_t* desc,
       for (int c = c0; c <= c1; ++c)
         for (int64_t id : grid[(size_t)r * cols + c]) {
           const int oc = kps[id].octave;
-          if (oc <= max_level[q] && oc >= min_level[q] && !(exclude && exclude[id])) cand.push_back(id);
+          if (!(oc <= max_level[q] && oc >= min_level[q])) continue;
+          if (exclude && exclude[id]) {
+            if (excluded_hits) ++excluded_hits[id];
+            continue;
+          }
+          cand.push_back(id);
         }
     n_cand[q] = (int32_t)cand.size();
     if (cand.empty()) {
@@ -993,4 +1004,13 @@ extern "C" void orc_search_in_area(const orc_keypoint* kps, const uint8_t* desc,
     best_dist[q] = bd;
     second_dist[q] = sd;
   }
+}
+
+extern "C" void orc_search_in_area(const orc_keypoint* kps, const uint8_t* desc, int n, int width, int height, int nq, const float* qxy,
+                                   const float* radius, const int8_t* min_level, const int8_t* max_level, const uint8_t* q_desc,
+                                   const uint8_t* exclude, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
+                                   int32_t* n_cand) {
+  const float bounds[4] = {0.f, (float)width, 0.f, (float)height};
+  orc_search_in_area_ex(kps, desc, n, bounds, nq, qxy, radius, min_level, max_level, q_desc, exclude, best_idx, best_dist, second_dist, n_cand,
+                        nullptr);
 }

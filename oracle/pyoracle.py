@@ -146,6 +146,24 @@ class Oracle:
         self.lib.orc_sincos(float(t), mode, C.byref(s), C.byref(c))
         return s.value, c.value
 
+    def search_in_area_ex(self, kps, desc, bounds, qxy, radius, min_level, max_level, q_desc, exclude=None):
+        """as search_in_area with the target frame's bounds (min_u, max_u, min_v, max_v); also returns the excluded-hit counts"""
+        kps = np.ascontiguousarray(kps)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        qxy = np.ascontiguousarray(qxy, np.float32).reshape(-1, 2)
+        nq = qxy.shape[0]
+        radius = np.ascontiguousarray(radius, np.float32)
+        min_level = np.ascontiguousarray(min_level, np.int8)
+        max_level = np.ascontiguousarray(max_level, np.int8)
+        q_desc = np.ascontiguousarray(q_desc, np.uint8).reshape(-1, 32)
+        bnd = np.ascontiguousarray(bounds, np.float32).reshape(4)
+        ex = None if exclude is None else np.ascontiguousarray(exclude, np.uint8)
+        out = [np.zeros(max(nq, 1), np.int32) for _ in range(4)]
+        hits = np.zeros(max(kps.shape[0], 1), np.int32)
+        self.lib.orc_search_in_area_ex(_p(kps), _p(desc), kps.shape[0], _p(bnd), nq, _p(qxy), _p(radius), _p(min_level), _p(max_level),
+                                       _p(q_desc), _p(ex) if ex is not None else None, *[_p(o) for o in out], _p(hits))
+        return tuple(o[:nq] for o in out) + (hits[:kps.shape[0]],)
+
     def search_in_area(self, kps, desc, width, height, qxy, radius, min_level, max_level, q_desc, exclude=None):
         kps = np.ascontiguousarray(kps)
         desc = np.ascontiguousarray(desc, np.uint8)

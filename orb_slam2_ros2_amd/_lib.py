@@ -101,7 +101,7 @@ EXPORTS = [
     "orbfe_get_capacity",
     "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_slot", "orbfe_fetch_batch", "orbfe_fetch_stereo_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
     "orbfe_host_alloc", "orbfe_host_alloc_on", "orbfe_host_free", "orbfe_stream_submit", "orbfe_stream_wait", "orbfe_stream_device_results", "orbfe_record_bytes", "orbfe_stream_pack_records",
-    "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_search_in_area_features", "orbfe_extract_color", "orbfe_frame_rgbd", "orbfe_project_map_points",
+    "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_search_in_area_features", "orbfe_search_in_area_features_ex", "orbfe_extract_color", "orbfe_frame_rgbd", "orbfe_project_map_points",
     "orbfe_map_pb_summary", "orbfe_map_pb_reencode", "orbfe_map_pb_to_txt", "orbfe_map_txt_to_pb", "orbfe_map_local_graph", "orbfe_map_local_ba",
     "orbfe_profile_enable", "orbfe_profile_read", "orbfe_stage_name", "orbfe_debug_candidates",
 ]
@@ -167,6 +167,7 @@ def load() -> C.CDLL:
     L.orbfe_pose_only_optimize.argtypes = [vp, i32, vp, vp, vp, vp, vp] + [C.c_double] * 5 + [vp, vp, vp]
     L.orbfe_search_in_area.argtypes = [vp, i32, i32] + [vp] * 10
     L.orbfe_search_in_area_features.argtypes = [vp, i32, vp, vp, i32] + [vp] * 10
+    L.orbfe_search_in_area_features_ex.argtypes = [vp, i32, vp, vp, vp, i32] + [vp] * 11
     L.orbfe_extract_color.argtypes = [vp, vp, C.c_size_t, i32, vp, vp, vp]
     L.orbfe_frame_rgbd.argtypes = [vp, i32, C.POINTER(Camera), vp, i32, C.c_size_t, f32, vp, vp, vp]
     L.orbfe_project_map_points.argtypes = [vp, i32, vp, vp, vp, vp, C.POINTER(FramePose), C.POINTER(Camera), vp, vp, vp, vp, vp]
@@ -505,8 +506,10 @@ class Context:
                                                   ptr(ex), *[ptr(o) for o in out]))
         return tuple(o[:nq] for o in out)
 
-    def search_in_area_features(self, t_kps, t_desc, qxy, radius, min_level, max_level, q_desc, exclude=None):
-        """orbfe_search_in_area against a caller-supplied feature set (a KeyFrame's keypoints [KP_DTYPE] and descriptors)"""
+    def search_in_area_features(self, t_kps, t_desc, qxy, radius, min_level, max_level, q_desc, exclude=None, bounds=None, want_hits=False):
+        """orbfe_search_in_area against a caller-supplied feature set (a KeyFrame's keypoints [KP_DTYPE] and descriptors).
+        bounds = (min_u, max_u, min_v, max_v) of the target frame (None: the image); want_hits: also return, per excluded feature, how many
+        queries had it in their window (orbfe_search_in_area_features_ex)."""
         t_kps = np.ascontiguousarray(t_kps, KP_DTYPE)
         t_desc = np.ascontiguousarray(t_desc, np.uint8).reshape(-1, 32)
         nt = t_kps.shape[0]
@@ -521,9 +524,16 @@ class Context:
             ex = np.zeros(max(nt, 1), np.uint8)
             ex[:len(exclude)] = np.asarray(exclude, np.uint8)
         out = [np.zeros(max(nq, 1), np.int32) for _ in range(4)]
-        self._check(self.lib.orbfe_search_in_area_features(self.h, nt, ptr(t_kps), ptr(t_desc), nq, ptr(qxy), ptr(radius), ptr(min_level),
-                                                           ptr(max_level), ptr(q_desc), ptr(ex), *[ptr(o) for o in out]))
-        return tuple(o[:nq] for o in out)
+        if bounds is None and not want_hits:
+            self._check(self.lib.orbfe_search_in_area_features(self.h, nt, ptr(t_kps), ptr(t_desc), nq, ptr(qxy), ptr(radius), ptr(min_level),
+                                                               ptr(max_level), ptr(q_desc), ptr(ex), *[ptr(o) for o in out]))
+            return tuple(o[:nq] for o in out)
+        bnd = None if bounds is None else np.ascontiguousarray(bounds, np.float32).reshape(4)
+        hits = np.zeros(max(nt, 1), np.int32) if want_hits else None
+        self._check(self.lib.orbfe_search_in_area_features_ex(self.h, nt, ptr(t_kps), ptr(t_desc), ptr(bnd), nq, ptr(qxy), ptr(radius),
+                                                              ptr(min_level), ptr(max_level), ptr(q_desc), ptr(ex), *[ptr(o) for o in out], ptr(hits)))
+        res = tuple(o[:nq] for o in out)
+        return res + (hits[:nt],) if want_hits else res
 
     # ---- BA -------------------------------------------------------------------------------------
     def ba_eval_edges(self, poses, points, edge_pose, edge_point, meas, is_stereo, info, huber_delta, fx, fy, cx, cy, bf,

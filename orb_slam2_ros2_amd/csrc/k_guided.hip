@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_search_area(const uint4* __restrict__ k
                                                      const int8_t* __restrict__ max_level, const uint8_t* __restrict__ q_desc,
                                                      const uint8_t* __restrict__ exclude, int32_t* __restrict__ best_idx,
                                                      int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist,
-                                                     int32_t* __restrict__ n_cand) {
+                                                     int32_t* __restrict__ n_cand, int32_t* __restrict__ excluded_hits) {
   __shared__ int32_t stage_all[4][128];  // per wave: filtered candidates waiting to fill a 64-lane chunk (order preserved)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int32_t* stage = stage_all[wv];
@@ -149,7 +149,13 @@ __global__ __launch_bounds__(256) void k_search_area(const uint4* __restrict__ k
         if (i < end) {
           id = cell_feat[i];
           const int oc = (int)(kpl[id].y & 0xFFu);
-          pass = oc <= hi && oc >= lo && !(exclude && exclude[id]);
+          pass = oc <= hi && oc >= lo;
+          if (pass && exclude && exclude[id]) {
+            // a feature the caller excluded WAS in this query's window: searchByProjection bumps MapPoint::addMatchInTrack once per such
+            // (query, feature) occurrence while it filters the candidates (src/ORBMatcher.cc:321-331) -- the counts let the caller do the same
+            pass = false;
+            if (excluded_hits) atomicAdd(&excluded_hits[id], 1);
+          }
         }
         const unsigned long long m = __ballot(pass);
         if (pass) stage[staged + __popcll(m & ((1ull << lane) - 1ull))] = id;
@@ -262,11 +268,11 @@ void launch_grid_build(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t
 void launch_search_area(hipStream_t s, const uint4* d_kpl, const uint8_t* d_desc, int width, int height, int rows, int cols,
                         const int32_t* d_cell_off, const int32_t* d_cell_feat, int nq, const float* d_qxy, const float* d_radius,
                         const int8_t* d_min_level, const int8_t* d_max_level, const uint8_t* d_q_desc, const uint8_t* d_exclude,
-                        int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second, int32_t* d_n_cand) {
+                        int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second, int32_t* d_n_cand, int32_t* d_excluded_hits) {
   if (nq <= 0) return;
   hipLaunchKernelGGL(k_search_area, dim3((nq + 3) / 4), dim3(256), 0, s, d_kpl, d_desc, width, height, rows, cols, d_cell_off,
                      d_cell_feat, nq, d_qxy, d_radius, d_min_level, d_max_level, d_q_desc, d_exclude, d_best_idx, d_best_dist, d_second,
-                     d_n_cand);
+                     d_n_cand, d_excluded_hits);
 }
 
 }  // namespace orbfe

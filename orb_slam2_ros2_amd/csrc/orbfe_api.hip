@@ -92,7 +92,7 @@ void launch_grid_build(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t
 void launch_search_area(hipStream_t s, const uint4* d_kpl, const uint8_t* d_desc, int width, int height, int rows, int cols,
                         const int32_t* d_cell_off, const int32_t* d_cell_feat, int nq, const float* d_qxy, const float* d_radius,
                         const int8_t* d_min_level, const int8_t* d_max_level, const uint8_t* d_q_desc, const uint8_t* d_exclude,
-                        int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second, int32_t* d_n_cand);
+                        int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second, int32_t* d_n_cand, int32_t* d_excluded_hits);
 void launch_pose_only(hipStream_t s, int n, const double* Xw, const double* meas, const double* info, const float* sigma2,
                       const double* pose_in, BaParamsDev prm, double d_mono, double d_stereo, double* err, uint8_t* level,
                       uint8_t* robust, uint8_t* inlier, double* pose_out, int32_t* n_good);
@@ -2259,11 +2259,31 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
 
 // The grid-guided search against a feature set on the device: the features of an image slot (orbfe_search_in_area) or a set the caller
 // uploaded (orbfe_search_in_area_features: a KeyFrame's keypoints and descriptors -- keyframes are not resident in a slot).
+// grid of a frame: VirtualFrame::initGrid (Frame.cc:55-56) sizes it from the undistorted bounds, findFeaturesInArea clips the box at
+// (int)mfMaxU / (int)mfMaxV (:291-293).  bounds = {min_u, max_u, min_v, max_v}; NULL: the image itself (no distortion: 0, width, 0, height)
+struct AreaGrid {
+  int rows, cols, clip_w, clip_h;
+};
+static bool area_grid(const orbfe_ctx* c, const float* bounds, AreaGrid* g) {
+  if (!bounds) {
+    *g = {(c->cfg.height + 47) / 48, (c->cfg.width + 63) / 64, c->cfg.width, c->cfg.height};
+    return true;
+  }
+  if (!(std::isfinite(bounds[0]) && std::isfinite(bounds[1]) && std::isfinite(bounds[2]) && std::isfinite(bounds[3])) ||
+      !(bounds[1] > bounds[0]) || !(bounds[3] > bounds[2]) || bounds[1] > 65536.f || bounds[3] > 65536.f || bounds[1] < 1.f || bounds[3] < 1.f)
+    return false;
+  *g = {cv_ceil_f((float)(bounds[3] - bounds[2]) / 48), cv_ceil_f((float)(bounds[1] - bounds[0]) / 64), (int)bounds[1], (int)bounds[3]};
+  return g->rows >= 1 && g->cols >= 1;
+}
+
 static orbfe_status search_area_core(orbfe_ctx* c, const char* who, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, const uint4* d_kpl,
                                      const uint8_t* d_desc, size_t n_target, size_t tmp_used, int32_t nq, const float* qxy,
                                      const float* radius, const int8_t* min_level, const int8_t* max_level, const uint8_t* q_desc,
-                                     const uint8_t* exclude, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist, int32_t* n_cand) {
-  const int rows = (c->cfg.height + 47) / 48, cols = (c->cfg.width + 63) / 64;  // cvCeil((float)(max-min)/grid), Frame.cc:55-56
+                                     const uint8_t* exclude, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist, int32_t* n_cand,
+                                     const float* bounds = nullptr, int32_t* excluded_hits = nullptr) {
+  AreaGrid ag;
+  if (!area_grid(c, bounds, &ag)) return fail(c, ORBFE_EBADARG, "%s: bad frame bounds", who);
+  const int rows = ag.rows, cols = ag.cols;
   const size_t ncells = (size_t)rows * cols;
   if ((2 * ncells + 1) * 4 > 60 * 1024) return fail(c, ORBFE_EBADSIZE, "%s: %zu grid cells exceed the LDS counters", who, ncells);
   const size_t NT = std::max<size_t>(n_target, 1);
@@ -2275,7 +2295,7 @@ static orbfe_status search_area_core(orbfe_ctx* c, const char* who, const orbfe_
   };
   const size_t o_co = take((ncells + 1) * 4), o_cf = take(NT * 4), o_q = take((size_t)nq * 8), o_r = take((size_t)nq * 4),
                o_lo = take((size_t)nq), o_hi = take((size_t)nq), o_d = take((size_t)nq * 32), o_ex = take(NT), o_bi = take((size_t)nq * 4),
-               o_bd = take((size_t)nq * 4), o_sd = take((size_t)nq * 4), o_nc = take((size_t)nq * 4);
+               o_bd = take((size_t)nq * 4), o_sd = take((size_t)nq * 4), o_nc = take((size_t)nq * 4), o_eh = take(NT * 4);
   if (off > c->tmp_bytes) return fail(c, ORBFE_ENOMEM, "%s: scratch not reserved", who);  // (the callers reserve before they upload)
   uint8_t* b = (uint8_t*)c->d_tmp;
   HIP_TRY(c, hipMemcpyAsync(b + o_q, qxy, (size_t)nq * 8, hipMemcpyHostToDevice, c->stream));
@@ -2284,15 +2304,19 @@ static orbfe_status search_area_core(orbfe_ctx* c, const char* who, const orbfe_
   HIP_TRY(c, hipMemcpyAsync(b + o_hi, max_level, (size_t)nq, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(b + o_d, q_desc, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
   if (exclude) HIP_TRY(c, hipMemcpyAsync(b + o_ex, exclude, n_target, hipMemcpyHostToDevice, c->stream));
+  const bool hits = exclude && excluded_hits;
+  if (hits) HIP_TRY(c, hipMemsetAsync(b + o_eh, 0, NT * 4, c->stream));
   {
     StageTimer tm(c, ORBFE_STAGE_MATCH, c->stream);
     launch_grid_build(c->stream, d_kps, d_n_kp, rows, cols, (int32_t*)(b + o_co), (int32_t*)(b + o_cf));
-    launch_search_area(c->stream, d_kpl, d_desc, c->cfg.width, c->cfg.height, rows, cols, (const int32_t*)(b + o_co),
+    launch_search_area(c->stream, d_kpl, d_desc, ag.clip_w, ag.clip_h, rows, cols, (const int32_t*)(b + o_co),
                        (const int32_t*)(b + o_cf), nq, (const float*)(b + o_q), (const float*)(b + o_r), (const int8_t*)(b + o_lo),
                        (const int8_t*)(b + o_hi), b + o_d, exclude ? b + o_ex : nullptr, (int32_t*)(b + o_bi), (int32_t*)(b + o_bd),
-                       (int32_t*)(b + o_sd), (int32_t*)(b + o_nc));
+                       (int32_t*)(b + o_sd), (int32_t*)(b + o_nc), hits ? (int32_t*)(b + o_eh) : nullptr);
   }
   HIP_TRY(c, hipGetLastError());
+  if (hits) HIP_TRY(c, hipMemcpyAsync(excluded_hits, b + o_eh, n_target * 4, hipMemcpyDeviceToHost, c->stream));
+  else if (excluded_hits && n_target) std::memset(excluded_hits, 0, n_target * 4);
   HIP_TRY(c, hipMemcpyAsync(best_idx, b + o_bi, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(best_dist, b + o_bd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(second_dist, b + o_sd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
@@ -2302,9 +2326,11 @@ static orbfe_status search_area_core(orbfe_ctx* c, const char* who, const orbfe_
   return ORBFE_OK;
 }
 // scratch the core needs beyond `tmp_used`
-static size_t search_area_scratch(const orbfe_ctx* c, size_t n_target, int32_t nq) {
-  const size_t ncells = (size_t)((c->cfg.height + 47) / 48) * ((c->cfg.width + 63) / 64), NT = std::max<size_t>(n_target, 1);
-  return ((ncells + 1) * 4 + NT * 5 + (size_t)nq * (8 + 4 + 1 + 1 + 32 + 16)) + 12 * 256 + 4096;
+static size_t search_area_scratch(const orbfe_ctx* c, size_t n_target, int32_t nq, const float* bounds = nullptr) {
+  AreaGrid ag;
+  if (!area_grid(c, bounds, &ag)) ag = {(c->cfg.height + 47) / 48, (c->cfg.width + 63) / 64, 0, 0};
+  const size_t ncells = (size_t)ag.rows * ag.cols, NT = std::max<size_t>(n_target, 1);
+  return ((ncells + 1) * 4 + NT * 9 + (size_t)nq * (8 + 4 + 1 + 1 + 32 + 16)) + 13 * 256 + 4096;
 }
 
 orbfe_status orbfe_search_in_area(orbfe_ctx* c, int32_t slot, int32_t nq, const float* qxy, const float* radius, const int8_t* min_level,
@@ -2328,10 +2354,20 @@ orbfe_status orbfe_search_in_area_features(orbfe_ctx* c, int32_t nt, const orbfe
                                            const float* qxy, const float* radius, const int8_t* min_level, const int8_t* max_level,
                                            const uint8_t* q_desc, const uint8_t* exclude, int32_t* best_idx, int32_t* best_dist,
                                            int32_t* second_dist, int32_t* n_cand) {
+  return orbfe_search_in_area_features_ex(c, nt, t_kps, t_desc, nullptr, nq, qxy, radius, min_level, max_level, q_desc, exclude, best_idx,
+                                          best_dist, second_dist, n_cand, nullptr);
+}
+
+orbfe_status orbfe_search_in_area_features_ex(orbfe_ctx* c, int32_t nt, const orbfe_keypoint* t_kps, const uint8_t* t_desc,
+                                              const float* bounds, int32_t nq, const float* qxy, const float* radius,
+                                              const int8_t* min_level, const int8_t* max_level, const uint8_t* q_desc, const uint8_t* exclude,
+                                              int32_t* best_idx, int32_t* best_dist, int32_t* second_dist, int32_t* n_cand,
+                                              int32_t* excluded_hits) {
   ApiLock api_lk(c);
   if (!c || nt < 0 || nq < 0 || (nt && (!t_kps || !t_desc))) return fail(c, ORBFE_EBADARG, "search_in_area_features: bad count / NULL features");
   if (nq && (!qxy || !radius || !min_level || !max_level || !q_desc || !best_idx || !best_dist || !second_dist || !n_cand))
     return fail(c, ORBFE_EBADARG, "search_in_area_features: NULL argument");
+  if (excluded_hits && nt) std::memset(excluded_hits, 0, (size_t)nt * 4);
   if (nq == 0) return ORBFE_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
@@ -2339,7 +2375,7 @@ orbfe_status orbfe_search_in_area_features(orbfe_ctx* c, int32_t nt, const orbfe
   // the uploaded feature set at the front of the scratch: keypoints | octave list in the layout of the slot arrays | descriptors | count
   const size_t o_k = 0, o_l = o_k + align_up(NT * sizeof(orbfe_keypoint), 256), o_d = o_l + align_up(NT * sizeof(uint4), 256),
                o_n = o_d + align_up(NT * 32, 256), used = o_n + 256;
-  TRY(ensure_tmp(c, used + search_area_scratch(c, NT, nq)));
+  TRY(ensure_tmp(c, used + search_area_scratch(c, NT, nq, bounds)));
   uint8_t* b = (uint8_t*)c->d_tmp;
   std::vector<uint4> kpl(NT, make_uint4(0u, 0u, 0u, 0u));
   for (int i = 0; i < nt; ++i) {
@@ -2358,7 +2394,7 @@ orbfe_status orbfe_search_in_area_features(orbfe_ctx* c, int32_t nt, const orbfe
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // (kpl and nt live on this frame)
   return search_area_core(c, "search_in_area_features", (const orbfe_keypoint*)(b + o_k), (const int32_t*)(b + o_n), (const uint4*)(b + o_l),
                           b + o_d, (size_t)nt, used, nq, qxy, radius, min_level, max_level, q_desc, exclude, best_idx, best_dist,
-                          second_dist, n_cand);
+                          second_dist, n_cand, bounds, excluded_hits);
 }
 
 orbfe_status orbfe_project_map_points(orbfe_ctx* c, int32_t n, const float* pos, const float* view_dir, const float* max_dist,

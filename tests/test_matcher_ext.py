@@ -260,7 +260,18 @@ def test_device_sim3_and_fuse_equal_the_injected_oracle_path(orc, kfs):
     assert all(np.array_equal(x, y) for x, y in zip(a, b)) and (a[3] > 0).sum() > 100
     again = ctx.search_in_area_features(kfC["kps"], kfC["desc"], qxy, rad, lo, hi, kfM["desc"][q], ex)   # nothing was corrupted
     assert all(np.array_equal(x, y) for x, y in zip(again, orc.search_in_area(kfC["kps"], kfC["desc"], W, H, qxy, rad, lo, hi, kfM["desc"][q], ex)))
+    # the extended form: undistorted frame bounds that differ from the image (a distorted camera: VirtualFrame::mfMinU..mfMaxV size the
+    # grid and clip the box) and the per-feature counts of "excluded but in the window" (addMatchInTrack in searchByProjection)
+    for bnd in ((0.0, float(W), 0.0, float(H)), (-23.7, W + 41.2, -11.3, H + 17.9), (5.5, W - 60.25, 2.0, H - 50.5)):
+        a = ctx.search_in_area_features(kfC["kps"], kfC["desc"], qxy, rad, lo, hi, kfM["desc"][q], ex, bounds=bnd, want_hits=True)
+        b = orc.search_in_area_ex(kfC["kps"], kfC["desc"], bnd, qxy, rad, lo, hi, kfM["desc"][q], ex)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), bnd
+        assert a[4].sum() > 50 and (a[4][ex == 0] == 0).all()
+    nohit = ctx.search_in_area_features(kfC["kps"], kfC["desc"], qxy, rad, lo, hi, kfM["desc"][q], None, want_hits=True)
+    assert not nohit[4].any()
     from orb_slam2_ros2_amd._lib import OrbfeError
+    with pytest.raises(OrbfeError):
+        ctx.search_in_area_features(kfC["kps"], kfC["desc"], qxy, rad, lo, hi, kfM["desc"][q], ex, bounds=(10.0, 5.0, 0.0, 100.0))
     neg = kfC["kps"].copy()
     neg["octave"][10] = -1
     with pytest.raises(OrbfeError):

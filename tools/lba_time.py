@@ -11,7 +11,11 @@ fixed = np.zeros(60, np.uint8); fixed[:20] = 1
 pr["poses"][:20] = pr["poses_true"][:20]
 ctx = Context(640, 480, n_features=500, max_images=1)
 ctx.ba_local_optimize(pr, fixed)
-t0 = time.perf_counter(); g = ctx.ba_local_optimize(pr, fixed); t1 = time.perf_counter()
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+t0 = time.perf_counter()
+for _ in range(reps):
+    g = ctx.ba_local_optimize(pr, fixed)
+t1 = t0 + (time.perf_counter() - t0) / reps
 orc = pyoracle.Oracle(pyoracle.build(fast=True, out_dir="/tmp/orb_oracle_lba"))
 t2 = time.perf_counter(); o = orc.ba_local_optimize(pr, fixed); t3 = time.perf_counter()
 print(f"edges {len(pr['edge_pose'])} free poses 40: device {1e3 * (t1 - t0):.1f} ms, cpu oracle {1e3 * (t3 - t2):.1f} ms, iters {g['iters']}, "
