@@ -9,6 +9,11 @@
 //   orbfe::dropin::OptimizePoseOnly       the body of `static int Optimizer::OptimizePoseOnly(Frame::SharedPtr)` (Optimizer.h:72, src/Optimizer.cc:33-203)
 //   orbfe::dropin::OptimizeLocalMap       the body of `static void Optimizer::OptimizeLocalMap(KeyFrame::SharedPtr, bool&)` (Optimizer.h:69,
 //                                         src/Optimizer.cc:225-442)
+//   orbfe::dropin::searchByBow            the body of `int ORBMatcher::searchByBow(VirtualFrame::SharedPtr, VirtualFrame::SharedPtr,
+//                                         std::vector<cv::DMatch>&, bool, bool)` (ORBMatcher.h:42, src/ORBMatcher.cc:170-253)
+//   orbfe::dropin::searchByProjection x2  frame <- frame (ORBMatcher.h:49, src/ORBMatcher.cc:265-347) and frame <- map points (ORBMatcher.h:52,
+//                                         :561-612)
+//   orbfe::dropin::frameRGBD              the tail of `Frame::Frame` for RGB-D input (src/Frame.cc:130-131, :139-157)
 //
 // The three bodies are templates over the reference's Frame / KeyFrame / MapPoint / Camera types (they only use the accessors
 // the reference's own function bodies use), so this header does not have to see the reference's headers; INTEGRATION.md shows the
@@ -18,6 +23,7 @@
 #pragma once
 #include <opencv2/core.hpp>
 
+#include <atomic>
 #include <set>
 
 #include "orbfe_shim.hpp"
@@ -96,19 +102,12 @@ inline int descDistance(const cv::Mat& a, const cv::Mat& b) {
   return d;
 }
 
-// int ORBMatcher::searchByStereo(Frame::SharedPtr pFrame)  (src/ORBMatcher.cc:18-81).  Uses pFrame->mvFeatsLeft, mvDepths, mvFeatsRightU,
-// mpExtractorLeft / mpExtractorRight (ORBMatcher is a friend of Frame, Frame.h:302-303) and Camera::mfFx / mfBf.
-template <class CameraT, class FramePtr>
-int searchByStereo(FramePtr pFrame) {
-  const size_t nLeft = pFrame->mvFeatsLeft.size();
-  std::vector<double> ru, dp;
-  const int n = orbfe::ORBMatcher().searchByStereo(pFrame->mpExtractorLeft->device(), pFrame->mpExtractorRight->device(), CameraT::mfFx,
-                                                   CameraT::mfBf, ru, dp);
-  ru.resize(nLeft, -1.0);
-  dp.resize(nLeft, -1.0);
-  pFrame->mvFeatsRightU.assign(ru.begin(), ru.end());
-  pFrame->mvDepths.assign(dp.begin(), dp.end());
-  return n;
+// A context of its own for the guided searches of every calling thread (Tracking, LocalMapping and LoopClosing all match: System.cc:119-129);
+// the searches below upload the target's feature set and pass the target frame's own bounds, so the context's geometry is a token.
+inline orbfe_ctx* matcherContext() {
+  static std::atomic<int> nextRole{0};
+  thread_local const int role = nextRole.fetch_add(1) % 16;
+  return ContextPool::get(160, 120, 16, 1, 1.2f, 20, 7, "", 0, 1, 1000 + role);
 }
 
 inline void matToPose(const cv::Mat& Rcw, const cv::Mat& tcw, double out[7]) {  // Converter::ConvertTcw2SE3 (src/Optimizer.cc:628-641)
@@ -132,9 +131,32 @@ inline cv::Mat poseToMat(const double p[7]) {  // Converter::ConvertSE32Tcw (:64
   return T;
 }
 
+// The bodies.  They read and write what the reference's own member functions read and write, protected members included
+// (mvFeatsLeft, mvLeftDescriptor, mvpMapPoints, mFeatVec, mvDepths, mvFeatsRightU, mpExtractorLeft ...): ORBMatcher / Optimizer are
+// friends of the frame classes (Frame.h:23, :302-303), but friendship does not reach a function they call -- so the bodies are static
+// members of ONE struct, and the frame classes name it next to their existing friend lines:
+//     friend struct orbfe::dropin::Bodies;       // VirtualFrame, Frame, KeyFrame (beside `friend class ORBMatcher;`)
+// tests/cpp/test_dropin.cpp keeps the stand-in classes' members protected with exactly that line.  The free functions of the same names
+// after the struct forward to it.
+struct Bodies {
+// int ORBMatcher::searchByStereo(Frame::SharedPtr pFrame)  (src/ORBMatcher.cc:18-81).  Uses pFrame->mvFeatsLeft, mvDepths, mvFeatsRightU,
+// mpExtractorLeft / mpExtractorRight (ORBMatcher is a friend of Frame, Frame.h:302-303) and Camera::mfFx / mfBf.
+template <class CameraT, class FramePtr>
+static int searchByStereo(FramePtr pFrame) {
+  const size_t nLeft = pFrame->mvFeatsLeft.size();
+  std::vector<double> ru, dp;
+  const int n = orbfe::ORBMatcher().searchByStereo(pFrame->mpExtractorLeft->device(), pFrame->mpExtractorRight->device(), CameraT::mfFx,
+                                                   CameraT::mfBf, ru, dp);
+  ru.resize(nLeft, -1.0);
+  dp.resize(nLeft, -1.0);
+  pFrame->mvFeatsRightU.assign(ru.begin(), ru.end());
+  pFrame->mvDepths.assign(dp.begin(), dp.end());
+  return n;
+}
+
 // static int Optimizer::OptimizePoseOnly(Frame::SharedPtr pFrame)  (src/Optimizer.cc:33-203)
 template <class CameraT, class FramePtr>
-int OptimizePoseOnly(FramePtr pFrame) {
+static int OptimizePoseOnly(FramePtr pFrame) {
   auto mapPoints = pFrame->getMapPoints();
   const auto& kps = pFrame->getLeftKeyPoints();
   const size_t N = pFrame->mvFeatsLeft.size();
@@ -194,7 +216,7 @@ int OptimizePoseOnly(FramePtr pFrame) {
 // Vertex / edge order: the reference walks a std::set of map-point pointers (address order); here the map points go in ascending
 // getID() so that a run is reproducible -- the order only permutes the sums of the normal equations.
 template <class CameraT, class KeyFramePtr>
-void OptimizeLocalMap(KeyFramePtr pkframe, bool& isStop) {
+static void OptimizeLocalMap(KeyFramePtr pkframe, bool& isStop) {
   using KeyFrameT = typename KeyFramePtr::element_type;
   auto group = pkframe->getConnectedKfs(0);
   group.push_back(pkframe);
@@ -299,6 +321,310 @@ void OptimizeLocalMap(KeyFramePtr pkframe, bool& isStop) {
     }
   }
   KeyFrameT::updateConnections(pkframe);
+}
+
+  // ---- the per-frame guided matchers (include/ORB_SLAM2/ORBMatcher.h:42,49,52) ---------------------------------------------------------
+  static void descRows(const std::vector<cv::Mat>& rows, std::vector<Descriptor>& out) {
+    out.resize(rows.size());
+    for (size_t i = 0; i < rows.size(); ++i) std::memcpy(out[i].data(), rows[i].data, 32);
+  }
+  static void toKeypoints(const std::vector<cv::KeyPoint>& kps, std::vector<orbfe_keypoint>& out) {
+    static_assert(sizeof(cv::KeyPoint) == sizeof(orbfe_keypoint), "cv::KeyPoint layout");
+    out.resize(kps.size());
+    if (!kps.empty()) std::memcpy((void*)out.data(), kps.data(), sizeof(orbfe_keypoint) * kps.size());
+  }
+  // ORBMatcher::verifyAngle (src/ORBMatcher.cc:1013-1051)
+  static void verifyAngle(std::vector<cv::DMatch>& matches, const std::vector<cv::KeyPoint>& keyPoints1,
+                          const std::vector<cv::KeyPoint>& keyPoints2) {
+    const int nBins = orbfe::ORBMatcher::mnBinNum;
+    std::vector<std::vector<cv::DMatch>> hist((size_t)nBins);
+    for (const auto& dmatch : matches) {
+      float diff = keyPoints1[dmatch.queryIdx].angle - keyPoints2[dmatch.trainIdx].angle;
+      diff = diff >= 0 ? diff : 360 + diff;
+      int bin = diff / (360 / nBins);
+      if (bin == 30) bin = 0;
+      hist[(size_t)bin].push_back(dmatch);
+    }
+    std::set<std::size_t> goodBinIds;
+    for (int c = 0; c < orbfe::ORBMatcher::mnBinChoose; ++c) {
+      int maxSize = 0;
+      std::size_t maxId = 0;
+      bool bInit = false;
+      for (std::size_t id = 0; id < (std::size_t)nBins; ++id) {
+        if (goodBinIds.count(id)) continue;
+        if ((int)hist[id].size() > maxSize) maxId = id, maxSize = (int)hist[id].size(), bInit = true;
+      }
+      if (bInit) goodBinIds.insert(maxId);
+    }
+    std::vector<cv::DMatch> ret;
+    for (auto id : goodBinIds) ret.insert(ret.end(), hist[id].begin(), hist[id].end());
+    matches.swap(ret);
+  }
+  // ORBMatcher::setMapPoints (src/ORBMatcher.cc:815-830)
+  template <class MapPoints>
+  static void setMapPoints(MapPoints& toMatchMps, MapPoints& matchMps, const std::vector<cv::DMatch>& matches) {
+    for (const auto& dmatch : matches) {
+      auto& matchPMp = matchMps[dmatch.trainIdx];
+      if (matchPMp && !matchPMp->isBad()) {
+        matchPMp->addMatchInTrack();
+        toMatchMps[dmatch.queryIdx] = matchPMp;
+      } else {
+        matchPMp = nullptr;
+      }
+    }
+  }
+
+  // int ORBMatcher::searchByBow(VirtualFrame::SharedPtr pFrame, VirtualFrame::SharedPtr pKframe, std::vector<cv::DMatch>& matches,
+  //                             bool bAddMPs, bool bLoop)   (ORBMatcher.h:42, src/ORBMatcher.cc:170-253); mfRatio / mbCheckOri: the matcher's
+  // members.  All getBestMatch scans of the call (one per keyframe feature that shares a vocabulary node with the frame) run as ONE
+  // orbfe_match_bruteforce launch over CSR candidate lists in the reference's order.
+  template <class FramePtrF, class FramePtrK>
+  static int searchByBow(FramePtrF pFrame, FramePtrK pKframe, std::vector<cv::DMatch>& matches, bool bAddMPs, bool bLoop, float mfRatio,
+                         bool mbCheckOri) {
+    pFrame->computeBow();
+    pKframe->computeBow();
+    auto mapPointsF = pFrame->getMapPoints();
+    auto mapPointsKF = pKframe->getMapPoints();
+    std::map<unsigned, std::vector<unsigned>> fvF, fvK;  // DBoW3::FeatureVector: node id -> feature ids, ordered by node id
+    for (const auto& node : pFrame->mFeatVec) fvF[(unsigned)node.first].assign(node.second.begin(), node.second.end());
+    for (const auto& node : pKframe->mFeatVec) fvK[(unsigned)node.first].assign(node.second.begin(), node.second.end());
+    auto flags = [](decltype(mapPointsF)& mps, std::vector<uint8_t>& good, std::vector<uint8_t>& inMap) {
+      good.assign(mps.size(), 0), inMap.assign(mps.size(), 0);
+      for (size_t i = 0; i < mps.size(); ++i) {
+        good[i] = mps[i] && !mps[i]->isBad();
+        inMap[i] = good[i] && mps[i]->isInMap();
+      }
+    };
+    std::vector<uint8_t> goodF, inMapF, goodK, inMapK;
+    flags(mapPointsF, goodF, inMapF);
+    flags(mapPointsKF, goodK, inMapK);
+    std::vector<Descriptor> descF, descK;
+    descRows(pFrame->mvLeftDescriptor, descF);
+    descRows(pKframe->mvLeftDescriptor, descK);
+    const std::vector<float> noAngles;  // the orientation check runs below, on the caller's whole `matches` as the reference does
+    if (!fvF.empty() && !fvK.empty()) {
+      const auto found = orbfe::ORBMatcher(mfRatio, false).searchByBow(matcherContext(), descF, descK, fvF, fvK, goodF, inMapF, goodK, inMapK,
+                                                                       noAngles, noAngles, bAddMPs, bLoop);
+      for (const auto& m : found) matches.emplace_back(m.queryIdx, m.trainIdx, (float)m.distance);
+    }
+    if (mbCheckOri) verifyAngle(matches, pFrame->getLeftKeyPoints(), pKframe->getLeftKeyPoints());
+    if (!bAddMPs && !bLoop) setMapPoints(pFrame->mvpMapPoints, mapPointsKF, matches);
+    return (int)matches.size();
+  }
+
+  // what findFeaturesInArea needs of the TARGET frame, uploaded with the call (orbfe_search_in_area_features_ex): its features, its
+  // descriptors and its undistorted bounds (VirtualFrame::mfMinU .. mfMaxV)
+  struct Target {
+    std::vector<orbfe_keypoint> kps;
+    std::vector<Descriptor> desc;
+    float bounds[4];
+  };
+  template <class FramePtr>
+  static void target(FramePtr f, Target& t) {
+    toKeypoints(f->mvFeatsLeft, t.kps);
+    descRows(f->mvLeftDescriptor, t.desc);
+    t.bounds[0] = f->mfMinU, t.bounds[1] = f->mfMaxU, t.bounds[2] = f->mfMinV, t.bounds[3] = f->mfMaxV;
+  }
+  struct Queries {
+    std::vector<int> who;
+    std::vector<float> uv, radius;
+    std::vector<int8_t> lo, hi;
+    std::vector<Descriptor> desc;
+    void add(int id, float u, float v, float r, int minLevel, int maxLevel, const cv::Mat& d) {
+      who.push_back(id), uv.push_back(u), uv.push_back(v), radius.push_back(r), lo.push_back((int8_t)minLevel), hi.push_back((int8_t)maxLevel);
+      desc.emplace_back();
+      std::memcpy(desc.back().data(), d.data, 32);
+    }
+  };
+  static orbfe::ORBMatcher::AreaMatch searchTarget(const Target& t, const Queries& q, const std::vector<uint8_t>* exclude,
+                                                   std::vector<int32_t>* excludedHits) {
+    const int32_t n = (int32_t)q.who.size();
+    orbfe::ORBMatcher::AreaMatch m;
+    m.bestIdx.resize(n), m.bestDist.resize(n), m.secondDist.resize(n), m.nCand.resize(n);
+    if (excludedHits) excludedHits->assign(std::max<size_t>(t.kps.size(), 1), 0);
+    orbfe_ctx* ctx = matcherContext();
+    check(ctx, orbfe_search_in_area_features_ex(ctx, (int32_t)t.kps.size(), t.kps.data(), t.desc.empty() ? nullptr : t.desc[0].data(), t.bounds, n,
+                                                q.uv.data(), q.radius.data(), q.lo.data(), q.hi.data(), n ? q.desc[0].data() : nullptr,
+                                                exclude ? exclude->data() : nullptr, m.bestIdx.data(), m.bestDist.data(), m.secondDist.data(),
+                                                m.nCand.data(), excludedHits ? excludedHits->data() : nullptr));
+    return m;
+  }
+
+  // int ORBMatcher::searchByProjection(VirtualFrame::SharedPtr pFrame1, VirtualFrame::SharedPtr pFrame2, std::vector<cv::DMatch>& matches,
+  //                                    float th, bool bFuse)   (ORBMatcher.h:49, src/ORBMatcher.cc:265-347)
+  template <class CameraT, class FramePtr1, class FramePtr2>
+  static int searchByProjection(FramePtr1 pFrame1, FramePtr2 pFrame2, std::vector<cv::DMatch>& matches, float th, bool bFuse, float mfRatio) {
+    matches.clear();
+    cv::Mat Rcw1, tcw1, Rcw2, tcw2;
+    pFrame1->getPose(Rcw1, tcw1);
+    pFrame2->getPose(Rcw2, tcw2);
+    // twc1 = -Rcw1.t() * tcw1;  tlc = Rcw2 * twc1 + tcw2   (cv::gemm on 3x3 / 3x1 floats: products summed in float, alpha / beta in double)
+    float twc1[3], z = 0.f;
+    for (int r = 0; r < 3; ++r) {
+      const float sm = Rcw1.template at<float>(0, r) * tcw1.template at<float>(0, 0) + Rcw1.template at<float>(1, r) * tcw1.template at<float>(1, 0) +
+                       Rcw1.template at<float>(2, r) * tcw1.template at<float>(2, 0);
+      twc1[r] = (float)(-1.0 * (double)sm);
+    }
+    {
+      const float sm = Rcw2.template at<float>(2, 0) * twc1[0] + Rcw2.template at<float>(2, 1) * twc1[1] + Rcw2.template at<float>(2, 2) * twc1[2];
+      z = (float)((double)sm + (double)tcw2.template at<float>(2, 0));
+    }
+    const float zabs = std::abs(z);
+    bool up = false, down = false;
+    if (zabs > CameraT::mfBl) z > 0 ? up = true : down = true;
+    auto mps1 = pFrame1->getMapPoints();
+    auto mps2 = pFrame2->getMapPoints();
+    Queries q;
+    for (std::size_t idx = 0; idx < mps2.size(); ++idx) {
+      auto pMp2 = mps2[idx];
+      if (!pMp2 || pMp2->isBad()) continue;
+      if (bFuse) {
+        float vecDistance, cosTheta;
+        cv::Point2f uv;
+        if (!pMp2->isInVision(pFrame1, vecDistance, uv, cosTheta)) continue;
+      }
+      const auto& feature = pFrame2->mvFeatsLeft[idx];
+      int minOctave, maxOctave;
+      if (up)
+        minOctave = feature.octave, maxOctave = 7;
+      else if (down)
+        minOctave = 0, maxOctave = feature.octave;
+      else
+        minOctave = std::max(0, feature.octave - 1), maxOctave = std::min(feature.octave + 1, 7);
+      // findFeaturesInArea (src/Frame.cc:286-311): radius * getScaledFactor2(kp.octave)
+      q.add((int)idx, feature.pt.x, feature.pt.y, th * pFrame1->getScaledFactor2(feature.octave), minOctave, maxOctave, pFrame2->mvLeftDescriptor[idx]);
+    }
+    if (!q.who.empty()) {
+      Target t;
+      target(pFrame1, t);
+      std::vector<uint8_t> hasGood;  // !bFuse: features of frame 1 that keep their map point are no candidates (:321-331) ...
+      std::vector<int32_t> hits;
+      if (!bFuse) {
+        hasGood.assign(std::max<size_t>(t.kps.size(), 1), 0);
+        for (size_t c = 0; c < mps1.size() && c < hasGood.size(); ++c) hasGood[c] = mps1[c] && !mps1[c]->isBad();
+      }
+      const auto m = searchTarget(t, q, bFuse ? nullptr : &hasGood, bFuse ? nullptr : &hits);
+      if (!bFuse)  // ... and addMatchInTrack is called once for every query that had such a feature in its window
+        for (size_t c = 0; c < mps1.size() && c < hits.size(); ++c)
+          for (int32_t k = 0; k < hits[c]; ++k) mps1[c]->addMatchInTrack();
+      for (size_t k = 0; k < q.who.size(); ++k) {
+        if (m.nCand[k] <= 0) continue;
+        const float ratio = (float)m.bestDist[k] / (float)m.secondDist[k];
+        if (ratio < mfRatio && m.bestDist[k] < orbfe::ORBMatcher::mnMinThreshold) matches.emplace_back(m.bestIdx[k], q.who[k], (float)m.bestDist[k]);
+      }
+    }
+    if (!bFuse) setMapPoints(pFrame1->mvpMapPoints, pFrame2->mvpMapPoints, matches);
+    return (int)matches.size();
+  }
+
+  // int ORBMatcher::searchByProjection(VirtualFrame::SharedPtr pframe, const std::vector<MapPoint::SharedPtr>& mapPoints, float th,
+  //                                    std::vector<cv::DMatch>& matches, bool bFuse)   (ORBMatcher.h:52, src/ORBMatcher.cc:561-612)
+  // nLevels = ORBExtractor::mnLevels.  isInVision / predictLevel are the map point's own methods, per point as there; the
+  // findFeaturesInArea + getBestMatch of ALL visible points are one launch.
+  template <class FramePtr, class MapPointPtr>
+  static int searchByProjection(FramePtr pframe, const std::vector<MapPointPtr>& mapPoints, float th, std::vector<cv::DMatch>& matches, bool bFuse,
+                                float mfRatio, int nLevels) {
+    int nMatches = 0;
+    auto pFrameMapPoints = pframe->getMapPoints();
+    if (!bFuse)
+      for (auto& pMp : pFrameMapPoints)
+        if (pMp && !pMp->isBad()) ++nMatches;
+    Queries q;
+    for (std::size_t idx = 0; idx < mapPoints.size(); ++idx) {
+      auto pMp = mapPoints[idx];
+      if (!pMp || pMp->isBad() || !pMp->isInMap()) continue;
+      float distance, cosTheta;
+      cv::KeyPoint kp;
+      if (!pMp->isInVision(pframe, distance, kp.pt, cosTheta)) continue;
+      kp.octave = pMp->predictLevel(distance);
+      const float radius = cosTheta > 0.998f ? 2.5f : 4.0f;
+      const int minLevel = std::max(0, kp.octave - 1), maxLevel = std::min(nLevels - 1, kp.octave + 1);
+      q.add((int)idx, kp.pt.x, kp.pt.y, (radius * th) * pframe->getScaledFactor2(kp.octave), minLevel, maxLevel, pMp->getDesc());
+    }
+    if (q.who.empty()) return nMatches;
+    Target t;
+    target(pframe, t);
+    const auto m = searchTarget(t, q, nullptr, nullptr);
+    for (size_t k = 0; k < q.who.size(); ++k) {
+      if (m.nCand[k] <= 0) continue;
+      const float fRatio = (float)m.bestDist[k] / (float)m.secondDist[k];
+      if (!(m.bestDist[k] < orbfe::ORBMatcher::mnMinThreshold && fRatio < mfRatio)) continue;
+      auto pMp = mapPoints[(size_t)q.who[k]];
+      if (!bFuse) {
+        auto pMpInF = pframe->getMapPoint((std::size_t)m.bestIdx[k]);  // sees the assignments made earlier in this loop, as the reference's does
+        if (!pMpInF || pMpInF->isBad() || !pMpInF->isInMap()) {
+          pframe->setMapPoint(m.bestIdx[k], pMp);
+          pMp->addMatchInTrack();
+          ++nMatches;
+        }
+      } else {
+        matches.push_back(cv::DMatch(m.bestIdx[k], q.who[k], (float)m.bestDist[k]));
+        ++nMatches;
+      }
+    }
+    return nMatches;
+  }
+
+  // The tail of Frame::Frame (RGB-D) after extract() (src/Frame.cc:130-131, :139-157): depthImg.convertTo(CV_32F) / dScale, the copy of the
+  // distorted keypoints, Camera::undistortPoints(mvFeatsLeft), the depth / rightU lookup -- as one call on the extractor's slot.  depthImg
+  // as read from the file: CV_16U (TUM) or CV_32F.  initGrid() stays with the caller (the grid is rebuilt on the device per search).
+  template <class CameraT, class FrameT>
+  static void frameRGBD(FrameT* self, const cv::Mat& depthImg, float dScale) {
+    const auto& ext = self->mpExtractorLeft->device();
+    if (!ext.resident()) throw std::logic_error("frameRGBD: the extractor's slot has been re-used since extract()");
+    orbfe_camera cam{};
+    cam.fx = CameraT::mfFx, cam.fy = CameraT::mfFy, cam.cx = CameraT::mfCx, cam.cy = CameraT::mfCy, cam.bf = CameraT::mfBf;
+    if (!CameraT::mDistCoeff.empty()) {
+      const int nd = CameraT::mDistCoeff.rows * CameraT::mDistCoeff.cols;
+      float d[5] = {0, 0, 0, 0, 0};
+      for (int i = 0; i < nd && i < 5; ++i) d[i] = CameraT::mDistCoeff.template at<float>(i);
+      cam.k1 = d[0], cam.k2 = d[1], cam.p1 = d[2], cam.p2 = d[3], cam.k3 = d[4];
+    }
+    const size_t n = self->mvFeatsLeft.size();
+    const size_t cap = (size_t)std::max<int>(orbfe_get_capacity(ext.context()), 1);
+    std::vector<orbfe_keypoint> und(cap);
+    std::vector<double> depth(cap), rightU(cap);
+    const int type = depthImg.type() == CV_32F ? 1 : 0;
+    if (depthImg.type() != CV_32F && depthImg.type() != CV_16U) throw std::invalid_argument("frameRGBD: depth image must be CV_16U or CV_32F");
+    check(ext.context(), orbfe_frame_rgbd(ext.context(), ext.slot(), &cam, depthImg.data, type, depthImg.step, dScale, und.data(), depth.data(),
+                                          rightU.data()));
+    std::memcpy((void*)self->mvFeatsLeft.data(), und.data(), sizeof(orbfe_keypoint) * n);
+    self->mvpMapPoints.resize(n, nullptr);
+    self->mvDepths.assign(depth.begin(), depth.begin() + n);
+    self->mvFeatsRightU.assign(rightU.begin(), rightU.begin() + n);
+  }
+};  // struct Bodies
+
+// the same bodies as free functions (what INTEGRATION.md's one-line members call)
+template <class CameraT, class FramePtr>
+int searchByStereo(FramePtr pFrame) {
+  return Bodies::template searchByStereo<CameraT>(pFrame);
+}
+template <class CameraT, class FramePtr>
+int OptimizePoseOnly(FramePtr pFrame) {
+  return Bodies::template OptimizePoseOnly<CameraT>(pFrame);
+}
+template <class CameraT, class KeyFramePtr>
+void OptimizeLocalMap(KeyFramePtr pkframe, bool& isStop) {
+  Bodies::template OptimizeLocalMap<CameraT>(pkframe, isStop);
+}
+template <class FramePtrF, class FramePtrK>
+int searchByBow(FramePtrF pFrame, FramePtrK pKframe, std::vector<cv::DMatch>& matches, bool bAddMPs, bool bLoop, float mfRatio = 0.6f,
+                bool mbCheckOri = true) {
+  return Bodies::searchByBow(pFrame, pKframe, matches, bAddMPs, bLoop, mfRatio, mbCheckOri);
+}
+template <class CameraT, class FramePtr1, class FramePtr2>
+int searchByProjection(FramePtr1 pFrame1, FramePtr2 pFrame2, std::vector<cv::DMatch>& matches, float th, bool bFuse, float mfRatio = 0.6f) {
+  return Bodies::template searchByProjection<CameraT>(pFrame1, pFrame2, matches, th, bFuse, mfRatio);
+}
+template <class FramePtr, class MapPointPtr>
+int searchByProjection(FramePtr pframe, const std::vector<MapPointPtr>& mapPoints, float th, std::vector<cv::DMatch>& matches, bool bFuse,
+                       float mfRatio, int nLevels) {
+  return Bodies::searchByProjection(pframe, mapPoints, th, matches, bFuse, mfRatio, nLevels);
+}
+template <class CameraT, class FrameT>
+void frameRGBD(FrameT* self, const cv::Mat& depthImg, float dScale) {
+  Bodies::template frameRGBD<CameraT>(self, depthImg, dScale);
 }
 
 }  // namespace dropin

@@ -82,15 +82,17 @@ inline std::vector<int8_t> loadBriefTemplate(const std::string& path) {
 class ContextPool {
  public:
   static constexpr int kSlots = 4;  // two stereo frames' worth: the frame being built and the one before it
-  using Key = std::tuple<int, int, int, int, float, int, int, std::string, int, int>;
+  using Key = std::tuple<int, int, int, int, float, int, int, std::string, int, int, int>;
   struct Lease {
     int slot = -1;
     uint64_t generation = 0;
   };
   static orbfe_ctx* get(int w, int h, int nFeatures, int nLevels, float scale, int maxTh, int minTh, const std::string& tplPath,
-                        int device = 0, int maxImages = kSlots) {
+                        int device = 0, int maxImages = kSlots, int tag = 0) {
+    // tag: contexts that differ in nothing else -- one per calling thread role (dropin::matcherContext / solverContext): a context
+    // serves one call at a time, and the reference's matchers and optimisers run on three threads at once (System.cc:119-129)
     std::lock_guard<std::mutex> lk(mu());
-    Key key{w, h, nFeatures, nLevels, scale, maxTh, minTh, tplPath, device, maxImages};
+    Key key{w, h, nFeatures, nLevels, scale, maxTh, minTh, tplPath, device, maxImages, tag};
     auto it = pool().find(key);
     if (it != pool().end()) return it->second.get();
     std::vector<int8_t> tpl;

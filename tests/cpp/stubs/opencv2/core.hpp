@@ -11,6 +11,7 @@
 
 #define CV_8U 0
 #define CV_8UC1 0
+#define CV_16U 2
 #define CV_32F 5
 #define CV_Assert(expr) assert(expr)
 
@@ -26,6 +27,13 @@ struct KeyPoint {  // same members, order and size (28 bytes) as cv::KeyPoint
   Point2f pt;
   float size = 0.f, angle = -1.f, response = 0.f;
   int octave = 0, class_id = -1;
+};
+
+struct DMatch {  // same members as cv::DMatch
+  int queryIdx = -1, trainIdx = -1, imgIdx = -1;
+  float distance = 3.402823466e+38f;
+  DMatch() = default;
+  DMatch(int q, int t, float d) : queryIdx(q), trainIdx(t), imgIdx(-1), distance(d) {}
 };
 
 class Mat {
@@ -69,7 +77,7 @@ class Mat {
   }
 
  private:
-  size_t elem() const { return type_ == CV_32F ? 4 : 1; }
+  size_t elem() const { return type_ == CV_32F ? 4 : (type_ == CV_16U ? 2 : 1); }
   int type_ = CV_8U;
   std::shared_ptr<std::vector<uint8_t>> own_;
 };

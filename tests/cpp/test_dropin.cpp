@@ -7,22 +7,29 @@
 //                                             every result compared with a single-threaded run           -> "THREADS_OK ..."
 //   localba <map.pb> <kf id>                  the KeyFrame adapter against the array-level path on the same map -> "LOCALBA_OK ..."
 //   poseonly                                  the Frame adapter against the array-level call              -> "POSEONLY_OK ..."
+//   matchers <L.raw> <R.raw> <w> <h>          searchByBow / searchByProjection x2 with the reference's signatures against the array-level
+//                                             mirrors on the same frames and map state                   -> "MATCHERS_OK ..."
+//   rgbd <gray.raw> <w> <h>                   the RGB-D tail of Frame::Frame against orbfe_frame_rgbd    -> "RGBD_OK ..."
+//   access                                    host-only: every matcher body instantiated on a class with PROTECTED members + the friend line
 //   latency <L.raw> <R.raw> <w> <h> <iters>   timing of Frame::Frame (two threads) + searchByStereo per pair, host to host -> "LATENCY_OK ..."
 // Exit 3 + "NO_DEVICE" when no HIP device is usable (there is no CPU fallback).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <numeric>
 #include <thread>
 
 #include "../../orb_slam2_ros2_amd/host/orbfe_dropin.hpp"
 
 namespace ref {  // ---- stand-ins with the reference's accessor names ----------------------------------------------------------------
 struct Camera {
-  static inline float mfFx = 718.856f, mfFy = 718.856f, mfCx = 607.1928f, mfCy = 185.2157f, mfBf = 718.856f * 0.537166f;
+  static inline float mfFx = 718.856f, mfFy = 718.856f, mfCx = 607.1928f, mfCy = 185.2157f, mfBf = 718.856f * 0.537166f, mfBl = 0.537166f;
+  static inline cv::Mat mDistCoeff;
 };
 
 struct KeyFrame;
+struct VirtualFrame;
 struct MapPoint {
   typedef std::shared_ptr<MapPoint> SharedPtr;
   typedef std::function<bool(std::weak_ptr<KeyFrame>, std::weak_ptr<KeyFrame>)> Cmp;
@@ -40,6 +47,20 @@ struct MapPoint {
   cv::Mat getPos() const { return mPos.clone(); }
   void setPos(cv::Mat p) { mPos = p.clone(); }
   void addInlierInTrack() { ++nInlier; }
+  // what the guided matchers read of a map point (MapPoint.h): the stand-in returns stored answers -- the adapters only forward them
+  int nMatchInTrack = 0, mLevel = 0;
+  bool mVisible = false;
+  float mDist = 0.f, mCos = 1.f;
+  cv::Point2f mUV;
+  cv::Mat mDesc;
+  void addMatchInTrack() { ++nMatchInTrack; }
+  template <class FramePtr>
+  bool isInVision(FramePtr, float& dist, cv::Point2f& uv, float& cosTheta) {
+    dist = mDist, uv = mUV, cosTheta = mCos;
+    return mVisible;
+  }
+  int predictLevel(float) { return mLevel; }
+  cv::Mat getDesc() { return mDesc; }
   void updateDescriptor() { ++nDescUpdates; }
   void updateNormalAndDepth() { ++nNormalUpdates; }
   void eraseObservetion(std::shared_ptr<KeyFrame> kf, bool = true) { mObs.erase(kf); }
@@ -55,7 +76,13 @@ struct VirtualFrame {
   std::vector<double> mvDepths, mvFeatsRightU;
   std::vector<MapPoint::SharedPtr> mvpMapPoints;
   cv::Mat mRcw, mtcw;
-  float mfMaxU = 0, mfMaxV = 0;
+  float mfMaxU = 0, mfMaxV = 0, mfMinU = 0, mfMinV = 0;
+  std::vector<cv::Mat> mvLeftDescriptor;
+  std::map<unsigned, std::vector<unsigned>> mFeatVec;  // DBoW3::FeatureVector is a std::map<NodeId, std::vector<unsigned>>
+  int nBowCalls = 0;
+  void computeBow() { ++nBowCalls; }
+  MapPoint::SharedPtr getMapPoint(std::size_t idx) { return mvpMapPoints[idx]; }
+  void setMapPoint(int idx, MapPoint::SharedPtr p) { mvpMapPoints[idx] = p; }
   std::vector<MapPoint::SharedPtr> getMapPoints() { return mvpMapPoints; }
   const std::vector<cv::KeyPoint>& getLeftKeyPoints() const { return mvFeatsLeft; }
   const cv::KeyPoint& getLeftKeyPoint(const std::size_t& i) const { return mvFeatsLeft[i]; }
@@ -83,7 +110,7 @@ struct Frame : VirtualFrame {
   cv::Mat mLeftIm, mRightIm;
   ORB_SLAM2_ROS2::ORBExtractor::SharedPtr mpExtractorLeft, mpExtractorRight;
   std::vector<cv::KeyPoint> mvFeatsRight;
-  std::vector<cv::Mat> mvLeftDescriptor, mRightDescriptor;
+  std::vector<cv::Mat> mRightDescriptor;
   int mnN = 0;
   // Frame::Frame stereo (src/Frame.cc:85-111), threads as there
   Frame(cv::Mat l, cv::Mat r, bool threads) : mLeftIm(l), mRightIm(r) {
@@ -112,7 +139,6 @@ struct KeyFrame : VirtualFrame {
   std::size_t getID() const { return mnId; }
   bool isBad() const { return mbBad; }
   std::vector<SharedPtr> getConnectedKfs(int) { return mConnected; }
-  void setMapPoint(std::size_t idx, MapPoint::SharedPtr p) { mvpMapPoints[idx] = p; }
   static void updateConnections(SharedPtr) { ++nUpdateConnections; }
 };
 }  // namespace ref
@@ -222,6 +248,315 @@ static int mode_latency(int argc, char** argv) {
   printf("LATENCY_OK %d %.1f %.1f %.1f %.1f %.1f %.1f %zu %d %016llx\n", iters, pct(total[1], 0.5), pct(total[1], 0.99), pct(ext[1], 0.5),
          pct(total[0], 0.5), pct(total[0], 0.99), pct(ext[0], 0.5), nl, nm, (unsigned long long)want);
   return 0;
+}
+
+// ---- the per-frame guided matchers with the reference's signatures against the array-level mirrors (orbfe_shim.hpp, oracle-checked in
+// tests/test_guided_wrappers.py / test_matcher_ext.py) on frames extracted from the two images -------------------------------------------
+static std::vector<orbfe::Descriptor> rows_of(const std::vector<cv::Mat>& d) {
+  std::vector<orbfe::Descriptor> out(d.size());
+  for (size_t i = 0; i < d.size(); ++i) std::memcpy(out[i].data(), d[i].data, 32);
+  return out;
+}
+static std::vector<orbfe_keypoint> kps_of(const std::vector<cv::KeyPoint>& k) {
+  std::vector<orbfe_keypoint> out(k.size());
+  if (!k.empty()) std::memcpy((void*)out.data(), k.data(), k.size() * sizeof(orbfe_keypoint));
+  return out;
+}
+static bool same_matches(const std::vector<cv::DMatch>& a, const std::vector<orbfe::ORBMatcher::DMatch>& b) {
+  if (a.size() != b.size()) return false;
+  for (size_t i = 0; i < a.size(); ++i)
+    if (a[i].queryIdx != b[i].queryIdx || a[i].trainIdx != b[i].trainIdx || a[i].distance != (float)b[i].distance) return false;
+  return true;
+}
+// VirtualFrame::findFeaturesInArea (src/Frame.cc:286-311) over all features, without a grid: membership is by CELL, not by distance
+static std::vector<int> area_members(const std::vector<cv::KeyPoint>& feats, float maxU, float maxV, float x, float y, float radius, int lo, int hi) {
+  auto cvr = [](float v) { return (int)std::lrintf(v); };
+  auto fl = [](float v) { return (int)std::floor(v); };
+  const int minX = std::max(0, cvr(x - radius)), maxX = std::min((int)maxU, cvr(x + radius));
+  const int minY = std::max(0, cvr(y - radius)), maxY = std::min((int)maxV, cvr(y + radius));
+  const int c0 = fl((float)minX / 64), c1 = fl((float)maxX / 64), r0 = fl((float)minY / 48), r1 = fl((float)maxY / 48);
+  std::vector<int> out;
+  for (size_t i = 0; i < feats.size(); ++i) {
+    const int r = fl(feats[i].pt.y / 48), c = fl(feats[i].pt.x / 64);
+    if (r >= r0 && r <= r1 && c >= c0 && c <= c1 && feats[i].octave <= hi && feats[i].octave >= lo) out.push_back((int)i);
+  }
+  return out;
+}
+
+static int mode_matchers(int argc, char** argv) {
+  if (argc < 6) return 2;
+  const int w = atoi(argv[4]), h = atoi(argv[5]);
+  std::vector<uint8_t> L, R;
+  if (!read_file(argv[2], L) || !read_file(argv[3], R) || L.size() != (size_t)w * h || R.size() != L.size()) return 2;
+  cv::Mat ml(h, w, CV_8UC1, L.data()), mr(h, w, CV_8UC1, R.data());
+  ref::MapPoint::Cmp cmp = [](std::weak_ptr<ref::KeyFrame>, std::weak_ptr<ref::KeyFrame>) { return false; };
+  auto F1 = std::make_shared<ref::Frame>(ml, mr, true);  // the frame being tracked: features of the left image, resident in a slot
+  auto F2 = std::make_shared<ref::Frame>(mr, ml, true);  // the "last frame": features of the right image (displaced by the disparity)
+  ref::VirtualFrame::mvfScaledFactors = ORB_SLAM2_ROS2::ORBExtractor::getScaledFactors();
+  for (auto* f : {F1.get(), F2.get()}) {
+    f->mfMinU = 0, f->mfMinV = 0, f->mfMaxU = (float)w, f->mfMaxV = (float)h;
+    f->mRcw = cv::Mat(3, 3, CV_32F), f->mtcw = cv::Mat(3, 1, CV_32F);
+    for (int r = 0; r < 3; ++r) f->mRcw.at<float>(r, r) = 1.f;
+  }
+  const size_t n1 = F1->mvFeatsLeft.size(), n2 = F2->mvFeatsLeft.size();
+  auto make_mp = [&](size_t id, bool bad, bool inMap) {
+    auto p = std::make_shared<ref::MapPoint>(cmp);
+    p->mId = id, p->mbBad = bad, p->mbInMap = inMap;
+    return p;
+  };
+  auto populate = [&]() {
+    F1->mvpMapPoints.assign(n1, nullptr);
+    F2->mvpMapPoints.assign(n2, nullptr);
+    for (size_t i = 0; i < n1; ++i)
+      if (i % 10 < 3) F1->mvpMapPoints[i] = make_mp(i, i % 50 == 1, i % 4 != 0);  // 30 % carry a map point, a few of them bad
+    for (size_t i = 0; i < n2; ++i)
+      if (i % 10 < 7) F2->mvpMapPoints[i] = make_mp(100000 + i, i % 40 == 2, i % 3 != 0);
+  };
+  orbfe_ctx* ctx1 = F1->mpExtractorLeft->device().context();
+  const int slot1 = F1->mpExtractorLeft->device().slot();
+  const std::vector<float>& sf = ref::VirtualFrame::mvfScaledFactors;
+  int fails = 0, total_matches = 0;
+  auto expect = [&](bool ok, const char* what) {
+    if (!ok) fprintf(stderr, "matchers: %s\n", what), ++fails;
+  };
+
+  // ---- searchByProjection(frame1, frame2, matches, th, bFuse): three motions (still / forward / backward), both modes -----------------
+  for (int motion = 0; motion < 3; ++motion)
+    for (int fuse = 0; fuse < 2; ++fuse) {
+      populate();
+      const float tz = motion == 0 ? 0.1f : (motion == 1 ? -2.0f : 2.0f);  // tlc.z = tcw2.z - tcw1.z with identity rotations
+      F1->mtcw.at<float>(2, 0) = tz, F2->mtcw.at<float>(2, 0) = 0.f;
+      const float z = -tz;
+      const float th = 15.f;
+      if (fuse)
+        for (size_t i = 0; i < n2; ++i)
+          if (F2->mvpMapPoints[i]) F2->mvpMapPoints[i]->mVisible = i % 6 != 0;
+      // the array-level mirror on the same state
+      std::vector<uint8_t> valid2(n2, 0), hasMp1(n1, 0);
+      for (size_t i = 0; i < n2; ++i) {
+        auto& p = F2->mvpMapPoints[i];
+        valid2[i] = p && !p->isBad() && (!fuse || p->mVisible);
+      }
+      for (size_t i = 0; i < n1; ++i) hasMp1[i] = F1->mvpMapPoints[i] && !F1->mvpMapPoints[i]->isBad();
+      const auto want = orbfe::ORBMatcher(0.7f).searchByProjection(ctx1, slot1, sf, kps_of(F2->mvFeatsLeft), rows_of(F2->mvLeftDescriptor), valid2,
+                                                                   hasMp1, th, z, ref::Camera::mfBl, fuse != 0);
+      // addMatchInTrack as the reference makes them: once per (query, kept-map-point feature in its window) occurrence (:321-331)
+      std::vector<int> wantTrack(n1, 0);
+      if (!fuse) {
+        const bool up = std::abs(z) > ref::Camera::mfBl && z > 0, down = std::abs(z) > ref::Camera::mfBl && !(z > 0);
+        for (size_t i = 0; i < n2; ++i) {
+          if (!valid2[i]) continue;
+          const auto& kp = F2->mvFeatsLeft[i];
+          const int lo = up ? kp.octave : (down ? 0 : std::max(0, kp.octave - 1)), hi = up ? 7 : (down ? kp.octave : std::min(kp.octave + 1, 7));
+          for (int c : area_members(F1->mvFeatsLeft, F1->mfMaxU, F1->mfMaxV, kp.pt.x, kp.pt.y, th * ref::VirtualFrame::getScaledFactor2(kp.octave), lo, hi))
+            if (hasMp1[(size_t)c]) ++wantTrack[(size_t)c];
+        }
+      }
+      auto mps1_before = F1->mvpMapPoints;
+      std::vector<cv::DMatch> got{cv::DMatch(1, 2, 3.f)};  // stale content must be cleared (:267)
+      const int nret = orbfe::dropin::searchByProjection<ref::Camera>(F1, F2, got, th, fuse != 0, 0.7f);
+      expect(nret == (int)got.size() && same_matches(got, want), "searchByProjection(frame, frame): matches differ from the mirror");
+      total_matches += (int)got.size();
+      bool side_ok = true;
+      for (size_t c = 0; c < n1; ++c) {
+        // setMapPoints (:815-830) on the non-fuse path: the matched features of frame 1 take frame 2's map point, which is bumped once more
+        if (mps1_before[c]) side_ok = side_ok && mps1_before[c]->nMatchInTrack == (fuse ? 0 : wantTrack[c]);
+      }
+      std::vector<int> bump2(n2, 0);
+      for (const auto& m : want) {
+        if (fuse) {
+          side_ok = side_ok && F1->mvpMapPoints[(size_t)m.queryIdx] == mps1_before[(size_t)m.queryIdx];
+        } else {
+          side_ok = side_ok && F1->mvpMapPoints[(size_t)m.queryIdx] == F2->mvpMapPoints[(size_t)m.trainIdx];
+          ++bump2[(size_t)m.trainIdx];
+        }
+      }
+      for (size_t i = 0; i < n2; ++i)
+        if (F2->mvpMapPoints[i] && valid2[i]) side_ok = side_ok && F2->mvpMapPoints[i]->nMatchInTrack == bump2[i];
+      expect(side_ok, "searchByProjection(frame, frame): map-point side effects differ");
+      if (!fuse && motion == 0) expect(std::accumulate(wantTrack.begin(), wantTrack.end(), 0) > 100, "exclusion path not exercised");
+    }
+
+  // ---- searchByProjection(frame, mapPoints, th, matches, bFuse) ---------------------------------------------------------------------------
+  for (int fuse = 0; fuse < 2; ++fuse) {
+    populate();
+    std::vector<ref::MapPoint::SharedPtr> local;
+    std::vector<float> uv, cosT;
+    std::vector<int> level;
+    std::vector<orbfe::Descriptor> mpDesc;
+    std::vector<uint8_t> usable;
+    for (size_t i = 0; i < n2; ++i) {  // local map points "seen" near where frame 2 has its features
+      auto p = make_mp(200000 + i, i % 37 == 3, i % 29 != 5);
+      p->mVisible = i % 9 != 4;
+      p->mUV = cv::Point2f(F2->mvFeatsLeft[i].pt.x + (float)((int)(i % 7) - 3), F2->mvFeatsLeft[i].pt.y + (float)((int)(i % 5) - 2));
+      p->mDist = 5.f + (float)(i % 11), p->mCos = i % 3 ? 0.9995f : 0.99f, p->mLevel = F2->mvFeatsLeft[i].octave;
+      p->mDesc = F2->mvLeftDescriptor[i].clone();
+      if (i % 13 == 6) p = nullptr;
+      local.push_back(p);
+      uv.push_back(p ? p->mUV.x : 0.f), uv.push_back(p ? p->mUV.y : 0.f);
+      cosT.push_back(p ? p->mCos : 0.f), level.push_back(p ? p->mLevel : 0);
+      mpDesc.push_back(rows_of({F2->mvLeftDescriptor[i]})[0]);
+      usable.push_back(p && !p->isBad() && p->isInMap() && p->mVisible);
+    }
+    std::vector<uint8_t> hasGood(n1, 0);
+    for (size_t i = 0; i < n1; ++i) {
+      auto& p = F1->mvpMapPoints[i];
+      hasGood[i] = p && !p->isBad() && p->isInMap();
+    }
+    int preset = 0;
+    for (auto& p : F1->mvpMapPoints) preset += p && !p->isBad();
+    std::vector<orbfe::ORBMatcher::DMatch> want;
+    int wantN = orbfe::ORBMatcher(0.7f).searchByProjection(ctx1, slot1, sf, 8, uv, level, cosT, mpDesc, usable, 3.f, hasGood, want, fuse != 0);
+    if (!fuse) {  // the mirror counts the features it was told carry a map point; the reference counts `pMp && !isBad()` (:567-572)
+      int told = 0;
+      for (uint8_t g : hasGood) told += g;
+      wantN += preset - told;
+    }
+    std::vector<cv::DMatch> got;
+    auto before = F1->mvpMapPoints;
+    const int nret = orbfe::dropin::searchByProjection(F1, local, 3.f, got, fuse != 0, 0.7f, 8);
+    expect(nret == wantN, "searchByProjection(frame, mapPoints): count differs from the mirror");
+    if (fuse) {
+      expect(same_matches(got, want), "searchByProjection(frame, mapPoints, fuse): matches differ");
+    } else {
+      bool ok = got.empty();
+      std::vector<int> bumped(local.size(), 0);
+      for (const auto& m : want) {
+        ok = ok && F1->mvpMapPoints[(size_t)m.queryIdx] == local[(size_t)m.trainIdx];
+        ++bumped[(size_t)m.trainIdx];
+      }
+      size_t changed = 0;
+      for (size_t i = 0; i < n1; ++i) changed += F1->mvpMapPoints[i] != before[i];
+      ok = ok && changed == want.size();
+      for (size_t i = 0; i < local.size(); ++i)
+        if (local[i]) ok = ok && local[i]->nMatchInTrack == bumped[i];
+      expect(ok, "searchByProjection(frame, mapPoints): assignments differ");
+    }
+    total_matches += (int)want.size();
+  }
+
+  // ---- searchByBow(frame, keyframe, matches, bAddMPs, bLoop) --------------------------------------------------------------------------------
+  for (int mode = 0; mode < 3; ++mode) {
+    const bool bAddMPs = mode == 1, bLoop = mode == 2;
+    populate();
+    F1->mFeatVec.clear(), F2->mFeatVec.clear();
+    for (size_t i = 0; i < n1; ++i) F1->mFeatVec[(unsigned)((F1->mvLeftDescriptor[i].data[0] ^ F1->mvLeftDescriptor[i].data[7]) % 97) * 3].push_back((unsigned)i);
+    for (size_t i = 0; i < n2; ++i) F2->mFeatVec[(unsigned)((F2->mvLeftDescriptor[i].data[0] ^ F2->mvLeftDescriptor[i].data[7]) % 97) * 3].push_back((unsigned)i);
+    F2->mFeatVec[1].push_back(0);  // a node only one side has
+    auto flags = [](std::vector<ref::MapPoint::SharedPtr>& mps, std::vector<uint8_t>& good, std::vector<uint8_t>& inMap) {
+      good.assign(mps.size(), 0), inMap.assign(mps.size(), 0);
+      for (size_t i = 0; i < mps.size(); ++i) good[i] = mps[i] && !mps[i]->isBad(), inMap[i] = good[i] && mps[i]->isInMap();
+    };
+    std::vector<uint8_t> gF, iF, gK, iK;
+    flags(F1->mvpMapPoints, gF, iF);
+    flags(F2->mvpMapPoints, gK, iK);
+    std::vector<float> aF, aK;
+    for (auto& k : F1->mvFeatsLeft) aF.push_back(k.angle);
+    for (auto& k : F2->mvFeatsLeft) aK.push_back(k.angle);
+    const auto want = orbfe::ORBMatcher(0.8f, true).searchByBow(orbfe::dropin::matcherContext(), rows_of(F1->mvLeftDescriptor),
+                                                                rows_of(F2->mvLeftDescriptor), F1->mFeatVec, F2->mFeatVec, gF, iF, gK, iK, aF, aK, bAddMPs,
+                                                                bLoop);
+    auto before = F1->mvpMapPoints;
+    std::vector<cv::DMatch> got;
+    const int nret = orbfe::dropin::searchByBow(F1, F2, got, bAddMPs, bLoop, 0.8f, true);
+    expect(nret == (int)got.size() && same_matches(got, want) && F1->nBowCalls > 0 && F2->nBowCalls > 0, "searchByBow: matches differ from the mirror");
+    bool ok = true;
+    for (size_t i = 0; i < n1; ++i) {
+      ref::MapPoint::SharedPtr exp = before[i];
+      if (!bAddMPs && !bLoop)
+        for (const auto& m : want)
+          if ((size_t)m.queryIdx == i && gK[(size_t)m.trainIdx]) exp = F2->mvpMapPoints[(size_t)m.trainIdx];
+      ok = ok && F1->mvpMapPoints[i] == exp;
+    }
+    expect(ok, "searchByBow: setMapPoints differs");
+    expect(!want.empty(), "searchByBow: no matches at all");
+    total_matches += (int)want.size();
+  }
+  printf("MATCHERS_%s %zu %zu %d\n", fails ? "FAIL" : "OK", n1, n2, total_matches);
+  return fails ? 1 : 0;
+}
+
+// ---- Frame::Frame (RGB-D) tail: the adapter against the array-level orbfe_frame_rgbd (oracle-checked in tests/test_frame_glue.py) ----------
+static int mode_rgbd(int argc, char** argv) {
+  if (argc < 5) return 2;
+  const int w = atoi(argv[3]), h = atoi(argv[4]);
+  std::vector<uint8_t> G;
+  if (!read_file(argv[2], G) || G.size() != (size_t)w * h) return 2;
+  ref::Camera::mfFx = 520.908620f, ref::Camera::mfFy = 521.007327f, ref::Camera::mfCx = 325.141442f, ref::Camera::mfCy = 249.701764f;
+  ref::Camera::mfBf = 40.0f;
+  ref::Camera::mDistCoeff = cv::Mat(5, 1, CV_32F);
+  const float dc[5] = {0.231222f, -0.784899f, -0.003257f, -0.000105f, 0.917205f};
+  for (int i = 0; i < 5; ++i) ref::Camera::mDistCoeff.at<float>(i) = dc[i];
+  cv::Mat gray(h, w, CV_8UC1, G.data());
+  cv::Mat depth(h, w, CV_16U);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) depth.at<uint16_t>(y, x) = (uint16_t)(((x / 16 + y / 12) % 9 == 0) ? 0 : 3000 + 37 * ((x * 7 + y * 13) % 400));
+  struct F : ref::VirtualFrame {
+    ORB_SLAM2_ROS2::ORBExtractor::SharedPtr mpExtractorLeft;
+    cv::Mat mLeftIm;
+  } f;
+  f.mLeftIm = gray;
+  f.mpExtractorLeft = std::make_shared<ORB_SLAM2_ROS2::ORBExtractor>(f.mLeftIm, 1000, 8, 1.2f, "", 20, 7);
+  f.mpExtractorLeft->extract(f.mvFeatsLeft, f.mvLeftDescriptor);
+  const auto distorted = f.mvFeatsLeft;
+  // the array-level call first (it undistorts the slot's keypoints in place, so the adapter afterwards starts from a fresh extraction)
+  const auto& dev = f.mpExtractorLeft->device();
+  const size_t cap = (size_t)orbfe_get_capacity(dev.context());
+  std::vector<orbfe_keypoint> und(cap);
+  std::vector<double> d(cap), ru(cap);
+  orbfe_camera cam = {ref::Camera::mfFx, ref::Camera::mfFy, ref::Camera::mfCx, ref::Camera::mfCy, dc[0], dc[1], dc[2], dc[3], dc[4], ref::Camera::mfBf};
+  orbfe::check(dev.context(), orbfe_frame_rgbd(dev.context(), dev.slot(), &cam, depth.data, 0, depth.step, 5208.f, und.data(), d.data(), ru.data()));
+  f.mpExtractorLeft->extract(f.mvFeatsLeft, f.mvLeftDescriptor);
+  orbfe::dropin::frameRGBD<ref::Camera>(&f, depth, 5208.f);
+  const size_t n = f.mvFeatsLeft.size();
+  bool ok = n == distorted.size() && n > 300 && f.mvDepths.size() == n && f.mvFeatsRightU.size() == n && f.mvpMapPoints.size() == n;
+  size_t moved = 0, with_depth = 0;
+  for (size_t i = 0; ok && i < n; ++i) {
+    ok = std::memcmp(&f.mvFeatsLeft[i], &und[i], sizeof(orbfe_keypoint)) == 0 && f.mvDepths[i] == d[i] && f.mvFeatsRightU[i] == ru[i];
+    moved += f.mvFeatsLeft[i].pt.x != distorted[i].pt.x;
+    with_depth += f.mvDepths[i] > 0;
+  }
+  printf("RGBD_%s %zu %zu %zu\n", ok && moved > n / 2 && with_depth > n / 2 && with_depth < n ? "OK" : "FAIL", n, moved, with_depth);
+  return ok ? 0 : 1;
+}
+
+// ---- the friend line: frame classes whose data members are PROTECTED, as in the reference (Frame.h:272-292), name orbfe::dropin::Bodies
+// beside `friend class ORBMatcher;` -- this instantiates every matcher body on such a class (host-only: empty frames never reach the device)
+namespace prot {
+struct MapPoint : ref::MapPoint {
+  using ref::MapPoint::MapPoint;
+};
+class VFrame {
+  friend struct orbfe::dropin::Bodies;
+
+ public:
+  typedef std::shared_ptr<VFrame> SharedPtr;
+  void computeBow() {}
+  std::vector<ref::MapPoint::SharedPtr> getMapPoints() { return mvpMapPoints; }
+  ref::MapPoint::SharedPtr getMapPoint(std::size_t i) { return mvpMapPoints[i]; }
+  void setMapPoint(int i, ref::MapPoint::SharedPtr p) { mvpMapPoints[i] = p; }
+  const std::vector<cv::KeyPoint>& getLeftKeyPoints() const { return mvFeatsLeft; }
+  void getPose(cv::Mat& R, cv::Mat& t) const { R = mRcw.clone(), t = mtcw.clone(); }
+  static float getScaledFactor2(const int& l) { return ref::VirtualFrame::getScaledFactor2(l); }
+  float mfMaxU = 640, mfMaxV = 480, mfMinU = 0, mfMinV = 0;
+  VFrame() : mRcw(3, 3, CV_32F), mtcw(3, 1, CV_32F) {}
+
+ protected:
+  std::vector<cv::KeyPoint> mvFeatsLeft;
+  std::vector<cv::Mat> mvLeftDescriptor;
+  std::vector<ref::MapPoint::SharedPtr> mvpMapPoints;
+  std::map<unsigned, std::vector<unsigned>> mFeatVec;
+  cv::Mat mRcw, mtcw;
+};
+}  // namespace prot
+static int mode_access() {
+  auto a = std::make_shared<prot::VFrame>(), b = std::make_shared<prot::VFrame>();
+  std::vector<cv::DMatch> m;
+  std::vector<ref::MapPoint::SharedPtr> none;
+  const int n = orbfe::dropin::searchByBow(a, b, m, false, false) + orbfe::dropin::searchByProjection<ref::Camera>(a, b, m, 7.f, false) +
+                orbfe::dropin::searchByProjection(a, none, 3.f, m, true, 0.6f, 8);
+  printf("ACCESS_OK %d\n", n);
+  return n == 0 ? 0 : 1;
 }
 
 static int mode_localba(int argc, char** argv) {
@@ -427,6 +762,9 @@ int main(int argc, char** argv) {
     if (mode == "policy") return mode_policy();
     if (mode == "threads") return mode_threads(argc, argv);
     if (mode == "latency") return mode_latency(argc, argv);
+    if (mode == "matchers") return mode_matchers(argc, argv);
+    if (mode == "rgbd") return mode_rgbd(argc, argv);
+    if (mode == "access") return mode_access();
     if (mode == "localba") return mode_localba(argc, argv);
     if (mode == "poseonly") return mode_poseonly();
     return 2;

@@ -121,6 +121,9 @@ def test_dropin_header_compiles_against_the_stand_in_opencv_and_fails_loudly_wit
     # host-only mode: the write-back policy of OptimizeLocalMap at exactly 30 % outliers in a keyframe (float quotient vs double 0.3)
     pol = subprocess.run([exe, "policy"], capture_output=True, text=True)
     assert pol.returncode == 0 and pol.stdout.split() == ["POLICY_OK", "1", "0", "0", "1"], pol.stdout + pol.stderr
+    # host-only: the matcher bodies instantiated on frame classes with PROTECTED data members + `friend struct orbfe::dropin::Bodies;`
+    acc = subprocess.run([exe, "access"], capture_output=True, text=True)
+    assert acc.returncode == 0 and acc.stdout.split() == ["ACCESS_OK", "0"], acc.stdout + acc.stderr
     if torch.cuda.is_available():
         pytest.skip("a device is present: the run-time half is tests/test_gpu_dropin.py")
     r = subprocess.run([exe, "poseonly"], capture_output=True, text=True)

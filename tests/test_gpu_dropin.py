@@ -60,3 +60,84 @@ def test_frame_adapter_of_optimize_pose_only_equals_the_array_path(exe):
     assert out.returncode == 0, out.stdout + out.stderr
     tag, good, good_arrays, kept, marks, pose_diff, err = out.stdout.split()
     assert tag == "POSEONLY_OK" and int(pose_diff) == 0 and int(kept) == int(good) == int(marks) and float(err) < 0.02
+
+
+def test_matcher_adapters_with_the_reference_signatures_equal_the_array_level_mirrors(exe, tmp_path):
+    """searchByBow(VirtualFramePtr, VirtualFramePtr, vector<DMatch>&, bool, bool), searchByProjection(frame, frame, ...),
+    searchByProjection(frame, mapPoints, ...) (include/ORB_SLAM2/ORBMatcher.h:42,49,52) over stand-in Frame / MapPoint classes: matches, setMapPoints,
+    addMatchInTrack counts against the array-level mirrors (oracle-checked in test_guided_wrappers.py) on the same frames and map state."""
+    L, R = synth.stereo_pair(3)
+    L.tofile(tmp_path / "L.raw")
+    R.tofile(tmp_path / "R.raw")
+    out = subprocess.run([exe, "matchers", str(tmp_path / "L.raw"), str(tmp_path / "R.raw"), "1241", "376"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    tag, n1, n2, total = out.stdout.split()
+    assert tag == "MATCHERS_OK" and int(n1) > 1500 and int(n2) > 1500 and int(total) > 500
+
+
+def test_rgbd_frame_tail_adapter_equals_the_array_level_call(exe, tmp_path):
+    """Frame::Frame for RGB-D input (src/Frame.cc:125-159) after extract(): undistortion + depth / rightU lookup through the adapter against
+    orbfe_frame_rgbd on the same slot (which tests/test_frame_glue.py holds to the oracle)."""
+    img = synth.mono_image(0)
+    img.tofile(tmp_path / "G.raw")
+    out = subprocess.run([exe, "rgbd", str(tmp_path / "G.raw"), "640", "480"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.split()[0] == "RGBD_OK", out.stdout + out.stderr
+
+
+def test_matcher_calls_from_a_third_thread_beside_two_extracting_threads(tmp_path):
+    """The reference runs fuse / searchBySim3 / searchForTriangulation on the LocalMapping and LoopClosing threads while Tracking builds
+    Frames on two extractor threads (System.cc:119-129).  One context, three threads: two orbfe_extract_slot lanes and a stream of
+    orbfe_search_in_area_features calls; every result must equal the single-threaded one (the per-context API lock)."""
+    import threading
+
+    import numpy as np
+
+    from orb_slam2_ros2_amd._lib import Context
+    L, R = synth.stereo_pair(5)
+    ctx = Context(1241, 376, max_images=4)
+    (lk, ld), (rk, rd) = ctx.extract_batch([L, R])
+    r = np.random.default_rng(0)
+    nq = 200
+    q = r.integers(0, len(rk), nq)
+    qxy = np.stack([rk["x"][q], rk["y"][q]], 1).astype(np.float32)
+    rad = r.uniform(5, 60, nq).astype(np.float32)
+    lo, hi = np.zeros(nq, np.int8), np.full(nq, 7, np.int8)
+    want = ctx.search_in_area_features(lk, ld, qxy, rad, lo, hi, rd[q])
+    errs, stop = [], threading.Event()
+
+    def extractor(slot, img, ref_k, ref_d):
+        try:
+            for _ in range(150):
+                k, d = ctx.extract_slot(slot, img)
+                if not (np.array_equal(k, ref_k) and np.array_equal(d, ref_d)):
+                    errs.append(f"slot {slot}: features differ")
+                    return
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex))
+
+    def matcher():
+        try:
+            n = 0
+            while not stop.is_set() or n < 20:
+                got = ctx.search_in_area_features(lk, ld, qxy, rad, lo, hi, rd[q])
+                if not all(np.array_equal(a, b) for a, b in zip(got, want)):
+                    errs.append("search differs")
+                    return
+                bi, bd, sd = ctx.match_bruteforce(rd[q], ld)   # another entry point that shares the context's scratch buffer
+                if bi.shape[0] != nq:
+                    errs.append("bruteforce shape")
+                    return
+                n += 1
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex))
+
+    ts = [threading.Thread(target=extractor, args=(2, L, lk, ld)), threading.Thread(target=extractor, args=(3, R, rk, rd)),
+          threading.Thread(target=matcher)]
+    for t in ts:
+        t.start()
+    ts[0].join()
+    ts[1].join()
+    stop.set()
+    ts[2].join()
+    ctx.close()
+    assert not errs, errs
