@@ -93,6 +93,11 @@ void launch_search_area(hipStream_t s, const uint4* d_kpl, const uint8_t* d_desc
                         const int32_t* d_cell_off, const int32_t* d_cell_feat, int nq, const float* d_qxy, const float* d_radius,
                         const int8_t* d_min_level, const int8_t* d_max_level, const uint8_t* d_q_desc, const uint8_t* d_exclude,
                         int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second, int32_t* d_n_cand, int32_t* d_excluded_hits);
+void launch_lm_build(hipStream_t s, const LmLaunch& L, int gate, int which, int write_last);
+void launch_lm_maxdiag(hipStream_t s, const LmLaunch& L, int gate);
+void launch_lm_step(hipStream_t s, const LmLaunch& L);
+void launch_lm_switch(hipStream_t s, const LmLaunch& L);
+void launch_lm_final(hipStream_t s, const LmLaunch& L);
 void launch_pose_only(hipStream_t s, int n, const double* Xw, const double* meas, const double* info, const float* sigma2,
                       const double* pose_in, BaParamsDev prm, double d_mono, double d_stereo, double* err, uint8_t* level,
                       uint8_t* robust, uint8_t* inlier, double* pose_out, int32_t* n_good);
@@ -240,6 +245,11 @@ struct orbfe_ctx {
   size_t tmp_bytes = 0;
   // pinned host staging for small result reads
   int32_t* h_counts = nullptr;
+  // local BA with the Levenberg-Marquardt control on the device (k_lm.hip): a host-mapped byte the control kernel polls -- the caller's
+  // stop flag is mirrored into it while the call waits -- and the page-locked copy of the state record
+  volatile uint8_t* h_abort = nullptr;
+  LmState* h_lm_state = nullptr;
+  bool lm_on_device = true;  // ORBFE_LBA_HOST_LM=1: round 2's host-driven loop (kept for A/B runs and for > LM_CHOL_MAX_NB free keyframes)
 
   // profiling
   int prof = 0;  // 0 off | 1 every stage timed alone (overlaps and graphs off) | 2..: only stage (prof - 2) timed, in the production schedule
@@ -950,6 +960,8 @@ void orbfe_destroy(orbfe_ctx* c) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
+  if (c->h_abort) (void)hipHostFree((void*)c->h_abort);
+  if (c->h_lm_state) (void)hipHostFree(c->h_lm_state);
   if (c->hs.h2d) (void)hipStreamSynchronize(c->hs.h2d);
   if (c->hs.d2h) (void)hipStreamSynchronize(c->hs.d2h);
   for (int b = 0; b < orbfe_ctx::HostStream::kDepth; ++b) {
@@ -1069,6 +1081,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
       }
     }
     if (const char* rr = getenv("ORBFE_RESIZE_REGIONS")) c->resize_regions = atoi(rr) != 0;
+    if (const char* hl = getenv("ORBFE_LBA_HOST_LM")) c->lm_on_device = atoi(hl) == 0;
     if (const char* be = getenv("ORBFE_BLUR_L0_EARLY")) c->blur_l0_early = atoi(be) != 0;
     if (const char* xl = getenv("ORBFE_EXT_LEVEL0")) c->ext_level0 = atoi(xl) != 0;
     const char* ov = getenv("ORBFE_OVERLAP_BLUR");
@@ -2111,6 +2124,20 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
                o_err = take((size_t)E * 24), o_chi2 = take((size_t)E * 8), o_rho = take((size_t)E * 16), o_last = take((size_t)E * 8),
                o_level = take((size_t)E), o_depth = take((size_t)E), o_bad = take((size_t)E), o_sc = take(64),
                o_big = take(nf > LBA_MAX_FREE ? ((n + 1) * 6 + (size_t)nf * 36 + n) * 8 : 8);
+  // the device-side Levenberg-Marquardt path (k_lm.hip): second estimate / system buffers, per-edge terms, blocked reduced system
+  const bool dev_lm = c->lm_on_device && E > 0 && nf <= LM_CHOL_MAX_NB;
+  const int chi_blocks = (E + 255) / 256, scale_blocks = (NP + NK + 255) / 256;
+  size_t l_pose1 = 0, l_pt1 = 0, l_terms[2] = {0, 0}, l_hpl1 = 0, l_hpp1 = 0, l_bp1 = 0, l_hll1 = 0, l_bl1 = 0, l_chi[2] = {0, 0}, l_sblk = 0,
+         l_scale = 0, l_state = 0, l_pose_out = 0, l_pt_out = 0;
+  if (dev_lm) {
+    l_pose1 = take((size_t)NK * 56), l_pt1 = take((size_t)NP * 24);
+    l_terms[0] = take((size_t)E * 256), l_terms[1] = take((size_t)E * 256);
+    l_hpl1 = take((size_t)E * 144), l_hpp1 = take((size_t)NK * 288), l_bp1 = take((size_t)NK * 48), l_hll1 = take((size_t)NP * 72),
+    l_bl1 = take((size_t)NP * 24);
+    l_chi[0] = take((size_t)chi_blocks * 8), l_chi[1] = take((size_t)chi_blocks * 8);
+    l_sblk = take((size_t)nf * (nf + 1) / 2 * 288), l_scale = take((size_t)scale_blocks * 8), l_state = take(sizeof(LmState));
+    l_pose_out = take((size_t)NK * 56), l_pt_out = take((size_t)NP * 24);
+  }
   TRY(ensure_tmp(c, off));
   uint8_t* b = (uint8_t*)c->d_tmp;
   hipStream_t st = c->stream;
@@ -2147,6 +2174,88 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
   const int32_t* d_ek = (const int32_t*)(b + o_ep);
   const int32_t* d_ep = (const int32_t*)(b + o_et);
   double* d_sc = (double*)(b + o_sc);  // [0] robust chi2, [1] max diagonal, [2] lambda, [3] ok (int), [4] scale
+  if (dev_lm) {
+    // ---- Levenberg-Marquardt control on the device: enqueue the whole optimisation, synchronise once ------------------------------
+    if (!c->h_abort) {
+      HIP_TRY(c, hipHostMalloc((void**)&c->h_abort, 64, hipHostMallocMapped));
+      HIP_TRY(c, hipHostMalloc((void**)&c->h_lm_state, sizeof(LmState), hipHostMallocDefault));
+    }
+    void* d_abort = nullptr;
+    HIP_TRY(c, hipHostGetDevicePointer(&d_abort, (void*)c->h_abort, 0));
+    *c->h_abort = (stop_flag && *stop_flag) ? 1 : 0;
+    LmLaunch L{};
+    L.NK = NK, L.NP = NP, L.E = E, L.nf = nf;
+    L.poses[0] = d_poses, L.poses[1] = (double*)(b + l_pose1), L.points[0] = d_points, L.points[1] = (double*)(b + l_pt1);
+    L.terms[0] = (double*)(b + l_terms[0]), L.terms[1] = (double*)(b + l_terms[1]);
+    L.Hpl[0] = (double*)(b + o_hpl), L.Hpl[1] = (double*)(b + l_hpl1), L.Hpp[0] = (double*)(b + o_hpp), L.Hpp[1] = (double*)(b + l_hpp1);
+    L.bp[0] = (double*)(b + o_bp), L.bp[1] = (double*)(b + l_bp1), L.Hll[0] = (double*)(b + o_hll), L.Hll[1] = (double*)(b + l_hll1);
+    L.bl[0] = (double*)(b + o_bl), L.bl[1] = (double*)(b + l_bl1), L.chi_part[0] = (double*)(b + l_chi[0]), L.chi_part[1] = (double*)(b + l_chi[1]);
+    L.state = (LmState*)(b + l_state);
+    L.edge_pose = d_ek, L.edge_point = d_ep, L.pt_off = (const int32_t*)(b + o_pto), L.pt_edges = (const int32_t*)(b + o_pte);
+    L.ps_off = (const int32_t*)(b + o_pso), L.ps_edges = (const int32_t*)(b + o_pse), L.free_pose = (const int32_t*)(b + o_free);
+    L.pose_slot = (const int32_t*)(b + o_slot), L.pair_off = (const int32_t*)(b + o_pairoff), L.pairs = (const int2*)(b + o_pairs);
+    L.meas = (const double*)(b + o_meas), L.info = (const double*)(b + o_info), L.is_stereo = b + o_st, L.fixed = b + o_fix;
+    L.info_eff = (double*)(b + o_info_eff), L.delta_eff = (double*)(b + o_delta), L.chi2_last = (double*)(b + o_last), L.level = b + o_level;
+    L.Dinv = (double*)(b + o_dinv), L.W = (double*)(b + o_w), L.Sblk = (double*)(b + l_sblk), L.rhs = (double*)(b + o_rhs), L.x = (double*)(b + o_x);
+    L.scale_part = (double*)(b + l_scale), L.chi2_out = (double*)(b + o_chi2), L.poses_out = (double*)(b + l_pose_out);
+    L.points_out = (double*)(b + l_pt_out), L.bad = b + o_bad, L.abort_flag = (const volatile uint8_t*)d_abort, L.prm = prm;
+    LmState init{};
+    init.iters[0] = iters_first, init.iters[1] = iters_second, init.need_chi = 1, init.ok = 1;
+    *c->h_lm_state = init;
+    HIP_TRY(c, hipMemcpyAsync(L.state, c->h_lm_state, sizeof(LmState), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(L.Dinv, 0, (size_t)std::max(NP, 1) * 72, st));  // (read by a trial whose point block was singular)
+    HIP_TRY(c, hipStreamSynchronize(st));                                      // (the state record is re-used as the download target below)
+    StageTimer tm(c, ORBFE_STAGE_BA, st);
+    launch_lm_build(st, L, 0, 0, iters_first > 0 ? 1 : 0);  // computeActiveErrors + buildSystem at the initial estimate
+    launch_lm_maxdiag(st, L, 0);
+    int steps_a = iters_first + 1, steps_b = iters_second + 2;
+    LmState fin{};
+    for (int pass = 0;; ++pass) {
+      for (int k = 0; k < steps_a; ++k) launch_lm_step(st, L);
+      launch_lm_switch(st, L);
+      for (int k = 0; k < steps_b; ++k) launch_lm_step(st, L);
+      launch_lm_final(st, L);
+      HIP_TRY(c, hipGetLastError());
+      HIP_TRY(c, hipMemcpyAsync(c->h_lm_state, L.state, sizeof(LmState), hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipMemcpyAsync(o->poses, L.poses_out, (size_t)NK * 56, hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipMemcpyAsync(o->points, L.points_out, (size_t)NP * 24, hipMemcpyDeviceToHost, st));
+      if (o->level) HIP_TRY(c, hipMemcpyAsync(o->level, L.level, (size_t)E, hipMemcpyDeviceToHost, st));
+      if (o->chi2) HIP_TRY(c, hipMemcpyAsync(o->chi2, L.chi2_out, (size_t)E * 8, hipMemcpyDeviceToHost, st));
+      if (o->bad) HIP_TRY(c, hipMemcpyAsync(o->bad, L.bad, (size_t)E, hipMemcpyDeviceToHost, st));
+      if (stop_flag) {
+        // the device polls the mapped byte between the trials; the caller's flag (LocalMapping::mbAbortBA, written by the Tracking
+        // thread) is mirrored into it while this thread waits
+        hipEvent_t ev = nullptr;
+        HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t er = hipEventRecord(ev, st);
+        while (er == hipSuccess) {
+          if (*stop_flag) *c->h_abort = 1;
+          er = hipEventQuery(ev);
+          if (er == hipErrorNotReady) {
+            (void)hipGetLastError();
+            er = hipSuccess;
+            sched_yield();
+            continue;
+          }
+          break;
+        }
+        (void)hipEventDestroy(ev);
+        HIP_TRY(c, er);
+      }
+      HIP_TRY(c, hipStreamSynchronize(st));
+      fin = *c->h_lm_state;
+      if (fin.finalized) break;
+      if (pass >= 64) return fail(c, ORBFE_EDEVICE, "ba_local_optimize: the device-side Levenberg-Marquardt loop did not finish (round %d, phase %d)", fin.round, fin.phase);
+      steps_a = fin.switched || fin.round == 2 ? 0 : 4;  // more trials were rejected than provisioned: continue where the state stands
+      steps_b = 4;
+    }
+    if (o->iterations) {
+      o->iterations[0] = fin.done[0];
+      o->iterations[1] = fin.done[1];
+    }
+    drain_timers(c);
+    return ORBFE_OK;
+  }
   struct HostScalars {
     double chi, maxdiag, lambda;
     int32_t ok, pad;

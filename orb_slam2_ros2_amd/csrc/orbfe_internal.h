@@ -120,3 +120,41 @@ struct KpAux {
 struct BaParamsDev {
   double fx, fy, cx, cy, bf;
 };
+
+// ---- device-side Levenberg-Marquardt control of the local BA (k_lm.hip) -------------------------------------------------------------
+#define LM_CHOL_MAX_NB 42  // free keyframes the register-resident Cholesky takes: 42 * 41 / 2 = 861 off-diagonal blocks, two per thread of 448
+
+// The state record one control lane advances between the trials (device memory; the host reads it once per call).
+struct LmState {
+  double lambda, ni, current_chi, rho, maxdiag;
+  double chi_of[2];     // robust chi2 of the estimate in buffer 0 / 1
+  int32_t iters[2];     // iteration budgets of the two optimize() calls (Optimizer.cc:336, :361)
+  int32_t done[2];      // iterations started (what optimize() returns)
+  int32_t round;        // 0 / 1: which optimize() call; 2: both over
+  int32_t it;           // iteration index inside the round
+  int32_t qmax;         // trials of the current iteration
+  int32_t phase;        // 0: start an iteration | 1: a trial ran, decide it | 3: run another trial of this iteration | 2: round over
+  int32_t cur;          // which of the two estimate / system buffers is current
+  int32_t run_step, run_switch, run_final;  // gates the kernels of a step / the switch group / the final group read
+  int32_t switched, finalized, stopped;
+  int32_t ok;           // cleared by the solver kernels of a trial when a point block or a pivot is singular
+  int32_t need_chi;     // the current system was (re)built outside a trial: take its chi2 from the partial sums
+  int32_t pad;
+};
+
+struct LmLaunch {
+  int NK, NP, E, nf;
+  double *poses[2], *points[2], *terms[2], *Hpl[2], *Hpp[2], *bp[2], *Hll[2], *bl[2], *chi_part[2];
+  LmState* state;
+  const int32_t *edge_pose, *edge_point, *pt_off, *pt_edges, *ps_off, *ps_edges, *free_pose, *pose_slot, *pair_off;
+  const int2* pairs;
+  const double *meas, *info;
+  const uint8_t *is_stereo, *fixed;
+  double *info_eff, *delta_eff, *chi2_last;
+  uint8_t* level;
+  double *Dinv, *W, *Sblk, *rhs, *x, *scale_part;
+  double *chi2_out, *poses_out, *points_out;
+  uint8_t* bad;
+  const volatile uint8_t* abort_flag;  // device address of a host-mapped byte the caller's stop flag is mirrored into
+  BaParamsDev prm;
+};

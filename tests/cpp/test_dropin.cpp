@@ -363,14 +363,13 @@ static int mode_matchers(int argc, char** argv) {
         if (mps1_before[c]) side_ok = side_ok && mps1_before[c]->nMatchInTrack == (fuse ? 0 : wantTrack[c]);
       }
       std::vector<int> bump2(n2, 0);
-      for (const auto& m : want) {
-        if (fuse) {
-          side_ok = side_ok && F1->mvpMapPoints[(size_t)m.queryIdx] == mps1_before[(size_t)m.queryIdx];
-        } else {
-          side_ok = side_ok && F1->mvpMapPoints[(size_t)m.queryIdx] == F2->mvpMapPoints[(size_t)m.trainIdx];
+      auto expect1 = mps1_before;  // several features of frame 2 may pick the same feature of frame 1: the last match wins (:823)
+      for (const auto& m : want)
+        if (!fuse) {
+          expect1[(size_t)m.queryIdx] = F2->mvpMapPoints[(size_t)m.trainIdx];
           ++bump2[(size_t)m.trainIdx];
         }
-      }
+      for (size_t c = 0; c < n1; ++c) side_ok = side_ok && F1->mvpMapPoints[c] == expect1[c];
       for (size_t i = 0; i < n2; ++i)
         if (F2->mvpMapPoints[i] && valid2[i]) side_ok = side_ok && F2->mvpMapPoints[i]->nMatchInTrack == bump2[i];
       expect(side_ok, "searchByProjection(frame, frame): map-point side effects differ");
