@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_lm_linearize(int n_edges, LmBuffers B, 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           double h = 0;
-          for (int r = 0; r < rows; ++r) h += Bm[6 * r + a] * w * A[3 * r + c];
+          _Pragma("unroll") for (int r = 0; r < 3; ++r) if (r < rows) h += Bm[6 * r + a] * w * A[3 * r + c];
           out[3 * a + c] = h;
         }
     }
@@ -191,7 +191,10 @@ __global__ __launch_bounds__(256) void k_lm_linearize(int n_edges, LmBuffers B, 
   if (threadIdx.x == 0) B.chi_part[buf][blockIdx.x] = s;
 }
 
-// Hll / bl per point (blocks [0, pt_blocks)) and Hpp / bp per pose (one 256-thread block per pose after them), from the stored terms
+// Hll / bl per point (blocks [0, pt_blocks): 32 points per block, EIGHT lanes per point, one edge each) and Hpp / bp per pose (one
+// 256-thread block per pose after them: one edge per thread), from the stored terms.  Every lane has ONE dependent chain (list entry ->
+// terms) instead of one per edge of its vertex: a first version with a lane per point / per block entry walking the edges took 130 us,
+// bound by those chains.  Partial sums are combined in a fixed butterfly (+ a fixed order over the four waves of a pose).
 __global__ __launch_bounds__(256) void k_lm_blocks(int n_points, int n_poses, int pt_blocks, LmBuffers B, const LmState* __restrict__ st, int gate,
                                                    int which, const uint8_t* __restrict__ pose_fixed, const int32_t* __restrict__ pt_off,
                                                    const int32_t* __restrict__ pt_edges, const int32_t* __restrict__ ps_off,
@@ -202,54 +205,82 @@ __global__ __launch_bounds__(256) void k_lm_blocks(int n_points, int n_poses, in
   const int buf = st->cur ^ which;
   const double* terms = B.terms[buf];
   if ((int)blockIdx.x < pt_blocks) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= n_points) return;
-    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-    for (int i = pt_off[p]; i < pt_off[p + 1]; ++i) {
-      const double* t = terms + (size_t)pt_edges[i] * LM_TERM;
-      const int rows = (int)t[31];
-      const double w = t[30];
+    const int p = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+    double acc[12];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        double s = 0;
-        for (int r = 0; r < rows; ++r) s += t[3 * r + a] * t[27 + r];
-        b[a] -= s;
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0;
+    if (p < n_points) {
+      for (int i = pt_off[p] + sub; i < pt_off[p + 1]; i += 8) {
+        const double* t = terms + (size_t)pt_edges[i] * LM_TERM;
+        const int rows = (int)t[31];
+        const double w = t[30];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          double h = 0;
-          for (int r = 0; r < rows; ++r) h += t[3 * r + a] * w * t[3 * r + c];
-          H[3 * a + c] += h;
+        for (int a = 0; a < 3; ++a) {
+          double s = 0;
+          _Pragma("unroll") for (int r = 0; r < 3; ++r) if (r < rows) s += t[3 * r + a] * t[27 + r];
+          acc[9 + a] -= s;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            double h = 0;
+            _Pragma("unroll") for (int r = 0; r < 3; ++r) if (r < rows) h += t[3 * r + a] * w * t[3 * r + c];
+            acc[3 * a + c] += h;
+          }
         }
       }
     }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) B.Hll[buf][(size_t)p * 9 + k] = H[k];
+    for (int k = 0; k < 12; ++k) {
+      double v = acc[k];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      acc[k] = v;
+    }
+    if (p < n_points && sub == 0) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) B.bl[buf][(size_t)p * 3 + k] = b[k];
+      for (int k = 0; k < 9; ++k) B.Hll[buf][(size_t)p * 9 + k] = acc[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) B.bl[buf][(size_t)p * 3 + k] = acc[9 + k];
+    }
     return;
   }
   const int k = (int)blockIdx.x - pt_blocks;
   if (k >= n_poses) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  double acc = 0.0;
-  if (!pose_fixed[k] && lane < 42) {  // lane = entry: (a, c) of Hpp for lane < 36, else entry of bp; wave wv takes the edges q = wv (mod 4)
-    const int a = lane < 36 ? lane / 6 : lane - 36, c = lane < 36 ? lane - 6 * (lane / 6) : 0;
-    for (int q = ps_off[k] + wv; q < ps_off[k + 1]; q += 4) {
+  double acc[42];
+#pragma unroll
+  for (int i = 0; i < 42; ++i) acc[i] = 0.0;
+  if (!pose_fixed[k]) {
+    for (int q = ps_off[k] + (int)threadIdx.x; q < ps_off[k + 1]; q += 256) {
       const double* t = terms + (size_t)ps_edges[q] * LM_TERM;
       const int rows = (int)t[31];
-      if (lane < 36) {
-        const double w = t[30];
-        double h = 0;
-        for (int r = 0; r < rows; ++r) h += t[9 + 6 * r + a] * w * t[9 + 6 * r + c];
-        acc += h;
-      } else {
+      const double w = t[30];
+      double Bv[18], we[3];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) Bv[i] = t[9 + i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) we[i] = t[27 + i];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
         double s = 0;
-        for (int r = 0; r < rows; ++r) s += t[9 + 6 * r + a] * t[27 + r];
-        acc -= s;
+        _Pragma("unroll") for (int r = 0; r < 3; ++r) if (r < rows) s += Bv[6 * r + a] * we[r];
+        acc[36 + a] -= s;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double h = 0;
+          _Pragma("unroll") for (int r = 0; r < 3; ++r) if (r < rows) h += Bv[6 * r + a] * w * Bv[6 * r + c];
+          acc[6 * a + c] += h;
+        }
       }
     }
   }
-  if (lane < 42) part[wv][lane] = acc;
+#pragma unroll
+  for (int i = 0; i < 42; ++i) {
+    double v = acc[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) part[wv][i] = v;
+  }
   __syncthreads();
   if (threadIdx.x < 42) {
     const double v = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
@@ -286,12 +317,13 @@ __global__ __launch_bounds__(1024) void k_lm_maxdiag(int n_poses, int n_points, 
   if (threadIdx.x == 0) st->maxdiag = sh[0];
 }
 
-// per point: Dinv = (Hll + lambda I)^-1 (Eigen's 3x3 inverse: cofactors / determinant), then W(e) = Hpl(e) Dinv for the point's edges
+// per point: Dinv = (Hll + lambda I)^-1 (Eigen's 3x3 inverse: cofactors / determinant), then W(e) = Hpl(e) Dinv for the point's edges.
+// EIGHT lanes per point (each inverts the same block and takes one edge): one dependent chain per lane instead of one per edge.
 __global__ __launch_bounds__(256) void k_lm_prep(int n_points, LmBuffers B, LmState* __restrict__ st, const int32_t* __restrict__ pt_off,
                                                  const int32_t* __restrict__ pt_edges, double* __restrict__ Dinv, double* __restrict__ W) {
 #pragma clang fp contract(off)
   if (!lm_gate(st, 1)) return;
-  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int p = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
   if (p >= n_points) return;
   const int buf = st->cur;
   const double lambda = st->lambda;
@@ -302,7 +334,7 @@ __global__ __launch_bounds__(256) void k_lm_prep(int n_points, LmBuffers B, LmSt
   const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
   const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
   if (det == 0 || !isfinite(det)) {
-    st->ok = 0;
+    if (sub == 0) st->ok = 0;
     return;
   }
   const double id = 1.0 / det;
@@ -316,14 +348,19 @@ __global__ __launch_bounds__(256) void k_lm_prep(int n_points, LmBuffers B, LmSt
   D[6] = c02 * id;
   D[7] = (M[1] * M[6] - M[0] * M[7]) * id;
   D[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+  if (sub == 0) {
 #pragma unroll
-  for (int i = 0; i < 9; ++i) Dinv[(size_t)p * 9 + i] = D[i];
-  for (int q = pt_off[p]; q < pt_off[p + 1]; ++q) {
+    for (int i = 0; i < 9; ++i) Dinv[(size_t)p * 9 + i] = D[i];
+  }
+  for (int q = pt_off[p] + sub; q < pt_off[p + 1]; q += 8) {
     const int e = pt_edges[q];
     const double* H = B.Hpl[buf] + (size_t)e * 18;
+    double hv[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) hv[k] = H[k];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      const double h0 = H[3 * a], h1 = H[3 * a + 1], h2 = H[3 * a + 2];
+      const double h0 = hv[3 * a], h1 = hv[3 * a + 1], h2 = hv[3 * a + 2];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         double s = 0;
@@ -427,16 +464,24 @@ __global__ __launch_bounds__(64) void k_lm_schur(int nf, LmBuffers B, const LmSt
 #define LM_CHOL_THREADS 512
 #define LM_CHOL_OFF 448  // threads that own off-diagonal blocks
 
-__device__ __forceinline__ void lm_tri_index(int t, int& I, int& J) {  // t -> (I, J), I > J, strictly lower: t = I (I - 1) / 2 + J
-  I = (int)((sqrt(8.0 * (double)t + 1.0) + 1.0) * 0.5);
-  while (I * (I - 1) / 2 > t) --I;
-  while ((I + 1) * I / 2 <= t) ++I;
-  J = t - I * (I - 1) / 2;
+// t -> (I, J), I > J: the strictly-lower blocks in COLUMN-major order (column 0 first, rows ascending inside a column).  At block
+// column kb the blocks still being updated (J > kb) are then a contiguous TAIL of the order and the panel (J == kb) a contiguous run
+// just before it: whole waves drop out of the update as the factorisation proceeds (a wave with one active lane issues as many
+// instructions as a full one -- with the row-major order every wave kept a few active lanes to the end and a block column cost the same
+// 7.6 us at kb = 39 as at kb = 0).
+__device__ __forceinline__ void lm_tri_index(int t, int nb, int& I, int& J) {
+  int j = 0, base = 0;
+  while (j < nb - 1 && base + (nb - 1 - j) <= t) {
+    base += nb - 1 - j;
+    ++j;
+  }
+  J = j;
+  I = j + 1 + (t - base);
 }
 
 // X L^T = A for the rows of one block, in place (L, inv: LDS)
 __device__ __forceinline__ void lm_panel_solve(double (&A)[36], const double* L, const double* inv) {
-#pragma clang fp contract(off)
+#pragma clang fp contract(fast)
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
     double v[6];
@@ -444,7 +489,7 @@ __device__ __forceinline__ void lm_panel_solve(double (&A)[36], const double* L,
     for (int c = 0; c < 6; ++c) {
       double sv = A[6 * a + c];
 #pragma unroll
-      for (int m = 0; m < c; ++m) sv -= v[m] * L[6 * c + m];
+      for (int m = 0; m < c; ++m) sv = fma(-v[m], L[6 * c + m], sv);  // (LDS broadcast reads; copies in registers would spill)
       v[c] = sv * inv[c];
     }
 #pragma unroll
@@ -453,10 +498,10 @@ __device__ __forceinline__ void lm_panel_solve(double (&A)[36], const double* L,
 }
 // A -= P_I P_J^T (panel blocks in LDS)
 __device__ __forceinline__ void lm_block_update(double (&A)[36], const double* PI, const double* PJ) {
-#pragma clang fp contract(off)
-  double pj[36];
-#pragma unroll
-  for (int k = 0; k < 36; ++k) pj[k] = PJ[k];
+#pragma clang fp contract(fast)  // fused multiply-adds here: the trailing update is two thirds of the kernel's instructions, and the
+                                 // factorisation's rounding is not part of any bit-exact contract (its order already differs from g2o's LLT)
+  // one row of P_I against all of P_J: the 36 accumulators are this thread's block, P_J is re-read from LDS per row (6 x 18 16-byte
+  // reads, all lanes of a column share them) -- holding P_J in registers beside TWO blocks per thread spilled
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
     double pi[6];
@@ -464,179 +509,266 @@ __device__ __forceinline__ void lm_block_update(double (&A)[36], const double* P
     for (int k = 0; k < 6; ++k) pi[k] = PI[6 * a + k];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      const double* q = pj + 6 * c;
-      A[6 * a + c] -= pi[0] * q[0] + pi[1] * q[1] + pi[2] * q[2] + pi[3] * q[3] + pi[4] * q[4] + pi[5] * q[5];
+      const double* q = PJ + 6 * c;
+      double acc = A[6 * a + c];
+      acc = fma(-pi[0], q[0], acc);
+      acc = fma(-pi[1], q[1], acc);
+      acc = fma(-pi[2], q[2], acc);
+      acc = fma(-pi[3], q[3], acc);
+      acc = fma(-pi[4], q[4], acc);
+      acc = fma(-pi[5], q[5], acc);
+      A[6 * a + c] = acc;
     }
   }
 }
 
-__global__ __launch_bounds__(LM_CHOL_THREADS) void k_lm_chol(int nb, LmState* __restrict__ st, const double* __restrict__ Sblk,
-                                                             const double* __restrict__ rhs, double* __restrict__ x) {
-#pragma clang fp contract(off)
-  __shared__ __attribute__((aligned(16))) double P[(LM_CHOL_MAX_NB + 1) * LM_PSTRIDE];  // panel blocks of the current column; slot nb: the rhs row (6)
-  __shared__ __attribute__((aligned(16))) double Lk[36 + 6];                            // L_kk (row-major, lower) + 1 / diagonal
-  __shared__ double yv[6 * LM_CHOL_MAX_NB];                                             // y, then x
-  __shared__ int s_ok;
-  if (!lm_gate(st, 1)) return;
-  const int t = threadIdx.x;
-  const int n_off = nb * (nb - 1) / 2;  // strictly-lower blocks
-  const bool diag = t >= LM_CHOL_OFF && t - LM_CHOL_OFF < nb;
-  // off-diagonal owners: blocks (I0, J0) and (I1, J1); a diagonal owner keeps its block in A0 (I0 == J0) and its right-hand side in Y
+// the same for a DIAGONAL block: only the lower triangle is ever read (21 of the 36 entries)
+__device__ __forceinline__ void lm_diag_update(double (&A)[36], const double* PJ) {
+#pragma clang fp contract(fast)
+  double pj[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) pj[k] = PJ[k];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int c = 0; c <= a; ++c) {
+      const double* pa = pj + 6 * a;
+      const double* q = pj + 6 * c;
+      double acc = A[6 * a + c];
+      acc = fma(-pa[0], q[0], acc);
+      acc = fma(-pa[1], q[1], acc);
+      acc = fma(-pa[2], q[2], acc);
+      acc = fma(-pa[3], q[3], acc);
+      acc = fma(-pa[4], q[4], acc);
+      acc = fma(-pa[5], q[5], acc);
+      A[6 * a + c] = acc;
+    }
+}
+
+#ifdef LM_CHOL_STAMPS  // diagnostic build only (tools/exp/chol_bench.hip): where a block column's time goes, per wave
+__device__ long long g_lm_stamps[8][8];
+#define LM_ST(k) \
+  if ((t & 63) == 0) { const long long now_ = __builtin_amdgcn_s_memtime(); g_lm_stamps[t >> 6][k] += now_ - last_; last_ = now_; }
+#define LM_ST_INIT long long last_ = __builtin_amdgcn_s_memtime();
+#else
+#define LM_ST(k)
+#define LM_ST_INIT
+#endif
+
+struct LmCholShared {
+  double P[(LM_CHOL_MAX_NB + 1) * LM_PSTRIDE];  // panel blocks of the current column; slot nb: the rhs row (6)
+  double Lk[36 + 6];                            // L_kk (row-major, lower) + 1 / diagonal
+  double yv[6 * LM_CHOL_MAX_NB];                // y, then x
+  int ok;
+};
+
+// The two roles run SEPARATE copies of the block-column loop (same barriers at the same points): the waves of off-diagonal owners keep
+// two blocks (144 registers) live, the diagonal wave one block + the right-hand side + the reciprocals -- written as one loop with
+// role branches the register allocator spilled ~100 bytes per lane into scratch in every phase (a block column then cost 5 us).
+__device__ __forceinline__ void lm_chol_offdiag(int nb, int t, LmCholShared& sh, const double* __restrict__ Sblk) {
+#pragma clang fp contract(fast)
+  const int n_off = nb * (nb - 1) / 2;
   int I0 = -1, J0 = -1, I1 = -1, J1 = -1;
-  double A0[36], A1[36], Y[6];
+  double A0[36], A1[36];
 #pragma unroll
   for (int k = 0; k < 36; ++k) A0[k] = 0.0, A1[k] = 0.0;
+  if (t < n_off) {
+    lm_tri_index(t, nb, I0, J0);
+    const double* src = Sblk + ((size_t)I0 * (I0 + 1) / 2 + J0) * 36;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) Y[k] = 0.0;
-  if (t < LM_CHOL_OFF) {
-    if (t < n_off) {
-      lm_tri_index(t, I0, J0);
-      const double* src = Sblk + ((size_t)I0 * (I0 + 1) / 2 + J0) * 36;
+    for (int k = 0; k < 36; ++k) A0[k] = src[k];
+  }
+  if (t + LM_CHOL_OFF < n_off) {
+    lm_tri_index(t + LM_CHOL_OFF, nb, I1, J1);
+    const double* src = Sblk + ((size_t)I1 * (I1 + 1) / 2 + J1) * 36;
 #pragma unroll
-      for (int k = 0; k < 36; ++k) A0[k] = src[k];
+    for (int k = 0; k < 36; ++k) A1[k] = src[k];
+  }
+  __syncthreads();  // (A) s_ok initialised
+  LM_ST_INIT
+  __syncthreads();  // (B) first diagonal block factorised
+  LM_ST(0)
+  for (int kb = 0; kb < nb; ++kb) {
+    if (!sh.ok) break;  // uniform (read after a barrier)
+    if (J0 == kb) {
+      lm_panel_solve(A0, sh.Lk, sh.Lk + 36);
+      double* dst = sh.P + (size_t)I0 * LM_PSTRIDE;
+#pragma unroll
+      for (int k = 0; k < 36; ++k) dst[k] = A0[k];
     }
-    if (t + LM_CHOL_OFF < n_off) {
-      lm_tri_index(t + LM_CHOL_OFF, I1, J1);
-      const double* src = Sblk + ((size_t)I1 * (I1 + 1) / 2 + J1) * 36;
+    if (J1 == kb) {
+      lm_panel_solve(A1, sh.Lk, sh.Lk + 36);
+      double* dst = sh.P + (size_t)I1 * LM_PSTRIDE;
 #pragma unroll
-      for (int k = 0; k < 36; ++k) A1[k] = src[k];
+      for (int k = 0; k < 36; ++k) dst[k] = A1[k];
     }
-  } else if (diag) {
-    I0 = J0 = t - LM_CHOL_OFF;
+    LM_ST(1)
+    __syncthreads();
+    LM_ST(2)
+    if (J0 > kb) lm_block_update(A0, sh.P + (size_t)I0 * LM_PSTRIDE, sh.P + (size_t)J0 * LM_PSTRIDE);
+    if (J1 > kb) lm_block_update(A1, sh.P + (size_t)I1 * LM_PSTRIDE, sh.P + (size_t)J1 * LM_PSTRIDE);
+    LM_ST(3)
+    __syncthreads();
+    LM_ST(4)
+  }
+  if (!sh.ok) return;
+  for (int kb = nb - 1; kb >= 0; --kb) {
+    __syncthreads();  // x_kb published by the diagonal owner
+    // y_J -= L_{kb,J}^T x_kb : the only writer of y_J in this step (a thread's two blocks have different (I, J))
+    if (I0 == kb) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double v = sh.yv[6 * J0 + c];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v = fma(-A0[6 * a + c], sh.yv[6 * kb + a], v);
+        sh.yv[6 * J0 + c] = v;
+      }
+    }
+    if (I1 == kb) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double v = sh.yv[6 * J1 + c];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v = fma(-A1[6 * a + c], sh.yv[6 * kb + a], v);
+        sh.yv[6 * J1 + c] = v;
+      }
+    }
+    __syncthreads();
+  }
+  LM_ST(6)
+}
+
+__device__ __forceinline__ void lm_chol_diag(int nb, int t, LmCholShared& sh, const double* __restrict__ Sblk, const double* __restrict__ rhs) {
+#pragma clang fp contract(fast)
+  const int I0 = t - LM_CHOL_OFF;
+  const bool diag = I0 < nb;
+  double A0[36], Y[6], invd[6];  // the diagonal block, its right-hand side, 1 / L_jj (substitutions multiply, they do not divide)
+#pragma unroll
+  for (int k = 0; k < 36; ++k) A0[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Y[k] = 0.0, invd[k] = 0.0;
+  if (diag) {
     const double* src = Sblk + ((size_t)I0 * (I0 + 1) / 2 + I0) * 36;
 #pragma unroll
     for (int k = 0; k < 36; ++k) A0[k] = src[k];
 #pragma unroll
     for (int k = 0; k < 6; ++k) Y[k] = rhs[6 * I0 + k];
   }
-  if (t == 0) s_ok = 1;
-  __syncthreads();
-
-  auto factor_diag = [&]() {  // lower Cholesky of A0 in place (this thread owns a diagonal block), publish L and 1 / diag
+  auto factor_diag = [&]() {  // lower Cholesky of A0 in place, right-looking; publish L and 1 / diag
     bool good = true;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      double d = A0[7 * j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) d -= A0[6 * j + k] * A0[6 * j + k];
+      const double d = A0[7 * j];
       if (!(d > 0) || !isfinite(d)) good = false;
-      d = sqrt(d);
-      A0[7 * j] = d;
-      const double inv = 1.0 / d;
-      Lk[36 + j] = inv;
+      // y ~ 1 / sqrt(d): hardware estimate + two Newton steps of three dependent operations each; L_jj = d y.  The six pivots of a
+      // diagonal block are the serial spine of the factorisation: sqrt() followed by a division was ~60 dependent operations per pivot
+      const double h = 0.5 * d;
+      double y = __builtin_amdgcn_rsq(d);
+      y = fma(y, fma(-(h * y), y, 0.5), y);
+      y = fma(y, fma(-(h * y), y, 0.5), y);
+      A0[7 * j] = d * y;
+      invd[j] = y;
 #pragma unroll
-      for (int i2 = j + 1; i2 < 6; ++i2) {
-        double v = A0[6 * i2 + j];
+      for (int i2 = j + 1; i2 < 6; ++i2) A0[6 * i2 + j] *= y;
 #pragma unroll
-        for (int k = 0; k < j; ++k) v -= A0[6 * i2 + k] * A0[6 * j + k];
-        A0[6 * i2 + j] = v * inv;
-      }
+      for (int i2 = j + 1; i2 < 6; ++i2)
+#pragma unroll
+        for (int k = j + 1; k <= i2; ++k) A0[6 * i2 + k] = fma(-A0[6 * i2 + j], A0[6 * k + j], A0[6 * i2 + k]);
     }
-    if (!good) s_ok = 0;
+    if (!good) sh.ok = 0;
 #pragma unroll
-    for (int k = 0; k < 36; ++k) Lk[k] = A0[k];
+    for (int k = 0; k < 36; ++k) sh.Lk[k] = A0[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sh.Lk[36 + k] = invd[k];
   };
+  __syncthreads();  // (A)
+  LM_ST_INIT
   if (diag && I0 == 0) factor_diag();
-  __syncthreads();
-
+  __syncthreads();  // (B)
+  LM_ST(0)
   for (int kb = 0; kb < nb; ++kb) {
-    if (!s_ok) break;  // uniform (read after a barrier)
-    // (2) panel: X L_kk^T = A for the blocks (I, kb), I > kb, and the right-hand-side block kb
-    if (!diag) {
-      if (J0 == kb) {
-        lm_panel_solve(A0, Lk, Lk + 36);
-        double* dst = P + (size_t)I0 * LM_PSTRIDE;
-#pragma unroll
-        for (int k = 0; k < 36; ++k) dst[k] = A0[k];
-      }
-      if (J1 == kb) {
-        lm_panel_solve(A1, Lk, Lk + 36);
-        double* dst = P + (size_t)I1 * LM_PSTRIDE;
-#pragma unroll
-        for (int k = 0; k < 36; ++k) dst[k] = A1[k];
-      }
-    } else if (I0 == kb) {  // y_kb L_kk^T = Y (the factor is still in this thread's registers)
+    if (!sh.ok) break;
+    if (diag && I0 == kb) {  // y_kb L_kk^T = Y (the factor is still in this thread's registers)
       double v[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
         double sv = Y[c];
 #pragma unroll
-        for (int m = 0; m < c; ++m) sv -= v[m] * A0[6 * c + m];
-        v[c] = sv * Lk[36 + c];
+        for (int m = 0; m < c; ++m) sv = fma(-v[m], A0[6 * c + m], sv);
+        v[c] = sv * invd[c];
       }
-      double* dst = P + (size_t)nb * LM_PSTRIDE;
+      double* dst = sh.P + (size_t)nb * LM_PSTRIDE;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) dst[k] = v[k], yv[6 * kb + k] = v[k];
+      for (int k = 0; k < 6; ++k) dst[k] = v[k], sh.yv[6 * kb + k] = v[k];
     }
+    LM_ST(1)
     __syncthreads();
-    // (3) trailing update: blocks (I, J) with J > kb (diagonal ones included), the right-hand-side blocks J > kb
-    if (!diag) {
-      if (J0 > kb) lm_block_update(A0, P + (size_t)I0 * LM_PSTRIDE, P + (size_t)J0 * LM_PSTRIDE);
-      if (J1 > kb) lm_block_update(A1, P + (size_t)I1 * LM_PSTRIDE, P + (size_t)J1 * LM_PSTRIDE);
-    } else if (I0 > kb) {
-      const double* PJ = P + (size_t)I0 * LM_PSTRIDE;
-      lm_block_update(A0, PJ, PJ);
-      const double* PY = P + (size_t)nb * LM_PSTRIDE;
+    LM_ST(2)
+    if (diag && I0 > kb) {
+      const double* PJ = sh.P + (size_t)I0 * LM_PSTRIDE;
+      lm_diag_update(A0, PJ);
+      const double* PY = sh.P + (size_t)nb * LM_PSTRIDE;
       double py[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) py[k] = PY[k];
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
         const double* q = PJ + 6 * c;
-        Y[c] -= py[0] * q[0] + py[1] * q[1] + py[2] * q[2] + py[3] * q[3] + py[4] * q[4] + py[5] * q[5];
+        double acc = Y[c];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) acc = fma(-py[m], q[m], acc);
+        Y[c] = acc;
       }
+      LM_ST(5)
       if (I0 == kb + 1) factor_diag();  // look-ahead: the next diagonal block is complete now
     }
+    LM_ST(3)
     __syncthreads();
+    LM_ST(4)
   }
-  if (!s_ok) {
-    if (t == 0) st->ok = 0;
-    for (int k = t; k < 6 * nb; k += LM_CHOL_THREADS) x[k] = 0.0;
-    return;
-  }
-  // backward substitution L^T x = y, block by block from the bottom
+  if (!sh.ok) return;
   for (int kb = nb - 1; kb >= 0; --kb) {
     if (diag && I0 == kb) {
       double xv[6];
 #pragma unroll
       for (int a = 5; a >= 0; --a) {
-        double v = yv[6 * kb + a];
+        double v = sh.yv[6 * kb + a];
 #pragma unroll
-        for (int m = a + 1; m < 6; ++m) v -= A0[6 * m + a] * xv[m];
-        xv[a] = v / A0[7 * a];
+        for (int m = a + 1; m < 6; ++m) v = fma(-A0[6 * m + a], xv[m], v);
+        xv[a] = v * invd[a];
       }
 #pragma unroll
-      for (int a = 0; a < 6; ++a) yv[6 * kb + a] = xv[a];
+      for (int a = 0; a < 6; ++a) sh.yv[6 * kb + a] = xv[a];
     }
     __syncthreads();
-    if (!diag) {  // y_J -= L_{kb,J}^T x_kb : the only writer of y_J in this step (a thread's two blocks have different (I, J))
-      if (I0 == kb) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          double v = yv[6 * J0 + c];
-#pragma unroll
-          for (int a = 0; a < 6; ++a) v -= A0[6 * a + c] * yv[6 * kb + a];
-          yv[6 * J0 + c] = v;
-        }
-      }
-      if (I1 == kb) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          double v = yv[6 * J1 + c];
-#pragma unroll
-          for (int a = 0; a < 6; ++a) v -= A1[6 * a + c] * yv[6 * kb + a];
-          yv[6 * J1 + c] = v;
-        }
-      }
-    }
     __syncthreads();
   }
-  for (int k = t; k < 6 * nb; k += LM_CHOL_THREADS) x[k] = yv[k];
+  LM_ST(6)
+}
+
+__global__ __launch_bounds__(LM_CHOL_THREADS) void k_lm_chol(int nb, LmState* __restrict__ st, const double* __restrict__ Sblk,
+                                                             const double* __restrict__ rhs, double* __restrict__ x) {
+  __shared__ __attribute__((aligned(16))) LmCholShared sh;
+  if (!lm_gate(st, 1)) return;
+  const int t = threadIdx.x;
+  if (t == 0) sh.ok = 1;
+  if (t < LM_CHOL_OFF)
+    lm_chol_offdiag(nb, t, sh, Sblk);
+  else
+    lm_chol_diag(nb, t, sh, Sblk, rhs);
+  __syncthreads();
+  if (!sh.ok) {
+    if (t == 0) st->ok = 0;
+    for (int k = t; k < 6 * nb; k += LM_CHOL_THREADS) x[k] = 0.0;
+    return;
+  }
+  for (int k = t; k < 6 * nb; k += LM_CHOL_THREADS) x[k] = sh.yv[k];
 }
 
 // SparseOptimizer::update into the OTHER buffer: poses <- exp(dx) * pose (free poses; fixed ones are copied), points <- point + Dinv (bl
-// - sum Hpl^T dxp); computeScale partial sums sum_i dx_i (lambda dx_i + b_i) per block -> scale_part[blockIdx.x]
-__global__ __launch_bounds__(256) void k_lm_update(int n_poses, int n_points, LmBuffers B, const LmState* __restrict__ st,
+// - sum Hpl^T dxp); computeScale partial sums sum_i dx_i (lambda dx_i + b_i) per block -> scale_part[blockIdx.x].
+// Blocks [0, pt_blocks): 32 points each, eight lanes per point (one edge each, fixed butterfly); the blocks after them: 256 poses each.
+__global__ __launch_bounds__(256) void k_lm_update(int n_poses, int n_points, int pt_blocks, LmBuffers B, const LmState* __restrict__ st,
                                                    const int32_t* __restrict__ pose_slot, const double* __restrict__ x,
                                                    const int32_t* __restrict__ pt_off, const int32_t* __restrict__ pt_edges,
                                                    const int32_t* __restrict__ edge_pose, const double* __restrict__ Dinv,
@@ -646,54 +778,64 @@ __global__ __launch_bounds__(256) void k_lm_update(int n_poses, int n_points, Lm
   if (!lm_gate(st, 1)) return;
   const int cur = st->cur, nxt = cur ^ 1;
   const double lambda = st->lambda;
-  const int t = blockIdx.x * 256 + threadIdx.x;
   double acc = 0.0;
-  if (t < n_points) {
-    const int p = t;
-    const double* bl = B.bl[cur] + (size_t)p * 3;
-    double r0 = bl[0], r1 = bl[1], r2 = bl[2];
-    for (int q = pt_off[p]; q < pt_off[p + 1]; ++q) {
-      const int e = pt_edges[q];
-      const int s = pose_slot[edge_pose[e]];
-      if (s < 0) continue;
-      const double* h = B.Hpl[cur] + (size_t)e * 18;
-      const double* d = x + 6 * s;
-      double s0 = 0, s1 = 0, s2 = 0;
+  if ((int)blockIdx.x < pt_blocks) {
+    const int p = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+    double s0 = 0, s1 = 0, s2 = 0;
+    if (p < n_points) {
+      for (int q = pt_off[p] + sub; q < pt_off[p + 1]; q += 8) {
+        const int e = pt_edges[q];
+        const int s = pose_slot[edge_pose[e]];
+        if (s < 0) continue;
+        const double* h = B.Hpl[cur] + (size_t)e * 18;
+        const double* d = x + 6 * s;
 #pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        s0 += h[3 * a] * d[a];
-        s1 += h[3 * a + 1] * d[a];
-        s2 += h[3 * a + 2] * d[a];
+        for (int a = 0; a < 6; ++a) {
+          s0 += h[3 * a] * d[a];
+          s1 += h[3 * a + 1] * d[a];
+          s2 += h[3 * a + 2] * d[a];
+        }
       }
-      r0 -= s0, r1 -= s1, r2 -= s2;
     }
-    const double* D = Dinv + (size_t)p * 9;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const double dv = D[3 * a] * r0 + D[3 * a + 1] * r1 + D[3 * a + 2] * r2;
-      B.points[nxt][(size_t)p * 3 + a] = B.points[cur][(size_t)p * 3 + a] + dv;
-      acc += dv * (lambda * dv + bl[a]);
+    for (int o = 1; o < 8; o <<= 1) {
+      s0 += __shfl_xor(s0, o);
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
     }
-  } else if (t < n_points + n_poses) {
-    const int k = t - n_points;
-    const int s = pose_slot[k];
-    const double* src = B.poses[cur] + (size_t)k * 7;
-    double* dst = B.poses[nxt] + (size_t)k * 7;
-    if (s >= 0) {
-      double upd[6];
+    if (p < n_points && sub == 0) {
+      const double* bl = B.bl[cur] + (size_t)p * 3;
+      const double r0 = bl[0] - s0, r1 = bl[1] - s1, r2 = bl[2] - s2;
+      const double* D = Dinv + (size_t)p * 9;
 #pragma unroll
-      for (int a = 0; a < 6; ++a) upd[a] = x[6 * s + a];
-      PoseDev T, R;
-      for (int a = 0; a < 4; ++a) T.q[a] = src[a];
-      for (int a = 0; a < 3; ++a) T.t[a] = src[4 + a];
-      pose_oplus(T, upd, R);
-      for (int a = 0; a < 4; ++a) dst[a] = R.q[a];
-      for (int a = 0; a < 3; ++a) dst[4 + a] = R.t[a];
-      const double* bp = B.bp[cur] + (size_t)k * 6;
+      for (int a = 0; a < 3; ++a) {
+        const double dv = D[3 * a] * r0 + D[3 * a + 1] * r1 + D[3 * a + 2] * r2;
+        B.points[nxt][(size_t)p * 3 + a] = B.points[cur][(size_t)p * 3 + a] + dv;
+        acc += dv * (lambda * dv + bl[a]);
+      }
+    }
+  } else {
+    const int k = ((int)blockIdx.x - pt_blocks) * 256 + threadIdx.x;
+    if (k < n_poses) {
+      const int s = pose_slot[k];
+      const double* src = B.poses[cur] + (size_t)k * 7;
+      double* dst = B.poses[nxt] + (size_t)k * 7;
+      if (s >= 0) {
+        double upd[6];
 #pragma unroll
-      for (int a = 0; a < 6; ++a) acc += upd[a] * (lambda * upd[a] + bp[a]);
-    } else {
-      for (int a = 0; a < 7; ++a) dst[a] = src[a];
+        for (int a = 0; a < 6; ++a) upd[a] = x[6 * s + a];
+        PoseDev T, R;
+        for (int a = 0; a < 4; ++a) T.q[a] = src[a];
+        for (int a = 0; a < 3; ++a) T.t[a] = src[4 + a];
+        pose_oplus(T, upd, R);
+        for (int a = 0; a < 4; ++a) dst[a] = R.q[a];
+        for (int a = 0; a < 3; ++a) dst[4 + a] = R.t[a];
+        const double* bp = B.bp[cur] + (size_t)k * 6;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc += upd[a] * (lambda * upd[a] + bp[a]);
+      } else {
+        for (int a = 0; a < 7; ++a) dst[a] = src[a];
+      }
     }
   }
   const double s = block_sum_256(acc, sh);
@@ -705,17 +847,18 @@ __global__ __launch_bounds__(256) void k_lm_update(int n_poses, int n_points, Lm
 // | 2: after the switch group | 3: the final point | 4: after the final group.
 // g2o: SparseOptimizer::optimize + OptimizationAlgorithmLevenberg::solve (tau = 1e-5, <= 10 trials per iteration).
 // ---------------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double lm_sum(const double* p, int n) {
+__device__ __forceinline__ double lm_sum(const double* p, int n) {  // all 64 lanes: lane-strided partial sums, then a fixed butterfly
   double s = 0;
-  for (int i = 0; i < n; ++i) s += p[i];
+  for (int i = threadIdx.x; i < n; i += 64) s += p[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   return s;
 }
 
 __global__ __launch_bounds__(64) void k_lm_ctrl(LmState* __restrict__ st, LmBuffers B, int mode, int chi_blocks, int scale_blocks,
                                                 const double* __restrict__ scale_part, const volatile uint8_t* __restrict__ abort_flag) {
 #pragma clang fp contract(off)
-  if (threadIdx.x != 0) return;
-  LmState s = *st;
+  LmState s = *st;  // (every lane runs the same scalar program; lane 0 stores the result)
   if (abort_flag && *abort_flag) s.stopped = 1;
   if (mode == 2 && s.run_switch) {  // the switch group has run: round 1 starts on the system it rebuilt (new information / no kernels)
     s.run_switch = 0;
@@ -725,18 +868,21 @@ __global__ __launch_bounds__(64) void k_lm_ctrl(LmState* __restrict__ st, LmBuff
     s.phase = 0;
     s.need_chi = 1;
   }
+  const int cur0 = s.cur;
+  const double sum_cur = lm_sum(B.chi_part[cur0], chi_blocks), sum_trial = lm_sum(B.chi_part[cur0 ^ 1], chi_blocks);
+  const double sum_scale = lm_sum(scale_part, scale_blocks);
   if (mode == 4 && s.run_final) {
     s.run_final = 0;
     s.finalized = 1;
   }
   if (s.need_chi) {
-    s.chi_of[s.cur] = lm_sum(B.chi_part[s.cur], chi_blocks);
+    s.chi_of[s.cur] = sum_cur;
     s.need_chi = 0;
   }
   // (a) a trial ran since the last control point: decide it
   if (s.phase == 1) {
-    const double chi_trial = lm_sum(B.chi_part[s.cur ^ 1], chi_blocks);
-    const double scale = lm_sum(scale_part, scale_blocks);
+    const double chi_trial = sum_trial;
+    const double scale = sum_scale;
     const bool ok2 = s.ok != 0;
     const double temp_chi = ok2 ? chi_trial : 1.7976931348623157e308;
     double rho = (s.current_chi - temp_chi) / (scale + 1e-3);
@@ -806,7 +952,7 @@ __global__ __launch_bounds__(64) void k_lm_ctrl(LmState* __restrict__ st, LmBuff
     }
     if (s.round == 2 && !s.finalized) s.run_final = 1;
   }
-  *st = s;
+  if (threadIdx.x == 0) *st = s;
 }
 
 // Optimizer.cc:338-359 between the two rounds: level 1 for chi2 > 5.991 / 7.815 or non-positive depth at the CURRENT estimate, kernels dropped
@@ -842,8 +988,9 @@ __global__ __launch_bounds__(256) void k_lm_classify(int n_edges, LmBuffers B, c
 __global__ __launch_bounds__(256) void k_lm_final(int n_edges, int n_poses, int n_points, LmBuffers B, const LmState* __restrict__ st,
                                                   const int32_t* __restrict__ edge_pose, const int32_t* __restrict__ edge_point,
                                                   const double* __restrict__ meas, const uint8_t* __restrict__ is_stereo,
-                                                  const double* __restrict__ info, BaParamsDev prm, double* __restrict__ chi2_out,
-                                                  uint8_t* __restrict__ bad, double* __restrict__ poses_out, double* __restrict__ points_out) {
+                                                  const double* __restrict__ info, BaParamsDev prm, const uint8_t* __restrict__ level,
+                                                  double* __restrict__ chi2_out, uint8_t* __restrict__ bad, uint8_t* __restrict__ level_out,
+                                                  double* __restrict__ poses_out, double* __restrict__ points_out) {
 #pragma clang fp contract(off)
   if (!lm_gate(st, 3)) return;
   const int buf = st->cur;
@@ -869,6 +1016,7 @@ __global__ __launch_bounds__(256) void k_lm_final(int n_edges, int n_poses, int 
     const double c2 = stq ? (e0 * (w * e0) + e1 * (w * e1) + e2 * (w * e2)) : (e0 * (w * e0) + e1 * (w * e1));
     chi2_out[e] = c2;
     bad[e] = (c2 > (stq ? 7.815 : 5.991) || !(z > 0.0)) ? 1 : 0;
+    level_out[e] = level[e];
   }
   for (int i = e; i < n_poses * 7; i += gridDim.x * 256) poses_out[i] = B.poses[buf][i];
   for (int i = e; i < n_points * 3; i += gridDim.x * 256) points_out[i] = B.points[buf][i];
@@ -887,7 +1035,7 @@ static LmBuffers lm_buffers(const LmLaunch& L) {
 // linearize + blocks of buffer cur ^ which, gated
 void launch_lm_build(hipStream_t s, const LmLaunch& L, int gate, int which, int write_last) {
   const LmBuffers B = lm_buffers(L);
-  const int eb = (L.E + 255) / 256, pb = (L.NP + 255) / 256;
+  const int eb = (L.E + 255) / 256, pb = (L.NP + 31) / 32;
   if (L.E > 0)
     hipLaunchKernelGGL(k_lm_linearize, dim3(eb), dim3(256), 0, s, L.E, B, L.state, gate, which, L.edge_pose, L.edge_point, L.meas, L.is_stereo,
                        L.info_eff, L.delta_eff, L.fixed, L.level, L.prm, L.chi2_last, write_last);
@@ -899,22 +1047,22 @@ void launch_lm_maxdiag(hipStream_t s, const LmLaunch& L, int gate) {
   hipLaunchKernelGGL(k_lm_maxdiag, dim3(1), dim3(1024), 0, s, L.NK, L.NP, lm_buffers(L), L.state, gate, L.fixed);
 }
 void launch_lm_ctrl(hipStream_t s, const LmLaunch& L, int mode) {
-  hipLaunchKernelGGL(k_lm_ctrl, dim3(1), dim3(64), 0, s, L.state, lm_buffers(L), mode, (L.E + 255) / 256, (L.NP + L.NK + 255) / 256, L.scale_part,
-                     L.abort_flag);
+  hipLaunchKernelGGL(k_lm_ctrl, dim3(1), dim3(64), 0, s, L.state, lm_buffers(L), mode, (L.E + 255) / 256, (L.NP + 31) / 32 + (L.NK + 255) / 256,
+                     L.scale_part, L.abort_flag);
 }
 // one trial: ctrl + solve + update + the system at the trial estimate
 void launch_lm_step(hipStream_t s, const LmLaunch& L) {
   const LmBuffers B = lm_buffers(L);
   launch_lm_ctrl(s, L, 0);
-  if (L.NP > 0) hipLaunchKernelGGL(k_lm_prep, dim3((L.NP + 255) / 256), dim3(256), 0, s, L.NP, B, L.state, L.pt_off, L.pt_edges, L.Dinv, L.W);
+  if (L.NP > 0) hipLaunchKernelGGL(k_lm_prep, dim3((L.NP + 31) / 32), dim3(256), 0, s, L.NP, B, L.state, L.pt_off, L.pt_edges, L.Dinv, L.W);
   if (L.nf > 0) {
     hipLaunchKernelGGL(k_lm_schur, dim3(L.nf * (L.nf + 1) / 2), dim3(64), 0, s, L.nf, B, L.state, L.free_pose, L.pair_off, L.pairs, L.ps_off,
                        L.ps_edges, L.edge_point, L.W, L.Sblk, L.rhs);
     hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(LM_CHOL_THREADS), 0, s, L.nf, L.state, L.Sblk, L.rhs, L.x);
   }
-  const int nt = L.NP + L.NK;
-  if (nt > 0)
-    hipLaunchKernelGGL(k_lm_update, dim3((nt + 255) / 256), dim3(256), 0, s, L.NK, L.NP, B, L.state, L.pose_slot, L.x, L.pt_off, L.pt_edges,
+  const int ub = (L.NP + 31) / 32 + (L.NK + 255) / 256;
+  if (ub > 0)
+    hipLaunchKernelGGL(k_lm_update, dim3(ub), dim3(256), 0, s, L.NK, L.NP, (L.NP + 31) / 32, B, L.state, L.pose_slot, L.x, L.pt_off, L.pt_edges,
                        L.edge_pose, L.Dinv, L.scale_part);
   launch_lm_build(s, L, 1, 1, 1);
 }
@@ -933,7 +1081,7 @@ void launch_lm_final(hipStream_t s, const LmLaunch& L) {
   launch_lm_ctrl(s, L, 3);
   const int n = std::max(L.E, 1);
   hipLaunchKernelGGL(k_lm_final, dim3((n + 255) / 256), dim3(256), 0, s, L.E, L.NK, L.NP, B, L.state, L.edge_pose, L.edge_point, L.meas, L.is_stereo,
-                     L.info, L.prm, L.chi2_out, L.bad, L.poses_out, L.points_out);
+                     L.info, L.prm, L.level, L.chi2_out, L.bad, L.level_out, L.poses_out, L.points_out);
   launch_lm_ctrl(s, L, 4);
 }
 

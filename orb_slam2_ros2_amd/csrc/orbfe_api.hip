@@ -2126,9 +2126,9 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
                o_big = take(nf > LBA_MAX_FREE ? ((n + 1) * 6 + (size_t)nf * 36 + n) * 8 : 8);
   // the device-side Levenberg-Marquardt path (k_lm.hip): second estimate / system buffers, per-edge terms, blocked reduced system
   const bool dev_lm = c->lm_on_device && E > 0 && nf <= LM_CHOL_MAX_NB;
-  const int chi_blocks = (E + 255) / 256, scale_blocks = (NP + NK + 255) / 256;
+  const int chi_blocks = (E + 255) / 256, scale_blocks = (NP + 31) / 32 + (NK + 255) / 256;
   size_t l_pose1 = 0, l_pt1 = 0, l_terms[2] = {0, 0}, l_hpl1 = 0, l_hpp1 = 0, l_bp1 = 0, l_hll1 = 0, l_bl1 = 0, l_chi[2] = {0, 0}, l_sblk = 0,
-         l_scale = 0, l_state = 0, l_pose_out = 0, l_pt_out = 0;
+         l_scale = 0, l_state = 0, l_pose_out = 0, l_pt_out = 0, l_chi2_out = 0, l_level_out = 0, l_bad_out = 0, l_out_end = 0;
   if (dev_lm) {
     l_pose1 = take((size_t)NK * 56), l_pt1 = take((size_t)NP * 24);
     l_terms[0] = take((size_t)E * 256), l_terms[1] = take((size_t)E * 256);
@@ -2136,13 +2136,22 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     l_bl1 = take((size_t)NP * 24);
     l_chi[0] = take((size_t)chi_blocks * 8), l_chi[1] = take((size_t)chi_blocks * 8);
     l_sblk = take((size_t)nf * (nf + 1) / 2 * 288), l_scale = take((size_t)scale_blocks * 8), l_state = take(sizeof(LmState));
-    l_pose_out = take((size_t)NK * 56), l_pt_out = take((size_t)NP * 24);
+    // the results as ONE block (one download): poses | points | chi2 | level | bad
+    l_pose_out = take((size_t)NK * 56), l_pt_out = take((size_t)NP * 24), l_chi2_out = take((size_t)E * 8), l_level_out = take((size_t)E),
+    l_bad_out = take((size_t)E), l_out_end = take(8);
   }
   TRY(ensure_tmp(c, off));
   uint8_t* b = (uint8_t*)c->d_tmp;
   hipStream_t st = c->stream;
+  // ONE upload: the inputs and the lists built above are laid out in page-locked staging memory exactly as in the device scratch
+  // (they are its first o_hpp bytes) and go up as a single asynchronous copy -- eighteen copies from pageable memory were staged by the
+  // runtime one by one, ~0.3 ms of a 4 ms call
+  const size_t up_bytes = o_hpp;
+  TRY(ensure_stage(c, std::max(up_bytes, dev_lm ? l_out_end - l_pose_out : (size_t)0)));  // (also the target of the one result download)
+  uint8_t* hs = c->main.h_stage;
   auto up = [&](size_t o2, const void* src, size_t bytes) -> hipError_t {
-    return bytes ? hipMemcpyAsync(b + o2, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess;
+    if (bytes) std::memcpy(hs + o2, src, bytes);
+    return hipSuccess;
   };
   std::vector<uint8_t> fixed_h(std::max(NK, 1), 0);
   if (pose_fixed) std::memcpy(fixed_h.data(), pose_fixed, NK);
@@ -2164,9 +2173,9 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
   HIP_TRY(c, up(o_slot, slot.data(), (size_t)NK * 4));
   HIP_TRY(c, up(o_pairoff, pair_off.data(), pair_off.size() * 4));
   HIP_TRY(c, up(o_pairs, pairs.data(), pairs.size() * 8));
+  HIP_TRY(c, hipMemcpyAsync(b, hs, up_bytes, hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemsetAsync(b + o_level, 0, std::max(E, 1), st));
   HIP_TRY(c, hipMemsetAsync(b + o_last, 0, (size_t)std::max(E, 1) * 8, st));
-  HIP_TRY(c, hipStreamSynchronize(st));  // the host vectors above go out of use only now
 
   const BaParamsDev prm = {p->fx, p->fy, p->cx, p->cy, p->bf};
   double* d_poses = (double*)(b + o_pose);
@@ -2197,14 +2206,14 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     L.meas = (const double*)(b + o_meas), L.info = (const double*)(b + o_info), L.is_stereo = b + o_st, L.fixed = b + o_fix;
     L.info_eff = (double*)(b + o_info_eff), L.delta_eff = (double*)(b + o_delta), L.chi2_last = (double*)(b + o_last), L.level = b + o_level;
     L.Dinv = (double*)(b + o_dinv), L.W = (double*)(b + o_w), L.Sblk = (double*)(b + l_sblk), L.rhs = (double*)(b + o_rhs), L.x = (double*)(b + o_x);
-    L.scale_part = (double*)(b + l_scale), L.chi2_out = (double*)(b + o_chi2), L.poses_out = (double*)(b + l_pose_out);
-    L.points_out = (double*)(b + l_pt_out), L.bad = b + o_bad, L.abort_flag = (const volatile uint8_t*)d_abort, L.prm = prm;
+    L.scale_part = (double*)(b + l_scale), L.chi2_out = (double*)(b + l_chi2_out), L.poses_out = (double*)(b + l_pose_out);
+    L.points_out = (double*)(b + l_pt_out), L.bad = b + l_bad_out, L.level_out = b + l_level_out;
+    L.abort_flag = (const volatile uint8_t*)d_abort, L.prm = prm;
     LmState init{};
     init.iters[0] = iters_first, init.iters[1] = iters_second, init.need_chi = 1, init.ok = 1;
     *c->h_lm_state = init;
     HIP_TRY(c, hipMemcpyAsync(L.state, c->h_lm_state, sizeof(LmState), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemsetAsync(L.Dinv, 0, (size_t)std::max(NP, 1) * 72, st));  // (read by a trial whose point block was singular)
-    HIP_TRY(c, hipStreamSynchronize(st));                                      // (the state record is re-used as the download target below)
     StageTimer tm(c, ORBFE_STAGE_BA, st);
     launch_lm_build(st, L, 0, 0, iters_first > 0 ? 1 : 0);  // computeActiveErrors + buildSystem at the initial estimate
     launch_lm_maxdiag(st, L, 0);
@@ -2217,11 +2226,8 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
       launch_lm_final(st, L);
       HIP_TRY(c, hipGetLastError());
       HIP_TRY(c, hipMemcpyAsync(c->h_lm_state, L.state, sizeof(LmState), hipMemcpyDeviceToHost, st));
-      HIP_TRY(c, hipMemcpyAsync(o->poses, L.poses_out, (size_t)NK * 56, hipMemcpyDeviceToHost, st));
-      HIP_TRY(c, hipMemcpyAsync(o->points, L.points_out, (size_t)NP * 24, hipMemcpyDeviceToHost, st));
-      if (o->level) HIP_TRY(c, hipMemcpyAsync(o->level, L.level, (size_t)E, hipMemcpyDeviceToHost, st));
-      if (o->chi2) HIP_TRY(c, hipMemcpyAsync(o->chi2, L.chi2_out, (size_t)E * 8, hipMemcpyDeviceToHost, st));
-      if (o->bad) HIP_TRY(c, hipMemcpyAsync(o->bad, L.bad, (size_t)E, hipMemcpyDeviceToHost, st));
+      const size_t out_bytes = l_out_end - l_pose_out;
+      HIP_TRY(c, hipMemcpyAsync(hs, b + l_pose_out, out_bytes, hipMemcpyDeviceToHost, st));  // the upload from hs finished long ago (stream order)
       if (stop_flag) {
         // the device polls the mapped byte between the trials; the caller's flag (LocalMapping::mbAbortBA, written by the Tracking
         // thread) is mirrored into it while this thread waits
@@ -2244,7 +2250,14 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
       }
       HIP_TRY(c, hipStreamSynchronize(st));
       fin = *c->h_lm_state;
-      if (fin.finalized) break;
+      if (fin.finalized) {
+        std::memcpy(o->poses, hs, (size_t)NK * 56);
+        std::memcpy(o->points, hs + (l_pt_out - l_pose_out), (size_t)NP * 24);
+        if (o->chi2) std::memcpy(o->chi2, hs + (l_chi2_out - l_pose_out), (size_t)E * 8);
+        if (o->level) std::memcpy(o->level, hs + (l_level_out - l_pose_out), (size_t)E);
+        if (o->bad) std::memcpy(o->bad, hs + (l_bad_out - l_pose_out), (size_t)E);
+        break;
+      }
       if (pass >= 64) return fail(c, ORBFE_EDEVICE, "ba_local_optimize: the device-side Levenberg-Marquardt loop did not finish (round %d, phase %d)", fin.round, fin.phase);
       steps_a = fin.switched || fin.round == 2 ? 0 : 4;  // more trials were rejected than provisioned: continue where the state stands
       steps_b = 4;

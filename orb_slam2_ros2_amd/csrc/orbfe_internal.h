@@ -154,7 +154,7 @@ struct LmLaunch {
   uint8_t* level;
   double *Dinv, *W, *Sblk, *rhs, *x, *scale_part;
   double *chi2_out, *poses_out, *points_out;
-  uint8_t* bad;
+  uint8_t *bad, *level_out;
   const volatile uint8_t* abort_flag;  // device address of a host-mapped byte the caller's stop flag is mirrored into
   BaParamsDev prm;
 };
