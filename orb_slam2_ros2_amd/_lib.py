@@ -582,8 +582,9 @@ class Context:
         self._check(self.lib.orbfe_ba_build_system(self.h, C.byref(prob), ptr(fixed), C.byref(o)))
         return out
 
-    def ba_local_optimize(self, prob, pose_fixed=None, iters_first=5, iters_second=10):
-        """prob: dict with the orbfe_ba_problem arrays (see ba_synth.make_problem) -> dict(poses, points, level, chi2, bad, iters)"""
+    def ba_local_optimize(self, prob, pose_fixed=None, iters_first=5, iters_second=10, stop=None):
+        """prob: dict with the orbfe_ba_problem arrays (see ba_synth.make_problem) -> dict(poses, points, level, chi2, bad, iters).
+        stop: a numpy uint8 array of one element another thread may set to 1 while the call runs (the reference's `bool& isStop`)"""
         f64 = lambda a, shape: np.ascontiguousarray(a, np.float64).reshape(shape)
         poses, points, meas = f64(prob["poses"], (-1, 7)), f64(prob["points"], (-1, 3)), f64(prob["meas"], (-1, 3))
         info, delta = f64(prob["info"], -1), f64(prob["huber_delta"], -1)
@@ -598,7 +599,9 @@ class Context:
                    bad=np.zeros(max(E, 1), np.uint8), iters=np.zeros(2, np.int32))
         o = BaOptimizeOut(ptr(out["poses"]).value, ptr(out["points"]).value, ptr(out["level"]).value, ptr(out["chi2"]).value,
                           ptr(out["bad"]).value, ptr(out["iters"]).value)
-        self._check(self.lib.orbfe_ba_local_optimize(self.h, C.byref(bp), ptr(fixed), iters_first, iters_second, None, C.byref(o)))
+        if stop is not None:
+            assert isinstance(stop, np.ndarray) and stop.dtype == np.uint8 and stop.size >= 1
+        self._check(self.lib.orbfe_ba_local_optimize(self.h, C.byref(bp), ptr(fixed), iters_first, iters_second, ptr(stop), C.byref(o)))
         for k in ("level", "chi2", "bad"):
             out[k] = out[k][:E]
         return out

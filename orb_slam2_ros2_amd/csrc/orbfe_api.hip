@@ -2217,7 +2217,9 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     StageTimer tm(c, ORBFE_STAGE_BA, st);
     launch_lm_build(st, L, 0, 0, iters_first > 0 ? 1 : 0);  // computeActiveErrors + buildSystem at the initial estimate
     launch_lm_maxdiag(st, L, 0);
-    int steps_a = iters_first + 1, steps_b = iters_second + 2;
+    // trials provisioned per pass: every iteration needs at least one, a rejected trial costs one more; what is left over runs as no-ops
+    // (a few microseconds each), what is missing is enqueued in the next pass, after the one synchronisation of this one
+    int steps_a = std::min(iters_first + 1, 24), steps_b = std::min(iters_second + 2, 24);
     LmState fin{};
     for (int pass = 0;; ++pass) {
       for (int k = 0; k < steps_a; ++k) launch_lm_step(st, L);
@@ -2258,9 +2260,10 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
         if (o->bad) std::memcpy(o->bad, hs + (l_bad_out - l_pose_out), (size_t)E);
         break;
       }
-      if (pass >= 64) return fail(c, ORBFE_EDEVICE, "ba_local_optimize: the device-side Levenberg-Marquardt loop did not finish (round %d, phase %d)", fin.round, fin.phase);
-      steps_a = fin.switched || fin.round == 2 ? 0 : 4;  // more trials were rejected than provisioned: continue where the state stands
-      steps_b = 4;
+      if (pass >= 4096) return fail(c, ORBFE_EDEVICE, "ba_local_optimize: the device-side Levenberg-Marquardt loop did not finish (round %d, phase %d)", fin.round, fin.phase);
+      // more trials were needed than provisioned: continue where the state stands
+      steps_a = fin.switched || fin.round == 2 ? 0 : std::min(std::max(iters_first - fin.it, 0) + 2, 24);
+      steps_b = std::min((fin.switched ? std::max(iters_second - fin.it, 0) : iters_second) + 2, 24);
     }
     if (o->iterations) {
       o->iterations[0] = fin.done[0];
