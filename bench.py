@@ -836,6 +836,13 @@ def main():
                 line["roofline_valu"] = {"kernel": dom, "bound": "valu", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s",
                                          "frac": ach / peak, "valu_per_wave": ent["valu_per_wave"], "waves_per_launch": ent["waves_per_step"],
                                          "source": "profiles/" + sq_files[-1]}
+                # the whole step against the same ceiling: sum over the kernels of waves x vector instructions per wave / the step time
+                tot_valu = sum(k["waves_per_step"] * k["valu_per_wave"] for k in sq["kernels"].values())
+                step_s = dt / args.steps
+                line["roofline_valu"]["pipeline_frac"] = tot_valu / step_s / peak
+                line["roofline_valu"]["pipeline_valu_issue_ms"] = tot_valu / peak * 1e3
+                line["roofline_valu"]["pipeline_what"] = ("vector instructions of ALL kernels of a step (SQ_INSTS_VALU x waves, committed counter pass) / "
+                                                          "step time / 614.4 G wave-instructions per second: the share of the step that is vector issue")
         except Exception:
             pass
 
@@ -848,6 +855,11 @@ def main():
             if ent and tj.get("pairs_per_step") == B and tj.get("images_per_launch") == images_per_launch:
                 line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
                 line["roofline"]["traffic_source"] = tj.get("source", "profiles/pmc_traffic.json")
+                pk = tj.get("per_kernel", {}).get(kern_of.get(dom, ""), {})
+                line["roofline"]["traffic_factor"] = pk.get("read_factor", 2.0)   # raw FETCH_SIZE -> bytes, for this kernel's load shape
+                line["roofline"]["traffic_factor_source"] = tj.get("read_factor_source", "MI355X_MICROARCH.md (x2)")
+                line["roofline"]["traffic_what"] = tj.get("what", "memory-side request bytes (Infinity-Cache hits included): an upper bound of the HBM bytes")
+                line["roofline"]["traffic_over_algorithmic"] = ent["hbm_bytes_per_launch"] / stage_bytes[dom]
         except Exception:
             pass
 

@@ -19,7 +19,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_f -- python3 bench.p
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_w -- python3 bench.py --steps 8 --warmup 1 --prewarm-seconds 0.2 --cpu-seconds 0 --host-io-steps 0 --sequence-leg 0 > /dev/null 2> $OUT/prof_w.err
 F=$(find $OUT/prof_f -name "*counter_collection.csv" | head -1)
 W=$(find $OUT/prof_w -name "*counter_collection.csv" | head -1)
-python3 tools/pmc_summary.py $F $W 512 $OUT/pmc_traffic.json 1024
+python3 tools/pmc_summary.py $F $W 512 $OUT/pmc_traffic.json 1024 profiles/r3_fetch_calibration.json
 python3 -c "import json; d=json.load(open('$OUT/pmc_traffic.json')); print({k: round(v['hbm_bytes_per_launch']/1e9, 3) for k, v in d['kernels'].items()})"
 # per-wave instruction counts (their own pass: counters only, no trace domains)
 rm -rf $OUT/prof_sq
