@@ -214,12 +214,31 @@ __device__ __forceinline__ int pp_group_tab(uint32_t x, uint32_t y, const uint16
 // Everything after the strip counts: scatter into the strip segments, best-first expansion, selection, ordering.
 // IN_LDS selects the address space of the record home H at compile time (ds_* instead of flat_* accesses: a flat access
 // costs several hundred cycles even when it lands in LDS, and a pop is a chain of dependent accesses).
-template <bool IN_LDS>
+// NW = waves per tree.  1: the batch path (one wave per tree: a 1024-image launch has more trees than the chip has wave slots to spare).
+// 4: small launches (a frame or two: 16 trees on 256 CUs) -- the best-first expansion itself stays on wave 0, but the phases around it
+// are data-parallel: the pre-partition (two passes over the candidates, ~45 us of a level-0 tree's 123 us on one wave) and the
+// per-node winner scan (~40 us) are spread over all four waves.  WSYNC: ordering inside the part only wave 0 runs (a wave's own LDS
+// traffic executes in order; its global traffic needs the wait) -- a workgroup barrier there when the wave is the whole workgroup.
+template <int NW>
+__device__ __forceinline__ void qt_wsync() {
+  if (NW == 1) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <bool IN_LDS, int NW>
 __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __restrict__ A, int N, uint32_t* H, uint32_t* __restrict__ T,
                                           double* n_rb, double* n_re, double* n_cb, double* n_ce, unsigned long long* n_key,
                                           uint32_t* n_beg, unsigned long long* sortbuf, unsigned long long* bkey, uint32_t* bj,
-                                          int batch_on, int node_cap, int need,
-                                          int sort_cap, uint32_t* __restrict__ out_sel, int32_t* __restrict__ sel_count_out, int lane) {
+                                          uint32_t* shared_ints, int batch_on, int node_cap, int need,
+                                          int sort_cap, uint32_t* __restrict__ out_sel, int32_t* __restrict__ sel_count_out, int lane, int wv) {
+  constexpr int NT = 64 * NW;
+  const int tid = wv * 64 + lane;
+  const bool w0 = wv == 0;
   int n_act = 0;
   uint32_t next_seq = 0;
   // ---- first pop: the root, whose children are the initSplit strips (ORBExtractor.cc:81-96, 147-170) ----
@@ -241,8 +260,8 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     uint32_t* cur = (uint32_t*)n_cb;  // group sizes, then group cursors (runs on into n_ce)
     uint16_t* xtab = (uint16_t*)n_key;
     uint16_t* ytab = xtab + tab_w2;
-    for (int g = lane; g < ng; g += 64) cur[g] = 0;
-    for (int x = lane; x < tab_w; x += 64) xtab[x] = 0;  // columns on a strip boundary or outside the region: bit 15 clear
+    for (int g = tid; g < ng; g += NT) cur[g] = 0;
+    for (int x = tid; x < tab_w; x += NT) xtab[x] = 0;  // columns on a strip boundary or outside the region: bit 15 clear
     PpGeom G;
     G.ns = ns;
     G.y_max = (int)ceil((double)L.reg_h) - 1;  // y > 0 && y < reg_h
@@ -253,7 +272,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       const double lo = L.strips[k < ns ? k : 0], hi = L.strips[k < ns ? k + 1 : 1];
       G.s_lo[k] = (int)floor(lo) + 1;  // x > lo
       G.s_hi[k] = (int)ceil(hi) - 1;   // x < hi
-      if (lane == k && k < ns) thr15(lo, hi, xt + 15 * k);
+      if (tid == k && k < ns) thr15(lo, hi, xt + 15 * k);
     }
     __syncthreads();
 #pragma unroll
@@ -262,11 +281,11 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         Thr t[15];
 #pragma unroll
         for (int q = 0; q < 15; ++q) t[q] = xt[15 * k + q];
-        for (int x = max(G.s_lo[k], 0) + lane; x <= G.s_hi[k] && x < tab_w; x += 64)
+        for (int x = max(G.s_lo[k], 0) + tid; x <= G.s_hi[k] && x < tab_w; x += NT)
           xtab[x] = (uint16_t)(0x8000u | ((uint32_t)k << 12) | pp_axis_code(x, t));
       }
     }
-    for (int y = lane; y < tab_h; y += 64) ytab[y] = (uint16_t)(((y >= 1 && y <= G.y_max) ? 0x8000u : 0u) | pp_axis_code(y, yt));
+    for (int y = tid; y < tab_h; y += NT) ytab[y] = (uint16_t)(((y >= 1 && y <= G.y_max) ? 0x8000u : 0u) | pp_axis_code(y, yt));
     __syncthreads();
     auto group_of = [&](uint32_t r) -> int {
       // (candidates lie inside the region; the clamp only guards the table)
@@ -283,12 +302,12 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     };
     {
       uint32_t nxt[16];
-      load16(0, nxt);
-      for (int b0 = 0; b0 < N; b0 += 1024) {
+      load16(wv * 1024, nxt);
+      for (int b0 = wv * 1024; b0 < N; b0 += NW * 1024) {
         uint32_t rec[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) rec[u] = nxt[u];
-        if (b0 + 1024 < N) load16(b0 + 1024, nxt);
+        if (b0 + NW * 1024 < N) load16(b0 + NW * 1024, nxt);
         int g[16];  // (all groups first, then the atomics: the table reads must not queue behind the atomics they may alias)
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -302,7 +321,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     }
     __syncthreads();
     // totals of the 84 + 256 nodes below every strip, then sizes -> cursors (exclusive prefix in layout order)
-    for (int t = lane; t < ns * QT_PP_TOTALS; t += 64) {
+    for (int t = tid; t < ns * QT_PP_TOTALS; t += NT) {
       const int st = t / QT_PP_TOTALS, k = t - QT_PP_TOTALS * st;
       const uint32_t* c = cur + st * QT_PP_GROUPS;
       uint32_t v = 0;
@@ -317,18 +336,18 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       }
       tot[t] = (uint16_t)v;
     }
-    for (int t = lane; t < ns * QT_PP_TOTALS4; t += 64) {
+    for (int t = tid; t < ns * QT_PP_TOTALS4; t += NT) {
       const int st = t / QT_PP_TOTALS4, m = t - QT_PP_TOTALS4 * st;  // m = 64 q1 + 16 q2 + 4 q3 + q4
       tot4[t] = (uint16_t)cur[st * QT_PP_GROUPS + (m >> 6) * 85 + ((m >> 4) & 3) * 21 + ((m >> 2) & 3) * 5 + (m & 3)];
     }
     __syncthreads();
     int carry = 0, strip_base = 0, strip_cnt = 0;  // lane st keeps the segment of strip st
-    for (int g0 = 0; g0 < ng; g0 += 64) {
+    for (int g0 = 0; w0 && g0 < ng; g0 += 64) {     // (one wave: a scan of ~22 rows of 64 group sizes)
       const int g = g0 + lane;
       const int v = (g < ng) ? (int)cur[g] : 0;
       const int incl = wave_incl_scan(v, lane);
       const int excl = carry + incl - v;
-      __syncthreads();
+      qt_wsync<NW>();
       if (g < ng) cur[g] = (uint32_t)excl;
       for (int st = 0; st < ns; ++st) {  // strip st starts at group 341 st and ends where strip st + 1 starts
         const int first = st * QT_PP_GROUPS, last = first + QT_PP_GROUPS - 1;
@@ -348,12 +367,12 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     // pass 2: scatter
     {
       uint32_t nxt[16];
-      load16(0, nxt);
-      for (int b0 = 0; b0 < N; b0 += 1024) {
+      load16(wv * 1024, nxt);
+      for (int b0 = wv * 1024; b0 < N; b0 += NW * 1024) {
         uint32_t rec[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) rec[u] = nxt[u];
-        if (b0 + 1024 < N) load16(b0 + 1024, nxt);
+        if (b0 + NW * 1024 < N) load16(b0 + NW * 1024, nxt);
         int g[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -369,7 +388,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       }
     }
     __syncthreads();
-    for (int st = 0; st < ns; ++st) {
+    for (int st = 0; w0 && st < ns; ++st) {
       const int c = __builtin_amdgcn_readlane(strip_cnt, st);
       const int off = __builtin_amdgcn_readlane(strip_base, st);
       if (c > 0) {
@@ -385,7 +404,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         ++next_seq;
       }
     }
-  } else {
+  } else if (w0) {
     // Pass 1 counts the records of each strip (lane s keeps strip s's counter), pass 2 scatters them into the
     // strip segments of H.  Four records per lane are in flight per step to hide the global-load latency.
     int my_cnt = 0;
@@ -660,7 +679,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
           n_act += grow;
           next_seq += (uint32_t)(grow + v);
           if (n_act + 3 > pp_limit) pp_ok = false;  // the table has reached the totals parked in its tail
-          if (!IN_LDS) __syncthreads();
+          if (!IN_LDS) qt_wsync<NW>();
           continue;
         }
       }
@@ -744,7 +763,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       for (int c = 0; c < QT_INPLACE_CHUNKS; ++c)
 #pragma unroll
         for (int k = 0; k < 4; ++k) c4[k] += __popcll(__ballot(q[c] == k));
-      if (!IN_LDS) __syncthreads();  // every record is in a register before the segment is overwritten
+      if (!IN_LDS) qt_wsync<NW>();  // every record is in a register before the segment is overwritten
       int run4[4] = {0, c4[0], c4[0] + c4[1], c4[0] + c4[1] + c4[2]};
 #pragma unroll
       for (int c = 0; c < QT_INPLACE_CHUNKS; ++c)
@@ -784,7 +803,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
           run4[k] += __popcll(m);
         }
       }
-      __syncthreads();
+      qt_wsync<NW>();
       const int kept = c4[0] + c4[1] + c4[2] + c4[3];
       for (int i = lane; i < kept; i += 64) seg[i] = tmp[i];
       c0 = c4[0];
@@ -825,7 +844,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       }
       next_seq += (uint32_t)added;
     }
-    if (!IN_LDS) __syncthreads();  // LDS traffic of one wave is executed in order; global needs the wait
+    if (!IN_LDS) qt_wsync<NW>();  // LDS traffic of one wave is executed in order; global needs the wait
   }
   __syncthreads();
 
@@ -847,13 +866,18 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     const uint32_t ms = wave_min_u32((bj >= 0 && bc == mc) ? bs : 0xFFFFFFFFu);
     const unsigned long long win = __ballot(bj >= 0 && bc == mc && bs == ms);
     const int j = __builtin_amdgcn_readlane(bj, __ffsll((long long)win) - 1);
-    __syncthreads();
+    qt_wsync<NW>();
     --n_act;
     if (lane == 0 && j != n_act) {
       n_key[j] = n_key[n_act];
       n_beg[j] = n_beg[n_act];
     }
+    qt_wsync<NW>();
+  }
+  if (NW > 1) {  // the helper waves join in again: they need the node count
+    if (w0 && lane == 0) shared_ints[0] = (uint32_t)n_act;
     __syncthreads();
+    n_act = (int)shared_ints[0];
   }
 
   // per node: first maximum response (ORBExtractor.cc:103-117).  Sort key = candidate order recomputed from the coordinates:
@@ -892,8 +916,18 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     // smaller strides exchange with lane ^ stride (a first version through LDS with a barrier per stage took 94 k cycles,
     // a quarter of the pop loop)
     unsigned long long key[8];
+    if (NW == 1) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) key[r] = (r * 64 < sort_cap) ? node_key(r * 64 + lane) : ~0ull;
+      for (int r = 0; r < 8; ++r) key[r] = (r * 64 < sort_cap) ? node_key(r * 64 + lane) : ~0ull;
+    } else {
+      // all waves scan nodes (one node per thread per trip); the keys meet in LDS (the fp64 bound arrays are dead), wave 0 sorts them
+      __syncthreads();
+      for (int j = tid; j < sort_cap; j += NT) sortbuf[j] = node_key(j);
+      __syncthreads();
+      if (!w0) return;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) key[r] = (r * 64 < sort_cap) ? sortbuf[r * 64 + lane] : ~0ull;
+    }
     for (int k = 2; k <= sort_cap; k <<= 1) {
       for (int st = k >> 1; st > 0; st >>= 1) {
         if (st >= 64) {
@@ -934,7 +968,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     }
   } else {
     // (the sort buffer aliases the fp64 bound arrays, which are dead now; keys / begins live behind them)
-    for (int j = lane; j < sort_cap; j += 64) {
+    for (int j = tid; j < sort_cap; j += NT) {
       const unsigned long long key = node_key(j);
       __syncthreads();
       sortbuf[j] = key;
@@ -942,7 +976,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     __syncthreads();
     for (int k = 2; k <= sort_cap; k <<= 1) {
       for (int st = k >> 1; st > 0; st >>= 1) {
-        for (int i = lane; i < sort_cap; i += 64) {
+        for (int i = tid; i < sort_cap; i += NT) {
           const int p = i ^ st;
           if (p > i) {
             const unsigned long long a = sortbuf[i], b2 = sortbuf[p];
@@ -956,24 +990,25 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         __syncthreads();
       }
     }
-    for (int j = lane; j < n_act; j += 64) {
+    for (int j = tid; j < n_act; j += NT) {
       const unsigned long long key = sortbuf[j];
       const uint32_t y = (uint32_t)(key >> 20) & 0xFFFu, x = (uint32_t)(key >> 8) & 0xFFFu, r = (uint32_t)key & 0xFFu;  // key = order<<8 | r
       out_sel[j] = ORBFE_PACK_XYR(x, y, r);
     }
   }
-  if (lane == 0) *sel_count_out = n_act;
+  if (w0 && lane == 0) *sel_count_out = n_act;
 }
 
 
-__global__ __launch_bounds__(64) void k_quadtree(const LevelDev* __restrict__ lv, int n_levels, const uint32_t* __restrict__ cand,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_quadtree(const LevelDev* __restrict__ lv, int n_levels, const uint32_t* __restrict__ cand,
                                                  uint32_t* __restrict__ scratch_b, uint32_t* __restrict__ scratch_c,
                                                  size_t scratch_pitch,
                                                  uint32_t* __restrict__ sel, int32_t* __restrict__ sel_count, int n_features,
                                                  const int32_t* __restrict__ n_cand, int node_cap, int sort_cap, int rec_cap, int batch,
                                                  QtGroups groups) {
   extern __shared__ double lds[];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int img = blockIdx.y;
   // One wave works through the trees of a GROUP of levels, one after the other (blockIdx.x = group; the host balances the groups by
   // quota: the level-0 tree alone, the small levels together).  With one wave per level a 1024-image launch filled every wave slot
@@ -991,7 +1026,8 @@ __global__ __launch_bounds__(64) void k_quadtree(const LevelDev* __restrict__ lv
   uint32_t* n_beg = (uint32_t*)(n_key + node_cap);
   unsigned long long* bkey = (unsigned long long*)(n_beg + ((node_cap + 1) & ~1));  // head list of the batched pops: 64 keys + 64 slots
   uint32_t* bj = (uint32_t*)(bkey + 64);
-  uint32_t* lds_recs = bj + 64;
+  uint32_t* shared_ints = bj + 64;  // [4]: what wave 0 tells the helper waves of a tree
+  uint32_t* lds_recs = shared_ints + 4;
   unsigned long long* sortbuf = (unsigned long long*)lds;
 
   uint32_t* out_sel = sel + (size_t)img * n_features + L.quota_off;
@@ -1005,6 +1041,7 @@ __global__ __launch_bounds__(64) void k_quadtree(const LevelDev* __restrict__ lv
 
   if (need <= 1) {
     // while (mnNodes < mnNeedNodes ...) never runs: the map holds only the root (ORBExtractor.cc:151)
+    if (wv != 0) continue;  // (one wave's work)
     if (need == 1 && N > 0) {
       // root->getFeature(): maximum response, first in candidate order on ties
       uint32_t br = 0;
@@ -1036,12 +1073,13 @@ __global__ __launch_bounds__(64) void k_quadtree(const LevelDev* __restrict__ lv
   }
 
   if (in_lds)
-    tree_body<true>(L, A, N, lds_recs, gb, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, bkey, bj, batch, node_cap, need, sort_cap, out_sel,
-                    sel_count + (size_t)img * n_levels + level, lane);
+    tree_body<true, NW>(L, A, N, lds_recs, gb, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, bkey, bj, shared_ints, batch, node_cap, need, sort_cap,
+                        out_sel, sel_count + (size_t)img * n_levels + level, lane, wv);
   else
-    tree_body<false>(L, A, N, gb, gc, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, bkey, bj, batch, node_cap, need, sort_cap, out_sel,
-                     sel_count + (size_t)img * n_levels + level, lane);
+    tree_body<false, NW>(L, A, N, gb, gc, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, bkey, bj, shared_ints, batch, node_cap, need, sort_cap,
+                         out_sel, sel_count + (size_t)img * n_levels + level, lane, wv);
   // the next tree reuses the LDS: the accesses of one wave execute in order, the fence only pins the compiler
+  if (NW > 1) __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   }
@@ -1049,7 +1087,7 @@ __global__ __launch_bounds__(64) void k_quadtree(const LevelDev* __restrict__ lv
 
 size_t quadtree_lds_bytes(int node_cap, int rec_cap) {
   return (size_t)node_cap * (4 * sizeof(double) + sizeof(unsigned long long) + sizeof(uint32_t)) + 8 + 64 * (sizeof(unsigned long long) + sizeof(uint32_t)) +
-         (size_t)rec_cap * sizeof(uint32_t);
+         16 + (size_t)rec_cap * sizeof(uint32_t);
 }
 
 // The dynamic-LDS limit of a kernel is state of the process and the device, not of a context: contexts of different geometries come
@@ -1064,18 +1102,23 @@ hipError_t quadtree_configure(size_t lds_bytes) {
   std::lock_guard<std::mutex> lk(mu);
   const int slot = dev >= 0 && dev < 64 ? dev : 63;
   if (lds_bytes <= current[slot]) return hipSuccess;
-  e = hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  e = hipFuncSetAttribute((const void*)k_quadtree<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_quadtree<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e == hipSuccess) current[slot] = lds_bytes;
   return e;
 }
 
 void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint32_t* d_cand, uint32_t* d_scr_b, uint32_t* d_scr_c,
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
-                     int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups) {
+                     int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree) {
   if (n_img <= 0) return;
   const size_t lds = quadtree_lds_bytes(node_cap, rec_cap);
-  hipLaunchKernelGGL(k_quadtree, dim3(n_groups, n_img), dim3(64), lds, s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
-                     d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups);
+  if (waves_per_tree >= 4)
+    hipLaunchKernelGGL(k_quadtree<4>, dim3(n_groups, n_img), dim3(256), lds, s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
+                       d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups);
+  else
+    hipLaunchKernelGGL(k_quadtree<1>, dim3(n_groups, n_img), dim3(64), lds, s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
+                       d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups);
 }
 
 }  // namespace orbfe

@@ -40,7 +40,7 @@ size_t quadtree_lds_bytes(int node_cap, int rec_cap);
 hipError_t quadtree_configure(size_t lds_bytes);
 void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint32_t* d_cand, uint32_t* d_scr_b, uint32_t* d_scr_c,
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
-                     int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups);
+                     int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree);
 // k_brief.hip
 void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
@@ -214,6 +214,7 @@ struct orbfe_ctx {
   bool qt_groups_forced = false;
   int rec_cap = 0;           // upper bound of candidate records one quadtree wave keeps in LDS (launch picks <= this)
   int qt_batch = 1;          // k_quadtree: several pops per step (ORBFE_QT_BATCH=0: one at a time)
+  int qt_waves = 4;          // waves per tree in launches of a frame or two (ORBFE_QT_WAVES=1: one)
   int n_cu = 256;            // compute units of the device
   int node_cap = 0, sort_cap = 0;
   int lvl_max_pw[ORBFE_MAX_LEVELS] = {0}, lvl_max_ph[ORBFE_MAX_LEVELS] = {0};  // largest FAST cell patch per level (sizes the LDS of k_fast)
@@ -678,6 +679,7 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
       c->qt_n_groups = ng;
     }
     if (const char* env = getenv("ORBFE_QT_BATCH")) c->qt_batch = atoi(env) != 0;
+    if (const char* env = getenv("ORBFE_QT_WAVES")) c->qt_waves = atoi(env);
     if (const char* env = getenv("ORBFE_FAST_SIDE_FROM")) c->fast_side_from = atoi(env);
   }
   // umax (ORBExtractor::initMaxU)
@@ -896,7 +898,9 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     const int rec_cap = budget > node_bytes ? (int)std::min<size_t>((budget - node_bytes) / 4, (size_t)c->rec_cap) : 0;
     launch_quadtree(st, c->d_lv, nl, c->d_scr_a + i0 * c->scratch_pitch, c->d_scr_b + i0 * c->scratch_pitch,
                     c->d_scr_c + i0 * c->scratch_pitch, c->scratch_pitch, c->d_sel + i0 * NF, c->d_sel_count + i0 * nl,
-                    c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img, c->qt_batch, grouped ? c->qt_groups : c->qt_single, n_groups);
+                    c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img, c->qt_batch, grouped ? c->qt_groups : c->qt_single, n_groups,
+                    // helper waves for the data-parallel phases of a tree where the launch leaves the chip empty (a frame or two)
+                    (!grouped && trees * 4 <= c->n_cu * 4 && c->qt_waves > 1) ? 4 : 1);
   }
   {
     StageTimer t(c, ORBFE_STAGE_BRIEF, st, timing);
