@@ -71,9 +71,9 @@ typedef struct orbfe_keypoint {
 
 typedef struct orbfe_config {
   int32_t width, height;       /* level-0 image size (e.g. 1241x376 KITTI, 640x480 TUM)                 */
-  int32_t n_features;          /* ORBExtractor.nFeatures.  Capacity limit: the largest per-level quota (level 0) must
-                                  stay below ~2700 keypoints (its quadtree node table lives in one CU's LDS), i.e.
-                                  nFeatures <= ~12000 for 8 levels at scale 1.2; larger values fail with ORBFE_EBADARG.
+  int32_t n_features;          /* ORBExtractor.nFeatures.  No limit besides 65535 (indices of the stereo row table are 16 bit):
+                                  a level whose quota exceeds ~2700 keypoints (nFeatures > ~12000 at 8 levels x 1.2) keeps its
+                                  quadtree node table in global memory instead of one CU's LDS -- exact, slower.
                                   (One more deviation, harmless: the quadtree's split loop is capped at 80 N + 1024 steps for N
                                   candidates; the reference's degenerate case -- fewer candidates than the quota, quirk Q3 -- ends
                                   by itself after ~50 halvings per point, far below the cap.)                              */

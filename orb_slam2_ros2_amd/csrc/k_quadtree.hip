@@ -230,7 +230,11 @@ __device__ __forceinline__ void qt_wsync() {
   }
 }
 
-template <bool IN_LDS, int NW>
+// NODES_LDS = false: the node table and the sort buffer live in GLOBAL memory (a level whose quota one CU's LDS cannot hold: the
+// reference has no limit on nFeatures, ORBExtractor.cc:291-301).  The records are global then too (IN_LDS = false), so every step
+// already ends in the wait that orders a wave's global stores before its next loads; the pre-partition (whose tables borrow the LDS
+// node arrays) is off and the strips are counted with ballots.  Slow (a pop is a chain of global round trips) but exact.
+template <bool IN_LDS, int NW, bool NODES_LDS = true>
 __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __restrict__ A, int N, uint32_t* H, uint32_t* __restrict__ T,
                                           double* n_rb, double* n_re, double* n_cb, double* n_ce, unsigned long long* n_key,
                                           uint32_t* n_beg, unsigned long long* sortbuf, unsigned long long* bkey, uint32_t* bj,
@@ -251,7 +255,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
   // coordinate -> code tables (uint16) in the n_key array, cursors across n_cb | n_ce, x thresholds in n_re: the node table is not in use yet
   const int tab_w = (int)ceil(L.strips[ns]) + 1, tab_h = (int)ceil((double)L.reg_h) + 1;
   const int tab_w2 = (tab_w + 1) & ~1;
-  bool pp_ok = N > 0 && N <= 65535 && ns <= QT_PP_MAX_STRIPS && node_cap >= 176 && tab_w <= 4096 && tab_h <= 4096 &&
+  bool pp_ok = NODES_LDS && N > 0 && N <= 65535 && ns <= QT_PP_MAX_STRIPS && node_cap >= 176 && tab_w <= 4096 && tab_h <= 4096 &&
                (tab_w2 + tab_h) * 2 <= node_cap * 8 && ns * QT_PP_GROUPS * 4 <= node_cap * 16 && ns * 15 * 8 <= node_cap * 8 &&
                n4_off + ns * (QT_PP_TOTALS4 / 2) <= (int)L.cand_cap;
   if (pp_ok) {
@@ -1006,7 +1010,7 @@ __global__ __launch_bounds__(64 * NW) void k_quadtree(const LevelDev* __restrict
                                                  size_t scratch_pitch,
                                                  uint32_t* __restrict__ sel, int32_t* __restrict__ sel_count, int n_features,
                                                  const int32_t* __restrict__ n_cand, int node_cap, int sort_cap, int rec_cap, int batch,
-                                                 QtGroups groups) {
+                                                 QtGroups groups, uint8_t* __restrict__ big_base, size_t big_pitch) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int img = blockIdx.y;
@@ -1072,7 +1076,16 @@ __global__ __launch_bounds__(64 * NW) void k_quadtree(const LevelDev* __restrict
     continue;
   }
 
-  if (in_lds)
+  if (L.qt_big_cap > 0) {  // the level's node table does not fit the LDS: everything in global memory
+    const size_t cap = (size_t)L.qt_big_cap;
+    double* g_rb = (double*)(big_base + (size_t)img * big_pitch + L.qt_big_off);
+    double *g_re = g_rb + cap, *g_cb = g_re + cap, *g_ce = g_cb + cap;
+    unsigned long long* g_key = (unsigned long long*)(g_ce + cap);
+    uint32_t* g_beg = (uint32_t*)(g_key + cap);
+    unsigned long long* g_sort = (unsigned long long*)(g_beg + ((cap + 1) & ~(size_t)1));
+    tree_body<false, NW, false>(L, A, N, gb, gc, g_rb, g_re, g_cb, g_ce, g_key, g_beg, g_sort, bkey, bj, shared_ints, batch, (int)cap, need,
+                                L.qt_big_sort, out_sel, sel_count + (size_t)img * n_levels + level, lane, wv);
+  } else if (in_lds)
     tree_body<true, NW>(L, A, N, lds_recs, gb, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, bkey, bj, shared_ints, batch, node_cap, need, sort_cap,
                         out_sel, sel_count + (size_t)img * n_levels + level, lane, wv);
   else
@@ -1110,15 +1123,15 @@ hipError_t quadtree_configure(size_t lds_bytes) {
 
 void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint32_t* d_cand, uint32_t* d_scr_b, uint32_t* d_scr_c,
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
-                     int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree) {
+                     int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree, uint8_t* d_big, size_t big_pitch) {
   if (n_img <= 0) return;
   const size_t lds = quadtree_lds_bytes(node_cap, rec_cap);
   if (waves_per_tree >= 4)
     hipLaunchKernelGGL(k_quadtree<4>, dim3(n_groups, n_img), dim3(256), lds, s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
-                       d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups);
+                       d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch);
   else
     hipLaunchKernelGGL(k_quadtree<1>, dim3(n_groups, n_img), dim3(64), lds, s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
-                       d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups);
+                       d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch);
 }
 
 }  // namespace orbfe

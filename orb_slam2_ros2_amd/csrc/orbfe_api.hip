@@ -40,7 +40,7 @@ size_t quadtree_lds_bytes(int node_cap, int rec_cap);
 hipError_t quadtree_configure(size_t lds_bytes);
 void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint32_t* d_cand, uint32_t* d_scr_b, uint32_t* d_scr_c,
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
-                     int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree);
+                     int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree, uint8_t* d_big, size_t big_pitch);
 // k_brief.hip
 void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
@@ -226,6 +226,8 @@ struct orbfe_ctx {
   int8_t* d_pattern = nullptr;
   uint8_t *d_pyr = nullptr, *d_blur = nullptr;
   uint32_t *d_scr_a = nullptr, *d_scr_b = nullptr, *d_scr_c = nullptr;  // candidate lists | quadtree home / bounce buffers
+  uint8_t* d_qt_big = nullptr;  // node tables + sort buffers of the levels whose quota does not fit one CU's LDS (qt_big_pitch bytes per image)
+  size_t qt_big_pitch = 0;
   uint32_t* d_sel = nullptr;
   int32_t *d_sel_count = nullptr, *d_n_cand = nullptr, *d_n_kp = nullptr;
   orbfe_keypoint* d_kps = nullptr;
@@ -643,12 +645,32 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
   c->bl_tiles = bl_tiles;
   c->img_pitch = align_up(plane_off, 4096);
   c->scratch_pitch = align_up(cand_base, 64);
-  c->node_cap = max_quota + max_ini + 8;
+  // The node table of a level lives in one CU's LDS as far as that goes (~2700 nodes in 120 KB); the reference has no limit on
+  // nFeatures (ORBExtractor.cc:291-301), so the levels with larger quotas keep theirs in global memory (k_quadtree, NODES_LDS = false)
+  int lds_nodes = max_quota + max_ini + 8;
+  while (quadtree_lds_bytes(lds_nodes, 0) > 120 * 1024) lds_nodes -= 8;
+  if (const char* env = getenv("ORBFE_QT_LDS_NODES")) lds_nodes = std::max(64, std::min(lds_nodes, atoi(env)));  // (tests: force the global path)
+  int max_lds_quota = 0;
+  size_t big_off = 0;
+  for (int l = 0; l < nl; ++l) {
+    LevelDev& L = c->lv[l];
+    L.qt_big_off = 0, L.qt_big_cap = 0, L.qt_big_sort = 0;
+    const int cap_l = quota[l] + max_ini + 8;
+    if (cap_l <= lds_nodes) {
+      max_lds_quota = std::max(max_lds_quota, quota[l]);
+      continue;
+    }
+    int sl = 2;
+    while (sl < quota[l]) sl <<= 1;
+    L.qt_big_off = (uint32_t)big_off, L.qt_big_cap = cap_l, L.qt_big_sort = sl;
+    big_off += align_up((size_t)cap_l * 44 + 8 + (size_t)sl * 8, 256);
+  }
+  c->qt_big_pitch = big_off;
+  c->node_cap = std::min(lds_nodes, max_lds_quota + max_ini + 8);
+  c->node_cap = std::max(c->node_cap, 192);  // (the pre-partition borrows the node arrays for its tables)
   int sc = 2;
-  while (sc < max_quota) sc <<= 1;
+  while (sc < max_lds_quota) sc <<= 1;
   c->sort_cap = sc;
-  if (quadtree_lds_bytes(c->node_cap, 0) > 120 * 1024)
-    return fail(c, ORBFE_EBADARG, "per-level quota %d needs more LDS than one CU has", max_quota);
   {
     uint32_t max_cand = 0;
     for (int l = 0; l < nl; ++l) max_cand = std::max(max_cand, c->lv[l].cand_cap);
@@ -900,7 +922,8 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
                     c->d_scr_c + i0 * c->scratch_pitch, c->scratch_pitch, c->d_sel + i0 * NF, c->d_sel_count + i0 * nl,
                     c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img, c->qt_batch, grouped ? c->qt_groups : c->qt_single, n_groups,
                     // helper waves for the data-parallel phases of a tree where the launch leaves the chip empty (a frame or two)
-                    (!grouped && trees * 4 <= c->n_cu * 4 && c->qt_waves > 1) ? 4 : 1);
+                    (!grouped && trees * 4 <= c->n_cu * 4 && c->qt_waves > 1) ? 4 : 1, c->d_qt_big ? c->d_qt_big + i0 * c->qt_big_pitch : nullptr,
+                    c->qt_big_pitch);
   }
   {
     StageTimer t(c, ORBFE_STAGE_BRIEF, st, timing);
@@ -960,7 +983,7 @@ void orbfe_destroy(orbfe_ctx* c) {
   void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_rs_tiles, c->d_pattern, c->d_pyr,     c->d_blur,
                   c->d_scr_a, c->d_scr_c,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_kp,
                   c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos, c->d_kx, c->d_kpl,   c->d_right_u, c->d_depth, c->d_n_match,
-                  c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist, c->d_rs_regions, c->d_rg_xtaps, c->d_rg_ytaps};
+                  c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist, c->d_rs_regions, c->d_rg_xtaps, c->d_rg_ytaps, c->d_qt_big};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -1009,7 +1032,7 @@ void orbfe_destroy(orbfe_ctx* c) {
 orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   if (!cfg || !out) return fail(nullptr, ORBFE_EBADARG, "orbfe_create: NULL argument");
   *out = nullptr;
-  if (cfg->width <= 0 || cfg->height <= 0 || cfg->n_features < 0 || cfg->n_levels < 1 || cfg->n_levels > ORBFE_MAX_LEVELS ||
+  if (cfg->width <= 0 || cfg->height <= 0 || cfg->n_features < 0 || cfg->n_features > 65535 || cfg->n_levels < 1 || cfg->n_levels > ORBFE_MAX_LEVELS ||
       !(cfg->scale_factor > 1.0f) || cfg->max_images < 1 || cfg->max_images > 65535)
     return fail(nullptr, ORBFE_EBADARG, "orbfe_create: bad config (w=%d h=%d nfeat=%d levels=%d scale=%g max_images=%d)", cfg->width,
                 cfg->height, cfg->n_features, cfg->n_levels, (double)cfg->scale_factor, cfg->max_images);
@@ -1120,6 +1143,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   ALLOC(c->d_scr_a, M * c->scratch_pitch);
   ALLOC(c->d_scr_b, M * c->scratch_pitch);
   ALLOC(c->d_scr_c, M * c->scratch_pitch);
+  if (c->qt_big_pitch) ALLOC(c->d_qt_big, M * c->qt_big_pitch);
   ALLOC(c->d_sel, M * NF);
   ALLOC(c->d_sel_count, M * NL);
   ALLOC(c->d_n_cand, M * NL);

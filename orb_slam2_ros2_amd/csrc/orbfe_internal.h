@@ -86,6 +86,10 @@ struct LevelDev {
   uint32_t cand_base;    // first record (uint32 units) of this level inside one image's candidate buffer
   uint32_t cand_cap;     // = n_cells * cell_cap
   int32_t n_ini;         // root strips
+  // a level whose quota does not fit the node table one CU's LDS can hold keeps its table (and sort buffer) in global memory:
+  // qt_big_cap > 0 nodes at byte offset qt_big_off of the image's block of the context's d_qt_big buffer, qt_big_sort keys to sort
+  uint32_t qt_big_off;
+  int32_t qt_big_cap, qt_big_sort;
   double strips[ORBFE_MAX_STRIPS + 1];
   // resize tap tables (levels >= 1): offsets into the context's tap array
   uint32_t xtab_off, ytab_off;

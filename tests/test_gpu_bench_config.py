@@ -59,6 +59,10 @@ KNOBS = [
     {"ORBFE_QT_REC_CAP": "0"},            # quadtree: records in global memory + bounce buffer (what 1024 images per launch use)
     {"ORBFE_QT_REC_CAP": "600"},          # ... and a partial LDS cache
     {"ORBFE_QT_BATCH": "0"},              # one pop per step
+    {"ORBFE_QT_WAVES": "1"},              # one wave per tree in the host-pointer / slot paths too (default there: four)
+    {"ORBFE_QT_LDS_NODES": "300"},        # node tables of the levels with quota > ~290 in GLOBAL memory (what nFeatures > ~12 000 uses)
+    {"ORBFE_QT_LDS_NODES": "300", "ORBFE_QT_WAVES": "1", "ORBFE_QT_BATCH": "0"},
+    {"ORBFE_LBA_HOST_LM": "1"},           # (no effect on this path; the switch must at least not break context creation)
     {"ORBFE_QT_GROUPS": "8"},             # one quadtree wave per level (default: the levels of an image dealt to 4 waves)
     {"ORBFE_QT_GROUPS": "1"},             # ... and all levels of an image in one wave
     {"ORBFE_PIPELINE_STEREO": "0"},       # stereo match in line

@@ -563,3 +563,24 @@ def test_device_batch_whose_resize_reads_the_callers_images(orc, lib):
             n = len(lk)
             assert nm == r["n_matches"] and np.array_equal(ru[:n], r["right_u"]) and np.array_equal(dp[:n], r["depth"]), (stride, f)
     ctx.close()
+
+
+def test_no_limit_on_n_features_20000(orc):
+    """The reference has no bound on nFeatures (ORBExtractor.cc:291-301: quotas are just rounded shares).  At 20 000 features the quotas of
+    levels 0-2 (4340 / 3617 / 3014) exceed the node table one CU's LDS can hold: those trees keep their tables in global memory.  A dense
+    frame (many more FAST corners than the quotas) so that the big trees really select; and the standard frame, where levels with fewer
+    candidates than their quota come out empty (quirk Q3)."""
+    from orb_slam2_ros2_amd._lib import Context
+    ctx = Context(W, H, n_features=20000, max_images=2)
+    assert ctx.n_features >= 20000
+    for n_rect in (1500, 260):
+        L, R = synth.stereo_pair(11, W, H, n_rect=n_rect)
+        (lk, ld), (rk, rd) = ctx.extract_batch([L, R])
+        ek, ed = orc.extractor(L, n_features=20000).extract()
+        assert np.array_equal(lk, ek) and np.array_equal(ld, ed), n_rect
+        if n_rect == 1500:
+            assert len(lk) > 12000 and (lk["octave"] == 0).sum() == 4340
+        ref = orc.stereo_frame(L, R, n_features=20000, fx=FX, bf=BF)
+        nm, ru, dp, _, _ = ctx.stereo_match(0, 1, FX, BF)
+        assert np.array_equal(rk, ref["rk"]) and nm == ref["n_matches"] and np.array_equal(ru[:len(lk)], ref["right_u"])
+    ctx.close()
