@@ -117,12 +117,8 @@ def test_fuzzed_geometries(orc, lib, seed):
         with pytest.raises(lib.ImageSizeError):
             lib.Context(w, h, n_features=nf, n_levels=nl, scale_factor=sc, fast_hi=hi, fast_lo=lo, max_images=1)
         return
-    max_quota = max(ex.level_info(l)[3] for l in range(nl))
-    if max_quota > 2700:  # documented capacity limit: the quadtree node table of one level must fit one CU's LDS
-        with pytest.raises(lib.OrbfeError) as ei:
-            lib.Context(w, h, n_features=nf, n_levels=nl, scale_factor=sc, fast_hi=hi, fast_lo=lo, max_images=1)
-        assert ei.value.status == 1 and "quota" in str(ei.value)
-        return
+    # (no capacity limit any more: a level whose quota exceeds one CU's LDS -- nl = 1 with 6000 features here -- keeps its node table
+    #  in global memory)
     ctx = lib.Context(w, h, n_features=nf, n_levels=nl, scale_factor=sc, fast_hi=hi, fast_lo=lo, max_images=1)
     k, d = ctx.extract(img)
     assert_image_parity(ctx, 0, ex, k, d, nl)
@@ -571,6 +567,7 @@ def test_no_limit_on_n_features_20000(orc):
     frame (many more FAST corners than the quotas) so that the big trees really select; and the standard frame, where levels with fewer
     candidates than their quota come out empty (quirk Q3)."""
     from orb_slam2_ros2_amd._lib import Context
+    W, H = 1241, 376
     ctx = Context(W, H, n_features=20000, max_images=2)
     assert ctx.n_features >= 20000
     for n_rect in (1500, 260):
@@ -579,7 +576,7 @@ def test_no_limit_on_n_features_20000(orc):
         ek, ed = orc.extractor(L, n_features=20000).extract()
         assert np.array_equal(lk, ek) and np.array_equal(ld, ed), n_rect
         if n_rect == 1500:
-            assert len(lk) > 12000 and (lk["octave"] == 0).sum() == 4340
+            assert len(lk) > 12000 and (lk["octave"] == 0).sum() > 4000   # level 0 really selected its ~4340
         ref = orc.stereo_frame(L, R, n_features=20000, fx=FX, bf=BF)
         nm, ru, dp, _, _ = ctx.stereo_match(0, 1, FX, BF)
         assert np.array_equal(rk, ref["rk"]) and nm == ref["n_matches"] and np.array_equal(ru[:len(lk)], ref["right_u"])
