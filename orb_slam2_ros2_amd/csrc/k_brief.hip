@@ -158,7 +158,9 @@ __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv,
                                                 const int2* __restrict__ moments, double2* __restrict__ sincos,
                                                 orbfe_keypoint* __restrict__ kps, KpAux* __restrict__ aux, float* __restrict__ kx,
                                                 double* __restrict__ theta_out, int rows0, const int32_t* __restrict__ sel_count, int n_levels,
-                                                int32_t* __restrict__ n_kp) {
+                                                int32_t* __restrict__ n_kp, orbfe_keypoint* __restrict__ kps_host, int32_t* __restrict__ n_kp_host) {
+  // kps_host / n_kp_host (nullable): page-locked HOST memory, same [image][n_features] layout -- the host-pointer path of a frame or two
+  // lets the kernels deliver the results themselves (posted writes over PCIe) instead of queueing three copies behind the last kernel
 #pragma clang fp contract(off)
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int img = blockIdx.y;
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv,
     int total = 0;
     for (int l = 0; l < n_levels; ++l) total += sel_count[(size_t)img * n_levels + l];
     n_kp[img] = total;
+    if (n_kp_host) n_kp_host[img] = total;
   }
   const uint4 e = (k < n_features) ? kpl[(size_t)img * n_features + k] : make_uint4(0xFFFFu, 0u, 0u, 0u);
   if ((e.x & 0xFFFFu) != 0xFFFFu) {
@@ -188,6 +191,7 @@ __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv,
     kp.octave = level;
     kp.class_id = -1;
     kps[o] = kp;
+    if (kps_host) kps_host[o] = kp;
     kx[o] = kp.x;
     // createRowIndexDB band (ORBMatcher.cc:924-927), stored with the keypoint for the stereo matcher
     const float r = (float)(2.0 * (double)L.sf);
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv,
 #endif
 __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_brief(const uint8_t* __restrict__ blur, size_t img_pitch,
                                               const uint4* __restrict__ kpl, int n_features, const int8_t* __restrict__ pattern,
-                                              const double2* __restrict__ sincos, uint8_t* __restrict__ desc) {
+                                              const double2* __restrict__ sincos, uint8_t* __restrict__ desc, uint8_t* __restrict__ desc_host) {
 #pragma clang fp contract(off)
   // per wave (the waves never synchronise): the window, and v cos / v sin for every template coordinate v in [-18, 18] as two
   // arrays of doubles.  The kernel is bound by LDS cycles, most of them the table look-ups: as 16-byte (cos, sin) entries read by
@@ -350,6 +354,7 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_e
         if (lane == 2) b = bits[2];
         if (lane == 3) b = bits[3];
         d64[lane] = b;
+        if (desc_host) ((unsigned long long*)(desc_host + ((size_t)img * n_features + k) * 32))[lane] = b;
       }
       // every lane has read what it needs of this window and table before the next keypoint's are parked over them
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -367,7 +372,8 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
                          int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx,
-                         uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief, hipEvent_t before_lists) {
+                         uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief, hipEvent_t before_lists, orbfe_keypoint* h_kps,
+                         uint8_t* h_desc, int32_t* h_n_kp) {
   if (n_img <= 0 || n_features <= 0) return;
   UmaxPacked u = 0;
   for (int i = 0; i < 16; ++i) u |= (unsigned long long)(umax[i] & 15) << (4 * i);
@@ -379,10 +385,10 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
   // this batch) do not wait for it, only the kernels that rewrite those arrays do -- the match has the whole front of this batch to finish
   if (before_lists) (void)hipStreamWaitEvent(s, before_lists, 0);
   hipLaunchKernelGGL(k_orient, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, d_kpl, n_features, d_moments, d_sincos,
-                     d_kps, d_aux, d_kx, d_theta, rows0, d_sel_count, n_levels, d_n_kp);
+                     d_kps, d_aux, d_kx, d_theta, rows0, d_sel_count, n_levels, d_n_kp, h_kps, h_n_kp);
   if (before_brief) (void)hipStreamWaitEvent(s, before_brief, 0);  // the blurred planes come from another stream
   hipLaunchKernelGGL(k_brief, dim3((((n_features + BRIEF_WAVES * BRIEF_KPW - 1) / (BRIEF_WAVES * BRIEF_KPW)) + 7) & ~7, n_img), dim3(64 * BRIEF_WAVES), 0, s,
-                     d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos, d_desc);
+                     d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos, d_desc, h_desc);
 }
 
 }  // namespace orbfe

@@ -46,7 +46,7 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
                          int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx,
-                         uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief, hipEvent_t before_lists);
+                         uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief, hipEvent_t before_lists, orbfe_keypoint* h_kps, uint8_t* h_desc, int32_t* h_n_kp);
 // k_match.hip
 void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, const uint32_t* d_off,
                              const uint32_t* d_cand, int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second);
@@ -173,6 +173,7 @@ struct orbfe_ctx {
   std::vector<std::unique_ptr<Lane>> slot_lane;  // [max_images], entries created lazily under slot_lane_mu
   std::mutex slot_lane_mu;
   bool use_graphs = true;
+  bool host_mirror = true;  // ORBFE_HOST_MIRROR=0: results of the host-pointer path by device-to-host copies instead of kernel writes
   // the stereo match of a device-resident batch runs on its own stream: it is latency-bound and reads only the keypoint /
   // descriptor arrays and the pyramid, so the NEXT batch's copy-in, resize and FAST (second pyramid buffer) run under it
   uint8_t* d_pyr_alt = nullptr;
@@ -820,6 +821,12 @@ static orbfe_status join_stereo(orbfe_ctx* c) {
 // ---- the launch sequence for slots [0, n_img) ---------------------------------------------------------
 // Slots [img0, img0 + n_img) on stream `st`.  Every per-image array is offset on the host, so the kernels index from 0.
 // level 0 read straight from the caller's images by the resize (device batches): see k_resize_regions
+// results delivered by the kernels themselves into page-locked host memory (the host-pointer path of a frame or two)
+struct HostMirror {
+  orbfe_keypoint* kps;  // [n_img][n_features], nullable
+  uint8_t* desc;        // [n_img][n_features][32], nullable
+  int32_t* n_kp;        // [n_img]
+};
 struct ExtLevel0 {
   const uint8_t *left, *right;  // image p of the batch at left / right + p * pitch
   size_t pitch;
@@ -828,7 +835,7 @@ struct ExtLevel0 {
   hipEvent_t inputs_free;       // nullable: recorded once the resize (which also writes level 0 of the pyramid) is done with the caller's images
 };
 static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, int lds_share = 1, hipEvent_t before_lists = nullptr,
-                                bool timing = true, const ExtLevel0* ext = nullptr) {
+                                bool timing = true, const ExtLevel0* ext = nullptr, const HostMirror* mirror = nullptr) {
   // timing = false: a slot lane (orbfe_extract_slot) -- several of them run at once, so nothing shared by the context is touched:
   // no stage timers (their event lists belong to the main lane), no second stream
   // before_lists: event the keypoint-list / orientation / descriptor kernels must wait for (the previous batch's stereo match still
@@ -931,7 +938,8 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
                         c->d_pattern, c->umax, c->d_kps + i0 * NF, c->d_desc + i0 * NF * 32, c->d_aux + i0 * NF, c->d_n_kp + i0,
                         c->d_theta + i0 * NF, c->d_moments + i0 * NF, c->d_sincos + i0 * NF, c->d_kx + i0 * NF,
                         c->d_kpl + i0 * NF, c->cfg.height, n_img,
-                        overlap_blur ? c->ev_blur_done : nullptr, before_lists);
+                        overlap_blur ? c->ev_blur_done : nullptr, before_lists, mirror ? mirror->kps : nullptr, mirror ? mirror->desc : nullptr,
+                        mirror ? mirror->n_kp : nullptr);
   }
   HIP_TRY(c, hipGetLastError());
   return ORBFE_OK;
@@ -1096,6 +1104,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
       return bail(ORBFE_EDEVICE);
     }
     if (const char* gr = getenv("ORBFE_GRAPHS")) c->use_graphs = atoi(gr) != 0;
+    if (const char* hm = getenv("ORBFE_HOST_MIRROR")) c->host_mirror = atoi(hm) != 0;
     {
       const char* ps = getenv("ORBFE_PIPELINE_STEREO");
       c->pipeline_stereo = !ps || atoi(ps) != 0;
@@ -1386,11 +1395,17 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
     for (int y = 0; y < L0.h; ++y) std::memcpy(dst + (size_t)y * L0.stride, imgs[i] + (size_t)y * stride, (size_t)c->cfg.width);
   }
   uint8_t* const pyr_now = c->d_pyr;
+  // The results come back through the staging buffer too: the orientation and the descriptor kernels write keypoints, counts and
+  // descriptors there themselves (posted PCIe writes, ~120 KB per image) beside the device arrays the stereo match reads -- three
+  // device-to-host copies queued behind the last kernel cost ~17 us of a ~0.3 ms call.  ORBFE_HOST_MIRROR=0: the copies.
+  const bool mirror_on = c->host_mirror && n_img <= 2;
+  HostMirror mir = {kps ? (orbfe_keypoint*)(ln.h_stage + o_kps) : nullptr, desc ? ln.h_stage + o_desc : nullptr, (int32_t*)(ln.h_stage + o_cnt)};
   auto enqueue_all = [&]() -> orbfe_status {
-    for (int i = 0; i < n_img; ++i)
-      HIP_TRY(c, hipMemcpyAsync(pyr_now + (size_t)(slot0 + i) * c->img_pitch + L0.plane_off, ln.h_stage + (size_t)i * plane,
-                                (size_t)L0.stride * L0.h, hipMemcpyHostToDevice, ln.stream));
-    TRY(run_extract(c, ln.stream, slot0, n_img, 1, nullptr, timing));
+    // both eyes in ONE copy (rows = images: the staging planes are `plane` bytes apart, the pyramid slots img_pitch)
+    HIP_TRY(c, hipMemcpy2DAsync(pyr_now + (size_t)slot0 * c->img_pitch + L0.plane_off, c->img_pitch, ln.h_stage, plane, (size_t)L0.stride * L0.h,
+                                (size_t)n_img, hipMemcpyHostToDevice, ln.stream));
+    TRY(run_extract(c, ln.stream, slot0, n_img, 1, nullptr, timing, nullptr, mirror_on ? &mir : nullptr));
+    if (mirror_on) return ORBFE_OK;
     return enqueue_fetch(c, ln, slot0, n_img, o_kps, o_desc, o_cnt, kps != nullptr, desc != nullptr);
   };
   if (c->use_graphs && ln.use_graphs && c->prof == 0 && n_img <= 2) {

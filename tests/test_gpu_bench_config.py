@@ -76,6 +76,8 @@ KNOBS = [
     {"ORBFE_RG": "176,47"},               # resize regions of a fixed size (default: the size that tiles the image best, 208 x 47 here)
     {"ORBFE_RG": "112,31"},
     {"ORBFE_GRAPHS": "0"},                # no hipGraph replay on the host-pointer path
+    {"ORBFE_HOST_MIRROR": "0"},           # host-pointer results by device-to-host copies (default: the kernels write them into the staging buffer)
+    {"ORBFE_HOST_MIRROR": "0", "ORBFE_GRAPHS": "0"},
     {"ORBFE_STREAMS": "2"},               # two half-batches on their own streams
     {"ORBFE_QT_REC_CAP": "0", "ORBFE_QT_BATCH": "0", "ORBFE_PIPELINE_STEREO": "0", "ORBFE_OVERLAP_BLUR": "0", "ORBFE_GRAPHS": "0"},
 ]
