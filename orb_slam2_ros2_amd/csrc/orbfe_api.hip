@@ -1459,8 +1459,18 @@ orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* con
 // One image -> slot `slot` on that slot's own lane.  Calls on DIFFERENT slots may run at the same time on different threads.
 orbfe_status orbfe_extract_slot(orbfe_ctx* c, int32_t slot, const uint8_t* img, size_t stride, orbfe_keypoint* kps, uint8_t* desc,
                                 int32_t* n_out) {
-  if (!c || !img) return fail(c, ORBFE_EBADARG, "extract_slot: NULL argument");
-  if (slot < 0 || slot >= c->cfg.max_images) return fail(c, ORBFE_EBADARG, "extract_slot: slot %d of %d", slot, c->cfg.max_images);
+  const uint8_t* one[1] = {img};
+  return orbfe_extract_slots(c, slot, 1, one, stride, kps, desc, n_out);
+}
+
+// n_img images -> slots [slot0, slot0 + n_img) on slot0's lane: what a caller does who holds BOTH images of a stereo frame when the
+// first extract() is reached (host/orbfe_shim.hpp pairs the two extract() calls of Frame::Frame's threads into one launch sequence)
+orbfe_status orbfe_extract_slots(orbfe_ctx* c, int32_t slot, int32_t n_img, const uint8_t* const* imgs, size_t stride, orbfe_keypoint* kps,
+                                 uint8_t* desc, int32_t* n_out) {
+  if (!c || !imgs || n_img < 1) return fail(c, ORBFE_EBADARG, "extract_slots: NULL argument / no image");
+  const uint8_t* img = imgs[0];
+  if (!img) return fail(c, ORBFE_EBADARG, "extract_slot: NULL argument");
+  if (slot < 0 || slot + n_img > c->cfg.max_images) return fail(c, ORBFE_EBADARG, "extract_slot: slots %d..%d of %d", slot, slot + n_img - 1, c->cfg.max_images);
   if (stride < (size_t)c->cfg.width) return fail(c, ORBFE_EBADARG, "extract_slot: stride %zu < width %d", stride, c->cfg.width);
   HIP_TRY(c, hipSetDevice(c->device));
   orbfe_ctx::Lane* ln = nullptr;
@@ -1485,8 +1495,7 @@ orbfe_status orbfe_extract_slot(orbfe_ctx* c, int32_t slot, const uint8_t* img, 
   // ... and an asynchronous batch call may have left work on the context stream that still writes this slot
   HIP_TRY(c, hipEventRecord(ln->ev_main, c->stream));
   HIP_TRY(c, hipStreamWaitEvent(ln->stream, ln->ev_main, 0));
-  const uint8_t* one[1] = {img};
-  return extract_lane(c, *ln, slot, 1, one, stride, kps, desc, n_out, false);
+  return extract_lane(c, *ln, slot, n_img, imgs, stride, kps, desc, n_out, false);
 }
 
 orbfe_status orbfe_extract(orbfe_ctx* c, const uint8_t* img, size_t stride, orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out) {

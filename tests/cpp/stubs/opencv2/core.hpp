@@ -59,6 +59,11 @@ class Mat {
     return m;
   }
   void copyTo(Mat& o) const { o = clone(); }
+  Mat row(int r) const {  // a header on row r that shares the block (and keeps it alive), as cv::Mat::row does
+    Mat m;
+    m.rows = 1, m.cols = cols, m.step = step, m.data = data + (size_t)r * step, m.type_ = type_, m.own_ = own_;
+    return m;
+  }
   template <class T>
   T& at(int r, int c) {
     return *(T*)(data + (size_t)r * step + (size_t)c * sizeof(T));
