@@ -12,9 +12,7 @@
 #pragma once
 #include <algorithm>
 #include <array>
-#include <chrono>
 #include <cmath>
-#include <condition_variable>
 #include <cstdint>
 #include <cstring>
 #include <fstream>
@@ -24,7 +22,6 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
-#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -128,110 +125,6 @@ class ContextPool {
     l.generation = ++t.generation[(size_t)l.slot];
     return l;
   }
-  // two ADJACENT slots (even, odd) for the two images of one launch sequence
-  static std::pair<Lease, Lease> acquirePair(orbfe_ctx* ctx) {
-    std::lock_guard<std::mutex> lk(mu());
-    SlotTable& t = slots()[ctx];
-    if (t.generation.empty()) t.generation.assign(kSlots, 0);
-    const int n = (int)t.generation.size();
-    int s0 = (t.next + 1) & ~1;
-    if (s0 + 1 >= n) s0 = 0;
-    Lease a, b;
-    a.slot = s0, b.slot = s0 + 1;
-    a.generation = ++t.generation[(size_t)a.slot];
-    b.generation = ++t.generation[(size_t)b.slot];
-    t.next = (s0 + 2) % n;
-    return {a, b};
-  }
-
-  // ---- pairing of the two extract() calls of a stereo frame --------------------------------------------------------------------
-  // Frame::Frame constructs the left and the right extractor, then runs their extract() on two std::threads (src/Frame.cc:91-105).
-  // Two single-image launch sequences side by side take ~0.6 ms, one sequence over both images ~0.33 ms: the extract() that arrives
-  // first WAITS for the other one -- only if another extractor object of the same context has been constructed and has not extracted
-  // yet, so the single extractor of an RGB-D frame (Frame.cc:132-138) never waits -- and the second arrival runs both images as one
-  // orbfe_extract_slots call and hands the first its results.  The wait is bounded (the partner may never call extract()).
-  struct PairRequest {
-    const uint8_t* img = nullptr;
-    size_t step = 0;
-    orbfe_keypoint* kps = nullptr;
-    uint8_t* desc = nullptr;
-    int32_t n = 0;
-    Lease lease;
-    orbfe_status status = ORBFE_OK;
-    std::string error;
-    bool taken = false, done = false;
-  };
-  struct Rendezvous {
-    std::mutex m;
-    std::condition_variable cv;
-    PairRequest* waiting = nullptr;
-    int announced = 0;  // extractor objects constructed on this context that have not extracted yet
-  };
-  static Rendezvous& rendezvous(orbfe_ctx* ctx) {
-    std::lock_guard<std::mutex> lk(mu());
-    auto& p = rvs()[ctx];
-    if (!p) p.reset(new Rendezvous());
-    return *p;
-  }
-  static void announce(orbfe_ctx* ctx, int delta) {
-    Rendezvous& rv = rendezvous(ctx);
-    std::lock_guard<std::mutex> lk(rv.m);
-    rv.announced = std::max(0, rv.announced + delta);
-  }
-  // Extract `me` (img / step / output arrays of capacity cap filled in): alone, or together with a partner.  first_call: this object was
-  // still counted as announced.
-  static void pairedExtract(orbfe_ctx* ctx, PairRequest& me, size_t cap, bool first_call) {
-    Rendezvous& rv = rendezvous(ctx);
-    std::unique_lock<std::mutex> lk(rv.m);
-    if (first_call) rv.announced = std::max(0, rv.announced - 1);
-    if (rv.waiting && rv.waiting->step == me.step) {  // the partner is waiting: run both images as one launch sequence
-      PairRequest* other = rv.waiting;
-      rv.waiting = nullptr;
-      other->taken = true;
-      lk.unlock();
-      const auto leases = acquirePair(ctx);
-      static thread_local std::vector<orbfe_keypoint> k2;
-      static thread_local std::vector<uint8_t> d2;
-      k2.resize(2 * cap), d2.resize(2 * cap * 32);
-      const uint8_t* imgs[2] = {other->img, me.img};
-      int32_t n2[2] = {0, 0};
-      const orbfe_status st = orbfe_extract_slots(ctx, leases.first.slot, 2, imgs, me.step, k2.data(), d2.data(), n2);
-      const std::string err = st == ORBFE_OK ? std::string() : std::string(orbfe_last_error(ctx));
-      if (st == ORBFE_OK) {
-        std::memcpy((void*)other->kps, k2.data(), sizeof(orbfe_keypoint) * (size_t)n2[0]);
-        std::memcpy(other->desc, d2.data(), (size_t)32 * n2[0]);
-        std::memcpy((void*)me.kps, k2.data() + cap, sizeof(orbfe_keypoint) * (size_t)n2[1]);
-        std::memcpy(me.desc, d2.data() + cap * 32, (size_t)32 * n2[1]);
-      }
-      me.n = n2[1], me.lease = leases.second, me.status = st, me.error = err;
-      lk.lock();
-      other->n = n2[0], other->lease = leases.first, other->status = st, other->error = err, other->done = true;
-      lk.unlock();
-      rv.cv.notify_all();
-      return;
-    }
-    if (rv.announced > 0 && !rv.waiting) {  // a partner object exists and has not extracted yet: wait for it (bounded)
-      rv.waiting = &me;
-      rv.cv.wait_for(lk, std::chrono::microseconds(pairWaitUs()), [&] { return me.taken; });
-      if (me.taken) {
-        rv.cv.wait(lk, [&] { return me.done; });  // the leader is running both images
-        return;
-      }
-      if (rv.waiting == &me) rv.waiting = nullptr;
-    }
-    lk.unlock();
-    me.lease = acquire(ctx);
-    me.status = orbfe_extract_slot(ctx, me.lease.slot, me.img, me.step, me.kps, me.desc, &me.n);
-    if (me.status != ORBFE_OK) me.error = orbfe_last_error(ctx);
-  }
-  static int pairWaitUs() {
-    static const int us = [] {
-      const char* e = std::getenv("ORBFE_PAIR_WAIT_US");  // 0: never pair
-      return e ? std::max(0, std::atoi(e)) : 400;
-    }();
-    return us;
-  }
-
   static bool current(orbfe_ctx* ctx, const Lease& l) {
     std::lock_guard<std::mutex> lk(mu());
     auto it = slots().find(ctx);
@@ -256,10 +149,6 @@ class ContextPool {
     static std::map<orbfe_ctx*, SlotTable> s;
     return s;
   }
-  static std::map<orbfe_ctx*, std::unique_ptr<Rendezvous>>& rvs() {
-    static std::map<orbfe_ctx*, std::unique_ptr<Rendezvous>> r;
-    return r;
-  }
 };
 
 class ORBExtractor {
@@ -275,40 +164,15 @@ class ORBExtractor {
     mnFeats = orbfe_get_capacity(mCtx);  // array stride: nFeatures, or more where the reference's rounded quotas exceed it
     mScales.resize(pyramidLevels);
     check(mCtx, orbfe_get_scale_factors(mCtx, mScales.data(), pyramidLevels));
-    ContextPool::announce(mCtx, +1);  // "an extractor that has not extracted yet": what the first extract() of a stereo frame waits for
-    mAnnounced = true;
-    mCtorThread = std::this_thread::get_id();
   }
-  ~ORBExtractor() {
-    if (mAnnounced) ContextPool::announce(mCtx, -1);
-  }
-  ORBExtractor(const ORBExtractor&) = delete;
-  ORBExtractor& operator=(const ORBExtractor&) = delete;
 
   // ORBExtractor::extract (src/ORBExtractor.cc:499-508).  Thread-safe against extract() of OTHER objects (Frame.cc:100-105).
   void extract(std::vector<orbfe_keypoint>& keyPoints, std::vector<Descriptor>& descriptors) {
     keyPoints.resize(mnFeats);
     descriptors.resize(mnFeats);
-    ContextPool::PairRequest rq;
-    rq.img = mImage.data, rq.step = mImage.step, rq.kps = keyPoints.data(), rq.desc = descriptors.data()->data();
-    const bool first = mAnnounced;
-    mAnnounced = false;
-    // pairing only for the reference's pattern: the object's FIRST extract(), called on another thread than the one that constructed it
-    // (Frame::Frame's worker threads) -- a caller that extracts left and right one after the other on its own thread must not wait
-    if (ContextPool::pairWaitUs() > 0 && first && std::this_thread::get_id() != mCtorThread) {
-      ContextPool::pairedExtract(mCtx, rq, (size_t)mnFeats, first);  // alone, or as one launch sequence with the frame's other eye
-    } else {
-      if (first) ContextPool::announce(mCtx, -1);
-      rq.lease = ContextPool::acquire(mCtx);
-      rq.status = orbfe_extract_slot(mCtx, rq.lease.slot, rq.img, rq.step, rq.kps, rq.desc, &rq.n);
-      if (rq.status != ORBFE_OK) rq.error = orbfe_last_error(mCtx);
-    }
-    mLease = rq.lease;
-    if (rq.status != ORBFE_OK) {
-      if (rq.status == ORBFE_EBADSIZE) throw ImageSizeError(rq.error);
-      throw std::runtime_error(rq.error);
-    }
-    const int32_t n = rq.n;
+    int32_t n = 0;
+    mLease = ContextPool::acquire(mCtx);
+    check(mCtx, orbfe_extract_slot(mCtx, mLease.slot, mImage.data, mImage.step, keyPoints.data(), descriptors.data()->data(), &n));
     keyPoints.resize(n);
     descriptors.resize(n);
     mnKeyPoints = n;
@@ -341,8 +205,6 @@ class ORBExtractor {
  private:
   ImageView mImage;
   int mnFeats, mnLevels, mnKeyPoints = 0;
-  bool mAnnounced = false;
-  std::thread::id mCtorThread;
   orbfe_ctx* mCtx = nullptr;
   ContextPool::Lease mLease;
   std::vector<float> mScales;
