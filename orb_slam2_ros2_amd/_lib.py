@@ -360,6 +360,23 @@ class Context:
         self._check(self.lib.orbfe_extract_slot(self.h, slot, img.ctypes.data, img.strides[0], ptr(kps), ptr(desc), C.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
 
+    def extract_slots(self, slot0, imgs):
+        """len(imgs) images -> the consecutive slots slot0 .. as ONE launch sequence on slot0's lane (orbfe_extract_slots)"""
+        n_img = len(imgs)
+        arrs = []
+        for img in imgs:
+            img = np.asarray(img)
+            if img.shape != (self.height, self.width):
+                raise ValueError(f"image shape {img.shape} != context geometry {(self.height, self.width)}")
+            arrs.append(np.ascontiguousarray(img, np.uint8))
+        nf = max(self.n_features, 1)
+        ptrs = (C.c_void_p * n_img)(*[a.ctypes.data for a in arrs])
+        kps = np.zeros((n_img, nf), KP_DTYPE)
+        desc = np.zeros((n_img, nf, 32), np.uint8)
+        n = np.zeros(n_img, np.int32)
+        self._check(self.lib.orbfe_extract_slots(self.h, slot0, n_img, ptrs, self.width, ptr(kps), ptr(desc), ptr(n)))
+        return [(kps[i, :n[i]].copy(), desc[i, :n[i]].copy()) for i in range(n_img)]
+
     def fetch_batch(self, slot0, n_slots):
         """packed results of slots [slot0, slot0 + n_slots): (kps [n][NF], desc [n][NF][32], counts [n])"""
         nf = max(self.n_features, 1)

@@ -56,6 +56,11 @@ def main():
             t.join()
         m, r, d, _, _ = ctx.stereo_match(2, 3, FX, BF)
         assert pair_digest(out[2][0], out[2][1], out[3][0], out[3][1], r, d, m) == gold[str(f)], f"slot path, frame {f}"
+    # ... and both eyes as one launch sequence on a slot lane (orbfe_extract_slots), twice so the captured graph is replayed
+    for f in (11, 11, 4):
+        (lk, ld), (rk, rd) = ctx.extract_slots(2, list(frames[f]))
+        m, r, d, _, _ = ctx.stereo_match(2, 3, FX, BF)
+        assert pair_digest(lk, ld, rk, rd, r, d, m) == gold[str(f)], f"extract_slots, frame {f}"
     ctx.close()
     print("KNOB_OK", n_pairs)
 
