@@ -82,6 +82,10 @@ class WindowGather:
         self.recv = ([[torch.empty(shape, dtype=dtype, device=device) for _ in range(world)] for _ in range(2)]
                      if (rank == dst and self.collective) else None)
         self.cuda = self.send[0].is_cuda
+        # The gathers and the sink copies are issued on a stream of their own: torch's current stream is normally the LEGACY default
+        # stream, and work queued there synchronises with every blocking stream of the process -- a 78 MB drain per window on it stalled
+        # the front end's upload / compute pipeline (measured: the 4541-pair job 0.132 s windowed against 0.122 s with one gather at the end)
+        self.side = torch.cuda.Stream(device=device) if self.cuda else None
         self.fence = [None, None]     # per buffer set: an event after which the set may be rewritten
         self.inflight = None          # (window, work) of the gather not yet drained on dst
         self.next = 0
@@ -104,6 +108,13 @@ class WindowGather:
         """dst: hand the parts of the gather in flight to the sink (after the gather, on the current stream)"""
         if self.inflight is None:
             return
+        if self.side is not None:
+            with self.torch.cuda.stream(self.side):
+                self._drain_on_current()
+        else:
+            self._drain_on_current()
+
+    def _drain_on_current(self):
         w, work = self.inflight
         self.inflight = None
         if work is not None:
@@ -133,7 +144,11 @@ class WindowGather:
         self._drain()
         work = None
         if self.collective:
-            work = dist.gather(self.send[w % 2], self.recv[w % 2] if self.rank == self.dst else None, dst=self.dst, async_op=True)
+            if self.side is not None:
+                with self.torch.cuda.stream(self.side):   # (the send buffer is complete: its pack kernel was waited for on the host)
+                    work = dist.gather(self.send[w % 2], self.recv[w % 2] if self.rank == self.dst else None, dst=self.dst, async_op=True)
+            else:
+                work = dist.gather(self.send[w % 2], self.recv[w % 2] if self.rank == self.dst else None, dst=self.dst, async_op=True)
         self.inflight = (w, work)
 
     def finish(self):
