@@ -31,6 +31,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the first HIP call (see orb_slam2_ros2_amd/__init__.py): one hardware queue per stream
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
