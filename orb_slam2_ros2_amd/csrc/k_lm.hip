@@ -463,6 +463,9 @@ __global__ __launch_bounds__(64) void k_lm_schur(int nf, LmBuffers B, const LmSt
 #define LM_PSTRIDE 38  // doubles per panel block in LDS: 304 bytes = 76 dwords, 76 mod 64 = 12 -> sixteen lanes' 16-byte reads hit distinct banks
 #define LM_CHOL_THREADS 512
 #define LM_CHOL_OFF 448  // threads that own off-diagonal blocks
+#ifndef LM_DIAG_WAVE
+#define LM_DIAG_WAVE 3
+#endif
 
 // t -> (I, J), I > J: the strictly-lower blocks in COLUMN-major order (column 0 first, rows ascending inside a column).  At block
 // column kb the blocks still being updated (J > kb) are then a contiguous TAIL of the order and the panel (J == kb) a contiguous run
@@ -500,24 +503,32 @@ __device__ __forceinline__ void lm_panel_solve(double (&A)[36], const double* L,
 __device__ __forceinline__ void lm_block_update(double (&A)[36], const double* PI, const double* PJ) {
 #pragma clang fp contract(fast)  // fused multiply-adds here: the trailing update is two thirds of the kernel's instructions, and the
                                  // factorisation's rounding is not part of any bit-exact contract (its order already differs from g2o's LLT)
-  // one row of P_I against all of P_J: the 36 accumulators are this thread's block, P_J is re-read from LDS per row (6 x 18 16-byte
-  // reads, all lanes of a column share them) -- holding P_J in registers beside TWO blocks per thread spilled
+  // The block is updated in three parts of two COLUMNS: a third of P_J (12 doubles) is held in registers and every row of P_I is read once
+  // per part -- 6 + 18 reads of 16 bytes per part, 72 per block, where re-reading P_J for every row took 126.  (All of P_J, or half of it,
+  // in registers beside two blocks per thread spills.)  Measured: the same 118 us either way -- the phase is bound by fp64 issue on the
+  // SIMD that hosts the diagonal wave, not by the LDS port (see k_lm_chol).
 #pragma unroll
-  for (int a = 0; a < 6; ++a) {
-    double pi[6];
+  for (int h = 0; h < 3; ++h) {
+    double pj[12];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) pi[k] = PI[6 * a + k];
+    for (int k = 0; k < 12; ++k) pj[k] = PJ[12 * h + k];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const double* q = PJ + 6 * c;
-      double acc = A[6 * a + c];
-      acc = fma(-pi[0], q[0], acc);
-      acc = fma(-pi[1], q[1], acc);
-      acc = fma(-pi[2], q[2], acc);
-      acc = fma(-pi[3], q[3], acc);
-      acc = fma(-pi[4], q[4], acc);
-      acc = fma(-pi[5], q[5], acc);
-      A[6 * a + c] = acc;
+    for (int a = 0; a < 6; ++a) {
+      double pi[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pi[k] = PI[6 * a + k];
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const double* q = pj + 6 * cc;
+        double acc = A[6 * a + 2 * h + cc];
+        acc = fma(-pi[0], q[0], acc);
+        acc = fma(-pi[1], q[1], acc);
+        acc = fma(-pi[2], q[2], acc);
+        acc = fma(-pi[3], q[3], acc);
+        acc = fma(-pi[4], q[4], acc);
+        acc = fma(-pi[5], q[5], acc);
+        A[6 * a + 2 * h + cc] = acc;
+      }
     }
   }
 }
@@ -612,28 +623,50 @@ __device__ __forceinline__ void lm_chol_offdiag(int nb, int t, LmCholShared& sh,
     LM_ST(4)
   }
   if (!sh.ok) return;
+  // Backward substitution (the chain lives in the diagonal wave, see lm_chol_diag): the SUB-diagonal blocks L_{I,I-1} go to it through
+  // the panel area, which nobody reads any more; the other blocks of row kb are applied here, one step behind the chain.
+  if (I0 == J0 + 1) {
+    double* dst = sh.P + (size_t)I0 * LM_PSTRIDE;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) dst[k] = A0[k];
+  }
+  if (I1 == J1 + 1 && I1 >= 0) {
+    double* dst = sh.P + (size_t)I1 * LM_PSTRIDE;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) dst[k] = A1[k];
+  }
+  __syncthreads();  // (C)
   for (int kb = nb - 1; kb >= 0; --kb) {
     __syncthreads();  // x_kb published by the diagonal owner
-    // y_J -= L_{kb,J}^T x_kb : the only writer of y_J in this step (a thread's two blocks have different (I, J))
-    if (I0 == kb) {
+    // y_J -= L_{kb,J}^T x_kb for J <= kb - 2: the only writer of y_J in this step; y_J is read two or more steps later
+    // both blocks of this thread at once (their LDS round trips and chains overlap), two partial sums per entry: this update sits
+    // between two barriers of every step -- one block after the other with six-deep chains it was 0.6 us per step, longer than the chain
+    // of the diagonal wave it runs beside
+    const bool u0 = I0 == kb && J0 < kb - 1, u1 = I1 == kb && J1 < kb - 1;
+    if (u0 || u1) {
+      double xk[6], v0[6], v1[6];
+      const int j0 = u0 ? J0 : 0, j1 = u1 ? J1 : 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) xk[a] = sh.yv[6 * kb + a], v0[a] = sh.yv[6 * j0 + a], v1[a] = sh.yv[6 * j1 + a];
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
-        double v = sh.yv[6 * J0 + c];
+        double p0 = fma(-A0[c], xk[0], v0[c]), q0 = -A0[18 + c] * xk[3];
+        double p1 = fma(-A1[c], xk[0], v1[c]), q1 = -A1[18 + c] * xk[3];
+        p0 = fma(-A0[6 + c], xk[1], p0), q0 = fma(-A0[24 + c], xk[4], q0);
+        p1 = fma(-A1[6 + c], xk[1], p1), q1 = fma(-A1[24 + c], xk[4], q1);
+        p0 = fma(-A0[12 + c], xk[2], p0), q0 = fma(-A0[30 + c], xk[5], q0);
+        p1 = fma(-A1[12 + c], xk[2], p1), q1 = fma(-A1[30 + c], xk[5], q1);
+        v0[c] = p0 + q0, v1[c] = p1 + q1;
+      }
+      if (u0) {
 #pragma unroll
-        for (int a = 0; a < 6; ++a) v = fma(-A0[6 * a + c], sh.yv[6 * kb + a], v);
-        sh.yv[6 * J0 + c] = v;
+        for (int c = 0; c < 6; ++c) sh.yv[6 * J0 + c] = v0[c];
+      }
+      if (u1) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) sh.yv[6 * J1 + c] = v1[c];
       }
     }
-    if (I1 == kb) {
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        double v = sh.yv[6 * J1 + c];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) v = fma(-A1[6 * a + c], sh.yv[6 * kb + a], v);
-        sh.yv[6 * J1 + c] = v;
-      }
-    }
-    __syncthreads();
   }
   LM_ST(6)
 }
@@ -660,12 +693,13 @@ __device__ __forceinline__ void lm_chol_diag(int nb, int t, LmCholShared& sh, co
     for (int j = 0; j < 6; ++j) {
       const double d = A0[7 * j];
       if (!(d > 0) || !isfinite(d)) good = false;
-      // y ~ 1 / sqrt(d): hardware estimate + two Newton steps of three dependent operations each; L_jj = d y.  The six pivots of a
-      // diagonal block are the serial spine of the factorisation: sqrt() followed by a division was ~60 dependent operations per pivot
-      const double h = 0.5 * d;
-      double y = __builtin_amdgcn_rsq(d);
-      y = fma(y, fma(-(h * y), y, 0.5), y);
-      y = fma(y, fma(-(h * y), y, 0.5), y);
+      // y ~ 1 / sqrt(d): the hardware estimate y0 (~23 bits) and ONE third-order step y0 (1 + e / 2 + 3 e^2 / 8), e = 1 - d y0^2 (error
+      // ~ e^3: below double rounding), four dependent operations deep -- two Newton steps were six; L_jj = d y.  The six pivots of a
+      // diagonal block are the serial spine of the factorisation (a dependent fp64 operation of a lone wave takes ~30 cycles): sqrt()
+      // followed by a division was ~60 dependent operations per pivot
+      const double y0 = __builtin_amdgcn_rsq(d);
+      const double e = fma(-(d * y0), y0, 1.0);
+      const double y = fma(y0 * e, fma(0.375, e, 0.5), y0);
       A0[7 * j] = d * y;
       invd[j] = y;
 #pragma unroll
@@ -727,12 +761,39 @@ __device__ __forceinline__ void lm_chol_diag(int nb, int t, LmCholShared& sh, co
     LM_ST(4)
   }
   if (!sh.ok) return;
+  // Backward substitution L^T x = y.  Step kb needs y_kb complete, and the last contribution to it comes from the step before
+  // (L_{kb+1,kb}^T x_{kb+1}): with every row's blocks applied by their owners that is two workgroup barriers per block row on the
+  // critical path (0.9 us each: a quarter of the kernel).  The diagonal lane kb therefore keeps the sub-diagonal block L_{kb+1,kb} itself and
+  // applies it in its own step; the owners of the other blocks of row kb + 1 work one step behind (their targets y_J, J <= kb - 1, are
+  // read at step J at the earliest, a barrier later): ONE barrier per block row, and the chain stays in this wave.
+  __syncthreads();  // (C) sub-diagonal blocks published
+  double Sub[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) Sub[k] = 0.0;
+  if (diag && I0 + 1 < nb) {
+    const double* src = sh.P + (size_t)(I0 + 1) * LM_PSTRIDE;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) Sub[k] = src[k];
+  }
   for (int kb = nb - 1; kb >= 0; --kb) {
     if (diag && I0 == kb) {
+      double xn[6], yk[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        xn[a] = (kb + 1 < nb) ? sh.yv[6 * (kb + 1) + a] : 0.0;
+        yk[a] = sh.yv[6 * kb + a];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {  // two partial sums: the chain is three fused multiply-adds and an add deep, not six
+        double s0 = fma(-Sub[c], xn[0], yk[c]), s1 = -Sub[18 + c] * xn[3];
+        s0 = fma(-Sub[6 + c], xn[1], s0), s1 = fma(-Sub[24 + c], xn[4], s1);
+        s0 = fma(-Sub[12 + c], xn[2], s0), s1 = fma(-Sub[30 + c], xn[5], s1);
+        yk[c] = s0 + s1;
+      }
       double xv[6];
 #pragma unroll
       for (int a = 5; a >= 0; --a) {
-        double v = sh.yv[6 * kb + a];
+        double v = yk[a];
 #pragma unroll
         for (int m = a + 1; m < 6; ++m) v = fma(-A0[6 * m + a], xv[m], v);
         xv[a] = v * invd[a];
@@ -740,7 +801,6 @@ __device__ __forceinline__ void lm_chol_diag(int nb, int t, LmCholShared& sh, co
 #pragma unroll
       for (int a = 0; a < 6; ++a) sh.yv[6 * kb + a] = xv[a];
     }
-    __syncthreads();
     __syncthreads();
   }
   LM_ST(6)
@@ -752,10 +812,16 @@ __global__ __launch_bounds__(LM_CHOL_THREADS) void k_lm_chol(int nb, LmState* __
   if (!lm_gate(st, 1)) return;
   const int t = threadIdx.x;
   if (t == 0) sh.ok = 1;
-  if (t < LM_CHOL_OFF)
-    lm_chol_offdiag(nb, t, sh, Sblk);
+  // Role by wave: the diagonal wave is wave LM_DIAG_WAVE of the workgroup, the owners of off-diagonal blocks are the other seven in
+  // order.  Waves w and w + 4 share a SIMD, and the diagonal wave (250 fp64 instructions per block column, the serial spine) should share
+  // its SIMD with the LIGHTEST owner wave: in column-major order that is the last one (threads 384..447 of the order: blocks of columns
+  // 11-13 only, no second block), which is wave 7 when the diagonal wave is wave 3: 118 -> 112 us at 40 block rows (tools/exp/chol_bench.hip;
+  // s_setprio(3) in the diagonal wave on top of that: no gain).
+  const int wv = t >> 6;
+  if (wv != LM_DIAG_WAVE)
+    lm_chol_offdiag(nb, wv < LM_DIAG_WAVE ? t : t - 64, sh, Sblk);
   else
-    lm_chol_diag(nb, t, sh, Sblk, rhs);
+    lm_chol_diag(nb, LM_CHOL_OFF + (t & 63), sh, Sblk, rhs);
   __syncthreads();
   if (!sh.ok) {
     if (t == 0) st->ok = 0;

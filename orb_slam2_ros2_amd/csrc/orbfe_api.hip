@@ -2133,6 +2133,8 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
   }
   std::vector<int32_t> pair_off((size_t)nf * nf + 1, 0);
   std::vector<int2> pairs;
+  // the device-side Levenberg-Marquardt path (k_lm.hip) builds the blocks i >= j only: half the pairs to list, to stage and to upload
+  const bool lower_only = c && c->lm_on_device && E > 0 && nf <= LM_CHOL_MAX_NB;
   {
     for (int pt = 0; pt < NP; ++pt)
       for (int a = pt_off[pt]; a < pt_off[pt + 1]; ++a) {
@@ -2140,7 +2142,7 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
         if (i < 0) continue;
         for (int b2 = pt_off[pt]; b2 < pt_off[pt + 1]; ++b2) {
           const int j = slot[p->edge_pose[pt_edges[b2]]];
-          if (j >= 0) ++pair_off[(size_t)i * nf + j + 1];
+          if (j >= 0 && !(lower_only && j > i)) ++pair_off[(size_t)i * nf + j + 1];
         }
       }
     for (size_t q = 0; q < (size_t)nf * nf; ++q) pair_off[q + 1] += pair_off[q];
@@ -2152,7 +2154,7 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
         if (i < 0) continue;
         for (int b2 = pt_off[pt]; b2 < pt_off[pt + 1]; ++b2) {
           const int e2 = pt_edges[b2], j = slot[p->edge_pose[e2]];
-          if (j >= 0) pairs[cur[(size_t)i * nf + j]++] = make_int2(e1, e2);
+          if (j >= 0 && !(lower_only && j > i)) pairs[cur[(size_t)i * nf + j]++] = make_int2(e1, e2);
         }
       }
   }
@@ -2177,7 +2179,7 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
                o_level = take((size_t)E), o_depth = take((size_t)E), o_bad = take((size_t)E), o_sc = take(64),
                o_big = take(nf > LBA_MAX_FREE ? ((n + 1) * 6 + (size_t)nf * 36 + n) * 8 : 8);
   // the device-side Levenberg-Marquardt path (k_lm.hip): second estimate / system buffers, per-edge terms, blocked reduced system
-  const bool dev_lm = c->lm_on_device && E > 0 && nf <= LM_CHOL_MAX_NB;
+  const bool dev_lm = lower_only;
   const int chi_blocks = (E + 255) / 256, scale_blocks = (NP + 31) / 32 + (NK + 255) / 256;
   size_t l_pose1 = 0, l_pt1 = 0, l_terms[2] = {0, 0}, l_hpl1 = 0, l_hpp1 = 0, l_bp1 = 0, l_hll1 = 0, l_bl1 = 0, l_chi[2] = {0, 0}, l_sblk = 0,
          l_scale = 0, l_state = 0, l_pose_out = 0, l_pt_out = 0, l_chi2_out = 0, l_level_out = 0, l_bad_out = 0, l_out_end = 0;
@@ -2271,7 +2273,8 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     launch_lm_maxdiag(st, L, 0);
     // trials provisioned per pass: every iteration needs at least one, a rejected trial costs one more; what is left over runs as no-ops
     // (a few microseconds each), what is missing is enqueued in the next pass, after the one synchronisation of this one
-    int steps_a = std::min(iters_first + 1, 24), steps_b = std::min(iters_second + 2, 24);
+    // (measured: a provisioned trial that turns out not to be needed is seven empty launches of 4.6 us; one spare per round)
+    int steps_a = std::min(iters_first + 1, 24), steps_b = std::min(iters_second + 1, 24);
     LmState fin{};
     for (int pass = 0;; ++pass) {
       for (int k = 0; k < steps_a; ++k) launch_lm_step(st, L);
