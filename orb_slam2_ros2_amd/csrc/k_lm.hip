@@ -5,17 +5,19 @@
 // (twice when a round needed more rejected trials than were provisioned).  Round 2 ran this loop on the host with two blocking
 // synchronisations per trial: 12.2 ms for BASELINE config 5, most of it round trips and three kernels written for convenience.
 //
-// One TRIAL (= one step of the enqueued stream), every kernel gated by state.run_step:
-//   k_lm_ctrl        decide the outstanding trial (rho = (chi_cur - chi_trial) / (scale + 1e-3); accept: lambda *= max(1/3, 1 - (2 rho - 1)^3),
+// One TRIAL (= one step of the enqueued stream), every kernel gated by state.run_step (six launches; every launch of a dependent
+// stream costs 4.6 us before it does anything, so the pose side of the system rides in k_lm_prep):
+//   k_lm_ctrl        (lm_ctrl_body; optionally in the tail of the previous trial's k_lm_linpoints, see launch_lm_steps) decide the outstanding trial (rho = (chi_cur - chi_trial) / (scale + 1e-3); accept: lambda *= max(1/3, 1 - (2 rho - 1)^3),
 //                    swap the estimate / system buffers; reject: lambda *= ni, ni *= 2), start the next iteration or trial, or finish
 //   k_lm_prep        per point: (Hll + lambda I)^-1, W(e) = Hpl(e) Dinv for its edges             (BlockSolver_6_3::solve, marginalised points)
+//                    + Hpp / bp per pose of the CURRENT system from its stored edge terms (blocks after the point blocks)
 //   k_lm_schur       one wave per block (i >= j) of free poses: S_ij = [i == j](Hpp_i + lambda I) - sum W(e1) Hpl(e2)^T, lanes over the pairs
 //   k_lm_chol        dense Cholesky + both substitutions of the reduced system by ONE workgroup with the matrix in REGISTERS:
 //                    one 6x6 block per thread, the panel of a block column exchanged through LDS (up to 42 free keyframes)
 //   k_lm_update      oplus into the OTHER estimate buffer (no push / pop copies), computeScale partial sums
-//   k_lm_linearize   one lane per edge at the trial estimate: error, chi2, Huber weight, both Jacobians ONCE, Hpl, partial sums of
-//                    the robust chi2 -- kept as the system of the next iteration if the trial is accepted (g2o rebuilds the same numbers)
-//   k_lm_blocks      Hll / bl per point and Hpp / bp per pose from the stored edge terms (segmented sums over host-built CSR lists)
+//   k_lm_linpoints   eight lanes per point, one edge each, at the trial estimate: error, chi2, Huber weight, both Jacobians ONCE, Hpl,
+//                    Hll / bl of the point, partial sums of the robust chi2 -- kept as the system of the next iteration if the trial is
+//                    accepted (g2o rebuilds the same numbers); vertex -> edge lists are host-built CSR
 // All fp64, contraction off, every sum in a fixed order: run-to-run identical.  Scatter-adds of 6x6 / 6x3 / 3x3 blocks keyed by vertex
 // ids and a <= 258-row triangular factorisation are no dense contractions worth MFMA tiles.
 #include <hip/hip_runtime.h>
@@ -65,187 +67,218 @@ __device__ __forceinline__ bool lm_gate(const LmState* st, int gate) {
   return *p != 0;
 }
 
-__global__ __launch_bounds__(256) void k_lm_linearize(int n_edges, LmBuffers B, const LmState* __restrict__ st, int gate, int which,
-                                                      const int32_t* __restrict__ edge_pose, const int32_t* __restrict__ edge_point,
-                                                      const double* __restrict__ meas, const uint8_t* __restrict__ is_stereo,
-                                                      const double* __restrict__ info, const double* __restrict__ delta,
-                                                      const uint8_t* __restrict__ pose_fixed, const uint8_t* __restrict__ level, BaParamsDev prm,
-                                                      double* __restrict__ chi2_last, int write_last) {
+struct LmCtrlArgs {  // what the control step needs (k_lm_ctrl, or the tail of k_lm_linpoints)
+  LmState* st;
+  int mode;  // -1: no control step in the tail
+  int chi_blocks, scale_blocks;
+  const double* scale_part;
+  const volatile uint8_t* abort_flag;
+  unsigned int* ticket;  // zero between launches
+};
+__device__ void lm_ctrl_body(LmState* __restrict__ st, const LmBuffers& B, int mode, int chi_blocks, int scale_blocks,
+                             const double* __restrict__ scale_part, const volatile uint8_t* __restrict__ abort_flag);
+
+// One edge at the estimate of buffer `buf`: error, chi2, Huber weight, both Jacobians, Hpl -> terms / Hpl / chi2_last; returns the
+// robust chi2 (0 for an inactive edge) and leaves A (3x3), w e (3), w and the row count in registers for the point's blocks.
+__device__ __forceinline__ double lm_linearize_edge(int e, int buf, const LmBuffers& B, const int32_t* __restrict__ edge_pose, int pt,
+                                                    const double* __restrict__ meas, const uint8_t* __restrict__ is_stereo,
+                                                    const double* __restrict__ info, const double* __restrict__ delta,
+                                                    const uint8_t* __restrict__ pose_fixed, const uint8_t* __restrict__ level,
+                                                    const BaParamsDev& prm, double* __restrict__ chi2_last, int write_last, double (&A)[9],
+                                                    double (&we)[3], double& w_out, int& rows_out) {
+#pragma clang fp contract(off)
+  double r0 = 0.0;
+  const int kp = edge_pose[e];
+  const double* T = B.poses[buf] + (size_t)kp * 7;
+  const double* X = B.points[buf] + (size_t)pt * 3;
+  const double qx = T[0], qy = T[1], qz = T[2], qw = T[3];
+  const double X0 = X[0], X1 = X[1], X2 = X[2];
+  double uvx = qy * X2 - qz * X1, uvy = qz * X0 - qx * X2, uvz = qx * X1 - qy * X0;
+  uvx += uvx;
+  uvy += uvy;
+  uvz += uvz;
+  const double x = X0 + qw * uvx + (qy * uvz - qz * uvy) + T[4];
+  const double y = X1 + qw * uvy + (qz * uvx - qx * uvz) + T[5];
+  const double z = X2 + qw * uvz + (qx * uvy - qy * uvx) + T[6];
+  const bool stq = is_stereo[e] != 0;
+  const double fx = prm.fx, fy = prm.fy, cx = prm.cx, cy = prm.cy, bf = prm.bf;
+  const double* m = meas + (size_t)e * 3;
+  const double u = x / z * fx + cx, v = y / z * fy + cy;
+  const double e0 = m[0] - u, e1 = m[1] - v;
+  const double e2 = stq ? (m[2] - (u - bf / z)) : 0.0;
+  const double wi = info[e];
+  const double c2 = stq ? (e0 * (wi * e0) + e1 * (wi * e1) + e2 * (wi * e2)) : (e0 * (wi * e0) + e1 * (wi * e1));
+  // RobustKernelHuber::robustify (delta <= 0: no kernel)
+  const double dl = delta[e];
+  double rr0 = c2, r1 = 1.0;
+  if (dl > 0.0) {
+    const double dsqr = dl * dl;
+    if (c2 > dsqr) {
+      const double sq = sqrt(c2);
+      rr0 = 2 * sq * dl - dsqr;
+      r1 = dl / sq;
+    }
+  }
+  if (level[e] == 0) {  // activeRobustChi2 + the per-edge _error bookkeeping of the ACTIVE edges (g2o evaluates only those)
+    r0 = rr0;
+    if (write_last) chi2_last[e] = c2;
+  }
+  const double w = r1 * wi;
+  double* t = B.terms[buf] + (size_t)e * LM_TERM;
+  const double z_2 = z * z;
+  const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+  const double twx = tx * qw, twy = ty * qw, twz = tz * qw;
+  const double txx = tx * qx, txy = ty * qx, txz = tz * qx;
+  const double tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
+  double Bm[18];
+  if (stq) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      A[k] = -fx * R[k] / z + fx * x * R[6 + k] / z_2;
+      A[3 + k] = -fy * R[3 + k] / z + fy * y * R[6 + k] / z_2;
+      A[6 + k] = A[k] - bf * R[6 + k] / z_2;
+    }
+  } else {
+    const double t02 = -x / z * fx, t12 = -y / z * fy, s = -1. / z;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      A[k] = (s * fx) * R[k] + (s * t02) * R[6 + k];
+      A[3 + k] = (s * fy) * R[3 + k] + (s * t12) * R[6 + k];
+      A[6 + k] = 0.0;
+    }
+  }
+  Bm[0] = x * y / z_2 * fx;
+  Bm[1] = -(1 + (x * x / z_2)) * fx;
+  Bm[2] = y / z * fx;
+  Bm[3] = -1. / z * fx;
+  Bm[4] = 0;
+  Bm[5] = x / z_2 * fx;
+  Bm[6] = (1 + y * y / z_2) * fy;
+  Bm[7] = -x * y / z_2 * fy;
+  Bm[8] = -x / z * fy;
+  Bm[9] = 0;
+  Bm[10] = -1. / z * fy;
+  Bm[11] = y / z_2 * fy;
+  if (stq) {
+    Bm[12] = Bm[0] - bf * y / z_2;
+    Bm[13] = Bm[1] + bf * x / z_2;
+    Bm[14] = Bm[2];
+    Bm[15] = Bm[3];
+    Bm[16] = 0;
+    Bm[17] = Bm[5] - bf / z_2;
+  } else {
+#pragma unroll
+    for (int k = 12; k < 18; ++k) Bm[k] = 0.0;
+  }
+  const int rows = stq ? 3 : 2;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) t[k] = A[k];
+#pragma unroll
+  for (int k = 0; k < 18; ++k) t[9 + k] = Bm[k];
+  we[0] = w * e0, we[1] = w * e1, we[2] = w * e2;
+  t[27] = we[0];
+  t[28] = we[1];
+  t[29] = we[2];
+  t[30] = w;
+  t[31] = (double)rows;
+  w_out = w;
+  rows_out = rows;
+  // Hpl(e) = B^T W A (zero for the edges of fixed poses: they have no block)
+  double* out = B.Hpl[buf] + (size_t)e * 18;
+  if (pose_fixed[kp]) {
+#pragma unroll
+    for (int i = 0; i < 18; ++i) out[i] = 0.0;
+  } else {
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double h = 0;
+        _Pragma("unroll") for (int r = 0; r < 3; ++r) if (r < rows) h += Bm[6 * r + a] * w * A[3 * r + c];
+        out[3 * a + c] = h;
+      }
+  }
+  return r0;
+}
+
+// The system at one estimate, point side: 32 points per block, EIGHT lanes per point, one edge each (a point's edges in list order):
+// the lane linearises its edge (terms, Hpl, chi2) and the eight lanes sum Hll / bl of their point in a fixed butterfly -- the edge terms
+// never come back from memory for this.  (Until late r3 this was two launches, one lane per edge and then eight lanes per point reading
+// the terms back: 10 + 17 us, and every launch of this stream costs 4.6 us before it does anything.)  The robust chi2 is summed per block
+// in a fixed tree -> chi_part[buf][block]; the control step adds the blocks.
+// tail.mode >= 0: the LAST block to finish runs the control step (lm_ctrl_body) for the trial that follows, instead of a launch of its own.
+__global__ __launch_bounds__(256) void k_lm_linpoints(int n_points, LmBuffers B, const LmState* __restrict__ st, int gate, int which,
+                                                      const int32_t* __restrict__ pt_off, const int32_t* __restrict__ pt_edges,
+                                                      const int32_t* __restrict__ edge_pose, const double* __restrict__ meas,
+                                                      const uint8_t* __restrict__ is_stereo, const double* __restrict__ info,
+                                                      const double* __restrict__ delta, const uint8_t* __restrict__ pose_fixed,
+                                                      const uint8_t* __restrict__ level, BaParamsDev prm, double* __restrict__ chi2_last,
+                                                      int write_last, LmCtrlArgs tail) {
 #pragma clang fp contract(off)
   __shared__ double sh[256];
+  __shared__ unsigned int s_ticket;
   if (!lm_gate(st, gate)) return;
   const int buf = st->cur ^ which;
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int p = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+  double acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0.0;
   double r0 = 0.0;
-  if (e < n_edges) {
-    const int kp = edge_pose[e];
-    const double* T = B.poses[buf] + (size_t)kp * 7;
-    const double* X = B.points[buf] + (size_t)edge_point[e] * 3;
-    const double qx = T[0], qy = T[1], qz = T[2], qw = T[3];
-    const double X0 = X[0], X1 = X[1], X2 = X[2];
-    double uvx = qy * X2 - qz * X1, uvy = qz * X0 - qx * X2, uvz = qx * X1 - qy * X0;
-    uvx += uvx;
-    uvy += uvy;
-    uvz += uvz;
-    const double x = X0 + qw * uvx + (qy * uvz - qz * uvy) + T[4];
-    const double y = X1 + qw * uvy + (qz * uvx - qx * uvz) + T[5];
-    const double z = X2 + qw * uvz + (qx * uvy - qy * uvx) + T[6];
-    const bool stq = is_stereo[e] != 0;
-    const double fx = prm.fx, fy = prm.fy, cx = prm.cx, cy = prm.cy, bf = prm.bf;
-    const double* m = meas + (size_t)e * 3;
-    const double u = x / z * fx + cx, v = y / z * fy + cy;
-    const double e0 = m[0] - u, e1 = m[1] - v;
-    const double e2 = stq ? (m[2] - (u - bf / z)) : 0.0;
-    const double wi = info[e];
-    const double c2 = stq ? (e0 * (wi * e0) + e1 * (wi * e1) + e2 * (wi * e2)) : (e0 * (wi * e0) + e1 * (wi * e1));
-    // RobustKernelHuber::robustify (delta <= 0: no kernel)
-    const double dl = delta[e];
-    double rr0 = c2, r1 = 1.0;
-    if (dl > 0.0) {
-      const double dsqr = dl * dl;
-      if (c2 > dsqr) {
-        const double sq = sqrt(c2);
-        rr0 = 2 * sq * dl - dsqr;
-        r1 = dl / sq;
-      }
-    }
-    if (level[e] == 0) {  // activeRobustChi2 + the per-edge _error bookkeeping of the ACTIVE edges (g2o evaluates only those)
-      r0 = rr0;
-      if (write_last) chi2_last[e] = c2;
-    }
-    const double w = r1 * wi;
-    double* t = B.terms[buf] + (size_t)e * LM_TERM;
-    const double z_2 = z * z;
-    const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
-    const double twx = tx * qw, twy = ty * qw, twz = tz * qw;
-    const double txx = tx * qx, txy = ty * qx, txz = tz * qx;
-    const double tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
-    const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
-    double A[9], Bm[18];
-    if (stq) {
+  if (p < n_points) {
+    for (int i = pt_off[p] + sub; i < pt_off[p + 1]; i += 8) {
+      const int e = pt_edges[i];
+      double A[9], we[3], w;
+      int rows;
+      r0 += lm_linearize_edge(e, buf, B, edge_pose, p, meas, is_stereo, info, delta, pose_fixed, level, prm, chi2_last, write_last, A, we, w, rows);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        A[k] = -fx * R[k] / z + fx * x * R[6 + k] / z_2;
-        A[3 + k] = -fy * R[3 + k] / z + fy * y * R[6 + k] / z_2;
-        A[6 + k] = A[k] - bf * R[6 + k] / z_2;
-      }
-    } else {
-      const double t02 = -x / z * fx, t12 = -y / z * fy, s = -1. / z;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        A[k] = (s * fx) * R[k] + (s * t02) * R[6 + k];
-        A[3 + k] = (s * fy) * R[3 + k] + (s * t12) * R[6 + k];
-        A[6 + k] = 0.0;
-      }
-    }
-    Bm[0] = x * y / z_2 * fx;
-    Bm[1] = -(1 + (x * x / z_2)) * fx;
-    Bm[2] = y / z * fx;
-    Bm[3] = -1. / z * fx;
-    Bm[4] = 0;
-    Bm[5] = x / z_2 * fx;
-    Bm[6] = (1 + y * y / z_2) * fy;
-    Bm[7] = -x * y / z_2 * fy;
-    Bm[8] = -x / z * fy;
-    Bm[9] = 0;
-    Bm[10] = -1. / z * fy;
-    Bm[11] = y / z_2 * fy;
-    if (stq) {
-      Bm[12] = Bm[0] - bf * y / z_2;
-      Bm[13] = Bm[1] + bf * x / z_2;
-      Bm[14] = Bm[2];
-      Bm[15] = Bm[3];
-      Bm[16] = 0;
-      Bm[17] = Bm[5] - bf / z_2;
-    } else {
-#pragma unroll
-      for (int k = 12; k < 18; ++k) Bm[k] = 0.0;
-    }
-    const int rows = stq ? 3 : 2;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) t[k] = A[k];
-#pragma unroll
-    for (int k = 0; k < 18; ++k) t[9 + k] = Bm[k];
-    t[27] = w * e0;
-    t[28] = w * e1;
-    t[29] = w * e2;
-    t[30] = w;
-    t[31] = (double)rows;
-    // Hpl(e) = B^T W A (zero for the edges of fixed poses: they have no block)
-    double* out = B.Hpl[buf] + (size_t)e * 18;
-    if (pose_fixed[kp]) {
-#pragma unroll
-      for (int i = 0; i < 18; ++i) out[i] = 0.0;
-    } else {
-#pragma unroll
-      for (int a = 0; a < 6; ++a)
+      for (int a = 0; a < 3; ++a) {
+        double s = 0;
+        _Pragma("unroll") for (int r = 0; r < 3; ++r) if (r < rows) s += A[3 * r + a] * we[r];
+        acc[9 + a] -= s;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           double h = 0;
-          _Pragma("unroll") for (int r = 0; r < 3; ++r) if (r < rows) h += Bm[6 * r + a] * w * A[3 * r + c];
-          out[3 * a + c] = h;
-        }
-    }
-  }
-  const double s = block_sum_256(r0, sh);
-  if (threadIdx.x == 0) B.chi_part[buf][blockIdx.x] = s;
-}
-
-// Hll / bl per point (blocks [0, pt_blocks): 32 points per block, EIGHT lanes per point, one edge each) and Hpp / bp per pose (one
-// 256-thread block per pose after them: one edge per thread), from the stored terms.  Every lane has ONE dependent chain (list entry ->
-// terms) instead of one per edge of its vertex: a first version with a lane per point / per block entry walking the edges took 130 us,
-// bound by those chains.  Partial sums are combined in a fixed butterfly (+ a fixed order over the four waves of a pose).
-__global__ __launch_bounds__(256) void k_lm_blocks(int n_points, int n_poses, int pt_blocks, LmBuffers B, const LmState* __restrict__ st, int gate,
-                                                   int which, const uint8_t* __restrict__ pose_fixed, const int32_t* __restrict__ pt_off,
-                                                   const int32_t* __restrict__ pt_edges, const int32_t* __restrict__ ps_off,
-                                                   const int32_t* __restrict__ ps_edges) {
-#pragma clang fp contract(off)
-  __shared__ double part[4][42];
-  if (!lm_gate(st, gate)) return;
-  const int buf = st->cur ^ which;
-  const double* terms = B.terms[buf];
-  if ((int)blockIdx.x < pt_blocks) {
-    const int p = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
-    double acc[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) acc[k] = 0.0;
-    if (p < n_points) {
-      for (int i = pt_off[p] + sub; i < pt_off[p + 1]; i += 8) {
-        const double* t = terms + (size_t)pt_edges[i] * LM_TERM;
-        const int rows = (int)t[31];
-        const double w = t[30];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          double s = 0;
-          _Pragma("unroll") for (int r = 0; r < 3; ++r) if (r < rows) s += t[3 * r + a] * t[27 + r];
-          acc[9 + a] -= s;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            double h = 0;
-            _Pragma("unroll") for (int r = 0; r < 3; ++r) if (r < rows) h += t[3 * r + a] * w * t[3 * r + c];
-            acc[3 * a + c] += h;
-          }
+          _Pragma("unroll") for (int r = 0; r < 3; ++r) if (r < rows) h += A[3 * r + a] * w * A[3 * r + c];
+          acc[3 * a + c] += h;
         }
       }
     }
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      double v = acc[k];
-      v += __shfl_xor(v, 1);
-      v += __shfl_xor(v, 2);
-      v += __shfl_xor(v, 4);
-      acc[k] = v;
-    }
-    if (p < n_points && sub == 0) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) B.Hll[buf][(size_t)p * 9 + k] = acc[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) B.bl[buf][(size_t)p * 3 + k] = acc[9 + k];
-    }
-    return;
   }
-  const int k = (int)blockIdx.x - pt_blocks;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    double v = acc[k];
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    acc[k] = v;
+  }
+  if (p < n_points && sub == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) B.Hll[buf][(size_t)p * 9 + k] = acc[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) B.bl[buf][(size_t)p * 3 + k] = acc[9 + k];
+  }
+  const double s = block_sum_256(r0, sh);
+  if (threadIdx.x == 0) B.chi_part[buf][blockIdx.x] = s;
+  if (tail.mode < 0) return;
+  // the last block to get here has every block's partial sum behind it (release: fence, then the ticket; acquire: the ticket, then a fence)
+  __threadfence();
+  if (threadIdx.x == 0) s_ticket = atomicAdd(tail.ticket, 1u);
+  __syncthreads();
+  if (s_ticket != gridDim.x - 1) return;
+  __threadfence();
+  if (threadIdx.x < 64) lm_ctrl_body(tail.st, B, tail.mode, tail.chi_blocks, tail.scale_blocks, tail.scale_part, tail.abort_flag);
+  if (threadIdx.x == 0) *tail.ticket = 0u;
+}
+
+// Hpp / bp per pose (one 256-thread block per pose: one edge per thread) from the stored terms of buffer buf.  Partial sums are
+// combined in a fixed butterfly + a fixed order over the four waves.
+__device__ __forceinline__ void lm_pose_block(int k, int n_poses, int buf, const LmBuffers& B, const uint8_t* __restrict__ pose_fixed,
+                                              const int32_t* __restrict__ ps_off, const int32_t* __restrict__ ps_edges, double (*part)[42]) {
+#pragma clang fp contract(off)
   if (k >= n_poses) return;
+  const double* terms = B.terms[buf];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double acc[42];
 #pragma unroll
@@ -290,6 +323,13 @@ __global__ __launch_bounds__(256) void k_lm_blocks(int n_points, int n_poses, in
       B.bp[buf][(size_t)k * 6 + threadIdx.x - 36] = v;
   }
 }
+__global__ __launch_bounds__(256) void k_lm_poseblocks(int n_poses, LmBuffers B, const LmState* __restrict__ st, int gate, int which,
+                                                       const uint8_t* __restrict__ pose_fixed, const int32_t* __restrict__ ps_off,
+                                                       const int32_t* __restrict__ ps_edges) {
+  __shared__ double part[4][42];
+  if (!lm_gate(st, gate)) return;
+  lm_pose_block((int)blockIdx.x, n_poses, st->cur ^ which, B, pose_fixed, ps_off, ps_edges, part);
+}
 
 // computeLambdaInit: max |H_jj| over the active vertices of the CURRENT system -> state.maxdiag
 __global__ __launch_bounds__(1024) void k_lm_maxdiag(int n_poses, int n_points, LmBuffers B, LmState* __restrict__ st, int gate,
@@ -319,10 +359,21 @@ __global__ __launch_bounds__(1024) void k_lm_maxdiag(int n_poses, int n_points, 
 
 // per point: Dinv = (Hll + lambda I)^-1 (Eigen's 3x3 inverse: cofactors / determinant), then W(e) = Hpl(e) Dinv for the point's edges.
 // EIGHT lanes per point (each inverts the same block and takes one edge): one dependent chain per lane instead of one per edge.
-__global__ __launch_bounds__(256) void k_lm_prep(int n_points, LmBuffers B, LmState* __restrict__ st, const int32_t* __restrict__ pt_off,
-                                                 const int32_t* __restrict__ pt_edges, double* __restrict__ Dinv, double* __restrict__ W) {
+// Blocks [pt_blocks, pt_blocks + n_poses): Hpp / bp of the CURRENT system (lm_pose_block).  The pose side of a system is only ever used
+// once its estimate is the current one (k_lm_schur, k_lm_update's scale), so it is not built with the trial's system but here, beside the
+// point inverses of the trial that follows -- for an accepted trial that is its first computation, after a rejected one a recomputation
+// of the same numbers.  One launch less per trial, and this work runs beside the point blocks instead of after them.
+__global__ __launch_bounds__(256) void k_lm_prep(int n_points, int n_poses, int pt_blocks, LmBuffers B, LmState* __restrict__ st,
+                                                 const int32_t* __restrict__ pt_off, const int32_t* __restrict__ pt_edges,
+                                                 double* __restrict__ Dinv, double* __restrict__ W, const uint8_t* __restrict__ pose_fixed,
+                                                 const int32_t* __restrict__ ps_off, const int32_t* __restrict__ ps_edges) {
 #pragma clang fp contract(off)
+  __shared__ double part[4][42];
   if (!lm_gate(st, 1)) return;
+  if ((int)blockIdx.x >= pt_blocks) {
+    lm_pose_block((int)blockIdx.x - pt_blocks, n_poses, st->cur, B, pose_fixed, ps_off, ps_edges, part);
+    return;
+  }
   const int p = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
   if (p >= n_points) return;
   const int buf = st->cur;
@@ -914,15 +965,16 @@ __global__ __launch_bounds__(256) void k_lm_update(int n_poses, int n_points, in
 // g2o: SparseOptimizer::optimize + OptimizationAlgorithmLevenberg::solve (tau = 1e-5, <= 10 trials per iteration).
 // ---------------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double lm_sum(const double* p, int n) {  // all 64 lanes: lane-strided partial sums, then a fixed butterfly
+  const volatile double* vp = p;  // (in the tail of k_lm_linpoints these were written by other blocks of the SAME launch: no cached copies)
   double s = 0;
-  for (int i = threadIdx.x; i < n; i += 64) s += p[i];
+  for (int i = threadIdx.x; i < n; i += 64) s += vp[i];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   return s;
 }
 
-__global__ __launch_bounds__(64) void k_lm_ctrl(LmState* __restrict__ st, LmBuffers B, int mode, int chi_blocks, int scale_blocks,
-                                                const double* __restrict__ scale_part, const volatile uint8_t* __restrict__ abort_flag) {
+__device__ void lm_ctrl_body(LmState* __restrict__ st, const LmBuffers& B, int mode, int chi_blocks, int scale_blocks,
+                             const double* __restrict__ scale_part, const volatile uint8_t* __restrict__ abort_flag) {
 #pragma clang fp contract(off)
   LmState s = *st;  // (every lane runs the same scalar program; lane 0 stores the result)
   if (abort_flag && *abort_flag) s.stopped = 1;
@@ -1020,6 +1072,10 @@ __global__ __launch_bounds__(64) void k_lm_ctrl(LmState* __restrict__ st, LmBuff
   }
   if (threadIdx.x == 0) *st = s;
 }
+__global__ __launch_bounds__(64) void k_lm_ctrl(LmState* __restrict__ st, LmBuffers B, int mode, int chi_blocks, int scale_blocks,
+                                                const double* __restrict__ scale_part, const volatile uint8_t* __restrict__ abort_flag) {
+  lm_ctrl_body(st, B, mode, chi_blocks, scale_blocks, scale_part, abort_flag);
+}
 
 // Optimizer.cc:338-359 between the two rounds: level 1 for chi2 > 5.991 / 7.815 or non-positive depth at the CURRENT estimate, kernels dropped
 __global__ __launch_bounds__(256) void k_lm_classify(int n_edges, LmBuffers B, const LmState* __restrict__ st, const int32_t* __restrict__ edge_pose,
@@ -1098,39 +1154,65 @@ static LmBuffers lm_buffers(const LmLaunch& L) {
   return B;
 }
 
-// linearize + blocks of buffer cur ^ which, gated
-void launch_lm_build(hipStream_t s, const LmLaunch& L, int gate, int which, int write_last) {
+static LmCtrlArgs lm_ctrl_args(const LmLaunch& L, int mode) {
+  LmCtrlArgs a;
+  a.st = L.state, a.mode = mode, a.chi_blocks = (L.NP + 31) / 32, a.scale_blocks = (L.NP + 31) / 32 + (L.NK + 255) / 256;
+  a.scale_part = L.scale_part, a.abort_flag = L.abort_flag, a.ticket = L.ticket;
+  return a;
+}
+// the system of buffer cur ^ which, gated: the point side (+ the control step of the next trial in its tail, tail_mode >= 0) and,
+// with_poses, the pose side as a launch of its own (inside a trial it rides with k_lm_prep of the NEXT trial instead)
+void launch_lm_build(hipStream_t s, const LmLaunch& L, int gate, int which, int write_last, int tail_mode, bool with_poses) {
   const LmBuffers B = lm_buffers(L);
-  const int eb = (L.E + 255) / 256, pb = (L.NP + 31) / 32;
-  if (L.E > 0)
-    hipLaunchKernelGGL(k_lm_linearize, dim3(eb), dim3(256), 0, s, L.E, B, L.state, gate, which, L.edge_pose, L.edge_point, L.meas, L.is_stereo,
-                       L.info_eff, L.delta_eff, L.fixed, L.level, L.prm, L.chi2_last, write_last);
-  if (pb + L.NK > 0)
-    hipLaunchKernelGGL(k_lm_blocks, dim3(pb + L.NK), dim3(256), 0, s, L.NP, L.NK, pb, B, L.state, gate, which, L.fixed, L.pt_off, L.pt_edges, L.ps_off,
-                       L.ps_edges);
+  const int pb = (L.NP + 31) / 32;
+  if (pb > 0)
+    hipLaunchKernelGGL(k_lm_linpoints, dim3(pb), dim3(256), 0, s, L.NP, B, L.state, gate, which, L.pt_off, L.pt_edges, L.edge_pose, L.meas,
+                       L.is_stereo, L.info_eff, L.delta_eff, L.fixed, L.level, L.prm, L.chi2_last, write_last, lm_ctrl_args(L, tail_mode));
+  if (with_poses && L.NK > 0)
+    hipLaunchKernelGGL(k_lm_poseblocks, dim3(L.NK), dim3(256), 0, s, L.NK, B, L.state, gate, which, L.fixed, L.ps_off, L.ps_edges);
 }
 void launch_lm_maxdiag(hipStream_t s, const LmLaunch& L, int gate) {
   hipLaunchKernelGGL(k_lm_maxdiag, dim3(1), dim3(1024), 0, s, L.NK, L.NP, lm_buffers(L), L.state, gate, L.fixed);
 }
 void launch_lm_ctrl(hipStream_t s, const LmLaunch& L, int mode) {
-  hipLaunchKernelGGL(k_lm_ctrl, dim3(1), dim3(64), 0, s, L.state, lm_buffers(L), mode, (L.E + 255) / 256, (L.NP + 31) / 32 + (L.NK + 255) / 256,
-                     L.scale_part, L.abort_flag);
+  const LmCtrlArgs a = lm_ctrl_args(L, mode);
+  hipLaunchKernelGGL(k_lm_ctrl, dim3(1), dim3(64), 0, s, L.state, lm_buffers(L), mode, a.chi_blocks, a.scale_blocks, L.scale_part, L.abort_flag);
 }
-// one trial: ctrl + solve + update + the system at the trial estimate
-void launch_lm_step(hipStream_t s, const LmLaunch& L) {
+// one trial: solve + update + the system at the trial estimate.  The control step that decides it and schedules the next one runs in
+// the tail of the last kernel (ctrl_in_tail) -- the LAST trial of a group is followed by a control point of another mode (round switch,
+// final) that does the deciding itself, and the FIRST one is preceded by an explicit launch_lm_ctrl(0).
+void launch_lm_step(hipStream_t s, const LmLaunch& L, bool ctrl_in_tail) {
   const LmBuffers B = lm_buffers(L);
-  launch_lm_ctrl(s, L, 0);
-  if (L.NP > 0) hipLaunchKernelGGL(k_lm_prep, dim3((L.NP + 31) / 32), dim3(256), 0, s, L.NP, B, L.state, L.pt_off, L.pt_edges, L.Dinv, L.W);
+  const int pb = (L.NP + 31) / 32;
+  if (pb + L.NK > 0)
+    hipLaunchKernelGGL(k_lm_prep, dim3(pb + L.NK), dim3(256), 0, s, L.NP, L.NK, pb, B, L.state, L.pt_off, L.pt_edges, L.Dinv, L.W, L.fixed, L.ps_off,
+                       L.ps_edges);
   if (L.nf > 0) {
     hipLaunchKernelGGL(k_lm_schur, dim3(L.nf * (L.nf + 1) / 2), dim3(64), 0, s, L.nf, B, L.state, L.free_pose, L.pair_off, L.pairs, L.ps_off,
                        L.ps_edges, L.edge_point, L.W, L.Sblk, L.rhs);
     hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(LM_CHOL_THREADS), 0, s, L.nf, L.state, L.Sblk, L.rhs, L.x);
   }
-  const int ub = (L.NP + 31) / 32 + (L.NK + 255) / 256;
+  const int ub = pb + (L.NK + 255) / 256;
   if (ub > 0)
-    hipLaunchKernelGGL(k_lm_update, dim3(ub), dim3(256), 0, s, L.NK, L.NP, (L.NP + 31) / 32, B, L.state, L.pose_slot, L.x, L.pt_off, L.pt_edges,
+    hipLaunchKernelGGL(k_lm_update, dim3(ub), dim3(256), 0, s, L.NK, L.NP, pb, B, L.state, L.pose_slot, L.x, L.pt_off, L.pt_edges,
                        L.edge_pose, L.Dinv, L.scale_part);
-  launch_lm_build(s, L, 1, 1, 1);
+  launch_lm_build(s, L, 1, 1, 1, ctrl_in_tail ? 0 : -1, false);
+}
+// `n` trials as one group: control step, the trials, then the caller's control point (launch_lm_switch / launch_lm_final)
+void launch_lm_steps(hipStream_t s, const LmLaunch& L, int n) {
+  // Measured with the control step in the tail of every trial but the last: k_lm_linpoints 11.7 -> 23.2 us (a fence, a ticket and a
+  // barrier in each of its 94 blocks, then ~4 us of serial loads in the last one) against 6.2 us for the launch it saves.  Kept as a
+  // mechanism (ORBFE_LM_TAIL_CTRL=1, tested); the default is a launch per control step.
+  if (n <= 0) return;
+  if (L.tail_ctrl) {
+    launch_lm_ctrl(s, L, 0);
+    for (int k = 0; k < n; ++k) launch_lm_step(s, L, k + 1 < n);
+    return;
+  }
+  for (int k = 0; k < n; ++k) {
+    launch_lm_ctrl(s, L, 0);
+    launch_lm_step(s, L, false);
+  }
 }
 void launch_lm_switch(hipStream_t s, const LmLaunch& L) {
   const LmBuffers B = lm_buffers(L);
@@ -1138,7 +1220,7 @@ void launch_lm_switch(hipStream_t s, const LmLaunch& L) {
   if (L.E > 0)
     hipLaunchKernelGGL(k_lm_classify, dim3((L.E + 255) / 256), dim3(256), 0, s, L.E, B, L.state, L.edge_pose, L.edge_point, L.chi2_last, L.is_stereo,
                        L.level, L.info_eff, L.delta_eff);
-  launch_lm_build(s, L, 2, 0, 1);
+  launch_lm_build(s, L, 2, 0, 1, -1, true);
   launch_lm_maxdiag(s, L, 2);
   launch_lm_ctrl(s, L, 2);
 }

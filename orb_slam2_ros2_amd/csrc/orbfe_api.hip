@@ -93,9 +93,9 @@ void launch_search_area(hipStream_t s, const uint4* d_kpl, const uint8_t* d_desc
                         const int32_t* d_cell_off, const int32_t* d_cell_feat, int nq, const float* d_qxy, const float* d_radius,
                         const int8_t* d_min_level, const int8_t* d_max_level, const uint8_t* d_q_desc, const uint8_t* d_exclude,
                         int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second, int32_t* d_n_cand, int32_t* d_excluded_hits);
-void launch_lm_build(hipStream_t s, const LmLaunch& L, int gate, int which, int write_last);
+void launch_lm_build(hipStream_t s, const LmLaunch& L, int gate, int which, int write_last, int tail_mode, bool with_poses);
 void launch_lm_maxdiag(hipStream_t s, const LmLaunch& L, int gate);
-void launch_lm_step(hipStream_t s, const LmLaunch& L);
+void launch_lm_steps(hipStream_t s, const LmLaunch& L, int n);
 void launch_lm_switch(hipStream_t s, const LmLaunch& L);
 void launch_lm_final(hipStream_t s, const LmLaunch& L);
 void launch_pose_only(hipStream_t s, int n, const double* Xw, const double* meas, const double* info, const float* sigma2,
@@ -253,6 +253,7 @@ struct orbfe_ctx {
   // stop flag is mirrored into it while the call waits -- and the page-locked copy of the state record
   volatile uint8_t* h_abort = nullptr;
   LmState* h_lm_state = nullptr;
+  bool lm_tail_ctrl = false;  // ORBFE_LM_TAIL_CTRL=1 (k_lm.hip, launch_lm_steps): measured slower, kept as a tested mechanism
   bool lm_on_device = true;  // ORBFE_LBA_HOST_LM=1: round 2's host-driven loop (kept for A/B runs and for > LM_CHOL_MAX_NB free keyframes)
 
   // profiling
@@ -1118,6 +1119,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     }
     if (const char* rr = getenv("ORBFE_RESIZE_REGIONS")) c->resize_regions = atoi(rr) != 0;
     if (const char* hl = getenv("ORBFE_LBA_HOST_LM")) c->lm_on_device = atoi(hl) == 0;
+    if (const char* tc = getenv("ORBFE_LM_TAIL_CTRL")) c->lm_tail_ctrl = atoi(tc) != 0;
     if (const char* be = getenv("ORBFE_BLUR_L0_EARLY")) c->blur_l0_early = atoi(be) != 0;
     if (const char* xl = getenv("ORBFE_EXT_LEVEL0")) c->ext_level0 = atoi(xl) != 0;
     const char* ov = getenv("ORBFE_OVERLAP_BLUR");
@@ -2180,7 +2182,7 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
                o_big = take(nf > LBA_MAX_FREE ? ((n + 1) * 6 + (size_t)nf * 36 + n) * 8 : 8);
   // the device-side Levenberg-Marquardt path (k_lm.hip): second estimate / system buffers, per-edge terms, blocked reduced system
   const bool dev_lm = lower_only;
-  const int chi_blocks = (E + 255) / 256, scale_blocks = (NP + 31) / 32 + (NK + 255) / 256;
+  const int chi_blocks = (NP + 31) / 32, scale_blocks = (NP + 31) / 32 + (NK + 255) / 256;  // (k_lm_linpoints: a partial sum per block of 32 points)
   size_t l_pose1 = 0, l_pt1 = 0, l_terms[2] = {0, 0}, l_hpl1 = 0, l_hpp1 = 0, l_bp1 = 0, l_hll1 = 0, l_bl1 = 0, l_chi[2] = {0, 0}, l_sblk = 0,
          l_scale = 0, l_state = 0, l_pose_out = 0, l_pt_out = 0, l_chi2_out = 0, l_level_out = 0, l_bad_out = 0, l_out_end = 0;
   if (dev_lm) {
@@ -2189,7 +2191,7 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     l_hpl1 = take((size_t)E * 144), l_hpp1 = take((size_t)NK * 288), l_bp1 = take((size_t)NK * 48), l_hll1 = take((size_t)NP * 72),
     l_bl1 = take((size_t)NP * 24);
     l_chi[0] = take((size_t)chi_blocks * 8), l_chi[1] = take((size_t)chi_blocks * 8);
-    l_sblk = take((size_t)nf * (nf + 1) / 2 * 288), l_scale = take((size_t)scale_blocks * 8), l_state = take(sizeof(LmState));
+    l_sblk = take((size_t)nf * (nf + 1) / 2 * 288), l_scale = take((size_t)scale_blocks * 8), l_state = take(sizeof(LmState) + 64);  // + the tail ticket
     // the results as ONE block (one download): poses | points | chi2 | level | bad
     l_pose_out = take((size_t)NK * 56), l_pt_out = take((size_t)NP * 24), l_chi2_out = take((size_t)E * 8), l_level_out = take((size_t)E),
     l_bad_out = take((size_t)E), l_out_end = take(8);
@@ -2254,6 +2256,8 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     L.bp[0] = (double*)(b + o_bp), L.bp[1] = (double*)(b + l_bp1), L.Hll[0] = (double*)(b + o_hll), L.Hll[1] = (double*)(b + l_hll1);
     L.bl[0] = (double*)(b + o_bl), L.bl[1] = (double*)(b + l_bl1), L.chi_part[0] = (double*)(b + l_chi[0]), L.chi_part[1] = (double*)(b + l_chi[1]);
     L.state = (LmState*)(b + l_state);
+    L.ticket = (unsigned int*)(b + l_state + ((sizeof(LmState) + 15) & ~(size_t)15));
+    L.tail_ctrl = c->lm_tail_ctrl ? 1 : 0;
     L.edge_pose = d_ek, L.edge_point = d_ep, L.pt_off = (const int32_t*)(b + o_pto), L.pt_edges = (const int32_t*)(b + o_pte);
     L.ps_off = (const int32_t*)(b + o_pso), L.ps_edges = (const int32_t*)(b + o_pse), L.free_pose = (const int32_t*)(b + o_free);
     L.pose_slot = (const int32_t*)(b + o_slot), L.pair_off = (const int32_t*)(b + o_pairoff), L.pairs = (const int2*)(b + o_pairs);
@@ -2267,9 +2271,10 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     init.iters[0] = iters_first, init.iters[1] = iters_second, init.need_chi = 1, init.ok = 1;
     *c->h_lm_state = init;
     HIP_TRY(c, hipMemcpyAsync(L.state, c->h_lm_state, sizeof(LmState), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(L.ticket, 0, 16, st));
     HIP_TRY(c, hipMemsetAsync(L.Dinv, 0, (size_t)std::max(NP, 1) * 72, st));  // (read by a trial whose point block was singular)
     StageTimer tm(c, ORBFE_STAGE_BA, st);
-    launch_lm_build(st, L, 0, 0, iters_first > 0 ? 1 : 0);  // computeActiveErrors + buildSystem at the initial estimate
+    launch_lm_build(st, L, 0, 0, iters_first > 0 ? 1 : 0, -1, true);  // computeActiveErrors + buildSystem at the initial estimate
     launch_lm_maxdiag(st, L, 0);
     // trials provisioned per pass: every iteration needs at least one, a rejected trial costs one more; what is left over runs as no-ops
     // (a few microseconds each), what is missing is enqueued in the next pass, after the one synchronisation of this one
@@ -2277,9 +2282,9 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     int steps_a = std::min(iters_first + 1, 24), steps_b = std::min(iters_second + 1, 24);
     LmState fin{};
     for (int pass = 0;; ++pass) {
-      for (int k = 0; k < steps_a; ++k) launch_lm_step(st, L);
+      launch_lm_steps(st, L, steps_a);
       launch_lm_switch(st, L);
-      for (int k = 0; k < steps_b; ++k) launch_lm_step(st, L);
+      launch_lm_steps(st, L, steps_b);
       launch_lm_final(st, L);
       HIP_TRY(c, hipGetLastError());
       HIP_TRY(c, hipMemcpyAsync(c->h_lm_state, L.state, sizeof(LmState), hipMemcpyDeviceToHost, st));

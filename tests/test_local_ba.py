@@ -76,6 +76,30 @@ def test_device_local_ba_matches_oracle(orc, seed, n_kf, n_pt, n_fixed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"ORBFE_LBA_HOST_LM": "1"}, {"ORBFE_LM_TAIL_CTRL": "1"}])
+def test_device_local_ba_variants_are_bit_identical(monkeypatch, env):
+    """The host-driven Levenberg-Marquardt loop (round 2's, still the path past 42 free keyframes) and the control step in the tail of
+    k_lm_linpoints against the default (control on the device, a launch per control step): the same kernels compute the same numbers
+    in the same order, so poses, points and per-edge results must be identical bit for bit.  (The switches are read at orbfe_create.)"""
+    from orb_slam2_ros2_amd._lib import Context
+    pr, fixed = _problem(6, 60, 3000, 20)
+    ctx = Context(640, 480, n_features=500, max_images=1)
+    ref = ctx.ba_local_optimize(pr, fixed)
+    ctx.close()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ctx = Context(640, 480, n_features=500, max_images=1)
+    got = ctx.ba_local_optimize(pr, fixed)
+    ctx.close()
+    assert tuple(got["iters"]) == tuple(ref["iters"])
+    if "ORBFE_LM_TAIL_CTRL" in env:
+        assert all(np.array_equal(got[k], ref[k]) for k in ("poses", "points", "level", "chi2", "bad"))
+    else:   # other factorisation kernel (LDS-resident column Cholesky): same iterations, results to rounding
+        assert np.abs(got["poses"] - ref["poses"]).max() < 1e-9 and np.abs(got["points"] - ref["points"]).max() < 1e-9
+        assert (got["level"] != ref["level"]).sum() <= 1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed,n_kf,n_pt,n_fixed", [(11, 155, 2500, 5), (12, 101, 1500, 0), (13, 310, 4000, 10)])
 def test_device_local_ba_beyond_100_free_keyframes(orc, seed, n_kf, n_pt, n_fixed):
     """Optimizer::OptimizeLocalMap takes every keyframe covisible with the current one (getConnectedKfs(0), Optimizer.cc:232): no bound.
