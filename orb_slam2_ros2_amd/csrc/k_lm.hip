@@ -67,6 +67,29 @@ __device__ __forceinline__ bool lm_gate(const LmState* st, int gate) {
   return *p != 0;
 }
 
+// Sum over the 64 lanes in a FIXED tree (deterministic), the same value returned to every lane.  Data-parallel-primitive moves instead
+// of __shfl_xor: a shuffle of a double is two ds_bpermute_b32 through the LDS crossbar, and the block sums below reduce 36 / 42 values
+// per wave (~500 permutes); here a step is two full-rate register moves and an add.  Tree: an inclusive scan inside each row of 16
+// (row_shr 1, 2, 4, 8: lane 15 of a row = pairwise tree over its lanes), then (row 1 + row 0), (row 3 + row 2), and their sum in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double lm_dpp_f64(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (unsigned long long)(uint32_t)lo));
+}
+__device__ __forceinline__ double wave_sum_fixed(double v) {
+  v += lm_dpp_f64<0x111, 0xf>(v);  // row_shr:1  (lanes without a source add the +0.0 of `old`)
+  v += lm_dpp_f64<0x112, 0xf>(v);  // row_shr:2
+  v += lm_dpp_f64<0x114, 0xf>(v);  // row_shr:4
+  v += lm_dpp_f64<0x118, 0xf>(v);  // row_shr:8
+  v += lm_dpp_f64<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3
+  v += lm_dpp_f64<0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), 63);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 struct LmCtrlArgs {  // what the control step needs (k_lm_ctrl, or the tail of k_lm_linpoints)
   LmState* st;
   int mode;  // -1: no control step in the tail
@@ -309,9 +332,7 @@ __device__ __forceinline__ void lm_pose_block(int k, int n_poses, int buf, const
   }
 #pragma unroll
   for (int i = 0; i < 42; ++i) {
-    double v = acc[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const double v = wave_sum_fixed(acc[i]);
     if (lane == 0) part[wv][i] = v;
   }
   __syncthreads();
@@ -425,14 +446,8 @@ __global__ __launch_bounds__(256) void k_lm_prep(int n_points, int n_poses, int 
 }
 
 // Reduced system, one wave per block (i >= j) of free poses, the lanes over the block's pairs (e1, e2): pose(e1) = i, pose(e2) = j, same
-// point.  Sblk: lower-triangular blocks, block (i, j) at (i (i + 1) / 2 + j) * 36, row-major inside.  The diagonal blocks also form
-// the right-hand side rhs_i = bp_i - sum_{e of pose i} W(e) bl(point(e)).
-__device__ __forceinline__ double wave_sum_fixed(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);  // fixed butterfly: deterministic
-  return v;
-}
-
+// point.  Sblk: lower-triangular blocks, block (i, j) at (i (i + 1) / 2 + j) * 36, row-major inside.  nf more waves form the right-hand
+// side rhs_i = bp_i - sum_{e of pose i} W(e) bl(point(e)).
 __global__ __launch_bounds__(64) void k_lm_schur(int nf, LmBuffers B, const LmState* __restrict__ st, const int32_t* __restrict__ free_pose,
                                                  const int32_t* __restrict__ pair_off, const int2* __restrict__ pairs,
                                                  const int32_t* __restrict__ ps_off, const int32_t* __restrict__ ps_edges,
@@ -440,19 +455,43 @@ __global__ __launch_bounds__(64) void k_lm_schur(int nf, LmBuffers B, const LmSt
                                                  double* __restrict__ Sblk, double* __restrict__ rhs) {
 #pragma clang fp contract(off)
   if (!lm_gate(st, 1)) return;
+  const int lane = threadIdx.x;
+  const int buf = st->cur;
+  const int n_blk = nf * (nf + 1) / 2;
+  if ((int)blockIdx.x >= n_blk) {
+    // the right-hand side of block row i in a wave of its own: behind the diagonal block's sum in the same wave it doubled the longest
+    // chain of dependent round trips of this launch (26 us; the other 780 waves were done after 12)
+    const int i = (int)blockIdx.x - n_blk;
+    const int ki = free_pose[i];
+    double r[6] = {0, 0, 0, 0, 0, 0};
+    for (int q = ps_off[ki] + lane; q < ps_off[ki + 1]; q += 64) {
+      const int e = ps_edges[q];
+      const double* w = W + (size_t)e * 18;
+      const double* bb = B.bl[buf] + (size_t)edge_point[e] * 3;
+      const double b0 = bb[0], b1 = bb[1], b2 = bb[2];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) r[a] += w[3 * a] * b0 + w[3 * a + 1] * b1 + w[3 * a + 2] * b2;
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const double s = wave_sum_fixed(r[a]);
+      if (lane == a) rhs[6 * i + a] = B.bp[buf][(size_t)ki * 6 + a] - s;
+    }
+    return;
+  }
   // blockIdx.x -> (i, j), i >= j
   const int b = blockIdx.x;
   int i = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
   while ((i + 1) * (i + 2) / 2 <= b) ++i;
   while (i * (i + 1) / 2 > b) --i;
   const int j = b - i * (i + 1) / 2;
-  const int lane = threadIdx.x;
-  const int buf = st->cur;
   const double* Hpl = B.Hpl[buf];
   double acc[36];
 #pragma unroll
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
   const int q0 = pair_off[i * nf + j], q1 = pair_off[i * nf + j + 1];
+  // (measured and dropped: four trips of the pair list in flight at once for the ~260-pair diagonal blocks -- the clamped loads of the
+  //  one-trip blocks, 780 of 820, cost more than the diagonal ones gain: 17.5 -> 21 us)
   for (int q = q0 + lane; q < q1; q += 64) {
     const int2 pr = pairs[q];
     const double* w = W + (size_t)pr.x * 18;
@@ -478,22 +517,6 @@ __global__ __launch_bounds__(64) void k_lm_schur(int nf, LmBuffers B, const LmSt
         v = d - s;
       }
       out[k] = v;
-    }
-  }
-  if (i == j) {
-    double r[6] = {0, 0, 0, 0, 0, 0};
-    for (int q = ps_off[ki] + lane; q < ps_off[ki + 1]; q += 64) {
-      const int e = ps_edges[q];
-      const double* w = W + (size_t)e * 18;
-      const double* bb = B.bl[buf] + (size_t)edge_point[e] * 3;
-      const double b0 = bb[0], b1 = bb[1], b2 = bb[2];
-#pragma unroll
-      for (int a = 0; a < 6; ++a) r[a] += w[3 * a] * b0 + w[3 * a + 1] * b1 + w[3 * a + 2] * b2;
-    }
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      const double s = wave_sum_fixed(r[a]);
-      if (lane == a) rhs[6 * i + a] = B.bp[buf][(size_t)ki * 6 + a] - s;
     }
   }
 }
@@ -1188,7 +1211,7 @@ void launch_lm_step(hipStream_t s, const LmLaunch& L, bool ctrl_in_tail) {
     hipLaunchKernelGGL(k_lm_prep, dim3(pb + L.NK), dim3(256), 0, s, L.NP, L.NK, pb, B, L.state, L.pt_off, L.pt_edges, L.Dinv, L.W, L.fixed, L.ps_off,
                        L.ps_edges);
   if (L.nf > 0) {
-    hipLaunchKernelGGL(k_lm_schur, dim3(L.nf * (L.nf + 1) / 2), dim3(64), 0, s, L.nf, B, L.state, L.free_pose, L.pair_off, L.pairs, L.ps_off,
+    hipLaunchKernelGGL(k_lm_schur, dim3(L.nf * (L.nf + 1) / 2 + L.nf), dim3(64), 0, s, L.nf, B, L.state, L.free_pose, L.pair_off, L.pairs, L.ps_off,
                        L.ps_edges, L.edge_point, L.W, L.Sblk, L.rhs);
     hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(LM_CHOL_THREADS), 0, s, L.nf, L.state, L.Sblk, L.rhs, L.x);
   }
