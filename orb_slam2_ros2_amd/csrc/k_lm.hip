@@ -632,6 +632,7 @@ __device__ __forceinline__ void lm_diag_update(double (&A)[36], const double* PJ
 
 #ifdef LM_CHOL_STAMPS  // diagnostic build only (tools/exp/chol_bench.hip): where a block column's time goes, per wave
 __device__ long long g_lm_stamps[8][8];
+__device__ unsigned int g_lm_hwid[8];
 #define LM_ST(k) \
   if ((t & 63) == 0) { const long long now_ = __builtin_amdgcn_s_memtime(); g_lm_stamps[t >> 6][k] += now_ - last_; last_ = now_; }
 #define LM_ST_INIT long long last_ = __builtin_amdgcn_s_memtime();
@@ -892,6 +893,9 @@ __global__ __launch_bounds__(LM_CHOL_THREADS) void k_lm_chol(int nb, LmState* __
   // 11-13 only, no second block), which is wave 7 when the diagonal wave is wave 3: 118 -> 112 us at 40 block rows (tools/exp/chol_bench.hip;
   // s_setprio(3) in the diagonal wave on top of that: no gain).
   const int wv = t >> 6;
+#ifdef LM_CHOL_STAMPS
+  if ((t & 63) == 0) g_lm_hwid[wv] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID, all 32 bits
+#endif
   if (wv != LM_DIAG_WAVE)
     lm_chol_offdiag(nb, wv < LM_DIAG_WAVE ? t : t - 64, sh, Sblk);
   else
@@ -1095,9 +1099,11 @@ __device__ void lm_ctrl_body(LmState* __restrict__ st, const LmBuffers& B, int m
   }
   if (threadIdx.x == 0) *st = s;
 }
-__global__ __launch_bounds__(64) void k_lm_ctrl(LmState* __restrict__ st, LmBuffers B, int mode, int chi_blocks, int scale_blocks,
-                                                const double* __restrict__ scale_part, const volatile uint8_t* __restrict__ abort_flag) {
+__global__ __launch_bounds__(64) void k_lm_ctrl(LmState* st, LmBuffers B, int mode, int chi_blocks, int scale_blocks,
+                                                const double* __restrict__ scale_part, const volatile uint8_t* __restrict__ abort_flag,
+                                                LmState* state_out) {
   lm_ctrl_body(st, B, mode, chi_blocks, scale_blocks, scale_part, abort_flag);
+  if (state_out && threadIdx.x == 0) *state_out = *st;  // (lane 0 wrote *st itself) -> the result block, for the host
 }
 
 // Optimizer.cc:338-359 between the two rounds: level 1 for chi2 > 5.991 / 7.815 or non-positive depth at the CURRENT estimate, kernels dropped
@@ -1199,7 +1205,8 @@ void launch_lm_maxdiag(hipStream_t s, const LmLaunch& L, int gate) {
 }
 void launch_lm_ctrl(hipStream_t s, const LmLaunch& L, int mode) {
   const LmCtrlArgs a = lm_ctrl_args(L, mode);
-  hipLaunchKernelGGL(k_lm_ctrl, dim3(1), dim3(64), 0, s, L.state, lm_buffers(L), mode, a.chi_blocks, a.scale_blocks, L.scale_part, L.abort_flag);
+  hipLaunchKernelGGL(k_lm_ctrl, dim3(1), dim3(64), 0, s, L.state, lm_buffers(L), mode, a.chi_blocks, a.scale_blocks, L.scale_part, L.abort_flag,
+                     mode == 4 ? L.state_out : (LmState*)nullptr);
 }
 // one trial: solve + update + the system at the trial estimate.  The control step that decides it and schedules the next one runs in
 // the tail of the last kernel (ctrl_in_tail) -- the LAST trial of a group is followed by a control point of another mode (round switch,

@@ -2174,27 +2174,30 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
                o_info = take((size_t)E * 8), o_info_eff = take((size_t)E * 8), o_delta = take((size_t)E * 8), o_fix = take((size_t)NK),
                o_pto = take((size_t)(NP + 1) * 4), o_pte = take((size_t)E * 4), o_pso = take((size_t)(NK + 1) * 4), o_pse = take((size_t)E * 4),
                o_free = take((size_t)nf * 4), o_slot = take((size_t)NK * 4), o_pairoff = take(pair_off.size() * 4),
-               o_pairs = take(pairs.size() * 8), o_hpp = take((size_t)NK * 288), o_bp = take((size_t)NK * 48), o_hll = take((size_t)NP * 72),
-               o_bl = take((size_t)NP * 24), o_hpl = take((size_t)E * 144), o_dinv = take((size_t)NP * 72), o_w = take((size_t)E * 144),
+               o_pairs = take(pairs.size() * 8), o_lmstate = take(sizeof(LmState)),  // (the initial control state rides in the one upload)
+               o_hpp = take((size_t)NK * 288), o_bp = take((size_t)NK * 48), o_hll = take((size_t)NP * 72),
+               o_bl = take((size_t)NP * 24), o_hpl = take((size_t)E * 144), o_w = take((size_t)E * 144),
                o_s = take(n * n * 8), o_rhs = take(n * 8), o_x = take(n * 8), o_dxp = take((size_t)NK * 48), o_dxl = take((size_t)NP * 24),
-               o_err = take((size_t)E * 24), o_chi2 = take((size_t)E * 8), o_rho = take((size_t)E * 16), o_last = take((size_t)E * 8),
-               o_level = take((size_t)E), o_depth = take((size_t)E), o_bad = take((size_t)E), o_sc = take(64),
+               o_err = take((size_t)E * 24), o_chi2 = take((size_t)E * 8), o_rho = take((size_t)E * 16),
+               // one block that starts as zeros (ONE fill): edge levels | chi2 of the last linearisation | point inverses | tail ticket
+               o_level = take((size_t)E), o_last = take((size_t)E * 8), o_dinv = take((size_t)NP * 72), o_ticket = take(64), o_zero_end = take(8),
+               o_depth = take((size_t)E), o_bad = take((size_t)E), o_sc = take(64),
                o_big = take(nf > LBA_MAX_FREE ? ((n + 1) * 6 + (size_t)nf * 36 + n) * 8 : 8);
   // the device-side Levenberg-Marquardt path (k_lm.hip): second estimate / system buffers, per-edge terms, blocked reduced system
   const bool dev_lm = lower_only;
   const int chi_blocks = (NP + 31) / 32, scale_blocks = (NP + 31) / 32 + (NK + 255) / 256;  // (k_lm_linpoints: a partial sum per block of 32 points)
   size_t l_pose1 = 0, l_pt1 = 0, l_terms[2] = {0, 0}, l_hpl1 = 0, l_hpp1 = 0, l_bp1 = 0, l_hll1 = 0, l_bl1 = 0, l_chi[2] = {0, 0}, l_sblk = 0,
-         l_scale = 0, l_state = 0, l_pose_out = 0, l_pt_out = 0, l_chi2_out = 0, l_level_out = 0, l_bad_out = 0, l_out_end = 0;
+         l_scale = 0, l_pose_out = 0, l_pt_out = 0, l_chi2_out = 0, l_level_out = 0, l_bad_out = 0, l_state_out = 0, l_out_end = 0;
   if (dev_lm) {
     l_pose1 = take((size_t)NK * 56), l_pt1 = take((size_t)NP * 24);
     l_terms[0] = take((size_t)E * 256), l_terms[1] = take((size_t)E * 256);
     l_hpl1 = take((size_t)E * 144), l_hpp1 = take((size_t)NK * 288), l_bp1 = take((size_t)NK * 48), l_hll1 = take((size_t)NP * 72),
     l_bl1 = take((size_t)NP * 24);
     l_chi[0] = take((size_t)chi_blocks * 8), l_chi[1] = take((size_t)chi_blocks * 8);
-    l_sblk = take((size_t)nf * (nf + 1) / 2 * 288), l_scale = take((size_t)scale_blocks * 8), l_state = take(sizeof(LmState) + 64);  // + the tail ticket
+    l_sblk = take((size_t)nf * (nf + 1) / 2 * 288), l_scale = take((size_t)scale_blocks * 8);
     // the results as ONE block (one download): poses | points | chi2 | level | bad
     l_pose_out = take((size_t)NK * 56), l_pt_out = take((size_t)NP * 24), l_chi2_out = take((size_t)E * 8), l_level_out = take((size_t)E),
-    l_bad_out = take((size_t)E), l_out_end = take(8);
+    l_bad_out = take((size_t)E), l_state_out = take(sizeof(LmState)), l_out_end = take(8);  // (+ the control state as the last control step left it)
   }
   TRY(ensure_tmp(c, off));
   uint8_t* b = (uint8_t*)c->d_tmp;
@@ -2229,9 +2232,13 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
   HIP_TRY(c, up(o_slot, slot.data(), (size_t)NK * 4));
   HIP_TRY(c, up(o_pairoff, pair_off.data(), pair_off.size() * 4));
   HIP_TRY(c, up(o_pairs, pairs.data(), pairs.size() * 8));
+  {
+    LmState init{};
+    init.iters[0] = iters_first, init.iters[1] = iters_second, init.need_chi = 1, init.ok = 1;
+    HIP_TRY(c, up(o_lmstate, &init, sizeof init));
+  }
   HIP_TRY(c, hipMemcpyAsync(b, hs, up_bytes, hipMemcpyHostToDevice, st));
-  HIP_TRY(c, hipMemsetAsync(b + o_level, 0, std::max(E, 1), st));
-  HIP_TRY(c, hipMemsetAsync(b + o_last, 0, (size_t)std::max(E, 1) * 8, st));
+  HIP_TRY(c, hipMemsetAsync(b + o_level, 0, o_zero_end - o_level, st));  // (every memset is a launch of 4.6 us: six of them preceded the first kernel)
 
   const BaParamsDev prm = {p->fx, p->fy, p->cx, p->cy, p->bf};
   double* d_poses = (double*)(b + o_pose);
@@ -2243,7 +2250,6 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     // ---- Levenberg-Marquardt control on the device: enqueue the whole optimisation, synchronise once ------------------------------
     if (!c->h_abort) {
       HIP_TRY(c, hipHostMalloc((void**)&c->h_abort, 64, hipHostMallocMapped));
-      HIP_TRY(c, hipHostMalloc((void**)&c->h_lm_state, sizeof(LmState), hipHostMallocDefault));
     }
     void* d_abort = nullptr;
     HIP_TRY(c, hipHostGetDevicePointer(&d_abort, (void*)c->h_abort, 0));
@@ -2255,8 +2261,8 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     L.Hpl[0] = (double*)(b + o_hpl), L.Hpl[1] = (double*)(b + l_hpl1), L.Hpp[0] = (double*)(b + o_hpp), L.Hpp[1] = (double*)(b + l_hpp1);
     L.bp[0] = (double*)(b + o_bp), L.bp[1] = (double*)(b + l_bp1), L.Hll[0] = (double*)(b + o_hll), L.Hll[1] = (double*)(b + l_hll1);
     L.bl[0] = (double*)(b + o_bl), L.bl[1] = (double*)(b + l_bl1), L.chi_part[0] = (double*)(b + l_chi[0]), L.chi_part[1] = (double*)(b + l_chi[1]);
-    L.state = (LmState*)(b + l_state);
-    L.ticket = (unsigned int*)(b + l_state + ((sizeof(LmState) + 15) & ~(size_t)15));
+    L.state = (LmState*)(b + o_lmstate);
+    L.ticket = (unsigned int*)(b + o_ticket);
     L.tail_ctrl = c->lm_tail_ctrl ? 1 : 0;
     L.edge_pose = d_ek, L.edge_point = d_ep, L.pt_off = (const int32_t*)(b + o_pto), L.pt_edges = (const int32_t*)(b + o_pte);
     L.ps_off = (const int32_t*)(b + o_pso), L.ps_edges = (const int32_t*)(b + o_pse), L.free_pose = (const int32_t*)(b + o_free);
@@ -2267,19 +2273,18 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     L.scale_part = (double*)(b + l_scale), L.chi2_out = (double*)(b + l_chi2_out), L.poses_out = (double*)(b + l_pose_out);
     L.points_out = (double*)(b + l_pt_out), L.bad = b + l_bad_out, L.level_out = b + l_level_out;
     L.abort_flag = (const volatile uint8_t*)d_abort, L.prm = prm;
-    LmState init{};
-    init.iters[0] = iters_first, init.iters[1] = iters_second, init.need_chi = 1, init.ok = 1;
-    *c->h_lm_state = init;
-    HIP_TRY(c, hipMemcpyAsync(L.state, c->h_lm_state, sizeof(LmState), hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemsetAsync(L.ticket, 0, 16, st));
-    HIP_TRY(c, hipMemsetAsync(L.Dinv, 0, (size_t)std::max(NP, 1) * 72, st));  // (read by a trial whose point block was singular)
+    // (the initial state went up with the inputs; the ticket and the point inverses -- read by a trial whose point block was singular --
+    //  are part of the one zero fill)
+    L.state_out = (LmState*)(b + l_state_out);
     StageTimer tm(c, ORBFE_STAGE_BA, st);
     launch_lm_build(st, L, 0, 0, iters_first > 0 ? 1 : 0, -1, true);  // computeActiveErrors + buildSystem at the initial estimate
     launch_lm_maxdiag(st, L, 0);
     // trials provisioned per pass: every iteration needs at least one, a rejected trial costs one more; what is left over runs as no-ops
     // (a few microseconds each), what is missing is enqueued in the next pass, after the one synchronisation of this one
-    // (measured: a provisioned trial that turns out not to be needed is seven empty launches of 4.6 us; one spare per round)
-    int steps_a = std::min(iters_first + 1, 24), steps_b = std::min(iters_second + 1, 24);
+    // (measured: a provisioned trial that turns out not to be needed is six empty launches of 4.6 us; one spare
+    // -- in round 0, where coming up one short would leave the ten trials of round 1 as no-ops in this pass; round 1 gets none: if a trial
+    // of it is rejected, the second pass enqueues what is missing)
+    int steps_a = std::min(iters_first + 1, 24), steps_b = std::min(iters_second, 24);
     LmState fin{};
     for (int pass = 0;; ++pass) {
       launch_lm_steps(st, L, steps_a);
@@ -2287,7 +2292,6 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
       launch_lm_steps(st, L, steps_b);
       launch_lm_final(st, L);
       HIP_TRY(c, hipGetLastError());
-      HIP_TRY(c, hipMemcpyAsync(c->h_lm_state, L.state, sizeof(LmState), hipMemcpyDeviceToHost, st));
       const size_t out_bytes = l_out_end - l_pose_out;
       HIP_TRY(c, hipMemcpyAsync(hs, b + l_pose_out, out_bytes, hipMemcpyDeviceToHost, st));  // the upload from hs finished long ago (stream order)
       if (stop_flag) {
@@ -2311,7 +2315,7 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
         HIP_TRY(c, er);
       }
       HIP_TRY(c, hipStreamSynchronize(st));
-      fin = *c->h_lm_state;
+      std::memcpy(&fin, hs + (l_state_out - l_pose_out), sizeof fin);
       if (fin.finalized) {
         std::memcpy(o->poses, hs, (size_t)NK * 56);
         std::memcpy(o->points, hs + (l_pt_out - l_pose_out), (size_t)NP * 24);

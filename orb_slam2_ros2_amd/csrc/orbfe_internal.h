@@ -150,6 +150,7 @@ struct LmLaunch {
   int NK, NP, E, nf;
   double *poses[2], *points[2], *terms[2], *Hpl[2], *Hpp[2], *bp[2], *Hll[2], *bl[2], *chi_part[2];
   LmState* state;
+  LmState* state_out;  // copy of the state after the last control step of a pass, inside the result block (one download)
   const int32_t *edge_pose, *edge_point, *pt_off, *pt_edges, *ps_off, *ps_edges, *free_pose, *pose_slot, *pair_off;
   const int2* pairs;
   const double *meas, *info;

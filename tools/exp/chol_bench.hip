@@ -59,6 +59,21 @@ int main(int argc, char** argv) {
   }
   printf("nb %d: %.1f us per factorisation + solve, max residual %.2e\n", nb, ms / reps * 1e3, err);
 #ifdef LM_CHOL_STAMPS
+  {  // launch by launch: duration against the SIMD each wave landed on (HW_ID bits 5:4)
+    for (int rep = 0; rep < 24; ++rep) {
+      hipEventRecord(a);
+      hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(LM_CHOL_THREADS), 0, 0, nb, d_st, d_blk, d_rhs, d_x);
+      hipEventRecord(b);
+      hipEventSynchronize(b);
+      float one = 0;
+      hipEventElapsedTime(&one, a, b);
+      unsigned int hw[8];
+      hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_lm_hwid), sizeof hw);
+      printf("launch %2d: %6.1f us  simd of waves 0..7:", rep, one * 1e3);
+      for (int w = 0; w < 8; ++w) printf(" %u", (hw[w] >> 4) & 3);
+      printf("  cu %u se %u\n", (hw[0] >> 8) & 15, (hw[0] >> 13) & 7);
+    }
+  }
   long long stp[8][8];
   hipMemcpyFromSymbol(stp, HIP_SYMBOL(g_lm_stamps), sizeof stp);
   const char* names[8] = {"load+diag0", "panel work", "panel wait", "update work", "update wait", "diag updates", "back-subst", "-"};

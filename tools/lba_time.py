@@ -18,5 +18,5 @@ for _ in range(reps):
 t1 = t0 + (time.perf_counter() - t0) / reps
 orc = pyoracle.Oracle(pyoracle.build(fast=True, out_dir="/tmp/orb_oracle_lba"))
 t2 = time.perf_counter(); o = orc.ba_local_optimize(pr, fixed); t3 = time.perf_counter()
-print(f"edges {len(pr['edge_pose'])} free poses 40: device {1e3 * (t1 - t0):.1f} ms, cpu oracle {1e3 * (t3 - t2):.1f} ms, iters {g['iters']}, "
+print(f"edges {len(pr['edge_pose'])} free poses 40: device {1e3 * (t1 - t0):.3f} ms, cpu oracle {1e3 * (t3 - t2):.1f} ms, iters {g['iters']}, "
       f"max pose diff {np.abs(g['poses'] - o['poses']).max():.2e}")
