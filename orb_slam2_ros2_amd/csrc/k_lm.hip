@@ -445,11 +445,55 @@ __global__ __launch_bounds__(256) void k_lm_prep(int n_points, int n_poses, int 
   }
 }
 
+// The pair lists of the reduced system, built on the device once per call: block (i >= j) of free poses gets the pairs (e1, e2) of edges
+// with pose(e1) = i, pose(e2) = j that observe the same point, in the order of pose i's edge list, at pairs[b * cap ...], pair_cnt[b] of
+// them.  k_lm_pair_table: table[slot j][point] = the edge of pose j that observes the point (or -1; a pose observes a point at most once --
+// the host checks that and takes the host-driven path otherwise).  k_lm_pairs: one wave per block walks pose i's list, looks each point up
+// in row j and compacts the hits in list order (ballot + prefix count: deterministic).  The host built these lists until late r3:
+// two passes over sum(observations^2) ~ 100 k combinations, 0.37 ms of a 3.1 ms call before the first kernel could start.
+__global__ __launch_bounds__(256) void k_lm_pair_table(int n_edges, int n_points, const int32_t* __restrict__ edge_pose,
+                                                       const int32_t* __restrict__ edge_point, const int32_t* __restrict__ pose_slot,
+                                                       int32_t* __restrict__ table) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_edges) return;
+  const int s = pose_slot[edge_pose[e]];
+  if (s >= 0) table[(size_t)s * n_points + edge_point[e]] = e;
+}
+__global__ __launch_bounds__(64) void k_lm_pairs(int nf, int n_points, int cap, const int32_t* __restrict__ free_pose,
+                                                 const int32_t* __restrict__ ps_off, const int32_t* __restrict__ ps_edges,
+                                                 const int32_t* __restrict__ edge_point, const int32_t* __restrict__ table,
+                                                 int2* __restrict__ pairs, int32_t* __restrict__ pair_cnt) {
+  const int b = blockIdx.x;
+  int i = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+  while ((i + 1) * (i + 2) / 2 <= b) ++i;
+  while (i * (i + 1) / 2 > b) --i;
+  const int j = b - i * (i + 1) / 2;
+  const int lane = threadIdx.x;
+  const int ki = free_pose[i];
+  const int32_t* row = table + (size_t)j * n_points;
+  int2* out = pairs + (size_t)b * cap;
+  int n = 0;
+  const int q_end = ps_off[ki + 1];
+  for (int q0 = ps_off[ki]; q0 < q_end; q0 += 64) {
+    const int q = q0 + lane;
+    int e1 = -1, e2 = -1;
+    if (q < q_end) {
+      e1 = ps_edges[q];
+      e2 = row[edge_point[e1]];
+    }
+    const bool hit = e2 >= 0;
+    const unsigned long long m = __ballot(hit);
+    if (hit) out[n + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(e1, e2);
+    n += __popcll(m);
+  }
+  if (lane == 0) pair_cnt[b] = n;
+}
+
 // Reduced system, one wave per block (i >= j) of free poses, the lanes over the block's pairs (e1, e2): pose(e1) = i, pose(e2) = j, same
 // point.  Sblk: lower-triangular blocks, block (i, j) at (i (i + 1) / 2 + j) * 36, row-major inside.  nf more waves form the right-hand
 // side rhs_i = bp_i - sum_{e of pose i} W(e) bl(point(e)).
 __global__ __launch_bounds__(64) void k_lm_schur(int nf, LmBuffers B, const LmState* __restrict__ st, const int32_t* __restrict__ free_pose,
-                                                 const int32_t* __restrict__ pair_off, const int2* __restrict__ pairs,
+                                                 const int32_t* __restrict__ pair_cnt, int pair_cap, const int2* __restrict__ pairs,
                                                  const int32_t* __restrict__ ps_off, const int32_t* __restrict__ ps_edges,
                                                  const int32_t* __restrict__ edge_point, const double* __restrict__ W,
                                                  double* __restrict__ Sblk, double* __restrict__ rhs) {
@@ -489,7 +533,7 @@ __global__ __launch_bounds__(64) void k_lm_schur(int nf, LmBuffers B, const LmSt
   double acc[36];
 #pragma unroll
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-  const int q0 = pair_off[i * nf + j], q1 = pair_off[i * nf + j + 1];
+  const int q0 = b * pair_cap, q1 = q0 + pair_cnt[b];
   // (measured and dropped: four trips of the pair list in flight at once for the ~260-pair diagonal blocks -- the clamped loads of the
   //  one-trip blocks, 780 of 820, cost more than the diagonal ones gain: 17.5 -> 21 us)
   for (int q = q0 + lane; q < q1; q += 64) {
@@ -1200,6 +1244,13 @@ void launch_lm_build(hipStream_t s, const LmLaunch& L, int gate, int which, int 
   if (with_poses && L.NK > 0)
     hipLaunchKernelGGL(k_lm_poseblocks, dim3(L.NK), dim3(256), 0, s, L.NK, B, L.state, gate, which, L.fixed, L.ps_off, L.ps_edges);
 }
+// the pair lists of the reduced system (k_lm_pair_table / k_lm_pairs); L.pair_table holds 0xFF bytes (-1) when this is called
+void launch_lm_pairs(hipStream_t s, const LmLaunch& L) {
+  if (L.nf <= 0 || L.E <= 0) return;
+  hipLaunchKernelGGL(k_lm_pair_table, dim3((L.E + 255) / 256), dim3(256), 0, s, L.E, L.NP, L.edge_pose, L.edge_point, L.pose_slot, L.pair_table);
+  hipLaunchKernelGGL(k_lm_pairs, dim3(L.nf * (L.nf + 1) / 2), dim3(64), 0, s, L.nf, L.NP, L.pair_cap, L.free_pose, L.ps_off, L.ps_edges, L.edge_point,
+                     L.pair_table, L.pairs, L.pair_cnt);
+}
 void launch_lm_maxdiag(hipStream_t s, const LmLaunch& L, int gate) {
   hipLaunchKernelGGL(k_lm_maxdiag, dim3(1), dim3(1024), 0, s, L.NK, L.NP, lm_buffers(L), L.state, gate, L.fixed);
 }
@@ -1218,7 +1269,7 @@ void launch_lm_step(hipStream_t s, const LmLaunch& L, bool ctrl_in_tail) {
     hipLaunchKernelGGL(k_lm_prep, dim3(pb + L.NK), dim3(256), 0, s, L.NP, L.NK, pb, B, L.state, L.pt_off, L.pt_edges, L.Dinv, L.W, L.fixed, L.ps_off,
                        L.ps_edges);
   if (L.nf > 0) {
-    hipLaunchKernelGGL(k_lm_schur, dim3(L.nf * (L.nf + 1) / 2 + L.nf), dim3(64), 0, s, L.nf, B, L.state, L.free_pose, L.pair_off, L.pairs, L.ps_off,
+    hipLaunchKernelGGL(k_lm_schur, dim3(L.nf * (L.nf + 1) / 2 + L.nf), dim3(64), 0, s, L.nf, B, L.state, L.free_pose, L.pair_cnt, L.pair_cap, L.pairs, L.ps_off,
                        L.ps_edges, L.edge_point, L.W, L.Sblk, L.rhs);
     hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(LM_CHOL_THREADS), 0, s, L.nf, L.state, L.Sblk, L.rhs, L.x);
   }

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <limits>
@@ -95,6 +96,7 @@ void launch_search_area(hipStream_t s, const uint4* d_kpl, const uint8_t* d_desc
                         int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second, int32_t* d_n_cand, int32_t* d_excluded_hits);
 void launch_lm_build(hipStream_t s, const LmLaunch& L, int gate, int which, int write_last, int tail_mode, bool with_poses);
 void launch_lm_maxdiag(hipStream_t s, const LmLaunch& L, int gate);
+void launch_lm_pairs(hipStream_t s, const LmLaunch& L);
 void launch_lm_steps(hipStream_t s, const LmLaunch& L, int n);
 void launch_lm_switch(hipStream_t s, const LmLaunch& L);
 void launch_lm_final(hipStream_t s, const LmLaunch& L);
@@ -2099,6 +2101,14 @@ orbfe_status orbfe_ba_build_system(orbfe_ctx* c, const orbfe_ba_problem* p, cons
 orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, const uint8_t* pose_fixed, int32_t iters_first,
                                      int32_t iters_second, const volatile uint8_t* stop_flag, const orbfe_ba_optimize_out* o) {
   ApiLock api_lk(c);
+  static const bool trace_host = getenv("ORBFE_LBA_TRACE") != nullptr;  // diagnostic: host phases of this call on stderr
+  auto t_prev = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (!trace_host) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[orbfe lba] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(now - t_prev).count());
+    t_prev = now;
+  };
   if (!c || !p || !o) return fail(c, ORBFE_EBADARG, "ba_local_optimize: NULL argument");
   const int E = p->n_edges, NK = p->n_poses, NP = p->n_points;
   if (E < 0 || NK < 0 || NP < 0 || iters_first < 0 || iters_second < 0) return fail(c, ORBFE_EBADARG, "ba_local_optimize: negative size");
@@ -2133,18 +2143,37 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
       ps_edges[kc[p->edge_pose[e]]++] = e;
     }
   }
-  std::vector<int32_t> pair_off((size_t)nf * nf + 1, 0);
-  std::vector<int2> pairs;
-  // the device-side Levenberg-Marquardt path (k_lm.hip) builds the blocks i >= j only: half the pairs to list, to stage and to upload
-  const bool lower_only = c && c->lm_on_device && E > 0 && nf <= LM_CHOL_MAX_NB;
+  // The device-side Levenberg-Marquardt path (k_lm.hip) builds the pair lists of the reduced system itself, from a (pose, point) -> edge
+  // table: that needs a pose to observe a point at most once (as every map of the reference does); anything else takes the host-driven path.
+  bool single_obs = true;
+  int pair_cap = 1;
   {
+    std::vector<int32_t> seen(std::max(NK, 1), -1);
+    for (int pt = 0; pt < NP && single_obs; ++pt)
+      for (int a = pt_off[pt]; a < pt_off[pt + 1]; ++a) {
+        const int k = p->edge_pose[pt_edges[a]];
+        if (seen[k] == pt) {
+          single_obs = false;
+          break;
+        }
+        seen[k] = pt;
+      }
+    for (int k = 0; k < NK; ++k)
+      if (slot[k] >= 0) pair_cap = std::max(pair_cap, ps_off[k + 1] - ps_off[k]);
+  }
+  mark("validate + vertex lists");
+  std::vector<int32_t> pair_off(1, 0);
+  std::vector<int2> pairs;
+  const bool lower_only = c && c->lm_on_device && E > 0 && nf <= LM_CHOL_MAX_NB && single_obs;  // (= dev_lm below)
+  if (!lower_only) {
+    pair_off.assign((size_t)nf * nf + 1, 0);
     for (int pt = 0; pt < NP; ++pt)
       for (int a = pt_off[pt]; a < pt_off[pt + 1]; ++a) {
         const int i = slot[p->edge_pose[pt_edges[a]]];
         if (i < 0) continue;
         for (int b2 = pt_off[pt]; b2 < pt_off[pt + 1]; ++b2) {
           const int j = slot[p->edge_pose[pt_edges[b2]]];
-          if (j >= 0 && !(lower_only && j > i)) ++pair_off[(size_t)i * nf + j + 1];
+          if (j >= 0) ++pair_off[(size_t)i * nf + j + 1];
         }
       }
     for (size_t q = 0; q < (size_t)nf * nf; ++q) pair_off[q + 1] += pair_off[q];
@@ -2156,10 +2185,11 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
         if (i < 0) continue;
         for (int b2 = pt_off[pt]; b2 < pt_off[pt + 1]; ++b2) {
           const int e2 = pt_edges[b2], j = slot[p->edge_pose[e2]];
-          if (j >= 0 && !(lower_only && j > i)) pairs[cur[(size_t)i * nf + j]++] = make_int2(e1, e2);
+          if (j >= 0) pairs[cur[(size_t)i * nf + j]++] = make_int2(e1, e2);
         }
       }
   }
+  mark("pair lists");
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
   size_t off = 0;
@@ -2186,10 +2216,11 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
   // the device-side Levenberg-Marquardt path (k_lm.hip): second estimate / system buffers, per-edge terms, blocked reduced system
   const bool dev_lm = lower_only;
   const int chi_blocks = (NP + 31) / 32, scale_blocks = (NP + 31) / 32 + (NK + 255) / 256;  // (k_lm_linpoints: a partial sum per block of 32 points)
-  size_t l_pose1 = 0, l_pt1 = 0, l_terms[2] = {0, 0}, l_hpl1 = 0, l_hpp1 = 0, l_bp1 = 0, l_hll1 = 0, l_bl1 = 0, l_chi[2] = {0, 0}, l_sblk = 0,
+  size_t l_ptable = 0, l_pairs = 0, l_paircnt = 0, l_pose1 = 0, l_pt1 = 0, l_terms[2] = {0, 0}, l_hpl1 = 0, l_hpp1 = 0, l_bp1 = 0, l_hll1 = 0, l_bl1 = 0, l_chi[2] = {0, 0}, l_sblk = 0,
          l_scale = 0, l_pose_out = 0, l_pt_out = 0, l_chi2_out = 0, l_level_out = 0, l_bad_out = 0, l_state_out = 0, l_out_end = 0;
   if (dev_lm) {
     l_pose1 = take((size_t)NK * 56), l_pt1 = take((size_t)NP * 24);
+    l_ptable = take((size_t)nf * NP * 4), l_pairs = take((size_t)nf * (nf + 1) / 2 * pair_cap * 8), l_paircnt = take((size_t)nf * (nf + 1) / 2 * 4);
     l_terms[0] = take((size_t)E * 256), l_terms[1] = take((size_t)E * 256);
     l_hpl1 = take((size_t)E * 144), l_hpp1 = take((size_t)NK * 288), l_bp1 = take((size_t)NK * 48), l_hll1 = take((size_t)NP * 72),
     l_bl1 = take((size_t)NP * 24);
@@ -2237,6 +2268,7 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     init.iters[0] = iters_first, init.iters[1] = iters_second, init.need_chi = 1, init.ok = 1;
     HIP_TRY(c, up(o_lmstate, &init, sizeof init));
   }
+  mark("stage inputs");
   HIP_TRY(c, hipMemcpyAsync(b, hs, up_bytes, hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemsetAsync(b + o_level, 0, o_zero_end - o_level, st));  // (every memset is a launch of 4.6 us: six of them preceded the first kernel)
 
@@ -2266,7 +2298,8 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     L.tail_ctrl = c->lm_tail_ctrl ? 1 : 0;
     L.edge_pose = d_ek, L.edge_point = d_ep, L.pt_off = (const int32_t*)(b + o_pto), L.pt_edges = (const int32_t*)(b + o_pte);
     L.ps_off = (const int32_t*)(b + o_pso), L.ps_edges = (const int32_t*)(b + o_pse), L.free_pose = (const int32_t*)(b + o_free);
-    L.pose_slot = (const int32_t*)(b + o_slot), L.pair_off = (const int32_t*)(b + o_pairoff), L.pairs = (const int2*)(b + o_pairs);
+    L.pose_slot = (const int32_t*)(b + o_slot), L.pairs = (int2*)(b + l_pairs), L.pair_cnt = (int32_t*)(b + l_paircnt);
+    L.pair_table = (int32_t*)(b + l_ptable), L.pair_cap = pair_cap;
     L.meas = (const double*)(b + o_meas), L.info = (const double*)(b + o_info), L.is_stereo = b + o_st, L.fixed = b + o_fix;
     L.info_eff = (double*)(b + o_info_eff), L.delta_eff = (double*)(b + o_delta), L.chi2_last = (double*)(b + o_last), L.level = b + o_level;
     L.Dinv = (double*)(b + o_dinv), L.W = (double*)(b + o_w), L.Sblk = (double*)(b + l_sblk), L.rhs = (double*)(b + o_rhs), L.x = (double*)(b + o_x);
@@ -2277,6 +2310,8 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     //  are part of the one zero fill)
     L.state_out = (LmState*)(b + l_state_out);
     StageTimer tm(c, ORBFE_STAGE_BA, st);
+    HIP_TRY(c, hipMemsetAsync(L.pair_table, 0xFF, (size_t)nf * NP * 4, st));
+    launch_lm_pairs(st, L);
     launch_lm_build(st, L, 0, 0, iters_first > 0 ? 1 : 0, -1, true);  // computeActiveErrors + buildSystem at the initial estimate
     launch_lm_maxdiag(st, L, 0);
     // trials provisioned per pass: every iteration needs at least one, a rejected trial costs one more; what is left over runs as no-ops
@@ -2314,7 +2349,9 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
         (void)hipEventDestroy(ev);
         HIP_TRY(c, er);
       }
+      mark("enqueue");
       HIP_TRY(c, hipStreamSynchronize(st));
+      mark("device (wait)");
       std::memcpy(&fin, hs + (l_state_out - l_pose_out), sizeof fin);
       if (fin.finalized) {
         std::memcpy(o->poses, hs, (size_t)NK * 56);
@@ -2334,6 +2371,7 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
       o->iterations[1] = fin.done[1];
     }
     drain_timers(c);
+    mark("results out");
     return ORBFE_OK;
   }
   struct HostScalars {

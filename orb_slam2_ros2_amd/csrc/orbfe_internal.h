@@ -151,8 +151,11 @@ struct LmLaunch {
   double *poses[2], *points[2], *terms[2], *Hpl[2], *Hpp[2], *bp[2], *Hll[2], *bl[2], *chi_part[2];
   LmState* state;
   LmState* state_out;  // copy of the state after the last control step of a pass, inside the result block (one download)
-  const int32_t *edge_pose, *edge_point, *pt_off, *pt_edges, *ps_off, *ps_edges, *free_pose, *pose_slot, *pair_off;
-  const int2* pairs;
+  const int32_t *edge_pose, *edge_point, *pt_off, *pt_edges, *ps_off, *ps_edges, *free_pose, *pose_slot;
+  int2* pairs;          // [nf (nf + 1) / 2][pair_cap], built on the device (launch_lm_pairs)
+  int32_t* pair_cnt;    // [nf (nf + 1) / 2]
+  int32_t* pair_table;  // [nf][NP]: edge of free pose j observing the point, -1 if none
+  int pair_cap;         // longest edge list of a free pose
   const double *meas, *info;
   const uint8_t *is_stereo, *fixed;
   double *info_eff, *delta_eff, *chi2_last;
