@@ -176,6 +176,7 @@ struct orbfe_ctx {
   std::mutex slot_lane_mu;
   bool use_graphs = true;
   bool host_mirror = true;  // ORBFE_HOST_MIRROR=0: results of the host-pointer path by device-to-host copies instead of kernel writes
+  bool host_read = false;   // ORBFE_HOST_READ=1: images of the host-pointer path by kernel reads of the staging buffer instead of a host-to-device copy (measured slower)
   // the stereo match of a device-resident batch runs on its own stream: it is latency-bound and reads only the keypoint /
   // descriptor arrays and the pyramid, so the NEXT batch's copy-in, resize and FAST (second pyramid buffer) run under it
   uint8_t* d_pyr_alt = nullptr;
@@ -1108,6 +1109,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     }
     if (const char* gr = getenv("ORBFE_GRAPHS")) c->use_graphs = atoi(gr) != 0;
     if (const char* hm = getenv("ORBFE_HOST_MIRROR")) c->host_mirror = atoi(hm) != 0;
+    if (const char* hr = getenv("ORBFE_HOST_READ")) c->host_read = atoi(hr) != 0;
     {
       const char* ps = getenv("ORBFE_PIPELINE_STEREO");
       c->pipeline_stereo = !ps || atoi(ps) != 0;
@@ -1404,11 +1406,18 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
   // device-to-host copies queued behind the last kernel cost ~17 us of a ~0.3 ms call.  ORBFE_HOST_MIRROR=0: the copies.
   const bool mirror_on = c->host_mirror && n_img <= 2;
   HostMirror mir = {kps ? (orbfe_keypoint*)(ln.h_stage + o_kps) : nullptr, desc ? ln.h_stage + o_desc : nullptr, (int32_t*)(ln.h_stage + o_cnt)};
+  // ORBFE_HOST_READ=1 (measured, off by default): a frame or two go IN the same way -- the resize kernel reads the page-locked staging
+  // planes itself and writes level 0 of the pyramid from the blocks it stages, as it does for the caller's device images of a batch.
+  // The copy in front of the resize is 17 us + a 9 us gap for a pair; the kernel that reads over PCIe takes 50 us instead of 12 (0.93 MB
+  // at 19 GB/s: a few 16-byte requests per lane in flight against ~2 us of round trip) -- the copy engine wins.
+  const bool read_on = c->host_read && n_img <= 2 && c->resize_regions && c->ext_level0 && !c->rs_regions.empty();
+  const ExtLevel0 ext = {ln.h_stage, nullptr, plane, (int)L0.stride, (uint32_t)((size_t)L0.stride * L0.h), nullptr};
   auto enqueue_all = [&]() -> orbfe_status {
     // both eyes in ONE copy (rows = images: the staging planes are `plane` bytes apart, the pyramid slots img_pitch)
-    HIP_TRY(c, hipMemcpy2DAsync(pyr_now + (size_t)slot0 * c->img_pitch + L0.plane_off, c->img_pitch, ln.h_stage, plane, (size_t)L0.stride * L0.h,
-                                (size_t)n_img, hipMemcpyHostToDevice, ln.stream));
-    TRY(run_extract(c, ln.stream, slot0, n_img, 1, nullptr, timing, nullptr, mirror_on ? &mir : nullptr));
+    if (!read_on)
+      HIP_TRY(c, hipMemcpy2DAsync(pyr_now + (size_t)slot0 * c->img_pitch + L0.plane_off, c->img_pitch, ln.h_stage, plane, (size_t)L0.stride * L0.h,
+                                  (size_t)n_img, hipMemcpyHostToDevice, ln.stream));
+    TRY(run_extract(c, ln.stream, slot0, n_img, 1, nullptr, timing, read_on ? &ext : nullptr, mirror_on ? &mir : nullptr));
     if (mirror_on) return ORBFE_OK;
     return enqueue_fetch(c, ln, slot0, n_img, o_kps, o_desc, o_cnt, kps != nullptr, desc != nullptr);
   };
