@@ -205,6 +205,121 @@ __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv,
 }
 
 // ---------------------------------------------------------------------------------------------
+// 0 + 1 + 2 in ONE launch, for a frame or two (the host-pointer / slot paths): the three kernels above take ~5 us each there -- the
+//    floor of a dependent launch, not their work -- so the 16 lanes that sum a keypoint's moments first build its list entry themselves
+//    (the same loads, redundantly) and lane 15 of the row, which ends up with the sums, goes on to the orientation.  Same arithmetic,
+//    same results; a batch keeps the separate kernels (one lane per keypoint is the better shape for the fp64 trigonometry at scale).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_list_moments_orient(const LevelDev* __restrict__ lv, int n_levels, const uint32_t* __restrict__ sel,
+                                                             const int32_t* __restrict__ sel_count, int n_features,
+                                                             const uint8_t* __restrict__ pyr, size_t img_pitch, UmaxPacked umax,
+                                                             uint4* __restrict__ kpl, int2* __restrict__ moments, double2* __restrict__ sincos,
+                                                             orbfe_keypoint* __restrict__ kps, KpAux* __restrict__ aux, float* __restrict__ kx,
+                                                             double* __restrict__ theta_out, int rows0, int32_t* __restrict__ n_kp,
+                                                             orbfe_keypoint* __restrict__ kps_host, int32_t* __restrict__ n_kp_host) {
+#pragma clang fp contract(off)
+  __shared__ uint32_t s_mask[256];
+  {
+    const int it = threadIdx.x >> 4, sb = threadIdx.x & 15;
+    const int dy = (sb >> 3) + 2 * it - 15;
+    const int ady = dy < 0 ? -dy : dy;
+    uint32_t mask = 0u;
+    if (ady <= 15) {
+      const int d = (int)((umax >> (4 * ady)) & 15ull);
+      const int dx0 = 4 * (sb & 7) - 15;
+      const int lo = max(0, -d - dx0), hi = min(3, d - dx0);
+      mask = (hi >= lo) ? ((0xFFFFFFFFu >> (8 * (3 - hi))) & (0xFFFFFFFFu << (8 * lo))) : 0u;
+    }
+    s_mask[threadIdx.x] = mask;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, sub = lane & 15;
+  const int k = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  const int img = blockIdx.y;
+  const bool in_range = k < n_features;
+  // the list entry (k_kplist)
+  uint4 e = make_uint4(0xFFFFu, 0u, 0u, 0u);
+  int level = -1, total = 0;
+  {
+    int j;
+    level = locate_level(sel_count + (size_t)img * n_levels, n_levels, in_range ? k : 0x7FFFFFFF, &j, &total);
+    if (level >= 0) {
+      const LevelDev& L = lv[level];
+      const uint32_t rec = sel[(size_t)img * n_features + L.quota_off + j];
+      e.x = (ORBFE_REC_X(rec) + ORBFE_EDGE) | ((ORBFE_REC_Y(rec) + ORBFE_EDGE) << 16);
+      e.y = (uint32_t)level | (ORBFE_REC_R(rec) << 8);
+      e.z = L.plane_off;
+      e.w = (uint32_t)L.stride;
+    }
+  }
+  if (k == 0 && sub == 15) {
+    n_kp[img] = total;
+    if (n_kp_host) n_kp_host[img] = total;
+  }
+  // the moments (k_ic_moments)
+  const bool valid = (e.x & 0xFFFFu) != 0xFFFFu;
+  const int x = valid ? (int)(e.x & 0xFFFFu) : 16, y = valid ? (int)(e.x >> 16) : 16;
+  const uint8_t* I = pyr + (size_t)img * img_pitch;
+  const uint32_t plane = valid ? e.z : 0u;
+  const int stride = valid ? (int)e.w : 64;
+  constexpr int NIT = 16;
+  const uint32_t a0 = plane + (uint32_t)mad24u(y - 15 + (sub >> 3), stride, x - 15 + 4 * (sub & 7));
+  const uint32_t step = 2u * (uint32_t)stride;
+  uint32_t wv[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    uint32_t w;
+    __builtin_memcpy(&w, I + (a0 + (uint32_t)it * step), 4);
+    wv[it] = w;
+  }
+  uint32_t S = 0u, Wp = 0u, T = 0u;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const uint32_t w = wv[it] & s_mask[it * 16 + sub];
+    S = __builtin_amdgcn_udot4(w, 0x01010101u, S, false);
+    Wp = __builtin_amdgcn_udot4(w, 0x03020100u, Wp, false);
+    T = __builtin_amdgcn_udot4(w, 0x01010101u * (uint32_t)it, T, false);
+  }
+  const int S18 = (int)(S & 0x3FFFFu);
+  int m10 = (4 * (sub & 7) - 15) * S18 + (int)Wp;
+  int m01 = ((sub >> 3) - 15) * S18 + 2 * (int)T;
+#pragma unroll
+  for (int sh = 0; sh < 4; ++sh) {
+    m10 += (sh == 0) ? dpp_i32<0x111, 0xf>(m10) : (sh == 1) ? dpp_i32<0x112, 0xf>(m10) : (sh == 2) ? dpp_i32<0x114, 0xf>(m10) : dpp_i32<0x118, 0xf>(m10);
+    m01 += (sh == 0) ? dpp_i32<0x111, 0xf>(m01) : (sh == 1) ? dpp_i32<0x112, 0xf>(m01) : (sh == 2) ? dpp_i32<0x114, 0xf>(m01) : dpp_i32<0x118, 0xf>(m01);
+  }
+  if (sub != 15 || !in_range) return;
+  const size_t o = (size_t)img * n_features + k;
+  kpl[o] = e;
+  if (!valid) return;
+  moments[o] = make_int2(m10, m01);
+  // the orientation (k_orient)
+  const LevelDev& L = lv[level];
+  const double theta = orbmath::det_atan2((double)m01, (double)m10);
+  double sn, cs;
+  orbmath::det_sincos(theta, &sn, &cs);
+  sincos[o] = make_double2(sn, cs);
+  orbfe_keypoint kp;
+  kp.x = (float)x * L.sf;
+  kp.y = (float)y * L.sf;
+  kp.size = 7.0f;
+  kp.angle = (float)(theta / 3.14159265358979323846 * 180);
+  kp.response = (float)((e.y >> 8) & 0xFFu);
+  kp.octave = level;
+  kp.class_id = -1;
+  kps[o] = kp;
+  if (kps_host) kps_host[o] = kp;
+  kx[o] = kp.x;
+  const float r = (float)(2.0 * (double)L.sf);
+  const unsigned row = (unsigned)__float2int_rn(kp.y);
+  KpAux a;
+  a.row_max = (int16_t)min(rows0, __float2int_rn((float)row + r + 1.0f));
+  a.row_min = (int16_t)max(0, __float2int_rn((float)row - r));
+  aux[o] = a;
+  if (theta_out) theta_out[o] = theta;
+}
+
+// ---------------------------------------------------------------------------------------------
 // 3. rotated BRIEF, one wave per keypoint.  The 37x37 window of the BLURRED plane that the rotated template
 //    can reach (|offset| <= 18) is staged in LDS with coalesced word loads; the 512 data-dependent byte reads
 //    then hit LDS instead of issuing 8 global gathers with ~64 distinct cache lines each.
@@ -373,10 +488,19 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
                          int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx,
                          uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief, hipEvent_t before_lists, orbfe_keypoint* h_kps,
-                         uint8_t* h_desc, int32_t* h_n_kp) {
+                         uint8_t* h_desc, int32_t* h_n_kp, bool fuse_small) {
   if (n_img <= 0 || n_features <= 0) return;
   UmaxPacked u = 0;
   for (int i = 0; i < 16; ++i) u |= (unsigned long long)(umax[i] & 15) << (4 * i);
+  if (fuse_small && n_img <= 2) {  // list + moments + orientation in one launch (a frame or two: three launch floors of ~5 us become one)
+    if (before_lists) (void)hipStreamWaitEvent(s, before_lists, 0);
+    hipLaunchKernelGGL(k_list_moments_orient, dim3((n_features + 15) / 16, n_img), dim3(256), 0, s, d_lv, n_levels, d_sel, d_sel_count, n_features,
+                       d_pyr, img_pitch, u, d_kpl, d_moments, d_sincos, d_kps, d_aux, d_kx, d_theta, rows0, d_n_kp, h_kps, h_n_kp);
+    if (before_brief) (void)hipStreamWaitEvent(s, before_brief, 0);
+    hipLaunchKernelGGL(k_brief, dim3((((n_features + BRIEF_WAVES * BRIEF_KPW - 1) / (BRIEF_WAVES * BRIEF_KPW)) + 7) & ~7, n_img), dim3(64 * BRIEF_WAVES), 0, s,
+                       d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos, d_desc, h_desc);
+    return;
+  }
   hipLaunchKernelGGL(k_kplist, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, n_levels, d_sel, d_sel_count, n_features,
                      d_kpl);
   hipLaunchKernelGGL(k_ic_moments, dim3((n_features + 15) / 16, n_img), dim3(256), 0, s, d_pyr, img_pitch, d_kpl, n_features, u,

@@ -111,13 +111,14 @@ __device__ __forceinline__ int cv_floor_f(float v) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rowtable(const KpAux* __restrict__ aux, const int32_t* __restrict__ n_kp, int n_features, int rows,
                                                   int list_cap, uint32_t* __restrict__ rowoff, uint16_t* __restrict__ rowlist, int slot_r0,
-                                                  int slot_step, int pair0) {
+                                                  int slot_step, int pair0, int32_t* __restrict__ n_match) {
   extern __shared__ uint32_t s_rt[];  // cnt[rows] | part[256]
   uint32_t* cnt = s_rt;
   uint32_t* part = s_rt + rows;
   const int tid = threadIdx.x;
   const int slot = slot_r0 + blockIdx.x * slot_step;
   const int pair = pair0 + blockIdx.x;
+  if (tid == 0) n_match[pair] = 0;  // k_stereo counts into it (a memset in front of this kernel was one more launch)
   const KpAux* A = aux + (size_t)slot * n_features;
   uint32_t* RO = rowoff + (size_t)pair * (rows + 1);
   uint16_t* RL = rowlist + (size_t)pair * list_cap;
@@ -161,6 +162,12 @@ __global__ __launch_bounds__(256) void k_rowtable(const KpAux* __restrict__ aux,
   }
 }
 
+// results of ONE pair delivered to page-locked host memory by the kernel itself (all nullable; index = left keypoint): the single-pair
+// entry point queued up to five device-to-host copies behind the kernel otherwise
+struct StereoHost {
+  double *right_u, *depth;
+  int32_t *best_right, *best_dist;
+};
 __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv, int n_levels, const uint8_t* __restrict__ pyr, size_t img_pitch,
                                                 const orbfe_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
                                                 const float* __restrict__ kx, const uint32_t* __restrict__ rowoff,
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
                                                 int n_features, float fx, float bf, int cols0, int mean_threshold,
                                                 double* __restrict__ right_u, double* __restrict__ depth, int32_t* __restrict__ n_match,
                                                 int32_t* __restrict__ best_right, int32_t* __restrict__ best_dist, int slot_l0,
-                                                int slot_r0, int slot_step, int pair0) {
+                                                int slot_r0, int slot_step, int pair0, StereoHost host) {
 #pragma clang fp contract(off)
   __shared__ uint32_t s_sad[4][11 * 4 + 11 * 7 + 7];  // per wave: left 11 rows x 4 words, right 11 rows x 7 words
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -202,6 +209,10 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
       depth[out_i] = -1.0;
       best_right[out_i] = -1;
       best_dist[out_i] = -1;
+      if (host.right_u) host.right_u[li] = -1.0;
+      if (host.depth) host.depth[li] = -1.0;
+      if (host.best_right) host.best_right[li] = -1;
+      if (host.best_dist) host.best_dist[li] = -1;
     }
     return;
   }
@@ -317,6 +328,10 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
     depth[out_i] = out_depth;
     best_right[out_i] = any ? b.min_idx : -1;
     best_dist[out_i] = any ? b.min_d : -1;
+    if (host.right_u) host.right_u[li] = out_u;
+    if (host.depth) host.depth[li] = out_depth;
+    if (host.best_right) host.best_right[li] = any ? b.min_idx : -1;
+    if (host.best_dist) host.best_dist[li] = any ? b.min_d : -1;
     if (matched) atomicAdd(&n_match[pair], 1);
   }
 }
@@ -331,13 +346,17 @@ void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const ui
 void launch_stereo(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, size_t img_pitch, const orbfe_keypoint* d_kps,
                    const uint8_t* d_desc, const KpAux* d_aux, const float* d_kx, uint32_t* d_rowoff, uint16_t* d_rowlist, int rows, int list_cap,
                    const int32_t* d_n_kp, int n_features, float fx, float bf, int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
-                   int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs) {
+                   int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs, double* h_right_u, double* h_depth,
+                   int32_t* h_best_right, int32_t* h_best_dist) {
+  // h_*: page-locked host arrays [n_features] for the results of ONE pair (n_pairs == 1), or null
   if (n_pairs <= 0 || n_features <= 0) return;
+  StereoHost host = {nullptr, nullptr, nullptr, nullptr};
+  if (n_pairs == 1) host = {h_right_u, h_depth, h_best_right, h_best_dist};
   hipLaunchKernelGGL(k_rowtable, dim3(n_pairs), dim3(256), (size_t)(rows + 256) * sizeof(uint32_t), s, d_aux, d_n_kp, n_features, rows, list_cap,
-                     d_rowoff, d_rowlist, slot_r0, slot_step, pair0);
+                     d_rowoff, d_rowlist, slot_r0, slot_step, pair0, d_n_match);
   hipLaunchKernelGGL(k_stereo, dim3((n_features + 3) / 4, n_pairs), dim3(256), 0, s, d_lv, n_levels, d_pyr, img_pitch, d_kps, d_desc,
                      d_kx, d_rowoff, d_rowlist, rows, list_cap, d_n_kp, n_features, fx, bf, cols0, mean_threshold, d_right_u, d_depth, d_n_match, d_best_right,
-                     d_best_dist, slot_l0, slot_r0, slot_step, pair0);
+                     d_best_dist, slot_l0, slot_r0, slot_step, pair0, host);
 }
 
 }  // namespace orbfe

@@ -153,7 +153,10 @@ __global__ __launch_bounds__(256) void k_resize_regions(const LevelDev* __restri
                                                         const RgXTap* __restrict__ xtaps, const RgYTap* __restrict__ ytaps,
                                                         uint8_t* __restrict__ pyr, size_t img_pitch, int tile_bytes, int xt_bytes,
                                                         const uint8_t* __restrict__ src_a, const uint8_t* __restrict__ src_b, size_t src_pitch,
-                                                        int sstride, uint32_t src_bytes, int copy_l0) {
+                                                        int sstride, uint32_t src_bytes, int copy_l0, int32_t* __restrict__ d_zero, int n_zero) {
+  // d_zero[0 .. n_zero): cleared by the first block (the candidate counters of the FAST launches that follow this kernel)
+  if (blockIdx.x == 0 && blockIdx.y == 0)
+    for (int i = threadIdx.x; i < n_zero; i += 256) d_zero[i] = 0;
   // level 0 is read from (src_a, src_b, src_pitch, sstride): the pyramid's own level-0 planes (src_b null: image i at src_a + i src_pitch),
   // or -- device batches -- the CALLER's left / right images (image i = eye i & 1 of pair i >> 1), so that the resize does not wait
   // for the copy-in but runs beside it.  src_bytes: size of one source image; a 16-byte unit that would end past it (the last unit
@@ -540,10 +543,12 @@ void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, c
 
 void launch_resize_regions(hipStream_t s, const LevelDev* d_lv, int n_levels, const RsRegion* d_regions, int n_regions, int tile_bytes,
                            int xt_bytes, int yt_bytes, const RgXTap* d_xtaps, const RgYTap* d_ytaps, uint8_t* d_pyr, size_t img_pitch, int n_img,
-                           const uint8_t* src_a, const uint8_t* src_b, size_t src_pitch, int src_stride, uint32_t src_bytes, int copy_l0) {
+                           const uint8_t* src_a, const uint8_t* src_b, size_t src_pitch, int src_stride, uint32_t src_bytes, int copy_l0,
+                           int32_t* d_zero, int n_zero) {
   if (n_img <= 0 || n_regions <= 0) return;
   hipLaunchKernelGGL(k_resize_regions, dim3(n_regions, n_img), dim3(256), (size_t)(tile_bytes + xt_bytes + yt_bytes), s, d_lv, n_levels,
-                     d_regions, d_xtaps, d_ytaps, d_pyr, img_pitch, tile_bytes, xt_bytes, src_a, src_b, src_pitch, src_stride, src_bytes, copy_l0);
+                     d_regions, d_xtaps, d_ytaps, d_pyr, img_pitch, tile_bytes, xt_bytes, src_a, src_b, src_pitch, src_stride, src_bytes, copy_l0, d_zero,
+                     n_zero);
 }
 
 // tiles [tile_first, tile_first + n_tiles) of the per-image tile list (level-major: a range of tiles is a range of levels)

@@ -27,7 +27,7 @@ void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, c
                    size_t img_pitch, int n_img);
 void launch_resize_regions(hipStream_t s, const LevelDev* d_lv, int n_levels, const RsRegion* d_regions, int n_regions, int tile_bytes,
                            int xt_bytes, int yt_bytes, const RgXTap* d_xtaps, const RgYTap* d_ytaps, uint8_t* d_pyr, size_t img_pitch, int n_img,
-                           const uint8_t* src_a, const uint8_t* src_b, size_t src_pitch, int src_stride, uint32_t src_bytes, int copy_l0);
+                           const uint8_t* src_a, const uint8_t* src_b, size_t src_pitch, int src_stride, uint32_t src_bytes, int copy_l0, int32_t* d_zero, int n_zero);
 void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int tile_first, int n_tiles, const uint8_t* d_pyr, uint8_t* d_blur,
                  size_t img_pitch, const int taps[7], int n_img);
 void launch_load_level0(hipStream_t st, const uint8_t* d_src, const uint8_t* d_src_b, size_t src_stride, size_t src_pitch, uint8_t* d_pyr,
@@ -47,14 +47,16 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
                          int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx,
-                         uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief, hipEvent_t before_lists, orbfe_keypoint* h_kps, uint8_t* h_desc, int32_t* h_n_kp);
+                         uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief, hipEvent_t before_lists, orbfe_keypoint* h_kps, uint8_t* h_desc, int32_t* h_n_kp,
+                         bool fuse_small);
 // k_match.hip
 void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, const uint32_t* d_off,
                              const uint32_t* d_cand, int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second);
 void launch_stereo(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, size_t img_pitch, const orbfe_keypoint* d_kps,
                    const uint8_t* d_desc, const KpAux* d_aux, const float* d_kx, uint32_t* d_rowoff, uint16_t* d_rowlist, int rows, int list_cap,
                    const int32_t* d_n_kp, int n_features, float fx, float bf, int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
-                   int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs);
+                   int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs, double* h_right_u, double* h_depth,
+                   int32_t* h_best_right, int32_t* h_best_dist);
 // k_glue.hip
 void launch_cvt_gray(hipStream_t s, const uint8_t* d_src, size_t src_stride, uint8_t* d_dst, int dst_stride, int w, int h, int order,
                      int variant);
@@ -176,6 +178,7 @@ struct orbfe_ctx {
   std::mutex slot_lane_mu;
   bool use_graphs = true;
   bool host_mirror = true;  // ORBFE_HOST_MIRROR=0: results of the host-pointer path by device-to-host copies instead of kernel writes
+  bool fuse_orient = true;  // ORBFE_FUSE_ORIENT=0: keypoint list, moments and orientation of a frame or two as three launches (as batches do) instead of one
   bool host_read = false;   // ORBFE_HOST_READ=1: images of the host-pointer path by kernel reads of the staging buffer instead of a host-to-device copy (measured slower)
   // the stereo match of a device-resident batch runs on its own stream: it is latency-bound and reads only the keypoint /
   // descriptor arrays and the pyramid, so the NEXT batch's copy-in, resize and FAST (second pyramid buffer) run under it
@@ -860,13 +863,16 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     HIP_TRY(c, hipStreamWaitEvent(c->blur_stream, c->ev_blur_go, 0));
     launch_blur(c->blur_stream, c->d_lv, nl, 0, l0_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
   }
+  // FAST's candidate counters are zeroed by the resize kernel (block 0): a memset between the blur and FAST is one more launch in the
+  // chain -- 4.6 us of a 0.2 ms frame
+  const bool zeroed_by_resize = c->resize_regions && !c->rs_regions.empty();
   {
     StageTimer t(c, ORBFE_STAGE_RESIZE, st, timing);
-    if (c->resize_regions && !c->rs_regions.empty())
+    if (zeroed_by_resize)
       launch_resize_regions(st, c->d_lv, nl, c->d_rs_regions, (int)c->rs_regions.size(), c->rg_tile_bytes, c->rg_xt_bytes, c->rg_yt_bytes,
                             c->d_rg_xtaps, c->d_rg_ytaps, pyr, c->img_pitch, n_img, ext ? ext->left : pyr + c->lv[0].plane_off,
                             ext ? ext->right : nullptr, ext ? ext->pitch : c->img_pitch, ext ? ext->stride : c->lv[0].stride,
-                            ext ? ext->bytes : 0xFFFFFFFFu, ext ? 1 : 0);
+                            ext ? ext->bytes : 0xFFFFFFFFu, ext ? 1 : 0, n_cand, n_img * nl);
     else
       launch_resize(st, c->d_lv, c->d_rs_tiles, c->rs_n, c->rs_bytes, c->d_taps, pyr, c->img_pitch, n_img);
   }
@@ -896,7 +902,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     StageTimer t(c, ORBFE_STAGE_BLUR, st, timing);
     launch_blur(st, c->d_lv, nl, 0, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
   }
-  HIP_TRY(c, hipMemsetAsync(n_cand, 0, sizeof(int32_t) * (size_t)n_img * nl, st));
+  if (!zeroed_by_resize) HIP_TRY(c, hipMemsetAsync(n_cand, 0, sizeof(int32_t) * (size_t)n_img * nl, st));
   {
     StageTimer t(c, ORBFE_STAGE_FAST, st, timing);
     launch_fast(st, c->d_lv, c->d_cells, c->lv.data(), c->lvl_max_pw, c->lvl_max_ph, pyr, c->img_pitch, c->cfg.fast_hi, c->cfg.fast_lo,
@@ -943,23 +949,28 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
                         c->d_theta + i0 * NF, c->d_moments + i0 * NF, c->d_sincos + i0 * NF, c->d_kx + i0 * NF,
                         c->d_kpl + i0 * NF, c->cfg.height, n_img,
                         overlap_blur ? c->ev_blur_done : nullptr, before_lists, mirror ? mirror->kps : nullptr, mirror ? mirror->desc : nullptr,
-                        mirror ? mirror->n_kp : nullptr);
+                        mirror ? mirror->n_kp : nullptr, c->fuse_orient);
   }
   HIP_TRY(c, hipGetLastError());
   return ORBFE_OK;
 }
 
+struct StereoHostOut {  // page-locked destinations for the results of one pair, written by k_stereo itself (nullable members)
+  double *right_u, *depth;
+  int32_t *best_right, *best_dist;
+};
 static orbfe_status run_stereo(orbfe_ctx* c, hipStream_t st, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs, float fx,
-                               float bf) {
+                               float bf, const StereoHostOut* ho = nullptr) {
   // (c->d_pyr is read here, at launch time: a later swap of the pyramid buffers does not affect a launch already queued)
-  HIP_TRY(c, hipMemsetAsync(c->d_n_match + pair0, 0, sizeof(int32_t) * n_pairs, st));
+  // (the match counters are zeroed by k_rowtable)
   {
     StageTimer t(c, ORBFE_STAGE_STEREO, st);
     launch_stereo(st, c->d_lv, c->cfg.n_levels, c->d_pyr, c->img_pitch, c->d_kps, c->d_desc, c->d_aux, c->d_kx, c->d_rowoff, c->d_rowlist,
                   c->cfg.height, c->row_list_cap, c->d_n_kp,
                   c->cfg.n_features, fx, bf,
                   c->cfg.width, kMeanThreshold, c->d_right_u, c->d_depth, c->d_n_match, c->d_best_right, c->d_best_dist, slot_l0,
-                  slot_r0, slot_step, pair0, n_pairs);
+                  slot_r0, slot_step, pair0, n_pairs, ho ? ho->right_u : nullptr, ho ? ho->depth : nullptr, ho ? ho->best_right : nullptr,
+                  ho ? ho->best_dist : nullptr);
   }
   HIP_TRY(c, hipGetLastError());
   return ORBFE_OK;
@@ -1110,6 +1121,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     if (const char* gr = getenv("ORBFE_GRAPHS")) c->use_graphs = atoi(gr) != 0;
     if (const char* hm = getenv("ORBFE_HOST_MIRROR")) c->host_mirror = atoi(hm) != 0;
     if (const char* hr = getenv("ORBFE_HOST_READ")) c->host_read = atoi(hr) != 0;
+    if (const char* fo = getenv("ORBFE_FUSE_ORIENT")) c->fuse_orient = atoi(fo) != 0;
     {
       const char* ps = getenv("ORBFE_PIPELINE_STEREO");
       c->pipeline_stereo = !ps || atoi(ps) != 0;
@@ -1592,8 +1604,29 @@ orbfe_status orbfe_stereo_match(orbfe_ctx* c, int32_t slot_left, int32_t slot_ri
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
   const int pair = slot_left / 2;
-  TRY(run_stereo(c, c->stream, slot_left, slot_right, 0, pair, 1, fx, bf));
-  return orbfe_fetch_stereo(c, pair, right_u, depth, n_matches, best_right, best_dist);
+  if (!c->host_mirror) {
+    TRY(run_stereo(c, c->stream, slot_left, slot_right, 0, pair, 1, fx, bf));
+    return orbfe_fetch_stereo(c, pair, right_u, depth, n_matches, best_right, best_dist);
+  }
+  // the kernel writes the requested arrays into the page-locked staging buffer itself; only the match count is copied (4 bytes)
+  const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
+  const size_t o_ru = 0, o_dp = align_up(NF * 8, 256), o_br = o_dp + align_up(NF * 8, 256), o_bd = o_br + align_up(NF * 4, 256),
+               o_nm = o_bd + align_up(NF * 4, 256), total = o_nm + 256;
+  TRY(ensure_stage(c, total));
+  uint8_t* h = c->main.h_stage;
+  const StereoHostOut ho = {right_u ? (double*)(h + o_ru) : nullptr, depth ? (double*)(h + o_dp) : nullptr,
+                            best_right ? (int32_t*)(h + o_br) : nullptr, best_dist ? (int32_t*)(h + o_bd) : nullptr};
+  TRY(run_stereo(c, c->stream, slot_left, slot_right, 0, pair, 1, fx, bf, &ho));
+  HIP_TRY(c, hipMemcpyAsync(h + o_nm, c->d_n_match + pair, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  const size_t n = (size_t)c->cfg.n_features;
+  if (right_u && n) std::memcpy(right_u, h + o_ru, sizeof(double) * n);
+  if (depth && n) std::memcpy(depth, h + o_dp, sizeof(double) * n);
+  if (best_right && n) std::memcpy(best_right, h + o_br, sizeof(int32_t) * n);
+  if (best_dist && n) std::memcpy(best_dist, h + o_bd, sizeof(int32_t) * n);
+  if (n_matches) std::memcpy(n_matches, h + o_nm, sizeof(int32_t));
+  return ORBFE_OK;
 }
 
 // Where the packed results of a batch go on the device (host-image stream), and the events around that copy.

@@ -63,6 +63,7 @@ KNOBS = [
     {"ORBFE_QT_LDS_NODES": "300"},        # node tables of the levels with quota > ~290 in GLOBAL memory (what nFeatures > ~12 000 uses)
     {"ORBFE_QT_LDS_NODES": "300", "ORBFE_QT_WAVES": "1", "ORBFE_QT_BATCH": "0"},
     {"ORBFE_LBA_HOST_LM": "1"},           # (no effect on this path; the switch must at least not break context creation)
+    {"ORBFE_FUSE_ORIENT": "0"},           # keypoint list / moments / orientation of a frame or two as three launches (default: one)
     {"ORBFE_HOST_READ": "1"},             # host-pointer / slot paths: the resize kernel reads the page-locked staging buffer (default: a host-to-device copy)
     {"ORBFE_HOST_READ": "1", "ORBFE_HOST_MIRROR": "0"},
     {"ORBFE_QT_GROUPS": "8"},             # one quadtree wave per level (default: the levels of an image dealt to 4 waves)
