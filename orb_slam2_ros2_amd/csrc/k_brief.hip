@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv,
 //    (the same loads, redundantly) and lane 15 of the row, which ends up with the sums, goes on to the orientation.  Same arithmetic,
 //    same results; a batch keeps the separate kernels (one lane per keypoint is the better shape for the fp64 trigonometry at scale).
 // ---------------------------------------------------------------------------------------------
+template <bool WITH_ORIENT>
 __global__ __launch_bounds__(256) void k_list_moments_orient(const LevelDev* __restrict__ lv, int n_levels, const uint32_t* __restrict__ sel,
                                                              const int32_t* __restrict__ sel_count, int n_features,
                                                              const uint8_t* __restrict__ pyr, size_t img_pitch, UmaxPacked umax,
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void k_list_moments_orient(const LevelDev* __r
       e.w = (uint32_t)L.stride;
     }
   }
-  if (k == 0 && sub == 15) {
+  if (WITH_ORIENT && k == 0 && sub == 15) {
     n_kp[img] = total;
     if (n_kp_host) n_kp_host[img] = total;
   }
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(256) void k_list_moments_orient(const LevelDev* __r
   kpl[o] = e;
   if (!valid) return;
   moments[o] = make_int2(m10, m01);
+  if (!WITH_ORIENT) return;  // (a batch: k_orient follows, one lane per keypoint)
   // the orientation (k_orient)
   const LevelDev& L = lv[level];
   const double theta = orbmath::det_atan2((double)m01, (double)m10);
@@ -494,13 +496,15 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
   for (int i = 0; i < 16; ++i) u |= (unsigned long long)(umax[i] & 15) << (4 * i);
   if (fuse_small && n_img <= 2) {  // list + moments + orientation in one launch (a frame or two: three launch floors of ~5 us become one)
     if (before_lists) (void)hipStreamWaitEvent(s, before_lists, 0);
-    hipLaunchKernelGGL(k_list_moments_orient, dim3((n_features + 15) / 16, n_img), dim3(256), 0, s, d_lv, n_levels, d_sel, d_sel_count, n_features,
+    hipLaunchKernelGGL(k_list_moments_orient<true>, dim3((n_features + 15) / 16, n_img), dim3(256), 0, s, d_lv, n_levels, d_sel, d_sel_count, n_features,
                        d_pyr, img_pitch, u, d_kpl, d_moments, d_sincos, d_kps, d_aux, d_kx, d_theta, rows0, d_n_kp, h_kps, h_n_kp);
     if (before_brief) (void)hipStreamWaitEvent(s, before_brief, 0);
     hipLaunchKernelGGL(k_brief, dim3((((n_features + BRIEF_WAVES * BRIEF_KPW - 1) / (BRIEF_WAVES * BRIEF_KPW)) + 7) & ~7, n_img), dim3(64 * BRIEF_WAVES), 0, s,
                        d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos, d_desc, h_desc);
     return;
   }
+  // (measured for batches and dropped: the list entry built inside the moments kernel, k_orient kept -- 5.550 / 5.543 ms per 512 pairs
+  //  without, 5.553 / 5.557 with: the list kernel's 0.12 ms hide nothing the moments do not already wait for)
   hipLaunchKernelGGL(k_kplist, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, n_levels, d_sel, d_sel_count, n_features,
                      d_kpl);
   hipLaunchKernelGGL(k_ic_moments, dim3((n_features + 15) / 16, n_img), dim3(256), 0, s, d_pyr, img_pitch, d_kpl, n_features, u,
