@@ -811,9 +811,9 @@ def main():
             # UnionNs / steps of profiles/*_kernel_stats.csv, tools/kernel_stats_from_db.py), not average x NLEVELS
             "kernel_launches_per_step": {"fast": NLEVELS, "orient_brief": 4, "resize": 1, "blur": 2, "quadtree": 1, "stereo": 2}[dom],
             "avg_launch_ms_alone": stages_inline[dom],
-            "rocprof_match": ("union of the k_fast launches of a step (UnionNs / steps in the newest profiles/r2_*_kernel_stats.csv); LIVE figure of the "
+            "rocprof_match": ("union of the k_fast launches of a step (UnionNs / steps in the newest profiles/r*_kernel_stats.csv); LIVE figure of the "
                               "production schedule: the level-0 blur runs beside FAST on the second stream (avg_launch_ms_alone: nothing beside it)")
-                             if dom == "fast" else "sum of the stage's kernels per step in the newest profiles/r2_*_kernel_stats.csv",
+                             if dom == "fast" else "sum of the stage's kernels per step in the newest profiles/r*_kernel_stats.csv",
             "all_stages": {k: {"ms": round(stages_inline[k], 4), "GBps": round(stage_bytes[k] / (stages_inline[k] * 1e-3) / 1e9, 1)}
                            for k in stages_inline if k in stage_bytes and stages_inline[k] > 0},
         },
