@@ -486,8 +486,11 @@ def latency_leg(device_id, n=500):
                                "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
         L.tofile(os.path.join(tmp, "L.raw"))
         R.tofile(os.path.join(tmp, "R.raw"))
+        # (the child gets the HIP runtime's default of 4 hardware queues, as a process that uses the C++ mirror has -- this bench raised
+        #  it to 16 for its own streams, which costs the one-frame-at-a-time path ~50 us: DESIGN 4.9 (h))
+        env = dict(os.environ, GPU_MAX_HW_QUEUES=os.environ.get("ORBFE_LATENCY_HW_QUEUES", "4"))
         r = subprocess.run([exe, "latency", os.path.join(tmp, "L.raw"), os.path.join(tmp, "R.raw"), str(W), str(H), str(n)],
-                           capture_output=True, text=True, timeout=300)
+                           capture_output=True, text=True, timeout=300, env=env)
         f = r.stdout.split()
         if r.returncode != 0 or not f or f[0] != "LATENCY_OK":
             raise RuntimeError((r.stdout + r.stderr)[-400:])
@@ -498,6 +501,7 @@ def latency_leg(device_id, n=500):
             "what": "ORB_SLAM2_ROS2::ORBExtractor x 2 on two std::threads (orbfe_extract_slot each, thread start / join included as in "
                     "Frame::Frame) + searchByStereo, C++ drop-in, host cv::Mat in, std::vector<cv::KeyPoint> / cv::Mat descriptors out"}
         out["same_objects_one_thread"] = {"median_ms": float(f[5]) / 1e3, "p99_ms": float(f[6]) / 1e3, "extract_median_ms": float(f[7]) / 1e3}
+        out["cpp_hw_queues"] = int(env["GPU_MAX_HW_QUEUES"])
     except (subprocess.CalledProcessError, RuntimeError, OSError) as ex:
         out["two_threads_extract_slot_plus_match"] = {"error": f"{type(ex).__name__}: {ex}"}
     return out

@@ -93,10 +93,8 @@ class ContextPool {
     // tag: contexts that differ in nothing else -- one per calling thread role (dropin::matcherContext / solverContext): a context
     // serves one call at a time, and the reference's matchers and optimisers run on three threads at once (System.cc:119-129)
     std::lock_guard<std::mutex> lk(mu());
-    // one hardware queue per HIP stream (the runtime's default of 4 makes uploads queue behind kernels, see INTEGRATION.md "Hardware
-    // queues"); read at the process's first HIP call, which in an ORB_SLAM2 process is the orbfe_create below.  An exported value wins.
-    static const int hwq = ::setenv("GPU_MAX_HW_QUEUES", "16", 0);
-    (void)hwq;
+    // (GPU_MAX_HW_QUEUES is left alone here: a process that builds one frame at a time -- this mirror's use -- is ~50 us per frame
+    //  FASTER with the runtime's default of 4 hardware queues; the batch / sequence streaming API wants 16: INTEGRATION.md 5a)
     Key key{w, h, nFeatures, nLevels, scale, maxTh, minTh, tplPath, device, maxImages, tag};
     auto it = pool().find(key);
     if (it != pool().end()) return it->second.get();
