@@ -405,6 +405,22 @@ def ba_leg(device_id):
                         "hbm_frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS if us else None,
                         "host_call": dict(_stats_ms(lambda: ctx.ba_eval_edges(**p), 30), what="host arrays in, 4.8 MB of results out over PCIe"),
                         "cpu_baseline": {"ms": _cpu_ms(lambda: orc.ba_eval_edges(**p)), "cores": 1, "kind": "port"}, "verified": True}
+    # ... and the same kernel at a size that fills the machine: the edge list tiled 64 times (the same poses and points; 61 workgroups of
+    # the config-5 problem occupy a quarter of the chip for two launch floors, which says nothing about the kernel's memory behaviour)
+    rep = 64
+    pl = dict(p)
+    for k in ("edge_pose", "edge_point", "meas", "is_stereo", "info", "huber_delta"):
+        pl[k] = np.ascontiguousarray(np.concatenate([p[k]] * rep))
+    rl = ctx.ba_eval_edges(**pl)
+    if abs(rl["chi2"].sum() - rep * g1["chi2_sum"]) > 1e-11 * rep * g1["chi2_sum"] or not np.array_equal(rl["chi2"][:E], r["chi2"]) or \
+            not np.array_equal(rl["chi2"][-E:], r["chi2"]):
+        raise SystemExit("bench.py: ba leg: the tiled edge evaluation differs from the golden vectors")
+    alg_l = 304 * E * rep + p["poses"].shape[0] * 56 + p["points"].shape[0] * 24
+    us_l = _kernel_us(ctx, "ba", lambda: ctx.ba_eval_edges(**pl), n=3)
+    out["edge_eval_tiled"] = {"edges": E * rep, "kernel_us": us_l, "algorithmic_bytes": alg_l, "GBps": alg_l / (us_l * 1e-6) / 1e9 if us_l else None,
+                              "hbm_frac": alg_l / (us_l * 1e-6) / 1e9 / HBM_PEAK_GBPS if us_l else None, "verified": True,
+                              "what": "the config-5 edge list 64 times over: the edge kernel with the chip full (SURVEY 8d: 304 B per edge)"}
+    del rl, pl
     # normal equations
     fx = np.zeros(p["poses"].shape[0], np.uint8)
     fx[0] = 1
