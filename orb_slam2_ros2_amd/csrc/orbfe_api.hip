@@ -2092,49 +2092,69 @@ orbfe_status orbfe_ba_build_system(orbfe_ctx* c, const orbfe_ba_problem* p, cons
     off += align_up(std::max<size_t>(bytes, 8), 256);
     return o2;
   };
+  // r3: the system is built by the kernels of the device-side Levenberg-Marquardt path (k_lm.hip: every edge linearised once, eight lanes
+  // per point, a workgroup per pose -- 22 us where round 1's three kernels, each recomputing every edge's Jacobians, took 171); inputs
+  // and lists go up as ONE block through the page-locked staging buffer, the blocks come back as one
   const size_t o_pose = take((size_t)NK * 56), o_pt = take((size_t)NP * 24), o_ep = take((size_t)E * 4), o_et = take((size_t)E * 4),
                o_meas = take((size_t)E * 24), o_st = take((size_t)E), o_info = take((size_t)E * 8), o_delta = take((size_t)E * 8),
                o_fix = take((size_t)NK), o_pto = take((size_t)(NP + 1) * 4), o_pte = take((size_t)E * 4), o_pso = take((size_t)(NK + 1) * 4),
-               o_pse = take((size_t)E * 4), o_hpp = take((size_t)NK * 288), o_bp = take((size_t)NK * 48), o_hll = take((size_t)NP * 72),
-               o_bl = take((size_t)NP * 24), o_hpl = take((size_t)E * 144);
+               o_pse = take((size_t)E * 4), o_state = take(sizeof(LmState)), o_level = take((size_t)E), o_up_end = take(8),
+               o_hpp = take((size_t)NK * 288), o_bp = take((size_t)NK * 48), o_hll = take((size_t)NP * 72),
+               o_bl = take((size_t)NP * 24), o_hpl = take((size_t)E * 144), o_out_end = take(8), o_terms = take((size_t)E * 256),
+               o_chi = take((size_t)((NP + 31) / 32) * 8);
   TRY(ensure_tmp(c, off));
+  TRY(ensure_stage(c, std::max(o_up_end, o_out_end - o_hpp)));
   uint8_t* b = (uint8_t*)c->d_tmp;
-  auto up = [&](size_t o2, const void* src, size_t bytes) -> hipError_t {
-    return bytes ? hipMemcpyAsync(b + o2, src, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+  uint8_t* hs = c->main.h_stage;
+  auto up = [&](size_t o2, const void* src, size_t bytes) {
+    if (bytes) std::memcpy(hs + o2, src, bytes);
   };
-  HIP_TRY(c, up(o_pose, p->poses, (size_t)NK * 56));
-  HIP_TRY(c, up(o_pt, p->points, (size_t)NP * 24));
-  HIP_TRY(c, up(o_ep, p->edge_pose, (size_t)E * 4));
-  HIP_TRY(c, up(o_et, p->edge_point, (size_t)E * 4));
-  HIP_TRY(c, up(o_meas, p->meas, (size_t)E * 24));
-  HIP_TRY(c, up(o_st, p->is_stereo, (size_t)E));
-  HIP_TRY(c, up(o_info, p->info, (size_t)E * 8));
-  HIP_TRY(c, up(o_delta, p->huber_delta, (size_t)E * 8));
-  if (pose_fixed) HIP_TRY(c, up(o_fix, pose_fixed, (size_t)NK));
-  HIP_TRY(c, up(o_pto, pt_off.data(), (size_t)(NP + 1) * 4));
-  HIP_TRY(c, up(o_pte, pt_edges.data(), (size_t)E * 4));
-  HIP_TRY(c, up(o_pso, ps_off.data(), (size_t)(NK + 1) * 4));
-  HIP_TRY(c, up(o_pse, ps_edges.data(), (size_t)E * 4));
+  up(o_pose, p->poses, (size_t)NK * 56);
+  up(o_pt, p->points, (size_t)NP * 24);
+  up(o_ep, p->edge_pose, (size_t)E * 4);
+  up(o_et, p->edge_point, (size_t)E * 4);
+  up(o_meas, p->meas, (size_t)E * 24);
+  up(o_st, p->is_stereo, (size_t)E);
+  up(o_info, p->info, (size_t)E * 8);
+  up(o_delta, p->huber_delta, (size_t)E * 8);
+  if (pose_fixed)
+    up(o_fix, pose_fixed, (size_t)NK);
+  else
+    std::memset(hs + o_fix, 0, (size_t)std::max(NK, 1));
+  up(o_pto, pt_off.data(), (size_t)(NP + 1) * 4);
+  up(o_pte, pt_edges.data(), (size_t)E * 4);
+  up(o_pso, ps_off.data(), (size_t)(NK + 1) * 4);
+  up(o_pse, ps_edges.data(), (size_t)E * 4);
+  std::memset(hs + o_state, 0, o_up_end - o_state);  // control state (buffer 0 current) and the edge levels (all active)
+  HIP_TRY(c, hipMemcpyAsync(b, hs, o_up_end, hipMemcpyHostToDevice, c->stream));
   BaParamsDev prm = {p->fx, p->fy, p->cx, p->cy, p->bf};
   {
+    LmLaunch L{};
+    L.NK = NK, L.NP = NP, L.E = E, L.nf = 0;
+    L.poses[0] = L.poses[1] = (double*)(b + o_pose), L.points[0] = L.points[1] = (double*)(b + o_pt);
+    L.terms[0] = L.terms[1] = (double*)(b + o_terms), L.Hpl[0] = L.Hpl[1] = (double*)(b + o_hpl);
+    L.Hpp[0] = L.Hpp[1] = (double*)(b + o_hpp), L.bp[0] = L.bp[1] = (double*)(b + o_bp);
+    L.Hll[0] = L.Hll[1] = (double*)(b + o_hll), L.bl[0] = L.bl[1] = (double*)(b + o_bl);
+    L.chi_part[0] = L.chi_part[1] = (double*)(b + o_chi);
+    L.state = (LmState*)(b + o_state);
+    L.edge_pose = (const int32_t*)(b + o_ep), L.edge_point = (const int32_t*)(b + o_et);
+    L.pt_off = (const int32_t*)(b + o_pto), L.pt_edges = (const int32_t*)(b + o_pte);
+    L.ps_off = (const int32_t*)(b + o_pso), L.ps_edges = (const int32_t*)(b + o_pse);
+    L.meas = (const double*)(b + o_meas), L.info = (const double*)(b + o_info), L.is_stereo = b + o_st, L.fixed = b + o_fix;
+    L.info_eff = (double*)(b + o_info), L.delta_eff = (double*)(b + o_delta), L.chi2_last = nullptr, L.level = b + o_level;
+    L.prm = prm;
     StageTimer tm(c, ORBFE_STAGE_BA, c->stream);
-    launch_ba_system(c->stream, NK, NP, E, (const double*)(b + o_pose), (const double*)(b + o_pt), (const int32_t*)(b + o_ep),
-                     (const int32_t*)(b + o_et), (const double*)(b + o_meas), b + o_st, (const double*)(b + o_info),
-                     (const double*)(b + o_delta), prm, pose_fixed ? b + o_fix : nullptr, (const int32_t*)(b + o_pto),
-                     (const int32_t*)(b + o_pte), (const int32_t*)(b + o_pso), (const int32_t*)(b + o_pse), (double*)(b + o_hpp),
-                     (double*)(b + o_bp), (double*)(b + o_hll), (double*)(b + o_bl), o->Hpl ? (double*)(b + o_hpl) : nullptr);
+    launch_lm_build(c->stream, L, 0, 0, 0, -1, true);
   }
   HIP_TRY(c, hipGetLastError());
-  auto down = [&](void* dst, size_t o2, size_t bytes) -> hipError_t {
-    return bytes ? hipMemcpyAsync(dst, b + o2, bytes, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
-  };
-  HIP_TRY(c, down(o->Hpp, o_hpp, (size_t)NK * 288));
-  HIP_TRY(c, down(o->bp, o_bp, (size_t)NK * 48));
-  HIP_TRY(c, down(o->Hll, o_hll, (size_t)NP * 72));
-  HIP_TRY(c, down(o->bl, o_bl, (size_t)NP * 24));
-  if (o->Hpl) HIP_TRY(c, down(o->Hpl, o_hpl, (size_t)E * 144));
+  HIP_TRY(c, hipMemcpyAsync(hs, b + o_hpp, (o->Hpl ? o_out_end : o_hpl) - o_hpp, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_timers(c);
+  std::memcpy(o->Hpp, hs, (size_t)NK * 288);
+  std::memcpy(o->bp, hs + (o_bp - o_hpp), (size_t)NK * 48);
+  std::memcpy(o->Hll, hs + (o_hll - o_hpp), (size_t)NP * 72);
+  std::memcpy(o->bl, hs + (o_bl - o_hpp), (size_t)NP * 24);
+  if (o->Hpl) std::memcpy(o->Hpl, hs + (o_hpl - o_hpp), (size_t)E * 144);
   return ORBFE_OK;
 }
 
