@@ -461,6 +461,7 @@ def ba_leg(device_id):
     if abs(n_good - g2["n_good"]) > 1 or not np.allclose(pose, g2["pose"], rtol=0, atol=1e-6):
         raise SystemExit("bench.py: ba leg: pose-only optimisation differs from the golden vectors")
     out["pose_only"] = dict(_stats_ms(lambda: ctx.pose_only_optimize(*a), 50), edges=int(len(pp["info"])),
+                            kernel_us=_kernel_us(ctx, "ba", lambda: ctx.pose_only_optimize(*a), n=20),
                             what="orbfe_pose_only_optimize: 4 x optimize(10) on one SE3 vertex, host arrays in and out",
                             cpu_baseline={"ms": _cpu_ms(lambda: orc.pose_only_optimize(*a)), "cores": 1, "kind": "port"}, verified=True)
     ctx.close()

@@ -24,6 +24,7 @@
 
 #include "orbfe_internal.h"
 #include "se3_dev.h"
+#include "wave_ops.h"
 
 namespace orbfe {
 
@@ -67,28 +68,8 @@ __device__ __forceinline__ bool lm_gate(const LmState* st, int gate) {
   return *p != 0;
 }
 
-// Sum over the 64 lanes in a FIXED tree (deterministic), the same value returned to every lane.  Data-parallel-primitive moves instead
-// of __shfl_xor: a shuffle of a double is two ds_bpermute_b32 through the LDS crossbar, and the block sums below reduce 36 / 42 values
-// per wave (~500 permutes); here a step is two full-rate register moves and an add.  Tree: an inclusive scan inside each row of 16
-// (row_shr 1, 2, 4, 8: lane 15 of a row = pairwise tree over its lanes), then (row 1 + row 0), (row 3 + row 2), and their sum in lane 63.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double lm_dpp_f64(double v) {
-  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, ROW_MASK, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, ROW_MASK, 0xf, false);
-  return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (unsigned long long)(uint32_t)lo));
-}
-__device__ __forceinline__ double wave_sum_fixed(double v) {
-  v += lm_dpp_f64<0x111, 0xf>(v);  // row_shr:1  (lanes without a source add the +0.0 of `old`)
-  v += lm_dpp_f64<0x112, 0xf>(v);  // row_shr:2
-  v += lm_dpp_f64<0x114, 0xf>(v);  // row_shr:4
-  v += lm_dpp_f64<0x118, 0xf>(v);  // row_shr:8
-  v += lm_dpp_f64<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3
-  v += lm_dpp_f64<0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3
-  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), 63);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
+// (fixed tree over the 64 lanes by data-parallel-primitive moves: wave_ops.h)
+__device__ __forceinline__ double wave_sum_fixed(double v) { return wave_sum_f64(v); }
 
 struct LmCtrlArgs {  // what the control step needs (k_lm_ctrl, or the tail of k_lm_linpoints)
   LmState* st;

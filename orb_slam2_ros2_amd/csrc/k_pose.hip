@@ -11,6 +11,9 @@
 
 #include "orbfe_internal.h"
 #include "se3_dev.h"
+#include "wave_ops.h"
+
+#include <cstdlib>
 
 namespace orbfe {
 
@@ -39,6 +42,49 @@ __device__ bool solve6(const double* A /*6x6 row-major*/, const double* b, doubl
     double s = y[i];
     for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k];
     x[i] = s / L[6 * i + i];
+  }
+  return true;
+}
+
+// (H + lambda I) x = b with H and b where they are (LDS), for the register-resident kernel, where this lane-0 solve and the pose update
+// behind it are the longest serial piece of a pass (9 k of its ~20 k cycles: ~33 fp64 divisions and square roots of ~100 dependent cycles
+// each): one reciprocal square root per pivot -- v_rsq_f64 and a third-order correction y0 (1 + e / 2 + 3 e^2 / 8), e = 1 - s y0^2, error
+// below double rounding -- L_ii = s y, and every division by L_ii a multiplication by y.
+__device__ __forceinline__ bool solve6_lambda(const double* H, double lambda, const double* b, double* x) {
+#pragma clang fp contract(off)
+  double L[36], inv[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      double s = (i == j) ? H[6 * i + j] + lambda : H[6 * i + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
+      if (i == j) {
+        if (!(s > 0) || !isfinite(s)) return false;
+        const double y0 = __builtin_amdgcn_rsq(s);
+        const double e = fma(-(s * y0), y0, 1.0);
+        const double y = fma(y0 * e, fma(0.375, e, 0.5), y0);
+        L[6 * i + i] = s * y;
+        inv[i] = y;
+      } else
+        L[6 * i + j] = s * inv[j];
+    }
+  }
+  double y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k];
+    y[i] = s * inv[i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double s = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k];
+    x[i] = s * inv[i];
   }
   return true;
 }
@@ -306,11 +352,340 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose_only(int n, const double*
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same optimisation with every edge in REGISTERS (r3): 512 threads, a thread owns up to POSE_EPT = 4 edges (n <= 2048: a frame has
+// at most nFeatures matched map points) -- map point, measurement, information, the last error, its flags -- for the whole call, so the
+// forty-odd passes over the edges touch no memory; the 27 sums of the normal equations are reduced together (a fixed tree per wave by
+// data-parallel-primitive moves, ONE barrier, the wave partials added in wave order) where the version above runs 27 block reductions of
+// two barriers each; and an iteration that follows an ACCEPTED trial does not evaluate the errors again (g2o does, and gets the numbers
+// the trial just produced: same pose, same arithmetic).
+// The loop is written as ONE state machine with a single evaluation site, a single build site and a single solve site: unrolled over
+// the register-resident edges and with fp64 divisions expanded, the straightforward nesting (evaluation inlined at three places) came to
+// 12 000 instructions = 96 KB of code, more than the 64 KB instruction cache two compute units share, and the kernel ran at the speed of
+// instruction fetch (10 us per iteration whatever the arithmetic did).  Thresholds, decisions and their order are those of the kernel above.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define POSE_EPT 4
+#define POSE_RT 512
+#ifdef POSE_STAMPS  // diagnostic build only (tools/exp/pose_bench.hip): cycles per section of the state machine, wave 0
+__device__ long long g_pose_stamps[8];
+#define PS_BEGIN long long ps_t_ = __builtin_amdgcn_s_memtime();
+#define PS(k)                                                  \
+  {                                                            \
+    const long long now_ = __builtin_amdgcn_s_memtime();       \
+    if (tid == 0) g_pose_stamps[k] += now_ - ps_t_;            \
+    ps_t_ = now_;                                              \
+  }
+#define PS_COUNT(k) \
+  if (tid == 0) g_pose_stamps[k] += 1;
+#else
+#define PS_BEGIN
+#define PS(k)
+#define PS_COUNT(k)
+#endif
+template <int NT>
+struct PoseSharedR {
+  PoseDev T, T0, backup;
+  double H[36], b[6], x[6];
+  double red[28][NT / 64];
+  double lambda, ni, current_chi, rho;
+  int qmax, cont_inner, stop_outer, accepted, n_bad;
+};
+template <int NT>
+__global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __restrict__ Xw, const double* __restrict__ meas,
+                                                           const double* __restrict__ info, const float* __restrict__ sigma2,
+                                                           const double* __restrict__ pose_in, BaParamsDev prm, double d_mono,
+                                                           double d_stereo, uint8_t* __restrict__ inlier_out,
+                                                           double* __restrict__ pose_out, int32_t* __restrict__ n_good) {
+#pragma clang fp contract(off)
+  __shared__ PoseSharedR<NT> S;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double X[POSE_EPT][3], M[POSE_EPT][3], W[POSE_EPT], E[POSE_EPT][3], TH[POSE_EPT];
+  bool have[POSE_EPT], st[POSE_EPT], lvl0[POSE_EPT], rob[POSE_EPT], inl[POSE_EPT];
+#pragma unroll
+  for (int u = 0; u < POSE_EPT; ++u) {
+    const int i = tid + u * NT;
+    have[u] = i < n;
+    const int ii = have[u] ? i : 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) X[u][k] = (n > 0) ? Xw[3 * ii + k] : 0.0, M[u][k] = (n > 0) ? meas[3 * ii + k] : 0.0;
+    W[u] = (n > 0) ? info[ii] : 0.0;
+    st[u] = !(M[u][2] < 0);
+    TH[u] = (st[u] ? 7.815 : 5.991) * (double)((n > 0) ? sigma2[ii] : 0.f);
+    lvl0[u] = have[u], rob[u] = true, inl[u] = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) E[u][k] = 0.0;
+  }
+  if (tid == 0) {
+    for (int i = 0; i < 4; ++i) S.T0.q[i] = pose_in[i];
+    for (int i = 0; i < 3; ++i) S.T0.t[i] = pose_in[4 + i];
+    S.T = S.T0;
+  }
+  __syncthreads();
+
+  auto edge_error = [&](int u, const PoseDev& T, double* e) {
+    double p[3];
+    quat_rotate(T.q, X[u], p);
+    const double x = p[0] + T.t[0], y = p[1] + T.t[1], z = p[2] + T.t[2];
+    const double uu = x / z * prm.fx + prm.cx, v = y / z * prm.fy + prm.cy;
+    e[0] = M[u][0] - uu;
+    e[1] = M[u][1] - v;
+    e[2] = (M[u][2] < 0) ? 0.0 : M[u][2] - (uu - prm.bf / z);
+  };
+  auto edge_chi2 = [&](int u, const double* e) {
+    double c = e[0] * (W[u] * e[0]) + e[1] * (W[u] * e[1]);
+    if (st[u]) c += e[2] * (W[u] * e[2]);
+    return c;
+  };
+  // sum over the workgroup of one value, result in every thread: wave tree, one partial per wave, waves added in order
+  auto block_sum1 = [&](double v) {
+    const double w = wave_sum_f64(v);
+    if (lane == 0) S.red[27][wv] = w;
+    __syncthreads();
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) s += S.red[27][k];
+    __syncthreads();
+    return s;
+  };
+
+  // edge->computeError() at construction (Optimizer.cc:90,111) -- (with the state machine below this is the only other use of edge_error
+  // besides the evaluation site and the re-classification)
+  {
+    const PoseDev T = S.T0;
+#pragma unroll
+    for (int u = 0; u < POSE_EPT; ++u)
+      if (have[u]) edge_error(u, T, E[u]);
+  }
+
+  for (int round = 0; round < 4; ++round) {
+    if (tid == 0) {
+      S.T = S.T0;  // every round restarts from the initial pose (Optimizer.cc:127)
+      S.n_bad = 0;
+    }
+    bool mine = false;
+#pragma unroll
+    for (int u = 0; u < POSE_EPT; ++u) mine = mine || lvl0[u];
+    const int any_active = __syncthreads_or(mine ? 1 : 0);
+    if (any_active) {
+      // ---- SparseOptimizer::optimize(10) with OptimizationAlgorithmLevenberg, as a state machine ----
+      int it = 0;            // iterations completed
+      bool do_solve = false; // the pass starts with a trial step (solve, oplus) and its evaluation decides that trial
+      double chi_cur = 0;
+      PS_BEGIN
+      for (;;) {
+        PS(0)
+        if (do_solve) {
+          if (tid == 0) {
+            S.backup = S.T;
+            double xs[6] = {0, 0, 0, 0, 0, 0};
+            S.cont_inner = solve6_lambda(S.H, S.lambda, S.b, xs) ? 1 : 0;  // ok2
+            for (int j = 0; j < 6; ++j) S.x[j] = xs[j];
+            PoseDev Tn;
+            pose_oplus(S.T, xs, Tn);
+            S.T = Tn;
+          }
+          __syncthreads();
+        }
+        PS(1)  // solve + oplus
+        PS_COUNT(6)
+        // computeActiveErrors + activeRobustChi2 at S.T -- the ONE evaluation site
+        double chi;
+        {
+          const PoseDev T = S.T;
+          double part = 0;
+#pragma unroll
+          for (int u = 0; u < POSE_EPT; ++u) {
+            if (!lvl0[u]) continue;
+            edge_error(u, T, E[u]);
+            const double c = edge_chi2(u, E[u]);
+            if (rob[u]) {
+              const double dl = st[u] ? d_stereo : d_mono;
+              const double dsqr = dl * dl;
+              part += (c <= dsqr) ? c : (2 * sqrt(c) * dl - dsqr);
+            } else
+              part += c;
+          }
+          chi = block_sum1(part);
+        }
+        PS(2)  // evaluation
+        if (!do_solve) {
+          chi_cur = chi;  // the errors of the current estimate: an iteration starts
+        } else {
+          if (tid == 0) {  // decide the trial
+            double temp_chi = S.cont_inner ? chi : 1.7976931348623157e308;
+            double rho = S.current_chi - temp_chi;
+            double scale = 0;
+            for (int j = 0; j < 6; ++j) scale += S.x[j] * (S.lambda * S.x[j] + S.b[j]);
+            scale += 1e-3;
+            rho /= scale;
+            bool finite_lambda = true;
+            S.accepted = 0;
+            if (rho > 0 && isfinite(temp_chi)) {
+              double alpha = 1. - pow((2 * rho - 1), 3);
+              alpha = fmin(alpha, 2. / 3.);
+              S.lambda *= fmax(1. / 3., alpha);
+              S.ni = 2;
+              S.current_chi = temp_chi;
+              S.accepted = 1;
+            } else {
+              S.lambda *= S.ni;
+              S.ni *= 2;
+              S.T = S.backup;
+              finite_lambda = isfinite(S.lambda);
+            }
+            S.rho = rho;
+            S.qmax += 1;
+            S.cont_inner = (finite_lambda && rho < 0 && S.qmax < 10) ? 1 : 0;
+            if (!S.cont_inner) S.stop_outer = (S.qmax == 10 || rho == 0 || !isfinite(S.lambda)) ? 1 : 0;
+          }
+          __syncthreads();
+          if (S.cont_inner) continue;  // another trial of the same iteration (new lambda, the same system)
+          if (S.stop_outer) break;
+          if (++it == 10) break;
+          if (!S.accepted) {  // (a trial neither accepted nor retried, e.g. a NaN gain ratio: the next iteration re-evaluates at the restored pose)
+            do_solve = false;
+            continue;
+          }
+          chi_cur = chi;  // accepted: these ARE the errors and the chi2 of the new current estimate
+        }
+        PS(3)  // decision
+        PS_COUNT(7)
+        // linearizeOplus + constructQuadraticForm of every active edge at S.T (errors of the last evaluation) -- the ONE build site
+        {
+          const PoseDev T = S.T;
+          double acc[27];
+#pragma unroll
+          for (int k = 0; k < 27; ++k) acc[k] = 0;
+#pragma unroll
+          for (int u = 0; u < POSE_EPT; ++u) {
+            if (!lvl0[u]) continue;
+            double p[3];
+            quat_rotate(T.q, X[u], p);
+            const double x = p[0] + T.t[0], y = p[1] + T.t[1], z = p[2] + T.t[2];
+            const double invz = 1.0 / z, invz_2 = invz * invz;
+            const bool s3 = st[u];
+            double J[3][6];
+            J[0][0] = x * y * invz_2 * prm.fx;
+            J[0][1] = -(1 + (x * x * invz_2)) * prm.fx;
+            J[0][2] = y * invz * prm.fx;
+            J[0][3] = -invz * prm.fx;
+            J[0][4] = 0;
+            J[0][5] = x * invz_2 * prm.fx;
+            J[1][0] = (1 + y * y * invz_2) * prm.fy;
+            J[1][1] = -x * y * invz_2 * prm.fy;
+            J[1][2] = -x * invz * prm.fy;
+            J[1][3] = 0;
+            J[1][4] = -invz * prm.fy;
+            J[1][5] = y * invz_2 * prm.fy;
+            J[2][0] = s3 ? J[0][0] - prm.bf * y * invz_2 : 0.0;
+            J[2][1] = s3 ? J[0][1] + prm.bf * x * invz_2 : 0.0;
+            J[2][2] = s3 ? J[0][2] : 0.0;
+            J[2][3] = s3 ? J[0][3] : 0.0;
+            J[2][4] = 0;
+            J[2][5] = s3 ? J[0][5] - prm.bf * invz_2 : 0.0;
+            const double e[3] = {E[u][0], E[u][1], s3 ? E[u][2] : 0.0};
+            const double w = W[u];
+            double r1 = 1.0;
+            if (rob[u]) {
+              const double c = edge_chi2(u, e);
+              const double dl = s3 ? d_stereo : d_mono;
+              if (c > dl * dl) r1 = dl / sqrt(c);
+            }
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+              acc[21 + a] -= r1 * (J[0][a] * (w * e[0]) + J[1][a] * (w * e[1]) + J[2][a] * (w * e[2]));
+#pragma unroll
+              for (int c2 = a; c2 < 6; ++c2) acc[k++] += J[0][a] * (r1 * w) * J[0][c2] + J[1][a] * (r1 * w) * J[1][c2] + J[2][a] * (r1 * w) * J[2][c2];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 27; ++k) {
+            const double w = wave_sum_f64(acc[k]);
+            if (lane == 0) S.red[k][wv] = w;
+          }
+          __syncthreads();
+          if (tid < 27) {
+            double sm = 0;
+#pragma unroll
+            for (int k = 0; k < NT / 64; ++k) sm += S.red[tid][k];
+            if (tid >= 21) {
+              S.b[tid - 21] = sm;
+            } else {  // tid -> (a, c2), a <= c2, in the order the sums were laid out
+              int a = 0, rem = tid;
+              while (rem >= 6 - a) rem -= 6 - a, ++a;
+              const int c2 = a + rem;
+              S.H[6 * a + c2] = sm;
+              S.H[6 * c2 + a] = sm;
+            }
+          }
+          __syncthreads();
+        }
+        PS(4)  // build
+        if (tid == 0) {
+          S.current_chi = chi_cur;
+          if (it == 0) {
+            double md = 0;
+            for (int j = 0; j < 6; ++j) md = fmax(fabs(S.H[7 * j]), md);
+            S.lambda = 1e-5 * md;
+            S.ni = 2;
+          }
+          S.rho = 0;
+          S.qmax = 0;
+          S.stop_outer = 0;
+        }
+        __syncthreads();
+        do_solve = true;
+      }
+    }
+    // ---- re-classification (Optimizer.cc:132-177): mono edges, then stereo edges; counts only ----
+    {
+      const PoseDev T = S.T;
+      int bad = 0;
+#pragma unroll
+      for (int u = 0; u < POSE_EPT; ++u) {
+        if (!have[u]) continue;
+        if (!inl[u]) edge_error(u, T, E[u]);
+        const double c = edge_chi2(u, E[u]);
+        if (c > TH[u]) {
+          inl[u] = false;
+          lvl0[u] = false;
+          ++bad;
+        } else {
+          inl[u] = true;
+          lvl0[u] = true;
+        }
+        if (round == 2) rob[u] = false;
+      }
+      const double tb = block_sum1((double)bad);
+      if (tid == 0) S.n_bad = (int)tb;
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < POSE_EPT; ++u)
+    if (have[u]) inlier_out[tid + u * NT] = inl[u] ? 1 : 0;
+  if (tid == 0) {
+    for (int i = 0; i < 4; ++i) pose_out[i] = S.T.q[i];
+    for (int i = 0; i < 3; ++i) pose_out[4 + i] = S.T.t[i];
+    *n_good = n - S.n_bad;
+  }
+}
+
 void launch_pose_only(hipStream_t s, int n, const double* Xw, const double* meas, const double* info, const float* sigma2,
                       const double* pose_in, BaParamsDev prm, double d_mono, double d_stereo, double* err, uint8_t* level,
                       uint8_t* robust, uint8_t* inlier, double* pose_out, int32_t* n_good) {
-  hipLaunchKernelGGL(k_pose_only, dim3(1), dim3(POSE_THREADS), 0, s, n, Xw, meas, info, sigma2, pose_in, prm, d_mono, d_stereo, err,
-                     level, robust, inlier, pose_out, n_good);
+  static const bool mem_version = [] { const char* v = getenv("ORBFE_POSE_IN_MEMORY"); return v && atoi(v) != 0; }();
+  // 256 threads up to 1024 edges (one wave per SIMD: the 27 wave reductions of a build are issued once per SIMD, not twice), 512 up to 2048
+  if (n <= 256 * POSE_EPT && !mem_version)
+    hipLaunchKernelGGL(k_pose_only_reg<256>, dim3(1), dim3(256), 0, s, n, Xw, meas, info, sigma2, pose_in, prm, d_mono, d_stereo, inlier, pose_out,
+                       n_good);
+  else if (n <= POSE_RT * POSE_EPT && !mem_version)
+    hipLaunchKernelGGL(k_pose_only_reg<POSE_RT>, dim3(1), dim3(POSE_RT), 0, s, n, Xw, meas, info, sigma2, pose_in, prm, d_mono, d_stereo, inlier, pose_out,
+                       n_good);
+  else
+    hipLaunchKernelGGL(k_pose_only, dim3(1), dim3(POSE_THREADS), 0, s, n, Xw, meas, info, sigma2, pose_in, prm, d_mono, d_stereo, err,
+                       level, robust, inlier, pose_out, n_good);
 }
 
 }  // namespace orbfe

@@ -2746,17 +2746,22 @@ orbfe_status orbfe_pose_only_optimize(orbfe_ctx* c, int32_t n, const double* xw,
     off += align_up(std::max<size_t>(bytes, 8), 256);
     return o2;
   };
-  const size_t o_x = take(N * 24), o_m = take(N * 24), o_i = take(N * 8), o_s = take(N * 4), o_p = take(56), o_e = take(N * 24),
-               o_l = take(N), o_r = take(N), o_in = take(N), o_po = take(56), o_ng = take(8);
+  // inputs as ONE upload through the page-locked staging buffer, results as one download (five copies from pageable memory up and three down
+  // were a fifth of the call)
+  const size_t o_x = take(N * 24), o_m = take(N * 24), o_i = take(N * 8), o_s = take(N * 4), o_p = take(56), o_up_end = take(8),
+               o_po = take(56), o_ng = take(8), o_in = take(N), o_out_end = take(8), o_e = take(N * 24), o_l = take(N), o_r = take(N);
   TRY(ensure_tmp(c, off));
+  TRY(ensure_stage(c, std::max(o_up_end, o_out_end - o_po)));
   uint8_t* b = (uint8_t*)c->d_tmp;
+  uint8_t* hs = c->main.h_stage;
   if (n) {
-    HIP_TRY(c, hipMemcpyAsync(b + o_x, xw, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(b + o_m, meas, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(b + o_i, info, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(b + o_s, sigma2, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    std::memcpy(hs + o_x, xw, (size_t)n * 24);
+    std::memcpy(hs + o_m, meas, (size_t)n * 24);
+    std::memcpy(hs + o_i, info, (size_t)n * 8);
+    std::memcpy(hs + o_s, sigma2, (size_t)n * 4);
   }
-  HIP_TRY(c, hipMemcpyAsync(b + o_p, pose_in, 56, hipMemcpyHostToDevice, c->stream));
+  std::memcpy(hs + o_p, pose_in, 56);
+  HIP_TRY(c, hipMemcpyAsync(b, hs, o_up_end, hipMemcpyHostToDevice, c->stream));
   BaParamsDev prm = {fx, fy, cx, cy, bf};
   {
     StageTimer tm(c, ORBFE_STAGE_BA, c->stream);
@@ -2765,11 +2770,12 @@ orbfe_status orbfe_pose_only_optimize(orbfe_ctx* c, int32_t n, const double* xw,
                      b + o_l, b + o_r, b + o_in, (double*)(b + o_po), (int32_t*)(b + o_ng));
   }
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(pose_out, b + o_po, 56, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(n_good, b + o_ng, 4, hipMemcpyDeviceToHost, c->stream));
-  if (inlier_out && n) HIP_TRY(c, hipMemcpyAsync(inlier_out, b + o_in, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(hs, b + o_po, (inlier_out && n ? o_in + (size_t)n : o_in) - o_po, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_timers(c);
+  std::memcpy(pose_out, hs, 56);
+  std::memcpy(n_good, hs + (o_ng - o_po), 4);
+  if (inlier_out && n) std::memcpy(inlier_out, hs + (o_in - o_po), (size_t)n);
   return ORBFE_OK;
 }
 

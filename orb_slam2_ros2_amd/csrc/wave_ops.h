@@ -69,4 +69,27 @@ __device__ __forceinline__ int wave_reduce_dpp(int v) {
   return __builtin_amdgcn_readlane(wave_incl_scan_dpp<Op>(v), 63);
 }
 
+// Sum of a double over the 64 lanes in a FIXED tree (deterministic), the same value returned to every lane.  Data-parallel-primitive moves
+// instead of __shfl_xor: a shuffle of a double is two ds_bpermute_b32 through the LDS crossbar; here a step is two full-rate register moves and
+// an add.  Tree: an inclusive scan inside each row of 16 (row_shr 1, 2, 4, 8: lane 15 of a row = pairwise tree over its lanes), then
+// (row 1 + row 0), (row 3 + row 2), and their sum in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (unsigned long long)(uint32_t)lo));
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_f64<ORBFE_DPP_ROW_SHR(1), 0xf>(v);  // (lanes without a source add the +0.0 of `old`)
+  v += dpp_f64<ORBFE_DPP_ROW_SHR(2), 0xf>(v);
+  v += dpp_f64<ORBFE_DPP_ROW_SHR(4), 0xf>(v);
+  v += dpp_f64<ORBFE_DPP_ROW_SHR(8), 0xf>(v);
+  v += dpp_f64<ORBFE_DPP_ROW_BCAST15, 0xa>(v);
+  v += dpp_f64<ORBFE_DPP_ROW_BCAST31, 0xc>(v);
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), 63);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 }  // namespace orbfe

@@ -37,7 +37,7 @@ def test_oracle_mono_only_and_degenerate_inputs(orc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,n", [(7, 1000), (8, 2000), (9, 257), (10, 40)])
+@pytest.mark.parametrize("seed,n", [(7, 1000), (8, 2000), (9, 257), (10, 40), (12, 1024), (13, 1025), (14, 2048), (15, 2500)])   # 256- / 512-thread register kernels, the in-memory one past 2048
 def test_device_optimiser_matches_oracle(orc, seed, n):
     from orb_slam2_ros2_amd._lib import Context
     from orb_slam2_ros2_amd import Optimizer
