@@ -2025,18 +2025,36 @@ orbfe_status orbfe_ba_eval_edges(orbfe_ctx* c, const orbfe_ba_problem* p, const 
   };
   const size_t o_pose = take((size_t)p->n_poses * 56), o_pt = take((size_t)p->n_points * 24), o_ep = take((size_t)E * 4),
                o_et = take((size_t)E * 4), o_meas = take((size_t)E * 24), o_st = take((size_t)E), o_info = take((size_t)E * 8),
-               o_delta = take((size_t)E * 8), o_err = take((size_t)E * 24), o_chi = take((size_t)E * 8), o_rho = take((size_t)E * 16),
-               o_jpt = take((size_t)E * 72), o_jps = take((size_t)E * 144), o_dp = take((size_t)E);
+               o_delta = take((size_t)E * 8), o_up_end = take(8), o_err = take((size_t)E * 24), o_chi = take((size_t)E * 8),
+               o_rho = take((size_t)E * 16), o_dp = take((size_t)E), o_jpt = take((size_t)E * 72), o_jps = take((size_t)E * 144), o_out_end = take(8);
   TRY(ensure_tmp(c, off));
   uint8_t* b = (uint8_t*)c->d_tmp;
-  HIP_TRY(c, hipMemcpyAsync(b + o_pose, p->poses, (size_t)p->n_poses * 56, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_pt, p->points, (size_t)p->n_points * 24, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_ep, p->edge_pose, (size_t)E * 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_et, p->edge_point, (size_t)E * 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_meas, p->meas, (size_t)E * 24, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_st, p->is_stereo, (size_t)E, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_info, p->info, (size_t)E * 8, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_delta, p->huber_delta, (size_t)E * 8, hipMemcpyHostToDevice, c->stream));
+  // up to 16 MB in all: inputs as ONE upload through the page-locked staging buffer and the results as one download (eight copies from
+  // and six to pageable memory otherwise -- each staged by the runtime on its own)
+  const size_t out_last = o->j_pose ? o_out_end : (o->j_point ? o_jps : o_jpt);
+  const bool staged = o_up_end + (out_last - o_err) <= ((size_t)16 << 20);
+  uint8_t* hs = nullptr;
+  if (staged) {
+    TRY(ensure_stage(c, std::max(o_up_end, out_last - o_err)));
+    hs = c->main.h_stage;
+  }
+  auto up = [&](size_t o2, const void* src, size_t bytes) -> hipError_t {
+    if (!bytes) return hipSuccess;
+    if (staged) {
+      std::memcpy(hs + o2, src, bytes);
+      return hipSuccess;
+    }
+    return hipMemcpyAsync(b + o2, src, bytes, hipMemcpyHostToDevice, c->stream);
+  };
+  HIP_TRY(c, up(o_pose, p->poses, (size_t)p->n_poses * 56));
+  HIP_TRY(c, up(o_pt, p->points, (size_t)p->n_points * 24));
+  HIP_TRY(c, up(o_ep, p->edge_pose, (size_t)E * 4));
+  HIP_TRY(c, up(o_et, p->edge_point, (size_t)E * 4));
+  HIP_TRY(c, up(o_meas, p->meas, (size_t)E * 24));
+  HIP_TRY(c, up(o_st, p->is_stereo, (size_t)E));
+  HIP_TRY(c, up(o_info, p->info, (size_t)E * 8));
+  HIP_TRY(c, up(o_delta, p->huber_delta, (size_t)E * 8));
+  if (staged) HIP_TRY(c, hipMemcpyAsync(b, hs, o_up_end, hipMemcpyHostToDevice, c->stream));
   BaParamsDev prm = {p->fx, p->fy, p->cx, p->cy, p->bf};
   {
     StageTimer tm(c, ORBFE_STAGE_BA, c->stream);
@@ -2047,6 +2065,18 @@ orbfe_status orbfe_ba_eval_edges(orbfe_ctx* c, const orbfe_ba_problem* p, const 
                     o->depth_positive ? b + o_dp : nullptr);
   }
   HIP_TRY(c, hipGetLastError());
+  if (staged) {
+    HIP_TRY(c, hipMemcpyAsync(hs, b + o_err, out_last - o_err, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drain_timers(c);
+    std::memcpy(o->error, hs, (size_t)E * 24);
+    std::memcpy(o->chi2, hs + (o_chi - o_err), (size_t)E * 8);
+    std::memcpy(o->rho, hs + (o_rho - o_err), (size_t)E * 16);
+    if (o->depth_positive) std::memcpy(o->depth_positive, hs + (o_dp - o_err), (size_t)E);
+    if (o->j_point) std::memcpy(o->j_point, hs + (o_jpt - o_err), (size_t)E * 72);
+    if (o->j_pose) std::memcpy(o->j_pose, hs + (o_jps - o_err), (size_t)E * 144);
+    return ORBFE_OK;
+  }
   HIP_TRY(c, hipMemcpyAsync(o->error, b + o_err, (size_t)E * 24, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(o->chi2, b + o_chi, (size_t)E * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(o->rho, b + o_rho, (size_t)E * 16, hipMemcpyDeviceToHost, c->stream));
