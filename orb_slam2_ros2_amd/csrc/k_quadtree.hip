@@ -234,6 +234,24 @@ __device__ __forceinline__ void qt_wsync() {
 // reference has no limit on nFeatures, ORBExtractor.cc:291-301).  The records are global then too (IN_LDS = false), so every step
 // already ends in the wait that orders a wave's global stores before its next loads; the pre-partition (whose tables borrow the LDS
 // node arrays) is off and the strips are counted with ballots.  Slow (a pop is a chain of global round trips) but exact.
+#ifdef QT_STAMPS  // diagnostic build only: timeline of one level-0 tree (device printf), see tools/exp/qt_stamps.sh
+__device__ int g_qt_stamp_count;
+#define QTS_DECL long long qts_t0 = __builtin_amdgcn_s_memtime(), qts_last = qts_t0; int qts_n = 0; long long qts_d[48]; int qts_i[48];
+#define QTS(info) { const long long now_ = __builtin_amdgcn_s_memtime(); if (qts_n < 48) { qts_d[qts_n] = now_ - qts_last; qts_i[qts_n] = (info); ++qts_n; } qts_last = now_; }
+#define QTS_PRINT                                                                                                                   \
+  if (w0 && lane == 0 && need > 400) {                                                                                              \
+    const int c_ = atomicAdd(&g_qt_stamp_count, 1);                                                                                 \
+    if (c_ == 5) {                                                                                                                  \
+      printf("QT tree N %d need %d n_act %d\n", N, need, n_act);                                                                   \
+      for (int k_ = 0; k_ < qts_n; ++k_)                                                                                            \
+        printf("  %2d: %7lld cycles  info %d (pops %d nmax %d pp %d)\n", k_, qts_d[k_], qts_i[k_], qts_i[k_] >> 16, (qts_i[k_] >> 8) & 255, qts_i[k_] & 255); \
+    }                                                                                                                               \
+  }
+#else
+#define QTS_DECL
+#define QTS(info)
+#define QTS_PRINT
+#endif
 template <bool IN_LDS, int NW, bool NODES_LDS = true>
 __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __restrict__ A, int N, uint32_t* H, uint32_t* __restrict__ T,
                                           double* n_rb, double* n_re, double* n_cb, double* n_ce, unsigned long long* n_key,
@@ -243,6 +261,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
   constexpr int NT = 64 * NW;
   const int tid = wv * 64 + lane;
   const bool w0 = wv == 0;
+  QTS_DECL
   int n_act = 0;
   uint32_t next_seq = 0;
   // ---- first pop: the root, whose children are the initSplit strips (ORBExtractor.cc:81-96, 147-170) ----
@@ -482,6 +501,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
   // A lone wave pays tens of cycles for every taken branch (nothing hides the instruction fetch), so the step is
   // written as straight-line predicated code: fixed 8-way unrolled arg-max, uniform-address LDS traffic executed by
   // all lanes instead of "if (lane == 0)" blocks, the four children written by lanes 0..3 at once.
+  QTS(-1)  // build (pre-partition) done
   const long long max_iter = 80ll * (long long)N + 1024;  // each point survives < ~64 halvings (fp64); hard stop for safety
   long long iter = 0;
   while (n_act < need && n_act > 0 && iter < max_iter) {
@@ -684,6 +704,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
           next_seq += (uint32_t)(grow + v);
           if (n_act + 3 > pp_limit) pp_ok = false;  // the table has reached the totals parked in its tail
           if (!IN_LDS) qt_wsync<NW>();
+          QTS((v << 16) | (nmax << 8) | (int)__popcll(__ballot(act && is_pp)))
           continue;
         }
       }
@@ -852,6 +873,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
   }
   __syncthreads();
 
+  QTS(-2)  // expansion done (single pops included in the last interval)
   // ---- nodes2kpoints (ORBExtractor.cc:182-192): keep the first min(need, size) nodes in map order ----
   while (n_act > need) {
     // drop the last node in map order = arg-min of the key
@@ -924,13 +946,44 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
 #pragma unroll
       for (int r = 0; r < 8; ++r) key[r] = (r * 64 < sort_cap) ? node_key(r * 64 + lane) : ~0ull;
     } else {
-      // all waves scan nodes (one node per thread per trip); the keys meet in LDS (the fp64 bound arrays are dead), wave 0 sorts them
+      // all waves scan nodes (one node per thread per trip); the keys meet in LDS (the fp64 bound arrays are dead) and every thread
+      // RANKS its own keys by counting the smaller ones -- the keys are read back with wave-uniform addresses (one LDS read serves
+      // the wave), they are distinct (the order key is the candidate's position), so the ranks are the sorted positions and the
+      // keypoints go straight to their output slots.  (Wave 0 alone sorting the keys in registers, 36 cross-lane exchange stages
+      // of eight keys, was a quarter of the 98 us of a level-0 tree: stamps build, tools/exp/qt_stamps.sh.)
       __syncthreads();
-      for (int j = tid; j < sort_cap; j += NT) sortbuf[j] = node_key(j);
-      __syncthreads();
-      if (!w0) return;
+      unsigned long long mine[(512 + NT - 1) / NT];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) key[r] = (r * 64 < sort_cap) ? sortbuf[r * 64 + lane] : ~0ull;
+      for (int u = 0; u < (512 + NT - 1) / NT; ++u) {
+        const int j = tid + u * NT;
+        mine[u] = (j < sort_cap) ? node_key(j) : ~0ull;
+        if (j < sort_cap) sortbuf[j] = mine[u];
+      }
+      __syncthreads();
+      int rank[(512 + NT - 1) / NT];
+#pragma unroll
+      for (int u = 0; u < (512 + NT - 1) / NT; ++u) rank[u] = 0;
+      for (int i = 0; i < n_act; i += 4) {
+        unsigned long long o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = sortbuf[min(i + q, n_act - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < (512 + NT - 1) / NT; ++u) rank[u] += (i + q < n_act && o[q] < mine[u]) ? 1 : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < (512 + NT - 1) / NT; ++u) {
+        const int j = tid + u * NT;
+        if (j < n_act) {
+          const uint32_t y = (uint32_t)(mine[u] >> 20) & 0xFFFu, x = (uint32_t)(mine[u] >> 8) & 0xFFFu, rr = (uint32_t)mine[u] & 0xFFu;  // key = order<<8 | r
+          out_sel[rank[u]] = ORBFE_PACK_XYR(x, y, rr);
+        }
+      }
+      QTS(-4)
+      QTS_PRINT
+      if (w0 && lane == 0) *sel_count_out = n_act;
+      return;
     }
     for (int k = 2; k <= sort_cap; k <<= 1) {
       for (int st = k >> 1; st > 0; st >>= 1) {
@@ -1001,6 +1054,8 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     }
   }
   if (w0 && lane == 0) *sel_count_out = n_act;
+  QTS(-3)
+  QTS_PRINT
 }
 
 
