@@ -334,6 +334,11 @@ void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, co
   if (n_img <= 0) return;
   // a frame or two (the drop-in path): the whole sweep fits the machine at once, and eight back-to-back launches would each
   // cost a full wave lifetime (~18 us): one launch with the common carve-up instead (0.144 -> 0.03 ms for one stereo pair)
+  // (Built, parity-tested and dropped in r3 for this launch: four waves per cell, each a BAND of the cell's rows with one halo row on
+  //  each side and the cell-wide high / low verdict through LDS.  A band wave lives 2.6 us instead of ~18, but with one list
+  //  reservation per band the kernel took 98 us instead of 21 -- 4264 atomics on the two level-0 counters at ~45 ns each -- and with
+  //  sixteen-wave workgroups of four cells x four bands and ONE reservation per workgroup 24.8 us: three barriers, a serial prefix
+  //  and the atomic's round trip per workgroup cost what the shorter waves save.)
   int total_cells = 0, max_pw = 0, max_ph = 0;
   for (int l = 0; l < n_levels; ++l) {
     total_cells += h_lv[l].n_cells;
