@@ -56,24 +56,18 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   v += dpp_u32<0x143, 0xc>(0u, v);
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
-// max over the lanes BELOW this one (0 for lane 0)
+// max over the lanes BELOW this one (0 for lane 0; the values are >= 0).  Scans by data-parallel-primitive moves (wave_ops.h): the
+// __shfl_up versions were six / seven dependent ds_bpermute round trips each, ~1.5 k cycles per batched step and 11 k in the
+// sixteen-row prefix of the pre-partition (stamps build, tools/exp/qt_stamps.sh).
 __device__ __forceinline__ int wave_excl_max(int v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(v, o);
-    if (lane >= o) v = max(v, t);
-  }
-  const int prev = __shfl_up(v, 1);
+  const int incl = wave_incl_scan_dpp<OpMaxI>(v);
+  const int prev = __builtin_amdgcn_update_dpp(0, incl, 0x138, 0xf, 0xf, true);  // wave_shr:1 (lane 0 reads 0)
   return lane > 0 ? prev : 0;
 }
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int t = __shfl_up(v, o);
-    if (lane >= o) v += t;
-  }
-  return v;
+  (void)lane;
+  return wave_incl_scan_dpp<OpAddI>(v);
 }
 
 // Integer form of the strict fp64 membership test: coordinates are integers, so  x < mid  <=>  x <= ceil(mid) - 1  and
