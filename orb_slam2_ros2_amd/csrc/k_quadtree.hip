@@ -27,6 +27,9 @@
 #include "orbfe_internal.h"
 #include "wave_ops.h"
 
+#include <cmath>
+#include <vector>
+
 namespace orbfe {
 
 #define QT_INPLACE_CHUNKS 4  // nodes up to QT_INPLACE_CHUNKS*64 records are partitioned in registers
@@ -141,7 +144,7 @@ __device__ __forceinline__ int strip_of(uint32_t rec, const LevelDev& L) {
 struct Thr {
   int lt, gt;  // v <= lt: first half, v >= gt: second half, else on the line
 };
-__device__ __forceinline__ Thr make_thr(double mid) {
+__host__ __device__ __forceinline__ Thr make_thr(double mid) {
   Thr t;
   t.lt = (int)ceil(mid) - 1;
   t.gt = (int)floor(mid) + 1;
@@ -149,7 +152,7 @@ __device__ __forceinline__ Thr make_thr(double mid) {
 }
 // the fifteen midpoints of four halvings of (lo, hi): index 0 | 1 + b1 | 3 + 2 b1 + b2 | 7 + 4 b1 + 2 b2 + b3   (same fp64 operations
 // as the pop loop)
-__device__ __forceinline__ void thr15(double lo, double hi, Thr* out) {
+__host__ __device__ __forceinline__ void thr15(double lo, double hi, Thr* out) {
   const double m1 = (lo + hi) / 2;
   out[0] = make_thr(m1);
 #pragma unroll
@@ -170,7 +173,7 @@ __device__ __forceinline__ void thr15(double lo, double hi, Thr* out) {
     }
   }
 }
-__device__ __forceinline__ int half_of(int v, const Thr& t) { return v <= t.lt ? 0 : (v >= t.gt ? 1 : -1); }
+__host__ __device__ __forceinline__ int half_of(int v, const Thr& t) { return v <= t.lt ? 0 : (v >= t.gt ? 1 : -1); }
 
 struct PpGeom {
   int ns, y_max;
@@ -181,16 +184,16 @@ struct PpGeom {
 // hundred entries) and a record costs two independent LDS reads plus a dozen integer operations instead of ~90 with four
 // dependent threshold reads.  Code (16 bits): bit 15 = inside, bits 12-13 = strip (x table only), bits 4-6 = number of levels the
 // coordinate passes without sitting on a split line (0..4), bits 0-3 = the halves taken (level 1 in bit 3).
-__device__ __forceinline__ uint32_t pp_axis_code(int v, const Thr* t /*[15]*/) {
+__host__ __device__ __forceinline__ uint32_t pp_axis_code(int v, const Thr* t /*[15]*/) {
   const int b1 = half_of(v, t[0]);
-  const int c1 = max(b1, 0);
+  const int c1 = b1 > 0 ? b1 : 0;
   const int b2 = half_of(v, t[1 + c1]);
-  const int c2 = max(b2, 0);
+  const int c2 = b2 > 0 ? b2 : 0;
   const int b3 = half_of(v, t[3 + 2 * c1 + c2]);
-  const int c3 = max(b3, 0);
+  const int c3 = b3 > 0 ? b3 : 0;
   const int b4 = half_of(v, t[7 + 4 * c1 + 2 * c2 + c3]);
   const int nv = b1 < 0 ? 0 : (b2 < 0 ? 1 : (b3 < 0 ? 2 : (b4 < 0 ? 3 : 4)));
-  return (uint32_t)(nv << 4) | (uint32_t)(c1 << 3) | (uint32_t)(c2 << 2) | (uint32_t)(c3 << 1) | (uint32_t)max(b4, 0);
+  return (uint32_t)(nv << 4) | (uint32_t)(c1 << 3) | (uint32_t)(c2 << 2) | (uint32_t)(c3 << 1) | (uint32_t)(b4 > 0 ? b4 : 0);
 }
 __device__ __forceinline__ int pp_group_tab(uint32_t x, uint32_t y, const uint16_t* xtab, const uint16_t* ytab) {
   const uint32_t cx = xtab[x], cy = ytab[y];
@@ -251,7 +254,8 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
                                           double* n_rb, double* n_re, double* n_cb, double* n_ce, unsigned long long* n_key,
                                           uint32_t* n_beg, unsigned long long* sortbuf, unsigned long long* bkey, uint32_t* bj,
                                           uint32_t* shared_ints, int batch_on, int node_cap, int need,
-                                          int sort_cap, uint32_t* __restrict__ out_sel, int32_t* __restrict__ sel_count_out, int lane, int wv) {
+                                          int sort_cap, uint32_t* __restrict__ out_sel, int32_t* __restrict__ sel_count_out, int lane, int wv,
+                                          const uint16_t* __restrict__ qt_tabs, uint16_t* tot4_lds = nullptr) {
   constexpr int NT = 64 * NW;
   const int tid = wv * 64 + lane;
   const bool w0 = wv == 0;
@@ -264,46 +268,32 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
   uint16_t* tot = (uint16_t*)(n_rb + node_cap) - n_tot;      // the totals of levels 1-3 live in the tail of the (still empty) node table ...
   const int pp_limit = node_cap - (n_tot * 2 + 7) / 8;       // ... and are abandoned when the table grows into them
   const int n4_off = (N + 3) & ~3;                           // the fourth level's totals: global, behind the records of the bounce buffer
-  uint16_t* tot4 = (uint16_t*)(T + n4_off);
+  // (tot4_lds: launches of a frame or two have the LDS to spare -- three of a level-0 tree's seven batched steps read these totals, and
+  //  from global memory each read was a ~3 k-cycle round trip on the critical path)
+  uint16_t* tot4 = tot4_lds ? tot4_lds : (uint16_t*)(T + n4_off);
   // coordinate -> code tables (uint16) in the n_key array, cursors across n_cb | n_ce, x thresholds in n_re: the node table is not in use yet
   const int tab_w = (int)ceil(L.strips[ns]) + 1, tab_h = (int)ceil((double)L.reg_h) + 1;
   const int tab_w2 = (tab_w + 1) & ~1;
   bool pp_ok = NODES_LDS && N > 0 && N <= 65535 && ns <= QT_PP_MAX_STRIPS && node_cap >= 176 && tab_w <= 4096 && tab_h <= 4096 &&
                (tab_w2 + tab_h) * 2 <= node_cap * 8 && ns * QT_PP_GROUPS * 4 <= node_cap * 16 && ns * 15 * 8 <= node_cap * 8 &&
-               n4_off + ns * (QT_PP_TOTALS4 / 2) <= (int)L.cand_cap;
+               (tot4_lds != nullptr || n4_off + ns * (QT_PP_TOTALS4 / 2) <= (int)L.cand_cap);
   if (pp_ok) {
     const int ng = ns * QT_PP_GROUPS;
-    Thr* xt = (Thr*)n_re;             // x thresholds of every strip
     uint32_t* cur = (uint32_t*)n_cb;  // group sizes, then group cursors (runs on into n_ce)
     uint16_t* xtab = (uint16_t*)n_key;
     uint16_t* ytab = xtab + tab_w2;
     for (int g = tid; g < ng; g += NT) cur[g] = 0;
-    for (int x = tid; x < tab_w; x += NT) xtab[x] = 0;  // columns on a strip boundary or outside the region: bit 15 clear
-    PpGeom G;
-    G.ns = ns;
-    G.y_max = (int)ceil((double)L.reg_h) - 1;  // y > 0 && y < reg_h
-    Thr yt[15];
-    thr15(0.0, (double)L.reg_h, yt);
-#pragma unroll
-    for (int k = 0; k < QT_PP_MAX_STRIPS; ++k) {
-      const double lo = L.strips[k < ns ? k : 0], hi = L.strips[k < ns ? k + 1 : 1];
-      G.s_lo[k] = (int)floor(lo) + 1;  // x > lo
-      G.s_hi[k] = (int)ceil(hi) - 1;   // x < hi
-      if (tid == k && k < ns) thr15(lo, hi, xt + 15 * k);
+    // The coordinate -> code tables depend on the LEVEL's geometry alone (strip bounds, region height): the host builds them once per
+    // context (quadtree_build_tables, the same fp64 operations) and a tree only copies its level's ~3 KB into LDS.  Built here, per tree,
+    // they were 24 k of a level-0 tree's 224 k cycles with four waves (stamps build) -- and every tree wave of a batch paid them alone.
+    {
+      const uint32_t* src = (const uint32_t*)(qt_tabs + L.qt_tab_off);  // [tab_w2 | tab_h] uint16, 4-byte aligned
+      uint32_t* dst = (uint32_t*)xtab;
+      const int n32 = (tab_w2 + tab_h + 1) >> 1;
+      for (int i = tid; i < n32; i += NT) dst[i] = src[i];
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < QT_PP_MAX_STRIPS; ++k) {  // strip by strip: its fifteen thresholds are wave-uniform (no dependent reads per entry)
-      if (k < ns) {
-        Thr t[15];
-#pragma unroll
-        for (int q = 0; q < 15; ++q) t[q] = xt[15 * k + q];
-        for (int x = max(G.s_lo[k], 0) + tid; x <= G.s_hi[k] && x < tab_w; x += NT)
-          xtab[x] = (uint16_t)(0x8000u | ((uint32_t)k << 12) | pp_axis_code(x, t));
-      }
-    }
-    for (int y = tid; y < tab_h; y += NT) ytab[y] = (uint16_t)(((y >= 1 && y <= G.y_max) ? 0x8000u : 0u) | pp_axis_code(y, yt));
-    __syncthreads();
+    QTS(-10)  // tables
     auto group_of = [&](uint32_t r) -> int {
       // (candidates lie inside the region; the clamp only guards the table)
       return pp_group_tab(min(ORBFE_REC_X(r), (uint32_t)tab_w - 1u), min(ORBFE_REC_Y(r), (uint32_t)tab_h - 1u), xtab, ytab);
@@ -337,6 +327,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       }
     }
     __syncthreads();
+    QTS(-11)  // pass 1
     // totals of the 84 + 256 nodes below every strip, then sizes -> cursors (exclusive prefix in layout order)
     for (int t = tid; t < ns * QT_PP_TOTALS; t += NT) {
       const int st = t / QT_PP_TOTALS, k = t - QT_PP_TOTALS * st;
@@ -358,6 +349,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       tot4[t] = (uint16_t)cur[st * QT_PP_GROUPS + (m >> 6) * 85 + ((m >> 4) & 3) * 21 + ((m >> 2) & 3) * 5 + (m & 3)];
     }
     __syncthreads();
+    QTS(-12)  // totals
     int carry = 0, strip_base = 0, strip_cnt = 0;  // lane st keeps the segment of strip st
     for (int g0 = 0; w0 && g0 < ng; g0 += 64) {     // (one wave: a scan of ~22 rows of 64 group sizes)
       const int g = g0 + lane;
@@ -381,6 +373,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     }
     strip_cnt -= strip_base;
     __syncthreads();
+    QTS(-13)  // scan
     // pass 2: scatter
     {
       uint32_t nxt[16];
@@ -899,6 +892,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     __syncthreads();
     n_act = (int)shared_ints[0];
   }
+  QTS(-20)  // drop loop + rejoin
 
   // per node: first maximum response (ORBExtractor.cc:103-117).  Sort key = candidate order recomputed from the coordinates:
   // (cell row, cell col, y, x), then the response.  One lane per node, eight records requested per trip (with the records in
@@ -954,6 +948,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         if (j < sort_cap) sortbuf[j] = mine[u];
       }
       __syncthreads();
+      QTS(-21)  // node keys
       int rank[(512 + NT - 1) / NT];
 #pragma unroll
       for (int u = 0; u < (512 + NT - 1) / NT; ++u) rank[u] = 0;
@@ -1059,7 +1054,8 @@ __global__ __launch_bounds__(64 * NW) void k_quadtree(const LevelDev* __restrict
                                                  size_t scratch_pitch,
                                                  uint32_t* __restrict__ sel, int32_t* __restrict__ sel_count, int n_features,
                                                  const int32_t* __restrict__ n_cand, int node_cap, int sort_cap, int rec_cap, int batch,
-                                                 QtGroups groups, uint8_t* __restrict__ big_base, size_t big_pitch) {
+                                                 QtGroups groups, uint8_t* __restrict__ big_base, size_t big_pitch,
+                                                 const uint16_t* __restrict__ qt_tabs) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int img = blockIdx.y;
@@ -1081,6 +1077,8 @@ __global__ __launch_bounds__(64 * NW) void k_quadtree(const LevelDev* __restrict
   uint32_t* bj = (uint32_t*)(bkey + 64);
   uint32_t* shared_ints = bj + 64;  // [4]: what wave 0 tells the helper waves of a tree
   uint32_t* lds_recs = shared_ints + 4;
+  // several waves per tree (launches of a frame or two): the level-4 totals of the pre-partition behind the record cache
+  uint16_t* tot4_lds = NW > 1 ? (uint16_t*)(lds_recs + ((rec_cap + 3) & ~3)) : nullptr;
   unsigned long long* sortbuf = (unsigned long long*)lds;
 
   uint32_t* out_sel = sel + (size_t)img * n_features + L.quota_off;
@@ -1133,18 +1131,42 @@ __global__ __launch_bounds__(64 * NW) void k_quadtree(const LevelDev* __restrict
     uint32_t* g_beg = (uint32_t*)(g_key + cap);
     unsigned long long* g_sort = (unsigned long long*)(g_beg + ((cap + 1) & ~(size_t)1));
     tree_body<false, NW, false>(L, A, N, gb, gc, g_rb, g_re, g_cb, g_ce, g_key, g_beg, g_sort, bkey, bj, shared_ints, batch, (int)cap, need,
-                                L.qt_big_sort, out_sel, sel_count + (size_t)img * n_levels + level, lane, wv);
+                                L.qt_big_sort, out_sel, sel_count + (size_t)img * n_levels + level, lane, wv, qt_tabs);
   } else if (in_lds)
     tree_body<true, NW>(L, A, N, lds_recs, gb, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, bkey, bj, shared_ints, batch, node_cap, need, sort_cap,
-                        out_sel, sel_count + (size_t)img * n_levels + level, lane, wv);
+                        out_sel, sel_count + (size_t)img * n_levels + level, lane, wv, qt_tabs, tot4_lds);
   else
     tree_body<false, NW>(L, A, N, gb, gc, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, bkey, bj, shared_ints, batch, node_cap, need, sort_cap,
-                         out_sel, sel_count + (size_t)img * n_levels + level, lane, wv);
+                         out_sel, sel_count + (size_t)img * n_levels + level, lane, wv, qt_tabs, tot4_lds);
   // the next tree reuses the LDS: the accesses of one wave execute in order, the fence only pins the compiler
   if (NW > 1) __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   }
+}
+
+// The pre-partition's coordinate -> code tables of one level (tree_body): x table [tab_w2] then y table [tab_h], uint16 codes as
+// described at pp_axis_code.  Host side, once per context; returns false when the level's geometry rules the pre-partition out.
+bool quadtree_build_tables(const LevelDev& L, std::vector<uint16_t>& out) {
+  const int ns = L.n_ini;
+  out.clear();
+  if (ns < 1 || ns > QT_PP_MAX_STRIPS) return false;
+  const int tab_w = (int)std::ceil(L.strips[ns]) + 1, tab_h = (int)std::ceil((double)L.reg_h) + 1;
+  if (tab_w > 4096 || tab_h > 4096 || tab_w < 1 || tab_h < 1) return false;
+  const int tab_w2 = (tab_w + 1) & ~1;
+  out.assign((size_t)tab_w2 + tab_h + 1, 0);
+  const int y_max = (int)std::ceil((double)L.reg_h) - 1;  // y > 0 && y < reg_h
+  Thr yt[15];
+  thr15(0.0, (double)L.reg_h, yt);
+  for (int k = 0; k < ns; ++k) {
+    const double lo = L.strips[k], hi = L.strips[k + 1];
+    const int s_lo = (int)std::floor(lo) + 1, s_hi = (int)std::ceil(hi) - 1;  // x > lo, x < hi
+    Thr t[15];
+    thr15(lo, hi, t);
+    for (int x = std::max(s_lo, 0); x <= s_hi && x < tab_w; ++x) out[x] = (uint16_t)(0x8000u | ((uint32_t)k << 12) | pp_axis_code(x, t));
+  }
+  for (int y = 0; y < tab_h; ++y) out[tab_w2 + y] = (uint16_t)(((y >= 1 && y <= y_max) ? 0x8000u : 0u) | pp_axis_code(y, yt));
+  return true;
 }
 
 size_t quadtree_lds_bytes(int node_cap, int rec_cap) {
@@ -1172,15 +1194,16 @@ hipError_t quadtree_configure(size_t lds_bytes) {
 
 void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint32_t* d_cand, uint32_t* d_scr_b, uint32_t* d_scr_c,
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
-                     int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree, uint8_t* d_big, size_t big_pitch) {
+                     int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree, uint8_t* d_big, size_t big_pitch,
+                     const uint16_t* d_qt_tabs) {
   if (n_img <= 0) return;
   const size_t lds = quadtree_lds_bytes(node_cap, rec_cap);
   if (waves_per_tree >= 4)
-    hipLaunchKernelGGL(k_quadtree<4>, dim3(n_groups, n_img), dim3(256), lds, s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
-                       d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch);
+    hipLaunchKernelGGL(k_quadtree<4>, dim3(n_groups, n_img), dim3(256), lds + 16 + QT_PP_MAX_STRIPS * QT_PP_TOTALS4 * sizeof(uint16_t), s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
+                       d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch, d_qt_tabs);
   else
     hipLaunchKernelGGL(k_quadtree<1>, dim3(n_groups, n_img), dim3(64), lds, s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
-                       d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch);
+                       d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch, d_qt_tabs);
 }
 
 }  // namespace orbfe

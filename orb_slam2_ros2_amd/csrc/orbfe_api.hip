@@ -41,7 +41,9 @@ size_t quadtree_lds_bytes(int node_cap, int rec_cap);
 hipError_t quadtree_configure(size_t lds_bytes);
 void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint32_t* d_cand, uint32_t* d_scr_b, uint32_t* d_scr_c,
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
-                     int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree, uint8_t* d_big, size_t big_pitch);
+                     int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree, uint8_t* d_big, size_t big_pitch,
+                     const uint16_t* d_qt_tabs);
+bool quadtree_build_tables(const LevelDev& L, std::vector<uint16_t>& out);
 // k_brief.hip
 void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
@@ -233,6 +235,8 @@ struct orbfe_ctx {
   int8_t* d_pattern = nullptr;
   uint8_t *d_pyr = nullptr, *d_blur = nullptr;
   uint32_t *d_scr_a = nullptr, *d_scr_b = nullptr, *d_scr_c = nullptr;  // candidate lists | quadtree home / bounce buffers
+  uint16_t* d_qt_tabs = nullptr;  // per level: the quadtree pre-partition's coordinate -> code tables (LevelDev::qt_tab_off)
+  std::vector<uint16_t> qt_tabs;
   uint8_t* d_qt_big = nullptr;  // node tables + sort buffers of the levels whose quota does not fit one CU's LDS (qt_big_pitch bytes per image)
   size_t qt_big_pitch = 0;
   uint32_t* d_sel = nullptr;
@@ -674,6 +678,18 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
     big_off += align_up((size_t)cap_l * 44 + 8 + (size_t)sl * 8, 256);
   }
   c->qt_big_pitch = big_off;
+  // the pre-partition's coordinate -> code tables, per level (k_quadtree.hip, quadtree_build_tables)
+  c->qt_tabs.clear();
+  for (int l = 0; l < nl; ++l) {
+    std::vector<uint16_t> t;
+    c->lv[l].qt_tab_off = 0;
+    if (quadtree_build_tables(c->lv[l], t)) {
+      if (c->qt_tabs.size() & 1) c->qt_tabs.push_back(0);  // (4-byte aligned tables)
+      c->lv[l].qt_tab_off = (uint32_t)c->qt_tabs.size();
+      c->qt_tabs.insert(c->qt_tabs.end(), t.begin(), t.end());
+    }
+  }
+  if (c->qt_tabs.size() < 2) c->qt_tabs.resize(2, 0);
   c->node_cap = std::min(lds_nodes, max_lds_quota + max_ini + 8);
   c->node_cap = std::max(c->node_cap, 192);  // (the pre-partition borrows the node arrays for its tables)
   int sc = 2;
@@ -940,7 +956,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
                     c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img, c->qt_batch, grouped ? c->qt_groups : c->qt_single, n_groups,
                     // helper waves for the data-parallel phases of a tree where the launch leaves the chip empty (a frame or two)
                     (!grouped && trees * 4 <= c->n_cu * 4 && c->qt_waves > 1) ? 4 : 1, c->d_qt_big ? c->d_qt_big + i0 * c->qt_big_pitch : nullptr,
-                    c->qt_big_pitch);
+                    c->qt_big_pitch, c->d_qt_tabs);
   }
   {
     StageTimer t(c, ORBFE_STAGE_BRIEF, st, timing);
@@ -1006,7 +1022,7 @@ void orbfe_destroy(orbfe_ctx* c) {
   void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_rs_tiles, c->d_pattern, c->d_pyr,     c->d_blur,
                   c->d_scr_a, c->d_scr_c,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_kp,
                   c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos, c->d_kx, c->d_kpl,   c->d_right_u, c->d_depth, c->d_n_match,
-                  c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist, c->d_rs_regions, c->d_rg_xtaps, c->d_rg_ytaps, c->d_qt_big};
+                  c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist, c->d_rs_regions, c->d_rg_xtaps, c->d_rg_ytaps, c->d_qt_big, c->d_qt_tabs};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -1171,6 +1187,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   ALLOC(c->d_scr_b, M * c->scratch_pitch);
   ALLOC(c->d_scr_c, M * c->scratch_pitch);
   if (c->qt_big_pitch) ALLOC(c->d_qt_big, M * c->qt_big_pitch);
+  ALLOC(c->d_qt_tabs, c->qt_tabs.size());
   ALLOC(c->d_sel, M * NF);
   ALLOC(c->d_sel_count, M * NL);
   ALLOC(c->d_n_cand, M * NL);
@@ -1209,6 +1226,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   c->cfg.brief_pairs = nullptr;  // not retained
   if (e == hipSuccess) e = hipMemcpy(c->d_lv, c->lv.data(), sizeof(LevelDev) * NL, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(c->d_cells, c->cells.data(), sizeof(CellDev) * c->cells.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(c->d_qt_tabs, c->qt_tabs.data(), sizeof(uint16_t) * c->qt_tabs.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess && !c->taps.empty()) e = hipMemcpy(c->d_taps, c->taps.data(), sizeof(ResizeTap) * c->taps.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess && !c->rs_tile_tab.empty())
     e = hipMemcpy(c->d_rs_tiles, c->rs_tile_tab.data(), sizeof(RsTile) * c->rs_tile_tab.size(), hipMemcpyHostToDevice);
@@ -1230,7 +1248,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     fail(c, ORBFE_EDEVICE, "device initialisation failed: %s", hipGetErrorString(e));
     return bail(ORBFE_EDEVICE);
   }
-  e = quadtree_configure(quadtree_lds_bytes(c->node_cap, c->rec_cap));
+  e = quadtree_configure(quadtree_lds_bytes(c->node_cap, c->rec_cap) + 4096);  // (+ the level-4 totals of the several-waves-per-tree launches)
   if (e != hipSuccess) {
     fail(c, ORBFE_EDEVICE, "cannot reserve %zu B of LDS for the quadtree kernel: %s", quadtree_lds_bytes(c->node_cap, c->rec_cap),
          hipGetErrorString(e));

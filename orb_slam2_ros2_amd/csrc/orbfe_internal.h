@@ -90,6 +90,7 @@ struct LevelDev {
   // qt_big_cap > 0 nodes at byte offset qt_big_off of the image's block of the context's d_qt_big buffer, qt_big_sort keys to sort
   uint32_t qt_big_off;
   int32_t qt_big_cap, qt_big_sort;
+  uint32_t qt_tab_off;   // this level's coordinate -> code tables in the context's d_qt_tabs (uint16 units, even)
   double strips[ORBFE_MAX_STRIPS + 1];
   // resize tap tables (levels >= 1): offsets into the context's tap array
   uint32_t xtab_off, ytab_off;
