@@ -351,25 +351,45 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     __syncthreads();
     QTS(-12)  // totals
     int carry = 0, strip_base = 0, strip_cnt = 0;  // lane st keeps the segment of strip st
-    for (int g0 = 0; w0 && g0 < ng; g0 += 64) {     // (one wave: a scan of ~22 rows of 64 group sizes)
-      const int g = g0 + lane;
-      const int v = (g < ng) ? (int)cur[g] : 0;
-      const int incl = wave_incl_scan(v, lane);
-      const int excl = carry + incl - v;
-      qt_wsync<NW>();
-      if (g < ng) cur[g] = (uint32_t)excl;
-      for (int st = 0; st < ns; ++st) {  // strip st starts at group 341 st and ends where strip st + 1 starts
-        const int first = st * QT_PP_GROUPS, last = first + QT_PP_GROUPS - 1;
-        if (first >= g0 && first < g0 + 64) {
-          const int b = __builtin_amdgcn_readlane(excl, first - g0);
-          if (lane == st) strip_base = b;
-        }
-        if (last >= g0 && last < g0 + 64) {
-          const int e = __builtin_amdgcn_readlane(excl + v, last - g0);
-          if (lane == st) strip_cnt = e;
+    if (w0) {
+      // one wave: an exclusive scan over the <= 22 rows of 64 group sizes.  All rows are read first, scanned in registers (the row
+      // scans are independent: only the carry is a chain, and it is scalar) and written back at the end -- row by row with a
+      // synchronisation between a row's read and its write this was 19 k of a level-0 tree's cycles.
+      constexpr int ROWS = (QT_PP_MAX_STRIPS * QT_PP_GROUPS + 63) / 64;
+      int vals[ROWS];
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        const int g = r * 64 + lane;
+        vals[r] = (r * 64 < ng && g < ng) ? (int)cur[g] : 0;
+      }
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        const int g0 = r * 64;
+        if (g0 < ng) {  // wave-uniform
+          const int v = vals[r];
+          const int incl = wave_incl_scan(v, lane);
+          const int excl = carry + incl - v;
+          for (int st = 0; st < ns; ++st) {  // strip st starts at group 341 st and ends where strip st + 1 starts
+            const int first = st * QT_PP_GROUPS, last = first + QT_PP_GROUPS - 1;
+            if (first >= g0 && first < g0 + 64) {
+              const int bb = __builtin_amdgcn_readlane(excl, first - g0);
+              if (lane == st) strip_base = bb;
+            }
+            if (last >= g0 && last < g0 + 64) {
+              const int ee = __builtin_amdgcn_readlane(excl + v, last - g0);
+              if (lane == st) strip_cnt = ee;
+            }
+          }
+          carry += __builtin_amdgcn_readlane(incl, 63);
+          vals[r] = excl;
         }
       }
-      carry += __builtin_amdgcn_readlane(incl, 63);
+      qt_wsync<NW>();
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        const int g = r * 64 + lane;
+        if (r * 64 < ng && g < ng) cur[g] = (uint32_t)vals[r];
+      }
     }
     strip_cnt -= strip_base;
     __syncthreads();
@@ -952,14 +972,17 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       int rank[(512 + NT - 1) / NT];
 #pragma unroll
       for (int u = 0; u < (512 + NT - 1) / NT; ++u) rank[u] = 0;
-      for (int i = 0; i < n_act; i += 4) {
-        unsigned long long o[4];
+      // (sixteen keys per trip, all requested before the first is compared: with four the loop ran at the LDS latency, 385 cycles a trip.
+      //  The slots past n_act hold ~0: they never count.)
+      for (int i = 0; i < sort_cap; i += 16) {
+        if (i >= n_act) break;  // wave-uniform
+        unsigned long long o[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = sortbuf[min(i + q, n_act - 1)];
+        for (int q = 0; q < 16; ++q) o[q] = (i + q < sort_cap) ? sortbuf[i + q] : ~0ull;  // (sort_cap is a power of two, possibly < 16)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 16; ++q)
 #pragma unroll
-          for (int u = 0; u < (512 + NT - 1) / NT; ++u) rank[u] += (i + q < n_act && o[q] < mine[u]) ? 1 : 0;
+          for (int u = 0; u < (512 + NT - 1) / NT; ++u) rank[u] += (o[q] < mine[u]) ? 1 : 0;
       }
 #pragma unroll
       for (int u = 0; u < (512 + NT - 1) / NT; ++u) {
