@@ -104,6 +104,16 @@ __device__ __forceinline__ unsigned long long order_key(uint32_t rec, const Leve
   return ((unsigned long long)(uint32_t)mad24u((int)idx, L.n_cols, (int)jdx) << 24) | ((unsigned long long)y << 12) | (unsigned long long)x;
 }
 
+// the same order in 32 bits: cell << 14 | row inside the cell << 7 | column inside the cell (cells are at most 74 pixels wide and
+// high -- the largest patch the context accepts is 80 -- and a level has < 2^18 of them).  64-bit integer compares are quarter-rate.
+__device__ __forceinline__ uint32_t order_key32(uint32_t rec, const LevelDev& L) {
+  const uint32_t x = ORBFE_REC_X(rec), y = ORBFE_REC_Y(rec);
+  const uint32_t jdx = min((uint32_t)mul24u((int)(x - 3u), (int)L.inv_w_cell) >> 20, (uint32_t)L.n_cols - 1u);
+  const uint32_t idx = min((uint32_t)mul24u((int)(y - 3u), (int)L.inv_h_cell) >> 20, (uint32_t)L.n_rows - 1u);
+  const uint32_t dy = y - 3u - (uint32_t)mul24u((int)idx, L.h_cell), dx = x - 3u - (uint32_t)mul24u((int)jdx, L.w_cell);
+  return ((uint32_t)mad24u((int)idx, L.n_cols, (int)jdx) << 14) | ((dy & 127u) << 7) | (dx & 127u);
+}
+
 // root strip of a record (Quadtree::initSplit children, strict membership) or -1
 __device__ __forceinline__ int strip_of(uint32_t rec, const LevelDev& L) {
   const double x = (double)ORBFE_REC_X(rec), y = (double)ORBFE_REC_Y(rec);
@@ -961,11 +971,15 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       // of eight keys, was a quarter of the 98 us of a level-0 tree: stamps build, tools/exp/qt_stamps.sh.)
       __syncthreads();
       unsigned long long mine[(512 + NT - 1) / NT];
+      uint32_t k32[(512 + NT - 1) / NT];
+      uint32_t* sort32 = (uint32_t*)sortbuf;  // the ranking compares 32-bit order keys (order_key32)
 #pragma unroll
       for (int u = 0; u < (512 + NT - 1) / NT; ++u) {
         const int j = tid + u * NT;
         mine[u] = (j < sort_cap) ? node_key(j) : ~0ull;
-        if (j < sort_cap) sortbuf[j] = mine[u];
+        const uint32_t y = (uint32_t)(mine[u] >> 20) & 0xFFFu, x = (uint32_t)(mine[u] >> 8) & 0xFFFu;
+        k32[u] = (j < n_act) ? order_key32(ORBFE_PACK_XYR(x, y, 0u), L) : 0xFFFFFFFFu;
+        if (j < max(sort_cap, 16)) sort32[j] = k32[u];
       }
       __syncthreads();
       QTS(-21)  // node keys
@@ -976,13 +990,16 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       //  The slots past n_act hold ~0: they never count.)
       for (int i = 0; i < sort_cap; i += 16) {
         if (i >= n_act) break;  // wave-uniform
-        unsigned long long o[16];
+        uint32_t o[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) o[q] = (i + q < sort_cap) ? sortbuf[i + q] : ~0ull;  // (sort_cap is a power of two, possibly < 16)
+        for (int q = 0; q < 16; q += 4) {
+          const uint4 w = *(const uint4*)(sort32 + i + q);  // (slots up to max(sort_cap, 16) are written)
+          o[q] = w.x, o[q + 1] = w.y, o[q + 2] = w.z, o[q + 3] = w.w;
+        }
 #pragma unroll
         for (int q = 0; q < 16; ++q)
 #pragma unroll
-          for (int u = 0; u < (512 + NT - 1) / NT; ++u) rank[u] += (o[q] < mine[u]) ? 1 : 0;
+          for (int u = 0; u < (512 + NT - 1) / NT; ++u) rank[u] += (o[q] < k32[u]) ? 1 : 0;
       }
 #pragma unroll
       for (int u = 0; u < (512 + NT - 1) / NT; ++u) {
