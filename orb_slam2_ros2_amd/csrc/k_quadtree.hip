@@ -317,6 +317,12 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         r[u] = A[max(min(i, N - 1), 0)];  // (clamped: unconditional loads, validity is checked when the record is used)
       }
     };
+    // (the records of the FIRST trip and their groups stay in registers for the scatter pass: up to 1024 records per wave need no
+    //  second load -- an exposed global round trip -- and no second classification)
+    uint32_t rec0[16];
+    int g0[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) rec0[u] = 0u, g0[u] = -1;
     {
       uint32_t nxt[16];
       load16(wv * 1024, nxt);
@@ -330,6 +336,10 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         for (int u = 0; u < 16; ++u) {
           const int i = b0 + u * 64 + lane;
           g[u] = (i < N) ? group_of(rec[u]) : -1;
+        }
+        if (b0 == wv * 1024) {  // wave-uniform
+#pragma unroll
+          for (int u = 0; u < 16; ++u) rec0[u] = rec[u], g0[u] = g[u];
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u)
@@ -407,17 +417,22 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     // pass 2: scatter
     {
       uint32_t nxt[16];
-      load16(wv * 1024, nxt);
+      if (wv * 1024 + NW * 1024 < N) load16(wv * 1024 + NW * 1024, nxt);  // (the first trip's records are still in registers)
       for (int b0 = wv * 1024; b0 < N; b0 += NW * 1024) {
         uint32_t rec[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) rec[u] = nxt[u];
-        if (b0 + NW * 1024 < N) load16(b0 + NW * 1024, nxt);
         int g[16];
+        if (b0 == wv * 1024) {  // wave-uniform
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int i = b0 + u * 64 + lane;
-          g[u] = (i < N) ? group_of(rec[u]) : -1;
+          for (int u = 0; u < 16; ++u) rec[u] = rec0[u], g[u] = g0[u];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) rec[u] = nxt[u];
+          if (b0 + NW * 1024 < N) load16(b0 + NW * 1024, nxt);
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int i = b0 + u * 64 + lane;
+            g[u] = (i < N) ? group_of(rec[u]) : -1;
+          }
         }
         uint32_t pos[16];
 #pragma unroll
