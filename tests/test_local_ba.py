@@ -212,3 +212,18 @@ def test_device_local_ba_stop_flag(orc):
     if alone["iters"][0] > 60:   # the flag came first: the round ended early, no classification, no second round
         assert g["iters"][0] < alone["iters"][0] and g["iters"][1] == 0 and not g["level"].any(), (g["iters"], alone["iters"])
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_kf,n_fixed", [(3, 2), (44, 2), (45, 2), (10, 10), (10, 0)])
+def test_device_local_ba_around_the_device_lm_limit(orc, n_kf, n_fixed):
+    """1, 42 (the last size of the register-resident Cholesky: Levenberg-Marquardt control on the device), 43 (the first of the host-driven
+    loop), no free and no fixed keyframe at all: same iteration counts and trajectory as the oracle."""
+    from orb_slam2_ros2_amd._lib import Context
+    pr, fixed = _problem(20 + n_kf, n_kf, 300, n_fixed)
+    ctx = Context(640, 480, n_features=500, max_images=1)
+    g = ctx.ba_local_optimize(pr, fixed)
+    o = orc.ba_local_optimize(pr, fixed)
+    ctx.close()
+    assert tuple(g["iters"]) == tuple(o["iters"])
+    assert _pose_dist(g["poses"], o["poses"]) < 1e-6 and np.abs(g["points"] - o["points"]).max() < 1e-6

@@ -57,3 +57,20 @@ def test_device_optimiser_matches_oracle(orc, seed, n):
     o = orc.pose_only_optimize(**mono)
     assert np.abs(g[1] - o[1]).max() < 1e-6 and (g[2] != o[2]).sum() <= 1
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 2, 5, 63, 64, 65, 255, 256, 257])
+def test_device_optimiser_small_and_wave_boundary_sizes(orc, n):
+    """Edge counts around the register kernel's thread / wave boundaries (and none at all): pose, inlier flags and count against the oracle."""
+    from orb_slam2_ros2_amd._lib import Context
+    p = ba_synth.make_pose_problem(seed=3 + n, n=max(n, 1))
+    a = _args(p)
+    if n == 0:
+        for k in ("Xw", "meas", "info", "sigma2"):
+            a[k] = a[k][:0]
+    ctx = Context(640, 480, n_features=500, max_images=1)
+    g = ctx.pose_only_optimize(**a)
+    o = orc.pose_only_optimize(**a)
+    ctx.close()
+    assert np.abs(g[1] - o[1]).max() < 1e-6 and abs(g[0] - o[0]) <= 1 and (g[2] != o[2]).sum() <= 1
