@@ -680,6 +680,7 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
   c->qt_big_pitch = big_off;
   // the pre-partition's coordinate -> code tables, per level (k_quadtree.hip, quadtree_build_tables)
   c->qt_tabs.clear();
+  int pp_nodes = 0;  // node-table entries the pre-partition's scratch needs (it borrows the table: k_quadtree.hip, pp_ok)
   for (int l = 0; l < nl; ++l) {
     std::vector<uint16_t> t;
     c->lv[l].qt_tab_off = 0;
@@ -687,11 +688,19 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
       if (c->qt_tabs.size() & 1) c->qt_tabs.push_back(0);  // (4-byte aligned tables)
       c->lv[l].qt_tab_off = (uint32_t)c->qt_tabs.size();
       c->qt_tabs.insert(c->qt_tabs.end(), t.begin(), t.end());
+      const int ns = c->lv[l].n_ini;
+      const int need = std::max({176, (int)((t.size() * 2 + 7) / 8), (ns * 341 + 3) / 4, ns * 15});
+      if (c->lv[l].qt_big_cap == 0) pp_nodes = std::max(pp_nodes, need);
     }
   }
   if (c->qt_tabs.size() < 2) c->qt_tabs.resize(2, 0);
   c->node_cap = std::min(lds_nodes, max_lds_quota + max_ini + 8);
-  c->node_cap = std::max(c->node_cap, 192);  // (the pre-partition borrows the node arrays for its tables)
+  // The node table is at least as large as the pre-partition's scratch, up to 512 entries (22 KB): with nFeatures = 800 .. 1600 on
+  // a KITTI-sized image the largest quota is below the ~405 entries the coordinate tables of level 0 take, the pre-partition switched
+  // itself off and the trees split their thousands of candidates 64 records a step -- 1.45 ms per 1024 images at nFeatures = 800
+  // against 0.40 ms at 2000 (tools/exp/qt_occ.py).
+  if (!getenv("ORBFE_QT_LDS_NODES")) c->node_cap = std::max(c->node_cap, std::min(pp_nodes, 512));
+  c->node_cap = std::max(c->node_cap, 192);
   int sc = 2;
   while (sc < max_lds_quota) sc <<= 1;
   c->sort_cap = sc;
