@@ -695,11 +695,11 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
   }
   if (c->qt_tabs.size() < 2) c->qt_tabs.resize(2, 0);
   c->node_cap = std::min(lds_nodes, max_lds_quota + max_ini + 8);
-  // The node table is at least as large as the pre-partition's scratch, up to 512 entries (22 KB): with nFeatures = 800 .. 1600 on
+  // The node table is at least as large as the pre-partition's scratch, up to 1024 entries (45 KB): with nFeatures = 800 .. 1600 on
   // a KITTI-sized image the largest quota is below the ~405 entries the coordinate tables of level 0 take, the pre-partition switched
   // itself off and the trees split their thousands of candidates 64 records a step -- 1.45 ms per 1024 images at nFeatures = 800
   // against 0.40 ms at 2000 (tools/exp/qt_occ.py).
-  if (!getenv("ORBFE_QT_LDS_NODES")) c->node_cap = std::max(c->node_cap, std::min(pp_nodes, 512));
+  if (!getenv("ORBFE_QT_LDS_NODES")) c->node_cap = std::max(c->node_cap, std::min(pp_nodes, 1024));  // (1920 x 1080: 735 entries, 32 KB per tree -- four trees per CU, still 3x faster than splitting 25 k candidates 64 at a time)
   c->node_cap = std::max(c->node_cap, 192);
   int sc = 2;
   while (sc < max_lds_quota) sc <<= 1;

@@ -125,6 +125,33 @@ def test_fuzzed_geometries(orc, lib, seed):
     ctx.close()
 
 
+@pytest.mark.parametrize("w,h,nf", [(1920, 1080, 1000), (1241, 376, 800), (640, 480, 1000)])
+def test_other_camera_geometries_single_frame_and_batch(orc, lib, w, h, nf):
+    """Sizes and feature counts around the quadtree's pre-partition limits (r3: the node table is sized for the pre-partition's scratch --
+    a 1080p level 0 takes 735 entries, nFeatures = 800 on a KITTI frame 405 where the quota alone asks for 185): one frame through the
+    host-pointer path (four waves per tree) and 40 images through the device-batch path (one wave per tree group), against the oracle."""
+    import torch
+    L, R = synth.stereo_pair(3, w, h)
+    exl, exr = orc.extractor(L, n_features=nf), orc.extractor(R, n_features=nf)
+    ctx = lib.Context(w, h, n_features=nf, max_images=40)
+    (lk, ld), (rk, rd) = ctx.extract_batch([L, R])
+    assert_image_parity(ctx, 0, exl, lk, ld, 8)
+    assert_image_parity(ctx, 1, exr, rk, rd, 8, check_planes=False)
+    n = 20
+    dl = torch.from_numpy(np.stack([L if i % 2 == 0 else R for i in range(n)])).cuda()
+    dr = torch.from_numpy(np.stack([R if i % 2 == 0 else L for i in range(n)])).cuda()
+    ctx.stereo_batch_device(dl.data_ptr(), dr.data_ptr(), w, w * h, n, FX, BF)
+    ok_l, od_l = exl.extract()
+    ok_r, od_r = exr.extract()
+    for pair in (0, 1, n - 1):
+        for eye in (0, 1):
+            k, d = ctx.fetch_features(2 * pair + eye)
+            is_left_image = (pair % 2 == 0) == (eye == 0)
+            ok, od = (ok_l, od_l) if is_left_image else (ok_r, od_r)
+            assert np.array_equal(k, ok) and np.array_equal(d, od), (pair, eye)
+    ctx.close()
+
+
 @pytest.mark.parametrize("nf", [2000, 120, 24])
 def test_sparse_image_levels_with_fewer_candidates_than_quota_yield_nothing(orc, lib, nf):
     img, _ = synth.stereo_pair(5, sparse=True)

@@ -1,3 +1,5 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-for nf in 1000 2000 2500 3000 4000; do python3 tools/exp/qt_occ.py $nf 2>/dev/null | tail -1; done
+python3 tools/exp/qt_occ.py 1000 1920 1080 2>/dev/null | tail -1
+python3 tools/exp/qt_occ.py 2000 1920 1080 2>/dev/null | tail -1
+python3 tools/exp/qt_occ.py 2000 1241 376 2>/dev/null | tail -1
