@@ -2626,7 +2626,9 @@ static orbfe_status search_area_core(orbfe_ctx* c, const char* who, const orbfe_
                                      const uint8_t* d_desc, size_t n_target, size_t tmp_used, int32_t nq, const float* qxy,
                                      const float* radius, const int8_t* min_level, const int8_t* max_level, const uint8_t* q_desc,
                                      const uint8_t* exclude, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist, int32_t* n_cand,
-                                     const float* bounds = nullptr, int32_t* excluded_hits = nullptr) {
+                                     const float* bounds = nullptr, int32_t* excluded_hits = nullptr, bool staged_prefix = false) {
+  // staged_prefix: the caller has written the first tmp_used bytes of the scratch into the staging buffer (same offsets): they go up
+  // with the queries
   AreaGrid ag;
   if (!area_grid(c, bounds, &ag)) return fail(c, ORBFE_EBADARG, "%s: bad frame bounds", who);
   const int rows = ag.rows, cols = ag.cols;
@@ -2639,18 +2641,26 @@ static orbfe_status search_area_core(orbfe_ctx* c, const char* who, const orbfe_
     off += align_up(std::max<size_t>(bytes, 8), 256);
     return o2;
   };
-  const size_t o_co = take((ncells + 1) * 4), o_cf = take(NT * 4), o_q = take((size_t)nq * 8), o_r = take((size_t)nq * 4),
-               o_lo = take((size_t)nq), o_hi = take((size_t)nq), o_d = take((size_t)nq * 32), o_ex = take(NT), o_bi = take((size_t)nq * 4),
-               o_bd = take((size_t)nq * 4), o_sd = take((size_t)nq * 4), o_nc = take((size_t)nq * 4), o_eh = take(NT * 4);
+  // queries first (they continue the caller's uploaded block, if any, so that everything goes up as ONE copy through the page-locked
+  // staging buffer), then the grid, then the results (one download): ten copies from / to pageable memory were most of a 0.2 ms call
+  const size_t o_q = take((size_t)nq * 8), o_r = take((size_t)nq * 4), o_lo = take((size_t)nq), o_hi = take((size_t)nq),
+               o_d = take((size_t)nq * 32), o_ex = take(NT), o_in_end = take(8), o_co = take((ncells + 1) * 4), o_cf = take(NT * 4),
+               o_bi = take((size_t)nq * 4), o_bd = take((size_t)nq * 4), o_sd = take((size_t)nq * 4), o_nc = take((size_t)nq * 4),
+               o_eh = take(NT * 4), o_out_end = take(8);
   if (off > c->tmp_bytes) return fail(c, ORBFE_ENOMEM, "%s: scratch not reserved", who);  // (the callers reserve before they upload)
   uint8_t* b = (uint8_t*)c->d_tmp;
-  HIP_TRY(c, hipMemcpyAsync(b + o_q, qxy, (size_t)nq * 8, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_r, radius, (size_t)nq * 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_lo, min_level, (size_t)nq, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_hi, max_level, (size_t)nq, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_d, q_desc, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
-  if (exclude) HIP_TRY(c, hipMemcpyAsync(b + o_ex, exclude, n_target, hipMemcpyHostToDevice, c->stream));
   const bool hits = exclude && excluded_hits;
+  const size_t out_bytes = (hits ? o_out_end : o_eh) - o_bi;
+  TRY(ensure_stage(c, std::max(o_in_end, out_bytes)));  // (a caller with a staged prefix has reserved at least this much already)
+  uint8_t* hs = c->main.h_stage;
+  std::memcpy(hs + o_q, qxy, (size_t)nq * 8);
+  std::memcpy(hs + o_r, radius, (size_t)nq * 4);
+  std::memcpy(hs + o_lo, min_level, (size_t)nq);
+  std::memcpy(hs + o_hi, max_level, (size_t)nq);
+  std::memcpy(hs + o_d, q_desc, (size_t)nq * 32);
+  if (exclude) std::memcpy(hs + o_ex, exclude, n_target);
+  const size_t up0 = staged_prefix ? 0 : o_q;
+  HIP_TRY(c, hipMemcpyAsync(b + up0, hs + up0, o_in_end - up0, hipMemcpyHostToDevice, c->stream));
   if (hits) HIP_TRY(c, hipMemsetAsync(b + o_eh, 0, NT * 4, c->stream));
   {
     StageTimer tm(c, ORBFE_STAGE_MATCH, c->stream);
@@ -2661,14 +2671,15 @@ static orbfe_status search_area_core(orbfe_ctx* c, const char* who, const orbfe_
                        (int32_t*)(b + o_sd), (int32_t*)(b + o_nc), hits ? (int32_t*)(b + o_eh) : nullptr);
   }
   HIP_TRY(c, hipGetLastError());
-  if (hits) HIP_TRY(c, hipMemcpyAsync(excluded_hits, b + o_eh, n_target * 4, hipMemcpyDeviceToHost, c->stream));
-  else if (excluded_hits && n_target) std::memset(excluded_hits, 0, n_target * 4);
-  HIP_TRY(c, hipMemcpyAsync(best_idx, b + o_bi, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(best_dist, b + o_bd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(second_dist, b + o_sd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(n_cand, b + o_nc, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(hs, b + o_bi, out_bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_timers(c);
+  std::memcpy(best_idx, hs, (size_t)nq * 4);
+  std::memcpy(best_dist, hs + (o_bd - o_bi), (size_t)nq * 4);
+  std::memcpy(second_dist, hs + (o_sd - o_bi), (size_t)nq * 4);
+  std::memcpy(n_cand, hs + (o_nc - o_bi), (size_t)nq * 4);
+  if (hits) std::memcpy(excluded_hits, hs + (o_eh - o_bi), n_target * 4);
+  else if (excluded_hits && n_target) std::memset(excluded_hits, 0, n_target * 4);
   return ORBFE_OK;
 }
 // scratch the core needs beyond `tmp_used`
@@ -2676,7 +2687,7 @@ static size_t search_area_scratch(const orbfe_ctx* c, size_t n_target, int32_t n
   AreaGrid ag;
   if (!area_grid(c, bounds, &ag)) ag = {(c->cfg.height + 47) / 48, (c->cfg.width + 63) / 64, 0, 0};
   const size_t ncells = (size_t)ag.rows * ag.cols, NT = std::max<size_t>(n_target, 1);
-  return ((ncells + 1) * 4 + NT * 9 + (size_t)nq * (8 + 4 + 1 + 1 + 32 + 16)) + 13 * 256 + 4096;
+  return ((ncells + 1) * 4 + NT * 9 + (size_t)nq * (8 + 4 + 1 + 1 + 32 + 16)) + 15 * 256 + 4096;
 }
 
 orbfe_status orbfe_search_in_area(orbfe_ctx* c, int32_t slot, int32_t nq, const float* qxy, const float* radius, const int8_t* min_level,
@@ -2722,8 +2733,11 @@ orbfe_status orbfe_search_in_area_features_ex(orbfe_ctx* c, int32_t nt, const or
   const size_t o_k = 0, o_l = o_k + align_up(NT * sizeof(orbfe_keypoint), 256), o_d = o_l + align_up(NT * sizeof(uint4), 256),
                o_n = o_d + align_up(NT * 32, 256), used = o_n + 256;
   TRY(ensure_tmp(c, used + search_area_scratch(c, NT, nq, bounds)));
+  TRY(ensure_stage(c, used + search_area_scratch(c, NT, nq, bounds)));
   uint8_t* b = (uint8_t*)c->d_tmp;
-  std::vector<uint4> kpl(NT, make_uint4(0u, 0u, 0u, 0u));
+  uint8_t* hs = c->main.h_stage;
+  uint4* kpl = (uint4*)(hs + o_l);  // (built in the staging buffer: it goes up with everything else)
+  std::memset(kpl, 0, NT * sizeof(uint4));
   for (int i = 0; i < nt; ++i) {
     // caller-supplied features (a KeyFrame's undistorted mvFeatsLeft): coordinates may lie outside the image or be non-finite -- the grid
     // kernel clamps them into the border cells; the octave must be one a pyramid can have (it is compared as an unsigned byte)
@@ -2732,15 +2746,13 @@ orbfe_status orbfe_search_in_area_features_ex(orbfe_ctx* c, int32_t nt, const or
     kpl[(size_t)i].y = (uint32_t)t_kps[i].octave;  // the search reads the octave from here
   }
   if (nt) {
-    HIP_TRY(c, hipMemcpyAsync(b + o_k, t_kps, (size_t)nt * sizeof(orbfe_keypoint), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(b + o_l, kpl.data(), (size_t)nt * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(b + o_d, t_desc, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
+    std::memcpy(hs + o_k, t_kps, (size_t)nt * sizeof(orbfe_keypoint));
+    std::memcpy(hs + o_d, t_desc, (size_t)nt * 32);
   }
-  HIP_TRY(c, hipMemcpyAsync(b + o_n, &nt, 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));  // (kpl and nt live on this frame)
+  std::memcpy(hs + o_n, &nt, 4);
   return search_area_core(c, "search_in_area_features", (const orbfe_keypoint*)(b + o_k), (const int32_t*)(b + o_n), (const uint4*)(b + o_l),
                           b + o_d, (size_t)nt, used, nq, qxy, radius, min_level, max_level, q_desc, exclude, best_idx, best_dist,
-                          second_dist, n_cand, bounds, excluded_hits);
+                          second_dist, n_cand, bounds, excluded_hits, true);
 }
 
 orbfe_status orbfe_project_map_points(orbfe_ctx* c, int32_t n, const float* pos, const float* view_dir, const float* max_dist,
@@ -2760,14 +2772,17 @@ orbfe_status orbfe_project_map_points(orbfe_ctx* c, int32_t n, const float* pos,
     off += align_up(std::max<size_t>(bytes, 8), 256);
     return o2;
   };
-  const size_t o_p = take(N * 12), o_v = take(N * 12), o_mx = take(N * 4), o_mn = take(N * 4), o_uv = take(N * 8), o_d = take(N * 4),
-               o_c = take(N * 4), o_l = take(N), o_s = take(N);
+  const size_t o_p = take(N * 12), o_v = take(N * 12), o_mx = take(N * 4), o_mn = take(N * 4), o_in_end = take(8), o_uv = take(N * 8),
+               o_d = take(N * 4), o_c = take(N * 4), o_l = take(N), o_s = take(N), o_out_end = take(8);
   TRY(ensure_tmp(c, off));
+  TRY(ensure_stage(c, std::max(o_in_end, o_out_end - o_uv)));  // one copy up, one down, through the page-locked staging buffer
   uint8_t* b = (uint8_t*)c->d_tmp;
-  HIP_TRY(c, hipMemcpyAsync(b + o_p, pos, N * 12, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_v, view_dir, N * 12, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_mx, max_dist, N * 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(b + o_mn, min_dist, N * 4, hipMemcpyHostToDevice, c->stream));
+  uint8_t* hs = c->main.h_stage;
+  std::memcpy(hs + o_p, pos, N * 12);
+  std::memcpy(hs + o_v, view_dir, N * 12);
+  std::memcpy(hs + o_mx, max_dist, N * 4);
+  std::memcpy(hs + o_mn, min_dist, N * 4);
+  HIP_TRY(c, hipMemcpyAsync(b, hs, o_in_end, hipMemcpyHostToDevice, c->stream));
   const float cam4[4] = {cam->fx, cam->fy, cam->cx, cam->cy};
   const float bounds4[4] = {pose->min_u, pose->max_u, pose->min_v, pose->max_v};
   {
@@ -2778,13 +2793,14 @@ orbfe_status orbfe_project_map_points(orbfe_ctx* c, int32_t n, const float* pos,
                               (float*)(b + o_uv), (float*)(b + o_d), (float*)(b + o_c), (int8_t*)(b + o_l), b + o_s);
   }
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(uv, b + o_uv, N * 8, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(distance, b + o_d, N * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(cos_theta, b + o_c, N * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(level, b + o_l, N, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(visible, b + o_s, N, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(hs, b + o_uv, o_out_end - o_uv, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_timers(c);
+  std::memcpy(uv, hs, N * 8);
+  std::memcpy(distance, hs + (o_d - o_uv), N * 4);
+  std::memcpy(cos_theta, hs + (o_c - o_uv), N * 4);
+  std::memcpy(level, hs + (o_l - o_uv), N);
+  std::memcpy(visible, hs + (o_s - o_uv), N);
   return ORBFE_OK;
 }
 
