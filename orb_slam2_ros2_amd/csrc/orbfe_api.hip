@@ -2010,11 +2010,26 @@ orbfe_status orbfe_match_bruteforce(orbfe_ctx* c, const uint8_t* q, int32_t nq, 
   size_t o_bd = o_bi + align_up((size_t)nq * 4, 256), o_sd = o_bd + align_up((size_t)nq * 4, 256), total = o_sd + align_up((size_t)nq * 4, 256);
   TRY(ensure_tmp(c, total));
   uint8_t* base = (uint8_t*)c->d_tmp;
-  HIP_TRY(c, hipMemcpyAsync(base + o_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
-  if (nt) HIP_TRY(c, hipMemcpyAsync(base + o_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
-  if (cand_offsets) {
-    HIP_TRY(c, hipMemcpyAsync(base + o_off, cand_offsets, ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, c->stream));
-    if (n_cand) HIP_TRY(c, hipMemcpyAsync(base + o_cand, cand_idx, n_cand * 4, hipMemcpyHostToDevice, c->stream));
+  // up to 8 MB: one upload and one download through the page-locked staging buffer (seven copies from / to pageable memory otherwise)
+  const bool staged = total <= ((size_t)8 << 20);
+  uint8_t* hs = nullptr;
+  if (staged) {
+    TRY(ensure_stage(c, total));
+    hs = c->main.h_stage;
+    std::memcpy(hs + o_q, q, (size_t)nq * 32);
+    if (nt) std::memcpy(hs + o_t, t, (size_t)nt * 32);
+    if (cand_offsets) {
+      std::memcpy(hs + o_off, cand_offsets, ((size_t)nq + 1) * 4);
+      if (n_cand) std::memcpy(hs + o_cand, cand_idx, n_cand * 4);
+    }
+    HIP_TRY(c, hipMemcpyAsync(base, hs, o_bi, hipMemcpyHostToDevice, c->stream));
+  } else {
+    HIP_TRY(c, hipMemcpyAsync(base + o_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+    if (nt) HIP_TRY(c, hipMemcpyAsync(base + o_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
+    if (cand_offsets) {
+      HIP_TRY(c, hipMemcpyAsync(base + o_off, cand_offsets, ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, c->stream));
+      if (n_cand) HIP_TRY(c, hipMemcpyAsync(base + o_cand, cand_idx, n_cand * 4, hipMemcpyHostToDevice, c->stream));
+    }
   }
   {
     StageTimer tm(c, ORBFE_STAGE_MATCH, c->stream);
@@ -2022,6 +2037,15 @@ orbfe_status orbfe_match_bruteforce(orbfe_ctx* c, const uint8_t* q, int32_t nq, 
                             (const uint32_t*)(base + o_cand), (int32_t*)(base + o_bi), (int32_t*)(base + o_bd), (int32_t*)(base + o_sd));
   }
   HIP_TRY(c, hipGetLastError());
+  if (staged) {
+    HIP_TRY(c, hipMemcpyAsync(hs, base + o_bi, total - o_bi, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drain_timers(c);
+    std::memcpy(best_idx, hs, (size_t)nq * 4);
+    std::memcpy(best_dist, hs + (o_bd - o_bi), (size_t)nq * 4);
+    std::memcpy(second_dist, hs + (o_sd - o_bi), (size_t)nq * 4);
+    return ORBFE_OK;
+  }
   HIP_TRY(c, hipMemcpyAsync(best_idx, base + o_bi, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(best_dist, base + o_bd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(second_dist, base + o_sd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
