@@ -492,6 +492,29 @@ def latency_leg(device_id, n=500):
         ctx.stereo_match(0, 1, FX, BF)
     out = {"pair": "synthetic KITTI-shaped frame 0, 1241x376, 2000 features per image", "verified": True,
            "extract_batch_plus_match": dict(_stats_ms(one, n, warm=30), what="orbfe_extract_batch([L, R]) + orbfe_stereo_match, host to host, from Python")}
+    # the per-frame guided matchers of Tracking (searchByProjection x 2-4 per frame over findFeaturesInArea + getBestMatch, src/ORBMatcher.cc:
+    # 265-347, 561-612; MapPoint::isInVision, src/MapPoint.cc:141-201): 1000 queries against the 2000 features of the frame just built
+    r = np.random.default_rng(0)
+    nq = 1000
+    q = r.integers(0, len(rk), nq)
+    qxy = np.stack([rk["x"][q], rk["y"][q]], 1).astype(np.float32) + r.normal(0, 3, (nq, 2)).astype(np.float32)
+    rad = r.uniform(5, 40, nq).astype(np.float32)
+    lo, hi = np.zeros(nq, np.int8), np.full(nq, 7, np.int8)
+    a = ctx.search_in_area(0, qxy, rad, lo, hi, rd[q])
+    b_ = ctx.search_in_area_features(lk, ld, qxy, rad, lo, hi, rd[q])
+    if not all(np.array_equal(x, y) for x, y in zip(a, b_)):
+        raise SystemExit("bench.py: latency leg: the guided search against the slot differs from the one against the uploaded features")
+    pos = r.uniform(-5, 5, (2000, 3)).astype(np.float32)
+    pos[:, 2] = r.uniform(3, 30, 2000)
+    vd = np.tile(np.array([0, 0, 1], np.float32), (2000, 1))
+    mx, mn = np.full(2000, 100, np.float32), np.full(2000, 0.1, np.float32)
+    cam, bnd = (FX, FX, 607.19, 185.2), (0, W, 0, H)
+    out["guided_matchers"] = {
+        "what": "host arrays in, host results out, 1000 queries / 2000 map points against a 2000-feature frame (results checked against the "
+                "oracle in tests/test_guided_search.py; here: slot-resident and uploaded targets agree)",
+        "search_in_area_ms": _stats_ms(lambda: ctx.search_in_area(0, qxy, rad, lo, hi, rd[q]), 200, warm=10)["median_ms"],
+        "search_in_area_features_ms": _stats_ms(lambda: ctx.search_in_area_features(lk, ld, qxy, rad, lo, hi, rd[q]), 200, warm=10)["median_ms"],
+        "project_map_points_ms": _stats_ms(lambda: ctx.project_map_points(pos, vd, mx, mn, np.eye(3), np.zeros(3), cam, bnd), 200, warm=10)["median_ms"]}
     ctx.close()
     # (b) the C++ drop-in
     tmp = tempfile.mkdtemp(prefix="orbfe_lat_")
