@@ -712,7 +712,7 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
     if (const char* env = getenv("ORBFE_QT_REC_CAP")) c->rec_cap = std::max(0, std::min(c->rec_cap, atoi(env)));
     {
       // levels -> waves: longest-processing-time first on the quotas (a tree's work grows with its quota and candidate count)
-      int ng = std::min(nl, 4);
+      int ng = std::min(nl, 2);  // (4 until the tables / scans of a tree became cheap, late r3: same-box 5.542 / 5.512 ms per step with 4, 5.498 / 5.500 with 2, 5.502 with 3)
       if (const char* env = getenv("ORBFE_QT_GROUPS")) {
         ng = std::max(1, std::min(nl, atoi(env)));
         c->qt_groups_forced = true;

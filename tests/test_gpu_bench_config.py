@@ -66,7 +66,8 @@ KNOBS = [
     {"ORBFE_FUSE_ORIENT": "0"},           # keypoint list / moments / orientation of a frame or two as three launches (default: one)
     {"ORBFE_HOST_READ": "1"},             # host-pointer / slot paths: the resize kernel reads the page-locked staging buffer (default: a host-to-device copy)
     {"ORBFE_HOST_READ": "1", "ORBFE_HOST_MIRROR": "0"},
-    {"ORBFE_QT_GROUPS": "8"},             # one quadtree wave per level (default: the levels of an image dealt to 4 waves)
+    {"ORBFE_QT_GROUPS": "8"},             # one quadtree wave per level (default: the levels of an image dealt to 2 waves)
+    {"ORBFE_QT_GROUPS": "4"},             # ... to 4 waves (the default until late r3)
     {"ORBFE_QT_GROUPS": "1"},             # ... and all levels of an image in one wave
     {"ORBFE_PIPELINE_STEREO": "0"},       # stereo match in line
     {"ORBFE_OVERLAP_BLUR": "0"},          # blur in line, no second stream
