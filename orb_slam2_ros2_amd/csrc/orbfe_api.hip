@@ -217,7 +217,8 @@ struct orbfe_ctx {
   int rs_n[3] = {0, 0, 0}, rs_bytes[3] = {0, 0, 0};  // resize tiles of 64x64 / 64x32 / 64x16 outputs (in this order) and their LDS
   size_t img_pitch = 0;      // bytes per image in pyr / blur
   size_t scratch_pitch = 0;  // uint32 records per image
-  QtGroups qt_groups;        // levels per quadtree wave (balanced by quota), qt_n_groups waves per image (ORBFE_QT_GROUPS)
+  QtGroups qt_groups;        // ORBFE_QT_GROUPS: levels per quadtree wave (balanced by quota), qt_n_groups waves per image, whatever the launch size
+  QtGroups qt_groups_of[3];  // the same for 1, 2 and 4 waves per image (picked by launch size)
   QtGroups qt_single;        // one level per wave: launches too small to fill the wave slots (a frame or two: the chain of several trees in one wave would only add latency)
   int qt_n_groups = 0;
   bool qt_groups_forced = false;
@@ -711,25 +712,32 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
     c->rec_cap = (int)std::min<size_t>(std::min<size_t>(max_cand, 8192), budget / 4);
     if (const char* env = getenv("ORBFE_QT_REC_CAP")) c->rec_cap = std::max(0, std::min(c->rec_cap, atoi(env)));
     {
-      // levels -> waves: longest-processing-time first on the quotas (a tree's work grows with its quota and candidate count)
-      int ng = std::min(nl, 2);  // (4 until the tables / scans of a tree became cheap, late r3: same-box 5.542 / 5.512 ms per step with 4, 5.498 / 5.500 with 2, 5.502 with 3)
-      if (const char* env = getenv("ORBFE_QT_GROUPS")) {
-        ng = std::max(1, std::min(nl, atoi(env)));
-        c->qt_groups_forced = true;
-      }
+      // levels -> waves: longest-processing-time first on the quotas (a tree's work grows with its quota and candidate count).
+      // Tables for 1, 2 and 4 waves per image: a launch takes the one that makes ~8 tree waves per CU -- as many as are resident at once
+      // (LDS and registers) -- so that the launch is ONE round of waves: same-box, per step of 128 / 256 / 512 pairs, one wave per
+      // level | 4 | 2 waves per image: 0.154 | 0.182 | 0.300, 0.300 | 0.210 | 0.349, 0.61 | 0.388 | 0.366 ms.  ORBFE_QT_GROUPS forces one.
       std::memset(&c->qt_single, 0, sizeof c->qt_single);
       for (int l = 0; l < nl; ++l) c->qt_single.mask[l] = 1u << l;
-      std::memset(&c->qt_groups, 0, sizeof c->qt_groups);
-      std::vector<double> load(ng, 0.0);
       std::vector<int> order(nl);
       for (int l = 0; l < nl; ++l) order[l] = l;
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return c->lv[a].quota > c->lv[b].quota; });
-      for (int l : order) {
-        int g = 0;
-        for (int k = 1; k < ng; ++k)
-          if (load[k] < load[g]) g = k;
-        load[g] += (double)c->lv[l].quota + 1.0;
-        c->qt_groups.mask[g] |= 1u << l;
+      auto deal = [&](int ng, QtGroups* out) {
+        std::memset(out, 0, sizeof *out);
+        std::vector<double> load(ng, 0.0);
+        for (int l : order) {
+          int g = 0;
+          for (int k = 1; k < ng; ++k)
+            if (load[k] < load[g]) g = k;
+          load[g] += (double)c->lv[l].quota + 1.0;
+          out->mask[g] |= 1u << l;
+        }
+      };
+      for (int k = 0; k < 3; ++k) deal(std::min(nl, 1 << k), &c->qt_groups_of[k]);
+      int ng = 0;  // 0: by launch size
+      if (const char* env = getenv("ORBFE_QT_GROUPS")) {
+        ng = std::max(1, std::min(nl, atoi(env)));
+        c->qt_groups_forced = true;
+        deal(ng, &c->qt_groups);
       }
       c->qt_n_groups = ng;
     }
@@ -949,8 +957,17 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     // tree, 40-150 dependent steps), so what matters most is that EVERY tree of the launch is resident at once; the
     // records go to LDS only as far as that still holds (measured at 1024 trees: 4 trees/CU 0.59 ms, 3 trees/CU 0.96 ms).
     // several levels per wave only where one wave per level would fill more than half of the chip's wave slots (8 per SIMD)
-    const bool grouped = c->qt_groups_forced || (long long)nl * n_img > (long long)c->n_cu * 16;
-    const int n_groups = grouped ? c->qt_n_groups : nl;
+    // waves per image so that the launch has about 8 tree waves per CU (one round): 4 from 1/2 x, 2 from 1 x, 1 from 2 x that many images
+    int gsel = -1;  // -1: one wave per level
+    if (!c->qt_groups_forced && nl > 4) {
+      const long long per8 = (long long)c->n_cu * 8;
+      if ((long long)n_img * 1 >= per8) gsel = 0;
+      else if ((long long)n_img * 2 >= per8) gsel = 1;
+      else if ((long long)n_img * 4 >= per8) gsel = 2;
+    }
+    const bool grouped = c->qt_groups_forced || gsel >= 0;
+    const int n_groups = c->qt_groups_forced ? c->qt_n_groups : (gsel >= 0 ? std::min(nl, 1 << gsel) : nl);
+    const QtGroups& qt_tab = c->qt_groups_forced ? c->qt_groups : (gsel >= 0 ? c->qt_groups_of[gsel] : c->qt_single);
     const int trees = n_groups * n_img;
     const int per_cu = (trees + c->n_cu - 1) / c->n_cu;
     // lds_share > 1: that many chunks run side by side on their own streams; each quadtree launch leaves the rest of the
@@ -962,7 +979,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     const int rec_cap = budget > node_bytes ? (int)std::min<size_t>((budget - node_bytes) / 4, (size_t)c->rec_cap) : 0;
     launch_quadtree(st, c->d_lv, nl, c->d_scr_a + i0 * c->scratch_pitch, c->d_scr_b + i0 * c->scratch_pitch,
                     c->d_scr_c + i0 * c->scratch_pitch, c->scratch_pitch, c->d_sel + i0 * NF, c->d_sel_count + i0 * nl,
-                    c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img, c->qt_batch, grouped ? c->qt_groups : c->qt_single, n_groups,
+                    c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img, c->qt_batch, qt_tab, n_groups,
                     // helper waves for the data-parallel phases of a tree where the launch leaves the chip empty (a frame or two)
                     (!grouped && trees * 4 <= c->n_cu * 4 && c->qt_waves > 1) ? 4 : 1, c->d_qt_big ? c->d_qt_big + i0 * c->qt_big_pitch : nullptr,
                     c->qt_big_pitch, c->d_qt_tabs);
