@@ -1322,15 +1322,21 @@ orbfe_status orbfe_fetch_features(orbfe_ctx* c, int32_t slot, orbfe_keypoint* kp
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
   const size_t NF = (size_t)c->cfg.n_features;
-  int32_t n = 0;
-  HIP_TRY(c, hipMemcpyAsync(c->h_counts, c->d_n_kp + slot, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  n = c->h_counts[0];
-  if (n < 0 || (size_t)n > NF) return fail(c, ORBFE_EDEVICE, "fetch_features: corrupt count %d", n);
-  if (kps && n) HIP_TRY(c, hipMemcpyAsync(kps, c->d_kps + (size_t)slot * NF, sizeof(orbfe_keypoint) * n, hipMemcpyDeviceToHost, c->stream));
-  if (desc && n) HIP_TRY(c, hipMemcpyAsync(desc, c->d_desc + (size_t)slot * NF * 32, (size_t)32 * n, hipMemcpyDeviceToHost, c->stream));
+  // count, keypoints and descriptors of the whole slot into the page-locked staging buffer behind ONE synchronisation (the count first and
+  // then exactly n entries into pageable memory were two round trips)
+  const size_t h_k = 256, h_d = h_k + align_up(NF * sizeof(orbfe_keypoint), 256), h_total = h_d + align_up(NF * 32, 256);
+  TRY(ensure_stage(c, h_total));
+  uint8_t* hs = c->main.h_stage;
+  HIP_TRY(c, hipMemcpyAsync(hs, c->d_n_kp + slot, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  if (kps && NF) HIP_TRY(c, hipMemcpyAsync(hs + h_k, c->d_kps + (size_t)slot * NF, sizeof(orbfe_keypoint) * NF, hipMemcpyDeviceToHost, c->stream));
+  if (desc && NF) HIP_TRY(c, hipMemcpyAsync(hs + h_d, c->d_desc + (size_t)slot * NF * 32, (size_t)32 * NF, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_timers(c);
+  int32_t n = 0;
+  std::memcpy(&n, hs, 4);
+  if (n < 0 || (size_t)n > NF) return fail(c, ORBFE_EDEVICE, "fetch_features: corrupt count %d", n);
+  if (kps && n) std::memcpy(kps, hs + h_k, sizeof(orbfe_keypoint) * (size_t)n);
+  if (desc && n) std::memcpy(desc, hs + h_d, (size_t)32 * n);
   if (n_out) *n_out = n;
   return ORBFE_OK;
 }
