@@ -106,7 +106,7 @@ void launch_lm_switch(hipStream_t s, const LmLaunch& L);
 void launch_lm_final(hipStream_t s, const LmLaunch& L);
 void launch_pose_only(hipStream_t s, int n, const double* Xw, const double* meas, const double* info, const float* sigma2,
                       const double* pose_in, BaParamsDev prm, double d_mono, double d_stereo, double* err, uint8_t* level,
-                      uint8_t* robust, uint8_t* inlier, double* pose_out, int32_t* n_good);
+                      uint8_t* robust, uint8_t* inlier, double* pose_out, int32_t* n_good, bool mem_version);
 }  // namespace orbfe
 
 using namespace orbfe;
@@ -264,6 +264,7 @@ struct orbfe_ctx {
   // stop flag is mirrored into it while the call waits -- and the page-locked copy of the state record
   volatile uint8_t* h_abort = nullptr;
   LmState* h_lm_state = nullptr;
+  bool pose_in_memory = false;  // ORBFE_POSE_IN_MEMORY=1: round 2's pose-only kernel (edges re-read from memory every pass)
   bool lm_tail_ctrl = false;  // ORBFE_LM_TAIL_CTRL=1 (k_lm.hip, launch_lm_steps): measured slower, kept as a tested mechanism
   bool lm_on_device = true;  // ORBFE_LBA_HOST_LM=1: round 2's host-driven loop (kept for A/B runs and for > LM_CHOL_MAX_NB free keyframes)
 
@@ -1178,6 +1179,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     if (const char* rr = getenv("ORBFE_RESIZE_REGIONS")) c->resize_regions = atoi(rr) != 0;
     if (const char* hl = getenv("ORBFE_LBA_HOST_LM")) c->lm_on_device = atoi(hl) == 0;
     if (const char* tc = getenv("ORBFE_LM_TAIL_CTRL")) c->lm_tail_ctrl = atoi(tc) != 0;
+    if (const char* pm = getenv("ORBFE_POSE_IN_MEMORY")) c->pose_in_memory = atoi(pm) != 0;
     if (const char* be = getenv("ORBFE_BLUR_L0_EARLY")) c->blur_l0_early = atoi(be) != 0;
     if (const char* xl = getenv("ORBFE_EXT_LEVEL0")) c->ext_level0 = atoi(xl) != 0;
     const char* ov = getenv("ORBFE_OVERLAP_BLUR");
@@ -2895,7 +2897,7 @@ orbfe_status orbfe_pose_only_optimize(orbfe_ctx* c, int32_t n, const double* xw,
     StageTimer tm(c, ORBFE_STAGE_BA, c->stream);
     launch_pose_only(c->stream, n, (const double*)(b + o_x), (const double*)(b + o_m), (const double*)(b + o_i), (const float*)(b + o_s),
                      (const double*)(b + o_p), prm, (double)(float)std::sqrt(5.991), (double)(float)std::sqrt(7.815), (double*)(b + o_e),
-                     b + o_l, b + o_r, b + o_in, (double*)(b + o_po), (int32_t*)(b + o_ng));
+                     b + o_l, b + o_r, b + o_in, (double*)(b + o_po), (int32_t*)(b + o_ng), c->pose_in_memory);
   }
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(hs, b + o_po, (inlier_out && n ? o_in + (size_t)n : o_in) - o_po, hipMemcpyDeviceToHost, c->stream));
