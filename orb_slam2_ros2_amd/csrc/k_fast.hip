@@ -32,6 +32,13 @@
 #include "orbfe_internal.h"
 #include "wave_ops.h"
 
+#ifndef FAST_PP40_MAX
+#define FAST_PP40_MAX 37  // xa + pw <= 40
+#endif
+#ifndef FAST_PV36_MAX
+#define FAST_PV36_MAX 40  // iw + 2 <= 36
+#endif
+
 namespace orbfe {
 
 // (the necessary test takes one row step per loop trip.  Measured on one box, per 128 pairs: 1 -> 2.252 ms, 2 -> 2.278, 4 -> 2.287: the
@@ -117,15 +124,14 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
   //         instructions per wave).  The global address is only 4-byte aligned (x0 - xa); gfx950 takes that for dwordx4.
   const int xa = cell.x0 & 3;
   {
-    constexpr int UPR = PP / 16;                    // 16-byte units per LDS row
+    constexpr int UPR = (PP + 15) / 16;             // 16-byte units per patch row (pitch 40: the third one is half a unit)
     constexpr int RPP = 64 / UPR;                   // rows per pass
     constexpr int MUL = (128 + UPR - 1) / UPR;      // lane / UPR == (lane * MUL) >> 7 for lane < 64 (UPR = 3: 43, UPR = 5: 26)
-    static_assert(PP % 16 == 0 && (UPR == 3 || UPR == 5), "patch pitch");
+    static_assert(PP % 8 == 0 && (UPR == 3 || UPR == 5), "patch pitch");
     const int row0 = (lane * MUL) >> 7, part = lane - row0 * UPR;
     const int nbytes = (xa + pw + 3) & ~3;          // bytes of a patch row that are needed
     const uint8_t* src = pyr + (size_t)img * img_pitch + L.plane_off + (size_t)cell.y0 * L.stride + (cell.x0 - xa);
     const uint32_t stride = (uint32_t)L.stride;
-    uint4* lds_q = (uint4*)lds_all;
     constexpr int BATCH = 2;
     if (row0 < RPP && 16 * part < nbytes) {         // (a unit that starts past the needed bytes is never read: it may lie past the row)
       for (int rb = row0; rb < ph; rb += RPP * BATCH) {
@@ -142,7 +148,15 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
 #pragma unroll
         for (int it = 0; it < BATCH; ++it) {
           const int r = rb + RPP * it;
-          if (r < ph) lds_q[r * UPR + part] = wv[it];
+          if (r < ph) {
+            if (PP % 16 == 0) {
+              ((uint4*)lds_all)[r * UPR + part] = wv[it];
+            } else {  // rows 8-byte aligned only: two 8-byte stores, the half unit at the end of a row one
+              uint2* d = (uint2*)(P + r * PP + 16 * part);
+              d[0] = make_uint2(wv[it].x, wv[it].y);
+              if (part < UPR - 1) d[1] = make_uint2(wv[it].z, wv[it].w);
+            }
+          }
         }
       }
     }
@@ -310,6 +324,7 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
   }
 }
 
+
 // LDS carve-up for cell patches up to max_pw x max_ph with pitches pp / pv (host side helper)
 void fast_lds_layout(int max_pw, int max_ph, int pp, int pv, int* v_off, int* q_off, int* q_cap, int* total) {
   const int p_bytes = (max_ph * pp + 15) & ~15;
@@ -321,11 +336,39 @@ void fast_lds_layout(int max_pw, int max_ph, int pp, int pv, int* v_off, int* q_
   *q_off = p_bytes + v_bytes;
   *q_cap = q_bytes / 2;
   *total = p_bytes + v_bytes + q_bytes;
+#ifdef FAST_LDS_PAD
+  *total += FAST_LDS_PAD;  // (tools/exp: the occupancy experiment of the launcher's comment)
+#endif
+}
+
+// One kernel launch for cells [cell_first, cell_first + n_cells) whose patches are at most max_pw x max_ph: the tightest pitches the
+// patches allow.  The kernel's throughput follows the resident waves almost one to one (r3, same-box A/B: 520 bytes of padding per
+// wave, 30 -> 27 waves per CU on level 0, +10 % time), so the patch pitch is 40 where xa + pw <= 40 and the score map's 36 where
+// iw + 2 <= 36: levels 0..2 of 1241x376 fit 32 waves per CU (5120 bytes each) instead of 30 (worth ~1 %: the knee is just below).
+// Built, bit-exact and dropped in r3: the necessary test on TWO pixels per lane -- the patch parked row-paired (dword = pixel (r, c) |
+// pixel (r + ih/2, c) << 16, every ring read one aligned 32-bit LDS read for both; misaligned LDS reads cost 28 aligned ones,
+// tools/exp/lds_misaligned.hip, so horizontal pairs are out), v_pk_min/max_u16 + v_pk_sub_i16 and sign-bit verdicts, the score map in
+// the unused upper bytes, Q capped to keep 5120 bytes per wave with a dense fallback for cells whose survivors do not fit: 8 trips of 34
+// vector instructions instead of 15 of ~30, but the interleaving stores, the half-select of every window / score address and the
+// dual list moved into the scoring trips gave back all of it (892 vector instructions per wave against 813, SQ counters of
+// tools/exp/fast_sq.sh) with 3.5 x the LDS bank-conflict cycles: 2.22 ms against 2.07.
+static void launch_fast_cells(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, int max_pw, int max_ph, const uint8_t* d_pyr,
+                              size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch, int32_t* d_n_cand, int n_levels,
+                              int cell_first, int n_cells, int n_img) {
+  int v_off, q_off, q_cap, total;
+  const int pp = max_pw <= FAST_PP40_MAX ? 40 : (max_pw <= 44 ? 48 : 80), pv = max_pw <= FAST_PV36_MAX ? 36 : (max_pw <= 44 ? 40 : 72);
+  fast_lds_layout(max_pw, max_ph, pp, pv, &v_off, &q_off, &q_cap, &total);
+#define FAST_GO(K) hipLaunchKernelGGL(K, dim3(n_cells, n_img), dim3(64), total, s, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo, d_cand, \
+                                      cand_pitch, d_n_cand, n_levels, cell_first, n_cells, v_off, q_off, q_cap)
+  if (pp == 40) FAST_GO((k_fast<40, 36>));
+  else if (pp == 48 && pv == 36) FAST_GO((k_fast<48, 36>));
+  else if (pp == 48) FAST_GO((k_fast<48, 40>));
+  else FAST_GO((k_fast<80, 72>));
+#undef FAST_GO
 }
 
 // One launch per pyramid level: the cells of a level have (almost) one size, so each launch reserves just the LDS its
-// patches need (levels 0..3 of 1241x376, 87 % of the cells, run at the full 32 waves per CU).  Measured: merging
-// levels 0..3 into one launch with their common carve-up (31 waves) is 5 % slower than the four separate launches.
+// patches need.  Measured: merging levels 0..3 into one launch with their common carve-up is 5 % slower than the four separate launches.
 void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, const LevelDev* h_lv, const int* lvl_max_pw,
                  const int* lvl_max_ph, const uint8_t* d_pyr, size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch,
                  int32_t* d_n_cand, int n_levels, int n_img, hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, int side_from) {
@@ -346,15 +389,8 @@ void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, co
     max_ph = std::max(max_ph, lvl_max_ph[l]);
   }
   if ((long long)total_cells * n_img <= 16384 && max_pw > 6 && max_ph > 6) {
-    const bool small = max_pw <= 44;
-    int v_off, q_off, q_cap, total;
-    fast_lds_layout(max_pw, max_ph, small ? 48 : 80, small ? 40 : 72, &v_off, &q_off, &q_cap, &total);
-    if (small)
-      hipLaunchKernelGGL((k_fast<48, 40>), dim3(total_cells, n_img), dim3(64), total, s, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo, d_cand,
-                         cand_pitch, d_n_cand, n_levels, 0, total_cells, v_off, q_off, q_cap);
-    else
-      hipLaunchKernelGGL((k_fast<80, 72>), dim3(total_cells, n_img), dim3(64), total, s, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo, d_cand,
-                         cand_pitch, d_n_cand, n_levels, 0, total_cells, v_off, q_off, q_cap);
+    launch_fast_cells(s, d_lv, d_cells, max_pw, max_ph, d_pyr, img_pitch, t_hi, t_lo, d_cand, cand_pitch, d_n_cand, n_levels, 0, total_cells,
+                      n_img);
     return;
   }
   const bool split = side && ev_go && ev_done && side_from > 0 && side_from < n_levels;
@@ -365,16 +401,8 @@ void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, co
   for (int l = 0; l < n_levels; ++l) {
     const int n_cells = h_lv[l].n_cells;
     if (n_cells <= 0 || lvl_max_pw[l] <= 6 || lvl_max_ph[l] <= 6) continue;
-    hipStream_t s_l = (split && l >= side_from) ? side : s;
-    const bool small = lvl_max_pw[l] <= 44;
-    int v_off, q_off, q_cap, total;
-    fast_lds_layout(lvl_max_pw[l], lvl_max_ph[l], small ? 48 : 80, small ? 40 : 72, &v_off, &q_off, &q_cap, &total);
-    if (small)
-      hipLaunchKernelGGL((k_fast<48, 40>), dim3(n_cells, n_img), dim3(64), total, s_l, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo,
-                         d_cand, cand_pitch, d_n_cand, n_levels, (int)h_lv[l].cell_base, n_cells, v_off, q_off, q_cap);
-    else
-      hipLaunchKernelGGL((k_fast<80, 72>), dim3(n_cells, n_img), dim3(64), total, s_l, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo,
-                         d_cand, cand_pitch, d_n_cand, n_levels, (int)h_lv[l].cell_base, n_cells, v_off, q_off, q_cap);
+    launch_fast_cells((split && l >= side_from) ? side : s, d_lv, d_cells, lvl_max_pw[l], lvl_max_ph[l], d_pyr, img_pitch, t_hi, t_lo, d_cand,
+                      cand_pitch, d_n_cand, n_levels, (int)h_lv[l].cell_base, n_cells, n_img);
   }
   if (split) {
     (void)hipEventRecord(ev_done, side);
