@@ -32,6 +32,9 @@
 #include "orbfe_internal.h"
 #include "wave_ops.h"
 
+#ifndef FAST_CPW
+#define FAST_CPW 4
+#endif
 #ifndef FAST_PP40_MAX
 #define FAST_PP40_MAX 37  // xa + pw <= 40
 #endif
@@ -86,17 +89,25 @@ __device__ __forceinline__ int arc_score1(const uint8_t* a, int sgn) {
   return max(max(max(a0, a1), a2), max(max(a3, a4), m9[15]));
 }
 
-// PP / PV: compile-time pitches of the LDS patch and of the score map (48 / 40 for patches up to 44 px wide -- every
-// cell of the 30-px grid --, 80 / 72 for the largest patch the context accepts)
+// PP / PV: compile-time pitches of the LDS patch and of the score map (40 / 36, 48 / 36 and 48 / 40 for the patches of the 30-px grid,
+// 80 / 72 for the largest patch the context accepts).
+//
+// A wave works through cells ci = blockIdx.x, + n_groups, + 2 n_groups ... of its launch (n_groups = n_cells: one cell per wave, the
+// drop-in path's launches; a quarter of that for the batches).  Of a one-cell wave's ~10.7 us a fifth is spent at s_waitcnt for global
+// memory (SQ counters, r3) -- the patch at its start, the list reservation's round trip at its end -- with nothing to issue, and eight
+// such waves per SIMD leave the vector unit idle a fifth of the time.  In the loop both are off the critical path: the NEXT cell's patch
+// is requested into registers before the current cell is worked on, and a cell's records (almost always <= 64: one per lane, in a
+// register) are stored only after the NEXT cell's work, when the reservation issued before it has long returned.
 template <int PP, int PV>
-__global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, const CellDev* __restrict__ cells,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fast(const LevelDev* __restrict__ lv, const CellDev* __restrict__ cells,
                                              const uint8_t* __restrict__ pyr, size_t img_pitch, int t_hi, int t_lo,
                                              uint32_t* __restrict__ cand, size_t cand_pitch, int32_t* __restrict__ n_cand,
-                                             int n_levels, int cell_first, int n_cells, int lds_v_off, int lds_q_off, int q_cap) {
+                                             int n_levels, int cell_first, int n_cells, int lds_v_off, int lds_q_off, int q_cap,
+                                             int n_groups) {
   extern __shared__ uint32_t lds_all[];
-  // One cell per single-wave workgroup (four cells per workgroup measured 10 % slower: the LDS of a workgroup stays
-  // allocated until its slowest cell is done); the kernel is VALU-bound and gains from every extra resident wave
-  // (21 -> 26 waves per CU: -7 %), so the LDS carve-up is per level and as tight as the level's largest patch allows.
+  // One wave per workgroup (four waves per workgroup measured 10 % slower: the LDS of a workgroup stays allocated until its slowest
+  // wave is done); the kernel gains from every extra resident wave (21 -> 26 waves per CU: -7 %), so the LDS carve-up is per launch
+  // and as tight as the launch's largest patch allows.
   // WAVE_SYNC: the LDS accesses of one wave execute in order, the fence only pins the compiler -- no s_barrier needed.
 #define WAVE_SYNC()                                          \
   do {                                                       \
@@ -108,222 +119,315 @@ __global__ __launch_bounds__(64) void k_fast(const LevelDev* __restrict__ lv, co
   uint8_t* V = (uint8_t*)lds_w + lds_v_off;  // (ih+2) rows of scores with a zero border, pitch PV, pixel (iy,ix) at V[(iy+1)*PV + ix+1]
   uint16_t* Q = (uint16_t*)((uint8_t*)lds_w + lds_q_off);  // [q_cap] survivors from the front; pixels that need the second
                                                            // polarity too are listed again from the back
-  // (the NMS verdict of a queue entry goes into bit 14 of the entry itself: its polarity / dual tags are spent by then)
 
   const int lane = threadIdx.x & 63;
   const int img = blockIdx.y;
-  if ((int)blockIdx.x >= n_cells) return;
-  const CellDev cell = cells[cell_first + blockIdx.x];
-  const LevelDev& L = lv[cell.level];
-  const int pw = cell.pw, ph = cell.ph;
-  const int iw = pw - 6, ih = ph - 6;  // interior cv::FAST scans: rows/cols 3 .. size-4
-  if (iw <= 0 || ih <= 0) return;
-  // ---- 1. patch -> LDS: 16-byte units (PP / 16 per row: 3 for the 30-px grid's patches), 21 rows per pass, every pass of a lane
-  //         requested before the first is parked (rows clamped, so the loads are unconditional): two loads and two stores per lane
-  //         for a 36-row patch where 32-bit words took nine of each plus their address arithmetic (~ 60 of the kernel's ~1080 VALU
-  //         instructions per wave).  The global address is only 4-byte aligned (x0 - xa); gfx950 takes that for dwordx4.
-  const int xa = cell.x0 & 3;
-  {
-    constexpr int UPR = (PP + 15) / 16;             // 16-byte units per patch row (pitch 40: the third one is half a unit)
-    constexpr int RPP = 64 / UPR;                   // rows per pass
-    constexpr int MUL = (128 + UPR - 1) / UPR;      // lane / UPR == (lane * MUL) >> 7 for lane < 64 (UPR = 3: 43, UPR = 5: 26)
-    static_assert(PP % 8 == 0 && (UPR == 3 || UPR == 5), "patch pitch");
-    const int row0 = (lane * MUL) >> 7, part = lane - row0 * UPR;
-    const int nbytes = (xa + pw + 3) & ~3;          // bytes of a patch row that are needed
-    const uint8_t* src = pyr + (size_t)img * img_pitch + L.plane_off + (size_t)cell.y0 * L.stride + (cell.x0 - xa);
-    const uint32_t stride = (uint32_t)L.stride;
-    constexpr int BATCH = 2;
-    if (row0 < RPP && 16 * part < nbytes) {         // (a unit that starts past the needed bytes is never read: it may lie past the row)
-      for (int rb = row0; rb < ph; rb += RPP * BATCH) {
-        uint4 wv[BATCH];
+  int ci = __builtin_amdgcn_readfirstlane(blockIdx.x);
+  if (ci >= n_cells) return;
+  // ---- patch -> registers: 16-byte units (3 per row for the 30-px grid's patches: 21 rows per pass of the wave), every pass of a lane
+  //      requested at once (rows clamped, so the loads are unconditional).  The global address is only 4-byte aligned (x0 - xa);
+  //      gfx950 takes that for dwordx4.
+  constexpr int UPR = (PP + 15) / 16;             // 16-byte units per patch row (pitch 40: the third one is half a unit)
+  constexpr int RPP = 64 / UPR;                   // rows per pass
+  constexpr int MUL = (128 + UPR - 1) / UPR;      // lane / UPR == (lane * MUL) >> 7 for lane < 64 (UPR = 3: 43, UPR = 5: 26)
+  constexpr int NB = 2;                          // passes kept in flight: 42 rows at three units per row
+  static_assert(PP % 8 == 0 && (UPR == 3 || UPR == 5), "patch pitch");
+  // (a lane's row / unit recomputed where needed, behind an opaque copy of the lane number: held across the cell loop the two values cost
+  //  the registers that tip the kernel over 64 -- a spill whose reload is a vector memory operation pending at the loop's back edge)
+#define FAST_ROW_PART()           \
+  int lane_o = lane;              \
+  asm volatile("" : "+v"(lane_o)); \
+  const int row0 = (lane_o * MUL) >> 7, part = lane_o - row0 * UPR
+  const uint8_t* img_base = pyr + (size_t)img * img_pitch;
+  auto patch_src = [&](const CellDev& c) __attribute__((always_inline)) -> const uint8_t* {
+    const LevelDev& Lc = lv[c.level];
+    return img_base + Lc.plane_off + (size_t)c.y0 * Lc.stride + (c.x0 - (c.x0 & 3));
+  };
+  // (every lane loads, rows and units clamped into the patch: a load behind a lane condition leaves the compiler merging old and new
+  //  register values right behind it -- a wait for the data where it was only meant to be requested)
+  auto fetch = [&](const CellDev& c, uint4 (&wv)[NB]) __attribute__((always_inline)) {
+    FAST_ROW_PART();
+    const int nbytes = ((c.x0 & 3) + c.pw + 3) & ~3;  // bytes of a patch row that are needed
+    const uint8_t* src = patch_src(c);
+    const int stride = lv[c.level].stride;
+    const int xoff = 16 * part < nbytes ? 16 * part : 0;  // (a unit that starts past the needed bytes may lie past the row: it loads the row's first instead and is never parked)
 #pragma unroll
-        for (int it = 0; it < BATCH; ++it) {
-          const int r = min(rb + RPP * it, ph - 1);
-          wv[it] = *(const uint4*)(src + (uint32_t)mad24u(r, (int)stride, 16 * part));  // full-rate 24-bit product: rows and strides < 2^13
-        }
-        // both passes in flight before the first is consumed (left alone, the compiler sinks the second load into the branch that
-        // guards its store and the wave pays two memory round trips)
-#pragma unroll
-        for (int it = 0; it < BATCH; ++it) asm volatile("" : "+v"(wv[it].x), "+v"(wv[it].y), "+v"(wv[it].z), "+v"(wv[it].w));
-#pragma unroll
-        for (int it = 0; it < BATCH; ++it) {
-          const int r = rb + RPP * it;
-          if (r < ph) {
-            if (PP % 16 == 0) {
-              ((uint4*)lds_all)[r * UPR + part] = wv[it];
-            } else {  // rows 8-byte aligned only: two 8-byte stores, the half unit at the end of a row one
-              uint2* d = (uint2*)(P + r * PP + 16 * part);
-              d[0] = make_uint2(wv[it].x, wv[it].y);
-              if (part < UPR - 1) d[1] = make_uint2(wv[it].z, wv[it].w);
-            }
-          }
-        }
-      }
+    for (int it = 0; it < NB; ++it) {
+      const int r = min(row0 + RPP * it, c.ph - 1);
+      wv[it] = *(const uint4*)(src + (uint32_t)mad24u(r, stride, xoff));  // full-rate 24-bit product: rows and strides < 2^13
     }
-  }
-  // ---- zero the V map (with border), 16 bytes per store (its carve-up is rounded to 16) ----
-  {
-    const int vq = ((ih + 2) * PV + 3 + 15) >> 4;
-    uint4* V128 = (uint4*)V;
-    for (int k = lane; k < vq; k += 64) V128[k] = make_uint4(0u, 0u, 0u, 0u);
-  }
-  WAVE_SYNC();
+  };
+  // the cell's record through the scalar cache (16 bytes, 16-byte aligned: left as a struct of 16-bit fields it is fetched with vector
+  // loads -- a memory round trip before the patch can even be requested)
+  auto load_cell = [&](int idx) __attribute__((always_inline)) -> CellDev {
+    static_assert(sizeof(CellDev) == 16, "CellDev");
+    const uint4 raw = *(const uint4*)(cells + (cell_first + idx));
+    CellDev c;
+    c.level = (int16_t)(raw.x & 0xFFFFu);
+    c.x0 = (int16_t)(raw.x >> 16);
+    c.y0 = (int16_t)(raw.y & 0xFFFFu);
+    c.pw = (int16_t)(raw.y >> 16);
+    c.ph = (int16_t)(raw.z & 0xFFFFu);
+    c.offx = (int16_t)(raw.z >> 16);
+    c.offy = (int16_t)(raw.w & 0xFFFFu);
+    c.pad = 0;
+    return c;
+  };
+  auto park_unit = [&](int r, int part, const uint4& w) __attribute__((always_inline)) {
+    if (PP % 16 == 0) {
+      ((uint4*)lds_all)[r * UPR + part] = w;
+    } else {  // rows 8-byte aligned only: two 8-byte stores, the half unit at the end of a row one
+      uint2* d = (uint2*)(P + r * PP + 16 * part);
+      d[0] = make_uint2(w.x, w.y);
+      if (part < UPR - 1) d[1] = make_uint2(w.z, w.w);
+    }
+  };
 
-  int nq = 0, n_keep = 0;
-  for (int pass = 0; pass < 2; ++pass) {
-    const int t_pass = pass == 0 ? t_hi : t_lo;  // cv::FAST(patch, hi); if that yields nothing: cv::FAST(patch, lo)
-    if (pass == 1) {
-      if (t_lo >= t_hi) break;  // the second call could only return a subset of the (empty) first
-      const int vq = ((ih + 2) * PV + 3 + 15) >> 4;
-      uint4* V128 = (uint4*)V;
-      for (int k = lane; k < vq; k += 64) V128[k] = make_uint4(0u, 0u, 0u, 0u);
-      WAVE_SYNC();
-    }
-    // ---- 2. necessary test on every interior pixel; survivors -> queue, tagged with the polarity to score.  The wave covers
-    //         a (64/lw rows) x (lw columns) tile per step, lw = 16/32/64 by cell width, so addresses advance by a constant.
-    //         (The queue order is free: NMS does not depend on it and the candidate list of a level is a set.  Two pixels
-    //         per lane in packed halves would need unaligned 16-bit LDS reads: measured ~20 cycles each on gfx950.)
-    nq = 0;
-    int nd = 0;
-    bool d_overflow = false;
-    {
-      const int shift = iw <= 16 ? 4 : (iw <= 32 ? 5 : 6);
-      const int lw = 1 << shift, rpi = 64 >> shift;
-      const int lx = lane & (lw - 1), ly = lane >> shift;
-      for (int x0 = 0; x0 < iw; x0 += lw) {
-        const int ix = x0 + lx;
-        const uint8_t* a0 = P + ly * PP + xa + ix;  // top-left corner of the pixel's 7x7 window
-        const uint32_t e_lane = (uint32_t)ix | ((uint32_t)ly << 7);
-        const int thr_x = ix < iw ? t_pass : 0x7FFF;
-        const uint8_t* a = a0;
-        // every predicate is ONE vector compare whose lane mask feeds the ballot and the branch directly (a predicate built from
-        // several masks is expanded to 0 / 1 per lane and compared again before a ballot: two more VALU instructions each)
-        auto trip = [&](const int y0, const int thr) __attribute__((always_inline)) {
-          const int v = a[3 * PP + 3];
-          const int r0 = a[6 * PP + 3], r8 = a[3], r4 = a[3 * PP + 6], r12 = a[3 * PP];
-          const int r2 = a[5 * PP + 5], r10 = a[PP + 1], r6 = a[PP + 5], r14 = a[5 * PP + 1];
-          const int lo_of_hi = min(min(max(r0, r8), max(r4, r12)), min(max(r2, r10), max(r6, r14)));
-          const int hi_of_lo = max(max(min(r0, r8), min(r4, r12)), max(min(r2, r10), min(r6, r14)));
-          const int sb = lo_of_hi - v;  // > t: every opposite pair has a pixel brighter than v + t
-          const int sd = v - hi_of_lo;  // > t: ... darker than v - t
-          // two compares; their lane masks are combined on the SCALAR unit and handed back as lane predicates (inverse ballot: the
-          // mask register is used as it is) -- max / min of the two margins and a compare each were four vector instructions
-          const bool pd = sd > thr;
-          const unsigned long long mb = __ballot(sb > thr), md = __ballot(pd);
-          const unsigned long long m = mb | md, m2 = mb & md;
-          const bool any = __builtin_amdgcn_inverse_ballot_w64(m), dual = __builtin_amdgcn_inverse_ballot_w64(m2);
-          const uint32_t eh = e_lane + ((uint32_t)y0 << 7);
-          if (any) Q[nq + mbcnt64(m, 0)] = (uint16_t)(eh | (pd ? 0u : Q_BRIGHT) | (dual ? Q_DUAL : 0u));
-          nq += __popcll(m);
-          if (m2) {  // both polarities passed: the main entry scores the dark one, the list at the back of Q the bright one
-            const int k = __popcll(m2);
-            if (nq + nd + k <= q_cap) {
-              if (dual) Q[q_cap - 1 - (nd + mbcnt64(m2, 0))] = (uint16_t)eh;
-              nd += k;
-            } else {
-              d_overflow = true;  // (pathological cell) the tagged entries are re-scanned one by one below
-            }
-          }
-        };
-        // lanes right of the interior can never pass (thr_x), so the column test costs nothing per trip; the row test is only needed in
-        // the last, partial trip of a column block (its rows past the interior are read -- they lie inside this wave's carve-up -- but
-        // cannot pass either)
-        int y0 = 0;
-        for (; y0 + rpi <= ih; y0 += rpi, a += rpi * PP) trip(y0, thr_x);
-        if (y0 < ih) trip(y0, y0 + ly < ih ? thr_x : 0x7FFF);
+  // registers -> LDS (both passes were in flight before the first is consumed), the rows past the prefetched ones straight from memory
+  // (patches taller than 42 / 24 rows)
+  auto park = [&](const CellDev& c, uint4 (&wv)[NB]) __attribute__((always_inline)) {
+    FAST_ROW_PART();
+    const int nbytes = ((c.x0 & 3) + c.pw + 3) & ~3;
+    if (c.pw > 6 && c.ph > 6 && row0 < RPP && 16 * part < nbytes) {
+#pragma unroll
+      for (int it = 0; it < NB; ++it) {
+        const int r = row0 + RPP * it;
+        if (r < c.ph) park_unit(r, part, wv[it]);
+      }
+      if (c.ph > RPP * NB) {  // wave-uniform
+        const uint8_t* src = patch_src(c);
+        const int stride = lv[c.level].stride;
+        for (int r = row0 + RPP * NB; r < c.ph; r += RPP) park_unit(r, part, *(const uint4*)(src + (uint32_t)mad24u(r, stride, 16 * part)));
       }
     }
-    if (nq + nd > q_cap) {  // the front grew into the back list after it was written: drop the list, re-scan instead
-      nd = 0;
-      d_overflow = true;
+  };
+
+  // every lane "uses" the prefetched registers at ONE place that every path through the cell loop crosses (the last cell's included): a
+  // wait left on some paths only leaves the loads pending on the others as far as the compiler can tell, and it then waits -- for
+  // everything in flight, the reservation included -- wherever those registers are next written
+#define FAST_PATCH_ARRIVED() \
+  _Pragma("unroll") for (int it = 0; it < NB; ++it) asm volatile("" : "+v"(wv[it].x), "+v"(wv[it].y), "+v"(wv[it].z), "+v"(wv[it].w))
+
+  CellDev cell = load_cell(ci);
+  uint4 wv[NB];
+  fetch(cell, wv);
+  FAST_PATCH_ARRIVED();
+  park(cell, wv);
+  // the previous cell's records, one per lane, waiting for its list reservation (lane 0 of base_prev) to return
+  uint32_t rec_prev = 0u;
+  int n_prev = 0, base_prev = 0;
+  uint32_t* out_prev = cand;
+
+  for (;;) {
+    const LevelDev& L = lv[cell.level];
+    const int pw = cell.pw, ph = cell.ph;
+    const int iw = pw - 6, ih = ph - 6;  // interior cv::FAST scans: rows/cols 3 .. size-4
+    const int xa = cell.x0 & 3;
+    const int ci_next = ci + n_groups;
+    const bool has_next = ci_next < n_cells;
+    const bool live = iw > 0 && ih > 0;
+    int nq = 0, n_keep = 0;
+    if (live) {
+      // ---- zero the V map (with border), 16 bytes per store (its carve-up is rounded to 16) ----
+      {
+        const int vq = ((ih + 2) * PV + 3 + 15) >> 4;
+        uint4* V128 = (uint4*)V;
+        for (int k = lane; k < vq; k += 64) V128[k] = make_uint4(0u, 0u, 0u, 0u);
+      }
     }
+    // the next cell's patch travels while this one is worked on (unconditionally -- a wave's last cell asks for its own patch once
+    // more and drops it --: behind `if (has_next)` the registers become a merge of old and new values, copied, and so waited for, at once)
+    const CellDev cell_next = load_cell(has_next ? ci_next : ci);
+    fetch(cell_next, wv);
     WAVE_SYNC();
 
-    // ---- 3. exact test + score for the survivors, one queue entry per lane (trips of 64).  Only about
-    //         half of the survivors are corners: those (and the dual-tagged entries, whose second polarity is still to come) are
-    //         compacted in place at the front of Q, so that the NMS and the output pass touch no entry that cannot matter.
-    int nc = 0;
-    for (int j0 = 0; j0 < nq; j0 += 64) {
-      const bool act = j0 + lane < nq;
-      const uint32_t q = Q[min(j0 + lane, nq - 1)];
-      const int ix = Q_IX(q), iy = Q_IY(q);
-      const int A = arc_score1<PP>(P + iy * PP + xa + ix, (q & Q_BRIGHT) ? -1 : 1);
-      const bool c = act && A > t_pass;
-      if (c) V[(iy + 1) * PV + ix + 1] = (uint8_t)min(255, A);
-      const bool keep = c || (act && (q & Q_DUAL));
-      const unsigned long long m = __ballot(keep);
-      if (keep) Q[nc + mbcnt64(m, 0)] = (uint16_t)q;  // (in place: this trip's entries were all read above, later trips read further back)
-      nc += __popcll(m);
-    }
-    nq = nc;
-    if (nd > 0 || d_overflow) {
+    if (live) {
+      for (int pass = 0; pass < 2; ++pass) {
+        const int t_pass = pass == 0 ? t_hi : t_lo;  // cv::FAST(patch, hi); if that yields nothing: cv::FAST(patch, lo)
+        if (pass == 1) {
+          if (t_lo >= t_hi) break;  // the second call could only return a subset of the (empty) first
+          const int vq = ((ih + 2) * PV + 3 + 15) >> 4;
+          uint4* V128 = (uint4*)V;
+          for (int k = lane; k < vq; k += 64) V128[k] = make_uint4(0u, 0u, 0u, 0u);
+          WAVE_SYNC();
+        }
+      // ---- 2. necessary test on every interior pixel; survivors -> queue, tagged with the polarity to score.  The wave covers
+      //         a (64/lw rows) x (lw columns) tile per step, lw = 16/32/64 by cell width, so addresses advance by a constant.
+      //         (The queue order is free: NMS does not depend on it and the candidate list of a level is a set.  Two pixels
+      //         per lane in packed halves would need unaligned 16-bit LDS reads: measured ~20 cycles each on gfx950.)
+      nq = 0;
+      int nd = 0;
+      bool d_overflow = false;
+      {
+        const int shift = iw <= 16 ? 4 : (iw <= 32 ? 5 : 6);
+        const int lw = 1 << shift, rpi = 64 >> shift;
+        const int lx = lane & (lw - 1), ly = lane >> shift;
+        for (int x0 = 0; x0 < iw; x0 += lw) {
+          const int ix = x0 + lx;
+          const uint8_t* a0 = P + ly * PP + xa + ix;  // top-left corner of the pixel's 7x7 window
+          const uint32_t e_lane = (uint32_t)ix | ((uint32_t)ly << 7);
+          const int thr_x = ix < iw ? t_pass : 0x7FFF;
+          const uint8_t* a = a0;
+          // every predicate is ONE vector compare whose lane mask feeds the ballot and the branch directly (a predicate built from
+          // several masks is expanded to 0 / 1 per lane and compared again before a ballot: two more VALU instructions each)
+          auto trip = [&](const int y0, const int thr) __attribute__((always_inline)) {
+            const int v = a[3 * PP + 3];
+            const int r0 = a[6 * PP + 3], r8 = a[3], r4 = a[3 * PP + 6], r12 = a[3 * PP];
+            const int r2 = a[5 * PP + 5], r10 = a[PP + 1], r6 = a[PP + 5], r14 = a[5 * PP + 1];
+            const int lo_of_hi = min(min(max(r0, r8), max(r4, r12)), min(max(r2, r10), max(r6, r14)));
+            const int hi_of_lo = max(max(min(r0, r8), min(r4, r12)), max(min(r2, r10), min(r6, r14)));
+            const int sb = lo_of_hi - v;  // > t: every opposite pair has a pixel brighter than v + t
+            const int sd = v - hi_of_lo;  // > t: ... darker than v - t
+            // two compares; their lane masks are combined on the SCALAR unit and handed back as lane predicates (inverse ballot: the
+            // mask register is used as it is) -- max / min of the two margins and a compare each were four vector instructions
+            const bool pd = sd > thr;
+            const unsigned long long mb = __ballot(sb > thr), md = __ballot(pd);
+            const unsigned long long m = mb | md, m2 = mb & md;
+            const bool any = __builtin_amdgcn_inverse_ballot_w64(m), dual = __builtin_amdgcn_inverse_ballot_w64(m2);
+            const uint32_t eh = e_lane + ((uint32_t)y0 << 7);
+            if (any) Q[nq + mbcnt64(m, 0)] = (uint16_t)(eh | (pd ? 0u : Q_BRIGHT) | (dual ? Q_DUAL : 0u));
+            nq += __popcll(m);
+            if (m2) {  // both polarities passed: the main entry scores the dark one, the list at the back of Q the bright one
+              const int k = __popcll(m2);
+              if (nq + nd + k <= q_cap) {
+                if (dual) Q[q_cap - 1 - (nd + mbcnt64(m2, 0))] = (uint16_t)eh;
+                nd += k;
+              } else {
+                d_overflow = true;  // (pathological cell) the tagged entries are re-scanned one by one below
+              }
+            }
+          };
+          // lanes right of the interior can never pass (thr_x), so the column test costs nothing per trip; the row test is only needed in
+          // the last, partial trip of a column block (its rows past the interior are read -- they lie inside this wave's carve-up -- but
+          // cannot pass either)
+          int y0 = 0;
+          for (; y0 + rpi <= ih; y0 += rpi, a += rpi * PP) trip(y0, thr_x);
+          if (y0 < ih) trip(y0, y0 + ly < ih ? thr_x : 0x7FFF);
+        }
+      }
+      if (nq + nd > q_cap) {  // the front grew into the back list after it was written: drop the list, re-scan instead
+        nd = 0;
+        d_overflow = true;
+      }
       WAVE_SYNC();
-      for (int j = lane; j < nd; j += 64) {  // the back list: V = max(A, B)
-        const uint32_t q = Q[q_cap - 1 - j];
+
+      // ---- 3. exact test + score for the survivors, one queue entry per lane (trips of 64).  Only about
+      //         half of the survivors are corners: those (and the dual-tagged entries, whose second polarity is still to come) are
+      //         compacted in place at the front of Q, so that the NMS and the output pass touch no entry that cannot matter.
+      int nc = 0;
+      for (int j0 = 0; j0 < nq; j0 += 64) {
+        const bool act = j0 + lane < nq;
+        const uint32_t q = Q[min(j0 + lane, nq - 1)];
         const int ix = Q_IX(q), iy = Q_IY(q);
-        const int B = arc_score1<PP>(P + iy * PP + xa + ix, -1);
-        uint8_t* vp = V + (iy + 1) * PV + ix + 1;
-        if (B > t_pass) *vp = (uint8_t)max((int)*vp, min(255, B));
+        const int A = arc_score1<PP>(P + iy * PP + xa + ix, (q & Q_BRIGHT) ? -1 : 1);
+        const bool c = act && A > t_pass;
+        if (c) V[(iy + 1) * PV + ix + 1] = (uint8_t)min(255, A);
+        const bool keep = c || (act && (q & Q_DUAL));
+        const unsigned long long m = __ballot(keep);
+        if (keep) Q[nc + mbcnt64(m, 0)] = (uint16_t)q;  // (in place: this trip's entries were all read above, later trips read further back)
+        nc += __popcll(m);
       }
-      if (d_overflow) {  // entries that did not fit the back list (max is idempotent, so re-scoring listed ones is harmless)
-        for (int q = lane; q < nq; q += 64) {
-          const uint32_t e = Q[q];
-          if (e & Q_DUAL) {
-            const int ix = Q_IX(e), iy = Q_IY(e);
-            const uint8_t* a = P + iy * PP + xa + ix;
-            const int B = arc_score1<PP>(a, -1);
-            uint8_t* vp = V + (iy + 1) * PV + ix + 1;
-            if (B > t_pass) *vp = (uint8_t)max((int)*vp, min(255, B));
+      nq = nc;
+      if (nd > 0 || d_overflow) {
+        WAVE_SYNC();
+        for (int j = lane; j < nd; j += 64) {  // the back list: V = max(A, B)
+          const uint32_t q = Q[q_cap - 1 - j];
+          const int ix = Q_IX(q), iy = Q_IY(q);
+          const int B = arc_score1<PP>(P + iy * PP + xa + ix, -1);
+          uint8_t* vp = V + (iy + 1) * PV + ix + 1;
+          if (B > t_pass) *vp = (uint8_t)max((int)*vp, min(255, B));
+        }
+        if (d_overflow) {  // entries that did not fit the back list (max is idempotent, so re-scoring listed ones is harmless)
+          for (int q = lane; q < nq; q += 64) {
+            const uint32_t e = Q[q];
+            if (e & Q_DUAL) {
+              const int ix = Q_IX(e), iy = Q_IY(e);
+              const uint8_t* a = P + iy * PP + xa + ix;
+              const int B = arc_score1<PP>(a, -1);
+              uint8_t* vp = V + (iy + 1) * PV + ix + 1;
+              if (B > t_pass) *vp = (uint8_t)max((int)*vp, min(255, B));
+            }
           }
         }
       }
-    }
-    WAVE_SYNC();
+      WAVE_SYNC();
 
-    // ---- 4. NMS over the queue: an entry is kept iff its score beats its 8 neighbours' (0 where nothing was scored) ----
-    n_keep = 0;
-    for (int q0 = 0; q0 < nq; q0 += 64) {
-      const int q = q0 + lane;
-      bool is_max = false;
-      if (q < nq) {
-        const uint32_t e = Q[q];
-        const uint8_t* c = V + Q_IY(e) * PV + Q_IX(e);  // top-left corner of the 3x3 neighbourhood
-        // all nine reads requested at once, one compare against the largest neighbour (v > max >= 0 also says v != 0): written as a
-        // chain of && the compiler made nine dependent LDS round trips of it, each behind its own branch
-        const int v = c[PV + 1];
-        const int n0 = c[0], n1 = c[1], n2 = c[2], n3 = c[PV], n4 = c[PV + 2], n5 = c[2 * PV], n6 = c[2 * PV + 1], n7 = c[2 * PV + 2];
-        is_max = v > max(max(max(n0, n1), n2), max(max(max(n3, n4), n5), max(n6, n7)));
-        Q[q] = (uint16_t)(Q_XY(e) | (is_max ? Q_BRIGHT : 0u));  // (scores in the map are > t_pass by construction)
+        // ---- 4. NMS over the queue: an entry is kept iff its score beats its 8 neighbours' (0 where nothing was scored); the kept ones
+        //         are compacted at the front of Q (in place: a trip's entries are all read before it writes, and it writes no further
+        //         than it has read)
+        n_keep = 0;
+        for (int q0 = 0; q0 < nq; q0 += 64) {
+          const int q = q0 + lane;
+          bool is_max = false;
+          uint32_t e = 0u;
+          if (q < nq) {
+            e = Q[q];
+            const uint8_t* c = V + Q_IY(e) * PV + Q_IX(e);  // top-left corner of the 3x3 neighbourhood
+            // all nine reads requested at once, one compare against the largest neighbour (v > max >= 0 also says v != 0): written as a
+            // chain of && the compiler made nine dependent LDS round trips of it, each behind its own branch
+            const int v = c[PV + 1];
+            const int n0 = c[0], n1 = c[1], n2 = c[2], n3 = c[PV], n4 = c[PV + 2], n5 = c[2 * PV], n6 = c[2 * PV + 1], n7 = c[2 * PV + 2];
+            is_max = v > max(max(max(n0, n1), n2), max(max(max(n3, n4), n5), max(n6, n7)));  // (scores in the map are > t_pass by construction)
+          }
+          const unsigned long long m = __ballot(is_max);
+          if (is_max) Q[n_keep + mbcnt64(m, 0)] = (uint16_t)Q_XY(e);
+          n_keep += __popcll(m);
+        }
+        WAVE_SYNC();
+        if (n_keep > 0) break;
       }
-      n_keep += __popcll(__ballot(is_max));
     }
-    WAVE_SYNC();
-    if (n_keep > 0) break;
-  }
-  {
-    // The list of a level is a SET: the quadtree orders candidates by (cell, y, x) recomputed from the coordinates, so cells may
-    // append in any order -- one atomic reservation per cell, then the wave writes its records.
-    const int total = n_keep;
-    if (total == 0) return;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&n_cand[(size_t)img * n_levels + cell.level], total);
-    base = __builtin_amdgcn_readfirstlane(base);
-    uint32_t* out = cand + (size_t)img * cand_pitch + L.cand_base + base;
-    int cnt = 0;
-    for (int q0 = 0; q0 < nq; q0 += 64) {
-      const int q = q0 + lane;
-      const uint32_t e = q < nq ? (uint32_t)Q[q] : 0u;
-      const bool keep = (e & Q_BRIGHT) != 0;
-      const unsigned long long m = __ballot(keep);
-      if (keep) {
-        const int ix = Q_IX(e), iy = Q_IY(e);
-        out[cnt + mbcnt64(m, 0)] = ORBFE_PACK_XYR(ix + 3 + cell.offx, iy + 3 + cell.offy, V[(iy + 1) * PV + ix + 1] - 1);
+    // ---- 5. output.  The list of a level is a SET: the quadtree orders candidates by (cell, y, x) recomputed from the coordinates, so
+    //         cells may append in any order -- one atomic reservation per cell, then the wave writes its records.
+    if (n_prev > 0) {  // the previous cell's: its reservation was issued a whole cell ago
+      const int b = __builtin_amdgcn_readfirstlane(base_prev);
+      if (lane < n_prev) out_prev[b + lane] = rec_prev;
+      n_prev = 0;
+    }
+    // A cell's records (almost always <= 64) go to registers, the NEXT cell's patch is parked -- that waits for the patch alone: the last
+    // reservation has just been consumed above --, and only then is this cell's reservation issued; its value is looked at after
+    // the next cell's work.
+    bool defer = false;
+    uint32_t* const out = cand + (size_t)img * cand_pitch + L.cand_base;
+    int32_t* const counter = &n_cand[(size_t)img * n_levels + cell.level];
+    auto record = [&](int j) __attribute__((always_inline)) -> uint32_t {
+      const uint32_t e = Q[min(j, n_keep - 1)];
+      const int ix = Q_IX(e), iy = Q_IY(e);
+      return ORBFE_PACK_XYR(ix + 3 + cell.offx, iy + 3 + cell.offy, V[(iy + 1) * PV + ix + 1] - 1);
+    };
+    // (this file is compiled with -mllvm -amdgpu-atomic-optimizer-strategy=None, see the Makefile: the optimizer rewrites an atomicAdd on
+    //  a uniform address into a wave reduction that waits for the returned value on the spot; left alone the instruction returns into
+    //  lane 0's register and the compiler waits where that is first read)
+    auto reserve = [&]() __attribute__((always_inline)) -> int {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(counter, n_keep);
+      return base;
+    };
+    if (n_keep > 0) {
+      if (has_next && n_keep <= 64) {
+        rec_prev = record(lane);
+        defer = true;
+      } else {
+        const int b = __builtin_amdgcn_readfirstlane(reserve());
+        for (int j0 = 0; j0 < n_keep; j0 += 64) {
+          const uint32_t r = record(j0 + lane);
+          if (j0 + lane < n_keep) out[b + j0 + lane] = r;
+        }
       }
-      cnt += __popcll(m);
     }
+    FAST_PATCH_ARRIVED();
+    if (!has_next) break;
+    WAVE_SYNC();  // (the records above were read from Q / V before the next cell's patch and map overwrite them)
+    park(cell_next, wv);
+    if (defer) {
+      base_prev = reserve();
+      n_prev = n_keep;
+      out_prev = out;
+    }
+    ci = ci_next;
+    cell = cell_next;
   }
 }
-
 
 // LDS carve-up for cell patches up to max_pw x max_ph with pitches pp / pv (host side helper)
 void fast_lds_layout(int max_pw, int max_ph, int pp, int pv, int* v_off, int* q_off, int* q_cap, int* total) {
@@ -358,8 +462,12 @@ static void launch_fast_cells(hipStream_t s, const LevelDev* d_lv, const CellDev
   int v_off, q_off, q_cap, total;
   const int pp = max_pw <= FAST_PP40_MAX ? 40 : (max_pw <= 44 ? 48 : 80), pv = max_pw <= FAST_PV36_MAX ? 36 : (max_pw <= 44 ? 40 : 72);
   fast_lds_layout(max_pw, max_ph, pp, pv, &v_off, &q_off, &q_cap, &total);
-#define FAST_GO(K) hipLaunchKernelGGL(K, dim3(n_cells, n_img), dim3(64), total, s, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo, d_cand, \
-                                      cand_pitch, d_n_cand, n_levels, cell_first, n_cells, v_off, q_off, q_cap)
+  // cells per wave: one for the drop-in path's launches (every cell its own wave: the launch is a single wave lifetime), FAST_CPW where the
+  // launch holds many rounds of waves anyway
+  const int cpw = (long long)n_cells * n_img >= 65536 ? FAST_CPW : 1;
+  const int n_groups = (n_cells + cpw - 1) / cpw;
+#define FAST_GO(K) hipLaunchKernelGGL(K, dim3(n_groups, n_img), dim3(64), total, s, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo, d_cand, \
+                                      cand_pitch, d_n_cand, n_levels, cell_first, n_cells, v_off, q_off, q_cap, n_groups)
   if (pp == 40) FAST_GO((k_fast<40, 36>));
   else if (pp == 48 && pv == 36) FAST_GO((k_fast<48, 36>));
   else if (pp == 48) FAST_GO((k_fast<48, 40>));
