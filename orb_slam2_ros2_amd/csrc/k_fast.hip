@@ -16,7 +16,7 @@
 //   1. patch -> LDS with aligned 32-bit loads;
 //   2. every interior pixel takes a 9-read necessary test (a 9-arc contains one pixel of each opposite ring
 //      pair, so min over 4 pairs of max(pair) must exceed v+t, or max of min(pair) be below v-t); survivors are
-//      appended -- in raster order, one entry per polarity that passed -- to an LDS queue with ballot/prefix;
+//      appended -- one entry per pixel, tagged with the polarity to score and whether both passed -- to an LDS queue with ballot/prefix;
 //   3. the queue is processed densely, one entry per lane: the entry's polarity is scored in 32-bit registers (v_mad_i32_i24 applies
 //      the sign, v_min3_i32 / v_max3_i32 the arcs) into a zero-bordered V map, V = max(A, B) where both polarities were queued;
 //   4. NMS runs over the queue only, never over the whole patch again; the kept maxima are appended to the level's
@@ -287,15 +287,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             const uint32_t eh = e_lane + ((uint32_t)y0 << 7);
             if (any) Q[nq + mbcnt64(m, 0)] = (uint16_t)(eh | (pd ? 0u : Q_BRIGHT) | (dual ? Q_DUAL : 0u));
             nq += __popcll(m);
-            if (m2) {  // both polarities passed: the main entry scores the dark one, the list at the back of Q the bright one
-              const int k = __popcll(m2);
-              if (nq + nd + k <= q_cap) {
-                if (dual) Q[q_cap - 1 - (nd + mbcnt64(m2, 0))] = (uint16_t)eh;
-                nd += k;
-              } else {
-                d_overflow = true;  // (pathological cell) the tagged entries are re-scanned one by one below
-              }
-            }
           };
           // lanes right of the interior can never pass (thr_x), so the column test costs nothing per trip; the row test is only needed in
           // the last, partial trip of a column block (its rows past the interior are read -- they lie inside this wave's carve-up -- but
@@ -305,15 +296,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
           if (y0 < ih) trip(y0, y0 + ly < ih ? thr_x : 0x7FFF);
         }
       }
-      if (nq + nd > q_cap) {  // the front grew into the back list after it was written: drop the list, re-scan instead
-        nd = 0;
-        d_overflow = true;
-      }
       WAVE_SYNC();
 
       // ---- 3. exact test + score for the survivors, one queue entry per lane (trips of 64).  Only about
       //         half of the survivors are corners: those (and the dual-tagged entries, whose second polarity is still to come) are
-      //         compacted in place at the front of Q, so that the NMS and the output pass touch no entry that cannot matter.
+      //         compacted in place at the front of Q, so that the NMS and the output pass touch no entry that cannot matter.  The
+      //         dual-tagged ones (both polarities passed: the main entry scores the dark one) are listed once more from the back of
+      //         Q for the bright one -- here, in 3.4 trips per cell, not in the test's 15.
       int nc = 0;
       for (int j0 = 0; j0 < nq; j0 += 64) {
         const bool act = j0 + lane < nq;
@@ -322,10 +311,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         const int A = arc_score1<PP>(P + iy * PP + xa + ix, (q & Q_BRIGHT) ? -1 : 1);
         const bool c = act && A > t_pass;
         if (c) V[(iy + 1) * PV + ix + 1] = (uint8_t)min(255, A);
-        const bool keep = c || (act && (q & Q_DUAL));
-        const unsigned long long m = __ballot(keep);
+        const bool dual = act && (q & Q_DUAL);
+        const bool keep = c || dual;
+        const unsigned long long m = __ballot(keep), m2 = __ballot(dual);
         if (keep) Q[nc + mbcnt64(m, 0)] = (uint16_t)q;  // (in place: this trip's entries were all read above, later trips read further back)
         nc += __popcll(m);
+        if (m2) {
+          const int k = __popcll(m2);
+          if (nq + nd + k <= q_cap) {  // (the unread part of the front ends at nq)
+            if (dual) Q[q_cap - 1 - (nd + mbcnt64(m2, 0))] = (uint16_t)q;
+            nd += k;
+          } else {
+            d_overflow = true;  // (pathological cell) the tagged entries are re-scanned one by one below
+          }
+        }
       }
       nq = nc;
       if (nd > 0 || d_overflow) {
