@@ -500,7 +500,9 @@ void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, co
                       n_img);
     return;
   }
-  const bool split = side && ev_go && ev_done && side_from > 0 && side_from < n_levels;
+  // side_from < 0: every (-side_from)-th ... alternate levels (1, 3, 5 ... for -1) go to the side stream
+  const bool alt = side && ev_go && ev_done && side_from < 0;
+  const bool split = alt || (side && ev_go && ev_done && side_from > 0 && side_from < n_levels);
   if (split) {
     (void)hipEventRecord(ev_go, s);
     (void)hipStreamWaitEvent(side, ev_go, 0);
@@ -508,7 +510,8 @@ void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, co
   for (int l = 0; l < n_levels; ++l) {
     const int n_cells = h_lv[l].n_cells;
     if (n_cells <= 0 || lvl_max_pw[l] <= 6 || lvl_max_ph[l] <= 6) continue;
-    launch_fast_cells((split && l >= side_from) ? side : s, d_lv, d_cells, lvl_max_pw[l], lvl_max_ph[l], d_pyr, img_pitch, t_hi, t_lo, d_cand,
+    const bool on_side = alt ? ((l % (1 - side_from)) != 0) : (split && l >= side_from);
+    launch_fast_cells(on_side ? side : s, d_lv, d_cells, lvl_max_pw[l], lvl_max_ph[l], d_pyr, img_pitch, t_hi, t_lo, d_cand,
                       cand_pitch, d_n_cand, n_levels, (int)h_lv[l].cell_base, n_cells, n_img);
   }
   if (split) {

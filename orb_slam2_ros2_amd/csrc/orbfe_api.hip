@@ -190,6 +190,8 @@ struct orbfe_ctx {
   std::atomic<bool> stereo_pending{false};  // (read by slot calls on other threads)
   bool pipeline_stereo = true;
   hipStream_t blur_stream = nullptr;
+  hipStream_t fast_stream = nullptr;  // k_fast's odd levels (ORBFE_FAST_ALT): a launch's tail of half-empty CUs runs under the next level's start
+  int fast_alt = 0;
   hipEvent_t ev_blur_go = nullptr, ev_blur_done = nullptr, ev_fast_go = nullptr, ev_fast_done = nullptr;
   int fast_side_from = 0;  // k_fast launches of levels >= this run on the blur stream beside the large levels (ORBFE_FAST_SIDE_FROM; 0: off -- the default
                            // since the level-0 blur occupies that stream until well into FAST: the small levels queued behind it, 3 / 5 / 0: 5.75 / 5.72 / 5.71 ms)
@@ -940,8 +942,9 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   {
     StageTimer t(c, ORBFE_STAGE_FAST, st, timing);
     launch_fast(st, c->d_lv, c->d_cells, c->lv.data(), c->lvl_max_pw, c->lvl_max_ph, pyr, c->img_pitch, c->cfg.fast_hi, c->cfg.fast_lo,
-                c->d_scr_a + i0 * c->scratch_pitch, c->scratch_pitch, n_cand, nl, n_img, overlap_blur ? c->blur_stream : nullptr,
-                c->ev_fast_go, c->ev_fast_done, c->fast_side_from);
+                c->d_scr_a + i0 * c->scratch_pitch, c->scratch_pitch, n_cand, nl, n_img,
+                (c->fast_alt && c->fast_stream && timing && n_img >= 32) ? c->fast_stream : (overlap_blur ? c->blur_stream : nullptr),
+                c->ev_fast_go, c->ev_fast_done, (c->fast_alt && c->fast_stream && timing && n_img >= 32) ? -c->fast_alt : c->fast_side_from);
   }
   if (overlap_blur && !blur_queued) {
     HIP_TRY(c, hipEventRecord(c->ev_blur_go, st));
@@ -1040,6 +1043,7 @@ void orbfe_destroy(orbfe_ctx* c) {
     if (sl && sl->stream) (void)hipStreamSynchronize(sl->stream);
   if (c->stereo_stream) (void)hipStreamSynchronize(c->stereo_stream);
   if (c->blur_stream) (void)hipStreamSynchronize(c->blur_stream);
+  if (c->fast_stream) (void)hipStreamSynchronize(c->fast_stream);
   for (int k = 0; k < orbfe_ctx::kMaxSide; ++k)
     if (c->side[k]) (void)hipStreamSynchronize(c->side[k]);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -1087,6 +1091,7 @@ void orbfe_destroy(orbfe_ctx* c) {
   if (c->ev_fast_go) (void)hipEventDestroy(c->ev_fast_go);
   if (c->ev_fast_done) (void)hipEventDestroy(c->ev_fast_done);
   if (c->blur_stream) (void)hipStreamDestroy(c->blur_stream);
+  if (c->fast_stream) (void)hipStreamDestroy(c->fast_stream);
   if (c->stereo_stream) (void)hipStreamDestroy(c->stereo_stream);
   if (c->ev_brief_done) (void)hipEventDestroy(c->ev_brief_done);
   if (c->ev_stereo_done) (void)hipEventDestroy(c->ev_stereo_done);
@@ -1184,7 +1189,9 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     if (const char* xl = getenv("ORBFE_EXT_LEVEL0")) c->ext_level0 = atoi(xl) != 0;
     const char* ov = getenv("ORBFE_OVERLAP_BLUR");
     if (!ov || atoi(ov) != 0) {
+      if (const char* fa = getenv("ORBFE_FAST_ALT")) c->fast_alt = atoi(fa);
       if (hipStreamCreateWithFlags(&c->blur_stream, hipStreamNonBlocking) != hipSuccess ||
+          hipStreamCreateWithFlags(&c->fast_stream, hipStreamNonBlocking) != hipSuccess ||
           hipEventCreateWithFlags(&c->ev_blur_go, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&c->ev_blur_done, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&c->ev_fast_go, hipEventDisableTiming) != hipSuccess ||
