@@ -503,6 +503,8 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                        d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos, d_desc, h_desc);
     return;
   }
+  // (measured and dropped: two or three groups of four keypoints per wave in k_ic_moments, all their loads in flight together -- the stage
+  //  1.33 / 1.39 ms with one, 1.31 / 1.38 with two, 1.33 / 1.38 with three: the kernel is not waiting on its own round trips;)
   // (measured and dropped: k_brief's XCD-aware block order for k_ic_moments -- 5.61 / 5.66 ms per 512 pairs without, 5.69 / 5.66 with)
   // (measured for batches and dropped: the list entry built inside the moments kernel, k_orient kept -- 5.550 / 5.543 ms per 512 pairs
   //  without, 5.553 / 5.557 with: the list kernel's 0.12 ms hide nothing the moments do not already wait for)

@@ -576,6 +576,9 @@ def test_device_batch_whose_resize_reads_the_callers_images(orc, lib):
             for buf, img in ((buf_l, L), (buf_r, R)):
                 view = buf[p * pitch:p * pitch + 376 * stride].view(376, stride)
                 view[:, :1241] = torch.from_numpy(img).cuda()
+        # the strided copies above are kernels on torch's stream; the context works on streams of its own and takes the images as READY
+        # (include/orbfe.h, orbfe_stereo_batch_device): without this the last image written can still be in flight when it is read
+        torch.cuda.synchronize()
         ctx.stereo_batch_device(buf_l.data_ptr(), buf_r.data_ptr(), stride, pitch, B, FX, BF)
         ctx.sync()
         for f, r in ref.items():
