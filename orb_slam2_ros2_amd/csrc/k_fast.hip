@@ -457,13 +457,13 @@ void fast_lds_layout(int max_pw, int max_ph, int pp, int pv, int* v_off, int* q_
 // tools/exp/fast_sq.sh) with 3.5 x the LDS bank-conflict cycles: 2.22 ms against 2.07.
 static void launch_fast_cells(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, int max_pw, int max_ph, const uint8_t* d_pyr,
                               size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch, int32_t* d_n_cand, int n_levels,
-                              int cell_first, int n_cells, int n_img) {
+                              int cell_first, int n_cells, int n_img, int cpw_force) {
   int v_off, q_off, q_cap, total;
   const int pp = max_pw <= FAST_PP40_MAX ? 40 : (max_pw <= 44 ? 48 : 80), pv = max_pw <= FAST_PV36_MAX ? 36 : (max_pw <= 44 ? 40 : 72);
   fast_lds_layout(max_pw, max_ph, pp, pv, &v_off, &q_off, &q_cap, &total);
   // cells per wave: one for the drop-in path's launches (every cell its own wave: the launch is a single wave lifetime), FAST_CPW where the
   // launch holds many rounds of waves anyway
-  const int cpw = (long long)n_cells * n_img >= 65536 ? FAST_CPW : 1;
+  const int cpw = cpw_force > 0 ? cpw_force : ((long long)n_cells * n_img >= 65536 ? FAST_CPW : 1);  // (ORBFE_FAST_CPW: the tests' way into the cell loop with small inputs)
   const int n_groups = (n_cells + cpw - 1) / cpw;
 #define FAST_GO(K) hipLaunchKernelGGL(K, dim3(n_groups, n_img), dim3(64), total, s, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo, d_cand, \
                                       cand_pitch, d_n_cand, n_levels, cell_first, n_cells, v_off, q_off, q_cap, n_groups)
@@ -478,7 +478,7 @@ static void launch_fast_cells(hipStream_t s, const LevelDev* d_lv, const CellDev
 // patches need.  Measured: merging levels 0..3 into one launch with their common carve-up is 5 % slower than the four separate launches.
 void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, const LevelDev* h_lv, const int* lvl_max_pw,
                  const int* lvl_max_ph, const uint8_t* d_pyr, size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch,
-                 int32_t* d_n_cand, int n_levels, int n_img, hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, int side_from) {
+                 int32_t* d_n_cand, int n_levels, int n_img, hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, int side_from, int cpw_force) {
   // side (nullable): the launches of levels >= side_from go to this stream (after ev_go, recorded on s here; ev_done joins them
   // back into s): the small levels do not fill the machine and their waves run in the tails the large levels' launches leave
   if (n_img <= 0) return;
@@ -497,7 +497,7 @@ void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, co
   }
   if ((long long)total_cells * n_img <= 16384 && max_pw > 6 && max_ph > 6) {
     launch_fast_cells(s, d_lv, d_cells, max_pw, max_ph, d_pyr, img_pitch, t_hi, t_lo, d_cand, cand_pitch, d_n_cand, n_levels, 0, total_cells,
-                      n_img);
+                      n_img, cpw_force);
     return;
   }
   // side_from < 0: every (-side_from)-th ... alternate levels (1, 3, 5 ... for -1) go to the side stream
@@ -512,7 +512,7 @@ void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, co
     if (n_cells <= 0 || lvl_max_pw[l] <= 6 || lvl_max_ph[l] <= 6) continue;
     const bool on_side = alt ? ((l % (1 - side_from)) != 0) : (split && l >= side_from);
     launch_fast_cells(on_side ? side : s, d_lv, d_cells, lvl_max_pw[l], lvl_max_ph[l], d_pyr, img_pitch, t_hi, t_lo, d_cand,
-                      cand_pitch, d_n_cand, n_levels, (int)h_lv[l].cell_base, n_cells, n_img);
+                      cand_pitch, d_n_cand, n_levels, (int)h_lv[l].cell_base, n_cells, n_img, cpw_force);
   }
   if (split) {
     (void)hipEventRecord(ev_done, side);

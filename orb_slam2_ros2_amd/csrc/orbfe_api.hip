@@ -35,7 +35,7 @@ void launch_load_level0(hipStream_t st, const uint8_t* d_src, const uint8_t* d_s
 // k_fast.hip
 void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, const LevelDev* h_lv, const int* lvl_max_pw,
                  const int* lvl_max_ph, const uint8_t* d_pyr, size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch,
-                 int32_t* d_n_cand, int n_levels, int n_img, hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, int side_from);
+                 int32_t* d_n_cand, int n_levels, int n_img, hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, int side_from, int cpw_force);
 // k_quadtree.hip
 size_t quadtree_lds_bytes(int node_cap, int rec_cap);
 hipError_t quadtree_configure(size_t lds_bytes);
@@ -192,6 +192,7 @@ struct orbfe_ctx {
   hipStream_t blur_stream = nullptr;
   hipStream_t fast_stream = nullptr;  // k_fast's odd levels (ORBFE_FAST_ALT): a launch's tail of half-empty CUs runs under the next level's start
   int fast_alt = 0;
+  int fast_cpw = 0;  // ORBFE_FAST_CPW: cells per k_fast wave (0: one for small launches, four for large ones)
   hipEvent_t ev_blur_go = nullptr, ev_blur_done = nullptr, ev_fast_go = nullptr, ev_fast_done = nullptr;
   int fast_side_from = 0;  // k_fast launches of levels >= this run on the blur stream beside the large levels (ORBFE_FAST_SIDE_FROM; 0: off -- the default
                            // since the level-0 blur occupies that stream until well into FAST: the small levels queued behind it, 3 / 5 / 0: 5.75 / 5.72 / 5.71 ms)
@@ -944,7 +945,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     launch_fast(st, c->d_lv, c->d_cells, c->lv.data(), c->lvl_max_pw, c->lvl_max_ph, pyr, c->img_pitch, c->cfg.fast_hi, c->cfg.fast_lo,
                 c->d_scr_a + i0 * c->scratch_pitch, c->scratch_pitch, n_cand, nl, n_img,
                 (c->fast_alt && c->fast_stream && timing && n_img >= 32) ? c->fast_stream : (overlap_blur ? c->blur_stream : nullptr),
-                c->ev_fast_go, c->ev_fast_done, (c->fast_alt && c->fast_stream && timing && n_img >= 32) ? -c->fast_alt : c->fast_side_from);
+                c->ev_fast_go, c->ev_fast_done, (c->fast_alt && c->fast_stream && timing && n_img >= 32) ? -c->fast_alt : c->fast_side_from, c->fast_cpw);
   }
   if (overlap_blur && !blur_queued) {
     HIP_TRY(c, hipEventRecord(c->ev_blur_go, st));
@@ -1185,6 +1186,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     if (const char* hl = getenv("ORBFE_LBA_HOST_LM")) c->lm_on_device = atoi(hl) == 0;
     if (const char* tc = getenv("ORBFE_LM_TAIL_CTRL")) c->lm_tail_ctrl = atoi(tc) != 0;
     if (const char* pm = getenv("ORBFE_POSE_IN_MEMORY")) c->pose_in_memory = atoi(pm) != 0;
+    if (const char* fc = getenv("ORBFE_FAST_CPW")) c->fast_cpw = std::max(0, std::min(64, atoi(fc)));
     if (const char* be = getenv("ORBFE_BLUR_L0_EARLY")) c->blur_l0_early = atoi(be) != 0;
     if (const char* xl = getenv("ORBFE_EXT_LEVEL0")) c->ext_level0 = atoi(xl) != 0;
     const char* ov = getenv("ORBFE_OVERLAP_BLUR");

@@ -75,6 +75,8 @@ KNOBS = [
     {"ORBFE_EXT_LEVEL0": "0"},            # copy level 0 in first, then resize from the copy (default: the resize reads the caller's images beside the copy-in)
     {"ORBFE_FAST_SIDE_FROM": "3"},        # the k_fast launches of levels >= 3 on the second stream
     {"ORBFE_FAST_SIDE_FROM": "5"},
+    {"ORBFE_FAST_CPW": "4"},              # k_fast: four cells per wave in every launch (default: only where a launch holds >= 65536 cells)
+    {"ORBFE_FAST_CPW": "7"},
     {"ORBFE_FAST_ALT": "1"},              # k_fast's odd levels on a stream of their own (default: all eight launches in line)
     {"ORBFE_NO_XCD_ORDER": "1"},          # row-major cell / tile tables
     {"ORBFE_RESIZE_REGIONS": "0"},        # resize by the per-class output tiles instead of the region-driven single pass

@@ -176,6 +176,30 @@ def test_flat_and_noise_only_images(orc, lib):
     ctx.close()
 
 
+@pytest.mark.parametrize("cpw", ["2", "5"])
+def test_fast_cell_loop_on_noise_and_on_a_frame(orc, lib, cpw, monkeypatch):
+    """k_fast's cell loop (several cells per wave: the next patch prefetched, a cell's records stored a cell later) is what large
+    batches run; ORBFE_FAST_CPW (read at orbfe_create) forces it for single images, so that its rare branches see the pathological
+    cells too: more than 64 kept maxima in a cell (stored at once, not deferred), the dual-polarity list and its overflow, empty
+    cells between full ones."""
+    monkeypatch.setenv("ORBFE_FAST_CPW", cpw)
+    ctx = lib.Context(400, 300, n_features=500, n_levels=4, max_images=1)
+    half = np.full((300, 400), 128, np.uint8)
+    half[:, 200:] = (np.random.default_rng(7).integers(0, 2, (300, 200)) * 255).astype(np.uint8)  # flat cells beside salt-and-pepper ones
+    for img in (np.random.default_rng(1).integers(0, 256, (300, 400)).astype(np.uint8),
+                (np.random.default_rng(2).integers(0, 2, (300, 400)) * 255).astype(np.uint8),
+                ((np.indices((300, 400)).sum(0) & 1) * 200 + np.random.default_rng(3).integers(0, 40, (300, 400))).astype(np.uint8), half):
+        k, d = ctx.extract(img)
+        assert_image_parity(ctx, 0, orc.extractor(img, n_features=500, n_levels=4), k, d, 4)
+    ctx.close()
+    ctx = lib.Context(1241, 376, max_images=2)
+    L, R = synth.stereo_pair(6)
+    (lk, ld), (rk, rd) = ctx.extract_batch([L, R])
+    assert_image_parity(ctx, 0, orc.extractor(L), lk, ld, 8)
+    assert_image_parity(ctx, 1, orc.extractor(R), rk, rd, 8)
+    ctx.close()
+
+
 def test_blur_variant_and_custom_template(orc, lib):
     img, _ = synth.stereo_pair(2, 640, 360, n_rect=150)
     r = np.random.default_rng(9)
