@@ -2,8 +2,9 @@
 //
 // Replaces the cell loop of ORBExtractor::extractFast (src/ORB_SLAM2/src/ORBExtractor.cc:346-375):
 //   cv::FAST(patch, kps, iniThFAST, true);  if (kps.empty()) cv::FAST(patch, kps, minThFAST, true);
-// One wavefront per cell patch (what the reference hands to cv::FAST as a ROI view), so NMS and the
-// fallback see exactly the pixels cv::FAST would see (seams between cells are NOT suppressed).
+// One wavefront works on ONE cell patch at a time (what the reference hands to cv::FAST as a ROI view), so NMS and the
+// fallback see exactly the pixels cv::FAST would see (seams between cells are NOT suppressed); in large launches a wave takes
+// several cells in turn, the next one's patch travelling while the current one is worked on (k_fast's own comment).
 //
 // Formulation (proved equivalent to OpenCV's FAST_t<16> + cornerScore<16> in DESIGN.md):
 //   d_k = v - ring_k;  A = max over the 16 arcs of 9 contiguous ring pixels of min(d);  B = same for -d
@@ -13,7 +14,7 @@
 // so one V map serves both thresholds; the cell emits {V > hi} if that set is non-empty, else {V > lo}.
 //
 // Work-efficient schedule inside the wave (most pixels are not corners):
-//   1. patch -> LDS with aligned 32-bit loads;
+//   1. patch -> registers -> LDS in 16-byte units;
 //   2. every interior pixel takes a 9-read necessary test (a 9-arc contains one pixel of each opposite ring
 //      pair, so min over 4 pairs of max(pair) must exceed v+t, or max of min(pair) be below v-t); survivors are
 //      appended -- one entry per pixel, tagged with the polarity to score and whether both passed -- to an LDS queue with ballot/prefix;
