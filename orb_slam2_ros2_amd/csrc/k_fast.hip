@@ -146,12 +146,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   };
   // (every lane loads, rows and units clamped into the patch: a load behind a lane condition leaves the compiler merging old and new
   //  register values right behind it -- a wait for the data where it was only meant to be requested)
-  auto fetch = [&](const CellDev& c, uint4 (&wv)[NB]) __attribute__((always_inline)) {
+  // (dry, wave-uniform: the request of a wave's last cell, which has no successor -- every lane asks for the patch's first 16 bytes, one
+  //  cache line per load instead of a patch that would be dropped: the whole patch again cost 16 % more fetched bytes per sweep)
+  auto fetch = [&](const CellDev& c, uint4 (&wv)[NB], bool dry) __attribute__((always_inline)) {
     FAST_ROW_PART();
     const int nbytes = ((c.x0 & 3) + c.pw + 3) & ~3;  // bytes of a patch row that are needed
     const uint8_t* src = patch_src(c);
-    const int stride = lv[c.level].stride;
-    const int xoff = 16 * part < nbytes ? 16 * part : 0;  // (a unit that starts past the needed bytes may lie past the row: it loads the row's first instead and is never parked)
+    const int stride = dry ? 0 : lv[c.level].stride;
+    const int xoff = (16 * part < nbytes && !dry) ? 16 * part : 0;  // (a unit that starts past the needed bytes may lie past the row: it loads the row's first instead and is never parked)
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
       const int r = min(row0 + RPP * it, c.ph - 1);
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 
   CellDev cell = load_cell(ci);
   uint4 wv[NB];
-  fetch(cell, wv);
+  fetch(cell, wv, false);
   FAST_PATCH_ARRIVED();
   park(cell, wv);
   // the previous cell's records, one per lane, waiting for its list reservation (lane 0 of base_prev) to return
@@ -236,10 +238,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         for (int k = lane; k < vq; k += 64) V128[k] = make_uint4(0u, 0u, 0u, 0u);
       }
     }
-    // the next cell's patch travels while this one is worked on (unconditionally -- a wave's last cell asks for its own patch once
-    // more and drops it --: behind `if (has_next)` the registers become a merge of old and new values, copied, and so waited for, at once)
+    // the next cell's patch travels while this one is worked on (unconditionally -- a wave's last cell makes a dry request --: behind
+    // `if (has_next)` the registers become a merge of old and new values, copied, and so waited for, at once)
     const CellDev cell_next = load_cell(has_next ? ci_next : ci);
-    fetch(cell_next, wv);
+    fetch(cell_next, wv, !has_next);
     WAVE_SYNC();
 
     if (live) {
