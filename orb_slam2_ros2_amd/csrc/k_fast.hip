@@ -467,7 +467,9 @@ static void launch_fast_cells(hipStream_t s, const LevelDev* d_lv, const CellDev
   // cells per wave: one for the drop-in path's launches (every cell its own wave: the launch is a single wave lifetime), FAST_CPW where the
   // launch holds many rounds of waves anyway
   const int cpw = cpw_force > 0 ? cpw_force : ((long long)n_cells * n_img >= 65536 ? FAST_CPW : 1);  // (ORBFE_FAST_CPW: the tests' way into the cell loop with small inputs)
-  const int n_groups = (n_cells + cpw - 1) / cpw;
+  // a multiple of 8: the cell table is in XCD order (orbfe_create: table position = strip (mod 8), workgroups go round-robin to the 8 XCDs),
+  // so a wave's cells ci, ci + n_groups ... stay on its XCD's strip and the launch's rows of workgroups start on XCD 0 for every image
+  const int n_groups = ((n_cells + cpw - 1) / cpw + 7) & ~7;
 #define FAST_GO(K) hipLaunchKernelGGL(K, dim3(n_groups, n_img), dim3(64), total, s, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo, d_cand, \
                                       cand_pitch, d_n_cand, n_levels, cell_first, n_cells, v_off, q_off, q_cap, n_groups)
   if (pp == 40) FAST_GO((k_fast<40, 36>));
