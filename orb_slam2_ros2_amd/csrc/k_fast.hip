@@ -465,7 +465,8 @@ static void launch_fast_cells(hipStream_t s, const LevelDev* d_lv, const CellDev
   const int pp = max_pw <= FAST_PP40_MAX ? 40 : (max_pw <= 44 ? 48 : 80), pv = max_pw <= FAST_PV36_MAX ? 36 : (max_pw <= 44 ? 40 : 72);
   fast_lds_layout(max_pw, max_ph, pp, pv, &v_off, &q_off, &q_cap, &total);
   // cells per wave: one for the drop-in path's launches (every cell its own wave: the launch is a single wave lifetime), FAST_CPW where the
-  // launch holds many rounds of waves anyway
+  // launch holds many rounds of waves anyway (tools/exp/cpw_by_batch.sh, ms per step of 16 / 64 / 128 / 256 pairs: this rule 0.394 / 0.909 / 1.522 /
+  // 2.654, one cell everywhere 0.403 / 0.910 / 1.542 / 2.695, four everywhere 0.476 / 0.933 / 1.541 / 2.683)
   const int cpw = cpw_force > 0 ? cpw_force : ((long long)n_cells * n_img >= 65536 ? FAST_CPW : 1);  // (ORBFE_FAST_CPW: the tests' way into the cell loop with small inputs)
   // a multiple of 8: the cell table is in XCD order (orbfe_create: table position = strip (mod 8), workgroups go round-robin to the 8 XCDs),
   // so a wave's cells ci, ci + n_groups ... stay on its XCD's strip and the launch's rows of workgroups start on XCD 0 for every image
