@@ -431,6 +431,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   }
 }
 
+#undef FAST_PATCH_ARRIVED
+#undef FAST_ROW_PART
+#undef WAVE_SYNC
+
 // LDS carve-up for cell patches up to max_pw x max_ph with pitches pp / pv (host side helper)
 void fast_lds_layout(int max_pw, int max_ph, int pp, int pv, int* v_off, int* q_off, int* q_cap, int* total) {
   const int p_bytes = (max_ph * pp + 15) & ~15;
