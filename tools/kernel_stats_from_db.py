@@ -43,3 +43,27 @@ if iv:
     union += ce - cs
     span = max(e_ for _, e_ in iv) - iv[0][0]
     print(f'"# all kernels: union busy ns {union}, trace span ns {span}, idle fraction inside the span {1 - union / span:.4f}"')
+
+# template instances of one kernel (k_fast<40, 36>, k_fast<48, 36>: one per LDS carve-up) as ONE stage: the union over all of them
+import re
+groups = {}
+for n in names:
+    m = re.search(r"(\w+)<[^>]*>\(", n)
+    if m:
+        groups.setdefault(m.group(1), []).append(n)
+for base, members in groups.items():
+    if len(members) < 2:
+        continue
+    q = ",".join("?" * len(members))
+    iv = db.execute(f"select start, end from kernels where name in ({q}) order by start", members).fetchall()
+    union, cs, ce = 0, iv[0][0], iv[0][1]
+    for s_, e_ in iv[1:]:
+        if s_ > ce:
+            union += ce - cs
+            cs, ce = s_, e_
+        else:
+            ce = max(ce, e_)
+    union += ce - cs
+    steps = max((r[1] for r in rows if "k_brief" in r[0]), default=0)
+    per = f", {union / steps / 1e6:.4f} ms per step ({steps} steps = calls of k_brief)" if steps else ""
+    print(f'"# {base}: {len(members)} template instances, {len(iv)} launches, union ns {union}{per}"')
