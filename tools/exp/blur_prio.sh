@@ -1,5 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box: the step by the blur stream's priority (ORBFE_BLUR_PRIO: 1 = highest, -1 = lowest, 0 = default)
+# (needs a library built from a patched tree: the experiment was reverted after the measurement recorded in DESIGN 4.9 -- the script documents how it was run)
 cd ${GRAFT_REPO_ROOT:-.}
 for rep in 1 2; do
 for n in 0 1 -1; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box: the step with the quadtree's per-level node tables / record caches on and off (ORBFE_QT_PER_LEVEL)
+# (needs a library built from a patched tree: the experiment was reverted after the measurement recorded in DESIGN 4.9 -- the script documents how it was run)
 cd ${GRAFT_REPO_ROOT:-.}
 for rep in 1 2; do
 for n in 0 1; do
