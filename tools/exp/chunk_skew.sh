@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box: half-batch streams (ORBFE_STREAMS) with and without the skew experiment (ORBFE_CHUNK_SKEW=1: a chunk's FAST waits for
-# (needs a library built from a patched tree: the experiment was reverted after the measurement recorded in DESIGN 4.9 -- the script documents how it was run)
 # the previous chunk's, so that one chunk's vector-bound head runs beside the other's latency-bound tail).  Needs a build with the experiment.
+# (needs a library built from a patched tree: the experiment was reverted after the measurement recorded in DESIGN 4.9 -- the script documents how it was run)
 cd ${GRAFT_REPO_ROOT:-.}
 for rep in 1 2; do
 for kv in "ORBFE_STREAMS=1" "ORBFE_STREAMS=2" "ORBFE_STREAMS=2 ORBFE_CHUNK_SKEW=1" "ORBFE_STREAMS=3 ORBFE_CHUNK_SKEW=1" "ORBFE_STREAMS=4 ORBFE_CHUNK_SKEW=1"; do

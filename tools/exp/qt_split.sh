@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box: the step with ORBFE_QT_SPLIT (the chunk's quadtree in two halves, the first half's lists / moments / orientation /
-# (needs a library built from a patched tree: the experiment was reverted after the measurement recorded in DESIGN 4.9 -- the script documents how it was run)
 # descriptors on a second stream beside the second half's trees); bench.py checks every pair against the golden digests first
+# (needs a library built from a patched tree: the experiment was reverted after the measurement recorded in DESIGN 4.9 -- the script documents how it was run)
 cd ${GRAFT_REPO_ROOT:-.}
 for rep in 1 2; do
 for n in 0 1; do
