@@ -7,7 +7,10 @@
 // is (a) across the (image, level) pairs of a batch -- one wave each -- and (b) inside one expansion step.
 // The cost that matters is the LATENCY of one pop+split (a level needs 40-150 of them, one after the
 // other), so everything a step touches lives in LDS:
-//   * node table (bounds in fp64, key = count<<32 | ~insertion_seq, segment begin) in LDS;
+//   * node table in LDS, 16 bytes per node: key = count<<32 | ~insertion_seq, segment begin | pre-partition code, and the node's
+//     PATH (strip, depth, column / row index at that depth: two bits per halving).  The fp64 bounds are not stored: a split replays
+//     the reference's own halvings (b + e) / 2 from the strip bounds down the path (node_mid) -- a node with two or more records spans
+//     more than a pixel, so it is at most 11 halvings deep (coordinates are 12-bit) and its children 12;
 //   * the candidate records (x:12 | y:12 | response:8, 4 bytes) in ONE LDS array; a node owns a contiguous
 //     segment; a node with <= 512 records is split IN PLACE through registers (8 records per lane, ballots
 //     give the stable 4-way partition); only the few big nodes near the root bounce through a global
@@ -93,6 +96,34 @@ __device__ __forceinline__ int quadrant_of(uint32_t p, const SplitInt& s) {
   return (qx >= 0 && qy >= 0) ? (qy * 2 + qx) : -1;  // rows outer, cols inner (ORBExtractor.cc:60-72)
 }
 
+// ---- node path -------------------------------------------------------------------------------------------------------------------
+// strip (4 bits) | depth (4 bits) | column index at that depth (12 bits) | row index (12 bits).  The reference's child bounds are
+// (b, (b + e) / 2) and ((b + e) / 2, e) per axis (ORBExtractor.cc:60-72), rows and columns halved independently, so the bounds of a
+// node are a function of its strip and the halves taken: they are REPLAYED with the same fp64 operations when the node is split,
+// never stored (32 of a node's 44 bytes were four doubles; at 16 bytes a tree's table is 7 KB and sixteen trees fit a CU).
+// Depth <= 12 is enough: only nodes with two or more records are ever split (a table whose largest count is one can never reach
+// the quota: every pop replaces a one-record node by at most one one-record child until all have vanished -- tree_body returns the
+// empty selection at once), two distinct pixels strictly inside a node need it wider or higher than one pixel, and coordinates are
+// below 4096.
+#define QT_PATH(s, d, ix, iy) (((uint32_t)(s) << 28) | ((uint32_t)(d) << 24) | ((uint32_t)(ix) << 12) | (uint32_t)(iy))
+#define QT_PATH_CHILD(p, q) \
+  (((p)&0xF0000000u) | ((((p) >> 24) & 15u) + 1u) << 24 | ((((p) >> 11) & 0xFFEu) | ((uint32_t)(q)&1u)) << 12 | ((((p) << 1) & 0xFFEu) | ((uint32_t)(q) >> 1)))
+__device__ __forceinline__ void node_mid(const LevelDev& L, uint32_t path, double& midx, double& midy) {
+  const int s = (int)(path >> 28), d = (int)((path >> 24) & 15u);
+  const uint32_t ix = (path >> 12) & 0xFFFu, iy = path & 0xFFFu;
+  double cb = L.strips[s], ce = L.strips[s + 1], rb = 0.0, re = (double)L.reg_h;
+  for (int k = d - 1; k >= 0; --k) {
+    const double mx = (cb + ce) / 2, my = (rb + re) / 2;
+    const bool hx = (ix >> k) & 1u, hy = (iy >> k) & 1u;
+    cb = hx ? mx : cb;
+    ce = hx ? ce : mx;
+    rb = hy ? my : rb;
+    re = hy ? re : my;
+  }
+  midx = (cb + ce) / 2;
+  midy = (rb + re) / 2;
+}
+
 // candidate order of the reference = (cell row, cell column, y, x): cells are visited row-major and cv::FAST emits
 // a patch in raster order (ORBExtractor.cc:346-373).  39-bit key, smaller = earlier.
 __device__ __forceinline__ unsigned long long order_key(uint32_t rec, const LevelDev& L) {
@@ -146,6 +177,7 @@ __device__ __forceinline__ int strip_of(uint32_t rec, const LevelDev& L) {
 #define QT_PP_TOTALS 84    // levels 1-3, LDS
 #define QT_PP_TOTALS4 256  // level 4, global memory
 #define QT_PP_MAX_STRIPS 4
+#define QT_PP_HALF 704       // 11 rows of 64 groups: see the packed counters in tree_body
 #define QT_CODE_SHIFT 22
 #define QT_BEG_MASK 0x3FFFFFu  // n_beg = segment begin | pre-partition code << 22 (0: a node split the ordinary way)
 
@@ -261,8 +293,8 @@ __device__ int g_qt_stamp_count;
 #endif
 template <bool IN_LDS, int NW, bool NODES_LDS = true>
 __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __restrict__ A, int N, uint32_t* H, uint32_t* __restrict__ T,
-                                          double* n_rb, double* n_re, double* n_cb, double* n_ce, unsigned long long* n_key,
-                                          uint32_t* n_beg, unsigned long long* sortbuf, unsigned long long* bkey, uint32_t* bj,
+                                          unsigned long long* n_key, uint2* n_bp /* = n_key + node_cap: x = begin | code, y = path */,
+                                          unsigned long long* sortbuf, unsigned long long* bkey, uint32_t* bj,
                                           uint32_t* shared_ints, int batch_on, int node_cap, int need,
                                           int sort_cap, uint32_t* __restrict__ out_sel, int32_t* __restrict__ sel_count_out, int lane, int wv,
                                           const uint16_t* __restrict__ qt_tabs, uint16_t* tot4_lds = nullptr) {
@@ -275,32 +307,40 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
   // ---- first pop: the root, whose children are the initSplit strips (ORBExtractor.cc:81-96, 147-170) ----
   const int ns = L.n_ini;
   const int n_tot = (ns * QT_PP_TOTALS + 3) & ~3;
-  uint16_t* tot = (uint16_t*)(n_rb + node_cap) - n_tot;      // the totals of levels 1-3 live in the tail of the (still empty) node table ...
-  const int pp_limit = node_cap - (n_tot * 2 + 7) / 8;       // ... and are abandoned when the table grows into them
+  // The pre-partition borrows the (still empty) node table, node_cap * 16 bytes from n_key on: group counters, then cursors, as 16-bit
+  // halves of 32-bit words (N <= 65535; group g < QT_PP_HALF in the low half of word g, the others in the high half of word g - QT_PP_HALF,
+  // so that a lane of the cursor scan owns both halves of the words it writes) | the coordinate -> code tables (uint16) | ... | the
+  // totals of levels 1-3 in the table's tail, which stay until the table grows into them.
+  uint8_t* const tab_base = (uint8_t*)n_key;
+  uint16_t* tot = (uint16_t*)(tab_base + (size_t)node_cap * 16) - n_tot;
+  const int pp_limit = node_cap - (n_tot * 2 + 7) / 8;       // first node slot whose n_bp entry overlaps the parked totals
   const int n4_off = (N + 3) & ~3;                           // the fourth level's totals: global, behind the records of the bounce buffer
   // (tot4_lds: launches of a frame or two have the LDS to spare -- three of a level-0 tree's seven batched steps read these totals, and
   //  from global memory each read was a ~3 k-cycle round trip on the critical path)
   uint16_t* tot4 = tot4_lds ? tot4_lds : (uint16_t*)(T + n4_off);
-  // coordinate -> code tables (uint16) in the n_key array, cursors across n_cb | n_ce, x thresholds in n_re: the node table is not in use yet
   const int tab_w = (int)ceil(L.strips[ns]) + 1, tab_h = (int)ceil((double)L.reg_h) + 1;
   const int tab_w2 = (tab_w + 1) & ~1;
-  bool pp_ok = NODES_LDS && N > 0 && N <= 65535 && ns <= QT_PP_MAX_STRIPS && node_cap >= 176 && tab_w <= 4096 && tab_h <= 4096 &&
-               (tab_w2 + tab_h) * 2 <= node_cap * 8 && ns * QT_PP_GROUPS * 4 <= node_cap * 16 && ns * 15 * 8 <= node_cap * 8 &&
+  const int ng = ns * QT_PP_GROUPS;
+  const int cur_words = min(ng, QT_PP_HALF);
+  const int tab_words = (tab_w2 + tab_h + 1) >> 1;
+  bool pp_ok = NODES_LDS && N > 0 && N <= 65535 && ns <= QT_PP_MAX_STRIPS && tab_w <= 4096 && tab_h <= 4096 &&
+               (cur_words + tab_words) * 4 + n_tot * 2 <= node_cap * 16 &&
                (tot4_lds != nullptr || n4_off + ns * (QT_PP_TOTALS4 / 2) <= (int)L.cand_cap);
   if (pp_ok) {
-    const int ng = ns * QT_PP_GROUPS;
-    uint32_t* cur = (uint32_t*)n_cb;  // group sizes, then group cursors (runs on into n_ce)
-    uint16_t* xtab = (uint16_t*)n_key;
+    uint32_t* cur = (uint32_t*)tab_base;  // packed group sizes, then group cursors
+    uint16_t* xtab = (uint16_t*)(cur + cur_words);
     uint16_t* ytab = xtab + tab_w2;
-    for (int g = tid; g < ng; g += NT) cur[g] = 0;
+    auto cur_w = [&](int g) -> int { return g < QT_PP_HALF ? g : g - QT_PP_HALF; };
+    auto cur_sh = [&](int g) -> int { return g < QT_PP_HALF ? 0 : 16; };
+    auto cur_get = [&](int g) -> uint32_t { return (cur[cur_w(g)] >> cur_sh(g)) & 0xFFFFu; };
+    for (int g = tid; g < cur_words; g += NT) cur[g] = 0;
     // The coordinate -> code tables depend on the LEVEL's geometry alone (strip bounds, region height): the host builds them once per
     // context (quadtree_build_tables, the same fp64 operations) and a tree only copies its level's ~3 KB into LDS.  Built here, per tree,
     // they were 24 k of a level-0 tree's 224 k cycles with four waves (stamps build) -- and every tree wave of a batch paid them alone.
     {
       const uint32_t* src = (const uint32_t*)(qt_tabs + L.qt_tab_off);  // [tab_w2 | tab_h] uint16, 4-byte aligned
       uint32_t* dst = (uint32_t*)xtab;
-      const int n32 = (tab_w2 + tab_h + 1) >> 1;
-      for (int i = tid; i < n32; i += NT) dst[i] = src[i];
+      for (int i = tid; i < tab_words; i += NT) dst[i] = src[i];
     }
     __syncthreads();
     QTS(-10)  // tables
@@ -343,7 +383,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-          if (g[u] >= 0) atomicAdd(&cur[g[u]], 1u);  // LDS atomic; lanes of one group serialise, a chunk spans a handful of groups
+          if (g[u] >= 0) atomicAdd(&cur[cur_w(g[u])], 1u << cur_sh(g[u]));  // LDS atomic; lanes of one group serialise, a chunk spans a handful of groups
       }
     }
     __syncthreads();
@@ -351,22 +391,22 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     // totals of the 84 + 256 nodes below every strip, then sizes -> cursors (exclusive prefix in layout order)
     for (int t = tid; t < ns * QT_PP_TOTALS; t += NT) {
       const int st = t / QT_PP_TOTALS, k = t - QT_PP_TOTALS * st;
-      const uint32_t* c = cur + st * QT_PP_GROUPS;
+      const int c = st * QT_PP_GROUPS;
       uint32_t v = 0;
       if (k < 4) {
-        for (int i = 0; i < 85; ++i) v += c[k * 85 + i];
+        for (int i = 0; i < 85; ++i) v += cur_get(c + k * 85 + i);
       } else if (k < 20) {
         const int q1 = (k - 4) >> 2, q2 = (k - 4) & 3;
-        for (int i = 0; i < 21; ++i) v += c[q1 * 85 + q2 * 21 + i];
+        for (int i = 0; i < 21; ++i) v += cur_get(c + q1 * 85 + q2 * 21 + i);
       } else {
         const int m = k - 20;
-        for (int i = 0; i < 5; ++i) v += c[(m >> 4) * 85 + ((m >> 2) & 3) * 21 + (m & 3) * 5 + i];
+        for (int i = 0; i < 5; ++i) v += cur_get(c + (m >> 4) * 85 + ((m >> 2) & 3) * 21 + (m & 3) * 5 + i);
       }
       tot[t] = (uint16_t)v;
     }
     for (int t = tid; t < ns * QT_PP_TOTALS4; t += NT) {
       const int st = t / QT_PP_TOTALS4, m = t - QT_PP_TOTALS4 * st;  // m = 64 q1 + 16 q2 + 4 q3 + q4
-      tot4[t] = (uint16_t)cur[st * QT_PP_GROUPS + (m >> 6) * 85 + ((m >> 4) & 3) * 21 + ((m >> 2) & 3) * 5 + (m & 3)];
+      tot4[t] = (uint16_t)cur_get(st * QT_PP_GROUPS + (m >> 6) * 85 + ((m >> 4) & 3) * 21 + ((m >> 2) & 3) * 5 + (m & 3));
     }
     __syncthreads();
     QTS(-12)  // totals
@@ -380,7 +420,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) {
         const int g = r * 64 + lane;
-        vals[r] = (r * 64 < ng && g < ng) ? (int)cur[g] : 0;
+        vals[r] = (r * 64 < ng && g < ng) ? (int)cur_get(g) : 0;
       }
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) {
@@ -405,10 +445,11 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         }
       }
       qt_wsync<NW>();
+      static_assert(ROWS == 2 * (QT_PP_HALF / 64), "a lane owns both halves of a counter word");
 #pragma unroll
-      for (int r = 0; r < ROWS; ++r) {
+      for (int r = 0; r < ROWS / 2; ++r) {  // word r * 64 + lane = groups (r, lane) and (r + ROWS / 2, lane)
         const int g = r * 64 + lane;
-        if (r * 64 < ng && g < ng) cur[g] = (uint32_t)vals[r];
+        if (g < cur_words) cur[g] = (uint32_t)vals[r] | ((uint32_t)vals[r + ROWS / 2] << 16);  // (rows past the last group hold 0)
       }
     }
     strip_cnt -= strip_base;
@@ -436,7 +477,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         }
         uint32_t pos[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) pos[u] = (g[u] >= 0) ? atomicAdd(&cur[g[u]], 1u) : 0u;
+        for (int u = 0; u < 16; ++u) pos[u] = (g[u] >= 0) ? ((atomicAdd(&cur[cur_w(g[u])], 1u << cur_sh(g[u])) >> cur_sh(g[u])) & 0xFFFFu) : 0u;
 #pragma unroll
         for (int u = 0; u < 16; ++u)
           if (g[u] >= 0) H[pos[u]] = rec[u];  // the order inside a group is irrelevant (see above)
@@ -448,12 +489,8 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       const int off = __builtin_amdgcn_readlane(strip_base, st);
       if (c > 0) {
         if (lane == 0) {
-          n_rb[n_act] = 0.0;
-          n_re[n_act] = (double)L.reg_h;
-          n_cb[n_act] = L.strips[st];
-          n_ce[n_act] = L.strips[st + 1];
           n_key[n_act] = ((unsigned long long)c << 32) | (unsigned long long)(0xFFFFFFFFu - next_seq);
-          n_beg[n_act] = (uint32_t)off | ((uint32_t)(1 + st * QT_PP_INTERNAL + 84) << QT_CODE_SHIFT);
+          n_bp[n_act] = make_uint2((uint32_t)off | ((uint32_t)(1 + st * QT_PP_INTERNAL + 84) << QT_CODE_SHIFT), QT_PATH(st, 0, 0, 0));
         }
         ++n_act;
         ++next_seq;
@@ -490,12 +527,8 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       const int off = __builtin_amdgcn_readlane(run, st);
       if (c > 0) {
         if (lane == 0) {
-          n_rb[n_act] = 0.0;
-          n_re[n_act] = (double)L.reg_h;
-          n_cb[n_act] = L.strips[st];
-          n_ce[n_act] = L.strips[st + 1];
           n_key[n_act] = ((unsigned long long)c << 32) | (unsigned long long)(0xFFFFFFFFu - next_seq);
-          n_beg[n_act] = (uint32_t)off;
+          n_bp[n_act] = make_uint2((uint32_t)off, QT_PATH(st, 0, 0, 0));
         }
         ++n_act;
         ++next_seq;
@@ -561,6 +594,10 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         lmax = max(lmax, (uint32_t)(lk[u] >> 32));
       }
       const uint32_t mc = wave_max_u32(lmax);
+      if (mc <= 1u) {  // only one-record nodes are left and the quota is not reached: it never will be (see QT_PATH) -- the reference
+        n_act = 0;     // halves every point until it sits on a split line and returns the empty set (quirk Q3)
+        break;
+      }
       uint32_t C = (mc >> 1) + 1;  // the head = every node with count >= C: a prefix of the pop order whatever C is
       int B;
       for (;;) {
@@ -616,12 +653,16 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         const bool act = lane < B;
         const int j = (int)myj;
         const int n = (int)(mykey >> 32);
-        const double rb = n_rb[j], re = n_re[j], cb = n_cb[j], ce = n_ce[j];
-        const uint32_t beg_raw = n_beg[j];
+        const uint2 bp = n_bp[j];
+        const uint32_t beg_raw = bp.x, path = bp.y;
         const int beg = (int)(beg_raw & QT_BEG_MASK), code = (int)(beg_raw >> QT_CODE_SHIFT);
-        const double midy = (rb + re) / 2, midx = (cb + ce) / 2;
-        const SplitInt sp = make_split(midx, midy);
         const bool is_pp = pp_ok && code != 0;
+        SplitInt sp = {0, 0, 0, 0};
+        if (__ballot(act && !is_pp)) {  // (a pre-partitioned node reads its totals: no bounds)
+          double midx, midy;
+          node_mid(L, (act && !is_pp) ? path : 0u, midx, midy);
+          sp = make_split(midx, midy);
+        }
         const unsigned long long big = __ballot(act && !is_pp && n > 64);
         const int b_eff = big ? min(B, __ffsll((long long)big) - 1) : B;
         int c0 = 0, c1 = 0, c2 = 0, c3 = 0, child_code = 0;
@@ -704,12 +745,8 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
               const int rank = q == 0 ? 0 : (q == 1 ? ne0 : (q == 2 ? ne0 + ne1 : ne0 + ne1 + ne2));
               if (cc > 0) {
                 const int slot = rank == 0 ? j : slot0 + rank - 1;  // first child into the popped node's slot, the others appended
-                n_rb[slot] = (q & 2) ? midy : rb;
-                n_re[slot] = (q & 2) ? re : midy;
-                n_cb[slot] = (q & 1) ? midx : cb;
-                n_ce[slot] = (q & 1) ? ce : midx;
                 n_key[slot] = ((unsigned long long)cc << 32) | (unsigned long long)(0xFFFFFFFFu - (seq0 + (uint32_t)rank));
-                n_beg[slot] = (uint32_t)offc | ((uint32_t)(child_code ? child_code + q : 0) << QT_CODE_SHIFT);
+                n_bp[slot] = make_uint2((uint32_t)offc | ((uint32_t)(child_code ? child_code + q : 0) << QT_CODE_SHIFT), QT_PATH_CHILD(path, q));
               }
             }
             if (!is_pp) {  // in-place 4-way partition straight from the registers (the node's segment belongs to this lane alone)
@@ -757,16 +794,24 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       }
     }
     const uint32_t mc = wave_max_u32(bc);
+    if (mc <= 1u) {  // (as above: quirk Q3)
+      n_act = 0;
+      break;
+    }
     const uint32_t ms = wave_max_u32(bc == mc ? bs : 0u);
     const unsigned long long win = __ballot(bc == mc && bs == ms);
     const int j = __builtin_amdgcn_readlane(bj, __ffsll((long long)win) - 1);
-    const double rb = n_rb[j], re = n_re[j], cb = n_cb[j], ce = n_ce[j];
     const int n = (int)mc;
-    const uint32_t beg_raw = n_beg[j];
+    const uint2 bp = n_bp[j];
+    const uint32_t beg_raw = bp.x, path = bp.y;
     const int beg = (int)(beg_raw & QT_BEG_MASK), code = (int)(beg_raw >> QT_CODE_SHIFT);
     // (the popped node's slot is reused by its first child below: no erase-and-compact round trip through the table)
-    const double midy = (rb + re) / 2, midx = (cb + ce) / 2;
-    const SplitInt sp = make_split(midx, midy);
+    SplitInt sp = {0, 0, 0, 0};
+    if (!(pp_ok && code != 0)) {  // wave-uniform
+      double midx, midy;
+      node_mid(L, path, midx, midy);
+      sp = make_split(midx, midy);
+    }
     uint32_t* seg = H + beg;
     int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     int child_code = 0;  // pre-partition code of child 0 (children q get child_code + q), 0: none
@@ -877,25 +922,16 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       if (n_act + 3 > pp_limit) pp_ok = false;  // the table reaches the totals parked in its tail: split the ordinary way from now on
       if (lane < 4 && cc > 0) {
         const int slot = rank == 0 ? j : n_act + rank - 1;  // first child into the popped node's slot, the others appended
-        n_rb[slot] = (lane & 2) ? midy : rb;
-        n_re[slot] = (lane & 2) ? re : midy;
-        n_cb[slot] = (lane & 1) ? midx : cb;
-        n_ce[slot] = (lane & 1) ? ce : midx;
         n_key[slot] = ((unsigned long long)cc << 32) | (unsigned long long)(0xFFFFFFFFu - (next_seq + (uint32_t)rank));
-        n_beg[slot] = (uint32_t)offc | ((uint32_t)(child_code ? child_code + lane : 0) << QT_CODE_SHIFT);
+        n_bp[slot] = make_uint2((uint32_t)offc | ((uint32_t)(child_code ? child_code + lane : 0) << QT_CODE_SHIFT), QT_PATH_CHILD(path, lane));
       }
       const int added = ne0 + ne1 + ne2 + ne3;
       if (added == 0) {  // every record sat on a split line: the node disappears, the last entry fills its slot
         --n_act;
-        const double t0 = n_rb[n_act], t1 = n_re[n_act], t2 = n_cb[n_act], t3 = n_ce[n_act];
         const unsigned long long t4 = n_key[n_act];
-        const uint32_t t5 = n_beg[n_act];
-        n_rb[j] = t0;
-        n_re[j] = t1;
-        n_cb[j] = t2;
-        n_ce[j] = t3;
+        const uint2 t5 = n_bp[n_act];
         n_key[j] = t4;
-        n_beg[j] = t5;
+        n_bp[j] = t5;
       } else {
         n_act += added - 1;
       }
@@ -928,7 +964,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     --n_act;
     if (lane == 0 && j != n_act) {
       n_key[j] = n_key[n_act];
-      n_beg[j] = n_beg[n_act];
+      n_bp[j] = n_bp[n_act];
     }
     qt_wsync<NW>();
   }
@@ -947,7 +983,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
   sort_cap = min(sort_cap, sc);
   auto node_key = [&](int j) -> unsigned long long {
     if (j >= n_act) return ~0ull;
-    const uint32_t* p = H + (n_beg[j] & QT_BEG_MASK);
+    const uint32_t* p = H + (n_bp[j].x & QT_BEG_MASK);
     const int n = (int)(n_key[j] >> 32);
     uint32_t best = 0, br = 0;
     unsigned long long bk = ~0ull;
@@ -1070,7 +1106,6 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       }
     }
   } else {
-    // (the sort buffer aliases the fp64 bound arrays, which are dead now; keys / begins live behind them)
     for (int j = tid; j < sort_cap; j += NT) {
       const unsigned long long key = node_key(j);
       __syncthreads();
@@ -1113,7 +1148,7 @@ __global__ __launch_bounds__(64 * NW) void k_quadtree(const LevelDev* __restrict
                                                  const int32_t* __restrict__ n_cand, int node_cap, int sort_cap, int rec_cap, int batch,
                                                  QtGroups groups, uint8_t* __restrict__ big_base, size_t big_pitch,
                                                  const uint16_t* __restrict__ qt_tabs) {
-  extern __shared__ double lds[];
+  extern __shared__ unsigned long long lds[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int img = blockIdx.y;
   // One wave works through the trees of a GROUP of levels, one after the other (blockIdx.x = group; the host balances the groups by
@@ -1123,20 +1158,16 @@ __global__ __launch_bounds__(64 * NW) void k_quadtree(const LevelDev* __restrict
   for (uint32_t todo = groups.mask[blockIdx.x]; todo; todo &= todo - 1) {
   const int level = __builtin_ctz(todo);
   const LevelDev& L = lv[level];
-  // LDS carve-up: 4 fp64 bound arrays | u64 keys | u32 begins | records.  The sort buffer aliases the bounds.
-  double* n_rb = lds;
-  double* n_re = n_rb + node_cap;
-  double* n_cb = n_re + node_cap;
-  double* n_ce = n_cb + node_cap;
-  unsigned long long* n_key = (unsigned long long*)(n_ce + node_cap);
-  uint32_t* n_beg = (uint32_t*)(n_key + node_cap);
-  unsigned long long* bkey = (unsigned long long*)(n_beg + ((node_cap + 1) & ~1));  // head list of the batched pops: 64 keys + 64 slots
+  // LDS carve-up: u64 keys | (begin, path) pairs | head list of the batched pops | sort buffer (quotas above 512, or several waves per tree) | records.
+  unsigned long long* n_key = (unsigned long long*)lds;
+  uint2* n_bp = (uint2*)(n_key + node_cap);
+  unsigned long long* bkey = (unsigned long long*)(n_bp + node_cap);  // head list of the batched pops: 64 keys + 64 slots
   uint32_t* bj = (uint32_t*)(bkey + 64);
   uint32_t* shared_ints = bj + 64;  // [4]: what wave 0 tells the helper waves of a tree
-  uint32_t* lds_recs = shared_ints + 4;
+  unsigned long long* sortbuf = (unsigned long long*)(shared_ints + 4);
+  uint32_t* lds_recs = (uint32_t*)((uint8_t*)sortbuf + (sort_cap > 512 ? (size_t)sort_cap * 8 : (NW > 1 ? 2048 : 0)));
   // several waves per tree (launches of a frame or two): the level-4 totals of the pre-partition behind the record cache
   uint16_t* tot4_lds = NW > 1 ? (uint16_t*)(lds_recs + ((rec_cap + 3) & ~3)) : nullptr;
-  unsigned long long* sortbuf = (unsigned long long*)lds;
 
   uint32_t* out_sel = sel + (size_t)img * n_features + L.quota_off;
   const int need = L.quota;
@@ -1182,18 +1213,16 @@ __global__ __launch_bounds__(64 * NW) void k_quadtree(const LevelDev* __restrict
 
   if (L.qt_big_cap > 0) {  // the level's node table does not fit the LDS: everything in global memory
     const size_t cap = (size_t)L.qt_big_cap;
-    double* g_rb = (double*)(big_base + (size_t)img * big_pitch + L.qt_big_off);
-    double *g_re = g_rb + cap, *g_cb = g_re + cap, *g_ce = g_cb + cap;
-    unsigned long long* g_key = (unsigned long long*)(g_ce + cap);
-    uint32_t* g_beg = (uint32_t*)(g_key + cap);
-    unsigned long long* g_sort = (unsigned long long*)(g_beg + ((cap + 1) & ~(size_t)1));
-    tree_body<false, NW, false>(L, A, N, gb, gc, g_rb, g_re, g_cb, g_ce, g_key, g_beg, g_sort, bkey, bj, shared_ints, batch, (int)cap, need,
+    unsigned long long* g_key = (unsigned long long*)(big_base + (size_t)img * big_pitch + L.qt_big_off);
+    uint2* g_bp = (uint2*)(g_key + cap);
+    unsigned long long* g_sort = (unsigned long long*)(g_bp + cap);
+    tree_body<false, NW, false>(L, A, N, gb, gc, g_key, g_bp, g_sort, bkey, bj, shared_ints, batch, (int)cap, need,
                                 L.qt_big_sort, out_sel, sel_count + (size_t)img * n_levels + level, lane, wv, qt_tabs);
   } else if (in_lds)
-    tree_body<true, NW>(L, A, N, lds_recs, gb, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, bkey, bj, shared_ints, batch, node_cap, need, sort_cap,
+    tree_body<true, NW>(L, A, N, lds_recs, gb, n_key, n_bp, sortbuf, bkey, bj, shared_ints, batch, node_cap, need, sort_cap,
                         out_sel, sel_count + (size_t)img * n_levels + level, lane, wv, qt_tabs, tot4_lds);
   else
-    tree_body<false, NW>(L, A, N, gb, gc, n_rb, n_re, n_cb, n_ce, n_key, n_beg, sortbuf, bkey, bj, shared_ints, batch, node_cap, need, sort_cap,
+    tree_body<false, NW>(L, A, N, gb, gc, n_key, n_bp, sortbuf, bkey, bj, shared_ints, batch, node_cap, need, sort_cap,
                          out_sel, sel_count + (size_t)img * n_levels + level, lane, wv, qt_tabs, tot4_lds);
   // the next tree reuses the LDS: the accesses of one wave execute in order, the fence only pins the compiler
   if (NW > 1) __syncthreads();
@@ -1226,9 +1255,10 @@ bool quadtree_build_tables(const LevelDev& L, std::vector<uint16_t>& out) {
   return true;
 }
 
-size_t quadtree_lds_bytes(int node_cap, int rec_cap) {
-  return (size_t)node_cap * (4 * sizeof(double) + sizeof(unsigned long long) + sizeof(uint32_t)) + 8 + 64 * (sizeof(unsigned long long) + sizeof(uint32_t)) +
-         16 + (size_t)rec_cap * sizeof(uint32_t);
+// node table (16 bytes a node) + head list of the batched pops + flags + the sort buffer of quotas above 512 + record cache
+size_t quadtree_lds_bytes(int node_cap, int rec_cap, int sort_cap) {
+  return (size_t)node_cap * 16 + 64 * (sizeof(unsigned long long) + sizeof(uint32_t)) + 16 + (sort_cap > 512 ? (size_t)sort_cap * 8 : 0) +
+         (size_t)rec_cap * sizeof(uint32_t);
 }
 
 // The dynamic-LDS limit of a kernel is state of the process and the device, not of a context: contexts of different geometries come
@@ -1254,9 +1284,9 @@ void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const ui
                      int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree, uint8_t* d_big, size_t big_pitch,
                      const uint16_t* d_qt_tabs) {
   if (n_img <= 0) return;
-  const size_t lds = quadtree_lds_bytes(node_cap, rec_cap);
+  const size_t lds = quadtree_lds_bytes(node_cap, rec_cap, sort_cap);
   if (waves_per_tree >= 4)
-    hipLaunchKernelGGL(k_quadtree<4>, dim3(n_groups, n_img), dim3(256), lds + 16 + QT_PP_MAX_STRIPS * QT_PP_TOTALS4 * sizeof(uint16_t), s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
+    hipLaunchKernelGGL(k_quadtree<4>, dim3(n_groups, n_img), dim3(256), lds + 2048 + 16 + QT_PP_MAX_STRIPS * QT_PP_TOTALS4 * sizeof(uint16_t), s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
                        d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch, d_qt_tabs);
   else
     hipLaunchKernelGGL(k_quadtree<1>, dim3(n_groups, n_img), dim3(64), lds, s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,

@@ -37,7 +37,7 @@ void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, co
                  const int* lvl_max_ph, const uint8_t* d_pyr, size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch,
                  int32_t* d_n_cand, int n_levels, int n_img, hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, int side_from, int cpw_force);
 // k_quadtree.hip
-size_t quadtree_lds_bytes(int node_cap, int rec_cap);
+size_t quadtree_lds_bytes(int node_cap, int rec_cap, int sort_cap);
 hipError_t quadtree_configure(size_t lds_bytes);
 void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint32_t* d_cand, uint32_t* d_scr_b, uint32_t* d_scr_c,
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
@@ -228,6 +228,7 @@ struct orbfe_ctx {
   int rec_cap = 0;           // upper bound of candidate records one quadtree wave keeps in LDS (launch picks <= this)
   int qt_batch = 1;          // k_quadtree: several pops per step (ORBFE_QT_BATCH=0: one at a time)
   int qt_waves = 4;          // waves per tree in launches of a frame or two (ORBFE_QT_WAVES=1: one)
+  int qt_per_cu = 16;        // tree waves a launch aims to put on a CU (one round): the levels of an image are dealt to 1, 2 or 4 waves accordingly
   int n_cu = 256;            // compute units of the device
   int node_cap = 0, sort_cap = 0;
   int lvl_max_pw[ORBFE_MAX_LEVELS] = {0}, lvl_max_ph[ORBFE_MAX_LEVELS] = {0};  // largest FAST cell patch per level (sizes the LDS of k_fast)
@@ -665,7 +666,12 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
   // The node table of a level lives in one CU's LDS as far as that goes (~2700 nodes in 120 KB); the reference has no limit on
   // nFeatures (ORBExtractor.cc:291-301), so the levels with larger quotas keep theirs in global memory (k_quadtree, NODES_LDS = false)
   int lds_nodes = max_quota + max_ini + 8;
-  while (quadtree_lds_bytes(lds_nodes, 0) > 120 * 1024) lds_nodes -= 8;
+  auto sort_cap_of = [](int q) {
+    int sc = 2;
+    while (sc < q) sc <<= 1;
+    return sc;
+  };
+  while (quadtree_lds_bytes(lds_nodes, 0, sort_cap_of(lds_nodes)) > 120 * 1024) lds_nodes -= 8;
   if (const char* env = getenv("ORBFE_QT_LDS_NODES")) lds_nodes = std::max(64, std::min(lds_nodes, atoi(env)));  // (tests: force the global path)
   int max_lds_quota = 0;
   size_t big_off = 0;
@@ -680,7 +686,7 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
     int sl = 2;
     while (sl < quota[l]) sl <<= 1;
     L.qt_big_off = (uint32_t)big_off, L.qt_big_cap = cap_l, L.qt_big_sort = sl;
-    big_off += align_up((size_t)cap_l * 44 + 8 + (size_t)sl * 8, 256);
+    big_off += align_up((size_t)cap_l * 16 + (size_t)sl * 8, 256);
   }
   c->qt_big_pitch = big_off;
   // the pre-partition's coordinate -> code tables, per level (k_quadtree.hip, quadtree_build_tables)
@@ -694,25 +700,25 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
       c->lv[l].qt_tab_off = (uint32_t)c->qt_tabs.size();
       c->qt_tabs.insert(c->qt_tabs.end(), t.begin(), t.end());
       const int ns = c->lv[l].n_ini;
-      const int need = std::max({176, (int)((t.size() * 2 + 7) / 8), (ns * 341 + 3) / 4, ns * 15});
+      // bytes of the pre-partition's scratch (k_quadtree.hip, pp_ok): packed group counters + the two tables + the parked totals, in 16-byte nodes
+      const size_t pp_bytes = (size_t)std::min(ns * 341, 704) * 4 + ((t.size() + 1) / 2) * 4 + (size_t)((ns * 84 + 3) & ~3) * 2;
+      const int need = (int)((pp_bytes + 15) / 16) + 4;
       if (c->lv[l].qt_big_cap == 0) pp_nodes = std::max(pp_nodes, need);
     }
   }
   if (c->qt_tabs.size() < 2) c->qt_tabs.resize(2, 0);
   c->node_cap = std::min(lds_nodes, max_lds_quota + max_ini + 8);
-  // The node table is at least as large as the pre-partition's scratch, up to 1024 entries (45 KB): with nFeatures = 800 .. 1600 on
-  // a KITTI-sized image the largest quota is below the ~405 entries the coordinate tables of level 0 take, the pre-partition switched
+  // The node table is at least as large as the pre-partition's scratch, up to 1024 entries (16 KB): with nFeatures = 800 .. 1600 on
+  // a KITTI-sized image the largest quota is below the ~410 entries the scratch of level 0 takes, the pre-partition switched
   // itself off and the trees split their thousands of candidates 64 records a step -- 1.45 ms per 1024 images at nFeatures = 800
   // against 0.40 ms at 2000 (tools/exp/qt_occ.py).
-  if (!getenv("ORBFE_QT_LDS_NODES")) c->node_cap = std::max(c->node_cap, std::min(pp_nodes, 1024));  // (1920 x 1080: 735 entries, 32 KB per tree -- four trees per CU, still 3x faster than splitting 25 k candidates 64 at a time)
+  if (!getenv("ORBFE_QT_LDS_NODES")) c->node_cap = std::max(c->node_cap, std::min(pp_nodes, 1024));  // (1920 x 1080: ~600 entries, 9.5 KB per tree)
   c->node_cap = std::max(c->node_cap, 192);
-  int sc = 2;
-  while (sc < max_lds_quota) sc <<= 1;
-  c->sort_cap = sc;
+  c->sort_cap = sort_cap_of(max_lds_quota);
   {
     uint32_t max_cand = 0;
     for (int l = 0; l < nl; ++l) max_cand = std::max(max_cand, c->lv[l].cand_cap);
-    const size_t budget = 150 * 1024 - quadtree_lds_bytes(c->node_cap, 0);
+    const size_t budget = 150 * 1024 - quadtree_lds_bytes(c->node_cap, 0, c->sort_cap);
     c->rec_cap = (int)std::min<size_t>(std::min<size_t>(max_cand, 8192), budget / 4);
     if (const char* env = getenv("ORBFE_QT_REC_CAP")) c->rec_cap = std::max(0, std::min(c->rec_cap, atoi(env)));
     {
@@ -747,6 +753,7 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
     }
     if (const char* env = getenv("ORBFE_QT_BATCH")) c->qt_batch = atoi(env) != 0;
     if (const char* env = getenv("ORBFE_QT_WAVES")) c->qt_waves = atoi(env);
+    if (const char* env = getenv("ORBFE_QT_PER_CU")) c->qt_per_cu = std::max(1, atoi(env));
     if (const char* env = getenv("ORBFE_FAST_SIDE_FROM")) c->fast_side_from = atoi(env);
   }
   // umax (ORBExtractor::initMaxU)
@@ -965,7 +972,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     // waves per image so that the launch has about 8 tree waves per CU (one round): 4 from 1/2 x, 2 from 1 x, 1 from 2 x that many images
     int gsel = -1;  // -1: one wave per level
     if (!c->qt_groups_forced && nl > 4) {
-      const long long per8 = (long long)c->n_cu * 8;
+      const long long per8 = (long long)c->n_cu * c->qt_per_cu;
       if ((long long)n_img * 1 >= per8) gsel = 0;
       else if ((long long)n_img * 2 >= per8) gsel = 1;
       else if ((long long)n_img * 4 >= per8) gsel = 2;
@@ -978,7 +985,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     // lds_share > 1: that many chunks run side by side on their own streams; each quadtree launch leaves the rest of the
     // CU's LDS to the other chunks' kernels so that they can fill the SIMDs the tree waves leave idle.
     const size_t lds_cu = (160 * 1024 - 2048) / (size_t)std::max(lds_share, 1);
-    const size_t node_bytes = quadtree_lds_bytes(c->node_cap, 0);
+    const size_t node_bytes = quadtree_lds_bytes(c->node_cap, 0, c->sort_cap);
     size_t budget = lds_cu / (size_t)std::max(per_cu, 1);
     budget -= budget % 512;
     const int rec_cap = budget > node_bytes ? (int)std::min<size_t>((budget - node_bytes) / 4, (size_t)c->rec_cap) : 0;
@@ -1285,9 +1292,9 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     fail(c, ORBFE_EDEVICE, "device initialisation failed: %s", hipGetErrorString(e));
     return bail(ORBFE_EDEVICE);
   }
-  e = quadtree_configure(quadtree_lds_bytes(c->node_cap, c->rec_cap) + 4096);  // (+ the level-4 totals of the several-waves-per-tree launches)
+  e = quadtree_configure(quadtree_lds_bytes(c->node_cap, c->rec_cap, c->sort_cap) + 2048 + 4096);  // (+ the rank buffer and the level-4 totals of the several-waves-per-tree launches)
   if (e != hipSuccess) {
-    fail(c, ORBFE_EDEVICE, "cannot reserve %zu B of LDS for the quadtree kernel: %s", quadtree_lds_bytes(c->node_cap, c->rec_cap),
+    fail(c, ORBFE_EDEVICE, "cannot reserve %zu B of LDS for the quadtree kernel: %s", quadtree_lds_bytes(c->node_cap, c->rec_cap, c->sort_cap),
          hipGetErrorString(e));
     return bail(ORBFE_EDEVICE);
   }
