@@ -340,7 +340,14 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     {
       const uint32_t* src = (const uint32_t*)(qt_tabs + L.qt_tab_off);  // [tab_w2 | tab_h] uint16, 4-byte aligned
       uint32_t* dst = (uint32_t*)xtab;
-      for (int i = tid; i < tab_words; i += NT) dst[i] = src[i];
+      for (int i0 = 0; i0 < tab_words; i0 += 4 * NT) {  // four independent loads per trip (the loop was a chain of single round trips)
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = src[min(i0 + u * NT + tid, tab_words - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i0 + u * NT + tid < tab_words) dst[i0 + u * NT + tid] = v[u];
+      }
     }
     __syncthreads();
     QTS(-10)  // tables
@@ -350,39 +357,42 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     };
     // pass 1: group sizes.  Sixteen records per lane per trip, and the next trip's records are requested before this trip's are
     // classified: a lone wave sees every global round trip, so the loads of trip k+1 fly under the work of trip k.
+    // PU records per lane per trip: sixteen with helper waves (a frame or two: registers are free), eight in the one-wave batch kernel,
+    // which is compiled for four waves per SIMD (128 VGPRs)
+    constexpr int PU = NW == 1 ? 8 : 16, PCH = 64 * PU;
     auto load16 = [&](int b0, uint32_t* r) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
+      for (int u = 0; u < PU; ++u) {
         const int i = b0 + u * 64 + lane;
         r[u] = A[max(min(i, N - 1), 0)];  // (clamped: unconditional loads, validity is checked when the record is used)
       }
     };
-    // (the records of the FIRST trip and their groups stay in registers for the scatter pass: up to 1024 records per wave need no
+    // (the records of the FIRST trip and their groups stay in registers for the scatter pass: up to PCH records per wave need no
     //  second load -- an exposed global round trip -- and no second classification)
-    uint32_t rec0[16];
-    int g0[16];
+    uint32_t rec0[PU];
+    int g0[PU];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) rec0[u] = 0u, g0[u] = -1;
+    for (int u = 0; u < PU; ++u) rec0[u] = 0u, g0[u] = -1;
     {
-      uint32_t nxt[16];
-      load16(wv * 1024, nxt);
-      for (int b0 = wv * 1024; b0 < N; b0 += NW * 1024) {
-        uint32_t rec[16];
+      uint32_t nxt[PU];
+      load16(wv * PCH, nxt);
+      for (int b0 = wv * PCH; b0 < N; b0 += NW * PCH) {
+        uint32_t rec[PU];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) rec[u] = nxt[u];
-        if (b0 + NW * 1024 < N) load16(b0 + NW * 1024, nxt);
-        int g[16];  // (all groups first, then the atomics: the table reads must not queue behind the atomics they may alias)
+        for (int u = 0; u < PU; ++u) rec[u] = nxt[u];
+        if (b0 + NW * PCH < N) load16(b0 + NW * PCH, nxt);
+        int g[PU];  // (all groups first, then the atomics: the table reads must not queue behind the atomics they may alias)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < PU; ++u) {
           const int i = b0 + u * 64 + lane;
           g[u] = (i < N) ? group_of(rec[u]) : -1;
         }
-        if (b0 == wv * 1024) {  // wave-uniform
+        if (b0 == wv * PCH) {  // wave-uniform
 #pragma unroll
-          for (int u = 0; u < 16; ++u) rec0[u] = rec[u], g0[u] = g[u];
+          for (int u = 0; u < PU; ++u) rec0[u] = rec[u], g0[u] = g[u];
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
+        for (int u = 0; u < PU; ++u)
           if (g[u] >= 0) atomicAdd(&cur[cur_w(g[u])], 1u << cur_sh(g[u]));  // LDS atomic; lanes of one group serialise, a chunk spans a handful of groups
       }
     }
@@ -457,29 +467,29 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     QTS(-13)  // scan
     // pass 2: scatter
     {
-      uint32_t nxt[16];
-      if (wv * 1024 + NW * 1024 < N) load16(wv * 1024 + NW * 1024, nxt);  // (the first trip's records are still in registers)
-      for (int b0 = wv * 1024; b0 < N; b0 += NW * 1024) {
-        uint32_t rec[16];
-        int g[16];
-        if (b0 == wv * 1024) {  // wave-uniform
+      uint32_t nxt[PU];
+      if (wv * PCH + NW * PCH < N) load16(wv * PCH + NW * PCH, nxt);  // (the first trip's records are still in registers)
+      for (int b0 = wv * PCH; b0 < N; b0 += NW * PCH) {
+        uint32_t rec[PU];
+        int g[PU];
+        if (b0 == wv * PCH) {  // wave-uniform
 #pragma unroll
-          for (int u = 0; u < 16; ++u) rec[u] = rec0[u], g[u] = g0[u];
+          for (int u = 0; u < PU; ++u) rec[u] = rec0[u], g[u] = g0[u];
         } else {
 #pragma unroll
-          for (int u = 0; u < 16; ++u) rec[u] = nxt[u];
-          if (b0 + NW * 1024 < N) load16(b0 + NW * 1024, nxt);
+          for (int u = 0; u < PU; ++u) rec[u] = nxt[u];
+          if (b0 + NW * PCH < N) load16(b0 + NW * PCH, nxt);
 #pragma unroll
-          for (int u = 0; u < 16; ++u) {
+          for (int u = 0; u < PU; ++u) {
             const int i = b0 + u * 64 + lane;
             g[u] = (i < N) ? group_of(rec[u]) : -1;
           }
         }
-        uint32_t pos[16];
+        uint32_t pos[PU];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) pos[u] = (g[u] >= 0) ? ((atomicAdd(&cur[cur_w(g[u])], 1u << cur_sh(g[u])) >> cur_sh(g[u])) & 0xFFFFu) : 0u;
+        for (int u = 0; u < PU; ++u) pos[u] = (g[u] >= 0) ? ((atomicAdd(&cur[cur_w(g[u])], 1u << cur_sh(g[u])) >> cur_sh(g[u])) & 0xFFFFu) : 0u;
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
+        for (int u = 0; u < PU; ++u)
           if (g[u] >= 0) H[pos[u]] = rec[u];  // the order inside a group is irrelevant (see above)
       }
     }
@@ -663,7 +673,9 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
           node_mid(L, (act && !is_pp) ? path : 0u, midx, midy);
           sp = make_split(midx, midy);
         }
-        const unsigned long long big = __ballot(act && !is_pp && n > 64);
+        // (BR: the records of an ordinary member its lane holds in registers; larger nodes take the one-node path)
+        constexpr int BR = NW == 1 ? 32 : 64;
+        const unsigned long long big = __ballot(act && !is_pp && n > BR);
         const int b_eff = big ? min(B, __ffsll((long long)big) - 1) : B;
         int c0 = 0, c1 = 0, c2 = 0, c3 = 0, child_code = 0;
         if (is_pp) {
@@ -692,9 +704,9 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         const bool ld = lane < b_eff && !is_pp;
         const int nmax = (int)wave_max_u32(ld ? (uint32_t)n : 0u);
         uint32_t* seg = H + beg;
-        uint32_t rec[64];
+        uint32_t rec[BR];
 #pragma unroll
-        for (int c8 = 0; c8 < 8; ++c8) {
+        for (int c8 = 0; c8 < BR / 8; ++c8) {
           if (c8 * 8 < nmax) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -709,7 +721,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         if (ld) {
           int k0 = 0, k1 = 0, k2 = 0, k3 = 0;
 #pragma unroll
-          for (int c8 = 0; c8 < 8; ++c8) {
+          for (int c8 = 0; c8 < BR / 8; ++c8) {
             if (c8 * 8 < nmax) {
 #pragma unroll
               for (int u = 0; u < 8; ++u) {
@@ -752,7 +764,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
             if (!is_pp) {  // in-place 4-way partition straight from the registers (the node's segment belongs to this lane alone)
               int p0 = 0, p1 = c0, p2 = c0 + c1, p3 = c0 + c1 + c2;
 #pragma unroll
-              for (int c8 = 0; c8 < 8; ++c8) {
+              for (int c8 = 0; c8 < BR / 8; ++c8) {
                 if (c8 * 8 < nmax) {
 #pragma unroll
                   for (int u = 0; u < 8; ++u) {
@@ -1141,7 +1153,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
 
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_quadtree(const LevelDev* __restrict__ lv, int n_levels, const uint32_t* __restrict__ cand,
+__device__ __forceinline__ void quadtree_levels(const LevelDev* __restrict__ lv, int n_levels, const uint32_t* __restrict__ cand,
                                                  uint32_t* __restrict__ scratch_b, uint32_t* __restrict__ scratch_c,
                                                  size_t scratch_pitch,
                                                  uint32_t* __restrict__ sel, int32_t* __restrict__ sel_count, int n_features,
@@ -1231,6 +1243,19 @@ __global__ __launch_bounds__(64 * NW) void k_quadtree(const LevelDev* __restrict
   }
 }
 
+#define QT_KERNEL_ARGS                                                                                                                 \
+  const LevelDev *__restrict__ lv, int n_levels, const uint32_t *__restrict__ cand, uint32_t *__restrict__ scratch_b,                   \
+      uint32_t *__restrict__ scratch_c, size_t scratch_pitch, uint32_t *__restrict__ sel, int32_t *__restrict__ sel_count, int n_features, \
+      const int32_t *__restrict__ n_cand, int node_cap, int sort_cap, int rec_cap, int batch, QtGroups groups, uint8_t *__restrict__ big_base, \
+      size_t big_pitch, const uint16_t *__restrict__ qt_tabs
+#define QT_KERNEL_PASS \
+  lv, n_levels, cand, scratch_b, scratch_c, scratch_pitch, sel, sel_count, n_features, n_cand, node_cap, sort_cap, rec_cap, batch, groups, big_base, big_pitch, qt_tabs
+// One wave per tree (batches): compiled for FOUR waves per SIMD (128 VGPRs) -- with 16-byte nodes sixteen trees fit a CU's LDS, and the
+// launch deals an image's levels to as many waves as make sixteen per CU, so that a SIMD has four dependent chains to interleave.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_quadtree(QT_KERNEL_ARGS) { quadtree_levels<1>(QT_KERNEL_PASS); }
+// Four waves per tree (a frame or two on an otherwise empty chip): registers are free
+__global__ __launch_bounds__(256) void k_quadtree_w4(QT_KERNEL_ARGS) { quadtree_levels<4>(QT_KERNEL_PASS); }
+
 // The pre-partition's coordinate -> code tables of one level (tree_body): x table [tab_w2] then y table [tab_h], uint16 codes as
 // described at pp_axis_code.  Host side, once per context; returns false when the level's geometry rules the pre-partition out.
 bool quadtree_build_tables(const LevelDev& L, std::vector<uint16_t>& out) {
@@ -1273,8 +1298,8 @@ hipError_t quadtree_configure(size_t lds_bytes) {
   std::lock_guard<std::mutex> lk(mu);
   const int slot = dev >= 0 && dev < 64 ? dev : 63;
   if (lds_bytes <= current[slot]) return hipSuccess;
-  e = hipFuncSetAttribute((const void*)k_quadtree<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_quadtree<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  e = hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_quadtree_w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e == hipSuccess) current[slot] = lds_bytes;
   return e;
 }
@@ -1286,10 +1311,10 @@ void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const ui
   if (n_img <= 0) return;
   const size_t lds = quadtree_lds_bytes(node_cap, rec_cap, sort_cap);
   if (waves_per_tree >= 4)
-    hipLaunchKernelGGL(k_quadtree<4>, dim3(n_groups, n_img), dim3(256), lds + 2048 + 16 + QT_PP_MAX_STRIPS * QT_PP_TOTALS4 * sizeof(uint16_t), s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
+    hipLaunchKernelGGL(k_quadtree_w4, dim3(n_groups, n_img), dim3(256), lds + 2048 + 16 + QT_PP_MAX_STRIPS * QT_PP_TOTALS4 * sizeof(uint16_t), s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
                        d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch, d_qt_tabs);
   else
-    hipLaunchKernelGGL(k_quadtree<1>, dim3(n_groups, n_img), dim3(64), lds, s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
+    hipLaunchKernelGGL(k_quadtree, dim3(n_groups, n_img), dim3(64), lds, s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
                        d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch, d_qt_tabs);
 }
 
