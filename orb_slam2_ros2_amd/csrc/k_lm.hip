@@ -19,7 +19,9 @@
 //                    Hll / bl of the point, partial sums of the robust chi2 -- kept as the system of the next iteration if the trial is
 //                    accepted (g2o rebuilds the same numbers); vertex -> edge lists are host-built CSR
 // All fp64, contraction off, every sum in a fixed order: run-to-run identical.  Scatter-adds of 6x6 / 6x3 / 3x3 blocks keyed by vertex
-// ids and a <= 258-row triangular factorisation are no dense contractions worth MFMA tiles.
+// ids and a <= 258-row triangular factorisation are no dense contractions worth MFMA tiles; past LM_CHOL_MAX_NB free
+// keyframes the reduced system IS one (6 nf rows, dense): k_lmbig.hip factorises it in 48 x 48 tiles with the trailing updates on the
+// fp64 matrix cores, gated by the same state record.
 #include <hip/hip_runtime.h>
 
 #include "orbfe_internal.h"
@@ -477,7 +479,9 @@ __global__ __launch_bounds__(64) void k_lm_schur(int nf, LmBuffers B, const LmSt
                                                  const int32_t* __restrict__ pair_cnt, int pair_cap, const int2* __restrict__ pairs,
                                                  const int32_t* __restrict__ ps_off, const int32_t* __restrict__ ps_edges,
                                                  const int32_t* __restrict__ edge_point, const double* __restrict__ W,
-                                                 double* __restrict__ Sblk, double* __restrict__ rhs) {
+                                                 double* __restrict__ Sblk, double* __restrict__ rhs, double* __restrict__ M, int ld) {
+  // M != nullptr: the dense layout of the blocked solver (k_lmbig.hip) -- block (i, j) at rows 6 i, columns 6 j of a row-major matrix of
+  // pitch ld, the right-hand side in row ld
 #pragma clang fp contract(off)
   if (!lm_gate(st, 1)) return;
   const int lane = threadIdx.x;
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(64) void k_lm_schur(int nf, LmBuffers B, const LmSt
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
       const double s = wave_sum_fixed(r[a]);
-      if (lane == a) rhs[6 * i + a] = B.bp[buf][(size_t)ki * 6 + a] - s;
+      if (lane == a) (M ? M[(size_t)ld * ld + 6 * i + a] : rhs[6 * i + a]) = B.bp[buf][(size_t)ki * 6 + a] - s;
     }
     return;
   }
@@ -541,7 +545,10 @@ __global__ __launch_bounds__(64) void k_lm_schur(int nf, LmBuffers B, const LmSt
         if (k / 6 == k % 6) d += st->lambda;
         v = d - s;
       }
-      out[k] = v;
+      if (M)
+        M[(size_t)(6 * i + k / 6) * ld + 6 * j + k % 6] = v;
+      else
+        out[k] = v;
     }
   }
 }
@@ -1198,6 +1205,9 @@ __global__ __launch_bounds__(256) void k_lm_final(int n_edges, int n_poses, int 
   for (int i = e; i < n_points * 3; i += gridDim.x * 256) points_out[i] = B.points[buf][i];
 }
 
+// k_lmbig.hip: the blocked multi-workgroup solver of windows past LM_CHOL_MAX_NB free keyframes
+void launch_lm_chol_big(hipStream_t s, const LmLaunch& L);
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 static LmBuffers lm_buffers(const LmLaunch& L) {
   LmBuffers B;
@@ -1251,8 +1261,11 @@ void launch_lm_step(hipStream_t s, const LmLaunch& L, bool ctrl_in_tail) {
                        L.ps_edges);
   if (L.nf > 0) {
     hipLaunchKernelGGL(k_lm_schur, dim3(L.nf * (L.nf + 1) / 2 + L.nf), dim3(64), 0, s, L.nf, B, L.state, L.free_pose, L.pair_cnt, L.pair_cap, L.pairs, L.ps_off,
-                       L.ps_edges, L.edge_point, L.W, L.Sblk, L.rhs);
-    hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(LM_CHOL_THREADS), 0, s, L.nf, L.state, L.Sblk, L.rhs, L.x);
+                       L.ps_edges, L.edge_point, L.W, L.Sblk, L.rhs, L.M, L.ld);
+    if (L.M)
+      launch_lm_chol_big(s, L);
+    else
+      hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(LM_CHOL_THREADS), 0, s, L.nf, L.state, L.Sblk, L.rhs, L.x);
   }
   const int ub = pb + (L.NK + 255) / 256;
   if (ub > 0)

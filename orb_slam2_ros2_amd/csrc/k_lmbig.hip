@@ -1,0 +1,392 @@
+// k_lmbig.hip -- the reduced system of the local BA for windows past the register-resident solver of k_lm.hip (more than
+// LM_CHOL_MAX_NB free keyframes): a blocked, multi-workgroup Cholesky with the trailing updates on the fp64 matrix cores
+// (v_mfma_f64_16x16x4_f64), gated by the device-side Levenberg-Marquardt state exactly like k_lm_chol, so that a window of any size
+// keeps ONE enqueue and ONE synchronisation per call.
+//
+// The reference puts every covisible keyframe into the free set (Optimizer.cc:232-233, no bound) and solves the reduced system with
+// g2o's BlockSolver_6_3 over a sparse Cholesky (Optimizer.h:49-54).  Here the reduced system is dense: at 300 free keyframes an
+// 1800 x 1800 factorisation, ~1.9 GFLOP per trial -- the dense contraction north_star reserves the matrix cores for.
+//
+// Layout: M = (ld + 48) x ld doubles, row-major, ld = 6 nf rounded up to 48.  Rows / columns [6 nf, ld) are padding (unit diagonal);
+// row ld carries the right-hand side, so the forward substitution is part of the factorisation (an extra tile row), the other rows of
+// that tile row are zero.  Only the lower triangle is read.
+//
+// One launch per tile column (48 x 48 tiles, k = -1 .. KT - 2): workgroup (i, j), k < j <= i, does
+//   A_ij -= L_ik L_jk^T                                  three waves, a 16-row strip each, 3 x 12 MFMA 16x16x4 per strip
+// and the workgroups of column j = k + 1 go on to finish THAT column: (k+1, k+1) factorises its tile in 16-column blocks (one wave
+// factorises and inverts a 16 x 16 diagonal block, rows in lanes, the column exchanged by v_readlane; the blocks below it and the
+// rank-16 updates run on the matrix cores), publishes it with the three block inverses and raises flags[k+1]; the tiles below it wait
+// for the flag and solve X L^T = A for their 48 rows by blocked substitution, X_b = (A_b - sum X_c L_bc^T) inv_bb^T, every product an
+// MFMA (a column-at-a-time substitution by one wave was 14 us a tile, the 48-column factorisation 24 us: tools/exp/lmb_bench.hip).  The diagonal workgroup is workgroup 0 of the launch and waits for nobody, so the wait cannot deadlock (workgroups are
+// dispatched in index order).  After the last launch L and y are complete; k_lmb_back solves L^T x = y with one workgroup.
+// Fixed summation order everywhere: run-to-run identical.  A non-positive pivot clears LmState::ok (g2o: the linear solver fails, the
+// trial is rejected) and x = 0.
+#include <hip/hip_runtime.h>
+
+#include "orbfe_internal.h"
+
+namespace orbfe {
+
+#define LMB_T 48
+#define LMB_LS 49  // LDS row pitch of a tile in doubles (odd: the 16 rows a wave's operand read touches fall on distinct banks)
+
+typedef double lmb_d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bool lmb_gate(const LmState* st) { return *(const volatile int32_t*)&st->run_step != 0; }
+
+// pad diagonal of M (once per call, after the zero fill)
+__global__ __launch_bounds__(64) void k_lmb_init(double* __restrict__ M, int n, int ld) {
+  const int i = n + (int)threadIdx.x;
+  if (i < ld) M[(size_t)i * ld + i] = 1.0;
+}
+
+#define LMB_IS 17  // pitch of a 16 x 16 inverse in LDS
+struct LmbShared {
+  double Li[LMB_T * LMB_LS];  // L_ik, later the factorised diagonal tile of the column for the panel solves
+  double Lj[LMB_T * LMB_LS];  // L_jk
+  double C[LMB_T * LMB_LS];   // the updated tile on its way to the factorisation / solve
+  double Inv[3][16 * LMB_IS]; // inverses of the three 16 x 16 diagonal blocks of the diagonal tile (lower triangular)
+  int fail;
+};
+
+// ---- 16 x 16 fragments on the matrix core --------------------------------------------------------------------------------------------
+// v_mfma_f64_16x16x4_f64: A operand lane l = A[l & 15][l >> 4], B operand lane l = B[l >> 4][l & 15], C / D register rg of lane l =
+// element (row (l >> 4) + 4 rg, column l & 15).  All products here are X Y^T with X and Y row-major in LDS (k along the row), so both
+// operands are read the same way.
+__device__ __forceinline__ lmb_d4 lmb_frag_load(const double* P, int pitch, int lane) {
+  lmb_d4 f;
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) f[rg] = P[((lane >> 4) + 4 * rg) * pitch + (lane & 15)];
+  return f;
+}
+__device__ __forceinline__ void lmb_frag_store(double* P, int pitch, int lane, lmb_d4 f) {
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) P[((lane >> 4) + 4 * rg) * pitch + (lane & 15)] = f[rg];
+}
+// acc +- X[0..15][0..15] Y[0..15][0..15]^T
+template <bool NEG>
+__device__ __forceinline__ lmb_d4 lmb_mm_abt(lmb_d4 acc, const double* X, int px, const double* Y, int py, int lane) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const double a = X[(lane & 15) * px + 4 * s + (lane >> 4)];
+    const double b = Y[(lane & 15) * py + 4 * s + (lane >> 4)];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -a : a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+__device__ __forceinline__ void lmb_wave_sync() {  // a wave's own LDS traffic executes in order: this only pins the compiler
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Cholesky of the 16 x 16 block at D (pitch LMB_LS, lower triangle, in place) and its inverse -> inv (pitch LMB_IS), by ONE wave: lanes
+// 0..15 own a row each, the finished column travels by v_readlane (fifteen scalar pairs live at most).  Pivot: 1 / sqrt by v_rsq_f64
+// and one third-order correction, L_cc = d y, as in k_lm_chol.  Returns false on a bad pivot.
+__device__ __forceinline__ bool lmb_potrf16(double* D, double* inv, int lane) {
+#pragma clang fp contract(fast)
+  const int r = lane & 15;
+  double a[16], y[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) a[c] = D[r * LMB_LS + c];
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[c]), c), __builtin_amdgcn_readlane(__double2loint(a[c]), c));
+    if (!(piv > 0.0)) ok = false;  // (uniform)
+    const double d = piv > 0.0 ? piv : 1.0;
+    const double y0 = __builtin_amdgcn_rsq(d);
+    const double e = fma(-(d * y0), y0, 1.0);
+    y[c] = fma(y0 * e, fma(0.375, e, 0.5), y0);
+    const double l = r == c ? d * y[c] : a[c] * y[c];  // column c of L, lane = row (rows above c: garbage, never read)
+    a[c] = l;
+#pragma unroll
+    for (int j = c + 1; j < 16; ++j) {
+      const double lj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(l), j), __builtin_amdgcn_readlane(__double2loint(l), j));
+      a[j] = fma(-l, lj, a[j]);  // (lanes r < j update the upper triangle: never read)
+    }
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) D[r * LMB_LS + c] = c <= r ? a[c] : 0.0;
+  }
+  lmb_wave_sync();
+  // inverse: lane j solves L x = e_j (column j of the inverse), L read back as wave-uniform (broadcast) LDS reads
+  double x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = i == r ? 1.0 : 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const double xk = x[k] * y[k];
+    x[k] = xk;
+#pragma unroll
+    for (int i = k + 1; i < 16; ++i) x[i] = fma(-D[i * LMB_LS + k], xk, x[i]);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) inv[i * LMB_IS + r] = i >= r ? x[i] : 0.0;
+  }
+  return ok;
+}
+
+// The diagonal tile in sh.C (lower triangle) -> L in place, the inverses of its three diagonal blocks in sh.Inv.  Three waves, 16-column
+// blocks: factor the block (one wave), L_below = A_below inv^T and the rank-16 updates of what is left on the matrix cores.
+__device__ __forceinline__ void lmb_potrf_tile(LmbShared& sh, int wv, int lane) {
+  double* C = sh.C;
+  // block column 0
+  if (wv == 0 && !lmb_potrf16(C, sh.Inv[0], lane)) sh.fail = 1;
+  __syncthreads();
+  if (wv > 0) {  // L_w0 = A_w0 inv11^T
+    lmb_d4 f = {0, 0, 0, 0};
+    f = lmb_mm_abt<false>(f, C + 16 * wv * LMB_LS, LMB_LS, sh.Inv[0], LMB_IS, lane);
+    lmb_wave_sync();
+    lmb_frag_store(C + 16 * wv * LMB_LS, LMB_LS, lane, f);
+  }
+  __syncthreads();
+  if (wv == 1) {  // A22 -= L21 L21^T, then its factorisation
+    lmb_d4 f = lmb_frag_load(C + 16 * LMB_LS + 16, LMB_LS, lane);
+    f = lmb_mm_abt<true>(f, C + 16 * LMB_LS, LMB_LS, C + 16 * LMB_LS, LMB_LS, lane);
+    lmb_frag_store(C + 16 * LMB_LS + 16, LMB_LS, lane, f);
+    lmb_wave_sync();
+    if (!lmb_potrf16(C + 16 * LMB_LS + 16, sh.Inv[1], lane)) sh.fail = 1;
+  } else if (wv == 2) {  // A32 -= L31 L21^T, A33 -= L31 L31^T
+    lmb_d4 f = lmb_frag_load(C + 32 * LMB_LS + 16, LMB_LS, lane);
+    f = lmb_mm_abt<true>(f, C + 32 * LMB_LS, LMB_LS, C + 16 * LMB_LS, LMB_LS, lane);
+    lmb_d4 g = lmb_frag_load(C + 32 * LMB_LS + 32, LMB_LS, lane);
+    g = lmb_mm_abt<true>(g, C + 32 * LMB_LS, LMB_LS, C + 32 * LMB_LS, LMB_LS, lane);
+    lmb_frag_store(C + 32 * LMB_LS + 16, LMB_LS, lane, f);
+    lmb_frag_store(C + 32 * LMB_LS + 32, LMB_LS, lane, g);
+  }
+  __syncthreads();
+  if (wv == 2) {  // L32 = A32 inv22^T, A33 -= L32 L32^T, factor
+    lmb_d4 f = {0, 0, 0, 0};
+    f = lmb_mm_abt<false>(f, C + 32 * LMB_LS + 16, LMB_LS, sh.Inv[1], LMB_IS, lane);
+    lmb_wave_sync();
+    lmb_frag_store(C + 32 * LMB_LS + 16, LMB_LS, lane, f);
+    lmb_wave_sync();
+    lmb_d4 g = lmb_frag_load(C + 32 * LMB_LS + 32, LMB_LS, lane);
+    g = lmb_mm_abt<true>(g, C + 32 * LMB_LS + 16, LMB_LS, C + 32 * LMB_LS + 16, LMB_LS, lane);
+    lmb_frag_store(C + 32 * LMB_LS + 32, LMB_LS, lane, g);
+    lmb_wave_sync();
+    if (!lmb_potrf16(C + 32 * LMB_LS + 32, sh.Inv[2], lane)) sh.fail = 1;
+  }
+  __syncthreads();
+}
+
+// X L^T = A for the 16 rows of strip wv of the tile in sh.C, in place: L (the column's diagonal tile, row-major) in sh.Li, the inverses
+// of its diagonal blocks in sh.Inv.  Blocked forward substitution, every product on the matrix core; a wave touches its own rows only.
+__device__ __forceinline__ void lmb_trsm_strip(LmbShared& sh, int wv, int lane) {
+  double* R = sh.C + 16 * wv * LMB_LS;
+  const double* L = sh.Li;
+  lmb_d4 x = {0, 0, 0, 0};
+  x = lmb_mm_abt<false>(x, R, LMB_LS, sh.Inv[0], LMB_IS, lane);  // X1 = A1 inv11^T
+  lmb_d4 a2 = lmb_frag_load(R + 16, LMB_LS, lane), a3 = lmb_frag_load(R + 32, LMB_LS, lane);
+  lmb_wave_sync();
+  lmb_frag_store(R, LMB_LS, lane, x);
+  lmb_wave_sync();
+  a2 = lmb_mm_abt<true>(a2, R, LMB_LS, L + 16 * LMB_LS, LMB_LS, lane);  // A2 -= X1 L21^T
+  a3 = lmb_mm_abt<true>(a3, R, LMB_LS, L + 32 * LMB_LS, LMB_LS, lane);  // A3 -= X1 L31^T
+  lmb_frag_store(R + 16, LMB_LS, lane, a2);
+  lmb_wave_sync();
+  x = lmb_d4{0, 0, 0, 0};
+  x = lmb_mm_abt<false>(x, R + 16, LMB_LS, sh.Inv[1], LMB_IS, lane);  // X2 = A2 inv22^T
+  lmb_wave_sync();
+  lmb_frag_store(R + 16, LMB_LS, lane, x);
+  lmb_wave_sync();
+  a3 = lmb_mm_abt<true>(a3, R + 16, LMB_LS, L + 32 * LMB_LS + 16, LMB_LS, lane);  // A3 -= X2 L32^T
+  lmb_frag_store(R + 32, LMB_LS, lane, a3);
+  lmb_wave_sync();
+  x = lmb_d4{0, 0, 0, 0};
+  x = lmb_mm_abt<false>(x, R + 32, LMB_LS, sh.Inv[2], LMB_IS, lane);  // X3 = A3 inv33^T
+  lmb_wave_sync();
+  lmb_frag_store(R + 32, LMB_LS, lane, x);
+}
+
+// One tile column.  k: the column whose panel is final (-1: none yet); the launch finishes column k + 1.
+__global__ __launch_bounds__(192) void k_lmb_step(int k, int KT, int ld, double* __restrict__ M, double* __restrict__ Linv, LmState* __restrict__ st,
+                                                  int32_t* __restrict__ flags) {
+  __shared__ LmbShared sh;
+  if (!lmb_gate(st)) return;
+  if (*(volatile int32_t*)&flags[KT] != 0) return;  // an earlier column hit a bad pivot
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  // blockIdx.x -> (i, j): column-major over the trailing tiles, column k + 1 first (its diagonal tile is workgroup 0)
+  const int m = KT - 1 - k;  // tile columns left; tile rows k + 1 .. KT (KT: the right-hand-side row)
+  int jq = 0, base = 0;
+  while (jq < m - 1 && base + (m + 1 - jq) <= (int)blockIdx.x) {
+    base += m + 1 - jq;
+    ++jq;
+  }
+  const int j = k + 1 + jq, i = j + ((int)blockIdx.x - base);
+  double* Aij = M + (size_t)i * LMB_T * ld + (size_t)j * LMB_T;
+  const bool diag = i == j;
+  lmb_d4 acc[3];
+  // C fragment of strip wv, sub-tile b: row = 16 wv + (lane >> 4) + 4 reg, col = 16 b + (lane & 15)
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) acc[b][rg] = Aij[(size_t)(16 * wv + (lane >> 4) + 4 * rg) * ld + 16 * b + (lane & 15)];
+  if (k >= 0) {
+    const double* Lik = M + (size_t)i * LMB_T * ld + (size_t)k * LMB_T;
+    const double* Ljk = M + (size_t)j * LMB_T * ld + (size_t)k * LMB_T;
+    for (int e = t; e < LMB_T * LMB_T; e += 192) {
+      const int r = e / LMB_T, c = e - r * LMB_T;
+      sh.Li[r * LMB_LS + c] = Lik[(size_t)r * ld + c];
+      sh.Lj[r * LMB_LS + c] = Ljk[(size_t)r * ld + c];
+    }
+    __syncthreads();
+    const int row = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < LMB_T / 4; ++s) {
+      const double a = -sh.Li[(16 * wv + row) * LMB_LS + 4 * s + kq];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        if (diag && b > wv) continue;  // (only the lower triangle of a diagonal tile is ever read)
+        const double bv = sh.Lj[(16 * b + row) * LMB_LS + 4 * s + kq];
+        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[b], 0, 0, 0);
+      }
+    }
+  }
+  if (jq != 0) {  // an interior tile of the trailing matrix: done
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) Aij[(size_t)(16 * wv + (lane >> 4) + 4 * rg) * ld + 16 * b + (lane & 15)] = acc[b][rg];
+    return;
+  }
+  // ---- column k + 1: factorise (diagonal tile) or solve (the tiles below it) ----
+  __syncthreads();  // (the operand tiles are dead)
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) sh.C[(16 * wv + (lane >> 4) + 4 * rg) * LMB_LS + 16 * b + (lane & 15)] = acc[b][rg];
+  if (t == 0) sh.fail = 0;
+  __syncthreads();
+  if (diag) {
+    lmb_potrf_tile(sh, wv, lane);
+    for (int e = t; e < LMB_T * LMB_T; e += 192) {
+      const int r = e / LMB_T, c = e - r * LMB_T;
+      Aij[(size_t)r * ld + c] = sh.C[r * LMB_LS + c];
+    }
+    for (int e = t; e < 3 * 256; e += 192) Linv[(size_t)j * 768 + e] = sh.Inv[e >> 8][((e & 255) >> 4) * LMB_IS + (e & 15)];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (t == 0) {
+      if (sh.fail) {
+        st->ok = 0;
+        __hip_atomic_store(&flags[KT], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_store(&flags[j], sh.fail ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  // wait for the diagonal tile of this column (workgroup 0 of this launch: dispatched before this one, waits for nobody)
+  if (t == 0) {
+    int f;
+    while ((f = __hip_atomic_load(&flags[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(2);
+    sh.fail = f == 2;
+  }
+  __syncthreads();
+  if (sh.fail) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const double* Ljj = M + (size_t)j * LMB_T * ld + (size_t)j * LMB_T;
+  for (int e = t; e < LMB_T * LMB_T; e += 192) {
+    const int r = e / LMB_T, c = e - r * LMB_T;
+    sh.Li[r * LMB_LS + c] = __builtin_nontemporal_load(&Ljj[(size_t)r * ld + c]);
+  }
+  for (int e = t; e < 3 * 256; e += 192) sh.Inv[e >> 8][((e & 255) >> 4) * LMB_IS + (e & 15)] = __builtin_nontemporal_load(&Linv[(size_t)j * 768 + e]);
+  __syncthreads();
+  lmb_trsm_strip(sh, wv, lane);
+  __syncthreads();
+  for (int e = t; e < LMB_T * LMB_T; e += 192) {
+    const int r = e / LMB_T, c = e - r * LMB_T;
+    Aij[(size_t)r * ld + c] = sh.C[r * LMB_LS + c];
+  }
+}
+
+// L^T x = y (y = row ld of M after the factorisation), one workgroup; resets the column flags for the next trial.
+__global__ __launch_bounds__(1024) void k_lmb_back(int n, int KT, int ld, const double* __restrict__ M, LmState* __restrict__ st, int32_t* __restrict__ flags,
+                                                  double* __restrict__ x) {
+#pragma clang fp contract(fast)
+  extern __shared__ double lmb_y[];  // [ld] y -> x, then [48] the x of the current tile, then its diagonal tile
+  if (!lmb_gate(st)) return;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const bool failed = *(volatile int32_t*)&flags[KT] != 0;
+  if (failed) {
+    for (int c = t; c < n; c += 1024) x[c] = 0.0;
+    __syncthreads();
+    for (int q = t; q <= KT; q += 1024) flags[q] = 0;
+    return;
+  }
+  double* xs = lmb_y + ld;
+  for (int c = t; c < ld; c += 1024) lmb_y[c] = M[(size_t)ld * ld + c];
+  __syncthreads();
+  double* Lt = xs + LMB_T;  // [48][49]: the diagonal tile of the current column (a serial chain must not wait on global loads)
+  for (int kt = KT - 1; kt >= 0; --kt) {
+    const double* Lkk = M + (size_t)kt * LMB_T * ld + (size_t)kt * LMB_T;
+    for (int e = t; e < LMB_T * LMB_T; e += 1024) {
+      const int r = e / LMB_T, c = e - r * LMB_T;
+      Lt[r * LMB_LS + c] = Lkk[(size_t)r * ld + c];
+    }
+    __syncthreads();
+    if (wv == 0) {
+      // L_kk^T x_k = y_k: column-oriented, lane r holds y_r; x_c is final once the rows c' > c have been subtracted
+      const int r = lane < LMB_T ? lane : LMB_T - 1;
+      double yv = lmb_y[kt * LMB_T + r];
+#pragma unroll 4
+      for (int c = LMB_T - 1; c >= 0; --c) {
+        const double lc = Lt[c * LMB_LS + r];  // row c of L_kk (columns r <= c matter)
+        const double dcc = Lt[c * LMB_LS + c];
+        const double yc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(yv), c), __builtin_amdgcn_readlane(__double2loint(yv), c));
+        const double xc = yc / dcc;
+        if (lane == c) yv = xc;
+        if (lane < c) yv = fma(-lc, xc, yv);
+      }
+      if (lane < LMB_T) {
+        xs[lane] = yv;
+        lmb_y[kt * LMB_T + lane] = yv;
+      }
+    }
+    __syncthreads();
+    // y_j -= L_kj^T x_k for every column left of the tile: row panel kt of L, one column per thread
+    for (int c = t; c < kt * LMB_T; c += 1024) {
+      const double* col = M + (size_t)kt * LMB_T * ld + c;
+      double lv[LMB_T];
+#pragma unroll
+      for (int r = 0; r < LMB_T; ++r) lv[r] = col[(size_t)r * ld];  // (all requested before the first is used: one round trip)
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int r = 0; r < LMB_T; r += 4) {
+        s0 = fma(lv[r], xs[r], s0);
+        s1 = fma(lv[r + 1], xs[r + 1], s1);
+        s2 = fma(lv[r + 2], xs[r + 2], s2);
+        s3 = fma(lv[r + 3], xs[r + 3], s3);
+      }
+      lmb_y[c] -= (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+  }
+  for (int c = t; c < n; c += 1024) x[c] = lmb_y[c];
+  for (int q = t; q <= KT; q += 1024) flags[q] = 0;
+}
+
+size_t lm_big_inv_bytes(int nf) { return (((size_t)6 * nf + LMB_T - 1) / LMB_T) * 768 * sizeof(double); }
+size_t lm_big_bytes(int nf) {
+  const size_t ld = ((size_t)6 * nf + LMB_T - 1) / LMB_T * LMB_T;
+  return (ld + LMB_T) * ld * sizeof(double);
+}
+int lm_big_ld(int nf) { return (int)(((size_t)6 * nf + LMB_T - 1) / LMB_T * LMB_T); }
+
+void launch_lm_big_init(hipStream_t s, const LmLaunch& L) {  // M is zero-filled by the caller
+  if (L.ld > 6 * L.nf) hipLaunchKernelGGL(k_lmb_init, dim3(1), dim3(64), 0, s, L.M, 6 * L.nf, L.ld);
+}
+
+void launch_lm_chol_big(hipStream_t s, const LmLaunch& L) {
+  const int KT = L.ld / LMB_T;
+  for (int k = -1; k <= KT - 2; ++k) {
+    const int m = KT - 1 - k;
+    const int grid = k < 0 ? m + 1 : m * (m + 3) / 2;
+    hipLaunchKernelGGL(k_lmb_step, dim3(grid), dim3(192), 0, s, k, KT, L.ld, L.M, L.lmb_inv, L.state, L.lmb_flags);
+  }
+  hipLaunchKernelGGL(k_lmb_back, dim3(1), dim3(1024), (size_t)(L.ld + LMB_T + LMB_T * LMB_LS) * sizeof(double), s, 6 * L.nf, KT, L.ld, L.M, L.state, L.lmb_flags, L.x);
+}
+
+}  // namespace orbfe

@@ -76,6 +76,11 @@ void launch_lba_solve(hipStream_t s, int n_poses, int n_points, int n_edges, int
                       const double* bp, const double* Hll, const double* bl, const double* Hpl, const double* lambda_p, double* Dinv, double* W,
                       double* S, double* rhs, double* x, int* ok, double* poses, double* points, double* dxp, double* dxl, double* scale_out,
                       double* big_scratch);
+// k_lmbig.hip
+size_t lm_big_bytes(int nf);
+size_t lm_big_inv_bytes(int nf);
+int lm_big_ld(int nf);
+void launch_lm_big_init(hipStream_t s, const LmLaunch& L);
 void launch_lba_classify(hipStream_t s, int n_edges, const double* chi2_last, const uint8_t* depth_pos, const uint8_t* is_stereo,
                          uint8_t* level, double* info_eff, double* delta_eff);
 void launch_lba_final(hipStream_t s, int n_edges, const double* chi2, const uint8_t* depth_pos, const uint8_t* is_stereo, uint8_t* bad);
@@ -2356,7 +2361,8 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
   mark("validate + vertex lists");
   std::vector<int32_t> pair_off(1, 0);
   std::vector<int2> pairs;
-  const bool lower_only = c && c->lm_on_device && E > 0 && nf <= LM_CHOL_MAX_NB && single_obs;  // (= dev_lm below)
+  const bool lower_only = c && c->lm_on_device && E > 0 && nf <= LM_BIG_MAX_NB && single_obs;  // (= dev_lm below)
+  const bool big_solver = lower_only && nf > LM_CHOL_MAX_NB;  // the blocked multi-workgroup Cholesky of k_lmbig.hip
   if (!lower_only) {
     pair_off.assign((size_t)nf * nf + 1, 0);
     for (int pt = 0; pt < NP; ++pt)
@@ -2409,7 +2415,7 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
   const bool dev_lm = lower_only;
   const int chi_blocks = (NP + 31) / 32, scale_blocks = (NP + 31) / 32 + (NK + 255) / 256;  // (k_lm_linpoints: a partial sum per block of 32 points)
   size_t l_ptable = 0, l_pairs = 0, l_paircnt = 0, l_pose1 = 0, l_pt1 = 0, l_terms[2] = {0, 0}, l_hpl1 = 0, l_hpp1 = 0, l_bp1 = 0, l_hll1 = 0, l_bl1 = 0, l_chi[2] = {0, 0}, l_sblk = 0,
-         l_scale = 0, l_pose_out = 0, l_pt_out = 0, l_chi2_out = 0, l_level_out = 0, l_bad_out = 0, l_state_out = 0, l_out_end = 0;
+         l_scale = 0, l_big = 0, l_bigflags = 0, l_biginv = 0, l_pose_out = 0, l_pt_out = 0, l_chi2_out = 0, l_level_out = 0, l_bad_out = 0, l_state_out = 0, l_out_end = 0;
   if (dev_lm) {
     l_pose1 = take((size_t)NK * 56), l_pt1 = take((size_t)NP * 24);
     l_ptable = take((size_t)nf * NP * 4), l_pairs = take((size_t)nf * (nf + 1) / 2 * pair_cap * 8), l_paircnt = take((size_t)nf * (nf + 1) / 2 * 4);
@@ -2417,7 +2423,9 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     l_hpl1 = take((size_t)E * 144), l_hpp1 = take((size_t)NK * 288), l_bp1 = take((size_t)NK * 48), l_hll1 = take((size_t)NP * 72),
     l_bl1 = take((size_t)NP * 24);
     l_chi[0] = take((size_t)chi_blocks * 8), l_chi[1] = take((size_t)chi_blocks * 8);
-    l_sblk = take((size_t)nf * (nf + 1) / 2 * 288), l_scale = take((size_t)scale_blocks * 8);
+    l_sblk = take(big_solver ? 8 : (size_t)nf * (nf + 1) / 2 * 288), l_scale = take((size_t)scale_blocks * 8);
+    l_big = take(big_solver ? lm_big_bytes(nf) : 8), l_bigflags = take(big_solver ? ((size_t)lm_big_ld(nf) / 48 + 2) * 4 : 8),
+    l_biginv = take(big_solver ? lm_big_inv_bytes(nf) : 8);
     // the results as ONE block (one download): poses | points | chi2 | level | bad
     l_pose_out = take((size_t)NK * 56), l_pt_out = take((size_t)NP * 24), l_chi2_out = take((size_t)E * 8), l_level_out = take((size_t)E),
     l_bad_out = take((size_t)E), l_state_out = take(sizeof(LmState)), l_out_end = take(8);  // (+ the control state as the last control step left it)
@@ -2501,7 +2509,12 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     // (the initial state went up with the inputs; the ticket and the point inverses -- read by a trial whose point block was singular --
     //  are part of the one zero fill)
     L.state_out = (LmState*)(b + l_state_out);
+    L.M = big_solver ? (double*)(b + l_big) : nullptr, L.ld = big_solver ? lm_big_ld(nf) : 0, L.lmb_flags = (int32_t*)(b + l_bigflags), L.lmb_inv = (double*)(b + l_biginv);
     StageTimer tm(c, ORBFE_STAGE_BA, st);
+    if (big_solver) {
+      HIP_TRY(c, hipMemsetAsync(b + l_big, 0, (l_bigflags - l_big) + ((size_t)L.ld / 48 + 2) * 4, st));  // the matrix and the flags behind it
+      launch_lm_big_init(st, L);
+    }
     HIP_TRY(c, hipMemsetAsync(L.pair_table, 0xFF, (size_t)nf * NP * 4, st));
     launch_lm_pairs(st, L);
     launch_lm_build(st, L, 0, 0, iters_first > 0 ? 1 : 0, -1, true);  // computeActiveErrors + buildSystem at the initial estimate

@@ -128,6 +128,7 @@ struct BaParamsDev {
 
 // ---- device-side Levenberg-Marquardt control of the local BA (k_lm.hip) -------------------------------------------------------------
 #define LM_CHOL_MAX_NB 42  // free keyframes the register-resident Cholesky takes: 42 * 41 / 2 = 861 off-diagonal blocks, two per thread of 448
+#define LM_BIG_MAX_NB 1000 // free keyframes the blocked multi-workgroup Cholesky takes (k_lmbig.hip: the back substitution keeps y in 48 KB of LDS)
 
 // The state record one control lane advances between the trials (device memory; the host reads it once per call).
 struct LmState {
@@ -162,6 +163,10 @@ struct LmLaunch {
   double *info_eff, *delta_eff, *chi2_last;
   uint8_t* level;
   double *Dinv, *W, *Sblk, *rhs, *x, *scale_part;
+  double* M;            // nf > LM_CHOL_MAX_NB: the dense reduced system of the blocked solver (k_lmbig.hip), (ld + 48) x ld, else nullptr
+  int ld;
+  int32_t* lmb_flags;   // [ld / 48 + 1], zero between trials
+  double* lmb_inv;      // [ld / 48][3][256]: inverses of the 16 x 16 diagonal blocks of the factorised diagonal tiles
   double *chi2_out, *poses_out, *points_out;
   uint8_t *bad, *level_out;
   const volatile uint8_t* abort_flag;  // device address of a host-mapped byte the caller's stop flag is mirrored into
