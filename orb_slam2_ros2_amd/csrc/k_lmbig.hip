@@ -13,12 +13,12 @@
 //
 // One launch per tile column (48 x 48 tiles, k = -1 .. KT - 2): workgroup (i, j), k < j <= i, does
 //   A_ij -= L_ik L_jk^T                                  three waves, a 16-row strip each, 3 x 12 MFMA 16x16x4 per strip
-// and the workgroups of column j = k + 1 go on to finish THAT column: (k+1, k+1) factorises its tile in 16-column blocks (one wave
-// factorises and inverts a 16 x 16 diagonal block, rows in lanes, the column exchanged by v_readlane; the blocks below it and the
-// rank-16 updates run on the matrix cores), publishes it with the three block inverses and raises flags[k+1]; the tiles below it wait
-// for the flag and solve X L^T = A for their 48 rows by blocked substitution, X_b = (A_b - sum X_c L_bc^T) inv_bb^T, every product an
-// MFMA (a column-at-a-time substitution by one wave was 14 us a tile, the 48-column factorisation 24 us: tools/exp/lmb_bench.hip).  The diagonal workgroup is workgroup 0 of the launch and waits for nobody, so the wait cannot deadlock (workgroups are
-// dispatched in index order).  After the last launch L and y are complete; k_lmb_back solves L^T x = y with one workgroup.
+// and the workgroups of column j = k + 1 go on to finish THAT column: each updates and factorises the column's diagonal tile in
+// 16-column blocks (one wave factorises and inverts a 16 x 16 diagonal block, rows in lanes, the column exchanged by v_readlane; the
+// blocks below it and the rank-16 updates run on the matrix cores) and solves X L^T = A for its own 48 rows by blocked substitution,
+// X_b = (A_b - sum X_c L_bc^T) inv_bb^T, every product an MFMA (a column-at-a-time substitution by one wave was 14 us a tile, the
+// 48-column factorisation 24 us: tools/exp/lmb_bench.hip).  No workgroup waits for another.  After the last launch L and y are
+// complete; k_lmb_back solves L^T x = y with one workgroup.
 // Fixed summation order everywhere: run-to-run identical.  A non-positive pivot clears LmState::ok (g2o: the linear solver fails, the
 // trial is rejected) and x = 0.
 #include <hip/hip_runtime.h>
@@ -97,7 +97,7 @@ __device__ __forceinline__ bool lmb_potrf16(double* D, double* inv, int lane) {
     const double y0 = __builtin_amdgcn_rsq(d);
     const double e = fma(-(d * y0), y0, 1.0);
     y[c] = fma(y0 * e, fma(0.375, e, 0.5), y0);
-    const double l = r == c ? d * y[c] : a[c] * y[c];  // column c of L, lane = row (rows above c: garbage, never read)
+    const double l = a[c] * y[c];  // column c of L, lane = row: lane c's a[c] IS the pivot (rows above c: garbage, never read)
     a[c] = l;
 #pragma unroll
     for (int j = c + 1; j < 16; ++j) {
@@ -172,11 +172,9 @@ __device__ __forceinline__ void lmb_potrf_tile(LmbShared& sh, int wv, int lane) 
   __syncthreads();
 }
 
-// X L^T = A for the 16 rows of strip wv of the tile in sh.C, in place: L (the column's diagonal tile, row-major) in sh.Li, the inverses
+// X L^T = A for the 16 rows at R (pitch LMB_LS), in place: L = the column's factorised diagonal tile (row-major, pitch LMB_LS), the inverses
 // of its diagonal blocks in sh.Inv.  Blocked forward substitution, every product on the matrix core; a wave touches its own rows only.
-__device__ __forceinline__ void lmb_trsm_strip(LmbShared& sh, int wv, int lane) {
-  double* R = sh.C + 16 * wv * LMB_LS;
-  const double* L = sh.Li;
+__device__ __forceinline__ void lmb_trsm_strip(double* R, const double* L, LmbShared& sh, int lane) {
   lmb_d4 x = {0, 0, 0, 0};
   x = lmb_mm_abt<false>(x, R, LMB_LS, sh.Inv[0], LMB_IS, lane);  // X1 = A1 inv11^T
   lmb_d4 a2 = lmb_frag_load(R + 16, LMB_LS, lane), a3 = lmb_frag_load(R + 32, LMB_LS, lane);
@@ -202,13 +200,17 @@ __device__ __forceinline__ void lmb_trsm_strip(LmbShared& sh, int wv, int lane) 
 }
 
 // One tile column.  k: the column whose panel is final (-1: none yet); the launch finishes column k + 1.
+// EVERY workgroup of column k + 1 updates and factorises the column's diagonal tile itself (the same instructions on the same inputs:
+// the same bits) instead of waiting for the one workgroup that owns it: the owner's store -> flag -> poll -> load chain was ~9 us of
+// global round trips per column on top of the 10 us factorisation, the other CUs are idle anyway, and nothing in the kernel waits on
+// another workgroup.  Only the owner writes the tile and its block inverses back (the back substitution reads them).
 __global__ __launch_bounds__(192) void k_lmb_step(int k, int KT, int ld, double* __restrict__ M, double* __restrict__ Linv, LmState* __restrict__ st,
                                                   int32_t* __restrict__ flags) {
   __shared__ LmbShared sh;
   if (!lmb_gate(st)) return;
   if (*(volatile int32_t*)&flags[KT] != 0) return;  // an earlier column hit a bad pivot
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  // blockIdx.x -> (i, j): column-major over the trailing tiles, column k + 1 first (its diagonal tile is workgroup 0)
+  // blockIdx.x -> (i, j): column-major over the trailing tiles, column k + 1 first
   const int m = KT - 1 - k;  // tile columns left; tile rows k + 1 .. KT (KT: the right-hand-side row)
   int jq = 0, base = 0;
   while (jq < m - 1 && base + (m + 1 - jq) <= (int)blockIdx.x) {
@@ -217,13 +219,18 @@ __global__ __launch_bounds__(192) void k_lmb_step(int k, int KT, int ld, double*
   }
   const int j = k + 1 + jq, i = j + ((int)blockIdx.x - base);
   double* Aij = M + (size_t)i * LMB_T * ld + (size_t)j * LMB_T;
-  const bool diag = i == j;
-  lmb_d4 acc[3];
+  double* Ajj = M + (size_t)j * LMB_T * ld + (size_t)j * LMB_T;
+  const bool diag = i == j, column = jq == 0;
+  lmb_d4 acc[3], dacc[3];
   // C fragment of strip wv, sub-tile b: row = 16 wv + (lane >> 4) + 4 reg, col = 16 b + (lane & 15)
 #pragma unroll
   for (int b = 0; b < 3; ++b)
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) acc[b][rg] = Aij[(size_t)(16 * wv + (lane >> 4) + 4 * rg) * ld + 16 * b + (lane & 15)];
+    for (int rg = 0; rg < 4; ++rg) {
+      const size_t o = (size_t)(16 * wv + (lane >> 4) + 4 * rg) * ld + 16 * b + (lane & 15);
+      acc[b][rg] = Aij[o];
+      dacc[b][rg] = (column && !diag) ? Ajj[o] : 0.0;
+    }
   if (k >= 0) {
     const double* Lik = M + (size_t)i * LMB_T * ld + (size_t)k * LMB_T;
     const double* Ljk = M + (size_t)j * LMB_T * ld + (size_t)k * LMB_T;
@@ -237,78 +244,67 @@ __global__ __launch_bounds__(192) void k_lmb_step(int k, int KT, int ld, double*
 #pragma unroll
     for (int s = 0; s < LMB_T / 4; ++s) {
       const double a = -sh.Li[(16 * wv + row) * LMB_LS + 4 * s + kq];
+      const double aj = -sh.Lj[(16 * wv + row) * LMB_LS + 4 * s + kq];
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
-        if (diag && b > wv) continue;  // (only the lower triangle of a diagonal tile is ever read)
         const double bv = sh.Lj[(16 * b + row) * LMB_LS + 4 * s + kq];
-        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[b], 0, 0, 0);
+        if (!(diag && b > wv)) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[b], 0, 0, 0);  // (only the lower triangle of a diagonal tile is ever read)
+        if (column && !diag && b <= wv) dacc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj, bv, dacc[b], 0, 0, 0);
       }
     }
   }
-  if (jq != 0) {  // an interior tile of the trailing matrix: done
+  if (!column) {  // an interior tile of the trailing matrix: done
 #pragma unroll
     for (int b = 0; b < 3; ++b)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) Aij[(size_t)(16 * wv + (lane >> 4) + 4 * rg) * ld + 16 * b + (lane & 15)] = acc[b][rg];
     return;
   }
-  // ---- column k + 1: factorise (diagonal tile) or solve (the tiles below it) ----
+  // ---- column k + 1: the diagonal tile -> sh.C (factorised there), the own tile of a workgroup below it -> sh.Li ----
   __syncthreads();  // (the operand tiles are dead)
 #pragma unroll
   for (int b = 0; b < 3; ++b)
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) sh.C[(16 * wv + (lane >> 4) + 4 * rg) * LMB_LS + 16 * b + (lane & 15)] = acc[b][rg];
+    for (int rg = 0; rg < 4; ++rg) {
+      const int o = (16 * wv + (lane >> 4) + 4 * rg) * LMB_LS + 16 * b + (lane & 15);
+      sh.C[o] = diag ? acc[b][rg] : dacc[b][rg];
+      if (!diag) sh.Li[o] = acc[b][rg];
+    }
   if (t == 0) sh.fail = 0;
   __syncthreads();
+  lmb_potrf_tile(sh, wv, lane);
   if (diag) {
-    lmb_potrf_tile(sh, wv, lane);
     for (int e = t; e < LMB_T * LMB_T; e += 192) {
       const int r = e / LMB_T, c = e - r * LMB_T;
       Aij[(size_t)r * ld + c] = sh.C[r * LMB_LS + c];
     }
     for (int e = t; e < 3 * 256; e += 192) Linv[(size_t)j * 768 + e] = sh.Inv[e >> 8][((e & 255) >> 4) * LMB_IS + (e & 15)];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (t == 0) {
-      if (sh.fail) {
-        st->ok = 0;
-        __hip_atomic_store(&flags[KT], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __hip_atomic_store(&flags[j], sh.fail ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0 && sh.fail) {
+      st->ok = 0;
+      flags[KT] = 1;
     }
     return;
   }
-  // wait for the diagonal tile of this column (workgroup 0 of this launch: dispatched before this one, waits for nobody)
-  if (t == 0) {
-    int f;
-    while ((f = __hip_atomic_load(&flags[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(2);
-    sh.fail = f == 2;
-  }
-  __syncthreads();
   if (sh.fail) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  const double* Ljj = M + (size_t)j * LMB_T * ld + (size_t)j * LMB_T;
-  for (int e = t; e < LMB_T * LMB_T; e += 192) {
-    const int r = e / LMB_T, c = e - r * LMB_T;
-    sh.Li[r * LMB_LS + c] = __builtin_nontemporal_load(&Ljj[(size_t)r * ld + c]);
-  }
-  for (int e = t; e < 3 * 256; e += 192) sh.Inv[e >> 8][((e & 255) >> 4) * LMB_IS + (e & 15)] = __builtin_nontemporal_load(&Linv[(size_t)j * 768 + e]);
-  __syncthreads();
-  lmb_trsm_strip(sh, wv, lane);
+  lmb_trsm_strip(sh.Li + 16 * wv * LMB_LS, sh.C, sh, lane);
   __syncthreads();
   for (int e = t; e < LMB_T * LMB_T; e += 192) {
     const int r = e / LMB_T, c = e - r * LMB_T;
-    Aij[(size_t)r * ld + c] = sh.C[r * LMB_LS + c];
+    Aij[(size_t)r * ld + c] = sh.Li[r * LMB_LS + c];
   }
 }
 
 // L^T x = y (y = row ld of M after the factorisation), one workgroup; resets the column flags for the next trial.
-__global__ __launch_bounds__(1024) void k_lmb_back(int n, int KT, int ld, const double* __restrict__ M, LmState* __restrict__ st, int32_t* __restrict__ flags,
-                                                  double* __restrict__ x) {
+// Per tile column, from the last: x_k = L_kk^-T y_k by blocked backward substitution with the three 16 x 16 inverses the factorisation
+// left behind (five 16 x 16 matrix-vector products, sixteen lanes each), then y_j -= L_kj^T x_k for every column left of the tile
+// (one column per thread, its 48 loads in flight at once); the next diagonal tile is requested before the panel update and lands under it.
+// (First version: a 48-step substitution straight from global memory, 1.75 ms at 300 keyframes; from LDS 0.40 ms.)
+__global__ __launch_bounds__(1024) void k_lmb_back(int n, int KT, int ld, const double* __restrict__ M, const double* __restrict__ Linv,
+                                                   LmState* __restrict__ st, int32_t* __restrict__ flags, double* __restrict__ x) {
 #pragma clang fp contract(fast)
-  extern __shared__ double lmb_y[];  // [ld] y -> x, then [48] the x of the current tile, then its diagonal tile
+  extern __shared__ double lmb_y[];  // [ld] y -> x | [48] x of the current tile | [48][49] its diagonal tile | [3][16][17] the inverses
   if (!lmb_gate(st)) return;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int t = threadIdx.x;
   const bool failed = *(volatile int32_t*)&flags[KT] != 0;
   if (failed) {
     for (int c = t; c < n; c += 1024) x[c] = 0.0;
@@ -317,32 +313,64 @@ __global__ __launch_bounds__(1024) void k_lmb_back(int n, int KT, int ld, const 
     return;
   }
   double* xs = lmb_y + ld;
+  double* Lt = xs + LMB_T;
+  double* Iv = Lt + LMB_T * LMB_LS;
   for (int c = t; c < ld; c += 1024) lmb_y[c] = M[(size_t)ld * ld + c];
-  __syncthreads();
-  double* Lt = xs + LMB_T;  // [48][49]: the diagonal tile of the current column (a serial chain must not wait on global loads)
-  for (int kt = KT - 1; kt >= 0; --kt) {
+  // (tile elements of thread t: e = t, t + 1024, t + 2048 of 2304; inverse elements e = t of 768)
+  auto tile_fetch = [&](int kt, double (&v)[3], double& iv) {
     const double* Lkk = M + (size_t)kt * LMB_T * ld + (size_t)kt * LMB_T;
-    for (int e = t; e < LMB_T * LMB_T; e += 1024) {
-      const int r = e / LMB_T, c = e - r * LMB_T;
-      Lt[r * LMB_LS + c] = Lkk[(size_t)r * ld + c];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int e = t + 1024 * u;
+      v[u] = e < LMB_T * LMB_T ? Lkk[(size_t)(e / LMB_T) * ld + e % LMB_T] : 0.0;
     }
-    __syncthreads();
-    if (wv == 0) {
-      // L_kk^T x_k = y_k: column-oriented, lane r holds y_r; x_c is final once the rows c' > c have been subtracted
-      const int r = lane < LMB_T ? lane : LMB_T - 1;
-      double yv = lmb_y[kt * LMB_T + r];
-#pragma unroll 4
-      for (int c = LMB_T - 1; c >= 0; --c) {
-        const double lc = Lt[c * LMB_LS + r];  // row c of L_kk (columns r <= c matter)
-        const double dcc = Lt[c * LMB_LS + c];
-        const double yc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(yv), c), __builtin_amdgcn_readlane(__double2loint(yv), c));
-        const double xc = yc / dcc;
-        if (lane == c) yv = xc;
-        if (lane < c) yv = fma(-lc, xc, yv);
-      }
-      if (lane < LMB_T) {
-        xs[lane] = yv;
-        lmb_y[kt * LMB_T + lane] = yv;
+    iv = t < 768 ? Linv[(size_t)kt * 768 + t] : 0.0;
+  };
+  auto tile_store = [&](const double (&v)[3], double iv) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int e = t + 1024 * u;
+      if (e < LMB_T * LMB_T) Lt[(e / LMB_T) * LMB_LS + e % LMB_T] = v[u];
+    }
+    if (t < 768) Iv[(t >> 8) * 16 * LMB_IS + ((t & 255) >> 4) * LMB_IS + (t & 15)] = iv;
+  };
+  double tv[3], tiv;
+  tile_fetch(KT - 1, tv, tiv);
+  tile_store(tv, tiv);
+  __syncthreads();
+  for (int kt = KT - 1; kt >= 0; --kt) {
+    if (kt > 0) tile_fetch(kt - 1, tv, tiv);  // lands under this step's work
+    if (t < 64) {
+      // out[i] = sum_k Mx[k][i] v[k] over a 16 x 16 block (transposed product), lanes 0..15
+      const int i = t & 15;
+      double* yk = lmb_y + kt * LMB_T;
+      auto mv_t = [&](const double* Mx, int pitch, const double* v) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; k2 += 2) {
+          s0 = fma(Mx[k2 * pitch + i], v[k2], s0);
+          s1 = fma(Mx[(k2 + 1) * pitch + i], v[k2 + 1], s1);
+        }
+        return s0 + s1;
+      };
+      const double x3 = mv_t(Iv + 2 * 16 * LMB_IS, LMB_IS, yk + 32);
+      if (t < 16) xs[32 + i] = x3;
+      lmb_wave_sync();
+      const double y2 = yk[16 + i] - mv_t(Lt + 32 * LMB_LS + 16, LMB_LS, xs + 32);
+      lmb_wave_sync();
+      if (t < 16) yk[16 + i] = y2;
+      lmb_wave_sync();
+      const double x2 = mv_t(Iv + 16 * LMB_IS, LMB_IS, yk + 16);
+      if (t < 16) xs[16 + i] = x2;
+      lmb_wave_sync();
+      const double y1 = yk[i] - (mv_t(Lt + 32 * LMB_LS, LMB_LS, xs + 32) + mv_t(Lt + 16 * LMB_LS, LMB_LS, xs + 16));
+      lmb_wave_sync();
+      if (t < 16) yk[i] = y1;
+      lmb_wave_sync();
+      const double x1 = mv_t(Iv, LMB_IS, yk);
+      if (t < 16) {
+        xs[i] = x1;
+        yk[i] = x1, yk[16 + i] = x2, yk[32 + i] = x3;
       }
     }
     __syncthreads();
@@ -362,6 +390,7 @@ __global__ __launch_bounds__(1024) void k_lmb_back(int n, int KT, int ld, const 
       }
       lmb_y[c] -= (s0 + s1) + (s2 + s3);
     }
+    if (kt > 0) tile_store(tv, tiv);  // (the tile solve of this step is over: the barrier above)
     __syncthreads();
   }
   for (int c = t; c < n; c += 1024) x[c] = lmb_y[c];
@@ -386,7 +415,8 @@ void launch_lm_chol_big(hipStream_t s, const LmLaunch& L) {
     const int grid = k < 0 ? m + 1 : m * (m + 3) / 2;
     hipLaunchKernelGGL(k_lmb_step, dim3(grid), dim3(192), 0, s, k, KT, L.ld, L.M, L.lmb_inv, L.state, L.lmb_flags);
   }
-  hipLaunchKernelGGL(k_lmb_back, dim3(1), dim3(1024), (size_t)(L.ld + LMB_T + LMB_T * LMB_LS) * sizeof(double), s, 6 * L.nf, KT, L.ld, L.M, L.state, L.lmb_flags, L.x);
+  hipLaunchKernelGGL(k_lmb_back, dim3(1), dim3(1024), (size_t)(L.ld + LMB_T + LMB_T * LMB_LS + 3 * 16 * LMB_IS) * sizeof(double), s, 6 * L.nf, KT, L.ld, L.M, L.lmb_inv, L.state, L.lmb_flags,
+                     L.x);
 }
 
 }  // namespace orbfe

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(192) void k_time_potrf(const double* __restrict__ A
     __syncthreads();
     const long long t0 = __builtin_amdgcn_s_memtime();
     if (what == 0) lmb_potrf_tile(sh, wv, lane);
-    else lmb_trsm_strip(sh, wv, lane);
+    else lmb_trsm_strip(sh.C + 16 * wv * LMB_LS, sh.Li, sh, lane);
     __syncthreads();
     tot += __builtin_amdgcn_s_memtime() - t0;
   }
@@ -97,6 +97,19 @@ int main(int argc, char** argv) {
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     best = std::min(best, ms);
+  }
+  {  // the back substitution alone (L and y are in place; it only reads them)
+    float bb = 1e9;
+    for (int rep = 0; rep < 5; ++rep) {
+      hipEventRecord(e0, 0);
+      hipLaunchKernelGGL(k_lmb_back, dim3(1), dim3(1024), (size_t)(ld + LMB_T + LMB_T * LMB_LS + 3 * 16 * LMB_IS) * sizeof(double), 0, n, KT, ld, dM, dinv, dst, dfl, dx);
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      bb = std::min(bb, ms);
+    }
+    printf("  back substitution alone %.3f ms\n", bb);
   }
   std::vector<double> xg(n);
   hipMemcpy(xg.data(), dx, n * 8, hipMemcpyDeviceToHost);
