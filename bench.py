@@ -185,18 +185,21 @@ def sequence_batch(block_frames, max_pairs):
     return max(1, min(max_pairs, (max(block_frames, 1) + 3) // 4))
 
 
-def sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend, collective, window=1):
+def sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend, collective, window=1, exchange="shared"):
     """One timed sequence: F stereo pairs (frame f = synthetic frame f mod U) cut into blocks per rank, each rank streaming its block from
-    page-locked host memory in batches of <= B, records packed on the device straight into the send buffer of the batch's WINDOW, every
-    window gathered on rank 0 (RCCL / the test backend) while the next one is computed and drained from there to page-locked host memory
-    -- then every record checked.  collective: take the gather through the process group even with one rank.
-    Returns (seconds, frames of this rank, records checked against the host path)."""
+    page-locked host memory in batches of <= B, records packed on the device straight into the buffer of the batch's WINDOW, and
+      exchange = "shared": every rank copies its windows into its rows of ONE page-locked POSIX shared-memory segment over its own PCIe
+                 link while the next window is computed; the collective carries the 16-byte record heads only (sharding.WindowDrain);
+      exchange = "gather": every window gathered on rank 0 over the collective and drained from there to page-locked host memory
+                 (sharding.WindowGather: all records cross rank 0's one PCIe link)
+    -- then every record checked.  collective: take the collective through the process group even with one rank.
+    Returns (seconds, frames of this rank, records checked against the host path, info)."""
     import torch
     import torch.distributed as dist
 
     from orb_slam2_ros2_amd import synth
     from orb_slam2_ros2_amd.sequence import DeviceSequenceProcessor, record_bytes, run_sequence, unpack_record
-    from orb_slam2_ros2_amd.sharding import frame_range
+    from orb_slam2_ros2_amd.sharding import SharedRecordStore, frame_range
 
     b, e = frame_range(F, rank, world)
     proc = DeviceSequenceProcessor(ctx, lambda f: synth.stereo_pair(f % U, W, H), B, FX, BF, dev, content_key=lambda f: f % U)
@@ -215,25 +218,60 @@ def sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend, collective, wind
             dist.barrier()
             torch.cuda.synchronize()
 
-    host_out = torch.empty((F, record_bytes(ctx.n_features)), dtype=torch.uint8).pin_memory() if rank == 0 else None  # where the result lands
+    rb = record_bytes(ctx.n_features)
+    store, host_out = None, None
+    if exchange == "shared":
+        # rank 0 creates the segment (a file in /dev/shm: no GPU involved), the others map it after the barrier; every rank page-locks
+        # its mapping for its own GPU
+        name = f"orbfe_seq_{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if world > 1 else os.getpid()}_{F}"
+        if rank == 0:
+            try:
+                os.unlink(os.path.join("/dev/shm", name))
+            except FileNotFoundError:
+                pass
+            store = SharedRecordStore(name, F, rb, create=True)
+        if world > 1:
+            dist.barrier()
+        if rank != 0:
+            store = SharedRecordStore(name, F, rb, create=False)
+        store.pin()
+    elif rank == 0:
+        host_out = torch.empty((F, rb), dtype=torch.uint8).pin_memory()  # where the result lands
 
     def sink(first, t):   # rank 0: one rank's part of a finished window -> page-locked host memory, behind the gather on torch's stream
         host_out[first:first + t.shape[0]].copy_(t, non_blocking=True)
 
-    kw = dict(window=window, sink=sink if rank == 0 else None, collect_into=proc.collect_into if on_device else None,
-              force_collective=collective)
+    kw = dict(window=window, collect_into=proc.collect_into if on_device else None, force_collective=collective)
+    if store is not None:
+        kw["store"] = store
+    else:
+        kw["sink"] = sink if rank == 0 else None
     # warm-up: one pass over (at most) two batches per rank, including the exchange
     run_sequence(min(F, 2 * B * world), rank, world, B, proc.submit, collect, **kw)
     sync_all()
     t0 = time.perf_counter()
-    _, n_local = run_sequence(F, rank, world, B, proc.submit, collect, **kw)
-    rec_host = host_out
+    summary, n_local = run_sequence(F, rank, world, B, proc.submit, collect, **kw)
+    t_rank = time.perf_counter() - t0   # this rank's own frames are in host memory (shared) / handed to the collective (gather)
+    rec_host = store.tensor if store is not None else host_out
     sync_all()
     dt = time.perf_counter() - t0
+    rates = [n_local / t_rank if t_rank > 0 else 0.0]
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        mine = torch.tensor([rates[0]], dtype=torch.float64, device=xdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rates = [float(t.item()) for t in allr]
+    info = {"exchange": exchange, "per_rank_pairs_per_s": [round(r, 1) for r in rates],
+            "communicator_nranks": dist.get_world_size() if dist.is_initialized() else 0,
+            "payload": ("records: each rank -> its rows of one page-locked POSIX shared-memory segment over its own PCIe link; collective: "
+                        "16 B per frame (n, n_matches)") if exchange == "shared" else
+                       "records: gathered on rank 0 over the collective, drained from there over rank 0's PCIe link",
+            "collective_bytes": int(F) * (16 if exchange == "shared" else rb), "host_bytes": int(F) * rb}
+    if store is not None and rank == 0 and summary is not None:
+        info["summary_rows"] = int(summary.shape[0])
     checked = 0
     if rank == 0:
         # every frame's record against the record of the first frame with the same content (frames repeat with period U), and the
@@ -252,10 +290,18 @@ def sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend, collective, wind
                     and np.array_equal(u["right_u"], ru[:n]) and np.array_equal(u["depth"], dp[:n])):
                 raise SystemExit(f"bench.py: sequence: record of frame {f} differs from the host-pointer path")
             checked += 1
+        if store is not None and summary is not None:   # the gathered heads against the records in the segment
+            heads = np.ascontiguousarray(r[:, :16]).view(np.int32)
+            if not np.array_equal(heads, summary.numpy()):
+                raise SystemExit("bench.py: sequence: the gathered record heads differ from the records in the shared segment")
     for l, r_ in set(proc.pinned.values()):
         l.free()
         r_.free()
-    return dt, n_local, checked
+    if store is not None:
+        if world > 1:
+            dist.barrier()   # rank 0 has read what it checks
+        store.close()
+    return dt, n_local, checked, info
 
 
 def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend, collective):
@@ -273,7 +319,8 @@ def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend, collect
     b, e = frame_range(F, rank, world)
     B = sequence_batch((F + world - 1) // world, B)   # from the per-rank block size, the same on every rank
     ctx = Context(W, H, NFEAT, NLEVELS, SCALE, TH_HI, TH_LO, device_id=local_rank, max_images=2 * B)
-    dt, n_local, checked = sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend, collective, window=max(1, args.sequence_window))
+    dt, n_local, checked, xinfo = sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend, collective, window=max(1, args.sequence_window),
+                                               exchange=args.sequence_exchange)
     line = None
     if rank == 0:
         n_batches = (max(e - b, 1) + B - 1) // B
@@ -285,15 +332,16 @@ def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend, collect
             "config": {
                 "workload": f"Full KITTI-00-shaped sequence ({F} stereo pairs, {U} distinct synthetic frames) frame-sharded across "
                             f"{world} GPU(s), gather of the per-frame records to rank 0",
-                "io": "page-locked host images -> device (upload overlapped with compute); records packed on the device, gathered per "
-                      f"window of {max(1, args.sequence_window)} batch(es) over " + (("RCCL" if collective else "no collective (single rank)") if backend == "nccl" else backend) +
-                      " while the next window is computed, drained to page-locked host memory of rank 0 -- all inside the timed region",
-                "gathered_payload": "per frame: n, n_matches, left keypoints [2000 x 28 B], left descriptors [2000 x 32 B], right_u and "
-                                    "depth [2000 x f64]",
-                "record_bytes": record_bytes(ctx.n_features), "gathered_bytes": int(F) * record_bytes(ctx.n_features),
+                "io": "page-locked host images -> device (upload overlapped with compute); records packed on the device, per "
+                      f"window of {max(1, args.sequence_window)} batch(es) brought to one host memory (see exchange.payload; collective: " +
+                      (("RCCL" if collective else "none (single rank)") if backend == "nccl" else backend) +
+                      ") while the next window is computed -- all inside the timed region",
+                "record": "per frame: n, n_matches, left keypoints [2000 x 28 B], left descriptors [2000 x 32 B], right_u and "
+                          "depth [2000 x f64]",
+                "record_bytes": record_bytes(ctx.n_features), "result_bytes": int(F) * record_bytes(ctx.n_features),
                 "pairs_per_batch": B, "batches_per_window": max(1, args.sequence_window), "frames_rank0": n_local,
                 "records_checked_against_host_path": checked, "records_checked_for_repeat_consistency": max(0, F - min(U, F)),
-                "collective_executed": bool(collective),
+                "collective_executed": bool(collective), "exchange": xinfo,
                 "parallelism": f"frame_range blocks over {world} GPU(s)",
             },
             "roofline": None, "cpu_baseline": None,
@@ -448,12 +496,28 @@ def ba_leg(device_id):
                                       "in, host results out", iterations=gl["iters"],
                                  cpu_baseline={"ms": _cpu_ms(lambda: orc.ba_local_optimize(pr, fixed), 2.0, 3), "cores": 1, "kind": "port"},
                                  verified=True)
-    # the same with 300 free keyframes (multi-workgroup Cholesky); checked against the oracle in the GPU suite, timed here
+    # the same over the window size: past 42 free keyframes the blocked multi-workgroup Cholesky (fp64 MFMA) takes the reduced system; the
+    # 43 / 64 / 100 problems are 50 points per keyframe and 10 fixed keyframes (tools/lba_sizes.py), the 300 one is the GPU suite's
+    for nf_w in (43, 64, 100):
+        n_kf = nf_w + 10
+        w = ba_synth.make_problem(seed=100 + nf_w, n_kf=n_kf, n_pt=50 * n_kf, with_truth=True)
+        fw = np.zeros(n_kf, np.uint8)
+        fw[:10] = 1
+        w["poses"][:10] = w["poses_true"][:10]
+        out[f"local_optimize_{nf_w}_free_keyframes"] = dict(_stats_ms(lambda: ctx.ba_local_optimize(w, fw), 5, warm=1), edges=int(w["edge_pose"].size),
+                                                            cpu_baseline={"ms": _cpu_ms(lambda: orc.ba_local_optimize(w, fw), 1.0, 1), "cores": 1, "kind": "port"})
     big = ba_synth.make_problem(seed=13, n_kf=310, n_pt=4000, with_truth=True)
     fb = np.zeros(310, np.uint8)
     fb[:10] = 1
     big["poses"][:10] = big["poses_true"][:10]
-    out["local_optimize_300_free_keyframes"] = dict(_stats_ms(lambda: ctx.ba_local_optimize(big, fb), 5, warm=1), edges=int(big["edge_pose"].size))
+    gb = ctx.ba_local_optimize(big, fb)
+    t0 = time.perf_counter()
+    ob = orc.ba_local_optimize(big, fb)
+    cpu_big_ms = (time.perf_counter() - t0) * 1e3
+    if tuple(gb["iters"]) != tuple(ob["iters"]) or np.abs(gb["points"] - ob["points"]).max() > 1e-7:
+        raise SystemExit("bench.py: ba leg: the 300-keyframe local BA differs from the oracle")
+    out["local_optimize_300_free_keyframes"] = dict(_stats_ms(lambda: ctx.ba_local_optimize(big, fb), 5, warm=1), edges=int(big["edge_pose"].size),
+                                                    cpu_baseline={"ms": cpu_big_ms, "cores": 1, "kind": "port", "sample": "one call"}, verified=True)
     # pose only
     pp = ba_synth.make_pose_problem()
     a = (pp["Xw"], pp["meas"], pp["info"], pp["sigma2"], pp["pose"], pp["fx"], pp["fy"], pp["cx"], pp["cy"], pp["bf"])
@@ -562,9 +626,13 @@ def main():
                     help="run a whole sequence of this many stereo pairs (BASELINE config 4: 4541), sharded over the ranks, instead of the "
                          "fixed-batch step loop")
     ap.add_argument("--sequence-unique", type=int, default=64, help="distinct synthetic frames behind the sequence (frame f = f mod this)")
-    ap.add_argument("--sequence-leg", type=int, default=1024,
-                    help="frames PER RANK of the short sequence job reported beside the step loop (`sequence` object: blocks per rank, records "
-                         "gathered on rank 0 -- over RCCL when N > 1); 0 skips it")
+    ap.add_argument("--sequence-leg", type=int, default=4541,
+                    help="frames of the sequence job reported beside the step loop (`sequence` object: BASELINE config 4 -- 4541 stereo pairs cut "
+                         "into blocks over the ranks, the per-frame records brought to one host memory); 0 skips it")
+    ap.add_argument("--sequence-exchange", choices=["shared", "gather"], default="shared",
+                    help="how the per-frame records of a sequence job reach one place: 'shared' = every rank drains its windows into one "
+                         "page-locked POSIX shared-memory segment over its own PCIe link, the collective carries 16 B per frame; 'gather' = "
+                         "the records are gathered on rank 0 over the collective and drained over rank 0's link")
     ap.add_argument("--sequence-window", type=int, default=1, help="batches per gather window of the sequence job (sharding.WindowGather)")
     ap.add_argument("--legs", default="cfg3,ba,latency", help="comma-separated extra legs of the default line (north_star beyond the stereo step): "
                     "cfg3 (2000x2000 Hamming), ba (config-5 edge evaluation / normal equations / local BA / pose-only), latency (one pair, host "
@@ -786,18 +854,18 @@ def main():
 
     seq_leg = None
     if args.sequence_leg > 0:
-        F_leg = args.sequence_leg * world
+        F_leg = args.sequence_leg   # the whole job, cut into blocks over the ranks (BASELINE config 4: 4541)
         U_leg = max(1, min(args.sequence_unique, 128))
-        B_leg = sequence_batch(args.sequence_leg, B)
-        t_seq, _, n_chk = sequence_job(ctx, F_leg, B_leg, U_leg, rank, world, dev, xdev, backend, collective, window=max(1, args.sequence_window))
-        seq_leg = {"frames": F_leg, "pairs_per_s": F_leg / t_seq, "seconds": t_seq, "gathered_bytes": F_leg * ctx.record_bytes(),
+        B_leg = sequence_batch((F_leg + world - 1) // world, B)
+        t_seq, _, n_chk, xinfo = sequence_job(ctx, F_leg, B_leg, U_leg, rank, world, dev, xdev, backend, collective, window=max(1, args.sequence_window),
+                                              exchange=args.sequence_exchange)
+        seq_leg = {"frames": F_leg, "pairs_per_s": F_leg / t_seq, "seconds": t_seq, "result_bytes": F_leg * ctx.record_bytes(), "exchange": xinfo,
                    "pairs_per_batch": B_leg, "batches_per_window": max(1, args.sequence_window), "collective_executed": bool(collective),
                    "records_checked_against_host_path": n_chk, "records_checked_for_repeat_consistency": max(0, F_leg - min(U_leg, F_leg)),
-                   "what": "BASELINE config 4 in small: contiguous blocks of frames per rank, page-locked host images -> extraction + stereo match "
-                           "-> per-frame records packed on the device -> a gather per window to rank 0 (" +
+                   "what": "BASELINE config 4: contiguous blocks of frames per rank, page-locked host images -> extraction + stereo match "
+                           "-> per-frame records packed on the device -> (exchange.payload) under the next window's compute, collective = " +
                            (("RCCL" if collective else "none: single rank, no process group") if backend == "nccl" else backend) +
-                           ") under the next window's compute -> page-locked host memory, all inside the timed region; "
-                           "`python bench.py --sequence 4541` runs the full one"}
+                           ", all inside the timed region; `python bench.py --sequence 4541` runs the same job as the whole line"}
 
     live_ms, live_n = live[dom]
     stages_inline = dict(stages)

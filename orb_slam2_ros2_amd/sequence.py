@@ -65,7 +65,7 @@ def unpack_record(rec: np.ndarray, n_features: int) -> dict:
 
 def run_sequence(n_frames: int, rank: int, world: int, batch_pairs: int, submit: Callable[[Sequence[int]], object],
                  collect: Callable[[object], "object"], depth: int = 3, dst: int = 0, window: int = 0, sink=None, collect_into=None,
-                 force_collective: bool = False):
+                 force_collective: bool = False, store=None):
     """Process this rank's block of the sequence in batches of <= batch_pairs frames, `depth` batches in flight, and gather all
     records on `dst`.
 
@@ -76,10 +76,15 @@ def run_sequence(n_frames: int, rank: int, world: int, batch_pairs: int, submit:
     (sharding.WindowGather) that runs while the next window is computed; on dst every finished part goes to sink(first_frame, tensor)
     (e.g. a non-blocking copy to page-locked host memory) or, without a sink, is kept and returned assembled.  collect_into(handle,
     out) packs a batch straight into a slice of the window's send buffer (no intermediate tensor).
+    store (a sharding.SharedRecordStore, window > 0): the records do not cross GPUs at all -- every rank copies its windows into its rows
+    of the node's shared page-locked host segment over its own PCIe link (sharding.WindowDrain) and only the 16-byte record heads are
+    gathered; the first return value is then the int32 [n_frames, 4] summary (n, n_matches, 0, 0) on dst.
     Returns (records [n_frames, record_bytes] on dst / None elsewhere or when a sink took them, number of frames this rank processed)."""
     import torch
     b, e = frame_range(n_frames, rank, world)
     B = max(1, batch_pairs)
+    if store is not None and window <= 0:
+        raise ValueError("run_sequence: a shared record store needs window > 0")
     if window <= 0:
         chunks, flight = [], []
         for s in range(b, e, B):
@@ -94,10 +99,13 @@ def run_sequence(n_frames: int, rank: int, world: int, batch_pairs: int, submit:
             local = collect(submit(range(0, 0)))[:0]
         return gather_frames(local, n_frames, rank, world, dst, force_collective), e - b
 
-    from .sharding import WindowGather
+    from .sharding import WindowDrain, WindowGather
     proto = collect(submit(range(0, 0)))   # zero-frame batch: record shape, dtype and device
     win = window * B
-    wg = WindowGather(n_frames, rank, world, win, tuple(proto.shape[1:]), proto.dtype, proto.device, dst, sink, force_collective)
+    if store is not None:
+        wg = WindowDrain(n_frames, rank, world, win, tuple(proto.shape[1:]), proto.dtype, proto.device, store, dst, force_collective)
+    else:
+        wg = WindowGather(n_frames, rank, world, win, tuple(proto.shape[1:]), proto.dtype, proto.device, dst, sink, force_collective)
     starts = list(range(b, e, B))
     flight, nxt = [], 0
 

@@ -50,6 +50,26 @@ def main():
     assert rec is None and np.array_equal(host.numpy(), plain_h), "windowed gather differs"
     n_windows = (n_frames + batch - 1) // batch
     assert calls == [(w * batch, min(batch, n_frames - w * batch)) for w in range(n_windows)], calls
+    # the same windows WITHOUT collect_into: the send buffer is filled by an asynchronous copy on torch's current stream, which the
+    # gather's side stream has to wait for
+    host.fill_(0xEE)
+    rec, _ = run_sequence(n_frames, 0, 1, batch, proc.submit, proc.collect, window=1, sink=sink, force_collective=True)
+    torch.cuda.synchronize()
+    assert rec is None and np.array_equal(host.numpy(), plain_h), "windowed gather (copy_ fallback) differs"
+    # one node = one host memory: the records drained into a page-locked POSIX shared-memory segment (hipHostRegister) by the rank
+    # itself, RCCL carries the 16-byte record heads only (sharding.WindowDrain)
+    from orb_slam2_ros2_amd.sharding import SharedRecordStore
+    store = SharedRecordStore(f"orbfe_rccl1_{os.getpid()}", n_frames, record_bytes(ctx.n_features), create=True)
+    try:
+        store.array[:] = 0xEE
+        store.pin()
+        assert store.pinned and store.tensor.is_pinned()
+        summary, _ = run_sequence(n_frames, 0, 1, batch, proc.submit, proc.collect, window=1, collect_into=proc.collect_into,
+                                  force_collective=True, store=store)
+        assert np.array_equal(np.array(store.array), plain_h), "shared-segment drain differs"
+        assert np.array_equal(summary.numpy(), np.ascontiguousarray(plain_h[:, :16]).view(np.int32)), "gathered record heads differ"
+    finally:
+        store.close()
     # the per-pair summary gather of bench.py's step loop
     summary = torch.arange(4 * 16, dtype=torch.int32, device=dev).reshape(16, 4)
     outs = [torch.empty_like(summary)]

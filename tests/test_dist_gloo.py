@@ -219,3 +219,62 @@ def test_window_gather_rejects_out_of_order_and_unfinished_windows():
     wg.push(2)
     out = wg.finish()
     assert out.shape == (5, 3) and out[:, 0].tolist() == [1, 1, 2, 2, 3]
+
+
+# ---- the shared host segment (one node = one host memory): every rank drains its own windows, only the record heads are gathered ----
+def _drain_worker(rank, world, port, n_frames, batch, window, name, q):
+    import torch.distributed as dist
+    from orb_slam2_ros2_amd.sequence import record_bytes, run_sequence
+    from orb_slam2_ros2_amd.sharding import SharedRecordStore
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    store = SharedRecordStore(name, n_frames, record_bytes(NF_SMALL), create=False)   # the parent created it before any rank started
+    submit, collect = _small_frame_processor()
+    summary, n_local = run_sequence(n_frames, rank, world, batch, submit, collect, window=window, store=store, force_collective=(world == 1))
+    if rank == 0:
+        q.put((summary.numpy(), n_local))
+    else:
+        assert summary is None
+    store.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames,batch,window", [(4, 11, 2, 1),   # per 3: the last rank holds 2 frames (uneven blocks, ragged windows)
+                                                         (4, 2, 2, 1),    # per 1: ranks 2 and 3 hold nothing
+                                                         (2, 9, 2, 2),
+                                                         (1, 5, 2, 1)])   # one rank through the collective
+def test_shared_host_segment_drain_equals_single_gather(world, n_frames, batch, window):
+    """sharding.WindowDrain: the records land in a POSIX shared-memory segment (each rank writes its own rows), the collective carries
+    only (n, n_matches) per frame -- against the records of a single-process run."""
+    import uuid
+    import torch.multiprocessing as mp
+    from orb_slam2_ros2_amd.sequence import record_bytes, run_sequence, unpack_record
+    from orb_slam2_ros2_amd.sharding import SharedRecordStore
+    name = f"orbfe_test_{uuid.uuid4().hex[:12]}"
+    store = SharedRecordStore(name, n_frames, record_bytes(NF_SMALL), create=True)
+    try:
+        store.array[:] = 0xEE
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_drain_worker, args=(r, world, port, n_frames, batch, window, name, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        summary, n0 = q.get(timeout=240)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        submit, collect = _small_frame_processor()
+        ref, _ = run_sequence(n_frames, 0, 1, batch, submit, collect)
+        ref = ref.numpy()
+        got = np.array(store.array)
+        assert got.shape == ref.shape and np.array_equal(got, ref)
+        assert n0 == min(n_frames, (n_frames + world - 1) // world)
+        for f in range(n_frames):
+            u = unpack_record(ref[f], NF_SMALL)
+            assert tuple(summary[f]) == (u["n"], u["n_matches"], 0, 0)
+    finally:
+        store.close()
+    assert not os.path.exists(os.path.join("/dev/shm", name))
