@@ -31,7 +31,8 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the first HIP call (see orb_slam2_ros2_amd/__init__.py): one hardware queue per stream
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the first HIP call: one hardware queue per stream of the streaming legs
+                                                    # (= orbfe_recommended_hw_queues(); the library only warns, it cannot set it)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -637,9 +638,6 @@ def main():
     ap.add_argument("--legs", default="cfg3,ba,latency", help="comma-separated extra legs of the default line (north_star beyond the stereo step): "
                     "cfg3 (2000x2000 Hamming), ba (config-5 edge evaluation / normal equations / local BA / pose-only), latency (one pair, host "
                     "to host, in the reference's call shape); '' skips them")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="half-batch streams the library may split a batch over (1 = none, the library default and the fastest "
-                         "setting measured; the blur-under-quadtree overlap inside a batch is independent of this)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -711,7 +709,6 @@ def main():
             rccl_note = f"init_process_group('nccl', world_size=1) failed: {type(ex).__name__}: {ex}"
             collective = False
 
-    os.environ["ORBFE_STREAMS"] = str(max(1, args.streams))
     from orb_slam2_ros2_amd import synth
     from orb_slam2_ros2_amd._lib import Context
 
@@ -790,10 +787,9 @@ def main():
     prof = ctx.profile_read()
     ctx.profile_enable(0)
     stages = {k: (ms / n if n else 0.0) for k, (ms, n) in prof.items() if n}
-    n_chunks = max(1, min(args.streams, 4, B // 8))
-    images_per_launch = 2 * B // n_chunks
+    images_per_launch = 2 * B
     stage_bytes = {k: per_image_bytes[k] * images_per_launch for k in per_image_bytes}
-    stage_bytes["stereo"] = match_bytes * B // n_chunks
+    stage_bytes["stereo"] = match_bytes * B
     dom = max((k for k in stages if k in stage_bytes), key=lambda k: stages[k])
     stage_id = {"resize": 0, "blur": 1, "fast": 2, "quadtree": 3, "orient_brief": 4, "stereo": 5}[dom]
 
@@ -897,7 +893,6 @@ def main():
                         "searchByStereo; batched",
             "io": "device-resident",   # images are in HBM when the clock starts, results stay there (see host_io for the PCIe-inclusive rate)
             "pairs_per_step_per_gpu": B,
-            "streams": args.streams,
             "n_features": NFEAT,
             "levels": NLEVELS,
             "parallelism": f"frames sharded over {world} GPU(s), RCCL gather of per-pair results at sequence end",

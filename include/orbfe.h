@@ -176,6 +176,10 @@ void* orbfe_host_alloc(size_t bytes); /* page-locked host memory (NULL on failur
  * multi-rank job calls with its own device, so that ranks which never called hipSetDevice do not all pin to GPU 0's node          */
 void* orbfe_host_alloc_on(int32_t device_id, size_t bytes);
 void orbfe_host_free(void* p);
+/* Hardware queues the streaming entry points want (GPU_MAX_HW_QUEUES, read by the HIP runtime at the process's FIRST HIP call: the
+ * process exports it, a library cannot).  orbfe_stream_submit prints one line on stderr when the variable is unset or below 8; the
+ * one-frame-at-a-time entry points are faster with the runtime's default and never ask for it.                                   */
+int32_t orbfe_recommended_hw_queues(void);
 orbfe_status orbfe_stream_submit(orbfe_ctx* ctx, const uint8_t* left, const uint8_t* right, size_t stride_bytes,
                                  size_t image_pitch_bytes, int32_t n_pairs, float fx, float bf, const orbfe_batch_results* out,
                                  int64_t* ticket);

@@ -4,15 +4,20 @@ ORBExtractor / ORBMatcher / Optimizer call shapes.  See include/orbfe.h for the 
 Importing this package does not load the HIP library; constructing any of the classes does, and raises
 if the library or a device is missing (there is no CPU fallback).
 """
-import os as _os
 
-# The front end keeps up to eight HIP streams busy at once (compute, stereo match, blur, upload, download, the slot lanes, torch's and
-# RCCL's own), and the HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues -- 4 by default.  Two
-# streams that share a queue run one after the other: with 4 queues the upload of batch k+1 queued behind the kernels of batch k and the
-# 4541-pair sequence took 0.127 s; with 16 it takes 0.087 s (profiles/r3_hw_queues.txt).  Read by the runtime at its first HIP call,
-# so it is set here, before anything of this package touches the device; a value the caller exported wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+def configure_streaming() -> int:
+    """Export GPU_MAX_HW_QUEUES for a process that is going to STREAM batches (orbfe_stream_submit / DeviceSequenceProcessor): the HIP
+    runtime multiplexes all streams of a process onto that many hardware queues (4 by default) and reads the variable at its first HIP
+    call, so this must run before anything touches the GPU (before `import torch` initialises it); a value already exported wins.
+    Importing the package does not do this: one-frame-at-a-time users (ORBExtractor / StereoFrontEnd) are ~50 us per frame faster with
+    the runtime's default.  Returns the value in effect."""
+    import os
+    from ._lib import load
+    want = int(load().orbfe_recommended_hw_queues())
+    return int(os.environ.setdefault("GPU_MAX_HW_QUEUES", str(want)))
+
 
 from .frontend import Frame, ORBExtractor, ORBMatcher, Optimizer, StereoFrontEnd  # noqa: F401
 
-__all__ = ["Frame", "ORBExtractor", "ORBMatcher", "Optimizer", "StereoFrontEnd"]
+__all__ = ["Frame", "ORBExtractor", "ORBMatcher", "Optimizer", "StereoFrontEnd", "configure_streaming"]

@@ -100,7 +100,7 @@ EXPORTS = [
     "orbfe_abi_version", "orbfe_create", "orbfe_destroy", "orbfe_last_error", "orbfe_get_level_info", "orbfe_get_scale_factors",
     "orbfe_get_capacity",
     "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_slot", "orbfe_extract_slots", "orbfe_fetch_batch", "orbfe_fetch_stereo_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
-    "orbfe_host_alloc", "orbfe_host_alloc_on", "orbfe_host_free", "orbfe_stream_submit", "orbfe_stream_wait", "orbfe_stream_device_results", "orbfe_record_bytes", "orbfe_stream_pack_records",
+    "orbfe_host_alloc", "orbfe_host_alloc_on", "orbfe_host_free", "orbfe_recommended_hw_queues", "orbfe_stream_submit", "orbfe_stream_wait", "orbfe_stream_device_results", "orbfe_record_bytes", "orbfe_stream_pack_records",
     "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_search_in_area_features", "orbfe_search_in_area_features_ex", "orbfe_extract_color", "orbfe_frame_rgbd", "orbfe_project_map_points",
     "orbfe_map_pb_summary", "orbfe_map_pb_reencode", "orbfe_map_pb_to_txt", "orbfe_map_txt_to_pb", "orbfe_map_local_graph", "orbfe_map_local_ba",
     "orbfe_profile_enable", "orbfe_profile_read", "orbfe_stage_name", "orbfe_debug_candidates",

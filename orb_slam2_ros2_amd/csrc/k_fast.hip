@@ -488,9 +488,9 @@ static void launch_fast_cells(hipStream_t s, const LevelDev* d_lv, const CellDev
 // patches need.  Measured: merging levels 0..3 into one launch with their common carve-up is 5 % slower than the four separate launches.
 void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, const LevelDev* h_lv, const int* lvl_max_pw,
                  const int* lvl_max_ph, const uint8_t* d_pyr, size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch,
-                 int32_t* d_n_cand, int n_levels, int n_img, hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, int side_from, int cpw_force) {
-  // side (nullable): the launches of levels >= side_from go to this stream (after ev_go, recorded on s here; ev_done joins them
-  // back into s): the small levels do not fill the machine and their waves run in the tails the large levels' launches leave
+                 int32_t* d_n_cand, int n_levels, int n_img, int cpw_force) {
+  // (the launches of the small levels on a second stream beside the large ones, or alternating levels on two streams, were measured in
+  //  rounds 2-3 and dropped: profiles/NOTES_r1-r3.md)
   if (n_img <= 0) return;
   // a frame or two (the drop-in path): the whole sweep fits the machine at once, and eight back-to-back launches would each
   // cost a full wave lifetime (~18 us): one launch with the common carve-up instead (0.144 -> 0.03 ms for one stereo pair)
@@ -510,23 +510,11 @@ void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, co
                       n_img, cpw_force);
     return;
   }
-  // side_from < 0: every (-side_from)-th ... alternate levels (1, 3, 5 ... for -1) go to the side stream
-  const bool alt = side && ev_go && ev_done && side_from < 0;
-  const bool split = alt || (side && ev_go && ev_done && side_from > 0 && side_from < n_levels);
-  if (split) {
-    (void)hipEventRecord(ev_go, s);
-    (void)hipStreamWaitEvent(side, ev_go, 0);
-  }
   for (int l = 0; l < n_levels; ++l) {
     const int n_cells = h_lv[l].n_cells;
     if (n_cells <= 0 || lvl_max_pw[l] <= 6 || lvl_max_ph[l] <= 6) continue;
-    const bool on_side = alt ? ((l % (1 - side_from)) != 0) : (split && l >= side_from);
-    launch_fast_cells(on_side ? side : s, d_lv, d_cells, lvl_max_pw[l], lvl_max_ph[l], d_pyr, img_pitch, t_hi, t_lo, d_cand,
-                      cand_pitch, d_n_cand, n_levels, (int)h_lv[l].cell_base, n_cells, n_img, cpw_force);
-  }
-  if (split) {
-    (void)hipEventRecord(ev_done, side);
-    (void)hipStreamWaitEvent(s, ev_done, 0);
+    launch_fast_cells(s, d_lv, d_cells, lvl_max_pw[l], lvl_max_ph[l], d_pyr, img_pitch, t_hi, t_lo, d_cand, cand_pitch, d_n_cand, n_levels,
+                      (int)h_lv[l].cell_base, n_cells, n_img, cpw_force);
   }
 }
 

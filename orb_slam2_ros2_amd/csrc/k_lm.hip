@@ -7,7 +7,7 @@
 //
 // One TRIAL (= one step of the enqueued stream), every kernel gated by state.run_step (six launches; every launch of a dependent
 // stream costs 4.6 us before it does anything, so the pose side of the system rides in k_lm_prep):
-//   k_lm_ctrl        (lm_ctrl_body; optionally in the tail of the previous trial's k_lm_linpoints, see launch_lm_steps) decide the outstanding trial (rho = (chi_cur - chi_trial) / (scale + 1e-3); accept: lambda *= max(1/3, 1 - (2 rho - 1)^3),
+//   k_lm_ctrl        (lm_ctrl_body) decide the outstanding trial (rho = (chi_cur - chi_trial) / (scale + 1e-3); accept: lambda *= max(1/3, 1 - (2 rho - 1)^3),
 //                    swap the estimate / system buffers; reject: lambda *= ni, ni *= 2), start the next iteration or trial, or finish
 //   k_lm_prep        per point: (Hll + lambda I)^-1, W(e) = Hpl(e) Dinv for its edges             (BlockSolver_6_3::solve, marginalised points)
 //                    + Hpp / bp per pose of the CURRENT system from its stored edge terms (blocks after the point blocks)
@@ -73,14 +73,6 @@ __device__ __forceinline__ bool lm_gate(const LmState* st, int gate) {
 // (fixed tree over the 64 lanes by data-parallel-primitive moves: wave_ops.h)
 __device__ __forceinline__ double wave_sum_fixed(double v) { return wave_sum_f64(v); }
 
-struct LmCtrlArgs {  // what the control step needs (k_lm_ctrl, or the tail of k_lm_linpoints)
-  LmState* st;
-  int mode;  // -1: no control step in the tail
-  int chi_blocks, scale_blocks;
-  const double* scale_part;
-  const volatile uint8_t* abort_flag;
-  unsigned int* ticket;  // zero between launches
-};
 __device__ void lm_ctrl_body(LmState* __restrict__ st, const LmBuffers& B, int mode, int chi_blocks, int scale_blocks,
                              const double* __restrict__ scale_part, const volatile uint8_t* __restrict__ abort_flag);
 
@@ -213,17 +205,17 @@ __device__ __forceinline__ double lm_linearize_edge(int e, int buf, const LmBuff
 // never come back from memory for this.  (Until late r3 this was two launches, one lane per edge and then eight lanes per point reading
 // the terms back: 10 + 17 us, and every launch of this stream costs 4.6 us before it does anything.)  The robust chi2 is summed per block
 // in a fixed tree -> chi_part[buf][block]; the control step adds the blocks.
-// tail.mode >= 0: the LAST block to finish runs the control step (lm_ctrl_body) for the trial that follows, instead of a launch of its own.
+// (Measured and dropped in r3: the control step of the next trial in the tail of this kernel -- a fence, a ticket and a barrier in each
+//  of its 94 blocks, then ~4 us of serial loads in the last one: 11.7 -> 23.2 us against 6.2 us for the launch it saves.)
 __global__ __launch_bounds__(256) void k_lm_linpoints(int n_points, LmBuffers B, const LmState* __restrict__ st, int gate, int which,
                                                       const int32_t* __restrict__ pt_off, const int32_t* __restrict__ pt_edges,
                                                       const int32_t* __restrict__ edge_pose, const double* __restrict__ meas,
                                                       const uint8_t* __restrict__ is_stereo, const double* __restrict__ info,
                                                       const double* __restrict__ delta, const uint8_t* __restrict__ pose_fixed,
                                                       const uint8_t* __restrict__ level, BaParamsDev prm, double* __restrict__ chi2_last,
-                                                      int write_last, LmCtrlArgs tail) {
+                                                      int write_last) {
 #pragma clang fp contract(off)
   __shared__ double sh[256];
-  __shared__ unsigned int s_ticket;
   if (!lm_gate(st, gate)) return;
   const int buf = st->cur ^ which;
   const int p = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
@@ -267,15 +259,6 @@ __global__ __launch_bounds__(256) void k_lm_linpoints(int n_points, LmBuffers B,
   }
   const double s = block_sum_256(r0, sh);
   if (threadIdx.x == 0) B.chi_part[buf][blockIdx.x] = s;
-  if (tail.mode < 0) return;
-  // the last block to get here has every block's partial sum behind it (release: fence, then the ticket; acquire: the ticket, then a fence)
-  __threadfence();
-  if (threadIdx.x == 0) s_ticket = atomicAdd(tail.ticket, 1u);
-  __syncthreads();
-  if (s_ticket != gridDim.x - 1) return;
-  __threadfence();
-  if (threadIdx.x < 64) lm_ctrl_body(tail.st, B, tail.mode, tail.chi_blocks, tail.scale_blocks, tail.scale_part, tail.abort_flag);
-  if (threadIdx.x == 0) *tail.ticket = 0u;
 }
 
 // Hpp / bp per pose (one 256-thread block per pose: one edge per thread) from the stored terms of buffer buf.  Partial sums are
@@ -1218,20 +1201,14 @@ static LmBuffers lm_buffers(const LmLaunch& L) {
   return B;
 }
 
-static LmCtrlArgs lm_ctrl_args(const LmLaunch& L, int mode) {
-  LmCtrlArgs a;
-  a.st = L.state, a.mode = mode, a.chi_blocks = (L.NP + 31) / 32, a.scale_blocks = (L.NP + 31) / 32 + (L.NK + 255) / 256;
-  a.scale_part = L.scale_part, a.abort_flag = L.abort_flag, a.ticket = L.ticket;
-  return a;
-}
-// the system of buffer cur ^ which, gated: the point side (+ the control step of the next trial in its tail, tail_mode >= 0) and,
-// with_poses, the pose side as a launch of its own (inside a trial it rides with k_lm_prep of the NEXT trial instead)
-void launch_lm_build(hipStream_t s, const LmLaunch& L, int gate, int which, int write_last, int tail_mode, bool with_poses) {
+// the system of buffer cur ^ which, gated: the point side and, with_poses, the pose side as a launch of its own (inside a trial it
+// rides with k_lm_prep of the NEXT trial instead)
+void launch_lm_build(hipStream_t s, const LmLaunch& L, int gate, int which, int write_last, bool with_poses) {
   const LmBuffers B = lm_buffers(L);
   const int pb = (L.NP + 31) / 32;
   if (pb > 0)
     hipLaunchKernelGGL(k_lm_linpoints, dim3(pb), dim3(256), 0, s, L.NP, B, L.state, gate, which, L.pt_off, L.pt_edges, L.edge_pose, L.meas,
-                       L.is_stereo, L.info_eff, L.delta_eff, L.fixed, L.level, L.prm, L.chi2_last, write_last, lm_ctrl_args(L, tail_mode));
+                       L.is_stereo, L.info_eff, L.delta_eff, L.fixed, L.level, L.prm, L.chi2_last, write_last);
   if (with_poses && L.NK > 0)
     hipLaunchKernelGGL(k_lm_poseblocks, dim3(L.NK), dim3(256), 0, s, L.NK, B, L.state, gate, which, L.fixed, L.ps_off, L.ps_edges);
 }
@@ -1246,14 +1223,11 @@ void launch_lm_maxdiag(hipStream_t s, const LmLaunch& L, int gate) {
   hipLaunchKernelGGL(k_lm_maxdiag, dim3(1), dim3(1024), 0, s, L.NK, L.NP, lm_buffers(L), L.state, gate, L.fixed);
 }
 void launch_lm_ctrl(hipStream_t s, const LmLaunch& L, int mode) {
-  const LmCtrlArgs a = lm_ctrl_args(L, mode);
-  hipLaunchKernelGGL(k_lm_ctrl, dim3(1), dim3(64), 0, s, L.state, lm_buffers(L), mode, a.chi_blocks, a.scale_blocks, L.scale_part, L.abort_flag,
+  hipLaunchKernelGGL(k_lm_ctrl, dim3(1), dim3(64), 0, s, L.state, lm_buffers(L), mode, (L.NP + 31) / 32, (L.NP + 31) / 32 + (L.NK + 255) / 256, L.scale_part, L.abort_flag,
                      mode == 4 ? L.state_out : (LmState*)nullptr);
 }
-// one trial: solve + update + the system at the trial estimate.  The control step that decides it and schedules the next one runs in
-// the tail of the last kernel (ctrl_in_tail) -- the LAST trial of a group is followed by a control point of another mode (round switch,
-// final) that does the deciding itself, and the FIRST one is preceded by an explicit launch_lm_ctrl(0).
-void launch_lm_step(hipStream_t s, const LmLaunch& L, bool ctrl_in_tail) {
+// one trial: solve + update + the system at the trial estimate (the control step that decides it is the caller's next launch)
+void launch_lm_step(hipStream_t s, const LmLaunch& L) {
   const LmBuffers B = lm_buffers(L);
   const int pb = (L.NP + 31) / 32;
   if (pb + L.NK > 0)
@@ -1271,22 +1245,13 @@ void launch_lm_step(hipStream_t s, const LmLaunch& L, bool ctrl_in_tail) {
   if (ub > 0)
     hipLaunchKernelGGL(k_lm_update, dim3(ub), dim3(256), 0, s, L.NK, L.NP, pb, B, L.state, L.pose_slot, L.x, L.pt_off, L.pt_edges,
                        L.edge_pose, L.Dinv, L.scale_part);
-  launch_lm_build(s, L, 1, 1, 1, ctrl_in_tail ? 0 : -1, false);
+  launch_lm_build(s, L, 1, 1, 1, false);
 }
-// `n` trials as one group: control step, the trials, then the caller's control point (launch_lm_switch / launch_lm_final)
+// `n` trials as one group: a control step and a trial each, then the caller's control point (launch_lm_switch / launch_lm_final)
 void launch_lm_steps(hipStream_t s, const LmLaunch& L, int n) {
-  // Measured with the control step in the tail of every trial but the last: k_lm_linpoints 11.7 -> 23.2 us (a fence, a ticket and a
-  // barrier in each of its 94 blocks, then ~4 us of serial loads in the last one) against 6.2 us for the launch it saves.  Kept as a
-  // mechanism (ORBFE_LM_TAIL_CTRL=1, tested); the default is a launch per control step.
-  if (n <= 0) return;
-  if (L.tail_ctrl) {
-    launch_lm_ctrl(s, L, 0);
-    for (int k = 0; k < n; ++k) launch_lm_step(s, L, k + 1 < n);
-    return;
-  }
   for (int k = 0; k < n; ++k) {
     launch_lm_ctrl(s, L, 0);
-    launch_lm_step(s, L, false);
+    launch_lm_step(s, L);
   }
 }
 void launch_lm_switch(hipStream_t s, const LmLaunch& L) {
@@ -1295,7 +1260,7 @@ void launch_lm_switch(hipStream_t s, const LmLaunch& L) {
   if (L.E > 0)
     hipLaunchKernelGGL(k_lm_classify, dim3((L.E + 255) / 256), dim3(256), 0, s, L.E, B, L.state, L.edge_pose, L.edge_point, L.chi2_last, L.is_stereo,
                        L.level, L.info_eff, L.delta_eff);
-  launch_lm_build(s, L, 2, 0, 1, -1, true);
+  launch_lm_build(s, L, 2, 0, 1, true);
   launch_lm_maxdiag(s, L, 2);
   launch_lm_ctrl(s, L, 2);
 }

@@ -672,13 +672,13 @@ __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __res
 
 void launch_pose_only(hipStream_t s, int n, const double* Xw, const double* meas, const double* info, const float* sigma2,
                       const double* pose_in, BaParamsDev prm, double d_mono, double d_stereo, double* err, uint8_t* level,
-                      uint8_t* robust, uint8_t* inlier, double* pose_out, int32_t* n_good, bool mem_version) {
-  // mem_version (ORBFE_POSE_IN_MEMORY=1): round 2's kernel whatever the size
+                      uint8_t* robust, uint8_t* inlier, double* pose_out, int32_t* n_good) {
+  // (past POSE_RT * POSE_EPT edges: round 2's kernel, which re-reads the edges from memory every pass)
   // 256 threads up to 1024 edges (one wave per SIMD: the 27 wave reductions of a build are issued once per SIMD, not twice), 512 up to 2048
-  if (n <= 256 * POSE_EPT && !mem_version)
+  if (n <= 256 * POSE_EPT)
     hipLaunchKernelGGL(k_pose_only_reg<256>, dim3(1), dim3(256), 0, s, n, Xw, meas, info, sigma2, pose_in, prm, d_mono, d_stereo, inlier, pose_out,
                        n_good);
-  else if (n <= POSE_RT * POSE_EPT && !mem_version)
+  else if (n <= POSE_RT * POSE_EPT)
     hipLaunchKernelGGL(k_pose_only_reg<POSE_RT>, dim3(1), dim3(POSE_RT), 0, s, n, Xw, meas, info, sigma2, pose_in, prm, d_mono, d_stereo, inlier, pose_out,
                        n_good);
   else

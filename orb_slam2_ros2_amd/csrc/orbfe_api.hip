@@ -35,7 +35,7 @@ void launch_load_level0(hipStream_t st, const uint8_t* d_src, const uint8_t* d_s
 // k_fast.hip
 void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, const LevelDev* h_lv, const int* lvl_max_pw,
                  const int* lvl_max_ph, const uint8_t* d_pyr, size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch,
-                 int32_t* d_n_cand, int n_levels, int n_img, hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, int side_from, int cpw_force);
+                 int32_t* d_n_cand, int n_levels, int n_img, int cpw_force);
 // k_quadtree.hip
 size_t quadtree_lds_bytes(int node_cap, int rec_cap, int sort_cap);
 hipError_t quadtree_configure(size_t lds_bytes);
@@ -103,7 +103,7 @@ void launch_search_area(hipStream_t s, const uint4* d_kpl, const uint8_t* d_desc
                         const int32_t* d_cell_off, const int32_t* d_cell_feat, int nq, const float* d_qxy, const float* d_radius,
                         const int8_t* d_min_level, const int8_t* d_max_level, const uint8_t* d_q_desc, const uint8_t* d_exclude,
                         int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second, int32_t* d_n_cand, int32_t* d_excluded_hits);
-void launch_lm_build(hipStream_t s, const LmLaunch& L, int gate, int which, int write_last, int tail_mode, bool with_poses);
+void launch_lm_build(hipStream_t s, const LmLaunch& L, int gate, int which, int write_last, bool with_poses);
 void launch_lm_maxdiag(hipStream_t s, const LmLaunch& L, int gate);
 void launch_lm_pairs(hipStream_t s, const LmLaunch& L);
 void launch_lm_steps(hipStream_t s, const LmLaunch& L, int n);
@@ -111,7 +111,7 @@ void launch_lm_switch(hipStream_t s, const LmLaunch& L);
 void launch_lm_final(hipStream_t s, const LmLaunch& L);
 void launch_pose_only(hipStream_t s, int n, const double* Xw, const double* meas, const double* info, const float* sigma2,
                       const double* pose_in, BaParamsDev prm, double d_mono, double d_stereo, double* err, uint8_t* level,
-                      uint8_t* robust, uint8_t* inlier, double* pose_out, int32_t* n_good, bool mem_version);
+                      uint8_t* robust, uint8_t* inlier, double* pose_out, int32_t* n_good);
 }  // namespace orbfe
 
 using namespace orbfe;
@@ -134,11 +134,6 @@ struct orbfe_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  // side streams for the chunked batch path
-  static const int kMaxSide = 4;  // upper bound; ORBFE_STREAMS picks the count (default 1)
-  int n_side = 0;
-  hipStream_t side[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
   // the blur of a batch runs on its own stream under the (latency-bound, LDS-hungry, SIMD-idle) quadtree of the same batch
   // the host-pointer path for one or two images (the drop-in call shape) is launch-bound: its copy-in / kernels / copy-out
   // sequence is captured once into a hipGraph per (image count, outputs wanted) and replayed
@@ -184,9 +179,6 @@ struct orbfe_ctx {
   std::vector<std::unique_ptr<Lane>> slot_lane;  // [max_images], entries created lazily under slot_lane_mu
   std::mutex slot_lane_mu;
   bool use_graphs = true;
-  bool host_mirror = true;  // ORBFE_HOST_MIRROR=0: results of the host-pointer path by device-to-host copies instead of kernel writes
-  bool fuse_orient = true;  // ORBFE_FUSE_ORIENT=0: keypoint list, moments and orientation of a frame or two as three launches (as batches do) instead of one
-  bool host_read = false;   // ORBFE_HOST_READ=1: images of the host-pointer path by kernel reads of the staging buffer instead of a host-to-device copy (measured slower)
   // the stereo match of a device-resident batch runs on its own stream: it is latency-bound and reads only the keypoint /
   // descriptor arrays and the pyramid, so the NEXT batch's copy-in, resize and FAST (second pyramid buffer) run under it
   uint8_t* d_pyr_alt = nullptr;
@@ -195,10 +187,8 @@ struct orbfe_ctx {
   std::atomic<bool> stereo_pending{false};  // (read by slot calls on other threads)
   bool pipeline_stereo = true;
   hipStream_t blur_stream = nullptr;
-  hipStream_t fast_stream = nullptr;  // k_fast's odd levels (ORBFE_FAST_ALT): a launch's tail of half-empty CUs runs under the next level's start
-  int fast_alt = 0;
   int fast_cpw = 0;  // ORBFE_FAST_CPW: cells per k_fast wave (0: one for small launches, four for large ones)
-  hipEvent_t ev_blur_go = nullptr, ev_blur_done = nullptr, ev_fast_go = nullptr, ev_fast_done = nullptr;
+  hipEvent_t ev_blur_go = nullptr, ev_blur_done = nullptr;
   int fast_side_from = 0;  // k_fast launches of levels >= this run on the blur stream beside the large levels (ORBFE_FAST_SIDE_FROM; 0: off -- the default
                            // since the level-0 blur occupies that stream until well into FAST: the small levels queued behind it, 3 / 5 / 0: 5.75 / 5.72 / 5.71 ms)
 
@@ -219,21 +209,12 @@ struct orbfe_ctx {
   RgXTap* d_rg_xtaps = nullptr;
   RgYTap* d_rg_ytaps = nullptr;
   int rg_tile_bytes = 0, rg_xt_bytes = 0, rg_yt_bytes = 0;
-  bool resize_regions = true;        // ORBFE_RESIZE_REGIONS=0: the per-class tile launches instead
-  bool blur_l0_early = true;         // ORBFE_BLUR_L0_EARLY=0: the whole blur after FAST
-  bool ext_level0 = true;            // ORBFE_EXT_LEVEL0=0: device batches copy level 0 in first, then resize from the copy
   int rs_n[3] = {0, 0, 0}, rs_bytes[3] = {0, 0, 0};  // resize tiles of 64x64 / 64x32 / 64x16 outputs (in this order) and their LDS
   size_t img_pitch = 0;      // bytes per image in pyr / blur
   size_t scratch_pitch = 0;  // uint32 records per image
-  QtGroups qt_groups;        // ORBFE_QT_GROUPS: levels per quadtree wave (balanced by quota), qt_n_groups waves per image, whatever the launch size
   QtGroups qt_groups_of[3];  // the same for 1, 2 and 4 waves per image (picked by launch size)
   QtGroups qt_single;        // one level per wave: launches too small to fill the wave slots (a frame or two: the chain of several trees in one wave would only add latency)
-  int qt_n_groups = 0;
-  bool qt_groups_forced = false;
   int rec_cap = 0;           // upper bound of candidate records one quadtree wave keeps in LDS (launch picks <= this)
-  int qt_batch = 1;          // k_quadtree: several pops per step (ORBFE_QT_BATCH=0: one at a time)
-  int qt_waves = 4;          // waves per tree in launches of a frame or two (ORBFE_QT_WAVES=1: one)
-  int qt_per_cu = 16;        // tree waves a launch aims to put on a CU (one round): the levels of an image are dealt to 1, 2 or 4 waves accordingly
   int n_cu = 256;            // compute units of the device
   int node_cap = 0, sort_cap = 0;
   int lvl_max_pw[ORBFE_MAX_LEVELS] = {0}, lvl_max_ph[ORBFE_MAX_LEVELS] = {0};  // largest FAST cell patch per level (sizes the LDS of k_fast)
@@ -273,8 +254,6 @@ struct orbfe_ctx {
   // stop flag is mirrored into it while the call waits -- and the page-locked copy of the state record
   volatile uint8_t* h_abort = nullptr;
   LmState* h_lm_state = nullptr;
-  bool pose_in_memory = false;  // ORBFE_POSE_IN_MEMORY=1: round 2's pose-only kernel (edges re-read from memory every pass)
-  bool lm_tail_ctrl = false;  // ORBFE_LM_TAIL_CTRL=1 (k_lm.hip, launch_lm_steps): measured slower, kept as a tested mechanism
   bool lm_on_device = true;  // ORBFE_LBA_HOST_LM=1: round 2's host-driven loop (kept for A/B runs and for > LM_CHOL_MAX_NB free keyframes)
 
   // profiling
@@ -573,10 +552,6 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
           const double fill = ((double)cfg.width / (nx * ww)) * ((double)cfg.height / (ny * hh));
           if (fill > best + 1e-9 || (fill > best - 1e-9 && ww * hh > RG_W * RG_H)) best = std::max(best, fill), RG_W = ww, RG_H = hh;
         }
-      if (const char* e = getenv("ORBFE_RG")) {  // "W,H" (tuning / tests)
-        int ww = 0, hh = 0;
-        if (sscanf(e, "%d,%d", &ww, &hh) == 2 && ww >= 64 && ww <= 1024 && ww % 16 == 0 && hh >= 8 && hh <= 255) RG_W = ww, RG_H = hh;
-      }
     }
     const int nrx = (cfg.width + RG_W - 1) / RG_W, nry = (cfg.height + RG_H - 1) / RG_H;
     bool ok = true;
@@ -730,7 +705,7 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
       // levels -> waves: longest-processing-time first on the quotas (a tree's work grows with its quota and candidate count).
       // Tables for 1, 2 and 4 waves per image: a launch takes the one that makes ~8 tree waves per CU -- as many as are resident at once
       // (LDS and registers) -- so that the launch is ONE round of waves: same-box, per step of 128 / 256 / 512 pairs, one wave per
-      // level | 4 | 2 waves per image: 0.154 | 0.182 | 0.300, 0.300 | 0.210 | 0.349, 0.61 | 0.388 | 0.366 ms.  ORBFE_QT_GROUPS forces one.
+      // level | 4 | 2 waves per image: 0.154 | 0.182 | 0.300, 0.300 | 0.210 | 0.349, 0.61 | 0.388 | 0.366 ms (r3, at eight per CU).
       std::memset(&c->qt_single, 0, sizeof c->qt_single);
       for (int l = 0; l < nl; ++l) c->qt_single.mask[l] = 1u << l;
       std::vector<int> order(nl);
@@ -748,18 +723,7 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
         }
       };
       for (int k = 0; k < 3; ++k) deal(std::min(nl, 1 << k), &c->qt_groups_of[k]);
-      int ng = 0;  // 0: by launch size
-      if (const char* env = getenv("ORBFE_QT_GROUPS")) {
-        ng = std::max(1, std::min(nl, atoi(env)));
-        c->qt_groups_forced = true;
-        deal(ng, &c->qt_groups);
-      }
-      c->qt_n_groups = ng;
     }
-    if (const char* env = getenv("ORBFE_QT_BATCH")) c->qt_batch = atoi(env) != 0;
-    if (const char* env = getenv("ORBFE_QT_WAVES")) c->qt_waves = atoi(env);
-    if (const char* env = getenv("ORBFE_QT_PER_CU")) c->qt_per_cu = std::max(1, atoi(env));
-    if (const char* env = getenv("ORBFE_FAST_SIDE_FROM")) c->fast_side_from = atoi(env);
   }
   // umax (ORBExtractor::initMaxU)
   {
@@ -890,7 +854,7 @@ struct ExtLevel0 {
   uint32_t bytes;               // size of one image
   hipEvent_t inputs_free;       // nullable: recorded once the resize (which also writes level 0 of the pyramid) is done with the caller's images
 };
-static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, int lds_share = 1, hipEvent_t before_lists = nullptr,
+static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, hipEvent_t before_lists = nullptr,
                                 bool timing = true, const ExtLevel0* ext = nullptr, const HostMirror* mirror = nullptr) {
   // timing = false: a slot lane (orbfe_extract_slot) -- several of them run at once, so nothing shared by the context is touched:
   // no stage timers (their event lists belong to the main lane), no second stream
@@ -902,10 +866,10 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   uint8_t* pyr = c->d_pyr + i0 * c->img_pitch;
   uint8_t* blur = c->d_blur + i0 * c->img_pitch;
   int32_t* n_cand = c->d_n_cand + i0 * nl;
-  const bool overlap_blur = timing && c->blur_stream && c->prof != 1 && lds_share == 1 && n_img >= 32;  // a frame or two: nothing to hide, only event latency to add (measured r3: the blur of one pair on the second stream, inside the captured graph: extract_batch 0.306 -> 0.366 ms)
+  const bool overlap_blur = timing && c->blur_stream && c->prof != 1 && n_img >= 32;  // a frame or two: nothing to hide, only event latency to add (measured r3: the blur of one pair on the second stream, inside the captured graph: extract_batch 0.306 -> 0.366 ms)
   // the blur of LEVEL 0 needs nothing but the copy-in: it starts beside the resize (a third of the blur's work out of the way of the
   // moments, which are as memory-bound as it is and take the sum of the two times when they meet)
-  const int l0_tiles = (overlap_blur && c->blur_l0_early && nl > 1) ? c->lv[1].bl_tile_base : 0;
+  const int l0_tiles = (overlap_blur && nl > 1) ? c->lv[1].bl_tile_base : 0;
   bool blur_queued = false;
   if (l0_tiles > 0 && !ext) {
     HIP_TRY(c, hipEventRecord(c->ev_blur_go, st));
@@ -914,7 +878,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   }
   // FAST's candidate counters are zeroed by the resize kernel (block 0): a memset between the blur and FAST is one more launch in the
   // chain -- 4.6 us of a 0.2 ms frame
-  const bool zeroed_by_resize = c->resize_regions && !c->rs_regions.empty();
+  const bool zeroed_by_resize = !c->rs_regions.empty();  // (empty: the geometry rules the region-driven resize out -- the per-class tile launches)
   {
     StageTimer t(c, ORBFE_STAGE_RESIZE, st, timing);
     if (zeroed_by_resize)
@@ -956,8 +920,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     StageTimer t(c, ORBFE_STAGE_FAST, st, timing);
     launch_fast(st, c->d_lv, c->d_cells, c->lv.data(), c->lvl_max_pw, c->lvl_max_ph, pyr, c->img_pitch, c->cfg.fast_hi, c->cfg.fast_lo,
                 c->d_scr_a + i0 * c->scratch_pitch, c->scratch_pitch, n_cand, nl, n_img,
-                (c->fast_alt && c->fast_stream && timing && n_img >= 32) ? c->fast_stream : (overlap_blur ? c->blur_stream : nullptr),
-                c->ev_fast_go, c->ev_fast_done, (c->fast_alt && c->fast_stream && timing && n_img >= 32) ? -c->fast_alt : c->fast_side_from, c->fast_cpw);
+                c->fast_cpw);
   }
   if (overlap_blur && !blur_queued) {
     HIP_TRY(c, hipEventRecord(c->ev_blur_go, st));
@@ -973,32 +936,30 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
     // LDS residency of the candidate records is traded against concurrency: the kernel is latency-bound (one wave per
     // tree, 40-150 dependent steps), so what matters most is that EVERY tree of the launch is resident at once; the
     // records go to LDS only as far as that still holds (measured at 1024 trees: 4 trees/CU 0.59 ms, 3 trees/CU 0.96 ms).
-    // several levels per wave only where one wave per level would fill more than half of the chip's wave slots (8 per SIMD)
-    // waves per image so that the launch has about 8 tree waves per CU (one round): 4 from 1/2 x, 2 from 1 x, 1 from 2 x that many images
+    // several levels per wave only where one wave per level would overfill the chip: waves per image so that the launch has about
+    // sixteen tree waves per CU (one round) -- 4 waves per image from 1024 images, 2 from 2048, 1 from 4096 on 256 CUs
     int gsel = -1;  // -1: one wave per level
-    if (!c->qt_groups_forced && nl > 4) {
-      const long long per8 = (long long)c->n_cu * c->qt_per_cu;
+    if (nl > 4) {
+      const long long per8 = (long long)c->n_cu * 16;  // sixteen tree waves per CU: 16-byte nodes, 128 VGPRs (k_quadtree.hip)
       if ((long long)n_img * 1 >= per8) gsel = 0;
       else if ((long long)n_img * 2 >= per8) gsel = 1;
       else if ((long long)n_img * 4 >= per8) gsel = 2;
     }
-    const bool grouped = c->qt_groups_forced || gsel >= 0;
-    const int n_groups = c->qt_groups_forced ? c->qt_n_groups : (gsel >= 0 ? std::min(nl, 1 << gsel) : nl);
-    const QtGroups& qt_tab = c->qt_groups_forced ? c->qt_groups : (gsel >= 0 ? c->qt_groups_of[gsel] : c->qt_single);
+    const bool grouped = gsel >= 0;
+    const int n_groups = gsel >= 0 ? std::min(nl, 1 << gsel) : nl;
+    const QtGroups& qt_tab = gsel >= 0 ? c->qt_groups_of[gsel] : c->qt_single;
     const int trees = n_groups * n_img;
     const int per_cu = (trees + c->n_cu - 1) / c->n_cu;
-    // lds_share > 1: that many chunks run side by side on their own streams; each quadtree launch leaves the rest of the
-    // CU's LDS to the other chunks' kernels so that they can fill the SIMDs the tree waves leave idle.
-    const size_t lds_cu = (160 * 1024 - 2048) / (size_t)std::max(lds_share, 1);
+    const size_t lds_cu = 160 * 1024 - 2048;
     const size_t node_bytes = quadtree_lds_bytes(c->node_cap, 0, c->sort_cap);
     size_t budget = lds_cu / (size_t)std::max(per_cu, 1);
     budget -= budget % 512;
     const int rec_cap = budget > node_bytes ? (int)std::min<size_t>((budget - node_bytes) / 4, (size_t)c->rec_cap) : 0;
     launch_quadtree(st, c->d_lv, nl, c->d_scr_a + i0 * c->scratch_pitch, c->d_scr_b + i0 * c->scratch_pitch,
                     c->d_scr_c + i0 * c->scratch_pitch, c->scratch_pitch, c->d_sel + i0 * NF, c->d_sel_count + i0 * nl,
-                    c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img, c->qt_batch, qt_tab, n_groups,
+                    c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img, 1, qt_tab, n_groups,
                     // helper waves for the data-parallel phases of a tree where the launch leaves the chip empty (a frame or two)
-                    (!grouped && trees * 4 <= c->n_cu * 4 && c->qt_waves > 1) ? 4 : 1, c->d_qt_big ? c->d_qt_big + i0 * c->qt_big_pitch : nullptr,
+                    (!grouped && trees * 4 <= c->n_cu * 4) ? 4 : 1, c->d_qt_big ? c->d_qt_big + i0 * c->qt_big_pitch : nullptr,
                     c->qt_big_pitch, c->d_qt_tabs);
   }
   {
@@ -1008,7 +969,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
                         c->d_theta + i0 * NF, c->d_moments + i0 * NF, c->d_sincos + i0 * NF, c->d_kx + i0 * NF,
                         c->d_kpl + i0 * NF, c->cfg.height, n_img,
                         overlap_blur ? c->ev_blur_done : nullptr, before_lists, mirror ? mirror->kps : nullptr, mirror ? mirror->desc : nullptr,
-                        mirror ? mirror->n_kp : nullptr, c->fuse_orient);
+                        mirror ? mirror->n_kp : nullptr, true);
   }
   HIP_TRY(c, hipGetLastError());
   return ORBFE_OK;
@@ -1056,9 +1017,6 @@ void orbfe_destroy(orbfe_ctx* c) {
     if (sl && sl->stream) (void)hipStreamSynchronize(sl->stream);
   if (c->stereo_stream) (void)hipStreamSynchronize(c->stereo_stream);
   if (c->blur_stream) (void)hipStreamSynchronize(c->blur_stream);
-  if (c->fast_stream) (void)hipStreamSynchronize(c->fast_stream);
-  for (int k = 0; k < orbfe_ctx::kMaxSide; ++k)
-    if (c->side[k]) (void)hipStreamSynchronize(c->side[k]);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->hs.d2h) (void)hipStreamSynchronize(c->hs.d2h);
   drain_timers(c);
@@ -1092,19 +1050,11 @@ void orbfe_destroy(orbfe_ctx* c) {
     }
   c->slot_lane.clear();
   if (c->main.h_stage) (void)hipHostFree(c->main.h_stage);
-  for (int k = 0; k < orbfe_ctx::kMaxSide; ++k) {
-    if (c->side[k]) (void)hipStreamDestroy(c->side[k]);
-    if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
-  }
   for (auto& ge : c->main.graphs) (void)hipGraphExecDestroy(ge.exec);
   c->main.graphs.clear();
-  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_blur_go) (void)hipEventDestroy(c->ev_blur_go);
   if (c->ev_blur_done) (void)hipEventDestroy(c->ev_blur_done);
-  if (c->ev_fast_go) (void)hipEventDestroy(c->ev_fast_go);
-  if (c->ev_fast_done) (void)hipEventDestroy(c->ev_fast_done);
   if (c->blur_stream) (void)hipStreamDestroy(c->blur_stream);
-  if (c->fast_stream) (void)hipStreamDestroy(c->fast_stream);
   if (c->stereo_stream) (void)hipStreamDestroy(c->stereo_stream);
   if (c->ev_brief_done) (void)hipEventDestroy(c->ev_brief_done);
   if (c->ev_stereo_done) (void)hipEventDestroy(c->ev_stereo_done);
@@ -1164,25 +1114,10 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   c->main.stream = c->stream;
   c->slot_lane.resize((size_t)cfg->max_images);
   {
-    const char* env = getenv("ORBFE_STREAMS");
-    int want = env ? atoi(env) : 1;
-    want = std::min(std::max(want, 1), (int)orbfe_ctx::kMaxSide);
-    bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
-    // (streams are not free: HIP multiplexes all of a process's streams onto 4 hardware queues, and two busy streams on one queue
-    //  serialise -- none is created that the chosen schedule does not use)
-    for (int k = 0; k < want && want > 1 && ok; ++k) {
-      ok = hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking) == hipSuccess &&
-           hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) == hipSuccess;
-      if (ok) c->n_side = k + 1;
-    }
-    if (!ok) {
-      fail(c, ORBFE_EDEVICE, "cannot create side streams");
-      return bail(ORBFE_EDEVICE);
-    }
+    // (streams are not free: HIP multiplexes all of a process's streams onto a few hardware queues, and two busy streams on one queue
+    //  serialise -- none is created that the schedule does not use.  Cutting a batch into chunks on streams of their own was measured
+    //  in rounds 1-3 and never won against the one-chunk schedule below: profiles/NOTES_r1-r3.md)
     if (const char* gr = getenv("ORBFE_GRAPHS")) c->use_graphs = atoi(gr) != 0;
-    if (const char* hm = getenv("ORBFE_HOST_MIRROR")) c->host_mirror = atoi(hm) != 0;
-    if (const char* hr = getenv("ORBFE_HOST_READ")) c->host_read = atoi(hr) != 0;
-    if (const char* fo = getenv("ORBFE_FUSE_ORIENT")) c->fuse_orient = atoi(fo) != 0;
     {
       const char* ps = getenv("ORBFE_PIPELINE_STEREO");
       c->pipeline_stereo = !ps || atoi(ps) != 0;
@@ -1194,22 +1129,13 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
         return bail(ORBFE_EDEVICE);
       }
     }
-    if (const char* rr = getenv("ORBFE_RESIZE_REGIONS")) c->resize_regions = atoi(rr) != 0;
     if (const char* hl = getenv("ORBFE_LBA_HOST_LM")) c->lm_on_device = atoi(hl) == 0;
-    if (const char* tc = getenv("ORBFE_LM_TAIL_CTRL")) c->lm_tail_ctrl = atoi(tc) != 0;
-    if (const char* pm = getenv("ORBFE_POSE_IN_MEMORY")) c->pose_in_memory = atoi(pm) != 0;
     if (const char* fc = getenv("ORBFE_FAST_CPW")) c->fast_cpw = std::max(0, std::min(64, atoi(fc)));
-    if (const char* be = getenv("ORBFE_BLUR_L0_EARLY")) c->blur_l0_early = atoi(be) != 0;
-    if (const char* xl = getenv("ORBFE_EXT_LEVEL0")) c->ext_level0 = atoi(xl) != 0;
     const char* ov = getenv("ORBFE_OVERLAP_BLUR");
     if (!ov || atoi(ov) != 0) {
-      if (const char* fa = getenv("ORBFE_FAST_ALT")) c->fast_alt = atoi(fa);
       if (hipStreamCreateWithFlags(&c->blur_stream, hipStreamNonBlocking) != hipSuccess ||
-          hipStreamCreateWithFlags(&c->fast_stream, hipStreamNonBlocking) != hipSuccess ||
           hipEventCreateWithFlags(&c->ev_blur_go, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&c->ev_blur_done, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&c->ev_fast_go, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&c->ev_fast_done, hipEventDisableTiming) != hipSuccess) {
+          hipEventCreateWithFlags(&c->ev_blur_done, hipEventDisableTiming) != hipSuccess) {
         fail(c, ORBFE_EDEVICE, "cannot create the blur stream");
         return bail(ORBFE_EDEVICE);
       }
@@ -1488,21 +1414,15 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
   uint8_t* const pyr_now = c->d_pyr;
   // The results come back through the staging buffer too: the orientation and the descriptor kernels write keypoints, counts and
   // descriptors there themselves (posted PCIe writes, ~120 KB per image) beside the device arrays the stereo match reads -- three
-  // device-to-host copies queued behind the last kernel cost ~17 us of a ~0.3 ms call.  ORBFE_HOST_MIRROR=0: the copies.
-  const bool mirror_on = c->host_mirror && n_img <= 2;
+  // device-to-host copies queued behind the last kernel cost ~17 us of a ~0.3 ms call.  More than two images: the copies.
+  const bool mirror_on = n_img <= 2;
   HostMirror mir = {kps ? (orbfe_keypoint*)(ln.h_stage + o_kps) : nullptr, desc ? ln.h_stage + o_desc : nullptr, (int32_t*)(ln.h_stage + o_cnt)};
-  // ORBFE_HOST_READ=1 (measured, off by default): a frame or two go IN the same way -- the resize kernel reads the page-locked staging
-  // planes itself and writes level 0 of the pyramid from the blocks it stages, as it does for the caller's device images of a batch.
-  // The copy in front of the resize is 17 us + a 9 us gap for a pair; the kernel that reads over PCIe takes 50 us instead of 12 (0.93 MB
-  // at 19 GB/s: a few 16-byte requests per lane in flight against ~2 us of round trip) -- the copy engine wins.
-  const bool read_on = c->host_read && n_img <= 2 && c->resize_regions && c->ext_level0 && !c->rs_regions.empty();
-  const ExtLevel0 ext = {ln.h_stage, nullptr, plane, (int)L0.stride, (uint32_t)((size_t)L0.stride * L0.h), nullptr};
   auto enqueue_all = [&]() -> orbfe_status {
     // both eyes in ONE copy (rows = images: the staging planes are `plane` bytes apart, the pyramid slots img_pitch)
-    if (!read_on)
-      HIP_TRY(c, hipMemcpy2DAsync(pyr_now + (size_t)slot0 * c->img_pitch + L0.plane_off, c->img_pitch, ln.h_stage, plane, (size_t)L0.stride * L0.h,
-                                  (size_t)n_img, hipMemcpyHostToDevice, ln.stream));
-    TRY(run_extract(c, ln.stream, slot0, n_img, 1, nullptr, timing, read_on ? &ext : nullptr, mirror_on ? &mir : nullptr));
+    // (measured and dropped: the resize kernel reading the page-locked planes itself -- 50 us against 12 + the 17 us copy)
+    HIP_TRY(c, hipMemcpy2DAsync(pyr_now + (size_t)slot0 * c->img_pitch + L0.plane_off, c->img_pitch, ln.h_stage, plane, (size_t)L0.stride * L0.h,
+                                (size_t)n_img, hipMemcpyHostToDevice, ln.stream));
+    TRY(run_extract(c, ln.stream, slot0, n_img, nullptr, timing, nullptr, mirror_on ? &mir : nullptr));
     if (mirror_on) return ORBFE_OK;
     return enqueue_fetch(c, ln, slot0, n_img, o_kps, o_desc, o_cnt, kps != nullptr, desc != nullptr);
   };
@@ -1685,10 +1605,6 @@ orbfe_status orbfe_stereo_match(orbfe_ctx* c, int32_t slot_left, int32_t slot_ri
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
   const int pair = slot_left / 2;
-  if (!c->host_mirror) {
-    TRY(run_stereo(c, c->stream, slot_left, slot_right, 0, pair, 1, fx, bf));
-    return orbfe_fetch_stereo(c, pair, right_u, depth, n_matches, best_right, best_dist);
-  }
   // the kernel writes the requested arrays into the page-locked staging buffer itself; only the match count is copied (4 bytes)
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
   const size_t o_ru = 0, o_dp = align_up(NF * 8, 256), o_br = o_dp + align_up(NF * 8, 256), o_bd = o_br + align_up(NF * 4, 256),
@@ -1736,16 +1652,10 @@ static PackLayout pack_layout(const orbfe_ctx* c, int n_pairs) {
 static orbfe_status batch_device_core(orbfe_ctx* c, const uint8_t* d_left, const uint8_t* d_right, size_t stride, size_t image_pitch,
                                       int32_t n_pairs, float fx, float bf, const PackDst* pack) {
   const LevelDev& L0 = c->lv[0];
-  // The batch is cut into chunks that run on separate streams: the quadtree is latency-bound (one wave per
-  // image level, a few hundred dependent steps) and leaves the machine almost idle, so the streaming kernels of the
-  // other chunks fill it.  With stage timing enabled the same chunks run one after the other on the main stream, so
-  // that every kernel is timed alone with the launch shape of the production path.
-  const int n_chunks = std::max(1, std::min<int>(c->n_side, std::max(1, n_pairs / 8)));
-  const bool serial = c->prof == 1 || n_chunks == 1;
-  // One chunk (the default): the stereo match goes to its own stream and this call returns with it still queued; the next call
-  // starts its copy-in / resize / FAST on the context stream right away, into the OTHER pyramid buffer, and only its keypoint-list
-  // kernels wait for the match (they rewrite what it reads).  Every other entry point joins the stereo stream first.
-  const bool pipe = c->pipeline_stereo && c->stereo_stream && c->prof != 1 && n_chunks == 1 && n_pairs >= 16;
+  // The stereo match goes to its own stream and this call returns with it still queued; the next call starts its copy-in / resize / FAST
+  // on the context stream right away, into the OTHER pyramid buffer, and only its keypoint-list kernels wait for the match (they rewrite
+  // what it reads).  Every other entry point joins the stereo stream first.  With stage timing on (prof == 1) everything runs in line.
+  const bool pipe = c->pipeline_stereo && c->stereo_stream && c->prof != 1 && n_pairs >= 16;
   if (pipe) {
     if (!c->d_pyr_alt) {
       // (cleared ON THE CONTEXT STREAM: a null-stream hipMemset returns before the device has run it and is not ordered with this
@@ -1763,45 +1673,34 @@ static orbfe_status batch_device_core(orbfe_ctx* c, const uint8_t* d_left, const
     std::swap(c->d_pyr, c->d_pyr_alt);
   else
     TRY(join_stereo(c));
-  HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-  for (int k = 0; k < n_chunks; ++k) {
-    const int p0 = (int)((long long)n_pairs * k / n_chunks), p1 = (int)((long long)n_pairs * (k + 1) / n_chunks);
-    if (p1 <= p0) continue;
-    hipStream_t st = serial ? c->stream : c->side[k];
-    if (!serial) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_fork, 0));
-    // level 0 of slot 2p / 2p+1 <- left / right image p.  One chunk of >= 32 images: the resize reads the caller's images itself and every
-    // workgroup writes its block of level 0 into the pyramid from the tile it has staged anyway -- no copy-in kernel, half its traffic
-    const bool ext0 = serial && k == 0 && c->ext_level0 && c->blur_stream && c->prof != 1 && c->resize_regions && !c->rs_regions.empty() &&
-                      2 * (p1 - p0) >= 32 && (size_t)stride * c->cfg.height <= 0xFFFFFFF0u;
+  {
+    hipStream_t st = c->stream;
+    // level 0 of slot 2p / 2p+1 <- left / right image p.  >= 32 images: the resize reads the caller's images itself and every workgroup
+    // writes its block of level 0 into the pyramid from the tile it has staged anyway -- no copy-in kernel, half its traffic
+    const bool ext0 = c->blur_stream && c->prof != 1 && !c->rs_regions.empty() && 2 * n_pairs >= 32 && (size_t)stride * c->cfg.height <= 0xFFFFFFF0u;
     ExtLevel0 ext;
     if (ext0) {
-      ext.left = d_left + (size_t)p0 * image_pitch, ext.right = d_right + (size_t)p0 * image_pitch;
+      ext.left = d_left, ext.right = d_right;
       ext.pitch = image_pitch, ext.stride = (int)stride, ext.bytes = (uint32_t)((size_t)stride * (c->cfg.height - 1) + c->cfg.width);
       ext.inputs_free = (pack && pack->in_free) ? pack->in_free : nullptr;
     } else {
-      launch_load_level0(st, d_left + (size_t)p0 * image_pitch, d_right + (size_t)p0 * image_pitch, stride, image_pitch, c->d_pyr, c->img_pitch,
-                         L0.plane_off, L0.stride, c->cfg.width, c->cfg.height, 2 * p0, 2, p1 - p0);
-      if (pack && pack->in_free && serial && k == n_chunks - 1) HIP_TRY(c, hipEventRecord(pack->in_free, st));  // the images may be overwritten
+      launch_load_level0(st, d_left, d_right, stride, image_pitch, c->d_pyr, c->img_pitch, L0.plane_off, L0.stride, c->cfg.width, c->cfg.height, 0, 2,
+                         n_pairs);
+      if (pack && pack->in_free) HIP_TRY(c, hipEventRecord(pack->in_free, st));  // the images may be overwritten
     }
-    TRY(run_extract(c, st, 2 * p0, 2 * (p1 - p0), serial ? 1 : n_chunks, (piped && c->stereo_pending) ? c->ev_stereo_done : nullptr, true,
-                    ext0 ? &ext : nullptr));
+    TRY(run_extract(c, st, 0, 2 * n_pairs, (piped && c->stereo_pending) ? c->ev_stereo_done : nullptr, true, ext0 ? &ext : nullptr));
     if (piped) {
       HIP_TRY(c, hipEventRecord(c->ev_brief_done, st));
       HIP_TRY(c, hipStreamWaitEvent(c->stereo_stream, c->ev_brief_done, 0));
-      TRY(run_stereo(c, c->stereo_stream, 2 * p0, 2 * p0 + 1, 2, p0, p1 - p0, fx, bf));
+      TRY(run_stereo(c, c->stereo_stream, 0, 1, 2, 0, n_pairs, fx, bf));
     } else {
-      TRY(run_stereo(c, st, 2 * p0, 2 * p0 + 1, 2, p0, p1 - p0, fx, bf));
-    }
-    if (!serial) {
-      HIP_TRY(c, hipEventRecord(c->ev_join[k], st));
-      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join[k], 0));
+      TRY(run_stereo(c, st, 0, 1, 2, 0, n_pairs, fx, bf));
     }
   }
   if (pack) {
     // the packed results of this batch -> the stream's result buffer (device to device: ~0.1 ms for 512 pairs), on the stream the
     // match ran on, BEFORE the next batch may rewrite the per-slot arrays; the download then runs beside the next batch
     hipStream_t ps = piped ? c->stereo_stream : c->stream;
-    if (pack->in_free && !serial) HIP_TRY(c, hipEventRecord(pack->in_free, c->stream));
     const PackLayout l = pack_layout(c, n_pairs);
     const size_t NF = (size_t)std::max(c->cfg.n_features, 1), n = (size_t)n_pairs;
     HIP_TRY(c, hipStreamWaitEvent(ps, pack->wait_free, 0));
@@ -1876,7 +1775,7 @@ void* orbfe_host_alloc_on(int32_t device_id, size_t bytes) {
   cpu_set_t old_set, local;
   const bool have_old = sched_getaffinity(0, sizeof old_set, &old_set) == 0;
   bool moved = false;
-  if (have_old && !getenv("ORBFE_NO_NUMA_PIN") && device_local_cpus(device_id, &local)) {
+  if (have_old && device_local_cpus(device_id, &local)) {
     cpu_set_t both;
     CPU_AND(&both, &local, &old_set);  // stay inside what this process is allowed to use
     if (CPU_COUNT(&both) > 0) moved = sched_setaffinity(0, sizeof both, &both) == 0;
@@ -1896,8 +1795,28 @@ void orbfe_host_free(void* p) {
   if (p) (void)hipHostFree(p);
 }
 
+// The streaming entry points keep up to eight HIP streams busy at once (compute, stereo match, blur, upload, download, slot lanes, the
+// caller's and RCCL's own), and the HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues -- 4 by
+// default.  Two streams that share a queue run one after the other: with 4 queues the upload of batch k + 1 queues behind the kernels
+// of batch k and the 4541-pair sequence takes 0.127 s, with 16 it takes 0.087 s (profiles/r3_hw_queues.txt).  The runtime reads the
+// variable at its first HIP call, so a library cannot set it: the process that streams exports it (bench.py does; a process that builds
+// one frame at a time should NOT -- 4 queues are ~50 us per frame faster there), and orbfe_stream_submit says so once if it is missing.
+int32_t orbfe_recommended_hw_queues(void) { return 16; }
+
 orbfe_status orbfe_stream_submit(orbfe_ctx* c, const uint8_t* left, const uint8_t* right, size_t stride, size_t image_pitch, int32_t n_pairs,
                                  float fx, float bf, const orbfe_batch_results* out, int64_t* ticket) {
+  {
+    static std::once_flag warned;
+    std::call_once(warned, [] {
+      const char* q = getenv("GPU_MAX_HW_QUEUES");
+      if (!q || atoi(q) < 8)
+        fprintf(stderr,
+                "[orbfe] orbfe_stream_submit: GPU_MAX_HW_QUEUES is %s; the streaming path overlaps upload, compute and download on streams of their "
+                "own and runs ~30 %% slower when they share hardware queues -- export GPU_MAX_HW_QUEUES=%d before the process's first HIP call "
+                "(orbfe_recommended_hw_queues())\n",
+                q ? q : "unset (4)", orbfe_recommended_hw_queues());
+    });
+  }
   ApiLock api_lk(c);
   if (!c || !left || !right || !out || !ticket || n_pairs <= 0) return fail(c, ORBFE_EBADARG, "stream_submit: NULL argument / no pairs");
   if (2 * n_pairs > c->cfg.max_images) return fail(c, ORBFE_ECAPACITY, "stream_submit: %d pairs need %d slots > %d", n_pairs, 2 * n_pairs, c->cfg.max_images);
@@ -2279,7 +2198,7 @@ orbfe_status orbfe_ba_build_system(orbfe_ctx* c, const orbfe_ba_problem* p, cons
     L.info_eff = (double*)(b + o_info), L.delta_eff = (double*)(b + o_delta), L.chi2_last = nullptr, L.level = b + o_level;
     L.prm = prm;
     StageTimer tm(c, ORBFE_STAGE_BA, c->stream);
-    launch_lm_build(c->stream, L, 0, 0, 0, -1, true);
+    launch_lm_build(c->stream, L, 0, 0, 0, true);
   }
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(hs, b + o_hpp, (o->Hpl ? o_out_end : o_hpl) - o_hpp, hipMemcpyDeviceToHost, c->stream));
@@ -2407,8 +2326,8 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
                o_bl = take((size_t)NP * 24), o_hpl = take((size_t)E * 144), o_w = take((size_t)E * 144),
                o_s = take(n * n * 8), o_rhs = take(n * 8), o_x = take(n * 8), o_dxp = take((size_t)NK * 48), o_dxl = take((size_t)NP * 24),
                o_err = take((size_t)E * 24), o_chi2 = take((size_t)E * 8), o_rho = take((size_t)E * 16),
-               // one block that starts as zeros (ONE fill): edge levels | chi2 of the last linearisation | point inverses | tail ticket
-               o_level = take((size_t)E), o_last = take((size_t)E * 8), o_dinv = take((size_t)NP * 72), o_ticket = take(64), o_zero_end = take(8),
+               // one block that starts as zeros (ONE fill): edge levels | chi2 of the last linearisation | point inverses
+               o_level = take((size_t)E), o_last = take((size_t)E * 8), o_dinv = take((size_t)NP * 72), o_zero_end = take(8),
                o_depth = take((size_t)E), o_bad = take((size_t)E), o_sc = take(64),
                o_big = take(nf > LBA_MAX_FREE ? ((n + 1) * 6 + (size_t)nf * 36 + n) * 8 : 8);
   // the device-side Levenberg-Marquardt path (k_lm.hip): second estimate / system buffers, per-edge terms, blocked reduced system
@@ -2494,8 +2413,6 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     L.bp[0] = (double*)(b + o_bp), L.bp[1] = (double*)(b + l_bp1), L.Hll[0] = (double*)(b + o_hll), L.Hll[1] = (double*)(b + l_hll1);
     L.bl[0] = (double*)(b + o_bl), L.bl[1] = (double*)(b + l_bl1), L.chi_part[0] = (double*)(b + l_chi[0]), L.chi_part[1] = (double*)(b + l_chi[1]);
     L.state = (LmState*)(b + o_lmstate);
-    L.ticket = (unsigned int*)(b + o_ticket);
-    L.tail_ctrl = c->lm_tail_ctrl ? 1 : 0;
     L.edge_pose = d_ek, L.edge_point = d_ep, L.pt_off = (const int32_t*)(b + o_pto), L.pt_edges = (const int32_t*)(b + o_pte);
     L.ps_off = (const int32_t*)(b + o_pso), L.ps_edges = (const int32_t*)(b + o_pse), L.free_pose = (const int32_t*)(b + o_free);
     L.pose_slot = (const int32_t*)(b + o_slot), L.pairs = (int2*)(b + l_pairs), L.pair_cnt = (int32_t*)(b + l_paircnt);
@@ -2517,7 +2434,7 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     }
     HIP_TRY(c, hipMemsetAsync(L.pair_table, 0xFF, (size_t)nf * NP * 4, st));
     launch_lm_pairs(st, L);
-    launch_lm_build(st, L, 0, 0, iters_first > 0 ? 1 : 0, -1, true);  // computeActiveErrors + buildSystem at the initial estimate
+    launch_lm_build(st, L, 0, 0, iters_first > 0 ? 1 : 0, true);  // computeActiveErrors + buildSystem at the initial estimate
     launch_lm_maxdiag(st, L, 0);
     // trials provisioned per pass: every iteration needs at least one, a rejected trial costs one more; what is left over runs as no-ops
     // (a few microseconds each), what is missing is enqueued in the next pass, after the one synchronisation of this one
@@ -2926,7 +2843,7 @@ orbfe_status orbfe_pose_only_optimize(orbfe_ctx* c, int32_t n, const double* xw,
     StageTimer tm(c, ORBFE_STAGE_BA, c->stream);
     launch_pose_only(c->stream, n, (const double*)(b + o_x), (const double*)(b + o_m), (const double*)(b + o_i), (const float*)(b + o_s),
                      (const double*)(b + o_p), prm, (double)(float)std::sqrt(5.991), (double)(float)std::sqrt(7.815), (double*)(b + o_e),
-                     b + o_l, b + o_r, b + o_in, (double*)(b + o_po), (int32_t*)(b + o_ng), c->pose_in_memory);
+                     b + o_l, b + o_r, b + o_in, (double*)(b + o_po), (int32_t*)(b + o_ng));
   }
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(hs, b + o_po, (inlier_out && n ? o_in + (size_t)n : o_in) - o_po, hipMemcpyDeviceToHost, c->stream));

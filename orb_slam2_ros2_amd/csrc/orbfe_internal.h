@@ -170,7 +170,5 @@ struct LmLaunch {
   double *chi2_out, *poses_out, *points_out;
   uint8_t *bad, *level_out;
   const volatile uint8_t* abort_flag;  // device address of a host-mapped byte the caller's stop flag is mirrored into
-  unsigned int* ticket;                // block counter of k_lm_linpoints' tail (zero between launches)
-  int tail_ctrl;                       // ORBFE_LM_TAIL_CTRL=1: the control step in the tail of k_lm_linpoints instead of a launch of its own
   BaParamsDev prm;
 };

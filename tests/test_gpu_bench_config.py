@@ -54,39 +54,19 @@ def test_bench_batch_of_512_pairs_equals_the_oracle(orc):
     ctx.close()
 
 
-KNOBS = [
+KNOBS = [   # the nine switches the library still reads (orbfe_create), each a fresh process
     {},                                   # the production schedule
     {"ORBFE_QT_REC_CAP": "0"},            # quadtree: records in global memory + bounce buffer (what 1024 images per launch use)
     {"ORBFE_QT_REC_CAP": "600"},          # ... and a partial LDS cache
-    {"ORBFE_QT_BATCH": "0"},              # one pop per step
-    {"ORBFE_QT_WAVES": "1"},              # one wave per tree in the host-pointer / slot paths too (default there: four)
     {"ORBFE_QT_LDS_NODES": "300"},        # node tables of the levels with quota > ~290 in GLOBAL memory (what nFeatures > ~12 000 uses)
-    {"ORBFE_QT_LDS_NODES": "300", "ORBFE_QT_WAVES": "1", "ORBFE_QT_BATCH": "0"},
     {"ORBFE_LBA_HOST_LM": "1"},           # (no effect on this path; the switch must at least not break context creation)
-    {"ORBFE_FUSE_ORIENT": "0"},           # keypoint list / moments / orientation of a frame or two as three launches (default: one)
-    {"ORBFE_HOST_READ": "1"},             # host-pointer / slot paths: the resize kernel reads the page-locked staging buffer (default: a host-to-device copy)
-    {"ORBFE_HOST_READ": "1", "ORBFE_HOST_MIRROR": "0"},
-    {"ORBFE_QT_GROUPS": "8"},             # one quadtree wave per level (default: the levels of an image dealt to 2 waves)
-    {"ORBFE_QT_GROUPS": "4"},             # ... to 4 waves (the default until late r3)
-    {"ORBFE_QT_GROUPS": "1"},             # ... and all levels of an image in one wave
     {"ORBFE_PIPELINE_STEREO": "0"},       # stereo match in line
     {"ORBFE_OVERLAP_BLUR": "0"},          # blur in line, no second stream
-    {"ORBFE_BLUR_L0_EARLY": "0"},         # the whole blur after FAST (default: level 0 beside the resize)
-    {"ORBFE_EXT_LEVEL0": "0"},            # copy level 0 in first, then resize from the copy (default: the resize reads the caller's images beside the copy-in)
-    {"ORBFE_FAST_SIDE_FROM": "3"},        # the k_fast launches of levels >= 3 on the second stream
-    {"ORBFE_FAST_SIDE_FROM": "5"},
     {"ORBFE_FAST_CPW": "4"},              # k_fast: four cells per wave in every launch (default: only where a launch holds >= 65536 cells)
     {"ORBFE_FAST_CPW": "7"},
-    {"ORBFE_FAST_ALT": "1"},              # k_fast's odd levels on a stream of their own (default: all eight launches in line)
     {"ORBFE_NO_XCD_ORDER": "1"},          # row-major cell / tile tables
-    {"ORBFE_RESIZE_REGIONS": "0"},        # resize by the per-class output tiles instead of the region-driven single pass
-    {"ORBFE_RG": "176,47"},               # resize regions of a fixed size (default: the size that tiles the image best, 208 x 47 here)
-    {"ORBFE_RG": "112,31"},
     {"ORBFE_GRAPHS": "0"},                # no hipGraph replay on the host-pointer path
-    {"ORBFE_HOST_MIRROR": "0"},           # host-pointer results by device-to-host copies (default: the kernels write them into the staging buffer)
-    {"ORBFE_HOST_MIRROR": "0", "ORBFE_GRAPHS": "0"},
-    {"ORBFE_STREAMS": "2"},               # two half-batches on their own streams
-    {"ORBFE_QT_REC_CAP": "0", "ORBFE_QT_BATCH": "0", "ORBFE_PIPELINE_STEREO": "0", "ORBFE_OVERLAP_BLUR": "0", "ORBFE_GRAPHS": "0"},
+    {"ORBFE_QT_REC_CAP": "0", "ORBFE_PIPELINE_STEREO": "0", "ORBFE_OVERLAP_BLUR": "0", "ORBFE_GRAPHS": "0"},
 ]
 
 

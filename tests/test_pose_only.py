@@ -74,19 +74,3 @@ def test_device_optimiser_small_and_wave_boundary_sizes(orc, n):
     o = orc.pose_only_optimize(**a)
     ctx.close()
     assert np.abs(g[1] - o[1]).max() < 1e-6 and abs(g[0] - o[0]) <= 1 and (g[2] != o[2]).sum() <= 1
-
-
-@pytest.mark.gpu
-def test_register_and_in_memory_kernels_agree(monkeypatch):
-    """ORBFE_POSE_IN_MEMORY=1 (round 2's kernel) against the register-resident state machine: same control flow and thresholds, sums in
-    other (fixed) orders -- pose to 1e-9, inlier flags equal but for an edge exactly on a threshold."""
-    from orb_slam2_ros2_amd._lib import Context
-    p = ba_synth.make_pose_problem(seed=21, n=700)
-    ctx = Context(640, 480, n_features=500, max_images=1)
-    a = ctx.pose_only_optimize(**_args(p))
-    ctx.close()
-    monkeypatch.setenv("ORBFE_POSE_IN_MEMORY", "1")
-    ctx = Context(640, 480, n_features=500, max_images=1)
-    b = ctx.pose_only_optimize(**_args(p))
-    ctx.close()
-    assert np.abs(a[1] - b[1]).max() < 1e-9 and abs(a[0] - b[0]) <= 1 and (a[2] != b[2]).sum() <= 1

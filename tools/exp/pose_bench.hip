@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
   BaParamsDev prm = {cam[0], cam[1], cam[2], cam[3], cam[4]};
   auto run = [&]() {
     launch_pose_only(0, n, d_x, d_m, d_i, d_s, d_p, prm, (double)(float)std::sqrt(5.991), (double)(float)std::sqrt(7.815), d_e, d_l, d_r, d_in, d_po,
-                     d_ng, getenv("ORBFE_POSE_IN_MEMORY") != nullptr);
+                     d_ng);
   };
   for (int w = 0; w < 3; ++w) run();
   hipDeviceSynchronize();

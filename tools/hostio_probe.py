@@ -25,7 +25,6 @@ def main():
     if "setdev" in sys.argv[2:]:
         torch.cuda.set_device(0)
     if "streams" in sys.argv[2:]:
-        os.environ["ORBFE_STREAMS"] = "1"
     if "explicit" in sys.argv[2:]:
         global Context
         _C = Context
