@@ -127,8 +127,15 @@ orbfe_status orbfe_extract_batch(orbfe_ctx* ctx, int32_t n_img, const uint8_t* c
 orbfe_status orbfe_extract_slot(orbfe_ctx* ctx, int32_t slot, const uint8_t* img, size_t stride_bytes, orbfe_keypoint* kps,
                                 uint8_t* desc, int32_t* n_out);
 /* The same for n_img images into the consecutive slots slot .. slot + n_img - 1 as ONE launch sequence on slot's lane (arrays as
- * orbfe_extract_batch): both eyes of a stereo frame when one caller holds both images -- the C++ mirror pairs the two extract() calls
- * that Frame::Frame's two threads make (src/Frame.cc:100-105) into one such call, which takes about half the time of two.           */
+ * orbfe_extract_batch): both eyes of a stereo frame when one caller holds both images, about half the time of two slot calls.  (The C++
+ * mirror keeps one orbfe_extract_slot per extract() thread, src/Frame.cc:100-105: pairing the two threads into one such call was
+ * measured and dropped)  The call holds the lanes of all the slots it writes; a slot call on any of them waits.
+ * Slot calls run concurrently with each other; they order themselves behind work the locked entry points left on the context
+ * stream, which takes the context's API lock for a moment -- a long call that holds it (orbfe_ba_local_optimize holds it for the whole
+ * optimisation) delays them: give the back end its own context.
+ * LIFETIME of a slot's device-resident results: until the next extraction INTO THAT SLOT.  The drop-in extractor rotates each eye over
+ * four slots (host/orbfe_dropin.hpp, ContextPool::kSlots), so a Frame's device-side features stay valid for the four extractions that
+ * follow it -- orbfe_stereo_match / orbfe_search_in_area / orbfe_get_pyramid on an older Frame read a newer frame's data.            */
 orbfe_status orbfe_extract_slots(orbfe_ctx* ctx, int32_t slot, int32_t n_img, const uint8_t* const* imgs, size_t stride_bytes,
                                  orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out);
 /* Copy one pyramid level of a slot to the host (tight rows).  blurred=0: the planes getPyramid() returns;

@@ -1482,7 +1482,7 @@ orbfe_status orbfe_extract_slot(orbfe_ctx* c, int32_t slot, const uint8_t* img, 
 }
 
 // n_img images -> slots [slot0, slot0 + n_img) on slot0's lane: what a caller does who holds BOTH images of a stereo frame when the
-// first extract() is reached (host/orbfe_shim.hpp pairs the two extract() calls of Frame::Frame's threads into one launch sequence)
+// first extract() is reached (host/orbfe_shim.hpp keeps one orbfe_extract_slot per extract() thread: pairing the threads was measured and dropped)
 orbfe_status orbfe_extract_slots(orbfe_ctx* c, int32_t slot, int32_t n_img, const uint8_t* const* imgs, size_t stride, orbfe_keypoint* kps,
                                  uint8_t* desc, int32_t* n_out) {
   if (!c || !imgs || n_img < 1) return fail(c, ORBFE_EBADARG, "extract_slots: NULL argument / no image");
@@ -1491,28 +1491,40 @@ orbfe_status orbfe_extract_slots(orbfe_ctx* c, int32_t slot, int32_t n_img, cons
   if (slot < 0 || slot + n_img > c->cfg.max_images) return fail(c, ORBFE_EBADARG, "extract_slot: slots %d..%d of %d", slot, slot + n_img - 1, c->cfg.max_images);
   if (stride < (size_t)c->cfg.width) return fail(c, ORBFE_EBADARG, "extract_slot: stride %zu < width %d", stride, c->cfg.width);
   HIP_TRY(c, hipSetDevice(c->device));
-  orbfe_ctx::Lane* ln = nullptr;
+  // the lanes of EVERY slot the call writes, created on first use and locked in index order (a concurrent slot call on any of them waits;
+  // two multi-slot calls cannot deadlock); the work runs on the first slot's lane
+  std::vector<orbfe_ctx::Lane*> lanes((size_t)n_img, nullptr);
   {
     std::lock_guard<std::mutex> lk(c->slot_lane_mu);
-    if (!c->slot_lane[(size_t)slot]) {
-      std::unique_ptr<orbfe_ctx::Lane> fresh(new orbfe_ctx::Lane());
-      HIP_TRY(c, hipStreamCreateWithFlags(&fresh->stream, hipStreamNonBlocking));
-      fresh->own_stream = true;
-      if (hipEventCreateWithFlags(&fresh->ev_main, hipEventDisableTiming) != hipSuccess) {
-        (void)hipStreamDestroy(fresh->stream);
-        return fail(c, ORBFE_EDEVICE, "extract_slot: cannot create the lane event");
+    for (int k = 0; k < n_img; ++k) {
+      if (!c->slot_lane[(size_t)(slot + k)]) {
+        std::unique_ptr<orbfe_ctx::Lane> fresh(new orbfe_ctx::Lane());
+        HIP_TRY(c, hipStreamCreateWithFlags(&fresh->stream, hipStreamNonBlocking));
+        fresh->own_stream = true;
+        if (hipEventCreateWithFlags(&fresh->ev_main, hipEventDisableTiming) != hipSuccess) {
+          (void)hipStreamDestroy(fresh->stream);
+          return fail(c, ORBFE_EDEVICE, "extract_slot: cannot create the lane event");
+        }
+        c->slot_lane[(size_t)(slot + k)] = std::move(fresh);
       }
-      c->slot_lane[(size_t)slot] = std::move(fresh);
+      lanes[(size_t)k] = c->slot_lane[(size_t)(slot + k)].get();
     }
-    ln = c->slot_lane[(size_t)slot].get();
   }
-  std::lock_guard<std::mutex> lk(ln->mu);
+  std::vector<std::unique_lock<std::mutex>> held;
+  held.reserve(lanes.size());
+  for (orbfe_ctx::Lane* l : lanes) held.emplace_back(l->mu);
+  orbfe_ctx::Lane* ln = lanes[0];
   // a stereo match of an earlier device batch may still be reading the slot arrays (the flag is only read here: the calls that
   // change it must not overlap with slot calls)
   if (c->stereo_pending) HIP_TRY(c, hipStreamWaitEvent(ln->stream, c->ev_stereo_done, 0));
-  // ... and an asynchronous batch call may have left work on the context stream that still writes this slot
-  HIP_TRY(c, hipEventRecord(ln->ev_main, c->stream));
-  HIP_TRY(c, hipStreamWaitEvent(ln->stream, ln->ev_main, 0));
+  // ... and an asynchronous batch call may have left work on the context stream that still writes this slot.  The marker is recorded
+  // under the API lock: another thread may be inside hipStreamBeginCapture on the context stream (the first orbfe_extract /
+  // orbfe_extract_batch of a shape), and an event recorded into that capture would pull this lane's stream into it -- both graphs fail
+  {
+    ApiLock api_lk(c);
+    HIP_TRY(c, hipEventRecord(ln->ev_main, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(ln->stream, ln->ev_main, 0));
+  }
   return extract_lane(c, *ln, slot, n_img, imgs, stride, kps, desc, n_out, false);
 }
 
@@ -1961,7 +1973,9 @@ orbfe_status orbfe_stream_pack_records(orbfe_ctx* c, int64_t ticket, int32_t n_p
                       (const int32_t*)(src + l.o_nm), std::max(c->cfg.n_features, 1), n_pairs, d_records);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipEventRecord(hs.ev_done[b], hs.d2h));
-  HIP_TRY(c, hipEventSynchronize(hs.ev_done[b]));
+  hipEvent_t done = hs.ev_done[b];
+  api_lk.lk.unlock();  // the wait lasts a batch's compute and needs nothing of the context: another thread may submit / fetch meanwhile
+  HIP_TRY(c, hipEventSynchronize(done));
   return ORBFE_OK;
 }
 

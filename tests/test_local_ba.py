@@ -186,7 +186,6 @@ def test_device_local_ba_stop_flag(orc):
     host-mapped byte the call mirrors the caller's flag into.  Raised before the call: no iteration starts, no classification, no second
     round (`if (!isStop)`), the final chi2 test still runs.  Raised WHILE the call runs: the optimisation ends within one trial."""
     import threading
-    import time
 
     from orb_slam2_ros2_amd._lib import Context
     pr, fixed = _problem(21, 30, 1500, 10)
@@ -196,16 +195,24 @@ def test_device_local_ba_stop_flag(orc):
     o = orc.ba_local_optimize(pr, fixed, iters1=0, iters2=0)
     assert g["iters"].tolist() == [0, 0] and not g["level"].any()
     assert np.array_equal(g["poses"], pr["poses"]) and np.array_equal(g["points"], pr["points"]) and np.array_equal(g["bad"], o["bad"])
-    # while it runs: a budget of 3000 iterations, the flag after 2 ms (a trial takes ~0.1 ms)
+    # while it runs: a budget of 3000 + 3000 iterations; a second thread raises the flag as soon as the call has been entered (events, no
+    # clock: the call needs >= 60 trials of ~0.15 ms to end by itself, the flag thread one wake-up)
     alone = ctx.ba_local_optimize(pr, fixed, 3000, 0)     # how far Levenberg-Marquardt goes by itself (it ends on ten rejected trials in a row)
     stop[0] = 0
-    t0 = time.perf_counter()
-    threading.Timer(0.002, lambda: stop.__setitem__(0, 1)).start()
+    entered, returned, seen = threading.Event(), threading.Event(), {}
+
+    def raiser():
+        entered.wait()
+        stop[0] = 1
+        seen["before_return"] = not returned.is_set()
+    th = threading.Thread(target=raiser)
+    th.start()
+    entered.set()
     g = ctx.ba_local_optimize(pr, fixed, 3000, 3000, stop=stop)
-    dt = time.perf_counter() - t0
-    assert dt < 0.25, dt
+    returned.set()
+    th.join()
     assert np.isfinite(g["poses"]).all() and 0 <= g["iters"][0] <= alone["iters"][0]
-    if alone["iters"][0] > 60:   # the flag came first: the round ended early, no classification, no second round
+    if seen["before_return"] and alone["iters"][0] > 60:   # the flag came first: the round ended early, no classification, no second round
         assert g["iters"][0] < alone["iters"][0] and g["iters"][1] == 0 and not g["level"].any(), (g["iters"], alone["iters"])
     ctx.close()
 
