@@ -580,6 +580,60 @@ def latency_leg(device_id, n=500):
         "search_in_area_ms": _stats_ms(lambda: ctx.search_in_area(0, qxy, rad, lo, hi, rd[q]), 200, warm=10)["median_ms"],
         "search_in_area_features_ms": _stats_ms(lambda: ctx.search_in_area_features(lk, ld, qxy, rad, lo, hi, rd[q]), 200, warm=10)["median_ms"],
         "project_map_points_ms": _stats_ms(lambda: ctx.project_map_points(pos, vd, mx, mn, np.eye(3), np.zeros(3), cam, bnd), 200, warm=10)["median_ms"]}
+    # Tracking::trackLocalMap's chain for 2000 local map points (Tracking.cc:641-675): searchByProjection(frame, map points, th) + OptimizePoseOnly,
+    # as ONE call (orbfe_track_local_map: the frame's features are the slot's, one upload, one download) against the same three steps through
+    # the separate entry points (three round trips, the queries / edges marshalled on the host in between).  The map: the left image's
+    # keypoints back-projected at their stereo depth (tests/test_track_chain.py holds the fused call to the oracle's chain).
+    n_l = len(lk)
+    ru_full = np.full(NFEAT, -1.0)
+    ru_full[:n_l] = ru[:n_l]
+    depth = np.where(dp[:n_l] > 0, dp[:n_l], r.uniform(4, 30, n_l))
+    CXk, CYk = 607.1928, 185.2157
+    Xmp = np.stack([(lk["x"] - CXk) / FX * depth, (lk["y"] - CYk) / FX * depth, depth], 1).astype(np.float32)
+    take = np.concatenate([r.permutation(n_l)[: min(n_l, 1800)], r.integers(0, n_l, 2000 - min(n_l, 1800))])
+    mp_pos = Xmp[take] + r.normal(0, 0.01, (2000, 3)).astype(np.float32)
+    mp_desc = ld[take].copy()
+    mp_vd = (mp_pos / np.linalg.norm(mp_pos, axis=1, keepdims=True)).astype(np.float32)
+    dist = np.linalg.norm(mp_pos, axis=1)
+    mp_max, mp_min = (dist * 1.8).astype(np.float32), (dist * 0.6).astype(np.float32)
+    mp_flags = np.full(2000, 7, np.uint8)
+    sf = np.array([np.float32(SCALE) ** l for l in range(NLEVELS)], np.float32)
+    sig2 = (sf * sf).astype(np.float32)
+    isig2 = (np.float32(1.0) / sig2).astype(np.float32)
+    Rc, tc = np.eye(3, dtype=np.float32), np.array([0.03, -0.02, 0.04], np.float32)
+    p0 = np.array([0, 0, 0, 1, 0.03, -0.02, 0.04], np.float64)
+    camk, bndk = (FX, FX, CXk, CYk, BF), (0.0, float(W), 0.0, float(H))
+
+    def chain_fused():
+        return ctx.track_local_map(0, mp_pos, mp_vd, mp_max, mp_min, mp_desc, mp_flags, Rc, tc, camk, bndk, p0, sig2, isig2, right_u=ru_full)
+
+    def chain_three_calls():
+        pr = ctx.project_map_points(mp_pos, mp_vd, mp_max, mp_min, Rc, tc, camk[:4], bndk)
+        idx = np.flatnonzero(pr["visible"])
+        lvl = pr["level"][idx].astype(np.int64)
+        radius = ((np.where(pr["cos_theta"][idx] > np.float32(0.998), np.float32(2.5), np.float32(4.0)) * np.float32(3.0)) * sig2[lvl]).astype(np.float32)
+        bi, bd, sd, nc = ctx.search_in_area(0, pr["uv"][idx], radius, np.maximum(0, lvl - 1).astype(np.int8), np.minimum(NLEVELS - 1, lvl + 1).astype(np.int8),
+                                            mp_desc[idx])
+        ok = (nc > 0) & (bd < 50) & (bd.astype(np.float32) / sd.astype(np.float32) < np.float32(0.8))
+        held = np.full(NFEAT, -1, np.int64)
+        for k in np.flatnonzero(ok):          # the reference's loop, map-point order (first claim wins)
+            if held[bi[k]] < 0:
+                held[bi[k]] = idx[k]
+        ef = np.flatnonzero(held >= 0)
+        meas = np.stack([lk["x"][ef].astype(np.float64), lk["y"][ef].astype(np.float64), ru_full[ef]], 1)
+        oc = lk["octave"][ef]
+        return ctx.pose_only_optimize(mp_pos[held[ef]].astype(np.float64), meas, isig2[oc].astype(np.float64), sig2[oc], p0, FX, FX, CXk, CYk, BF), held
+
+    gf = chain_fused()
+    (ng3, pose3, _), held3 = chain_three_calls()
+    if not np.array_equal(gf["assigned"], held3) or abs(gf["n_good"] - ng3) > 1 or np.abs(gf["pose"] - pose3).max() > 1e-6:
+        raise SystemExit("bench.py: latency leg: the fused tracking chain differs from the three separate calls")
+    out["track_local_map"] = {
+        "what": "Tracking::trackLocalMap's device work for 2000 local map points against a 2000-feature frame, host arrays in, host results "
+                "out: orbfe_track_local_map (one call) vs orbfe_project_map_points + orbfe_search_in_area + orbfe_pose_only_optimize with "
+                "the reference's policy in numpy between them",
+        "n_matches": int(gf["n_matches"]), "n_edges": int(gf["n_edges"]), "n_good": int(gf["n_good"]),
+        "fused": _stats_ms(chain_fused, 200, warm=10), "three_calls": _stats_ms(chain_three_calls, 100, warm=5), "verified": True}
     ctx.close()
     # (b) the C++ drop-in
     tmp = tempfile.mkdtemp(prefix="orbfe_lat_")

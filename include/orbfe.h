@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define ORBFE_ABI_VERSION 2
+#define ORBFE_ABI_VERSION 3
 #define ORBFE_MAX_LEVELS 16
 #define ORBFE_DESC_BYTES 32
 
@@ -370,6 +370,49 @@ orbfe_status orbfe_project_map_points(orbfe_ctx* ctx, int32_t n, const float* po
                                       const float* max_dist /*[n]*/, const float* min_dist /*[n]*/, const orbfe_frame_pose* pose,
                                       const orbfe_camera* cam, float* uv /*[n][2]*/, float* distance /*[n]*/, float* cos_theta /*[n]*/,
                                       int8_t* level /*[n]*/, uint8_t* visible /*[n]*/);
+
+/* ---- the tracking chain of one frame as ONE call -------------------------------------------------------------------------
+ * Tracking::trackLocalMap (src/Tracking.cc:641-675) calls ORBMatcher::searchByProjection(frame, local map points, th)
+ * (src/ORBMatcher.cc:561-612: MapPoint::isInVision + predictLevel per point, findFeaturesInArea + getBestMatch, then the assignment
+ * in map-point order -- a feature that holds a good map point keeps it, a free one goes to the first point whose best match it is)
+ * and then Optimizer::OptimizePoseOnly(frame) (src/Optimizer.cc:33-178) on what the frame holds.  Called one by one
+ * (orbfe_project_map_points, orbfe_search_in_area, orbfe_pose_only_optimize) that is three host -> device -> host round trips with the
+ * map points and the frame's features marshalled each time; here the frame's features are the device-resident results of `slot`, the
+ * map points go up once, and the projections, windows, candidate lists, assignment and edge list stay on the device.
+ * flags[i]: bit 0 = !isBad && isInMap, bit 1 = !isBad, bit 2 = member of the list searchByProjection walks (a point the frame holds
+ * from an earlier stage but that is not in the local map carries bits 0-1 only: not searched, still an edge).
+ * Outputs: assigned[f] = index of the map point feature f holds after the search (-1: none); n_matches = searchByProjection's return
+ * value; when n_matches >= min_matches (else n_edges = -1, pose_out = pose_se3, no inliers -- trackLocalMap returns false there):
+ * n_edges, n_good = edges - nBad after the four rounds, pose_out (qx qy qz qw tx ty tz), inlier[f] = 1 where feature f's edge ended
+ * as an inlier.  The projection post-check (Optimizer.cc:180-190) and the map points' counters stay with the caller, as in
+ * orbfe_pose_only_optimize.  At most 2048 features per frame.                                                                    */
+typedef struct orbfe_track_input {
+  int32_t n_mp;
+  const float* pos;              /* [n_mp][3] MapPoint::getPos()                                                   */
+  const float* view_dir;         /* [n_mp][3]                                                                      */
+  const float* max_dist;         /* [n_mp]                                                                         */
+  const float* min_dist;         /* [n_mp]                                                                         */
+  const uint8_t* desc;           /* [n_mp][32] MapPoint::getDesc()                                                 */
+  const uint8_t* flags;          /* [n_mp], see above                                                              */
+  const int32_t* held;           /* [n_features], nullable: map point (index) a feature holds on entry, -1 none    */
+  const double* right_u;         /* [n_features], nullable (every edge mono): Frame::getRightU                     */
+  const float* level_sigma2;     /* [n_levels] VirtualFrame::getScaledFactor2(level)                               */
+  const float* level_inv_sigma2; /* [n_levels] getScaledFactorInv2(level)                                          */
+  const double* pose_se3;        /* [7] Converter::ConvertTcw2SE3(mRcw, mtcw): the optimisation's initial estimate */
+  float th;                      /* searchByProjection's th (Tracking.cc:645-649: 3, or 5 after a relocalisation)  */
+  float ratio;                   /* ORBMatcher::mfRatio (0.8 in trackLocalMap)                                     */
+  int32_t min_threshold;         /* ORBMatcher::mnMinThreshold (50)                                                */
+  int32_t min_matches;           /* Tracking.cc:656: below this many matches no optimisation (30)                  */
+} orbfe_track_input;
+typedef struct orbfe_track_output {
+  int32_t* assigned;  /* [n_features]                                  */
+  int32_t* edge_of;   /* [n_features], nullable: edge index of a feature in the optimisation (-1 none) */
+  uint8_t* inlier;    /* [n_features]                                  */
+  int32_t *n_matches, *n_edges, *n_good;
+  double* pose_out;   /* [7]                                           */
+} orbfe_track_output;
+orbfe_status orbfe_track_local_map(orbfe_ctx* ctx, int32_t slot, const orbfe_frame_pose* pose, const orbfe_camera* cam,
+                                   const orbfe_track_input* in, const orbfe_track_output* out);
 
 /* ---- map.pb: the reference's on-disk map, and a local bundle adjustment on it -------------------------------
  * `orbslam2.MapData` as Map::saveToProtobuf writes it (src/Map.cc:200-250; proto/Map.proto, Keyframe.proto,

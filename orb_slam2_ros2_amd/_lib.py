@@ -71,6 +71,18 @@ class FramePose(C.Structure):
                 ("max_v", C.c_float)]
 
 
+class TrackInput(C.Structure):
+    _fields_ = [("n_mp", C.c_int32), ("pos", C.c_void_p), ("view_dir", C.c_void_p), ("max_dist", C.c_void_p), ("min_dist", C.c_void_p),
+                ("desc", C.c_void_p), ("flags", C.c_void_p), ("held", C.c_void_p), ("right_u", C.c_void_p), ("level_sigma2", C.c_void_p),
+                ("level_inv_sigma2", C.c_void_p), ("pose_se3", C.c_void_p), ("th", C.c_float), ("ratio", C.c_float),
+                ("min_threshold", C.c_int32), ("min_matches", C.c_int32)]
+
+
+class TrackOutput(C.Structure):
+    _fields_ = [("assigned", C.c_void_p), ("edge_of", C.c_void_p), ("inlier", C.c_void_p), ("n_matches", C.c_void_p), ("n_edges", C.c_void_p),
+                ("n_good", C.c_void_p), ("pose_out", C.c_void_p)]
+
+
 class MapSummary(C.Structure):
     _fields_ = [("next_id", C.c_uint64), ("n_scale_factors", C.c_int32), ("n_keyframes", C.c_int32), ("n_mappoints", C.c_int32),
                 ("n_keypoints", C.c_int64), ("n_observations", C.c_int64)]
@@ -101,7 +113,7 @@ EXPORTS = [
     "orbfe_get_capacity",
     "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_slot", "orbfe_extract_slots", "orbfe_fetch_batch", "orbfe_fetch_stereo_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
     "orbfe_host_alloc", "orbfe_host_alloc_on", "orbfe_host_free", "orbfe_recommended_hw_queues", "orbfe_stream_submit", "orbfe_stream_wait", "orbfe_stream_device_results", "orbfe_record_bytes", "orbfe_stream_pack_records",
-    "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_search_in_area_features", "orbfe_search_in_area_features_ex", "orbfe_extract_color", "orbfe_frame_rgbd", "orbfe_project_map_points",
+    "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_search_in_area_features", "orbfe_search_in_area_features_ex", "orbfe_extract_color", "orbfe_frame_rgbd", "orbfe_project_map_points", "orbfe_track_local_map",
     "orbfe_map_pb_summary", "orbfe_map_pb_reencode", "orbfe_map_pb_to_txt", "orbfe_map_txt_to_pb", "orbfe_map_local_graph", "orbfe_map_local_ba",
     "orbfe_profile_enable", "orbfe_profile_read", "orbfe_stage_name", "orbfe_debug_candidates",
 ]
@@ -172,6 +184,7 @@ def load() -> C.CDLL:
     L.orbfe_extract_color.argtypes = [vp, vp, C.c_size_t, i32, vp, vp, vp]
     L.orbfe_frame_rgbd.argtypes = [vp, i32, C.POINTER(Camera), vp, i32, C.c_size_t, f32, vp, vp, vp]
     L.orbfe_project_map_points.argtypes = [vp, i32, vp, vp, vp, vp, C.POINTER(FramePose), C.POINTER(Camera), vp, vp, vp, vp, vp]
+    L.orbfe_track_local_map.argtypes = [vp, i32, C.POINTER(FramePose), C.POINTER(Camera), C.POINTER(TrackInput), C.POINTER(TrackOutput)]
     L.orbfe_map_pb_summary.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(MapSummary)]
     L.orbfe_map_pb_reencode.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.orbfe_map_pb_to_txt.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -639,6 +652,33 @@ class Context:
                                                       C.byref(cm), ptr(out["uv"]), ptr(out["distance"]), ptr(out["cos_theta"]),
                                                       ptr(out["level"]), ptr(out["visible"])))
         return {k: v[:n] for k, v in out.items()}
+
+    def track_local_map(self, slot, pos, view_dir, max_dist, min_dist, desc, flags, Rcw, tcw, cam, bounds, pose_se3, level_sigma2,
+                        level_inv_sigma2, held=None, right_u=None, th=3.0, ratio=0.8, min_threshold=50, min_matches=30):
+        """Tracking::trackLocalMap's device work as one call (orbfe_track_local_map): searchByProjection(frame, map points, th) against
+        the features of `slot`, then OptimizePoseOnly on what the frame holds.  cam = (fx, fy, cx, cy, bf); bounds = (minU, maxU, minV,
+        maxV) -> dict(assigned, edge_of, inlier, n_matches, n_edges, n_good, pose)"""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        pos, view_dir, max_dist, min_dist = f32(pos).reshape(-1, 3), f32(view_dir).reshape(-1, 3), f32(max_dist), f32(min_dist)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        flags = np.ascontiguousarray(flags, np.uint8)
+        n, NF = pos.shape[0], self.n_features
+        held = None if held is None else np.ascontiguousarray(held, np.int32)
+        right_u = None if right_u is None else np.ascontiguousarray(right_u, np.float64)
+        if (held is not None and held.size != NF) or (right_u is not None and right_u.size != NF):
+            raise ValueError("held / right_u must have n_features entries")
+        s2, is2, p0 = f32(level_sigma2), f32(level_inv_sigma2), np.ascontiguousarray(pose_se3, np.float64)
+        fp = FramePose((C.c_float * 9)(*f32(Rcw).reshape(9)), (C.c_float * 3)(*f32(tcw).reshape(3)), *[float(np.float32(b)) for b in bounds])
+        cm = Camera(*[float(np.float32(v)) for v in cam[:4]], 0, 0, 0, 0, 0, float(np.float32(cam[4])))
+        out = dict(assigned=np.zeros(NF, np.int32), edge_of=np.zeros(NF, np.int32), inlier=np.zeros(NF, np.uint8), pose=np.zeros(7))
+        nm, ne, ng = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        ti = TrackInput(n, *[ptr(a) for a in (pos, view_dir, max_dist, min_dist, desc, flags, held, right_u, s2, is2, p0)], th, ratio,
+                        min_threshold, min_matches)
+        to = TrackOutput(ptr(out["assigned"]), ptr(out["edge_of"]), ptr(out["inlier"]), C.cast(C.byref(nm), C.c_void_p),
+                         C.cast(C.byref(ne), C.c_void_p), C.cast(C.byref(ng), C.c_void_p), ptr(out["pose"]))
+        self._check(self.lib.orbfe_track_local_map(self.h, slot, C.byref(fp), C.byref(cm), C.byref(ti), C.byref(to)))
+        out.update(n_matches=nm.value, n_edges=ne.value, n_good=ng.value)
+        return out
 
     def map_local_ba(self, pb: bytes, kf_id: int, fx, fy, cx, cy, bf):
         """Optimizer::OptimizeLocalMap around keyframe kf_id of a map.pb -> (updated map.pb bytes, report dict)"""

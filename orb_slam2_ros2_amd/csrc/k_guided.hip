@@ -125,6 +125,10 @@ __global__ __launch_bounds__(256) void k_search_area(const uint4* __restrict__ k
   const int q = blockIdx.x * 4 + wv;
   if (q >= nq) return;
   const float x = qxy[2 * q], y = qxy[2 * q + 1], rad = radius[q];
+  if (rad < 0.f) {  // (the tracking chain marks a map point that takes no part in the search this way)
+    if (lane == 0) n_cand[q] = 0, best_idx[q] = -1, best_dist[q] = ORB_INT_MAX, second_dist[q] = ORB_INT_MAX;
+    return;
+  }
   const int lo = min_level[q], hi = max_level[q];
   const int min_x = max(0, __float2int_rn(x - rad)), max_x = min(width, __float2int_rn(x + rad));
   const int min_y = max(0, __float2int_rn(y - rad)), max_y = min(height, __float2int_rn(y + rad));
@@ -243,6 +247,123 @@ __global__ __launch_bounds__(256) void k_project_map_points(int n, const float* 
   dist_out[i] = distance, cos_out[i] = cos_theta;
   level_out[i] = (int8_t)level;
   visible[i] = vis;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The tracking chain (Tracking::trackLocalMap, src/Tracking.cc:641-675): ORBMatcher::searchByProjection(frame, map points, th)
+// (src/ORBMatcher.cc:561-612) -> Optimizer::OptimizePoseOnly(frame) (src/Optimizer.cc:33-178) with every intermediate on the device.
+// k_track_queries: per map point, the search window the reference derives from isInVision / predictLevel (:575-582).
+// k_track_claim / k_track_edges: the reference assigns in map-point order -- a feature that holds a (good) map point keeps it, a free
+// feature goes to the FIRST map point whose best match it is (later ones find it taken): the minimum map-point index per feature,
+// an atomicMin.  The pose-only edges are the features that hold a good map point afterwards, in feature order (Optimizer.cc:59-118).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_track_queries(int n, const uint8_t* __restrict__ mp_flags, const uint8_t* __restrict__ visible,
+                                                       const float* __restrict__ cos_theta, const int8_t* __restrict__ level, float th,
+                                                       const float* __restrict__ level_sigma2, int n_levels, float* __restrict__ radius,
+                                                       int8_t* __restrict__ min_level, int8_t* __restrict__ max_level) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float r = -1.f;
+  int lo = 0, hi = 0;
+  if ((mp_flags[i] & 5) == 5 && visible[i]) {  // in the search list, !isBad, isInMap (ORBMatcher.cc:575-576)
+    const int oc = level[i];
+    const float base = cos_theta[i] > 0.998f ? 2.5f : 4.0f;
+    r = (base * th) * level_sigma2[oc];  // findFeaturesInArea(kp, radius * th, ..): radius * getScaledFactor2(octave) (Frame.cc:289)
+    lo = max(0, oc - 1), hi = min(n_levels - 1, oc + 1);
+  }
+  radius[i] = r;
+  min_level[i] = (int8_t)lo, max_level[i] = (int8_t)hi;
+}
+
+__global__ __launch_bounds__(256) void k_track_claim(int n, const int32_t* __restrict__ n_cand, const int32_t* __restrict__ best_idx,
+                                                     const int32_t* __restrict__ best_dist, const int32_t* __restrict__ second_dist,
+                                                     int min_threshold, float ratio, int32_t* __restrict__ claim) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || n_cand[i] <= 0) return;
+  const float fr = (float)best_dist[i] / (float)second_dist[i];  // getBestMatch's ratio (ORBMatcher.cc:988); second = INT_MAX -> ~0
+  if (best_dist[i] < min_threshold && fr < ratio) atomicMin(&claim[best_idx[i]], i);
+}
+
+// One workgroup: final assignment per feature, the reference's match count, and the pose-only edge list in feature order.
+// held[f]: map point the feature holds on entry (-1 none); mp_flags bit 0: !isBad && isInMap (the occupancy test, ORBMatcher.cc:595, and
+// the search loop's own filter, :575), bit 1: !isBad (the initial count, :566-571, and the edge test, Optimizer.cc:64), bit 2: member of
+// the list searchByProjection walks.
+__global__ __launch_bounds__(1024) void k_track_edges(const orbfe_keypoint* __restrict__ kps, const int32_t* __restrict__ n_kp_ptr, int n_features,
+                                                      const int32_t* __restrict__ held, const int32_t* __restrict__ claim,
+                                                      const uint8_t* __restrict__ mp_flags, const float* __restrict__ mp_pos,
+                                                      const double* __restrict__ right_u, const float* __restrict__ level_sigma2,
+                                                      const float* __restrict__ level_inv_sigma2, int min_matches,
+                                                      int32_t* __restrict__ assigned, int32_t* __restrict__ edge_of, double* __restrict__ Xw,
+                                                      double* __restrict__ meas, double* __restrict__ info, float* __restrict__ sigma2,
+                                                      int32_t* __restrict__ counts /*[0] n_matches, [1] n_edges (-1: below min_matches)*/) {
+  __shared__ int s_wave[16], s_match[16];
+  __shared__ int s_base;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int n_kp = min(*n_kp_ptr, n_features);
+  if (t == 0) s_base = 0;
+  int total_matches = 0;
+  __syncthreads();
+  for (int f0 = 0; f0 < n_features; f0 += 1024) {
+    const int f = f0 + t;
+    int mp = -1;
+    bool c_held = false, c_new = false, edge = false;
+    if (f < n_kp) {
+      const int h = held ? held[f] : -1;
+      c_held = h >= 0 && (mp_flags[h] & 2);  // `if (pMp && !pMp->isBad()) ++nMatches` (ORBMatcher.cc:566-571)
+      mp = h;
+      const int cl = claim[f];
+      if (cl != 0x7F7F7F7F && !(h >= 0 && (mp_flags[h] & 1))) mp = cl, c_new = true;  // setMapPoint + ++nMatches (:595-599)
+      edge = mp >= 0 && (mp_flags[mp] & 2);
+    }
+    if (f < n_features) assigned[f] = mp;
+    const unsigned long long me = __ballot(edge);
+    const int wm = __popcll(__ballot(c_held)) + __popcll(__ballot(c_new));
+    if (lane == 0) s_wave[wv] = __popcll(me), s_match[wv] = wm;
+    __syncthreads();
+    int before = s_base, chunk_edges = 0, chunk_matches = 0;
+    for (int w = 0; w < 16; ++w) {
+      if (w < wv) before += s_wave[w];
+      chunk_edges += s_wave[w], chunk_matches += s_match[w];
+    }
+    total_matches += chunk_matches;
+    const int pos = before + __popcll(me & ((1ull << lane) - 1ull));
+    if (f < n_features) edge_of[f] = edge ? pos : -1;
+    if (edge) {
+      const orbfe_keypoint k = kps[f];
+      Xw[3 * pos] = (double)mp_pos[3 * mp], Xw[3 * pos + 1] = (double)mp_pos[3 * mp + 1], Xw[3 * pos + 2] = (double)mp_pos[3 * mp + 2];
+      const double ru = right_u ? right_u[f] : -1.0;
+      meas[3 * pos] = (double)k.x, meas[3 * pos + 1] = (double)k.y, meas[3 * pos + 2] = ru < 0 ? -1.0 : ru;
+      const int oc = k.octave;
+      info[pos] = (double)level_inv_sigma2[oc];
+      sigma2[pos] = level_sigma2[oc];
+    }
+    __syncthreads();
+    if (t == 0) s_base += chunk_edges;
+    __syncthreads();
+  }
+  if (t == 0) {
+    counts[0] = total_matches;
+    counts[1] = total_matches < min_matches ? -1 : s_base;  // Tracking::trackLocalMap returns before the optimisation (Tracking.cc:656-657)
+  }
+}
+
+void launch_track_queries(hipStream_t s, int n, const uint8_t* d_flags, const uint8_t* d_visible, const float* d_cos, const int8_t* d_level, float th,
+                          const float* d_sigma2, int n_levels, float* d_radius, int8_t* d_min_level, int8_t* d_max_level) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_track_queries, dim3((n + 255) / 256), dim3(256), 0, s, n, d_flags, d_visible, d_cos, d_level, th, d_sigma2, n_levels, d_radius,
+                     d_min_level, d_max_level);
+}
+void launch_track_claim(hipStream_t s, int n, const int32_t* d_n_cand, const int32_t* d_best_idx, const int32_t* d_best_dist, const int32_t* d_second,
+                        int min_threshold, float ratio, int32_t* d_claim) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_track_claim, dim3((n + 255) / 256), dim3(256), 0, s, n, d_n_cand, d_best_idx, d_best_dist, d_second, min_threshold, ratio, d_claim);
+}
+void launch_track_edges(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, int n_features, const int32_t* d_held, const int32_t* d_claim,
+                        const uint8_t* d_mp_flags, const float* d_mp_pos, const double* d_right_u, const float* d_sigma2, const float* d_inv_sigma2,
+                        int min_matches, int32_t* d_assigned, int32_t* d_edge_of, double* d_Xw, double* d_meas, double* d_info, float* d_sig,
+                        int32_t* d_counts) {
+  hipLaunchKernelGGL(k_track_edges, dim3(1), dim3(1024), 0, s, d_kps, d_n_kp, n_features, d_held, d_claim, d_mp_flags, d_mp_pos, d_right_u, d_sigma2,
+                     d_inv_sigma2, min_matches, d_assigned, d_edge_of, d_Xw, d_meas, d_info, d_sig, d_counts);
 }
 
 void launch_project_map_points(hipStream_t s, int n, const float* d_pos, const float* d_vdir, const float* d_max, const float* d_min,

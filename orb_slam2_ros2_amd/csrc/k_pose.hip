@@ -393,10 +393,22 @@ __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __res
                                                            const double* __restrict__ info, const float* __restrict__ sigma2,
                                                            const double* __restrict__ pose_in, BaParamsDev prm, double d_mono,
                                                            double d_stereo, uint8_t* __restrict__ inlier_out,
-                                                           double* __restrict__ pose_out, int32_t* __restrict__ n_good) {
+                                                           double* __restrict__ pose_out, int32_t* __restrict__ n_good,
+                                                           const int32_t* __restrict__ n_dev) {
 #pragma clang fp contract(off)
   __shared__ PoseSharedR<NT> S;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (n_dev) {  // the tracking chain: the edge list was built on the device, `n` is only its upper bound; < 0: no optimisation at all
+    const int nd = *n_dev;
+    // (both register kernels are launched: the one whose capacity class the count falls into runs, the other returns)
+    if (NT == 256 ? nd > 256 * POSE_EPT : (nd >= 0 && nd <= 256 * POSE_EPT)) return;
+    if (nd < 0) {
+      if (tid < 7) pose_out[tid] = pose_in[tid];
+      if (tid == 0) *n_good = 0;
+      return;
+    }
+    n = min(n, nd);
+  }
   double X[POSE_EPT][3], M[POSE_EPT][3], W[POSE_EPT], E[POSE_EPT][3], TH[POSE_EPT];
   bool have[POSE_EPT], st[POSE_EPT], lvl0[POSE_EPT], rob[POSE_EPT], inl[POSE_EPT];
 #pragma unroll
@@ -672,15 +684,19 @@ __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __res
 
 void launch_pose_only(hipStream_t s, int n, const double* Xw, const double* meas, const double* info, const float* sigma2,
                       const double* pose_in, BaParamsDev prm, double d_mono, double d_stereo, double* err, uint8_t* level,
-                      uint8_t* robust, uint8_t* inlier, double* pose_out, int32_t* n_good) {
+                      uint8_t* robust, uint8_t* inlier, double* pose_out, int32_t* n_good, const int32_t* n_dev) {
+  // n_dev (nullable, the tracking chain): the edge count in device memory, n its upper bound (register kernels only)
   // (past POSE_RT * POSE_EPT edges: round 2's kernel, which re-reads the edges from memory every pass)
   // 256 threads up to 1024 edges (one wave per SIMD: the 27 wave reductions of a build are issued once per SIMD, not twice), 512 up to 2048
+  if (n_dev && n > 256 * POSE_EPT && n <= POSE_RT * POSE_EPT)  // the count is on the device: the 256-thread kernel takes it if it fits (20 % faster there), else the next launch does
+    hipLaunchKernelGGL(k_pose_only_reg<256>, dim3(1), dim3(256), 0, s, 256 * POSE_EPT, Xw, meas, info, sigma2, pose_in, prm, d_mono, d_stereo, inlier,
+                       pose_out, n_good, n_dev);
   if (n <= 256 * POSE_EPT)
     hipLaunchKernelGGL(k_pose_only_reg<256>, dim3(1), dim3(256), 0, s, n, Xw, meas, info, sigma2, pose_in, prm, d_mono, d_stereo, inlier, pose_out,
-                       n_good);
+                       n_good, n_dev);
   else if (n <= POSE_RT * POSE_EPT)
     hipLaunchKernelGGL(k_pose_only_reg<POSE_RT>, dim3(1), dim3(POSE_RT), 0, s, n, Xw, meas, info, sigma2, pose_in, prm, d_mono, d_stereo, inlier, pose_out,
-                       n_good);
+                       n_good, n_dev);
   else
     hipLaunchKernelGGL(k_pose_only, dim3(1), dim3(POSE_THREADS), 0, s, n, Xw, meas, info, sigma2, pose_in, prm, d_mono, d_stereo, err,
                        level, robust, inlier, pose_out, n_good);

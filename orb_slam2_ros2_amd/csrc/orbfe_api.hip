@@ -111,7 +111,15 @@ void launch_lm_switch(hipStream_t s, const LmLaunch& L);
 void launch_lm_final(hipStream_t s, const LmLaunch& L);
 void launch_pose_only(hipStream_t s, int n, const double* Xw, const double* meas, const double* info, const float* sigma2,
                       const double* pose_in, BaParamsDev prm, double d_mono, double d_stereo, double* err, uint8_t* level,
-                      uint8_t* robust, uint8_t* inlier, double* pose_out, int32_t* n_good);
+                      uint8_t* robust, uint8_t* inlier, double* pose_out, int32_t* n_good, const int32_t* n_dev = nullptr);
+void launch_track_queries(hipStream_t s, int n, const uint8_t* d_flags, const uint8_t* d_visible, const float* d_cos, const int8_t* d_level, float th,
+                          const float* d_sigma2, int n_levels, float* d_radius, int8_t* d_min_level, int8_t* d_max_level);
+void launch_track_claim(hipStream_t s, int n, const int32_t* d_n_cand, const int32_t* d_best_idx, const int32_t* d_best_dist, const int32_t* d_second,
+                        int min_threshold, float ratio, int32_t* d_claim);
+void launch_track_edges(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, int n_features, const int32_t* d_held, const int32_t* d_claim,
+                        const uint8_t* d_mp_flags, const float* d_mp_pos, const double* d_right_u, const float* d_sigma2, const float* d_inv_sigma2,
+                        int min_matches, int32_t* d_assigned, int32_t* d_edge_of, double* d_Xw, double* d_meas, double* d_info, float* d_sig,
+                        int32_t* d_counts);
 }  // namespace orbfe
 
 using namespace orbfe;
@@ -2866,6 +2874,115 @@ orbfe_status orbfe_pose_only_optimize(orbfe_ctx* c, int32_t n, const double* xw,
   std::memcpy(pose_out, hs, 56);
   std::memcpy(n_good, hs + (o_ng - o_po), 4);
   if (inlier_out && n) std::memcpy(inlier_out, hs + (o_in - o_po), (size_t)n);
+  return ORBFE_OK;
+}
+
+// Tracking::trackLocalMap's device work as ONE call (src/Tracking.cc:641-675): isInVision / predictLevel per map point
+// (MapPoint.cc:141-201), ORBMatcher::searchByProjection(frame, map points, th) (ORBMatcher.cc:561-612) against the features of `slot`,
+// and Optimizer::OptimizePoseOnly (Optimizer.cc:33-178) on what the frame holds afterwards -- one upload, seven launches, one download;
+// the projections, the windows, the candidate lists, the assignment and the edge list never leave the device.
+orbfe_status orbfe_track_local_map(orbfe_ctx* c, int32_t slot, const orbfe_frame_pose* pose, const orbfe_camera* cam, const orbfe_track_input* in,
+                                   const orbfe_track_output* out) {
+  ApiLock api_lk(c);
+  if (!c || !pose || !cam || !in || !out || slot < 0 || slot >= c->cfg.max_images) return fail(c, ORBFE_EBADARG, "track_local_map: NULL argument / bad slot");
+  const int n = in->n_mp, nl = c->cfg.n_levels;
+  const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
+  if (n < 0 || !in->pose_se3 || !in->level_sigma2 || !in->level_inv_sigma2 || !out->assigned || !out->n_matches || !out->n_edges || !out->n_good ||
+      !out->pose_out || !out->inlier || (n && (!in->pos || !in->view_dir || !in->max_dist || !in->min_dist || !in->desc || !in->flags)))
+    return fail(c, ORBFE_EBADARG, "track_local_map: NULL array");
+  if (NF > 2048) return fail(c, ORBFE_EBADSIZE, "track_local_map: %zu features per frame (the fused pose kernel keeps up to 2048 edges in registers)", NF);
+  if (in->held)
+    for (size_t f = 0; f < NF; ++f)
+      if (in->held[f] < -1 || in->held[f] >= n) return fail(c, ORBFE_EBADARG, "track_local_map: held[%zu] = %d out of range", f, in->held[f]);
+  const float bounds[4] = {pose->min_u, pose->max_u, pose->min_v, pose->max_v};
+  AreaGrid ag;
+  if (!area_grid(c, bounds, &ag)) return fail(c, ORBFE_EBADARG, "track_local_map: bad frame bounds");
+  const size_t ncells = (size_t)ag.rows * ag.cols;
+  if ((2 * ncells + 1) * 4 > 60 * 1024) return fail(c, ORBFE_EBADSIZE, "track_local_map: %zu grid cells exceed the LDS counters", ncells);
+  HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
+  const size_t N = (size_t)std::max(n, 1);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o2 = off;
+    off += align_up(std::max<size_t>(bytes, 8), 256);
+    return o2;
+  };
+  // [ upload | claim (0x7F fill) | device-only | download ]
+  const size_t o_pos = take(N * 12), o_vd = take(N * 12), o_mx = take(N * 4), o_mn = take(N * 4), o_desc = take(N * 32), o_fl = take(N),
+               o_held = take(NF * 4), o_ru = take(NF * 8), o_s2 = take((size_t)nl * 4), o_is2 = take((size_t)nl * 4), o_p0 = take(56),
+               o_up_end = take(8), o_claim = take(NF * 4), o_claim_end = take(8), o_uv = take(N * 8), o_dist = take(N * 4), o_cos = take(N * 4),
+               o_lvl = take(N), o_vis = take(N), o_rad = take(N * 4), o_lo = take(N), o_hi = take(N), o_co = take((ncells + 1) * 4),
+               o_cf = take(NF * 4), o_bi = take(N * 4), o_bd = take(N * 4), o_sd = take(N * 4), o_nc = take(N * 4), o_xw = take(NF * 24),
+               o_ms = take(NF * 24), o_info = take(NF * 8), o_sig = take(NF * 4), o_err = take(NF * 24), o_l = take(NF), o_r = take(NF),
+               o_dn = take(0), o_cnt = take(16), o_ng = take(8), o_po = take(56), o_asg = take(NF * 4), o_eo = take(NF * 4), o_in = take(NF),
+               o_dn_end = take(8);
+  (void)o_dn;
+  TRY(ensure_tmp(c, off));
+  TRY(ensure_stage(c, std::max(o_up_end, o_dn_end - o_cnt)));
+  uint8_t* b = (uint8_t*)c->d_tmp;
+  uint8_t* hs = c->main.h_stage;
+  if (n) {
+    std::memcpy(hs + o_pos, in->pos, (size_t)n * 12);
+    std::memcpy(hs + o_vd, in->view_dir, (size_t)n * 12);
+    std::memcpy(hs + o_mx, in->max_dist, (size_t)n * 4);
+    std::memcpy(hs + o_mn, in->min_dist, (size_t)n * 4);
+    std::memcpy(hs + o_desc, in->desc, (size_t)n * 32);
+    std::memcpy(hs + o_fl, in->flags, (size_t)n);
+  }
+  if (in->held) std::memcpy(hs + o_held, in->held, NF * 4);
+  else std::memset(hs + o_held, 0xFF, NF * 4);
+  if (in->right_u) std::memcpy(hs + o_ru, in->right_u, NF * 8);
+  else
+    for (size_t f = 0; f < NF; ++f) ((double*)(hs + o_ru))[f] = -1.0;
+  std::memcpy(hs + o_s2, in->level_sigma2, (size_t)nl * 4);
+  std::memcpy(hs + o_is2, in->level_inv_sigma2, (size_t)nl * 4);
+  std::memcpy(hs + o_p0, in->pose_se3, 56);
+  hipStream_t st = c->stream;
+  HIP_TRY(c, hipMemcpyAsync(b, hs, o_up_end, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemsetAsync(b + o_claim, 0x7F, o_claim_end - o_claim, st));
+  const float cam4[4] = {cam->fx, cam->fy, cam->cx, cam->cy};
+  const BaParamsDev prm = {(double)cam->fx, (double)cam->fy, (double)cam->cx, (double)cam->cy, (double)cam->bf};
+  {
+    StageTimer tm(c, ORBFE_STAGE_MATCH, st);
+    launch_project_map_points(st, n, (const float*)(b + o_pos), (const float*)(b + o_vd), (const float*)(b + o_mx), (const float*)(b + o_mn),
+                              pose->Rcw, pose->tcw, cam4, bounds, std::log(c->cfg.scale_factor), 7, (float*)(b + o_uv), (float*)(b + o_dist),
+                              (float*)(b + o_cos), (int8_t*)(b + o_lvl), b + o_vis);
+    launch_track_queries(st, n, b + o_fl, b + o_vis, (const float*)(b + o_cos), (const int8_t*)(b + o_lvl), in->th, (const float*)(b + o_s2), nl,
+                         (float*)(b + o_rad), (int8_t*)(b + o_lo), (int8_t*)(b + o_hi));
+    launch_grid_build(st, c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, ag.rows, ag.cols, (int32_t*)(b + o_co), (int32_t*)(b + o_cf));
+    launch_search_area(st, c->d_kpl + (size_t)slot * NF, c->d_desc + (size_t)slot * NF * 32, ag.clip_w, ag.clip_h, ag.rows, ag.cols,
+                       (const int32_t*)(b + o_co), (const int32_t*)(b + o_cf), n, (const float*)(b + o_uv), (const float*)(b + o_rad),
+                       (const int8_t*)(b + o_lo), (const int8_t*)(b + o_hi), b + o_desc, nullptr, (int32_t*)(b + o_bi), (int32_t*)(b + o_bd),
+                       (int32_t*)(b + o_sd), (int32_t*)(b + o_nc), nullptr);
+    launch_track_claim(st, n, (const int32_t*)(b + o_nc), (const int32_t*)(b + o_bi), (const int32_t*)(b + o_bd), (const int32_t*)(b + o_sd),
+                       in->min_threshold, in->ratio, (int32_t*)(b + o_claim));
+    launch_track_edges(st, c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, (int)NF, (const int32_t*)(b + o_held), (const int32_t*)(b + o_claim),
+                       b + o_fl, (const float*)(b + o_pos), (const double*)(b + o_ru), (const float*)(b + o_s2), (const float*)(b + o_is2),
+                       in->min_matches, (int32_t*)(b + o_asg), (int32_t*)(b + o_eo), (double*)(b + o_xw), (double*)(b + o_ms),
+                       (double*)(b + o_info), (float*)(b + o_sig), (int32_t*)(b + o_cnt));
+  }
+  {
+    StageTimer tm(c, ORBFE_STAGE_BA, st);
+    launch_pose_only(st, (int)NF, (const double*)(b + o_xw), (const double*)(b + o_ms), (const double*)(b + o_info), (const float*)(b + o_sig),
+                     (const double*)(b + o_p0), prm, (double)(float)std::sqrt(5.991), (double)(float)std::sqrt(7.815), (double*)(b + o_err), b + o_l,
+                     b + o_r, b + o_in, (double*)(b + o_po), (int32_t*)(b + o_ng), (const int32_t*)(b + o_cnt) + 1);
+  }
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(hs, b + o_cnt, o_dn_end - o_cnt, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  drain_timers(c);
+  const int32_t* cnt = (const int32_t*)hs;
+  *out->n_matches = cnt[0];
+  *out->n_edges = cnt[1];
+  std::memcpy(out->n_good, hs + (o_ng - o_cnt), 4);
+  std::memcpy(out->pose_out, hs + (o_po - o_cnt), 56);
+  std::memcpy(out->assigned, hs + (o_asg - o_cnt), NF * 4);
+  const int32_t* eo = (const int32_t*)(hs + (o_eo - o_cnt));
+  const uint8_t* ein = hs + (o_in - o_cnt);
+  const bool optimised = cnt[1] >= 0;
+  for (size_t f = 0; f < NF; ++f) out->inlier[f] = (optimised && eo[f] >= 0) ? ein[eo[f]] : 0;
+  if (out->edge_of) std::memcpy(out->edge_of, eo, NF * 4);
   return ORBFE_OK;
 }
 

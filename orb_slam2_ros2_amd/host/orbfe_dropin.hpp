@@ -14,6 +14,8 @@
 //   orbfe::dropin::searchByProjection x2  frame <- frame (ORBMatcher.h:49, src/ORBMatcher.cc:265-347) and frame <- map points (ORBMatcher.h:52,
 //                                         :561-612)
 //   orbfe::dropin::frameRGBD              the tail of `Frame::Frame` for RGB-D input (src/Frame.cc:130-131, :139-157)
+//   orbfe::dropin::trackLocalMap          the middle of `Tracking::trackLocalMap` (src/Tracking.cc:650-658): searchByProjection(frame, local map
+//                                         points, th) + OptimizePoseOnly(frame) as ONE device call
 //
 // The three bodies are templates over the reference's Frame / KeyFrame / MapPoint / Camera types (they only use the accessors
 // the reference's own function bodies use), so this header does not have to see the reference's headers; INTEGRATION.md shows the
@@ -576,6 +578,122 @@ static void OptimizeLocalMap(KeyFramePtr pkframe, bool& isStop) {
     return nMatches;
   }
 
+  // The middle of Tracking::trackLocalMap (src/Tracking.cc:650-658) as ONE device call (orbfe_track_local_map):
+  //     nMatches = matcher.searchByProjection(mpCurrFrame, mvpLocalMps, th, matches);     (src/ORBMatcher.cc:561-612, bFuse = false)
+  //     if (nMatches < 30) return false;
+  //     Optimizer::OptimizePoseOnly(mpCurrFrame);                                          (src/Optimizer.cc:33-203)
+  // Returns nMatches; nGood = OptimizePoseOnly's return value, or -1 when nMatches < minMatches and nothing was optimised.  The frame's
+  // features are the device-resident results of its left extractor's slot (extract() of THIS frame must be among the last four of the
+  // extractor pool: ContextPool::kSlots); when the slot has been re-used the two bodies above run one after the other instead.  The
+  // map points' own methods are NOT called for the visibility test here: pos / view direction / distance range go to the device, which
+  // evaluates MapPoint::isInVision and predictLevel (MapPoint.cc:141-201) in the reference's float / double mix.
+  template <class CameraT, class FramePtr, class MapPointPtr>
+  static int trackLocalMap(FramePtr pframe, const std::vector<MapPointPtr>& mapPoints, float th, float mfRatio, int nLevels, int& nGood,
+                           int minMatches = 30) {
+    const auto& ext = pframe->mpExtractorLeft->device();
+    const size_t N = pframe->mvFeatsLeft.size();
+    if (!ext.resident() || (size_t)orbfe_get_capacity(ext.context()) > 2048) {
+      std::vector<cv::DMatch> matches;
+      const int nMatches = searchByProjection(pframe, mapPoints, th, matches, false, mfRatio, nLevels);
+      nGood = nMatches < minMatches ? -1 : OptimizePoseOnly<CameraT>(pframe);
+      return nMatches;
+    }
+    orbfe_ctx* ctx = ext.context();
+    const size_t NF = (size_t)orbfe_get_capacity(ctx);
+    using BasePtr = typename std::decay<decltype(pframe->getMapPoint(0))>::type;
+    // the arrays: the list as given (null entries dropped), then the points the frame holds that are not in it
+    std::vector<float> pos, vdir, maxD, minD;
+    std::vector<uint8_t> desc, flags;
+    std::vector<int> whoList;           // array index -> index in mapPoints (-1: an extra)
+    std::vector<BasePtr> ptrOf;         // array index -> the map point
+    std::map<const void*, int> indexOf;
+    auto push = [&](const BasePtr& base, const cv::Mat& p, const cv::Mat& v, float mx, float mn, const cv::Mat& d, uint8_t fl, int who) {
+      for (int a = 0; a < 3; ++a) pos.push_back(p.template at<float>(a)), vdir.push_back(v.empty() ? 0.f : v.template at<float>(a));
+      maxD.push_back(mx), minD.push_back(mn);
+      const size_t o = desc.size();
+      desc.resize(o + 32, 0);
+      if (!d.empty()) std::memcpy(desc.data() + o, d.data, 32);
+      flags.push_back(fl);
+      whoList.push_back(who);
+      indexOf[(const void*)base.get()] = (int)ptrOf.size();
+      ptrOf.push_back(base);
+    };
+    for (size_t i = 0; i < mapPoints.size(); ++i) {
+      const auto& pMp = mapPoints[i];
+      if (!pMp || indexOf.count((const void*)pMp.get())) continue;  // (a point listed twice is searched once: the second visit finds its feature taken)
+      const bool bad = pMp->isBad(), inMap = pMp->isInMap();
+      float mx = 0.f, mn = 0.f;
+      pMp->getDistance(mx, mn);
+      push(BasePtr(pMp), pMp->getPos(), pMp->getViewDirection(), mx, mn, pMp->getDesc(), (uint8_t)(4 | (bad ? 0 : 2) | ((!bad && inMap) ? 1 : 0)), (int)i);
+    }
+    auto frameMps = pframe->getMapPoints();
+    std::vector<int32_t> held(NF, -1);
+    for (size_t f = 0; f < N && f < NF; ++f) {
+      const auto& h = frameMps[f];
+      if (!h) continue;
+      auto it = indexOf.find((const void*)h.get());
+      if (it == indexOf.end()) {
+        const bool bad = h->isBad(), inMap = h->isInMap();
+        push(h, h->getPos(), cv::Mat(), 0.f, 0.f, cv::Mat(), (uint8_t)((bad ? 0 : 2) | ((!bad && inMap) ? 1 : 0)), -1);
+        it = indexOf.find((const void*)h.get());
+      }
+      held[f] = it->second;
+    }
+    std::vector<double> rightU(NF, -1.0);
+    for (size_t f = 0; f < N && f < NF; ++f) rightU[f] = pframe->getRightU(f);
+    std::vector<float> sig2((size_t)nLevels), invSig2((size_t)nLevels);
+    for (int l = 0; l < nLevels; ++l) sig2[(size_t)l] = pframe->getScaledFactor2(l), invSig2[(size_t)l] = pframe->getScaledFactorInv2(l);
+    orbfe_frame_pose fp{};
+    for (int r = 0; r < 3; ++r) {
+      for (int c2 = 0; c2 < 3; ++c2) fp.Rcw[3 * r + c2] = pframe->mRcw.template at<float>(r, c2);
+      fp.tcw[r] = pframe->mtcw.template at<float>(r, 0);
+    }
+    fp.min_u = pframe->mfMinU, fp.max_u = pframe->mfMaxU, fp.min_v = pframe->mfMinV, fp.max_v = pframe->mfMaxV;
+    orbfe_camera cam{};
+    cam.fx = CameraT::mfFx, cam.fy = CameraT::mfFy, cam.cx = CameraT::mfCx, cam.cy = CameraT::mfCy, cam.bf = CameraT::mfBf;
+    double pose0[7], poseOut[7];
+    matToPose(pframe->mRcw, pframe->mtcw, pose0);
+    orbfe_track_input in{};
+    in.n_mp = (int32_t)ptrOf.size();
+    in.pos = pos.data(), in.view_dir = vdir.data(), in.max_dist = maxD.data(), in.min_dist = minD.data(), in.desc = desc.data(), in.flags = flags.data();
+    in.held = held.data(), in.right_u = rightU.data(), in.level_sigma2 = sig2.data(), in.level_inv_sigma2 = invSig2.data(), in.pose_se3 = pose0;
+    in.th = th, in.ratio = mfRatio, in.min_threshold = orbfe::ORBMatcher::mnMinThreshold, in.min_matches = minMatches;
+    std::vector<int32_t> assigned(NF, -1);
+    std::vector<uint8_t> inl(NF, 0);
+    int32_t nMatches = 0, nEdges = 0, good = 0;
+    orbfe_track_output out{};
+    out.assigned = assigned.data(), out.inlier = inl.data(), out.n_matches = &nMatches, out.n_edges = &nEdges, out.n_good = &good, out.pose_out = poseOut;
+    check(ctx, orbfe_track_local_map(ctx, ext.slot(), &fp, &cam, &in, &out));
+    // searchByProjection's side effects (:595-599): the new assignments, in map-point order for the counters' sake
+    for (size_t f = 0; f < N && f < NF; ++f)
+      if (assigned[f] != held[f] && assigned[f] >= 0) {
+        pframe->setMapPoint((int)f, ptrOf[(size_t)assigned[f]]);
+        ptrOf[(size_t)assigned[f]]->addMatchInTrack();
+      }
+    if (nEdges < 0) {  // nMatches < minMatches: trackLocalMap returns false before the optimisation
+      nGood = -1;
+      return nMatches;
+    }
+    // OptimizePoseOnly's tail (:180-203): the projection post-check with the frame's pose as it still is, the counters, the pose
+    int nBad = nEdges - good;
+    for (size_t f = 0; f < N && f < NF; ++f) {
+      auto cur = pframe->getMapPoint(f);
+      bool keep = inl[f] != 0;
+      if (keep) {
+        bool isPositive = false;
+        auto uv = pframe->project2UV(cur->getPos(), isPositive);
+        if (!isPositive || uv.x > pframe->mfMaxU || uv.x < 0 || uv.y > pframe->mfMaxV || uv.y < 0) keep = false, ++nBad;
+      }
+      if (!keep)
+        pframe->mvpMapPoints[f] = nullptr;
+      else
+        pframe->mvpMapPoints[f]->addInlierInTrack();
+    }
+    pframe->setPose(poseToMat(poseOut));
+    nGood = nEdges - nBad;
+    return nMatches;
+  }
+
   // The tail of Frame::Frame (RGB-D) after extract() (src/Frame.cc:130-131, :139-157): depthImg.convertTo(CV_32F) / dScale, the copy of the
   // distorted keypoints, Camera::undistortPoints(mvFeatsLeft), the depth / rightU lookup -- as one call on the extractor's slot.  depthImg
   // as read from the file: CV_16U (TUM) or CV_32F.  initGrid() stays with the caller (the grid is rebuilt on the device per search).
@@ -618,6 +736,11 @@ int OptimizePoseOnly(FramePtr pFrame) {
 template <class CameraT, class KeyFramePtr>
 void OptimizeLocalMap(KeyFramePtr pkframe, bool& isStop) {
   Bodies::template OptimizeLocalMap<CameraT>(pkframe, isStop);
+}
+template <class CameraT, class FramePtr, class MapPointPtr>
+int trackLocalMap(FramePtr pframe, const std::vector<MapPointPtr>& mapPoints, float th, int& nGood, float mfRatio = 0.8f, int nLevels = 8,
+                  int minMatches = 30) {
+  return Bodies::template trackLocalMap<CameraT>(pframe, mapPoints, th, mfRatio, nLevels, nGood, minMatches);
 }
 template <class FramePtrF, class FramePtrK>
 int searchByBow(FramePtrF pFrame, FramePtrK pKframe, std::vector<cv::DMatch>& matches, bool bAddMPs, bool bLoop, float mfRatio = 0.6f,

@@ -9,6 +9,8 @@
 //   poseonly                                  the Frame adapter against the array-level call              -> "POSEONLY_OK ..."
 //   matchers <L.raw> <R.raw> <w> <h>          searchByBow / searchByProjection x2 with the reference's signatures against the array-level
 //                                             mirrors on the same frames and map state                   -> "MATCHERS_OK ..."
+//   trackchain <L.raw> <R.raw> <w> <h>        Tracking::trackLocalMap's middle as ONE call (dropin::trackLocalMap) against searchByProjection +
+//                                             OptimizePoseOnly one after the other on a twin frame      -> "TRACKCHAIN_OK ..."
 //   rgbd <gray.raw> <w> <h>                   the RGB-D tail of Frame::Frame against orbfe_frame_rgbd    -> "RGBD_OK ..."
 //   access                                    host-only: every matcher body instantiated on a class with PROTECTED members + the friend line
 //   latency <L.raw> <R.raw> <w> <h> <iters>   timing of Frame::Frame (two threads) + searchByStereo per pair, host to host -> "LATENCY_OK ..."
@@ -721,6 +723,170 @@ static int mode_poseonly() {
   return (pose_diff == 0 && kept == good && inlier_marks == kept && good <= good_arrays && good > 250 && err < 0.02) ? 0 : 1;
 }
 
+// A map point with real geometry: MapPoint::isInVision / predictLevel (src/MapPoint.cc:141-201) in the float / double mix of the
+// reference's cv::Mat expressions (the recipe csrc/k_guided.hip documents), getViewDirection / getDistance as MapPoint.h:104-147.
+struct GeoMapPoint : ref::MapPoint {
+  typedef std::shared_ptr<GeoMapPoint> SharedPtr;
+  cv::Mat mView;
+  float mMax = 0.f, mMin = 0.f;
+  explicit GeoMapPoint(ref::MapPoint::Cmp c) : ref::MapPoint(c) {}
+  cv::Mat getViewDirection() const { return mView.clone(); }
+  void getDistance(float& mx, float& mn) const { mx = mMax, mn = mMin; }
+  template <class FramePtr>
+  bool isInVision(FramePtr f, float& dist, cv::Point2f& uv, float& cosTheta) {
+    float R[9], t[3], X[3], D[3], pc[3];
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) R[3 * r + c] = f->mRcw.template at<float>(r, c);
+      t[r] = f->mtcw.template at<float>(r, 0), X[r] = mPos.at<float>(r), D[r] = mView.at<float>(r);
+    }
+    for (int r = 0; r < 3; ++r) {
+      const float s = R[3 * r] * X[0] + R[3 * r + 1] * X[1] + R[3 * r + 2] * X[2];
+      pc[r] = (float)((double)s + (double)t[r]);
+    }
+    if (pc[2] < 0.f) return false;
+    const float x = pc[0], y = pc[1], z = pc[2];
+    const float distance = std::sqrt(x * x + y * y + z * z);
+    dist = distance;
+    if (!(distance < mMax && distance > mMin)) return false;
+    const float u = x / z * ref::Camera::mfFx + ref::Camera::mfCx, v = y / z * ref::Camera::mfFy + ref::Camera::mfCy;
+    uv.x = u, uv.y = v;
+    if (!(u < f->mfMaxU && v < f->mfMaxV && u > f->mfMinU && v > f->mfMinV)) return false;
+    float vd[3];
+    for (int r = 0; r < 3; ++r) vd[r] = R[3 * r] * D[0] + R[3 * r + 1] * D[1] + R[3 * r + 2] * D[2];
+    const double nn = (double)vd[0] * (double)vd[0] + (double)vd[1] * (double)vd[1] + (double)vd[2] * (double)vd[2];
+    const float vabs = (float)std::sqrt(nn);
+    const double dot = (double)vd[0] * (double)pc[0] + (double)vd[1] * (double)pc[1] + (double)vd[2] * (double)pc[2];
+    cosTheta = (float)(dot / (double)(distance * vabs));
+    return !(cosTheta < 0.5f);
+  }
+  int predictLevel(float distance) const {
+    const float lr = (float)std::log((double)(mMax / distance));
+    int level = (int)std::lrintf(lr / std::log(1.2f));
+    return level < 0 ? 0 : (level > 7 ? 7 : level);
+  }
+};
+
+static int mode_trackchain(int argc, char** argv) {
+  if (argc < 6) return 2;
+  const int w = atoi(argv[4]), h = atoi(argv[5]);
+  std::vector<uint8_t> L, R;
+  if (!read_file(argv[2], L) || !read_file(argv[3], R) || L.size() != (size_t)w * h || R.size() != L.size()) return 2;
+  cv::Mat ml(h, w, CV_8UC1, L.data()), mr(h, w, CV_8UC1, R.data());
+  ref::MapPoint::Cmp cmp = [](std::weak_ptr<ref::KeyFrame>, std::weak_ptr<ref::KeyFrame>) { return false; };
+  // twin frames of the same images: A runs the two reference-shaped bodies one after the other, B the fused call
+  auto FA = std::make_shared<ref::Frame>(ml, mr, true);
+  auto FB = std::make_shared<ref::Frame>(ml, mr, true);
+  ref::VirtualFrame::mvfScaledFactors = ORB_SLAM2_ROS2::ORBExtractor::getScaledFactors();
+  const size_t n = FA->mvFeatsLeft.size();
+  if (FB->mvFeatsLeft.size() != n) return 1;
+  for (auto& f : {FA, FB}) {
+    orbfe::dropin::searchByStereo<ref::Camera>(f);
+    f->mfMinU = 0, f->mfMinV = 0, f->mfMaxU = (float)w, f->mfMaxV = (float)h;
+    cv::Mat T(4, 4, CV_32F);
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) T.at<float>(r, c) = r == c ? 1.f : 0.f;
+    T.at<float>(0, 3) = 0.04f, T.at<float>(1, 3) = -0.02f, T.at<float>(2, 3) = 0.05f;  // the estimate: a few centimetres off the truth (identity)
+    f->setPose(T);
+  }
+  uint64_t s = 777;
+  auto rnd = [&]() {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    return (double)(s >> 11) / 9007199254740992.0;
+  };
+  // the local map: most keypoints back-projected at their stereo depth (true pose = identity), descriptors a few bits off; some points
+  // that project nowhere near a feature; bad / not-in-map points; a fifth of the features hold a point from an earlier stage
+  std::vector<GeoMapPoint::SharedPtr> listA, listB;
+  auto add = [&](const float* X, const cv::Mat& desc, bool bad, bool inMap) {
+    for (auto* lst : {&listA, &listB}) {
+      auto p = std::make_shared<GeoMapPoint>(cmp);
+      p->mId = lst->size();
+      p->mPos = cv::Mat(3, 1, CV_32F), p->mView = cv::Mat(3, 1, CV_32F);
+      float nrm = std::sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
+      for (int a = 0; a < 3; ++a) p->mPos.at<float>(a) = X[a], p->mView.at<float>(a) = X[a] / nrm;
+      p->mMax = nrm * 1.8f, p->mMin = nrm * 0.6f;
+      p->mDesc = desc.clone();
+      p->mbBad = bad, p->mbInMap = inMap;
+      lst->push_back(p);
+    }
+  };
+  for (size_t i = 0; i < n; ++i) {
+    if (i % 5 == 4) continue;
+    const auto& kp = FA->mvFeatsLeft[i];
+    const double d = FA->mvDepths[i] > 0 ? FA->mvDepths[i] : 6.0 + 20.0 * rnd();
+    const float X[3] = {(float)((kp.pt.x - ref::Camera::mfCx) / ref::Camera::mfFx * d), (float)((kp.pt.y - ref::Camera::mfCy) / ref::Camera::mfFy * d), (float)d};
+    cv::Mat desc = FA->mvLeftDescriptor[i].clone();
+    for (int k = 0; k < 5; ++k) {
+      const int bit = (int)(rnd() * 256) % 256;
+      desc.data[bit / 8] ^= (uint8_t)(1u << (bit % 8));
+    }
+    add(X, desc, i % 61 == 7, i % 47 != 9);
+  }
+  for (int i = 0; i < 200; ++i) {
+    const float X[3] = {(float)(-15 + 30 * rnd()), (float)(-4 + 8 * rnd()), (float)(3 + 30 * rnd())};
+    cv::Mat desc(1, 32, CV_8U);
+    for (int k = 0; k < 32; ++k) desc.data[k] = (uint8_t)(rnd() * 256);
+    add(X, desc, false, true);
+  }
+  listA.insert(listA.begin() + 10, nullptr), listB.insert(listB.begin() + 10, nullptr);  // the reference's lists hold null entries
+  for (size_t i = 0; i < n; ++i)
+    if (i % 5 == 1) {
+      const size_t j = (size_t)(rnd() * listA.size()) % listA.size();
+      if (i % 25 == 1) {  // ... held by the frame but not in the local map
+        const float X[3] = {1.f, 0.5f, 9.f};
+        for (auto& pr : {std::make_pair(FA, 0), std::make_pair(FB, 1)}) {
+          auto p = std::make_shared<GeoMapPoint>(cmp);
+          p->mPos = cv::Mat(3, 1, CV_32F);
+          for (int a = 0; a < 3; ++a) p->mPos.at<float>(a) = X[a] + (float)i * 0.001f;
+          p->mbBad = i % 50 == 1;
+          pr.first->mvpMapPoints[i] = p;
+        }
+      } else if (listA[j]) {
+        FA->mvpMapPoints[i] = listA[j], FB->mvpMapPoints[i] = listB[j];
+      }
+    }
+  // A: the two bodies
+  std::vector<cv::DMatch> matches;
+  const int nA = orbfe::dropin::searchByProjection(FA, listA, 3.f, matches, false, 0.8f, 8);
+  const int goodA = nA < 30 ? -1 : orbfe::dropin::OptimizePoseOnly<ref::Camera>(FA);
+  // B: one call
+  int goodB = -2;
+  const int nB = orbfe::dropin::trackLocalMap<ref::Camera>(FB, listB, 3.f, goodB);
+  int fails = 0, kept = 0;
+  auto expect = [&](bool ok, const char* what) {
+    if (!ok) fprintf(stderr, "trackchain: %s\n", what), ++fails;
+  };
+  expect(nA == nB, "searchByProjection's count differs");
+  expect(std::abs(goodA - goodB) <= 1, "OptimizePoseOnly's return value differs");
+  // the same features keep a map point, and it is the twin of A's (position in the list, or the same extra by position)
+  int assign_diff = 0;
+  for (size_t i = 0; i < n; ++i) {
+    auto a = FA->mvpMapPoints[i], b = FB->mvpMapPoints[i];
+    if ((a == nullptr) != (b == nullptr)) {
+      ++assign_diff;
+      continue;
+    }
+    if (!a) continue;
+    ++kept;
+    const auto ia = std::find(listA.begin(), listA.end(), a), ib = std::find(listB.begin(), listB.end(), b);
+    if ((ia == listA.end()) != (ib == listB.end()) || (ia != listA.end() && ia - listA.begin() != ib - listB.begin())) ++assign_diff;
+  }
+  expect(assign_diff <= 1, "the frames' map points differ");  // (an edge exactly on a chi2 threshold may flip between the two kernel shapes)
+  double pose_diff = 0;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) pose_diff = std::max(pose_diff, (double)std::fabs(FA->mRcw.at<float>(r, c) - FB->mRcw.at<float>(r, c)));
+    pose_diff = std::max(pose_diff, (double)std::fabs(FA->mtcw.at<float>(r, 0) - FB->mtcw.at<float>(r, 0)));
+  }
+  expect(pose_diff < 1e-5, "the optimised poses differ");
+  const double err = std::fabs(FB->mtcw.at<float>(0, 0)) + std::fabs(FB->mtcw.at<float>(1, 0)) + std::fabs(FB->mtcw.at<float>(2, 0));
+  expect(err < 0.02, "the pose did not converge to the truth");
+  int cnt_diff = 0;
+  for (size_t i = 0; i < listA.size(); ++i)
+    if (listA[i]) cnt_diff += listA[i]->nMatchInTrack != listB[i]->nMatchInTrack || std::abs(listA[i]->nInlier - listB[i]->nInlier) > (assign_diff ? 1 : 0);
+  expect(cnt_diff <= 2 * assign_diff, "addMatchInTrack / addInlierInTrack counts differ");
+  printf("TRACKCHAIN_OK %zu %d %d %d %d %d %.2e %.4f\n", n, nA, goodA, goodB, kept, assign_diff, pose_diff, err);
+  return (fails == 0 && nA > 800 && goodA > 300) ? 0 : 1;
+}
+
 // host-only: the write-back policy of Optimizer.cc:391-404 at EXACTLY 30 % -- `size / (float)nGoodMp > 0.3` compares a float quotient with
 // a double literal: 3 / 10 = 0.3f widens to 0.30000001192..., which IS greater than 0.3, so the keyframe counts as bad
 static int mode_policy() {
@@ -763,6 +929,7 @@ int main(int argc, char** argv) {
     if (mode == "latency") return mode_latency(argc, argv);
     if (mode == "matchers") return mode_matchers(argc, argv);
     if (mode == "rgbd") return mode_rgbd(argc, argv);
+    if (mode == "trackchain") return mode_trackchain(argc, argv);
     if (mode == "access") return mode_access();
     if (mode == "localba") return mode_localba(argc, argv);
     if (mode == "poseonly") return mode_poseonly();

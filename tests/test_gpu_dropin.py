@@ -75,6 +75,20 @@ def test_matcher_adapters_with_the_reference_signatures_equal_the_array_level_mi
     assert tag == "MATCHERS_OK" and int(n1) > 1500 and int(n2) > 1500 and int(total) > 100
 
 
+def test_fused_tracking_chain_adapter_equals_the_two_bodies(exe, tmp_path):
+    """dropin::trackLocalMap -- Tracking::trackLocalMap's searchByProjection(frame, local map points, th) + OptimizePoseOnly(frame)
+    (src/Tracking.cc:650-658) as ONE device call -- against the two reference-signature bodies run one after the other on a twin frame
+    with twin map points: match count, assignments, counters, the optimised pose (the array-level call is held to the oracle's three-step
+    chain in tests/test_track_chain.py)."""
+    L, R = synth.stereo_pair(4)
+    L.tofile(tmp_path / "L.raw")
+    R.tofile(tmp_path / "R.raw")
+    out = subprocess.run([exe, "trackchain", str(tmp_path / "L.raw"), str(tmp_path / "R.raw"), "1241", "376"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    f = out.stdout.split()
+    assert f[0] == "TRACKCHAIN_OK" and int(f[2]) > 800 and abs(int(f[3]) - int(f[4])) <= 1 and float(f[7]) < 1e-5
+
+
 def test_rgbd_frame_tail_adapter_equals_the_array_level_call(exe, tmp_path):
     """Frame::Frame for RGB-D input (src/Frame.cc:125-159) after extract(): undistortion + depth / rightU lookup through the adapter against
     orbfe_frame_rgbd on the same slot (which tests/test_frame_glue.py holds to the oracle)."""
