@@ -16,6 +16,7 @@
 
 #include "orb_math.h"
 #include "orbfe_internal.h"
+#include "rowtable_body.h"
 #include "wave_ops.h"
 
 namespace orbfe {
@@ -336,9 +337,18 @@ __global__ __launch_bounds__(256) void k_list_moments_orient(const LevelDev* __r
 #ifndef BRIEF_KPW
 #define BRIEF_KPW 2  // consecutive keypoints per wave (measured: 2 and 3 equal, 4 and 8 slower -- fewer, longer waves balance worse)
 #endif
+struct BriefRowTable {  // rowoff == nullptr: descriptor blocks only
+  const KpAux* aux;      // of the launch's first image
+  const int32_t* n_kp;   // of the launch's first image
+  uint32_t* rowoff;      // per-slot tables of the context (orbfe_api.hip: spec tables)
+  uint16_t* rowlist;
+  int32_t* n_match;      // per pair
+  int rows, list_cap, slot0, n_brief_blocks;
+};
 __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_brief(const uint8_t* __restrict__ blur, size_t img_pitch,
                                               const uint4* __restrict__ kpl, int n_features, const int8_t* __restrict__ pattern,
-                                              const double2* __restrict__ sincos, uint8_t* __restrict__ desc, uint8_t* __restrict__ desc_host) {
+                                              const double2* __restrict__ sincos, uint8_t* __restrict__ desc, uint8_t* __restrict__ desc_host,
+                                              BriefRowTable rt) {
 #pragma clang fp contract(off)
   // per wave (the waves never synchronise): the window, and v cos / v sin for every template coordinate v in [-18, 18] as two
   // arrays of doubles.  The kernel is bound by LDS cycles, most of them the table look-ups: as 16-byte (cos, sin) entries read by
@@ -355,6 +365,20 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_e
                     (sizeof(double) * 40 * BRIEF_WAVES + sizeof(uint32_t) * (BRIEF_ROWS * BRIEF_WORDS + 1) * BRIEF_WAVES) % 512 != 0,
                 "rc[w] and rs[w] must not be reachable by one ds_read2(st64)_b64");
   __shared__ Lds lds;
+  if (rt.rowoff && (int)blockIdx.x >= rt.n_brief_blocks) {
+    // A frame or two: the LAST eight workgroups of a row are not descriptor blocks; the first of them builds the row table of the image
+    // (ORBMatcher::createRowIndexDB, ORBMatcher.cc:915-932: it needs the row bands k_orient left, nothing of this kernel) into the
+    // slot's own table and zeroes the match counter of the slot's pair, so that an orbfe_stereo_match that follows launches k_stereo
+    // alone -- 14 us of table building run beside the descriptors instead of in front of the match
+    if ((int)blockIdx.x != rt.n_brief_blocks) return;
+    static_assert(sizeof(Lds) >= 9000, "the table's row counters borrow the descriptor kernel's LDS (launch_orient_brief checks the row count against 9000 bytes)");
+    uint32_t* cnt = (uint32_t*)&lds;
+    const int slot = rt.slot0 + (int)blockIdx.y;
+    if (threadIdx.x == 0) rt.n_match[slot >> 1] = 0;
+    rowtable_build(rt.aux + (size_t)blockIdx.y * n_features, min(rt.n_kp[blockIdx.y], n_features), rt.rows, rt.list_cap,
+                   rt.rowoff + (size_t)slot * (rt.rows + 1), rt.rowlist + (size_t)slot * rt.list_cap, cnt, cnt + rt.rows, (int)threadIdx.x);
+    return;
+  }
   const int lane = threadIdx.x & 63;
   uint32_t* win = lds.win[threadIdx.x >> 6];
   double* rc = lds.rc[threadIdx.x >> 6];
@@ -362,7 +386,7 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_e
   // XCD-aware block order: workgroups go round-robin to the 8 XCDs (own L2 each) and consecutive keypoints are spatial neighbours
   // (candidate order) whose 37x37 windows overlap; block b of the grid takes keypoint block (b % 8) * (grid / 8) + b / 8, so one XCD
   // works through one contiguous eighth of the list (gridDim.x is a multiple of 8).  Fetched bytes 2.69 -> 0.85 GB per 1024 images.
-  const int per_xcd = (int)gridDim.x >> 3;
+  const int per_xcd = (rt.rowoff ? rt.n_brief_blocks : (int)gridDim.x) >> 3;
   const int kb = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
   const int k0 = (kb * BRIEF_WAVES + (threadIdx.x >> 6)) * BRIEF_KPW;
   const int img = blockIdx.y;
@@ -490,7 +514,9 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
                          int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx,
                          uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief, hipEvent_t before_lists, orbfe_keypoint* h_kps,
-                         uint8_t* h_desc, int32_t* h_n_kp, bool fuse_small) {
+                         uint8_t* h_desc, int32_t* h_n_kp, bool fuse_small, uint32_t* d_rowoff_slot, uint16_t* d_rowlist_slot, int32_t* d_n_match,
+                         int rt_rows, int rt_list_cap, int rt_slot0) {
+  // d_rowoff_slot != nullptr (a frame or two): the launch of the descriptors also builds the row table of every image into the slot's table
   if (n_img <= 0 || n_features <= 0) return;
   UmaxPacked u = 0;
   for (int i = 0; i < 16; ++i) u |= (unsigned long long)(umax[i] & 15) << (4 * i);
@@ -499,8 +525,12 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
     hipLaunchKernelGGL(k_list_moments_orient<true>, dim3((n_features + 15) / 16, n_img), dim3(256), 0, s, d_lv, n_levels, d_sel, d_sel_count, n_features,
                        d_pyr, img_pitch, u, d_kpl, d_moments, d_sincos, d_kps, d_aux, d_kx, d_theta, rows0, d_n_kp, h_kps, h_n_kp);
     if (before_brief) (void)hipStreamWaitEvent(s, before_brief, 0);
-    hipLaunchKernelGGL(k_brief, dim3((((n_features + BRIEF_WAVES * BRIEF_KPW - 1) / (BRIEF_WAVES * BRIEF_KPW)) + 7) & ~7, n_img), dim3(64 * BRIEF_WAVES), 0, s,
-                       d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos, d_desc, h_desc);
+    const int nb = (((n_features + BRIEF_WAVES * BRIEF_KPW - 1) / (BRIEF_WAVES * BRIEF_KPW)) + 7) & ~7;
+    BriefRowTable rt{};
+    if (d_rowoff_slot && (size_t)(rt_rows + 4) * 4 <= 9000)
+      rt = BriefRowTable{d_aux, d_n_kp, d_rowoff_slot, d_rowlist_slot, d_n_match, rt_rows, rt_list_cap, rt_slot0, nb};
+    hipLaunchKernelGGL(k_brief, dim3(nb + (rt.rowoff ? 8 : 0), n_img), dim3(64 * BRIEF_WAVES), 0, s, d_blur, img_pitch, d_kpl, n_features, d_pattern,
+                       d_sincos, d_desc, h_desc, rt);
     return;
   }
   // (measured and dropped: two or three groups of four keypoints per wave in k_ic_moments, all their loads in flight together -- the stage
@@ -519,7 +549,7 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                      d_kps, d_aux, d_kx, d_theta, rows0, d_sel_count, n_levels, d_n_kp, h_kps, h_n_kp);
   if (before_brief) (void)hipStreamWaitEvent(s, before_brief, 0);  // the blurred planes come from another stream
   hipLaunchKernelGGL(k_brief, dim3((((n_features + BRIEF_WAVES * BRIEF_KPW - 1) / (BRIEF_WAVES * BRIEF_KPW)) + 7) & ~7, n_img), dim3(64 * BRIEF_WAVES), 0, s,
-                     d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos, d_desc, h_desc);
+                     d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos, d_desc, h_desc, BriefRowTable{});
 }
 
 }  // namespace orbfe

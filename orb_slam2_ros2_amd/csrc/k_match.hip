@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "orbfe_internal.h"
+#include "rowtable_body.h"
 #include "wave_ops.h"
 
 namespace orbfe {
@@ -123,43 +124,7 @@ __global__ __launch_bounds__(256) void k_rowtable(const KpAux* __restrict__ aux,
   uint32_t* RO = rowoff + (size_t)pair * (rows + 1);
   uint16_t* RL = rowlist + (size_t)pair * list_cap;
   const int nr = min(n_kp[slot], n_features);
-  for (int y = tid; y < rows; y += 256) cnt[y] = 0;
-  __syncthreads();
-  for (int i = tid; i < nr; i += 256) {
-    const KpAux a = A[i];
-    for (int y = a.row_min; y < a.row_max; ++y) atomicAdd(&cnt[y], 1u);  // (k_orient clips the band to [0, rows])
-  }
-  __syncthreads();
-  // exclusive prefix sum over the rows: a run of rows per thread, the 256 run totals scanned in LDS
-  const int per = (rows + 255) >> 8;
-  const int y0 = tid * per, y1 = min(y0 + per, rows);
-  uint32_t sum = 0;
-  for (int y = y0; y < y1; ++y) sum += cnt[y];
-  // inclusive scan of the 256 run totals: DPP scan inside each wave, the four wave totals through LDS (two barriers, not sixteen)
-  const uint32_t incl_w = (uint32_t)wave_incl_scan_dpp<OpAddI>((int)sum);
-  if ((tid & 63) == 63) part[tid >> 6] = incl_w;
-  __syncthreads();
-  uint32_t wave_base = 0;
-  for (int k = 0; k < (tid >> 6); ++k) wave_base += part[k];
-  const uint32_t incl = wave_base + incl_w;
-  const uint32_t total_all = part[0] + part[1] + part[2] + part[3];
-  __syncthreads();
-  uint32_t run = incl - sum;
-  for (int y = y0; y < y1; ++y) {
-    const uint32_t c = cnt[y];
-    cnt[y] = run;  // from here on: the row's write cursor
-    RO[y] = run;
-    run += c;
-  }
-  if (tid == 255) RO[rows] = total_all;
-  __syncthreads();
-  for (int i = tid; i < nr; i += 256) {
-    const KpAux a = A[i];
-    for (int y = a.row_min; y < a.row_max; ++y) {
-      const uint32_t p = atomicAdd(&cnt[y], 1u);
-      if (p < (uint32_t)list_cap) RL[p] = (uint16_t)i;  // (list_cap = n_features x the widest band: always true)
-    }
-  }
+  rowtable_build(A, nr, rows, list_cap, RO, RL, cnt, part, tid);
 }
 
 // results of ONE pair delivered to page-locked host memory by the kernel itself (all nullable; index = left keypoint): the single-pair
@@ -176,7 +141,8 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
                                                 int n_features, float fx, float bf, int cols0, int mean_threshold,
                                                 double* __restrict__ right_u, double* __restrict__ depth, int32_t* __restrict__ n_match,
                                                 int32_t* __restrict__ best_right, int32_t* __restrict__ best_dist, int slot_l0,
-                                                int slot_r0, int slot_step, int pair0, StereoHost host) {
+                                                int slot_r0, int slot_step, int pair0, StereoHost host, int table_of_slot) {
+  // table_of_slot: the row tables are indexed by the RIGHT slot (built at extraction: k_brief), not by the pair
 #pragma clang fp contract(off)
   __shared__ uint32_t s_sad[4][11 * 4 + 11 * 7 + 7];  // per wave: left 11 rows x 4 words, right 11 rows x 7 words
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -190,8 +156,9 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
   const uint8_t* LD = desc + (size_t)sl * n_features * 32;
   const uint8_t* RD = desc + (size_t)sr * n_features * 32;
   const float* RX = kx + (size_t)sr * n_features;
-  const uint32_t* RO = rowoff + (size_t)pair * (rows + 1);
-  const uint16_t* RL = rowlist + (size_t)pair * list_cap;
+  const size_t tab = table_of_slot ? (size_t)sr : (size_t)pair;
+  const uint32_t* RO = rowoff + tab * (rows + 1);
+  const uint16_t* RL = rowlist + tab * list_cap;
   // first round trip: the count, the left keypoint, its descriptor and -- lane = level -- the three per-level constants the SAD
   // stage will want for the two octaves it does not know yet
   // (slot li always exists in the buffers; whether it holds a keypoint is decided after the loads are in flight)
@@ -347,16 +314,19 @@ void launch_stereo(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint
                    const uint8_t* d_desc, const KpAux* d_aux, const float* d_kx, uint32_t* d_rowoff, uint16_t* d_rowlist, int rows, int list_cap,
                    const int32_t* d_n_kp, int n_features, float fx, float bf, int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
                    int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs, double* h_right_u, double* h_depth,
-                   int32_t* h_best_right, int32_t* h_best_dist) {
+                   int32_t* h_best_right, int32_t* h_best_dist, bool table_ready) {
   // h_*: page-locked host arrays [n_features] for the results of ONE pair (n_pairs == 1), or null
+  // table_ready: d_rowoff / d_rowlist are the per-SLOT tables the extraction of the right image left behind (k_brief) and the match
+  // counter is zero: no table launch
   if (n_pairs <= 0 || n_features <= 0) return;
   StereoHost host = {nullptr, nullptr, nullptr, nullptr};
   if (n_pairs == 1) host = {h_right_u, h_depth, h_best_right, h_best_dist};
+  if (!table_ready)
   hipLaunchKernelGGL(k_rowtable, dim3(n_pairs), dim3(256), (size_t)(rows + 256) * sizeof(uint32_t), s, d_aux, d_n_kp, n_features, rows, list_cap,
                      d_rowoff, d_rowlist, slot_r0, slot_step, pair0, d_n_match);
   hipLaunchKernelGGL(k_stereo, dim3((n_features + 3) / 4, n_pairs), dim3(256), 0, s, d_lv, n_levels, d_pyr, img_pitch, d_kps, d_desc,
                      d_kx, d_rowoff, d_rowlist, rows, list_cap, d_n_kp, n_features, fx, bf, cols0, mean_threshold, d_right_u, d_depth, d_n_match, d_best_right,
-                     d_best_dist, slot_l0, slot_r0, slot_step, pair0, host);
+                     d_best_dist, slot_l0, slot_r0, slot_step, pair0, host, table_ready ? 1 : 0);
 }
 
 }  // namespace orbfe

@@ -29,6 +29,7 @@
 
 #include "orbfe_internal.h"
 #include "wave_ops.h"
+#include "blur_body.h"
 
 #include <cmath>
 #include <vector>
@@ -1253,8 +1254,23 @@ __device__ __forceinline__ void quadtree_levels(const LevelDev* __restrict__ lv,
 // One wave per tree (batches): compiled for FOUR waves per SIMD (128 VGPRs) -- with 16-byte nodes sixteen trees fit a CU's LDS, and the
 // launch deals an image's levels to as many waves as make sixteen per CU, so that a SIMD has four dependent chains to interleave.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_quadtree(QT_KERNEL_ARGS) { quadtree_levels<1>(QT_KERNEL_PASS); }
-// Four waves per tree (a frame or two on an otherwise empty chip): registers are free
-__global__ __launch_bounds__(256) void k_quadtree_w4(QT_KERNEL_ARGS) { quadtree_levels<4>(QT_KERNEL_PASS); }
+// Four waves per tree (a frame or two on an otherwise empty chip): registers are free.  The launch also carries the BLUR of the
+// frame(s) as extra workgroups (blockIdx.x >= n_groups: one blur tile each, blur.n_tiles of them): only the descriptors read the blurred
+// planes, so a pair's 15 us of blur run beside its 60 us of trees instead of as a launch of its own in front of FAST.
+struct QtBlur {
+  const uint8_t* pyr;  // nullptr: no blur tiles in this launch
+  uint8_t* blur;
+  size_t img_pitch;
+  BlurTaps taps;
+  int n_groups;
+};
+__global__ __launch_bounds__(256) void k_quadtree_w4(QT_KERNEL_ARGS, QtBlur bl) {
+  if (bl.pyr && (int)blockIdx.x >= bl.n_groups) {
+    blur_tile(lv, n_levels, bl.pyr, bl.blur, bl.img_pitch, bl.taps, (int)blockIdx.x - bl.n_groups, (int)blockIdx.y, (int)threadIdx.x);
+    return;
+  }
+  quadtree_levels<4>(QT_KERNEL_PASS);
+}
 
 // The pre-partition's coordinate -> code tables of one level (tree_body): x table [tab_w2] then y table [tab_h], uint16 codes as
 // described at pp_axis_code.  Host side, once per context; returns false when the level's geometry rules the pre-partition out.
@@ -1307,12 +1323,19 @@ hipError_t quadtree_configure(size_t lds_bytes) {
 void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint32_t* d_cand, uint32_t* d_scr_b, uint32_t* d_scr_c,
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
                      int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree, uint8_t* d_big, size_t big_pitch,
-                     const uint16_t* d_qt_tabs) {
+                     const uint16_t* d_qt_tabs, const uint8_t* blur_pyr, uint8_t* blur_out, size_t img_pitch, const int* blur_taps, int blur_tiles) {
+  // blur_pyr != nullptr (four-wave launches only): the blur of the same images rides in this launch, blur_tiles workgroups per image
   if (n_img <= 0) return;
   const size_t lds = quadtree_lds_bytes(node_cap, rec_cap, sort_cap);
+  QtBlur bl{};
+  bl.n_groups = n_groups;
+  if (waves_per_tree >= 4 && blur_pyr && blur_tiles > 0) {
+    bl.pyr = blur_pyr, bl.blur = blur_out, bl.img_pitch = img_pitch;
+    for (int i = 0; i < 7; ++i) bl.taps.t[i] = blur_taps[i];
+  }
   if (waves_per_tree >= 4)
-    hipLaunchKernelGGL(k_quadtree_w4, dim3(n_groups, n_img), dim3(256), lds + 2048 + 16 + QT_PP_MAX_STRIPS * QT_PP_TOTALS4 * sizeof(uint16_t), s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
-                       d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch, d_qt_tabs);
+    hipLaunchKernelGGL(k_quadtree_w4, dim3(n_groups + (bl.pyr ? blur_tiles : 0), n_img), dim3(256), lds + 2048 + 16 + QT_PP_MAX_STRIPS * QT_PP_TOTALS4 * sizeof(uint16_t), s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
+                       d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch, d_qt_tabs, bl);
   else
     hipLaunchKernelGGL(k_quadtree, dim3(n_groups, n_img), dim3(64), lds, s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
                        d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch, d_qt_tabs);

@@ -42,7 +42,7 @@ hipError_t quadtree_configure(size_t lds_bytes);
 void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint32_t* d_cand, uint32_t* d_scr_b, uint32_t* d_scr_c,
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
                      int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree, uint8_t* d_big, size_t big_pitch,
-                     const uint16_t* d_qt_tabs);
+                     const uint16_t* d_qt_tabs, const uint8_t* blur_pyr, uint8_t* blur_out, size_t img_pitch, const int* blur_taps, int blur_tiles);
 bool quadtree_build_tables(const LevelDev& L, std::vector<uint16_t>& out);
 // k_brief.hip
 void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,
@@ -50,7 +50,8 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
                          int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx,
                          uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief, hipEvent_t before_lists, orbfe_keypoint* h_kps, uint8_t* h_desc, int32_t* h_n_kp,
-                         bool fuse_small);
+                         bool fuse_small, uint32_t* d_rowoff_slot = nullptr, uint16_t* d_rowlist_slot = nullptr,
+                         int32_t* d_n_match = nullptr, int rt_rows = 0, int rt_list_cap = 0, int rt_slot0 = 0);
 // k_match.hip
 void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, const uint32_t* d_off,
                              const uint32_t* d_cand, int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second);
@@ -58,7 +59,7 @@ void launch_stereo(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint
                    const uint8_t* d_desc, const KpAux* d_aux, const float* d_kx, uint32_t* d_rowoff, uint16_t* d_rowlist, int rows, int list_cap,
                    const int32_t* d_n_kp, int n_features, float fx, float bf, int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
                    int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs, double* h_right_u, double* h_depth,
-                   int32_t* h_best_right, int32_t* h_best_dist);
+                   int32_t* h_best_right, int32_t* h_best_dist, bool table_ready = false);
 // k_glue.hip
 void launch_cvt_gray(hipStream_t s, const uint8_t* d_src, size_t src_stride, uint8_t* d_dst, int dst_stride, int w, int h, int order,
                      int variant);
@@ -251,6 +252,12 @@ struct orbfe_ctx {
   uint32_t* d_rowoff = nullptr;  // per pair: offsets[height + 1] of the right image's row table (createRowIndexDB)
   uint16_t* d_rowlist = nullptr; // per pair: the table's entries, row_list_cap = n_features x the widest band
   int row_list_cap = 0;
+  // Contexts of a few slots (the one-frame-at-a-time call shapes): per-SLOT row tables, built by the descriptor launch of every
+  // extraction of one or two images, so that orbfe_stereo_match launches k_stereo alone.  slot_table_ok[s]: slot s's table belongs to
+  // its current features; pair_count_zero[p]: the match counter of pair p has not been counted into since an extraction zeroed it.
+  uint32_t* d_rowoff_slot = nullptr;
+  uint16_t* d_rowlist_slot = nullptr;
+  std::unique_ptr<std::atomic<uint8_t>[]> slot_table_ok, pair_count_zero;
   double *d_right_u = nullptr, *d_depth = nullptr;
   int32_t *d_n_match = nullptr, *d_best_right = nullptr, *d_best_dist = nullptr;
   // generic staging for match / BA calls
@@ -862,6 +869,14 @@ struct ExtLevel0 {
   uint32_t bytes;               // size of one image
   hipEvent_t inputs_free;       // nullable: recorded once the resize (which also writes level 0 of the pyramid) is done with the caller's images
 };
+// slots [s0, s0 + n) have just been (or are about to be) rewritten by an extraction; small: one that also built their row tables
+static void note_slots_written(orbfe_ctx* c, int s0, int n, bool small) {
+  if (!c->slot_table_ok) return;
+  for (int s = s0; s < s0 + n && s < c->cfg.max_images; ++s) {
+    c->slot_table_ok[(size_t)s] = small ? 1 : 0;
+    if (small) c->pair_count_zero[(size_t)(s >> 1)] = 1;
+  }
+}
 static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, hipEvent_t before_lists = nullptr,
                                 bool timing = true, const ExtLevel0* ext = nullptr, const HostMirror* mirror = nullptr) {
   // timing = false: a slot lane (orbfe_extract_slot) -- several of them run at once, so nothing shared by the context is touched:
@@ -871,6 +886,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   const int nl = c->cfg.n_levels;
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
   const size_t i0 = (size_t)img0;
+  note_slots_written(c, img0, n_img, n_img <= 2);
   uint8_t* pyr = c->d_pyr + i0 * c->img_pitch;
   uint8_t* blur = c->d_blur + i0 * c->img_pitch;
   int32_t* n_cand = c->d_n_cand + i0 * nl;
@@ -919,7 +935,12 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
   // context, the blur stays in line.  (Measured and dropped: starting each level's quadtree under FAST of the smaller levels on
   // a third stream -- the tree waves then share their SIMDs with a VALU-saturating kernel and the dependent chain stretches:
   // 3.04 -> 4.6 ms per 128 pairs.)
-  if (!overlap_blur) {
+  // A frame or two without stage timing: the blur's tiles ride in the quadtree launch below as extra workgroups (the launch has sixteen
+  // tree workgroups per image on 256 CUs; the blurred planes are read by the descriptors only) -- one launch and its ~15 us off the chain.
+  // With stage timing on the blur keeps its own launch so that the stages are timed apart.
+  const bool qt_small = nl > 0 && (long long)nl * n_img <= c->n_cu;  // (= launch_quadtree's four-waves-per-tree condition below)
+  const bool blur_in_qt = !overlap_blur && qt_small && c->prof == 0;
+  if (!overlap_blur && !blur_in_qt) {
     StageTimer t(c, ORBFE_STAGE_BLUR, st, timing);
     launch_blur(st, c->d_lv, nl, 0, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
   }
@@ -968,7 +989,7 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
                     c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img, 1, qt_tab, n_groups,
                     // helper waves for the data-parallel phases of a tree where the launch leaves the chip empty (a frame or two)
                     (!grouped && trees * 4 <= c->n_cu * 4) ? 4 : 1, c->d_qt_big ? c->d_qt_big + i0 * c->qt_big_pitch : nullptr,
-                    c->qt_big_pitch, c->d_qt_tabs);
+                    c->qt_big_pitch, c->d_qt_tabs, blur_in_qt ? pyr : nullptr, blur, c->img_pitch, c->blur_taps, c->bl_tiles);
   }
   {
     StageTimer t(c, ORBFE_STAGE_BRIEF, st, timing);
@@ -977,7 +998,10 @@ static orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_im
                         c->d_theta + i0 * NF, c->d_moments + i0 * NF, c->d_sincos + i0 * NF, c->d_kx + i0 * NF,
                         c->d_kpl + i0 * NF, c->cfg.height, n_img,
                         overlap_blur ? c->ev_blur_done : nullptr, before_lists, mirror ? mirror->kps : nullptr, mirror ? mirror->desc : nullptr,
-                        mirror ? mirror->n_kp : nullptr, true);
+                        mirror ? mirror->n_kp : nullptr, true, n_img <= 2 ? c->d_rowoff_slot : nullptr, c->d_rowlist_slot, c->d_n_match, c->cfg.height,
+                        c->row_list_cap, img0);
+    // (the per-slot row tables: valid after an extraction of one or two images, stale after any other -- the flags are host state and
+    //  this function also runs under graph CAPTURE, so the callers set them: extract_lane / note_slots_written)
   }
   HIP_TRY(c, hipGetLastError());
   return ORBFE_OK;
@@ -988,17 +1012,18 @@ struct StereoHostOut {  // page-locked destinations for the results of one pair,
   int32_t *best_right, *best_dist;
 };
 static orbfe_status run_stereo(orbfe_ctx* c, hipStream_t st, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs, float fx,
-                               float bf, const StereoHostOut* ho = nullptr) {
+                               float bf, const StereoHostOut* ho = nullptr, bool table_ready = false) {
   // (c->d_pyr is read here, at launch time: a later swap of the pyramid buffers does not affect a launch already queued)
   // (the match counters are zeroed by k_rowtable)
   {
     StageTimer t(c, ORBFE_STAGE_STEREO, st);
-    launch_stereo(st, c->d_lv, c->cfg.n_levels, c->d_pyr, c->img_pitch, c->d_kps, c->d_desc, c->d_aux, c->d_kx, c->d_rowoff, c->d_rowlist,
+    launch_stereo(st, c->d_lv, c->cfg.n_levels, c->d_pyr, c->img_pitch, c->d_kps, c->d_desc, c->d_aux, c->d_kx,
+                  table_ready ? c->d_rowoff_slot : c->d_rowoff, table_ready ? c->d_rowlist_slot : c->d_rowlist,
                   c->cfg.height, c->row_list_cap, c->d_n_kp,
                   c->cfg.n_features, fx, bf,
                   c->cfg.width, kMeanThreshold, c->d_right_u, c->d_depth, c->d_n_match, c->d_best_right, c->d_best_dist, slot_l0,
                   slot_r0, slot_step, pair0, n_pairs, ho ? ho->right_u : nullptr, ho ? ho->depth : nullptr, ho ? ho->best_right : nullptr,
-                  ho ? ho->best_dist : nullptr);
+                  ho ? ho->best_dist : nullptr, table_ready);
   }
   HIP_TRY(c, hipGetLastError());
   return ORBFE_OK;
@@ -1032,7 +1057,7 @@ void orbfe_destroy(orbfe_ctx* c) {
   void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_rs_tiles, c->d_pattern, c->d_pyr,     c->d_blur,
                   c->d_scr_a, c->d_scr_c,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_kp,
                   c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos, c->d_kx, c->d_kpl,   c->d_right_u, c->d_depth, c->d_n_match,
-                  c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist, c->d_rs_regions, c->d_rg_xtaps, c->d_rg_ytaps, c->d_qt_big, c->d_qt_tabs};
+                  c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist, c->d_rowoff_slot, c->d_rowlist_slot, c->d_rs_regions, c->d_rg_xtaps, c->d_rg_ytaps, c->d_qt_big, c->d_qt_tabs};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -1191,6 +1216,13 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   }
   ALLOC(c->d_rowoff, NP * (size_t)(c->cfg.height + 1));
   ALLOC(c->d_rowlist, NP * (size_t)c->row_list_cap);
+  if (M <= 16 && ((size_t)c->cfg.height + 4) * 4 <= 9000) {  // (k_brief's table workgroup borrows 9000 bytes of the descriptor kernel's LDS)
+    ALLOC(c->d_rowoff_slot, M * (size_t)(c->cfg.height + 1));
+    ALLOC(c->d_rowlist_slot, M * (size_t)c->row_list_cap);
+    c->slot_table_ok.reset(new std::atomic<uint8_t>[M]);
+    c->pair_count_zero.reset(new std::atomic<uint8_t>[M]);
+    for (size_t k = 0; k < M; ++k) c->slot_table_ok[k] = 0, c->pair_count_zero[k] = 0;
+  }
   ALLOC(c->d_right_u, NP * NF);
   ALLOC(c->d_depth, NP * NF);
   ALLOC(c->d_n_match, NP);
@@ -1420,6 +1452,7 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
     for (int y = 0; y < L0.h; ++y) std::memcpy(dst + (size_t)y * L0.stride, imgs[i] + (size_t)y * stride, (size_t)c->cfg.width);
   }
   uint8_t* const pyr_now = c->d_pyr;
+  note_slots_written(c, slot0, n_img, n_img <= 2);  // (also when a captured graph is replayed: run_extract does not run then)
   // The results come back through the staging buffer too: the orientation and the descriptor kernels write keypoints, counts and
   // descriptors there themselves (posted PCIe writes, ~120 KB per image) beside the device arrays the stereo match reads -- three
   // device-to-host copies queued behind the last kernel cost ~17 us of a ~0.3 ms call.  More than two images: the copies.
@@ -1633,7 +1666,11 @@ orbfe_status orbfe_stereo_match(orbfe_ctx* c, int32_t slot_left, int32_t slot_ri
   uint8_t* h = c->main.h_stage;
   const StereoHostOut ho = {right_u ? (double*)(h + o_ru) : nullptr, depth ? (double*)(h + o_dp) : nullptr,
                             best_right ? (int32_t*)(h + o_br) : nullptr, best_dist ? (int32_t*)(h + o_bd) : nullptr};
-  TRY(run_stereo(c, c->stream, slot_left, slot_right, 0, pair, 1, fx, bf, &ho));
+  // The right image's row table: built by its extraction when that was a one- or two-image call of this (small) context -- the match
+  // is then k_stereo alone; the pair's counter was zeroed there too unless an earlier match has counted into it since.
+  const bool table_ready = c->slot_table_ok && c->slot_table_ok[(size_t)slot_right] != 0;
+  if (table_ready && !c->pair_count_zero[(size_t)pair].exchange(0)) HIP_TRY(c, hipMemsetAsync(c->d_n_match + pair, 0, sizeof(int32_t), c->stream));
+  TRY(run_stereo(c, c->stream, slot_left, slot_right, 0, pair, 1, fx, bf, &ho, table_ready));
   HIP_TRY(c, hipMemcpyAsync(h + o_nm, c->d_n_match + pair, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_timers(c);
