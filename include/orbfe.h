@@ -250,6 +250,11 @@ typedef struct orbfe_ba_edge_out {
   uint8_t* depth_positive; /* [n_edges] isDepthPositive(), nullable                                     */
 } orbfe_ba_edge_out;
 
+/* DIAGNOSTIC entry points (this one and orbfe_ba_build_system): they return the per-edge Jacobians / the normal-equation blocks of ONE
+ * linearisation to the host -- 4.8 MB over PCIe for the 15 597 edges of BASELINE config 5, which is why the host-array call takes about
+ * as long as one CPU core needs for the arithmetic (0.42 vs 0.46 ms; the kernel itself 10 us).  They exist so that the edge formulas and
+ * the quadratic form can be checked against the oracle; the optimisers (orbfe_ba_local_optimize, orbfe_pose_only_optimize,
+ * orbfe_track_local_map) evaluate, build and solve on the device and move only poses, points and flags.                              */
 orbfe_status orbfe_ba_eval_edges(orbfe_ctx* ctx, const orbfe_ba_problem* prob, const orbfe_ba_edge_out* out);
 
 /* Normal-equation blocks of one linearisation, laid out like g2o's BlockSolver_6_3 (src/Optimizer.h:49-54): replaces

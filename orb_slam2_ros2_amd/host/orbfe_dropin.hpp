@@ -14,6 +14,7 @@
 //   orbfe::dropin::searchByProjection x2  frame <- frame (ORBMatcher.h:49, src/ORBMatcher.cc:265-347) and frame <- map points (ORBMatcher.h:52,
 //                                         :561-612)
 //   orbfe::dropin::frameRGBD              the tail of `Frame::Frame` for RGB-D input (src/Frame.cc:130-131, :139-157)
+//   orbfe::dropin::searchBySim3 x2, searchForTriangulation, fuse x2   the back-end matchers (ORBMatcher.h:55-67, src/ORBMatcher.cc:424-559, 691-787)
 //   orbfe::dropin::trackLocalMap          the middle of `Tracking::trackLocalMap` (src/Tracking.cc:650-658): searchByProjection(frame, local map
 //                                         points, th) + OptimizePoseOnly(frame) as ONE device call
 //
@@ -374,8 +375,8 @@ static void OptimizeLocalMap(KeyFramePtr pkframe, bool& isStop) {
     matches.swap(ret);
   }
   // ORBMatcher::setMapPoints (src/ORBMatcher.cc:815-830)
-  template <class MapPoints>
-  static void setMapPoints(MapPoints& toMatchMps, MapPoints& matchMps, const std::vector<cv::DMatch>& matches) {
+  template <class MapPointsA, class MapPointsB>
+  static void setMapPoints(MapPointsA& toMatchMps, MapPointsB& matchMps, const std::vector<cv::DMatch>& matches) {
     for (const auto& dmatch : matches) {
       auto& matchPMp = matchMps[dmatch.trainIdx];
       if (matchPMp && !matchPMp->isBad()) {
@@ -578,6 +579,241 @@ static void OptimizeLocalMap(KeyFramePtr pkframe, bool& isStop) {
     return nMatches;
   }
 
+  // ---- the back-end matchers (LocalMapping / LoopClosing callers), include/ORB_SLAM2/ORBMatcher.h:55-67 ----------------------------------
+  // A KeyFrame as the array-level mirror reads it (orbfe::ORBMatcher::KeyFrameView)
+  template <class KeyFramePtr>
+  static void keyFrameView(KeyFramePtr kf, orbfe::ORBMatcher::KeyFrameView& v) {
+    toKeypoints(kf->mvFeatsLeft, v.kps);
+    descRows(kf->getLeftDescriptor(), v.desc);
+    auto mps = kf->getMapPoints();
+    const size_t n = v.kps.size();
+    v.pos.assign(3 * n, 0.f), v.good.assign(n, 0), v.inMap.assign(n, 0), v.maxDist.assign(n, 0.f), v.minDist.assign(n, 0.f);
+    for (size_t i = 0; i < n && i < mps.size(); ++i) {
+      const auto& p = mps[i];
+      if (!p || p->isBad()) continue;
+      v.good[i] = 1, v.inMap[i] = p->isInMap() ? 1 : 0;
+      const cv::Mat X = p->getPos();
+      for (int a = 0; a < 3; ++a) v.pos[3 * i + a] = X.template at<float>(a);
+      p->getDistance(v.maxDist[i], v.minDist[i]);
+    }
+  }
+  template <class Sim3T>
+  static orbfe::ORBMatcher::Sim3 toSim3(const Sim3T& g) {  // Sim3Ret: mRqp, mtqp, mfS (include/ORB_SLAM2/Sim3Solver.h:14-48)
+    orbfe::ORBMatcher::Sim3 o;
+    o.s = g.mfS;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) o.R[3 * r + c] = g.mRqp.template at<float>(r, c);
+      o.t[r] = g.mtqp.template at<float>(r, 0);
+    }
+    return o;
+  }
+  template <class CameraT, class FramePtr>
+  static orbfe::ORBMatcher::Intrinsics intrinsics(FramePtr f) {
+    return {CameraT::mfFx, CameraT::mfFy, CameraT::mfCx, CameraT::mfCy, f->mfMinU, f->mfMaxU, f->mfMinV, f->mfMaxV};
+  }
+  static void poseFloats(const cv::Mat& Rcw, const cv::Mat& tcw, float* R, float* t) {
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) R[3 * r + c] = Rcw.template at<float>(r, c);
+      t[r] = tcw.template at<float>(r, 0);
+    }
+  }
+
+  // int ORBMatcher::searchBySim3(KeyFramePtr mpCurr, KeyFramePtr mpMatch, std::vector<cv::DMatch>& matches, Sim3Ret& g2oScm, float th)
+  // (ORBMatcher.h:55, src/ORBMatcher.cc:424-484): both SIM3Project sweeps as two device searches
+  template <class CameraT, class KeyFramePtr, class Sim3T>
+  static int searchBySim3(KeyFramePtr mpCurr, KeyFramePtr mpMatch, std::vector<cv::DMatch>& matches, Sim3T& g2oScm, float th, float mfRatio) {
+    orbfe::ORBMatcher::KeyFrameView C, M;
+    keyFrameView(mpCurr, C), keyFrameView(mpMatch, M);
+    cv::Mat Rcw, tcw, Rmw, tmw;
+    mpCurr->getPose(Rcw, tcw), mpMatch->getPose(Rmw, tmw);
+    float Rc[9], tc[3], Rm[9], tm[3];
+    poseFloats(Rcw, tcw, Rc, tc), poseFloats(Rmw, tmw, Rm, tm);
+    std::vector<std::pair<int, int>> pairs;
+    for (const auto& m : matches) pairs.emplace_back(m.queryIdx, m.trainIdx);
+    const size_t had = pairs.size();
+    orbfe::ORBMatcher(mfRatio).searchBySim3(matcherContext(), C, M, pairs, toSim3(g2oScm), Rc, tc, Rm, tm, th, intrinsics<CameraT>(mpCurr),
+                                            mpCurr->mvfScaledFactors);
+    for (size_t k = had; k < pairs.size(); ++k) {
+      cv::DMatch m;
+      m.queryIdx = pairs[k].first, m.trainIdx = pairs[k].second;
+      matches.push_back(m);
+    }
+    return (int)matches.size();
+  }
+
+  // int ORBMatcher::searchBySim3(KeyFramePtr pCurr, const std::vector<MapPointPtr>& vLoopGroupMps, std::vector<MapPointPtr>& vMatchedMps,
+  //                              Sim3Ret& g2oScw, float th)   (ORBMatcher.h:58, src/ORBMatcher.cc:501-559)
+  // The projection tests run on the host in the reference's float / double mix (Sim3Ret * p = (float)(s * (R p) + t) with cv::gemm's alpha /
+  // beta in double; cv::norm and Mat::dot accumulate in double), every findFeaturesInArea + getBestMatch as ONE device search.
+  template <class CameraT, class KeyFramePtr, class MapPointPtr, class Sim3T>
+  static int searchBySim3(KeyFramePtr pCurr, const std::vector<MapPointPtr>& vLoopGroupMps, std::vector<MapPointPtr>& vMatchedMps, Sim3T& g2oScw,
+                          float th, float mfRatio) {
+    int nMatches = 0;
+    std::set<MapPointPtr> sAlreadyMatched;
+    for (const auto& p : vMatchedMps)
+      if (p && !p->isBad() && p->isInMap()) sAlreadyMatched.insert(p), ++nMatches;
+    const orbfe::ORBMatcher::Sim3 S = toSim3(g2oScw);
+    const auto& sf = pCurr->mvfScaledFactors;
+    const float logScale = std::log(sf.size() > 1 ? sf[1] : 1.2f);
+    Queries q;
+    for (size_t i = 0; i < vLoopGroupMps.size(); ++i) {
+      const auto& pMp = vLoopGroupMps[i];
+      if (!pMp || pMp->isBad() || !pMp->isInMap()) continue;
+      if (sAlreadyMatched.count(pMp)) continue;
+      const cv::Mat Xw = pMp->getPos();
+      const float pw[3] = {Xw.template at<float>(0), Xw.template at<float>(1), Xw.template at<float>(2)};
+      float pc[3];
+      orbfe::ORBMatcher::affine(S.s, S.R, pw, S.t, pc);
+      if (pc[2] <= 0) continue;
+      const float u = CameraT::mfFx * (pc[0] / pc[2]) + CameraT::mfCx, v = CameraT::mfFy * (pc[1] / pc[2]) + CameraT::mfCy;  // Camera::project
+      if (!(u < pCurr->mfMaxU && v < pCurr->mfMaxV && u > pCurr->mfMinU && v > pCurr->mfMinV)) continue;                 // isInImage
+      const float dWithS = (float)std::sqrt((double)pc[0] * pc[0] + (double)pc[1] * pc[1] + (double)pc[2] * pc[2]);         // cv::norm: double sum
+      const float d = dWithS / S.s;
+      float mx = 0.f, mn = 0.f;
+      pMp->getDistance(mx, mn);
+      if (!(d < mx && d > mn)) continue;                                                                                     // isGoodDistance
+      const cv::Mat vd = pMp->getViewDirection();
+      const float vw[3] = {vd.template at<float>(0), vd.template at<float>(1), vd.template at<float>(2)};
+      float rv[3];
+      orbfe::ORBMatcher::matVec(S.R, vw, rv);
+      const double dot = (double)rv[0] * pc[0] + (double)rv[1] * pc[1] + (double)rv[2] * pc[2];                              // Mat::dot
+      if (dot < 0.5 * dWithS) continue;
+      const int o = orbfe::ORBMatcher::predictLevel(mx, d, logScale);
+      q.add((int)i, u, v, th * pCurr->getScaledFactor2(o), o - 1, o + 1, pMp->getDesc());
+    }
+    if (q.who.empty()) return nMatches;
+    Target t;
+    target(pCurr, t);
+    const auto m = searchTarget(t, q, nullptr, nullptr);
+    for (size_t k = 0; k < q.who.size(); ++k) {
+      if (m.nCand[k] <= 0) continue;
+      const float ratio = (float)m.bestDist[k] / (float)m.secondDist[k];
+      if (m.bestDist[k] <= orbfe::ORBMatcher::mnMinThreshold && ratio <= mfRatio) {
+        vMatchedMps[(size_t)m.bestIdx[k]] = vLoopGroupMps[(size_t)q.who[k]];
+        ++nMatches;
+      }
+    }
+    return nMatches;
+  }
+
+  // int ORBMatcher::processFuseMps(matches, fMapPoints, vMapPoints, pkf1, map, bLoop)   (src/ORBMatcher.cc:623-661): the reference's policy on the
+  // reference's objects (setMapPoint / addObservation / MapPoint::replace / getObsNum)
+  template <class KeyFramePtr, class FMapPoints, class VMapPoints, class MapPtr>
+  static int processFuseMps(const std::vector<cv::DMatch>& matches, FMapPoints& fMapPoints, VMapPoints& vMapPoints, KeyFramePtr& pkf1, MapPtr& map,
+                            bool bLoop) {
+    using MapPointT = typename std::decay<decltype(*fMapPoints[0])>::type;
+    int nFuse = 0;
+    for (const auto& match : matches) {
+      auto& pMp1 = fMapPoints[(size_t)match.queryIdx];
+      auto pMp2 = vMapPoints[(size_t)match.trainIdx];
+      if (!pMp2 || pMp2->isBad()) continue;
+      if (!pMp1 || pMp1->isBad()) {
+        pkf1->setMapPoint(match.queryIdx, pMp2);
+        pMp2->addObservation(pkf1, match.queryIdx);
+        ++nFuse;
+      } else {
+        if (pMp1 == pMp2) continue;
+        if (bLoop) {
+          MapPointT::replace(pMp2, pMp1, map);
+          ++nFuse;
+        } else {
+          const int obs1 = pMp1->getObsNum(), obs2 = pMp2->getObsNum();
+          if (obs1 >= obs2)
+            MapPointT::replace(pMp1, pMp2, map);
+          else
+            MapPointT::replace(pMp2, pMp1, map);
+          ++nFuse;
+        }
+      }
+    }
+    return nFuse;
+  }
+
+  // int ORBMatcher::fuse(KeyFramePtr pkf1, const std::vector<MapPointPtr>& mapPoints, MapPtr map, bool bLoop, float th)
+  // (ORBMatcher.h:64, src/ORBMatcher.cc:691-714)
+  template <class KeyFramePtr, class MapPointPtr, class MapPtr>
+  static int fuse(KeyFramePtr pkf1, const std::vector<MapPointPtr>& mapPoints, MapPtr map, bool bLoop, float th, float mfRatio, int nLevels) {
+    std::vector<cv::DMatch> matches;
+    std::set<MapPointPtr> sMapPoints;
+    std::vector<MapPointPtr> vMapPoints;
+    auto fMapPoints = pkf1->getMapPoints();
+    for (auto& p : fMapPoints)
+      if (p && !p->isBad()) sMapPoints.insert(p);
+    for (auto& p : mapPoints) {
+      if (sMapPoints.find(p) != sMapPoints.end()) continue;
+      vMapPoints.push_back(p);
+    }
+    searchByProjection(pkf1, vMapPoints, th, matches, true, mfRatio, nLevels);
+    fMapPoints = pkf1->getMapPoints();
+    return processFuseMps(matches, fMapPoints, vMapPoints, pkf1, map, bLoop);
+  }
+
+  // int ORBMatcher::fuse(KeyFramePtr pkf1, KeyFramePtr pkf2, MapPtr map)   (ORBMatcher.h:67, src/ORBMatcher.cc:724-732)
+  template <class CameraT, class KeyFramePtr, class MapPtr>
+  static int fuse(KeyFramePtr pkf1, KeyFramePtr pkf2, MapPtr map, float mfRatio) {
+    std::vector<cv::DMatch> matches;
+    searchByProjection<CameraT>(pkf1, pkf2, matches, 3.0f, true, mfRatio);
+    auto fMapPoints = pkf1->getMapPoints();
+    auto vMapPoints = pkf2->getMapPoints();
+    return processFuseMps(matches, fMapPoints, vMapPoints, pkf1, map, false);
+  }
+
+  // int ORBMatcher::searchForTriangulation(KeyFramePtr pkf1, KeyFramePtr pkf2, std::vector<cv::DMatch>& matches)
+  // (ORBMatcher.h:61, src/ORBMatcher.cc:736-787): searchByBow(pkf1, pkf2, matches, true) on the device, then the mutual epipolar test with the
+  // reference's float cv::Mat products (elements summed in float left to right; Mat::dot in double): F21 = KInv^T [t21]x R21 KInv
+  template <class CameraT, class KeyFramePtr>
+  static int searchForTriangulation(KeyFramePtr pkf1, KeyFramePtr pkf2, std::vector<cv::DMatch>& matches, float mfRatio, bool mbCheckOri) {
+    const int nAddMatches = searchByBow(pkf1, pkf2, matches, true, false, mfRatio, mbCheckOri);
+    if (!nAddMatches) return 0;
+    auto mul = [](const float* A, int n, int k, const float* B, int m2, float* out) {  // out[n][m2] = A[n][k] B[k][m2]
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < m2; ++j) {
+          float acc = A[i * k] * B[j];
+          for (int q = 1; q < k; ++q) acc = acc + A[i * k + q] * B[q * m2 + j];
+          out[i * m2 + j] = acc;
+        }
+    };
+    auto mat16 = [](const cv::Mat& T, float* o) {
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) o[4 * r + c] = T.template at<float>(r, c);
+    };
+    float P1[16], P1i[16], P2[16], P2i[16], T21[16], T12[16], Ki[9], KiT[9];
+    mat16(pkf1->getPose(), P1), mat16(pkf1->getPoseInv(), P1i), mat16(pkf2->getPose(), P2), mat16(pkf2->getPoseInv(), P2i);
+    mul(P2, 4, 4, P1i, 4, T21), mul(P1, 4, 4, P2i, 4, T12);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) Ki[3 * r + c] = CameraT::mKInv.template at<float>(r, c), KiT[3 * c + r] = Ki[3 * r + c];
+    auto fundamental = [&](const float* T, float* F) {
+      const float x = T[3], y = T[7], z = T[11];
+      const float ssm[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+      float R[9], a[9], b[9];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) R[3 * r + c] = T[4 * r + c];
+      mul(KiT, 3, 3, ssm, 3, a), mul(a, 3, 3, R, 3, b), mul(b, 3, 3, Ki, 3, F);
+    };
+    float F21[9], F12[9];
+    fundamental(T21, F21), fundamental(T12, F12);
+    auto dist = [&](const float* pl, const float* F, const float* pt) {  // point2LineDistance(pl^T F, pt) (:789-795)
+      float prm[3];
+      mul(pl, 1, 3, F, 3, prm);
+      const double dot = (double)prm[0] * pt[0] + (double)prm[1] * pt[1] + (double)prm[2] * pt[2];
+      return (float)std::abs(dot) / std::sqrt(prm[0] * prm[0] + prm[1] * prm[1]);
+    };
+    std::vector<cv::DMatch> goodMatches;
+    for (int idx = 0; idx < nAddMatches; ++idx) {
+      const auto& match = matches[(size_t)idx];
+      const auto kpt1 = pkf1->mvFeatsLeft[(size_t)match.queryIdx];
+      const auto kpt2 = pkf2->mvFeatsLeft[(size_t)match.trainIdx];
+      const float pt1[3] = {kpt1.pt.x, kpt1.pt.y, 1.f}, pt2[3] = {kpt2.pt.x, kpt2.pt.y, 1.f};
+      const float th1 = 5.991 * pkf1->getScaledFactor2(kpt1.octave);
+      if (dist(pt2, F21, pt1) > th1) continue;
+      const float th2 = 5.991 * pkf2->getScaledFactor2(kpt2.octave);
+      if (dist(pt1, F12, pt2) > th2) continue;
+      goodMatches.push_back(match);
+    }
+    std::swap(goodMatches, matches);
+    return (int)matches.size();
+  }
+
   // The middle of Tracking::trackLocalMap (src/Tracking.cc:650-658) as ONE device call (orbfe_track_local_map):
   //     nMatches = matcher.searchByProjection(mpCurrFrame, mvpLocalMps, th, matches);     (src/ORBMatcher.cc:561-612, bFuse = false)
   //     if (nMatches < 30) return false;
@@ -736,6 +972,28 @@ int OptimizePoseOnly(FramePtr pFrame) {
 template <class CameraT, class KeyFramePtr>
 void OptimizeLocalMap(KeyFramePtr pkframe, bool& isStop) {
   Bodies::template OptimizeLocalMap<CameraT>(pkframe, isStop);
+}
+template <class CameraT, class KeyFramePtr, class Sim3T>
+int searchBySim3(KeyFramePtr mpCurr, KeyFramePtr mpMatch, std::vector<cv::DMatch>& matches, Sim3T& g2oScm, float th, float mfRatio = 0.6f) {
+  return Bodies::template searchBySim3<CameraT>(mpCurr, mpMatch, matches, g2oScm, th, mfRatio);
+}
+template <class CameraT, class KeyFramePtr, class MapPointPtr, class Sim3T>
+int searchBySim3(KeyFramePtr pCurr, const std::vector<MapPointPtr>& vLoopGroupMps, std::vector<MapPointPtr>& vMatchedMps, Sim3T& g2oScw, float th,
+                 float mfRatio = 0.6f) {
+  return Bodies::template searchBySim3<CameraT>(pCurr, vLoopGroupMps, vMatchedMps, g2oScw, th, mfRatio);
+}
+template <class CameraT, class KeyFramePtr>
+int searchForTriangulation(KeyFramePtr pkf1, KeyFramePtr pkf2, std::vector<cv::DMatch>& matches, float mfRatio = 0.6f, bool mbCheckOri = true) {
+  return Bodies::template searchForTriangulation<CameraT>(pkf1, pkf2, matches, mfRatio, mbCheckOri);
+}
+template <class KeyFramePtr, class MapPointPtr, class MapPtr>
+int fuse(KeyFramePtr pkf1, const std::vector<MapPointPtr>& mapPoints, MapPtr map, bool bLoop = false, float th = 3.0f, float mfRatio = 0.6f,
+         int nLevels = 8) {
+  return Bodies::fuse(pkf1, mapPoints, map, bLoop, th, mfRatio, nLevels);
+}
+template <class CameraT, class KeyFramePtr, class MapPtr>
+int fuse(KeyFramePtr pkf1, KeyFramePtr pkf2, MapPtr map, float mfRatio = 0.6f) {
+  return Bodies::template fuse<CameraT>(pkf1, pkf2, map, mfRatio);
 }
 template <class CameraT, class FramePtr, class MapPointPtr>
 int trackLocalMap(FramePtr pframe, const std::vector<MapPointPtr>& mapPoints, float th, int& nGood, float mfRatio = 0.8f, int nLevels = 8,

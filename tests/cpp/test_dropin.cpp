@@ -11,6 +11,8 @@
 //                                             mirrors on the same frames and map state                   -> "MATCHERS_OK ..."
 //   trackchain <L.raw> <R.raw> <w> <h>        Tracking::trackLocalMap's middle as ONE call (dropin::trackLocalMap) against searchByProjection +
 //                                             OptimizePoseOnly one after the other on a twin frame      -> "TRACKCHAIN_OK ..."
+//   backend <L.raw> <R.raw> <w> <h>           searchBySim3 x2, fuse x2, searchForTriangulation with the reference's signatures on a
+//                                             geometrically consistent pair of keyframes               -> "BACKEND_OK ..."
 //   rgbd <gray.raw> <w> <h>                   the RGB-D tail of Frame::Frame against orbfe_frame_rgbd    -> "RGBD_OK ..."
 //   access                                    host-only: every matcher body instantiated on a class with PROTECTED members + the friend line
 //   latency <L.raw> <R.raw> <w> <h> <iters>   timing of Frame::Frame (two threads) + searchByStereo per pair, host to host -> "LATENCY_OK ..."
@@ -28,6 +30,7 @@ namespace ref {  // ---- stand-ins with the reference's accessor names ---------
 struct Camera {
   static inline float mfFx = 718.856f, mfFy = 718.856f, mfCx = 607.1928f, mfCy = 185.2157f, mfBf = 718.856f * 0.537166f, mfBl = 0.537166f;
   static inline cv::Mat mDistCoeff;
+  static inline cv::Mat mKInv;  // Camera::mKInv (3x3 float)
 };
 
 struct KeyFrame;
@@ -80,6 +83,28 @@ struct VirtualFrame {
   cv::Mat mRcw, mtcw;
   float mfMaxU = 0, mfMaxV = 0, mfMinU = 0, mfMinV = 0;
   std::vector<cv::Mat> mvLeftDescriptor;
+  const std::vector<cv::Mat>& getLeftDescriptor() const { return mvLeftDescriptor; }
+  cv::Mat getPose() const {  // 4x4 float Tcw / Twc as VirtualFrame::getPose / getPoseInv return them
+    cv::Mat T(4, 4, CV_32F);
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) T.at<float>(r, c) = r == c ? 1.f : 0.f;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) T.at<float>(r, c) = mRcw.at<float>(r, c);
+      T.at<float>(r, 3) = mtcw.at<float>(r, 0);
+    }
+    return T;
+  }
+  cv::Mat getPoseInv() const {
+    cv::Mat T(4, 4, CV_32F);
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) T.at<float>(r, c) = r == c ? 1.f : 0.f;
+    for (int r = 0; r < 3; ++r) {
+      float t = 0.f;
+      for (int c = 0; c < 3; ++c) T.at<float>(r, c) = mRcw.at<float>(c, r), t += mRcw.at<float>(c, r) * mtcw.at<float>(c, 0);
+      T.at<float>(r, 3) = -t;
+    }
+    return T;
+  }
   std::map<unsigned, std::vector<unsigned>> mFeatVec;  // DBoW3::FeatureVector is a std::map<NodeId, std::vector<unsigned>>
   int nBowCalls = 0;
   void computeBow() { ++nBowCalls; }
@@ -732,6 +757,18 @@ struct GeoMapPoint : ref::MapPoint {
   explicit GeoMapPoint(ref::MapPoint::Cmp c) : ref::MapPoint(c) {}
   cv::Mat getViewDirection() const { return mView.clone(); }
   void getDistance(float& mx, float& mn) const { mx = mMax, mn = mMin; }
+  // what the fuse policy touches (MapPoint.h: addObservation, getObsNum, static replace)
+  int mObsNum = 0;
+  std::vector<std::pair<void*, std::size_t>> mAdded;
+  template <class KeyFramePtr>
+  void addObservation(KeyFramePtr kf, std::size_t idx) { mAdded.emplace_back((void*)kf.get(), idx), ++mObsNum; }
+  int getObsNum() const { return mObsNum; }
+  struct MapStub {
+    std::vector<std::pair<std::size_t, std::size_t>> replaced;  // (kept id, dropped id)
+  };
+  static void replace(std::shared_ptr<GeoMapPoint> keep, std::shared_ptr<GeoMapPoint> drop, std::shared_ptr<MapStub> map) {
+    map->replaced.emplace_back(keep->mId, drop->mId);
+  }
   template <class FramePtr>
   bool isInVision(FramePtr f, float& dist, cv::Point2f& uv, float& cosTheta) {
     float R[9], t[3], X[3], D[3], pc[3];
@@ -887,6 +924,190 @@ static int mode_trackchain(int argc, char** argv) {
   return (fails == 0 && nA > 800 && goodA > 300) ? 0 : 1;
 }
 
+// The back-end matchers with the reference's signatures (ORBMatcher.h:55-67) over stand-in KeyFrames whose features are a real stereo pair's:
+// K1 = the left image at the identity pose, K2 = the right image one baseline to the right, map points = K1's keypoints back-projected
+// at their stereo depth, so that every adapter has true correspondences to find.
+struct Sim3Stub {  // Sim3Ret (include/ORB_SLAM2/Sim3Solver.h:14-48)
+  cv::Mat mRqp, mtqp;
+  float mfS = 1.f;
+};
+struct GeoKeyFrame : ref::KeyFrame {
+  typedef std::shared_ptr<GeoKeyFrame> SharedPtr;
+  std::vector<GeoMapPoint::SharedPtr> mGeo;  // the same objects as mvpMapPoints, typed
+  std::vector<GeoMapPoint::SharedPtr> getMapPoints() { return mGeo; }
+  GeoMapPoint::SharedPtr getMapPoint(std::size_t i) { return mGeo[i]; }
+  void setMapPoint(int i, GeoMapPoint::SharedPtr p) { mGeo[(size_t)i] = p, mvpMapPoints[(size_t)i] = p; }
+};
+static int mode_backend(int argc, char** argv) {
+  if (argc < 6) return 2;
+  const int w = atoi(argv[4]), h = atoi(argv[5]);
+  std::vector<uint8_t> L, R;
+  if (!read_file(argv[2], L) || !read_file(argv[3], R) || L.size() != (size_t)w * h || R.size() != L.size()) return 2;
+  cv::Mat ml(h, w, CV_8UC1, L.data()), mr(h, w, CV_8UC1, R.data());
+  ref::MapPoint::Cmp cmp = [](std::weak_ptr<ref::KeyFrame>, std::weak_ptr<ref::KeyFrame>) { return false; };
+  auto F = std::make_shared<ref::Frame>(ml, mr, true);
+  ref::VirtualFrame::mvfScaledFactors = ORB_SLAM2_ROS2::ORBExtractor::getScaledFactors();
+  orbfe::dropin::searchByStereo<ref::Camera>(F);
+  const float fx = ref::Camera::mfFx, fy = ref::Camera::mfFy, cx = ref::Camera::mfCx, cy = ref::Camera::mfCy, bl = ref::Camera::mfBl;
+  ref::Camera::mKInv = cv::Mat(3, 3, CV_32F);
+  {
+    const float ki[9] = {1.f / fx, 0.f, -cx / fx, 0.f, 1.f / fy, -cy / fy, 0.f, 0.f, 1.f};
+    for (int i = 0; i < 9; ++i) ref::Camera::mKInv.at<float>(i / 3, i % 3) = ki[i];
+  }
+  auto make_kf = [&](const std::vector<cv::KeyPoint>& kps, const std::vector<cv::Mat>& desc, float tx) {
+    auto k = std::make_shared<GeoKeyFrame>();
+    k->mvFeatsLeft = kps, k->mvLeftDescriptor = desc;
+    k->mfMinU = 0, k->mfMinV = 0, k->mfMaxU = (float)w, k->mfMaxV = (float)h;
+    cv::Mat T(4, 4, CV_32F);
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) T.at<float>(r, c) = r == c ? 1.f : 0.f;
+    T.at<float>(0, 3) = tx;
+    k->setPose(T);
+    k->mvpMapPoints.assign(kps.size(), nullptr), k->mGeo.assign(kps.size(), nullptr);
+    return k;
+  };
+  auto K1 = make_kf(F->mvFeatsLeft, F->mvLeftDescriptor, 0.f);
+  // K2: the same scene from one baseline to the right -- K1's stereo-matched keypoints at their right-image column (mvFeatsRightU) with
+  // their descriptors a few bits off (every adapter then has a true partner for every map point), the unmatched ones pushed off by rows
+  std::vector<cv::KeyPoint> kps2 = F->mvFeatsLeft;
+  std::vector<cv::Mat> desc2;
+  {
+    uint64_t s2 = 99;
+    auto rnd2 = [&]() {
+      s2 = s2 * 6364136223846793005ull + 1442695040888963407ull;
+      return (unsigned)(s2 >> 40);
+    };
+    for (size_t i = 0; i < kps2.size(); ++i) {
+      cv::Mat d = F->mvLeftDescriptor[i].clone();
+      if (F->mvDepths[i] > 0) {
+        kps2[i].pt.x = (float)F->mvFeatsRightU[i];
+        for (int k = 0; k < 3; ++k) {
+          const unsigned bit = rnd2() % 256;
+          d.data[bit / 8] ^= (uint8_t)(1u << (bit % 8));
+        }
+      } else {
+        kps2[i].pt.y = std::min((float)h - 20.f, std::max(20.f, kps2[i].pt.y + ((i & 1) ? 60.f : -60.f)));
+        for (int k = 0; k < 32; ++k) d.data[k] = (uint8_t)rnd2();
+      }
+      desc2.push_back(d);
+    }
+  }
+  auto K2 = make_kf(kps2, desc2, -bl);  // the right camera: x_c2 = x_w - baseline
+  const size_t n1 = K1->mvFeatsLeft.size(), n2 = K2->mvFeatsLeft.size();
+  size_t next_id = 0;
+  auto geo = [&](float X, float Y, float Z, const cv::Mat& desc, int octave) {
+    auto p = std::make_shared<GeoMapPoint>(cmp);
+    p->mId = next_id++;
+    p->mPos = cv::Mat(3, 1, CV_32F), p->mView = cv::Mat(3, 1, CV_32F);
+    const float nrm = std::sqrt(X * X + Y * Y + Z * Z);
+    p->mPos.at<float>(0) = X, p->mPos.at<float>(1) = Y, p->mPos.at<float>(2) = Z;
+    p->mView.at<float>(0) = X / nrm, p->mView.at<float>(1) = Y / nrm, p->mView.at<float>(2) = Z / nrm;
+    p->mMax = nrm * 1.05f * ref::VirtualFrame::getScaledFactor(octave), p->mMin = nrm * 0.5f;  // predictLevel(|X|) = the feature's octave
+    p->mDesc = desc.clone();
+    return p;
+  };
+  // K1's stereo-matched features carry map points; their right-image partners are found by position (rightU on the same row band)
+  std::vector<int> partner(n1, -1);
+  for (size_t i = 0; i < n1; ++i) {
+    if (!(F->mvDepths[i] > 0)) continue;
+    const auto& kp = K1->mvFeatsLeft[i];
+    const float Z = (float)F->mvDepths[i];
+    auto p = geo((kp.pt.x - cx) / fx * Z, (kp.pt.y - cy) / fy * Z, Z, K1->mvLeftDescriptor[i], kp.octave);
+    K1->setMapPoint((int)i, p);
+  }
+  int fails = 0;
+  auto expect = [&](bool ok, const char* what) {
+    if (!ok) fprintf(stderr, "backend: %s\n", what), ++fails;
+  };
+  // ---- searchBySim3(pCurr = K2, loop map points = K1's, matched, Scw = K2's pose as a similarity, th) -------------------------------------
+  Sim3Stub Scw;
+  Scw.mRqp = K2->mRcw.clone(), Scw.mtqp = K2->mtcw.clone(), Scw.mfS = 1.f;
+  std::vector<GeoMapPoint::SharedPtr> loopMps;
+  for (size_t i = 0; i < n1; ++i) loopMps.push_back(K1->mGeo[i]);
+  std::vector<GeoMapPoint::SharedPtr> matched(n2, nullptr);
+  matched[0] = loopMps[1] ? loopMps[1] : nullptr;  // one already matched: counted, not searched again
+  const int pre = matched[0] ? 1 : 0;
+  const int nLoop = orbfe::dropin::searchBySim3<ref::Camera>(K2, loopMps, matched, Scw, 10.f);
+  int filled = 0, near = 0;
+  for (size_t j = 0; j < n2; ++j) {
+    if (!matched[j]) continue;
+    ++filled;
+    const auto& X = matched[j]->mPos;
+    const float u = fx * ((X.at<float>(0) - bl) / X.at<float>(2)) + cx, v = fy * (X.at<float>(1) / X.at<float>(2)) + cy;
+    near += std::fabs(u - K2->mvFeatsLeft[j].pt.x) < 10.f * 5.2f && std::fabs(v - K2->mvFeatsLeft[j].pt.y) < 10.f * 5.2f;
+  }
+  expect(nLoop >= pre && filled > 200 && nLoop >= filled - 1, "searchBySim3(kf, map points): too few matches or a wrong count");
+  expect(near >= filled - 1, "searchBySim3(kf, map points): a match lies outside its search window");
+  // K2 takes the loop matches as its map points (what LoopClosing does with them), a few of them bad / not in the map
+  for (size_t j = 0; j < n2; ++j)
+    if (matched[j] && j % 3 != 0) K2->setMapPoint((int)j, matched[j]);
+  // ---- searchBySim3(K1, K2, matches, Scm, th): the features K2 did NOT take (j % 3 == 0) are found again through the similarity ----------
+  // give K2's remaining features map points of their own (copies of the geometry: different objects) so that SIM3Project has candidates
+  for (size_t j = 0; j < n2; ++j)
+    if (matched[j] && j % 3 == 0) {
+      const auto& X = matched[j]->mPos;
+      K2->setMapPoint((int)j, geo(X.at<float>(0), X.at<float>(1), X.at<float>(2), K2->mvLeftDescriptor[j], K2->mvFeatsLeft[j].octave));
+    }
+  Sim3Stub Scm;  // p_c1 = p_c2 + baseline
+  Scm.mRqp = K1->mRcw.clone(), Scm.mtqp = cv::Mat(3, 1, CV_32F), Scm.mfS = 1.f;
+  Scm.mtqp.at<float>(0) = bl, Scm.mtqp.at<float>(1) = 0.f, Scm.mtqp.at<float>(2) = 0.f;
+  std::vector<cv::DMatch> sm;
+  const int nSim = orbfe::dropin::searchBySim3<ref::Camera>(K1, K2, sm, Scm, 7.5f);
+  int sim_ok = 0;
+  for (const auto& m : sm) sim_ok += orbfe::dropin::descDistance(K1->mvLeftDescriptor[(size_t)m.queryIdx], K2->mvLeftDescriptor[(size_t)m.trainIdx]) <= 50;
+  expect(nSim == (int)sm.size() && nSim > 200 && sim_ok == nSim, "searchBySim3(kf, kf): matches missing or past the descriptor threshold");
+  {
+    std::set<int> q, t;
+    for (const auto& m : sm) q.insert(m.queryIdx), t.insert(m.trainIdx);
+    expect(q.size() == sm.size(), "searchBySim3(kf, kf): a feature of the current keyframe matched twice");
+  }
+  // ---- fuse(K2, map points of K1, map, bLoop, th): add where the feature is free, replace by observation count where it is not ----------
+  auto map = std::make_shared<GeoMapPoint::MapStub>();
+  std::vector<GeoMapPoint::SharedPtr> cand;
+  for (size_t i = 0; i < n1; ++i)
+    if (K1->mGeo[i]) {
+      K1->mGeo[i]->mObsNum = (int)(i % 5);
+      cand.push_back(K1->mGeo[i]);
+    }
+  for (size_t j = 0; j < n2; ++j)
+    if (K2->mGeo[j]) K2->mGeo[j]->mObsNum = std::max(K2->mGeo[j]->mObsNum, 2);
+  size_t held_before = 0, free_before = 0;
+  for (size_t j = 0; j < n2; ++j) (K2->mGeo[j] ? held_before : free_before) += 1;
+  const auto before = K2->mGeo;
+  const int nFuse = orbfe::dropin::fuse(K2, cand, map, false, 3.0f);
+  size_t added = 0;
+  for (size_t j = 0; j < n2; ++j) added += !before[j] && K2->mGeo[j];
+  bool policy_ok = true;
+  for (const auto& r : map->replaced) policy_ok = policy_ok && r.first != r.second;
+  expect(nFuse == (int)(added + map->replaced.size()) && nFuse > 50 && policy_ok, "fuse(kf, map points): count != adds + replacements");
+  for (size_t j = 0; j < n2; ++j)
+    if (!before[j] && K2->mGeo[j]) policy_ok = policy_ok && !K2->mGeo[j]->mAdded.empty() && K2->mGeo[j]->mAdded.back().second == j;
+  expect(policy_ok, "fuse(kf, map points): addObservation missing for an added point");
+  // ---- fuse(K1, K2, map): K2's map points projected into K1 by searchByProjection(frame, frame, bFuse) -----------------------------------
+  auto map2 = std::make_shared<GeoMapPoint::MapStub>();
+  const int nFuse2 = orbfe::dropin::fuse<ref::Camera>(K1, K2, map2);
+  expect(nFuse2 >= 0 && nFuse2 >= (int)map2->replaced.size(), "fuse(kf, kf): count below the replacements");
+  // ---- searchForTriangulation(K1, K2, matches): BoW matches of features without map points, then the mutual epipolar test.  The pair is
+  //      rectified (identity rotations, translation along x): the epipolar lines are the image rows, so a kept match has |v1 - v2| within
+  //      sqrt(5.991) sigma and a match that is rows apart must go
+  K1->mGeo.assign(n1, nullptr), K1->mvpMapPoints.assign(n1, nullptr), K2->mGeo.assign(n2, nullptr), K2->mvpMapPoints.assign(n2, nullptr);
+  for (auto* kf : {K1.get(), K2.get()}) {  // a one-node vocabulary per octave: the BoW lists are the octaves' features
+    kf->mFeatVec.clear();
+    for (size_t i = 0; i < kf->mvFeatsLeft.size(); ++i) kf->mFeatVec[(unsigned)kf->mvFeatsLeft[i].octave].push_back((unsigned)i);
+  }
+  std::vector<cv::DMatch> tri;
+  const int nTri = orbfe::dropin::searchForTriangulation<ref::Camera>(K1, K2, tri);
+  int row_ok = 0;
+  for (const auto& m : tri) {
+    const auto &a = K1->mvFeatsLeft[(size_t)m.queryIdx], &b = K2->mvFeatsLeft[(size_t)m.trainIdx];
+    const float s = ref::VirtualFrame::getScaledFactor(std::max(a.octave, b.octave));
+    row_ok += std::fabs(a.pt.y - b.pt.y) <= std::sqrt(5.991f) * s * 1.001f + 1e-3f;
+  }
+  expect(nTri == (int)tri.size() && nTri > 100 && row_ok == nTri, "searchForTriangulation: a kept match violates the epipolar bound");
+  printf("BACKEND_OK %zu %zu %d %d %d %d %d %d\n", n1, n2, nLoop, nSim, nFuse, nFuse2, nTri, (int)map->replaced.size());
+  return fails == 0 ? 0 : 1;
+}
+
 // host-only: the write-back policy of Optimizer.cc:391-404 at EXACTLY 30 % -- `size / (float)nGoodMp > 0.3` compares a float quotient with
 // a double literal: 3 / 10 = 0.3f widens to 0.30000001192..., which IS greater than 0.3, so the keyframe counts as bad
 static int mode_policy() {
@@ -930,6 +1151,7 @@ int main(int argc, char** argv) {
     if (mode == "matchers") return mode_matchers(argc, argv);
     if (mode == "rgbd") return mode_rgbd(argc, argv);
     if (mode == "trackchain") return mode_trackchain(argc, argv);
+    if (mode == "backend") return mode_backend(argc, argv);
     if (mode == "access") return mode_access();
     if (mode == "localba") return mode_localba(argc, argv);
     if (mode == "poseonly") return mode_poseonly();

@@ -89,6 +89,21 @@ def test_fused_tracking_chain_adapter_equals_the_two_bodies(exe, tmp_path):
     assert f[0] == "TRACKCHAIN_OK" and int(f[2]) > 800 and abs(int(f[3]) - int(f[4])) <= 1 and float(f[7]) < 1e-5
 
 
+def test_back_end_matcher_adapters_with_the_reference_signatures(exe, tmp_path):
+    """searchBySim3 x2, searchForTriangulation, fuse x2 (include/ORB_SLAM2/ORBMatcher.h:55-67) over stand-in KeyFrame / MapPoint / Sim3Ret /
+    Map classes on a geometrically consistent pair of keyframes (a real stereo pair: the left image at the identity, the right one a
+    baseline away, map points back-projected at their stereo depth): true correspondences found inside their windows and under the
+    descriptor threshold, counts = adds + replacements, addObservation / MapPoint::replace called as processFuseMps prescribes, the
+    epipolar bound of a rectified pair.  The device core underneath is held to the oracle in test_guided_search.py / test_matcher_ext.py."""
+    L, R = synth.stereo_pair(5)
+    L.tofile(tmp_path / "L.raw")
+    R.tofile(tmp_path / "R.raw")
+    out = subprocess.run([exe, "backend", str(tmp_path / "L.raw"), str(tmp_path / "R.raw"), "1241", "376"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    f = out.stdout.split()
+    assert f[0] == "BACKEND_OK" and int(f[3]) > 200 and int(f[4]) > 200 and int(f[5]) > 50 and int(f[7]) > 100
+
+
 def test_rgbd_frame_tail_adapter_equals_the_array_level_call(exe, tmp_path):
     """Frame::Frame for RGB-D input (src/Frame.cc:125-159) after extract(): undistortion + depth / rightU lookup through the adapter against
     orbfe_frame_rgbd on the same slot (which tests/test_frame_glue.py holds to the oracle)."""
