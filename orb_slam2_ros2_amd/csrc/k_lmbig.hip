@@ -18,7 +18,7 @@
 // blocks below it and the rank-16 updates run on the matrix cores) and solves X L^T = A for its own 48 rows by blocked substitution,
 // X_b = (A_b - sum X_c L_bc^T) inv_bb^T, every product an MFMA (a column-at-a-time substitution by one wave was 14 us a tile, the
 // 48-column factorisation 24 us: tools/exp/lmb_bench.hip).  No workgroup waits for another.  After the last launch L and y are
-// complete; k_lmb_back solves L^T x = y with one workgroup.
+// complete; k_lmb_back_mw solves L^T x = y with one workgroup per tile column (k_lmb_back: the one-workgroup version, kept for tools/exp/lmb_bench.hip).
 // Fixed summation order everywhere: run-to-run identical.  A non-positive pivot clears LmState::ok (g2o: the linear solver fails, the
 // trial is rejected) and x = 0.
 #include <hip/hip_runtime.h>
@@ -210,6 +210,8 @@ __global__ __launch_bounds__(192) void k_lmb_step(int k, int KT, int ld, double*
   if (!lmb_gate(st)) return;
   if (*(volatile int32_t*)&flags[KT] != 0) return;  // an earlier column hit a bad pivot
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (k < 0 && blockIdx.x == 0)  // the back substitution's column flags of the PREVIOUS factorisation (k_lmb_back_mw polls them: it cannot reset them itself)
+    for (int q = t; q < KT; q += 192) flags[KT + 1 + q] = 0;
   // blockIdx.x -> (i, j): column-major over the trailing tiles, column k + 1 first
   const int m = KT - 1 - k;  // tile columns left; tile rows k + 1 .. KT (KT: the right-hand-side row)
   int jq = 0, base = 0;
@@ -397,6 +399,100 @@ __global__ __launch_bounds__(1024) void k_lmb_back(int n, int KT, int ld, const 
   for (int q = t; q <= KT; q += 1024) flags[q] = 0;
 }
 
+// The same over MANY CUs: one workgroup per tile column, column KT - 1 first (workgroup 0).  Workgroup j owns y_j: it subtracts
+// L_kj^T x_k for k = KT - 1 ... j + 1 as the x_k become available (the 48 x 48 tile of the next k is requested BEFORE the wait, so a
+// column's critical path is flag -> 48 doubles of x -> one tile's matrix-vector product -> the 16-wide block solves -> publish), solves
+// its own tile and raises xready[j].  A workgroup waits only for workgroups of SMALLER index (dispatched before it; workgroup 0 waits for
+// nobody), so the waits cannot deadlock.  xready[] is zeroed by the first launch of the NEXT factorisation (k_lmb_step, k = -1): no
+// workgroup of this kernel may reset a flag another one is still polling.  The one-workgroup version moved the whole 13 MB of an
+// 1800-row factor through one CU: 0.44 ms; this one 0.15.
+__global__ __launch_bounds__(192) void k_lmb_back_mw(int n, int KT, int ld, const double* __restrict__ M, const double* __restrict__ Linv,
+                                                     LmState* __restrict__ st, int32_t* __restrict__ flags, int32_t* __restrict__ xready,
+                                                     double* __restrict__ x) {
+#pragma clang fp contract(fast)
+  __shared__ double Lt[LMB_T * LMB_LS];
+  __shared__ double Iv[3 * 16 * LMB_IS];
+  __shared__ double yj[LMB_T], xk[LMB_T], part[4][LMB_T];
+  if (!lmb_gate(st)) return;
+  const int t = threadIdx.x;
+  const int j = KT - 1 - (int)blockIdx.x;
+  if (*(volatile int32_t*)&flags[KT] != 0) {  // a bad pivot: x = 0 (every workgroup its own rows; nobody waits)
+    for (int c = t; c < LMB_T; c += 192)
+      if (j * LMB_T + c < n) x[j * LMB_T + c] = 0.0;
+    if (j == 0 && t == 0) flags[KT] = 0;  // (read at kernel starts only: the next reader is the next factorisation)
+    return;
+  }
+  const int c = t % LMB_T, pr = t / LMB_T;  // column of the tile, row part (12 rows each)
+  if (t < LMB_T) yj[t] = M[(size_t)ld * ld + (size_t)j * LMB_T + t];
+  {  // this column's diagonal tile and block inverses (needed last: they travel under everything else)
+    const double* Ljj = M + (size_t)j * LMB_T * ld + (size_t)j * LMB_T;
+    for (int e = t; e < LMB_T * LMB_T; e += 192) Lt[(e / LMB_T) * LMB_LS + e % LMB_T] = Ljj[(size_t)(e / LMB_T) * ld + e % LMB_T];
+    for (int e = t; e < 3 * 256; e += 192) Iv[(e >> 8) * 16 * LMB_IS + ((e & 255) >> 4) * LMB_IS + (e & 15)] = Linv[(size_t)j * 768 + e];
+  }
+  auto tile_rows = [&](int kt, double (&lv)[12]) {
+    const double* T = M + ((size_t)kt * LMB_T + 12 * pr) * ld + (size_t)j * LMB_T + c;
+#pragma unroll
+    for (int r = 0; r < 12; ++r) lv[r] = T[(size_t)r * ld];
+  };
+  double lv[12];
+  if (KT - 1 > j) tile_rows(KT - 1, lv);
+  __syncthreads();
+  for (int kt = KT - 1; kt > j; --kt) {
+    if (t == 0) {
+      while (__hip_atomic_load(&xready[kt], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (t < LMB_T) xk[t] = __builtin_nontemporal_load(&x[(size_t)kt * LMB_T + t]);
+    __syncthreads();
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 12; r += 2) {
+      s0 = fma(lv[r], xk[12 * pr + r], s0);
+      s1 = fma(lv[r + 1], xk[12 * pr + r + 1], s1);
+    }
+    part[pr][c] = s0 + s1;
+    if (kt - 1 > j) tile_rows(kt - 1, lv);  // the next tile travels while this one is folded in
+    __syncthreads();
+    if (t < LMB_T) yj[t] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+    __syncthreads();
+  }
+  if (t < 64) {  // x_j = L_jj^-T y_j by the block inverses (as k_lmb_back)
+    const int i = t & 15;
+    auto mv_t = [&](const double* Mx, int pitch, const double* v) {
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int k2 = 0; k2 < 16; k2 += 2) {
+        a0 = fma(Mx[k2 * pitch + i], v[k2], a0);
+        a1 = fma(Mx[(k2 + 1) * pitch + i], v[k2 + 1], a1);
+      }
+      return a0 + a1;
+    };
+    const double x3 = mv_t(Iv + 2 * 16 * LMB_IS, LMB_IS, yj + 32);
+    if (t < 16) xk[32 + i] = x3;
+    lmb_wave_sync();
+    const double y2 = yj[16 + i] - mv_t(Lt + 32 * LMB_LS + 16, LMB_LS, xk + 32);
+    lmb_wave_sync();
+    if (t < 16) yj[16 + i] = y2;
+    lmb_wave_sync();
+    const double x2 = mv_t(Iv + 16 * LMB_IS, LMB_IS, yj + 16);
+    if (t < 16) xk[16 + i] = x2;
+    lmb_wave_sync();
+    const double y1 = yj[i] - (mv_t(Lt + 32 * LMB_LS, LMB_LS, xk + 32) + mv_t(Lt + 16 * LMB_LS, LMB_LS, xk + 16));
+    lmb_wave_sync();
+    if (t < 16) yj[i] = y1;
+    lmb_wave_sync();
+    const double x1 = mv_t(Iv, LMB_IS, yj);
+    if (t < 16) {
+      double* xo = x + (size_t)j * LMB_T;  // (x has ld entries: the padding rows come out 0)
+      xo[i] = x1, xo[16 + i] = x2, xo[32 + i] = x3;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    lmb_wave_sync();
+    if (t == 0) __hip_atomic_store(&xready[j], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 size_t lm_big_inv_bytes(int nf) { return (((size_t)6 * nf + LMB_T - 1) / LMB_T) * 768 * sizeof(double); }
 size_t lm_big_bytes(int nf) {
   const size_t ld = ((size_t)6 * nf + LMB_T - 1) / LMB_T * LMB_T;
@@ -415,8 +511,8 @@ void launch_lm_chol_big(hipStream_t s, const LmLaunch& L) {
     const int grid = k < 0 ? m + 1 : m * (m + 3) / 2;
     hipLaunchKernelGGL(k_lmb_step, dim3(grid), dim3(192), 0, s, k, KT, L.ld, L.M, L.lmb_inv, L.state, L.lmb_flags);
   }
-  hipLaunchKernelGGL(k_lmb_back, dim3(1), dim3(1024), (size_t)(L.ld + LMB_T + LMB_T * LMB_LS + 3 * 16 * LMB_IS) * sizeof(double), s, 6 * L.nf, KT, L.ld, L.M, L.lmb_inv, L.state, L.lmb_flags,
-                     L.x);
+  // x gets ld entries (the padding rows come out 0); flags: [0, KT) unused, [KT] bad pivot, [KT + 1, 2 KT + 1) the back substitution's column flags
+  hipLaunchKernelGGL(k_lmb_back_mw, dim3(KT), dim3(192), 0, s, 6 * L.nf, KT, L.ld, L.M, L.lmb_inv, L.state, L.lmb_flags, L.lmb_flags + KT + 1, L.x);
 }
 
 }  // namespace orbfe

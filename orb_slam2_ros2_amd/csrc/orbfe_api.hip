@@ -2383,7 +2383,7 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
                o_pairs = take(pairs.size() * 8), o_lmstate = take(sizeof(LmState)),  // (the initial control state rides in the one upload)
                o_hpp = take((size_t)NK * 288), o_bp = take((size_t)NK * 48), o_hll = take((size_t)NP * 72),
                o_bl = take((size_t)NP * 24), o_hpl = take((size_t)E * 144), o_w = take((size_t)E * 144),
-               o_s = take(n * n * 8), o_rhs = take(n * 8), o_x = take(n * 8), o_dxp = take((size_t)NK * 48), o_dxl = take((size_t)NP * 24),
+               o_s = take(n * n * 8), o_rhs = take(n * 8), o_x = take((n + 48) * 8), o_dxp = take((size_t)NK * 48), o_dxl = take((size_t)NP * 24),
                o_err = take((size_t)E * 24), o_chi2 = take((size_t)E * 8), o_rho = take((size_t)E * 16),
                // one block that starts as zeros (ONE fill): edge levels | chi2 of the last linearisation | point inverses
                o_level = take((size_t)E), o_last = take((size_t)E * 8), o_dinv = take((size_t)NP * 72), o_zero_end = take(8),
@@ -2402,7 +2402,7 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     l_bl1 = take((size_t)NP * 24);
     l_chi[0] = take((size_t)chi_blocks * 8), l_chi[1] = take((size_t)chi_blocks * 8);
     l_sblk = take(big_solver ? 8 : (size_t)nf * (nf + 1) / 2 * 288), l_scale = take((size_t)scale_blocks * 8);
-    l_big = take(big_solver ? lm_big_bytes(nf) : 8), l_bigflags = take(big_solver ? ((size_t)lm_big_ld(nf) / 48 + 2) * 4 : 8),
+    l_big = take(big_solver ? lm_big_bytes(nf) : 8), l_bigflags = take(big_solver ? (2 * ((size_t)lm_big_ld(nf) / 48) + 4) * 4 : 8),
     l_biginv = take(big_solver ? lm_big_inv_bytes(nf) : 8);
     // the results as ONE block (one download): poses | points | chi2 | level | bad
     l_pose_out = take((size_t)NK * 56), l_pt_out = take((size_t)NP * 24), l_chi2_out = take((size_t)E * 8), l_level_out = take((size_t)E),
@@ -2488,7 +2488,7 @@ orbfe_status orbfe_ba_local_optimize(orbfe_ctx* c, const orbfe_ba_problem* p, co
     L.M = big_solver ? (double*)(b + l_big) : nullptr, L.ld = big_solver ? lm_big_ld(nf) : 0, L.lmb_flags = (int32_t*)(b + l_bigflags), L.lmb_inv = (double*)(b + l_biginv);
     StageTimer tm(c, ORBFE_STAGE_BA, st);
     if (big_solver) {
-      HIP_TRY(c, hipMemsetAsync(b + l_big, 0, (l_bigflags - l_big) + ((size_t)L.ld / 48 + 2) * 4, st));  // the matrix and the flags behind it
+      HIP_TRY(c, hipMemsetAsync(b + l_big, 0, (l_bigflags - l_big) + (2 * ((size_t)L.ld / 48) + 4) * 4, st));  // the matrix and the flags behind it
       launch_lm_big_init(st, L);
     }
     HIP_TRY(c, hipMemsetAsync(L.pair_table, 0xFF, (size_t)nf * NP * 4, st));

@@ -165,7 +165,7 @@ struct LmLaunch {
   double *Dinv, *W, *Sblk, *rhs, *x, *scale_part;
   double* M;            // nf > LM_CHOL_MAX_NB: the dense reduced system of the blocked solver (k_lmbig.hip), (ld + 48) x ld, else nullptr
   int ld;
-  int32_t* lmb_flags;   // [ld / 48 + 1], zero between trials
+  int32_t* lmb_flags;   // [2 ld / 48 + 2]: [KT] bad pivot, [KT + 1 ...] the back substitution's column flags
   double* lmb_inv;      // [ld / 48][3][256]: inverses of the 16 x 16 diagonal blocks of the factorised diagonal tiles
   double *chi2_out, *poses_out, *points_out;
   uint8_t *bad, *level_out;
