@@ -557,6 +557,13 @@ def latency_leg(device_id, n=500):
         ctx.stereo_match(0, 1, FX, BF)
     out = {"pair": "synthetic KITTI-shaped frame 0, 1241x376, 2000 features per image", "verified": True,
            "extract_batch_plus_match": dict(_stats_ms(one, n, warm=30), what="orbfe_extract_batch([L, R]) + orbfe_stereo_match, host to host, from Python")}
+    # Frame::createStereo's device work (Frame.h:313-323: two extractions, then searchByStereo) as ONE call: the same kernels in one
+    # launch sequence, one synchronisation
+    (flk, fld), (frk, frd), fnm, fru, fdp = ctx.frame_stereo(L, R, FX, BF)
+    if pair_digest(flk, fld, frk, frd, fru, fdp, fnm) != gold["0"]:
+        raise SystemExit("bench.py: latency leg: orbfe_frame_stereo differs from the golden digest")
+    out["frame_stereo_one_call"] = dict(_stats_ms(lambda: ctx.frame_stereo(L, R, FX, BF), n, warm=30),
+                                        what="orbfe_frame_stereo(L, R): both extractions + the stereo match as one launch sequence, host to host, from Python")
     # the per-frame guided matchers of Tracking (searchByProjection x 2-4 per frame over findFeaturesInArea + getBestMatch, src/ORBMatcher.cc:
     # 265-347, 561-612; MapPoint::isInVision, src/MapPoint.cc:141-201): 1000 queries against the 2000 features of the frame just built
     r = np.random.default_rng(0)
@@ -660,6 +667,12 @@ def latency_leg(device_id, n=500):
             "what": "ORB_SLAM2_ROS2::ORBExtractor x 2 on two std::threads (orbfe_extract_slot each, thread start / join included as in "
                     "Frame::Frame) + searchByStereo, C++ drop-in, host cv::Mat in, std::vector<cv::KeyPoint> / cv::Mat descriptors out"}
         out["same_objects_one_thread"] = {"median_ms": float(f[5]) / 1e3, "p99_ms": float(f[6]) / 1e3, "extract_median_ms": float(f[7]) / 1e3}
+        if len(f) >= 13:
+            out["createStereo_one_call_cpp"] = {
+                "median_ms": float(f[11]) / 1e3, "p99_ms": float(f[12]) / 1e3,
+                "what": "the same Frame built by orbfe::dropin::createStereo (ORBExtractor::extractStereo -> orbfe_frame_stereo_slots): both "
+                        "extractions and the stereo match as one device call in place of the two threads and searchByStereo; every frame "
+                        "hashed equal to the two-thread one"}
         out["cpp_hw_queues"] = int(env["GPU_MAX_HW_QUEUES"])
     except (subprocess.CalledProcessError, RuntimeError, OSError) as ex:
         out["two_threads_extract_slot_plus_match"] = {"error": f"{type(ex).__name__}: {ex}"}

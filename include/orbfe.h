@@ -149,6 +149,23 @@ orbfe_status orbfe_get_pyramid(orbfe_ctx* ctx, int32_t slot, int32_t level, int3
 orbfe_status orbfe_stereo_match(orbfe_ctx* ctx, int32_t slot_left, int32_t slot_right, float fx, float bf, double* right_u,
                                 double* depth, int32_t* n_matches, int32_t* best_right, int32_t* best_dist);
 
+/* ---- one stereo frame, host images in, everything out: ONE call -------------------------------
+ * The device work of Frame::createStereo (include/ORB_SLAM2/Frame.h:313-323: the Frame constructor, src/ORB_SLAM2/src/Frame.cc:85-110,
+ * with ORBExtractor::extract on the left and the right image, then ORBMatcher::searchByStereo, src/ORB_SLAM2/src/ORBMatcher.cc:18):
+ * left -> slot 0, right -> slot 1, their stereo match behind them in the same launch
+ * sequence, one synchronisation.  kps / desc / n_out as orbfe_extract_batch with two images ([2][n_features]), right_u / depth as
+ * orbfe_stereo_match.  Results are those of orbfe_extract_batch([left, right]) + orbfe_stereo_match(0, 1): the same kernels in the
+ * same order; what the call saves is the second call's launch, copy and wake-up (tests/test_gpu_frame_stereo.py compares them).   */
+orbfe_status orbfe_frame_stereo(orbfe_ctx* ctx, const uint8_t* left, const uint8_t* right, size_t stride_bytes, float fx, float bf,
+                                orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out, double* right_u, double* depth,
+                                int32_t* n_matches);
+/* The same into the slot pair (slot_left, slot_left + 1), slot_left even, on slot_left's lane -- concurrent with slot calls on other
+ * slots, lifetime of the device-resident results as for orbfe_extract_slot (the drop-in's createStereo adapter rotates over the pairs
+ * of its context: host/orbfe_dropin.hpp).                                                                                          */
+orbfe_status orbfe_frame_stereo_slots(orbfe_ctx* ctx, int32_t slot_left, const uint8_t* left, const uint8_t* right, size_t stride_bytes,
+                                      float fx, float bf, orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out, double* right_u,
+                                      double* depth, int32_t* n_matches);
+
 /* ---- whole stereo pairs, images already in device memory --------------------------------------
  * d_left/d_right: device pointers to n_pairs images each, image p at base + p*image_pitch_bytes,
  * rows stride_bytes apart.  Pair p uses slots 2p (left) and 2p+1 (right).  Asynchronous on the

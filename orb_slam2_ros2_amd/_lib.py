@@ -5,6 +5,7 @@ There is no fallback: if the HIP library is missing or no device is usable this 
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import os
 
 import numpy as np
@@ -111,7 +112,7 @@ class BaEdgeOut(C.Structure):
 EXPORTS = [
     "orbfe_abi_version", "orbfe_create", "orbfe_destroy", "orbfe_last_error", "orbfe_get_level_info", "orbfe_get_scale_factors",
     "orbfe_get_capacity",
-    "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_slot", "orbfe_extract_slots", "orbfe_fetch_batch", "orbfe_fetch_stereo_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
+    "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_slot", "orbfe_extract_slots", "orbfe_frame_stereo", "orbfe_frame_stereo_slots", "orbfe_fetch_batch", "orbfe_fetch_stereo_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
     "orbfe_host_alloc", "orbfe_host_alloc_on", "orbfe_host_free", "orbfe_recommended_hw_queues", "orbfe_stream_submit", "orbfe_stream_wait", "orbfe_stream_device_results", "orbfe_record_bytes", "orbfe_stream_pack_records",
     "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_search_in_area_features", "orbfe_search_in_area_features_ex", "orbfe_extract_color", "orbfe_frame_rgbd", "orbfe_project_map_points", "orbfe_track_local_map",
     "orbfe_map_pb_summary", "orbfe_map_pb_reencode", "orbfe_map_pb_to_txt", "orbfe_map_txt_to_pb", "orbfe_map_local_graph", "orbfe_map_local_ba",
@@ -152,6 +153,8 @@ def load() -> C.CDLL:
     L.orbfe_extract_batch.argtypes = [vp, i32, vp, C.c_size_t, vp, vp, vp]
     L.orbfe_extract_slot.argtypes = [vp, i32, vp, C.c_size_t, vp, vp, vp]
     L.orbfe_extract_slots.argtypes = [vp, i32, i32, vp, C.c_size_t, vp, vp, vp]
+    L.orbfe_frame_stereo.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp]
+    L.orbfe_frame_stereo_slots.argtypes = [vp, i32, vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp]
     L.orbfe_fetch_batch.argtypes = [vp, i32, i32, vp, vp, vp]
     L.orbfe_fetch_stereo_batch.argtypes = [vp, i32, i32, vp, vp, vp]
     L.orbfe_get_pyramid.argtypes = [vp, i32, i32, i32, vp]
@@ -337,9 +340,9 @@ class Context:
         return out
 
     # ---- extraction -------------------------------------------------------------------------
-    def extract_batch(self, imgs):
+    def _host_images(self, imgs):
+        """the images as the library reads them (uint8 rows of one stride >= width) and that stride"""
         imgs = [np.asarray(im) for im in imgs]
-        n = len(imgs)
         for im in imgs:
             if im.shape != (self.height, self.width):
                 raise ValueError(f"image shape {im.shape} != context geometry {(self.height, self.width)}")
@@ -348,13 +351,46 @@ class Context:
         if not (len(strides) == 1 and all(im.dtype == np.uint8 and im.strides[1] == 1 and im.strides[0] >= self.width for im in imgs)):
             imgs = [np.ascontiguousarray(im, np.uint8) for im in imgs]
             strides = {self.width}
-        stride = strides.pop() if n else self.width
+        return imgs, (strides.pop() if imgs else self.width)
+
+    def _result_arrays(self, n):
+        """the [n][n_features] arrays a call's results land in: kept per context and image count (the first touch of a quarter of a
+        megabyte of fresh pages was a fifth of a one-pair call); what the caller gets are copies of the filled parts"""
+        cache = self.__dict__.setdefault("_res_cache", {})
+        n = (threading.get_ident(), n)  # (a set per calling thread: the copies are taken after the library call has returned)
+        if n not in cache:
+            nf = max(self.n_features, 1)
+            n_img = n[1]
+            cache[n] = (np.zeros((max(n_img, 1), nf), KP_DTYPE), np.zeros((max(n_img, 1), nf, 32), np.uint8), np.zeros(max(n_img, 1), np.int32),
+                        np.zeros(nf, np.float64), np.zeros(nf, np.float64))
+        return cache[n]
+
+    def extract_batch(self, imgs):
+        imgs, stride = self._host_images(imgs)
+        n = len(imgs)
         arr = (C.c_void_p * max(n, 1))(*[im.ctypes.data for im in imgs])
-        kps = np.zeros((max(n, 1), max(self.n_features, 1)), KP_DTYPE)
-        desc = np.zeros((max(n, 1), max(self.n_features, 1), 32), np.uint8)
-        cnt = np.zeros(max(n, 1), np.int32)
+        if n <= 2:
+            kps, desc, cnt = self._result_arrays(n)[:3]
+        else:
+            kps = np.zeros((n, max(self.n_features, 1)), KP_DTYPE)
+            desc = np.zeros((n, max(self.n_features, 1), 32), np.uint8)
+            cnt = np.zeros(n, np.int32)
         self._check(self.lib.orbfe_extract_batch(self.h, n, arr, stride, ptr(kps), ptr(desc), ptr(cnt)))
         return [(kps[i, :cnt[i]].copy(), desc[i, :cnt[i]].copy()) for i in range(n)]
+
+    def frame_stereo(self, left, right, fx, bf, slot_left=None):
+        """orbfe_frame_stereo: both extractions and the stereo match of one frame as one call (Frame::createStereo's device work).
+        -> ((kpsL, descL), (kpsR, descR), n_matches, right_u, depth); slot_left (even): orbfe_frame_stereo_slots into that slot pair"""
+        (left, right), stride = self._host_images([left, right])
+        kps, desc, cnt, ru, dp = self._result_arrays(2)
+        nm = C.c_int32(0)
+        if slot_left is None:
+            self._check(self.lib.orbfe_frame_stereo(self.h, left.ctypes.data, right.ctypes.data, stride, fx, bf, ptr(kps), ptr(desc), ptr(cnt),
+                                                    ptr(ru), ptr(dp), C.byref(nm)))
+        else:
+            self._check(self.lib.orbfe_frame_stereo_slots(self.h, slot_left, left.ctypes.data, right.ctypes.data, stride, fx, bf, ptr(kps),
+                                                          ptr(desc), ptr(cnt), ptr(ru), ptr(dp), C.byref(nm)))
+        return ((kps[0, :cnt[0]].copy(), desc[0, :cnt[0]].copy()), (kps[1, :cnt[1]].copy(), desc[1, :cnt[1]].copy()), nm.value, ru.copy(), dp.copy())
 
     def extract(self, img):
         return self.extract_batch([img])[0]

@@ -34,43 +34,75 @@ __device__ __forceinline__ int grid_cell(float v, int size, int n) {
 // ---------------------------------------------------------------------------------------------
 // grid build: one workgroup per call.  cell_off[ncells+1], cell_feat[n] (features of a cell in ascending index).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_grid_build(const orbfe_keypoint* __restrict__ kps, const int32_t* __restrict__ n_kp_ptr,
-                                                    int rows, int cols, int32_t* __restrict__ cell_off, int32_t* __restrict__ cell_feat) {
-  extern __shared__ int32_t l_grid[];  // [ncells + 1] offsets, then [ncells] fill cursors
+#define GRID_NT 1024
+__global__ __launch_bounds__(GRID_NT) void k_grid_build(const orbfe_keypoint* __restrict__ kps, const int32_t* __restrict__ n_kp_ptr,
+                                                        int rows, int cols, int feat_in_lds, int32_t* __restrict__ cell_off,
+                                                        int32_t* __restrict__ cell_feat) {
+  // [ncells + 1] offsets, [ncells] counts / fill cursors, then (feat_in_lds) the [n] unordered feature lists and the [n] cells of the features
+  extern __shared__ int32_t l_grid[];
+  __shared__ int32_t l_scan[GRID_NT];
+  const int tid = threadIdx.x;
   const int n = *n_kp_ptr;
   const int ncells = rows * cols;
   int32_t* l_off = l_grid;
   int32_t* l_cur = l_grid + ncells + 1;
-  for (int c = threadIdx.x; c <= ncells; c += 256) {
-    l_off[c] = 0;
-    if (c < ncells) l_cur[c] = 0;
+  int32_t* feat = feat_in_lds ? l_cur + ncells : cell_feat;
+  int32_t* l_cell = feat + n;  // (feat_in_lds only)
+  for (int c = tid; c < ncells; c += GRID_NT) l_cur[c] = 0;
+  __syncthreads();
+  // The coordinates are read ONCE (a thread's loads independent of each other) and the cell kept in LDS: with 256 threads each of the
+  // three passes below walked eight dependent trips to memory, ~1 us each -- 24 of this kernel's 27 us.
+  for (int i = tid; i < n; i += GRID_NT) {
+    const int cell = grid_cell(kps[i].y, GRID_H, rows) * cols + grid_cell(kps[i].x, GRID_W, cols);
+    if (feat_in_lds) l_cell[i] = cell;
+    atomicAdd(&l_cur[cell], 1);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int r = grid_cell(kps[i].y, GRID_H, rows), c = grid_cell(kps[i].x, GRID_W, cols);
-    atomicAdd(&l_off[r * cols + c + 1], 1);
-  }
+  // exclusive prefix over the cells: a thread sums a run of consecutive cells, the run totals are scanned, the thread writes its run's offsets
+  const int per = (ncells + GRID_NT - 1) / GRID_NT;
+  const int c0 = min(tid * per, ncells), c1 = min(c0 + per, ncells);
+  int local = 0;
+  for (int c = c0; c < c1; ++c) local += l_cur[c];
+  l_scan[tid] = local;
   __syncthreads();
-  if (threadIdx.x == 0) {  // exclusive prefix (a few hundred cells)
-    int acc = 0;
-    for (int c = 0; c < ncells; ++c) {
-      const int k = l_off[c + 1];
+  for (int o = 1; o < GRID_NT; o <<= 1) {
+    const int v = tid >= o ? l_scan[tid - o] : 0;
+    __syncthreads();
+    l_scan[tid] += v;
+    __syncthreads();
+  }
+  {
+    int acc = l_scan[tid] - local;
+    for (int c = c0; c < c1; ++c) {
+      const int k = l_cur[c];
       l_off[c] = acc;
+      l_cur[c] = 0;
       acc += k;
     }
-    l_off[ncells] = acc;
+    if (tid == GRID_NT - 1) l_off[ncells] = l_scan[GRID_NT - 1];
   }
   __syncthreads();
-  for (int c = threadIdx.x; c <= ncells; c += 256) cell_off[c] = l_off[c];
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int r = grid_cell(kps[i].y, GRID_H, rows), c = grid_cell(kps[i].x, GRID_W, cols);
-    const int cell = r * cols + c;
-    cell_feat[l_off[cell] + atomicAdd(&l_cur[cell], 1)] = i;
+  for (int c = tid; c <= ncells; c += GRID_NT) cell_off[c] = l_off[c];
+  for (int i = tid; i < n; i += GRID_NT) {
+    const int cell = feat_in_lds ? l_cell[i] : grid_cell(kps[i].y, GRID_H, rows) * cols + grid_cell(kps[i].x, GRID_W, cols);
+    feat[l_off[cell] + atomicAdd(&l_cur[cell], 1)] = i;
   }
   __syncthreads();
-  // the reference pushes indices in ascending order (Frame.cc:61-68): sort every (short) cell list
-  for (int c = threadIdx.x; c < ncells; c += 256) {
-    int32_t* L = cell_feat + l_off[c];
+  // the reference pushes indices in ascending order (Frame.cc:61-68)
+  if (feat_in_lds) {
+    // every feature finds its place in its cell's list by counting the smaller indices there: the work of a sort, spread over the threads
+    // (one thread sorting the densest cell of a clustered frame was the long pole of the per-cell sort below)
+    for (int i = tid; i < n; i += GRID_NT) {
+      const int cell = l_cell[i];
+      const int base = l_off[cell], k = l_off[cell + 1] - base;
+      int rank = 0;
+      for (int j = 0; j < k; ++j) rank += feat[base + j] < i ? 1 : 0;
+      cell_feat[base + rank] = i;
+    }
+    return;
+  }
+  for (int c = tid; c < ncells; c += GRID_NT) {
+    int32_t* L = feat + l_off[c];
     const int k = l_off[c + 1] - l_off[c];
     for (int a = 1; a < k; ++a) {
       const int32_t v = L[a];
@@ -380,10 +412,14 @@ void launch_project_map_points(hipStream_t s, int n, const float* d_pos, const f
                      d_level, d_vis);
 }
 
-void launch_grid_build(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, int rows, int cols, int32_t* d_cell_off,
-                       int32_t* d_cell_feat) {
-  const size_t lds = (size_t)(2 * rows * cols + 1) * sizeof(int32_t);
-  hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), lds, s, d_kps, d_n_kp, rows, cols, d_cell_off, d_cell_feat);
+void launch_grid_build(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, int n_cap, int rows, int cols,
+                       int32_t* d_cell_off, int32_t* d_cell_feat) {
+  // n_cap: upper bound of *d_n_kp; the cells' lists are filled and ordered in LDS when they fit there
+  const size_t base = (size_t)(2 * rows * cols + 1) * sizeof(int32_t);
+  const size_t lists = (size_t)n_cap * 2 * sizeof(int32_t);
+  const bool in_lds = base + lists <= 56 * 1024;
+  hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(GRID_NT), in_lds ? base + lists : base, s, d_kps, d_n_kp, rows, cols, in_lds ? 1 : 0,
+                     d_cell_off, d_cell_feat);
 }
 
 void launch_search_area(hipStream_t s, const uint4* d_kpl, const uint8_t* d_desc, int width, int height, int rows, int cols,

@@ -380,6 +380,8 @@ __device__ long long g_pose_stamps[8];
 #define PS(k)
 #define PS_COUNT(k)
 #endif
+#define POSE_TRIALS 10  // g2o's Levenberg-Marquardt gives an iteration at most 10 trial steps (qmax)
+#define POSE_STAGE_LD (256 + 8)  // doubles per row of the staged sums: rows 8 double-banks apart => the 8 x 8 readers of a wave 2 per bank pair
 template <int NT>
 struct PoseSharedR {
   PoseDev T, T0, backup;
@@ -387,6 +389,12 @@ struct PoseSharedR {
   double red[28][NT / 64];
   double lambda, ni, current_chi, rho;
   int qmax, cont_inner, stop_outer, accepted, n_bad;
+  // every trial step an iteration can take, solved at once on POSE_TRIALS lanes when its system is built (see the build site)
+  PoseDev trial_T[POSE_TRIALS];
+  double trial_x[POSE_TRIALS][6];
+  int trial_ok[POSE_TRIALS];
+  // the 27 sums of the normal equations staged per thread (256-thread kernel; the 512-thread one reduces in registers)
+  double stage[NT == 256 ? 27 * POSE_STAGE_LD : 1];
 };
 template <int NT>
 __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __restrict__ Xw, const double* __restrict__ meas,
@@ -485,18 +493,16 @@ __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __res
       for (;;) {
         PS(0)
         if (do_solve) {
-          if (tid == 0) {
+          if (tid == 0) {  // trial S.qmax of this iteration: solved when the system was built
+            const int q = S.qmax;
             S.backup = S.T;
-            double xs[6] = {0, 0, 0, 0, 0, 0};
-            S.cont_inner = solve6_lambda(S.H, S.lambda, S.b, xs) ? 1 : 0;  // ok2
-            for (int j = 0; j < 6; ++j) S.x[j] = xs[j];
-            PoseDev Tn;
-            pose_oplus(S.T, xs, Tn);
-            S.T = Tn;
+            S.cont_inner = S.trial_ok[q];  // ok2
+            for (int j = 0; j < 6; ++j) S.x[j] = S.trial_x[q][j];
+            S.T = S.trial_T[q];
           }
           __syncthreads();
         }
-        PS(1)  // solve + oplus
+        PS(1)  // trial step taken
         PS_COUNT(6)
         // computeActiveErrors + activeRobustChi2 at S.T -- the ONE evaluation site
         double chi;
@@ -609,27 +615,59 @@ __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __res
               for (int c2 = a; c2 < 6; ++c2) acc[k++] += J[0][a] * (r1 * w) * J[0][c2] + J[1][a] * (r1 * w) * J[1][c2] + J[2][a] * (r1 * w) * J[2][c2];
             }
           }
+          PS(5)  // build: per-edge arithmetic
+          if constexpr (NT == 256) {
+            // every thread stages its 27 partial sums; eight threads per sum add 32 staged values each (ascending), a fixed tree joins the
+            // eight: 27 + 32 LDS accesses and 35 additions per thread, where 27 wave trees of data-parallel-primitive moves took as long as
+            // the edges' arithmetic (6.7 k of a build's 13.5 k cycles)
 #pragma unroll
-          for (int k = 0; k < 27; ++k) {
-            const double w = wave_sum_f64(acc[k]);
-            if (lane == 0) S.red[k][wv] = w;
-          }
-          __syncthreads();
-          if (tid < 27) {
-            double sm = 0;
+            for (int k = 0; k < 27; ++k) S.stage[k * POSE_STAGE_LD + tid] = acc[k];
+            __syncthreads();
+            if (tid < 27 * 8) {
+              const int k = tid >> 3, part = tid & 7;
+              const double* row = S.stage + k * POSE_STAGE_LD + part;
+              double sm = 0;
 #pragma unroll
-            for (int k = 0; k < NT / 64; ++k) sm += S.red[tid][k];
-            if (tid >= 21) {
-              S.b[tid - 21] = sm;
-            } else {  // tid -> (a, c2), a <= c2, in the order the sums were laid out
-              int a = 0, rem = tid;
-              while (rem >= 6 - a) rem -= 6 - a, ++a;
-              const int c2 = a + rem;
-              S.H[6 * a + c2] = sm;
-              S.H[6 * c2 + a] = sm;
+              for (int j = 0; j < 32; ++j) sm += row[8 * j];
+              sm += dpp_f64<ORBFE_DPP_ROW_SHR(1), 0xf>(sm);  // lanes 8 m + 7 of a row of 16 end up with the sum of their eight
+              sm += dpp_f64<ORBFE_DPP_ROW_SHR(2), 0xf>(sm);
+              sm += dpp_f64<ORBFE_DPP_ROW_SHR(4), 0xf>(sm);
+              if (part == 7) {
+                if (k >= 21) {
+                  S.b[k - 21] = sm;
+                } else {  // k -> (a, c2), a <= c2, in the order the sums were laid out
+                  int a = 0, rem = k;
+                  while (rem >= 6 - a) rem -= 6 - a, ++a;
+                  const int c2 = a + rem;
+                  S.H[6 * a + c2] = sm;
+                  S.H[6 * c2 + a] = sm;
+                }
+              }
             }
+            __syncthreads();
+          } else {
+#pragma unroll
+            for (int k = 0; k < 27; ++k) {
+              const double w = wave_sum_f64(acc[k]);
+              if (lane == 0) S.red[k][wv] = w;
+            }
+            __syncthreads();
+            if (tid < 27) {
+              double sm = 0;
+#pragma unroll
+              for (int k = 0; k < NT / 64; ++k) sm += S.red[tid][k];
+              if (tid >= 21) {
+                S.b[tid - 21] = sm;
+              } else {  // tid -> (a, c2), a <= c2, in the order the sums were laid out
+                int a = 0, rem = tid;
+                while (rem >= 6 - a) rem -= 6 - a, ++a;
+                const int c2 = a + rem;
+                S.H[6 * a + c2] = sm;
+                S.H[6 * c2 + a] = sm;
+              }
+            }
+            __syncthreads();
           }
-          __syncthreads();
         }
         PS(4)  // build
         if (tid == 0) {
@@ -645,6 +683,23 @@ __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __res
           S.stop_outer = 0;
         }
         __syncthreads();
+        // The trial steps of this iteration, all at once: a rejected trial multiplies lambda by ni and doubles ni, the system and the pose
+        // it starts from stay -- so trial q's damping is known now, and lane q solves (H + lambda_q I) x = b and applies x to the pose
+        // beside the others (one instruction stream; a call of 28 iterations takes ~59 trials, most of the rejected ones in the runs of ten
+        // that end a converged round).  Same recurrence, same solve, same update as taking them one by one.
+        if (tid < POSE_TRIALS) {
+          double lam = S.lambda, ni = S.ni;
+          for (int q = 0; q < tid; ++q) lam *= ni, ni *= 2;
+          double xs[6] = {0, 0, 0, 0, 0, 0};
+          const bool ok = solve6_lambda(S.H, lam, S.b, xs);
+          PoseDev Tn;
+          pose_oplus(S.T, xs, Tn);
+          S.trial_T[tid] = Tn;
+          for (int j = 0; j < 6; ++j) S.trial_x[tid][j] = xs[j];
+          S.trial_ok[tid] = ok ? 1 : 0;
+        }
+        __syncthreads();
+        PS(1)  // solve + oplus of the iteration's trials
         do_solve = true;
       }
     }

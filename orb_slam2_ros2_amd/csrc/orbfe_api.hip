@@ -98,7 +98,7 @@ void launch_ba_system(hipStream_t s, int n_poses, int n_points, int n_edges, con
 void launch_project_map_points(hipStream_t s, int n, const float* d_pos, const float* d_vdir, const float* d_max, const float* d_min,
                                const float* R, const float* t, const float* cam4, const float* bounds4, float log_sf, int max_level,
                                float* d_uv, float* d_dist, float* d_cos, int8_t* d_level, uint8_t* d_vis);
-void launch_grid_build(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, int rows, int cols, int32_t* d_cell_off,
+void launch_grid_build(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, int n_cap, int rows, int cols, int32_t* d_cell_off,
                        int32_t* d_cell_feat);
 void launch_search_area(hipStream_t s, const uint4* d_kpl, const uint8_t* d_desc, int width, int height, int rows, int cols,
                         const int32_t* d_cell_off, const int32_t* d_cell_feat, int nq, const float* d_qxy, const float* d_radius,
@@ -149,6 +149,8 @@ struct orbfe_ctx {
   struct GraphEntry {
     int slot0, n_img;
     bool want_kps, want_desc;
+    bool stereo;   // the stereo match of the two slots rides in the graph (orbfe_frame_stereo), with these camera constants
+    float fx, bf;
     const uint8_t* stage;
     const uint8_t* pyr;  // the pyramid buffer baked into the captured kernels (the pipelined batch path swaps the context's two buffers)
     hipGraphExec_t exec;
@@ -1012,11 +1014,11 @@ struct StereoHostOut {  // page-locked destinations for the results of one pair,
   int32_t *best_right, *best_dist;
 };
 static orbfe_status run_stereo(orbfe_ctx* c, hipStream_t st, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs, float fx,
-                               float bf, const StereoHostOut* ho = nullptr, bool table_ready = false) {
+                               float bf, const StereoHostOut* ho = nullptr, bool table_ready = false, bool timing = true) {
   // (c->d_pyr is read here, at launch time: a later swap of the pyramid buffers does not affect a launch already queued)
   // (the match counters are zeroed by k_rowtable)
   {
-    StageTimer t(c, ORBFE_STAGE_STEREO, st);
+    StageTimer t(c, ORBFE_STAGE_STEREO, st, timing);  // (timing = false: a slot lane, which touches nothing the context shares)
     launch_stereo(st, c->d_lv, c->cfg.n_levels, c->d_pyr, c->img_pitch, c->d_kps, c->d_desc, c->d_aux, c->d_kx,
                   table_ready ? c->d_rowoff_slot : c->d_rowoff, table_ready ? c->d_rowlist_slot : c->d_rowlist,
                   c->cfg.height, c->row_list_cap, c->d_n_kp,
@@ -1438,13 +1440,21 @@ static orbfe_status fetch_extract_results(orbfe_ctx* c, int n_img, size_t o_kps,
 
 // Host images -> slots [slot0, slot0 + n_img) on lane `ln`: copy-in, the launch sequence, results back, one synchronisation.  One or
 // two images (the drop-in call shape) are launch-bound: the whole sequence is captured once per lane into a hipGraph and replayed.
+// fs (orbfe_frame_stereo; two images): the stereo match of (slot0, slot0 + 1) follows the extraction in the same launch sequence, its
+// results come back through the staging buffer as the features do
+struct FrameStereoReq {
+  float fx, bf;
+  double *right_u, *depth;  // [n_features], caller's
+  int32_t* n_matches;
+};
 static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, int n_img, const uint8_t* const* imgs, size_t stride,
-                                 orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out, bool timing) {
+                                 orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out, bool timing, const FrameStereoReq* fs = nullptr) {
   const LevelDev& L0 = c->lv[0];
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
   const size_t plane = align_up((size_t)L0.stride * L0.h, 256);
   const size_t o_kps = (size_t)n_img * plane, o_desc = o_kps + align_up((size_t)n_img * NF * sizeof(orbfe_keypoint), 256);
-  const size_t o_cnt = o_desc + align_up((size_t)n_img * NF * 32, 256), total = o_cnt + align_up((size_t)n_img * 4, 256);
+  const size_t o_cnt = o_desc + align_up((size_t)n_img * NF * 32, 256), o_ru = o_cnt + align_up((size_t)n_img * 4, 256);
+  const size_t o_dp = o_ru + (fs ? align_up(NF * 8, 256) : 0), total = o_dp + (fs ? align_up(NF * 8, 256) : 0);
   TRY(ensure_stage(c, ln, total));
   for (int i = 0; i < n_img; ++i) {
     if (!imgs[i]) return fail(c, ORBFE_EBADARG, "extract: image %d is NULL", i);
@@ -1464,8 +1474,30 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
     HIP_TRY(c, hipMemcpy2DAsync(pyr_now + (size_t)slot0 * c->img_pitch + L0.plane_off, c->img_pitch, ln.h_stage, plane, (size_t)L0.stride * L0.h,
                                 (size_t)n_img, hipMemcpyHostToDevice, ln.stream));
     TRY(run_extract(c, ln.stream, slot0, n_img, nullptr, timing, nullptr, mirror_on ? &mir : nullptr));
+    if (fs) {
+      // the right image's row table and the zeroed pair counter come out of the extraction above when this context builds them there
+      const StereoHostOut ho = {(double*)(ln.h_stage + o_ru), (double*)(ln.h_stage + o_dp), nullptr, nullptr};
+      const bool table_ready = c->slot_table_ok && c->slot_table_ok[(size_t)slot0 + 1] != 0;
+      TRY(run_stereo(c, ln.stream, slot0, slot0 + 1, 0, slot0 / 2, 1, fs->fx, fs->bf, &ho, table_ready, timing));
+    }
     if (mirror_on) return ORBFE_OK;
     return enqueue_fetch(c, ln, slot0, n_img, o_kps, o_desc, o_cnt, kps != nullptr, desc != nullptr);
+  };
+  // the match has counted into the pair's counter: a later orbfe_stereo_match on these slots clears it first
+  auto finish = [&]() -> orbfe_status {
+    TRY(finish_fetch(c, ln, n_img, o_kps, o_desc, o_cnt, kps, desc, n_out, timing));
+    if (fs) {
+      if (c->pair_count_zero) c->pair_count_zero[(size_t)(slot0 / 2)] = 0;
+      const double* ru = (const double*)(ln.h_stage + o_ru);
+      const double* dp = (const double*)(ln.h_stage + o_dp);
+      const size_t n = (size_t)c->cfg.n_features;
+      int32_t nm = 0;  // k_stereo counts exactly the features it gives a right coordinate (>= 0; -1 otherwise)
+      for (size_t i = 0; i < n; ++i) nm += ru[i] >= 0.0 ? 1 : 0;
+      if (fs->right_u && n) std::memcpy(fs->right_u, ru, sizeof(double) * n);
+      if (fs->depth && n) std::memcpy(fs->depth, dp, sizeof(double) * n);
+      if (fs->n_matches) *fs->n_matches = nm;
+    }
+    return ORBFE_OK;
   };
   if (c->use_graphs && ln.use_graphs && c->prof == 0 && n_img <= 2) {
     hipGraphExec_t exec = nullptr;
@@ -1475,7 +1507,8 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
         it = ln.graphs.erase(it);
         continue;
       }
-      if (it->slot0 == slot0 && it->n_img == n_img && it->want_kps == (kps != nullptr) && it->want_desc == (desc != nullptr) && it->pyr == pyr_now)
+      if (it->slot0 == slot0 && it->n_img == n_img && it->want_kps == (kps != nullptr) && it->want_desc == (desc != nullptr) && it->pyr == pyr_now &&
+          it->stereo == (fs != nullptr) && (!fs || (it->fx == fs->fx && it->bf == fs->bf)))
         exec = it->exec;
       ++it;
     }
@@ -1487,7 +1520,7 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
       if (ok) ok = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess;
       if (g) (void)hipGraphDestroy(g);
       if (ok) {
-        ln.graphs.push_back({slot0, n_img, kps != nullptr, desc != nullptr, ln.h_stage, pyr_now, exec});
+        ln.graphs.push_back({slot0, n_img, kps != nullptr, desc != nullptr, fs != nullptr, fs ? fs->fx : 0.f, fs ? fs->bf : 0.f, ln.h_stage, pyr_now, exec});
       } else {
         (void)hipGetLastError();
         exec = nullptr;
@@ -1496,11 +1529,11 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
     }
     if (exec) {
       HIP_TRY(c, hipGraphLaunch(exec, ln.stream));
-      return finish_fetch(c, ln, n_img, o_kps, o_desc, o_cnt, kps, desc, n_out, timing);
+      return finish();
     }
   }
   TRY(enqueue_all());
-  return finish_fetch(c, ln, n_img, o_kps, o_desc, o_cnt, kps, desc, n_out, timing);
+  return finish();
 }
 
 orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* const* imgs, size_t stride, orbfe_keypoint* kps,
@@ -1515,6 +1548,23 @@ orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* con
   return extract_lane(c, c->main, 0, n_img, imgs, stride, kps, desc, n_out, true);
 }
 
+// The device work of Frame::createStereo (include/ORB_SLAM2/Frame.h:313-323: the constructor's two extractions, src/Frame.cc:100-105,
+// then ORBMatcher::searchByStereo) as ONE call: both images up, the extraction of slots 0 and 1 and their stereo match as one launch sequence (one graph replay), every
+// result back through the staging buffer, one synchronisation.  Same results as orbfe_extract_batch([left, right]) followed by
+// orbfe_stereo_match(0, 1) -- the same kernels in the same order -- without the second call's launch, copy and wake-up.
+orbfe_status orbfe_frame_stereo(orbfe_ctx* c, const uint8_t* left, const uint8_t* right, size_t stride, float fx, float bf,
+                                orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out, double* right_u, double* depth, int32_t* n_matches) {
+  ApiLock api_lk(c);
+  if (!c || !left || !right) return fail(c, ORBFE_EBADARG, "frame_stereo: NULL argument");
+  if (c->cfg.max_images < 2) return fail(c, ORBFE_ECAPACITY, "frame_stereo: the context holds %d image(s), a stereo frame needs 2", c->cfg.max_images);
+  if (stride < (size_t)c->cfg.width) return fail(c, ORBFE_EBADARG, "frame_stereo: stride %zu < width %d", stride, c->cfg.width);
+  HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
+  const uint8_t* imgs[2] = {left, right};
+  const FrameStereoReq fs = {fx, bf, right_u, depth, n_matches};
+  return extract_lane(c, c->main, 0, 2, imgs, stride, kps, desc, n_out, true, &fs);
+}
+
 // One image -> slot `slot` on that slot's own lane.  Calls on DIFFERENT slots may run at the same time on different threads.
 orbfe_status orbfe_extract_slot(orbfe_ctx* c, int32_t slot, const uint8_t* img, size_t stride, orbfe_keypoint* kps, uint8_t* desc,
                                 int32_t* n_out) {
@@ -1524,8 +1574,8 @@ orbfe_status orbfe_extract_slot(orbfe_ctx* c, int32_t slot, const uint8_t* img, 
 
 // n_img images -> slots [slot0, slot0 + n_img) on slot0's lane: what a caller does who holds BOTH images of a stereo frame when the
 // first extract() is reached (host/orbfe_shim.hpp keeps one orbfe_extract_slot per extract() thread: pairing the threads was measured and dropped)
-orbfe_status orbfe_extract_slots(orbfe_ctx* c, int32_t slot, int32_t n_img, const uint8_t* const* imgs, size_t stride, orbfe_keypoint* kps,
-                                 uint8_t* desc, int32_t* n_out) {
+static orbfe_status extract_slots_impl(orbfe_ctx* c, int32_t slot, int32_t n_img, const uint8_t* const* imgs, size_t stride, orbfe_keypoint* kps,
+                                       uint8_t* desc, int32_t* n_out, const FrameStereoReq* fs) {
   if (!c || !imgs || n_img < 1) return fail(c, ORBFE_EBADARG, "extract_slots: NULL argument / no image");
   const uint8_t* img = imgs[0];
   if (!img) return fail(c, ORBFE_EBADARG, "extract_slot: NULL argument");
@@ -1566,7 +1616,23 @@ orbfe_status orbfe_extract_slots(orbfe_ctx* c, int32_t slot, int32_t n_img, cons
     HIP_TRY(c, hipEventRecord(ln->ev_main, c->stream));
     HIP_TRY(c, hipStreamWaitEvent(ln->stream, ln->ev_main, 0));
   }
-  return extract_lane(c, *ln, slot, n_img, imgs, stride, kps, desc, n_out, false);
+  return extract_lane(c, *ln, slot, n_img, imgs, stride, kps, desc, n_out, false, fs);
+}
+orbfe_status orbfe_extract_slots(orbfe_ctx* c, int32_t slot, int32_t n_img, const uint8_t* const* imgs, size_t stride, orbfe_keypoint* kps,
+                                 uint8_t* desc, int32_t* n_out) {
+  return extract_slots_impl(c, slot, n_img, imgs, stride, kps, desc, n_out, nullptr);
+}
+// orbfe_frame_stereo into the slot pair (slot_left, slot_left + 1), slot_left even, on slot_left's lane: what the drop-in's frame-level
+// adapter calls (the extractor objects rotate over the context's slots; a Frame's device-side features live as long as its slots do)
+orbfe_status orbfe_frame_stereo_slots(orbfe_ctx* c, int32_t slot_left, const uint8_t* left, const uint8_t* right, size_t stride, float fx,
+                                      float bf, orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out, double* right_u, double* depth,
+                                      int32_t* n_matches) {
+  if (!c || !left || !right) return fail(c, ORBFE_EBADARG, "frame_stereo_slots: NULL argument");
+  if (slot_left < 0 || (slot_left & 1) || slot_left + 2 > c->cfg.max_images)
+    return fail(c, ORBFE_EBADARG, "frame_stereo_slots: slot %d (even, and slot + 1 < max_images %d)", slot_left, c->cfg.max_images);
+  const uint8_t* imgs[2] = {left, right};
+  const FrameStereoReq fs = {fx, bf, right_u, depth, n_matches};
+  return extract_slots_impl(c, slot_left, 2, imgs, stride, kps, desc, n_out, &fs);
 }
 
 orbfe_status orbfe_extract(orbfe_ctx* c, const uint8_t* img, size_t stride, orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out) {
@@ -2726,7 +2792,7 @@ static orbfe_status search_area_core(orbfe_ctx* c, const char* who, const orbfe_
   if (hits) HIP_TRY(c, hipMemsetAsync(b + o_eh, 0, NT * 4, c->stream));
   {
     StageTimer tm(c, ORBFE_STAGE_MATCH, c->stream);
-    launch_grid_build(c->stream, d_kps, d_n_kp, rows, cols, (int32_t*)(b + o_co), (int32_t*)(b + o_cf));
+    launch_grid_build(c->stream, d_kps, d_n_kp, (int)NT, rows, cols, (int32_t*)(b + o_co), (int32_t*)(b + o_cf));
     launch_search_area(c->stream, d_kpl, d_desc, ag.clip_w, ag.clip_h, rows, cols, (const int32_t*)(b + o_co),
                        (const int32_t*)(b + o_cf), nq, (const float*)(b + o_q), (const float*)(b + o_r), (const int8_t*)(b + o_lo),
                        (const int8_t*)(b + o_hi), b + o_d, exclude ? b + o_ex : nullptr, (int32_t*)(b + o_bi), (int32_t*)(b + o_bd),
@@ -2987,7 +3053,7 @@ orbfe_status orbfe_track_local_map(orbfe_ctx* c, int32_t slot, const orbfe_frame
                               (float*)(b + o_cos), (int8_t*)(b + o_lvl), b + o_vis);
     launch_track_queries(st, n, b + o_fl, b + o_vis, (const float*)(b + o_cos), (const int8_t*)(b + o_lvl), in->th, (const float*)(b + o_s2), nl,
                          (float*)(b + o_rad), (int8_t*)(b + o_lo), (int8_t*)(b + o_hi));
-    launch_grid_build(st, c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, ag.rows, ag.cols, (int32_t*)(b + o_co), (int32_t*)(b + o_cf));
+    launch_grid_build(st, c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, (int)NF, ag.rows, ag.cols, (int32_t*)(b + o_co), (int32_t*)(b + o_cf));
     launch_search_area(st, c->d_kpl + (size_t)slot * NF, c->d_desc + (size_t)slot * NF * 32, ag.clip_w, ag.clip_h, ag.rows, ag.cols,
                        (const int32_t*)(b + o_co), (const int32_t*)(b + o_cf), n, (const float*)(b + o_uv), (const float*)(b + o_rad),
                        (const int8_t*)(b + o_lo), (const int8_t*)(b + o_hi), b + o_desc, nullptr, (int32_t*)(b + o_bi), (int32_t*)(b + o_bd),

@@ -55,16 +55,32 @@ __device__ inline void pose_oplus(const PoseDev& T, const double* upd, PoseDev& 
     q[1] = (R[0][2] - R[2][0]) * t;
     q[2] = (R[1][0] - R[0][1]) * t;
   } else {
+    // (the three cases of Eigen's largest-diagonal branch spelled out: indexing R and q by a run-time i would move both out of registers)
     int i = 0;
     if (R[1][1] > R[0][0]) i = 1;
-    if (R[2][2] > R[i][i]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    double t = sqrt(R[i][i] - R[j][j] - R[k][k] + 1.0);
-    q[i] = 0.5 * t;
-    t = 0.5 / t;
-    q[3] = (R[k][j] - R[j][k]) * t;
-    q[j] = (R[j][i] + R[i][j]) * t;
-    q[k] = (R[k][i] + R[i][k]) * t;
+    if (i == 0 ? R[2][2] > R[0][0] : R[2][2] > R[1][1]) i = 2;
+    if (i == 0) {
+      double t = sqrt(R[0][0] - R[1][1] - R[2][2] + 1.0);
+      q[0] = 0.5 * t;
+      t = 0.5 / t;
+      q[3] = (R[2][1] - R[1][2]) * t;
+      q[1] = (R[1][0] + R[0][1]) * t;
+      q[2] = (R[2][0] + R[0][2]) * t;
+    } else if (i == 1) {
+      double t = sqrt(R[1][1] - R[2][2] - R[0][0] + 1.0);
+      q[1] = 0.5 * t;
+      t = 0.5 / t;
+      q[3] = (R[0][2] - R[2][0]) * t;
+      q[2] = (R[2][1] + R[1][2]) * t;
+      q[0] = (R[0][1] + R[1][0]) * t;
+    } else {
+      double t = sqrt(R[2][2] - R[0][0] - R[1][1] + 1.0);
+      q[2] = 0.5 * t;
+      t = 0.5 / t;
+      q[3] = (R[1][0] - R[0][1]) * t;
+      q[0] = (R[0][2] + R[2][0]) * t;
+      q[1] = (R[1][2] + R[2][1]) * t;
+    }
   }
   double te[3];
   for (int i = 0; i < 3; ++i) te[i] = V[i][0] * upd[3] + V[i][1] * upd[4] + V[i][2] * upd[5];

@@ -5,6 +5,8 @@
 //                                         std::string&, int, int), extract(std::vector<cv::KeyPoint>&, std::vector<cv::Mat>&), getPyramid(),
 //                                         getScaledFactors(), the public statics.  Two objects may extract on two threads (Frame.cc:100-105).
 //   orbfe::dropin::searchByStereo         the body of `int ORBMatcher::searchByStereo(Frame::SharedPtr)` (ORBMatcher.h:38, src/ORBMatcher.cc:18-81)
+//   orbfe::dropin::createStereo           the two extract() threads of `Frame::Frame` (src/Frame.cc:100-105) and the searchByStereo of
+//                                         `Frame::createStereo` (Frame.h:319) as ONE device call (ORBExtractor::extractStereo)
 //   orbfe::dropin::descDistance           `static int ORBMatcher::descDistance(const cv::Mat&, const cv::Mat&)` (ORBMatcher.h:77)
 //   orbfe::dropin::OptimizePoseOnly       the body of `static int Optimizer::OptimizePoseOnly(Frame::SharedPtr)` (Optimizer.h:72, src/Optimizer.cc:33-203)
 //   orbfe::dropin::OptimizeLocalMap       the body of `static void Optimizer::OptimizeLocalMap(KeyFrame::SharedPtr, bool&)` (Optimizer.h:69,
@@ -53,6 +55,25 @@ class ORBExtractor {
     std::vector<orbfe_keypoint> k;
     std::vector<orbfe::Descriptor> d;
     mImpl.extract(k, d);
+    deliver(k, d, keyPoints, descriptors);
+  }
+  // Both extractions of a stereo frame and its stereo match as ONE device call (orbfe_frame_stereo_slots): what Frame::createStereo does
+  // with two extract() threads (src/Frame.cc:100-105) and ORBMatcher::searchByStereo (include/ORB_SLAM2/Frame.h:319), for a caller that
+  // changes those lines (orbfe::dropin::createStereo below is the body).  `this` is the left extractor.
+  int extractStereo(ORBExtractor& right, float fx, float bf, std::vector<cv::KeyPoint>& kpsLeft, std::vector<cv::Mat>& descLeft,
+                    std::vector<cv::KeyPoint>& kpsRight, std::vector<cv::Mat>& descRight, std::vector<double>& rightU,
+                    std::vector<double>& depths) {
+    std::vector<orbfe_keypoint> kl, kr;
+    std::vector<orbfe::Descriptor> dl, dr;
+    const int n = mImpl.extractStereo(right.mImpl, fx, bf, kl, dl, kr, dr, rightU, depths);
+    deliver(kl, dl, kpsLeft, descLeft);
+    right.deliver(kr, dr, kpsRight, descRight);
+    return n;
+  }
+
+ private:
+  void deliver(const std::vector<orbfe_keypoint>& k, std::vector<orbfe::Descriptor>& d, std::vector<cv::KeyPoint>& keyPoints,
+               std::vector<cv::Mat>& descriptors) {
     static_assert(sizeof(cv::KeyPoint) == sizeof(orbfe_keypoint), "cv::KeyPoint layout");
     keyPoints.resize(k.size());
     std::memcpy((void*)keyPoints.data(), k.data(), sizeof(orbfe_keypoint) * k.size());
@@ -73,6 +94,8 @@ class ORBExtractor {
     std::lock_guard<std::mutex> lk(mPyrMutex);
     mvPyramids.clear();  // a new extraction: the planes are fetched again when somebody asks
   }
+
+ public:
   // The reference fills mvPyramids in the constructor; its only reader is ORBMatcher::searchByStereo (src/ORBMatcher.cc:27-28), which
   // runs on the device here.  The 8 planes (1.4 MB) therefore cross PCIe only if somebody calls this.
   const std::vector<cv::Mat>& getPyramid() const {
@@ -166,6 +189,15 @@ static int searchByStereo(FramePtr pFrame) {
   pFrame->mvFeatsRightU.assign(ru.begin(), ru.end());
   pFrame->mvDepths.assign(dp.begin(), dp.end());
   return n;
+}
+
+// The device work of Frame::createStereo (include/ORB_SLAM2/Frame.h:313-323) as one call: stands for the two extract() threads of the
+// Frame constructor (src/Frame.cc:100-105) AND the searchByStereo of Frame.h:319 -- fills mvFeatsLeft / mvLeftDescriptor / mvFeatsRight /
+// mRightDescriptor / mvFeatsRightU / mvDepths and returns the match count (Frame::mnN).  INTEGRATION.md 2b shows the two edits.
+template <class CameraT, class FrameT>
+static int createStereo(FrameT* self) {
+  return self->mpExtractorLeft->extractStereo(*self->mpExtractorRight, CameraT::mfFx, CameraT::mfBf, self->mvFeatsLeft, self->mvLeftDescriptor,
+                                              self->mvFeatsRight, self->mRightDescriptor, self->mvFeatsRightU, self->mvDepths);
 }
 
 // static int Optimizer::OptimizePoseOnly(Frame::SharedPtr pFrame)  (src/Optimizer.cc:33-203)
@@ -964,6 +996,10 @@ static void OptimizeLocalMap(KeyFramePtr pkframe, bool& isStop) {
 template <class CameraT, class FramePtr>
 int searchByStereo(FramePtr pFrame) {
   return Bodies::template searchByStereo<CameraT>(pFrame);
+}
+template <class CameraT, class FrameT>
+int createStereo(FrameT* self) {
+  return Bodies::template createStereo<CameraT>(self);
 }
 template <class CameraT, class FramePtr>
 int OptimizePoseOnly(FramePtr pFrame) {

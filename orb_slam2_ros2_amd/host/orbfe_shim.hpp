@@ -128,6 +128,22 @@ class ContextPool {
     l.generation = ++t.generation[(size_t)l.slot];
     return l;
   }
+  // the next slot PAIR (even, odd) of the context for orbfe_frame_stereo_slots: both slots of the pair get a new generation
+  static std::pair<Lease, Lease> acquirePair(orbfe_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(mu());
+    SlotTable& t = slots()[ctx];
+    if (t.generation.empty()) t.generation.assign(kSlots, 0);
+    const int n = (int)t.generation.size();
+    if (n < 2) throw std::logic_error("ContextPool::acquirePair: the context has fewer than two slots");
+    int s = (t.next + 1) & ~1;
+    if (s + 1 >= n) s = 0;
+    t.next = (s + 2) % n;
+    Lease a, b;
+    a.slot = s, b.slot = s + 1;
+    a.generation = ++t.generation[(size_t)s];
+    b.generation = ++t.generation[(size_t)s + 1];
+    return {a, b};
+  }
   static bool current(orbfe_ctx* ctx, const Lease& l) {
     std::lock_guard<std::mutex> lk(mu());
     auto it = slots().find(ctx);
@@ -179,6 +195,30 @@ class ORBExtractor {
     keyPoints.resize(n);
     descriptors.resize(n);
     mnKeyPoints = n;
+  }
+
+  // Frame::createStereo's device work as ONE call (include/ORB_SLAM2/Frame.h:313-323: the two extractions of src/Frame.cc:100-105 and
+  // ORBMatcher::searchByStereo): `this` is the left extractor, `right` the right one; both take a slot of one pair of the context, the
+  // results are those of the two extract() calls followed by ORBMatcher::searchByStereo.  Returns the match count (Frame::mnN).
+  int extractStereo(ORBExtractor& right, float fx, float bf, std::vector<orbfe_keypoint>& kpsLeft, std::vector<Descriptor>& descLeft,
+                    std::vector<orbfe_keypoint>& kpsRight, std::vector<Descriptor>& descRight, std::vector<double>& rightU,
+                    std::vector<double>& depths) {
+    if (mCtx != right.mCtx) throw std::logic_error("extractStereo: the two extractors differ in geometry / parameters");
+    if (mImage.step != right.mImage.step) throw std::logic_error("extractStereo: the two images differ in row stride");
+    const size_t cap = (size_t)mnFeats;
+    std::vector<orbfe_keypoint> k(2 * cap);
+    std::vector<Descriptor> d(2 * cap);
+    rightU.resize(cap), depths.resize(cap);
+    int32_t n[2] = {0, 0}, nm = 0;
+    auto pair = ContextPool::acquirePair(mCtx);
+    mLease = pair.first, right.mLease = pair.second;
+    check(mCtx, orbfe_frame_stereo_slots(mCtx, mLease.slot, mImage.data, right.mImage.data, mImage.step, fx, bf, k.data(), d.data()->data(), n,
+                                         rightU.data(), depths.data(), &nm));
+    kpsLeft.assign(k.begin(), k.begin() + n[0]), descLeft.assign(d.begin(), d.begin() + n[0]);
+    kpsRight.assign(k.begin() + cap, k.begin() + cap + n[1]), descRight.assign(d.begin() + cap, d.begin() + cap + n[1]);
+    rightU.resize((size_t)n[0]), depths.resize((size_t)n[0]);
+    mnKeyPoints = n[0], right.mnKeyPoints = n[1];
+    return nm;
   }
 
   // level `l` of the un-blurred pyramid, tight rows (what getPyramid()[l] holds in the reference).  Read from the device on demand:

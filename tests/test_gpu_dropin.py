@@ -43,6 +43,22 @@ def test_two_extractor_objects_on_two_threads_200_times(orc, exe, tmp_path):
     assert (int(pyr_ok), int(stale_refused), int(levels)) == (1, 1, 8)
 
 
+def test_create_stereo_adapter_builds_the_same_frame_as_two_threads_and_search_by_stereo(orc, exe, tmp_path):
+    """mode `latency` builds the Frame three ways -- two extract() threads + searchByStereo (the reference's shape), the same calls on one
+    thread, and orbfe::dropin::createStereo (one device call) -- and fails unless every frame of every way hashes equal to the first"""
+    L, R = synth.stereo_pair(3)
+    L.tofile(tmp_path / "L.raw")
+    R.tofile(tmp_path / "R.raw")
+    out = subprocess.run([exe, "latency", str(tmp_path / "L.raw"), str(tmp_path / "R.raw"), "1241", "376", "40"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    f = out.stdout.split()
+    assert f[0] == "LATENCY_OK" and len(f) == 13
+    ref = orc.stereo_frame(L, R, fx=FX, bf=BF)
+    assert (int(f[8]), int(f[9])) == (len(ref["lk"]), ref["n_matches"])
+    assert float(f[11]) > 0
+
+
 def test_keyframe_adapter_of_optimize_local_map_equals_the_array_path(exe, tmp_path):
     import os
     pb = open(os.path.join(os.path.dirname(__file__), "golden", "map_small.pb"), "rb").read()

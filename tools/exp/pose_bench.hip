@@ -16,12 +16,15 @@ int main(int argc, char** argv) {
   int n = 0;
   double cam[5], pose[7];
   fread(&n, 4, 1, f);
+  const int n_file = n;
   fread(cam, 8, 5, f);
   fread(pose, 8, 7, f);
   std::vector<double> xw(3 * n), meas(3 * n), info(n);
   std::vector<float> s2(n);
   fread(xw.data(), 8, 3 * n, f), fread(meas.data(), 8, 3 * n, f), fread(info.data(), 8, n, f), fread(s2.data(), 4, n, f);
   fclose(f);
+  if (argc > 2) n = std::min(n, atoi(argv[2]));  // the first n edges only
+  (void)n_file;
   double *d_x, *d_m, *d_i, *d_p, *d_po, *d_e;
   float* d_s;
   uint8_t *d_l, *d_r, *d_in;
@@ -34,7 +37,7 @@ int main(int argc, char** argv) {
   BaParamsDev prm = {cam[0], cam[1], cam[2], cam[3], cam[4]};
   auto run = [&]() {
     launch_pose_only(0, n, d_x, d_m, d_i, d_s, d_p, prm, (double)(float)std::sqrt(5.991), (double)(float)std::sqrt(7.815), d_e, d_l, d_r, d_in, d_po,
-                     d_ng);
+                     d_ng, nullptr);
   };
   for (int w = 0; w < 3; ++w) run();
   hipDeviceSynchronize();
@@ -58,8 +61,8 @@ int main(int argc, char** argv) {
 #ifdef POSE_STAMPS
   long long st[8];
   hipMemcpyFromSymbol(st, HIP_SYMBOL(g_pose_stamps), sizeof st);
-  const char* names[5] = {"loop top", "solve + oplus", "evaluation", "decision", "build"};
-  for (int k = 0; k < 5; ++k) printf("  %-14s %8.1f k cycles per call\n", names[k], (double)st[k] / reps / 1e3);
+  const char* names[6] = {"loop top", "solve + oplus", "evaluation", "decision", "build: sums", "build: edges"};
+  for (int k = 0; k < 6; ++k) printf("  %-14s %8.1f k cycles per call\n", names[k], (double)st[k] / reps / 1e3);
   printf("  passes %.1f, builds %.1f per call\n", (double)st[6] / reps, (double)st[7] / reps);
 #endif
   return 0;
