@@ -293,9 +293,10 @@ __global__ __launch_bounds__(256) void k_resize_regions(const LevelDev* __restri
 // new row yields one output row (vertical 16.16 sum, +0x8000 >> 16) stored as one 32-bit word.
 // Integer arithmetic only => bit-exact with the two-pass definition.
 // ---------------------------------------------------------------------------------------------
+template <bool SAT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur(const LevelDev* __restrict__ lv, int n_levels, const uint8_t* __restrict__ pyr,
                                               uint8_t* __restrict__ blur, size_t img_pitch, BlurTaps taps, int tile_first) {
-  blur_tile(lv, n_levels, pyr, blur, img_pitch, taps, (int)blockIdx.x + tile_first, (int)blockIdx.y, (int)threadIdx.x);
+  blur_tile<SAT>(lv, n_levels, pyr, blur, img_pitch, taps, (int)blockIdx.x + tile_first, (int)blockIdx.y, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -382,7 +383,10 @@ void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int tile_fir
   if (n_tiles <= 0 || n_img <= 0) return;
   BlurTaps bt;
   for (int i = 0; i < 7; ++i) bt.t[i] = taps[i];
-  hipLaunchKernelGGL(k_blur, dim3(n_tiles, n_img), dim3(256), 0, s, d_lv, n_levels, d_pyr, d_blur, img_pitch, bt, tile_first);
+  if (blur_taps_saturate(taps))
+    hipLaunchKernelGGL(k_blur<true>, dim3(n_tiles, n_img), dim3(256), 0, s, d_lv, n_levels, d_pyr, d_blur, img_pitch, bt, tile_first);
+  else
+    hipLaunchKernelGGL(k_blur<false>, dim3(n_tiles, n_img), dim3(256), 0, s, d_lv, n_levels, d_pyr, d_blur, img_pitch, bt, tile_first);
 }
 
 }  // namespace orbfe

@@ -1266,7 +1266,10 @@ struct QtBlur {
 };
 __global__ __launch_bounds__(256) void k_quadtree_w4(QT_KERNEL_ARGS, QtBlur bl) {
   if (bl.pyr && (int)blockIdx.x >= bl.n_groups) {
-    blur_tile(lv, n_levels, bl.pyr, bl.blur, bl.img_pitch, bl.taps, (int)blockIdx.x - bl.n_groups, (int)blockIdx.y, (int)threadIdx.x);
+    if (blur_taps_saturate(bl.taps.t))  // (uniform)
+      blur_tile<true>(lv, n_levels, bl.pyr, bl.blur, bl.img_pitch, bl.taps, (int)blockIdx.x - bl.n_groups, (int)blockIdx.y, (int)threadIdx.x);
+    else
+      blur_tile<false>(lv, n_levels, bl.pyr, bl.blur, bl.img_pitch, bl.taps, (int)blockIdx.x - bl.n_groups, (int)blockIdx.y, (int)threadIdx.x);
     return;
   }
   quadtree_levels<4>(QT_KERNEL_PASS);

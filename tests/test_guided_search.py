@@ -55,7 +55,8 @@ def test_oracle_candidate_sets_and_order(orc, kitti_pair):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h,nf", [(1241, 376, 2000), (640, 480, 1000), (900, 300, 3000)])
+# (8000 features: the cells' lists no longer fit the grid kernel's LDS and are filled and sorted in device memory)
+@pytest.mark.parametrize("w,h,nf", [(1241, 376, 2000), (640, 480, 1000), (900, 300, 3000), (1241, 376, 8000)])
 def test_device_guided_search_matches_oracle(orc, w, h, nf):
     from orb_slam2_ros2_amd import ORBMatcher
     from orb_slam2_ros2_amd._lib import Context
