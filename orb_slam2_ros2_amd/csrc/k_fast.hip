@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #define FAST_ROW_PART()           \
   int lane_o = lane;              \
   asm volatile("" : "+v"(lane_o)); \
-  const int row0 = (lane_o * MUL) >> 7, part = lane_o - row0 * UPR
+  const int row0 = mul24u(lane_o, MUL) >> 7, part = lane_o - mul24u(row0, UPR) /* (24-bit products: full rate; the 32-bit ones are quarter rate) */
   const uint8_t* img_base = pyr + (size_t)img * img_pitch;
   auto patch_src = [&](const CellDev& c) __attribute__((always_inline)) -> const uint8_t* {
     const LevelDev& Lc = lv[c.level];
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     if (PP % 16 == 0) {
       ((uint4*)lds_all)[r * UPR + part] = w;
     } else {  // rows 8-byte aligned only: two 8-byte stores, the half unit at the end of a row one
-      uint2* d = (uint2*)(P + r * PP + 16 * part);
+      uint2* d = (uint2*)(P + (uint32_t)mad24u(r, PP, 16 * part));  // (as r * PP + ... the offset was a 64-bit quarter-rate multiply-add)
       d[0] = make_uint2(w.x, w.y);
       if (part < UPR - 1) d[1] = make_uint2(w.z, w.w);
     }
