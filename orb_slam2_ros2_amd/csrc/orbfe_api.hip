@@ -1469,9 +1469,15 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
   const bool mirror_on = n_img <= 2;
   HostMirror mir = {kps ? (orbfe_keypoint*)(ln.h_stage + o_kps) : nullptr, desc ? ln.h_stage + o_desc : nullptr, (int32_t*)(ln.h_stage + o_cnt)};
   auto enqueue_all = [&]() -> orbfe_status {
-    // both eyes in ONE copy (rows = images: the staging planes are `plane` bytes apart, the pyramid slots img_pitch)
-    // (measured and dropped: the resize kernel reading the page-locked planes itself -- 50 us against 12 + the 17 us copy)
-    HIP_TRY(c, hipMemcpy2DAsync(pyr_now + (size_t)slot0 * c->img_pitch + L0.plane_off, c->img_pitch, ln.h_stage, plane, (size_t)L0.stride * L0.h,
+    // (more images: both in ONE copy -- rows = images: the staging planes are `plane` bytes apart, the pyramid slots img_pitch)
+    // One or two images: level 0 is read from the page-locked staging planes by a copy KERNEL (16 bytes per load over PCIe, every byte
+    // once) -- 6 us less per pair than the copy engine's 27 us transfer and its hand-over to the compute queue (same box, alternating:
+    // extraction 0.278 -> 0.271 ms).  (The resize reading the staged planes itself was measured in r3 and dropped: it reads a pixel more than once.)
+    if (n_img <= 2)
+      launch_load_level0(ln.stream, ln.h_stage, nullptr, (size_t)L0.stride, plane, pyr_now, c->img_pitch, (uint32_t)L0.plane_off, L0.stride, c->cfg.width,
+                         L0.h, slot0, 1, n_img);
+    else
+      HIP_TRY(c, hipMemcpy2DAsync(pyr_now + (size_t)slot0 * c->img_pitch + L0.plane_off, c->img_pitch, ln.h_stage, plane, (size_t)L0.stride * L0.h,
                                 (size_t)n_img, hipMemcpyHostToDevice, ln.stream));
     TRY(run_extract(c, ln.stream, slot0, n_img, nullptr, timing, nullptr, mirror_on ? &mir : nullptr));
     if (fs) {
