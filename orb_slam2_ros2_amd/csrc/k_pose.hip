@@ -384,11 +384,9 @@ __device__ long long g_pose_stamps[8];
 #define POSE_STAGE_LD (256 + 8)  // doubles per row of the staged sums: rows 8 double-banks apart => the 8 x 8 readers of a wave 2 per bank pair
 template <int NT>
 struct PoseSharedR {
-  PoseDev T, T0, backup;
-  double H[36], b[6], x[6];
+  PoseDev T0;
+  double H[36], b[6];
   double red[28][NT / 64];
-  double lambda, ni, current_chi, rho;
-  int qmax, cont_inner, stop_outer, accepted, n_bad;
   // every trial step an iteration can take, solved at once on POSE_TRIALS lanes when its system is built (see the build site)
   PoseDev trial_T[POSE_TRIALS];
   double trial_x[POSE_TRIALS][6];
@@ -436,7 +434,6 @@ __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __res
   if (tid == 0) {
     for (int i = 0; i < 4; ++i) S.T0.q[i] = pose_in[i];
     for (int i = 0; i < 3; ++i) S.T0.t[i] = pose_in[4 + i];
-    S.T = S.T0;
   }
   __syncthreads();
 
@@ -454,17 +451,6 @@ __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __res
     if (st[u]) c += e[2] * (W[u] * e[2]);
     return c;
   };
-  // sum over the workgroup of one value, result in every thread: wave tree, one partial per wave, waves added in order
-  auto block_sum1 = [&](double v) {
-    const double w = wave_sum_f64(v);
-    if (lane == 0) S.red[27][wv] = w;
-    __syncthreads();
-    double s = 0;
-#pragma unroll
-    for (int k = 0; k < NT / 64; ++k) s += S.red[27][k];
-    __syncthreads();
-    return s;
-  };
 
   // edge->computeError() at construction (Optimizer.cc:90,111) -- (with the state machine below this is the only other use of edge_error
   // besides the evaluation site and the re-classification)
@@ -475,11 +461,27 @@ __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __res
       if (have[u]) edge_error(u, T, E[u]);
   }
 
+  // The Levenberg-Marquardt control runs in EVERY thread (late r4): damping, gain ratio, trial counter and the iteration's base pose are
+  // registers with the same value everywhere -- every thread reads the same sums and the same trial table and executes the same
+  // instructions -- so a trial is: read the trial's pose (LDS broadcast), evaluate, ONE barrier for the sum, decide.  With the control on
+  // lane 0 and its state in LDS a trial took four barriers and two store-barrier-load round trips (~1.2 k of a pass's ~5 k cycles).
+  PoseDev Tb = S.T0;  // the current estimate
+  int n_bad = 0;
+  int sum_slot = 0;  // the evaluation's per-wave partial sums alternate between two rows: one barrier per sum
+  auto block_sum_alt = [&](double v) {
+    const double w = wave_sum_f64(v);
+    double* row = S.red[27 - sum_slot];  // (rows 26 and 27: the 512-thread build's 27 sums use rows 0 .. 26 between two barriers of their own)
+    if (lane == 0) row[wv] = w;
+    __syncthreads();
+    double sm = 0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) sm += row[k];
+    sum_slot ^= 1;
+    return sm;
+  };
   for (int round = 0; round < 4; ++round) {
-    if (tid == 0) {
-      S.T = S.T0;  // every round restarts from the initial pose (Optimizer.cc:127)
-      S.n_bad = 0;
-    }
+    Tb = S.T0;  // every round restarts from the initial pose (Optimizer.cc:127)
+    n_bad = 0;
     bool mine = false;
 #pragma unroll
     for (int u = 0; u < POSE_EPT; ++u) mine = mine || lvl0[u];
@@ -487,32 +489,28 @@ __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __res
     if (any_active) {
       // ---- SparseOptimizer::optimize(10) with OptimizationAlgorithmLevenberg, as a state machine ----
       int it = 0;            // iterations completed
-      bool do_solve = false; // the pass starts with a trial step (solve, oplus) and its evaluation decides that trial
-      double chi_cur = 0;
+      bool do_solve = false; // the pass starts with a trial step and its evaluation decides that trial
+      double chi_cur = 0, current_chi = 0, lambda = 0, ni = 2;
+      int qmax = 0;
+      PoseDev Te = Tb;  // the pose the pass evaluates at
+      bool trial_ok = true;
       PS_BEGIN
       for (;;) {
         PS(0)
-        if (do_solve) {
-          if (tid == 0) {  // trial S.qmax of this iteration: solved when the system was built
-            const int q = S.qmax;
-            S.backup = S.T;
-            S.cont_inner = S.trial_ok[q];  // ok2
-            for (int j = 0; j < 6; ++j) S.x[j] = S.trial_x[q][j];
-            S.T = S.trial_T[q];
-          }
-          __syncthreads();
+        if (do_solve) {  // trial qmax of this iteration: solved when the system was built
+          Te = S.trial_T[qmax];
+          trial_ok = S.trial_ok[qmax] != 0;  // ok2
         }
         PS(1)  // trial step taken
         PS_COUNT(6)
-        // computeActiveErrors + activeRobustChi2 at S.T -- the ONE evaluation site
+        // computeActiveErrors + activeRobustChi2 at Te -- the ONE evaluation site
         double chi;
         {
-          const PoseDev T = S.T;
           double part = 0;
 #pragma unroll
           for (int u = 0; u < POSE_EPT; ++u) {
             if (!lvl0[u]) continue;
-            edge_error(u, T, E[u]);
+            edge_error(u, Te, E[u]);
             const double c = edge_chi2(u, E[u]);
             if (rob[u]) {
               const double dl = st[u] ? d_stereo : d_mono;
@@ -521,54 +519,55 @@ __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __res
             } else
               part += c;
           }
-          chi = block_sum1(part);
+          chi = block_sum_alt(part);
         }
         PS(2)  // evaluation
         if (!do_solve) {
           chi_cur = chi;  // the errors of the current estimate: an iteration starts
         } else {
-          if (tid == 0) {  // decide the trial
-            double temp_chi = S.cont_inner ? chi : 1.7976931348623157e308;
-            double rho = S.current_chi - temp_chi;
-            double scale = 0;
-            for (int j = 0; j < 6; ++j) scale += S.x[j] * (S.lambda * S.x[j] + S.b[j]);
-            scale += 1e-3;
-            rho /= scale;
-            bool finite_lambda = true;
-            S.accepted = 0;
-            if (rho > 0 && isfinite(temp_chi)) {
-              double alpha = 1. - pow((2 * rho - 1), 3);
-              alpha = fmin(alpha, 2. / 3.);
-              S.lambda *= fmax(1. / 3., alpha);
-              S.ni = 2;
-              S.current_chi = temp_chi;
-              S.accepted = 1;
-            } else {
-              S.lambda *= S.ni;
-              S.ni *= 2;
-              S.T = S.backup;
-              finite_lambda = isfinite(S.lambda);
-            }
-            S.rho = rho;
-            S.qmax += 1;
-            S.cont_inner = (finite_lambda && rho < 0 && S.qmax < 10) ? 1 : 0;
-            if (!S.cont_inner) S.stop_outer = (S.qmax == 10 || rho == 0 || !isfinite(S.lambda)) ? 1 : 0;
+          // decide the trial (every thread, the same numbers)
+          double xs[6], bs[6];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) xs[j] = S.trial_x[qmax][j], bs[j] = S.b[j];
+          const double temp_chi = trial_ok ? chi : 1.7976931348623157e308;
+          double rho = current_chi - temp_chi;
+          double scale = 0;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) scale += xs[j] * (lambda * xs[j] + bs[j]);
+          scale += 1e-3;
+          rho /= scale;
+          bool finite_lambda = true, accepted = false;
+          if (rho > 0 && isfinite(temp_chi)) {
+            double alpha = 1. - pow((2 * rho - 1), 3);
+            alpha = fmin(alpha, 2. / 3.);
+            lambda *= fmax(1. / 3., alpha);
+            ni = 2;
+            current_chi = temp_chi;
+            accepted = true;
+            Tb = Te;
+          } else {
+            lambda *= ni;
+            ni *= 2;
+            finite_lambda = isfinite(lambda);  // (the estimate stays Tb: g2o restores its backup)
           }
-          __syncthreads();
-          if (S.cont_inner) continue;  // another trial of the same iteration (new lambda, the same system)
-          if (S.stop_outer) break;
+          qmax += 1;
+          const bool cont_inner = finite_lambda && rho < 0 && qmax < 10;
+          if (cont_inner) continue;  // another trial of the same iteration (new lambda, the same system)
+          const bool stop_outer = qmax == 10 || rho == 0 || !isfinite(lambda);
+          if (stop_outer) break;
           if (++it == 10) break;
-          if (!S.accepted) {  // (a trial neither accepted nor retried, e.g. a NaN gain ratio: the next iteration re-evaluates at the restored pose)
+          if (!accepted) {  // (a trial neither accepted nor retried, e.g. a NaN gain ratio: the next iteration re-evaluates at the restored pose)
             do_solve = false;
+            Te = Tb;
             continue;
           }
           chi_cur = chi;  // accepted: these ARE the errors and the chi2 of the new current estimate
         }
         PS(3)  // decision
         PS_COUNT(7)
-        // linearizeOplus + constructQuadraticForm of every active edge at S.T (errors of the last evaluation) -- the ONE build site
+        // linearizeOplus + constructQuadraticForm of every active edge at the current estimate (errors of the last evaluation) -- the ONE build site
         {
-          const PoseDev T = S.T;
+          const PoseDev T = Tb;
           double acc[27];
 #pragma unroll
           for (int k = 0; k < 27; ++k) acc[k] = 0;
@@ -616,6 +615,7 @@ __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __res
             }
           }
           PS(5)  // build: per-edge arithmetic
+          // (the previous system's b and trial table are rewritten only behind the barrier below: every thread has read them by then)
           if constexpr (NT == 256) {
             // every thread stages its 27 partial sums; eight threads per sum add 32 staged values each (ascending), a fixed tree joins the
             // eight: 27 + 32 LDS accesses and 35 additions per thread, where 27 wave trees of data-parallel-primitive moves took as long as
@@ -670,30 +670,26 @@ __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __res
           }
         }
         PS(4)  // build
-        if (tid == 0) {
-          S.current_chi = chi_cur;
-          if (it == 0) {
-            double md = 0;
-            for (int j = 0; j < 6; ++j) md = fmax(fabs(S.H[7 * j]), md);
-            S.lambda = 1e-5 * md;
-            S.ni = 2;
-          }
-          S.rho = 0;
-          S.qmax = 0;
-          S.stop_outer = 0;
+        current_chi = chi_cur;
+        if (it == 0) {
+          double md = 0;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) md = fmax(fabs(S.H[7 * j]), md);
+          lambda = 1e-5 * md;
+          ni = 2;
         }
-        __syncthreads();
+        qmax = 0;
         // The trial steps of this iteration, all at once: a rejected trial multiplies lambda by ni and doubles ni, the system and the pose
         // it starts from stay -- so trial q's damping is known now, and lane q solves (H + lambda_q I) x = b and applies x to the pose
         // beside the others (one instruction stream; a call of 28 iterations takes ~59 trials, most of the rejected ones in the runs of ten
         // that end a converged round).  Same recurrence, same solve, same update as taking them one by one.
         if (tid < POSE_TRIALS) {
-          double lam = S.lambda, ni = S.ni;
-          for (int q = 0; q < tid; ++q) lam *= ni, ni *= 2;
+          double lam = lambda, nu = ni;
+          for (int q = 0; q < tid; ++q) lam *= nu, nu *= 2;
           double xs[6] = {0, 0, 0, 0, 0, 0};
           const bool ok = solve6_lambda(S.H, lam, S.b, xs);
           PoseDev Tn;
-          pose_oplus(S.T, xs, Tn);
+          pose_oplus(Tb, xs, Tn);
           S.trial_T[tid] = Tn;
           for (int j = 0; j < 6; ++j) S.trial_x[tid][j] = xs[j];
           S.trial_ok[tid] = ok ? 1 : 0;
@@ -705,12 +701,11 @@ __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __res
     }
     // ---- re-classification (Optimizer.cc:132-177): mono edges, then stereo edges; counts only ----
     {
-      const PoseDev T = S.T;
       int bad = 0;
 #pragma unroll
       for (int u = 0; u < POSE_EPT; ++u) {
         if (!have[u]) continue;
-        if (!inl[u]) edge_error(u, T, E[u]);
+        if (!inl[u]) edge_error(u, Tb, E[u]);
         const double c = edge_chi2(u, E[u]);
         if (c > TH[u]) {
           inl[u] = false;
@@ -722,18 +717,16 @@ __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __res
         }
         if (round == 2) rob[u] = false;
       }
-      const double tb = block_sum1((double)bad);
-      if (tid == 0) S.n_bad = (int)tb;
-      __syncthreads();
+      n_bad = (int)block_sum_alt((double)bad);
     }
   }
 #pragma unroll
   for (int u = 0; u < POSE_EPT; ++u)
     if (have[u]) inlier_out[tid + u * NT] = inl[u] ? 1 : 0;
   if (tid == 0) {
-    for (int i = 0; i < 4; ++i) pose_out[i] = S.T.q[i];
-    for (int i = 0; i < 3; ++i) pose_out[4 + i] = S.T.t[i];
-    *n_good = n - S.n_bad;
+    for (int i = 0; i < 4; ++i) pose_out[i] = Tb.q[i];
+    for (int i = 0; i < 3; ++i) pose_out[4 + i] = Tb.t[i];
+    *n_good = n - n_bad;
   }
 }
 

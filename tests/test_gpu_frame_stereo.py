@@ -134,6 +134,19 @@ def test_slot_pairs_beside_slot_calls_on_other_threads(lib):
         ctx.close(), ref.close()
 
 
+def test_context_without_per_slot_row_tables(lib):
+    """more than sixteen slots: the extraction builds no per-slot row table, the match inside the call builds the pair's own"""
+    ctx, ref = lib.Context(1241, 376, max_images=32), lib.Context(1241, 376, max_images=2)
+    try:
+        for f in (6, 2, 6):
+            L, R = synth.stereo_pair(f)
+            want = two_calls(ref, L, R)
+            assert_same(ctx.frame_stereo(L, R, FX, BF), want)
+            assert_same(ctx.frame_stereo(L, R, FX, BF, slot_left=30), want)
+    finally:
+        ctx.close(), ref.close()
+
+
 def test_argument_checks(lib):
     L, R = synth.stereo_pair(0)
     one = lib.Context(1241, 376, max_images=1)
