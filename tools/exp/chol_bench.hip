@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../orb_slam2_ros2_amd/csrc/k_lm.hip"
+#include "../../orb_slam2_ros2_amd/csrc/k_lmbig.hip"
 
 int main(int argc, char** argv) {
   using namespace orbfe;
