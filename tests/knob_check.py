@@ -61,6 +61,10 @@ def main():
         (lk, ld), (rk, rd) = ctx.extract_slots(2, list(frames[f]))
         m, r, d, _, _ = ctx.stereo_match(2, 3, FX, BF)
         assert pair_digest(lk, ld, rk, rd, r, d, m) == gold[str(f)], f"extract_slots, frame {f}"
+    # ... and the whole frame as one call (orbfe_frame_stereo / _slots): the match inside the extraction's launch sequence
+    for f, slot in ((6, None), (6, None), (12, 4), (12, 4), (2, None)):
+        (lk, ld), (rk, rd), m, r, d = ctx.frame_stereo(*frames[f], FX, BF, slot_left=slot)
+        assert pair_digest(lk, ld, rk, rd, r, d, m) == gold[str(f)], f"frame_stereo, frame {f}, slot {slot}"
     ctx.close()
     print("KNOB_OK", n_pairs)
 
