@@ -186,7 +186,7 @@ __device__ __forceinline__ void blur_tile(const LevelDev* __restrict__ lv, int n
     }
   };
   // Seven row loads in flight per lane: the register of a row is refilled with the row seven further down before the row is worked on.
-  // A wave with all BLUR_ROWS output rows (nine in ten) runs the rows as ONE straight-line block -- every row index, window slot and
+  // A wave with all BLUR_ROWS output rows (most of them) runs the rows as ONE straight-line block -- every row index, window slot and
   // prefetch decision a compile-time constant: with a branch per row the compiler's wait counts and register copies at the joins changed
   // with every edit (a full-window copy per row, or a wait for every outstanding load after each row); the rest take the loop.
   uint32_t mrow[7];

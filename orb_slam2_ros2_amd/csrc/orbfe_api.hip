@@ -470,7 +470,7 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
       L.rs_tiles_y = 0;
     }
     L.bl_tile_base = bl_tiles;
-    L.bl_tiles_x = (L.w + 247) / 248;  // k_blur: 62 words (248 px) per wave, 4 waves x 32 rows per block
+    L.bl_tiles_x = (L.w + 247) / 248;  // k_blur: 62 words (248 px) per wave, 4 waves x BLUR_ROWS rows per block
     L.bl_tiles_y = (L.h + 4 * BLUR_ROWS - 1) / (4 * BLUR_ROWS);
     bl_tiles += L.bl_tiles_x * L.bl_tiles_y;
   }
