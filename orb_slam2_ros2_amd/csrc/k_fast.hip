@@ -471,7 +471,9 @@ static void launch_fast_cells(hipStream_t s, const LevelDev* d_lv, const CellDev
   // cells per wave: one for the drop-in path's launches (every cell its own wave: the launch is a single wave lifetime), FAST_CPW where the
   // launch holds many rounds of waves anyway (tools/exp/cpw_by_batch.sh, ms per step of 16 / 64 / 128 / 256 pairs: this rule 0.394 / 0.909 / 1.522 /
   // 2.654, one cell everywhere 0.403 / 0.910 / 1.542 / 2.695, four everywhere 0.476 / 0.933 / 1.541 / 2.683)
-  const int cpw = cpw_force > 0 ? cpw_force : ((long long)n_cells * n_img >= 65536 ? FAST_CPW : 1);  // (ORBFE_FAST_CPW: the tests' way into the cell loop with small inputs)
+  // (late r4, after the other kernels' diets: eight cells per wave in the launches of 128 k cells and more -- 5.18 -> 5.14 ms per 512 pairs)
+  const long long work = (long long)n_cells * n_img;
+  const int cpw = cpw_force > 0 ? cpw_force : (work >= 131072 ? 2 * FAST_CPW : (work >= 65536 ? FAST_CPW : 1));  // (ORBFE_FAST_CPW: the tests' way into the cell loop with small inputs)
   // a multiple of 8: the cell table is in XCD order (orbfe_create: table position = strip (mod 8), workgroups go round-robin to the 8 XCDs),
   // so a wave's cells ci, ci + n_groups ... stay on its XCD's strip and the launch's rows of workgroups start on XCD 0 for every image
   const int n_groups = ((n_cells + cpw - 1) / cpw + 7) & ~7;
