@@ -564,6 +564,39 @@ def latency_leg(device_id, n=500):
         raise SystemExit("bench.py: latency leg: orbfe_frame_stereo differs from the golden digest")
     out["frame_stereo_one_call"] = dict(_stats_ms(lambda: ctx.frame_stereo(L, R, FX, BF), n, warm=30),
                                         what="orbfe_frame_stereo(L, R): both extractions + the stereo match as one launch sequence, host to host, from Python")
+    # BASELINE config 5's front half: one TUM-shaped RGB-D frame (640 x 480, 1000 features), host to host -- Tracking::grabFrame's cvtColor +
+    # the RGB-D Frame constructor (src/Tracking.cc:55-68, src/Frame.cc:125-159): colour image -> gray -> extraction, then undistortion + the
+    # depth / rightU lookup (results of both calls checked against the oracle in tests/test_frame_glue.py; here: every repetition equal)
+    try:
+        tum = dict(fx=520.908620, fy=521.007327, cx=325.141442, cy=249.701764, k1=0.231222, k2=-0.784899, p1=-0.003257, p2=-0.000105,
+                   k3=0.917205, bf=40.0)
+        rg = np.random.default_rng(5)
+        g = synth.mono_image(4, 640, 480)
+        bgr = np.stack([g, np.roll(g, 1, 1), np.roll(g, 2, 0)], 2).copy()
+        dep = rg.integers(0, 30000, (480, 640)).astype(np.uint16)
+        cr = Context(640, 480, n_features=1000, device_id=device_id, max_images=1)
+        k0_, d0_ = cr.extract_color(bgr, 2)
+        ku0, dd0, ru0 = cr.frame_rgbd(0, tum, dep, 5000.0)
+
+        def rgbd_frame():
+            k_, d_ = cr.extract_color(bgr, 2)
+            ku, dd, ru_ = cr.frame_rgbd(0, tum, dep, 5000.0)
+            return k_, d_, ku, dd, ru_
+        k1_, d1_, ku1, dd1, ru1 = rgbd_frame()
+        if not (np.array_equal(d0_, d1_) and ku0.tobytes() == ku1.tobytes() and np.array_equal(dd0, dd1) and np.array_equal(ru0, ru1)):
+            raise SystemExit("bench.py: latency leg: the RGB-D frame is not repeatable")
+        out["rgbd_frame_tum"] = dict(_stats_ms(rgbd_frame, 200, warm=20), keypoints=int(len(k0_)),
+                                     what="640x480 BGR image + 16-bit depth image in, undistorted keypoints / descriptors / depth / rightU out: "
+                                          "orbfe_extract_color + orbfe_frame_rgbd (BASELINE config 5's frame, 1000 features), from Python")
+        # ... and as ONE call (orbfe_frame_rgbd_image: Frame::createRGBD's device work as one launch sequence; the depth image is not uploaded)
+        k2_, d2_, dd2, ru2 = cr.frame_rgbd_image(bgr, tum, dep, 5000.0, 2)
+        if not (np.array_equal(d2_, d0_) and k2_.tobytes() == ku0[:len(k2_)].tobytes() and np.array_equal(dd2, dd0) and np.array_equal(ru2, ru0)):
+            raise SystemExit("bench.py: latency leg: orbfe_frame_rgbd_image differs from orbfe_extract_color + orbfe_frame_rgbd")
+        out["rgbd_frame_tum_one_call"] = dict(_stats_ms(lambda: cr.frame_rgbd_image(bgr, tum, dep, 5000.0, 2), 200, warm=20),
+                                              what="the same frame through orbfe_frame_rgbd_image, from Python")
+        cr.close()
+    except (RuntimeError, OSError) as ex:
+        out["rgbd_frame_tum"] = {"error": f"{type(ex).__name__}: {ex}"}
     # the per-frame guided matchers of Tracking (searchByProjection x 2-4 per frame over findFeaturesInArea + getBestMatch, src/ORBMatcher.cc:
     # 265-347, 561-612; MapPoint::isInVision, src/MapPoint.cc:141-201): 1000 queries against the 2000 features of the frame just built
     r = np.random.default_rng(0)

@@ -374,6 +374,17 @@ typedef struct orbfe_camera {
 } orbfe_camera;
 orbfe_status orbfe_extract_color(orbfe_ctx* ctx, const uint8_t* img, size_t stride_bytes, int32_t color_order, orbfe_keypoint* kps,
                                  uint8_t* desc, int32_t* n_out);
+/* The device work of Frame::createRGBD (include/ORB_SLAM2/Frame.h:326-331) as ONE call: cv::cvtColor of Tracking::grabFrame when
+ * color_order is 1 (RGB) or 2 (BGR) -- 0: the image is gray already -- (src/Tracking.cc:55-68), the extraction into `slot` (the RGB-D
+ * Frame constructor, src/ORB_SLAM2/src/Frame.cc:125-135), then the constructor's tail: Camera::undistortPoints and the depth / rightU
+ * lookup (:136-158).  One launch sequence on the slot's lane, one synchronisation; the depth image is not uploaded (the last kernel reads
+ * one value per keypoint from the page-locked staging copy).  Results as orbfe_extract_color / orbfe_extract_slot followed by
+ * orbfe_frame_rgbd (tests/test_frame_glue.py compares them): kps_undistorted / desc [n_features], depth_out / right_u_out [n_features]
+ * (-1 where there is no depth), nullable.                                                                                          */
+orbfe_status orbfe_frame_rgbd_image(orbfe_ctx* ctx, int32_t slot, const uint8_t* img, size_t stride_bytes, int32_t color_order,
+                                    const orbfe_camera* cam, const void* depth, int32_t depth_type, size_t depth_stride_bytes,
+                                    float depth_scale, orbfe_keypoint* kps_undistorted, uint8_t* desc, int32_t* n_out, double* depth_out,
+                                    double* right_u_out);
 orbfe_status orbfe_frame_rgbd(orbfe_ctx* ctx, int32_t slot, const orbfe_camera* cam, const void* depth, int32_t depth_type,
                               size_t depth_stride_bytes, float depth_scale, orbfe_keypoint* kps_undistorted, double* depth_out,
                               double* right_u_out);

@@ -112,7 +112,7 @@ class BaEdgeOut(C.Structure):
 EXPORTS = [
     "orbfe_abi_version", "orbfe_create", "orbfe_destroy", "orbfe_last_error", "orbfe_get_level_info", "orbfe_get_scale_factors",
     "orbfe_get_capacity",
-    "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_slot", "orbfe_extract_slots", "orbfe_frame_stereo", "orbfe_frame_stereo_slots", "orbfe_fetch_batch", "orbfe_fetch_stereo_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
+    "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_slot", "orbfe_extract_slots", "orbfe_frame_stereo", "orbfe_frame_stereo_slots", "orbfe_frame_rgbd_image", "orbfe_fetch_batch", "orbfe_fetch_stereo_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
     "orbfe_host_alloc", "orbfe_host_alloc_on", "orbfe_host_free", "orbfe_recommended_hw_queues", "orbfe_stream_submit", "orbfe_stream_wait", "orbfe_stream_device_results", "orbfe_record_bytes", "orbfe_stream_pack_records",
     "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_search_in_area_features", "orbfe_search_in_area_features_ex", "orbfe_extract_color", "orbfe_frame_rgbd", "orbfe_project_map_points", "orbfe_track_local_map",
     "orbfe_map_pb_summary", "orbfe_map_pb_reencode", "orbfe_map_pb_to_txt", "orbfe_map_txt_to_pb", "orbfe_map_local_graph", "orbfe_map_local_ba",
@@ -153,6 +153,7 @@ def load() -> C.CDLL:
     L.orbfe_extract_batch.argtypes = [vp, i32, vp, C.c_size_t, vp, vp, vp]
     L.orbfe_extract_slot.argtypes = [vp, i32, vp, C.c_size_t, vp, vp, vp]
     L.orbfe_extract_slots.argtypes = [vp, i32, i32, vp, C.c_size_t, vp, vp, vp]
+    L.orbfe_frame_rgbd_image.argtypes = [vp, i32, vp, C.c_size_t, i32, vp, vp, i32, C.c_size_t, C.c_float, vp, vp, vp, vp, vp]
     L.orbfe_frame_stereo.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp]
     L.orbfe_frame_stereo_slots.argtypes = [vp, i32, vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp]
     L.orbfe_fetch_batch.argtypes = [vp, i32, i32, vp, vp, vp]
@@ -768,6 +769,30 @@ class Context:
             dtype, stride = (0 if depth.dtype == np.uint16 else 1), depth.strides[0]
         self._check(self.lib.orbfe_frame_rgbd(self.h, slot, C.byref(cm), ptr(depth), dtype, stride, depth_scale, ptr(kps), ptr(d), ptr(ru)))
         return kps, d, ru   # [n_features] each; entries past the slot's keypoint count are zero (kps) / -1
+
+    def frame_rgbd_image(self, img, cam: dict, depth=None, depth_scale=1.0, color_order=0, slot=0):
+        """orbfe_frame_rgbd_image: (colour -> gray,) extraction, undistortion and the depth / rightU lookup of one RGB-D frame as one call
+        (Frame::createRGBD's device work).  img: (h, w) uint8, or (h, w, 3) with color_order 1 (RGB) / 2 (BGR).
+        -> (undistorted keypoints [n], descriptors [n], depth [n_features], right_u [n_features])"""
+        img = np.asarray(img)
+        want = (self.height, self.width, 3) if color_order else (self.height, self.width)
+        if img.shape != want:
+            raise ValueError(f"image shape {img.shape} != {want}")
+        if not (img.dtype == np.uint8 and img.flags.c_contiguous):
+            img = np.ascontiguousarray(img, np.uint8)
+        cm = Camera(*[float(cam[k]) for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "bf")])
+        nf = max(self.n_features, 1)
+        kps, desc = np.zeros(nf, KP_DTYPE), np.zeros((nf, 32), np.uint8)
+        d, ru = np.zeros(nf), np.zeros(nf)
+        n = C.c_int32(0)
+        dtype, stride = 0, 0
+        if depth is not None:
+            depth = np.ascontiguousarray(depth)
+            assert depth.dtype in (np.uint16, np.float32) and depth.shape == (self.height, self.width)
+            dtype, stride = (0 if depth.dtype == np.uint16 else 1), depth.strides[0]
+        self._check(self.lib.orbfe_frame_rgbd_image(self.h, slot, img.ctypes.data, img.strides[0], color_order, C.byref(cm), ptr(depth), dtype,
+                                                    stride, depth_scale, ptr(kps), ptr(desc), C.byref(n), ptr(d), ptr(ru)))
+        return kps[:n.value].copy(), desc[:n.value].copy(), d, ru
 
     # ---- instrumentation ------------------------------------------------------------------------
     def profile_enable(self, on=True):

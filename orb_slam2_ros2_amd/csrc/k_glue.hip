@@ -36,7 +36,10 @@ __global__ __launch_bounds__(256) void k_cvt_gray(const uint8_t* __restrict__ sr
 // one lane per keypoint of the slot: depth lookup at the distorted position, undistortion in place, rightU
 __global__ __launch_bounds__(256) void k_frame_rgbd(orbfe_keypoint* __restrict__ kps, const int32_t* __restrict__ n_kp_ptr, int n_features,
                                                     orbfe_camera cam, const uint8_t* __restrict__ depth, int depth_type, size_t depth_stride,
-                                                    float depth_scale, double* __restrict__ depth_out, double* __restrict__ right_u_out) {
+                                                    float depth_scale, double* __restrict__ depth_out, double* __restrict__ right_u_out,
+                                                    orbfe_keypoint* __restrict__ kps_host) {
+  // kps_host (nullable, orbfe_frame_rgbd_image): the undistorted keypoint records written to page-locked host memory as well; depth /
+  // depth_out / right_u_out may then be page-locked host pointers too (a thousand 2-byte reads and two 8 KB arrays over PCIe)
 #pragma clang fp contract(off)
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_features) return;
@@ -89,6 +92,11 @@ __global__ __launch_bounds__(256) void k_frame_rgbd(orbfe_keypoint* __restrict__
   }
   depth_out[i] = d_out;
   right_u_out[i] = ru_out;
+  if (kps_host) {
+    orbfe_keypoint k = kps[i];
+    k.x = xu, k.y = yu;
+    kps_host[i] = k;
+  }
 }
 
 // Frame records for the sequence-level gather: what Frame::createStereo leaves behind for the tracker, one fixed-size
@@ -128,9 +136,10 @@ void launch_cvt_gray(hipStream_t s, const uint8_t* d_src, size_t src_stride, uin
   hipLaunchKernelGGL(k_cvt_gray, dim3((w + 1023) / 1024, h), dim3(256), 0, s, d_src, src_stride, d_dst, dst_stride, w, order, variant);
 }
 void launch_frame_rgbd(hipStream_t s, orbfe_keypoint* d_kps, const int32_t* d_n_kp, int n_features, const orbfe_camera& cam,
-                       const uint8_t* d_depth, int depth_type, size_t depth_stride, float depth_scale, double* d_depth_out, double* d_right_u) {
+                       const uint8_t* d_depth, int depth_type, size_t depth_stride, float depth_scale, double* d_depth_out, double* d_right_u,
+                       orbfe_keypoint* h_kps) {
   hipLaunchKernelGGL(k_frame_rgbd, dim3((n_features + 255) / 256), dim3(256), 0, s, d_kps, d_n_kp, n_features, cam, d_depth, depth_type,
-                     depth_stride, depth_scale, d_depth_out, d_right_u);
+                     depth_stride, depth_scale, d_depth_out, d_right_u, h_kps);
 }
 
 }  // namespace orbfe

@@ -64,7 +64,7 @@ void launch_stereo(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint
 void launch_cvt_gray(hipStream_t s, const uint8_t* d_src, size_t src_stride, uint8_t* d_dst, int dst_stride, int w, int h, int order,
                      int variant);
 void launch_frame_rgbd(hipStream_t s, orbfe_keypoint* d_kps, const int32_t* d_n_kp, int n_features, const orbfe_camera& cam,
-                       const uint8_t* d_depth, int depth_type, size_t depth_stride, float depth_scale, double* d_depth_out, double* d_right_u);
+                       const uint8_t* d_depth, int depth_type, size_t depth_stride, float depth_scale, double* d_depth_out, double* d_right_u, orbfe_keypoint* h_kps = nullptr);
 void launch_pack_records(hipStream_t s, const uint8_t* d_kps, const uint8_t* d_desc, const int32_t* d_counts, const uint8_t* d_ru,
                          const uint8_t* d_dp, const int32_t* d_nm, int nf, int n_pairs, void* d_out);
 // k_lba.hip
@@ -154,6 +154,8 @@ struct orbfe_ctx {
     const uint8_t* stage;
     const uint8_t* pyr;  // the pyramid buffer baked into the captured kernels (the pipelined batch path swaps the context's two buffers)
     hipGraphExec_t exec;
+    bool rgbd = false;     // the RGB-D tail rides in the graph (orbfe_frame_rgbd_image), with the request's constants (FrameRgbdKey)
+    unsigned char rkey[72] = {0};
   };
   // One in-order host-pointer pipeline: a stream, its pinned staging buffer and the hipGraphs captured on it.  The context has a main
   // lane (its own stream) and, created on first use, one lane per image slot for orbfe_extract_slot: the reference extracts the left
@@ -1447,19 +1449,54 @@ struct FrameStereoReq {
   double *right_u, *depth;  // [n_features], caller's
   int32_t* n_matches;
 };
+// fr (orbfe_frame_rgbd_image; one image): the image may be a 3-channel one (converted to gray on the way into level 0), and the RGB-D tail of
+// the Frame constructor -- undistortion, depth / rightU lookup -- follows the extraction in the same launch sequence; the depth image is
+// read by that kernel straight from the staging buffer (one 2- or 4-byte read per keypoint: it is never uploaded)
+struct FrameRgbdReq {
+  int32_t color_order;  // 0: the image is gray | 1: RGB | 2: BGR
+  orbfe_camera cam;
+  const void* depth;    // nullable: undistortion only
+  int32_t depth_type;
+  size_t depth_stride;
+  float depth_scale;
+  double *depth_out, *right_u_out;  // [n_features], caller's, nullable
+};
+struct FrameRgbdKey {  // what of a request is baked into a captured launch sequence
+  int32_t color_order, has_depth, depth_type;
+  size_t depth_stride;
+  float depth_scale;
+  orbfe_camera cam;
+};
 static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, int n_img, const uint8_t* const* imgs, size_t stride,
-                                 orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out, bool timing, const FrameStereoReq* fs = nullptr) {
+                                 orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out, bool timing, const FrameStereoReq* fs = nullptr,
+                                 const FrameRgbdReq* fr = nullptr) {
   const LevelDev& L0 = c->lv[0];
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
-  const size_t plane = align_up((size_t)L0.stride * L0.h, 256);
+  const bool color = fr && fr->color_order != 0;
+  const size_t crow = align_up((size_t)c->cfg.width * 3, 16) + 16;  // staged colour rows: 4-aligned, with room for the last 12-byte group
+  const size_t plane = align_up(color ? crow * (size_t)L0.h : (size_t)L0.stride * L0.h, 256);
   const size_t o_kps = (size_t)n_img * plane, o_desc = o_kps + align_up((size_t)n_img * NF * sizeof(orbfe_keypoint), 256);
   const size_t o_cnt = o_desc + align_up((size_t)n_img * NF * 32, 256), o_ru = o_cnt + align_up((size_t)n_img * 4, 256);
-  const size_t o_dp = o_ru + (fs ? align_up(NF * 8, 256) : 0), total = o_dp + (fs ? align_up(NF * 8, 256) : 0);
+  const bool extra = fs || fr;
+  const size_t o_dp = o_ru + (extra ? align_up(NF * 8, 256) : 0), o_dimg = o_dp + (extra ? align_up(NF * 8, 256) : 0);
+  const size_t d_bytes = (fr && fr->depth) ? fr->depth_stride * (size_t)c->cfg.height : 0;
+  const size_t total = o_dimg + align_up(d_bytes, 256);
   TRY(ensure_stage(c, ln, total));
   for (int i = 0; i < n_img; ++i) {
     if (!imgs[i]) return fail(c, ORBFE_EBADARG, "extract: image %d is NULL", i);
     uint8_t* dst = ln.h_stage + (size_t)i * plane;
-    for (int y = 0; y < L0.h; ++y) std::memcpy(dst + (size_t)y * L0.stride, imgs[i] + (size_t)y * stride, (size_t)c->cfg.width);
+    if (color)
+      for (int y = 0; y < L0.h; ++y) std::memcpy(dst + (size_t)y * crow, imgs[i] + (size_t)y * stride, (size_t)c->cfg.width * 3);
+    else
+      for (int y = 0; y < L0.h; ++y) std::memcpy(dst + (size_t)y * L0.stride, imgs[i] + (size_t)y * stride, (size_t)c->cfg.width);
+  }
+  if (d_bytes) std::memcpy(ln.h_stage + o_dimg, fr->depth, d_bytes);
+  FrameRgbdKey rkey;
+  static_assert(sizeof(FrameRgbdKey) <= sizeof(orbfe_ctx::GraphEntry::rkey), "GraphEntry::rkey");
+  std::memset(&rkey, 0, sizeof rkey);
+  if (fr) {
+    rkey.color_order = fr->color_order, rkey.has_depth = fr->depth ? 1 : 0, rkey.depth_type = fr->depth_type;
+    rkey.depth_stride = fr->depth_stride, rkey.depth_scale = fr->depth_scale, rkey.cam = fr->cam;
   }
   uint8_t* const pyr_now = c->d_pyr;
   note_slots_written(c, slot0, n_img, n_img <= 2);  // (also when a captured graph is replayed: run_extract does not run then)
@@ -1467,13 +1504,16 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
   // descriptors there themselves (posted PCIe writes, ~120 KB per image) beside the device arrays the stereo match reads -- three
   // device-to-host copies queued behind the last kernel cost ~17 us of a ~0.3 ms call.  More than two images: the copies.
   const bool mirror_on = n_img <= 2;
-  HostMirror mir = {kps ? (orbfe_keypoint*)(ln.h_stage + o_kps) : nullptr, desc ? ln.h_stage + o_desc : nullptr, (int32_t*)(ln.h_stage + o_cnt)};
+  HostMirror mir = {(kps && !fr) ? (orbfe_keypoint*)(ln.h_stage + o_kps) : nullptr, desc ? ln.h_stage + o_desc : nullptr, (int32_t*)(ln.h_stage + o_cnt)};
   auto enqueue_all = [&]() -> orbfe_status {
     // (more images: both in ONE copy -- rows = images: the staging planes are `plane` bytes apart, the pyramid slots img_pitch)
     // One or two images: level 0 is read from the page-locked staging planes by a copy KERNEL (16 bytes per load over PCIe, every byte
     // once) -- 6 us less per pair than the copy engine's 27 us transfer and its hand-over to the compute queue (same box, alternating:
     // extraction 0.278 -> 0.271 ms).  (The resize reading the staged planes itself was measured in r3 and dropped: it reads a pixel more than once.)
-    if (n_img <= 2)
+    if (color)  // (one image) cv::cvtColor of Tracking::grabFrame on the way in: the kernel reads the staged rows itself
+      launch_cvt_gray(ln.stream, ln.h_stage, crow, pyr_now + (size_t)slot0 * c->img_pitch + L0.plane_off, L0.stride, c->cfg.width, c->cfg.height,
+                      fr->color_order, c->cfg.gray_variant ? 1 : 0);
+    else if (n_img <= 2)
       launch_load_level0(ln.stream, ln.h_stage, nullptr, (size_t)L0.stride, plane, pyr_now, c->img_pitch, (uint32_t)L0.plane_off, L0.stride, c->cfg.width,
                          L0.h, slot0, 1, n_img);
     else
@@ -1485,6 +1525,12 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
       const StereoHostOut ho = {(double*)(ln.h_stage + o_ru), (double*)(ln.h_stage + o_dp), nullptr, nullptr};
       const bool table_ready = c->slot_table_ok && c->slot_table_ok[(size_t)slot0 + 1] != 0;
       TRY(run_stereo(c, ln.stream, slot0, slot0 + 1, 0, slot0 / 2, 1, fs->fx, fs->bf, &ho, table_ready, timing));
+    }
+    if (fr) {
+      launch_frame_rgbd(ln.stream, c->d_kps + (size_t)slot0 * NF, c->d_n_kp + slot0, (int)NF, fr->cam, d_bytes ? ln.h_stage + o_dimg : nullptr,
+                        fr->depth_type, fr->depth_stride, fr->depth_scale, (double*)(ln.h_stage + o_dp), (double*)(ln.h_stage + o_ru),
+                        (orbfe_keypoint*)(ln.h_stage + o_kps));
+      HIP_TRY(c, hipGetLastError());
     }
     if (mirror_on) return ORBFE_OK;
     return enqueue_fetch(c, ln, slot0, n_img, o_kps, o_desc, o_cnt, kps != nullptr, desc != nullptr);
@@ -1503,6 +1549,11 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
       if (fs->depth && n) std::memcpy(fs->depth, dp, sizeof(double) * n);
       if (fs->n_matches) *fs->n_matches = nm;
     }
+    if (fr) {
+      const size_t n = (size_t)c->cfg.n_features;
+      if (fr->depth_out && n) std::memcpy(fr->depth_out, ln.h_stage + o_dp, sizeof(double) * n);
+      if (fr->right_u_out && n) std::memcpy(fr->right_u_out, ln.h_stage + o_ru, sizeof(double) * n);
+    }
     return ORBFE_OK;
   };
   if (c->use_graphs && ln.use_graphs && c->prof == 0 && n_img <= 2) {
@@ -1514,7 +1565,8 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
         continue;
       }
       if (it->slot0 == slot0 && it->n_img == n_img && it->want_kps == (kps != nullptr) && it->want_desc == (desc != nullptr) && it->pyr == pyr_now &&
-          it->stereo == (fs != nullptr) && (!fs || (it->fx == fs->fx && it->bf == fs->bf)))
+          it->stereo == (fs != nullptr) && (!fs || (it->fx == fs->fx && it->bf == fs->bf)) && it->rgbd == (fr != nullptr) &&
+          (!fr || std::memcmp(&it->rkey, &rkey, sizeof rkey) == 0))
         exec = it->exec;
       ++it;
     }
@@ -1526,7 +1578,10 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
       if (ok) ok = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess;
       if (g) (void)hipGraphDestroy(g);
       if (ok) {
-        ln.graphs.push_back({slot0, n_img, kps != nullptr, desc != nullptr, fs != nullptr, fs ? fs->fx : 0.f, fs ? fs->bf : 0.f, ln.h_stage, pyr_now, exec});
+        orbfe_ctx::GraphEntry ge{slot0, n_img, kps != nullptr, desc != nullptr, fs != nullptr, fs ? fs->fx : 0.f, fs ? fs->bf : 0.f, ln.h_stage, pyr_now, exec};
+        ge.rgbd = fr != nullptr;
+        std::memcpy(ge.rkey, &rkey, sizeof rkey);
+        ln.graphs.push_back(ge);
       } else {
         (void)hipGetLastError();
         exec = nullptr;
@@ -1581,12 +1636,12 @@ orbfe_status orbfe_extract_slot(orbfe_ctx* c, int32_t slot, const uint8_t* img, 
 // n_img images -> slots [slot0, slot0 + n_img) on slot0's lane: what a caller does who holds BOTH images of a stereo frame when the
 // first extract() is reached (host/orbfe_shim.hpp keeps one orbfe_extract_slot per extract() thread: pairing the threads was measured and dropped)
 static orbfe_status extract_slots_impl(orbfe_ctx* c, int32_t slot, int32_t n_img, const uint8_t* const* imgs, size_t stride, orbfe_keypoint* kps,
-                                       uint8_t* desc, int32_t* n_out, const FrameStereoReq* fs) {
+                                       uint8_t* desc, int32_t* n_out, const FrameStereoReq* fs, const FrameRgbdReq* fr = nullptr) {
   if (!c || !imgs || n_img < 1) return fail(c, ORBFE_EBADARG, "extract_slots: NULL argument / no image");
   const uint8_t* img = imgs[0];
   if (!img) return fail(c, ORBFE_EBADARG, "extract_slot: NULL argument");
   if (slot < 0 || slot + n_img > c->cfg.max_images) return fail(c, ORBFE_EBADARG, "extract_slot: slots %d..%d of %d", slot, slot + n_img - 1, c->cfg.max_images);
-  if (stride < (size_t)c->cfg.width) return fail(c, ORBFE_EBADARG, "extract_slot: stride %zu < width %d", stride, c->cfg.width);
+  if (stride < (size_t)c->cfg.width * ((fr && fr->color_order) ? 3 : 1)) return fail(c, ORBFE_EBADARG, "extract_slot: stride %zu < the row's %d bytes", stride, c->cfg.width * ((fr && fr->color_order) ? 3 : 1));
   HIP_TRY(c, hipSetDevice(c->device));
   // the lanes of EVERY slot the call writes, created on first use and locked in index order (a concurrent slot call on any of them waits;
   // two multi-slot calls cannot deadlock); the work runs on the first slot's lane
@@ -1622,11 +1677,28 @@ static orbfe_status extract_slots_impl(orbfe_ctx* c, int32_t slot, int32_t n_img
     HIP_TRY(c, hipEventRecord(ln->ev_main, c->stream));
     HIP_TRY(c, hipStreamWaitEvent(ln->stream, ln->ev_main, 0));
   }
-  return extract_lane(c, *ln, slot, n_img, imgs, stride, kps, desc, n_out, false, fs);
+  return extract_lane(c, *ln, slot, n_img, imgs, stride, kps, desc, n_out, false, fs, fr);
 }
 orbfe_status orbfe_extract_slots(orbfe_ctx* c, int32_t slot, int32_t n_img, const uint8_t* const* imgs, size_t stride, orbfe_keypoint* kps,
                                  uint8_t* desc, int32_t* n_out) {
   return extract_slots_impl(c, slot, n_img, imgs, stride, kps, desc, n_out, nullptr);
+}
+// The device work of Frame::createRGBD (include/ORB_SLAM2/Frame.h:326-331) for one image as ONE call: Tracking::grabFrame's cvtColor when the
+// image has three channels (src/Tracking.cc:55-68), the extraction (the RGB-D Frame constructor, src/Frame.cc:125-135), then
+// Camera::undistortPoints and the depth / rightU lookup (:136-158) -- what orbfe_extract_color / orbfe_extract_slot followed by
+// orbfe_frame_rgbd do in two calls.  On the slot's own lane (as orbfe_extract_slot).  The depth image is never uploaded: the last kernel
+// reads one value per keypoint from the page-locked staging copy.
+orbfe_status orbfe_frame_rgbd_image(orbfe_ctx* c, int32_t slot, const uint8_t* img, size_t stride, int32_t color_order, const orbfe_camera* cam,
+                                    const void* depth, int32_t depth_type, size_t depth_stride, float depth_scale, orbfe_keypoint* kps_undistorted,
+                                    uint8_t* desc, int32_t* n_out, double* depth_out, double* right_u_out) {
+  if (!c || !img || !cam) return fail(c, ORBFE_EBADARG, "frame_rgbd_image: NULL argument");
+  if (color_order < 0 || color_order > 2) return fail(c, ORBFE_EBADARG, "frame_rgbd_image: color_order %d (0 = gray, 1 = RGB, 2 = BGR)", color_order);
+  const size_t px = depth_type == 0 ? 2 : 4;
+  if (depth && (depth_type < 0 || depth_type > 1 || depth_stride < (size_t)c->cfg.width * px || !(depth_scale > 0)))
+    return fail(c, ORBFE_EBADARG, "frame_rgbd_image: depth type %d stride %zu scale %g", depth_type, depth_stride, (double)depth_scale);
+  const uint8_t* one[1] = {img};
+  const FrameRgbdReq fr = {color_order, *cam, depth, depth_type, depth_stride, depth_scale, depth_out, right_u_out};
+  return extract_slots_impl(c, slot, 1, one, stride, kps_undistorted, desc, n_out, nullptr, &fr);
 }
 // orbfe_frame_stereo into the slot pair (slot_left, slot_left + 1), slot_left even, on slot_left's lane: what the drop-in's frame-level
 // adapter calls (the extractor objects rotate over the context's slots; a Frame's device-side features live as long as its slots do)

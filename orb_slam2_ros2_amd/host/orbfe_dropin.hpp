@@ -16,6 +16,7 @@
 //   orbfe::dropin::searchByProjection x2  frame <- frame (ORBMatcher.h:49, src/ORBMatcher.cc:265-347) and frame <- map points (ORBMatcher.h:52,
 //                                         :561-612)
 //   orbfe::dropin::frameRGBD              the tail of `Frame::Frame` for RGB-D input (src/Frame.cc:130-131, :139-157)
+//   orbfe::dropin::createRGBD             extract() AND that tail as ONE device call (ORBExtractor::extractRGBD -> orbfe_frame_rgbd_image)
 //   orbfe::dropin::searchBySim3 x2, searchForTriangulation, fuse x2   the back-end matchers (ORBMatcher.h:55-67, src/ORBMatcher.cc:424-559, 691-787)
 //   orbfe::dropin::trackLocalMap          the middle of `Tracking::trackLocalMap` (src/Tracking.cc:650-658): searchByProjection(frame, local map
 //                                         points, th) + OptimizePoseOnly(frame) as ONE device call
@@ -69,6 +70,17 @@ class ORBExtractor {
     deliver(kl, dl, kpsLeft, descLeft);
     right.deliver(kr, dr, kpsRight, descRight);
     return n;
+  }
+
+  // The extraction and the RGB-D tail of the Frame constructor (src/Frame.cc:125-158) as ONE device call (orbfe_frame_rgbd_image): what the
+  // constructor does with extract(), Camera::undistortPoints and the depth loop (orbfe::dropin::createRGBD below is the body).
+  void extractRGBD(const orbfe_camera& cam, const cv::Mat& depthImg, float dScale, std::vector<cv::KeyPoint>& undistorted,
+                   std::vector<cv::Mat>& descriptors, std::vector<double>& depths, std::vector<double>& rightU) {
+    if (depthImg.type() != CV_32F && depthImg.type() != CV_16U) throw std::invalid_argument("extractRGBD: depth image must be CV_16U or CV_32F");
+    std::vector<orbfe_keypoint> k;
+    std::vector<orbfe::Descriptor> d;
+    mImpl.extractRGBD(cam, depthImg.data, depthImg.type() == CV_32F ? 1 : 0, (size_t)depthImg.step, dScale, k, d, depths, rightU);
+    deliver(k, d, undistorted, descriptors);
   }
 
  private:
@@ -965,10 +977,8 @@ static void OptimizeLocalMap(KeyFramePtr pkframe, bool& isStop) {
   // The tail of Frame::Frame (RGB-D) after extract() (src/Frame.cc:130-131, :139-157): depthImg.convertTo(CV_32F) / dScale, the copy of the
   // distorted keypoints, Camera::undistortPoints(mvFeatsLeft), the depth / rightU lookup -- as one call on the extractor's slot.  depthImg
   // as read from the file: CV_16U (TUM) or CV_32F.  initGrid() stays with the caller (the grid is rebuilt on the device per search).
-  template <class CameraT, class FrameT>
-  static void frameRGBD(FrameT* self, const cv::Mat& depthImg, float dScale) {
-    const auto& ext = self->mpExtractorLeft->device();
-    if (!ext.resident()) throw std::logic_error("frameRGBD: the extractor's slot has been re-used since extract()");
+  template <class CameraT>
+  static orbfe_camera cameraOf() {
     orbfe_camera cam{};
     cam.fx = CameraT::mfFx, cam.fy = CameraT::mfFy, cam.cx = CameraT::mfCx, cam.cy = CameraT::mfCy, cam.bf = CameraT::mfBf;
     if (!CameraT::mDistCoeff.empty()) {
@@ -977,6 +987,22 @@ static void OptimizeLocalMap(KeyFramePtr pkframe, bool& isStop) {
       for (int i = 0; i < nd && i < 5; ++i) d[i] = CameraT::mDistCoeff.template at<float>(i);
       cam.k1 = d[0], cam.k2 = d[1], cam.p1 = d[2], cam.p2 = d[3], cam.k3 = d[4];
     }
+    return cam;
+  }
+  // The whole device work of the RGB-D Frame constructor (src/Frame.cc:125-158, what Frame::createRGBD runs, include/ORB_SLAM2/Frame.h:
+  // 326-331) as ONE call: stands for extract() at :138 AND the tail frameRGBD covers -- fills mvFeatsLeft (undistorted), mvLeftDescriptor,
+  // mvDepths, mvFeatsRightU; mvpMapPoints is resized.  INTEGRATION.md 4b shows the edit.
+  template <class CameraT, class FrameT>
+  static void createRGBD(FrameT* self, const cv::Mat& depthImg, float dScale) {
+    self->mpExtractorLeft->extractRGBD(cameraOf<CameraT>(), depthImg, dScale, self->mvFeatsLeft, self->mvLeftDescriptor, self->mvDepths,
+                                       self->mvFeatsRightU);
+    self->mvpMapPoints.resize(self->mvFeatsLeft.size(), nullptr);
+  }
+  template <class CameraT, class FrameT>
+  static void frameRGBD(FrameT* self, const cv::Mat& depthImg, float dScale) {
+    const auto& ext = self->mpExtractorLeft->device();
+    if (!ext.resident()) throw std::logic_error("frameRGBD: the extractor's slot has been re-used since extract()");
+    const orbfe_camera cam = cameraOf<CameraT>();
     const size_t n = self->mvFeatsLeft.size();
     const size_t cap = (size_t)std::max<int>(orbfe_get_capacity(ext.context()), 1);
     std::vector<orbfe_keypoint> und(cap);
@@ -1000,6 +1026,10 @@ int searchByStereo(FramePtr pFrame) {
 template <class CameraT, class FrameT>
 int createStereo(FrameT* self) {
   return Bodies::template createStereo<CameraT>(self);
+}
+template <class CameraT, class FrameT>
+void createRGBD(FrameT* self, const cv::Mat& depthImg, float dScale) {
+  Bodies::template createRGBD<CameraT>(self, depthImg, dScale);
 }
 template <class CameraT, class FramePtr>
 int OptimizePoseOnly(FramePtr pFrame) {

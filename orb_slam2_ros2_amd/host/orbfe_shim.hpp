@@ -221,6 +221,21 @@ class ORBExtractor {
     return nm;
   }
 
+  // Frame::createRGBD's device work as ONE call (include/ORB_SLAM2/Frame.h:326-331; the RGB-D Frame constructor, src/Frame.cc:125-158):
+  // the extraction of this object's (gray) image, Camera::undistortPoints and the depth / rightU lookup -- the results of extract()
+  // followed by orbfe_frame_rgbd.  depth: the image as read from the file (type 0: 16-bit, 1: float), rows depthStep bytes apart.
+  void extractRGBD(const orbfe_camera& cam, const void* depth, int depthType, size_t depthStep, float depthScale,
+                   std::vector<orbfe_keypoint>& undistorted, std::vector<Descriptor>& descriptors, std::vector<double>& depths,
+                   std::vector<double>& rightU) {
+    undistorted.resize(mnFeats), descriptors.resize(mnFeats), depths.resize(mnFeats), rightU.resize(mnFeats);
+    int32_t n = 0;
+    mLease = ContextPool::acquire(mCtx);
+    check(mCtx, orbfe_frame_rgbd_image(mCtx, mLease.slot, mImage.data, mImage.step, 0, &cam, depth, depthType, depthStep, depthScale,
+                                       undistorted.data(), descriptors.data()->data(), &n, depths.data(), rightU.data()));
+    undistorted.resize(n), descriptors.resize(n), depths.resize(n), rightU.resize(n);
+    mnKeyPoints = n;
+  }
+
   // level `l` of the un-blurred pyramid, tight rows (what getPyramid()[l] holds in the reference).  Read from the device on demand:
   // if the slot has been handed to another extractor since, the pyramid is rebuilt from the image this object still refers to
   // (like the reference's pyramid, it lives as long as the image does).

@@ -546,6 +546,18 @@ static int mode_rgbd(int argc, char** argv) {
     moved += f.mvFeatsLeft[i].pt.x != distorted[i].pt.x;
     with_depth += f.mvDepths[i] > 0;
   }
+  // ... and the whole constructor as ONE device call (orbfe::dropin::createRGBD): the same frame, three times (graph replay, slot rotation)
+  for (int rep = 0; ok && rep < 3; ++rep) {
+    F g;
+    g.mLeftIm = gray;
+    g.mpExtractorLeft = std::make_shared<ORB_SLAM2_ROS2::ORBExtractor>(g.mLeftIm, 1000, 8, 1.2f, "", 20, 7);
+    orbfe::dropin::createRGBD<ref::Camera>(&g, depth, 5208.f);
+    ok = g.mvFeatsLeft.size() == n && g.mvLeftDescriptor.size() == n && g.mvDepths.size() == n && g.mvFeatsRightU.size() == n &&
+         g.mvpMapPoints.size() == n;
+    for (size_t i = 0; ok && i < n; ++i)
+      ok = std::memcmp(&g.mvFeatsLeft[i], &f.mvFeatsLeft[i], sizeof(orbfe_keypoint)) == 0 && g.mvDepths[i] == f.mvDepths[i] &&
+           g.mvFeatsRightU[i] == f.mvFeatsRightU[i] && std::memcmp(g.mvLeftDescriptor[i].data, f.mvLeftDescriptor[i].data, 32) == 0;
+  }
   printf("RGBD_%s %zu %zu %zu\n", ok && moved > n / 2 && with_depth > n / 2 && with_depth < n ? "OK" : "FAIL", n, moved, with_depth);
   return ok ? 0 : 1;
 }

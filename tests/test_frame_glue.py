@@ -129,6 +129,41 @@ def test_device_rgbd_tail_matches_oracle(orc, depth_dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("color_order,depth_dtype", [(0, np.uint16), (2, np.uint16), (1, np.float32), (0, None)])
+def test_device_one_call_rgbd_frame_equals_the_two_calls(orc, color_order, depth_dtype):
+    """orbfe_frame_rgbd_image (Frame::createRGBD's device work as one launch sequence) against orbfe_extract_color / orbfe_extract followed by
+    orbfe_frame_rgbd -- which the tests above pin to the oracle -- and, for the gray image, against the oracle directly; repeated so that the
+    captured sequence is replayed, with changing images and a second slot on its own lane"""
+    from orb_slam2_ros2_amd._lib import Context
+    ctx, ref = Context(640, 480, n_features=1000, max_images=2), Context(640, 480, n_features=1000, max_images=1)
+    rng = np.random.default_rng(11)
+    try:
+        for rep, f in enumerate((4, 4, 6, 4)):
+            gray = synth.mono_image(f, 640, 480)
+            img = gray if color_order == 0 else np.stack([gray, np.roll(gray, 3, 1), np.roll(gray, 2, 0)], 2).copy()
+            depth, scale = None, 1.0
+            if depth_dtype is not None:
+                raw = rng.integers(0, 30000, (480, 640)).astype(np.uint16)
+                raw[rng.random((480, 640)) < 0.2] = 0
+                depth, scale = (raw, 5000.0) if depth_dtype == np.uint16 else ((raw / np.float32(5000)).astype(np.float32), 1.0)
+            slot = rep & 1
+            ku, d, dd, ru = ctx.frame_rgbd_image(img, TUM, depth, scale, color_order, slot=slot)
+            k0, d0 = ref.extract_color(img, color_order) if color_order else ref.extract(img)
+            ku0, dd0, ru0 = ref.frame_rgbd(0, TUM, depth, scale)
+            n = len(k0)
+            assert len(ku) == n and np.array_equal(d, d0)
+            assert ku.tobytes() == ku0[:n].tobytes()
+            assert np.array_equal(dd.view(np.int64), dd0.view(np.int64)) and np.array_equal(ru.view(np.int64), ru0.view(np.int64))
+            if color_order == 0:
+                ok, od = orc.extractor(gray, n_features=1000).extract()
+                assert n == len(ok) and np.array_equal(d, od)
+            # the slot's device-resident results are the frame's: a guided search against it sees the undistorted keypoints
+            assert np.array_equal(ctx.pyramid(slot, 0, False), ref.pyramid(0, 0, False))
+    finally:
+        ctx.close(), ref.close()
+
+
+@pytest.mark.gpu
 def test_device_glue_error_paths():
     from orb_slam2_ros2_amd._lib import Context, OrbfeError
     ctx = Context(640, 480, n_features=500, max_images=1)
