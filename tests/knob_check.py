@@ -65,6 +65,15 @@ def main():
     for f, slot in ((6, None), (6, None), (12, 4), (12, 4), (2, None)):
         (lk, ld), (rk, rd), m, r, d = ctx.frame_stereo(*frames[f], FX, BF, slot_left=slot)
         assert pair_digest(lk, ld, rk, rd, r, d, m) == gold[str(f)], f"frame_stereo, frame {f}, slot {slot}"
+    # ... and an RGB-D frame as one call (orbfe_frame_rgbd_image) against the two calls it stands for, on two other slots
+    cam = dict(fx=718.856, fy=718.856, cx=607.19, cy=185.22, k1=0.05, k2=-0.02, p1=0.001, p2=-0.0005, k3=0.01, bf=386.14)
+    dep = (np.arange(376 * 1241, dtype=np.uint32).reshape(376, 1241) * 2654435761 >> 17).astype(np.uint16)
+    for f in (8, 8, 13):
+        ku, d, dd, ru = ctx.frame_rgbd_image(frames[f][0], cam, dep, 5000.0, 0, slot=6)
+        k0, d0 = ctx.extract_slot(7, frames[f][0])
+        ku0, dd0, ru0 = ctx.frame_rgbd(7, cam, dep, 5000.0)
+        assert len(ku) == len(k0) and np.array_equal(d, d0) and ku.tobytes() == ku0[:len(ku)].tobytes(), f"frame_rgbd_image, frame {f}"
+        assert np.array_equal(dd, dd0) and np.array_equal(ru, ru0), f"frame_rgbd_image depth, frame {f}"
     ctx.close()
     print("KNOB_OK", n_pairs)
 
