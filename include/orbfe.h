@@ -447,6 +447,36 @@ typedef struct orbfe_track_output {
 orbfe_status orbfe_track_local_map(orbfe_ctx* ctx, int32_t slot, const orbfe_frame_pose* pose, const orbfe_camera* cam,
                                    const orbfe_track_input* in, const orbfe_track_output* out);
 
+/* The middle of Tracking::trackMotionModel (src/Tracking.cc:382-396) as ONE call: ORBMatcher::searchByProjection(frame, lastFrame, matches, th)
+ * -- in this reference a search around the LAST frame's feature positions within th pixels, octave window by the motion direction, among the
+ * frame's features that hold no map point yet, accepted when ratio < mfRatio and distance < mnMinThreshold; every accepted query is a match
+ * and setMapPoints assigns them in query order, so the last query that picked a feature keeps it (src/ORBMatcher.cc:265-347, :815-830) --
+ * then, with fewer than min_matches matches, the same search with th_second among the features still free (Tracking.cc:388-391; the
+ * matches of the first stay), then Optimizer::OptimizePoseOnly(frame).  The frame's features are the device-resident results of `slot`.
+ * Queries = the last frame's features that hold a good map point, in feature order (the caller's filter, :286-289).
+ * Outputs as orbfe_track_local_map (assigned[f] = query index); n_matches = the accepted queries of all passes; excluded_hits[f]
+ * (nullable) = how many queries met feature f among their candidates while it held a map point (the addMatchInTrack calls of :322-331);
+ * passes (nullable) = 1 or 2.  The second search is decided on the host.  At most 2048 features per frame.                          */
+typedef struct orbfe_motion_input {
+  int32_t n;
+  const float* qxy;              /* [n][2] the last frame's (undistorted) feature positions: the search centres            */
+  const int8_t* q_min_level;     /* [n] octave window (:300-315: [octave, 7] forward, [0, octave] backward, else +-1)       */
+  const int8_t* q_max_level;     /* [n]                                                                                    */
+  const uint8_t* desc;           /* [n][32] the last frame's descriptors                                                   */
+  const float* pos;              /* [n][3] the map points' positions (the pose-only edges)                                 */
+  const int32_t* held;           /* [n_features], nullable: query index a feature of the frame holds on entry, -1 none     */
+  const double* right_u;         /* [n_features], nullable                                                                 */
+  const float* level_sigma2;     /* [n_levels]                                                                             */
+  const float* level_inv_sigma2; /* [n_levels]                                                                             */
+  const double* pose_se3;        /* [7] the predicted pose: the optimisation's initial estimate                            */
+  float th, th_second;           /* 15, 30 (Tracking.cc:387, 390); th_second <= 0: no second search                        */
+  float ratio;                   /* ORBMatcher::mfRatio (0.9 in trackMotionModel)                                          */
+  int32_t min_threshold;         /* ORBMatcher::mnMinThreshold                                                             */
+  int32_t min_matches;           /* 20 (Tracking.cc:388, 392)                                                              */
+} orbfe_motion_input;
+orbfe_status orbfe_track_motion_model(orbfe_ctx* ctx, int32_t slot, const float* bounds4 /* mfMinU mfMaxU mfMinV mfMaxV */, const orbfe_camera* cam,
+                                      const orbfe_motion_input* in, const orbfe_track_output* out, int32_t* excluded_hits, int32_t* passes);
+
 /* ---- map.pb: the reference's on-disk map, and a local bundle adjustment on it -------------------------------
  * `orbslam2.MapData` as Map::saveToProtobuf writes it (src/Map.cc:200-250; proto/Map.proto, Keyframe.proto,
  * MapPoint.proto), read and written without libprotobuf (host/map_pb.hpp).  The first three calls are host-only

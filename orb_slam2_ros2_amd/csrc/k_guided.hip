@@ -309,11 +309,21 @@ __global__ __launch_bounds__(256) void k_track_queries(int n, const uint8_t* __r
 
 __global__ __launch_bounds__(256) void k_track_claim(int n, const int32_t* __restrict__ n_cand, const int32_t* __restrict__ best_idx,
                                                      const int32_t* __restrict__ best_dist, const int32_t* __restrict__ second_dist,
-                                                     int min_threshold, float ratio, int32_t* __restrict__ claim) {
+                                                     int min_threshold, float ratio, int32_t* __restrict__ claim, int last_wins,
+                                                     int32_t* __restrict__ n_accept) {
+  // last_wins (the frame <- frame search, ORBMatcher.cc:265-347): every accepted query is a match and setMapPoints assigns them in query
+  // order (:815-830) -- the LAST query that picked a feature keeps it (atomicMax over claims that start at -1), and the return value counts
+  // the accepted queries (n_accept), not the features
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n || n_cand[i] <= 0) return;
   const float fr = (float)best_dist[i] / (float)second_dist[i];  // getBestMatch's ratio (ORBMatcher.cc:988); second = INT_MAX -> ~0
-  if (best_dist[i] < min_threshold && fr < ratio) atomicMin(&claim[best_idx[i]], i);
+  if (best_dist[i] < min_threshold && fr < ratio) {
+    if (last_wins) {
+      atomicMax(&claim[best_idx[i]], i);
+      atomicAdd(n_accept, 1);
+    } else
+      atomicMin(&claim[best_idx[i]], i);
+  }
 }
 
 // One workgroup: final assignment per feature, the reference's match count, and the pose-only edge list in feature order.
@@ -327,7 +337,10 @@ __global__ __launch_bounds__(1024) void k_track_edges(const orbfe_keypoint* __re
                                                       const float* __restrict__ level_inv_sigma2, int min_matches,
                                                       int32_t* __restrict__ assigned, int32_t* __restrict__ edge_of, double* __restrict__ Xw,
                                                       double* __restrict__ meas, double* __restrict__ info, float* __restrict__ sigma2,
-                                                      int32_t* __restrict__ counts /*[0] n_matches, [1] n_edges (-1: below min_matches)*/) {
+                                                      int32_t* __restrict__ counts /*[0] n_matches, [1] n_edges (-1: below min_matches)*/,
+                                                      int32_t unclaimed, const int32_t* __restrict__ n_accept, int base_matches) {
+  // unclaimed: the value a claim starts with (0x7F7F7F7F under atomicMin, -1 under atomicMax).  n_accept (nullable, the frame <- frame
+  // search): the matches of this pass are the accepted queries counted there, on top of base_matches from an earlier pass
   __shared__ int s_wave[16], s_match[16];
   __shared__ int s_base;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(1024) void k_track_edges(const orbfe_keypoint* __re
       c_held = h >= 0 && (mp_flags[h] & 2);  // `if (pMp && !pMp->isBad()) ++nMatches` (ORBMatcher.cc:566-571)
       mp = h;
       const int cl = claim[f];
-      if (cl != 0x7F7F7F7F && !(h >= 0 && (mp_flags[h] & 1))) mp = cl, c_new = true;  // setMapPoint + ++nMatches (:595-599)
+      if (cl != unclaimed && !(h >= 0 && (mp_flags[h] & 1))) mp = cl, c_new = true;  // setMapPoint + ++nMatches (:595-599)
       edge = mp >= 0 && (mp_flags[mp] & 2);
     }
     if (f < n_features) assigned[f] = mp;
@@ -374,6 +387,7 @@ __global__ __launch_bounds__(1024) void k_track_edges(const orbfe_keypoint* __re
     __syncthreads();
   }
   if (t == 0) {
+    if (n_accept) total_matches = base_matches + *n_accept;
     counts[0] = total_matches;
     counts[1] = total_matches < min_matches ? -1 : s_base;  // Tracking::trackLocalMap returns before the optimisation (Tracking.cc:656-657)
   }
@@ -386,16 +400,17 @@ void launch_track_queries(hipStream_t s, int n, const uint8_t* d_flags, const ui
                      d_min_level, d_max_level);
 }
 void launch_track_claim(hipStream_t s, int n, const int32_t* d_n_cand, const int32_t* d_best_idx, const int32_t* d_best_dist, const int32_t* d_second,
-                        int min_threshold, float ratio, int32_t* d_claim) {
+                        int min_threshold, float ratio, int32_t* d_claim, int last_wins, int32_t* d_n_accept) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_track_claim, dim3((n + 255) / 256), dim3(256), 0, s, n, d_n_cand, d_best_idx, d_best_dist, d_second, min_threshold, ratio, d_claim);
+  hipLaunchKernelGGL(k_track_claim, dim3((n + 255) / 256), dim3(256), 0, s, n, d_n_cand, d_best_idx, d_best_dist, d_second, min_threshold, ratio, d_claim,
+                     last_wins, d_n_accept);
 }
 void launch_track_edges(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, int n_features, const int32_t* d_held, const int32_t* d_claim,
                         const uint8_t* d_mp_flags, const float* d_mp_pos, const double* d_right_u, const float* d_sigma2, const float* d_inv_sigma2,
                         int min_matches, int32_t* d_assigned, int32_t* d_edge_of, double* d_Xw, double* d_meas, double* d_info, float* d_sig,
-                        int32_t* d_counts) {
+                        int32_t* d_counts, int32_t unclaimed, const int32_t* d_n_accept, int base_matches) {
   hipLaunchKernelGGL(k_track_edges, dim3(1), dim3(1024), 0, s, d_kps, d_n_kp, n_features, d_held, d_claim, d_mp_flags, d_mp_pos, d_right_u, d_sigma2,
-                     d_inv_sigma2, min_matches, d_assigned, d_edge_of, d_Xw, d_meas, d_info, d_sig, d_counts);
+                     d_inv_sigma2, min_matches, d_assigned, d_edge_of, d_Xw, d_meas, d_info, d_sig, d_counts, unclaimed, d_n_accept, base_matches);
 }
 
 void launch_project_map_points(hipStream_t s, int n, const float* d_pos, const float* d_vdir, const float* d_max, const float* d_min,

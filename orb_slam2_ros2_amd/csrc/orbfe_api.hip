@@ -116,11 +116,11 @@ void launch_pose_only(hipStream_t s, int n, const double* Xw, const double* meas
 void launch_track_queries(hipStream_t s, int n, const uint8_t* d_flags, const uint8_t* d_visible, const float* d_cos, const int8_t* d_level, float th,
                           const float* d_sigma2, int n_levels, float* d_radius, int8_t* d_min_level, int8_t* d_max_level);
 void launch_track_claim(hipStream_t s, int n, const int32_t* d_n_cand, const int32_t* d_best_idx, const int32_t* d_best_dist, const int32_t* d_second,
-                        int min_threshold, float ratio, int32_t* d_claim);
+                        int min_threshold, float ratio, int32_t* d_claim, int last_wins = 0, int32_t* d_n_accept = nullptr);
 void launch_track_edges(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, int n_features, const int32_t* d_held, const int32_t* d_claim,
                         const uint8_t* d_mp_flags, const float* d_mp_pos, const double* d_right_u, const float* d_sigma2, const float* d_inv_sigma2,
                         int min_matches, int32_t* d_assigned, int32_t* d_edge_of, double* d_Xw, double* d_meas, double* d_info, float* d_sig,
-                        int32_t* d_counts);
+                        int32_t* d_counts, int32_t unclaimed = 0x7F7F7F7F, const int32_t* d_n_accept = nullptr, int base_matches = 0);
 }  // namespace orbfe
 
 using namespace orbfe;
@@ -3164,6 +3164,133 @@ orbfe_status orbfe_track_local_map(orbfe_ctx* c, int32_t slot, const orbfe_frame
   const bool optimised = cnt[1] >= 0;
   for (size_t f = 0; f < NF; ++f) out->inlier[f] = (optimised && eo[f] >= 0) ? ein[eo[f]] : 0;
   if (out->edge_of) std::memcpy(out->edge_of, eo, NF * 4);
+  return ORBFE_OK;
+}
+
+// The middle of Tracking::trackMotionModel (src/Tracking.cc:382-396) as one call: ORBMatcher::searchByProjection(frame, lastFrame, matches, th)
+// -- in this reference a search around the LAST frame's feature positions, no projection (src/ORBMatcher.cc:265-347) -- then, with fewer than
+// min_matches matches, the same search again with th_second among the features still free, then Optimizer::OptimizePoseOnly(frame).  The
+// second search is decided on the host (one more synchronisation in the rare frame that needs it).
+orbfe_status orbfe_track_motion_model(orbfe_ctx* c, int32_t slot, const float* bounds4, const orbfe_camera* cam, const orbfe_motion_input* in,
+                                      const orbfe_track_output* out, int32_t* excluded_hits, int32_t* passes) {
+  ApiLock api_lk(c);
+  if (!c || !bounds4 || !cam || !in || !out || slot < 0 || slot >= c->cfg.max_images) return fail(c, ORBFE_EBADARG, "track_motion_model: NULL argument / bad slot");
+  const int n = in->n, nl = c->cfg.n_levels;
+  const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
+  if (n < 0 || !in->pose_se3 || !in->level_sigma2 || !in->level_inv_sigma2 || !out->assigned || !out->n_matches || !out->n_edges || !out->n_good ||
+      !out->pose_out || !out->inlier || (n && (!in->qxy || !in->q_min_level || !in->q_max_level || !in->desc || !in->pos)))
+    return fail(c, ORBFE_EBADARG, "track_motion_model: NULL array");
+  if (NF > 2048) return fail(c, ORBFE_EBADSIZE, "track_motion_model: %zu features per frame (the fused pose kernel keeps up to 2048 edges in registers)", NF);
+  if (in->held)
+    for (size_t f = 0; f < NF; ++f)
+      if (in->held[f] < -1 || in->held[f] >= n) return fail(c, ORBFE_EBADARG, "track_motion_model: held[%zu] = %d out of range", f, in->held[f]);
+  AreaGrid ag;
+  if (!area_grid(c, bounds4, &ag)) return fail(c, ORBFE_EBADARG, "track_motion_model: bad frame bounds");
+  const size_t ncells = (size_t)ag.rows * ag.cols;
+  if ((2 * ncells + 1) * 4 > 60 * 1024) return fail(c, ORBFE_EBADSIZE, "track_motion_model: %zu grid cells exceed the LDS counters", ncells);
+  HIP_TRY(c, hipSetDevice(c->device));
+  TRY(join_stereo(c));
+  const size_t N = (size_t)std::max(n, 1);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o2 = off;
+    off += align_up(std::max<size_t>(bytes, 8), 256);
+    return o2;
+  };
+  // [ upload once | upload per pass | claim (-1 fill), hits and counter (0 fill) | device-only | download ]
+  const size_t o_qxy = take(N * 8), o_lo = take(N), o_hi = take(N), o_desc = take(N * 32), o_pos = take(N * 12), o_fl = take(N), o_ru = take(NF * 8),
+               o_s2 = take((size_t)nl * 4), o_is2 = take((size_t)nl * 4), o_p0 = take(56), o_up1_end = take(8), o_rad = take(N * 4), o_held = take(NF * 4),
+               o_ex = take(NF), o_up2_end = take(8), o_claim = take(NF * 4), o_claim_end = take(8), o_eh = take(NF * 4), o_acc = take(16),
+               o_zero_end = take(8), o_co = take((ncells + 1) * 4), o_cf = take(NF * 4), o_bi = take(N * 4), o_bd = take(N * 4), o_sd = take(N * 4),
+               o_nc = take(N * 4), o_xw = take(NF * 24), o_ms = take(NF * 24), o_info = take(NF * 8), o_sig = take(NF * 4), o_err = take(NF * 24),
+               o_l = take(NF), o_r = take(NF), o_cnt = take(16), o_ng = take(8), o_po = take(56), o_asg = take(NF * 4), o_eo = take(NF * 4), o_in = take(NF),
+               o_ehd = take(NF * 4), o_dn_end = take(8);
+  TRY(ensure_tmp(c, off));
+  TRY(ensure_stage(c, std::max(o_up2_end, o_dn_end - o_cnt)));
+  uint8_t* b = (uint8_t*)c->d_tmp;
+  uint8_t* hs = c->main.h_stage;
+  if (n) {
+    std::memcpy(hs + o_qxy, in->qxy, (size_t)n * 8);
+    std::memcpy(hs + o_lo, in->q_min_level, (size_t)n);
+    std::memcpy(hs + o_hi, in->q_max_level, (size_t)n);
+    std::memcpy(hs + o_desc, in->desc, (size_t)n * 32);
+    std::memcpy(hs + o_pos, in->pos, (size_t)n * 12);
+    std::memset(hs + o_fl, 3, (size_t)n);  // every query is a good map point in the map (the caller's filter, ORBMatcher.cc:286-289)
+  }
+  if (in->right_u) std::memcpy(hs + o_ru, in->right_u, NF * 8);
+  else
+    for (size_t f = 0; f < NF; ++f) ((double*)(hs + o_ru))[f] = -1.0;
+  std::memcpy(hs + o_s2, in->level_sigma2, (size_t)nl * 4);
+  std::memcpy(hs + o_is2, in->level_inv_sigma2, (size_t)nl * 4);
+  std::memcpy(hs + o_p0, in->pose_se3, 56);
+  std::vector<int32_t> held(NF, -1);
+  if (in->held) std::memcpy(held.data(), in->held, NF * 4);
+  std::vector<int32_t> hits_total(excluded_hits ? NF : 0, 0);
+  hipStream_t st = c->stream;
+  const BaParamsDev prm = {(double)cam->fx, (double)cam->fy, (double)cam->cx, (double)cam->cy, (double)cam->bf};
+  int base_matches = 0, n_pass = 0;
+  const int32_t* cnt = (const int32_t*)hs;
+  for (int pass = 0; pass < 2; ++pass) {
+    const float th = pass == 0 ? in->th : in->th_second;
+    if (pass == 1 && !(th > 0)) break;
+    // the per-pass upload: radius, what the features hold, and the candidates that are excluded (a feature that holds a map point: :322-331)
+    for (int i = 0; i < n; ++i) ((float*)(hs + o_rad))[i] = th;
+    std::memcpy(hs + o_held, held.data(), NF * 4);
+    for (size_t f = 0; f < NF; ++f) hs[o_ex + f] = held[f] >= 0 ? 1 : 0;
+    if (pass == 0)
+      HIP_TRY(c, hipMemcpyAsync(b, hs, o_up2_end, hipMemcpyHostToDevice, st));
+    else
+      HIP_TRY(c, hipMemcpyAsync(b + o_rad, hs + o_rad, o_up2_end - o_rad, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(b + o_claim, 0xFF, o_claim_end - o_claim, st));
+    HIP_TRY(c, hipMemsetAsync(b + o_eh, 0, o_zero_end - o_eh, st));
+    {
+      StageTimer tm(c, ORBFE_STAGE_MATCH, st);
+      if (pass == 0)
+        launch_grid_build(st, c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, (int)NF, ag.rows, ag.cols, (int32_t*)(b + o_co), (int32_t*)(b + o_cf));
+      launch_search_area(st, c->d_kpl + (size_t)slot * NF, c->d_desc + (size_t)slot * NF * 32, ag.clip_w, ag.clip_h, ag.rows, ag.cols,
+                         (const int32_t*)(b + o_co), (const int32_t*)(b + o_cf), n, (const float*)(b + o_qxy), (const float*)(b + o_rad),
+                         (const int8_t*)(b + o_lo), (const int8_t*)(b + o_hi), b + o_desc, b + o_ex, (int32_t*)(b + o_bi), (int32_t*)(b + o_bd),
+                         (int32_t*)(b + o_sd), (int32_t*)(b + o_nc), (int32_t*)(b + o_eh));
+      launch_track_claim(st, n, (const int32_t*)(b + o_nc), (const int32_t*)(b + o_bi), (const int32_t*)(b + o_bd), (const int32_t*)(b + o_sd),
+                         in->min_threshold, in->ratio, (int32_t*)(b + o_claim), 1, (int32_t*)(b + o_acc));
+      launch_track_edges(st, c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, (int)NF, (const int32_t*)(b + o_held), (const int32_t*)(b + o_claim),
+                         b + o_fl, (const float*)(b + o_pos), (const double*)(b + o_ru), (const float*)(b + o_s2), (const float*)(b + o_is2),
+                         in->min_matches, (int32_t*)(b + o_asg), (int32_t*)(b + o_eo), (double*)(b + o_xw), (double*)(b + o_ms),
+                         (double*)(b + o_info), (float*)(b + o_sig), (int32_t*)(b + o_cnt), -1, (const int32_t*)(b + o_acc), base_matches);
+    }
+    {
+      StageTimer tm(c, ORBFE_STAGE_BA, st);
+      launch_pose_only(st, (int)NF, (const double*)(b + o_xw), (const double*)(b + o_ms), (const double*)(b + o_info), (const float*)(b + o_sig),
+                       (const double*)(b + o_p0), prm, (double)(float)std::sqrt(5.991), (double)(float)std::sqrt(7.815), (double*)(b + o_err), b + o_l,
+                       b + o_r, b + o_in, (double*)(b + o_po), (int32_t*)(b + o_ng), (const int32_t*)(b + o_cnt) + 1);
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(b + o_ehd, b + o_eh, NF * 4, hipMemcpyDeviceToDevice, st));  // (the hits sit in front of the downloaded block)
+    HIP_TRY(c, hipMemcpyAsync(hs, b + o_cnt, o_dn_end - o_cnt, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    ++n_pass;
+    if (excluded_hits) {
+      const int32_t* eh = (const int32_t*)(hs + (o_ehd - o_cnt));
+      for (size_t f = 0; f < NF; ++f) hits_total[f] += eh[f];
+    }
+    if (cnt[1] >= 0 || pass == 1 || !(in->th_second > 0)) break;
+    // fewer than min_matches: the matches of this pass stay (setMapPoints, :344-345) and are excluded from the next one
+    base_matches = cnt[0];
+    std::memcpy(held.data(), hs + (o_asg - o_cnt), NF * 4);
+  }
+  drain_timers(c);
+  *out->n_matches = cnt[0];
+  *out->n_edges = cnt[1];
+  std::memcpy(out->n_good, hs + (o_ng - o_cnt), 4);
+  std::memcpy(out->pose_out, hs + (o_po - o_cnt), 56);
+  std::memcpy(out->assigned, hs + (o_asg - o_cnt), NF * 4);
+  const int32_t* eo = (const int32_t*)(hs + (o_eo - o_cnt));
+  const uint8_t* ein = hs + (o_in - o_cnt);
+  const bool optimised = cnt[1] >= 0;
+  for (size_t f = 0; f < NF; ++f) out->inlier[f] = (optimised && eo[f] >= 0) ? ein[eo[f]] : 0;
+  if (out->edge_of) std::memcpy(out->edge_of, eo, NF * 4);
+  if (excluded_hits) std::memcpy(excluded_hits, hits_total.data(), NF * 4);
+  if (passes) *passes = n_pass;
   return ORBFE_OK;
 }
 

@@ -137,3 +137,143 @@ def test_track_local_map_matches_the_three_step_chain(orc, seed, th):
                                s["Rcw"], s["tcw"], (FX, FY, CX, CY, BF), (0.0, float(W), 0.0, float(H)), s["pose_se3"], sig2, inv_sig2)
     assert none["n_matches"] == 0 and (none["assigned"] == -1).all()
     ctx.close()
+
+
+# ---- Tracking::trackMotionModel's middle as one call (orbfe_track_motion_model) -------------------------------------------------
+def _motion_scene(ctx, seed, frac=0.7, jitter=3.0, flip_bits=8):
+    """The frame in slot 0 and a "last frame": a subset of the frame's own keypoints, moved by a few pixels, descriptors a few bits off,
+    each with a map point at the stereo depth under the TRUE pose -- what the last frame's features with good map points look like a
+    frame later."""
+    rng = np.random.default_rng(seed)
+    L, R = synth.stereo_pair(seed)
+    (kps, desc), _ = ctx.extract_batch([L, R])
+    nm, ru, dp, _, _ = ctx.stereo_match(0, 1, FX, BF)
+    n = len(kps)
+    ru_full = np.full(NF, -1.0)
+    ru_full[:n] = ru[:n]
+    q = np.array([0.01, -0.02, 0.005, 1.0]); q /= np.linalg.norm(q)
+    Rt = _quat_to_R(q); tt = np.array([0.05, -0.02, 0.1])
+    depth = np.where(dp[:n] > 0, dp[:n], rng.uniform(4, 30, n))
+    pc = np.stack([(kps["x"] - CX) / FX * depth, (kps["y"] - CY) / FY * depth, depth], 1)
+    Xw = (pc - tt) @ Rt
+    pick = np.sort(rng.permutation(n)[: int(frac * n)])                      # queries in feature order, as the reference walks them
+    pick = np.sort(np.concatenate([pick, pick[rng.permutation(len(pick))[: len(pick) // 12]]]))   # ... some features are seen by two of them
+    pos = (Xw[pick] + rng.normal(0, 0.01, (len(pick), 3))).astype(np.float32)
+    d = desc[pick].copy()
+    fl = rng.integers(0, 256, (len(pick), flip_bits))
+    for k in range(flip_bits):
+        d[np.arange(len(pick)), fl[:, k] // 8] ^= (1 << (fl[:, k] % 8)).astype(np.uint8)
+    qxy = np.stack([kps["x"][pick], kps["y"][pick]], 1).astype(np.float32) + rng.normal(0, jitter, (len(pick), 2)).astype(np.float32)
+    octv = kps["octave"][pick].astype(np.int64)
+    q0 = q + np.array([0.002, -0.001, 0.0015, 0.0]); q0 /= np.linalg.norm(q0)
+    t0 = tt + np.array([0.03, -0.02, 0.04])
+    return dict(kps=kps, desc=desc, n=n, right_u=ru_full, qxy=qxy, octave=octv, q_desc=d, pos=pos, pose_se3=np.concatenate([q0, t0]))
+
+
+def _windows(octave, mode):
+    if mode == "up":
+        return octave.astype(np.int8), np.full(len(octave), 7, np.int8)
+    if mode == "down":
+        return np.zeros(len(octave), np.int8), octave.astype(np.int8)
+    return np.maximum(0, octave - 1).astype(np.int8), np.minimum(7, octave + 1).astype(np.int8)
+
+
+def _reference_motion_chain(orc, s, lo, hi, th=15.0, th_second=30.0, ratio=0.9, min_threshold=50, min_matches=20, held=None):
+    """ORBMatcher::searchByProjection(frame, lastFrame, matches, th) (+ the th_second call) and OptimizePoseOnly, composed from the oracle's
+    findFeaturesInArea + getBestMatch and its pose-only optimiser the way src/ORBMatcher.cc:265-347, :815-830 and src/Tracking.cc:382-396 do"""
+    nq = len(s["qxy"])
+    held = np.full(NF, -1, np.int32) if held is None else held.copy()
+    hits = np.zeros(NF, np.int64)
+    total, passes = 0, 0
+    for radius in (th, th_second):
+        passes += 1
+        ex = (held >= 0).astype(np.uint8)[: s["n"]]
+        bi, bd, sd, nc, eh = orc.search_in_area_ex(s["kps"], s["desc"], (0.0, float(W), 0.0, float(H)), s["qxy"], np.full(nq, radius, np.float32), lo, hi,
+                                                   s["q_desc"], ex)
+        hits[: s["n"]] += eh
+        matches = [(int(bi[i]), i) for i in range(nq)
+                   if nc[i] > 0 and bd[i] < min_threshold and np.float32(bd[i]) / np.float32(sd[i]) < np.float32(ratio)]
+        for f, i in matches:                                              # setMapPoints: in query order, the last one stays
+            held[f] = i
+        total += len(matches)
+        if total >= min_matches or not th_second > 0:
+            break
+    out = dict(assigned=held, n_matches=total, passes=passes, hits=hits)
+    if total < min_matches:
+        return out
+    sig2 = (SF * SF).astype(np.float32)
+    inv_sig2 = (np.float32(1.0) / sig2).astype(np.float32)
+    ef = [f for f in range(s["n"]) if held[f] >= 0]
+    kp = s["kps"]
+    ru = s["right_u"][ef]
+    meas = np.stack([kp["x"][ef].astype(np.float64), kp["y"][ef].astype(np.float64), np.where(ru < 0, -1.0, ru)], 1)
+    oc = kp["octave"][ef]
+    n_good, pose, inl = orc.pose_only_optimize(s["pos"][held[ef]].astype(np.float64), meas, inv_sig2[oc].astype(np.float64), sig2[oc], s["pose_se3"],
+                                               FX, FY, CX, CY, BF)
+    inlier = np.zeros(NF, np.uint8)
+    inlier[ef] = inl
+    out.update(n_edges=len(ef), n_good=n_good, pose=pose, inlier=inlier, edge_features=ef)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,mode", [(3, "same"), (8, "up"), (11, "down")])
+def test_track_motion_model_matches_the_composed_chain(orc, seed, mode):
+    from orb_slam2_ros2_amd._lib import Context
+    ctx = Context(W, H, n_features=NF, max_images=2)
+    s = _motion_scene(ctx, seed)
+    lo, hi = _windows(s["octave"], mode)
+    sig2 = (SF * SF).astype(np.float32)
+    inv_sig2 = (np.float32(1.0) / sig2).astype(np.float32)
+    args = (0, s["qxy"], lo, hi, s["q_desc"], s["pos"], (FX, FY, CX, CY, BF), (0.0, float(W), 0.0, float(H)), s["pose_se3"], sig2, inv_sig2)
+    g = ctx.track_motion_model(*args, right_u=s["right_u"])
+    r = _reference_motion_chain(orc, s, lo, hi)
+    assert g["passes"] == r["passes"] == 1 and g["n_matches"] == r["n_matches"] and r["n_matches"] > 400
+    assert np.array_equal(g["assigned"][:s["n"]], r["assigned"][:s["n"]])
+    assert g["n_edges"] == r["n_edges"] and np.array_equal(np.flatnonzero(g["edge_of"] >= 0), np.array(r["edge_features"]))
+    assert g["n_matches"] > g["n_edges"]                                   # some queries lost their feature to a later one: matches count queries
+    assert abs(g["n_good"] - r["n_good"]) <= 1 and (g["inlier"] != r["inlier"]).sum() <= 1
+    assert np.abs(g["pose"] - r["pose"]).max() < 1e-6 and np.abs(g["pose"] - s["pose_se3"]).max() > 1e-3
+    assert not g["excluded_hits"].any()                                    # a fresh frame holds nothing
+    # features that hold a map point already are no candidates; the queries that meet them are counted (addMatchInTrack, :322-331)
+    rng = np.random.default_rng(seed)
+    held = np.full(NF, -1, np.int32)
+    hf = rng.permutation(s["n"])[: s["n"] // 5]
+    held[hf] = rng.integers(0, len(s["qxy"]), len(hf))
+    g2 = ctx.track_motion_model(*args, held=held, right_u=s["right_u"])
+    r2 = _reference_motion_chain(orc, s, lo, hi, held=held)
+    assert np.array_equal(g2["assigned"][:s["n"]], r2["assigned"][:s["n"]]) and g2["n_matches"] == r2["n_matches"]
+    assert np.array_equal(g2["excluded_hits"][:s["n"]], r2["hits"][:s["n"]]) and g2["excluded_hits"].sum() > 100
+    assert np.array_equal(g2["assigned"][hf], held[hf])
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_track_motion_model_second_search_and_too_few_matches(orc):
+    from orb_slam2_ros2_amd._lib import Context
+    ctx = Context(W, H, n_features=NF, max_images=2)
+    s = _motion_scene(ctx, 5, frac=0.06, jitter=40.0, flip_bits=4)       # ~130 queries, many of them cells away from their feature
+    lo, hi = _windows(s["octave"], "same")
+    sig2 = (SF * SF).astype(np.float32)
+    inv_sig2 = (np.float32(1.0) / sig2).astype(np.float32)
+    args = (0, s["qxy"], lo, hi, s["q_desc"], s["pos"], (FX, FY, CX, CY, BF), (0.0, float(W), 0.0, float(H)), s["pose_se3"], sig2, inv_sig2)
+    m1 = _reference_motion_chain(orc, s, lo, hi, th_second=0.0, min_matches=10 ** 6)["n_matches"]     # what the first search finds
+    need = m1 + 1                                                                                     # ... is one short
+    kw = dict(right_u=s["right_u"], ratio=0.9, min_matches=need)
+    g = ctx.track_motion_model(*args, **kw)
+    r = _reference_motion_chain(orc, s, lo, hi, min_matches=need)
+    assert r["passes"] == 2 and g["passes"] == 2 and r["n_matches"] > m1 + 10 and m1 > 20, (m1, r["n_matches"])
+    assert g["n_matches"] == r["n_matches"] and np.array_equal(g["assigned"][:s["n"]], r["assigned"][:s["n"]])
+    assert np.array_equal(g["excluded_hits"][:s["n"]], r["hits"][:s["n"]])
+    assert g["n_edges"] == r["n_edges"] and abs(g["n_good"] - r["n_good"]) <= 1 and np.abs(g["pose"] - r["pose"]).max() < 1e-6
+    # still too few after both searches: no optimisation (Tracking.cc:392-395)
+    few = ctx.track_motion_model(*args, right_u=s["right_u"], min_matches=10 ** 6)
+    assert few["passes"] == 2 and few["n_edges"] == -1 and few["n_good"] == 0 and not few["inlier"].any() and np.array_equal(few["pose"], s["pose_se3"])
+    # no second search asked for
+    one = ctx.track_motion_model(*args, right_u=s["right_u"], min_matches=10 ** 6, th_second=0.0)
+    assert one["passes"] == 1 and one["n_edges"] == -1
+    # no queries
+    none = ctx.track_motion_model(0, np.zeros((0, 2)), np.zeros(0, np.int8), np.zeros(0, np.int8), np.zeros((0, 32), np.uint8), np.zeros((0, 3)),
+                                  (FX, FY, CX, CY, BF), (0.0, float(W), 0.0, float(H)), s["pose_se3"], sig2, inv_sig2)
+    assert none["n_matches"] == 0 and (none["assigned"] == -1).all()
+    ctx.close()
