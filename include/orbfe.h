@@ -448,7 +448,8 @@ orbfe_status orbfe_track_local_map(orbfe_ctx* ctx, int32_t slot, const orbfe_fra
                                    const orbfe_track_input* in, const orbfe_track_output* out);
 
 /* The middle of Tracking::trackMotionModel (src/Tracking.cc:382-396) as ONE call: ORBMatcher::searchByProjection(frame, lastFrame, matches, th)
- * -- in this reference a search around the LAST frame's feature positions within th pixels, octave window by the motion direction, among the
+ * -- in this reference a search around the LAST frame's feature positions within th * getScaledFactor2(octave) pixels (VirtualFrame::
+ * findFeaturesInArea, src/Frame.cc:286-311: by grid cell), octave window by the motion direction, among the
  * frame's features that hold no map point yet, accepted when ratio < mfRatio and distance < mnMinThreshold; every accepted query is a match
  * and setMapPoints assigns them in query order, so the last query that picked a feature keeps it (src/ORBMatcher.cc:265-347, :815-830) --
  * then, with fewer than min_matches matches, the same search with th_second among the features still free (Tracking.cc:388-391; the
@@ -456,10 +457,13 @@ orbfe_status orbfe_track_local_map(orbfe_ctx* ctx, int32_t slot, const orbfe_fra
  * Queries = the last frame's features that hold a good map point, in feature order (the caller's filter, :286-289).
  * Outputs as orbfe_track_local_map (assigned[f] = query index); n_matches = the accepted queries of all passes; excluded_hits[f]
  * (nullable) = how many queries met feature f among their candidates while it held a map point (the addMatchInTrack calls of :322-331);
- * passes (nullable) = 1 or 2.  The second search is decided on the host.  At most 2048 features per frame.                          */
+ * query_matches[i] (nullable, [n]) = in how many of the searches query i was accepted as a match (setMapPoints calls addMatchInTrack for
+ * every match, whether a later query takes the feature over or not); passes (nullable) = 1 or 2.  The second search is decided on the
+ * host.  At most 2048 features per frame.                                                                                            */
 typedef struct orbfe_motion_input {
   int32_t n;
   const float* qxy;              /* [n][2] the last frame's (undistorted) feature positions: the search centres            */
+  const int8_t* q_octave;        /* [n] their octaves: findFeaturesInArea searches within th * getScaledFactor2(octave)     */
   const int8_t* q_min_level;     /* [n] octave window (:300-315: [octave, 7] forward, [0, octave] backward, else +-1)       */
   const int8_t* q_max_level;     /* [n]                                                                                    */
   const uint8_t* desc;           /* [n][32] the last frame's descriptors                                                   */
@@ -475,7 +479,8 @@ typedef struct orbfe_motion_input {
   int32_t min_matches;           /* 20 (Tracking.cc:388, 392)                                                              */
 } orbfe_motion_input;
 orbfe_status orbfe_track_motion_model(orbfe_ctx* ctx, int32_t slot, const float* bounds4 /* mfMinU mfMaxU mfMinV mfMaxV */, const orbfe_camera* cam,
-                                      const orbfe_motion_input* in, const orbfe_track_output* out, int32_t* excluded_hits, int32_t* passes);
+                                      const orbfe_motion_input* in, const orbfe_track_output* out, int32_t* excluded_hits, int32_t* query_matches,
+                                      int32_t* passes);
 
 /* ---- map.pb: the reference's on-disk map, and a local bundle adjustment on it -------------------------------
  * `orbslam2.MapData` as Map::saveToProtobuf writes it (src/Map.cc:200-250; proto/Map.proto, Keyframe.proto,

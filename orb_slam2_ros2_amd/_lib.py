@@ -80,7 +80,7 @@ class TrackInput(C.Structure):
 
 
 class MotionInput(C.Structure):
-    _fields_ = [("n", C.c_int32), ("qxy", C.c_void_p), ("q_min_level", C.c_void_p), ("q_max_level", C.c_void_p), ("desc", C.c_void_p),
+    _fields_ = [("n", C.c_int32), ("qxy", C.c_void_p), ("q_octave", C.c_void_p), ("q_min_level", C.c_void_p), ("q_max_level", C.c_void_p), ("desc", C.c_void_p),
                 ("pos", C.c_void_p), ("held", C.c_void_p), ("right_u", C.c_void_p), ("level_sigma2", C.c_void_p), ("level_inv_sigma2", C.c_void_p),
                 ("pose_se3", C.c_void_p), ("th", C.c_float), ("th_second", C.c_float), ("ratio", C.c_float), ("min_threshold", C.c_int32),
                 ("min_matches", C.c_int32)]
@@ -161,7 +161,7 @@ def load() -> C.CDLL:
     L.orbfe_extract_slot.argtypes = [vp, i32, vp, C.c_size_t, vp, vp, vp]
     L.orbfe_extract_slots.argtypes = [vp, i32, i32, vp, C.c_size_t, vp, vp, vp]
     L.orbfe_frame_rgbd_image.argtypes = [vp, i32, vp, C.c_size_t, i32, vp, vp, i32, C.c_size_t, C.c_float, vp, vp, vp, vp, vp]
-    L.orbfe_track_motion_model.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+    L.orbfe_track_motion_model.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.orbfe_frame_stereo.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp]
     L.orbfe_frame_stereo_slots.argtypes = [vp, i32, vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp]
     L.orbfe_fetch_batch.argtypes = [vp, i32, i32, vp, vp, vp]
@@ -725,18 +725,20 @@ class Context:
         out.update(n_matches=nm.value, n_edges=ne.value, n_good=ng.value)
         return out
 
-    def track_motion_model(self, slot, qxy, q_min_level, q_max_level, desc, pos, cam, bounds, pose_se3, level_sigma2, level_inv_sigma2,
+    def track_motion_model(self, slot, qxy, q_octave, q_min_level, q_max_level, desc, pos, cam, bounds, pose_se3, level_sigma2, level_inv_sigma2,
                            held=None, right_u=None, th=15.0, th_second=30.0, ratio=0.9, min_threshold=50, min_matches=20):
         """The middle of Tracking::trackMotionModel as one call (orbfe_track_motion_model): searchByProjection(frame, lastFrame, th) around the
-        last frame's feature positions against the features of `slot` (+ the th_second search when fewer than min_matches matched), then
+        last frame's feature positions (radius th * sigma2(octave)) against the features of `slot` (+ the th_second search when fewer than
+        min_matches matched), then
         OptimizePoseOnly.  cam = (fx, fy, cx, cy, bf); bounds = (minU, maxU, minV, maxV)
-        -> dict(assigned, edge_of, inlier, excluded_hits, n_matches, n_edges, n_good, pose, passes)"""
+        -> dict(assigned, edge_of, inlier, excluded_hits, query_matches, n_matches, n_edges, n_good, pose, passes)"""
         f32 = lambda a: np.ascontiguousarray(a, np.float32)
         qxy, pos = f32(qxy).reshape(-1, 2), f32(pos).reshape(-1, 3)
         lo, hi = np.ascontiguousarray(q_min_level, np.int8), np.ascontiguousarray(q_max_level, np.int8)
+        octv = np.ascontiguousarray(q_octave, np.int8)
         desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
         n, NF = qxy.shape[0], self.n_features
-        if not (pos.shape[0] == n and lo.size == n and hi.size == n and desc.shape[0] == n):
+        if not (pos.shape[0] == n and lo.size == n and hi.size == n and octv.size == n and desc.shape[0] == n):
             raise ValueError("qxy / levels / desc / pos disagree in length")
         held = None if held is None else np.ascontiguousarray(held, np.int32)
         right_u = None if right_u is None else np.ascontiguousarray(right_u, np.float64)
@@ -746,14 +748,14 @@ class Context:
         b4 = f32(bounds)
         cm = Camera(*[float(np.float32(v)) for v in cam[:4]], 0, 0, 0, 0, 0, float(np.float32(cam[4])))
         out = dict(assigned=np.zeros(NF, np.int32), edge_of=np.zeros(NF, np.int32), inlier=np.zeros(NF, np.uint8), pose=np.zeros(7),
-                   excluded_hits=np.zeros(NF, np.int32))
+                   excluded_hits=np.zeros(NF, np.int32), query_matches=np.zeros(max(n, 1), np.int32))
         nm, ne, ng, np_ = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
-        mi = MotionInput(n, *[ptr(a) for a in (qxy, lo, hi, desc, pos, held, right_u, s2, is2, p0)], th, th_second, ratio, min_threshold, min_matches)
+        mi = MotionInput(n, *[ptr(a) for a in (qxy, octv, lo, hi, desc, pos, held, right_u, s2, is2, p0)], th, th_second, ratio, min_threshold, min_matches)
         to = TrackOutput(ptr(out["assigned"]), ptr(out["edge_of"]), ptr(out["inlier"]), C.cast(C.byref(nm), C.c_void_p),
                          C.cast(C.byref(ne), C.c_void_p), C.cast(C.byref(ng), C.c_void_p), ptr(out["pose"]))
         self._check(self.lib.orbfe_track_motion_model(self.h, slot, ptr(b4), C.byref(cm), C.byref(mi), C.byref(to), ptr(out["excluded_hits"]),
-                                                      C.byref(np_)))
-        out.update(n_matches=nm.value, n_edges=ne.value, n_good=ng.value, passes=np_.value)
+                                                      ptr(out["query_matches"]), C.byref(np_)))
+        out.update(n_matches=nm.value, n_edges=ne.value, n_good=ng.value, passes=np_.value, query_matches=out["query_matches"][:n])
         return out
 
     def map_local_ba(self, pb: bytes, kf_id: int, fx, fy, cx, cy, bf):

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void k_track_queries(int n, const uint8_t* __r
 __global__ __launch_bounds__(256) void k_track_claim(int n, const int32_t* __restrict__ n_cand, const int32_t* __restrict__ best_idx,
                                                      const int32_t* __restrict__ best_dist, const int32_t* __restrict__ second_dist,
                                                      int min_threshold, float ratio, int32_t* __restrict__ claim, int last_wins,
-                                                     int32_t* __restrict__ n_accept) {
+                                                     int32_t* __restrict__ n_accept, uint8_t* __restrict__ accepted) {
   // last_wins (the frame <- frame search, ORBMatcher.cc:265-347): every accepted query is a match and setMapPoints assigns them in query
   // order (:815-830) -- the LAST query that picked a feature keeps it (atomicMax over claims that start at -1), and the return value counts
   // the accepted queries (n_accept), not the features
@@ -321,6 +321,7 @@ __global__ __launch_bounds__(256) void k_track_claim(int n, const int32_t* __res
     if (last_wins) {
       atomicMax(&claim[best_idx[i]], i);
       atomicAdd(n_accept, 1);
+      if (accepted) accepted[i] = 1;  // (setMapPoints calls addMatchInTrack for every match, kept or overwritten: the caller needs them all)
     } else
       atomicMin(&claim[best_idx[i]], i);
   }
@@ -400,10 +401,10 @@ void launch_track_queries(hipStream_t s, int n, const uint8_t* d_flags, const ui
                      d_min_level, d_max_level);
 }
 void launch_track_claim(hipStream_t s, int n, const int32_t* d_n_cand, const int32_t* d_best_idx, const int32_t* d_best_dist, const int32_t* d_second,
-                        int min_threshold, float ratio, int32_t* d_claim, int last_wins, int32_t* d_n_accept) {
+                        int min_threshold, float ratio, int32_t* d_claim, int last_wins, int32_t* d_n_accept, uint8_t* d_accepted) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_track_claim, dim3((n + 255) / 256), dim3(256), 0, s, n, d_n_cand, d_best_idx, d_best_dist, d_second, min_threshold, ratio, d_claim,
-                     last_wins, d_n_accept);
+                     last_wins, d_n_accept, d_accepted);
 }
 void launch_track_edges(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, int n_features, const int32_t* d_held, const int32_t* d_claim,
                         const uint8_t* d_mp_flags, const float* d_mp_pos, const double* d_right_u, const float* d_sigma2, const float* d_inv_sigma2,

@@ -116,7 +116,7 @@ void launch_pose_only(hipStream_t s, int n, const double* Xw, const double* meas
 void launch_track_queries(hipStream_t s, int n, const uint8_t* d_flags, const uint8_t* d_visible, const float* d_cos, const int8_t* d_level, float th,
                           const float* d_sigma2, int n_levels, float* d_radius, int8_t* d_min_level, int8_t* d_max_level);
 void launch_track_claim(hipStream_t s, int n, const int32_t* d_n_cand, const int32_t* d_best_idx, const int32_t* d_best_dist, const int32_t* d_second,
-                        int min_threshold, float ratio, int32_t* d_claim, int last_wins = 0, int32_t* d_n_accept = nullptr);
+                        int min_threshold, float ratio, int32_t* d_claim, int last_wins = 0, int32_t* d_n_accept = nullptr, uint8_t* d_accepted = nullptr);
 void launch_track_edges(hipStream_t s, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, int n_features, const int32_t* d_held, const int32_t* d_claim,
                         const uint8_t* d_mp_flags, const float* d_mp_pos, const double* d_right_u, const float* d_sigma2, const float* d_inv_sigma2,
                         int min_matches, int32_t* d_assigned, int32_t* d_edge_of, double* d_Xw, double* d_meas, double* d_info, float* d_sig,
@@ -3172,14 +3172,16 @@ orbfe_status orbfe_track_local_map(orbfe_ctx* c, int32_t slot, const orbfe_frame
 // min_matches matches, the same search again with th_second among the features still free, then Optimizer::OptimizePoseOnly(frame).  The
 // second search is decided on the host (one more synchronisation in the rare frame that needs it).
 orbfe_status orbfe_track_motion_model(orbfe_ctx* c, int32_t slot, const float* bounds4, const orbfe_camera* cam, const orbfe_motion_input* in,
-                                      const orbfe_track_output* out, int32_t* excluded_hits, int32_t* passes) {
+                                      const orbfe_track_output* out, int32_t* excluded_hits, int32_t* query_matches, int32_t* passes) {
   ApiLock api_lk(c);
   if (!c || !bounds4 || !cam || !in || !out || slot < 0 || slot >= c->cfg.max_images) return fail(c, ORBFE_EBADARG, "track_motion_model: NULL argument / bad slot");
   const int n = in->n, nl = c->cfg.n_levels;
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
   if (n < 0 || !in->pose_se3 || !in->level_sigma2 || !in->level_inv_sigma2 || !out->assigned || !out->n_matches || !out->n_edges || !out->n_good ||
-      !out->pose_out || !out->inlier || (n && (!in->qxy || !in->q_min_level || !in->q_max_level || !in->desc || !in->pos)))
+      !out->pose_out || !out->inlier || (n && (!in->qxy || !in->q_octave || !in->q_min_level || !in->q_max_level || !in->desc || !in->pos)))
     return fail(c, ORBFE_EBADARG, "track_motion_model: NULL array");
+  for (int i = 0; i < n; ++i)
+    if (in->q_octave[i] < 0 || in->q_octave[i] >= nl) return fail(c, ORBFE_EBADARG, "track_motion_model: q_octave[%d] = %d", i, (int)in->q_octave[i]);
   if (NF > 2048) return fail(c, ORBFE_EBADSIZE, "track_motion_model: %zu features per frame (the fused pose kernel keeps up to 2048 edges in registers)", NF);
   if (in->held)
     for (size_t f = 0; f < NF; ++f)
@@ -3201,10 +3203,10 @@ orbfe_status orbfe_track_motion_model(orbfe_ctx* c, int32_t slot, const float* b
   const size_t o_qxy = take(N * 8), o_lo = take(N), o_hi = take(N), o_desc = take(N * 32), o_pos = take(N * 12), o_fl = take(N), o_ru = take(NF * 8),
                o_s2 = take((size_t)nl * 4), o_is2 = take((size_t)nl * 4), o_p0 = take(56), o_up1_end = take(8), o_rad = take(N * 4), o_held = take(NF * 4),
                o_ex = take(NF), o_up2_end = take(8), o_claim = take(NF * 4), o_claim_end = take(8), o_eh = take(NF * 4), o_acc = take(16),
-               o_zero_end = take(8), o_co = take((ncells + 1) * 4), o_cf = take(NF * 4), o_bi = take(N * 4), o_bd = take(N * 4), o_sd = take(N * 4),
+               o_qa = take(N), o_zero_end = take(8), o_co = take((ncells + 1) * 4), o_cf = take(NF * 4), o_bi = take(N * 4), o_bd = take(N * 4), o_sd = take(N * 4),
                o_nc = take(N * 4), o_xw = take(NF * 24), o_ms = take(NF * 24), o_info = take(NF * 8), o_sig = take(NF * 4), o_err = take(NF * 24),
                o_l = take(NF), o_r = take(NF), o_cnt = take(16), o_ng = take(8), o_po = take(56), o_asg = take(NF * 4), o_eo = take(NF * 4), o_in = take(NF),
-               o_ehd = take(NF * 4), o_dn_end = take(8);
+               o_ehd = take(NF * 4), o_qad = take(N), o_dn_end = take(8);
   TRY(ensure_tmp(c, off));
   TRY(ensure_stage(c, std::max(o_up2_end, o_dn_end - o_cnt)));
   uint8_t* b = (uint8_t*)c->d_tmp;
@@ -3225,7 +3227,7 @@ orbfe_status orbfe_track_motion_model(orbfe_ctx* c, int32_t slot, const float* b
   std::memcpy(hs + o_p0, in->pose_se3, 56);
   std::vector<int32_t> held(NF, -1);
   if (in->held) std::memcpy(held.data(), in->held, NF * 4);
-  std::vector<int32_t> hits_total(excluded_hits ? NF : 0, 0);
+  std::vector<int32_t> hits_total(excluded_hits ? NF : 0, 0), qm_total(query_matches ? N : 0, 0);
   hipStream_t st = c->stream;
   const BaParamsDev prm = {(double)cam->fx, (double)cam->fy, (double)cam->cx, (double)cam->cy, (double)cam->bf};
   int base_matches = 0, n_pass = 0;
@@ -3234,7 +3236,7 @@ orbfe_status orbfe_track_motion_model(orbfe_ctx* c, int32_t slot, const float* b
     const float th = pass == 0 ? in->th : in->th_second;
     if (pass == 1 && !(th > 0)) break;
     // the per-pass upload: radius, what the features hold, and the candidates that are excluded (a feature that holds a map point: :322-331)
-    for (int i = 0; i < n; ++i) ((float*)(hs + o_rad))[i] = th;
+    for (int i = 0; i < n; ++i) ((float*)(hs + o_rad))[i] = th * in->level_sigma2[in->q_octave[i]];  // findFeaturesInArea: radius * getScaledFactor2(octave)
     std::memcpy(hs + o_held, held.data(), NF * 4);
     for (size_t f = 0; f < NF; ++f) hs[o_ex + f] = held[f] >= 0 ? 1 : 0;
     if (pass == 0)
@@ -3252,7 +3254,7 @@ orbfe_status orbfe_track_motion_model(orbfe_ctx* c, int32_t slot, const float* b
                          (const int8_t*)(b + o_lo), (const int8_t*)(b + o_hi), b + o_desc, b + o_ex, (int32_t*)(b + o_bi), (int32_t*)(b + o_bd),
                          (int32_t*)(b + o_sd), (int32_t*)(b + o_nc), (int32_t*)(b + o_eh));
       launch_track_claim(st, n, (const int32_t*)(b + o_nc), (const int32_t*)(b + o_bi), (const int32_t*)(b + o_bd), (const int32_t*)(b + o_sd),
-                         in->min_threshold, in->ratio, (int32_t*)(b + o_claim), 1, (int32_t*)(b + o_acc));
+                         in->min_threshold, in->ratio, (int32_t*)(b + o_claim), 1, (int32_t*)(b + o_acc), b + o_qa);
       launch_track_edges(st, c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, (int)NF, (const int32_t*)(b + o_held), (const int32_t*)(b + o_claim),
                          b + o_fl, (const float*)(b + o_pos), (const double*)(b + o_ru), (const float*)(b + o_s2), (const float*)(b + o_is2),
                          in->min_matches, (int32_t*)(b + o_asg), (int32_t*)(b + o_eo), (double*)(b + o_xw), (double*)(b + o_ms),
@@ -3266,6 +3268,7 @@ orbfe_status orbfe_track_motion_model(orbfe_ctx* c, int32_t slot, const float* b
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(b + o_ehd, b + o_eh, NF * 4, hipMemcpyDeviceToDevice, st));  // (the hits sit in front of the downloaded block)
+    HIP_TRY(c, hipMemcpyAsync(b + o_qad, b + o_qa, N, hipMemcpyDeviceToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(hs, b + o_cnt, o_dn_end - o_cnt, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     ++n_pass;
@@ -3273,6 +3276,8 @@ orbfe_status orbfe_track_motion_model(orbfe_ctx* c, int32_t slot, const float* b
       const int32_t* eh = (const int32_t*)(hs + (o_ehd - o_cnt));
       for (size_t f = 0; f < NF; ++f) hits_total[f] += eh[f];
     }
+    if (query_matches)
+      for (int i = 0; i < n; ++i) qm_total[(size_t)i] += hs[(o_qad - o_cnt) + (size_t)i];
     if (cnt[1] >= 0 || pass == 1 || !(in->th_second > 0)) break;
     // fewer than min_matches: the matches of this pass stay (setMapPoints, :344-345) and are excluded from the next one
     base_matches = cnt[0];
@@ -3290,6 +3295,7 @@ orbfe_status orbfe_track_motion_model(orbfe_ctx* c, int32_t slot, const float* b
   for (size_t f = 0; f < NF; ++f) out->inlier[f] = (optimised && eo[f] >= 0) ? ein[eo[f]] : 0;
   if (out->edge_of) std::memcpy(out->edge_of, eo, NF * 4);
   if (excluded_hits) std::memcpy(excluded_hits, hits_total.data(), NF * 4);
+  if (query_matches && n) std::memcpy(query_matches, qm_total.data(), (size_t)n * 4);
   if (passes) *passes = n_pass;
   return ORBFE_OK;
 }

@@ -18,6 +18,8 @@
 //   orbfe::dropin::frameRGBD              the tail of `Frame::Frame` for RGB-D input (src/Frame.cc:130-131, :139-157)
 //   orbfe::dropin::createRGBD             extract() AND that tail as ONE device call (ORBExtractor::extractRGBD -> orbfe_frame_rgbd_image)
 //   orbfe::dropin::searchBySim3 x2, searchForTriangulation, fuse x2   the back-end matchers (ORBMatcher.h:55-67, src/ORBMatcher.cc:424-559, 691-787)
+//   orbfe::dropin::trackMotionModel       the middle of `Tracking::trackMotionModel` (src/Tracking.cc:385-396): searchByProjection(frame, last frame,
+//                                         15) [+ 30] + OptimizePoseOnly(frame) as ONE device call
 //   orbfe::dropin::trackLocalMap          the middle of `Tracking::trackLocalMap` (src/Tracking.cc:650-658): searchByProjection(frame, local map
 //                                         points, th) + OptimizePoseOnly(frame) as ONE device call
 //
@@ -508,11 +510,9 @@ static void OptimizeLocalMap(KeyFramePtr pkframe, bool& isStop) {
     return m;
   }
 
-  // int ORBMatcher::searchByProjection(VirtualFrame::SharedPtr pFrame1, VirtualFrame::SharedPtr pFrame2, std::vector<cv::DMatch>& matches,
-  //                                    float th, bool bFuse)   (ORBMatcher.h:49, src/ORBMatcher.cc:265-347)
+  // forward / backward motion between two frames (src/ORBMatcher.cc:270-283)
   template <class CameraT, class FramePtr1, class FramePtr2>
-  static int searchByProjection(FramePtr1 pFrame1, FramePtr2 pFrame2, std::vector<cv::DMatch>& matches, float th, bool bFuse, float mfRatio) {
-    matches.clear();
+  static void motionDirection(FramePtr1 pFrame1, FramePtr2 pFrame2, bool& up, bool& down) {
     cv::Mat Rcw1, tcw1, Rcw2, tcw2;
     pFrame1->getPose(Rcw1, tcw1);
     pFrame2->getPose(Rcw2, tcw2);
@@ -528,8 +528,17 @@ static void OptimizeLocalMap(KeyFramePtr pkframe, bool& isStop) {
       z = (float)((double)sm + (double)tcw2.template at<float>(2, 0));
     }
     const float zabs = std::abs(z);
-    bool up = false, down = false;
+    up = down = false;
     if (zabs > CameraT::mfBl) z > 0 ? up = true : down = true;
+  }
+
+  // int ORBMatcher::searchByProjection(VirtualFrame::SharedPtr pFrame1, VirtualFrame::SharedPtr pFrame2, std::vector<cv::DMatch>& matches,
+  //                                    float th, bool bFuse)   (ORBMatcher.h:49, src/ORBMatcher.cc:265-347)
+  template <class CameraT, class FramePtr1, class FramePtr2>
+  static int searchByProjection(FramePtr1 pFrame1, FramePtr2 pFrame2, std::vector<cv::DMatch>& matches, float th, bool bFuse, float mfRatio) {
+    matches.clear();
+    bool up = false, down = false;
+    motionDirection<CameraT>(pFrame1, pFrame2, up, down);
     auto mps1 = pFrame1->getMapPoints();
     auto mps2 = pFrame2->getMapPoints();
     Queries q;
@@ -974,6 +983,130 @@ static void OptimizeLocalMap(KeyFramePtr pkframe, bool& isStop) {
     return nMatches;
   }
 
+  // The middle of Tracking::trackMotionModel (src/Tracking.cc:385-396) as ONE device call (orbfe_track_motion_model):
+  //     nMatches = matcher.searchByProjection(mpCurrFrame, mpLastFrame, matches, 15);
+  //     if (nMatches < 20) nMatches += matcher.searchByProjection(mpCurrFrame, mpLastFrame, matches, 30);
+  //     if (nMatches < 20) return false;   Optimizer::OptimizePoseOnly(mpCurrFrame);
+  // with the side effects of the bodies above: the matches' map points set in the frame (setMapPoints, in query order: the last one
+  // stays) with addMatchInTrack for every match and for every query that met a feature which already held a good point; then
+  // OptimizePoseOnly's tail (the projection post-check, addInlierInTrack, setPose).  Returns nMatches; nGood = -1 when they were too few.
+  // The current frame's features are the device-resident results of its extractor's slot; falls back to the two bodies when they are not.
+  template <class CameraT, class FramePtr1, class FramePtr2>
+  static int trackMotionModel(FramePtr1 pCurr, FramePtr2 pLast, float mfRatio, int& nGood, float th = 15.f, float thSecond = 30.f, int minMatches = 20) {
+    const auto& ext = pCurr->mpExtractorLeft->device();
+    const size_t N = pCurr->mvFeatsLeft.size();
+    if (!ext.resident() || (size_t)orbfe_get_capacity(ext.context()) > 2048) {
+      std::vector<cv::DMatch> matches;
+      int nMatches = searchByProjection<CameraT>(pCurr, pLast, matches, th, false, mfRatio);
+      if (nMatches < minMatches) nMatches += searchByProjection<CameraT>(pCurr, pLast, matches, thSecond, false, mfRatio);
+      nGood = nMatches < minMatches ? -1 : OptimizePoseOnly<CameraT>(pCurr);
+      return nMatches;
+    }
+    orbfe_ctx* ctx = ext.context();
+    const size_t NF = (size_t)orbfe_get_capacity(ctx);
+    bool up = false, down = false;
+    motionDirection<CameraT>(pCurr, pLast, up, down);
+    auto mps1 = pCurr->getMapPoints();
+    auto mps2 = pLast->getMapPoints();
+    std::vector<float> qxy, pos;
+    std::vector<int8_t> qOct, qLo, qHi;
+    std::vector<uint8_t> desc;
+    std::vector<int> who;  // query -> index in the last frame
+    for (std::size_t idx = 0; idx < mps2.size(); ++idx) {
+      auto pMp2 = mps2[idx];
+      if (!pMp2 || pMp2->isBad()) continue;
+      const auto& feature = pLast->mvFeatsLeft[idx];
+      int lo, hi;
+      if (up)
+        lo = feature.octave, hi = 7;
+      else if (down)
+        lo = 0, hi = feature.octave;
+      else
+        lo = std::max(0, feature.octave - 1), hi = std::min(feature.octave + 1, 7);
+      qxy.push_back(feature.pt.x), qxy.push_back(feature.pt.y);
+      qOct.push_back((int8_t)feature.octave), qLo.push_back((int8_t)lo), qHi.push_back((int8_t)hi);
+      const size_t o = desc.size();
+      desc.resize(o + 32);
+      std::memcpy(desc.data() + o, pLast->mvLeftDescriptor[idx].data, 32);
+      const cv::Mat p = pMp2->getPos();
+      for (int a = 0; a < 3; ++a) pos.push_back(p.template at<float>(a));
+      who.push_back((int)idx);
+    }
+    // what the current frame's features hold on entry: a good point makes the feature no candidate; it is an edge of the optimisation either
+    // way, so such points go in as extra "queries" that search nothing (an empty octave window)
+    std::vector<int32_t> held(NF, -1);
+    using BasePtr = typename std::decay<decltype(pCurr->getMapPoint(0))>::type;
+    std::vector<BasePtr> extra;
+    for (size_t f = 0; f < N && f < NF && f < mps1.size(); ++f) {
+      if (!mps1[f] || mps1[f]->isBad()) continue;
+      held[f] = (int32_t)who.size();
+      qxy.push_back(0.f), qxy.push_back(0.f), qOct.push_back(0), qLo.push_back(1), qHi.push_back(0);
+      desc.resize(desc.size() + 32, 0);
+      const cv::Mat p = mps1[f]->getPos();
+      for (int a = 0; a < 3; ++a) pos.push_back(p.template at<float>(a));
+      who.push_back(-1);
+      extra.push_back(mps1[f]);
+    }
+    const int nLevels = 8;
+    std::vector<float> sig2((size_t)nLevels), invSig2((size_t)nLevels);
+    for (int l = 0; l < nLevels; ++l) sig2[(size_t)l] = pCurr->getScaledFactor2(l), invSig2[(size_t)l] = pCurr->getScaledFactorInv2(l);
+    std::vector<double> rightU(NF, -1.0);
+    for (size_t f = 0; f < N && f < NF; ++f) rightU[f] = pCurr->getRightU(f);
+    const float bounds[4] = {pCurr->mfMinU, pCurr->mfMaxU, pCurr->mfMinV, pCurr->mfMaxV};
+    orbfe_camera cam{};
+    cam.fx = CameraT::mfFx, cam.fy = CameraT::mfFy, cam.cx = CameraT::mfCx, cam.cy = CameraT::mfCy, cam.bf = CameraT::mfBf;
+    double pose0[7], poseOut[7];
+    matToPose(pCurr->mRcw, pCurr->mtcw, pose0);
+    orbfe_motion_input in{};
+    in.n = (int32_t)who.size();
+    in.qxy = qxy.data(), in.q_octave = qOct.data(), in.q_min_level = qLo.data(), in.q_max_level = qHi.data(), in.desc = desc.data(), in.pos = pos.data();
+    in.held = held.data(), in.right_u = rightU.data(), in.level_sigma2 = sig2.data(), in.level_inv_sigma2 = invSig2.data(), in.pose_se3 = pose0;
+    in.th = th, in.th_second = thSecond, in.ratio = mfRatio, in.min_threshold = orbfe::ORBMatcher::mnMinThreshold, in.min_matches = minMatches;
+    std::vector<int32_t> assigned(NF, -1), hits(NF, 0), qMatches(std::max<size_t>(who.size(), 1), 0);
+    std::vector<uint8_t> inl(NF, 0);
+    int32_t nMatches = 0, nEdges = 0, good = 0, passes = 0;
+    orbfe_track_output out{};
+    out.assigned = assigned.data(), out.inlier = inl.data(), out.n_matches = &nMatches, out.n_edges = &nEdges, out.n_good = &good, out.pose_out = poseOut;
+    check(ctx, orbfe_track_motion_model(ctx, ext.slot(), bounds, &cam, &in, &out, hits.data(), qMatches.data(), &passes));
+    // the side effects of the searches (:322-331, :815-830)
+    // (a feature that held a good point on entry is met in both searches; one that the FIRST search assigned is met in the second -- it
+    //  keeps that point, no later query can take it -- so its visits belong to the point it ends up with)
+    for (size_t f = 0; f < N && f < NF && f < mps1.size(); ++f)
+      for (int32_t k = 0; k < hits[f]; ++k) {
+        if (held[f] >= 0)
+          mps1[f]->addMatchInTrack();
+        else if (assigned[f] >= 0)
+          mps2[(size_t)who[(size_t)assigned[f]]]->addMatchInTrack();
+      }
+    for (size_t k = 0; k < who.size(); ++k)
+      for (int32_t r = 0; who[k] >= 0 && r < qMatches[k]; ++r) mps2[(size_t)who[k]]->addMatchInTrack();
+    for (size_t f = 0; f < N && f < NF; ++f)
+      if (assigned[f] >= 0 && assigned[f] != held[f]) pCurr->mvpMapPoints[f] = mps2[(size_t)who[(size_t)assigned[f]]];
+    if (nEdges < 0) {
+      nGood = -1;
+      return nMatches;
+    }
+    // OptimizePoseOnly's tail (src/Optimizer.cc:180-203), as in trackLocalMap above
+    int nBad = nEdges - good;
+    for (size_t f = 0; f < N && f < NF; ++f) {
+      auto cur = pCurr->getMapPoint(f);
+      if (!cur || cur->isBad()) continue;
+      bool keep = inl[f] != 0;
+      if (keep) {
+        bool isPositive = false;
+        auto uv = pCurr->project2UV(cur->getPos(), isPositive);
+        if (!isPositive || uv.x > pCurr->mfMaxU || uv.x < 0 || uv.y > pCurr->mfMaxV || uv.y < 0) keep = false, ++nBad;
+      }
+      if (!keep)
+        pCurr->mvpMapPoints[f] = nullptr;
+      else
+        pCurr->mvpMapPoints[f]->addInlierInTrack();
+    }
+    pCurr->setPose(poseToMat(poseOut));
+    nGood = nEdges - nBad;
+    return nMatches;
+  }
+
   // The tail of Frame::Frame (RGB-D) after extract() (src/Frame.cc:130-131, :139-157): depthImg.convertTo(CV_32F) / dScale, the copy of the
   // distorted keypoints, Camera::undistortPoints(mvFeatsLeft), the depth / rightU lookup -- as one call on the extractor's slot.  depthImg
   // as read from the file: CV_16U (TUM) or CV_32F.  initGrid() stays with the caller (the grid is rebuilt on the device per search).
@@ -1026,6 +1159,10 @@ int searchByStereo(FramePtr pFrame) {
 template <class CameraT, class FrameT>
 int createStereo(FrameT* self) {
   return Bodies::template createStereo<CameraT>(self);
+}
+template <class CameraT, class FramePtr1, class FramePtr2>
+int trackMotionModel(FramePtr1 pCurr, FramePtr2 pLast, float mfRatio, int& nGood) {
+  return Bodies::template trackMotionModel<CameraT>(pCurr, pLast, mfRatio, nGood);
 }
 template <class CameraT, class FrameT>
 void createRGBD(FrameT* self, const cv::Mat& depthImg, float dScale) {

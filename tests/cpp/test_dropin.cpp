@@ -940,6 +940,134 @@ static int mode_trackchain(int argc, char** argv) {
   return (fails == 0 && nA > 800 && goodA > 300) ? 0 : 1;
 }
 
+// ---- Tracking::trackMotionModel's middle: the two bodies (searchByProjection(frame, lastFrame, 15 [, 30]) + OptimizePoseOnly) on frame A
+// against orbfe::dropin::trackMotionModel (one device call) on its twin B.  The last frame is the same stereo pair a frame earlier: its
+// keypoints a few pixels off, its descriptors a few bits off, map points where the current frame's stereo depth puts them.
+static int mode_motionchain(int argc, char** argv) {
+  if (argc < 6) return 2;
+  const int w = atoi(argv[4]), h = atoi(argv[5]);
+  std::vector<uint8_t> L, R;
+  if (!read_file(argv[2], L) || !read_file(argv[3], R) || L.size() != (size_t)w * h || R.size() != L.size()) return 2;
+  cv::Mat ml(h, w, CV_8UC1, L.data()), mr(h, w, CV_8UC1, R.data());
+  ref::MapPoint::Cmp cmp = [](std::weak_ptr<ref::KeyFrame>, std::weak_ptr<ref::KeyFrame>) { return false; };
+  auto identity = [](float tx, float ty, float tz) {
+    cv::Mat T(4, 4, CV_32F);
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) T.at<float>(r, c) = r == c ? 1.f : 0.f;
+    T.at<float>(0, 3) = tx, T.at<float>(1, 3) = ty, T.at<float>(2, 3) = tz;
+    return T;
+  };
+  int fails = 0;
+  auto expect = [&](bool ok, const char* what) {
+    if (!ok) fprintf(stderr, "motionchain: %s\n", what), ++fails;
+  };
+  int nA_first = 0, passes_seen = 0;
+  for (int scenario = 0; scenario < 2; ++scenario) {  // 0: plenty of matches at 15 | 1: the last frame far off -- the second search is needed
+    // (the stereo match right behind each construction: the extractors rotate over four slots; B's frame comes last and stays resident)
+    auto make = [&]() {
+      auto f = std::make_shared<ref::Frame>(ml, mr, true);
+      orbfe::dropin::searchByStereo<ref::Camera>(f);
+      f->mfMinU = 0, f->mfMinV = 0, f->mfMaxU = (float)w, f->mfMaxV = (float)h;
+      return f;
+    };
+    auto LA = make(), LB = make();  // the last frame, twice
+    ref::VirtualFrame::mvfScaledFactors = ORB_SLAM2_ROS2::ORBExtractor::getScaledFactors();  // (set by the first extractor's constructor)
+    auto FA = make(), FB = make();  // the current frame, twice
+    const size_t n = FA->mvFeatsLeft.size();
+    if (FB->mvFeatsLeft.size() != n || LA->mvFeatsLeft.size() != n) return 1;
+    LA->setPose(identity(0.f, 0.f, 0.f)), LB->setPose(identity(0.f, 0.f, 0.f));
+    FA->setPose(identity(0.04f, -0.02f, 0.05f)), FB->setPose(identity(0.04f, -0.02f, 0.05f));  // the predicted pose: a few centimetres off
+    uint64_t sd = 4242 + scenario;
+    auto rnd = [&]() {
+      sd = sd * 6364136223846793005ull + 1442695040888963407ull;
+      return (double)(sd >> 11) / 9007199254740992.0;
+    };
+    const double off = scenario == 0 ? 5.0 : 40.0;
+    for (size_t i = 0; i < n; ++i) {
+      const auto kp = LA->mvFeatsLeft[i];
+      if ((scenario == 0 && i % 5 != 4) || (scenario == 1 && i % 130 == 0)) {  // the feature holds a map point: true geometry of the current frame
+        const double d = LA->mvDepths[i] > 0 ? LA->mvDepths[i] : 6.0 + 20.0 * rnd();
+        for (auto& lf : {LA, LB}) {
+          auto p = std::make_shared<ref::MapPoint>(cmp);
+          p->mId = i;
+          p->mPos = cv::Mat(3, 1, CV_32F);
+          p->mPos.at<float>(0) = (float)((kp.pt.x - ref::Camera::mfCx) / ref::Camera::mfFx * d);
+          p->mPos.at<float>(1) = (float)((kp.pt.y - ref::Camera::mfCy) / ref::Camera::mfFy * d);
+          p->mPos.at<float>(2) = (float)d;
+          p->mbBad = i % 61 == 7;
+          lf->mvpMapPoints[i] = p;
+        }
+      }
+      // ... as it looked a frame ago
+      const float dx = (float)((rnd() - 0.5) * 2 * off), dy = (float)((rnd() - 0.5) * 2 * (scenario == 0 ? 5.0 : 30.0));
+      int bits[6];
+      for (int& b : bits) b = (int)(rnd() * 256) % 256;
+      for (auto& lf : {LA, LB}) {
+        lf->mvFeatsLeft[i].pt.x = std::min(std::max(kp.pt.x + dx, 0.f), (float)w - 1.f), lf->mvFeatsLeft[i].pt.y = std::min(std::max(kp.pt.y + dy, 0.f), (float)h - 1.f);
+        lf->mvLeftDescriptor[i] = lf->mvLeftDescriptor[i].clone();
+        for (int b : bits) lf->mvLeftDescriptor[i].data[b / 8] ^= (uint8_t)(1u << (b % 8));
+      }
+    }
+    if (scenario == 0)  // a few features of the current frame hold a point already: no candidates, their queries' visits are counted, edges of the optimisation
+      for (size_t i = 3; i < n; i += 23)
+        for (auto& f : {FA, FB}) {
+          auto p = std::make_shared<ref::MapPoint>(cmp);
+          p->mPos = cv::Mat(3, 1, CV_32F);
+          const auto& kp = f->mvFeatsLeft[i];
+          const double d = f->mvDepths[i] > 0 ? f->mvDepths[i] : 12.0;
+          p->mPos.at<float>(0) = (float)((kp.pt.x - ref::Camera::mfCx) / ref::Camera::mfFx * d), p->mPos.at<float>(1) = (float)((kp.pt.y - ref::Camera::mfCy) / ref::Camera::mfFy * d);
+          p->mPos.at<float>(2) = (float)d;
+          f->mvpMapPoints[i] = p;
+        }
+    // A: the bodies, as Tracking::trackMotionModel strings them together
+    std::vector<cv::DMatch> matches;
+    int nA = orbfe::dropin::searchByProjection<ref::Camera>(FA, LA, matches, 15.f, false, 0.9f);
+    const int first = nA;
+    if (nA < 20) nA += orbfe::dropin::searchByProjection<ref::Camera>(FA, LA, matches, 30.f, false, 0.9f);
+    const int goodA = nA < 20 ? -1 : orbfe::dropin::OptimizePoseOnly<ref::Camera>(FA);
+    // B: one call
+    int goodB = -2;
+    const int nB = orbfe::dropin::trackMotionModel<ref::Camera>(FB, LB, 0.9f, goodB);
+    expect(nA == nB, "the match counts differ");
+    expect(std::abs(goodA - goodB) <= 1, "OptimizePoseOnly's return value differs");
+    if (scenario == 0) nA_first = nA, expect(first >= 20 && nA > 600, "scenario 0 should match at the first radius");
+    else passes_seen = first < 20 ? 2 : 1, expect(first < 20 && nA >= first, "scenario 1 should need the second search");
+    int assign_diff = 0;
+    for (size_t i = 0; i < n; ++i) {
+      auto a = FA->mvpMapPoints[i], b = FB->mvpMapPoints[i];
+      if ((a == nullptr) != (b == nullptr)) {
+        ++assign_diff;
+        continue;
+      }
+      if (!a) continue;
+      const auto ia = std::find(LA->mvpMapPoints.begin(), LA->mvpMapPoints.end(), a), ib = std::find(LB->mvpMapPoints.begin(), LB->mvpMapPoints.end(), b);
+      if ((ia == LA->mvpMapPoints.end()) != (ib == LB->mvpMapPoints.end()) ||
+          (ia != LA->mvpMapPoints.end() && ia - LA->mvpMapPoints.begin() != ib - LB->mvpMapPoints.begin()))
+        ++assign_diff;
+    }
+    expect(assign_diff <= 1, "the frames' map points differ");
+    double pose_diff = 0;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) pose_diff = std::max(pose_diff, (double)std::fabs(FA->mRcw.at<float>(r, c) - FB->mRcw.at<float>(r, c)));
+      pose_diff = std::max(pose_diff, (double)std::fabs(FA->mtcw.at<float>(r, 0) - FB->mtcw.at<float>(r, 0)));
+    }
+    expect(pose_diff < 1e-5, "the optimised poses differ");
+    int cnt_diff = 0;
+    for (size_t i = 0; i < n; ++i) {
+      if (LA->mvpMapPoints[i])
+        cnt_diff += LA->mvpMapPoints[i]->nMatchInTrack != LB->mvpMapPoints[i]->nMatchInTrack ||
+                    std::abs(LA->mvpMapPoints[i]->nInlier - LB->mvpMapPoints[i]->nInlier) > (assign_diff ? 1 : 0);
+    }
+    expect(cnt_diff <= 2 * assign_diff, "addMatchInTrack / addInlierInTrack counts differ");
+    if (scenario == 0) {
+      const double err = std::fabs(FB->mtcw.at<float>(0, 0)) + std::fabs(FB->mtcw.at<float>(1, 0)) + std::fabs(FB->mtcw.at<float>(2, 0));
+      expect(err < 0.02 && goodA > 300, "the pose did not converge to the truth");
+    }
+  }
+  printf("MOTIONCHAIN_%s %d %d\n", fails == 0 ? "OK" : "FAIL", nA_first, passes_seen);
+  return fails == 0 ? 0 : 1;
+}
+
 // The back-end matchers with the reference's signatures (ORBMatcher.h:55-67) over stand-in KeyFrames whose features are a real stereo pair's:
 // K1 = the left image at the identity pose, K2 = the right image one baseline to the right, map points = K1's keypoints back-projected
 // at their stereo depth, so that every adapter has true correspondences to find.
@@ -1167,6 +1295,7 @@ int main(int argc, char** argv) {
     if (mode == "matchers") return mode_matchers(argc, argv);
     if (mode == "rgbd") return mode_rgbd(argc, argv);
     if (mode == "trackchain") return mode_trackchain(argc, argv);
+    if (mode == "motionchain") return mode_motionchain(argc, argv);
     if (mode == "backend") return mode_backend(argc, argv);
     if (mode == "access") return mode_access();
     if (mode == "localba") return mode_localba(argc, argv);

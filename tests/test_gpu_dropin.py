@@ -105,6 +105,19 @@ def test_fused_tracking_chain_adapter_equals_the_two_bodies(exe, tmp_path):
     assert f[0] == "TRACKCHAIN_OK" and int(f[2]) > 800 and abs(int(f[3]) - int(f[4])) <= 1 and float(f[7]) < 1e-5
 
 
+def test_fused_motion_model_chain_adapter_equals_the_two_bodies(exe, tmp_path):
+    """orbfe::dropin::trackMotionModel (one device call) against searchByProjection(frame, lastFrame, 15 [, 30]) + OptimizePoseOnly on a twin
+    frame: match counts, the map points the frame holds, the optimised pose and the map points' counters; a second scenario needs the search at 30"""
+    L, R = synth.stereo_pair(3)
+    L.tofile(tmp_path / "L.raw")
+    R.tofile(tmp_path / "R.raw")
+    out = subprocess.run([exe, "motionchain", str(tmp_path / "L.raw"), str(tmp_path / "R.raw"), "1241", "376"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    tag, n_first, passes = out.stdout.split()
+    assert tag == "MOTIONCHAIN_OK" and int(n_first) > 600 and int(passes) == 2
+
+
 def test_back_end_matcher_adapters_with_the_reference_signatures(exe, tmp_path):
     """searchBySim3 x2, searchForTriangulation, fuse x2 (include/ORB_SLAM2/ORBMatcher.h:55-67) over stand-in KeyFrame / MapPoint / Sim3Ret /
     Map classes on a geometrically consistent pair of keyframes (a real stereo pair: the left image at the identity, the right one a

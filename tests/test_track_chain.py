@@ -184,21 +184,23 @@ def _reference_motion_chain(orc, s, lo, hi, th=15.0, th_second=30.0, ratio=0.9, 
     nq = len(s["qxy"])
     held = np.full(NF, -1, np.int32) if held is None else held.copy()
     hits = np.zeros(NF, np.int64)
+    qm = np.zeros(nq, np.int64)
     total, passes = 0, 0
     for radius in (th, th_second):
         passes += 1
         ex = (held >= 0).astype(np.uint8)[: s["n"]]
-        bi, bd, sd, nc, eh = orc.search_in_area_ex(s["kps"], s["desc"], (0.0, float(W), 0.0, float(H)), s["qxy"], np.full(nq, radius, np.float32), lo, hi,
-                                                   s["q_desc"], ex)
+        rad = (np.float32(radius) * (SF * SF).astype(np.float32)[s["octave"]]).astype(np.float32)     # findFeaturesInArea: radius * getScaledFactor2(octave)
+        bi, bd, sd, nc, eh = orc.search_in_area_ex(s["kps"], s["desc"], (0.0, float(W), 0.0, float(H)), s["qxy"], rad, lo, hi, s["q_desc"], ex)
         hits[: s["n"]] += eh
         matches = [(int(bi[i]), i) for i in range(nq)
                    if nc[i] > 0 and bd[i] < min_threshold and np.float32(bd[i]) / np.float32(sd[i]) < np.float32(ratio)]
         for f, i in matches:                                              # setMapPoints: in query order, the last one stays
             held[f] = i
+            qm[i] += 1
         total += len(matches)
         if total >= min_matches or not th_second > 0:
             break
-    out = dict(assigned=held, n_matches=total, passes=passes, hits=hits)
+    out = dict(assigned=held, n_matches=total, passes=passes, hits=hits, query_matches=qm)
     if total < min_matches:
         return out
     sig2 = (SF * SF).astype(np.float32)
@@ -225,13 +227,14 @@ def test_track_motion_model_matches_the_composed_chain(orc, seed, mode):
     lo, hi = _windows(s["octave"], mode)
     sig2 = (SF * SF).astype(np.float32)
     inv_sig2 = (np.float32(1.0) / sig2).astype(np.float32)
-    args = (0, s["qxy"], lo, hi, s["q_desc"], s["pos"], (FX, FY, CX, CY, BF), (0.0, float(W), 0.0, float(H)), s["pose_se3"], sig2, inv_sig2)
+    args = (0, s["qxy"], s["octave"], lo, hi, s["q_desc"], s["pos"], (FX, FY, CX, CY, BF), (0.0, float(W), 0.0, float(H)), s["pose_se3"], sig2, inv_sig2)
     g = ctx.track_motion_model(*args, right_u=s["right_u"])
     r = _reference_motion_chain(orc, s, lo, hi)
     assert g["passes"] == r["passes"] == 1 and g["n_matches"] == r["n_matches"] and r["n_matches"] > 400
     assert np.array_equal(g["assigned"][:s["n"]], r["assigned"][:s["n"]])
     assert g["n_edges"] == r["n_edges"] and np.array_equal(np.flatnonzero(g["edge_of"] >= 0), np.array(r["edge_features"]))
     assert g["n_matches"] > g["n_edges"]                                   # some queries lost their feature to a later one: matches count queries
+    assert np.array_equal(g["query_matches"], r["query_matches"]) and g["query_matches"].sum() == g["n_matches"]
     assert abs(g["n_good"] - r["n_good"]) <= 1 and (g["inlier"] != r["inlier"]).sum() <= 1
     assert np.abs(g["pose"] - r["pose"]).max() < 1e-6 and np.abs(g["pose"] - s["pose_se3"]).max() > 1e-3
     assert not g["excluded_hits"].any()                                    # a fresh frame holds nothing
@@ -256,7 +259,7 @@ def test_track_motion_model_second_search_and_too_few_matches(orc):
     lo, hi = _windows(s["octave"], "same")
     sig2 = (SF * SF).astype(np.float32)
     inv_sig2 = (np.float32(1.0) / sig2).astype(np.float32)
-    args = (0, s["qxy"], lo, hi, s["q_desc"], s["pos"], (FX, FY, CX, CY, BF), (0.0, float(W), 0.0, float(H)), s["pose_se3"], sig2, inv_sig2)
+    args = (0, s["qxy"], s["octave"], lo, hi, s["q_desc"], s["pos"], (FX, FY, CX, CY, BF), (0.0, float(W), 0.0, float(H)), s["pose_se3"], sig2, inv_sig2)
     m1 = _reference_motion_chain(orc, s, lo, hi, th_second=0.0, min_matches=10 ** 6)["n_matches"]     # what the first search finds
     need = m1 + 1                                                                                     # ... is one short
     kw = dict(right_u=s["right_u"], ratio=0.9, min_matches=need)
@@ -264,7 +267,7 @@ def test_track_motion_model_second_search_and_too_few_matches(orc):
     r = _reference_motion_chain(orc, s, lo, hi, min_matches=need)
     assert r["passes"] == 2 and g["passes"] == 2 and r["n_matches"] > m1 + 10 and m1 > 20, (m1, r["n_matches"])
     assert g["n_matches"] == r["n_matches"] and np.array_equal(g["assigned"][:s["n"]], r["assigned"][:s["n"]])
-    assert np.array_equal(g["excluded_hits"][:s["n"]], r["hits"][:s["n"]])
+    assert np.array_equal(g["excluded_hits"][:s["n"]], r["hits"][:s["n"]]) and np.array_equal(g["query_matches"], r["query_matches"])
     assert g["n_edges"] == r["n_edges"] and abs(g["n_good"] - r["n_good"]) <= 1 and np.abs(g["pose"] - r["pose"]).max() < 1e-6
     # still too few after both searches: no optimisation (Tracking.cc:392-395)
     few = ctx.track_motion_model(*args, right_u=s["right_u"], min_matches=10 ** 6)
@@ -273,7 +276,7 @@ def test_track_motion_model_second_search_and_too_few_matches(orc):
     one = ctx.track_motion_model(*args, right_u=s["right_u"], min_matches=10 ** 6, th_second=0.0)
     assert one["passes"] == 1 and one["n_edges"] == -1
     # no queries
-    none = ctx.track_motion_model(0, np.zeros((0, 2)), np.zeros(0, np.int8), np.zeros(0, np.int8), np.zeros((0, 32), np.uint8), np.zeros((0, 3)),
+    none = ctx.track_motion_model(0, np.zeros((0, 2)), np.zeros(0, np.int8), np.zeros(0, np.int8), np.zeros(0, np.int8), np.zeros((0, 32), np.uint8), np.zeros((0, 3)),
                                   (FX, FY, CX, CY, BF), (0.0, float(W), 0.0, float(H)), s["pose_se3"], sig2, inv_sig2)
     assert none["n_matches"] == 0 and (none["assigned"] == -1).all()
     ctx.close()
