@@ -662,8 +662,11 @@ def latency_leg(device_id, n=500):
         ef = np.flatnonzero(held >= 0)
         meas = np.stack([lk["x"][ef].astype(np.float64), lk["y"][ef].astype(np.float64), ru_full[ef]], 1)
         oc = lk["octave"][ef]
-        return ctx.pose_only_optimize(mp_pos[held[ef]].astype(np.float64), meas, isig2[oc].astype(np.float64), sig2[oc], p0, FX, FX, CXk, CYk, BF), held
+        return ctx.pose_only_optimize(mp_pos[held[ef]].astype(np.float64), meas, isig2[oc].astype(np.float64), sig2[oc], p0, *cam32), held
 
+    # (the camera constants as the reference holds them -- Camera::mfFx ... are floats -- so that both paths optimise the same problem to the bit:
+    #  with 718.856 as a double on one side the two trajectories part after a few iterations and take different numbers of passes)
+    cam32 = tuple(float(np.float32(v)) for v in (FX, FX, CXk, CYk, BF))
     gf = chain_fused()
     (ng3, pose3, _), held3 = chain_three_calls()
     if not np.array_equal(gf["assigned"], held3) or abs(gf["n_good"] - ng3) > 1 or np.abs(gf["pose"] - pose3).max() > 1e-6:
@@ -674,6 +677,43 @@ def latency_leg(device_id, n=500):
                 "the reference's policy in numpy between them",
         "n_matches": int(gf["n_matches"]), "n_edges": int(gf["n_edges"]), "n_good": int(gf["n_good"]),
         "fused": _stats_ms(chain_fused, 200, warm=10), "three_calls": _stats_ms(chain_three_calls, 100, warm=5), "verified": True}
+    # Tracking::trackMotionModel's chain (Tracking.cc:385-396): searchByProjection(frame, lastFrame, 15 [, 30]) -- a search around the last frame's
+    # feature positions, last match wins -- + OptimizePoseOnly, as ONE call (orbfe_track_motion_model) against orbfe_search_in_area +
+    # orbfe_pose_only_optimize with the policy in numpy.  The last frame: 1600 of the frame's keypoints a few pixels off, descriptors 6 bits off.
+    qi = np.sort(r.permutation(n_l)[: min(n_l, 1600)])
+    m_qxy = np.stack([lk["x"][qi], lk["y"][qi]], 1).astype(np.float32) + r.normal(0, 3, (len(qi), 2)).astype(np.float32)
+    m_oct = lk["octave"][qi].astype(np.int8)
+    m_lo, m_hi = np.maximum(0, m_oct - 1).astype(np.int8), np.minimum(NLEVELS - 1, m_oct + 1).astype(np.int8)
+    m_desc = ld[qi].copy()
+    fb = r.integers(0, 256, (len(qi), 6))
+    for k in range(6):
+        m_desc[np.arange(len(qi)), fb[:, k] // 8] ^= (1 << (fb[:, k] % 8)).astype(np.uint8)
+    m_pos = Xmp[qi]
+
+    def motion_fused():
+        return ctx.track_motion_model(0, m_qxy, m_oct, m_lo, m_hi, m_desc, m_pos, camk, bndk, p0, sig2, isig2, right_u=ru_full)
+
+    def motion_two_calls():
+        rad15 = (np.float32(15.0) * sig2[m_oct.astype(np.int64)]).astype(np.float32)
+        bi, bd, sd, nc = ctx.search_in_area(0, m_qxy, rad15, m_lo, m_hi, m_desc)
+        ok = np.flatnonzero((nc > 0) & (bd < 50) & (bd.astype(np.float32) / sd.astype(np.float32) < np.float32(0.9)))
+        held = np.full(NFEAT, -1, np.int64)
+        held[bi[ok]] = ok                      # setMapPoints in query order: the last one stays (ascending assignment, duplicates overwritten)
+        ef = np.flatnonzero(held >= 0)
+        meas = np.stack([lk["x"][ef].astype(np.float64), lk["y"][ef].astype(np.float64), ru_full[ef]], 1)
+        oc = lk["octave"][ef]
+        return ctx.pose_only_optimize(m_pos[held[ef]].astype(np.float64), meas, isig2[oc].astype(np.float64), sig2[oc], p0, *cam32), held, len(ok)
+
+    gm = motion_fused()
+    (ngm, posem, _), heldm, nmm = motion_two_calls()
+    if gm["passes"] != 1 or gm["n_matches"] != nmm or not np.array_equal(gm["assigned"], heldm) or abs(gm["n_good"] - ngm) > 1 or np.abs(gm["pose"] - posem).max() > 1e-6:
+        raise SystemExit("bench.py: latency leg: the fused motion-model chain differs from the separate calls")
+    out["track_motion_model"] = {
+        "what": "Tracking::trackMotionModel's device work for 1600 last-frame features with map points against a 2000-feature frame, host arrays "
+                "in, host results out: orbfe_track_motion_model (one call) vs orbfe_search_in_area + orbfe_pose_only_optimize with the "
+                "reference's policy in numpy between them",
+        "n_matches": int(gm["n_matches"]), "n_edges": int(gm["n_edges"]), "n_good": int(gm["n_good"]),
+        "fused": _stats_ms(motion_fused, 200, warm=10), "two_calls": _stats_ms(motion_two_calls, 100, warm=5), "verified": True}
     ctx.close()
     # (b) the C++ drop-in
     tmp = tempfile.mkdtemp(prefix="orbfe_lat_")

@@ -381,7 +381,7 @@ __device__ long long g_pose_stamps[8];
 #define PS_COUNT(k)
 #endif
 #define POSE_TRIALS 10  // g2o's Levenberg-Marquardt gives an iteration at most 10 trial steps (qmax)
-#define POSE_STAGE_LD (256 + 8)  // doubles per row of the staged sums: rows 8 double-banks apart => the 8 x 8 readers of a wave 2 per bank pair
+#define POSE_STAGE_LD(NT) ((NT) + 8)  // doubles per row of the staged sums: rows 8 double-banks apart => the readers of a wave 2 per bank pair
 template <int NT>
 struct PoseSharedR {
   PoseDev T0;
@@ -391,8 +391,8 @@ struct PoseSharedR {
   PoseDev trial_T[POSE_TRIALS];
   double trial_x[POSE_TRIALS][6];
   int trial_ok[POSE_TRIALS];
-  // the 27 sums of the normal equations staged per thread (256-thread kernel; the 512-thread one reduces in registers)
-  double stage[NT == 256 ? 27 * POSE_STAGE_LD : 1];
+  // the 27 sums of the normal equations staged per thread (59 KB with 256 threads, 112 KB with 512: static LDS past 64 KB is fine on gfx950)
+  double stage[27 * POSE_STAGE_LD(NT)];
 };
 template <int NT>
 __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __restrict__ Xw, const double* __restrict__ meas,
@@ -616,23 +616,25 @@ __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __res
           }
           PS(5)  // build: per-edge arithmetic
           // (the previous system's b and trial table are rewritten only behind the barrier below: every thread has read them by then)
-          if constexpr (NT == 256) {
-            // every thread stages its 27 partial sums; eight threads per sum add 32 staged values each (ascending), a fixed tree joins the
-            // eight: 27 + 32 LDS accesses and 35 additions per thread, where 27 wave trees of data-parallel-primitive moves took as long as
-            // the edges' arithmetic (6.7 k of a build's 13.5 k cycles)
+          {
+            // every thread stages its 27 partial sums; NT / 32 threads per sum add 32 staged values each (ascending), a fixed tree joins
+            // them: 27 + 32 LDS accesses and ~36 additions per thread, where 27 wave trees of data-parallel-primitive moves took as long as
+            // the edges' arithmetic (6.7 k of a build's 13.5 k cycles with 256 threads)
+            constexpr int PARTS = NT / 32, LD = POSE_STAGE_LD(NT);
 #pragma unroll
-            for (int k = 0; k < 27; ++k) S.stage[k * POSE_STAGE_LD + tid] = acc[k];
+            for (int k = 0; k < 27; ++k) S.stage[k * LD + tid] = acc[k];
             __syncthreads();
-            if (tid < 27 * 8) {
-              const int k = tid >> 3, part = tid & 7;
-              const double* row = S.stage + k * POSE_STAGE_LD + part;
+            if (tid < 27 * PARTS) {
+              const int k = tid / PARTS, part = tid % PARTS;
+              const double* row = S.stage + k * LD + part;
               double sm = 0;
 #pragma unroll
-              for (int j = 0; j < 32; ++j) sm += row[8 * j];
-              sm += dpp_f64<ORBFE_DPP_ROW_SHR(1), 0xf>(sm);  // lanes 8 m + 7 of a row of 16 end up with the sum of their eight
+              for (int j = 0; j < 32; ++j) sm += row[PARTS * j];
+              sm += dpp_f64<ORBFE_DPP_ROW_SHR(1), 0xf>(sm);  // the last lane of each group of PARTS (8: half a row of 16, 16: a row) ends up with the group's sum
               sm += dpp_f64<ORBFE_DPP_ROW_SHR(2), 0xf>(sm);
               sm += dpp_f64<ORBFE_DPP_ROW_SHR(4), 0xf>(sm);
-              if (part == 7) {
+              if (PARTS == 16) sm += dpp_f64<ORBFE_DPP_ROW_SHR(8), 0xf>(sm);
+              if (part == PARTS - 1) {
                 if (k >= 21) {
                   S.b[k - 21] = sm;
                 } else {  // k -> (a, c2), a <= c2, in the order the sums were laid out
@@ -642,28 +644,6 @@ __global__ __launch_bounds__(NT) void k_pose_only_reg(int n, const double* __res
                   S.H[6 * a + c2] = sm;
                   S.H[6 * c2 + a] = sm;
                 }
-              }
-            }
-            __syncthreads();
-          } else {
-#pragma unroll
-            for (int k = 0; k < 27; ++k) {
-              const double w = wave_sum_f64(acc[k]);
-              if (lane == 0) S.red[k][wv] = w;
-            }
-            __syncthreads();
-            if (tid < 27) {
-              double sm = 0;
-#pragma unroll
-              for (int k = 0; k < NT / 64; ++k) sm += S.red[tid][k];
-              if (tid >= 21) {
-                S.b[tid - 21] = sm;
-              } else {  // tid -> (a, c2), a <= c2, in the order the sums were laid out
-                int a = 0, rem = tid;
-                while (rem >= 6 - a) rem -= 6 - a, ++a;
-                const int c2 = a + rem;
-                S.H[6 * a + c2] = sm;
-                S.H[6 * c2 + a] = sm;
               }
             }
             __syncthreads();

@@ -23,7 +23,10 @@ if mc:
     for r in db.execute(f"select start, end, {nm}" + (f", {sz}" if sz else "") + " from memory_copies").fetchall():
         rows.append((r[0], r[1], f"copy {r[2]}" + (f" {r[3]} B" if sz else "")))
 rows.sort()
-idx = [i for i, r in enumerate(rows) if "k_track_queries" in r[2]]
+import os
+anchor = os.environ.get("TRACK_ANCHOR", "k_track_queries")
+idx = [i for i, r in enumerate(rows) if anchor in r[2]]
+if anchor != "k_track_queries": idx = [i for i in idx if i > [j for j, r in enumerate(rows) if "k_track_queries" in r[2]][-1]]
 i0 = idx[len(idx) // 2]
 i1 = idx[len(idx) // 2 + 1]
 # walk back over the uploads of this call
