@@ -1460,9 +1460,10 @@ struct FrameRgbdReq {
   size_t depth_stride;
   float depth_scale;
   double *depth_out, *right_u_out;  // [n_features], caller's, nullable
+  bool no_tail;                     // orbfe_extract_color: the conversion and the extraction only (the keypoints stay as extracted)
 };
 struct FrameRgbdKey {  // what of a request is baked into a captured launch sequence
-  int32_t color_order, has_depth, depth_type;
+  int32_t color_order, has_depth /* 2: no tail at all */, depth_type;
   size_t depth_stride;
   float depth_scale;
   orbfe_camera cam;
@@ -1495,7 +1496,7 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
   static_assert(sizeof(FrameRgbdKey) <= sizeof(orbfe_ctx::GraphEntry::rkey), "GraphEntry::rkey");
   std::memset(&rkey, 0, sizeof rkey);
   if (fr) {
-    rkey.color_order = fr->color_order, rkey.has_depth = fr->depth ? 1 : 0, rkey.depth_type = fr->depth_type;
+    rkey.color_order = fr->color_order, rkey.has_depth = fr->no_tail ? 2 : (fr->depth ? 1 : 0), rkey.depth_type = fr->depth_type;
     rkey.depth_stride = fr->depth_stride, rkey.depth_scale = fr->depth_scale, rkey.cam = fr->cam;
   }
   uint8_t* const pyr_now = c->d_pyr;
@@ -1504,7 +1505,8 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
   // descriptors there themselves (posted PCIe writes, ~120 KB per image) beside the device arrays the stereo match reads -- three
   // device-to-host copies queued behind the last kernel cost ~17 us of a ~0.3 ms call.  More than two images: the copies.
   const bool mirror_on = n_img <= 2;
-  HostMirror mir = {(kps && !fr) ? (orbfe_keypoint*)(ln.h_stage + o_kps) : nullptr, desc ? ln.h_stage + o_desc : nullptr, (int32_t*)(ln.h_stage + o_cnt)};
+  const bool rgbd_tail = fr && !fr->no_tail;
+  HostMirror mir = {(kps && !rgbd_tail) ? (orbfe_keypoint*)(ln.h_stage + o_kps) : nullptr, desc ? ln.h_stage + o_desc : nullptr, (int32_t*)(ln.h_stage + o_cnt)};
   auto enqueue_all = [&]() -> orbfe_status {
     // (more images: both in ONE copy -- rows = images: the staging planes are `plane` bytes apart, the pyramid slots img_pitch)
     // One or two images: level 0 is read from the page-locked staging planes by a copy KERNEL (16 bytes per load over PCIe, every byte
@@ -1526,7 +1528,7 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
       const bool table_ready = c->slot_table_ok && c->slot_table_ok[(size_t)slot0 + 1] != 0;
       TRY(run_stereo(c, ln.stream, slot0, slot0 + 1, 0, slot0 / 2, 1, fs->fx, fs->bf, &ho, table_ready, timing));
     }
-    if (fr) {
+    if (rgbd_tail) {
       launch_frame_rgbd(ln.stream, c->d_kps + (size_t)slot0 * NF, c->d_n_kp + slot0, (int)NF, fr->cam, d_bytes ? ln.h_stage + o_dimg : nullptr,
                         fr->depth_type, fr->depth_stride, fr->depth_scale, (double*)(ln.h_stage + o_dp), (double*)(ln.h_stage + o_ru),
                         (orbfe_keypoint*)(ln.h_stage + o_kps));
@@ -1549,7 +1551,7 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
       if (fs->depth && n) std::memcpy(fs->depth, dp, sizeof(double) * n);
       if (fs->n_matches) *fs->n_matches = nm;
     }
-    if (fr) {
+    if (rgbd_tail) {
       const size_t n = (size_t)c->cfg.n_features;
       if (fr->depth_out && n) std::memcpy(fr->depth_out, ln.h_stage + o_dp, sizeof(double) * n);
       if (fr->right_u_out && n) std::memcpy(fr->right_u_out, ln.h_stage + o_ru, sizeof(double) * n);
@@ -1697,7 +1699,7 @@ orbfe_status orbfe_frame_rgbd_image(orbfe_ctx* c, int32_t slot, const uint8_t* i
   if (depth && (depth_type < 0 || depth_type > 1 || depth_stride < (size_t)c->cfg.width * px || !(depth_scale > 0)))
     return fail(c, ORBFE_EBADARG, "frame_rgbd_image: depth type %d stride %zu scale %g", depth_type, depth_stride, (double)depth_scale);
   const uint8_t* one[1] = {img};
-  const FrameRgbdReq fr = {color_order, *cam, depth, depth_type, depth_stride, depth_scale, depth_out, right_u_out};
+  const FrameRgbdReq fr = {color_order, *cam, depth, depth_type, depth_stride, depth_scale, depth_out, right_u_out, false};
   return extract_slots_impl(c, slot, 1, one, stride, kps_undistorted, desc, n_out, nullptr, &fr);
 }
 // orbfe_frame_stereo into the slot pair (slot_left, slot_left + 1), slot_left even, on slot_left's lane: what the drop-in's frame-level
@@ -1720,26 +1722,19 @@ orbfe_status orbfe_extract(orbfe_ctx* c, const uint8_t* img, size_t stride, orbf
 
 orbfe_status orbfe_extract_color(orbfe_ctx* c, const uint8_t* img, size_t stride, int32_t color_order, orbfe_keypoint* kps, uint8_t* desc,
                                  int32_t* n_out) {
+  // (through the one-frame launch sequence since late r4: the conversion kernel reads the staged colour rows itself, the sequence is
+  //  replayed from a captured graph and the results come back through the staging buffer -- the same path as orbfe_extract_batch)
   ApiLock api_lk(c);
   if (!c || !img) return fail(c, ORBFE_EBADARG, "extract_color: NULL argument");
   if (color_order != 1 && color_order != 2) return fail(c, ORBFE_EBADARG, "extract_color: color_order %d (1 = RGB, 2 = BGR)", color_order);
   if (stride < (size_t)c->cfg.width * 3) return fail(c, ORBFE_EBADARG, "extract_color: stride %zu < 3 * width", stride);
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
-  const LevelDev& L0 = c->lv[0];
-  const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
-  const size_t row = align_up((size_t)c->cfg.width * 3, 16) + 16;  // 4-aligned rows with room for the last 12-byte group
-  const size_t plane = align_up(row * (size_t)L0.h, 256);
-  const size_t o_kps = plane, o_desc = o_kps + align_up(NF * sizeof(orbfe_keypoint), 256), o_cnt = o_desc + align_up(NF * 32, 256),
-               total = o_cnt + 256;
-  TRY(ensure_stage(c, total));
-  TRY(ensure_tmp(c, plane));
-  for (int y = 0; y < L0.h; ++y) std::memcpy(c->main.h_stage + (size_t)y * row, img + (size_t)y * stride, (size_t)c->cfg.width * 3);
-  HIP_TRY(c, hipMemcpyAsync(c->d_tmp, c->main.h_stage, row * (size_t)L0.h, hipMemcpyHostToDevice, c->stream));
-  launch_cvt_gray(c->stream, (const uint8_t*)c->d_tmp, row, c->d_pyr + L0.plane_off, L0.stride, c->cfg.width, c->cfg.height, color_order,
-                  c->cfg.gray_variant ? 1 : 0);
-  TRY(run_extract(c, c->stream, 0, 1));
-  return fetch_extract_results(c, 1, o_kps, o_desc, o_cnt, kps, desc, n_out);
+  const uint8_t* one[1] = {img};
+  FrameRgbdReq fr;
+  std::memset(&fr, 0, sizeof fr);
+  fr.color_order = color_order, fr.no_tail = true;
+  return extract_lane(c, c->main, 0, 1, one, stride, kps, desc, n_out, true, nullptr, &fr);
 }
 
 orbfe_status orbfe_frame_rgbd(orbfe_ctx* c, int32_t slot, const orbfe_camera* cam, const void* depth, int32_t depth_type,
@@ -3207,6 +3202,7 @@ orbfe_status orbfe_track_motion_model(orbfe_ctx* c, int32_t slot, const float* b
                o_nc = take(N * 4), o_xw = take(NF * 24), o_ms = take(NF * 24), o_info = take(NF * 8), o_sig = take(NF * 4), o_err = take(NF * 24),
                o_l = take(NF), o_r = take(NF), o_cnt = take(16), o_ng = take(8), o_po = take(56), o_asg = take(NF * 4), o_eo = take(NF * 4), o_in = take(NF),
                o_ehd = take(NF * 4), o_qad = take(N), o_dn_end = take(8);
+  (void)o_up1_end;
   TRY(ensure_tmp(c, off));
   TRY(ensure_stage(c, std::max(o_up2_end, o_dn_end - o_cnt)));
   uint8_t* b = (uint8_t*)c->d_tmp;
