@@ -1803,7 +1803,10 @@ orbfe_status orbfe_stereo_match(orbfe_ctx* c, int32_t slot_left, int32_t slot_ri
   const bool table_ready = c->slot_table_ok && c->slot_table_ok[(size_t)slot_right] != 0;
   if (table_ready && !c->pair_count_zero[(size_t)pair].exchange(0)) HIP_TRY(c, hipMemsetAsync(c->d_n_match + pair, 0, sizeof(int32_t), c->stream));
   TRY(run_stereo(c, c->stream, slot_left, slot_right, 0, pair, 1, fx, bf, &ho, table_ready));
-  HIP_TRY(c, hipMemcpyAsync(h + o_nm, c->d_n_match + pair, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  // (the count: with right_u in the staging buffer it is counted there -- k_stereo counts exactly the features it gives a right coordinate --
+  //  and the 4-byte copy, a transfer of its own behind the kernel, is left out)
+  const bool count_on_host = right_u != nullptr;
+  if (n_matches && !count_on_host) HIP_TRY(c, hipMemcpyAsync(h + o_nm, c->d_n_match + pair, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_timers(c);
   const size_t n = (size_t)c->cfg.n_features;
@@ -1811,7 +1814,15 @@ orbfe_status orbfe_stereo_match(orbfe_ctx* c, int32_t slot_left, int32_t slot_ri
   if (depth && n) std::memcpy(depth, h + o_dp, sizeof(double) * n);
   if (best_right && n) std::memcpy(best_right, h + o_br, sizeof(int32_t) * n);
   if (best_dist && n) std::memcpy(best_dist, h + o_bd, sizeof(int32_t) * n);
-  if (n_matches) std::memcpy(n_matches, h + o_nm, sizeof(int32_t));
+  if (n_matches) {
+    if (count_on_host) {
+      int32_t nm = 0;
+      const double* ru = (const double*)(h + o_ru);
+      for (size_t i = 0; i < n; ++i) nm += ru[i] >= 0.0 ? 1 : 0;
+      *n_matches = nm;
+    } else
+      std::memcpy(n_matches, h + o_nm, sizeof(int32_t));
+  }
   return ORBFE_OK;
 }
 
