@@ -262,6 +262,12 @@ struct orbfe_ctx {
   uint32_t* d_rowoff_slot = nullptr;
   uint16_t* d_rowlist_slot = nullptr;
   std::unique_ptr<std::atomic<uint8_t>[]> slot_table_ok, pair_count_zero;
+  // The frame grid of a slot (VirtualFrame::initGrid) is kept from one guided search to the next: Tracking searches the same frame two to
+  // four times.  grid_key[s] = rows << 16 | cols of the grid held for slot s's current keypoints, 0: none (a new extraction into the slot
+  // or an in-place undistortion clears it).  Allocated on first use, grid_cells entries per slot.
+  int32_t *d_grid_off = nullptr, *d_grid_feat = nullptr;
+  size_t grid_cells = 0;
+  std::unique_ptr<std::atomic<uint32_t>[]> grid_key;
   double *d_right_u = nullptr, *d_depth = nullptr;
   int32_t *d_n_match = nullptr, *d_best_right = nullptr, *d_best_dist = nullptr;
   // generic staging for match / BA calls
@@ -875,6 +881,8 @@ struct ExtLevel0 {
 };
 // slots [s0, s0 + n) have just been (or are about to be) rewritten by an extraction; small: one that also built their row tables
 static void note_slots_written(orbfe_ctx* c, int s0, int n, bool small) {
+  if (c->grid_key)
+    for (int s = s0; s < s0 + n && s < c->cfg.max_images; ++s) c->grid_key[(size_t)s] = 0;
   if (!c->slot_table_ok) return;
   for (int s = s0; s < s0 + n && s < c->cfg.max_images; ++s) {
     c->slot_table_ok[(size_t)s] = small ? 1 : 0;
@@ -1096,6 +1104,8 @@ void orbfe_destroy(orbfe_ctx* c) {
   if (c->ev_brief_done) (void)hipEventDestroy(c->ev_brief_done);
   if (c->ev_stereo_done) (void)hipEventDestroy(c->ev_stereo_done);
   if (c->d_pyr_alt) (void)hipFree(c->d_pyr_alt);
+  if (c->d_grid_off) (void)hipFree(c->d_grid_off);
+  if (c->d_grid_feat) (void)hipFree(c->d_grid_feat);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1756,6 +1766,7 @@ orbfe_status orbfe_frame_rgbd(orbfe_ctx* c, int32_t slot, const orbfe_camera* ca
   TRY(ensure_stage(c, h_total));
   uint8_t* hs = c->main.h_stage;
   if (depth) std::memcpy(hs, depth, d_bytes);
+  if (c->grid_key) c->grid_key[(size_t)slot] = 0;  // (the keypoints move: a grid kept for the slot is stale)
   launch_frame_rgbd(c->stream, c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, (int)NF, *cam, depth ? hs : nullptr, depth_type, depth_stride,
                     depth_scale, (double*)(hs + h_res), (double*)(hs + h_ru), kps_out ? (orbfe_keypoint*)(hs + h_k) : nullptr);
   HIP_TRY(c, hipGetLastError());
@@ -2827,13 +2838,41 @@ static bool area_grid(const orbfe_ctx* c, const float* bounds, AreaGrid* g) {
   return g->rows >= 1 && g->cols >= 1;
 }
 
+// the grid of `slot` for the geometry ag on stream st: the one kept from the last search if the slot's keypoints are still the same
+static orbfe_status slot_grid(orbfe_ctx* c, hipStream_t st, int slot, const AreaGrid& ag, const int32_t** d_off, const int32_t** d_feat) {
+  const size_t NF = (size_t)std::max(c->cfg.n_features, 1), M = (size_t)c->cfg.max_images, ncells = (size_t)ag.rows * ag.cols;
+  if (!c->grid_key) {
+    c->grid_key.reset(new std::atomic<uint32_t>[M]);
+    for (size_t k = 0; k < M; ++k) c->grid_key[k] = 0;
+  }
+  if (ncells + 1 > c->grid_cells) {  // first use, or a larger grid than any before: (re)allocate, nothing cached survives
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (c->d_grid_off) (void)hipFree(c->d_grid_off);
+    if (!c->d_grid_feat) HIP_TRY(c, hipMalloc((void**)&c->d_grid_feat, M * NF * sizeof(int32_t)));
+    c->d_grid_off = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&c->d_grid_off, M * (ncells + 1) * sizeof(int32_t)));
+    c->grid_cells = ncells + 1;
+    for (size_t k = 0; k < M; ++k) c->grid_key[k] = 0;
+  }
+  int32_t* off = c->d_grid_off + (size_t)slot * c->grid_cells;
+  int32_t* feat = c->d_grid_feat + (size_t)slot * NF;
+  const uint32_t key = ((uint32_t)ag.rows << 16) | (uint32_t)ag.cols;
+  if (c->grid_key[(size_t)slot] != key) {
+    launch_grid_build(st, c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, (int)NF, ag.rows, ag.cols, off, feat);
+    c->grid_key[(size_t)slot] = key;
+  }
+  *d_off = off, *d_feat = feat;
+  return ORBFE_OK;
+}
+
 static orbfe_status search_area_core(orbfe_ctx* c, const char* who, const orbfe_keypoint* d_kps, const int32_t* d_n_kp, const uint4* d_kpl,
                                      const uint8_t* d_desc, size_t n_target, size_t tmp_used, int32_t nq, const float* qxy,
                                      const float* radius, const int8_t* min_level, const int8_t* max_level, const uint8_t* q_desc,
                                      const uint8_t* exclude, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist, int32_t* n_cand,
-                                     const float* bounds = nullptr, int32_t* excluded_hits = nullptr, bool staged_prefix = false) {
+                                     const float* bounds = nullptr, int32_t* excluded_hits = nullptr, bool staged_prefix = false,
+                                     int cache_slot = -1) {
   // staged_prefix: the caller has written the first tmp_used bytes of the scratch into the staging buffer (same offsets): they go up
-  // with the queries
+  // with the queries.  cache_slot >= 0: the target is that slot -- its grid is kept between searches (slot_grid)
   AreaGrid ag;
   if (!area_grid(c, bounds, &ag)) return fail(c, ORBFE_EBADARG, "%s: bad frame bounds", who);
   const int rows = ag.rows, cols = ag.cols;
@@ -2869,9 +2908,13 @@ static orbfe_status search_area_core(orbfe_ctx* c, const char* who, const orbfe_
   if (hits) HIP_TRY(c, hipMemsetAsync(b + o_eh, 0, NT * 4, c->stream));
   {
     StageTimer tm(c, ORBFE_STAGE_MATCH, c->stream);
-    launch_grid_build(c->stream, d_kps, d_n_kp, (int)NT, rows, cols, (int32_t*)(b + o_co), (int32_t*)(b + o_cf));
-    launch_search_area(c->stream, d_kpl, d_desc, ag.clip_w, ag.clip_h, rows, cols, (const int32_t*)(b + o_co),
-                       (const int32_t*)(b + o_cf), nq, (const float*)(b + o_q), (const float*)(b + o_r), (const int8_t*)(b + o_lo),
+    const int32_t *g_off = (const int32_t*)(b + o_co), *g_feat = (const int32_t*)(b + o_cf);
+    if (cache_slot >= 0)
+      TRY(slot_grid(c, c->stream, cache_slot, ag, &g_off, &g_feat));
+    else
+      launch_grid_build(c->stream, d_kps, d_n_kp, (int)NT, rows, cols, (int32_t*)(b + o_co), (int32_t*)(b + o_cf));
+    launch_search_area(c->stream, d_kpl, d_desc, ag.clip_w, ag.clip_h, rows, cols, g_off,
+                       g_feat, nq, (const float*)(b + o_q), (const float*)(b + o_r), (const int8_t*)(b + o_lo),
                        (const int8_t*)(b + o_hi), b + o_d, exclude ? b + o_ex : nullptr, (int32_t*)(b + o_bi), (int32_t*)(b + o_bd),
                        (int32_t*)(b + o_sd), (int32_t*)(b + o_nc), hits ? (int32_t*)(b + o_eh) : nullptr);
   }
@@ -2909,7 +2952,7 @@ orbfe_status orbfe_search_in_area(orbfe_ctx* c, int32_t slot, int32_t nq, const 
   TRY(ensure_tmp(c, search_area_scratch(c, NF, nq)));
   return search_area_core(c, "search_in_area", c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, c->d_kpl + (size_t)slot * NF,
                           c->d_desc + (size_t)slot * NF * 32, NF, 0, nq, qxy, radius, min_level, max_level, q_desc, exclude, best_idx,
-                          best_dist, second_dist, n_cand);
+                          best_dist, second_dist, n_cand, nullptr, nullptr, false, slot);
 }
 
 orbfe_status orbfe_search_in_area_features(orbfe_ctx* c, int32_t nt, const orbfe_keypoint* t_kps, const uint8_t* t_desc, int32_t nq,
@@ -3092,8 +3135,8 @@ orbfe_status orbfe_track_local_map(orbfe_ctx* c, int32_t slot, const orbfe_frame
   const size_t o_pos = take(N * 12), o_vd = take(N * 12), o_mx = take(N * 4), o_mn = take(N * 4), o_desc = take(N * 32), o_fl = take(N),
                o_held = take(NF * 4), o_ru = take(NF * 8), o_s2 = take((size_t)nl * 4), o_is2 = take((size_t)nl * 4), o_p0 = take(56),
                o_up_end = take(8), o_claim = take(NF * 4), o_claim_end = take(8), o_uv = take(N * 8), o_dist = take(N * 4), o_cos = take(N * 4),
-               o_lvl = take(N), o_vis = take(N), o_rad = take(N * 4), o_lo = take(N), o_hi = take(N), o_co = take((ncells + 1) * 4),
-               o_cf = take(NF * 4), o_bi = take(N * 4), o_bd = take(N * 4), o_sd = take(N * 4), o_nc = take(N * 4), o_xw = take(NF * 24),
+               o_lvl = take(N), o_vis = take(N), o_rad = take(N * 4), o_lo = take(N), o_hi = take(N),
+               o_bi = take(N * 4), o_bd = take(N * 4), o_sd = take(N * 4), o_nc = take(N * 4), o_xw = take(NF * 24),
                o_ms = take(NF * 24), o_info = take(NF * 8), o_sig = take(NF * 4), o_err = take(NF * 24), o_l = take(NF), o_r = take(NF),
                o_dn = take(0), o_cnt = take(16), o_ng = take(8), o_po = take(56), o_asg = take(NF * 4), o_eo = take(NF * 4), o_in = take(NF),
                o_dn_end = take(8);
@@ -3130,9 +3173,10 @@ orbfe_status orbfe_track_local_map(orbfe_ctx* c, int32_t slot, const orbfe_frame
                               (float*)(b + o_cos), (int8_t*)(b + o_lvl), b + o_vis);
     launch_track_queries(st, n, b + o_fl, b + o_vis, (const float*)(b + o_cos), (const int8_t*)(b + o_lvl), in->th, (const float*)(b + o_s2), nl,
                          (float*)(b + o_rad), (int8_t*)(b + o_lo), (int8_t*)(b + o_hi));
-    launch_grid_build(st, c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, (int)NF, ag.rows, ag.cols, (int32_t*)(b + o_co), (int32_t*)(b + o_cf));
+    const int32_t *g_off = nullptr, *g_feat = nullptr;
+    TRY(slot_grid(c, st, slot, ag, &g_off, &g_feat));
     launch_search_area(st, c->d_kpl + (size_t)slot * NF, c->d_desc + (size_t)slot * NF * 32, ag.clip_w, ag.clip_h, ag.rows, ag.cols,
-                       (const int32_t*)(b + o_co), (const int32_t*)(b + o_cf), n, (const float*)(b + o_uv), (const float*)(b + o_rad),
+                       g_off, g_feat, n, (const float*)(b + o_uv), (const float*)(b + o_rad),
                        (const int8_t*)(b + o_lo), (const int8_t*)(b + o_hi), b + o_desc, nullptr, (int32_t*)(b + o_bi), (int32_t*)(b + o_bd),
                        (int32_t*)(b + o_sd), (int32_t*)(b + o_nc), nullptr);
     launch_track_claim(st, n, (const int32_t*)(b + o_nc), (const int32_t*)(b + o_bi), (const int32_t*)(b + o_bd), (const int32_t*)(b + o_sd),
@@ -3202,7 +3246,7 @@ orbfe_status orbfe_track_motion_model(orbfe_ctx* c, int32_t slot, const float* b
   const size_t o_qxy = take(N * 8), o_lo = take(N), o_hi = take(N), o_desc = take(N * 32), o_pos = take(N * 12), o_fl = take(N), o_ru = take(NF * 8),
                o_s2 = take((size_t)nl * 4), o_is2 = take((size_t)nl * 4), o_p0 = take(56), o_up1_end = take(8), o_rad = take(N * 4), o_held = take(NF * 4),
                o_ex = take(NF), o_up2_end = take(8), o_claim = take(NF * 4), o_claim_end = take(8), o_eh = take(NF * 4), o_acc = take(16),
-               o_qa = take(N), o_zero_end = take(8), o_co = take((ncells + 1) * 4), o_cf = take(NF * 4), o_bi = take(N * 4), o_bd = take(N * 4), o_sd = take(N * 4),
+               o_qa = take(N), o_zero_end = take(8), o_bi = take(N * 4), o_bd = take(N * 4), o_sd = take(N * 4),
                o_nc = take(N * 4), o_xw = take(NF * 24), o_ms = take(NF * 24), o_info = take(NF * 8), o_sig = take(NF * 4), o_err = take(NF * 24),
                o_l = take(NF), o_r = take(NF), o_cnt = take(16), o_ng = take(8), o_po = take(56), o_asg = take(NF * 4), o_eo = take(NF * 4), o_in = take(NF),
                o_ehd = take(NF * 4), o_qad = take(N), o_dn_end = take(8);
@@ -3247,10 +3291,10 @@ orbfe_status orbfe_track_motion_model(orbfe_ctx* c, int32_t slot, const float* b
     HIP_TRY(c, hipMemsetAsync(b + o_eh, 0, o_zero_end - o_eh, st));
     {
       StageTimer tm(c, ORBFE_STAGE_MATCH, st);
-      if (pass == 0)
-        launch_grid_build(st, c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, (int)NF, ag.rows, ag.cols, (int32_t*)(b + o_co), (int32_t*)(b + o_cf));
+      const int32_t *g_off = nullptr, *g_feat = nullptr;
+      TRY(slot_grid(c, st, slot, ag, &g_off, &g_feat));
       launch_search_area(st, c->d_kpl + (size_t)slot * NF, c->d_desc + (size_t)slot * NF * 32, ag.clip_w, ag.clip_h, ag.rows, ag.cols,
-                         (const int32_t*)(b + o_co), (const int32_t*)(b + o_cf), n, (const float*)(b + o_qxy), (const float*)(b + o_rad),
+                         g_off, g_feat, n, (const float*)(b + o_qxy), (const float*)(b + o_rad),
                          (const int8_t*)(b + o_lo), (const int8_t*)(b + o_hi), b + o_desc, b + o_ex, (int32_t*)(b + o_bi), (int32_t*)(b + o_bd),
                          (int32_t*)(b + o_sd), (int32_t*)(b + o_nc), (int32_t*)(b + o_eh));
       launch_track_claim(st, n, (const int32_t*)(b + o_nc), (const int32_t*)(b + o_bi), (const int32_t*)(b + o_bd), (const int32_t*)(b + o_sd),

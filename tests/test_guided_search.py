@@ -76,3 +76,30 @@ def test_device_guided_search_matches_oracle(orc, w, h, nf):
             assert np.array_equal(g, r), name
     assert got[3].max() > 128      # some query exercises the multi-chunk path (more than two 64-candidate chunks)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_kept_grid_follows_the_slots_keypoints(orc):
+    """the grid of a slot is kept between searches (Tracking searches a frame two to four times): a new extraction into the slot, an
+    in-place undistortion (orbfe_frame_rgbd) and other frame bounds must each rebuild it"""
+    from orb_slam2_ros2_amd import ORBMatcher
+    from orb_slam2_ros2_amd._lib import Context
+    w, h, nf = 640, 480, 1000
+    ctx = Context(w, h, n_features=nf, max_images=2)
+    rng = np.random.default_rng(3)
+    tum = dict(fx=520.908620, fy=521.007327, cx=325.141442, cy=249.701764, k1=0.231222, k2=-0.784899, p1=-0.003257, p2=-0.000105, k3=0.917205, bf=40.0)
+    for f in (60, 61):
+        img = synth.mono_image(f, w, h)
+        kps, desc = ctx.extract_slot(1, img)
+        qxy, radius, lo, hi, qd, _ = _queries(kps, desc, rng, 400, th=15.0)
+        ref = orc.search_in_area(kps, desc, w, h, qxy, radius, lo, hi, qd, None)
+        for rep in range(3):                                   # the second and third search use the kept grid
+            got = ORBMatcher.searchInArea(ctx, 1, qxy, radius, lo, hi, qd, None)
+            assert all(np.array_equal(g, r) for g, r in zip(got, ref)), (f, rep)
+        ku, _, _ = ctx.frame_rgbd(1, tum)                      # Camera::undistortPoints in place: the keypoints move
+        assert (ku["x"][:len(kps)] != kps["x"]).sum() > len(kps) // 2
+        ref_u = orc.search_in_area(ku[:len(kps)], desc, w, h, qxy, radius, lo, hi, qd, None)
+        got_u = ORBMatcher.searchInArea(ctx, 1, qxy, radius, lo, hi, qd, None)
+        assert all(np.array_equal(g, r) for g, r in zip(got_u, ref_u)), f
+        assert not all(np.array_equal(g, r) for g, r in zip(got_u, ref))      # ... and the answers with them
+    ctx.close()
