@@ -1230,6 +1230,8 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   }
   ALLOC(c->d_rowoff, NP * (size_t)(c->cfg.height + 1));
   ALLOC(c->d_rowlist, NP * (size_t)c->row_list_cap);
+  c->grid_key.reset(new std::atomic<uint32_t>[M]);  // (here, not on first use: slot calls on other threads clear entries without the API lock)
+  for (size_t k = 0; k < M; ++k) c->grid_key[k] = 0;
   if (M <= 16 && ((size_t)c->cfg.height + 4) * 4 <= 9000) {  // (k_brief's table workgroup borrows 9000 bytes of the descriptor kernel's LDS)
     ALLOC(c->d_rowoff_slot, M * (size_t)(c->cfg.height + 1));
     ALLOC(c->d_rowlist_slot, M * (size_t)c->row_list_cap);
@@ -2841,10 +2843,6 @@ static bool area_grid(const orbfe_ctx* c, const float* bounds, AreaGrid* g) {
 // the grid of `slot` for the geometry ag on stream st: the one kept from the last search if the slot's keypoints are still the same
 static orbfe_status slot_grid(orbfe_ctx* c, hipStream_t st, int slot, const AreaGrid& ag, const int32_t** d_off, const int32_t** d_feat) {
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1), M = (size_t)c->cfg.max_images, ncells = (size_t)ag.rows * ag.cols;
-  if (!c->grid_key) {
-    c->grid_key.reset(new std::atomic<uint32_t>[M]);
-    for (size_t k = 0; k < M; ++k) c->grid_key[k] = 0;
-  }
   if (ncells + 1 > c->grid_cells) {  // first use, or a larger grid than any before: (re)allocate, nothing cached survives
     HIP_TRY(c, hipStreamSynchronize(st));
     if (c->d_grid_off) (void)hipFree(c->d_grid_off);
