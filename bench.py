@@ -40,11 +40,14 @@ sys.path.insert(0, ROOT)
 W, H, NFEAT, NLEVELS, SCALE, TH_HI, TH_LO = 1241, 376, 2000, 8, 1.2, 20, 7
 FX, BF = 718.856, 718.856 * 0.537166  # config/kitti_config_00.yaml: Camera.fx, Camera.bl
 HBM_PEAK_GBPS = 8000.0
+PCIE_PEAK_GBPS = 63.0   # PCIe 5.0 x16, one direction (MI355X_MICROARCH.md)
 
 
 def algorithmic_bytes(ctx, n_cand_per_image):
-    """algorithmic bytes per image for each kernel, and per stereo pair in total.  The quadtree has no
-    entry in 8(d) (it only touches the candidate records): 4 B per candidate read + 4 B per selected keypoint written."""
+    """algorithmic bytes per image for each kernel, and per stereo pair in total (20 012 776 B for the KITTI shape at
+    2000 features -- 8(d)'s own figure, which has no quadtree entry).  The quadtree only touches the candidate records: 4 B per
+    candidate read + 4 B per selected keypoint written; that term prices the quadtree STAGE (returned separately) and is NOT part of
+    the per-pair total."""
     P = sum(ctx.level_info(l).width * ctx.level_info(l).height for l in range(NLEVELS))
     S0 = W * H
     K = NFEAT
@@ -52,11 +55,11 @@ def algorithmic_bytes(ctx, n_cand_per_image):
         "resize": S0 + (P - S0),            # read level 0, write levels 1..7
         "blur": 2 * P,                      # read + write every plane
         "fast": P,                          # read every plane (+ candidate records, not counted)
-        "quadtree": 4 * n_cand_per_image + 4 * K,
         "orient_brief": K * (749 + 512) + K * 60,
     }
     per_pair_match = 2 * K * 32 + 2 * K * 28 + K * 12 * 121 + K * 16
     per_pair = 2 * sum(per_image.values()) + per_pair_match
+    per_image["quadtree"] = 4 * n_cand_per_image + 4 * K   # stage pricing only (after the total)
     return per_image, per_pair_match, per_pair
 
 
@@ -752,6 +755,79 @@ def latency_leg(device_id, n=500):
     return out
 
 
+def content_sweep(ctx, B, dev, rect_hosts, steps):
+    """The same step on every content class of synth.CONTENT_CLASSES: the reference's input contract is a camera
+    image (example/Stereo/KittiStereo.cc:28-33) and the cost of the path depends on the content -- cells that repeat cv::FAST at the
+    low threshold (ORBExtractor.cc:365-367), candidates the quadtree spreads, right keypoints per row band.  Per class: 16 distinct
+    pairs tiled to B (as the headline batch), device-resident; stage times with every kernel ALONE (HIP events), then `steps` steps of
+    the production schedule; EVERY pair of the last batch checked against the committed oracle digests (golden_v1 bench_pairs for
+    "rect", golden_v4 for the rest, tools/make_golden_v4.py) before a number is reported."""
+    import torch
+
+    from orb_slam2_ros2_amd import synth
+    from orb_slam2_ros2_amd.digest import batch_digests
+    g1 = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v1.json")))["bench_pairs"]
+    g4 = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v4.json")))["classes"]
+    U = min(B, 16)
+    out = {}
+    for cls in synth.CONTENT_CLASSES:
+        if cls == "rect":
+            left_h, right_h = rect_hosts
+            gold = g1
+        else:
+            fr = [synth.stereo_pair_content(f, cls, W, H) for f in range(U)]
+            reps = (B + U - 1) // U
+            left_h = np.stack(([a for a, _ in fr] * reps)[:B])
+            right_h = np.stack(([b for _, b in fr] * reps)[:B])
+            gold = g4[cls]["pairs"]
+        dl, dr = torch.from_numpy(left_h).to(dev), torch.from_numpy(right_h).to(dev)
+
+        def step():
+            ctx.stereo_batch_device(dl.data_ptr(), dr.data_ptr(), W, W * H, B, FX, BF)
+        for _ in range(5):
+            step()
+        ctx.sync()
+        ctx.profile_enable(1)
+        ctx.profile_read()
+        for _ in range(5):
+            step()
+        ctx.sync()
+        alone = {k: ms / n for k, (ms, n) in ctx.profile_read().items() if n}
+        ctx.profile_enable(0)
+        for _ in range(3):
+            step()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        ctx.sync()
+        ms_step = (time.perf_counter() - t0) / steps * 1e3
+        kps, desc, cnt = ctx.fetch_batch(0, 2 * B)
+        ru, dp, nm = ctx.fetch_stereo_batch(0, B)
+        dig = batch_digests(kps, desc, cnt, ru, dp, nm)
+        bad = [p_ for p_ in range(B) if dig[p_] != gold[str(p_ % U)]]
+        if bad:
+            raise SystemExit(f"bench.py: content sweep: class {cls}: {len(bad)} of {B} pairs differ from the golden digests (first: pair {bad[0]})")
+        lo = cells = n_cand = 0
+        for l in range(NLEVELS):
+            c = ctx.debug_candidates(0, l)
+            li = ctx.level_info(l)
+            a, b = synth.lo_pass_cells(c, li.width - 32, li.height - 32, TH_HI)
+            lo, cells, n_cand = lo + a, cells + b, n_cand + len(c)
+        out[cls] = {"ms_per_step": ms_step, "pairs_per_s": B / ms_step * 1e3, "fast_ms": alone.get("fast"), "quadtree_ms": alone.get("quadtree"),
+                    "stereo_ms": alone.get("stereo"), "resize_ms": alone.get("resize"), "blur_ms": alone.get("blur"),
+                    "orient_brief_ms": alone.get("orient_brief"), "frac_cells_lo_pass": lo / max(cells, 1), "candidates_per_image": n_cand,
+                    "keypoints_per_image": float(cnt.mean()), "matches_per_pair": float(nm.mean()), "verified_pairs": B, "steps": steps}
+        del dl, dr, kps, desc, ru, dp
+        torch.cuda.empty_cache()
+    ms = [v["ms_per_step"] for v in out.values()]
+    out["worst_over_best"] = max(ms) / min(ms)
+    out["what"] = ("the headline step (512 pairs resident in HBM, production schedule) per synthetic content class, every pair verified against the "
+                   "oracle's digests; *_ms: the stage's kernels ALONE (HIP events, untimed pass); frac_cells_lo_pass / candidates_per_image: the left "
+                   "image of frame 0 (cells without a corner at 20 repeat cv::FAST at 7); 'rect' is the class `value` is quoted on")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -775,6 +851,9 @@ def main():
                          "page-locked POSIX shared-memory segment over its own PCIe link, the collective carries 16 B per frame; 'gather' = "
                          "the records are gathered on rank 0 over the collective and drained over rank 0's link")
     ap.add_argument("--sequence-window", type=int, default=1, help="batches per gather window of the sequence job (sharding.WindowGather)")
+    ap.add_argument("--content-steps", type=int, default=40,
+                    help="timed steps per content class of the content sweep (config.content_sweep: rect / camera / saturated / sparse, every "
+                         "pair verified against the golden digests); 0 skips it")
     ap.add_argument("--legs", default="cfg3,ba,latency", help="comma-separated extra legs of the default line (north_star beyond the stereo step): "
                     "cfg3 (2000x2000 Hamming), ba (config-5 edge evaluation / normal equations / local BA / pose-only), latency (one pair, host "
                     "to host, in the reference's call shape); '' skips them")
@@ -1003,6 +1082,10 @@ def main():
                            (("RCCL" if collective else "none: single rank, no process group") if backend == "nccl" else backend) +
                            ", all inside the timed region; `python bench.py --sequence 4541` runs the same job as the whole line"}
 
+    sweep = None
+    if rank == 0 and world == 1 and args.content_steps > 0:
+        sweep = content_sweep(ctx, B, dev, (left_h, right_h), args.content_steps)
+
     live_ms, live_n = live[dom]
     stages_inline = dict(stages)
     if live_n:
@@ -1030,13 +1113,23 @@ def main():
         "sequence": seq_leg,
         "config": {
             "workload": "Single 1241x376 KITTI-shaped stereo pair, 8-level pyramid, 2000 FAST+rBRIEF keypoints per image, "
-                        "searchByStereo; batched",
+                        "searchByStereo; batched (512 pairs per step).  `value` is DEVICE-RESIDENT: the images are in HBM when the clock starts "
+                        "and the results stay there; the rate of SURVEY 8(d)'s protocol -- page-locked host images in, full results back in host "
+                        "memory, PCIe both ways inside the clock -- is config.host_io_pairs_per_s, the whole-sequence job (BASELINE config 4, "
+                        "host images in, per-frame records out) config.sequence_pairs_per_s",
             "io": "device-resident",   # images are in HBM when the clock starts, results stay there (see host_io for the PCIe-inclusive rate)
+            "host_io_pairs_per_s": host_io["pairs_per_s"] if host_io else None,
+            "h2d_GBps": host_io["h2d_GBps"] if host_io else None,
+            "d2h_GBps": host_io["d2h_GBps"] if host_io else None,
+            "pcie_frac": (host_io["h2d_GBps"] / PCIE_PEAK_GBPS) if host_io else None,   # upload direction, per GPU, of 63 GB/s (PCIe 5.0 x16)
+            "sequence_pairs_per_s": seq_leg["pairs_per_s"] if seq_leg else None,
+            "content_sweep": sweep,
             "pairs_per_step_per_gpu": B,
             "n_features": NFEAT,
             "levels": NLEVELS,
             "parallelism": f"frames sharded over {world} GPU(s), RCCL gather of per-pair results at sequence end",
-            "algorithmic_bytes_per_pair": pair_bytes,
+            "algorithmic_bytes_per_pair": pair_bytes,          # 20 012 776 for this shape (no quadtree term)
+            "quadtree_record_bytes_per_pair": 2 * per_image_bytes["quadtree"],   # candidate records read + selections written (prices the stage only)
             "pipeline_hbm_GBps": pair_bytes * fps / world / 1e9,
             "pipeline_hbm_frac": pair_bytes * fps / world / 1e9 / HBM_PEAK_GBPS,
             "stage_ms_per_launch": {k: round(v, 4) for k, v in stages_inline.items()},

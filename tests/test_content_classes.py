@@ -1,0 +1,140 @@
+"""The content classes of synth.stereo_pair_content: CPU -- the generator and the oracle against
+tests/golden/golden_v4.json (tools/make_golden_v4.py); GPU -- the HIP path against the oracle on every class, arrays and digests,
+through the single-frame calls and through the batched call bench.py's content sweep times.
+
+What the classes are for (ORBExtractor.cc:346-375): "camera" sends more than a third of the cells through the second cv::FAST call at
+the low threshold, "saturated" hands the quadtree several times the candidates of the class the headline is quoted on, "sparse"
+leaves the fine levels below their quota (quirk Q3: they return nothing)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from orb_slam2_ros2_amd import synth
+from orb_slam2_ros2_amd.digest import batch_digests, pair_digest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G4 = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v4.json")))["classes"]
+FX, BF = 718.856, 718.856 * 0.537166
+CLASSES = [c for c in synth.CONTENT_CLASSES if c != "rect"]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_rect_class_is_the_headline_generator():
+    a, b = synth.stereo_pair_content(3, "rect", 320, 200), synth.stereo_pair(3, 320, 200)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    with pytest.raises(ValueError):
+        synth.stereo_pair_content(0, "fog")
+
+
+@pytest.mark.parametrize("cls", CLASSES)
+def test_oracle_on_content_class_matches_golden_v4(orc, cls):
+    g = G4[cls]["frames"]["0"]
+    L, R = synth.stereo_pair_content(0, cls)
+    assert L.dtype == np.uint8 and L.shape == (376, 1241) and sha(L) == g["left_sha"] and sha(R) == g["right_sha"]
+    r = orc.stereo_frame(L, R, fx=FX, bf=BF, math_mode=0, threads=2)
+    assert (len(r["lk"]), len(r["rk"]), int(r["n_matches"])) == (g["n_left"], g["n_right"], g["n_matches"])
+    assert pair_digest(r["lk"], r["ld"], r["rk"], r["rd"], r["right_u"], r["depth"], r["n_matches"]) == G4[cls]["pairs"]["0"]
+    ex = orc.extractor(L)
+    k, _ = ex.extract()
+    lo = cells = 0
+    for l in range(8):
+        c = ex.candidates(l)
+        assert len(c) == g["candidates_per_level"][l]
+        wl, hl = ex.level_info(l)[:2]
+        a, b = synth.lo_pass_cells(c, wl - 32, hl - 32)
+        lo, cells = lo + a, cells + b
+    assert [int((k["octave"] == l).sum()) for l in range(8)] == g["selected_per_level"]
+    assert (lo, cells) == (g["cells_lo_pass"], g["cells"])
+
+
+def test_the_classes_span_what_they_are_meant_to():
+    """the properties the classes exist for, from the committed oracle statistics (frames 0 and 1)"""
+    for f in ("0", "1"):
+        cam, sat, spa = (G4[c]["frames"][f] for c in ("camera", "saturated", "sparse"))
+        assert cam["cells_lo_pass"] > 0.3 * cam["cells"] and cam["n_left"] == 2000        # a third of the cells repeat at 7, still 2000 features
+        assert sat["cells_lo_pass"] == 0 and sum(sat["candidates_per_level"]) > 35000     # corners everywhere, ~19 x the quota
+        assert min(sat["candidates_per_level"][l] for l in range(8)) > 1000
+        assert sum(1 for n in spa["selected_per_level"] if n == 0) >= 3 and spa["n_left"] > 0   # Q3 on several levels, not on all
+
+
+def test_lo_pass_cells_against_a_direct_count(orc):
+    """the host-side statistic against its definition: a cell takes the low pass iff cv::FAST at the high threshold finds nothing in it"""
+    L, _ = synth.stereo_pair_content(1, "camera")
+    ex = orc.extractor(L)
+    ex.extract()
+    for l in (0, 5):
+        plane = ex.plane(l)
+        wl, hl = ex.level_info(l)[:2]
+        w, h = wl - 32, hl - 32
+        n_cols, n_rows = w // 30, h // 30
+        wc, hc = w // n_cols, h // n_rows
+        lo = cells = 0
+        for i in range(n_rows):
+            y0 = 16 + i * hc
+            y1 = min(y0 + hc + 6, 16 + h)
+            if y0 >= 16 + h - 6:
+                continue
+            for j in range(n_cols):
+                x0 = 16 + j * wc
+                x1 = min(x0 + wc + 6, 16 + w)
+                if x0 >= 16 + w - 6:
+                    continue
+                cells += 1
+                lo += len(orc.fast(np.ascontiguousarray(plane[y0:y1, x0:x1]), 20, True)) == 0
+        assert synth.lo_pass_cells(ex.candidates(l), w, h) == (lo, cells)
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls", CLASSES)
+def test_gpu_single_frames_of_content_class_equal_the_oracle(orc, cls):
+    from orb_slam2_ros2_amd._lib import Context
+    ctx = Context(1241, 376, max_images=2)
+    for f in (0, 1, 2):
+        L, R = synth.stereo_pair_content(f, cls)
+        ref = orc.stereo_frame(L, R, fx=FX, bf=BF)
+        (lk, ld), (rk, rd) = ctx.extract_batch([L, R])
+        nm, ru, dp, _, _ = ctx.stereo_match(0, 1, FX, BF)
+        n = len(lk)
+        assert np.array_equal(lk, ref["lk"]) and np.array_equal(ld, ref["ld"]), f"{cls} frame {f}: left features"
+        assert np.array_equal(rk, ref["rk"]) and np.array_equal(rd, ref["rd"]), f"{cls} frame {f}: right features"
+        assert nm == ref["n_matches"] and np.array_equal(ru[:n].view(np.int64), ref["right_u"].view(np.int64)), f"{cls} frame {f}: right_u"
+        assert np.array_equal(dp[:n].view(np.int64), ref["depth"].view(np.int64)), f"{cls} frame {f}: depth"
+        assert pair_digest(lk, ld, rk, rd, ru, dp, nm) == G4[cls]["pairs"][str(f)]
+        if f == 0:   # the candidate SETS per level (the quadtree's input), and the one-call frame
+            ex = orc.extractor(L)
+            ex.extract()
+            for l in range(8):
+                assert np.array_equal(ctx.debug_candidates(0, l), ex.candidates(l)), f"{cls}: level {l} candidates"
+            (flk, fld), (frk, frd), fnm, fru, fdp = ctx.frame_stereo(L, R, FX, BF)
+            assert pair_digest(flk, fld, frk, frd, fru, fdp, fnm) == G4[cls]["pairs"]["0"]
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls", CLASSES)
+def test_gpu_batch_of_content_class_equals_the_golden_digests(cls):
+    """the batched device-resident call at a size whose launches run the cell loop of k_fast and the global-record quadtree (what the
+    content sweep of bench.py times): 16 distinct frames x 16"""
+    import torch
+    from orb_slam2_ros2_amd._lib import Context
+    B, U = 256, 16
+    fr = [synth.stereo_pair_content(f, cls) for f in range(U)]
+    ctx = Context(1241, 376, max_images=2 * B)
+    dl = torch.from_numpy(np.stack([fr[i % U][0] for i in range(B)])).cuda()
+    dr = torch.from_numpy(np.stack([fr[i % U][1] for i in range(B)])).cuda()
+    for _ in range(2):
+        ctx.stereo_batch_device(dl.data_ptr(), dr.data_ptr(), 1241, 1241 * 376, B, FX, BF)
+    ctx.sync()
+    kps, desc, cnt = ctx.fetch_batch(0, 2 * B)
+    ru, dp, nm = ctx.fetch_stereo_batch(0, B)
+    dig = batch_digests(kps, desc, cnt, ru, dp, nm)
+    bad = [p for p in range(B) if dig[p] != G4[cls]["pairs"][str(p % U)]]
+    assert not bad, f"{cls}: pairs {bad[:8]} differ from golden_v4"
+    ctx.close()
