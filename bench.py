@@ -31,8 +31,10 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the first HIP call: one hardware queue per stream of the streaming legs
-                                                    # (= orbfe_recommended_hw_queues(); the library only warns, it cannot set it)
+if "--only-leg" not in sys.argv:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the first HIP call: one hardware queue per stream of the streaming legs
+                                                        # (= orbfe_recommended_hw_queues(); the library only warns, it cannot set it).  The
+                                                        # one-frame latency leg runs in a child WITHOUT it (--only-leg): what a drop-in user has
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -559,6 +561,7 @@ def latency_leg(device_id, n=500):
         ctx.extract_batch([L, R])
         ctx.stereo_match(0, 1, FX, BF)
     out = {"pair": "synthetic KITTI-shaped frame 0, 1241x376, 2000 features per image", "verified": True,
+           "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "unset (runtime default: what a drop-in user has)"),
            "extract_batch_plus_match": dict(_stats_ms(one, n, warm=30), what="orbfe_extract_batch([L, R]) + orbfe_stereo_match, host to host, from Python")}
     # Frame::createStereo's device work (Frame.h:313-323: two extractions, then searchByStereo) as ONE call: the same kernels in one
     # launch sequence, one synchronisation
@@ -728,9 +731,10 @@ def latency_leg(device_id, n=500):
                                "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
         L.tofile(os.path.join(tmp, "L.raw"))
         R.tofile(os.path.join(tmp, "R.raw"))
-        # (the child gets the HIP runtime's default of 4 hardware queues, as a process that uses the C++ mirror has -- this bench raised
-        #  it to 16 for its own streams, which costs the one-frame-at-a-time path ~50 us: DESIGN 4.9 (h))
-        env = dict(os.environ, GPU_MAX_HW_QUEUES=os.environ.get("ORBFE_LATENCY_HW_QUEUES", "4"))
+        # (the C++ child gets the same setting as this leg: the runtime's default unless ORBFE_LATENCY_HW_QUEUES asks for a value)
+        env = dict(os.environ)
+        if os.environ.get("ORBFE_LATENCY_HW_QUEUES"):
+            env["GPU_MAX_HW_QUEUES"] = os.environ["ORBFE_LATENCY_HW_QUEUES"]
         r = subprocess.run([exe, "latency", os.path.join(tmp, "L.raw"), os.path.join(tmp, "R.raw"), str(W), str(H), str(n)],
                            capture_output=True, text=True, timeout=300, env=env)
         f = r.stdout.split()
@@ -749,7 +753,7 @@ def latency_leg(device_id, n=500):
                 "what": "the same Frame built by orbfe::dropin::createStereo (ORBExtractor::extractStereo -> orbfe_frame_stereo_slots): both "
                         "extractions and the stereo match as one device call in place of the two threads and searchByStereo; every frame "
                         "hashed equal to the two-thread one"}
-        out["cpp_hw_queues"] = int(env["GPU_MAX_HW_QUEUES"])
+        out["cpp_hw_queues"] = env.get("GPU_MAX_HW_QUEUES", "unset (runtime default)")
     except (subprocess.CalledProcessError, RuntimeError, OSError) as ex:
         out["two_threads_extract_slot_plus_match"] = {"error": f"{type(ex).__name__}: {ex}"}
     return out
@@ -851,6 +855,10 @@ def main():
                          "page-locked POSIX shared-memory segment over its own PCIe link, the collective carries 16 B per frame; 'gather' = "
                          "the records are gathered on rank 0 over the collective and drained over rank 0's link")
     ap.add_argument("--sequence-window", type=int, default=1, help="batches per gather window of the sequence job (sharding.WindowGather)")
+    ap.add_argument("--only-leg", default="", help="(internal) run ONE extra leg (cfg3 | ba | latency) in this process and print its JSON object: "
+                    "the default line runs the latency leg this way, in a child started WITHOUT GPU_MAX_HW_QUEUES -- the streaming legs of the "
+                    "parent want 16 hardware queues, a caller that processes one frame at a time has the runtime's default, ~50 us per frame "
+                    "faster (ADVICE r4)")
     ap.add_argument("--content-steps", type=int, default=40,
                     help="timed steps per content class of the content sweep (config.content_sweep: rect / camera / saturated / sparse, every "
                          "pair verified against the golden digests); 0 skips it")
@@ -858,6 +866,12 @@ def main():
                     "cfg3 (2000x2000 Hamming), ba (config-5 edge evaluation / normal equations / local BA / pose-only), latency (one pair, host "
                     "to host, in the reference's call shape); '' skips them")
     args = ap.parse_args()
+
+    if args.only_leg:
+        dev_id = int(os.environ.get("LOCAL_RANK", "0"))
+        leg = {"cfg3": cfg3_leg, "ba": ba_leg, "latency": latency_leg}[args.only_leg](dev_id)
+        print(json.dumps(leg))
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) as CHILD processes -- before anything in this process
@@ -1264,7 +1278,15 @@ def main():
         if "ba" in legs:
             line["ba"] = ba_leg(local_rank)
         if "latency" in legs:
-            line["latency"] = latency_leg(local_rank)
+            # in a child process started without GPU_MAX_HW_QUEUES: the setting a one-frame-at-a-time caller has (recorded in the leg)
+            import subprocess
+            env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+            env["LOCAL_RANK"] = str(local_rank)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--only-leg", "latency"], env=env, capture_output=True, text=True, timeout=900)
+            try:
+                line["latency"] = json.loads(r.stdout.strip().split("\n")[-1])
+            except Exception:   # noqa: BLE001
+                raise SystemExit("bench.py: latency leg (child process) failed:\n" + r.stdout[-2000:] + r.stderr[-4000:])
         line["legs_seconds"] = time.perf_counter() - t_legs
     if rank == 0:
         emit(line)

@@ -208,10 +208,19 @@ __global__ __launch_bounds__(192) void k_lmb_step(int k, int KT, int ld, double*
                                                   int32_t* __restrict__ flags) {
   __shared__ LmbShared sh;
   if (!lmb_gate(st)) return;
-  if (*(volatile int32_t*)&flags[KT] != 0) return;  // an earlier column hit a bad pivot
+  // an earlier column of THIS factorisation hit a bad pivot.  (Not looked at by the first launch, k = -1: there is no earlier column, and
+  // the flag may still be up from the PREVIOUS factorisation -- it is cleared below, in stream order, by the one workgroup that may raise
+  // it again in this launch.)
+  if (k >= 0 && *(volatile int32_t*)&flags[KT] != 0) return;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  if (k < 0 && blockIdx.x == 0)  // the back substitution's column flags of the PREVIOUS factorisation (k_lmb_back_mw polls them: it cannot reset them itself)
+  if (k < 0 && blockIdx.x == 0) {
+    // the state of the PREVIOUS factorisation, cleared here and nowhere else: the back substitution's column flags (k_lmb_back_mw polls
+    // them) and the bad-pivot flag (k_lmb_back_mw's workgroups read it at their start; one of them clearing it for the others was a
+    // window for a late workgroup to take the normal path and wait for columns that never publish -- ADVICE r4).  Workgroup 0 is also
+    // the owner of column 0's diagonal tile, the only one that can raise the flag in this launch: same thread, program order.
     for (int q = t; q < KT; q += 192) flags[KT + 1 + q] = 0;
+    if (t == 0) flags[KT] = 0;
+  }
   // blockIdx.x -> (i, j): column-major over the trailing tiles, column k + 1 first
   const int m = KT - 1 - k;  // tile columns left; tile rows k + 1 .. KT (KT: the right-hand-side row)
   int jq = 0, base = 0;
@@ -419,8 +428,7 @@ __global__ __launch_bounds__(192) void k_lmb_back_mw(int n, int KT, int ld, cons
   if (*(volatile int32_t*)&flags[KT] != 0) {  // a bad pivot: x = 0 (every workgroup its own rows; nobody waits)
     for (int c = t; c < LMB_T; c += 192)
       if (j * LMB_T + c < n) x[j * LMB_T + c] = 0.0;
-    if (j == 0 && t == 0) flags[KT] = 0;  // (read at kernel starts only: the next reader is the next factorisation)
-    return;
+    return;  // (the flag stays up until the next factorisation's first launch clears it: every workgroup of THIS launch must see it)
   }
   const int c = t % LMB_T, pr = t / LMB_T;  // column of the tile, row part (12 rows each)
   if (t < LMB_T) yj[t] = M[(size_t)ld * ld + (size_t)j * LMB_T + t];

@@ -263,11 +263,14 @@ struct orbfe_ctx {
   uint16_t* d_rowlist_slot = nullptr;
   std::unique_ptr<std::atomic<uint8_t>[]> slot_table_ok, pair_count_zero;
   // The frame grid of a slot (VirtualFrame::initGrid) is kept from one guided search to the next: Tracking searches the same frame two to
-  // four times.  grid_key[s] = rows << 16 | cols of the grid held for slot s's current keypoints, 0: none (a new extraction into the slot
-  // or an in-place undistortion clears it).  Allocated on first use, grid_cells entries per slot.
+  // four times.  grid_key[s] = generation << 32 | (rows << 16 | cols) of the grid held for slot s's current keypoints, low half 0: none.
+  // A new extraction into the slot or an in-place undistortion bumps the generation and clears the key in ONE atomic step
+  // (grid_invalidate) -- slot calls do that without the API lock -- and a search publishes the grid it built only by compare-exchange
+  // from the state it saw before building: a slot rewritten in between leaves no stale grid marked valid.  Allocated on
+  // first use, grid_cells entries per slot.
   int32_t *d_grid_off = nullptr, *d_grid_feat = nullptr;
   size_t grid_cells = 0;
-  std::unique_ptr<std::atomic<uint32_t>[]> grid_key;
+  std::unique_ptr<std::atomic<uint64_t>[]> grid_key;
   double *d_right_u = nullptr, *d_depth = nullptr;
   int32_t *d_n_match = nullptr, *d_best_right = nullptr, *d_best_dist = nullptr;
   // generic staging for match / BA calls
@@ -880,9 +883,15 @@ struct ExtLevel0 {
   hipEvent_t inputs_free;       // nullable: recorded once the resize (which also writes level 0 of the pyramid) is done with the caller's images
 };
 // slots [s0, s0 + n) have just been (or are about to be) rewritten by an extraction; small: one that also built their row tables
+static void grid_invalidate(orbfe_ctx* c, int slot) {
+  if (!c->grid_key) return;
+  std::atomic<uint64_t>& a = c->grid_key[(size_t)slot];
+  uint64_t v = a.load();
+  while (!a.compare_exchange_weak(v, ((v >> 32) + 1) << 32)) {
+  }
+}
 static void note_slots_written(orbfe_ctx* c, int s0, int n, bool small) {
-  if (c->grid_key)
-    for (int s = s0; s < s0 + n && s < c->cfg.max_images; ++s) c->grid_key[(size_t)s] = 0;
+  for (int s = s0; s < s0 + n && s < c->cfg.max_images; ++s) grid_invalidate(c, s);
   if (!c->slot_table_ok) return;
   for (int s = s0; s < s0 + n && s < c->cfg.max_images; ++s) {
     c->slot_table_ok[(size_t)s] = small ? 1 : 0;
@@ -1230,7 +1239,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   }
   ALLOC(c->d_rowoff, NP * (size_t)(c->cfg.height + 1));
   ALLOC(c->d_rowlist, NP * (size_t)c->row_list_cap);
-  c->grid_key.reset(new std::atomic<uint32_t>[M]);  // (here, not on first use: slot calls on other threads clear entries without the API lock)
+  c->grid_key.reset(new std::atomic<uint64_t>[M]);  // (here, not on first use: slot calls on other threads clear entries without the API lock)
   for (size_t k = 0; k < M; ++k) c->grid_key[k] = 0;
   if (M <= 16 && ((size_t)c->cfg.height + 4) * 4 <= 9000) {  // (k_brief's table workgroup borrows 9000 bytes of the descriptor kernel's LDS)
     ALLOC(c->d_rowoff_slot, M * (size_t)(c->cfg.height + 1));
@@ -1768,7 +1777,7 @@ orbfe_status orbfe_frame_rgbd(orbfe_ctx* c, int32_t slot, const orbfe_camera* ca
   TRY(ensure_stage(c, h_total));
   uint8_t* hs = c->main.h_stage;
   if (depth) std::memcpy(hs, depth, d_bytes);
-  if (c->grid_key) c->grid_key[(size_t)slot] = 0;  // (the keypoints move: a grid kept for the slot is stale)
+  grid_invalidate(c, slot);  // (the keypoints move: a grid kept for the slot is stale)
   launch_frame_rgbd(c->stream, c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, (int)NF, *cam, depth ? hs : nullptr, depth_type, depth_stride,
                     depth_scale, (double*)(hs + h_res), (double*)(hs + h_ru), kps_out ? (orbfe_keypoint*)(hs + h_k) : nullptr);
   HIP_TRY(c, hipGetLastError());
@@ -2850,14 +2859,17 @@ static orbfe_status slot_grid(orbfe_ctx* c, hipStream_t st, int slot, const Area
     c->d_grid_off = nullptr;
     HIP_TRY(c, hipMalloc((void**)&c->d_grid_off, M * (ncells + 1) * sizeof(int32_t)));
     c->grid_cells = ncells + 1;
-    for (size_t k = 0; k < M; ++k) c->grid_key[k] = 0;
+    for (size_t k = 0; k < M; ++k) grid_invalidate(c, (int)k);
   }
   int32_t* off = c->d_grid_off + (size_t)slot * c->grid_cells;
   int32_t* feat = c->d_grid_feat + (size_t)slot * NF;
   const uint32_t key = ((uint32_t)ag.rows << 16) | (uint32_t)ag.cols;
-  if (c->grid_key[(size_t)slot] != key) {
+  uint64_t seen = c->grid_key[(size_t)slot].load();
+  if ((uint32_t)seen != key) {
     launch_grid_build(st, c->d_kps + (size_t)slot * NF, c->d_n_kp + slot, (int)NF, ag.rows, ag.cols, off, feat);
-    c->grid_key[(size_t)slot] = key;
+    // kept for the next search only if no extraction touched the slot since `seen` (its generation is part of the compared value); on
+    // failure nothing is cached: this call still uses what it built, the next one builds again
+    (void)c->grid_key[(size_t)slot].compare_exchange_strong(seen, (seen & 0xFFFFFFFF00000000ull) | key);
   }
   *d_off = off, *d_feat = feat;
   return ORBFE_OK;

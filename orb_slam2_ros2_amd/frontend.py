@@ -17,18 +17,28 @@ from ._lib import Context, ImageSizeError, OrbfeError  # noqa: F401
 
 
 def load_brief_template(path: str) -> np.ndarray:
-    """Parse a BRIEF template file exactly as ORBExtractor::initBriefTemplate does (ORBExtractor.cc:242-267):
-    skip the header line, then `x1 y1 x2 y2` per line.  Raises FileNotFoundError like FileNotOpenError."""
+    """Parse a BRIEF template file exactly as ORBExtractor::initBriefTemplate does (ORBExtractor.cc:242-267): skip the header line, then
+    EVERY line is a pair `x1 y1 x2 y2` read with operator>> -- a value that does not parse, and every value after it, stays 0 (a blank
+    line is the pair (0,0)-(0,0)); no count is checked there.  computeBRIEF (:426-456) walks the whole list but only the first 32 bytes
+    = 256 pairs reach the descriptor (:405-406), so a longer file behaves like its first 256 lines; a shorter one makes the reference
+    read past the end of a vector (undefined behaviour) and is refused here.  Raises FileNotFoundError like FileNotOpenError."""
     rows = []
     with open(path, "r") as f:
-        lines = f.read().split("\n")
+        text = f.read()
+    lines = text.split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()                       # std::getline yields no extra line after a final newline
     for ln in lines[1:]:
-        toks = ln.split()
-        if len(toks) >= 4:
-            rows.append([int(float(t)) for t in toks[:4]])
-    if len(rows) != 256:
-        raise ValueError(f"{path}: expected 256 BRIEF pairs, found {len(rows)}")
-    return np.asarray(rows, np.int8)
+        vals = [0.0, 0.0, 0.0, 0.0]
+        for k, tok in enumerate(ln.split()[:4]):
+            try:
+                vals[k] = float(tok)
+            except ValueError:
+                break                     # the stream is in a failed state: the remaining values keep their zeros
+        rows.append([int(v) for v in vals])
+    if len(rows) < 256:
+        raise ValueError(f"{path}: {len(rows)} BRIEF pairs; the descriptor needs 256 (the reference would index past its template)")
+    return np.asarray(rows[:256], np.int8)
 
 
 from .matcher_ext import MatcherExt  # searchBySim3 x2, processFuseMps, the epipolar half of searchForTriangulation

@@ -1088,10 +1088,11 @@ static void OptimizeLocalMap(KeyFramePtr pkframe, bool& isStop) {
     }
     // OptimizePoseOnly's tail (src/Optimizer.cc:180-203), as in trackLocalMap above
     int nBad = nEdges - good;
+    // (every entry that is not an inlier is cleared -- also a bad point that never became an edge: `if (!inLier[idx])
+    //  mvpMapPoints[idx] = nullptr` runs over the whole vector, :190-199 -- exactly as in trackLocalMap above)
     for (size_t f = 0; f < N && f < NF; ++f) {
       auto cur = pCurr->getMapPoint(f);
-      if (!cur || cur->isBad()) continue;
-      bool keep = inl[f] != 0;
+      bool keep = inl[f] != 0 && cur && !cur->isBad();
       if (keep) {
         bool isPositive = false;
         auto uv = pCurr->project2UV(cur->getPos(), isPositive);

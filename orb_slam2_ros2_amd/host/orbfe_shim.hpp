@@ -26,6 +26,9 @@
 #include <tuple>
 #include <vector>
 
+#include <exception>
+#include <thread>
+
 #include "../../include/orbfe.h"
 #include "map_pb.hpp"
 
@@ -53,7 +56,11 @@ inline void check(orbfe_ctx* ctx, orbfe_status st) {
   throw std::runtime_error(msg);
 }
 
-// Parses config/brief_template.txt exactly like ORBExtractor::initBriefTemplate (src/ORBExtractor.cc:242-267).
+// Parses config/brief_template.txt exactly like ORBExtractor::initBriefTemplate (src/ORBExtractor.cc:242-267): the header line is
+// skipped, EVERY further line is a pair read with operator>> (a value that does not parse, and all after it, stay 0: a blank line is the
+// pair (0,0)-(0,0)), no count is checked.  Only the first 256 pairs reach the 32-byte descriptor (computeBRIEF, :405-406, :426-456), so a
+// longer file behaves like its first 256 lines; a shorter one makes the reference index past its template (undefined behaviour) and is
+// refused here.
 inline std::vector<int8_t> loadBriefTemplate(const std::string& path) {
   std::ifstream ifs(path);
   if (!ifs.is_open()) throw FileNotOpenError("BRIEF template file cannot be opened: " + path);
@@ -66,11 +73,12 @@ inline std::vector<int8_t> loadBriefTemplate(const std::string& path) {
       continue;
     }
     std::istringstream iss(line);
-    float v[4];
-    if (!(iss >> v[0] >> v[1] >> v[2] >> v[3])) continue;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    iss >> v[0] >> v[1] >> v[2] >> v[3];
     for (float f : v) out.push_back((int8_t)f);
   }
-  if (out.size() != 1024) throw std::runtime_error("BRIEF template must hold 256 pairs: " + path);
+  if (out.size() < 1024) throw std::runtime_error("BRIEF template holds fewer than the 256 pairs a descriptor needs: " + path);
+  out.resize(1024);
   return out;
 }
 
@@ -186,15 +194,46 @@ class ORBExtractor {
   }
 
   // ORBExtractor::extract (src/ORBExtractor.cc:499-508).  Thread-safe against extract() of OTHER objects (Frame.cc:100-105).
+  //
+  // Errors.  The reference runs this member on a bare std::thread (`std::thread leftThread(std::bind(&ORBExtractor::extract, ...))`,
+  // src/Frame.cc:100-105): an exception that leaves it there is std::terminate.  The reference's extract() cannot fail; this one can (a
+  // device error), so on a thread OTHER than the one that constructed the object the failure is CAPTURED -- the call returns with no
+  // keypoints -- and rethrown by the next call anybody makes on this object from another thread: rethrowPending(), called by
+  // ORBMatcher::searchByStereo (the very next statement of Frame::createStereo, Frame.h:319), getPyramidLevel, extractStereo,
+  // extractRGBD and by extract() itself.  On the constructing thread the exception propagates at once, as before.
   void extract(std::vector<orbfe_keypoint>& keyPoints, std::vector<Descriptor>& descriptors) {
-    keyPoints.resize(mnFeats);
-    descriptors.resize(mnFeats);
-    int32_t n = 0;
-    mLease = ContextPool::acquire(mCtx);
-    check(mCtx, orbfe_extract_slot(mCtx, mLease.slot, mImage.data, mImage.step, keyPoints.data(), descriptors.data()->data(), &n));
-    keyPoints.resize(n);
-    descriptors.resize(n);
-    mnKeyPoints = n;
+    const bool foreign = std::this_thread::get_id() != mOwner;
+    if (!foreign) rethrowPending();
+    try {
+      keyPoints.resize(mnFeats);
+      descriptors.resize(mnFeats);
+      int32_t n = 0;
+      mLease = ContextPool::acquire(mCtx);
+      check(mCtx, orbfe_extract_slot(mCtx, mLease.slot, mImage.data, mImage.step, keyPoints.data(), descriptors.data()->data(), &n));
+      keyPoints.resize(n);
+      descriptors.resize(n);
+      mnKeyPoints = n;
+    } catch (...) {
+      keyPoints.clear();
+      descriptors.clear();
+      mnKeyPoints = 0;
+      if (!foreign) throw;
+      std::lock_guard<std::mutex> lk(mPendingMutex);
+      mPending = std::current_exception();
+    }
+  }
+  // rethrows (once) what an extract() on a foreign thread captured; no-op otherwise
+  void rethrowPending() const {
+    std::exception_ptr e;
+    {
+      std::lock_guard<std::mutex> lk(mPendingMutex);
+      std::swap(e, mPending);
+    }
+    if (e) std::rethrow_exception(e);
+  }
+  bool hasPendingError() const {
+    std::lock_guard<std::mutex> lk(mPendingMutex);
+    return (bool)mPending;
   }
 
   // Frame::createStereo's device work as ONE call (include/ORB_SLAM2/Frame.h:313-323: the two extractions of src/Frame.cc:100-105 and
@@ -203,6 +242,7 @@ class ORBExtractor {
   int extractStereo(ORBExtractor& right, float fx, float bf, std::vector<orbfe_keypoint>& kpsLeft, std::vector<Descriptor>& descLeft,
                     std::vector<orbfe_keypoint>& kpsRight, std::vector<Descriptor>& descRight, std::vector<double>& rightU,
                     std::vector<double>& depths) {
+    rethrowPending(), right.rethrowPending();
     if (mCtx != right.mCtx) throw std::logic_error("extractStereo: the two extractors differ in geometry / parameters");
     if (mImage.step != right.mImage.step) throw std::logic_error("extractStereo: the two images differ in row stride");
     const size_t cap = (size_t)mnFeats;
@@ -227,6 +267,7 @@ class ORBExtractor {
   void extractRGBD(const orbfe_camera& cam, const void* depth, int depthType, size_t depthStep, float depthScale,
                    std::vector<orbfe_keypoint>& undistorted, std::vector<Descriptor>& descriptors, std::vector<double>& depths,
                    std::vector<double>& rightU) {
+    rethrowPending();
     undistorted.resize(mnFeats), descriptors.resize(mnFeats), depths.resize(mnFeats), rightU.resize(mnFeats);
     int32_t n = 0;
     mLease = ContextPool::acquire(mCtx);
@@ -240,6 +281,7 @@ class ORBExtractor {
   // if the slot has been handed to another extractor since, the pyramid is rebuilt from the image this object still refers to
   // (like the reference's pyramid, it lives as long as the image does).
   std::vector<uint8_t> getPyramidLevel(int l, int* w = nullptr, int* h = nullptr) {
+    rethrowPending();
     orbfe_level_info li{};
     check(mCtx, orbfe_get_level_info(mCtx, l, &li));
     if (!resident()) {
@@ -266,6 +308,9 @@ class ORBExtractor {
   orbfe_ctx* mCtx = nullptr;
   ContextPool::Lease mLease;
   std::vector<float> mScales;
+  std::thread::id mOwner = std::this_thread::get_id();  // the constructing thread (Frame::Frame's)
+  mutable std::mutex mPendingMutex;
+  mutable std::exception_ptr mPending;                  // what extract() captured on a foreign thread
 };
 
 class ORBMatcher {
@@ -284,6 +329,7 @@ class ORBMatcher {
   // (-1 where unmatched) and returns the match count (Frame::mnN).
   int searchByStereo(const ORBExtractor& left, const ORBExtractor& right, float fx, float bf, std::vector<double>& rightU,
                      std::vector<double>& depths) const {
+    left.rethrowPending(), right.rethrowPending();  // a failure of one of Frame::Frame's extract() threads surfaces here (see extract())
     if (left.context() != right.context()) throw std::logic_error("searchByStereo: the two extractors differ in geometry / parameters");
     if (!left.resident() || !right.resident())
       throw std::logic_error("searchByStereo: the extractors' device results have been overwritten (more than "

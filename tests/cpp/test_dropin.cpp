@@ -239,6 +239,41 @@ static int mode_threads(int argc, char** argv) {
   return (pyr_ok && stale_refused) ? 0 : 1;
 }
 
+// A device error inside extract() on Frame::Frame's bare threads (src/Frame.cc:100-105) must not reach std::terminate: the failure is
+// captured and rethrown by the next call on the object (searchByStereo, the next statement of Frame::createStereo).  The error is provoked
+// with a cv::Mat header whose row stride is shorter than its width (orbfe_extract_slot refuses it: ORBFE_EBADARG).
+static int mode_threaderr(int argc, char** argv) {
+  if (argc < 6) return 2;
+  const int w = atoi(argv[4]), h = atoi(argv[5]);
+  std::vector<uint8_t> L, R;
+  if (!read_file(argv[2], L) || !read_file(argv[3], R) || L.size() != (size_t)w * h || R.size() != L.size()) return 2;
+  cv::Mat ml(h, w, CV_8UC1, L.data()), bad(h, w, CV_8UC1, R.data(), (size_t)w - 8);
+  // (a) on two threads, as the reference: no terminate, the failing eye comes back empty, the match that follows throws
+  auto f = std::make_shared<ref::Frame>(ml, bad, 1);
+  const bool empty_right = f->mvFeatsRight.empty() && f->mRightDescriptor.empty() && !f->mvFeatsLeft.empty();
+  const bool pending = f->mpExtractorRight->device().hasPendingError() && !f->mpExtractorLeft->device().hasPendingError();
+  bool rethrown = false, names_cause = false;
+  try {
+    orbfe::dropin::searchByStereo<ref::Camera>(f);
+  } catch (const std::runtime_error& e) {
+    rethrown = true;
+    names_cause = std::string(e.what()).find("stride") != std::string::npos;
+  }
+  const bool once = !f->mpExtractorRight->device().hasPendingError();  // delivered: the object is usable again
+  // (b) on the constructing thread the exception propagates at once
+  bool direct = false;
+  try {
+    ref::Frame g(ml, bad, 0);
+  } catch (const std::runtime_error&) {
+    direct = true;
+  }
+  // (c) a good frame afterwards is unaffected
+  auto ok = std::make_shared<ref::Frame>(ml, cv::Mat(h, w, CV_8UC1, R.data()), 1);
+  const int nm = orbfe::dropin::searchByStereo<ref::Camera>(ok);
+  printf("THREADERR_OK %d %d %d %d %d %d %d\n", (int)empty_right, (int)pending, (int)rethrown, (int)names_cause, (int)once, (int)direct, nm);
+  return (empty_right && pending && rethrown && names_cause && once && direct && nm > 0) ? 0 : 1;
+}
+
 // Timing mode (bench.py's `latency` object): the reference's own call shape -- Frame::Frame builds two extractor objects and runs their
 // extract() on two std::threads (src/Frame.cc:91-105), then Frame::createStereo calls searchByStereo (Frame.h:316-319) -- from host
 // images to host results, per stereo pair.  Thread creation and join are part of Frame::Frame and are inside the number; every
@@ -1292,6 +1327,7 @@ int main(int argc, char** argv) {
     if (mode == "policy") return mode_policy();
     if (mode == "threads") return mode_threads(argc, argv);
     if (mode == "latency") return mode_latency(argc, argv);
+    if (mode == "threaderr") return mode_threaderr(argc, argv);
     if (mode == "matchers") return mode_matchers(argc, argv);
     if (mode == "rgbd") return mode_rgbd(argc, argv);
     if (mode == "trackchain") return mode_trackchain(argc, argv);

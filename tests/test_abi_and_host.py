@@ -60,6 +60,20 @@ def test_brief_template_parser(tmp_path):
     assert pat[0].tolist() == [8, -3, 9, 5] and pat.min() == -13 and pat.max() == 12
     with pytest.raises(FileNotFoundError):
         load_brief_template(str(tmp_path / "missing.txt"))
+    # what initBriefTemplate does with other files (ORBExtractor.cc:251-265): no count check -- a longer file acts through its first 256
+    # pairs (computeBRIEF copies 32 bytes, :405-406); a line that does not parse is a pair of zeros from the failed value on; a final
+    # newline adds no pair.  Fewer than 256 pairs would index past the template in the reference: refused.
+    rows = ["\t".join(str(v) for v in r) for r in pat]
+    p.write_text("hdr\n" + "\n".join(rows + ["1 2 3 4", "5 6 7 8"]) + "\n")
+    assert np.array_equal(load_brief_template(str(p)), pat)
+    broken = list(rows)
+    broken[3], broken[4] = "", "7 x 9 9"
+    p.write_text("hdr\n" + "\n".join(broken))
+    got = load_brief_template(str(p))
+    assert got[3].tolist() == [0, 0, 0, 0] and got[4].tolist() == [7, 0, 0, 0] and np.array_equal(got[5:], pat[5:])
+    p.write_text("hdr\n" + "\n".join(rows[:255]))
+    with pytest.raises(ValueError):
+        load_brief_template(str(p))
 
 
 def test_frame_range_partition():

@@ -43,6 +43,20 @@ def test_two_extractor_objects_on_two_threads_200_times(orc, exe, tmp_path):
     assert (int(pyr_ok), int(stale_refused), int(levels)) == (1, 1, 8)
 
 
+def test_device_error_on_an_extract_thread_is_captured_and_rethrown_by_the_next_call(exe, tmp_path):
+    """Frame::Frame runs extract() on bare std::threads (src/Frame.cc:100-105): an exception leaving one is std::terminate.  A failing
+    extract() on a foreign thread returns empty and the error surfaces at searchByStereo (the next statement of Frame::createStereo,
+    Frame.h:319); on the constructing thread it propagates at once; a later good frame is unaffected."""
+    L, R = synth.stereo_pair(3)
+    L.tofile(tmp_path / "L.raw")
+    R.tofile(tmp_path / "R.raw")
+    out = subprocess.run([exe, "threaderr", str(tmp_path / "L.raw"), str(tmp_path / "R.raw"), "1241", "376"], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr     # (std::terminate would be SIGABRT: -6)
+    f = out.stdout.split()
+    assert f[0] == "THREADERR_OK" and f[1:7] == ["1"] * 6 and int(f[7]) > 0
+
+
 def test_create_stereo_adapter_builds_the_same_frame_as_two_threads_and_search_by_stereo(orc, exe, tmp_path):
     """mode `latency` builds the Frame three ways -- two extract() threads + searchByStereo (the reference's shape), the same calls on one
     thread, and orbfe::dropin::createStereo (one device call) -- and fails unless every frame of every way hashes equal to the first"""

@@ -195,25 +195,39 @@ def test_device_local_ba_stop_flag(orc):
     o = orc.ba_local_optimize(pr, fixed, iters1=0, iters2=0)
     assert g["iters"].tolist() == [0, 0] and not g["level"].any()
     assert np.array_equal(g["poses"], pr["poses"]) and np.array_equal(g["points"], pr["points"]) and np.array_equal(g["bad"], o["bad"])
-    # while it runs: a budget of 3000 + 3000 iterations; a second thread raises the flag as soon as the call has been entered (events, no
-    # clock: the call needs >= 60 trials of ~0.15 ms to end by itself, the flag thread one wake-up)
-    alone = ctx.ba_local_optimize(pr, fixed, 3000, 0)     # how far Levenberg-Marquardt goes by itself (it ends on ten rejected trials in a row)
+    # WHILE it runs, asserted unconditionally: a window of 300 free keyframes (one trial ~1.2 ms on the blocked solver, the call by itself
+    # tens of milliseconds: `alone` measures both), the flag raised by a second thread a third of that time into the call -- long after
+    # the first iteration has started, long before Levenberg-Marquardt would end by itself (ten rejected trials in a row)
+    import time
+    big, fixed_b = _problem(13, 310, 4000, 10)
+    ctx.ba_local_optimize(big, fixed_b, 1, 0)                      # warm-up: buffers of this size, first launches
+    t0 = time.perf_counter()
+    alone = ctx.ba_local_optimize(big, fixed_b, 3000, 0)           # how far Levenberg-Marquardt goes by itself
+    t_alone = time.perf_counter() - t0
+    assert alone["iters"][0] >= 8 and t_alone > 0.012, (alone["iters"], t_alone)   # the premise: a long call
     stop[0] = 0
     entered, returned, seen = threading.Event(), threading.Event(), {}
 
     def raiser():
         entered.wait()
-        stop[0] = 1
+        time.sleep(t_alone / 3)
         seen["before_return"] = not returned.is_set()
+        stop[0] = 1
     th = threading.Thread(target=raiser)
     th.start()
     entered.set()
-    g = ctx.ba_local_optimize(pr, fixed, 3000, 3000, stop=stop)
+    t0 = time.perf_counter()
+    g = ctx.ba_local_optimize(big, fixed_b, 3000, 3000, stop=stop)
+    t_stopped = time.perf_counter() - t0
     returned.set()
     th.join()
-    assert np.isfinite(g["poses"]).all() and 0 <= g["iters"][0] <= alone["iters"][0]
-    if seen["before_return"] and alone["iters"][0] > 60:   # the flag came first: the round ended early, no classification, no second round
-        assert g["iters"][0] < alone["iters"][0] and g["iters"][1] == 0 and not g["level"].any(), (g["iters"], alone["iters"])
+    assert seen["before_return"], "the call returned before the flag was raised: the premise of the test does not hold"
+    # the flag came mid-run: iterations had started, the round ended early (within a trial or two of the flag: well before 3000 + 3000
+    # iterations' worth of time), no classification, no second round
+    assert np.isfinite(g["poses"]).all() and np.isfinite(g["points"]).all()
+    assert 1 <= g["iters"][0] < alone["iters"][0], (g["iters"], alone["iters"])
+    assert g["iters"][1] == 0 and not g["level"].any()
+    assert t_stopped < t_alone, (t_stopped, t_alone)
     ctx.close()
 
 
