@@ -270,8 +270,16 @@ def sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend, collective, wind
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         rates = [float(t.item()) for t in allr]
+    f_local = [frame_range(F, r, world)[1] - frame_range(F, r, world)[0] for r in range(world)]
     info = {"exchange": exchange, "per_rank_pairs_per_s": [round(r, 1) for r in rates],
             "communicator_nranks": dist.get_world_size() if dist.is_initialized() else 0,
+            # which bytes take which wire (one node: xGMI between the GPUs, one PCIe link per GPU to the one host memory)
+            "xgmi_bytes": int(sum(f_local[1:])) * (16 if exchange == "shared" else rb),
+            "pcie_bytes_per_rank": [int(n) * rb for n in f_local] if exchange == "shared" else [int(F) * rb] + [0] * (world - 1),
+            "wires": ("records: every rank's own PCIe link (device -> its rows of the shared page-locked segment); xGMI: the 16-byte record heads "
+                      "of the other ranks, gathered on rank 0") if exchange == "shared" else
+                     ("records: xGMI from every other rank to rank 0 (RCCL gather, north_star's form), then ALL of them over rank 0's one PCIe "
+                      "link to host memory"),
             "payload": ("records: each rank -> its rows of one page-locked POSIX shared-memory segment over its own PCIe link; collective: "
                         "16 B per frame (n, n_matches)") if exchange == "shared" else
                        "records: gathered on rank 0 over the collective, drained from there over rank 0's PCIe link",
@@ -1088,7 +1096,16 @@ def main():
         B_leg = sequence_batch((F_leg + world - 1) // world, B)
         t_seq, _, n_chk, xinfo = sequence_job(ctx, F_leg, B_leg, U_leg, rank, world, dev, xdev, backend, collective, window=max(1, args.sequence_window),
                                               exchange=args.sequence_exchange)
+        # ... and the same job with the OTHER exchange beside it: north_star names the RCCL-over-xGMI gather of the
+        # records; the default drains every rank's records over its own PCIe link.  Both in every line, so that the first multi-GPU run
+        # reports the two side by side.
+        other = "gather" if args.sequence_exchange == "shared" else "shared"
+        t_oth, _, n_chk_o, xinfo_o = sequence_job(ctx, F_leg, B_leg, U_leg, rank, world, dev, xdev, backend, collective, window=max(1, args.sequence_window),
+                                                 exchange=other)
+        seq_other = {"frames": F_leg, "pairs_per_s": F_leg / t_oth, "seconds": t_oth, "exchange": xinfo_o, "records_checked_against_host_path": n_chk_o,
+                     "collective_executed": bool(collective)}
         seq_leg = {"frames": F_leg, "pairs_per_s": F_leg / t_seq, "seconds": t_seq, "result_bytes": F_leg * ctx.record_bytes(), "exchange": xinfo,
+                   "other_exchange": seq_other,
                    "pairs_per_batch": B_leg, "batches_per_window": max(1, args.sequence_window), "collective_executed": bool(collective),
                    "records_checked_against_host_path": n_chk, "records_checked_for_repeat_consistency": max(0, F_leg - min(U_leg, F_leg)),
                    "what": "BASELINE config 4: contiguous blocks of frames per rank, page-locked host images -> extraction + stereo match "

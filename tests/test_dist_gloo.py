@@ -179,7 +179,8 @@ def _win_worker(rank, world, port, n_frames, batch, window, use_sink, q):
 @pytest.mark.parametrize("world,n_frames,batch,window,use_sink", [(2, 7, 2, 1, True),    # per 4: two windows of 2, rank 1 ends in a ragged one
                                                                  (2, 9, 2, 2, False),   # per 5: windows of 4, rank 1 has nothing in the second
                                                                  (2, 1, 4, 1, True),    # rank 1 has an empty block
-                                                                 (1, 5, 2, 1, True)])   # one rank THROUGH the collective (force_collective)
+                                                                 (1, 5, 2, 1, True),    # one rank THROUGH the collective (force_collective)
+                                                                 (8, 19, 2, 1, True)])  # eight ranks, `--sequence-exchange gather`: per 3, rank 6 holds 1 frame, rank 7 none
 def test_windowed_gather_equals_single_gather(world, n_frames, batch, window, use_sink):
     import torch.multiprocessing as mp
     from orb_slam2_ros2_amd.sequence import record_bytes, run_sequence
@@ -244,7 +245,9 @@ def _drain_worker(rank, world, port, n_frames, batch, window, name, q):
 @pytest.mark.parametrize("world,n_frames,batch,window", [(4, 11, 2, 1),   # per 3: the last rank holds 2 frames (uneven blocks, ragged windows)
                                                          (4, 2, 2, 1),    # per 1: ranks 2 and 3 hold nothing
                                                          (2, 9, 2, 2),
-                                                         (1, 5, 2, 1)])   # one rank through the collective
+                                                         (1, 5, 2, 1),    # one rank through the collective
+                                                         (8, 37, 2, 1),   # the node's shape: per 5, rank 7 holds 2 frames, ragged last windows
+                                                         (8, 5, 2, 2)])   # per 1: ranks 5, 6, 7 hold nothing, windows wider than the blocks
 def test_shared_host_segment_drain_equals_single_gather(world, n_frames, batch, window):
     """sharding.WindowDrain: the records land in a POSIX shared-memory segment (each rank writes its own rows), the collective carries
     only (n, n_matches) per frame -- against the records of a single-process run."""
