@@ -238,8 +238,7 @@ __host__ __device__ __forceinline__ uint32_t pp_axis_code(int v, const Thr* t /*
   const int nv = b1 < 0 ? 0 : (b2 < 0 ? 1 : (b3 < 0 ? 2 : (b4 < 0 ? 3 : 4)));
   return (uint32_t)(nv << 4) | (uint32_t)(c1 << 3) | (uint32_t)(c2 << 2) | (uint32_t)(c3 << 1) | (uint32_t)(b4 > 0 ? b4 : 0);
 }
-__device__ __forceinline__ int pp_group_tab(uint32_t x, uint32_t y, const uint16_t* xtab, const uint16_t* ytab) {
-  const uint32_t cx = xtab[x], cy = ytab[y];
+__device__ __forceinline__ int pp_group_codes(uint32_t cx, uint32_t cy) {
   const int nv = (int)min((cx >> 4) & 7u, (cy >> 4) & 7u);
   const int q1 = (int)(((cy >> 3) & 1u) * 2u + ((cx >> 3) & 1u));  // rows outer, cols inner (ORBExtractor.cc:60-72)
   const int q2 = (int)(((cy >> 2) & 1u) * 2u + ((cx >> 2) & 1u));
@@ -249,6 +248,70 @@ __device__ __forceinline__ int pp_group_tab(uint32_t x, uint32_t y, const uint16
   const int l2 = nv >= 2 ? q2 * 21 + l3 : 84;
   const int l1 = nv >= 1 ? q1 * 85 + l2 : 340;
   return ((cx & cy) & 0x8000u) ? (int)((cx >> 12) & 3u) * QT_PP_GROUPS + l1 : -1;
+}
+
+// Bitonic sort of ROWS x 64 (key, payload) pairs held in registers, element index = r * 64 + lane, ascending by key (the keys are distinct
+// or padding).  Strides >= 64 pair two registers of a lane; strides 1 and 2 exchange through DPP quad permutes (vector ALU, no LDS round
+// trip: 17 of the 39 cross-lane stages of 512 keys); the others through ds_bpermute -- ALL rows' exchanges of a stage are requested
+// before the first is consumed (r5: with one wait per row a level-0 tree spent 53 k cycles here, eight dependent LDS round trips per
+// stage).  ROWS is a template parameter so that no stage touches a row of padding.
+template <int ROWS>
+__device__ __forceinline__ void bitonic_rows(uint32_t (&key)[8], uint32_t (&pay)[8], int lane) {
+  constexpr int CAP = ROWS * 64;
+#pragma unroll 1
+  for (int k = 2; k <= CAP; k <<= 1) {
+#pragma unroll 1
+    for (int st = k >> 1; st > 0; st >>= 1) {
+      if (st >= 64) {
+        const int rs = st >> 6;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+          for (int q = 1; q < ROWS; q <<= 1) {
+            if (rs == q && (r & q) == 0) {
+              const bool up = ((r * 64) & k) == 0;
+              const uint32_t a = key[r], b2 = key[r | q], pa = pay[r], pb = pay[r | q];
+              const bool sw = (a > b2) == up;
+              key[r] = sw ? b2 : a;
+              key[r | q] = sw ? a : b2;
+              pay[r] = sw ? pb : pa;
+              pay[r | q] = sw ? pa : pb;
+            }
+          }
+        }
+      } else {
+        uint32_t ok[ROWS], op[ROWS];
+        if (st == 1) {
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) {
+            ok[r] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key[r], 0xB1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]
+            op[r] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pay[r], 0xB1, 0xf, 0xf, false);
+          }
+        } else if (st == 2) {
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) {
+            ok[r] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key[r], 0x4E, 0xf, 0xf, false);  // quad_perm [2, 3, 0, 1]
+            op[r] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pay[r], 0x4E, 0xf, 0xf, false);
+          }
+        } else {
+          const int src = (lane ^ st) << 2;
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) {
+            ok[r] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)key[r]);
+            op[r] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)pay[r]);
+          }
+        }
+        const bool lower = (lane & st) == 0;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          const bool up = (((r * 64) + lane) & k) == 0;
+          const bool other = (ok[r] < key[r]) == (lower == up);  // take the partner's pair: it holds the minimum and this lane keeps minima, or the reverse
+          pay[r] = other ? op[r] : pay[r];
+          key[r] = other ? ok[r] : key[r];
+        }
+      }
+    }
+  }
 }
 
 // Everything after the strip counts: scatter into the strip segments, best-first expansion, selection, ordering.
@@ -352,9 +415,19 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     }
     __syncthreads();
     QTS(-10)  // tables
-    auto group_of = [&](uint32_t r) -> int {
-      // (candidates lie inside the region; the clamp only guards the table)
-      return pp_group_tab(min(ORBFE_REC_X(r), (uint32_t)tab_w - 1u), min(ORBFE_REC_Y(r), (uint32_t)tab_h - 1u), xtab, ytab);
+    // a trip's records -> groups: ALL table reads of the trip first (two per record), then the arithmetic -- the compiler keeps the order
+    // it is given here, and read-by-read each record waited for its own two LDS round trips
+    auto groups_of = [&](const uint32_t* r, int* g, int n) {
+      uint32_t cx[16], cy[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (u < n) {  // (candidates lie inside the region; the clamp only guards the table)
+          cx[u] = xtab[min(ORBFE_REC_X(r[u]), (uint32_t)tab_w - 1u)];
+          cy[u] = ytab[min(ORBFE_REC_Y(r[u]), (uint32_t)tab_h - 1u)];
+        }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (u < n) g[u] = pp_group_codes(cx[u], cy[u]);
     };
     // pass 1: group sizes.  Sixteen records per lane per trip, and the next trip's records are requested before this trip's are
     // classified: a lone wave sees every global round trip, so the loads of trip k+1 fly under the work of trip k.
@@ -383,11 +456,12 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         for (int u = 0; u < PU; ++u) rec[u] = nxt[u];
         if (b0 + NW * PCH < N) load16(b0 + NW * PCH, nxt);
         int g[PU];  // (all groups first, then the atomics: the table reads must not queue behind the atomics they may alias)
+        // (classified UNCONDITIONALLY -- the loads are clamped, so every register holds a real record -- and masked afterwards: written as
+        //  `i < N ? group_of(rec) : -1` each record became a branch of its own whose two table reads were waited for on the spot, eight
+        //  dependent LDS round trips per trip instead of sixteen reads in flight)
+        groups_of(rec, g, PU);
 #pragma unroll
-        for (int u = 0; u < PU; ++u) {
-          const int i = b0 + u * 64 + lane;
-          g[u] = (i < N) ? group_of(rec[u]) : -1;
-        }
+        for (int u = 0; u < PU; ++u) g[u] |= -(int)(b0 + u * 64 + lane >= N);
         if (b0 == wv * PCH) {  // wave-uniform
 #pragma unroll
           for (int u = 0; u < PU; ++u) rec0[u] = rec[u], g0[u] = g[u];
@@ -399,21 +473,25 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     }
     __syncthreads();
     QTS(-11)  // pass 1
-    // totals of the 84 + 256 nodes below every strip, then sizes -> cursors (exclusive prefix in layout order)
-    for (int t = tid; t < ns * QT_PP_TOTALS; t += NT) {
-      const int st = t / QT_PP_TOTALS, k = t - QT_PP_TOTALS * st;
-      const int c = st * QT_PP_GROUPS;
-      uint32_t v = 0;
-      if (k < 4) {
-        for (int i = 0; i < 85; ++i) v += cur_get(c + k * 85 + i);
-      } else if (k < 20) {
-        const int q1 = (k - 4) >> 2, q2 = (k - 4) & 3;
-        for (int i = 0; i < 21; ++i) v += cur_get(c + q1 * 85 + q2 * 21 + i);
-      } else {
-        const int m = k - 20;
-        for (int i = 0; i < 5; ++i) v += cur_get(c + (m >> 4) * 85 + ((m >> 2) & 3) * 21 + (m & 3) * 5 + i);
-      }
-      tot[t] = (uint16_t)v;
+    // totals of the 84 + 256 nodes below every strip, then sizes -> cursors (exclusive prefix in layout order).  Bottom-up: a node's total
+    // is its four children's totals plus its own split-line group -- five reads per entry on each of the three levels.  (Until r5 every
+    // entry summed its groups directly: 85 dependent LDS reads for a child of the strip, 39 k of a level-0 tree's 337 k cycles.)
+    for (int t = tid; t < ns * 64; t += NT) {  // (q1, q2, q3): four leaves + the lines group
+      const int st = t >> 6, m = t & 63;
+      const int b = st * QT_PP_GROUPS + (m >> 4) * 85 + ((m >> 2) & 3) * 21 + (m & 3) * 5;
+      tot[st * QT_PP_TOTALS + 20 + m] = (uint16_t)(cur_get(b) + cur_get(b + 1) + cur_get(b + 2) + cur_get(b + 3) + cur_get(b + 4));
+    }
+    __syncthreads();
+    for (int t = tid; t < ns * 16; t += NT) {  // (q1, q2)
+      const int st = t >> 4, k = t & 15;
+      const uint16_t* t3 = tot + st * QT_PP_TOTALS + 20 + 4 * k;
+      tot[st * QT_PP_TOTALS + 4 + k] = (uint16_t)((uint32_t)t3[0] + t3[1] + t3[2] + t3[3] + cur_get(st * QT_PP_GROUPS + (k >> 2) * 85 + (k & 3) * 21 + 20));
+    }
+    __syncthreads();
+    for (int t = tid; t < ns * 4; t += NT) {  // (q1)
+      const int st = t >> 2, q1 = t & 3;
+      const uint16_t* t2 = tot + st * QT_PP_TOTALS + 4 + 4 * q1;
+      tot[st * QT_PP_TOTALS + q1] = (uint16_t)((uint32_t)t2[0] + t2[1] + t2[2] + t2[3] + cur_get(st * QT_PP_GROUPS + q1 * 85 + 84));
     }
     for (int t = tid; t < ns * QT_PP_TOTALS4; t += NT) {
       const int st = t / QT_PP_TOTALS4, m = t - QT_PP_TOTALS4 * st;  // m = 64 q1 + 16 q2 + 4 q3 + q4
@@ -470,6 +548,9 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     {
       uint32_t nxt[PU];
       if (wv * PCH + NW * PCH < N) load16(wv * PCH + NW * PCH, nxt);  // (the first trip's records are still in registers)
+      // (r5, measured and dropped: the groups of pass 1 kept in the bounce buffer for this pass instead of classifying every record a
+      //  second time -- ~35 vector instructions per record saved here, one store and one load added: pass 1 45 k -> 59 k cycles, this
+      //  pass 53 k -> 49 k on a level-0 tree: it is not the classification that bounds this pass)
       for (int b0 = wv * PCH; b0 < N; b0 += NW * PCH) {
         uint32_t rec[PU];
         int g[PU];
@@ -480,11 +561,9 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
 #pragma unroll
           for (int u = 0; u < PU; ++u) rec[u] = nxt[u];
           if (b0 + NW * PCH < N) load16(b0 + NW * PCH, nxt);
+          groups_of(rec, g, PU);
 #pragma unroll
-          for (int u = 0; u < PU; ++u) {
-            const int i = b0 + u * 64 + lane;
-            g[u] = (i < N) ? group_of(rec[u]) : -1;
-          }
+          for (int u = 0; u < PU; ++u) g[u] |= -(int)(b0 + u * 64 + lane >= N);
         }
         uint32_t pos[PU];
 #pragma unroll
@@ -1019,16 +1098,77 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     }
     return (bk << 8) | (unsigned long long)ORBFE_REC_R(best);
   };
+  // The same winner as node_key, for the sorts of up to 512 keys: the 32-bit order key (order_key32) and the winning record itself.
+  // The first 32 records of a lane's node are requested AT ONCE (one round trip; a node of the final table holds 10 - 25 records on the
+  // bench frames): eight at a time, every eight a dependent trip to memory, the scan of a level-0 tree's 434 nodes was ~30 round trips
+  // of ~2.5 k cycles -- most of the 91 k cycles of the selection phase (r5 stamps, tools/exp/qt_stamps.sh with QT_BATCH).  All compares
+  // are 32-bit (the 64-bit integer compares of the old keys are quarter-rate instructions).
+  auto node_win = [&](int j, uint32_t& k32, uint32_t& wrec) {
+    k32 = 0xFFFFFFFFu, wrec = 0u;
+    const bool live = j < n_act;
+    const uint32_t* p = H + (live ? (n_bp[j].x & QT_BEG_MASK) : 0u);
+    const int n = live ? (int)(n_key[j] >> 32) : 0;
+    const int nmax = (int)wave_max_u32((uint32_t)n);
+    uint32_t br = 0;
+    auto consider = [&](uint32_t rc) {
+      const uint32_t r = ORBFE_REC_R(rc);
+      if (r >= br) {  // maximum response; the reference keeps the FIRST maximum in candidate order
+        const uint32_t k = order_key32(rc, L);
+        if (r > br || k < k32) wrec = rc, br = r, k32 = k;
+      }
+    };
+    uint32_t rec[32];
+#pragma unroll
+    for (int c8 = 0; c8 < 4; ++c8) {
+      if (c8 * 8 < nmax) {  // wave-uniform
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rec[c8 * 8 + u] = p[min(c8 * 8 + u, max(n - 1, 0))];
+      }
+    }
+#pragma unroll
+    for (int c8 = 0; c8 < 4; ++c8) {
+      if (c8 * 8 < nmax) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (c8 * 8 + u < n) consider(rec[c8 * 8 + u]);
+      }
+    }
+    for (int i0 = 32; i0 < nmax; i0 += 8) {  // larger nodes (a table that ended before the quota was reached, a clustered level)
+      uint32_t rr[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rr[u] = p[min(i0 + u, max(n - 1, 0))];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u < n) consider(rr[u]);
+    }
+  };
   if (sort_cap <= 512) {
     // bitonic sort of up to 512 keys IN REGISTERS, key index = r * 64 + lane: strides >= 64 pair two registers of a lane,
     // smaller strides exchange with lane ^ stride (a first version through LDS with a barrier per stage took 94 k cycles,
     // a quarter of the pop loop)
-    unsigned long long key[8];
+    uint32_t key[8], pay[8];  // order key (order_key32) | the node's winning record
     if (NW == 1) {
-      // (measured and dropped: chunk-major over four or eight of a lane's nodes at a time, so that their record loads share round
-      //  trips -- same-box A/B of the batched step: equal; the stage alone 0.41 - 0.43 ms against 0.39)
+      // (measured and dropped in r4: chunk-major over four or eight of a lane's nodes at a time, so that their record loads share round
+      //  trips -- no gain; what r5 does instead is one deep request per node, see node_win)
+      // The scan is a LOOP over the table's rows (not unrolled: eight copies of it were a third of the kernel's code, and the kernel does not
+      // fit the instruction cache as it is); a lane parks its node's result in the node's own key slot -- nobody else reads that slot --
+      // and the sort below collects eight per lane.
+#pragma unroll 1
+      for (int j0 = 0; j0 < n_act; j0 += 64) {
+        uint32_t k32, wrec;
+        node_win(j0 + lane, k32, wrec);
+        if (j0 + lane < n_act) n_key[j0 + lane] = ((unsigned long long)wrec << 32) | (unsigned long long)k32;
+      }
+      QTS(-22)  // winner scan
+      qt_wsync<NW>();  // (the table may live in global memory: NODES_LDS = false)
 #pragma unroll
-      for (int r = 0; r < 8; ++r) key[r] = (r * 64 < sort_cap) ? node_key(r * 64 + lane) : ~0ull;
+      for (int r = 0; r < 8; ++r) {
+        key[r] = 0xFFFFFFFFu, pay[r] = 0u;
+        if (r * 64 < sort_cap && r * 64 + lane < n_act) {
+          const unsigned long long kv = n_key[r * 64 + lane];
+          key[r] = (uint32_t)kv, pay[r] = (uint32_t)(kv >> 32);
+        }
+      }
     } else {
       // all waves scan nodes (one node per thread per trip); the keys meet in LDS (the fp64 bound arrays are dead) and every thread
       // RANKS its own keys by counting the smaller ones -- the keys are read back with wave-uniform addresses (one LDS read serves
@@ -1036,15 +1176,14 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       // keypoints go straight to their output slots.  (Wave 0 alone sorting the keys in registers, 36 cross-lane exchange stages
       // of eight keys, was a quarter of the 98 us of a level-0 tree: stamps build, tools/exp/qt_stamps.sh.)
       __syncthreads();
-      unsigned long long mine[(512 + NT - 1) / NT];
+      uint32_t mine[(512 + NT - 1) / NT];
       uint32_t k32[(512 + NT - 1) / NT];
       uint32_t* sort32 = (uint32_t*)sortbuf;  // the ranking compares 32-bit order keys (order_key32)
 #pragma unroll
       for (int u = 0; u < (512 + NT - 1) / NT; ++u) {
         const int j = tid + u * NT;
-        mine[u] = (j < sort_cap) ? node_key(j) : ~0ull;
-        const uint32_t y = (uint32_t)(mine[u] >> 20) & 0xFFFu, x = (uint32_t)(mine[u] >> 8) & 0xFFFu;
-        k32[u] = (j < n_act) ? order_key32(ORBFE_PACK_XYR(x, y, 0u), L) : 0xFFFFFFFFu;
+        k32[u] = 0xFFFFFFFFu, mine[u] = 0u;
+        if (u * NT < sort_cap) node_win(j, k32[u], mine[u]);  // (uniform per wave: every lane of a wave shares u; lanes past n_act get padding)
         if (j < max(sort_cap, 16)) sort32[j] = k32[u];
       }
       __syncthreads();
@@ -1070,53 +1209,21 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
 #pragma unroll
       for (int u = 0; u < (512 + NT - 1) / NT; ++u) {
         const int j = tid + u * NT;
-        if (j < n_act) {
-          const uint32_t y = (uint32_t)(mine[u] >> 20) & 0xFFFu, x = (uint32_t)(mine[u] >> 8) & 0xFFFu, rr = (uint32_t)mine[u] & 0xFFu;  // key = order<<8 | r
-          out_sel[rank[u]] = ORBFE_PACK_XYR(x, y, rr);
-        }
+        if (j < n_act) out_sel[rank[u]] = mine[u];
       }
       QTS(-4)
       QTS_PRINT
       if (w0 && lane == 0) *sel_count_out = n_act;
       return;
     }
-    for (int k = 2; k <= sort_cap; k <<= 1) {
-      for (int st = k >> 1; st > 0; st >>= 1) {
-        if (st >= 64) {
-          const int rs = st >> 6;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) {
-#pragma unroll
-            for (int q = 1; q <= 4; q <<= 1) {
-              if (rs == q && (r & q) == 0) {
-                const bool up = ((r * 64) & k) == 0;
-                const unsigned long long a = key[r], b2 = key[r | q];
-                const bool sw = (a > b2) == up;
-                key[r] = sw ? b2 : a;
-                key[r | q] = sw ? a : b2;
-              }
-            }
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)key[r], st), hi = (uint32_t)__shfl_xor((int)(uint32_t)(key[r] >> 32), st);
-            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
-            const bool up = (((r * 64) + lane) & k) == 0;
-            const bool take_min = ((lane & st) == 0) == up;
-            const unsigned long long mn = key[r] < other ? key[r] : other, mx = key[r] < other ? other : key[r];
-            key[r] = take_min ? mn : mx;
-          }
-        }
-      }
-    }
+    if (sort_cap > 256) bitonic_rows<8>(key, pay, lane);  // (wave-uniform: sort_cap is the power of two above the level's quota)
+    else if (sort_cap > 128) bitonic_rows<4>(key, pay, lane);
+    else if (sort_cap > 64) bitonic_rows<2>(key, pay, lane);
+    else bitonic_rows<1>(key, pay, lane);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int j = r * 64 + lane;
-      if (j < n_act) {
-        const uint32_t y = (uint32_t)(key[r] >> 20) & 0xFFFu, x = (uint32_t)(key[r] >> 8) & 0xFFFu, rr = (uint32_t)key[r] & 0xFFu;  // key = order<<8 | r
-        out_sel[j] = ORBFE_PACK_XYR(x, y, rr);
-      }
+      if (j < n_act) out_sel[j] = pay[r];
     }
   } else {
     for (int j = tid; j < sort_cap; j += NT) {
@@ -1160,7 +1267,7 @@ __device__ __forceinline__ void quadtree_levels(const LevelDev* __restrict__ lv,
                                                  uint32_t* __restrict__ sel, int32_t* __restrict__ sel_count, int n_features,
                                                  const int32_t* __restrict__ n_cand, int node_cap, int sort_cap, int rec_cap, int batch,
                                                  QtGroups groups, uint8_t* __restrict__ big_base, size_t big_pitch,
-                                                 const uint16_t* __restrict__ qt_tabs) {
+                                                 const uint16_t* __restrict__ qt_tabs, int32_t* __restrict__ qt_next) {
   extern __shared__ unsigned long long lds[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int img = blockIdx.y;
@@ -1168,8 +1275,31 @@ __device__ __forceinline__ void quadtree_levels(const LevelDev* __restrict__ lv,
   // quota: the level-0 tree alone, the small levels together).  With one wave per level a 1024-image launch filled every wave slot
   // of the chip with tree waves (8 levels x 1024 images = 8 per SIMD) that mostly wait, and the blur issued beside it on the second
   // stream could only start as trees finished: the two kernels ran back to back, not side by side (timeline).
-  for (uint32_t todo = groups.mask[blockIdx.x]; todo; todo &= todo - 1) {
-  const int level = __builtin_ctz(todo);
+  // Which trees a wave works through: its group's levels (fixed masks), or -- launches with several waves per image -- the next level nobody
+  // has taken yet, most expensive first (groups.order), from the image's counter qt_next[img] (zeroed before the launch): the longest wave of
+  // a launch is its critical path, and how long a level's tree takes follows its candidate count, which the host does not know (r5: with
+  // masks dealt by quota the wave holding levels {0, 7} or {1, 6} ran 15 - 20 % longer than the others).
+#ifdef QT_STAMPS
+  const long long qtw_begin = __builtin_amdgcn_s_memtime();
+  int qtw_trees = 0;
+  unsigned qtw_mask = 0;
+  long long qtw_t[8];
+#endif
+  const bool dyn = NW == 1 && groups.n_order > 0 && qt_next != nullptr;
+  uint32_t todo = dyn ? 0u : groups.mask[blockIdx.x];
+  for (;;) {
+  int level;
+  if (dyn) {
+    int t = 0;
+    if (lane == 0) t = atomicAdd(&qt_next[img], 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= groups.n_order) break;
+    level = groups.order[t];
+  } else {
+    if (!todo) break;
+    level = __builtin_ctz(todo);
+    todo &= todo - 1;
+  }
   const LevelDev& L = lv[level];
   // LDS carve-up: u64 keys | (begin, path) pairs | head list of the batched pops | sort buffer (quotas above 512, or several waves per tree) | records.
   unsigned long long* n_key = (unsigned long long*)lds;
@@ -1251,16 +1381,26 @@ __device__ __forceinline__ void quadtree_levels(const LevelDev* __restrict__ lv,
   if (NW > 1) __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
+#ifdef QT_STAMPS
+  qtw_t[qtw_trees & 7] = __builtin_amdgcn_s_memtime();
+  ++qtw_trees;
+  qtw_mask |= 1u << level;
+#endif
   }
+#ifdef QT_STAMPS
+  if (NW == 1 && lane == 0 && (blockIdx.y % 100) == 7)
+    printf("QTW img %d wave %d trees %d mask %u begin %lld d0 %lld d1 %lld d2 %lld\n", (int)blockIdx.y, (int)blockIdx.x, qtw_trees, qtw_mask, qtw_begin,
+           qtw_t[0] - qtw_begin, qtw_trees > 1 ? qtw_t[1] - qtw_t[0] : 0ll, qtw_trees > 2 ? qtw_t[2] - qtw_t[1] : 0ll);
+#endif
 }
 
 #define QT_KERNEL_ARGS                                                                                                                 \
   const LevelDev *__restrict__ lv, int n_levels, const uint32_t *__restrict__ cand, uint32_t *__restrict__ scratch_b,                   \
       uint32_t *__restrict__ scratch_c, size_t scratch_pitch, uint32_t *__restrict__ sel, int32_t *__restrict__ sel_count, int n_features, \
       const int32_t *__restrict__ n_cand, int node_cap, int sort_cap, int rec_cap, int batch, QtGroups groups, uint8_t *__restrict__ big_base, \
-      size_t big_pitch, const uint16_t *__restrict__ qt_tabs
+      size_t big_pitch, const uint16_t *__restrict__ qt_tabs, int32_t *__restrict__ qt_next
 #define QT_KERNEL_PASS \
-  lv, n_levels, cand, scratch_b, scratch_c, scratch_pitch, sel, sel_count, n_features, n_cand, node_cap, sort_cap, rec_cap, batch, groups, big_base, big_pitch, qt_tabs
+  lv, n_levels, cand, scratch_b, scratch_c, scratch_pitch, sel, sel_count, n_features, n_cand, node_cap, sort_cap, rec_cap, batch, groups, big_base, big_pitch, qt_tabs, qt_next
 // One wave per tree (batches): compiled for FOUR waves per SIMD (128 VGPRs) -- with 16-byte nodes sixteen trees fit a CU's LDS, and the
 // launch deals an image's levels to as many waves as make sixteen per CU, so that a SIMD has four dependent chains to interleave.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_quadtree(QT_KERNEL_ARGS) { quadtree_levels<1>(QT_KERNEL_PASS); }
@@ -1336,7 +1476,9 @@ hipError_t quadtree_configure(size_t lds_bytes) {
 void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint32_t* d_cand, uint32_t* d_scr_b, uint32_t* d_scr_c,
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
                      int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree, uint8_t* d_big, size_t big_pitch,
-                     const uint16_t* d_qt_tabs, const uint8_t* blur_pyr, uint8_t* blur_out, size_t img_pitch, const int* blur_taps, int blur_tiles) {
+                     const uint16_t* d_qt_tabs, const uint8_t* blur_pyr, uint8_t* blur_out, size_t img_pitch, const int* blur_taps, int blur_tiles,
+                     int32_t* d_qt_next) {
+  // d_qt_next != nullptr and groups.n_order > 0 (one-wave launches only): the image's waves pull levels from d_qt_next[img], zeroed here
   // blur_pyr != nullptr (four-wave launches only): the blur of the same images rides in this launch, blur_tiles workgroups per image
   if (n_img <= 0) return;
   const size_t lds = quadtree_lds_bytes(node_cap, rec_cap, sort_cap);
@@ -1348,10 +1490,13 @@ void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const ui
   }
   if (waves_per_tree >= 4)
     hipLaunchKernelGGL(k_quadtree_w4, dim3(n_groups + (bl.pyr ? blur_tiles : 0), n_img), dim3(256), lds + 2048 + 16 + QT_PP_MAX_STRIPS * QT_PP_TOTALS4 * sizeof(uint16_t), s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
-                       d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch, d_qt_tabs, bl);
-  else
+                       d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch, d_qt_tabs, (int32_t*)nullptr, bl);
+  else {
+    int32_t* next = (groups.n_order > 0 && n_groups > 1) ? d_qt_next : nullptr;
+    if (next) (void)hipMemsetAsync(next, 0, (size_t)n_img * sizeof(int32_t), s);
     hipLaunchKernelGGL(k_quadtree, dim3(n_groups, n_img), dim3(64), lds, s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
-                       d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch, d_qt_tabs);
+                       d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch, d_qt_tabs, next);
+  }
 }
 
 }  // namespace orbfe

@@ -427,7 +427,15 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
       for (int l = 0; l < nl; ++l) c->qt_single.mask[l] = 1u << l;
       std::vector<int> order(nl);
       for (int l = 0; l < nl; ++l) order[l] = l;
-      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return c->lv[a].quota > c->lv[b].quota; });
+      // A tree's cost: half of it follows the level's CANDIDATES (the two passes of the pre-partition, the winner scan: ~ the level's
+      // area), half its QUOTA (pops, the sort) -- r5 stamps of a level-0 tree, tools/exp/qt_stamps.sh.  Dealt by quota alone (r3 - r4) the
+      // level-0 tree shared its wave with level 7 and that wave was the launch's critical path: {0,7} {1,6} {2,5} {3,4} -> {0} {1,6} {2,5}
+      // {3,4,7} for 1241 x 376, the longest wave 15 % shorter.
+      std::vector<double> cost(nl);
+      for (int l = 0; l < nl; ++l)
+        cost[l] = (double)c->lv[l].quota / std::max(1, c->lv[0].quota) +
+                  ((double)c->lv[l].reg_w * c->lv[l].reg_h) / std::max(1.0, (double)c->lv[0].reg_w * c->lv[0].reg_h);
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
       auto deal = [&](int ng, QtGroups* out) {
         std::memset(out, 0, sizeof *out);
         std::vector<double> load(ng, 0.0);
@@ -435,9 +443,13 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
           int g = 0;
           for (int k = 1; k < ng; ++k)
             if (load[k] < load[g]) g = k;
-          load[g] += (double)c->lv[l].quota + 1.0;
+          load[g] += cost[l] + 1e-3;
           out->mask[g] |= 1u << l;
         }
+        // several waves per image: they pull the levels in cost order instead (k_quadtree.hip: quadtree_levels); the masks above remain
+        // what a launch without the counter uses
+        out->n_order = ng > 1 ? nl : 0;
+        for (int k = 0; k < nl; ++k) out->order[k] = (uint8_t)order[k];
       };
       for (int k = 0; k < 3; ++k) deal(std::min(nl, 1 << k), &c->qt_groups_of[k]);
     }
@@ -544,7 +556,7 @@ void orbfe_destroy(orbfe_ctx* c) {
   void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_rs_tiles, c->d_pattern, c->d_pyr,     c->d_blur,
                   c->d_scr_a, c->d_scr_c,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_kp,
                   c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos, c->d_kx, c->d_kpl,   c->d_right_u, c->d_depth, c->d_n_match,
-                  c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist, c->d_rowoff_slot, c->d_rowlist_slot, c->d_rs_regions, c->d_rg_xtaps, c->d_rg_ytaps, c->d_qt_big, c->d_qt_tabs};
+                  c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist, c->d_rowoff_slot, c->d_rowlist_slot, c->d_rs_regions, c->d_rg_xtaps, c->d_rg_ytaps, c->d_qt_big, c->d_qt_tabs, c->d_qt_next};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -687,6 +699,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   ALLOC(c->d_qt_tabs, c->qt_tabs.size());
   ALLOC(c->d_sel, M * NF);
   ALLOC(c->d_sel_count, M * NL);
+  ALLOC(c->d_qt_next, M);
   ALLOC(c->d_n_cand, M * NL);
   ALLOC(c->d_n_kp, M);
   ALLOC(c->d_kps, M * NF);

@@ -51,7 +51,8 @@ hipError_t quadtree_configure(size_t lds_bytes);
 void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint32_t* d_cand, uint32_t* d_scr_b, uint32_t* d_scr_c,
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
                      int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree, uint8_t* d_big, size_t big_pitch,
-                     const uint16_t* d_qt_tabs, const uint8_t* blur_pyr, uint8_t* blur_out, size_t img_pitch, const int* blur_taps, int blur_tiles);
+                     const uint16_t* d_qt_tabs, const uint8_t* blur_pyr, uint8_t* blur_out, size_t img_pitch, const int* blur_taps, int blur_tiles,
+                     int32_t* d_qt_next);
 bool quadtree_build_tables(const LevelDev& L, std::vector<uint16_t>& out);
 // k_brief.hip
 void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,
@@ -229,6 +230,7 @@ struct orbfe_ctx {
   size_t img_pitch = 0;      // bytes per image in pyr / blur
   size_t scratch_pitch = 0;  // uint32 records per image
   QtGroups qt_groups_of[3];  // the same for 1, 2 and 4 waves per image (picked by launch size)
+  int32_t* d_qt_next = nullptr;  // [max_images]: the per-image level counter of launches whose waves pull their levels (QtGroups::order)
   QtGroups qt_single;        // one level per wave: launches too small to fill the wave slots (a frame or two: the chain of several trees in one wave would only add latency)
   int rec_cap = 0;           // upper bound of candidate records one quadtree wave keeps in LDS (launch picks <= this)
   int n_cu = 256;            // compute units of the device

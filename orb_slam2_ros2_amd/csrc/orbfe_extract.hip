@@ -130,7 +130,7 @@ orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, hipE
                     c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img, 1, qt_tab, n_groups,
                     // helper waves for the data-parallel phases of a tree where the launch leaves the chip empty (a frame or two)
                     (!grouped && trees * 4 <= c->n_cu * 4) ? 4 : 1, c->d_qt_big ? c->d_qt_big + i0 * c->qt_big_pitch : nullptr,
-                    c->qt_big_pitch, c->d_qt_tabs, blur_in_qt ? pyr : nullptr, blur, c->img_pitch, c->blur_taps, c->bl_tiles);
+                    c->qt_big_pitch, c->d_qt_tabs, blur_in_qt ? pyr : nullptr, blur, c->img_pitch, c->blur_taps, c->bl_tiles, c->d_qt_next + i0);
   }
   {
     StageTimer t(c, ORBFE_STAGE_BRIEF, st, timing);

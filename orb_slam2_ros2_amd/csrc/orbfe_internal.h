@@ -67,6 +67,10 @@ struct RsRegion {
 // k_quadtree: the levels whose trees one wave works through, as bit masks (one per blockIdx.x)
 struct QtGroups {
   uint32_t mask[ORBFE_MAX_LEVELS];
+  // n_order > 0: the waves of an image do not take fixed masks but PULL levels, in this order (most expensive first), from a per-image
+  // counter: list scheduling with the trees' actual durations (a level's candidate count depends on the image)
+  uint8_t order[ORBFE_MAX_LEVELS];
+  int32_t n_order;
 };
 
 // Per pyramid level, resident in device memory (one table per context).

@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../../orb_slam2_ros2_amd/csrc"
 mkdir -p ../../tools/exp/libs /tmp/ab_$1
 FLAGS="-std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-function -I../../include $2"
-for f in orbfe_api k_pyramid k_fast k_quadtree k_brief k_match k_ba k_lba k_lm k_lmbig k_pose k_guided k_glue orbfe_map; do
+for f in $(grep '^SRCS' Makefile | sed 's/SRCS = //; s/\.hip//g'); do
   X=""; [ $f = k_fast ] && X="-mllvm -amdgpu-atomic-optimizer-strategy=None"
   /opt/rocm/bin/hipcc $FLAGS $X -c $f.hip -o /tmp/ab_$1/$f.o 2>/dev/null &
 done
