@@ -151,13 +151,26 @@ __global__ __launch_bounds__(256) void k_ic_moments(const uint8_t* __restrict__ 
   if (sub == 15 && valid) moments[(size_t)img * n_features + k] = make_int2(m10, m01);
 }
 
+// the stereo matcher's view of a keypoint (KpX): getPitch's patch centre is computed HERE, once, with the reference's own float operations
+__device__ __forceinline__ KpX kpx_of(const orbfe_keypoint& kp, float sf) {
+#pragma clang fp contract(off)
+  const float fxq = kp.x / sf, fyq = kp.y / sf;
+  int qx = (int)fxq, qy = (int)fyq;  // cvFloor
+  qx -= (qx > fxq);
+  qy -= (qy > fyq);
+  KpX r;
+  r.x = kp.x;
+  r.q = ORBFE_KPX_Q(kp.octave, qx, qy);
+  return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // 2. orientation: ONE LANE per keypoint.  theta = atan2(m01, m10) and cos/sin in fp64 with the shared
 //    deterministic routines; assembles the cv::KeyPoint record and the stereo row band.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv, const uint4* __restrict__ kpl, int n_features,
                                                 const int2* __restrict__ moments, double2* __restrict__ sincos,
-                                                orbfe_keypoint* __restrict__ kps, KpAux* __restrict__ aux, float* __restrict__ kx,
+                                                orbfe_keypoint* __restrict__ kps, KpAux* __restrict__ aux, KpX* __restrict__ kx,
                                                 double* __restrict__ theta_out, int rows0, const int32_t* __restrict__ sel_count, int n_levels,
                                                 int32_t* __restrict__ n_kp, orbfe_keypoint* __restrict__ kps_host, int32_t* __restrict__ n_kp_host) {
   // kps_host / n_kp_host (nullable): page-locked HOST memory, same [image][n_features] layout -- the host-pointer path of a frame or two
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv,
     kp.class_id = -1;
     kps[o] = kp;
     if (kps_host) kps_host[o] = kp;
-    kx[o] = kp.x;
+    kx[o] = kpx_of(kp, L.sf);
     // createRowIndexDB band (ORBMatcher.cc:924-927), stored with the keypoint for the stereo matcher
     const float r = (float)(2.0 * (double)L.sf);
     const unsigned row = (unsigned)__float2int_rn(kp.y);
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(256) void k_list_moments_orient(const LevelDev* __r
                                                              const int32_t* __restrict__ sel_count, int n_features,
                                                              const uint8_t* __restrict__ pyr, size_t img_pitch, UmaxPacked umax,
                                                              uint4* __restrict__ kpl, int2* __restrict__ moments, double2* __restrict__ sincos,
-                                                             orbfe_keypoint* __restrict__ kps, KpAux* __restrict__ aux, float* __restrict__ kx,
+                                                             orbfe_keypoint* __restrict__ kps, KpAux* __restrict__ aux, KpX* __restrict__ kx,
                                                              double* __restrict__ theta_out, int rows0, int32_t* __restrict__ n_kp,
                                                              orbfe_keypoint* __restrict__ kps_host, int32_t* __restrict__ n_kp_host) {
 #pragma clang fp contract(off)
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(256) void k_list_moments_orient(const LevelDev* __r
   kp.class_id = -1;
   kps[o] = kp;
   if (kps_host) kps_host[o] = kp;
-  kx[o] = kp.x;
+  kx[o] = kpx_of(kp, L.sf);
   const float r = (float)(2.0 * (double)L.sf);
   const unsigned row = (unsigned)__float2int_rn(kp.y);
   KpAux a;
@@ -512,7 +525,7 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_e
 void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
-                         int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx,
+                         int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, KpX* d_kx,
                          uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief, hipEvent_t before_lists, orbfe_keypoint* h_kps,
                          uint8_t* h_desc, int32_t* h_n_kp, bool fuse_small, uint32_t* d_rowoff_slot, uint16_t* d_rowlist_slot, int32_t* d_n_match,
                          int rt_rows, int rt_list_cap, int rt_slot0) {

@@ -58,7 +58,7 @@ bool quadtree_build_tables(const LevelDev& L, std::vector<uint16_t>& out);
 void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
                          const int8_t* d_pattern, const int umax[16], orbfe_keypoint* d_kps, uint8_t* d_desc, KpAux* d_aux,
-                         int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, float* d_kx,
+                         int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, KpX* d_kx,
                          uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief, hipEvent_t before_lists, orbfe_keypoint* h_kps, uint8_t* h_desc, int32_t* h_n_kp,
                          bool fuse_small, uint32_t* d_rowoff_slot = nullptr, uint16_t* d_rowlist_slot = nullptr,
                          int32_t* d_n_match = nullptr, int rt_rows = 0, int rt_list_cap = 0, int rt_slot0 = 0);
@@ -66,10 +66,11 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
 void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, const uint32_t* d_off,
                              const uint32_t* d_cand, int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second);
 void launch_stereo(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, size_t img_pitch, const orbfe_keypoint* d_kps,
-                   const uint8_t* d_desc, const KpAux* d_aux, const float* d_kx, uint32_t* d_rowoff, uint16_t* d_rowlist, int rows, int list_cap,
+                   const uint8_t* d_desc, const KpAux* d_aux, const KpX* d_kx, uint32_t* d_rowoff, uint16_t* d_rowlist, int rows, int list_cap,
                    const int32_t* d_n_kp, int n_features, float fx, float bf, int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
                    int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs, double* h_right_u, double* h_depth,
-                   int32_t* h_best_right, int32_t* h_best_dist, bool table_ready = false);
+                   int32_t* h_best_right, int32_t* h_best_dist, bool table_ready = false, uint2* d_lrange = nullptr,
+                   const StereoRowsBuf* rowsbuf = nullptr);
 // k_glue.hip
 void launch_cvt_gray(hipStream_t s, const uint8_t* d_src, size_t src_stride, uint8_t* d_dst, int dst_stride, int w, int h, int order,
                      int variant);
@@ -257,7 +258,9 @@ struct orbfe_ctx {
   uint4* d_kpl = nullptr;        // level-major keypoint list {x | y<<16, level | response<<8, plane offset, row stride}
   int2* d_moments = nullptr;     // per keypoint (m10, m01)
   double2* d_sincos = nullptr;   // per keypoint (sin, cos) of the orientation
-  float* d_kx = nullptr;         // per keypoint x (level-0 coordinates), SoA copy for the stereo candidate scan
+  KpX* d_kx = nullptr;           // per keypoint x (level-0 coordinates) + octave / patch centre: what the stereo match reads per candidate
+  StereoRowsBuf st_rows = {nullptr, nullptr, nullptr, nullptr};  // the row-parallel matcher's buffers (batches)
+  uint2* d_lrange = nullptr;     // [pairs][n_features]: a LEFT keypoint's candidate range in its pair's row list (k_rowtable writes it)
   uint32_t* d_rowoff = nullptr;  // per pair: offsets[height + 1] of the right image's row table (createRowIndexDB)
   uint16_t* d_rowlist = nullptr; // per pair: the table's entries, row_list_cap = n_features x the widest band
   int row_list_cap = 0;

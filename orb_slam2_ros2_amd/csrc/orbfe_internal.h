@@ -124,6 +124,23 @@ struct KpAux {
   int16_t row_min, row_max;  // [row_min, row_max)
 };
 
+// what the stereo matcher reads of a RIGHT keypoint per candidate (8 bytes next to each other): x in level-0 coordinates (the disparity range
+// test, ORBMatcher.cc:44-48) and what pixelSADMatch needs of the winner -- octave and the patch centre getPitch computes,
+// cvFloor(pt / scale[octave]) (ORBMatcher.cc:1004-1006) -- so that the best candidate's keypoint record is not a memory round trip of its own
+struct KpX {
+  float x;
+  uint32_t q;  // octave (3 bits) | cvFloor(pt.x / sf) << 3 (13 bits) | cvFloor(pt.y / sf) << 16
+};
+#define ORBFE_KPX_Q(oct, qx, qy) ((uint32_t)(oct) | ((uint32_t)(qx) << 3) | ((uint32_t)(qy) << 16))
+
+// device buffers of the batches' row-parallel stereo matcher (k_match.hip), per pair
+struct StereoRowsBuf {
+  uint32_t* lrow_off;
+  uint16_t* lrow_list;
+  uint4* work;
+  int32_t* work_n;
+};
+
 // local BA: non-fixed keyframes the dense reduced solver takes (its panel, right-hand side and diagonal blocks live in 64 KB of LDS)
 #define LBA_MAX_FREE 100
 
