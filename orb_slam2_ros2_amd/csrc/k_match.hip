@@ -424,6 +424,8 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
 // 128 words of patches per keypoint + ST4_PAD: with a pitch of exactly 128 words the four keypoints of a wave read the same LDS banks at every
 // step of the SAD loop (a four-way conflict on every one of its 242 byte reads per lane)
 #define ST4_WORDS (11 * 4 + 11 * 7 + 7 + ST4_PAD)
+// k_stereo_sad: 121 words of patches + 11 rows x 8 words of 16-bit left values, + 7: a pitch of 216 words puts the wave's four entries 24 banks apart
+#define ST5_WORDS (124 + 88 + 4)
 __device__ __forceinline__ int row_min_i(int v, int lane) {  // minimum over the lane's row of 16, in every lane of the row
   v = dpp_min_step<0x111, 0xf>(v);
   v = dpp_min_step<0x112, 0xf>(v);
@@ -711,7 +713,8 @@ __global__ __launch_bounds__(256) void k_stereo_sad(const LevelDev* __restrict__
                                                     const KpX* __restrict__ kx, int n_features, float bf, int cols0, StereoRows sr,
                                                     int32_t* __restrict__ n_match, int slot_l0, int slot_r0, int slot_step, int pair0) {
 #pragma clang fp contract(off)
-  __shared__ uint32_t s_sad[4][4][ST4_WORDS];  // per wave, per entry: left 11 rows x 4 words, right 11 rows x 7 words
+  // per wave, per entry: left 11 rows x 4 words | right 11 rows x 7 words | the left patch again as 16-bit values (pl - c1 + 255), 11 rows of 8 words
+  __shared__ __attribute__((aligned(16))) uint32_t s_sad[4][4][ST5_WORDS];
   __shared__ float s_sf[16];
   __shared__ uint32_t s_off[16];
   __shared__ int s_stride[16];
@@ -769,19 +772,46 @@ __global__ __launch_bounds__(256) void k_stereo_sad(const LevelDev* __restrict__
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // LDS accesses of one wave execute in order; this only pins the compiler
     const uint8_t* bl = (const uint8_t*)wl + ((lx - 5) - lxa);
-    const uint8_t* br = (const uint8_t*)wr + ((rx - 10) - rxa);
     const int c1 = bl[5 * 16 + 5];
+    // SAD() subtracts each patch's OWN centre pixel (ORBMatcher.cc:893-905): sum |(pl - c1) - (pr - c2)| = sum |(pl - c1 + 255) - (pr - c2 + 255)|,
+    // both sides in 0 .. 510.  The left side does not depend on the shift: the row's 16 lanes write it ONCE as 16-bit values, two per word
+    // (a row = 11 values + a zero = 6 words, pitch 8), so that a lane's row is three LDS reads on the left, two on the right and
+    // v_sad_u16 on PAIRS of pixels -- byte by byte a lane issued 242 LDS reads and 363 vector instructions per patch (r5: this kernel is
+    // what is left of the match on images with many stereo matches).
+    uint16_t* lp16 = (uint16_t*)(wl + 124);  // (16-byte aligned: the rows are read as 16 + 8 bytes)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int t = sub + 16 * it;
+      if (t < 121) {
+        const int rr = (t * 373) >> 12, cc = t - rr * 11;  // t / 11 for t < 121
+        lp16[rr * 16 + cc] = (uint16_t)((int)bl[rr * 16 + cc] - c1 + 255);
+      }
+    }
+    if (sub < 11) lp16[sub * 16 + 11] = 0;  // the twelfth value of a row: zero on both sides
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     int sad = ORB_INT_MAX;
     if (sub < 11) {
-      // each shifted right patch subtracts ITS OWN centre pixel (SAD(), ORBMatcher.cc:901-903)
-      const uint32_t c2 = br[5 * 28 + 5 + sub];
+      const int s_off_b = ((rx - 10) - rxa) + sub;       // byte offset of this lane's shifted patch inside a staged right row (0 .. 13)
+      const uint8_t* brc = (const uint8_t*)wr + s_off_b;
+      const uint32_t k2 = 255u - (uint32_t)brc[5 * 28 + 5];  // 255 - c2
+      const uint32_t K = k2 | (k2 << 16);
+      const uint32_t* rw = wr + (s_off_b >> 2);
+      const uint32_t sh = (uint32_t)(s_off_b & 3);
+      const uint32_t* lw = wl + 124;
       uint32_t acc = 0;
-      for (int rr = 0; rr < 11; ++rr) {
-        const uint8_t* pl = bl + rr * 16;
-        const uint8_t* pr = br + rr * 28 + sub;
 #pragma unroll
-        for (int cc = 0; cc < 11; ++cc)  // |(pl - c1) - (pr - c2)| = |(pl + c2) - (pr + c1)|, both sides non-negative: one v_sad_u32
-          acc = __builtin_amdgcn_sad_u16((uint32_t)pl[cc] + c2, (uint32_t)pr[cc] + (uint32_t)c1, acc);
+      for (int rr = 0; rr < 11; ++rr) {
+        const uint32_t r0 = rw[rr * 7], r1 = rw[rr * 7 + 1], r2 = rw[rr * 7 + 2], r3 = rw[rr * 7 + 3];
+        const uint32_t R0 = __builtin_amdgcn_alignbyte(r1, r0, sh), R1 = __builtin_amdgcn_alignbyte(r2, r1, sh), R2 = __builtin_amdgcn_alignbyte(r3, r2, sh);
+        const uint4 q03 = *(const uint4*)(lw + rr * 8);
+        const uint2 q45 = *(const uint2*)(lw + rr * 8 + 4);
+        acc = __builtin_amdgcn_sad_u16(q03.x, __builtin_amdgcn_perm(0u, R0, 0x0c010c00u) + K, acc);
+        acc = __builtin_amdgcn_sad_u16(q03.y, __builtin_amdgcn_perm(0u, R0, 0x0c030c02u) + K, acc);
+        acc = __builtin_amdgcn_sad_u16(q03.z, __builtin_amdgcn_perm(0u, R1, 0x0c010c00u) + K, acc);
+        acc = __builtin_amdgcn_sad_u16(q03.w, __builtin_amdgcn_perm(0u, R1, 0x0c030c02u) + K, acc);
+        acc = __builtin_amdgcn_sad_u16(q45.x, __builtin_amdgcn_perm(0u, R2, 0x0c010c00u) + K, acc);
+        acc = __builtin_amdgcn_sad_u16(q45.y, __builtin_amdgcn_perm(0u, R2, 0x0c0c0c02u) + k2, acc);  // pixel 10 | the zero
       }
       sad = (int)acc;
     }
