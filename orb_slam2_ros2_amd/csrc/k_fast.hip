@@ -55,6 +55,27 @@ namespace orbfe {
 #define Q_BRIGHT 0x4000u
 #define Q_DUAL 0x8000u  // both polarities passed the necessary test: the main entry scores the dark one
 
+#ifndef FAST_OPS16
+#define FAST_OPS16 1
+#endif
+#if FAST_OPS16
+__device__ __forceinline__ int fast_min16(int a, int b) {
+  int d;
+  asm("v_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ int fast_max16(int a, int b) {
+  int d;
+  asm("v_max_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+#define FAST_MIN16(a, b) fast_min16(a, b)
+#define FAST_MAX16(a, b) fast_max16(a, b)
+#else
+#define FAST_MIN16(a, b) min(a, b)
+#define FAST_MAX16(a, b) max(a, b)
+#endif
+
 __device__ __forceinline__ int mbcnt64(unsigned long long m, int acc) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)acc));
 }
@@ -277,8 +298,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             const int v = a[3 * PP + 3];
             const int r0 = a[6 * PP + 3], r8 = a[3], r4 = a[3 * PP + 6], r12 = a[3 * PP];
             const int r2 = a[5 * PP + 5], r10 = a[PP + 1], r6 = a[PP + 5], r14 = a[5 * PP + 1];
-            const int lo_of_hi = min(min(max(r0, r8), max(r4, r12)), min(max(r2, r10), max(r6, r14)));
-            const int hi_of_lo = max(max(min(r0, r8), min(r4, r12)), max(min(r2, r10), min(r6, r14)));
+            // (the 14 minima / maxima as 16-BIT instructions: on gfx950 the non-packed 16-bit VOP2 arithmetic goes through a SIMD at ~1.8 x
+            //  the rate of the 32-bit v_min / v_max / v_min3 at eight waves per SIMD -- profiles/r5_valu_census.txt -- and the operands are
+            //  bytes; the results' upper halves are zero on this generation, so the 32-bit subtractions below read them as they are)
+            const int lo_of_hi = FAST_MIN16(FAST_MIN16(FAST_MAX16(r0, r8), FAST_MAX16(r4, r12)), FAST_MIN16(FAST_MAX16(r2, r10), FAST_MAX16(r6, r14)));
+            const int hi_of_lo = FAST_MAX16(FAST_MAX16(FAST_MIN16(r0, r8), FAST_MIN16(r4, r12)), FAST_MAX16(FAST_MIN16(r2, r10), FAST_MIN16(r6, r14)));
             const int sb = lo_of_hi - v;  // > t: every opposite pair has a pixel brighter than v + t
             const int sd = v - hi_of_lo;  // > t: ... darker than v - t
             // two compares; their lane masks are combined on the SCALAR unit and handed back as lane predicates (inverse ballot: the

@@ -70,8 +70,16 @@
   X(60, "v_pk_lshlrev_b16 %0, 1, %0", a, c1, c2)                                 \
   X(61, "v_cvt_pk_u8_f32 %0, %1, 0, %0", a, g1, c2)                              \
   X(62, "v_alignbit_b32 %0, %0, %1, 8", a, c1, c2)                               \
-  X(63, "v_bfi_b32 %0, %0, %1, %2", a, c1, c2)
-#define N_OPS 64
+  X(63, "v_bfi_b32 %0, %0, %1, %2", a, c1, c2)                                  \
+  X(64, "v_sub_u16 %0, %0, %1", a, c1, c2)                                       \
+  X(65, "v_min_u16 %0, %0, %1", a, c1, c2)                                       \
+  X(66, "v_add_u16 %0, %0, %1", a, c1, c2)                                       \
+  X(67, "v_max_i16 %0, %0, %1", a, c1, c2)                                       \
+  X(68, "v_cmp_gt_i16 vcc, %0, %1", a, c1, c2)                                   \
+  X(69, "v_subrev_u16 %0, %0, %1", a, c1, c2)                                    \
+  X(70, "v_lshrrev_b16 %0, 1, %0", a, c1, c2)                                    \
+  X(71, "v_mul_lo_u16 %0, %0, %1", a, c1, c2)
+#define N_OPS 72
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(uint32_t* out, int iters) {
