@@ -761,6 +761,13 @@ def latency_leg(device_id, n=500):
                 "what": "the same Frame built by orbfe::dropin::createStereo (ORBExtractor::extractStereo -> orbfe_frame_stereo_slots): both "
                         "extractions and the stereo match as one device call in place of the two threads and searchByStereo; every frame "
                         "hashed equal to the two-thread one"}
+        if len(f) >= 15:
+            out["two_threads_eager_start"] = {
+                "median_ms": float(f[13]) / 1e3, "p99_ms": float(f[14]) / 1e3,
+                "what": "the reference's own shape again -- two extractor objects, two std::threads, searchByStereo -- with "
+                        "orbfe::ORBExtractor::eagerStart(): the constructors (which run before the threads exist, Frame.cc:91-92, and build the "
+                        "pyramid in the reference) enqueue the extraction (orbfe_extract_slot_begin), extract() collects it: the device works while "
+                        "the threads are created"}
         out["cpp_hw_queues"] = env.get("GPU_MAX_HW_QUEUES", "unset (runtime default)")
     except (subprocess.CalledProcessError, RuntimeError, OSError) as ex:
         out["two_threads_extract_slot_plus_match"] = {"error": f"{type(ex).__name__}: {ex}"}

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define ORBFE_ABI_VERSION 3
+#define ORBFE_ABI_VERSION 4
 #define ORBFE_MAX_LEVELS 16
 #define ORBFE_DESC_BYTES 32
 
@@ -126,6 +126,15 @@ orbfe_status orbfe_extract_batch(orbfe_ctx* ctx, int32_t n_img, const uint8_t* c
  * stay resident in the slot for orbfe_stereo_match(ctx, slot_left, slot_right, ..) / orbfe_get_pyramid / orbfe_search_in_area.   */
 orbfe_status orbfe_extract_slot(orbfe_ctx* ctx, int32_t slot, const uint8_t* img, size_t stride_bytes, orbfe_keypoint* kps,
                                 uint8_t* desc, int32_t* n_out);
+/* orbfe_extract_slot in two halves (ABI 4).  _begin stages the image and enqueues the whole extraction on the slot's lane, then RETURNS;
+ * _end waits for it and delivers what orbfe_extract_slot delivers (kps / desc may be NULL: only the count; all NULL: just drain).  For the
+ * reference's own construction order: `ORBExtractor::ORBExtractor(image, ...)` runs on the constructing thread BEFORE Frame::Frame starts
+ * its two extract() threads (src/ORB_SLAM2/src/Frame.cc:91-105) and already does the pyramid there (src/ORBExtractor.cc:205-214) -- a
+ * constructor that calls _begin lets the device work while the std::threads are being created (30 - 50 us each, p99 80 - 130 us on the
+ * GPU boxes of the pool), and extract() is then only _end.  The image must stay readable until _begin returns; between _begin and _end
+ * the slot accepts no other call (ORBFE_EBADARG), and every _begin must be followed by an _end, from any thread.                       */
+orbfe_status orbfe_extract_slot_begin(orbfe_ctx* ctx, int32_t slot, const uint8_t* img, size_t stride_bytes);
+orbfe_status orbfe_extract_slot_end(orbfe_ctx* ctx, int32_t slot, orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out);
 /* The same for n_img images into the consecutive slots slot .. slot + n_img - 1 as ONE launch sequence on slot's lane (arrays as
  * orbfe_extract_batch): both eyes of a stereo frame when one caller holds both images, about half the time of two slot calls.  (The C++
  * mirror keeps one orbfe_extract_slot per extract() thread, src/Frame.cc:100-105: pairing the two threads into one such call was

@@ -119,7 +119,7 @@ class BaEdgeOut(C.Structure):
 EXPORTS = [
     "orbfe_abi_version", "orbfe_create", "orbfe_destroy", "orbfe_last_error", "orbfe_get_level_info", "orbfe_get_scale_factors",
     "orbfe_get_capacity",
-    "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_slot", "orbfe_extract_slots", "orbfe_frame_stereo", "orbfe_frame_stereo_slots", "orbfe_frame_rgbd_image", "orbfe_track_motion_model", "orbfe_fetch_batch", "orbfe_fetch_stereo_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
+    "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_slot", "orbfe_extract_slot_begin", "orbfe_extract_slot_end", "orbfe_extract_slots", "orbfe_frame_stereo", "orbfe_frame_stereo_slots", "orbfe_frame_rgbd_image", "orbfe_track_motion_model", "orbfe_fetch_batch", "orbfe_fetch_stereo_batch", "orbfe_get_pyramid", "orbfe_stereo_match", "orbfe_stereo_batch_device", "orbfe_sync",
     "orbfe_host_alloc", "orbfe_host_alloc_on", "orbfe_host_free", "orbfe_recommended_hw_queues", "orbfe_stream_submit", "orbfe_stream_wait", "orbfe_stream_device_results", "orbfe_record_bytes", "orbfe_stream_pack_records",
     "orbfe_fetch_features", "orbfe_fetch_stereo", "orbfe_device_results", "orbfe_match_bruteforce", "orbfe_ba_eval_edges", "orbfe_ba_build_system", "orbfe_ba_local_optimize", "orbfe_pose_only_optimize", "orbfe_search_in_area", "orbfe_search_in_area_features", "orbfe_search_in_area_features_ex", "orbfe_extract_color", "orbfe_frame_rgbd", "orbfe_project_map_points", "orbfe_track_local_map",
     "orbfe_map_pb_summary", "orbfe_map_pb_reencode", "orbfe_map_pb_to_txt", "orbfe_map_txt_to_pb", "orbfe_map_local_graph", "orbfe_map_local_ba",
@@ -158,6 +158,8 @@ def load() -> C.CDLL:
     L.orbfe_get_capacity.restype = i32
     L.orbfe_extract.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
     L.orbfe_extract_batch.argtypes = [vp, i32, vp, C.c_size_t, vp, vp, vp]
+    L.orbfe_extract_slot_begin.argtypes = [vp, i32, vp, C.c_size_t]
+    L.orbfe_extract_slot_end.argtypes = [vp, i32, vp, vp, vp]
     L.orbfe_extract_slot.argtypes = [vp, i32, vp, C.c_size_t, vp, vp, vp]
     L.orbfe_extract_slots.argtypes = [vp, i32, i32, vp, C.c_size_t, vp, vp, vp]
     L.orbfe_frame_rgbd_image.argtypes = [vp, i32, vp, C.c_size_t, i32, vp, vp, i32, C.c_size_t, C.c_float, vp, vp, vp, vp, vp]
@@ -416,6 +418,24 @@ class Context:
         desc = np.zeros((nf, 32), np.uint8)
         n = C.c_int32(0)
         self._check(self.lib.orbfe_extract_slot(self.h, slot, img.ctypes.data, img.strides[0], ptr(kps), ptr(desc), C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_slot_begin(self, slot, img):
+        """orbfe_extract_slot in two halves: stage the image and enqueue the extraction on the slot's lane, return at once"""
+        img = np.asarray(img)
+        if img.shape != (self.height, self.width):
+            raise ValueError(f"image shape {img.shape} != context geometry {(self.height, self.width)}")
+        if not (img.dtype == np.uint8 and img.strides[1] == 1 and img.strides[0] >= self.width):
+            img = np.ascontiguousarray(img, np.uint8)
+        self._check(self.lib.orbfe_extract_slot_begin(self.h, slot, img.ctypes.data, img.strides[0]))
+
+    def extract_slot_end(self, slot):
+        """... wait for it and deliver what extract_slot delivers"""
+        nf = max(self.n_features, 1)
+        kps = np.zeros(nf, KP_DTYPE)
+        desc = np.zeros((nf, 32), np.uint8)
+        n = C.c_int32(0)
+        self._check(self.lib.orbfe_extract_slot_end(self.h, slot, ptr(kps), ptr(desc), C.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
 
     def extract_slots(self, slot0, imgs):

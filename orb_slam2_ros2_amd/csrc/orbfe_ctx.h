@@ -174,6 +174,7 @@ struct orbfe_ctx {
     size_t h_stage_bytes = 0;
     std::vector<GraphEntry> graphs;
     bool use_graphs = true;
+    bool pending = false;  // orbfe_extract_slot_begin has enqueued an extraction that orbfe_extract_slot_end has not collected yet
   };
   // Host-image stream (orbfe_stream_submit / _wait): batch k+1 is uploaded and the packed results of batch k-1 are downloaded while
   // batch k is computed.  kDepth (three) input and result buffers on the device, one copy stream per direction.

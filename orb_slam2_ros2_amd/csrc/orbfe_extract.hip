@@ -237,7 +237,9 @@ struct FrameRgbdKey {  // what of a request is baked into a captured launch sequ
 };
 static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, int n_img, const uint8_t* const* imgs, size_t stride,
                                  orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out, bool timing, const FrameStereoReq* fs = nullptr,
-                                 const FrameRgbdReq* fr = nullptr) {
+                                 const FrameRgbdReq* fr = nullptr, int phase = 0) {
+  // phase 0: the whole call | 1: stage + enqueue, then return (orbfe_extract_slot_begin: kps / desc non-NULL markers, nothing is written
+  // through them) | 2: wait + deliver (orbfe_extract_slot_end; imgs is not looked at)
   const LevelDev& L0 = c->lv[0];
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
   const bool color = fr && fr->color_order != 0;
@@ -250,7 +252,7 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
   const size_t d_bytes = (fr && fr->depth) ? fr->depth_stride * (size_t)c->cfg.height : 0;
   const size_t total = o_dimg + align_up(d_bytes, 256);
   TRY(ensure_stage(c, ln, total));
-  for (int i = 0; i < n_img; ++i) {
+  for (int i = 0; i < n_img && phase != 2; ++i) {
     if (!imgs[i]) return fail(c, ORBFE_EBADARG, "extract: image %d is NULL", i);
     uint8_t* dst = ln.h_stage + (size_t)i * plane;
     if (color)
@@ -267,7 +269,7 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
     rkey.depth_stride = fr->depth_stride, rkey.depth_scale = fr->depth_scale, rkey.cam = fr->cam;
   }
   uint8_t* const pyr_now = c->d_pyr;
-  note_slots_written(c, slot0, n_img, n_img <= 2);  // (also when a captured graph is replayed: run_extract does not run then)
+  if (phase != 2) note_slots_written(c, slot0, n_img, n_img <= 2);  // (also when a captured graph is replayed: run_extract does not run then)
   // The results come back through the staging buffer too: the orientation and the descriptor kernels write keypoints, counts and
   // descriptors there themselves (posted PCIe writes, ~120 KB per image) beside the device arrays the stereo match reads -- three
   // device-to-host copies queued behind the last kernel cost ~17 us of a ~0.3 ms call.  More than two images: the copies.
@@ -325,6 +327,7 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
     }
     return ORBFE_OK;
   };
+  if (phase == 2) return finish();
   if (c->use_graphs && ln.use_graphs && c->prof == 0 && n_img <= 2) {
     hipGraphExec_t exec = nullptr;
     for (auto it = ln.graphs.begin(); it != ln.graphs.end();) {
@@ -359,11 +362,11 @@ static orbfe_status extract_lane(orbfe_ctx* c, orbfe_ctx::Lane& ln, int slot0, i
     }
     if (exec) {
       HIP_TRY(c, hipGraphLaunch(exec, ln.stream));
-      return finish();
+      return phase == 1 ? ORBFE_OK : finish();
     }
   }
   TRY(enqueue_all());
-  return finish();
+  return phase == 1 ? ORBFE_OK : finish();
 }
 
 orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* const* imgs, size_t stride, orbfe_keypoint* kps,
@@ -405,12 +408,12 @@ orbfe_status orbfe_extract_slot(orbfe_ctx* c, int32_t slot, const uint8_t* img, 
 // n_img images -> slots [slot0, slot0 + n_img) on slot0's lane: what a caller does who holds BOTH images of a stereo frame when the
 // first extract() is reached (host/orbfe_shim.hpp keeps one orbfe_extract_slot per extract() thread: pairing the threads was measured and dropped)
 static orbfe_status extract_slots_impl(orbfe_ctx* c, int32_t slot, int32_t n_img, const uint8_t* const* imgs, size_t stride, orbfe_keypoint* kps,
-                                       uint8_t* desc, int32_t* n_out, const FrameStereoReq* fs, const FrameRgbdReq* fr = nullptr) {
+                                       uint8_t* desc, int32_t* n_out, const FrameStereoReq* fs, const FrameRgbdReq* fr = nullptr, int phase = 0) {
   if (!c || !imgs || n_img < 1) return fail(c, ORBFE_EBADARG, "extract_slots: NULL argument / no image");
   const uint8_t* img = imgs[0];
-  if (!img) return fail(c, ORBFE_EBADARG, "extract_slot: NULL argument");
+  if (!img && phase != 2) return fail(c, ORBFE_EBADARG, "extract_slot: NULL argument");
   if (slot < 0 || slot + n_img > c->cfg.max_images) return fail(c, ORBFE_EBADARG, "extract_slot: slots %d..%d of %d", slot, slot + n_img - 1, c->cfg.max_images);
-  if (stride < (size_t)c->cfg.width * ((fr && fr->color_order) ? 3 : 1)) return fail(c, ORBFE_EBADARG, "extract_slot: stride %zu < the row's %d bytes", stride, c->cfg.width * ((fr && fr->color_order) ? 3 : 1));
+  if (phase != 2 && stride < (size_t)c->cfg.width * ((fr && fr->color_order) ? 3 : 1)) return fail(c, ORBFE_EBADARG, "extract_slot: stride %zu < the row's %d bytes", stride, c->cfg.width * ((fr && fr->color_order) ? 3 : 1));
   HIP_TRY(c, hipSetDevice(c->device));
   // the lanes of EVERY slot the call writes, created on first use and locked in index order (a concurrent slot call on any of them waits;
   // two multi-slot calls cannot deadlock); the work runs on the first slot's lane
@@ -435,6 +438,13 @@ static orbfe_status extract_slots_impl(orbfe_ctx* c, int32_t slot, int32_t n_img
   held.reserve(lanes.size());
   for (orbfe_ctx::Lane* l : lanes) held.emplace_back(l->mu);
   orbfe_ctx::Lane* ln = lanes[0];
+  for (orbfe_ctx::Lane* l : lanes)
+    if (l->pending != (phase == 2)) return fail(c, ORBFE_EBADARG, phase == 2 ? "extract_slot_end: no orbfe_extract_slot_begin is outstanding on slot %d"
+                                                                               : "extract_slot: slot %d has an outstanding orbfe_extract_slot_begin", slot);
+  if (phase == 2) {
+    ln->pending = false;
+    return extract_lane(c, *ln, slot, n_img, imgs, stride, kps, desc, n_out, false, nullptr, nullptr, 2);
+  }
   // a stereo match of an earlier device batch may still be reading the slot arrays (the flag is only read here: the calls that
   // change it must not overlap with slot calls)
   if (c->stereo_pending) HIP_TRY(c, hipStreamWaitEvent(ln->stream, c->ev_stereo_done, 0));
@@ -446,8 +456,21 @@ static orbfe_status extract_slots_impl(orbfe_ctx* c, int32_t slot, int32_t n_img
     HIP_TRY(c, hipEventRecord(ln->ev_main, c->stream));
     HIP_TRY(c, hipStreamWaitEvent(ln->stream, ln->ev_main, 0));
   }
-  return extract_lane(c, *ln, slot, n_img, imgs, stride, kps, desc, n_out, false, fs, fr);
+  const orbfe_status st = extract_lane(c, *ln, slot, n_img, imgs, stride, kps, desc, n_out, false, fs, fr, phase);
+  if (phase == 1 && st == ORBFE_OK) ln->pending = true;
+  return st;
 }
+orbfe_status orbfe_extract_slot_begin(orbfe_ctx* c, int32_t slot, const uint8_t* img, size_t stride) {
+  const uint8_t* one[1] = {img};
+  static orbfe_keypoint kp_marker;  // (non-NULL: the launch sequence mirrors keypoints and descriptors into the staging buffer; nothing is written here)
+  static uint8_t desc_marker;
+  return extract_slots_impl(c, slot, 1, one, stride, &kp_marker, &desc_marker, nullptr, nullptr, nullptr, 1);
+}
+orbfe_status orbfe_extract_slot_end(orbfe_ctx* c, int32_t slot, orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out) {
+  const uint8_t* one[1] = {nullptr};
+  return extract_slots_impl(c, slot, 1, one, 0, kps, desc, n_out, nullptr, nullptr, 2);
+}
+
 orbfe_status orbfe_extract_slots(orbfe_ctx* c, int32_t slot, int32_t n_img, const uint8_t* const* imgs, size_t stride, orbfe_keypoint* kps,
                                  uint8_t* desc, int32_t* n_out) {
   return extract_slots_impl(c, slot, n_img, imgs, stride, kps, desc, n_out, nullptr);

@@ -191,6 +191,24 @@ class ORBExtractor {
     mnFeats = orbfe_get_capacity(mCtx);  // array stride: nFeatures, or more where the reference's rounded quotas exceed it
     mScales.resize(pyramidLevels);
     check(mCtx, orbfe_get_scale_factors(mCtx, mScales.data(), pyramidLevels));
+    if (eagerStart()) {  // the device starts on the image NOW, as the reference's constructor builds the pyramid now (src/ORBExtractor.cc:205-214)
+      mLease = ContextPool::acquire(mCtx);
+      check(mCtx, orbfe_extract_slot_begin(mCtx, mLease.slot, mImage.data, mImage.step));
+      mStarted = true;
+    }
+  }
+  ~ORBExtractor() {
+    if (mStarted) (void)orbfe_extract_slot_end(mCtx, mLease.slot, nullptr, nullptr, nullptr);  // an extraction nobody collected: drain the slot
+  }
+  ORBExtractor(const ORBExtractor&) = delete;
+  ORBExtractor& operator=(const ORBExtractor&) = delete;
+  // Process-wide switch (default off): the constructor enqueues the extraction (orbfe_extract_slot_begin) and extract() only collects it.
+  // For callers that keep the reference's Frame::Frame as it is -- two extractor objects built on the constructing thread, then one
+  // std::thread per extract() (src/Frame.cc:91-105): the device works while the threads are being created and scheduled (30 - 50 us each,
+  // the tail of that call shape).  Leave it off where a frame is built by extractStereo / extractRGBD (one device call: INTEGRATION 2b).
+  static bool& eagerStart() {
+    static bool on = false;
+    return on;
   }
 
   // ORBExtractor::extract (src/ORBExtractor.cc:499-508).  Thread-safe against extract() of OTHER objects (Frame.cc:100-105).
@@ -208,8 +226,13 @@ class ORBExtractor {
       keyPoints.resize(mnFeats);
       descriptors.resize(mnFeats);
       int32_t n = 0;
-      mLease = ContextPool::acquire(mCtx);
-      check(mCtx, orbfe_extract_slot(mCtx, mLease.slot, mImage.data, mImage.step, keyPoints.data(), descriptors.data()->data(), &n));
+      if (mStarted) {  // the constructor enqueued it (eagerStart): collect
+        mStarted = false;
+        check(mCtx, orbfe_extract_slot_end(mCtx, mLease.slot, keyPoints.data(), descriptors.data()->data(), &n));
+      } else {
+        mLease = ContextPool::acquire(mCtx);
+        check(mCtx, orbfe_extract_slot(mCtx, mLease.slot, mImage.data, mImage.step, keyPoints.data(), descriptors.data()->data(), &n));
+      }
       keyPoints.resize(n);
       descriptors.resize(n);
       mnKeyPoints = n;
@@ -243,6 +266,7 @@ class ORBExtractor {
                     std::vector<orbfe_keypoint>& kpsRight, std::vector<Descriptor>& descRight, std::vector<double>& rightU,
                     std::vector<double>& depths) {
     rethrowPending(), right.rethrowPending();
+    drainStarted(), right.drainStarted();
     if (mCtx != right.mCtx) throw std::logic_error("extractStereo: the two extractors differ in geometry / parameters");
     if (mImage.step != right.mImage.step) throw std::logic_error("extractStereo: the two images differ in row stride");
     const size_t cap = (size_t)mnFeats;
@@ -268,6 +292,7 @@ class ORBExtractor {
                    std::vector<orbfe_keypoint>& undistorted, std::vector<Descriptor>& descriptors, std::vector<double>& depths,
                    std::vector<double>& rightU) {
     rethrowPending();
+    drainStarted();
     undistorted.resize(mnFeats), descriptors.resize(mnFeats), depths.resize(mnFeats), rightU.resize(mnFeats);
     int32_t n = 0;
     mLease = ContextPool::acquire(mCtx);
@@ -308,6 +333,12 @@ class ORBExtractor {
   orbfe_ctx* mCtx = nullptr;
   ContextPool::Lease mLease;
   std::vector<float> mScales;
+  bool mStarted = false;  // eagerStart: the constructor's orbfe_extract_slot_begin is outstanding
+  void drainStarted() {
+    if (!mStarted) return;
+    mStarted = false;
+    check(mCtx, orbfe_extract_slot_end(mCtx, mLease.slot, nullptr, nullptr, nullptr));
+  }
   std::thread::id mOwner = std::this_thread::get_id();  // the constructing thread (Frame::Frame's)
   mutable std::mutex mPendingMutex;
   mutable std::exception_ptr mPending;                  // what extract() captured on a foreign thread

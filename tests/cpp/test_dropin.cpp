@@ -239,6 +239,63 @@ static int mode_threads(int argc, char** argv) {
   return (pyr_ok && stale_refused) ? 0 : 1;
 }
 
+// Where the tail of the reference's own call shape comes from: the frame of mode `latency` with threaded = 1, taken apart
+// -- the two constructors, thread start -> extract() entered, the two extract() calls, the join after the later one, searchByStereo --
+// median / p99 per part and the parts of the slowest frames.  Diagnostic (tools/exp/latency_tail.sh); no result is asserted beyond the hash.
+static int mode_latency_tail(int argc, char** argv) {
+  if (argc < 7) return 2;
+  const int w = atoi(argv[4]), h = atoi(argv[5]), iters = atoi(argv[6]);
+  std::vector<uint8_t> L, R;
+  if (!read_file(argv[2], L) || !read_file(argv[3], R) || L.size() != (size_t)w * h || R.size() != L.size()) return 2;
+  cv::Mat ml(h, w, CV_8UC1, L.data()), mr(h, w, CV_8UC1, R.data());
+  using clk = std::chrono::steady_clock;
+  auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+  struct Row {
+    double total, ctor, startL, startR, exL, exR, join, match;
+  };
+  std::vector<Row> rows;
+  for (int it = -30; it < iters; ++it) {
+    auto f = std::make_shared<ref::Frame>();
+    f->mLeftIm = ml, f->mRightIm = mr;
+    const auto t0 = clk::now();
+    f->mpExtractorLeft = std::make_shared<ORB_SLAM2_ROS2::ORBExtractor>(f->mLeftIm, 2000, 8, 1.2f, "", 20, 7);
+    f->mpExtractorRight = std::make_shared<ORB_SLAM2_ROS2::ORBExtractor>(f->mRightIm, 2000, 8, 1.2f, "", 20, 7);
+    const auto t1 = clk::now();
+    clk::time_point bL, eL, bR, eR;
+    std::thread tl([&] {
+      bL = clk::now();
+      f->mpExtractorLeft->extract(f->mvFeatsLeft, f->mvLeftDescriptor);
+      eL = clk::now();
+    });
+    std::thread tr([&] {
+      bR = clk::now();
+      f->mpExtractorRight->extract(f->mvFeatsRight, f->mRightDescriptor);
+      eR = clk::now();
+    });
+    tl.join();
+    tr.join();
+    const auto t2 = clk::now();
+    f->mvpMapPoints.resize(f->mvFeatsLeft.size(), nullptr);
+    f->mnN = orbfe::dropin::searchByStereo<ref::Camera>(f);
+    const auto t3 = clk::now();
+    if (it >= 0) rows.push_back({us(t0, t3), us(t0, t1), us(t1, bL), us(t1, bR), us(bL, eL), us(bR, eR), us(std::max(eL, eR), t2), us(t2, t3)});
+  }
+  auto col = [&](double Row::*m, double q) {
+    std::vector<double> v;
+    for (auto& r : rows) v.push_back(r.*m);
+    std::sort(v.begin(), v.end());
+    return v[std::min(v.size() - 1, (size_t)(q * v.size()))];
+  };
+  const char* names[] = {"total", "ctor x2", "start L", "start R", "extract L", "extract R", "join", "match"};
+  double Row::*mem[] = {&Row::total, &Row::ctor, &Row::startL, &Row::startR, &Row::exL, &Row::exR, &Row::join, &Row::match};
+  for (int k = 0; k < 8; ++k) printf("TAIL %-10s p50 %7.1f  p90 %7.1f  p99 %7.1f  max %7.1f us\n", names[k], col(mem[k], 0.5), col(mem[k], 0.9), col(mem[k], 0.99), col(mem[k], 1.0));
+  std::sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.total > b.total; });
+  for (size_t k = 0; k < 8 && k < rows.size(); ++k)
+    printf("SLOW %zu: total %.1f = ctor %.1f + start L %.1f / R %.1f + extract L %.1f / R %.1f + join %.1f + match %.1f\n", k, rows[k].total, rows[k].ctor,
+           rows[k].startL, rows[k].startR, rows[k].exL, rows[k].exR, rows[k].join, rows[k].match);
+  return 0;
+}
+
 // A device error inside extract() on Frame::Frame's bare threads (src/Frame.cc:100-105) must not reach std::terminate: the failure is
 // captured and rethrown by the next call on the object (searchByStereo, the next statement of Frame::createStereo).  The error is provoked
 // with a cv::Mat header whose row stride is shorter than its width (orbfe_extract_slot refuses it: ORBFE_EBADARG).
@@ -290,8 +347,12 @@ static int mode_latency(int argc, char** argv) {
   uint64_t want = 0;
   size_t nl = 0;
   int nm = 0;
-  std::vector<double> total[3], ext[3];
-  for (int threaded : {1, 0, 2}) {
+  std::vector<double> total[4], ext[4];
+  // way 3: way 1 (the reference's own Frame::Frame: two extract() threads, then searchByStereo) with the extractors' constructors starting
+  // the device work (orbfe::ORBExtractor::eagerStart: orbfe_extract_slot_begin in the constructor, extract() only collects)
+  for (int way : {1, 0, 2, 3}) {
+    const int threaded = way == 3 ? 1 : way;
+    orbfe::ORBExtractor::eagerStart() = way == 3;
     for (int it = -30; it < iters; ++it) {  // 30 untimed warm-up frames (graphs captured, clocks up)
       const auto t0 = clk::now();
       auto f = std::make_shared<ref::Frame>(ml, mr, threaded);
@@ -304,15 +365,17 @@ static int mode_latency(int argc, char** argv) {
         fprintf(stderr, "latency: iteration %d (threaded %d) differs from the first frame\n", it, threaded);
         return 1;
       }
-      if (it >= 0) total[threaded].push_back(us(t0, t2)), ext[threaded].push_back(us(t0, t1));
+      if (it >= 0) total[way].push_back(us(t0, t2)), ext[way].push_back(us(t0, t1));
     }
   }
+  orbfe::ORBExtractor::eagerStart() = false;
   auto pct = [](std::vector<double> v, double q) {
     std::sort(v.begin(), v.end());
     return v.empty() ? 0.0 : v[std::min(v.size() - 1, (size_t)(q * v.size()))];
   };
-  printf("LATENCY_OK %d %.1f %.1f %.1f %.1f %.1f %.1f %zu %d %016llx %.1f %.1f\n", iters, pct(total[1], 0.5), pct(total[1], 0.99), pct(ext[1], 0.5),
-         pct(total[0], 0.5), pct(total[0], 0.99), pct(ext[0], 0.5), nl, nm, (unsigned long long)want, pct(total[2], 0.5), pct(total[2], 0.99));
+  printf("LATENCY_OK %d %.1f %.1f %.1f %.1f %.1f %.1f %zu %d %016llx %.1f %.1f %.1f %.1f\n", iters, pct(total[1], 0.5), pct(total[1], 0.99), pct(ext[1], 0.5),
+         pct(total[0], 0.5), pct(total[0], 0.99), pct(ext[0], 0.5), nl, nm, (unsigned long long)want, pct(total[2], 0.5), pct(total[2], 0.99),
+         pct(total[3], 0.5), pct(total[3], 0.99));
   return 0;
 }
 
@@ -1328,6 +1391,7 @@ int main(int argc, char** argv) {
     if (mode == "threads") return mode_threads(argc, argv);
     if (mode == "latency") return mode_latency(argc, argv);
     if (mode == "threaderr") return mode_threaderr(argc, argv);
+    if (mode == "latency_tail") return mode_latency_tail(argc, argv);
     if (mode == "matchers") return mode_matchers(argc, argv);
     if (mode == "rgbd") return mode_rgbd(argc, argv);
     if (mode == "trackchain") return mode_trackchain(argc, argv);

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)  # loading must not need a GPU
     for s in syms:
         assert hasattr(lib, s), s
-    assert lib.orbfe_abi_version() == 3
+    assert lib.orbfe_abi_version() == 4
 
 
 def test_no_cpu_fallback_create_fails_loudly_without_device():

@@ -67,10 +67,10 @@ def test_create_stereo_adapter_builds_the_same_frame_as_two_threads_and_search_b
                          timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     f = out.stdout.split()
-    assert f[0] == "LATENCY_OK" and len(f) == 13
+    assert f[0] == "LATENCY_OK" and len(f) == 15
     ref = orc.stereo_frame(L, R, fx=FX, bf=BF)
     assert (int(f[8]), int(f[9])) == (len(ref["lk"]), ref["n_matches"])
-    assert float(f[11]) > 0
+    assert float(f[11]) > 0 and float(f[13]) > 0   # createStereo; the reference shape with the constructors starting the device (eagerStart)
 
 
 def test_keyframe_adapter_of_optimize_local_map_equals_the_array_path(exe, tmp_path):

@@ -162,3 +162,41 @@ def test_argument_checks(lib):
         ctx.frame_stereo(L, R, FX, BF, slot_left=2)  # still usable
     finally:
         one.close(), ctx.close()
+
+
+def test_extract_slot_in_two_halves_equals_the_one_call(orc):
+    """orbfe_extract_slot_begin / _end (ABI 4): the constructor-time start of the reference's extractor (Frame.cc:91-92 builds both
+    ORBExtractor objects before the extract() threads exist) -- same results as orbfe_extract_slot, the halves on different threads, both
+    eyes outstanding at once, the slot refusing other calls in between, a drain without outputs."""
+    import threading
+    from orb_slam2_ros2_amd._lib import Context, OrbfeError
+    L, R = synth.stereo_pair(2)
+    ctx = Context(1241, 376, max_images=4)
+    want_l, want_r = ctx.extract_slot(0, L), ctx.extract_slot(1, R)
+    ctx.extract_slot_begin(2, L)
+    ctx.extract_slot_begin(3, R)                 # both outstanding
+    with pytest.raises(OrbfeError):
+        ctx.extract_slot(2, L)                   # the slot is busy until _end
+    with pytest.raises(OrbfeError):
+        ctx.extract_slot_begin(2, L)
+    got = {}
+    th = [threading.Thread(target=lambda s=s: got.__setitem__(s, ctx.extract_slot_end(s))) for s in (2, 3)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    for (k, d), (wk, wd) in ((got[2], want_l), (got[3], want_r)):
+        assert np.array_equal(k, wk) and np.array_equal(d, wd)
+    with pytest.raises(OrbfeError):
+        ctx.extract_slot_end(2)                  # nothing outstanding
+    nm, ru, dp, _, _ = ctx.stereo_match(2, 3, FX, BF)      # the results are resident in the slots as after orbfe_extract_slot
+    ref = orc.stereo_frame(L, R, fx=FX, bf=BF)
+    assert nm == ref["n_matches"] and np.array_equal(ru[:len(want_l[0])], ref["right_u"])
+    for _ in range(3):                           # repeated use of one slot (the captured launch sequence is replayed)
+        ctx.extract_slot_begin(0, R)
+        k, d = ctx.extract_slot_end(0)
+        assert np.array_equal(k, want_r[0]) and np.array_equal(d, want_r[1])
+    ctx.extract_slot_begin(1, L)
+    ctx.lib.orbfe_extract_slot_end(ctx.h, 1, None, None, None)   # drain: no outputs
+    assert np.array_equal(ctx.extract_slot(1, L)[0], want_l[0])
+    ctx.close()
