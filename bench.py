@@ -1223,6 +1223,22 @@ def main():
                 line["roofline_valu"]["pipeline_valu_issue_ms"] = tot_valu / peak * 1e3
                 line["roofline_valu"]["pipeline_what"] = ("vector instructions of ALL kernels of a step (SQ_INSTS_VALU x waves, committed counter pass) / "
                                                           "step time / 614.4 G wave-instructions per second: the share of the step that is vector issue")
+                # r5: the issue rate depends on the opcode -- profiles/r5_valu_peak.txt, r5_valu_census.txt: most of what
+                # these kernels execute (32-bit min / max / min3, mads, dots, compares, cndmask, perms) issues once per 4 cycles per SIMD
+                # (535 - 575 G wave-instr/s measured chip-wide = 4 cycles at the ~2.2 GHz the chip holds under such a load; 614.4 is 4 cycles at the
+                # nominal 2.4 GHz), while 32-bit add / sub / logic / right shifts, fp32 add / mul / fma and the non-packed 16-bit arithmetic
+                # reach ~1.8 x that with 8 waves per SIMD.  `frac` above prices every instruction at 4 cycles; frac_class_weighted prices the
+                # kernel's STATIC opcode mix (tools/isa_class_mix.py), fast ones at 4 / 1.8 cycles -- the lower, more honest figure
+                mix_path = os.path.join(ROOT, "profiles", "r5_isa_class_mix.json")
+                if os.path.exists(mix_path):
+                    mix = json.load(open(mix_path))["kernels"].get(kern_of[dom])
+                    if mix:
+                        ff = mix["frac_fast"]
+                        peak_w = peak / ((1.0 - ff) + ff / 1.8)
+                        line["roofline_valu"]["issue_classes"] = {
+                            "source": "profiles/r5_valu_peak.txt, profiles/r5_valu_census.txt, profiles/r5_isa_class_mix.json",
+                            "slow_class_cycles": 4.0, "fast_class_speedup_at_8_waves_per_simd": 1.8, "static_frac_fast": ff,
+                            "peak_class_weighted": peak_w / 1e9, "frac_class_weighted": ach / peak_w}
         except Exception:
             pass
 
