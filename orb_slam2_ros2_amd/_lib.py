@@ -158,8 +158,9 @@ def load() -> C.CDLL:
     L.orbfe_get_capacity.restype = i32
     L.orbfe_extract.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
     L.orbfe_extract_batch.argtypes = [vp, i32, vp, C.c_size_t, vp, vp, vp]
-    L.orbfe_extract_slot_begin.argtypes = [vp, i32, vp, C.c_size_t]
-    L.orbfe_extract_slot_end.argtypes = [vp, i32, vp, vp, vp]
+    if hasattr(L, "orbfe_extract_slot_begin"):   # (ABI 4; tools/exp compares against libraries of earlier rounds)
+        L.orbfe_extract_slot_begin.argtypes = [vp, i32, vp, C.c_size_t]
+        L.orbfe_extract_slot_end.argtypes = [vp, i32, vp, vp, vp]
     L.orbfe_extract_slot.argtypes = [vp, i32, vp, C.c_size_t, vp, vp, vp]
     L.orbfe_extract_slots.argtypes = [vp, i32, i32, vp, C.c_size_t, vp, vp, vp]
     L.orbfe_frame_rgbd_image.argtypes = [vp, i32, vp, C.c_size_t, i32, vp, vp, i32, C.c_size_t, C.c_float, vp, vp, vp, vp, vp]

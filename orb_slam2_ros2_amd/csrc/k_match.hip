@@ -21,7 +21,7 @@
 #define STEREO4_FROM 4  // pairs per launch from which the batch matcher is used
 #endif
 #ifndef STEREO_ROWS
-#define STEREO_ROWS 1   // the batch matcher: 1 = row-parallel (k_stereo_rows + k_stereo_sad), 0 = four left keypoints per wave (k_stereo4)
+#define STEREO_ROWS 1   // the batch matcher: 1 = row-parallel (k_stereo_rows + k_stereo_sad), 0 = a wave per left keypoint everywhere (k_stereo)
 #endif
 
 namespace orbfe {
@@ -130,7 +130,7 @@ struct StereoRows {
 __global__ __launch_bounds__(256) void k_rowtable(const KpAux* __restrict__ aux, const int32_t* __restrict__ n_kp, int n_features, int rows,
                                                   int list_cap, uint32_t* __restrict__ rowoff, uint16_t* __restrict__ rowlist, int slot_r0,
                                                   int slot_step, int pair0, int32_t* __restrict__ n_match, const orbfe_keypoint* __restrict__ kps,
-                                                  int slot_l0, uint2* __restrict__ lrange, StereoRows sr) {
+                                                  int slot_l0, StereoRows sr) {
   extern __shared__ uint32_t s_rt[];  // cnt[rows] | part[256]
   uint32_t* cnt = s_rt;
   uint32_t* part = s_rt + rows;
@@ -143,30 +143,6 @@ __global__ __launch_bounds__(256) void k_rowtable(const KpAux* __restrict__ aux,
   uint16_t* RL = rowlist + (size_t)pair * list_cap;
   const int nr = min(n_kp[slot], n_features);
   rowtable_build(A, nr, rows, list_cap, RO, RL, cnt, part, tid);
-  if (lrange) {
-    // ... and, for k_stereo4, every LEFT keypoint's candidate range in that list -- rowIdxDB[round(y)], ORBMatcher.cc:38-41.  After the
-    // scatter cnt[y] is row y's END cursor = RO[y + 1] (rowtable_build), read from LDS.
-    __syncthreads();
-    const int sl = slot_l0 + blockIdx.x * slot_step;
-    const orbfe_keypoint* LK = kps + (size_t)sl * n_features;
-    uint2* LR = lrange + (size_t)pair * n_features;
-    const int nl = min(n_kp[sl], n_features);
-    for (int i0 = tid; i0 < n_features; i0 += 4 * 256) {
-      float y[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) y[k] = LK[min(i0 + 256 * k, n_features - 1)].y;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = i0 + 256 * k;
-        if (i < n_features) {
-          const int row = __float2int_rn(y[k]);
-          uint2 r = make_uint2(0u, 0u);
-          if (i < nl && (unsigned)row < (unsigned)rows) r = make_uint2(row > 0 ? cnt[row - 1] : 0u, cnt[row]);
-          LR[i] = r;
-        }
-      }
-    }
-  }
   if (!sr.lrow_off) return;
   // ---- the row-parallel matcher's inputs (k_stereo_rows): the LEFT keypoints by image row -- LO[rows + 1] offsets + LL list, the same counting
   //      sort on round(y) (ORBMatcher.cc:38-41: rowIdxDB[cvRound(kp.pt.y)]) -- and the defaults of the pair's outputs: a left keypoint that no
@@ -408,16 +384,6 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// The batches' form of k_stereo: FOUR left keypoints per wave, one per row of 16 lanes.  A keypoint's match is six dependent memory
-// round trips (keypoint + descriptor -> row range -> list entries -> their x and descriptors -> the best one's keypoint -> the two
-// patches) and some two hundred instructions: a wave per keypoint is parked at s_waitcnt for nearly all of its ~4 us, and a million of
-// them per 512 pairs hold wave slots and keep the memory system busy under the next batch's front for most of a step (the step with the
-// match skipped: 5.25 -> 4.95 ms, tools/exp/skip_stereo.sh).  With four keypoints side by side every round trip serves four of them;
-// a row's candidates take 16 lanes at a time (a row band holds 20 ... 60), the minima are DPP row reductions, and the 11 SADs of a
-// keypoint are 11 lanes with a whole 11 x 11 patch each.  Same arithmetic, same order of candidates (the minimum of distance << 16 |
-// index), bit-identical results (tests/test_gpu_parity.py, test_gpu_bench_config.py).
-// ---------------------------------------------------------------------------------------------
 #ifndef ST4_PAD
 #define ST4_PAD 8
 #endif
@@ -426,199 +392,13 @@ __global__ __launch_bounds__(256) void k_stereo(const LevelDev* __restrict__ lv,
 #define ST4_WORDS (11 * 4 + 11 * 7 + 7 + ST4_PAD)
 // k_stereo_sad: 121 words of patches + 11 rows x 8 words of 16-bit left values, + 7: a pitch of 216 words puts the wave's four entries 24 banks apart
 #define ST5_WORDS (124 + 88 + 4)
+
 __device__ __forceinline__ int row_min_i(int v, int lane) {  // minimum over the lane's row of 16, in every lane of the row
   v = dpp_min_step<0x111, 0xf>(v);
   v = dpp_min_step<0x112, 0xf>(v);
   v = dpp_min_step<0x114, 0xf>(v);
   v = dpp_min_step<0x118, 0xf>(v);
   return __shfl(v, lane | 15);
-}
-
-#ifndef ST4_NB
-#define ST4_NB 2  // candidate chunks (16 lanes each) whose loads are in flight together
-#endif
-__global__ __launch_bounds__(256) void k_stereo4(const LevelDev* __restrict__ lv, int n_levels, const uint8_t* __restrict__ pyr, size_t img_pitch,
-                                                 const orbfe_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
-                                                 const KpX* __restrict__ kx, const uint2* __restrict__ lrange,
-                                                 const uint16_t* __restrict__ rowlist, int rows, int list_cap,
-                                                 const int32_t* __restrict__ n_kp,
-                                                 int n_features, float fx, float bf, int cols0, int mean_threshold,
-                                                 double* __restrict__ right_u, double* __restrict__ depth, int32_t* __restrict__ n_match,
-                                                 int32_t* __restrict__ best_right, int32_t* __restrict__ best_dist, int slot_l0,
-                                                 int slot_r0, int slot_step, int pair0) {
-  // r5: FOUR dependent memory round trips per wave instead of ten.  (i) the left keypoint's candidate range comes with the keypoint (k_rowtable
-  // writes it per left keypoint: no keypoint -> row -> offsets chain); (ii) the candidate loop requests ST4_NB chunks of 16 list entries at
-  // once, then their x / octave / patch centre (KpX, 8 bytes) and descriptors at once -- three chunks one after the other were six
-  // dependent trips for a row band of 40 candidates; (iii) the winner's octave and patch centre ride with its x, so its keypoint record
-  // is not fetched.  The step follows this kernel closely on images with many stereo matches (content sweep).
-#pragma clang fp contract(off)
-  __shared__ uint32_t s_sad[4][4][ST4_WORDS];  // per wave, per keypoint: left 11 rows x 4 words, right 11 rows x 7 words
-  __shared__ float s_sf[16];
-  __shared__ uint32_t s_off[16];
-  __shared__ int s_stride[16];
-  if ((int)threadIdx.x < min(n_levels, 16)) {
-    s_sf[threadIdx.x] = lv[threadIdx.x].sf;
-    s_off[threadIdx.x] = lv[threadIdx.x].plane_off;
-    s_stride[threadIdx.x] = lv[threadIdx.x].stride;
-  }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, grp = lane >> 4, sub = lane & 15;
-  const int li = (blockIdx.x * 4 + wv) * 4 + grp;
-  const int pair = pair0 + blockIdx.y;
-  const int sl = slot_l0 + blockIdx.y * slot_step, sr = slot_r0 + blockIdx.y * slot_step;
-  const orbfe_keypoint* LK = kps + (size_t)sl * n_features;
-  const uint8_t* LD = desc + (size_t)sl * n_features * 32;
-  const uint8_t* RD = desc + (size_t)sr * n_features * 32;
-  const KpX* RX = kx + (size_t)sr * n_features;
-  const uint16_t* RL = rowlist + (size_t)pair * list_cap;
-  // first round trip: the count, the left keypoints, their descriptors and candidate ranges (slot li always exists in the buffers up to n_features)
-  const int nl = n_kp[sl];
-  const int li_c = min(li, n_features - 1);
-  const orbfe_keypoint l = LK[li_c];
-  const uint4 a0 = *(const uint4*)(LD + (size_t)li_c * 32);
-  const uint4 a1 = *(const uint4*)(LD + (size_t)li_c * 32 + 16);
-  const uint2 lr = lrange[(size_t)pair * n_features + li_c];
-  __syncthreads();  // (the level table; every wave of the block passes here)
-  const bool slot = li < n_features, valid = slot && li < nl;
-  const float max_u = l.x - 0;
-  const float min_u = fmaxf(0.f, l.x - fx);
-  // candidates = rowIdxDB[row] filtered by the u-range (ORBMatcher.cc:38-48); the reference takes the FIRST minimum of the list,
-  // which is in ascending right index: the minimum of (distance << 16 | index) over the candidates, in any order
-  const int beg = valid ? (int)lr.x : 0, end = valid ? (int)lr.y : 0;
-  int key = ORB_INT_MAX;
-  uint32_t kxb = 0u, kq = 0u;  // x (bits) and q of the lane's best candidate so far
-  for (int g0 = beg + sub; __any(g0 < end); g0 += 16 * ST4_NB) {
-    uint32_t idx[ST4_NB];
-#pragma unroll
-    for (int k = 0; k < ST4_NB; ++k) idx[k] = RL[(g0 + 16 * k < end) ? g0 + 16 * k : 0];  // (a lane without a candidate reads entry 0 of the list: masked below)
-    KpX xq[ST4_NB];
-    uint4 b0[ST4_NB], b1[ST4_NB];
-#pragma unroll
-    for (int k = 0; k < ST4_NB; ++k) {
-      const uint32_t ii = (g0 + 16 * k < end) ? idx[k] : 0u;  // (right keypoint 0 always exists in the buffers)
-      xq[k] = RX[ii];
-      b0[k] = *(const uint4*)(RD + (ii << 5));
-      b1[k] = *(const uint4*)(RD + (ii << 5) + 16);
-    }
-#pragma unroll
-    for (int k = 0; k < ST4_NB; ++k) {
-      const bool has = g0 + 16 * k < end;
-      const int d = __popc(a0.x ^ b0[k].x) + __popc(a0.y ^ b0[k].y) + __popc(a0.z ^ b0[k].z) + __popc(a0.w ^ b0[k].w) + __popc(a1.x ^ b1[k].x) +
-                    __popc(a1.y ^ b1[k].y) + __popc(a1.z ^ b1[k].z) + __popc(a1.w ^ b1[k].w);
-      const bool pass = has && xq[k].x < max_u && xq[k].x > min_u;
-      const int kk = pass ? (int)(((uint32_t)d << 16) | idx[k]) : ORB_INT_MAX;
-      const bool better = kk < key;
-      key = better ? kk : key;
-      kxb = better ? __float_as_uint(xq[k].x) : kxb;
-      kq = better ? xq[k].q : kq;
-    }
-  }
-  const int my_key = key;
-  key = row_min_i(key, lane);
-  const bool any = key != ORB_INT_MAX;
-  const int min_d = key >> 16, min_idx = key & 0xFFFF;
-  // the winner's x / q: from the lane of the row that holds the minimum (indices are distinct, so it is one lane)
-  const unsigned long long wm = __ballot(my_key == key);
-  const int wl_lane = (lane & ~15) + max(__ffs((int)((wm >> (16 * grp)) & 0xFFFFull)) - 1, 0);
-  const float r_x = __uint_as_float((uint32_t)__shfl((int)kxb, wl_lane));
-  const uint32_t r_q = (uint32_t)__shfl((int)kq, wl_lane);
-  const int r_oct = (int)(r_q & 7u);
-  double out_u = -1.0, out_depth = -1.0;
-  int matched = 0;
-  const bool cand = valid && any && min_d <= mean_threshold;
-  const bool go = cand && !(l.octave > r_oct + 1 || l.octave < r_oct - 1);
-  if (__any(go)) {
-    // ---- pixelSADMatch (ORBMatcher.cc:841-881): 11 SADs of centre-subtracted 11x11 patches ----
-    const int ol = go ? l.octave : 0, orr = go ? r_oct : 0;
-    const float sf_l = s_sf[ol], sf_r = s_sf[orr];
-    const int stride_l = s_stride[ol], stride_r = s_stride[orr];
-    const uint8_t* IL = pyr + (size_t)sl * img_pitch;  // wave-uniform bases; the rest of the address is a 32-bit offset
-    const uint8_t* IR = pyr + (size_t)sr * img_pitch;
-    const uint32_t off_l = s_off[ol], off_r = s_off[orr];
-    // (a keypoint that does not go on reads around (16, 16) of level 0: harmless)
-    const int lx = go ? cv_floor_f(l.x / sf_l) : 16, ly = go ? cv_floor_f(l.y / sf_l) : 16;  // getPitch (:1004-1006)
-    const int rx = go ? (int)((r_q >> 3) & 0x1FFFu) : 16, ry = go ? (int)(r_q >> 16) : 16;  // getPitch's centre of the right keypoint, computed with its record (KpX)
-    // stage the left 11x11 patch (x in [lx-5, lx+5]) and the right 11x21 window (x in [rx-10, rx+10]) in LDS as words: 121 words
-    // by 16 lanes, all eight requests of a lane in flight together
-    uint32_t* wl = s_sad[wv][grp];
-    uint32_t* wr = wl + 44;
-    const int lxa = (lx - 5) & ~3, rxa = (rx - 10) & ~3;
-    uint32_t wreg[8];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int t = min(sub + 16 * it, 120);
-      if (t < 44) {
-        const int rr = t >> 2, cc = t & 3;
-        wreg[it] = *(const uint32_t*)(IL + (off_l + (uint32_t)mad24u(ly - 5 + rr, stride_l, lxa + 4 * cc)));
-      } else {
-        const int u = t - 44;
-        const int rr = (u * 37) >> 8, cc = u - rr * 7;  // u / 7 for u < 77
-        wreg[it] = *(const uint32_t*)(IR + (off_r + (uint32_t)mad24u(ry - 5 + rr, stride_r, rxa + 4 * cc)));
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int t = sub + 16 * it;
-      if (t < 121) wl[t] = wreg[it];  // (wr = wl + 44: one index space)
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // LDS accesses of one wave execute in order; this only pins the compiler
-    const uint8_t* bl = (const uint8_t*)wl + ((lx - 5) - lxa);
-    const uint8_t* br = (const uint8_t*)wr + ((rx - 10) - rxa);
-    const int c1 = bl[5 * 16 + 5];
-    int sad = ORB_INT_MAX;
-    if (sub < 11) {
-      // each shifted right patch subtracts ITS OWN centre pixel (SAD(), ORBMatcher.cc:901-903)
-      const uint32_t c2 = br[5 * 28 + 5 + sub];
-      uint32_t acc = 0;
-      for (int rr = 0; rr < 11; ++rr) {
-        const uint8_t* pl = bl + rr * 16;
-        const uint8_t* pr = br + rr * 28 + sub;
-#pragma unroll
-        for (int cc = 0; cc < 11; ++cc)  // |(pl - c1) - (pr - c2)| = |(pl + c2) - (pr + c1)|, both sides non-negative: one v_sad_u32
-          acc = __builtin_amdgcn_sad_u16((uint32_t)pl[cc] + c2, (uint32_t)pr[cc] + (uint32_t)c1, acc);
-      }
-      sad = (int)acc;
-    }
-    // lanes 0..10 of a row hold SAD(L = lane-5); first minimum wins (strict <, :856)
-    const int smin = row_min_i(sad, lane);
-    const unsigned long long mm = __ballot(sad == smin && sub < 11);
-    const int best_l = __ffs((int)((mm >> (16 * grp)) & 0xFFFFull)) - 1;  // 0..10 == bestL + mnL
-    float delta_u = 0.f;
-    const int base = lane & ~15;
-    const int bl_c = min(max(best_l, 1), 9);
-    const float s1 = (float)__shfl(sad, base + bl_c - 1);
-    const float s2 = (float)__shfl(sad, base + bl_c);
-    const float s3 = (float)__shfl(sad, base + bl_c + 1);
-    if (best_l > 0 && best_l < 10) {
-      delta_u = (float)(0.5 * (double)(s1 - s3) / (double)(s1 + s3 - 2 * s2));
-      if (delta_u < 1 && delta_u > -1) delta_u *= sf_r;
-      else delta_u = 0.f;
-    }
-    float ru = r_x + delta_u;  // bestL itself is not added (quirk Q7)
-    ru = fmaxf(0.f, ru);
-    ru = fminf(ru, (float)cols0 - 1);
-    float delta = l.x - ru;
-    bool ok = true;
-    if (delta <= 0) {
-      ru = r_x;
-      delta = l.x - ru;
-      if (delta <= 0) ok = false;
-    }
-    if (go && ok) {
-      out_u = (double)ru;
-      out_depth = (double)(bf / (l.x - ru));
-      matched = 1;
-    }
-  }
-  if (sub == 0 && slot) {
-    const size_t out_i = (size_t)pair * n_features + li;
-    right_u[out_i] = out_u;
-    depth[out_i] = out_depth;
-    best_right[out_i] = (valid && any) ? min_idx : -1;
-    best_dist[out_i] = (valid && any) ? min_d : -1;
-  }
-  const int n_m = __popcll(__ballot(matched && sub == 0));
-  if (lane == 0 && n_m > 0) atomicAdd(&n_match[pair], n_m);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -866,26 +646,25 @@ void launch_stereo(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint
                    const uint8_t* d_desc, const KpAux* d_aux, const KpX* d_kx, uint32_t* d_rowoff, uint16_t* d_rowlist, int rows, int list_cap,
                    const int32_t* d_n_kp, int n_features, float fx, float bf, int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
                    int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs, double* h_right_u, double* h_depth,
-                   int32_t* h_best_right, int32_t* h_best_dist, bool table_ready, uint2* d_lrange, const StereoRowsBuf* rowsbuf) {
+                   int32_t* h_best_right, int32_t* h_best_dist, bool table_ready, const StereoRowsBuf* rowsbuf) {
   // h_*: page-locked host arrays [n_features] for the results of ONE pair (n_pairs == 1), or null
   // table_ready: d_rowoff / d_rowlist are the per-SLOT tables the extraction of the right image left behind (k_brief) and the match
   // counter is zero: no table launch
   if (n_pairs <= 0 || n_features <= 0) return;
   StereoHost host = {nullptr, nullptr, nullptr, nullptr};
   if (n_pairs == 1) host = {h_right_u, h_depth, h_best_right, h_best_dist};
-  // batches: the row-parallel matcher (k_stereo_rows + k_stereo_sad); STEREO_ROWS = 0: k_stereo4 (four left keypoints per wave, r3 / r5a)
+  // batches: the row-parallel matcher (k_stereo_rows + k_stereo_sad); a pair or two (and STEREO_ROWS = 0): a wave per left keypoint (k_stereo)
+  // (k_stereo4 -- four left keypoints per wave, the step between the two in r5 -- is kept as tools/exp/patches/k_stereo4.applied_r5.patch)
   StereoRows sr = {nullptr, nullptr, nullptr, nullptr, d_right_u, d_depth, d_best_right, d_best_dist};
   const bool batch = !table_ready && n_pairs >= STEREO4_FROM && n_levels <= 16;
   const bool by_rows = batch && STEREO_ROWS && rowsbuf && rowsbuf->lrow_off;
   if (by_rows) sr.lrow_off = rowsbuf->lrow_off, sr.lrow_list = rowsbuf->lrow_list, sr.work = rowsbuf->work, sr.work_n = rowsbuf->work_n;
   if (!table_ready)
   hipLaunchKernelGGL(k_rowtable, dim3(n_pairs), dim3(256), (size_t)(rows + 256) * sizeof(uint32_t), s, d_aux, d_n_kp, n_features, rows, list_cap,
-                     d_rowoff, d_rowlist, slot_r0, slot_step, pair0, d_n_match, d_kps, slot_l0,
-                     (batch && !by_rows) ? d_lrange : (uint2*)nullptr, sr);
+                     d_rowoff, d_rowlist, slot_r0, slot_step, pair0, d_n_match, d_kps, slot_l0, sr);
 #ifdef EXP_SKIP_STEREO  // (tools/exp: timing only -- what a free match would buy the step)
   if (n_pairs >= STEREO4_FROM) return;
 #endif
-  // a pair or two: a wave per left keypoint (2000 waves: the call is one wave lifetime); batches: four keypoints per wave (k_stereo4)
   if (by_rows) {
     hipLaunchKernelGGL(k_stereo_rows, dim3((rows + 3) / 4, n_pairs), dim3(256), 0, s, d_kx, d_desc, d_rowoff, d_rowlist, rows, list_cap, n_features, fx,
                        mean_threshold, sr, slot_l0, slot_r0, slot_step, pair0);
@@ -893,12 +672,6 @@ void launch_stereo(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint
                        sr, d_n_match, slot_l0, slot_r0, slot_step, pair0);
     return;
   }
-  const bool four = batch && d_lrange != nullptr;
-  if (four)
-    hipLaunchKernelGGL(k_stereo4, dim3((n_features + 15) / 16, n_pairs), dim3(256), 0, s, d_lv, n_levels, d_pyr, img_pitch, d_kps, d_desc,
-                       d_kx, d_lrange, d_rowlist, rows, list_cap, d_n_kp, n_features, fx, bf, cols0, mean_threshold, d_right_u, d_depth, d_n_match,
-                       d_best_right, d_best_dist, slot_l0, slot_r0, slot_step, pair0);
-  else
   hipLaunchKernelGGL(k_stereo, dim3((n_features + 3) / 4, n_pairs), dim3(256), 0, s, d_lv, n_levels, d_pyr, img_pitch, d_kps, d_desc,
                      d_kx, d_rowoff, d_rowlist, rows, list_cap, d_n_kp, n_features, fx, bf, cols0, mean_threshold, d_right_u, d_depth, d_n_match, d_best_right,
                      d_best_dist, slot_l0, slot_r0, slot_step, pair0, host, table_ready ? 1 : 0);

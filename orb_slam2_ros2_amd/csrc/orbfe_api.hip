@@ -556,7 +556,7 @@ void orbfe_destroy(orbfe_ctx* c) {
   void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_rs_tiles, c->d_pattern, c->d_pyr,     c->d_blur,
                   c->d_scr_a, c->d_scr_c,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_kp,
                   c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos, c->d_kx, c->d_kpl,   c->d_right_u, c->d_depth, c->d_n_match,
-                  c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist, c->d_rowoff_slot, c->d_rowlist_slot, c->d_rs_regions, c->d_rg_xtaps, c->d_rg_ytaps, c->d_qt_big, c->d_qt_tabs, c->d_qt_next, c->d_lrange, c->st_rows.lrow_off, c->st_rows.lrow_list, c->st_rows.work, c->st_rows.work_n};
+                  c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist, c->d_rowoff_slot, c->d_rowlist_slot, c->d_rs_regions, c->d_rg_xtaps, c->d_rg_ytaps, c->d_qt_big, c->d_qt_tabs, c->d_qt_next, c->st_rows.lrow_off, c->st_rows.lrow_list, c->st_rows.work, c->st_rows.work_n};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -717,7 +717,6 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     c->row_list_cap = (int)NF * ((int)(4.0f * sf_max) + 4);
   }
   ALLOC(c->d_rowoff, NP * (size_t)(c->cfg.height + 1));
-  ALLOC(c->d_lrange, NP * NF);
   ALLOC(c->st_rows.lrow_off, NP * (size_t)(c->cfg.height + 1));
   ALLOC(c->st_rows.lrow_list, NP * NF);
   ALLOC(c->st_rows.work, NP * NF);

@@ -69,8 +69,7 @@ void launch_stereo(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint
                    const uint8_t* d_desc, const KpAux* d_aux, const KpX* d_kx, uint32_t* d_rowoff, uint16_t* d_rowlist, int rows, int list_cap,
                    const int32_t* d_n_kp, int n_features, float fx, float bf, int cols0, int mean_threshold, double* d_right_u, double* d_depth, int32_t* d_n_match, int32_t* d_best_right,
                    int32_t* d_best_dist, int slot_l0, int slot_r0, int slot_step, int pair0, int n_pairs, double* h_right_u, double* h_depth,
-                   int32_t* h_best_right, int32_t* h_best_dist, bool table_ready = false, uint2* d_lrange = nullptr,
-                   const StereoRowsBuf* rowsbuf = nullptr);
+                   int32_t* h_best_right, int32_t* h_best_dist, bool table_ready = false, const StereoRowsBuf* rowsbuf = nullptr);
 // k_glue.hip
 void launch_cvt_gray(hipStream_t s, const uint8_t* d_src, size_t src_stride, uint8_t* d_dst, int dst_stride, int w, int h, int order,
                      int variant);
@@ -261,7 +260,6 @@ struct orbfe_ctx {
   double2* d_sincos = nullptr;   // per keypoint (sin, cos) of the orientation
   KpX* d_kx = nullptr;           // per keypoint x (level-0 coordinates) + octave / patch centre: what the stereo match reads per candidate
   StereoRowsBuf st_rows = {nullptr, nullptr, nullptr, nullptr};  // the row-parallel matcher's buffers (batches)
-  uint2* d_lrange = nullptr;     // [pairs][n_features]: a LEFT keypoint's candidate range in its pair's row list (k_rowtable writes it)
   uint32_t* d_rowoff = nullptr;  // per pair: offsets[height + 1] of the right image's row table (createRowIndexDB)
   uint16_t* d_rowlist = nullptr; // per pair: the table's entries, row_list_cap = n_features x the widest band
   int row_list_cap = 0;

@@ -164,7 +164,7 @@ static orbfe_status run_stereo(orbfe_ctx* c, hipStream_t st, int slot_l0, int sl
                   c->cfg.n_features, fx, bf,
                   c->cfg.width, kMeanThreshold, c->d_right_u, c->d_depth, c->d_n_match, c->d_best_right, c->d_best_dist, slot_l0,
                   slot_r0, slot_step, pair0, n_pairs, ho ? ho->right_u : nullptr, ho ? ho->depth : nullptr, ho ? ho->best_right : nullptr,
-                  ho ? ho->best_dist : nullptr, table_ready, c->d_lrange, &c->st_rows);
+                  ho ? ho->best_dist : nullptr, table_ready, &c->st_rows);
   }
   HIP_TRY(c, hipGetLastError());
   return ORBFE_OK;
