@@ -138,3 +138,45 @@ def test_gpu_batch_of_content_class_equals_the_golden_digests(cls):
     bad = [p for p in range(B) if dig[p] != G4[cls]["pairs"][str(p % U)]]
     assert not bad, f"{cls}: pairs {bad[:8]} differ from golden_v4"
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_row_parallel_matcher_with_crowded_rows(orc):
+    """k_stereo_rows takes a row's left keypoints in groups of 64 and its right candidates in chunks of 64: an image whose texture is one
+    horizontal band puts all 2000 keypoints into ~60 rows (more than 64 left keypoints in a row, candidate lists of several chunks) --
+    the batch call against the oracle, and against the one-wave-per-keypoint kernel the single-pair call uses."""
+    import torch
+    from orb_slam2_ros2_amd._lib import Context
+    sat = [synth.stereo_pair_content(f, "saturated") for f in range(2)]
+    pairs = []
+    for L, R in sat:
+        bl, br = np.full_like(L, 96), np.full_like(R, 96)
+        bl[160:215] = L[160:215]
+        br[160:215] = R[160:215]
+        pairs.append((bl, br))
+    ref = [orc.stereo_frame(L, R, fx=FX, bf=BF) for L, R in pairs]
+    rows = np.round(ref[0]["lk"]["y"]).astype(int)
+    assert np.bincount(rows).max() > 64 and len(ref[0]["lk"]) > 1000, "the premise: a row with more than 64 left keypoints"
+    B = 8
+    ctx = Context(1241, 376, max_images=2 * B)
+    dl = torch.from_numpy(np.stack([pairs[i % 2][0] for i in range(B)])).cuda()
+    dr = torch.from_numpy(np.stack([pairs[i % 2][1] for i in range(B)])).cuda()
+    ctx.stereo_batch_device(dl.data_ptr(), dr.data_ptr(), 1241, 1241 * 376, B, FX, BF)
+    ctx.sync()
+    kps, desc, cnt = ctx.fetch_batch(0, 2 * B)
+    ru, dp, nm = ctx.fetch_stereo_batch(0, B)
+    for p in range(B):
+        r = ref[p % 2]
+        nl = len(r["lk"])
+        assert cnt[2 * p] == nl and nm[p] == r["n_matches"], f"pair {p}: counts"
+        assert np.array_equal(kps[2 * p, :nl], r["lk"]) and np.array_equal(desc[2 * p, :nl], r["ld"])
+        assert np.array_equal(ru[p, :nl].view(np.int64), r["right_u"].view(np.int64)), f"pair {p}: right_u"
+        assert np.array_equal(dp[p, :nl].view(np.int64), r["depth"].view(np.int64)), f"pair {p}: depth"
+        assert (ru[p, nl:] == -1).all() and (dp[p, nl:] == -1).all()      # slots past the count keep the defaults
+    ctx.close()
+    c1 = Context(1241, 376, max_images=2)
+    c1.extract_batch(list(pairs[0]))
+    nm1, ru1, dp1, br1, bd1 = c1.stereo_match(0, 1, FX, BF)
+    nl = len(ref[0]["lk"])
+    assert nm1 == ref[0]["n_matches"] and np.array_equal(ru1[:nl].view(np.int64), ref[0]["right_u"].view(np.int64))
+    c1.close()
