@@ -1018,10 +1018,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm_seconds:
+    for _ in range(3):
         step()
-        ctx.sync()
+    ctx.sync()
 
     n_cand_img = sum(len(ctx.debug_candidates(0, l)) for l in range(NLEVELS))  # FAST candidates of one image (slot 0)
     per_image_bytes, match_bytes, pair_bytes = algorithmic_bytes(ctx, n_cand_img)
@@ -1041,6 +1040,13 @@ def main():
     dom = max((k for k in stages if k in stage_bytes), key=lambda k: stages[k])
     stage_id = {"resize": 0, "blur": 1, "fast": 2, "quadtree": 3, "orient_brief": 4, "stereo": 5}[dom]
 
+    # sustained load right in front of the clock (the stage pass above runs every kernel alone between synchronisations: the chip falls
+    # back towards its idle clocks there, and the first ~30 steps after that are up to 13 % slower -- a 20-step run would time exactly those)
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm_seconds:
+        for _ in range(4):
+            step()
+        ctx.sync()
     for _ in range(args.warmup):
         step()
     ctx.sync()
@@ -1054,6 +1060,7 @@ def main():
     for _ in range(args.steps):
         step()
     ctx.sync()
+    t_steps = time.perf_counter() - t0
     gathered = gather_results()
     sync_all()
     dt = time.perf_counter() - t0
@@ -1163,6 +1170,9 @@ def main():
             "sequence_pairs_per_s": seq_leg["pairs_per_s"] if seq_leg else None,
             "content_sweep": sweep,
             "pairs_per_step_per_gpu": B,
+            # the end-of-sequence exchange (summary gather + barrier) is INSIDE the clock: its share of a K-step run, so that a short run
+            # (the driver's 20 steps) and a long one (the default 300) can be compared
+            "steps_only_ms_per_step": t_steps / args.steps * 1e3, "exchange_and_barrier_ms": (dt - t_steps) * 1e3,
             "n_features": NFEAT,
             "levels": NLEVELS,
             "parallelism": f"frames sharded over {world} GPU(s), RCCL gather of per-pair results at sequence end",
