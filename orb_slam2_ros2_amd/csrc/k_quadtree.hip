@@ -339,13 +339,13 @@ __device__ __forceinline__ void qt_wsync() {
 // node arrays) is off and the strips are counted with ballots.  Slow (a pop is a chain of global round trips) but exact.
 #ifdef QT_STAMPS  // diagnostic build only: timeline of one level-0 tree (device printf), see tools/exp/qt_stamps.sh
 __device__ int g_qt_stamp_count;
-#define QTS_DECL long long qts_t0 = __builtin_amdgcn_s_memtime(), qts_last = qts_t0; int qts_n = 0; long long qts_d[48]; int qts_i[48];
+#define QTS_DECL long long qts_t0 = __builtin_amdgcn_s_memtime(), qts_last = qts_t0; int qts_n = 0; long long qts_d[48]; int qts_i[48]; int qts_single = 0, qts_single_n = 0, qts_fail = 0;
 #define QTS(info) { const long long now_ = __builtin_amdgcn_s_memtime(); if (qts_n < 48) { qts_d[qts_n] = now_ - qts_last; qts_i[qts_n] = (info); ++qts_n; } qts_last = now_; }
 #define QTS_PRINT                                                                                                                   \
   if (w0 && lane == 0 && need > 400) {                                                                                              \
     const int c_ = atomicAdd(&g_qt_stamp_count, 1);                                                                                 \
     if (c_ == 5) {                                                                                                                  \
-      printf("QT tree N %d need %d n_act %d\n", N, need, n_act);                                                                   \
+      printf("QT tree N %d need %d n_act %d single pops %d (records %d) batched attempts without a commit %d\n", N, need, n_act, qts_single, qts_single_n, qts_fail);                                                                   \
       for (int k_ = 0; k_ < qts_n; ++k_)                                                                                            \
         printf("  %2d: %7lld cycles  info %d (pops %d nmax %d pp %d)\n", k_, qts_d[k_], qts_i[k_], qts_i[k_] >> 16, (qts_i[k_] >> 8) & 255, qts_i[k_] & 255); \
     }                                                                                                                               \
@@ -699,6 +699,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         C = (C + mc + 1) >> 1;
       }
       if (B <= 64) {
+        QTS(-30)  // head threshold found
         // members -> dense list (table order), then one member per lane, sorted into pop order (key descending)
         int base = 0;
 #pragma unroll
@@ -722,12 +723,14 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         uint32_t myj = (lane < B) ? bj[lane] : 0u;
         {
           int rank = 0;
-          for (int i = 0; i < B; i += 4) {
+          // (sixteen keys requested per trip before the first is compared: four per trip, each trip waiting for its own reads, the ranking
+          //  of a 38-member head was 4.8 k cycles of a lone wave -- r5 stamps, tools/exp/qt_stamps.sh)
+          for (int i = 0; i < B; i += 16) {
+            unsigned long long o[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const unsigned long long o = (i + u < B) ? bkey[i + u] : 0ull;
-              rank += o > mykey;
-            }
+            for (int u = 0; u < 16; ++u) o[u] = bkey[min(i + u, 63)];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) rank += (i + u < B && o[u] > mykey) ? 1 : 0;
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
@@ -740,6 +743,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
           mykey = (lane < B) ? bkey[lane] : 0ull;
           myj = (lane < B) ? bj[lane] : 0u;
         }
+        QTS(-31)  // head ranked
         const bool act = lane < B;
         const int j = (int)myj;
         const int n = (int)(mykey >> 32);
@@ -787,7 +791,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         uint32_t rec[BR];
 #pragma unroll
         for (int c8 = 0; c8 < BR / 8; ++c8) {
-          if (c8 * 8 < nmax) {
+          if (c8 * 8 < nmax) {  // (nmax = 0 -- a head of pre-partitioned nodes only, most steps of a tree -- skips all of it)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
               const int i = c8 * 8 + u;
@@ -798,6 +802,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
             for (int u = 0; u < 8; ++u) rec[c8 * 8 + u] = 0u;
           }
         }
+        QTS(-32)  // records requested
         if (ld) {
           int k0 = 0, k1 = 0, k2 = 0, k3 = 0;
 #pragma unroll
@@ -813,6 +818,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
           }
           c0 = k0, c1 = k1, c2 = k2, c3 = k3;
         }
+        QTS(-33)  // quadrants counted
         const int ne0 = c0 > 0, ne1 = c1 > 0, ne2 = c2 > 0, ne3 = c3 > 0;
         const int added = ne0 + ne1 + ne2 + ne3;
         const bool in = lane < b_eff;
@@ -824,6 +830,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         int v = b_eff;
         if (bad) v = min(v, __ffsll((long long)bad) - 1);
         if (stop) v = min(v, __ffsll((long long)stop));
+        QTS(-34)  // prefix of valid pops
         if (v > 0) {
           const bool cm = lane < v;
           const int ex = incl - d;  // table growth of the earlier pops = (children of the earlier pops) - (earlier pops)
@@ -894,6 +901,9 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     const unsigned long long win = __ballot(bc == mc && bs == ms);
     const int j = __builtin_amdgcn_readlane(bj, __ffsll((long long)win) - 1);
     const int n = (int)mc;
+#ifdef QT_STAMPS
+    ++qts_single, qts_single_n += n;
+#endif
     const uint2 bp = n_bp[j];
     const uint32_t beg_raw = bp.x, path = bp.y;
     const int beg = (int)(beg_raw & QT_BEG_MASK), code = (int)(beg_raw >> QT_CODE_SHIFT);
