@@ -180,3 +180,33 @@ def test_gpu_row_parallel_matcher_with_crowded_rows(orc):
     nl = len(ref[0]["lk"])
     assert nm1 == ref[0]["n_matches"] and np.array_equal(ru1[:nl].view(np.int64), ref[0]["right_u"].view(np.int64))
     c1.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,nf,nl,cls", [(752, 480, 1200, 8, "camera"), (320, 240, 500, 5, "saturated"), (1920, 1080, 3000, 8, "rect")])
+def test_gpu_batch_matcher_at_other_geometries(orc, w, h, nf, nl, cls):
+    """the batch path (k_rowtable + k_stereo_rows + k_stereo_sad) away from the KITTI shape: other row counts, quotas, level counts and
+    focal lengths -- five pairs per call (the batch matcher starts at four), every pair against the oracle"""
+    import torch
+    from orb_slam2_ros2_amd._lib import Context
+    fx, bf = 0.58 * w, 0.58 * w * 0.11
+    B = 5
+    pairs = [synth.stereo_pair_content(10 + f, cls, w, h) for f in range(B)]
+    ref = [orc.stereo_frame(L, R, n_features=nf, n_levels=nl, fx=fx, bf=bf) for L, R in pairs]
+    ctx = Context(w, h, n_features=nf, n_levels=nl, max_images=2 * B)
+    dl = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
+    dr = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    for _ in range(2):
+        ctx.stereo_batch_device(dl.data_ptr(), dr.data_ptr(), w, w * h, B, fx, bf)
+    ctx.sync()
+    kps, desc, cnt = ctx.fetch_batch(0, 2 * B)
+    ru, dp, nm = ctx.fetch_stereo_batch(0, B)
+    assert sum(r["n_matches"] for r in ref) > 0
+    for p in range(B):
+        r = ref[p]
+        nl_, nr_ = len(r["lk"]), len(r["rk"])
+        assert (cnt[2 * p], cnt[2 * p + 1], nm[p]) == (nl_, nr_, r["n_matches"]), f"pair {p}: counts"
+        assert np.array_equal(kps[2 * p, :nl_], r["lk"]) and np.array_equal(desc[2 * p + 1, :nr_], r["rd"])
+        assert np.array_equal(ru[p, :nl_].view(np.int64), r["right_u"].view(np.int64)), f"pair {p}: right_u"
+        assert np.array_equal(dp[p, :nl_].view(np.int64), r["depth"].view(np.int64)), f"pair {p}: depth"
+    ctx.close()
