@@ -358,7 +358,8 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
   c->n_cells_total = cell_base;
   c->rs_tiles = rs_tiles;
   c->bl_tiles = bl_tiles;
-  c->img_pitch = align_up(plane_off, 4096);
+  c->pyr_spare_off = (uint32_t)plane_off;           // 256 bytes behind the last plane that no plane uses (k_blur_mfma's idle lanes store there)
+  c->img_pitch = align_up(plane_off + 256, 4096);
   c->scratch_pitch = align_up(cand_base, 64);
   // The node table of a level lives in one CU's LDS as far as that goes (~2700 nodes in 120 KB); the reference has no limit on
   // nFeatures (ORBExtractor.cc:291-301), so the levels with larger quotas keep theirs in global memory (k_quadtree, NODES_LDS = false)
@@ -556,7 +557,7 @@ void orbfe_destroy(orbfe_ctx* c) {
   void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_rs_tiles, c->d_pattern, c->d_pyr,     c->d_blur,
                   c->d_scr_a, c->d_scr_c,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_kp,
                   c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos, c->d_kx, c->d_kpl,   c->d_right_u, c->d_depth, c->d_n_match,
-                  c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist, c->d_rowoff_slot, c->d_rowlist_slot, c->d_rs_regions, c->d_rg_xtaps, c->d_rg_ytaps, c->d_qt_big, c->d_qt_tabs, c->d_qt_next, c->st_rows.lrow_off, c->st_rows.lrow_list, c->st_rows.work, c->st_rows.work_n};
+                  c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist, c->d_rowoff_slot, c->d_rowlist_slot, c->d_rs_regions, c->d_rg_xtaps, c->d_rg_ytaps, c->d_qt_big, c->d_qt_tabs, c->d_qt_next, c->d_mb_tx, c->d_mb_ty, c->st_rows.lrow_off, c->st_rows.lrow_list, c->st_rows.work, c->st_rows.work_n};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -700,6 +701,14 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   ALLOC(c->d_sel, M * NF);
   ALLOC(c->d_sel_count, M * NL);
   ALLOC(c->d_qt_next, M);
+  {
+    const char* mbe = getenv("ORBFE_BLUR_MFMA");
+    c->mb_ok = (!mbe || atoi(mbe) != 0) && mb_build(c->lv.data(), (int)NL, c->blur_taps, c->pyr_spare_off, &c->mb, &c->mb_tx, &c->mb_ty);
+    if (c->mb_ok) {
+      ALLOC(c->d_mb_tx, c->mb_tx.size());
+      ALLOC(c->d_mb_ty, c->mb_ty.size());
+    }
+  }
   ALLOC(c->d_n_cand, M * NL);
   ALLOC(c->d_n_kp, M);
   ALLOC(c->d_kps, M * NF);
@@ -759,6 +768,8 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     e = hipMemcpy(c->d_rg_xtaps, c->rg_xtaps.data(), sizeof(RgXTap) * c->rg_xtaps.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess && !c->rg_ytaps.empty())
     e = hipMemcpy(c->d_rg_ytaps, c->rg_ytaps.data(), sizeof(RgYTap) * c->rg_ytaps.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && c->mb_ok) e = hipMemcpy(c->d_mb_tx, c->mb_tx.data(), c->mb_tx.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && c->mb_ok) e = hipMemcpy(c->d_mb_ty, c->mb_ty.data(), c->mb_ty.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(c->d_pattern, pat, 1024, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(c->d_n_kp, 0, sizeof(int32_t) * M);
   if (e == hipSuccess) e = hipMemset(c->d_sel_count, 0, sizeof(int32_t) * M * NL);

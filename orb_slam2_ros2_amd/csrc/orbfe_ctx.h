@@ -39,6 +39,10 @@ void launch_resize_regions(hipStream_t s, const LevelDev* d_lv, int n_levels, co
                            const uint8_t* src_a, const uint8_t* src_b, size_t src_pitch, int src_stride, uint32_t src_bytes, int copy_l0, int32_t* d_zero, int n_zero);
 void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int tile_first, int n_tiles, const uint8_t* d_pyr, uint8_t* d_blur,
                  size_t img_pitch, const int taps[7], int n_img);
+// k_blur_mfma.hip: the batches' blur on the integer matrix cores (band tables built by mb_build; ok = false: keep k_blur)
+bool mb_build(const LevelDev* lv, int n_levels, const int taps[7], uint32_t spare_off, MbGeom* g, std::vector<uint8_t>* tx, std::vector<uint8_t>* ty);
+void launch_blur_mfma(hipStream_t s, const LevelDev* d_lv, int n_levels, const MbGeom& g, const uint8_t* d_pyr, uint8_t* d_blur, size_t img_pitch,
+                      const uint8_t* d_tx, const uint8_t* d_ty, int n_img);
 void launch_load_level0(hipStream_t st, const uint8_t* d_src, const uint8_t* d_src_b, size_t src_stride, size_t src_pitch, uint8_t* d_pyr,
                         size_t img_pitch, uint32_t plane_off, int dst_stride, int w, int h, int slot0, int slot_step, int n_img);
 // k_fast.hip
@@ -231,6 +235,11 @@ struct orbfe_ctx {
   size_t img_pitch = 0;      // bytes per image in pyr / blur
   size_t scratch_pitch = 0;  // uint32 records per image
   QtGroups qt_groups_of[3];  // the same for 1, 2 and 4 waves per image (picked by launch size)
+  uint32_t pyr_spare_off = 0;    // offset of 256 spare bytes inside every image's block of d_pyr / d_blur (behind the last plane)
+  MbGeom mb = {};                // k_blur_mfma's geometry; mb_ok: built for this tap set and pyramid (ORBFE_BLUR_MFMA=0 turns it off)
+  bool mb_ok = false;
+  uint8_t *d_mb_tx = nullptr, *d_mb_ty = nullptr;
+  std::vector<uint8_t> mb_tx, mb_ty;
   int32_t* d_qt_next = nullptr;  // [max_images]: the per-image level counter of launches whose waves pull their levels (QtGroups::order)
   QtGroups qt_single;        // one level per wave: launches too small to fill the wave slots (a frame or two: the chain of several trees in one wave would only add latency)
   int rec_cap = 0;           // upper bound of candidate records one quadtree wave keeps in LDS (launch picks <= this)

@@ -64,7 +64,10 @@ orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, hipE
       HIP_TRY(c, hipStreamWaitEvent(c->blur_stream, c->ev_blur_go, 0));
       {
         StageTimer t(c, ORBFE_STAGE_BLUR, c->blur_stream);  // (events on the stream the kernel is launched on)
-        launch_blur(c->blur_stream, c->d_lv, nl, 0, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
+        if (c->mb_ok)  // the batches' blur on the integer matrix cores (k_blur_mfma.hip)
+          launch_blur_mfma(c->blur_stream, c->d_lv, nl, c->mb, pyr, blur, c->img_pitch, c->d_mb_tx, c->d_mb_ty, n_img);
+        else
+          launch_blur(c->blur_stream, c->d_lv, nl, 0, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
       }
       HIP_TRY(c, hipEventRecord(c->ev_blur_done, c->blur_stream));
       blur_queued = true;
@@ -83,7 +86,10 @@ orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, hipE
   const bool blur_in_qt = !overlap_blur && qt_small && c->prof == 0;
   if (!overlap_blur && !blur_in_qt) {
     StageTimer t(c, ORBFE_STAGE_BLUR, st, timing);
-    launch_blur(st, c->d_lv, nl, 0, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
+    if (c->mb_ok && n_img >= 32)  // (stage timing of a batch: the kernel the production schedule runs)
+      launch_blur_mfma(st, c->d_lv, nl, c->mb, pyr, blur, c->img_pitch, c->d_mb_tx, c->d_mb_ty, n_img);
+    else
+      launch_blur(st, c->d_lv, nl, 0, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
   }
   if (!zeroed_by_resize) HIP_TRY(c, hipMemsetAsync(n_cand, 0, sizeof(int32_t) * (size_t)n_img * nl, st));
   {

@@ -104,6 +104,17 @@ struct LevelDev {
   int32_t bl_tiles_x, bl_tiles_y, bl_tile_base;  // blur:   64x16 output tiles
 };
 
+// k_blur_mfma.hip: launch geometry and band tables of the batches' blur on the integer matrix cores
+struct MbLevel {
+  int32_t wg_base, strips;  // first workgroup of the level (four 48-column strips each), strips per row
+  int32_t tx_off, ty_off;   // first band (512-byte units) of the level's column blocks / row blocks
+};
+struct MbGeom {
+  MbLevel lv[ORBFE_MAX_LEVELS];
+  int32_t n_wg;
+  uint32_t spare_off;  // byte offset, inside an image's block of the pyramid buffers, of 256 bytes no plane uses (lanes with nothing to store write there)
+};
+
 // One FAST cell (flattened over levels).  Patch = what the reference hands to cv::FAST (ORBExtractor.cc:363).
 struct CellDev {
   int16_t level;

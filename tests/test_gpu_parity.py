@@ -635,3 +635,29 @@ def test_no_limit_on_n_features_20000(orc):
         nm, ru, dp, _, _ = ctx.stereo_match(0, 1, FX, BF)
         assert np.array_equal(rk, ref["rk"]) and nm == ref["n_matches"] and np.array_equal(ru[:len(lk)], ref["right_u"])
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,nl", [(1241, 376, 8), (752, 480, 8), (640, 480, 8), (335, 200, 3), (336, 200, 3), (337, 200, 3), (351, 193, 3), (352, 207, 3),
+                                    (353, 208, 3), (383, 209, 3), (385, 191, 3), (1920, 1080, 8)])
+def test_device_batch_blur_on_the_matrix_cores(orc, lib, w, h, nl):
+    """Batches of >= 32 images blur on the integer matrix cores (k_blur_mfma.hip: both passes as banded v_mfma_i32_16x16x32_i8 products,
+    BORDER_REFLECT_101 folded into the bands): every blurred plane of every level of the first, a middle and the last image against the
+    oracle's cv::GaussianBlur restatement -- widths around the 48-column strips and 16-column blocks, heights around the 16-row tiles
+    (a last tile of 1 ... 16 rows), flat-white and flat-black images among them (the byte planes' signed offsets at their extremes)."""
+    import torch
+    B = 16
+    nf = 300 if w < 600 else 1000
+    pairs = [synth.stereo_pair_content(500 + f, ("rect", "camera", "saturated")[f % 3], w, h) for f in range(B)]
+    pairs[3] = (np.full((h, w), 255, np.uint8), np.zeros((h, w), np.uint8))
+    ctx = lib.Context(w, h, n_features=nf, n_levels=nl, max_images=2 * B)
+    dl = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
+    dr = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    ctx.stereo_batch_device(dl.data_ptr(), dr.data_ptr(), w, w * h, B, 0.58 * w, 0.58 * w * 0.11)
+    ctx.sync()
+    for slot in (0, 1, 6, 7, 2 * B - 1):
+        ex = orc.extractor(pairs[slot >> 1][slot & 1], n_features=nf, n_levels=nl)
+        for l in range(nl):
+            a, b = ctx.pyramid(slot, l, True), ex.plane(l, True)
+            assert a.shape == b.shape and np.array_equal(a, b), f"slot {slot} level {l}: {(a != b).sum()} blurred px differ (first at {np.argwhere(a != b)[:3].tolist()})"
+    ctx.close()

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../../orb_slam2_ros2_amd/csrc"
 mkdir -p ../../tools/exp/libs /tmp/ab_$1
 FLAGS="-std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-function -I../../include $2"
 for f in $(grep '^SRCS' Makefile | sed 's/SRCS = //; s/\.hip//g'); do
-  X=""; [ $f = k_fast ] && X="-mllvm -amdgpu-atomic-optimizer-strategy=None"
+  X=""; [ $f = k_fast ] && X="-mllvm -amdgpu-atomic-optimizer-strategy=None"; [ $f = k_blur_mfma ] && X="-mllvm -amdgpu-mfma-vgpr-form"
   /opt/rocm/bin/hipcc $FLAGS $X -c $f.hip -o /tmp/ab_$1/$f.o 2>/dev/null &
 done
 wait
