@@ -40,6 +40,9 @@ namespace orbfe {
 #ifndef MB_EXP
 #define MB_EXP 0
 #endif
+#ifndef MB_WAVES
+#define MB_WAVES 4  // waves (= neighbouring strips) per workgroup: 4 or 8
+#endif
 #define MB_COLS 48
 #define MB_PITCH 80  // bytes per staged row (64 + 16: rows m and m + 8 share banks, nothing worse)
 
@@ -50,18 +53,18 @@ __device__ __forceinline__ int mb_reflect101(int p, int n) {
   return p;
 }
 
-__global__ __launch_bounds__(256) void k_blur_mfma(const LevelDev* __restrict__ lv, int n_levels, MbGeom g, const uint8_t* __restrict__ pyr,
+__global__ __launch_bounds__(64 * MB_WAVES) void k_blur_mfma(const LevelDev* __restrict__ lv, int n_levels, MbGeom g, const uint8_t* __restrict__ pyr,
                                                    uint8_t* __restrict__ blur, size_t img_pitch, const uint2* __restrict__ tx_tab,
                                                    const uint2* __restrict__ ty_tab) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_rows[4][16 * MB_PITCH];
-  __shared__ __attribute__((aligned(16))) uint8_t s_out[2][16 * 4 * MB_COLS];  // the workgroup's row block on its way out: 16 rows x 192 bytes, two of them in turn
+  __shared__ __attribute__((aligned(16))) uint8_t s_rows[MB_WAVES][16 * MB_PITCH];
+  __shared__ __attribute__((aligned(16))) uint8_t s_out[2][16 * MB_WAVES * MB_COLS];  // the workgroup's row block on its way out: 16 rows x 192 bytes, two of them in turn
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   int l = 0;
   while (l + 1 < n_levels && (int)blockIdx.x >= g.lv[l + 1].wg_base) ++l;  // wave-uniform
   // the four waves of a workgroup = four neighbouring strips; a wave past the row's last strip has nothing to compute but keeps the
   // workgroup's barriers company (the row blocks leave through shared LDS, below)
   const int wgx = (int)blockIdx.x - g.lv[l].wg_base;
-  const int strip = wgx * 4 + wv;
+  const int strip = wgx * MB_WAVES + wv;
   const bool wave_active = strip < g.lv[l].strips;
   const LevelDev& L = lv[l];
   const int w = __builtin_amdgcn_readfirstlane(L.w), h = __builtin_amdgcn_readfirstlane(L.h), stride = __builtin_amdgcn_readfirstlane(L.stride);
@@ -114,12 +117,13 @@ __global__ __launch_bounds__(256) void k_blur_mfma(const LevelDev* __restrict__ 
   // row are a third of a cache line: written strip by strip as the waves come by, 1.35 ms; with the four strips of a workgroup written
   // together 1.06.  So the row block of the whole workgroup meets in shared LDS and wave v stores rows 4 v .. 4 v + 3 of it, twelve
   // 16-byte units = 192 contiguous bytes per row.
-  const int o_rr = (lane * 171) >> 11, o_unit = lane - 12 * o_rr;  // lane / 12, lane % 12 (lanes 48 .. 63: nothing to store)
-  const int o_row = 4 * wv + min(o_rr, 3);
+  constexpr int UPR = 3 * MB_WAVES, RPW = 16 / MB_WAVES;  // 16-byte units per row of the workgroup, rows per wave
+  const int o_rr = UPR == 12 ? (lane * 171) >> 11 : (lane * 171) >> 12, o_unit = lane - UPR * o_rr;  // lane / UPR, lane % UPR (lanes 48 .. 63: nothing to store)
+  const int o_row = RPW * wv + min(o_rr, RPW - 1);
   const uint32_t spare_off = g.spare_off - L.plane_off + 16u * (uint32_t)(lane & 15);  // (from D: the 256 spare bytes behind the last plane of the image's block)
-  const bool o_lane = lane < 48 && 4 * MB_COLS * wgx + 16 * o_unit < w;
-  const uint32_t st_off0 = (uint32_t)(o_row * stride + 4 * MB_COLS * wgx + 16 * o_unit);
-  const uint32_t o_lds = (uint32_t)(o_row * (4 * MB_COLS) + 16 * o_unit);
+  const bool o_lane = lane < 48 && MB_WAVES * MB_COLS * wgx + 16 * o_unit < w;
+  const uint32_t st_off0 = (uint32_t)(o_row * stride + MB_WAVES * MB_COLS * wgx + 16 * o_unit);
+  const uint32_t o_lds = (uint32_t)(o_row * (MB_WAVES * MB_COLS) + 16 * o_unit);
   const mb_v4i c_init = {8454144, 8454144, 8454144, 8454144};  // 2^23 + 2^15 + 2^15
   const mb_v4i c_zero = {0, 0, 0, 0};
 
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256) void k_blur_mfma(const LevelDev* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = ((uint32_t)vh[i] << 8) + (uint32_t)vl[i];
         const uint32_t o = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u) | __builtin_amdgcn_perm(v[3], v[2], 0x06020c0cu);
-        *(uint32_t*)(s_out[PAR] + m * (4 * MB_COLS) + MB_COLS * wv + 16 * nb + 4 * q) = o;
+        *(uint32_t*)(s_out[PAR] + m * (MB_WAVES * MB_COLS) + MB_COLS * wv + 16 * nb + 4 * q) = o;
       }
       __syncthreads();  // (one per row block: the buffer of the block after next is this one again, a barrier further on)
       // every lane stores, every time: the lanes below the image or right of it (and lanes 48 .. 63) write the image block's spare bytes
@@ -247,7 +251,7 @@ bool mb_build(const LevelDev* lv, int n_levels, const int taps[7], uint32_t spar
     g->lv[l].strips = strips;
     g->lv[l].tx_off = (int)(tx->size() / 512);
     g->lv[l].ty_off = (int)(ty->size() / 512);
-    wg += (strips + 3) / 4;
+    wg += (strips + MB_WAVES - 1) / MB_WAVES;
     for (int b = 0; b < 3 * strips; ++b) {
       uint8_t band[512];
       if (!mb_band(taps, lv[l].w, b, false, band)) return false;
@@ -266,7 +270,7 @@ bool mb_build(const LevelDev* lv, int n_levels, const int taps[7], uint32_t spar
 void launch_blur_mfma(hipStream_t s, const LevelDev* d_lv, int n_levels, const MbGeom& g, const uint8_t* d_pyr, uint8_t* d_blur, size_t img_pitch,
                       const uint8_t* d_tx, const uint8_t* d_ty, int n_img) {
   if (g.n_wg <= 0 || n_img <= 0) return;
-  hipLaunchKernelGGL(k_blur_mfma, dim3(g.n_wg, n_img), dim3(256), 0, s, d_lv, n_levels, g, d_pyr, d_blur, img_pitch, (const uint2*)d_tx,
+  hipLaunchKernelGGL(k_blur_mfma, dim3(g.n_wg, n_img), dim3(64 * MB_WAVES), 0, s, d_lv, n_levels, g, d_pyr, d_blur, img_pitch, (const uint2*)d_tx,
                      (const uint2*)d_ty);
 }
 
