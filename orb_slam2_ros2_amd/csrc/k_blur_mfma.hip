@@ -37,9 +37,6 @@
 
 namespace orbfe {
 
-#ifndef MB_EXP
-#define MB_EXP 0
-#endif
 #ifndef MB_WAVES
 #define MB_WAVES 4  // waves (= neighbouring strips) per workgroup: 4 or 8
 #endif
@@ -174,11 +171,7 @@ __global__ __launch_bounds__(64 * MB_WAVES) void k_blur_mfma(const LevelDev* __r
       // for ALL memory operations -- the tile requested a moment ago included -- where it needs the oldest loads only.)
       const uint4 ov = *(const uint4*)(s_out[PAR] + o_lds);
       const bool ok = o_lane && 16 * j + o_row < h;
-#if MB_EXP == 1  // (timing experiment: no stores but for one lane)
-      if (ov.x == 0x12345678u) *(uint4*)(D + spare_off) = ov;
-#else
       *(uint4*)(D + (ok ? st_off0 + (uint32_t)(16 * j * stride) : spare_off)) = ov;
-#endif
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
