@@ -21,6 +21,9 @@
 #define STEREO4_FROM 4  // pairs per launch from which the batch matcher is used
 #endif
 #ifndef STEREO_ROWS
+#ifndef STEREO_SAD_GRID
+#define STEREO_SAD_GRID 32  // workgroups per pair of k_stereo_sad (each loops over the work list): 512 entries per sweep
+#endif
 #define STEREO_ROWS 1   // the batch matcher: 1 = row-parallel (k_stereo_rows + k_stereo_sad), 0 = a wave per left keypoint everywhere (k_stereo)
 #endif
 
@@ -501,17 +504,22 @@ __global__ __launch_bounds__(256) void k_stereo_sad(const LevelDev* __restrict__
   const int pair = pair0 + blockIdx.y;
   const int n_work = sr.work_n[pair];
   if ((int)blockIdx.x * 16 >= n_work) return;  // (uniform for the block)
+  // A workgroup takes sixteen entries and then the sixteen gridDim.x workgroups further on: the launch is sized for a fraction of the
+  // worst case (every feature matched) -- sized for all of it, three quarters of its workgroups found nothing to do, each holding 14 KB
+  // of LDS and four wave slots for the round trip of the counter above, beside the next batch's FAST, whose throughput follows the
+  // waves it can keep resident.
   if ((int)threadIdx.x < min(n_levels, 16)) {
     s_sf[threadIdx.x] = lv[threadIdx.x].sf;
     s_off[threadIdx.x] = lv[threadIdx.x].plane_off;
     s_stride[threadIdx.x] = lv[threadIdx.x].stride;
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, grp = lane >> 4, sub = lane & 15;
-  const int wi = (blockIdx.x * 4 + wv) * 4 + grp;
   const int sl = slot_l0 + blockIdx.y * slot_step, srt = slot_r0 + blockIdx.y * slot_step;
+  __syncthreads();  // (the level table; every wave of the block passes here)
+  for (int bx = blockIdx.x; bx * 16 < n_work; bx += gridDim.x) {  // (uniform for the block)
+  const int wi = (bx * 4 + wv) * 4 + grp;
   const bool go = wi < n_work;
   const uint4 e = sr.work[(size_t)pair * n_features + (go ? wi : 0)];
-  __syncthreads();  // (the level table; every wave of the block passes here)
   const uint32_t li = e.x & 0xFFFFu;
   const float l_x = kx[(size_t)sl * n_features + li].x;  // (needed at the very end: it travels with the windows)
   const float r_x = __uint_as_float(e.z);
@@ -633,6 +641,9 @@ __global__ __launch_bounds__(256) void k_stereo_sad(const LevelDev* __restrict__
   }
   const int n_m = __popcll(__ballot(matched && sub == 0));
   if (lane == 0 && n_m > 0) atomicAdd(&n_match[pair], n_m);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();  // (the next entries' windows go where these were read from: a wave's LDS accesses execute in order)
+  }
 }
 
 void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, const uint32_t* d_off,
@@ -668,7 +679,7 @@ void launch_stereo(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint
   if (by_rows) {
     hipLaunchKernelGGL(k_stereo_rows, dim3((rows + 3) / 4, n_pairs), dim3(256), 0, s, d_kx, d_desc, d_rowoff, d_rowlist, rows, list_cap, n_features, fx,
                        mean_threshold, sr, slot_l0, slot_r0, slot_step, pair0);
-    hipLaunchKernelGGL(k_stereo_sad, dim3((n_features + 15) / 16, n_pairs), dim3(256), 0, s, d_lv, n_levels, d_pyr, img_pitch, d_kx, n_features, bf, cols0,
+    hipLaunchKernelGGL(k_stereo_sad, dim3(std::min((n_features + 15) / 16, STEREO_SAD_GRID), n_pairs), dim3(256), 0, s, d_lv, n_levels, d_pyr, img_pitch, d_kx, n_features, bf, cols0,
                        sr, d_n_match, slot_l0, slot_r0, slot_step, pair0);
     return;
   }
