@@ -10,12 +10,12 @@ XCDs' L2s (the keypoint windows of k_ic_moments / k_brief) shows more `traffic` 
 import collections, csv, json, sys
 
 # load shape of each kernel -> entry of the calibration file
-SHAPE = {"k_fast": "k_cal_dwordx4_4aligned_48", "k_blur": "k_cal_dword_aligned", "k_resize_regions": "k_cal_dwordx4_byte_aligned",
+SHAPE = {"k_fast": "k_cal_dwordx4_4aligned_48", "k_blur": "k_cal_dword_aligned", "k_blur_mfma": "k_cal_dword_aligned", "k_resize_regions": "k_cal_dwordx4_byte_aligned",
          "k_resize": "k_cal_dwordx4_aligned", "k_load_level0": "k_cal_dwordx4_byte_aligned", "k_ic_moments": "k_cal_dword_byte_aligned",
          "k_brief": "k_cal_dword_aligned", "k_stereo": "k_cal_dword_aligned", "k_quadtree": "k_cal_dword_aligned", "k_kplist": "k_cal_dword_aligned",
          "k_orient": "k_cal_dword_aligned", "k_rowtable": "k_cal_dword_aligned", "k_stereo_rows": "k_cal_dwordx4_aligned", "k_stereo_sad": "k_cal_dword_aligned",
          "k_stereo4": "k_cal_dwordx4_aligned"}
-STAGE = {"k_resize": "resize", "k_resize_fused": "resize", "k_resize_regions": "resize", "k_rowtable": "stereo", "k_kplist": "orient_brief", "k_blur": "blur", "k_fast": "fast", "k_quadtree": "quadtree", "k_ic_moments": "orient_brief",
+STAGE = {"k_resize": "resize", "k_resize_fused": "resize", "k_resize_regions": "resize", "k_rowtable": "stereo", "k_kplist": "orient_brief", "k_blur": "blur", "k_blur_mfma": "blur", "k_fast": "fast", "k_quadtree": "quadtree", "k_ic_moments": "orient_brief",
          "k_orient": "orient_brief", "k_brief": "orient_brief", "k_stereo": "stereo", "k_stereo_rows": "stereo", "k_stereo_sad": "stereo", "k_stereo4": "stereo", "k_load_level0": "load_level0"}
 
 
