@@ -20,11 +20,11 @@
 // The row pass leaves a 16 x 16 tile in the accumulator layout (lane = column, registers = rows 4 (lane >> 4) + i); the column pass
 // takes exactly that as its A operand (lane = "row" of A = image column, bytes = K = image rows) when the K slots are ORDERED like the
 // registers -- slot (lane >> 4, 4 t + i) = row 16 (j + t) - 8 + 4 (lane >> 4) + i -- and Ty_j is built in that order: no lane movement,
-// no LDS between the passes.  Its result has lane = image row, registers = four consecutive columns: one aligned 32-bit store.
+// no LDS between the passes.  Its result has lane = image row, registers = four consecutive columns.
 //
-// One wave = a strip of 48 columns (three 16-column blocks), walking down the plane in 16-row tiles; the 16 x 64-byte window of a tile
-// is staged in the wave's own LDS (coalesced 8-byte loads in, the A operand's 8 bytes per lane out).  Taps must sum to 256 with every
-// folded weight <= 127 (variant 0); other tap sets and the launches of a frame or two keep k_blur.
+// One wave = a strip of 48 columns (three 16-column blocks), walking down the plane in 16-row tiles, the next tile's operands requested
+// a tile ahead; the four strips of a workgroup hand their row blocks to shared LDS and leave as 192 contiguous bytes per row.  Taps
+// must sum to 256 with every folded weight <= 127 (variant 0); other tap sets and the launches of a frame or two keep k_blur.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -41,7 +41,6 @@ namespace orbfe {
 #define MB_WAVES 4  // waves (= neighbouring strips) per workgroup: 4 or 8
 #endif
 #define MB_COLS 48
-#define MB_PITCH 80  // bytes per staged row (64 + 16: rows m and m + 8 share banks, nothing worse)
 
 typedef int mb_v4i __attribute__((ext_vector_type(4)));
 
@@ -53,7 +52,6 @@ __device__ __forceinline__ int mb_reflect101(int p, int n) {
 __global__ __launch_bounds__(64 * MB_WAVES) void k_blur_mfma(const LevelDev* __restrict__ lv, int n_levels, MbGeom g, const uint8_t* __restrict__ pyr,
                                                    uint8_t* __restrict__ blur, size_t img_pitch, const uint2* __restrict__ tx_tab,
                                                    const uint2* __restrict__ ty_tab) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_rows[MB_WAVES][16 * MB_PITCH];
   __shared__ __attribute__((aligned(16))) uint8_t s_out[2][16 * MB_WAVES * MB_COLS];  // the workgroup's row block on its way out: 16 rows x 192 bytes, two of them in turn
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   int l = 0;
@@ -68,7 +66,6 @@ __global__ __launch_bounds__(64 * MB_WAVES) void k_blur_mfma(const LevelDev* __r
   const int img = blockIdx.y;
   const uint8_t* P = pyr + (size_t)img * img_pitch + L.plane_off;
   uint8_t* D = blur + (size_t)img * img_pitch + L.plane_off;
-  uint8_t* rows = s_rows[wv];
 
   const int q = lane >> 4, m = lane & 15;
 
@@ -79,29 +76,25 @@ __global__ __launch_bounds__(64 * MB_WAVES) void k_blur_mfma(const LevelDev* __r
     const uint2 t = tx_tab[(size_t)(g.lv[l].tx_off + 3 * min(strip, g.lv[l].strips - 1) + nb) * 64 + lane];
     txb[nb] = (long)(((unsigned long long)t.y << 32) | t.x);
   }
-  // staging: 16 rows x 8 units of 8 bytes, two units per lane; columns 48 strip - 8 ... + 55, each unit's address clamped into the row
-  // (a unit that starts left of the row or past its end holds no pixel of the image: its bytes meet zero weights)
-  int ld_row[2];
-  uint32_t ld_x[2], ld_lds[2];
+  // The row pass's A operand straight from memory in its lane layout: lane (q, m) takes 8 bytes of image row 16 tau - 8 + m at column
+  // 16 b - 8 + 8 q of each of its three blocks (the blocks' 32-column windows overlap by half: the second read of a byte hits the L1).
+  // Every address is clamped into the plane; a unit that starts left of the row or past its end holds no pixel of the image and meets
+  // zero weights.  (First version: the tile's 16 x 64-byte window staged in the wave's LDS by coalesced loads and read back from there
+  // -- the same step on `rect`, +0.7 % on `camera`, and 1.3 KB of LDS per wave that FAST beside it cannot use.  Measured and dropped,
+  // each +1.5 % on the step although it removes vector instructions: a scalar row offset for the tiles inside the plane -- two code
+  // paths --, the ^ 0x80 applied once per staged byte; tiles requested two steps ahead: no change.)
+  uint32_t dx[3];
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int it = lane + 64 * p, r = it >> 3, u = it & 7;
-    ld_row[p] = r;
-    ld_x[p] = (uint32_t)min(max(MB_COLS * strip - 8 + 8 * u, 0), stride - 8);
-    ld_lds[p] = (uint32_t)(r * MB_PITCH + 8 * u);
-  }
-  // (Measured and dropped, each +1.5 % on the step although it removes vector instructions: a scalar row offset for the tiles that lie
-  //  inside the plane -- two code paths --, and the ^ 0x80 applied to the sixteen staged bytes instead of the twenty-four read back.)
-  auto request = [&](int tau, uint2 (&v)[2]) __attribute__((always_inline)) {
+  for (int nb = 0; nb < 3; ++nb) dx[nb] = (uint32_t)min(max(MB_COLS * strip - 8 + 16 * nb + 8 * q, 0), stride - 8);
+  auto request = [&](int tau, uint2 (&v)[3]) __attribute__((always_inline)) {
+    const int gy = min(max(16 * tau - 8 + m, 0), h - 1);
+    const uint32_t ro = (uint32_t)(gy * stride);
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int gy = min(max(16 * tau - 8 + ld_row[p], 0), h - 1);
-      v[p] = *(const uint2*)(P + ((uint32_t)(gy * stride) + ld_x[p]));
-    }
+    for (int nb = 0; nb < 3; ++nb) v[nb] = *(const uint2*)(P + (ro + dx[nb]));
   };
   const int n_blocks = (h + 15) >> 4;  // row blocks of the output; tiles tau = 0 .. n_blocks (tile tau = rows 16 tau - 8 .. 16 tau + 7)
   const uint2* ty_l = ty_tab + (size_t)g.lv[l].ty_off * 64 + lane;
-  uint2 cur[2];
+  uint2 cur[3];
   uint2 ty_nx = make_uint2(0u, 0u);
   request(0, cur);
   uint32_t hi_t[2][3], lo_t[2][3];  // the packed planes of the tile in K slot 0 / 1 (= tile parity), per column block
@@ -127,8 +120,7 @@ __global__ __launch_bounds__(64 * MB_WAVES) void k_blur_mfma(const LevelDev* __r
   // tile tau (compile-time parity PAR = tau & 1): stage, row pass, and -- from the second tile on -- the column pass of row block tau - 1
   auto step = [&](const int tau, auto par) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par)::value;
-    *(uint2*)(rows + ld_lds[0]) = cur[0];
-    *(uint2*)(rows + ld_lds[1]) = cur[1];
+    const uint2 aop[3] = {cur[0], cur[1], cur[2]};
     // the next tile and the next row block's band travel under this tile's work.  (The band FIRST: requested after the rows and used in
     // this very step it made the compiler wait for everything outstanding -- the rows just requested included -- at every step.)
     const uint2 ty = ty_nx;
@@ -140,7 +132,7 @@ __global__ __launch_bounds__(64 * MB_WAVES) void k_blur_mfma(const LevelDev* __r
     __builtin_amdgcn_wave_barrier();  // a wave's LDS accesses execute in order; this only pins the compiler
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb) {
-      uint2 a = *(const uint2*)(rows + m * MB_PITCH + 16 * nb + 8 * q);
+      uint2 a = aop[nb];
       a.x ^= 0x80808080u, a.y ^= 0x80808080u;  // p - 128 as a signed byte
       const mb_v4i dh =
           __builtin_amdgcn_mfma_i32_16x16x32_i8((long)(((unsigned long long)a.y << 32) | a.x), txb[nb], c_zero, 0, 0, 0);
