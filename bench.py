@@ -1197,7 +1197,7 @@ def main():
             # batch, i.e. NLEVELS k_fast launches, the small levels on a second stream BESIDE the large ones.  Their rocprofv3
             # durations therefore overlap: the matching trace figure is the union of the launches' intervals per step (column
             # UnionNs / steps of profiles/*_kernel_stats.csv, tools/kernel_stats_from_db.py), not average x NLEVELS
-            "kernel_launches_per_step": {"fast": NLEVELS, "orient_brief": 4, "resize": 1, "blur": 2, "quadtree": 1, "stereo": 2}[dom],
+            "kernel_launches_per_step": {"fast": NLEVELS, "orient_brief": 4, "resize": 1, "blur": 1, "quadtree": 1, "stereo": 3}[dom],
             "avg_launch_ms_alone": stages_inline[dom],
             "rocprof_match": ("union of the k_fast launches of a step (UnionNs / steps in the newest profiles/r*_kernel_stats.csv); LIVE figure of the "
                               "production schedule: the level-0 blur runs beside FAST on the second stream (avg_launch_ms_alone: nothing beside it)")
@@ -1215,7 +1215,7 @@ def main():
     def _round_key(f):  # r2_v10 after r2_v9
         return [int(x) for x in _re.findall(r"\d+", f)]
     sq_files = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_sq_counters.json")), key=_round_key)
-    kern_of = {"fast": "k_fast", "blur": "k_blur", "quadtree": "k_quadtree", "stereo": "k_stereo", "resize": "k_resize_regions"}
+    kern_of = {"fast": "k_fast", "blur": "k_blur_mfma", "quadtree": "k_quadtree", "stereo": "k_stereo", "resize": "k_resize_regions"}
     if sq_files and dom in kern_of:
         try:
             sq = json.load(open(os.path.join(ROOT, "profiles", sq_files[-1])))
