@@ -852,7 +852,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--prewarm-seconds", type=float, default=1.5,
+    ap.add_argument("--prewarm-seconds", type=float, default=3.0,
                     help="untimed steps run before the W warm-up steps until this much wall time has passed: the GPU needs "
                          "~0.3 s of sustained load to leave its idle clocks (measured: first 30 steps 13 %% slower)")
     ap.add_argument("--pairs", type=int, default=512, help="stereo pairs per step (per GPU)")
@@ -1040,6 +1040,10 @@ def main():
     dom = max((k for k in stages if k in stage_bytes), key=lambda k: stages[k])
     stage_id = {"resize": 0, "blur": 1, "fast": 2, "quadtree": 3, "orient_brief": 4, "stereo": 5}[dom]
 
+    # warm-up of the exchange: the first torch indexing / RCCL call initialises lazily (tens of ms).  BEFORE the sustained load below, not
+    # between it and the clock: the chip's clocks sag within milliseconds of idling, and a 20-step run (0.1 s) is over before they are back
+    gather_results()
+    ctx.sync()
     # sustained load right in front of the clock (the stage pass above runs every kernel alone between synchronisations: the chip falls
     # back towards its idle clocks there, and the first ~30 steps after that are up to 13 % slower -- a 20-step run would time exactly those)
     t_pre = time.perf_counter()
@@ -1049,8 +1053,6 @@ def main():
         ctx.sync()
     for _ in range(args.warmup):
         step()
-    ctx.sync()
-    gather_results()  # warm-up of the exchange too: the first torch indexing / RCCL call initialises lazily (tens of ms)
     sync_all()
     # the timed region runs the production schedule (blur under the quadtree, stereo match of a batch under the front of the next);
     # the dominant stage alone carries HIP events on the stream it is launched on, so its duration is measured LIVE in this region --
