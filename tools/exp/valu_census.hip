@@ -78,8 +78,14 @@
   X(68, "v_cmp_gt_i16 vcc, %0, %1", a, c1, c2)                                   \
   X(69, "v_subrev_u16 %0, %0, %1", a, c1, c2)                                    \
   X(70, "v_lshrrev_b16 %0, 1, %0", a, c1, c2)                                    \
-  X(71, "v_mul_lo_u16 %0, %0, %1", a, c1, c2)
-#define N_OPS 72
+  X(71, "v_mul_lo_u16 %0, %0, %1", a, c1, c2)                                    \
+  X(72, "v_max_u16_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2", a, c1, c2) \
+  X(73, "v_min_u16_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_3", a, c1, c2) \
+  X(74, "v_sub_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1", a, c1, c2)   \
+  X(75, "v_max_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2", a, c1, c2) \
+  X(76, "v_and_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD", a, c1, c2)  \
+  X(77, "v_mov_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2", a, c1, c2)
+#define N_OPS 78
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(uint32_t* out, int iters) {
