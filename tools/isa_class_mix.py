@@ -4,7 +4,7 @@ the rate of the others once several waves share a SIMD (profiles/r5_valu_peak.tx
 against 535 - 575 G; one wave alone: the same 5 cycles either way).  FAST, as measured: 32-bit add / sub / and / or / xor / right shifts /
 mov, fp32 add / sub / mul / fma, and the non-packed 16-bit VOP2 arithmetic (add, sub, min, max, mul_lo, shifts).  SLOW: everything else the
 census tried -- 32-bit min / max / min3 / max3, v_lshlrev_b32, multiplies and mads, bfe / perm / alignbit / bfi, dots, sads, compares,
-cndmask, conversions, every packed (v_pk_*) op.  An opcode the census did not try counts as slow.
+cndmask, conversions, every packed (v_pk_*) op, and every *_sdwa form whatever its opcode.  An opcode the census did not try counts as slow.
 
 Compiles the kernel sources to ISA here (no GPU needed) and counts the opcodes of each kernel symbol: a STATIC mix (not weighted by
 execution), written to profiles/r5_isa_class_mix.json for bench.py's roofline_valu."""
@@ -31,7 +31,7 @@ def mix_of(src, extra=()):
         sym, body = m.group(1), m.group(2)
         name = re.sub(r"^_ZN5orbfe\d+", "", sym)
         name = re.match(r"[a-z_0-9]+", name).group(0) if re.match(r"[a-z_0-9]+", name) else sym
-        ops = collections.Counter(re.sub(r"_e(32|64)$|_dpp$|_sdwa$", "", x.group(1)) for x in re.finditer(r"^\s+(v_[a-z0-9_]+)", body, re.M))
+        ops = collections.Counter(re.sub(r"_e(32|64)$|_dpp$", "", x.group(1)) for x in re.finditer(r"^\s+(v_[a-z0-9_]+)", body, re.M))
         ops = {k: v for k, v in ops.items() if not k.startswith(NOT_ALU)}
         tot, fast = sum(ops.values()), sum(v for k, v in ops.items() if k in FAST)
         e = out.setdefault(name, {"valu_static": 0, "fast_static": 0, "instances": 0, "top": collections.Counter()})
