@@ -48,7 +48,7 @@ def mix_of(src, extra=()):
 def main():
     res = {"what": __doc__.split("\n\n")[0], "fast_opcodes": sorted(FAST), "kernels": {}}
     csrc = os.path.join(ROOT, "orb_slam2_ros2_amd", "csrc")
-    for f, extra in (("k_fast.hip", ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]), ("k_pyramid.hip", []), ("k_quadtree.hip", []), ("k_brief.hip", []),
+    for f, extra in (("k_fast.hip", ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]), ("k_pyramid.hip", []), ("k_blur_mfma.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]), ("k_quadtree.hip", []), ("k_brief.hip", []),
                      ("k_match.hip", [])):
         for k, v in mix_of(os.path.join(csrc, f), extra).items():
             if k.startswith("k_"):
