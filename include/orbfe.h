@@ -70,7 +70,7 @@ typedef struct orbfe_keypoint {
 } orbfe_keypoint;
 
 typedef struct orbfe_config {
-  int32_t width, height;       /* level-0 image size (e.g. 1241x376 KITTI, 640x480 TUM)                 */
+  int32_t width, height;       /* level-0 image size (e.g. 1241x376 KITTI, 640x480 TUM); each <= 4096    */
   int32_t n_features;          /* ORBExtractor.nFeatures.  No limit besides 65535 (indices of the stereo row table are 16 bit):
                                   a level whose quota exceeds ~2700 keypoints (nFeatures > ~12000 at 8 levels x 1.2) keeps its
                                   quadtree node table in global memory instead of one CU's LDS -- exact, slower.

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const KpX* __restrict__ kx,
     const int min_d = my_best >> 16, min_idx = my_best & 0xFFFF;
     const size_t o = (size_t)pair * n_features + my_li;
     if (any) sr.best_right[o] = min_idx, sr.best_dist[o] = min_d;
-    const int l_oct = (int)(lxq.q & 7u), r_oct = (int)(my_wq & 7u);
+    const int l_oct = ORBFE_KPX_OCT(lxq.q), r_oct = ORBFE_KPX_OCT(my_wq);
     const bool go = any && min_d <= mean_threshold && !(l_oct > r_oct + 1 || l_oct < r_oct - 1);
     const unsigned long long gm = __ballot(go);
     if (gm) {
@@ -527,15 +527,15 @@ __global__ __launch_bounds__(256) void k_stereo_sad(const LevelDev* __restrict__
   double out_u = -1.0, out_depth = -1.0;
   int matched = 0;
   {
-    const int ol = go ? (int)(l_q & 7u) : 0, orr = go ? (int)(r_q & 7u) : 0;
+    const int ol = go ? ORBFE_KPX_OCT(l_q) : 0, orr = go ? ORBFE_KPX_OCT(r_q) : 0;
     const float sf_r = s_sf[orr];
     const int stride_l = s_stride[ol], stride_r = s_stride[orr];
     const uint8_t* IL = pyr + (size_t)sl * img_pitch;  // wave-uniform bases; the rest of the address is a 32-bit offset
     const uint8_t* IR = pyr + (size_t)srt * img_pitch;
     const uint32_t off_l = s_off[ol], off_r = s_off[orr];
     // (an idle row of lanes reads around (16, 16) of level 0: harmless)
-    const int lx = go ? (int)((l_q >> 3) & 0x1FFFu) : 16, ly = go ? (int)(l_q >> 16) : 16;  // getPitch (:1004-1006), computed with the keypoint (KpX)
-    const int rx = go ? (int)((r_q >> 3) & 0x1FFFu) : 16, ry = go ? (int)(r_q >> 16) : 16;
+    const int lx = go ? ORBFE_KPX_QX(l_q) : 16, ly = go ? ORBFE_KPX_QY(l_q) : 16;  // getPitch (:1004-1006), computed with the keypoint (KpX)
+    const int rx = go ? ORBFE_KPX_QX(r_q) : 16, ry = go ? ORBFE_KPX_QY(r_q) : 16;
     uint32_t* wl = s_sad[wv][grp];
     uint32_t* wr = wl + 44;
     const int lxa = (lx - 5) & ~3, rxa = (rx - 10) & ~3;

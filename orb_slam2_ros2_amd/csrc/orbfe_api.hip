@@ -601,7 +601,8 @@ void orbfe_destroy(orbfe_ctx* c) {
 orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   if (!cfg || !out) return fail(nullptr, ORBFE_EBADARG, "orbfe_create: NULL argument");
   *out = nullptr;
-  if (cfg->width <= 0 || cfg->height <= 0 || cfg->n_features < 0 || cfg->n_features > 65535 || cfg->n_levels < 1 || cfg->n_levels > ORBFE_MAX_LEVELS ||
+  // 4096: candidate records carry x and y in 12 bits each (ORBFE_REC_*), the matcher's KpX record the patch centre in 14
+  if (cfg->width <= 0 || cfg->height <= 0 || cfg->width > 4096 || cfg->height > 4096 || cfg->n_features < 0 || cfg->n_features > 65535 || cfg->n_levels < 1 || cfg->n_levels > ORBFE_MAX_LEVELS ||
       !(cfg->scale_factor > 1.0f) || cfg->max_images < 1 || cfg->max_images > 65535)
     return fail(nullptr, ORBFE_EBADARG, "orbfe_create: bad config (w=%d h=%d nfeat=%d levels=%d scale=%g max_images=%d)", cfg->width,
                 cfg->height, cfg->n_features, cfg->n_levels, (double)cfg->scale_factor, cfg->max_images);
@@ -827,6 +828,7 @@ orbfe_status orbfe_sync(orbfe_ctx* c) {
 orbfe_status orbfe_fetch_features(orbfe_ctx* c, int32_t slot, orbfe_keypoint* kps, uint8_t* desc, int32_t* n_out) {
   ApiLock api_lk(c);
   if (!c || slot < 0 || slot >= c->cfg.max_images) return fail(c, ORBFE_EBADARG, "fetch_features: slot %d", slot);
+  TRY(slots_idle(c, slot, 1, "fetch_features"));
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
   const size_t NF = (size_t)c->cfg.n_features;
@@ -881,6 +883,7 @@ orbfe_status orbfe_fetch_batch(orbfe_ctx* c, int32_t slot0, int32_t n_slots, orb
   ApiLock api_lk(c);
   if (!c || slot0 < 0 || n_slots < 0 || slot0 + n_slots > c->cfg.max_images) return fail(c, ORBFE_EBADARG, "fetch_batch: slots [%d, %d)", slot0, slot0 + n_slots);
   if (n_slots == 0) return ORBFE_OK;
+  TRY(slots_idle(c, slot0, n_slots, "fetch_batch"));
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1), s0 = (size_t)slot0, n = (size_t)n_slots;
@@ -953,6 +956,7 @@ orbfe_status orbfe_debug_candidates(orbfe_ctx* c, int32_t slot, int32_t level, f
   ApiLock api_lk(c);
   if (!c || slot < 0 || slot >= c->cfg.max_images || level < 0 || level >= c->cfg.n_levels || !n_out)
     return fail(c, ORBFE_EBADARG, "debug_candidates: bad argument");
+  TRY(slots_idle(c, slot, 1, "debug_candidates"));
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
   const LevelDev& L = c->lv[level];

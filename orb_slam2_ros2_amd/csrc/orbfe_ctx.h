@@ -177,7 +177,8 @@ struct orbfe_ctx {
     size_t h_stage_bytes = 0;
     std::vector<GraphEntry> graphs;
     bool use_graphs = true;
-    bool pending = false;  // orbfe_extract_slot_begin has enqueued an extraction that orbfe_extract_slot_end has not collected yet
+    std::atomic<bool> pending{false};  // orbfe_extract_slot_begin has enqueued an extraction that orbfe_extract_slot_end has not collected yet
+                                       // (written under `mu`, read by slots_idle() of every other entry point that names the slot)
   };
   // Host-image stream (orbfe_stream_submit / _wait): batch k+1 is uploaded and the packed results of batch k-1 are downloaded while
   // batch k is computed.  kDepth (three) input and result buffers on the device, one copy stream per direction.
@@ -348,6 +349,17 @@ static orbfe_status dev_alloc(orbfe_ctx* c, T** p, size_t count) {
     orbfe_status st_ = (expr);             \
     if (st_ != ORBFE_OK) return st_;       \
   } while (0)
+
+// include/orbfe.h: between orbfe_extract_slot_begin and orbfe_extract_slot_end a slot accepts no other call.  Every entry point that reads or
+// writes slots [slot0, slot0 + n) asks here first: the begun extraction runs on the slot's own lane, which the context stream does not wait for.
+static inline orbfe_status slots_idle(orbfe_ctx* c, int slot0, int n, const char* who) {
+  std::lock_guard<std::mutex> lk(c->slot_lane_mu);
+  const int hi = std::min(slot0 + n, (int)c->slot_lane.size());
+  for (int k = std::max(slot0, 0); k < hi; ++k)
+    if (c->slot_lane[(size_t)k] && c->slot_lane[(size_t)k]->pending.load())
+      return fail(c, ORBFE_EBADARG, "%s: slot %d has an outstanding orbfe_extract_slot_begin (call orbfe_extract_slot_end first)", who, k);
+  return ORBFE_OK;
+}
 
 orbfe_status ensure_tmp(orbfe_ctx* c, size_t bytes);
 orbfe_status ensure_stage(orbfe_ctx* c, orbfe_ctx::Lane& ln, size_t bytes);

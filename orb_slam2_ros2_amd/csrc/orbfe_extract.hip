@@ -382,6 +382,7 @@ orbfe_status orbfe_extract_batch(orbfe_ctx* c, int32_t n_img, const uint8_t* con
   if (n_img > c->cfg.max_images) return fail(c, ORBFE_ECAPACITY, "extract_batch: %d images > max_images %d", n_img, c->cfg.max_images);
   if (stride < (size_t)c->cfg.width) return fail(c, ORBFE_EBADARG, "extract_batch: stride %zu < width %d", stride, c->cfg.width);
   if (n_img == 0) return ORBFE_OK;
+  TRY(slots_idle(c, 0, n_img, "extract_batch"));
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
   return extract_lane(c, c->main, 0, n_img, imgs, stride, kps, desc, n_out, true);
@@ -397,6 +398,7 @@ orbfe_status orbfe_frame_stereo(orbfe_ctx* c, const uint8_t* left, const uint8_t
   if (!c || !left || !right) return fail(c, ORBFE_EBADARG, "frame_stereo: NULL argument");
   if (c->cfg.max_images < 2) return fail(c, ORBFE_ECAPACITY, "frame_stereo: the context holds %d image(s), a stereo frame needs 2", c->cfg.max_images);
   if (stride < (size_t)c->cfg.width) return fail(c, ORBFE_EBADARG, "frame_stereo: stride %zu < width %d", stride, c->cfg.width);
+  TRY(slots_idle(c, 0, 2, "frame_stereo"));
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
   const uint8_t* imgs[2] = {left, right};
@@ -524,6 +526,7 @@ orbfe_status orbfe_extract_color(orbfe_ctx* c, const uint8_t* img, size_t stride
   if (!c || !img) return fail(c, ORBFE_EBADARG, "extract_color: NULL argument");
   if (color_order != 1 && color_order != 2) return fail(c, ORBFE_EBADARG, "extract_color: color_order %d (1 = RGB, 2 = BGR)", color_order);
   if (stride < (size_t)c->cfg.width * 3) return fail(c, ORBFE_EBADARG, "extract_color: stride %zu < 3 * width", stride);
+  TRY(slots_idle(c, 0, 1, "extract_color"));
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
   const uint8_t* one[1] = {img};
@@ -540,6 +543,7 @@ orbfe_status orbfe_frame_rgbd(orbfe_ctx* c, int32_t slot, const orbfe_camera* ca
   const size_t px = depth_type == 0 ? 2 : 4;
   if (depth && (depth_type < 0 || depth_type > 1 || depth_stride < (size_t)c->cfg.width * px || !(depth_scale > 0)))
     return fail(c, ORBFE_EBADARG, "frame_rgbd: depth type %d stride %zu scale %g", depth_type, depth_stride, (double)depth_scale);
+  TRY(slots_idle(c, slot, 1, "frame_rgbd"));
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
@@ -570,6 +574,7 @@ orbfe_status orbfe_get_pyramid(orbfe_ctx* c, int32_t slot, int32_t level, int32_
   ApiLock api_lk(c);
   if (!c || !dst || slot < 0 || slot >= c->cfg.max_images || level < 0 || level >= c->cfg.n_levels)
     return fail(c, ORBFE_EBADARG, "get_pyramid: slot %d level %d", slot, level);
+  TRY(slots_idle(c, slot, 1, "get_pyramid"));
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
   const LevelDev& L = c->lv[level];
@@ -584,6 +589,8 @@ orbfe_status orbfe_stereo_match(orbfe_ctx* c, int32_t slot_left, int32_t slot_ri
   ApiLock api_lk(c);
   if (!c || slot_left < 0 || slot_right < 0 || slot_left >= c->cfg.max_images || slot_right >= c->cfg.max_images)
     return fail(c, ORBFE_EBADARG, "stereo_match: slots %d/%d", slot_left, slot_right);
+  TRY(slots_idle(c, slot_left, 1, "stereo_match"));
+  TRY(slots_idle(c, slot_right, 1, "stereo_match"));
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
   const int pair = slot_left / 2;
@@ -705,6 +712,7 @@ orbfe_status orbfe_stereo_batch_device(orbfe_ctx* c, const uint8_t* d_left, cons
   if (stride < (size_t)c->cfg.width || image_pitch < stride * (size_t)c->cfg.height)
     return fail(c, ORBFE_EBADARG, "stereo_batch_device: stride/pitch too small");
   if (n_pairs == 0) return ORBFE_OK;
+  TRY(slots_idle(c, 0, 2 * n_pairs, "stereo_batch_device"));
   HIP_TRY(c, hipSetDevice(c->device));
   return batch_device_core(c, d_left, d_right, stride, image_pitch, n_pairs, fx, bf, nullptr);
 }

@@ -193,6 +193,7 @@ orbfe_status orbfe_search_in_area(orbfe_ctx* c, int32_t slot, int32_t nq, const 
   if (nq && (!qxy || !radius || !min_level || !max_level || !q_desc || !best_idx || !best_dist || !second_dist || !n_cand))
     return fail(c, ORBFE_EBADARG, "search_in_area: NULL argument");
   if (nq == 0) return ORBFE_OK;
+  TRY(slots_idle(c, slot, 1, "search_in_area"));
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
   const size_t NF = (size_t)std::max(c->cfg.n_features, 1);
@@ -320,6 +321,7 @@ orbfe_status orbfe_track_local_map(orbfe_ctx* c, int32_t slot, const orbfe_frame
   if (!area_grid(c, bounds, &ag)) return fail(c, ORBFE_EBADARG, "track_local_map: bad frame bounds");
   const size_t ncells = (size_t)ag.rows * ag.cols;
   if ((2 * ncells + 1) * 4 > 60 * 1024) return fail(c, ORBFE_EBADSIZE, "track_local_map: %zu grid cells exceed the LDS counters", ncells);
+  TRY(slots_idle(c, slot, 1, "track_local_map"));
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
   const size_t N = (size_t)std::max(n, 1);
@@ -431,6 +433,7 @@ orbfe_status orbfe_track_motion_model(orbfe_ctx* c, int32_t slot, const float* b
   if (!area_grid(c, bounds4, &ag)) return fail(c, ORBFE_EBADARG, "track_motion_model: bad frame bounds");
   const size_t ncells = (size_t)ag.rows * ag.cols;
   if ((2 * ncells + 1) * 4 > 60 * 1024) return fail(c, ORBFE_EBADSIZE, "track_motion_model: %zu grid cells exceed the LDS counters", ncells);
+  TRY(slots_idle(c, slot, 1, "track_motion_model"));
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(join_stereo(c));
   const size_t N = (size_t)std::max(n, 1);

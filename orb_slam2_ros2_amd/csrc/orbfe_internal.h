@@ -140,9 +140,12 @@ struct KpAux {
 // cvFloor(pt / scale[octave]) (ORBMatcher.cc:1004-1006) -- so that the best candidate's keypoint record is not a memory round trip of its own
 struct KpX {
   float x;
-  uint32_t q;  // octave (3 bits) | cvFloor(pt.x / sf) << 3 (13 bits) | cvFloor(pt.y / sf) << 16
+  uint32_t q;  // octave (4 bits: ORBFE_MAX_LEVELS = 16) | cvFloor(pt.x / sf) << 4 (14 bits) | cvFloor(pt.y / sf) << 18 (14 bits; orbfe_create bounds the image at 4096 x 4096)
 };
-#define ORBFE_KPX_Q(oct, qx, qy) ((uint32_t)(oct) | ((uint32_t)(qx) << 3) | ((uint32_t)(qy) << 16))
+#define ORBFE_KPX_Q(oct, qx, qy) ((uint32_t)(oct) | ((uint32_t)(qx) << 4) | ((uint32_t)(qy) << 18))
+#define ORBFE_KPX_OCT(q) ((int)((q)&15u))
+#define ORBFE_KPX_QX(q) ((int)(((q) >> 4) & 0x3FFFu))
+#define ORBFE_KPX_QY(q) ((int)((q) >> 18))
 
 // device buffers of the batches' row-parallel stereo matcher (k_match.hip), per pair
 struct StereoRowsBuf {

@@ -94,6 +94,7 @@ orbfe_status orbfe_stream_submit(orbfe_ctx* c, const uint8_t* left, const uint8_
   if (2 * n_pairs > c->cfg.max_images) return fail(c, ORBFE_ECAPACITY, "stream_submit: %d pairs need %d slots > %d", n_pairs, 2 * n_pairs, c->cfg.max_images);
   if (stride < (size_t)c->cfg.width || image_pitch < stride * (size_t)c->cfg.height)
     return fail(c, ORBFE_EBADARG, "stream_submit: stride/pitch too small");
+  TRY(slots_idle(c, 0, 2 * n_pairs, "stream_submit"));
   HIP_TRY(c, hipSetDevice(c->device));
   orbfe_ctx::HostStream& hs = c->hs;
   if (!hs.init) {

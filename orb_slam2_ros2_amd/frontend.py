@@ -10,10 +10,15 @@ Reference interfaces mirrored (relative to src/ORB_SLAM2/):
 """
 from __future__ import annotations
 
+import re
+
 import numpy as np
 
 from . import _lib
 from ._lib import Context, ImageSizeError, OrbfeError  # noqa: F401
+
+
+_ISTREAM_FLOAT = re.compile(r"\s*([+-]?(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?)")
 
 
 def load_brief_template(path: str) -> np.ndarray:
@@ -30,12 +35,18 @@ def load_brief_template(path: str) -> np.ndarray:
         lines.pop()                       # std::getline yields no extra line after a final newline
     for ln in lines[1:]:
         vals = [0.0, 0.0, 0.0, 0.0]
-        for k, tok in enumerate(ln.split()[:4]):
-            try:
-                vals[k] = float(tok)
-            except ValueError:
-                break                     # the stream is in a failed state: the remaining values keep their zeros
-        rows.append([int(v) for v in vals])
+        pos = 0
+        for k in range(4):
+            # operator>>(float): skip white space, then take the LONGEST prefix that reads as a number ("7x" is 7 and the NEXT extraction
+            # fails on the 'x'); when nothing parses the stream is in a failed state: this and the remaining values keep their zeros
+            m = _ISTREAM_FLOAT.match(ln, pos)
+            if not m:
+                break
+            vals[k] = float(m.group(1))
+            pos = m.end()
+        if any(not (-129.0 < v < 128.0) for v in vals):   # (the C++ loader's cast to int8_t would be undefined: both loaders refuse)
+            raise ValueError(f"{path}: BRIEF template value outside [-128, 127] in line {len(rows) + 2}")
+        rows.append([int(v) for v in vals])               # truncation toward zero, like the (int8_t) cast
     if len(rows) < 256:
         raise ValueError(f"{path}: {len(rows)} BRIEF pairs; the descriptor needs 256 (the reference would index past its template)")
     return np.asarray(rows[:256], np.int8)

@@ -14,6 +14,7 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -75,7 +76,10 @@ inline std::vector<int8_t> loadBriefTemplate(const std::string& path) {
     std::istringstream iss(line);
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     iss >> v[0] >> v[1] >> v[2] >> v[3];
-    for (float f : v) out.push_back((int8_t)f);
+    for (float f : v) {
+      if (!(f > -129.f && f < 128.f)) throw std::runtime_error("BRIEF template value outside [-128, 127] (line " + std::to_string(out.size() / 4 + 2) + "): " + path);
+      out.push_back((int8_t)f);
+    }
   }
   if (out.size() < 1024) throw std::runtime_error("BRIEF template holds fewer than the 256 pairs a descriptor needs: " + path);
   out.resize(1024);
@@ -125,26 +129,43 @@ class ContextPool {
     slots()[ctx] = SlotTable{0, std::vector<uint64_t>((size_t)maxImages, 0)};
     return ctx;
   }
-  // the next slot of the context, and the generation its new content carries
+  // the next slot of the context, and the generation its new content carries.  Slots on which an eagerStart constructor has begun an
+  // extraction that nobody has collected yet (setBusy) are passed over: the library refuses every other call on such a slot.  So at most
+  // `maxImages` (kSlots) extractor objects of one context can be constructed-but-not-extracted at a time; the next one throws.
   static Lease acquire(orbfe_ctx* ctx) {
     std::lock_guard<std::mutex> lk(mu());
-    SlotTable& t = slots()[ctx];
-    if (t.generation.empty()) t.generation.assign(kSlots, 0);
-    Lease l;
-    l.slot = t.next;
-    t.next = (t.next + 1) % (int)t.generation.size();
-    l.generation = ++t.generation[(size_t)l.slot];
-    return l;
+    SlotTable& t = table(ctx);
+    const int n = (int)t.generation.size();
+    for (int k = 0; k < n; ++k) {
+      const int s = (t.next + k) % n;
+      if (t.busy[(size_t)s]) continue;
+      Lease l;
+      l.slot = s;
+      t.next = (s + 1) % n;
+      l.generation = ++t.generation[(size_t)s];
+      return l;
+    }
+    throw std::logic_error("ContextPool::acquire: every slot of the context holds a started extraction nobody has collected "
+                           "(ORBExtractor::eagerStart: at most ContextPool::kSlots constructed-but-not-extracted objects per context)");
+  }
+  static void setBusy(orbfe_ctx* ctx, int slot, bool on) {
+    std::lock_guard<std::mutex> lk(mu());
+    SlotTable& t = table(ctx);
+    if (slot >= 0 && (size_t)slot < t.busy.size()) t.busy[(size_t)slot] = on ? 1 : 0;
   }
   // the next slot PAIR (even, odd) of the context for orbfe_frame_stereo_slots: both slots of the pair get a new generation
   static std::pair<Lease, Lease> acquirePair(orbfe_ctx* ctx) {
     std::lock_guard<std::mutex> lk(mu());
-    SlotTable& t = slots()[ctx];
-    if (t.generation.empty()) t.generation.assign(kSlots, 0);
+    SlotTable& t = table(ctx);
     const int n = (int)t.generation.size();
     if (n < 2) throw std::logic_error("ContextPool::acquirePair: the context has fewer than two slots");
     int s = (t.next + 1) & ~1;
     if (s + 1 >= n) s = 0;
+    for (int k = 0; t.busy[(size_t)s] || t.busy[(size_t)s + 1]; ++k) {  // (a pair with a started, uncollected extraction is passed over)
+      if (2 * k >= n) throw std::logic_error("ContextPool::acquirePair: every slot pair of the context holds a started extraction nobody has collected");
+      s += 2;
+      if (s + 1 >= n) s = 0;
+    }
     t.next = (s + 2) % n;
     Lease a, b;
     a.slot = s, b.slot = s + 1;
@@ -163,7 +184,14 @@ class ContextPool {
   struct SlotTable {
     int next = 0;
     std::vector<uint64_t> generation;
+    std::vector<uint8_t> busy;  // an orbfe_extract_slot_begin is outstanding on the slot (eagerStart)
   };
+  static SlotTable& table(orbfe_ctx* ctx) {  // (under mu())
+    SlotTable& t = slots()[ctx];
+    if (t.generation.empty()) t.generation.assign(kSlots, 0);
+    if (t.busy.size() != t.generation.size()) t.busy.assign(t.generation.size(), 0);
+    return t;
+  }
   static std::mutex& mu() {
     static std::mutex m;
     return m;
@@ -194,11 +222,15 @@ class ORBExtractor {
     if (eagerStart()) {  // the device starts on the image NOW, as the reference's constructor builds the pyramid now (src/ORBExtractor.cc:205-214)
       mLease = ContextPool::acquire(mCtx);
       check(mCtx, orbfe_extract_slot_begin(mCtx, mLease.slot, mImage.data, mImage.step));
+      ContextPool::setBusy(mCtx, mLease.slot, true);
       mStarted = true;
     }
   }
   ~ORBExtractor() {
-    if (mStarted) (void)orbfe_extract_slot_end(mCtx, mLease.slot, nullptr, nullptr, nullptr);  // an extraction nobody collected: drain the slot
+    if (!mStarted) return;  // an extraction nobody collected: drain the slot (a destructor cannot throw: a device error is reported on stderr)
+    const orbfe_status st = orbfe_extract_slot_end(mCtx, mLease.slot, nullptr, nullptr, nullptr);
+    ContextPool::setBusy(mCtx, mLease.slot, false);
+    if (st != ORBFE_OK) std::fprintf(stderr, "[orbfe] ~ORBExtractor: draining slot %d failed: %s\n", mLease.slot, orbfe_last_error(mCtx));
   }
   ORBExtractor(const ORBExtractor&) = delete;
   ORBExtractor& operator=(const ORBExtractor&) = delete;
@@ -228,7 +260,11 @@ class ORBExtractor {
       int32_t n = 0;
       if (mStarted) {  // the constructor enqueued it (eagerStart): collect
         mStarted = false;
-        check(mCtx, orbfe_extract_slot_end(mCtx, mLease.slot, keyPoints.data(), descriptors.data()->data(), &n));
+        const orbfe_status st = orbfe_extract_slot_end(mCtx, mLease.slot, keyPoints.data(), descriptors.data()->data(), &n);
+        ContextPool::setBusy(mCtx, mLease.slot, false);
+        check(mCtx, st);
+      } else if (mDrained && resident()) {  // getPyramidLevel / searchByStereo came first and drained the started extraction: its results are in the slot
+        check(mCtx, orbfe_fetch_features(mCtx, mLease.slot, keyPoints.data(), descriptors.data()->data(), &n));
       } else {
         mLease = ContextPool::acquire(mCtx);
         check(mCtx, orbfe_extract_slot(mCtx, mLease.slot, mImage.data, mImage.step, keyPoints.data(), descriptors.data()->data(), &n));
@@ -307,6 +343,7 @@ class ORBExtractor {
   // (like the reference's pyramid, it lives as long as the image does).
   std::vector<uint8_t> getPyramidLevel(int l, int* w = nullptr, int* h = nullptr) {
     rethrowPending();
+    drainStarted();  // (legal in the reference before extract(): its constructor has built the pyramid; a begun slot refuses orbfe_get_pyramid)
     orbfe_level_info li{};
     check(mCtx, orbfe_get_level_info(mCtx, l, &li));
     if (!resident()) {
@@ -333,11 +370,18 @@ class ORBExtractor {
   orbfe_ctx* mCtx = nullptr;
   ContextPool::Lease mLease;
   std::vector<float> mScales;
-  bool mStarted = false;  // eagerStart: the constructor's orbfe_extract_slot_begin is outstanding
-  void drainStarted() {
+  mutable bool mStarted = false;  // eagerStart: the constructor's orbfe_extract_slot_begin is outstanding
+  mutable bool mDrained = false;  // ... and was collected without its features (drainStarted): extract() fetches them from the slot
+  friend class ORBMatcher;
+  void drainStarted() const {
     if (!mStarted) return;
     mStarted = false;
-    check(mCtx, orbfe_extract_slot_end(mCtx, mLease.slot, nullptr, nullptr, nullptr));
+    int32_t n = 0;
+    const orbfe_status st = orbfe_extract_slot_end(mCtx, mLease.slot, nullptr, nullptr, &n);
+    ContextPool::setBusy(mCtx, mLease.slot, false);
+    check(mCtx, st);
+    mDrained = true;
+    const_cast<ORBExtractor*>(this)->mnKeyPoints = n;
   }
   std::thread::id mOwner = std::this_thread::get_id();  // the constructing thread (Frame::Frame's)
   mutable std::mutex mPendingMutex;
@@ -361,6 +405,7 @@ class ORBMatcher {
   int searchByStereo(const ORBExtractor& left, const ORBExtractor& right, float fx, float bf, std::vector<double>& rightU,
                      std::vector<double>& depths) const {
     left.rethrowPending(), right.rethrowPending();  // a failure of one of Frame::Frame's extract() threads surfaces here (see extract())
+    left.drainStarted(), right.drainStarted();      // eagerStart objects nobody has called extract() on: the match needs idle slots
     if (left.context() != right.context()) throw std::logic_error("searchByStereo: the two extractors differ in geometry / parameters");
     if (!left.resident() || !right.resident())
       throw std::logic_error("searchByStereo: the extractors' device results have been overwritten (more than "

@@ -71,6 +71,15 @@ def test_brief_template_parser(tmp_path):
     p.write_text("hdr\n" + "\n".join(broken))
     got = load_brief_template(str(p))
     assert got[3].tolist() == [0, 0, 0, 0] and got[4].tolist() == [7, 0, 0, 0] and np.array_equal(got[5:], pat[5:])
+    # operator>> takes the longest numeric PREFIX of a token: "7x" reads 7 and the next value fails on the 'x' (ADVICE r5); "2.9" truncates
+    broken[4], broken[5] = "7x 9 9 9", "2.9 -2.9 3 1e1"
+    p.write_text("hdr\n" + "\n".join(broken))
+    got = load_brief_template(str(p))
+    assert got[4].tolist() == [7, 0, 0, 0] and got[5].tolist() == [2, -2, 3, 10]
+    broken[6] = "1 2 300 4"          # no int8: refused by both loaders (the C++ cast would be undefined)
+    p.write_text("hdr\n" + "\n".join(broken))
+    with pytest.raises(ValueError):
+        load_brief_template(str(p))
     p.write_text("hdr\n" + "\n".join(rows[:255]))
     with pytest.raises(ValueError):
         load_brief_template(str(p))

@@ -183,7 +183,8 @@ def test_gpu_row_parallel_matcher_with_crowded_rows(orc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h,nf,nl,cls", [(752, 480, 1200, 8, "camera"), (320, 240, 500, 5, "saturated"), (1920, 1080, 3000, 8, "rect")])
+@pytest.mark.parametrize("w,h,nf,nl,cls", [(752, 480, 1200, 8, "camera"), (320, 240, 500, 5, "saturated"), (1920, 1080, 3000, 8, "rect"),
+                                           (1241, 376, 2000, 10, "camera")])   # ten levels: octaves 8, 9 in the matcher's packed record
 def test_gpu_batch_matcher_at_other_geometries(orc, w, h, nf, nl, cls):
     """the batch path (k_rowtable + k_stereo_rows + k_stereo_sad) away from the KITTI shape: other row counts, quotas, level counts and
     focal lengths -- five pairs per call (the batch matcher starts at four), every pair against the oracle"""
@@ -202,6 +203,8 @@ def test_gpu_batch_matcher_at_other_geometries(orc, w, h, nf, nl, cls):
     kps, desc, cnt = ctx.fetch_batch(0, 2 * B)
     ru, dp, nm = ctx.fetch_stereo_batch(0, B)
     assert sum(r["n_matches"] for r in ref) > 0
+    if nl > 8:   # matches whose LEFT keypoint sits on a level the 3-bit octave field of r5 could not hold
+        assert sum(int(((r["lk"]["octave"] >= 8) & (r["right_u"] >= 0)).sum()) for r in ref) > 0
     for p in range(B):
         r = ref[p]
         nl_, nr_ = len(r["lk"]), len(r["rk"])

@@ -179,6 +179,18 @@ def test_extract_slot_in_two_halves_equals_the_one_call(orc):
         ctx.extract_slot(2, L)                   # the slot is busy until _end
     with pytest.raises(OrbfeError):
         ctx.extract_slot_begin(2, L)
+    # ... and so does every other entry point that names the slot (they run on the context stream, which does not wait for the lane)
+    with pytest.raises(OrbfeError, match="outstanding"):
+        ctx.pyramid(2, 0)
+    with pytest.raises(OrbfeError, match="outstanding"):
+        ctx.stereo_match(2, 3, FX, BF)
+    with pytest.raises(OrbfeError, match="outstanding"):
+        ctx.stereo_match(0, 3, FX, BF)           # the right slot alone is pending
+    with pytest.raises(OrbfeError, match="outstanding"):
+        ctx.fetch_features(3)
+    with pytest.raises(OrbfeError, match="outstanding"):
+        ctx.extract_batch([L, R, L])             # would write slots 0..2
+    assert np.array_equal(ctx.extract_batch([L, R])[0][0], want_l[0])   # slots 0, 1 are idle: served, and the begun slots are untouched
     got = {}
     th = [threading.Thread(target=lambda s=s: got.__setitem__(s, ctx.extract_slot_end(s))) for s in (2, 3)]
     for t_ in th:
