@@ -39,812 +39,12 @@ if "--only-leg" not in sys.argv:
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H, NFEAT, NLEVELS, SCALE, TH_HI, TH_LO = 1241, 376, 2000, 8, 1.2, 20, 7
-FX, BF = 718.856, 718.856 * 0.537166  # config/kitti_config_00.yaml: Camera.fx, Camera.bl
-HBM_PEAK_GBPS = 8000.0
-PCIE_PEAK_GBPS = 63.0   # PCIe 5.0 x16, one direction (MI355X_MICROARCH.md)
-
-
-def algorithmic_bytes(ctx, n_cand_per_image):
-    """algorithmic bytes per image for each kernel, and per stereo pair in total (20 012 776 B for the KITTI shape at
-    2000 features -- 8(d)'s own figure, which has no quadtree entry).  The quadtree only touches the candidate records: 4 B per
-    candidate read + 4 B per selected keypoint written; that term prices the quadtree STAGE (returned separately) and is NOT part of
-    the per-pair total."""
-    P = sum(ctx.level_info(l).width * ctx.level_info(l).height for l in range(NLEVELS))
-    S0 = W * H
-    K = NFEAT
-    per_image = {
-        "resize": S0 + (P - S0),            # read level 0, write levels 1..7
-        "blur": 2 * P,                      # read + write every plane
-        "fast": P,                          # read every plane (+ candidate records, not counted)
-        "orient_brief": K * (749 + 512) + K * 60,
-    }
-    per_pair_match = 2 * K * 32 + 2 * K * 28 + K * 12 * 121 + K * 16
-    per_pair = 2 * sum(per_image.values()) + per_pair_match
-    per_image["quadtree"] = 4 * n_cand_per_image + 4 * K   # stage pricing only (after the total)
-    return per_image, per_pair_match, per_pair
-
-
-class _StdoutToStderr:
-    """RCCL prints a version banner on file descriptor 1 when its first communicator comes up; the contract is ONE JSON line on stdout.
-    While this is active, everything written to fd 1 -- by Python or by a native library -- goes to stderr."""
-
-    def __enter__(self):
-        sys.stdout.flush()
-        self.saved = os.dup(1)
-        os.dup2(2, 1)
-        return self
-
-    def __exit__(self, *exc):
-        sys.stdout.flush()
-        os.dup2(self.saved, 1)
-        os.close(self.saved)
-        return False
-
-
-def spawn_ranks(n: int) -> int:
-    import socket
-    import subprocess
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    # poll: when one rank dies (a missing GPU, a failed rendezvous) the others would wait in the collective init for ever -- end them
-    import threading
-    buf = []
-    rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
-    rd.start()
-    rcs = [None] * n
-    while any(rc is None for rc in rcs):
-        for r, p in enumerate(procs):
-            if rcs[r] is None:
-                rcs[r] = p.poll()
-        if any(rc not in (None, 0) for rc in rcs):
-            time.sleep(2.0)   # let the others fail by themselves with their own message first
-            for r, p in enumerate(procs):
-                if p.poll() is None:
-                    p.kill()   # exactly the children started above
-            rcs = [p.wait() for p in procs]
-            break
-        time.sleep(0.05)
-    rd.join(timeout=10)
-    sys.stdout.write("".join(x or "" for x in buf))
-    sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
-        return 1
-    return 0
-
-
-def host_io_leg(ctx, left_h, right_h, B, steps, want, world, sync_all, dist, torch, xdev):
-    """The step fed from page-locked host memory, results delivered to page-locked host memory (transfers included).
-    Three input buffers and three result sets rotate: batch k-2 is collected after batch k has been submitted."""
-    from orb_slam2_ros2_amd._lib import PinnedArray
-    from orb_slam2_ros2_amd.digest import batch_digests
-    pins = []
-    for _ in range(3):
-        l, r = PinnedArray(left_h.shape, np.uint8), PinnedArray(right_h.shape, np.uint8)
-        l.array[...] = left_h
-        r.array[...] = right_h
-        pins.append((l, r))
-    outs = [ctx.alloc_batch_results(B, pinned=True) for _ in range(3)]
-
-    def run(n):
-        tickets = []
-        for k in range(n):
-            tickets.append(ctx.stream_submit(pins[k % 3][0].array, pins[k % 3][1].array, B, FX, BF, outs[k % 3]))
-            if k >= 2:
-                ctx.stream_wait(tickets[k - 2])
-        for t in tickets[-2:]:
-            ctx.stream_wait(t)
-    run(4)
-    sync_all()
-    t0 = time.perf_counter()
-    run(steps)
-    sync_all()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    ok = 0
-    for o in outs:   # the last three batches, as delivered to the host
-        dig = batch_digests(o["kps"], o["desc"], o["counts"], o["right_u"], o["depth"], o["n_matches"])
-        bad = [p for p in range(B) if want[p] is not None and dig[p] != want[p]]
-        if bad:
-            raise SystemExit(f"bench.py: host_io leg: {len(bad)} of {B} pairs differ from the golden digests (first: pair {bad[0]})")
-        ok += sum(w is not None for w in want)
-    in_bytes = left_h.nbytes + right_h.nbytes
-    out_bytes = sum(o[k].nbytes for k in ("kps", "desc", "counts", "right_u", "depth", "n_matches") for o in outs[:1])
-    res = {
-        "pairs_per_s": steps * B * world / dt,
-        "ms_per_step": dt / steps * 1e3,
-        "steps": steps,
-        "h2d_GBps": in_bytes * steps / dt / 1e9,          # per GPU
-        "d2h_GBps": out_bytes * steps / dt / 1e9,         # per GPU
-        "h2d_bytes_per_pair": in_bytes // B,
-        "d2h_bytes_per_pair": out_bytes // B,
-        "verified_pairs": ok,
-        "what": "page-locked host images -> orbfe_stream_submit (upload k+1 / compute k / download k-1 overlapped) -> full result "
-                "arrays (keypoints, descriptors, right_u, depth, counts of both images) in page-locked host memory",
-    }
-    for o in outs:
-        for pa in o["_pinned"]:
-            pa.free()
-    for l, r in pins:
-        l.free()
-        r.free()
-    return res
-
-
-def sequence_batch(block_frames, max_pairs):
-    """Pairs per batch of a sequence job: at least FOUR batches per rank, so that the upload of batch k + 1 and the gather / drain of
-    batch k - 1 run under the compute of batch k (one batch of 512 + a tail of 56, as a block of 568 frames at 8 ranks used to be cut,
-    overlaps nothing), capped by --pairs."""
-    return max(1, min(max_pairs, (max(block_frames, 1) + 3) // 4))
-
-
-def sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend, collective, window=1, exchange="shared"):
-    """One timed sequence: F stereo pairs (frame f = synthetic frame f mod U) cut into blocks per rank, each rank streaming its block from
-    page-locked host memory in batches of <= B, records packed on the device straight into the buffer of the batch's WINDOW, and
-      exchange = "shared": every rank copies its windows into its rows of ONE page-locked POSIX shared-memory segment over its own PCIe
-                 link while the next window is computed; the collective carries the 16-byte record heads only (sharding.WindowDrain);
-      exchange = "gather": every window gathered on rank 0 over the collective and drained from there to page-locked host memory
-                 (sharding.WindowGather: all records cross rank 0's one PCIe link)
-    -- then every record checked.  collective: take the collective through the process group even with one rank.
-    Returns (seconds, frames of this rank, records checked against the host path, info)."""
-    import torch
-    import torch.distributed as dist
-
-    from orb_slam2_ros2_amd import synth
-    from orb_slam2_ros2_amd.sequence import DeviceSequenceProcessor, record_bytes, run_sequence, unpack_record
-    from orb_slam2_ros2_amd.sharding import SharedRecordStore, frame_range
-
-    b, e = frame_range(F, rank, world)
-    proc = DeviceSequenceProcessor(ctx, lambda f: synth.stereo_pair(f % U, W, H), B, FX, BF, dev, content_key=lambda f: f % U)
-    proc.prepare(range(b, e))   # page-locked batches of this rank's block, built before the clock starts
-
-    on_device = backend == "nccl"
-
-    def collect(h):
-        t = proc.collect(h)
-        return t if on_device else t.cpu()
-
-    def sync_all():
-        ctx.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    rb = record_bytes(ctx.n_features)
-    store, host_out = None, None
-    if exchange == "shared":
-        # rank 0 creates the segment (a file in /dev/shm: no GPU involved), the others map it after the barrier; every rank page-locks
-        # its mapping for its own GPU
-        name = f"orbfe_seq_{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if world > 1 else os.getpid()}_{F}"
-        if rank == 0:
-            try:
-                os.unlink(os.path.join("/dev/shm", name))
-            except FileNotFoundError:
-                pass
-            store = SharedRecordStore(name, F, rb, create=True)
-        if world > 1:
-            dist.barrier()
-        if rank != 0:
-            store = SharedRecordStore(name, F, rb, create=False)
-        store.pin()
-    elif rank == 0:
-        host_out = torch.empty((F, rb), dtype=torch.uint8).pin_memory()  # where the result lands
-
-    def sink(first, t):   # rank 0: one rank's part of a finished window -> page-locked host memory, behind the gather on torch's stream
-        host_out[first:first + t.shape[0]].copy_(t, non_blocking=True)
-
-    kw = dict(window=window, collect_into=proc.collect_into if on_device else None, force_collective=collective)
-    if store is not None:
-        kw["store"] = store
-    else:
-        kw["sink"] = sink if rank == 0 else None
-    # warm-up: one pass over (at most) two batches per rank, including the exchange
-    run_sequence(min(F, 2 * B * world), rank, world, B, proc.submit, collect, **kw)
-    sync_all()
-    t0 = time.perf_counter()
-    summary, n_local = run_sequence(F, rank, world, B, proc.submit, collect, **kw)
-    t_rank = time.perf_counter() - t0   # this rank's own frames are in host memory (shared) / handed to the collective (gather)
-    rec_host = store.tensor if store is not None else host_out
-    sync_all()
-    dt = time.perf_counter() - t0
-    rates = [n_local / t_rank if t_rank > 0 else 0.0]
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        mine = torch.tensor([rates[0]], dtype=torch.float64, device=xdev)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        rates = [float(t.item()) for t in allr]
-    f_local = [frame_range(F, r, world)[1] - frame_range(F, r, world)[0] for r in range(world)]
-    info = {"exchange": exchange, "per_rank_pairs_per_s": [round(r, 1) for r in rates],
-            "communicator_nranks": dist.get_world_size() if dist.is_initialized() else 0,
-            # which bytes take which wire (one node: xGMI between the GPUs, one PCIe link per GPU to the one host memory)
-            "xgmi_bytes": int(sum(f_local[1:])) * (16 if exchange == "shared" else rb),
-            "pcie_bytes_per_rank": [int(n) * rb for n in f_local] if exchange == "shared" else [int(F) * rb] + [0] * (world - 1),
-            "wires": ("records: every rank's own PCIe link (device -> its rows of the shared page-locked segment); xGMI: the 16-byte record heads "
-                      "of the other ranks, gathered on rank 0") if exchange == "shared" else
-                     ("records: xGMI from every other rank to rank 0 (RCCL gather, north_star's form), then ALL of them over rank 0's one PCIe "
-                      "link to host memory"),
-            "payload": ("records: each rank -> its rows of one page-locked POSIX shared-memory segment over its own PCIe link; collective: "
-                        "16 B per frame (n, n_matches)") if exchange == "shared" else
-                       "records: gathered on rank 0 over the collective, drained from there over rank 0's PCIe link",
-            "collective_bytes": int(F) * (16 if exchange == "shared" else rb), "host_bytes": int(F) * rb}
-    if store is not None and rank == 0 and summary is not None:
-        info["summary_rows"] = int(summary.shape[0])
-    checked = 0
-    if rank == 0:
-        # every frame's record against the record of the first frame with the same content (frames repeat with period U), and the
-        # distinct ones against a host-pointer run of the same library (whose digests the GPU suite pins to the golden fixtures)
-        r = rec_host.numpy()
-        assert r.shape == (F, record_bytes(ctx.n_features))
-        for f in range(min(U, F), F):
-            if not np.array_equal(r[f], r[f % U]):
-                raise SystemExit(f"bench.py: sequence: record of frame {f} differs from frame {f % U} (same image)")
-        for f in range(min(U, F, 8)):
-            u = unpack_record(r[f], ctx.n_features)
-            (lk, ld), _ = ctx.extract_batch(list(synth.stereo_pair(f % U, W, H)))
-            nm, ru, dp, _, _ = ctx.stereo_match(0, 1, FX, BF)
-            n = len(lk)
-            if not (u["n"] == n and u["n_matches"] == nm and np.array_equal(u["kps"], lk) and np.array_equal(u["desc"], ld)
-                    and np.array_equal(u["right_u"], ru[:n]) and np.array_equal(u["depth"], dp[:n])):
-                raise SystemExit(f"bench.py: sequence: record of frame {f} differs from the host-pointer path")
-            checked += 1
-        if store is not None and summary is not None:   # the gathered heads against the records in the segment
-            heads = np.ascontiguousarray(r[:, :16]).view(np.int32)
-            if not np.array_equal(heads, summary.numpy()):
-                raise SystemExit("bench.py: sequence: the gathered record heads differ from the records in the shared segment")
-    for l, r_ in set(proc.pinned.values()):
-        l.free()
-        r_.free()
-    if store is not None:
-        if world > 1:
-            dist.barrier()   # rank 0 has read what it checks
-        store.close()
-    return dt, n_local, checked, info
-
-
-def run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend, collective):
-    """BASELINE config 4: a whole sequence (KittiStereo.cc:28-37) sharded over the ranks, records gathered on rank 0."""
-    import torch
-    import torch.distributed as dist
-
-    from orb_slam2_ros2_amd import synth
-    from orb_slam2_ros2_amd._lib import Context
-    from orb_slam2_ros2_amd.digest import pair_digest  # noqa: F401  (records are checked field by field below)
-    from orb_slam2_ros2_amd.sequence import DeviceSequenceProcessor, record_bytes, run_sequence, unpack_record
-    from orb_slam2_ros2_amd.sharding import frame_range
-
-    F, B, U = args.sequence, args.pairs, max(1, min(args.sequence_unique, 128))
-    b, e = frame_range(F, rank, world)
-    B = sequence_batch((F + world - 1) // world, B)   # from the per-rank block size, the same on every rank
-    ctx = Context(W, H, NFEAT, NLEVELS, SCALE, TH_HI, TH_LO, device_id=local_rank, max_images=2 * B)
-    dt, n_local, checked, xinfo = sequence_job(ctx, F, B, U, rank, world, dev, xdev, backend, collective, window=max(1, args.sequence_window),
-                                               exchange=args.sequence_exchange)
-    line = None
-    if rank == 0:
-        n_batches = (max(e - b, 1) + B - 1) // B
-        line = {
-            "metric": "stereo frames/sec (extract+match) KITTI-00 1241x376; HBM GB/s vs roofline",
-            "value": F / dt, "unit": "stereo pairs/s", "n_gpus": world, "steps": n_batches, "warmup": 1,
-            "ms_per_step": dt / n_batches * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
-            "data": "synthetic",
-            "config": {
-                "workload": f"Full KITTI-00-shaped sequence ({F} stereo pairs, {U} distinct synthetic frames) frame-sharded across "
-                            f"{world} GPU(s), gather of the per-frame records to rank 0",
-                "io": "page-locked host images -> device (upload overlapped with compute); records packed on the device, per "
-                      f"window of {max(1, args.sequence_window)} batch(es) brought to one host memory (see exchange.payload; collective: " +
-                      (("RCCL" if collective else "none (single rank)") if backend == "nccl" else backend) +
-                      ") while the next window is computed -- all inside the timed region",
-                "record": "per frame: n, n_matches, left keypoints [2000 x 28 B], left descriptors [2000 x 32 B], right_u and "
-                          "depth [2000 x f64]",
-                "record_bytes": record_bytes(ctx.n_features), "result_bytes": int(F) * record_bytes(ctx.n_features),
-                "pairs_per_batch": B, "batches_per_window": max(1, args.sequence_window), "frames_rank0": n_local,
-                "records_checked_against_host_path": checked, "records_checked_for_repeat_consistency": max(0, F - min(U, F)),
-                "collective_executed": bool(collective), "exchange": xinfo,
-                "parallelism": f"frame_range blocks over {world} GPU(s)",
-            },
-            "roofline": None, "cpu_baseline": None,
-            "seconds": dt,
-        }
-    ctx.close()
-    return line
-
-
-# ---- the rest of north_star beside the stereo step: config 3, the BA half (config 5), the reference's own call shape -----------------
-def _sha(a):
-    import hashlib
-    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
-
-
-def _stats_ms(f, n, warm=5):
-    for _ in range(warm):
-        f()
-    ts = []
-    for _ in range(n):
-        t0 = time.perf_counter()
-        f()
-        ts.append((time.perf_counter() - t0) * 1e3)
-    a = np.sort(np.array(ts))
-    return {"median_ms": float(np.median(a)), "p99_ms": float(a[min(len(a) - 1, int(0.99 * len(a)))]), "n": n}
-
-
-def _kernel_us(ctx, stage, f, n=30):
-    """mean device time of the kernels of one call (HIP events on the library's stream around the kernels only: inputs already
-    uploaded, results not yet downloaded -- the device-resident figure)"""
-    f()
-    ctx.profile_enable(1)
-    ctx.profile_read()
-    for _ in range(n):
-        f()
-    ms, k = ctx.profile_read()[stage]
-    ctx.profile_enable(0)
-    return (ms / n) * 1e3 if k else None
-
-
-def _oracle_fast():
-    from oracle import pyoracle   # the CPU checker, timed beside the device on ONE host core (kind: "port")
-    return pyoracle.Oracle(pyoracle.build(fast=True, out_dir=os.path.join("/tmp", f"orb_oracle_{os.getuid()}")))
-
-
-def _cpu_ms(f, budget_s=1.5, max_n=5):
-    f()
-    ts = []
-    t_end = time.perf_counter() + budget_s
-    while len(ts) < max_n and (not ts or time.perf_counter() < t_end):
-        t0 = time.perf_counter()
-        f()
-        ts.append((time.perf_counter() - t0) * 1e3)
-    return float(np.median(ts))
-
-
-def cfg3_leg(device_id):
-    """BASELINE config 3: 2000 x 2000 Hamming-256 brute force (ORBMatcher::getBestMatch over all train descriptors,
-    src/ORBMatcher.cc:941-990), results bit-exact against tests/golden/golden_v1.json before any number is reported."""
-    from orb_slam2_ros2_amd import synth
-    from orb_slam2_ros2_amd._lib import Context
-    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v1.json")))["cfg3"]
-    ctx = Context(W, H, NFEAT, NLEVELS, SCALE, TH_HI, TH_LO, device_id=device_id, max_images=2)
-    q, t = synth.descriptors_cfg3()
-    bi, bd, sd = ctx.match_bruteforce(q, t)
-    if (_sha(bi), _sha(bd), _sha(sd)) != (gold["best_idx_sha"], gold["best_dist_sha"], gold["second_sha"]):
-        raise SystemExit("bench.py: cfg3 leg: results differ from the golden vectors")
-    us = _kernel_us(ctx, "match", lambda: ctx.match_bruteforce(q, t))
-    host = _stats_ms(lambda: ctx.match_bruteforce(q, t), 50)
-    orc = _oracle_fast()
-    cand = np.arange(t.shape[0], dtype=np.uint32)
-    t0 = time.perf_counter()
-    for i in range(100):
-        orc.best_match(q[i], t, cand)
-    cpu_ms = (time.perf_counter() - t0) / 100 * q.shape[0] * 1e3
-    ctx.close()
-    alg = 2 * 2000 * 32 + 2000 * 12   # SURVEY 8(d)
-    pairs = q.shape[0] * t.shape[0]
-    return {"workload": "2000 x 2000 Hamming-256 brute force, best / second best per query (quirk Q6), bit-exact vs golden_v1",
-            "verified": True, "kernel_us": us, "Gpair_per_s": pairs / (us * 1e-6) / 1e9 if us else None,
-            "algorithmic_bytes": alg, "GBps": alg / (us * 1e-6) / 1e9 if us else None,
-            "bound": "neither HBM (152 KB) nor issue: one launch of 500 workgroups, latency of a single wave pass",
-            "host_call": dict(host, what="host descriptors in, host results out (PCIe both ways included)"),
-            "cpu_baseline": {"ms": cpu_ms, "cores": 1, "kind": "port"}}
-
-
-def ba_leg(device_id):
-    """The BA half of north_star on the BASELINE config-5 problem (60 keyframes, 3000 points, 15 597 edges): g2o edge
-    evaluation (src/Optimizer.cc:296-330 set-up, computeError / linearizeOplus / Huber), the normal-equation build, the local BA
-    (Optimizer.cc:336-361: optimize(5) + optimize(10)) and OptimizePoseOnly (:33-178) -- each checked against the golden vectors first."""
-    from orb_slam2_ros2_amd import ba_synth
-    from orb_slam2_ros2_amd._lib import Context
-    g1 = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v1.json")))["cfg5_ba"]
-    g2 = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v2.json")))["pose_only"]
-    g3 = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v3.json")))
-    ctx = Context(640, 480, n_features=1000, device_id=device_id, max_images=1)
-    orc = _oracle_fast()
-    out = {"workload": "BASELINE config 5: synthetic local map, 60 keyframes / 3000 points / 15 597 edges (80 % stereo), TUM intrinsics"}
-    # edge evaluation
-    p = ba_synth.make_problem()
-    E = int(p["edge_pose"].size)
-    r = ctx.ba_eval_edges(**p)
-    if E != g1["n_edges"] or abs(r["chi2"].sum() - g1["chi2_sum"]) > 1e-12 * g1["chi2_sum"] or \
-            abs(np.abs(r["j_pose"]).sum() - g1["jpose_abs_sum"]) > 1e-10 * g1["jpose_abs_sum"]:
-        raise SystemExit("bench.py: ba leg: edge evaluation differs from the golden vectors")
-    alg = 304 * E + p["poses"].shape[0] * 56 + p["points"].shape[0] * 24
-    us = _kernel_us(ctx, "ba", lambda: ctx.ba_eval_edges(**p))
-    out["edge_eval"] = {"edges": E, "kernel_us": us, "algorithmic_bytes": alg, "GBps": alg / (us * 1e-6) / 1e9 if us else None,
-                        "hbm_frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS if us else None,
-                        "host_call": dict(_stats_ms(lambda: ctx.ba_eval_edges(**p), 30), what="host arrays in, 4.8 MB of results out over PCIe"),
-                        "cpu_baseline": {"ms": _cpu_ms(lambda: orc.ba_eval_edges(**p)), "cores": 1, "kind": "port"}, "verified": True}
-    # ... and the same kernel at a size that fills the machine: the edge list tiled 64 times (the same poses and points; 61 workgroups of
-    # the config-5 problem occupy a quarter of the chip for two launch floors, which says nothing about the kernel's memory behaviour)
-    rep = 64
-    pl = dict(p)
-    for k in ("edge_pose", "edge_point", "meas", "is_stereo", "info", "huber_delta"):
-        pl[k] = np.ascontiguousarray(np.concatenate([p[k]] * rep))
-    rl = ctx.ba_eval_edges(**pl)
-    if abs(rl["chi2"].sum() - rep * g1["chi2_sum"]) > 1e-11 * rep * g1["chi2_sum"] or not np.array_equal(rl["chi2"][:E], r["chi2"]) or \
-            not np.array_equal(rl["chi2"][-E:], r["chi2"]):
-        raise SystemExit("bench.py: ba leg: the tiled edge evaluation differs from the golden vectors")
-    alg_l = 304 * E * rep + p["poses"].shape[0] * 56 + p["points"].shape[0] * 24
-    us_l = _kernel_us(ctx, "ba", lambda: ctx.ba_eval_edges(**pl), n=3)
-    out["edge_eval_tiled"] = {"edges": E * rep, "kernel_us": us_l, "algorithmic_bytes": alg_l, "GBps": alg_l / (us_l * 1e-6) / 1e9 if us_l else None,
-                              "hbm_frac": alg_l / (us_l * 1e-6) / 1e9 / HBM_PEAK_GBPS if us_l else None, "verified": True,
-                              "what": "the config-5 edge list 64 times over: the edge kernel with the chip full (SURVEY 8d: 304 B per edge)"}
-    del rl, pl
-    # normal equations
-    fx = np.zeros(p["poses"].shape[0], np.uint8)
-    fx[0] = 1
-    fx[30:] = 1
-    sysd = ctx.ba_build_system(**p, pose_fixed=fx)
-    for k, want in g3["cfg5_system"].items():
-        if abs(np.abs(np.asarray(sysd[k], np.float64)).sum() - want) > 1e-9 * want:
-            raise SystemExit(f"bench.py: ba leg: normal-equation block {k} differs from the golden vectors")
-    out["build_system"] = {"kernel_us": _kernel_us(ctx, "ba", lambda: ctx.ba_build_system(**p, pose_fixed=fx)),
-                           "host_call": _stats_ms(lambda: ctx.ba_build_system(**p, pose_fixed=fx), 30),
-                           "cpu_baseline": {"ms": _cpu_ms(lambda: orc.ba_build_system(**p, pose_fixed=fx)), "cores": 1, "kind": "port"},
-                           "verified": True}
-    # local BA
-    pr = ba_synth.make_problem(seed=42, n_kf=60, n_pt=3000, with_truth=True)
-    fixed = np.zeros(60, np.uint8)
-    fixed[:20] = 1
-    pr["poses"][:20] = pr["poses_true"][:20]
-    r = ctx.ba_local_optimize(pr, fixed)
-    gl = g3["cfg5_lba"]
-    if r["iters"].tolist() != gl["iters"] or not np.allclose(r["poses"].ravel(), gl["poses"], rtol=0, atol=1e-7) or \
-            abs(r["chi2"].sum() - gl["chi2_sum"]) > 1e-6 * gl["chi2_sum"] or abs(int(r["bad"].sum()) - gl["n_bad"]) > 1:
-        raise SystemExit("bench.py: ba leg: local BA differs from the golden vectors")
-    out["local_optimize"] = dict(_stats_ms(lambda: ctx.ba_local_optimize(pr, fixed), 20, warm=2),
-                                 what="orbfe_ba_local_optimize: optimize(5) + re-classification + optimize(10), 40 free keyframes, host arrays "
-                                      "in, host results out", iterations=gl["iters"],
-                                 cpu_baseline={"ms": _cpu_ms(lambda: orc.ba_local_optimize(pr, fixed), 2.0, 3), "cores": 1, "kind": "port"},
-                                 verified=True)
-    # the same over the window size: past 42 free keyframes the blocked multi-workgroup Cholesky (fp64 MFMA) takes the reduced system; the
-    # 43 / 64 / 100 problems are 50 points per keyframe and 10 fixed keyframes (tools/lba_sizes.py), the 300 one is the GPU suite's
-    for nf_w in (43, 64, 100):
-        n_kf = nf_w + 10
-        w = ba_synth.make_problem(seed=100 + nf_w, n_kf=n_kf, n_pt=50 * n_kf, with_truth=True)
-        fw = np.zeros(n_kf, np.uint8)
-        fw[:10] = 1
-        w["poses"][:10] = w["poses_true"][:10]
-        out[f"local_optimize_{nf_w}_free_keyframes"] = dict(_stats_ms(lambda: ctx.ba_local_optimize(w, fw), 5, warm=1), edges=int(w["edge_pose"].size),
-                                                            cpu_baseline={"ms": _cpu_ms(lambda: orc.ba_local_optimize(w, fw), 1.0, 1), "cores": 1, "kind": "port"})
-    big = ba_synth.make_problem(seed=13, n_kf=310, n_pt=4000, with_truth=True)
-    fb = np.zeros(310, np.uint8)
-    fb[:10] = 1
-    big["poses"][:10] = big["poses_true"][:10]
-    gb = ctx.ba_local_optimize(big, fb)
-    t0 = time.perf_counter()
-    ob = orc.ba_local_optimize(big, fb)
-    cpu_big_ms = (time.perf_counter() - t0) * 1e3
-    if tuple(gb["iters"]) != tuple(ob["iters"]) or np.abs(gb["points"] - ob["points"]).max() > 1e-7:
-        raise SystemExit("bench.py: ba leg: the 300-keyframe local BA differs from the oracle")
-    out["local_optimize_300_free_keyframes"] = dict(_stats_ms(lambda: ctx.ba_local_optimize(big, fb), 5, warm=1), edges=int(big["edge_pose"].size),
-                                                    cpu_baseline={"ms": cpu_big_ms, "cores": 1, "kind": "port", "sample": "one call"}, verified=True)
-    # pose only
-    pp = ba_synth.make_pose_problem()
-    a = (pp["Xw"], pp["meas"], pp["info"], pp["sigma2"], pp["pose"], pp["fx"], pp["fy"], pp["cx"], pp["cy"], pp["bf"])
-    n_good, pose, _ = ctx.pose_only_optimize(*a)
-    if abs(n_good - g2["n_good"]) > 1 or not np.allclose(pose, g2["pose"], rtol=0, atol=1e-6):
-        raise SystemExit("bench.py: ba leg: pose-only optimisation differs from the golden vectors")
-    out["pose_only"] = dict(_stats_ms(lambda: ctx.pose_only_optimize(*a), 50), edges=int(len(pp["info"])),
-                            kernel_us=_kernel_us(ctx, "ba", lambda: ctx.pose_only_optimize(*a), n=20),
-                            what="orbfe_pose_only_optimize: 4 x optimize(10) on one SE3 vertex, host arrays in and out",
-                            cpu_baseline={"ms": _cpu_ms(lambda: orc.pose_only_optimize(*a)), "cores": 1, "kind": "port"}, verified=True)
-    ctx.close()
-    return out
-
-
-def latency_leg(device_id, n=500):
-    """One stereo pair from host images to host results, in the two call shapes a caller has: (a) one batched call for both eyes +
-    the match; (b) the reference's own -- Frame::Frame builds two ORBExtractor objects and runs extract() on two std::threads
-    (src/Frame.cc:91-105), then Frame::createStereo calls searchByStereo (include/ORB_SLAM2/Frame.h:316-319) -- through the C++
-    drop-in classes (tests/cpp/test_dropin.cpp, mode `latency`; no Python in that number)."""
-    import subprocess
-    import tempfile
-
-    from orb_slam2_ros2_amd import synth
-    from orb_slam2_ros2_amd._lib import Context
-    from orb_slam2_ros2_amd.digest import pair_digest
-    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v1.json")))["bench_pairs"]
-    L, R = synth.stereo_pair(0, W, H)
-    ctx = Context(W, H, NFEAT, NLEVELS, SCALE, TH_HI, TH_LO, device_id=device_id, max_images=2)
-    (lk, ld), (rk, rd) = ctx.extract_batch([L, R])
-    nm, ru, dp, _, _ = ctx.stereo_match(0, 1, FX, BF)
-    if pair_digest(lk, ld, rk, rd, ru, dp, nm) != gold["0"]:
-        raise SystemExit("bench.py: latency leg: the single-pair path differs from the golden digest")
-
-    def one():
-        ctx.extract_batch([L, R])
-        ctx.stereo_match(0, 1, FX, BF)
-    out = {"pair": "synthetic KITTI-shaped frame 0, 1241x376, 2000 features per image", "verified": True,
-           "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "unset (runtime default: what a drop-in user has)"),
-           "extract_batch_plus_match": dict(_stats_ms(one, n, warm=30), what="orbfe_extract_batch([L, R]) + orbfe_stereo_match, host to host, from Python")}
-    # Frame::createStereo's device work (Frame.h:313-323: two extractions, then searchByStereo) as ONE call: the same kernels in one
-    # launch sequence, one synchronisation
-    (flk, fld), (frk, frd), fnm, fru, fdp = ctx.frame_stereo(L, R, FX, BF)
-    if pair_digest(flk, fld, frk, frd, fru, fdp, fnm) != gold["0"]:
-        raise SystemExit("bench.py: latency leg: orbfe_frame_stereo differs from the golden digest")
-    out["frame_stereo_one_call"] = dict(_stats_ms(lambda: ctx.frame_stereo(L, R, FX, BF), n, warm=30),
-                                        what="orbfe_frame_stereo(L, R): both extractions + the stereo match as one launch sequence, host to host, from Python")
-    # BASELINE config 5's front half: one TUM-shaped RGB-D frame (640 x 480, 1000 features), host to host -- Tracking::grabFrame's cvtColor +
-    # the RGB-D Frame constructor (src/Tracking.cc:55-68, src/Frame.cc:125-159): colour image -> gray -> extraction, then undistortion + the
-    # depth / rightU lookup (results of both calls checked against the oracle in tests/test_frame_glue.py; here: every repetition equal)
-    try:
-        tum = dict(fx=520.908620, fy=521.007327, cx=325.141442, cy=249.701764, k1=0.231222, k2=-0.784899, p1=-0.003257, p2=-0.000105,
-                   k3=0.917205, bf=40.0)
-        rg = np.random.default_rng(5)
-        g = synth.mono_image(4, 640, 480)
-        bgr = np.stack([g, np.roll(g, 1, 1), np.roll(g, 2, 0)], 2).copy()
-        dep = rg.integers(0, 30000, (480, 640)).astype(np.uint16)
-        cr = Context(640, 480, n_features=1000, device_id=device_id, max_images=1)
-        k0_, d0_ = cr.extract_color(bgr, 2)
-        ku0, dd0, ru0 = cr.frame_rgbd(0, tum, dep, 5000.0)
-
-        def rgbd_frame():
-            k_, d_ = cr.extract_color(bgr, 2)
-            ku, dd, ru_ = cr.frame_rgbd(0, tum, dep, 5000.0)
-            return k_, d_, ku, dd, ru_
-        k1_, d1_, ku1, dd1, ru1 = rgbd_frame()
-        if not (np.array_equal(d0_, d1_) and ku0.tobytes() == ku1.tobytes() and np.array_equal(dd0, dd1) and np.array_equal(ru0, ru1)):
-            raise SystemExit("bench.py: latency leg: the RGB-D frame is not repeatable")
-        out["rgbd_frame_tum"] = dict(_stats_ms(rgbd_frame, 200, warm=20), keypoints=int(len(k0_)),
-                                     what="640x480 BGR image + 16-bit depth image in, undistorted keypoints / descriptors / depth / rightU out: "
-                                          "orbfe_extract_color + orbfe_frame_rgbd (BASELINE config 5's frame, 1000 features), from Python")
-        # ... and as ONE call (orbfe_frame_rgbd_image: Frame::createRGBD's device work as one launch sequence; the depth image is not uploaded)
-        k2_, d2_, dd2, ru2 = cr.frame_rgbd_image(bgr, tum, dep, 5000.0, 2)
-        if not (np.array_equal(d2_, d0_) and k2_.tobytes() == ku0[:len(k2_)].tobytes() and np.array_equal(dd2, dd0) and np.array_equal(ru2, ru0)):
-            raise SystemExit("bench.py: latency leg: orbfe_frame_rgbd_image differs from orbfe_extract_color + orbfe_frame_rgbd")
-        out["rgbd_frame_tum_one_call"] = dict(_stats_ms(lambda: cr.frame_rgbd_image(bgr, tum, dep, 5000.0, 2), 200, warm=20),
-                                              what="the same frame through orbfe_frame_rgbd_image, from Python")
-        cr.close()
-    except (RuntimeError, OSError) as ex:
-        out["rgbd_frame_tum"] = {"error": f"{type(ex).__name__}: {ex}"}
-    # the per-frame guided matchers of Tracking (searchByProjection x 2-4 per frame over findFeaturesInArea + getBestMatch, src/ORBMatcher.cc:
-    # 265-347, 561-612; MapPoint::isInVision, src/MapPoint.cc:141-201): 1000 queries against the 2000 features of the frame just built
-    r = np.random.default_rng(0)
-    nq = 1000
-    q = r.integers(0, len(rk), nq)
-    qxy = np.stack([rk["x"][q], rk["y"][q]], 1).astype(np.float32) + r.normal(0, 3, (nq, 2)).astype(np.float32)
-    rad = r.uniform(5, 40, nq).astype(np.float32)
-    lo, hi = np.zeros(nq, np.int8), np.full(nq, 7, np.int8)
-    a = ctx.search_in_area(0, qxy, rad, lo, hi, rd[q])
-    b_ = ctx.search_in_area_features(lk, ld, qxy, rad, lo, hi, rd[q])
-    if not all(np.array_equal(x, y) for x, y in zip(a, b_)):
-        raise SystemExit("bench.py: latency leg: the guided search against the slot differs from the one against the uploaded features")
-    pos = r.uniform(-5, 5, (2000, 3)).astype(np.float32)
-    pos[:, 2] = r.uniform(3, 30, 2000)
-    vd = np.tile(np.array([0, 0, 1], np.float32), (2000, 1))
-    mx, mn = np.full(2000, 100, np.float32), np.full(2000, 0.1, np.float32)
-    cam, bnd = (FX, FX, 607.19, 185.2), (0, W, 0, H)
-    out["guided_matchers"] = {
-        "what": "host arrays in, host results out, 1000 queries / 2000 map points against a 2000-feature frame (results checked against the "
-                "oracle in tests/test_guided_search.py; here: slot-resident and uploaded targets agree)",
-        "search_in_area_ms": _stats_ms(lambda: ctx.search_in_area(0, qxy, rad, lo, hi, rd[q]), 200, warm=10)["median_ms"],
-        "search_in_area_features_ms": _stats_ms(lambda: ctx.search_in_area_features(lk, ld, qxy, rad, lo, hi, rd[q]), 200, warm=10)["median_ms"],
-        "project_map_points_ms": _stats_ms(lambda: ctx.project_map_points(pos, vd, mx, mn, np.eye(3), np.zeros(3), cam, bnd), 200, warm=10)["median_ms"]}
-    # Tracking::trackLocalMap's chain for 2000 local map points (Tracking.cc:641-675): searchByProjection(frame, map points, th) + OptimizePoseOnly,
-    # as ONE call (orbfe_track_local_map: the frame's features are the slot's, one upload, one download) against the same three steps through
-    # the separate entry points (three round trips, the queries / edges marshalled on the host in between).  The map: the left image's
-    # keypoints back-projected at their stereo depth (tests/test_track_chain.py holds the fused call to the oracle's chain).
-    n_l = len(lk)
-    ru_full = np.full(NFEAT, -1.0)
-    ru_full[:n_l] = ru[:n_l]
-    depth = np.where(dp[:n_l] > 0, dp[:n_l], r.uniform(4, 30, n_l))
-    CXk, CYk = 607.1928, 185.2157
-    Xmp = np.stack([(lk["x"] - CXk) / FX * depth, (lk["y"] - CYk) / FX * depth, depth], 1).astype(np.float32)
-    take = np.concatenate([r.permutation(n_l)[: min(n_l, 1800)], r.integers(0, n_l, 2000 - min(n_l, 1800))])
-    mp_pos = Xmp[take] + r.normal(0, 0.01, (2000, 3)).astype(np.float32)
-    mp_desc = ld[take].copy()
-    mp_vd = (mp_pos / np.linalg.norm(mp_pos, axis=1, keepdims=True)).astype(np.float32)
-    dist = np.linalg.norm(mp_pos, axis=1)
-    mp_max, mp_min = (dist * 1.8).astype(np.float32), (dist * 0.6).astype(np.float32)
-    mp_flags = np.full(2000, 7, np.uint8)
-    sf = np.array([np.float32(SCALE) ** l for l in range(NLEVELS)], np.float32)
-    sig2 = (sf * sf).astype(np.float32)
-    isig2 = (np.float32(1.0) / sig2).astype(np.float32)
-    Rc, tc = np.eye(3, dtype=np.float32), np.array([0.03, -0.02, 0.04], np.float32)
-    p0 = np.array([0, 0, 0, 1, 0.03, -0.02, 0.04], np.float64)
-    camk, bndk = (FX, FX, CXk, CYk, BF), (0.0, float(W), 0.0, float(H))
-
-    def chain_fused():
-        return ctx.track_local_map(0, mp_pos, mp_vd, mp_max, mp_min, mp_desc, mp_flags, Rc, tc, camk, bndk, p0, sig2, isig2, right_u=ru_full)
-
-    def chain_three_calls():
-        pr = ctx.project_map_points(mp_pos, mp_vd, mp_max, mp_min, Rc, tc, camk[:4], bndk)
-        idx = np.flatnonzero(pr["visible"])
-        lvl = pr["level"][idx].astype(np.int64)
-        radius = ((np.where(pr["cos_theta"][idx] > np.float32(0.998), np.float32(2.5), np.float32(4.0)) * np.float32(3.0)) * sig2[lvl]).astype(np.float32)
-        bi, bd, sd, nc = ctx.search_in_area(0, pr["uv"][idx], radius, np.maximum(0, lvl - 1).astype(np.int8), np.minimum(NLEVELS - 1, lvl + 1).astype(np.int8),
-                                            mp_desc[idx])
-        ok = (nc > 0) & (bd < 50) & (bd.astype(np.float32) / sd.astype(np.float32) < np.float32(0.8))
-        held = np.full(NFEAT, -1, np.int64)
-        for k in np.flatnonzero(ok):          # the reference's loop, map-point order (first claim wins)
-            if held[bi[k]] < 0:
-                held[bi[k]] = idx[k]
-        ef = np.flatnonzero(held >= 0)
-        meas = np.stack([lk["x"][ef].astype(np.float64), lk["y"][ef].astype(np.float64), ru_full[ef]], 1)
-        oc = lk["octave"][ef]
-        return ctx.pose_only_optimize(mp_pos[held[ef]].astype(np.float64), meas, isig2[oc].astype(np.float64), sig2[oc], p0, *cam32), held
-
-    # (the camera constants as the reference holds them -- Camera::mfFx ... are floats -- so that both paths optimise the same problem to the bit:
-    #  with 718.856 as a double on one side the two trajectories part after a few iterations and take different numbers of passes)
-    cam32 = tuple(float(np.float32(v)) for v in (FX, FX, CXk, CYk, BF))
-    gf = chain_fused()
-    (ng3, pose3, _), held3 = chain_three_calls()
-    if not np.array_equal(gf["assigned"], held3) or abs(gf["n_good"] - ng3) > 1 or np.abs(gf["pose"] - pose3).max() > 1e-6:
-        raise SystemExit("bench.py: latency leg: the fused tracking chain differs from the three separate calls")
-    out["track_local_map"] = {
-        "what": "Tracking::trackLocalMap's device work for 2000 local map points against a 2000-feature frame, host arrays in, host results "
-                "out: orbfe_track_local_map (one call) vs orbfe_project_map_points + orbfe_search_in_area + orbfe_pose_only_optimize with "
-                "the reference's policy in numpy between them",
-        "n_matches": int(gf["n_matches"]), "n_edges": int(gf["n_edges"]), "n_good": int(gf["n_good"]),
-        "fused": _stats_ms(chain_fused, 200, warm=10), "three_calls": _stats_ms(chain_three_calls, 100, warm=5), "verified": True}
-    # Tracking::trackMotionModel's chain (Tracking.cc:385-396): searchByProjection(frame, lastFrame, 15 [, 30]) -- a search around the last frame's
-    # feature positions, last match wins -- + OptimizePoseOnly, as ONE call (orbfe_track_motion_model) against orbfe_search_in_area +
-    # orbfe_pose_only_optimize with the policy in numpy.  The last frame: 1600 of the frame's keypoints a few pixels off, descriptors 6 bits off.
-    qi = np.sort(r.permutation(n_l)[: min(n_l, 1600)])
-    m_qxy = np.stack([lk["x"][qi], lk["y"][qi]], 1).astype(np.float32) + r.normal(0, 3, (len(qi), 2)).astype(np.float32)
-    m_oct = lk["octave"][qi].astype(np.int8)
-    m_lo, m_hi = np.maximum(0, m_oct - 1).astype(np.int8), np.minimum(NLEVELS - 1, m_oct + 1).astype(np.int8)
-    m_desc = ld[qi].copy()
-    fb = r.integers(0, 256, (len(qi), 6))
-    for k in range(6):
-        m_desc[np.arange(len(qi)), fb[:, k] // 8] ^= (1 << (fb[:, k] % 8)).astype(np.uint8)
-    m_pos = Xmp[qi]
-
-    def motion_fused():
-        return ctx.track_motion_model(0, m_qxy, m_oct, m_lo, m_hi, m_desc, m_pos, camk, bndk, p0, sig2, isig2, right_u=ru_full)
-
-    def motion_two_calls():
-        rad15 = (np.float32(15.0) * sig2[m_oct.astype(np.int64)]).astype(np.float32)
-        bi, bd, sd, nc = ctx.search_in_area(0, m_qxy, rad15, m_lo, m_hi, m_desc)
-        ok = np.flatnonzero((nc > 0) & (bd < 50) & (bd.astype(np.float32) / sd.astype(np.float32) < np.float32(0.9)))
-        held = np.full(NFEAT, -1, np.int64)
-        held[bi[ok]] = ok                      # setMapPoints in query order: the last one stays (ascending assignment, duplicates overwritten)
-        ef = np.flatnonzero(held >= 0)
-        meas = np.stack([lk["x"][ef].astype(np.float64), lk["y"][ef].astype(np.float64), ru_full[ef]], 1)
-        oc = lk["octave"][ef]
-        return ctx.pose_only_optimize(m_pos[held[ef]].astype(np.float64), meas, isig2[oc].astype(np.float64), sig2[oc], p0, *cam32), held, len(ok)
-
-    gm = motion_fused()
-    (ngm, posem, _), heldm, nmm = motion_two_calls()
-    if gm["passes"] != 1 or gm["n_matches"] != nmm or not np.array_equal(gm["assigned"], heldm) or abs(gm["n_good"] - ngm) > 1 or np.abs(gm["pose"] - posem).max() > 1e-6:
-        raise SystemExit("bench.py: latency leg: the fused motion-model chain differs from the separate calls")
-    out["track_motion_model"] = {
-        "what": "Tracking::trackMotionModel's device work for 1600 last-frame features with map points against a 2000-feature frame, host arrays "
-                "in, host results out: orbfe_track_motion_model (one call) vs orbfe_search_in_area + orbfe_pose_only_optimize with the "
-                "reference's policy in numpy between them",
-        "n_matches": int(gm["n_matches"]), "n_edges": int(gm["n_edges"]), "n_good": int(gm["n_good"]),
-        "fused": _stats_ms(motion_fused, 200, warm=10), "two_calls": _stats_ms(motion_two_calls, 100, warm=5), "verified": True}
-    ctx.close()
-    # (b) the C++ drop-in
-    tmp = tempfile.mkdtemp(prefix="orbfe_lat_")
-    exe = os.path.join(tmp, "test_dropin")
-    pkg = os.path.join(ROOT, "orb_slam2_ros2_amd")
-    try:
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "tests", "cpp", "stubs"), "-o", exe,
-                               os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"), "-L" + pkg, "-lorbfe_hip", "-pthread",
-                               "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
-        L.tofile(os.path.join(tmp, "L.raw"))
-        R.tofile(os.path.join(tmp, "R.raw"))
-        # (the C++ child gets the same setting as this leg: the runtime's default unless ORBFE_LATENCY_HW_QUEUES asks for a value)
-        env = dict(os.environ)
-        if os.environ.get("ORBFE_LATENCY_HW_QUEUES"):
-            env["GPU_MAX_HW_QUEUES"] = os.environ["ORBFE_LATENCY_HW_QUEUES"]
-        r = subprocess.run([exe, "latency", os.path.join(tmp, "L.raw"), os.path.join(tmp, "R.raw"), str(W), str(H), str(n)],
-                           capture_output=True, text=True, timeout=300, env=env)
-        f = r.stdout.split()
-        if r.returncode != 0 or not f or f[0] != "LATENCY_OK":
-            raise RuntimeError((r.stdout + r.stderr)[-400:])
-        if int(f[8]) != len(lk) or int(f[9]) != nm:
-            raise SystemExit("bench.py: latency leg: the drop-in frame differs from the verified single-pair result")
-        out["two_threads_extract_slot_plus_match"] = {
-            "median_ms": float(f[2]) / 1e3, "p99_ms": float(f[3]) / 1e3, "extract_median_ms": float(f[4]) / 1e3, "n": int(f[1]),
-            "what": "ORB_SLAM2_ROS2::ORBExtractor x 2 on two std::threads (orbfe_extract_slot each, thread start / join included as in "
-                    "Frame::Frame) + searchByStereo, C++ drop-in, host cv::Mat in, std::vector<cv::KeyPoint> / cv::Mat descriptors out"}
-        out["same_objects_one_thread"] = {"median_ms": float(f[5]) / 1e3, "p99_ms": float(f[6]) / 1e3, "extract_median_ms": float(f[7]) / 1e3}
-        if len(f) >= 13:
-            out["createStereo_one_call_cpp"] = {
-                "median_ms": float(f[11]) / 1e3, "p99_ms": float(f[12]) / 1e3,
-                "what": "the same Frame built by orbfe::dropin::createStereo (ORBExtractor::extractStereo -> orbfe_frame_stereo_slots): both "
-                        "extractions and the stereo match as one device call in place of the two threads and searchByStereo; every frame "
-                        "hashed equal to the two-thread one"}
-        if len(f) >= 15:
-            out["two_threads_eager_start"] = {
-                "median_ms": float(f[13]) / 1e3, "p99_ms": float(f[14]) / 1e3,
-                "what": "the reference's own shape again -- two extractor objects, two std::threads, searchByStereo -- with "
-                        "orbfe::ORBExtractor::eagerStart(): the constructors (which run before the threads exist, Frame.cc:91-92, and build the "
-                        "pyramid in the reference) enqueue the extraction (orbfe_extract_slot_begin), extract() collects it: the device works while "
-                        "the threads are created"}
-        out["cpp_hw_queues"] = env.get("GPU_MAX_HW_QUEUES", "unset (runtime default)")
-    except (subprocess.CalledProcessError, RuntimeError, OSError) as ex:
-        out["two_threads_extract_slot_plus_match"] = {"error": f"{type(ex).__name__}: {ex}"}
-    return out
-
-
-def content_sweep(ctx, B, dev, rect_hosts, steps):
-    """The same step on every content class of synth.CONTENT_CLASSES: the reference's input contract is a camera
-    image (example/Stereo/KittiStereo.cc:28-33) and the cost of the path depends on the content -- cells that repeat cv::FAST at the
-    low threshold (ORBExtractor.cc:365-367), candidates the quadtree spreads, right keypoints per row band.  Per class: 16 distinct
-    pairs tiled to B (as the headline batch), device-resident; stage times with every kernel ALONE (HIP events), then `steps` steps of
-    the production schedule; EVERY pair of the last batch checked against the committed oracle digests (golden_v1 bench_pairs for
-    "rect", golden_v4 for the rest, tools/make_golden_v4.py) before a number is reported."""
-    import torch
-
-    from orb_slam2_ros2_amd import synth
-    from orb_slam2_ros2_amd.digest import batch_digests
-    g1 = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v1.json")))["bench_pairs"]
-    g4 = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v4.json")))["classes"]
-    U = min(B, 16)
-    out = {}
-    for cls in synth.CONTENT_CLASSES:
-        if cls == "rect":
-            left_h, right_h = rect_hosts
-            gold = g1
-        else:
-            fr = [synth.stereo_pair_content(f, cls, W, H) for f in range(U)]
-            reps = (B + U - 1) // U
-            left_h = np.stack(([a for a, _ in fr] * reps)[:B])
-            right_h = np.stack(([b for _, b in fr] * reps)[:B])
-            gold = g4[cls]["pairs"]
-        dl, dr = torch.from_numpy(left_h).to(dev), torch.from_numpy(right_h).to(dev)
-
-        def step():
-            ctx.stereo_batch_device(dl.data_ptr(), dr.data_ptr(), W, W * H, B, FX, BF)
-        for _ in range(5):
-            step()
-        ctx.sync()
-        ctx.profile_enable(1)
-        ctx.profile_read()
-        for _ in range(5):
-            step()
-        ctx.sync()
-        alone = {k: ms / n for k, (ms, n) in ctx.profile_read().items() if n}
-        ctx.profile_enable(0)
-        for _ in range(3):
-            step()
-        ctx.sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        ctx.sync()
-        ms_step = (time.perf_counter() - t0) / steps * 1e3
-        kps, desc, cnt = ctx.fetch_batch(0, 2 * B)
-        ru, dp, nm = ctx.fetch_stereo_batch(0, B)
-        dig = batch_digests(kps, desc, cnt, ru, dp, nm)
-        bad = [p_ for p_ in range(B) if dig[p_] != gold[str(p_ % U)]]
-        if bad:
-            raise SystemExit(f"bench.py: content sweep: class {cls}: {len(bad)} of {B} pairs differ from the golden digests (first: pair {bad[0]})")
-        lo = cells = n_cand = 0
-        for l in range(NLEVELS):
-            c = ctx.debug_candidates(0, l)
-            li = ctx.level_info(l)
-            a, b = synth.lo_pass_cells(c, li.width - 32, li.height - 32, TH_HI)
-            lo, cells, n_cand = lo + a, cells + b, n_cand + len(c)
-        out[cls] = {"ms_per_step": ms_step, "pairs_per_s": B / ms_step * 1e3, "fast_ms": alone.get("fast"), "quadtree_ms": alone.get("quadtree"),
-                    "stereo_ms": alone.get("stereo"), "resize_ms": alone.get("resize"), "blur_ms": alone.get("blur"),
-                    "orient_brief_ms": alone.get("orient_brief"), "frac_cells_lo_pass": lo / max(cells, 1), "candidates_per_image": n_cand,
-                    "keypoints_per_image": float(cnt.mean()), "matches_per_pair": float(nm.mean()), "verified_pairs": B, "steps": steps}
-        del dl, dr, kps, desc, ru, dp
-        torch.cuda.empty_cache()
-    ms = [v["ms_per_step"] for v in out.values()]
-    out["worst_over_best"] = max(ms) / min(ms)
-    out["what"] = ("the headline step (512 pairs resident in HBM, production schedule) per synthetic content class, every pair verified against the "
-                   "oracle's digests; *_ms: the stage's kernels ALONE (HIP events, untimed pass); frac_cells_lo_pass / candidates_per_image: the left "
-                   "image of frame 0 (cells without a corner at 20 repeat cv::FAST at 7); 'rect' is the class `value` is quoted on")
-    return out
+from benchlib.common import (BF, FX, H, HBM_PEAK_GBPS, NFEAT, NLEVELS, PCIE_PEAK_GBPS, SCALE, TH_HI, TH_LO, W, _StdoutToStderr,  # noqa: E402
+                             algorithmic_bytes, spawn_ranks)
+from benchlib.host_io import host_io_leg  # noqa: E402
+from benchlib.legs import ba_leg, cfg3_leg, latency_leg  # noqa: E402
+from benchlib.sequence_leg import run_sequence_mode, sequence_batch, sequence_job  # noqa: E402
+from benchlib.sweep import content_sweep  # noqa: E402
 
 
 def main():
@@ -861,7 +61,11 @@ def main():
     ap.add_argument("--sequence", type=int, default=0,
                     help="run a whole sequence of this many stereo pairs (BASELINE config 4: 4541), sharded over the ranks, instead of the "
                          "fixed-batch step loop")
-    ap.add_argument("--sequence-unique", type=int, default=64, help="distinct synthetic frames behind the sequence (frame f = f mod this)")
+    ap.add_argument("--sequence-unique", type=int, default=512, help="distinct synthetic frames behind the sequence (frame f = f mod this)")
+    ap.add_argument("--unique", type=int, default=0,
+                    help="distinct stereo pairs in the step's batch (0 = --pairs: every pair of a step is a different synthetic frame, as the "
+                         "reference reads a new image pair every iteration, example/Stereo/KittiStereo.cc:28-33; 16 = the tiling of rounds 1-5, "
+                         "whose 15 MB of level-0 pixels stay in the Infinity Cache)")
     ap.add_argument("--sequence-leg", type=int, default=4541,
                     help="frames of the sequence job reported beside the step loop (`sequence` object: BASELINE config 4 -- 4541 stereo pairs cut "
                          "into blocks over the ranks, the per-frame records brought to one host memory); 0 skips it")
@@ -892,6 +96,20 @@ def main():
         # `python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) as CHILD processes -- before anything in this process
         # has touched the GPU -- relay rank 0's JSON line and exit with the worst child status
         raise SystemExit(spawn_ranks(args.gpus))
+
+    # The synthetic frames of this rank, generated ONCE, outside every clock and BEFORE this process touches the GPU (forked workers):
+    # rank r owns frames [r U, (r + 1) U) of every step (weak scaling), U = --unique distinct pairs (default: all --pairs of a step);
+    # the sequence legs read frames f mod --sequence-unique, which on rank 0 are the same arrays.
+    from benchlib.common import generate_pairs, golden_digests
+    rank_env = int(os.environ.get("RANK", "0"))
+    n_unique = min(args.pairs, args.unique if args.unique > 0 else args.pairs)
+    U_seq = max(1, min(args.sequence_unique, 4541))
+    t_gen = time.perf_counter()
+    step_frames = list(range(rank_env * n_unique, (rank_env + 1) * n_unique)) if args.sequence <= 0 else []
+    seq_frames = list(range(U_seq)) if (args.sequence > 0 or args.sequence_leg > 0) else []
+    wanted = sorted(set(step_frames) | set(seq_frames))
+    frame_cache = dict(zip(wanted, generate_pairs(wanted)))
+    t_gen = time.perf_counter() - t_gen
 
     import torch
     import torch.distributed as dist
@@ -961,7 +179,7 @@ def main():
     from orb_slam2_ros2_amd._lib import Context
 
     if args.sequence > 0:
-        line = run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend, collective)
+        line = run_sequence_mode(args, rank, local_rank, world, dev, xdev, backend, collective, frame_cache)
         if rank == 0:
             line["rccl"] = rccl_note
             emit(line)
@@ -970,13 +188,9 @@ def main():
         return
 
     B = args.pairs
-    # synthetic frames of this rank's shard: rank r owns frames [r*B, (r+1)*B) of every step (weak scaling)
-    n_unique = min(B, 16)  # generating is host work; the batch tiles n_unique distinct pairs
-    lefts, rights = [], []
-    for i in range(n_unique):
-        l, r = synth.stereo_pair(rank * n_unique + i, W, H)
-        lefts.append(l)
-        rights.append(r)
+    # the batch: n_unique distinct pairs (default B: all different), tiled to B when fewer
+    lefts = [frame_cache[f][0] for f in step_frames]
+    rights = [frame_cache[f][1] for f in step_frames]
     reps = (B + n_unique - 1) // n_unique
     left_h = np.stack((lefts * reps)[:B])
     right_h = np.stack((rights * reps)[:B])
@@ -1082,14 +296,14 @@ def main():
         assert g0[0, 0] == len(kps) and g0[0, 2] == nm, "gathered summary disagrees with the fetched results"
         assert all(int(g[:, 2].min()) > 0 for g in (t.cpu().numpy() for t in gathered)), "a rank produced a pair without matches"
 
-    # every pair of the last timed batch against the committed digests (tests/golden/golden_v1.json: sha256 of keypoints, descriptors,
+    # every pair of the last timed batch against the committed digests (tests/golden/golden_v5.json: sha256 of keypoints, descriptors,
     # right_u, depth and match count per frame, made by the oracle): no oracle needed here, a fraction of a second, outside the clock
     from orb_slam2_ros2_amd.digest import batch_digests
-    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v1.json")))["bench_pairs"]
+    gold, hexn = golden_digests(step_frames)   # tests/golden/golden_v5.json: the oracle's digest of every frame of the 4541-pair sequence
     kps_all, desc_all, cnt_all = ctx.fetch_batch(0, 2 * B)
     ru_all, dp_all, nm_all = ctx.fetch_stereo_batch(0, B)
-    digests = batch_digests(kps_all, desc_all, cnt_all, ru_all, dp_all, nm_all)
-    want = [gold.get(str(rank * n_unique + (p % n_unique))) for p in range(B)]
+    digests = [d[:hexn] for d in batch_digests(kps_all, desc_all, cnt_all, ru_all, dp_all, nm_all)]
+    want = [gold[p % n_unique] for p in range(B)]
     wrong = [p for p in range(B) if want[p] is not None and digests[p] != want[p]]
     if wrong:
         raise SystemExit(f"bench.py: rank {rank}: {len(wrong)} of {B} pairs differ from the golden digests (first: pair {wrong[0]})")
@@ -1108,16 +322,16 @@ def main():
     seq_leg = None
     if args.sequence_leg > 0:
         F_leg = args.sequence_leg   # the whole job, cut into blocks over the ranks (BASELINE config 4: 4541)
-        U_leg = max(1, min(args.sequence_unique, 128))
+        U_leg = U_seq
         B_leg = sequence_batch((F_leg + world - 1) // world, B)
         t_seq, _, n_chk, xinfo = sequence_job(ctx, F_leg, B_leg, U_leg, rank, world, dev, xdev, backend, collective, window=max(1, args.sequence_window),
-                                              exchange=args.sequence_exchange)
+                                              exchange=args.sequence_exchange, frame_cache=frame_cache)
         # ... and the same job with the OTHER exchange beside it: north_star names the RCCL-over-xGMI gather of the
         # records; the default drains every rank's records over its own PCIe link.  Both in every line, so that the first multi-GPU run
         # reports the two side by side.
         other = "gather" if args.sequence_exchange == "shared" else "shared"
         t_oth, _, n_chk_o, xinfo_o = sequence_job(ctx, F_leg, B_leg, U_leg, rank, world, dev, xdev, backend, collective, window=max(1, args.sequence_window),
-                                                 exchange=other)
+                                                 exchange=other, frame_cache=frame_cache)
         seq_other = {"frames": F_leg, "pairs_per_s": F_leg / t_oth, "seconds": t_oth, "exchange": xinfo_o, "records_checked_against_host_path": n_chk_o,
                      "collective_executed": bool(collective)}
         seq_leg = {"frames": F_leg, "pairs_per_s": F_leg / t_seq, "seconds": t_seq, "result_bytes": F_leg * ctx.record_bytes(), "exchange": xinfo,
@@ -1131,7 +345,7 @@ def main():
 
     sweep = None
     if rank == 0 and world == 1 and args.content_steps > 0:
-        sweep = content_sweep(ctx, B, dev, (left_h, right_h), args.content_steps)
+        sweep = content_sweep(ctx, B, dev, (left_h, right_h), args.content_steps, want)
 
     live_ms, live_n = live[dom]
     stages_inline = dict(stages)
@@ -1160,7 +374,7 @@ def main():
         "sequence": seq_leg,
         "config": {
             "workload": "Single 1241x376 KITTI-shaped stereo pair, 8-level pyramid, 2000 FAST+rBRIEF keypoints per image, "
-                        "searchByStereo; batched (512 pairs per step).  `value` is DEVICE-RESIDENT: the images are in HBM when the clock starts "
+                        f"searchByStereo; batched ({B} pairs per step, {n_unique} of them distinct synthetic frames).  `value` is DEVICE-RESIDENT: the images are in HBM when the clock starts "
                         "and the results stay there; the rate of SURVEY 8(d)'s protocol -- page-locked host images in, full results back in host "
                         "memory, PCIe both ways inside the clock -- is config.host_io_pairs_per_s, the whole-sequence job (BASELINE config 4, "
                         "host images in, per-frame records out) config.sequence_pairs_per_s",
@@ -1209,67 +423,34 @@ def main():
         },
     }
 
-    # The same kernel against its VALU ISSUE ceiling: FAST is integer work on bytes and sits far below the HBM roofline because it is
-    # instruction-bound, so the HBM fraction alone says little about it.  wave-instructions per second = waves per launch x VALU
-    # instructions per wave (committed rocprofv3 SQ_* counter pass, profiles/) / the launch duration measured live above; peak = 256 CUs
-    # x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction.
-    import re as _re
-    def _round_key(f):  # r2_v10 after r2_v9
-        return [int(x) for x in _re.findall(r"\d+", f)]
-    sq_files = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_sq_counters.json")), key=_round_key)
-    kern_of = {"fast": "k_fast", "blur": "k_blur_mfma", "quadtree": "k_quadtree", "stereo": "k_stereo", "resize": "k_resize_regions"}
-    if sq_files and dom in kern_of:
-        try:
-            sq = json.load(open(os.path.join(ROOT, "profiles", sq_files[-1])))
-            ent = sq["kernels"].get(kern_of[dom])
-            if ent and sq.get("pairs_per_step") == B and dom_ms > 0:
-                peak = 256 * 4 * 2.4e9 / 4
-                ach = ent["waves_per_step"] * ent["valu_per_wave"] / (dom_ms * 1e-3)
-                line["roofline_valu"] = {"kernel": dom, "bound": "valu", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s",
-                                         "frac": ach / peak, "valu_per_wave": ent["valu_per_wave"], "waves_per_launch": ent["waves_per_step"],
-                                         "source": "profiles/" + sq_files[-1]}
-                # the whole step against the same ceiling: sum over the kernels of waves x vector instructions per wave / the step time
-                tot_valu = sum(k["waves_per_step"] * k["valu_per_wave"] for k in sq["kernels"].values())
-                step_s = dt / args.steps
-                line["roofline_valu"]["pipeline_frac"] = tot_valu / step_s / peak
-                line["roofline_valu"]["pipeline_valu_issue_ms"] = tot_valu / peak * 1e3
-                line["roofline_valu"]["pipeline_what"] = ("vector instructions of ALL kernels of a step (SQ_INSTS_VALU x waves, committed counter pass) / "
-                                                          "step time / 614.4 G wave-instructions per second: the share of the step that is vector issue")
-                # r5: the issue rate depends on the opcode -- profiles/r5_valu_peak.txt, r5_valu_census.txt: most of what
-                # these kernels execute (32-bit min / max / min3, mads, dots, compares, cndmask, perms) issues once per 4 cycles per SIMD
-                # (535 - 575 G wave-instr/s measured chip-wide = 4 cycles at the ~2.2 GHz the chip holds under such a load; 614.4 is 4 cycles at the
-                # nominal 2.4 GHz), while 32-bit add / sub / logic / right shifts, fp32 add / mul / fma and the non-packed 16-bit arithmetic
-                # reach ~1.8 x that with 8 waves per SIMD.  `frac` above prices every instruction at 4 cycles; frac_class_weighted prices the
-                # kernel's STATIC opcode mix (tools/isa_class_mix.py), fast ones at 4 / 1.8 cycles -- the lower, more honest figure
-                mix_path = os.path.join(ROOT, "profiles", "r5_isa_class_mix.json")
-                if os.path.exists(mix_path):
-                    mix = json.load(open(mix_path))["kernels"].get(kern_of[dom])
-                    if mix:
-                        ff = mix["frac_fast"]
-                        peak_w = peak / ((1.0 - ff) + ff / 1.8)
-                        line["roofline_valu"]["issue_classes"] = {
-                            "source": "profiles/r5_valu_peak.txt, profiles/r5_valu_census.txt, profiles/r5_isa_class_mix.json",
-                            "slow_class_cycles": 4.0, "fast_class_speedup_at_8_waves_per_simd": 1.8, "static_frac_fast": ff,
-                            "peak_class_weighted": peak_w / 1e9, "frac_class_weighted": ach / peak_w}
-        except Exception:
-            pass
+    # The dominant kernel and the whole step against the VALU ISSUE ceiling (committed rocprofv3 SQ_* pass), and the dominant kernel's
+    # memory-side traffic (committed FETCH_SIZE / WRITE_SIZE passes): benchlib/profile_reader.py
+    from benchlib.profile_reader import add_traffic, add_valu_roofline
+    add_valu_roofline(line, dom, dom_ms, dt / args.steps, B)
+    add_traffic(line, dom, stage_bytes, B, images_per_launch)
 
-    # HBM traffic of the dominant kernel from a committed rocprofv3 PMC pass of this same command (profiles/), if present
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            ent = tj.get("kernels", {}).get(dom)
-            if ent and tj.get("pairs_per_step") == B and tj.get("images_per_launch") == images_per_launch:
-                line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
-                line["roofline"]["traffic_source"] = tj.get("source", "profiles/pmc_traffic.json")
-                pk = tj.get("per_kernel", {}).get(kern_of.get(dom, ""), {})
-                line["roofline"]["traffic_factor"] = pk.get("read_factor", 2.0)   # raw FETCH_SIZE -> bytes, for this kernel's load shape
-                line["roofline"]["traffic_factor_source"] = tj.get("read_factor_source", "MI355X_MICROARCH.md (x2)")
-                line["roofline"]["traffic_what"] = tj.get("what", "memory-side request bytes (Infinity-Cache hits included): an upper bound of the HBM bytes")
-                line["roofline"]["traffic_over_algorithmic"] = ent["hbm_bytes_per_launch"] / stage_bytes[dom]
-        except Exception:
-            pass
+    # What DESIGN.md / README.md claim, as SCALAR keys of `config` (the driver's record keeps the scalars of `config`
+    # and drops nested objects -- config.content_sweep, config.stage_ms_per_launch and the roofline_valu object never reached BENCH_r05.json)
+    cfgd = line["config"]
+    cfgd["distinct_pairs_per_step"] = n_unique
+    cfgd["frame_generation_seconds"] = round(t_gen, 2)
+    for k, v in stages_inline.items():
+        cfgd[f"stage_{k}_ms"] = round(v, 4)            # the stage's kernels ALONE (HIP events, untimed pass)
+    cfgd[f"stage_{dom}_live_ms"] = round(dom_ms, 4)     # the dominant stage inside the timed region (= roofline.avg_launch_ms)
+    if sweep:
+        for cls in ("rect", "camera", "saturated", "sparse"):
+            if cls in sweep:
+                cfgd[f"content_{cls}_pairs_per_s"] = round(sweep[cls]["pairs_per_s"], 1)
+        cfgd["content_worst_over_best"] = round(sweep["worst_over_best"], 4)
+    rv = line.get("roofline_valu")
+    if rv:
+        cfgd["valu_pipeline_frac"] = round(rv.get("pipeline_frac", 0.0), 4)
+        cfgd["valu_pipeline_frac_at_measured_clock"] = round(rv.get("pipeline_frac_at_measured_clock", 0.0), 4)
+        cfgd[f"{dom}_valu_frac"] = round(rv["frac"], 4)
+        if "issue_classes" in rv:
+            cfgd[f"{dom}_valu_frac_class_weighted"] = round(rv["issue_classes"]["frac_class_weighted"], 4)
+    if line["roofline"].get("traffic"):
+        cfgd[f"{dom}_traffic_over_algorithmic"] = round(line["roofline"]["traffic_over_algorithmic"], 3)
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from oracle import pyoracle

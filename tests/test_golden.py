@@ -210,3 +210,19 @@ def test_v3_device_cfg5_local_ba_and_system():
     p, fx = _cfg5_system_args()
     check_cfg5_system(ctx.ba_build_system(**p, pose_fixed=fx))
     ctx.close()
+
+
+def test_golden_v5_sequence_digests(orc):
+    """tests/golden/golden_v5.json (tools/make_golden_v5.py): the oracle's pair digest of EVERY frame of the 4541-pair sequence -- what bench.py
+    verifies its 512 distinct pairs per step against.  Here: the fixture's shape, its agreement with golden_v1 on frames 0 .. 127, and the
+    oracle itself on a handful of frames across the range."""
+    from orb_slam2_ros2_amd.digest import pair_digest
+    g5 = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_v5.json")))
+    n, hx = g5["n_frames"], g5["hex_chars"]
+    assert n == 4541 == len(g5["pairs"]) and hx == 24 and all(len(d) == hx for d in g5["pairs"])
+    assert len(set(g5["pairs"])) == n                        # every frame is a different image pair
+    assert all(G["bench_pairs"][str(f)][:hx] == g5["pairs"][f] for f in range(128))
+    for f in (128, 511, 2222, 4540):
+        L, R = synth.stereo_pair(f)
+        r = orc.stereo_frame(L, R, fx=718.856, bf=718.856 * 0.537166, math_mode=0, threads=2)
+        assert pair_digest(r["lk"], r["ld"], r["rk"], r["rd"], r["right_u"], r["depth"], r["n_matches"])[:hx] == g5["pairs"][f], f"frame {f}"
