@@ -332,6 +332,9 @@ def main():
         other = "gather" if args.sequence_exchange == "shared" else "shared"
         t_oth, _, n_chk_o, xinfo_o = sequence_job(ctx, F_leg, B_leg, U_leg, rank, world, dev, xdev, backend, collective, window=max(1, args.sequence_window),
                                                  exchange=other, frame_cache=frame_cache)
+        if rank == 0 and xinfo.get("records_sha256") != xinfo_o.get("records_sha256"):
+            raise SystemExit(f"bench.py: sequence: the record stores of the two exchanges differ ({args.sequence_exchange}: {xinfo.get('records_sha256')}, "
+                             f"{other}: {xinfo_o.get('records_sha256')})")
         seq_other = {"frames": F_leg, "pairs_per_s": F_leg / t_oth, "seconds": t_oth, "exchange": xinfo_o, "records_checked_against_host_path": n_chk_o,
                      "collective_executed": bool(collective)}
         seq_leg = {"frames": F_leg, "pairs_per_s": F_leg / t_seq, "seconds": t_seq, "result_bytes": F_leg * ctx.record_bytes(), "exchange": xinfo,
