@@ -97,10 +97,10 @@ def main():
         # has touched the GPU -- relay rank 0's JSON line and exit with the worst child status
         raise SystemExit(spawn_ranks(args.gpus))
 
-    # The synthetic frames of this rank, generated ONCE, outside every clock and BEFORE this process touches the GPU (forked workers):
+    # The synthetic frames of this rank, generated ONCE, outside every clock, by a child process (tools/gen_frames.py: forked workers):
     # rank r owns frames [r U, (r + 1) U) of every step (weak scaling), U = --unique distinct pairs (default: all --pairs of a step);
     # the sequence legs read frames f mod --sequence-unique, which on rank 0 are the same arrays.
-    from benchlib.common import generate_pairs, golden_digests
+    from benchlib.common import generate_pairs_child, golden_digests
     rank_env = int(os.environ.get("RANK", "0"))
     n_unique = min(args.pairs, args.unique if args.unique > 0 else args.pairs)
     U_seq = max(1, min(args.sequence_unique, 4541))
@@ -108,8 +108,24 @@ def main():
     step_frames = list(range(rank_env * n_unique, (rank_env + 1) * n_unique)) if args.sequence <= 0 else []
     seq_frames = list(range(U_seq)) if (args.sequence > 0 or args.sequence_leg > 0) else []
     wanted = sorted(set(step_frames) | set(seq_frames))
-    frame_cache = dict(zip(wanted, generate_pairs(wanted)))
+    frame_cache = generate_pairs_child(wanted)   # (a child process forks the workers: this one may already carry a profiler's preload)
     t_gen = time.perf_counter() - t_gen
+
+    # The one-frame latency leg runs NOW, in a child process, while nothing else holds a context on the GPU (the r5
+    # record's p99 of 0.8 - 1.0 ms were this leg's C++ harness running beside the idle contexts of this process and of the leg's own
+    # Python half).  The child is started WITHOUT GPU_MAX_HW_QUEUES: the setting a one-frame-at-a-time caller has (recorded in the leg).
+    latency_result = None
+    if args.sequence <= 0 and args.gpus == 1 and rank_env == 0 and "latency" in [x for x in args.legs.split(",") if x]:
+        import subprocess
+        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        env["LOCAL_RANK"] = os.environ.get("LOCAL_RANK", "0")
+        t_lat = time.perf_counter()
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--only-leg", "latency"], env=env, capture_output=True, text=True, timeout=1200)
+        try:
+            latency_result = json.loads(r.stdout.strip().split("\n")[-1])
+            latency_result["leg_seconds"] = round(time.perf_counter() - t_lat, 1)
+        except Exception:   # noqa: BLE001
+            raise SystemExit("bench.py: latency leg (child process) failed:\n" + r.stdout[-2000:] + r.stderr[-4000:])
 
     import torch
     import torch.distributed as dist
@@ -513,16 +529,8 @@ def main():
             line["cfg3"] = cfg3_leg(local_rank)
         if "ba" in legs:
             line["ba"] = ba_leg(local_rank)
-        if "latency" in legs:
-            # in a child process started without GPU_MAX_HW_QUEUES: the setting a one-frame-at-a-time caller has (recorded in the leg)
-            import subprocess
-            env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-            env["LOCAL_RANK"] = str(local_rank)
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--only-leg", "latency"], env=env, capture_output=True, text=True, timeout=900)
-            try:
-                line["latency"] = json.loads(r.stdout.strip().split("\n")[-1])
-            except Exception:   # noqa: BLE001
-                raise SystemExit("bench.py: latency leg (child process) failed:\n" + r.stdout[-2000:] + r.stderr[-4000:])
+        if "latency" in legs and latency_result is not None:
+            line["latency"] = latency_result   # (measured at the very start of this run, before this process touched the GPU: see above)
         line["legs_seconds"] = time.perf_counter() - t_legs
     if rank == 0:
         emit(line)

@@ -163,6 +163,33 @@ def generate_pairs(frames, workers=None):
         return pool.map(_gen_pair, frames, chunksize=4)
 
 
+def generate_pairs_child(frames):
+    """{frame: (left, right)} through tools/gen_frames.py run as a CHILD process with a clean environment (no profiler preload): the child
+    forks the worker pool, this process never forks -- safe whatever this process has already loaded (bench.py under rocprofv3 has the
+    profiler's library, which initialises the GPU before Python starts; a GPU test session holds a context)."""
+    import subprocess
+    import tempfile
+    frames = sorted(set(frames))
+    out = {}
+    if not frames:
+        return out
+    runs, a = [], 0   # maximal runs of consecutive indices
+    for i in range(1, len(frames) + 1):
+        if i == len(frames) or frames[i] != frames[i - 1] + 1:
+            runs.append((frames[a], i - a))
+            a = i
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS"))}
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    for first, count in runs:
+        with tempfile.TemporaryDirectory(prefix="orbfe_frames_", dir=shm) as td:
+            npy = os.path.join(td, "f.npy")
+            subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_frames.py"), str(first), str(count), npy], check=True, env=env, timeout=1800)
+            arr = np.load(npy)
+        for k in range(count):
+            out[first + k] = (arr[k, 0], arr[k, 1])
+    return out
+
+
 def golden_digests(frames):
     """the oracle's digests (prefixes) of synthetic frames: tests/golden/golden_v5.json (tools/make_golden_v5.py: every frame of the 4541-pair
     sequence); None for a frame the fixture does not hold"""

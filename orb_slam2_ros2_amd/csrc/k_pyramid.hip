@@ -150,6 +150,8 @@ __global__ __launch_bounds__(256) void k_resize(const LevelDev* __restrict__ lv,
 // (x: byte offset inside the staged tile and the two pre-shifted coefficients packed for v_dot2; y: the two row offsets and the two
 // coefficients << 8), so a word costs one 16-byte and two 16-byte LDS reads of taps, not their unpacking.
 // ---------------------------------------------------------------------------------------------
+// PQ: the tile's LDS row pitch in 16-byte units when every region of the context has the same (0: read it per region)
+template <int PQ>
 __global__ __launch_bounds__(256) void k_resize_regions(const LevelDev* __restrict__ lv, int n_levels, const RsRegion* __restrict__ regions,
                                                         const RgXTap* __restrict__ xtaps, const RgYTap* __restrict__ ytaps,
                                                         uint8_t* __restrict__ pyr, size_t img_pitch, int tile_bytes, int xt_bytes,
@@ -228,9 +230,15 @@ __global__ __launch_bounds__(256) void k_resize_regions(const LevelDev* __restri
     }
   }
   typedef const __attribute__((address_space(3))) uint8_t* lds_bytes_t;
-  lds_bytes_t tb = (lds_bytes_t)tile;
   typedef unsigned short __attribute__((ext_vector_type(2))) us2;
   const uint4* lds4 = (const uint4*)rs_lds;
+  const uint32_t tile_addr = (uint32_t)(uintptr_t)(lds_bytes_t)(const uint8_t*)tile;  // the tile's LDS byte address, folded into the x offsets below
+  // r6: a thread keeps its word COLUMN and walks down the level's rows (rows_per_pass = 256 / nwx rows per step of the workgroup).  The x
+  // taps of the column -- two 16-byte LDS reads and the unpacking -- are then fetched once per level instead of once per word, the flat
+  // index -> (row, column) split (two 24-bit products, shifts, subtractions) happens once per level, and the row's y tap and the output
+  // address advance by constants.  With the tile's row pitch a compile-time constant (PQ: every region of a context has the same, see
+  // orbfe_create) the second source row of a word is the first one's address + pitch in the instruction's offset field: the taps of a
+  // downscale never clamp vertically (sy1 = sy0 + 1 always; orbfe_create checks it).  66 -> 51 vector and 19 -> 17 LDS instructions per word.
   for (int l = 1; l < n_levels; ++l) {
     struct {
       int wx0, nwx, oy0, noy, xt_lds, yt_lds;
@@ -244,41 +252,41 @@ __global__ __launch_bounds__(256) void k_resize_regions(const LevelDev* __restri
       G.inv_nwx = (uint32_t)__builtin_amdgcn_readlane((int)gq.w, l - 1);
     }
     const LevelDev& L = lv[l];
-    const int nwx = G.nwx, n_words = nwx * G.noy;
-    const uint32_t inv = G.inv_nwx;
-    // (indexed in 16-byte units from the 16-byte aligned base: what the compiler needs to see to emit ds_read_b128 -- through the
-    //  struct pointers it split every tap read into 4-byte pairs, and at the x taps' 32-byte lane stride those ran 8 deep into the banks)
+    const int nwx = G.nwx, noy = G.noy;
+    if (nwx == 0 || noy == 0) continue;  // wave-uniform
+    // (indexed in 16-byte units from the 16-byte aligned base: what the compiler needs to see to emit ds_read_b128)
     const uint4* xl = lds4 + ((tile_bytes >> 4) + (G.xt_lds >> 1));
     const uint4* yl = lds4 + (((tile_bytes + xt_bytes) >> 4) + G.yt_lds);
-    if (n_words == 0) continue;  // wave-uniform
-    uint8_t* out = base + L.plane_off + (size_t)G.oy0 * L.stride + 4 * G.wx0;
-    for (int idx = threadIdx.x; idx < n_words; idx += 256) {
-      const int r = (int)((uint32_t)mul24u(idx, (int)inv) >> 20), c = idx - mul24u(r, nwx);
-      const uint4 ayq = yl[r];
-      const struct { int o0, o1; uint32_t b0, b1; } ay = {(int)ayq.x, (int)ayq.y, ayq.z, ayq.w};
-      // (spelled out: the compiler splits these two 16-byte reads into four ds_read2_b32 however their address is formed)
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-      u32x4 xa, xb;
-      {
-        // (the taps of words c's pixels 0, 1 and 2, 3 sit in two arrays of nwx 16-byte units each: a 16-byte lane stride, no bank conflict)
-        const uint32_t xaddr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint4*)(xl + c);
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(xa), "=&v"(xb) : "v"(xaddr), "v"(xaddr + 16u * (uint32_t)nwx) : "memory");
-      }
-      const int sxo[4] = {(int)xa.x, (int)xa.z, (int)xb.x, (int)xb.z};
-      const uint32_t t2[4] = {xa.y, xa.w, xb.y, xb.w};
+    const int rpp = (int)((256u * G.inv_nwx) >> 20);  // rows per pass = 256 / nwx (inv_nwx = ceil(2^20 / nwx), nwx <= 256: exact)
+    const int rr = (int)((uint32_t)mul24u((int)threadIdx.x, (int)G.inv_nwx) >> 20), c = (int)threadIdx.x - mul24u(rr, nwx);
+    if (rr >= rpp) continue;  // (the threads past rows_per_pass x nwx sit this level out)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 xa, xb;
+    {
+      // (the taps of word c's pixels 0, 1 and 2, 3 sit in two arrays of nwx 16-byte units each: a 16-byte lane stride, no bank conflict)
+      const uint32_t xaddr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint4*)(xl + c);
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(xa), "=&v"(xb) : "v"(xaddr), "v"(xaddr + 16u * (uint32_t)nwx) : "memory");
+    }
+    const uint32_t sxa[4] = {xa.x + tile_addr, xa.z + tile_addr, xb.x + tile_addr, xb.z + tile_addr};
+    const uint32_t t2[4] = {xa.y, xa.w, xb.y, xb.w};
+    uint32_t out_off = L.plane_off + (uint32_t)mad24u(G.oy0 + rr, L.stride, 4 * (G.wx0 + c));
+    const uint32_t out_step = (uint32_t)mul24u(rpp, L.stride);
+    for (int r = rr; r < noy; r += rpp, out_off += out_step) {
+      const uint4 ayq = yl[r];  // o0, o1 (byte offsets of the two source rows in the tile), b0, b1 (coefficients << 8)
       uint32_t v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {  // (k_resize's inner loop: see the comments there)
-        lds_bytes_t r0 = tb + (ay.o0 + sxo[j]), r1 = tb + (ay.o1 + sxo[j]);
+        lds_bytes_t r0 = (lds_bytes_t)(uintptr_t)(sxa[j] + ayq.x);
+        lds_bytes_t r1 = PQ > 0 ? r0 + PQ * 16 : (lds_bytes_t)(uintptr_t)(sxa[j] + ayq.y);
         const uint32_t q0 = (uint32_t)r0[0] | ((uint32_t)r0[1] << 16), q1 = (uint32_t)r1[0] | ((uint32_t)r1[1] << 16);
         const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, q0), __builtin_bit_cast(us2, t2[j]), 0u, false) & 0xFFFFFF00u;
         const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, q1), __builtin_bit_cast(us2, t2[j]), 0u, false) & 0xFFFFFF00u;
         uint32_t m0, m1;
-        asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(m0) : "v"(ay.b0), "v"(h0));
-        asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(m1) : "v"(ay.b1), "v"(h1));
+        asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(m0) : "v"(ayq.z), "v"(h0));
+        asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(m1) : "v"(ayq.w), "v"(h1));
         v[j] = (m0 + m1 + 2u) >> 2;
       }
-      *(uint32_t*)(out + (uint32_t)mad24u(r, L.stride, 4 * c)) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+      *(uint32_t*)(base + out_off) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
     }
   }
 }
@@ -370,11 +378,23 @@ void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, c
 void launch_resize_regions(hipStream_t s, const LevelDev* d_lv, int n_levels, const RsRegion* d_regions, int n_regions, int tile_bytes,
                            int xt_bytes, int yt_bytes, const RgXTap* d_xtaps, const RgYTap* d_ytaps, uint8_t* d_pyr, size_t img_pitch, int n_img,
                            const uint8_t* src_a, const uint8_t* src_b, size_t src_pitch, int src_stride, uint32_t src_bytes, int copy_l0,
-                           int32_t* d_zero, int n_zero) {
+                           int32_t* d_zero, int n_zero, int pq) {
+  // pq: the regions' common LDS row pitch (16-byte units; orbfe_create makes it uniform) -- a compile-time constant of the kernel for the
+  // pitches region widths of 128 .. 256 pixels give, the run-time form (0) otherwise
   if (n_img <= 0 || n_regions <= 0) return;
-  hipLaunchKernelGGL(k_resize_regions, dim3(n_regions, n_img), dim3(256), (size_t)(tile_bytes + xt_bytes + yt_bytes), s, d_lv, n_levels,
-                     d_regions, d_xtaps, d_ytaps, d_pyr, img_pitch, tile_bytes, xt_bytes, src_a, src_b, src_pitch, src_stride, src_bytes, copy_l0, d_zero,
-                     n_zero);
+#define RS_GO(PQ)                                                                                                                                   \
+  hipLaunchKernelGGL(k_resize_regions<PQ>, dim3(n_regions, n_img), dim3(256), (size_t)(tile_bytes + xt_bytes + yt_bytes), s, d_lv, n_levels, d_regions, \
+                     d_xtaps, d_ytaps, d_pyr, img_pitch, tile_bytes, xt_bytes, src_a, src_b, src_pitch, src_stride, src_bytes, copy_l0, d_zero, n_zero)
+  switch (pq) {
+    case 9: RS_GO(9); break;
+    case 11: RS_GO(11); break;
+    case 13: RS_GO(13); break;
+    case 15: RS_GO(15); break;
+    case 17: RS_GO(17); break;
+    case 19: RS_GO(19); break;
+    default: RS_GO(0); break;
+  }
+#undef RS_GO
 }
 
 // tiles [tile_first, tile_first + n_tiles) of the per-image tile list (level-major: a range of tiles is a range of levels)

@@ -351,6 +351,27 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
         c->rg_yt_bytes = std::max(c->rg_yt_bytes, n_yt * 16);
         c->rs_regions.push_back(R);
       }
+    // One LDS row pitch for every region of the context (the widest region's, odd): k_resize_regions then has it as a compile-time
+    // constant and reaches a word's second source row through the instruction's offset field -- valid because a downscale's vertical taps
+    // never clamp (sy1 = sy0 + 1 for every output row: checked here, rg_pq = 0 -- the run-time form -- otherwise)
+    c->rg_pq = 0;
+    if (ok && !c->rs_regions.empty()) {
+      int pq_all = 0;
+      for (const RsRegion& R : c->rs_regions) pq_all = std::max(pq_all, (int)R.pq);
+      bool no_clamp = true;
+      c->rg_tile_bytes = 0;
+      for (RsRegion& R : c->rs_regions) {
+        for (int k = 0; k < (int)R.n_yt; ++k) {
+          RgYTap& o = c->rg_ytaps[R.yt_off + k];
+          o.o0 = o.o0 / (R.pq * 16) * (pq_all * 16);
+          o.o1 = o.o1 / (R.pq * 16) * (pq_all * 16);
+          if (o.o1 != o.o0 + pq_all * 16) no_clamp = false;
+        }
+        R.pq = (int16_t)pq_all;
+        c->rg_tile_bytes = std::max(c->rg_tile_bytes, pq_all * 16 * R.nr);
+      }
+      if (no_clamp) c->rg_pq = pq_all;
+    }
     c->rg_xt_bytes = (int)align_up((size_t)c->rg_xt_bytes, 16);
     if (!ok || c->rg_tile_bytes + c->rg_xt_bytes + c->rg_yt_bytes > 60 * 1024) c->rs_regions.clear();  // fall back to the tile classes
   }

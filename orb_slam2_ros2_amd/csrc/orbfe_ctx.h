@@ -36,7 +36,7 @@ void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, c
                    size_t img_pitch, int n_img);
 void launch_resize_regions(hipStream_t s, const LevelDev* d_lv, int n_levels, const RsRegion* d_regions, int n_regions, int tile_bytes,
                            int xt_bytes, int yt_bytes, const RgXTap* d_xtaps, const RgYTap* d_ytaps, uint8_t* d_pyr, size_t img_pitch, int n_img,
-                           const uint8_t* src_a, const uint8_t* src_b, size_t src_pitch, int src_stride, uint32_t src_bytes, int copy_l0, int32_t* d_zero, int n_zero);
+                           const uint8_t* src_a, const uint8_t* src_b, size_t src_pitch, int src_stride, uint32_t src_bytes, int copy_l0, int32_t* d_zero, int n_zero, int pq);
 void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int tile_first, int n_tiles, const uint8_t* d_pyr, uint8_t* d_blur,
                  size_t img_pitch, const int taps[7], int n_img);
 // k_blur_mfma.hip: the batches' blur on the integer matrix cores (band tables built by mb_build; ok = false: keep k_blur)
@@ -232,6 +232,7 @@ struct orbfe_ctx {
   RgXTap* d_rg_xtaps = nullptr;
   RgYTap* d_rg_ytaps = nullptr;
   int rg_tile_bytes = 0, rg_xt_bytes = 0, rg_yt_bytes = 0;
+  int rg_pq = 0;  // the regions' common LDS row pitch in 16-byte units when the kernel may take it as a constant (0: per region, at run time)
   int rs_n[3] = {0, 0, 0}, rs_bytes[3] = {0, 0, 0};  // resize tiles of 64x64 / 64x32 / 64x16 outputs (in this order) and their LDS
   size_t img_pitch = 0;      // bytes per image in pyr / blur
   size_t scratch_pitch = 0;  // uint32 records per image

@@ -50,7 +50,7 @@ orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, hipE
       launch_resize_regions(st, c->d_lv, nl, c->d_rs_regions, (int)c->rs_regions.size(), c->rg_tile_bytes, c->rg_xt_bytes, c->rg_yt_bytes,
                             c->d_rg_xtaps, c->d_rg_ytaps, pyr, c->img_pitch, n_img, ext ? ext->left : pyr + c->lv[0].plane_off,
                             ext ? ext->right : nullptr, ext ? ext->pitch : c->img_pitch, ext ? ext->stride : c->lv[0].stride,
-                            ext ? ext->bytes : 0xFFFFFFFFu, ext ? 1 : 0, n_cand, n_img * nl);
+                            ext ? ext->bytes : 0xFFFFFFFFu, ext ? 1 : 0, n_cand, n_img * nl, c->rg_pq);
     else
       launch_resize(st, c->d_lv, c->d_rs_tiles, c->rs_n, c->rs_bytes, c->d_taps, pyr, c->img_pitch, n_img);
   }

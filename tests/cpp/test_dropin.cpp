@@ -376,6 +376,13 @@ static int mode_latency(int argc, char** argv) {
   printf("LATENCY_OK %d %.1f %.1f %.1f %.1f %.1f %.1f %zu %d %016llx %.1f %.1f %.1f %.1f\n", iters, pct(total[1], 0.5), pct(total[1], 0.99), pct(ext[1], 0.5),
          pct(total[0], 0.5), pct(total[0], 0.99), pct(ext[0], 0.5), nl, nm, (unsigned long long)want, pct(total[2], 0.5), pct(total[2], 0.99),
          pct(total[3], 0.5), pct(total[3], 0.99));
+  // (r6: ONE harness for every one-frame figure anybody quotes -- bench.py's latency leg runs exactly this, alone on the GPU, with >= 2000
+  //  frames -- so the whole distribution of every call shape goes out too: way, frames, p50, p90, p99, p99.9, max of the frame; p50, p99 of
+  //  the constructor + extraction part)
+  const char* way_name[4] = {"one_thread", "two_threads", "create_stereo", "two_threads_eager"};
+  for (int way : {1, 0, 2, 3})
+    printf("LATQ %s %zu %.1f %.1f %.1f %.1f %.1f %.1f %.1f\n", way_name[way], total[way].size(), pct(total[way], 0.5), pct(total[way], 0.9), pct(total[way], 0.99),
+           pct(total[way], 0.999), pct(total[way], 1.0), pct(ext[way], 0.5), pct(ext[way], 0.99));
   return 0;
 }
 

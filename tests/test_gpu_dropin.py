@@ -66,8 +66,13 @@ def test_create_stereo_adapter_builds_the_same_frame_as_two_threads_and_search_b
     out = subprocess.run([exe, "latency", str(tmp_path / "L.raw"), str(tmp_path / "R.raw"), "1241", "376", "40"], capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
-    f = out.stdout.split()
+    lines = out.stdout.strip().split("\n")
+    f = lines[0].split()
     assert f[0] == "LATENCY_OK" and len(f) == 15
+    q = {l.split()[1]: [float(v) for v in l.split()[2:]] for l in lines[1:] if l.startswith("LATQ")}
+    assert set(q) == {"one_thread", "two_threads", "create_stereo", "two_threads_eager"}
+    for w_, (n_, p50, p90, p99, p999, mx, e50, e99) in q.items():   # the distribution of every call shape (the harness bench.py reports from)
+        assert n_ == 40 and 0 < p50 <= p90 <= p99 <= p999 <= mx and 0 < e50 <= e99
     ref = orc.stereo_frame(L, R, fx=FX, bf=BF)
     assert (int(f[8]), int(f[9])) == (len(ref["lk"]), ref["n_matches"])
     assert float(f[11]) > 0 and float(f[13]) > 0   # createStereo; the reference shape with the constructors starting the device (eagerStart)
