@@ -58,6 +58,11 @@ namespace orbfe {
 #ifndef FAST_OPS16
 #define FAST_OPS16 1
 #endif
+#ifndef FAST_SLIDE
+#define FAST_SLIDE 2  // the necessary test walks down its columns with register rings: 1 = window column 3 (7 LDS reads per pixel), 2 = columns 3 and
+                      // 1 (6 reads; the default), 3 = columns 3, 1, 5 (5 reads, but 64 registers and two spills in k_fast<40, 36>: the deferred
+                      // record of the previous cell goes to scratch and its reload waits for the patch prefetch); 0 = r5's two rows per trip, 9 reads
+#endif
 #if FAST_OPS16
 __device__ __forceinline__ int fast_min16(int a, int b) {
   int d;
@@ -315,12 +320,80 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             if (any) Q[nq + mbcnt64(m, 0)] = (uint16_t)(eh | (pd ? 0u : Q_BRIGHT) | (dual ? Q_DUAL : 0u));
             nq += __popcll(m);
           };
+#if FAST_SLIDE
+          // r6: a lane walks DOWN its column (row group ly takes rows ly H2 .. ly H2 + H2 - 1, one row per trip), so the ring pixels it
+          // reads recur: column 3 of the window is read at rows t, t + 3, t + 6 (r8, v, r0) and columns 1 / 5 at rows t + 1, t + 5 (r10 /
+          // r14, r6 / r2) -- each value fetched ONCE into a 7-slot register ring per column and used again three / four trips later; only
+          // columns 0 and 6 (r12, r4) are read once anyway.  With all three rings 5 LDS reads per trip instead of 9 (+ 14 per column block to
+          // fill them); the default (FAST_SLIDE = 2) keeps the rings of columns 3 and 1: 6 reads, 62 registers.  The kernel is co-limited by
+          // the LDS (profiles/r5_fast_lds_counters.txt).  Unrolled by 7 so that the ring slots are register names.  Same-box A/B
+          // (profiles/NOTES_r6.md): the step -0.8 % on the camera-like class (FAST alone 1.67 -> 1.60 ms), unchanged on `rect`.
+          {
+            const int H2 = (ih + rpi - 1) >> (6 - shift);   // rows per row group (rpi = 64 >> shift groups)
+            const int row0 = mul24u(ly, H2);
+            const uint8_t* aw = P + row0 * PP + xa + ix;      // window of the lane's first row
+            const uint32_t e_row0 = (uint32_t)ix | ((uint32_t)row0 << 7);
+            const int n_valid = ih - row0;                     // the lane's rows t < n_valid lie inside the interior (may be <= 0)
+            int w3[7], w1[7], w5[7];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) w3[k] = aw[k * PP + 3];
+#if FAST_SLIDE >= 2
+#pragma unroll
+            for (int k = 1; k < 5; ++k) w1[k] = aw[k * PP + 1];
+#endif
+#if FAST_SLIDE >= 3
+#pragma unroll
+            for (int k = 1; k < 5; ++k) w5[k] = aw[k * PP + 5];
+#endif
+            auto trip_s = [&](const int t, const int k, const int thr) __attribute__((always_inline)) {
+              const uint8_t* a = aw + t * PP;
+              w3[(k + 6) % 7] = a[6 * PP + 3];
+              const int r12 = a[3 * PP], r4 = a[3 * PP + 6];
+              const int r8 = w3[k % 7], v = w3[(k + 3) % 7], r0 = w3[(k + 6) % 7];
+#if FAST_SLIDE >= 2
+              w1[(k + 5) % 7] = a[5 * PP + 1];
+              const int r10 = w1[(k + 1) % 7], r14 = w1[(k + 5) % 7];
+#else
+              (void)w1;
+              const int r10 = a[PP + 1], r14 = a[5 * PP + 1];
+#endif
+#if FAST_SLIDE >= 3
+              w5[(k + 5) % 7] = a[5 * PP + 5];
+              const int r6 = w5[(k + 1) % 7], r2 = w5[(k + 5) % 7];
+#else
+              (void)w5;
+              const int r2 = a[5 * PP + 5], r6 = a[PP + 5];
+#endif
+              const int lo_of_hi = FAST_MIN16(FAST_MIN16(FAST_MAX16(r0, r8), FAST_MAX16(r4, r12)), FAST_MIN16(FAST_MAX16(r2, r10), FAST_MAX16(r6, r14)));
+              const int hi_of_lo = FAST_MAX16(FAST_MAX16(FAST_MIN16(r0, r8), FAST_MIN16(r4, r12)), FAST_MAX16(FAST_MIN16(r2, r10), FAST_MIN16(r6, r14)));
+              const int sb = lo_of_hi - v, sd = v - hi_of_lo;
+              const bool pd = sd > thr;
+              const unsigned long long mb = __ballot(sb > thr), md = __ballot(pd);
+              const unsigned long long m = mb | md, m2 = mb & md;
+              const bool any = __builtin_amdgcn_inverse_ballot_w64(m), dual = __builtin_amdgcn_inverse_ballot_w64(m2);
+              const uint32_t eh = e_row0 + ((uint32_t)t << 7);
+              if (any) Q[nq + mbcnt64(m, 0)] = (uint16_t)(eh | (pd ? 0u : Q_BRIGHT) | (dual ? Q_DUAL : 0u));
+              nq += __popcll(m);
+            };
+            // rows every group has (t < ih - (rpi - 1) H2, wave-uniform): the lane's column test alone; the remaining trips also test the row
+            const int t_full = max(0, ih - (rpi - 1) * H2);
+            for (int t0 = 0; t0 < H2; t0 += 7) {
+#pragma unroll
+              for (int k = 0; k < 7; ++k) {
+                const int t = t0 + k;
+                if (t >= H2) break;  // wave-uniform
+                trip_s(t, k, (t < t_full || t < n_valid) ? thr_x : 0x7FFF);
+              }
+            }
+          }
+#else
           // lanes right of the interior can never pass (thr_x), so the column test costs nothing per trip; the row test is only needed in
           // the last, partial trip of a column block (its rows past the interior are read -- they lie inside this wave's carve-up -- but
           // cannot pass either)
           int y0 = 0;
           for (; y0 + rpi <= ih; y0 += rpi, a += rpi * PP) trip(y0, thr_x);
           if (y0 < ih) trip(y0, y0 + ly < ih ? thr_x : 0x7FFF);
+#endif
         }
       }
       WAVE_SYNC();

@@ -33,3 +33,26 @@ while [ ! -f $T/idle_2.ready ]; do sleep 0.2; done
 run "beside two idle HIP processes"
 kill $P1 $P2 2>/dev/null || true; wait $P1 $P2 2>/dev/null || true
 run "alone again"
+# (e) beside a process that looks like bench.py's main process at the time the r5 leg ran: a one-rank RCCL process group (its helper
+#     threads), 1 GB of page-locked memory, a closed 1024-slot context
+python3 -c "
+import os, sys, time; sys.path.insert(0, '$R')
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29531'); os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+import torch, torch.distributed as dist
+from orb_slam2_ros2_amd._lib import Context
+dev = torch.device('cuda', 0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+t = torch.ones(4, device=dev); dist.all_reduce(t); torch.cuda.synchronize()
+pin = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
+c = Context(1241, 376, max_images=1024); c.close()
+open('$T/idle_3.ready', 'w').write('1')
+time.sleep(45)
+" > /dev/null 2>&1 &
+P3=$!
+while [ ! -f $T/idle_3.ready ]; do sleep 0.2; done
+N=500
+run "beside a bench-like parent (RCCL group of one rank, 1 GB pinned), 500 frames"
+run "the same again, 500 frames"
+kill $P3 2>/dev/null || true; wait $P3 2>/dev/null || true
+N=500
+run "alone, 500 frames"
