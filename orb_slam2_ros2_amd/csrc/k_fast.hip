@@ -293,33 +293,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         const int lx = lane & (lw - 1), ly = lane >> shift;
         for (int x0 = 0; x0 < iw; x0 += lw) {
           const int ix = x0 + lx;
+          const int thr_x = ix < iw ? t_pass : 0x7FFF;
+#if !FAST_SLIDE
           const uint8_t* a0 = P + ly * PP + xa + ix;  // top-left corner of the pixel's 7x7 window
           const uint32_t e_lane = (uint32_t)ix | ((uint32_t)ly << 7);
-          const int thr_x = ix < iw ? t_pass : 0x7FFF;
           const uint8_t* a = a0;
-          // every predicate is ONE vector compare whose lane mask feeds the ballot and the branch directly (a predicate built from
-          // several masks is expanded to 0 / 1 per lane and compared again before a ballot: two more VALU instructions each)
-          auto trip = [&](const int y0, const int thr) __attribute__((always_inline)) {
-            const int v = a[3 * PP + 3];
-            const int r0 = a[6 * PP + 3], r8 = a[3], r4 = a[3 * PP + 6], r12 = a[3 * PP];
-            const int r2 = a[5 * PP + 5], r10 = a[PP + 1], r6 = a[PP + 5], r14 = a[5 * PP + 1];
-            // (the 14 minima / maxima as 16-BIT instructions: on gfx950 the non-packed 16-bit VOP2 arithmetic goes through a SIMD at ~1.8 x
-            //  the rate of the 32-bit v_min / v_max / v_min3 at eight waves per SIMD -- profiles/r5_valu_census.txt -- and the operands are
-            //  bytes; the results' upper halves are zero on this generation, so the 32-bit subtractions below read them as they are)
-            const int lo_of_hi = FAST_MIN16(FAST_MIN16(FAST_MAX16(r0, r8), FAST_MAX16(r4, r12)), FAST_MIN16(FAST_MAX16(r2, r10), FAST_MAX16(r6, r14)));
-            const int hi_of_lo = FAST_MAX16(FAST_MAX16(FAST_MIN16(r0, r8), FAST_MIN16(r4, r12)), FAST_MAX16(FAST_MIN16(r2, r10), FAST_MIN16(r6, r14)));
-            const int sb = lo_of_hi - v;  // > t: every opposite pair has a pixel brighter than v + t
-            const int sd = v - hi_of_lo;  // > t: ... darker than v - t
-            // two compares; their lane masks are combined on the SCALAR unit and handed back as lane predicates (inverse ballot: the
-            // mask register is used as it is) -- max / min of the two margins and a compare each were four vector instructions
-            const bool pd = sd > thr;
-            const unsigned long long mb = __ballot(sb > thr), md = __ballot(pd);
-            const unsigned long long m = mb | md, m2 = mb & md;
-            const bool any = __builtin_amdgcn_inverse_ballot_w64(m), dual = __builtin_amdgcn_inverse_ballot_w64(m2);
-            const uint32_t eh = e_lane + ((uint32_t)y0 << 7);
-            if (any) Q[nq + mbcnt64(m, 0)] = (uint16_t)(eh | (pd ? 0u : Q_BRIGHT) | (dual ? Q_DUAL : 0u));
-            nq += __popcll(m);
-          };
+#endif
 #if FAST_SLIDE
           // r6: a lane walks DOWN its column (row group ly takes rows ly H2 .. ly H2 + H2 - 1, one row per trip), so the ring pixels it
           // reads recur: column 3 of the window is read at rows t, t + 3, t + 6 (r8, v, r0) and columns 1 / 5 at rows t + 1, t + 5 (r10 /
@@ -345,6 +324,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #pragma unroll
             for (int k = 1; k < 5; ++k) w5[k] = aw[k * PP + 5];
 #endif
+            // (every predicate is ONE vector compare whose lane mask feeds the ballot and the branch directly; the two masks are combined on the
+            //  scalar unit and handed back as lane predicates -- see the FAST_SLIDE = 0 form below for the measurements behind that)
             auto trip_s = [&](const int t, const int k, const int thr) __attribute__((always_inline)) {
               const uint8_t* a = aw + t * PP;
               w3[(k + 6) % 7] = a[6 * PP + 3];
@@ -387,6 +368,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             }
           }
 #else
+          // every predicate is ONE vector compare whose lane mask feeds the ballot and the branch directly (a predicate built from
+          // several masks is expanded to 0 / 1 per lane and compared again before a ballot: two more VALU instructions each)
+          auto trip = [&](const int y0, const int thr) __attribute__((always_inline)) {
+            const int v = a[3 * PP + 3];
+            const int r0 = a[6 * PP + 3], r8 = a[3], r4 = a[3 * PP + 6], r12 = a[3 * PP];
+            const int r2 = a[5 * PP + 5], r10 = a[PP + 1], r6 = a[PP + 5], r14 = a[5 * PP + 1];
+            // (the 14 minima / maxima as 16-BIT instructions: on gfx950 the non-packed 16-bit VOP2 arithmetic goes through a SIMD at ~1.8 x
+            //  the rate of the 32-bit v_min / v_max / v_min3 at eight waves per SIMD -- profiles/r5_valu_census.txt -- and the operands are
+            //  bytes; the results' upper halves are zero on this generation, so the 32-bit subtractions below read them as they are)
+            const int lo_of_hi = FAST_MIN16(FAST_MIN16(FAST_MAX16(r0, r8), FAST_MAX16(r4, r12)), FAST_MIN16(FAST_MAX16(r2, r10), FAST_MAX16(r6, r14)));
+            const int hi_of_lo = FAST_MAX16(FAST_MAX16(FAST_MIN16(r0, r8), FAST_MIN16(r4, r12)), FAST_MAX16(FAST_MIN16(r2, r10), FAST_MIN16(r6, r14)));
+            const int sb = lo_of_hi - v;  // > t: every opposite pair has a pixel brighter than v + t
+            const int sd = v - hi_of_lo;  // > t: ... darker than v - t
+            // two compares; their lane masks are combined on the SCALAR unit and handed back as lane predicates (inverse ballot: the
+            // mask register is used as it is) -- max / min of the two margins and a compare each were four vector instructions
+            const bool pd = sd > thr;
+            const unsigned long long mb = __ballot(sb > thr), md = __ballot(pd);
+            const unsigned long long m = mb | md, m2 = mb & md;
+            const bool any = __builtin_amdgcn_inverse_ballot_w64(m), dual = __builtin_amdgcn_inverse_ballot_w64(m2);
+            const uint32_t eh = e_lane + ((uint32_t)y0 << 7);
+            if (any) Q[nq + mbcnt64(m, 0)] = (uint16_t)(eh | (pd ? 0u : Q_BRIGHT) | (dual ? Q_DUAL : 0u));
+            nq += __popcll(m);
+          };
           // lanes right of the interior can never pass (thr_x), so the column test costs nothing per trip; the row test is only needed in
           // the last, partial trip of a column block (its rows past the interior are read -- they lie inside this wave's carve-up -- but
           // cannot pass either)
