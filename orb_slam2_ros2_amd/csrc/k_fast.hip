@@ -59,9 +59,8 @@ namespace orbfe {
 #define FAST_OPS16 1
 #endif
 #ifndef FAST_SLIDE
-#define FAST_SLIDE 2  // the necessary test walks down its columns with register rings: 1 = window column 3 (7 LDS reads per pixel), 2 = columns 3 and
-                      // 1 (6 reads; the default), 3 = columns 3, 1, 5 (5 reads, but 64 registers and two spills in k_fast<40, 36>: the deferred
-                      // record of the previous cell goes to scratch and its reload waits for the patch prefetch); 0 = r5's two rows per trip, 9 reads
+#define FAST_SLIDE 3  // the necessary test walks down its columns with register rings: 1 = window column 3 (7 LDS reads per pixel), 2 = columns 3 and
+                      // 1 (6 reads), 3 = columns 3, 1 and 5 (5 reads; the default: 63 registers, no spill); 0 = r5's two rows per trip, 9 reads
 #endif
 #if FAST_OPS16
 __device__ __forceinline__ int fast_min16(int a, int b) {
@@ -293,8 +292,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         const int lx = lane & (lw - 1), ly = lane >> shift;
         for (int x0 = 0; x0 < iw; x0 += lw) {
           const int ix = x0 + lx;
-          const int thr_x = ix < iw ? t_pass : 0x7FFF;
 #if !FAST_SLIDE
+          const int thr_x = ix < iw ? t_pass : 0x7FFF;
           const uint8_t* a0 = P + ly * PP + xa + ix;  // top-left corner of the pixel's 7x7 window
           const uint32_t e_lane = (uint32_t)ix | ((uint32_t)ly << 7);
           const uint8_t* a = a0;
@@ -304,15 +303,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
           // reads recur: column 3 of the window is read at rows t, t + 3, t + 6 (r8, v, r0) and columns 1 / 5 at rows t + 1, t + 5 (r10 /
           // r14, r6 / r2) -- each value fetched ONCE into a 7-slot register ring per column and used again three / four trips later; only
           // columns 0 and 6 (r12, r4) are read once anyway.  With all three rings 5 LDS reads per trip instead of 9 (+ 14 per column block to
-          // fill them); the default (FAST_SLIDE = 2) keeps the rings of columns 3 and 1: 6 reads, 62 registers.  The kernel is co-limited by
-          // the LDS (profiles/r5_fast_lds_counters.txt).  Unrolled by 7 so that the ring slots are register names.  Same-box A/B
-          // (profiles/NOTES_r6.md): the step -0.8 % on the camera-like class (FAST alone 1.67 -> 1.60 ms), unchanged on `rect`.
+          // fill them).  Unrolled by 7 so that the ring slots are register names.  What it buys (profiles/NOTES_r6.md, same-box A/B): LDS
+          // instructions per wave 1151 -> 927, LDS-array cycles 2680 -> 2438, k_fast alone -0.7 % (rect) / -2.2 % (camera-like) -- and the step
+          // within +-0.2 %: the kernel's LDS was not what held the step either.
           {
-            const int H2 = (ih + rpi - 1) >> (6 - shift);   // rows per row group (rpi = 64 >> shift groups)
+            // rows per row group (rpi = 64 >> shift groups).  (With the 30-px grid's patches -- 31 interior rows, pitch 40 -- the two groups sit
+            // 640 bytes apart, i.e. on the same LDS banks, and the scoring trips, which read the survivors of both groups together, take 70 % more
+            // bank-conflict cycles than with r5's row order: 483 against 288 of ~2600 LDS cycles per wave, tools/exp/lds_sq.sh.  One row more in
+            // the first group (17 + 14: 680 bytes apart) does not change that and costs a seventeenth trip per cell: measured slower, dropped.)
+            const int H2 = (ih + rpi - 1) >> (6 - shift);
             const int row0 = mul24u(ly, H2);
             const uint8_t* aw = P + row0 * PP + xa + ix;      // window of the lane's first row
             const uint32_t e_row0 = (uint32_t)ix | ((uint32_t)row0 << 7);
-            const int n_valid = ih - row0;                     // the lane's rows t < n_valid lie inside the interior (may be <= 0)
+            // which lanes hold an interior pixel in trip t -- as SCALAR masks: the columns right of the interior never do (col_mask), the last row
+            // group runs out of rows at t_full = ih - (rpi - 1) H2 (the other groups have all H2), so the verdict masks are cut on the scalar unit
+            // and the threshold stays the wave-uniform t_pass: no per-lane threshold, no vector instruction for the bounds
+            const unsigned long long col_mask = __ballot(ix < iw);
+            const unsigned long long not_last = rpi > 1 ? ((1ull << (64 - lw)) - 1ull) : 0ull;
+            const int t_full = ih - (rpi - 1) * H2;
             int w3[7], w1[7], w5[7];
 #pragma unroll
             for (int k = 0; k < 6; ++k) w3[k] = aw[k * PP + 3];
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #endif
             // (every predicate is ONE vector compare whose lane mask feeds the ballot and the branch directly; the two masks are combined on the
             //  scalar unit and handed back as lane predicates -- see the FAST_SLIDE = 0 form below for the measurements behind that)
-            auto trip_s = [&](const int t, const int k, const int thr) __attribute__((always_inline)) {
+            auto trip_s = [&](const int t, const int k) __attribute__((always_inline)) {
               const uint8_t* a = aw + t * PP;
               w3[(k + 6) % 7] = a[6 * PP + 3];
               const int r12 = a[3 * PP], r4 = a[3 * PP + 6];
@@ -348,22 +356,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
               const int lo_of_hi = FAST_MIN16(FAST_MIN16(FAST_MAX16(r0, r8), FAST_MAX16(r4, r12)), FAST_MIN16(FAST_MAX16(r2, r10), FAST_MAX16(r6, r14)));
               const int hi_of_lo = FAST_MAX16(FAST_MAX16(FAST_MIN16(r0, r8), FAST_MIN16(r4, r12)), FAST_MAX16(FAST_MIN16(r2, r10), FAST_MIN16(r6, r14)));
               const int sb = lo_of_hi - v, sd = v - hi_of_lo;
-              const bool pd = sd > thr;
-              const unsigned long long mb = __ballot(sb > thr), md = __ballot(pd);
+              const unsigned long long valid = t < t_full ? col_mask : (col_mask & not_last);
+              const unsigned long long mb = __ballot(sb > t_pass) & valid, md = __ballot(sd > t_pass) & valid;
               const unsigned long long m = mb | md, m2 = mb & md;
               const bool any = __builtin_amdgcn_inverse_ballot_w64(m), dual = __builtin_amdgcn_inverse_ballot_w64(m2);
+              const bool pd = __builtin_amdgcn_inverse_ballot_w64(md);
               const uint32_t eh = e_row0 + ((uint32_t)t << 7);
               if (any) Q[nq + mbcnt64(m, 0)] = (uint16_t)(eh | (pd ? 0u : Q_BRIGHT) | (dual ? Q_DUAL : 0u));
               nq += __popcll(m);
             };
-            // rows every group has (t < ih - (rpi - 1) H2, wave-uniform): the lane's column test alone; the remaining trips also test the row
-            const int t_full = max(0, ih - (rpi - 1) * H2);
             for (int t0 = 0; t0 < H2; t0 += 7) {
 #pragma unroll
               for (int k = 0; k < 7; ++k) {
                 const int t = t0 + k;
                 if (t >= H2) break;  // wave-uniform
-                trip_s(t, k, (t < t_full || t < n_valid) ? thr_x : 0x7FFF);
+                trip_s(t, k);
               }
             }
           }
