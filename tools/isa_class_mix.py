@@ -7,7 +7,7 @@ census tried -- 32-bit min / max / min3 / max3, v_lshlrev_b32, multiplies and ma
 cndmask, conversions, every packed (v_pk_*) op, and every *_sdwa form whatever its opcode.  An opcode the census did not try counts as slow.
 
 Compiles the kernel sources to ISA here (no GPU needed) and counts the opcodes of each kernel symbol: a STATIC mix (not weighted by
-execution), written to profiles/r5_isa_class_mix.json for bench.py's roofline_valu."""
+execution), written to profiles/<round>_isa_class_mix.json (argument: round tag, default r6) for bench.py's roofline_valu (the newest one is read)."""
 import collections
 import json
 import os
@@ -53,7 +53,7 @@ def main():
         for k, v in mix_of(os.path.join(csrc, f), extra).items():
             if k.startswith("k_"):
                 res["kernels"][k] = v
-    out = os.path.join(ROOT, "profiles", "r5_isa_class_mix.json")
+    out = os.path.join(ROOT, "profiles", (sys.argv[1] if len(sys.argv) > 1 else "r6") + "_isa_class_mix.json")
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     for k, v in sorted(res["kernels"].items()):
         print(f"{k:22s} VALU {v['valu_static']:6d}  fast {v['frac_fast']:.2f}  ({v['instances']} instance(s))")
