@@ -266,6 +266,7 @@ class ORBExtractor {
       } else if (mDrained && resident()) {  // getPyramidLevel / searchByStereo came first and drained the started extraction: its results are in the slot
         check(mCtx, orbfe_fetch_features(mCtx, mLease.slot, keyPoints.data(), descriptors.data()->data(), &n));
       } else {
+        mDrained = false;
         mLease = ContextPool::acquire(mCtx);
         check(mCtx, orbfe_extract_slot(mCtx, mLease.slot, mImage.data, mImage.step, keyPoints.data(), descriptors.data()->data(), &n));
       }
@@ -312,6 +313,7 @@ class ORBExtractor {
     int32_t n[2] = {0, 0}, nm = 0;
     auto pair = ContextPool::acquirePair(mCtx);
     mLease = pair.first, right.mLease = pair.second;
+    mDrained = right.mDrained = false;  // (the slots hold a new extraction: a drained eager start is history)
     check(mCtx, orbfe_frame_stereo_slots(mCtx, mLease.slot, mImage.data, right.mImage.data, mImage.step, fx, bf, k.data(), d.data()->data(), n,
                                          rightU.data(), depths.data(), &nm));
     kpsLeft.assign(k.begin(), k.begin() + n[0]), descLeft.assign(d.begin(), d.begin() + n[0]);
@@ -331,6 +333,7 @@ class ORBExtractor {
     drainStarted();
     undistorted.resize(mnFeats), descriptors.resize(mnFeats), depths.resize(mnFeats), rightU.resize(mnFeats);
     int32_t n = 0;
+    mDrained = false;  // (the slot is about to hold UNDISTORTED keypoints: extract() must not hand those out as the raw ones)
     mLease = ContextPool::acquire(mCtx);
     check(mCtx, orbfe_frame_rgbd_image(mCtx, mLease.slot, mImage.data, mImage.step, 0, &cam, depth, depthType, depthStep, depthScale,
                                        undistorted.data(), descriptors.data()->data(), &n, depths.data(), rightU.data()));
