@@ -598,7 +598,8 @@ static void launch_fast_cells(hipStream_t s, const LevelDev* d_lv, const CellDev
 // patches need.  Measured: merging levels 0..3 into one launch with their common carve-up is 5 % slower than the four separate launches.
 void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, const LevelDev* h_lv, const int* lvl_max_pw,
                  const int* lvl_max_ph, const uint8_t* d_pyr, size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch,
-                 int32_t* d_n_cand, int n_levels, int n_img, int cpw_force) {
+                 int32_t* d_n_cand, int n_levels, int n_img, int cpw_force, uint32_t level_mask, bool merge_masked) {
+  // level_mask: the levels this call launches (bit l; ~0u: all) -- an experiment of r6 puts some levels' launches on a second stream (run_extract)
   // (the launches of the small levels on a second stream beside the large ones, or alternating levels on two streams, were measured in
   //  rounds 2-3 and dropped: profiles/NOTES_r1-r3.md)
   if (n_img <= 0) return;
@@ -615,14 +616,30 @@ void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, co
     max_pw = std::max(max_pw, lvl_max_pw[l]);
     max_ph = std::max(max_ph, lvl_max_ph[l]);
   }
-  if ((long long)total_cells * n_img <= 16384 && max_pw > 6 && max_ph > 6) {
+  if ((long long)total_cells * n_img <= 16384 && max_pw > 6 && max_ph > 6 && level_mask == ~0u) {
     launch_fast_cells(s, d_lv, d_cells, max_pw, max_ph, d_pyr, img_pitch, t_hi, t_lo, d_cand, cand_pitch, d_n_cand, n_levels, 0, total_cells,
                       n_img, cpw_force);
     return;
   }
+  if (merge_masked && level_mask != ~0u) {
+    // (experiment, r6) the masked levels as ONE launch: they must be consecutive in the cell table; the carve-up is their largest patch's
+    int first = -1, last = -1, cells = 0, mpw = 0, mph = 0;
+    bool contiguous = true;
+    for (int l = 0; l < n_levels; ++l) {
+      if (!((level_mask >> l) & 1u) || h_lv[l].n_cells <= 0 || lvl_max_pw[l] <= 6 || lvl_max_ph[l] <= 6) continue;
+      if (first < 0) first = l;
+      if (last >= 0 && l != last + 1) contiguous = false;
+      last = l, cells += h_lv[l].n_cells, mpw = std::max(mpw, lvl_max_pw[l]), mph = std::max(mph, lvl_max_ph[l]);
+    }
+    if (first >= 0 && contiguous && (int)h_lv[last].cell_base + h_lv[last].n_cells - (int)h_lv[first].cell_base == cells) {
+      launch_fast_cells(s, d_lv, d_cells, mpw, mph, d_pyr, img_pitch, t_hi, t_lo, d_cand, cand_pitch, d_n_cand, n_levels, (int)h_lv[first].cell_base, cells,
+                        n_img, cpw_force);
+      return;
+    }
+  }
   for (int l = 0; l < n_levels; ++l) {
     const int n_cells = h_lv[l].n_cells;
-    if (n_cells <= 0 || lvl_max_pw[l] <= 6 || lvl_max_ph[l] <= 6) continue;
+    if (n_cells <= 0 || lvl_max_pw[l] <= 6 || lvl_max_ph[l] <= 6 || !((level_mask >> l) & 1u)) continue;
     launch_fast_cells(s, d_lv, d_cells, lvl_max_pw[l], lvl_max_ph[l], d_pyr, img_pitch, t_hi, t_lo, d_cand, cand_pitch, d_n_cand, n_levels,
                       (int)h_lv[l].cell_base, n_cells, n_img, cpw_force);
   }

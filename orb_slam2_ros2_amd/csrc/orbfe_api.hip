@@ -609,6 +609,9 @@ void orbfe_destroy(orbfe_ctx* c) {
   if (c->ev_blur_go) (void)hipEventDestroy(c->ev_blur_go);
   if (c->ev_blur_done) (void)hipEventDestroy(c->ev_blur_done);
   if (c->blur_stream) (void)hipStreamDestroy(c->blur_stream);
+  if (c->ev_fast_go) (void)hipEventDestroy(c->ev_fast_go);
+  if (c->ev_fast_side_done) (void)hipEventDestroy(c->ev_fast_side_done);
+  if (c->fast_stream) (void)hipStreamDestroy(c->fast_stream);
   if (c->stereo_stream) (void)hipStreamDestroy(c->stereo_stream);
   if (c->ev_brief_done) (void)hipEventDestroy(c->ev_brief_done);
   if (c->ev_stereo_done) (void)hipEventDestroy(c->ev_stereo_done);
@@ -688,12 +691,22 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     }
     if (const char* hl = getenv("ORBFE_LBA_HOST_LM")) c->lm_on_device = atoi(hl) == 0;
     if (const char* fc = getenv("ORBFE_FAST_CPW")) c->fast_cpw = std::max(0, std::min(64, atoi(fc)));
+    if (const char* fm = getenv("ORBFE_FAST_SIDE_MASK")) c->fast_side_mask = (int64_t)(strtoul(fm, nullptr, 0) & 0xFFFFu);
+    if (const char* fg = getenv("ORBFE_FAST_SIDE_MERGE")) c->fast_side_merge = atoi(fg) != 0;
     const char* ov = getenv("ORBFE_OVERLAP_BLUR");
     if (!ov || atoi(ov) != 0) {
       if (hipStreamCreateWithFlags(&c->blur_stream, hipStreamNonBlocking) != hipSuccess ||
           hipEventCreateWithFlags(&c->ev_blur_go, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&c->ev_blur_done, hipEventDisableTiming) != hipSuccess) {
         fail(c, ORBFE_EDEVICE, "cannot create the blur stream");
+        return bail(ORBFE_EDEVICE);
+      }
+      // (the side stream of FAST's small levels: only contexts that can hold a batch ever use it)
+      if (c->fast_side_mask != 0 && cfg->max_images >= 32 &&
+          (hipStreamCreateWithFlags(&c->fast_stream, hipStreamNonBlocking) != hipSuccess ||
+           hipEventCreateWithFlags(&c->ev_fast_go, hipEventDisableTiming) != hipSuccess ||
+           hipEventCreateWithFlags(&c->ev_fast_side_done, hipEventDisableTiming) != hipSuccess)) {
+        fail(c, ORBFE_EDEVICE, "cannot create the FAST side stream");
         return bail(ORBFE_EDEVICE);
       }
     }

@@ -48,7 +48,7 @@ void launch_load_level0(hipStream_t st, const uint8_t* d_src, const uint8_t* d_s
 // k_fast.hip
 void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, const LevelDev* h_lv, const int* lvl_max_pw,
                  const int* lvl_max_ph, const uint8_t* d_pyr, size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch,
-                 int32_t* d_n_cand, int n_levels, int n_img, int cpw_force);
+                 int32_t* d_n_cand, int n_levels, int n_img, int cpw_force, uint32_t level_mask = ~0u, bool merge_masked = false);
 // k_quadtree.hip
 size_t quadtree_lds_bytes(int node_cap, int rec_cap, int sort_cap);
 hipError_t quadtree_configure(size_t lds_bytes);
@@ -212,8 +212,13 @@ struct orbfe_ctx {
   hipStream_t blur_stream = nullptr;
   int fast_cpw = 0;  // ORBFE_FAST_CPW: cells per k_fast wave (0: one for small launches, four for large ones)
   hipEvent_t ev_blur_go = nullptr, ev_blur_done = nullptr;
-  int fast_side_from = 0;  // k_fast launches of levels >= this run on the blur stream beside the large levels (ORBFE_FAST_SIDE_FROM; 0: off -- the default
-                           // since the level-0 blur occupies that stream until well into FAST: the small levels queued behind it, 3 / 5 / 0: 5.75 / 5.72 / 5.71 ms)
+  // r6: the k_fast launches of the SMALL levels (fewer than 131072 cell x images: they run one or four cells per wave and each is little more
+  // than a ramp and a tail) go to fast_stream beside the launches of the large levels.  fast_side_mask: -1 = that rule (default), else the
+  // levels as a bit mask (ORBFE_FAST_SIDE_MASK; 0: everything on the context stream, r5's schedule)
+  int64_t fast_side_mask = -1;
+  bool fast_side_merge = false;  // ORBFE_FAST_SIDE_MERGE=1 (experiment): the side levels as one launch
+  hipStream_t fast_stream = nullptr;
+  hipEvent_t ev_fast_go = nullptr, ev_fast_side_done = nullptr;
 
   // geometry (host copies)
   std::vector<LevelDev> lv;
