@@ -156,10 +156,14 @@ __global__ __launch_bounds__(256) void k_resize_regions(const LevelDev* __restri
                                                         const RgXTap* __restrict__ xtaps, const RgYTap* __restrict__ ytaps,
                                                         uint8_t* __restrict__ pyr, size_t img_pitch, int tile_bytes, int xt_bytes,
                                                         const uint8_t* __restrict__ src_a, const uint8_t* __restrict__ src_b, size_t src_pitch,
-                                                        int sstride, uint32_t src_bytes, int copy_l0, int32_t* __restrict__ d_zero, int n_zero) {
-  // d_zero[0 .. n_zero): cleared by the first block (the candidate counters of the FAST launches that follow this kernel)
-  if (blockIdx.x == 0 && blockIdx.y == 0)
+                                                        int sstride, uint32_t src_bytes, int copy_l0, int32_t* __restrict__ d_zero, int n_zero,
+                                                        int32_t* __restrict__ d_zero2, int n_zero2) {
+  // d_zero[0 .. n_zero), d_zero2[0 .. n_zero2): cleared by the first block -- the candidate counters of the FAST launches that follow this
+  // kernel and (r6) the per-image level counters of the batch quadtree, whose own memset was a 20 us launch on the critical path
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
     for (int i = threadIdx.x; i < n_zero; i += 256) d_zero[i] = 0;
+    for (int i = threadIdx.x; i < n_zero2; i += 256) d_zero2[i] = 0;
+  }
   // level 0 is read from (src_a, src_b, src_pitch, sstride): the pyramid's own level-0 planes (src_b null: image i at src_a + i src_pitch),
   // or -- device batches -- the CALLER's left / right images (image i = eye i & 1 of pair i >> 1), so that the resize does not wait
   // for the copy-in but runs beside it.  src_bytes: size of one source image; a 16-byte unit that would end past it (the last unit
@@ -378,13 +382,13 @@ void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, c
 void launch_resize_regions(hipStream_t s, const LevelDev* d_lv, int n_levels, const RsRegion* d_regions, int n_regions, int tile_bytes,
                            int xt_bytes, int yt_bytes, const RgXTap* d_xtaps, const RgYTap* d_ytaps, uint8_t* d_pyr, size_t img_pitch, int n_img,
                            const uint8_t* src_a, const uint8_t* src_b, size_t src_pitch, int src_stride, uint32_t src_bytes, int copy_l0,
-                           int32_t* d_zero, int n_zero, int pq) {
+                           int32_t* d_zero, int n_zero, int pq, int32_t* d_zero2, int n_zero2) {
   // pq: the regions' common LDS row pitch (16-byte units; orbfe_create makes it uniform) -- a compile-time constant of the kernel for the
   // pitches region widths of 128 .. 256 pixels give, the run-time form (0) otherwise
   if (n_img <= 0 || n_regions <= 0) return;
 #define RS_GO(PQ)                                                                                                                                   \
   hipLaunchKernelGGL(k_resize_regions<PQ>, dim3(n_regions, n_img), dim3(256), (size_t)(tile_bytes + xt_bytes + yt_bytes), s, d_lv, n_levels, d_regions, \
-                     d_xtaps, d_ytaps, d_pyr, img_pitch, tile_bytes, xt_bytes, src_a, src_b, src_pitch, src_stride, src_bytes, copy_l0, d_zero, n_zero)
+                     d_xtaps, d_ytaps, d_pyr, img_pitch, tile_bytes, xt_bytes, src_a, src_b, src_pitch, src_stride, src_bytes, copy_l0, d_zero, n_zero, d_zero2, n_zero2)
   switch (pq) {
     case 9: RS_GO(9); break;
     case 11: RS_GO(11); break;

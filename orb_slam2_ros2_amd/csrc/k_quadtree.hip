@@ -1487,8 +1487,9 @@ void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const ui
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
                      int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree, uint8_t* d_big, size_t big_pitch,
                      const uint16_t* d_qt_tabs, const uint8_t* blur_pyr, uint8_t* blur_out, size_t img_pitch, const int* blur_taps, int blur_tiles,
-                     int32_t* d_qt_next) {
+                     int32_t* d_qt_next, bool next_zeroed) {
   // d_qt_next != nullptr and groups.n_order > 0 (one-wave launches only): the image's waves pull levels from d_qt_next[img], zeroed here
+  // unless the caller has had them zeroed already (next_zeroed: run_extract lets the resize kernel do it)
   // blur_pyr != nullptr (four-wave launches only): the blur of the same images rides in this launch, blur_tiles workgroups per image
   if (n_img <= 0) return;
   const size_t lds = quadtree_lds_bytes(node_cap, rec_cap, sort_cap);
@@ -1503,7 +1504,7 @@ void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const ui
                        d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch, d_qt_tabs, (int32_t*)nullptr, bl);
   else {
     int32_t* next = (groups.n_order > 0 && n_groups > 1) ? d_qt_next : nullptr;
-    if (next) (void)hipMemsetAsync(next, 0, (size_t)n_img * sizeof(int32_t), s);
+    if (next && !next_zeroed) (void)hipMemsetAsync(next, 0, (size_t)n_img * sizeof(int32_t), s);
     hipLaunchKernelGGL(k_quadtree, dim3(n_groups, n_img), dim3(64), lds, s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
                        d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch, d_qt_tabs, next);
   }

@@ -36,7 +36,7 @@ void launch_resize(hipStream_t s, const LevelDev* d_lv, const RsTile* d_tiles, c
                    size_t img_pitch, int n_img);
 void launch_resize_regions(hipStream_t s, const LevelDev* d_lv, int n_levels, const RsRegion* d_regions, int n_regions, int tile_bytes,
                            int xt_bytes, int yt_bytes, const RgXTap* d_xtaps, const RgYTap* d_ytaps, uint8_t* d_pyr, size_t img_pitch, int n_img,
-                           const uint8_t* src_a, const uint8_t* src_b, size_t src_pitch, int src_stride, uint32_t src_bytes, int copy_l0, int32_t* d_zero, int n_zero, int pq);
+                           const uint8_t* src_a, const uint8_t* src_b, size_t src_pitch, int src_stride, uint32_t src_bytes, int copy_l0, int32_t* d_zero, int n_zero, int pq, int32_t* d_zero2 = nullptr, int n_zero2 = 0);
 void launch_blur(hipStream_t s, const LevelDev* d_lv, int n_levels, int tile_first, int n_tiles, const uint8_t* d_pyr, uint8_t* d_blur,
                  size_t img_pitch, const int taps[7], int n_img);
 // k_blur_mfma.hip: the batches' blur on the integer matrix cores (band tables built by mb_build; ok = false: keep k_blur)
@@ -56,7 +56,7 @@ void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const ui
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
                      int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree, uint8_t* d_big, size_t big_pitch,
                      const uint16_t* d_qt_tabs, const uint8_t* blur_pyr, uint8_t* blur_out, size_t img_pitch, const int* blur_taps, int blur_tiles,
-                     int32_t* d_qt_next);
+                     int32_t* d_qt_next, bool next_zeroed = false);
 bool quadtree_build_tables(const LevelDev& L, std::vector<uint16_t>& out);
 // k_brief.hip
 void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,

@@ -50,7 +50,7 @@ orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, hipE
       launch_resize_regions(st, c->d_lv, nl, c->d_rs_regions, (int)c->rs_regions.size(), c->rg_tile_bytes, c->rg_xt_bytes, c->rg_yt_bytes,
                             c->d_rg_xtaps, c->d_rg_ytaps, pyr, c->img_pitch, n_img, ext ? ext->left : pyr + c->lv[0].plane_off,
                             ext ? ext->right : nullptr, ext ? ext->pitch : c->img_pitch, ext ? ext->stride : c->lv[0].stride,
-                            ext ? ext->bytes : 0xFFFFFFFFu, ext ? 1 : 0, n_cand, n_img * nl, c->rg_pq);
+                            ext ? ext->bytes : 0xFFFFFFFFu, ext ? 1 : 0, n_cand, n_img * nl, c->rg_pq, c->d_qt_next + i0, n_img);
     else
       launch_resize(st, c->d_lv, c->d_rs_tiles, c->rs_n, c->rs_bytes, c->d_taps, pyr, c->img_pitch, n_img);
   }
@@ -162,7 +162,7 @@ orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, hipE
                     c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img, 1, qt_tab, n_groups,
                     // helper waves for the data-parallel phases of a tree where the launch leaves the chip empty (a frame or two)
                     (!grouped && trees * 4 <= c->n_cu * 4) ? 4 : 1, c->d_qt_big ? c->d_qt_big + i0 * c->qt_big_pitch : nullptr,
-                    c->qt_big_pitch, c->d_qt_tabs, blur_in_qt ? pyr : nullptr, blur, c->img_pitch, c->blur_taps, c->bl_tiles, c->d_qt_next + i0);
+                    c->qt_big_pitch, c->d_qt_tabs, blur_in_qt ? pyr : nullptr, blur, c->img_pitch, c->blur_taps, c->bl_tiles, c->d_qt_next + i0, zeroed_by_resize);
   }
   {
     StageTimer t(c, ORBFE_STAGE_BRIEF, st, timing);
