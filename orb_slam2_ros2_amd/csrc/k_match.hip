@@ -24,6 +24,9 @@
 #ifndef STEREO_SAD_GRID
 #define STEREO_SAD_GRID 32  // workgroups per pair of k_stereo_sad (each loops over the work list): 512 entries per sweep
 #endif
+#ifndef STEREO_SAD_WAVES
+#define STEREO_SAD_WAVES 4  // waves per workgroup of k_stereo_sad (the waves never meet after the level table; the launch keeps 4 x STEREO_SAD_GRID waves per pair)
+#endif
 #define STEREO_ROWS 1   // the batch matcher: 1 = row-parallel (k_stereo_rows + k_stereo_sad), 0 = a wave per left keypoint everywhere (k_stereo)
 #endif
 
@@ -492,18 +495,18 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const KpX* __restrict__ kx,
 // pixelSADMatch (ORBMatcher.cc:841-881) + the sub-pixel / disparity bookkeeping of searchByStereo (:59-78) for the entries of the pair's work
 // list: FOUR entries per wave, one per row of 16 lanes -- the two patches staged in LDS, a keypoint's 11 SADs as 11 lanes with a whole
 // patch each (k_stereo4's second half; the entry carries the patch centres and octaves, so the windows are the first thing requested).
-__global__ __launch_bounds__(256) void k_stereo_sad(const LevelDev* __restrict__ lv, int n_levels, const uint8_t* __restrict__ pyr, size_t img_pitch,
+__global__ __launch_bounds__(64 * STEREO_SAD_WAVES) void k_stereo_sad(const LevelDev* __restrict__ lv, int n_levels, const uint8_t* __restrict__ pyr, size_t img_pitch,
                                                     const KpX* __restrict__ kx, int n_features, float bf, int cols0, StereoRows sr,
                                                     int32_t* __restrict__ n_match, int slot_l0, int slot_r0, int slot_step, int pair0) {
 #pragma clang fp contract(off)
   // per wave, per entry: left 11 rows x 4 words | right 11 rows x 7 words | the left patch again as 16-bit values (pl - c1 + 255), 11 rows of 8 words
-  __shared__ __attribute__((aligned(16))) uint32_t s_sad[4][4][ST5_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_sad[STEREO_SAD_WAVES][4][ST5_WORDS];
   __shared__ float s_sf[16];
   __shared__ uint32_t s_off[16];
   __shared__ int s_stride[16];
   const int pair = pair0 + blockIdx.y;
   const int n_work = sr.work_n[pair];
-  if ((int)blockIdx.x * 16 >= n_work) return;  // (uniform for the block)
+  if ((int)blockIdx.x * (4 * STEREO_SAD_WAVES) >= n_work) return;  // (uniform for the block)
   // A workgroup takes sixteen entries and then the sixteen gridDim.x workgroups further on: the launch is sized for a fraction of the
   // worst case (every feature matched) -- sized for all of it, three quarters of its workgroups found nothing to do, each holding 14 KB
   // of LDS and four wave slots for the round trip of the counter above, beside the next batch's FAST, whose throughput follows the
@@ -516,8 +519,8 @@ __global__ __launch_bounds__(256) void k_stereo_sad(const LevelDev* __restrict__
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, grp = lane >> 4, sub = lane & 15;
   const int sl = slot_l0 + blockIdx.y * slot_step, srt = slot_r0 + blockIdx.y * slot_step;
   __syncthreads();  // (the level table; every wave of the block passes here)
-  for (int bx = blockIdx.x; bx * 16 < n_work; bx += gridDim.x) {  // (uniform for the block)
-  const int wi = (bx * 4 + wv) * 4 + grp;
+  for (int bx = blockIdx.x; bx * (4 * STEREO_SAD_WAVES) < n_work; bx += gridDim.x) {  // (uniform for the block)
+  const int wi = (bx * STEREO_SAD_WAVES + wv) * 4 + grp;
   const bool go = wi < n_work;
   const uint4 e = sr.work[(size_t)pair * n_features + (go ? wi : 0)];
   const uint32_t li = e.x & 0xFFFFu;
@@ -679,7 +682,7 @@ void launch_stereo(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint
   if (by_rows) {
     hipLaunchKernelGGL(k_stereo_rows, dim3((rows + 3) / 4, n_pairs), dim3(256), 0, s, d_kx, d_desc, d_rowoff, d_rowlist, rows, list_cap, n_features, fx,
                        mean_threshold, sr, slot_l0, slot_r0, slot_step, pair0);
-    hipLaunchKernelGGL(k_stereo_sad, dim3(std::min((n_features + 15) / 16, STEREO_SAD_GRID), n_pairs), dim3(256), 0, s, d_lv, n_levels, d_pyr, img_pitch, d_kx, n_features, bf, cols0,
+    hipLaunchKernelGGL(k_stereo_sad, dim3(std::min((n_features + 4 * STEREO_SAD_WAVES - 1) / (4 * STEREO_SAD_WAVES), STEREO_SAD_GRID * 4 / STEREO_SAD_WAVES), n_pairs), dim3(64 * STEREO_SAD_WAVES), 0, s, d_lv, n_levels, d_pyr, img_pitch, d_kx, n_features, bf, cols0,
                        sr, d_n_match, slot_l0, slot_r0, slot_step, pair0);
     return;
   }
