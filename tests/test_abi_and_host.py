@@ -39,6 +39,18 @@ def test_no_cpu_fallback_create_fails_loudly_without_device():
         ORBExtractor(np.zeros((376, 1241), np.uint8), 2000, 8, 1.2)
 
 
+def test_create_refuses_what_its_records_cannot_hold():
+    """The argument check of orbfe_create runs before the device is looked for, so it is testable here: candidate records carry x and y in
+    12 bits and the matcher's KpX record the patch centre in 14 (r6: the bound is explicit), the level table holds ORBFE_MAX_LEVELS = 16."""
+    from orb_slam2_ros2_amd._lib import Context, OrbfeError
+    for kw in (dict(width=4097, height=376), dict(width=1241, height=4097), dict(width=0, height=376), dict(width=1241, height=376, n_levels=17),
+               dict(width=1241, height=376, n_levels=0), dict(width=1241, height=376, scale_factor=1.0), dict(width=1241, height=376, n_features=70000)):
+        w, h = kw.pop("width"), kw.pop("height")
+        with pytest.raises(OrbfeError) as ei:
+            Context(w, h, **kw)
+        assert ei.value.status == 1 and "bad config" in str(ei.value), kw     # ORBFE_EBADARG, not ORBFE_EDEVICE
+
+
 def test_product_never_touches_the_oracle():
     pkg = os.path.join(ROOT, "orb_slam2_ros2_amd")
     for dp, _, fns in os.walk(pkg):

@@ -96,6 +96,26 @@ def test_other_geometries_and_thresholds(orc, lib, w, h, nf, nl, sc, hi, lo):
     ctx.close()
 
 
+def test_widest_image_the_records_can_hold(orc, lib):
+    """4096 columns: the largest x a candidate record (12 bits) and the matcher's packed patch centre can carry -- one frame and one stereo
+    match against the oracle, with keypoints in the last columns the border allows"""
+    w, h = 4096, 400
+    L, R = synth.stereo_pair(21, w, h, n_rect=500)
+    ctx = lib.Context(w, h, n_features=1500, n_levels=4, max_images=2)
+    (lk, ld), (rk, rd) = ctx.extract_batch([L, R])
+    ex = orc.extractor(L, n_features=1500, n_levels=4)
+    assert_image_parity(ctx, 0, ex, lk, ld, 4)
+    assert lk["x"].max() > 4000
+    nm, ru, dp, _, _ = ctx.stereo_match(0, 1, 2000.0, 800.0)
+    ref = orc.stereo_frame(L, R, n_features=1500, n_levels=4, fx=2000.0, bf=800.0)
+    n = len(lk)
+    assert nm == ref["n_matches"] and nm > 0 and np.array_equal(ru[:n].view(np.int64), ref["right_u"].view(np.int64))
+    assert np.array_equal(dp[:n].view(np.int64), ref["depth"].view(np.int64))
+    ctx.close()
+    with pytest.raises(lib.OrbfeError):
+        lib.Context(4097, 400)
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_fuzzed_geometries(orc, lib, seed):
     """random image sizes / feature counts / pyramid shapes / thresholds: every LDS layout, tile edge and quota path"""
