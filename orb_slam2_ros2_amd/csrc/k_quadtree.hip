@@ -339,8 +339,8 @@ __device__ __forceinline__ void qt_wsync() {
 // node arrays) is off and the strips are counted with ballots.  Slow (a pop is a chain of global round trips) but exact.
 #ifdef QT_STAMPS  // diagnostic build only: timeline of one level-0 tree (device printf), see tools/exp/qt_stamps.sh
 __device__ int g_qt_stamp_count;
-#define QTS_DECL long long qts_t0 = __builtin_amdgcn_s_memtime(), qts_last = qts_t0; int qts_n = 0; long long qts_d[48]; int qts_i[48]; int qts_single = 0, qts_single_n = 0, qts_fail = 0;
-#define QTS(info) { const long long now_ = __builtin_amdgcn_s_memtime(); if (qts_n < 48) { qts_d[qts_n] = now_ - qts_last; qts_i[qts_n] = (info); ++qts_n; } qts_last = now_; }
+#define QTS_DECL long long qts_t0 = __builtin_amdgcn_s_memtime(), qts_last = qts_t0; int qts_n = 0; long long qts_d[96]; int qts_i[96]; int qts_single = 0, qts_single_n = 0, qts_fail = 0;
+#define QTS(info) { const long long now_ = __builtin_amdgcn_s_memtime(); if (qts_n < 96) { qts_d[qts_n] = now_ - qts_last; qts_i[qts_n] = (info); ++qts_n; } qts_last = now_; }
 #define QTS_PRINT                                                                                                                   \
   if (w0 && lane == 0 && need > 400) {                                                                                              \
     const int c_ = atomicAdd(&g_qt_stamp_count, 1);                                                                                 \
@@ -657,6 +657,58 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
   // written as straight-line predicated code: fixed 8-way unrolled arg-max, uniform-address LDS traffic executed by
   // all lanes instead of "if (lane == 0)" blocks, the four children written by lanes 0..3 at once.
   QTS(-1)  // build (pre-partition) done
+  // ---- NW > 1: the ORDINARY members of a batched step split by the whole workgroup (r6) ----------------------------------------------
+  // The expansion lives on wave 0, one node per lane -- and an ordinary member (a node below the pre-partition's four levels) was split by
+  // its lane alone, record after record, twice (count, then scatter): a step of 19 such nodes of up to 31 records was 17 k of a level-0
+  // tree's 106 k cycles with nineteen lanes of one wave at work and seven waves asleep at the barrier behind the loop.  Now wave 0 posts
+  // the members (segment, size, prefix of the sizes, integer split) in the idle sort area and every thread of the workgroup takes a
+  // record or two: member by binary search over the prefix, quadrant, an LDS atomic on the member's quadrant counter (its return value is
+  // the record's place inside the quadrant); wave 0 reads the counts, decides how many of the pops are valid exactly as before, posts the
+  // quadrants' offsets, and the threads store their records.  Four workgroup barriers per step, executed by every wave in the same order:
+  // the helper waves loop on coop_count / coop_scatter until wave 0 posts the empty job (the barrier that used to end the expansion).
+  uint32_t* const coop = (uint32_t*)sortbuf;  // [64][4] beg | n << 22, prefix, x_lt | x_gt << 16, y_lt | y_gt << 16; [64][4] counters, then offsets
+  constexpr int KR = (64 * 64 + NT - 1) / NT;   // records per thread: a head of 64 members of up to 64 records always fits
+  uint32_t crec[KR], cslot[KR];
+  int cmem[KR], cquad[KR];
+  auto coop_count = [&]() __attribute__((always_inline)) -> bool {
+    __syncthreads();  // (1) the job is posted
+    const int R = (int)shared_ints[1];
+    if (R == 0) return false;
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const int g = tid + k * NT;
+      cmem[k] = -1, cquad[k] = 0, crec[k] = 0u, cslot[k] = 0u;
+      if (g < R) {
+        int lo = 0;  // the last member whose prefix is <= g (members without records share their successor's prefix and come before it)
+#pragma unroll
+        for (int step = 32; step; step >>= 1)
+          if ((int)coop[(lo + step) * 4 + 1] <= g) lo += step;
+        const uint32_t d0 = coop[lo * 4], d1 = coop[lo * 4 + 1], d2 = coop[lo * 4 + 2], d3 = coop[lo * 4 + 3];
+        const uint32_t rec = H[(int)(d0 & QT_BEG_MASK) + (g - (int)d1)];
+        SplitInt s;
+        s.x_lt = (int)(int16_t)(d2 & 0xFFFFu), s.x_gt = (int)(d2 >> 16), s.y_lt = (int)(int16_t)(d3 & 0xFFFFu), s.y_gt = (int)(d3 >> 16);
+        const int q = quadrant_of(rec, s);
+        crec[k] = rec, cquad[k] = q;
+        if (q >= 0) {
+          cmem[k] = lo;
+          cslot[k] = atomicAdd(&coop[256 + lo * 4 + q], 1u);
+        }
+      }
+    }
+    __syncthreads();  // (2) the counts are complete
+    return true;
+  };
+  auto coop_scatter = [&]() __attribute__((always_inline)) {
+    __syncthreads();  // (3) offsets and the number of valid pops are posted
+    const int vv = (int)shared_ints[2];
+#pragma unroll
+    for (int k = 0; k < KR; ++k)
+      if (cmem[k] >= 0 && cmem[k] < vv) H[coop[256 + cmem[k] * 4 + cquad[k]] + cslot[k]] = crec[k];  // (every record was read before barrier 2)
+    __syncthreads();  // (4)
+  };
+  if (NW > 1 && !w0) {
+    while (coop_count()) coop_scatter();
+  }
   const long long max_iter = 80ll * (long long)N + 1024;  // each point survives < ~64 halvings (fp64); hard stop for safety
   long long iter = 0;
   while (n_act < need && n_act > 0 && iter < max_iter) {
@@ -786,7 +838,24 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         }
         // the ordinary members: all records of a node into the registers of its lane (one round trip for the whole head)
         const bool ld = lane < b_eff && !is_pp;
-        const int nmax = (int)wave_max_u32(ld ? (uint32_t)n : 0u);
+        const int nmax_all = (int)wave_max_u32(ld ? (uint32_t)n : 0u);
+        // (cooperative from eight records in the largest member: below that the lane-serial form is over before four barriers are)
+        const int r_tot = NW > 1 ? (int)wave_sum_u32(ld ? (uint32_t)n : 0u) : 0;
+        const bool coop_go = NW > 1 && IN_LDS && nmax_all >= 8 && r_tot <= KR * NT;  // (wave-uniform)
+        if (NW > 1 && coop_go) {
+          const int nn = ld ? n : 0;
+          const int pm = wave_incl_scan(nn, lane) - nn;
+          *(uint4*)(coop + lane * 4) = make_uint4((uint32_t)beg | ((uint32_t)nn << 22), (uint32_t)pm, ((uint32_t)sp.x_lt & 0xFFFFu) | ((uint32_t)sp.x_gt << 16),
+                                                  ((uint32_t)sp.y_lt & 0xFFFFu) | ((uint32_t)sp.y_gt << 16));
+          *(uint4*)(coop + 256 + lane * 4) = make_uint4(0u, 0u, 0u, 0u);
+          if (lane == 0) shared_ints[1] = (uint32_t)r_tot;
+          (void)coop_count();
+          if (ld) {
+            const uint4 cc = *(const uint4*)(coop + 256 + lane * 4);
+            c0 = (int)cc.x, c1 = (int)cc.y, c2 = (int)cc.z, c3 = (int)cc.w;
+          }
+        }
+        const int nmax = coop_go ? 0 : nmax_all;  // (the register form below: skipped)
         uint32_t* seg = H + beg;
         uint32_t rec[BR];
 #pragma unroll
@@ -803,7 +872,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
           }
         }
         QTS(-32)  // records requested
-        if (ld) {
+        if (ld && !coop_go) {
           int k0 = 0, k1 = 0, k2 = 0, k3 = 0;
 #pragma unroll
           for (int c8 = 0; c8 < BR / 8; ++c8) {
@@ -831,6 +900,11 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         if (bad) v = min(v, __ffsll((long long)bad) - 1);
         if (stop) v = min(v, __ffsll((long long)stop));
         QTS(-34)  // prefix of valid pops
+        if (NW > 1 && coop_go) {  // the quadrants' places, the number of valid pops; every thread stores its records (members past v keep theirs)
+          if (ld) *(uint4*)(coop + 256 + lane * 4) = make_uint4((uint32_t)beg, (uint32_t)(beg + c0), (uint32_t)(beg + c0 + c1), (uint32_t)(beg + c0 + c1 + c2));
+          if (lane == 0) shared_ints[2] = (uint32_t)v;
+          coop_scatter();
+        }
         if (v > 0) {
           const bool cm = lane < v;
           const int ex = incl - d;  // table growth of the earlier pops = (children of the earlier pops) - (earlier pops)
@@ -848,7 +922,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
                 n_bp[slot] = make_uint2((uint32_t)offc | ((uint32_t)(child_code ? child_code + q : 0) << QT_CODE_SHIFT), QT_PATH_CHILD(path, q));
               }
             }
-            if (!is_pp) {  // in-place 4-way partition straight from the registers (the node's segment belongs to this lane alone)
+            if (!is_pp && !coop_go) {  // in-place 4-way partition straight from the registers (the node's segment belongs to this lane alone)
               int p0 = 0, p1 = c0, p2 = c0 + c1, p3 = c0 + c1 + c2;
 #pragma unroll
               for (int c8 = 0; c8 < BR / 8; ++c8) {
@@ -1041,7 +1115,12 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     }
     if (!IN_LDS) qt_wsync<NW>();  // LDS traffic of one wave is executed in order; global needs the wait
   }
-  __syncthreads();
+  if (NW == 1) {
+    __syncthreads();
+  } else if (w0) {  // the empty job: the helper waves leave their loop at this barrier (their coop_count's first)
+    if (lane == 0) shared_ints[1] = 0u;
+    __syncthreads();
+  }
 
   QTS(-2)  // expansion done (single pops included in the last interval)
   // ---- nodes2kpoints (ORBExtractor.cc:182-192): keep the first min(need, size) nodes in map order ----
@@ -1186,21 +1265,76 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       // keypoints go straight to their output slots.  (Wave 0 alone sorting the keys in registers, 36 cross-lane exchange stages
       // of eight keys, was a quarter of the 98 us of a level-0 tree: stamps build, tools/exp/qt_stamps.sh.)
       __syncthreads();
-      uint32_t mine[(512 + NT - 1) / NT];
-      uint32_t k32[(512 + NT - 1) / NT];
+      constexpr int KPT = (512 + NT - 1) / NT;
+      uint32_t mine[KPT];
+      uint32_t k32[KPT];
       uint32_t* sort32 = (uint32_t*)sortbuf;  // the ranking compares 32-bit order keys (order_key32)
+      // r6: the ranks by BUCKETS of cells instead of by counting all smaller keys (every thread against every key: with eight waves that
+      // was 8.6 k of a level-0 tree's 112 k cycles, two waves per SIMD issuing ~1000 vector instructions each).  The order key is
+      // cell << 14 | position inside the cell, so a key's rank = the keys in the buckets of earlier cells (a histogram and its prefix) +
+      // the smaller keys of its own bucket (one to three on the bench frames).  Histogram and prefix borrow the node table, which is dead
+      // once every node's winner is known; a table too small for them (a context of a few dozen features) keeps the counting form.
+      constexpr int NBK = NT > 512 ? NT : 512, BPT = NBK / NT;
+      const bool by_bucket = NODES_LDS && (size_t)node_cap * 16 >= (size_t)(2 * NBK + NW) * sizeof(uint32_t);  // (uniform)
 #pragma unroll
-      for (int u = 0; u < (512 + NT - 1) / NT; ++u) {
+      for (int u = 0; u < KPT; ++u) {
         const int j = tid + u * NT;
         k32[u] = 0xFFFFFFFFu, mine[u] = 0u;
         if (u * NT < sort_cap) node_win(j, k32[u], mine[u]);  // (uniform per wave: every lane of a wave shares u; lanes past n_act get padding)
-        if (j < max(sort_cap, 16)) sort32[j] = k32[u];
+        if (!by_bucket && j < max(sort_cap, 16)) sort32[j] = k32[u];
       }
       __syncthreads();
       QTS(-21)  // node keys
-      int rank[(512 + NT - 1) / NT];
+      if (by_bucket) {
+        uint32_t* hist = (uint32_t*)n_key;  // [NBK] keys per bucket | [NBK] exclusive prefix | [NW] wave totals
+        uint32_t* pref = hist + NBK;
+        uint32_t* wsum = pref + NBK;
+        const int cells = L.n_cols * L.n_rows;
+        int bsh = 0;
+        while (((cells - 1) >> bsh) >= NBK) ++bsh;
+        for (int b = tid; b < NBK; b += NT) hist[b] = 0u;
+        __syncthreads();
+        uint32_t slot[KPT];
+        int bk[KPT];
 #pragma unroll
-      for (int u = 0; u < (512 + NT - 1) / NT; ++u) rank[u] = 0;
+        for (int u = 0; u < KPT; ++u) {
+          bk[u] = 0, slot[u] = 0u;
+          if (tid + u * NT < n_act) {
+            bk[u] = (int)((k32[u] >> 14) >> bsh);
+            slot[u] = atomicAdd(&hist[bk[u]], 1u);  // arrival order inside the bucket: arbitrary, only used to park the key
+          }
+        }
+        __syncthreads();
+        uint32_t loc[BPT], tsum = 0u;  // thread t owns buckets [t BPT, (t + 1) BPT)
+#pragma unroll
+        for (int q = 0; q < BPT; ++q) loc[q] = hist[tid * BPT + q], tsum += loc[q];
+        const uint32_t incl = (uint32_t)wave_incl_scan((int)tsum, lane);
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t base = incl - tsum;
+        for (int w = 0; w < NW; ++w) base += w < wv ? wsum[w] : 0u;  // (wave-uniform reads)
+#pragma unroll
+        for (int q = 0; q < BPT; ++q) {
+          pref[tid * BPT + q] = base;
+          base += loc[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < KPT; ++u)
+          if (tid + u * NT < n_act) sort32[pref[bk[u]] + slot[u]] = k32[u];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < KPT; ++u)
+          if (tid + u * NT < n_act) {
+            const uint32_t b0 = pref[bk[u]], c = hist[bk[u]];
+            uint32_t r = b0;
+            for (uint32_t i = 0; i < c; ++i) r += sort32[b0 + i] < k32[u] ? 1u : 0u;  // (distinct keys: the ranks are a permutation)
+            out_sel[r] = mine[u];
+          }
+      } else {
+      int rank[KPT];
+#pragma unroll
+      for (int u = 0; u < KPT; ++u) rank[u] = 0;
       // (sixteen keys per trip, all requested before the first is compared: with four the loop ran at the LDS latency, 385 cycles a trip.
       //  The slots past n_act hold ~0: they never count.)
       for (int i = 0; i < sort_cap; i += 16) {
@@ -1214,12 +1348,13 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
 #pragma unroll
         for (int q = 0; q < 16; ++q)
 #pragma unroll
-          for (int u = 0; u < (512 + NT - 1) / NT; ++u) rank[u] += (o[q] < k32[u]) ? 1 : 0;
+          for (int u = 0; u < KPT; ++u) rank[u] += (o[q] < k32[u]) ? 1 : 0;
       }
 #pragma unroll
-      for (int u = 0; u < (512 + NT - 1) / NT; ++u) {
+      for (int u = 0; u < KPT; ++u) {
         const int j = tid + u * NT;
         if (j < n_act) out_sel[rank[u]] = mine[u];
+      }
       }
       QTS(-4)
       QTS_PRINT
@@ -1424,15 +1559,19 @@ struct QtBlur {
   BlurTaps taps;
   int n_groups;
 };
-__global__ __launch_bounds__(256) void k_quadtree_w4(QT_KERNEL_ARGS, QtBlur bl) {
+#ifndef QT_SMALL_WAVES
+#define QT_SMALL_WAVES 8  // (a power of two: 4 -> 8 takes a pair's trees from 60 to 50 us, 16 -> 69; tools/exp/qt_waves.sh)
+#endif
+__global__ __launch_bounds__(64 * QT_SMALL_WAVES) void k_quadtree_w4(QT_KERNEL_ARGS, QtBlur bl) {
   if (bl.pyr && (int)blockIdx.x >= bl.n_groups) {
+    if (QT_SMALL_WAVES > 4 && threadIdx.x >= 256) return;  // (a blur tile is 256 threads' work and has no workgroup barrier)
     if (blur_taps_saturate(bl.taps.t))  // (uniform)
       blur_tile<true>(lv, n_levels, bl.pyr, bl.blur, bl.img_pitch, bl.taps, (int)blockIdx.x - bl.n_groups, (int)blockIdx.y, (int)threadIdx.x);
     else
       blur_tile<false>(lv, n_levels, bl.pyr, bl.blur, bl.img_pitch, bl.taps, (int)blockIdx.x - bl.n_groups, (int)blockIdx.y, (int)threadIdx.x);
     return;
   }
-  quadtree_levels<4>(QT_KERNEL_PASS);
+  quadtree_levels<QT_SMALL_WAVES>(QT_KERNEL_PASS);
 }
 
 // The pre-partition's coordinate -> code tables of one level (tree_body): x table [tab_w2] then y table [tab_h], uint16 codes as
@@ -1500,7 +1639,7 @@ void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const ui
     for (int i = 0; i < 7; ++i) bl.taps.t[i] = blur_taps[i];
   }
   if (waves_per_tree >= 4)
-    hipLaunchKernelGGL(k_quadtree_w4, dim3(n_groups + (bl.pyr ? blur_tiles : 0), n_img), dim3(256), lds + 2048 + 16 + QT_PP_MAX_STRIPS * QT_PP_TOTALS4 * sizeof(uint16_t), s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
+    hipLaunchKernelGGL(k_quadtree_w4, dim3(n_groups + (bl.pyr ? blur_tiles : 0), n_img), dim3(64 * QT_SMALL_WAVES), lds + 2048 + 16 + QT_PP_MAX_STRIPS * QT_PP_TOTALS4 * sizeof(uint16_t), s, d_lv, n_levels, d_cand, d_scr_b, d_scr_c, scratch_pitch, d_sel,
                        d_sel_count, n_features, d_n_cand, node_cap, sort_cap, rec_cap, batch, groups, d_big, big_pitch, d_qt_tabs, (int32_t*)nullptr, bl);
   else {
     int32_t* next = (groups.n_order > 0 && n_groups > 1) ? d_qt_next : nullptr;
