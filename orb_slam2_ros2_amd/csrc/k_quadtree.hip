@@ -397,6 +397,36 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     auto cur_w = [&](int g) -> int { return g < QT_PP_HALF ? g : g - QT_PP_HALF; };
     auto cur_sh = [&](int g) -> int { return g < QT_PP_HALF ? 0 : 16; };
     auto cur_get = [&](int g) -> uint32_t { return (cur[cur_w(g)] >> cur_sh(g)) & 0xFFFFu; };
+    // PU records per lane per trip: sixteen with helper waves (a frame or two: registers are free), eight in the one-wave batch kernel,
+    // which is compiled for four waves per SIMD (128 VGPRs).  With helper waves a trip takes only as many records per lane as it takes
+    // to cover the level ONCE with all waves (pu_eff, in uniform groups of four slots): 5087 candidates on eight waves are ten records a
+    // lane on every wave -- with whole trips of sixteen, five waves took one trip each and three had nothing to do.
+    constexpr int PU = NW == 1 ? 8 : 16;
+    const int pu_eff = NW == 1 ? PU : min(PU, max(1, (N + NT - 1) / NT));
+    const int pch = 64 * pu_eff;
+#define QT_SLOT_ON(u) (NW == 1 || ((u) & ~3) < pu_eff)  // (wave-uniform: a group of four slots is worked on or skipped as a whole)
+    // which record slot u of a lane holds: slot-major (a wave instruction's 64 records are consecutive: coalesced loads).  The experiment:
+    // LANE-major with helper waves -- the candidates arrive cell by cell (k_fast appends a cell's corners together), so 64 consecutive records
+    // fall into four to six groups of the pre-partition and the 64 lanes' LDS atomics on the group counters serialise a dozen deep; ten records
+    // apart the lanes of an instruction span some thirty cells.  (The order of the records inside a group is irrelevant.)
+#ifndef QT_LANE_MAJOR
+#define QT_LANE_MAJOR 0  // (measured with eight waves: pass 2 5.97 -> 5.1 k cycles, pass 1 8.8 -> 10.2 k -- its strided loads; left off)
+#endif
+#define QT_REC_AT(b0, u) ((NW > 1 && QT_LANE_MAJOR) ? (b0) + lane * pu_eff + (u) : (b0) + (u) * 64 + lane)
+    // pass 1: group sizes.  The next trip's records are requested before this trip's are classified: a lone wave sees every global round
+    // trip, so the loads of trip k+1 fly under the work of trip k.
+    auto load16 = [&](int b0, uint32_t* r) {
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        const int i = QT_REC_AT(b0, u);
+        r[u] = QT_SLOT_ON(u) ? A[max(min(i, N - 1), 0)] : 0u;  // (clamped: unconditional loads, validity is checked when the record is used)
+      }
+    };
+    auto slot_off = [&](int b0, int u) -> bool { return u >= pu_eff || QT_REC_AT(b0, u) >= N; };  // not a record of this trip
+    // (r6) the first trip's records are requested HERE, before the tables are copied: a tree's first global round trip -- the candidates
+    // k_fast has just written -- flies under the copy and its barrier instead of opening pass 1
+    uint32_t nxt0[PU];
+    if (NW > 1) load16(wv * pch, nxt0);  // (the one-wave batch kernel keeps its request in pass 1: eight more live registers across the copy buy it nothing)
     for (int g = tid; g < cur_words; g += NT) cur[g] = 0;
     // The coordinate -> code tables depend on the LEVEL's geometry alone (strip bounds, region height): the host builds them once per
     // context (quadtree_build_tables, the same fp64 operations) and a tree only copies its level's ~3 KB into LDS.  Built here, per tree,
@@ -421,27 +451,15 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
       uint32_t cx[16], cy[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u)
-        if (u < n) {  // (candidates lie inside the region; the clamp only guards the table)
+        if (u < n && QT_SLOT_ON(u)) {  // (candidates lie inside the region; the clamp only guards the table)
           cx[u] = xtab[min(ORBFE_REC_X(r[u]), (uint32_t)tab_w - 1u)];
           cy[u] = ytab[min(ORBFE_REC_Y(r[u]), (uint32_t)tab_h - 1u)];
         }
 #pragma unroll
       for (int u = 0; u < 16; ++u)
-        if (u < n) g[u] = pp_group_codes(cx[u], cy[u]);
+        if (u < n) g[u] = QT_SLOT_ON(u) ? pp_group_codes(cx[u], cy[u]) : -1;
     };
-    // pass 1: group sizes.  Sixteen records per lane per trip, and the next trip's records are requested before this trip's are
-    // classified: a lone wave sees every global round trip, so the loads of trip k+1 fly under the work of trip k.
-    // PU records per lane per trip: sixteen with helper waves (a frame or two: registers are free), eight in the one-wave batch kernel,
-    // which is compiled for four waves per SIMD (128 VGPRs)
-    constexpr int PU = NW == 1 ? 8 : 16, PCH = 64 * PU;
-    auto load16 = [&](int b0, uint32_t* r) {
-#pragma unroll
-      for (int u = 0; u < PU; ++u) {
-        const int i = b0 + u * 64 + lane;
-        r[u] = A[max(min(i, N - 1), 0)];  // (clamped: unconditional loads, validity is checked when the record is used)
-      }
-    };
-    // (the records of the FIRST trip and their groups stay in registers for the scatter pass: up to PCH records per wave need no
+    // (the records of the FIRST trip and their groups stay in registers for the scatter pass: up to a trip's records per wave need no
     //  second load -- an exposed global round trip -- and no second classification)
     uint32_t rec0[PU];
     int g0[PU];
@@ -449,26 +467,46 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     for (int u = 0; u < PU; ++u) rec0[u] = 0u, g0[u] = -1;
     {
       uint32_t nxt[PU];
-      load16(wv * PCH, nxt);
-      for (int b0 = wv * PCH; b0 < N; b0 += NW * PCH) {
+      if (NW > 1) {
+#pragma unroll
+        for (int u = 0; u < PU; ++u) nxt[u] = nxt0[u];
+      } else {
+        load16(wv * pch, nxt);
+      }
+      for (int b0 = wv * pch; b0 < N; b0 += NW * pch) {
         uint32_t rec[PU];
 #pragma unroll
         for (int u = 0; u < PU; ++u) rec[u] = nxt[u];
-        if (b0 + NW * PCH < N) load16(b0 + NW * PCH, nxt);
+        if (b0 + NW * pch < N) load16(b0 + NW * pch, nxt);
         int g[PU];  // (all groups first, then the atomics: the table reads must not queue behind the atomics they may alias)
         // (classified UNCONDITIONALLY -- the loads are clamped, so every register holds a real record -- and masked afterwards: written as
         //  `i < N ? group_of(rec) : -1` each record became a branch of its own whose two table reads were waited for on the spot, eight
         //  dependent LDS round trips per trip instead of sixteen reads in flight)
-        groups_of(rec, g, PU);
+#ifdef QT_STAMPS
+        { uint32_t x_ = 0;
 #pragma unroll
-        for (int u = 0; u < PU; ++u) g[u] |= -(int)(b0 + u * 64 + lane >= N);
-        if (b0 == wv * PCH) {  // wave-uniform
+          for (int u = 0; u < PU; ++u) x_ |= rec[u];
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (x_ == 0x12345u) g[0] = 0; QTS(-40) }
+#endif
+        groups_of(rec, g, PU);
+#ifdef QT_STAMPS
+        { int x_ = 0;
+#pragma unroll
+          for (int u = 0; u < PU; ++u) x_ += g[u];
+          asm volatile("" :: "v"(x_)); QTS(-41) }
+#endif
+#pragma unroll
+        for (int u = 0; u < PU; ++u) g[u] |= -(int)slot_off(b0, u);
+        if (b0 == wv * pch) {  // wave-uniform
 #pragma unroll
           for (int u = 0; u < PU; ++u) rec0[u] = rec[u], g0[u] = g[u];
         }
 #pragma unroll
         for (int u = 0; u < PU; ++u)
           if (g[u] >= 0) atomicAdd(&cur[cur_w(g[u])], 1u << cur_sh(g[u]));  // LDS atomic; lanes of one group serialise, a chunk spans a handful of groups
+#ifdef QT_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); QTS(-42)
+#endif
       }
     }
     __syncthreads();
@@ -500,6 +538,47 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     __syncthreads();
     QTS(-12)  // totals
     int carry = 0, strip_base = 0, strip_cnt = 0;  // lane st keeps the segment of strip st
+    if (NW > 1) {
+      // (r6) several waves per tree: the rows of 64 group sizes are dealt to the waves (row r to wave r mod NW), each scans its rows, the row
+      // totals meet in LDS (the head list of the batched pops is idle until the expansion) and every wave adds up the rows before its own.
+      // One wave scanning all 22 rows was 6.5 k of a level-0 tree's 93 k cycles.  Rows r and r + ROWS / 2 share their counter WORDS and may
+      // belong to different waves: the cursors go back as 16-bit stores.
+      constexpr int ROWS = (QT_PP_MAX_STRIPS * QT_PP_GROUPS + 63) / 64, RPW = (ROWS + NW - 1) / NW;
+      uint32_t* rowtot = (uint32_t*)bkey;  // [ROWS] row totals | [QT_PP_MAX_STRIPS] strip begins | [QT_PP_MAX_STRIPS] strip ends
+      int vals[RPW], incs[RPW];
+#pragma unroll
+      for (int k = 0; k < RPW; ++k) {
+        const int r = wv + k * NW, g = r * 64 + lane;
+        vals[k] = (r < ROWS && r * 64 < ng && g < ng) ? (int)cur_get(g) : 0;
+        incs[k] = wave_incl_scan(vals[k], lane);
+        if (r < ROWS && lane == 63) rowtot[r] = (uint32_t)incs[k];
+      }
+      __syncthreads();
+      const int rt = lane < ROWS ? (int)rowtot[lane] : 0;
+      const int rt_excl = wave_incl_scan(rt, lane) - rt;  // lane r: the groups in the rows before row r
+#pragma unroll
+      for (int k = 0; k < RPW; ++k) {
+        const int r = wv + k * NW, g0 = r * 64;
+        if (r < ROWS && g0 < ng) {  // wave-uniform
+          const int excl = __builtin_amdgcn_readlane(rt_excl, r) + incs[k] - vals[k];
+          for (int st = 0; st < ns; ++st) {  // strip st starts at group 341 st and ends where strip st + 1 starts
+            const int first = st * QT_PP_GROUPS, last = first + QT_PP_GROUPS - 1;
+            if (first >= g0 && first < g0 + 64) {
+              const int bb = __builtin_amdgcn_readlane(excl, first - g0);
+              if (lane == 0) rowtot[ROWS + st] = (uint32_t)bb;
+            }
+            if (last >= g0 && last < g0 + 64) {
+              const int ee = __builtin_amdgcn_readlane(excl + vals[k], last - g0);
+              if (lane == 0) rowtot[ROWS + QT_PP_MAX_STRIPS + st] = (uint32_t)ee;
+            }
+          }
+          const int g = g0 + lane;
+          if (g < ng) ((uint16_t*)cur)[2 * cur_w(g) + (cur_sh(g) ? 1 : 0)] = (uint16_t)excl;
+        }
+      }
+      __syncthreads();
+      if (lane < ns) strip_base = (int)rowtot[ROWS + lane], strip_cnt = (int)rowtot[ROWS + QT_PP_MAX_STRIPS + lane];
+    } else
     if (w0) {
       // one wave: an exclusive scan over the <= 22 rows of 64 group sizes.  All rows are read first, scanned in registers (the row
       // scans are independent: only the carry is a chain, and it is scalar) and written back at the end -- row by row with a
@@ -547,23 +626,23 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     // pass 2: scatter
     {
       uint32_t nxt[PU];
-      if (wv * PCH + NW * PCH < N) load16(wv * PCH + NW * PCH, nxt);  // (the first trip's records are still in registers)
+      if (wv * pch + NW * pch < N) load16(wv * pch + NW * pch, nxt);  // (the first trip's records are still in registers)
       // (r5, measured and dropped: the groups of pass 1 kept in the bounce buffer for this pass instead of classifying every record a
       //  second time -- ~35 vector instructions per record saved here, one store and one load added: pass 1 45 k -> 59 k cycles, this
       //  pass 53 k -> 49 k on a level-0 tree: it is not the classification that bounds this pass)
-      for (int b0 = wv * PCH; b0 < N; b0 += NW * PCH) {
+      for (int b0 = wv * pch; b0 < N; b0 += NW * pch) {
         uint32_t rec[PU];
         int g[PU];
-        if (b0 == wv * PCH) {  // wave-uniform
+        if (b0 == wv * pch) {  // wave-uniform
 #pragma unroll
           for (int u = 0; u < PU; ++u) rec[u] = rec0[u], g[u] = g0[u];
         } else {
 #pragma unroll
           for (int u = 0; u < PU; ++u) rec[u] = nxt[u];
-          if (b0 + NW * PCH < N) load16(b0 + NW * PCH, nxt);
+          if (b0 + NW * pch < N) load16(b0 + NW * pch, nxt);
           groups_of(rec, g, PU);
 #pragma unroll
-          for (int u = 0; u < PU; ++u) g[u] |= -(int)(b0 + u * 64 + lane >= N);
+          for (int u = 0; u < PU; ++u) g[u] |= -(int)slot_off(b0, u);
         }
         uint32_t pos[PU];
 #pragma unroll
@@ -586,6 +665,8 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         ++next_seq;
       }
     }
+#undef QT_SLOT_ON
+#undef QT_REC_AT
   } else if (w0) {
     // Pass 1 counts the records of each strip (lane s keeps strip s's counter), pass 2 scatters them into the
     // strip segments of H.  Four records per lane are in flight per step to hide the global-load latency.
