@@ -29,6 +29,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstring>
 
 #include "orbfe_internal.h"
 #include "wave_ops.h"
@@ -44,6 +46,28 @@
 #endif
 
 namespace orbfe {
+
+#ifdef FAST_STAMPS  // diagnostic build only (tools/exp/fast_stamps.sh): where a one-cell wave's life goes, in 100 MHz ticks of s_memrealtime
+__device__ unsigned long long g_fs_rec[8192][8];  // per wave: six phase durations, start, end (no atomics: 2462 waves on one address take 30 us each)
+#define FS_DECL unsigned long long fs_t0 = __builtin_amdgcn_s_memrealtime(), fs_last = fs_t0, fs_d[6] = {0, 0, 0, 0, 0, 0};
+#define FS(k)                                                                        \
+  {                                                                                  \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                      \
+    const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();                \
+    fs_d[k] += now_ - fs_last;                                                       \
+    fs_last = now_;                                                                  \
+  }
+#define FS_END                                                                                         \
+  if (lane == 0) {                                                                                     \
+    const unsigned w_ = (blockIdx.y * gridDim.x + blockIdx.x) & 8191u;                                 \
+    for (int k_ = 0; k_ < 6; ++k_) g_fs_rec[w_][k_] = fs_d[k_];                                        \
+    g_fs_rec[w_][6] = fs_t0, g_fs_rec[w_][7] = __builtin_amdgcn_s_memrealtime();                       \
+  }
+#else
+#define FS_DECL
+#define FS(k)
+#define FS_END
+#endif
 
 // (the necessary test takes one row step per loop trip.  Measured on one box, per 128 pairs: 1 -> 2.252 ms, 2 -> 2.278, 4 -> 2.287: the
 // reads of the extra pixels only lengthen the trip, eight waves per SIMD already cover the LDS latency)
@@ -124,12 +148,19 @@ __device__ __forceinline__ int arc_score1(const uint8_t* a, int sgn) {
 // such waves per SIMD leave the vector unit idle a fifth of the time.  In the loop both are off the critical path: the NEXT cell's patch
 // is requested into registers before the current cell is worked on, and a cell's records (almost always <= 64: one per lane, in a
 // register) are stored only after the NEXT cell's work, when the reservation issued before it has long returned.
-template <int PP, int PV>
+//
+// SH (a frame or two, r6): a level's candidates go to n_shards lists (shard = cell index mod n_shards, part shard of the level's region,
+// counters n_cand_sh[image][level][shard]) instead of one.  A pair's launch is 2462 one-cell waves whose lifetime is ONE round: each ends
+// with a reservation on one of sixteen (image, level) counters, and same-address atomics are served one after the other (~25 ns): the
+// 880 reservations of a level-0 counter alone take 22 us -- stamps build, tools/exp/fast_stamps.sh: a wave's own work 6.3 us, the wait for
+// its reservation 19.9 us on average, the launch 32 us.  The small-launch quadtree reads the shards as one list (k_quadtree.hip).  The
+// batches keep one list per level: their counters are 8 per image and the reservation is issued a whole cell before it is used.
+template <int PP, int PV, bool SH = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fast(const LevelDev* __restrict__ lv, const CellDev* __restrict__ cells,
                                              const uint8_t* __restrict__ pyr, size_t img_pitch, int t_hi, int t_lo,
                                              uint32_t* __restrict__ cand, size_t cand_pitch, int32_t* __restrict__ n_cand,
                                              int n_levels, int cell_first, int n_cells, int lds_v_off, int lds_q_off, int q_cap,
-                                             int n_groups) {
+                                             int n_groups, int32_t* __restrict__ n_cand_sh, int n_shards) {
   extern __shared__ uint32_t lds_all[];
   // One wave per workgroup (four waves per workgroup measured 10 % slower: the LDS of a workgroup stays allocated until its slowest
   // wave is done); the kernel gains from every extra resident wave (21 -> 26 waves per CU: -7 %), so the LDS carve-up is per launch
@@ -150,6 +181,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   const int img = blockIdx.y;
   int ci = __builtin_amdgcn_readfirstlane(blockIdx.x);
   if (ci >= n_cells) return;
+  FS_DECL
   // ---- patch -> registers: 16-byte units (3 per row for the 30-px grid's patches: 21 rows per pass of the wave), every pass of a lane
   //      requested at once (rows clamped, so the loads are unconditional).  The global address is only 4-byte aligned (x0 - xa);
   //      gfx950 takes that for dwordx4.
@@ -240,6 +272,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   uint4 wv[NB];
   fetch(cell, wv, false);
   FAST_PATCH_ARRIVED();
+  FS(0)  // cell record + patch arrived
   park(cell, wv);
   // the previous cell's records, one per lane, waiting for its list reservation (lane 0 of base_prev) to return
   uint32_t rec_prev = 0u;
@@ -268,6 +301,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const CellDev cell_next = load_cell(has_next ? ci_next : ci);
     fetch(cell_next, wv, !has_next);
     WAVE_SYNC();
+    FS(1)  // parked, map zeroed, next requested (waits for it in this build)
 
     if (live) {
       for (int pass = 0; pass < 2; ++pass) {
@@ -408,6 +442,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
       }
       WAVE_SYNC();
+      FS(2)  // necessary test
 
       // ---- 3. exact test + score for the survivors, one queue entry per lane (trips of 64).  Only about
       //         half of the survivors are corners: those (and the dual-tagged entries, whose second polarity is still to come) are
@@ -461,6 +496,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
       }
       WAVE_SYNC();
+      FS(3)  // scoring
 
         // ---- 4. NMS over the queue: an entry is kept iff its score beats its 8 neighbours' (0 where nothing was scored); the kept ones
         //         are compacted at the front of Q (in place: a trip's entries are all read before it writes, and it writes no further
@@ -484,6 +520,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
           n_keep += __popcll(m);
         }
         WAVE_SYNC();
+        FS(4)  // NMS
         if (n_keep > 0) break;
       }
     }
@@ -498,8 +535,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // reservation has just been consumed above --, and only then is this cell's reservation issued; its value is looked at after
     // the next cell's work.
     bool defer = false;
-    uint32_t* const out = cand + (size_t)img * cand_pitch + L.cand_base;
-    int32_t* const counter = &n_cand[(size_t)img * n_levels + cell.level];
+    const int shard = SH ? (ci & (n_shards - 1)) : 0;  // (n_shards: a power of two)
+    uint32_t* const out = cand + (size_t)img * cand_pitch + L.cand_base + (SH ? (size_t)shard * L.shard_cap : (size_t)0);
+    int32_t* const counter = SH ? &n_cand_sh[((size_t)img * n_levels + cell.level) * n_shards + shard] : &n_cand[(size_t)img * n_levels + cell.level];
     auto record = [&](int j) __attribute__((always_inline)) -> uint32_t {
       const uint32_t e = Q[min(j, n_keep - 1)];
       const int ix = Q_IX(e), iy = Q_IY(e);
@@ -526,6 +564,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       }
     }
     FAST_PATCH_ARRIVED();
+    FS(5)  // output
     if (!has_next) break;
     WAVE_SYNC();  // (the records above were read from Q / V before the next cell's patch and map overwrite them)
     park(cell_next, wv);
@@ -537,7 +576,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     ci = ci_next;
     cell = cell_next;
   }
+  FS_END
 }
+
+#ifdef FAST_STAMPS
+}  // namespace orbfe
+extern "C" void orbfe_debug_fast_stamps() {
+  static unsigned long long rec[8192][8];
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(rec, HIP_SYMBOL(orbfe::g_fs_rec), sizeof(rec));
+  const char* names[6] = {"arrive", "park", "necessary", "scoring", "nms", "output"};
+  unsigned long long first = ~0ull, last = 0, n = 0, sum[7] = {0}, mx[7] = {0};
+  for (int w = 0; w < 8192; ++w) {
+    if (!rec[w][7]) continue;
+    ++n;
+    first = first < rec[w][6] ? first : rec[w][6], last = last > rec[w][7] ? last : rec[w][7];
+    for (int k = 0; k < 6; ++k) sum[k] += rec[w][k], mx[k] = mx[k] > rec[w][k] ? mx[k] : rec[w][k];
+    const unsigned long long life = rec[w][7] - rec[w][6];
+    sum[6] += life, mx[6] = mx[6] > life ? mx[6] : life;
+  }
+  printf("FAST stamps (last launch): %llu waves, first start .. last end %.2f us\n", n, (last - first) * 0.01);
+  for (int k = 0; k < 6; ++k) printf("  %-10s mean %7.2f us  max %7.2f us\n", names[k], n ? sum[k] * 0.01 / n : 0.0, mx[k] * 0.01);
+  printf("  %-10s mean %7.2f us  max %7.2f us\n", "wave", n ? sum[6] * 0.01 / n : 0.0, mx[6] * 0.01);
+  // start times by decile of the launch, end times
+  unsigned long long smax = 0;
+  for (int w = 0; w < 8192; ++w) if (rec[w][7]) smax = smax > rec[w][6] - first ? smax : rec[w][6] - first;
+  printf("  last wave started %.2f us after the first\n", smax * 0.01);
+  memset(rec, 0, sizeof(rec));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(orbfe::g_fs_rec), rec, sizeof(rec));
+}
+namespace orbfe {
+#endif
 
 #undef FAST_PATCH_ARRIVED
 #undef FAST_ROW_PART
@@ -572,7 +641,7 @@ void fast_lds_layout(int max_pw, int max_ph, int pp, int pv, int* v_off, int* q_
 // tools/exp/fast_sq.sh) with 3.5 x the LDS bank-conflict cycles: 2.22 ms against 2.07.
 static void launch_fast_cells(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, int max_pw, int max_ph, const uint8_t* d_pyr,
                               size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch, int32_t* d_n_cand, int n_levels,
-                              int cell_first, int n_cells, int n_img, int cpw_force) {
+                              int cell_first, int n_cells, int n_img, int cpw_force, int32_t* d_n_cand_sh = nullptr, int n_shards = 1) {
   int v_off, q_off, q_cap, total;
   const int pp = max_pw <= FAST_PP40_MAX ? 40 : (max_pw <= 44 ? 48 : 80), pv = max_pw <= FAST_PV36_MAX ? 36 : (max_pw <= 44 ? 40 : 72);
   fast_lds_layout(max_pw, max_ph, pp, pv, &v_off, &q_off, &q_cap, &total);
@@ -586,19 +655,35 @@ static void launch_fast_cells(hipStream_t s, const LevelDev* d_lv, const CellDev
   // so a wave's cells ci, ci + n_groups ... stay on its XCD's strip and the launch's rows of workgroups start on XCD 0 for every image
   const int n_groups = ((n_cells + cpw - 1) / cpw + 7) & ~7;
 #define FAST_GO(K) hipLaunchKernelGGL(K, dim3(n_groups, n_img), dim3(64), total, s, d_lv, d_cells, d_pyr, img_pitch, t_hi, t_lo, d_cand, \
-                                      cand_pitch, d_n_cand, n_levels, cell_first, n_cells, v_off, q_off, q_cap, n_groups)
-  if (pp == 40) FAST_GO((k_fast<40, 36>));
+                                      cand_pitch, d_n_cand, n_levels, cell_first, n_cells, v_off, q_off, q_cap, n_groups, d_n_cand_sh, n_shards)
+  if (d_n_cand_sh && n_shards > 1) {  // a frame or two: sharded lists
+    if (pp == 40) FAST_GO((k_fast<40, 36, true>));
+    else if (pp == 48 && pv == 36) FAST_GO((k_fast<48, 36, true>));
+    else if (pp == 48) FAST_GO((k_fast<48, 40, true>));
+    else FAST_GO((k_fast<80, 72, true>));
+  } else if (pp == 40) FAST_GO((k_fast<40, 36>));
   else if (pp == 48 && pv == 36) FAST_GO((k_fast<48, 36>));
   else if (pp == 48) FAST_GO((k_fast<48, 40>));
   else FAST_GO((k_fast<80, 72>));
 #undef FAST_GO
 }
 
+bool fast_single_launch(const LevelDev* h_lv, const int* lvl_max_pw, const int* lvl_max_ph, int n_levels, int n_img) {
+  int total_cells = 0, max_pw = 0, max_ph = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    total_cells += h_lv[l].n_cells;
+    max_pw = std::max(max_pw, lvl_max_pw[l]);
+    max_ph = std::max(max_ph, lvl_max_ph[l]);
+  }
+  return n_img > 0 && (long long)total_cells * n_img <= 16384 && max_pw > 6 && max_ph > 6;
+}
+
 // One launch per pyramid level: the cells of a level have (almost) one size, so each launch reserves just the LDS its
 // patches need.  Measured: merging levels 0..3 into one launch with their common carve-up is 5 % slower than the four separate launches.
 void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, const LevelDev* h_lv, const int* lvl_max_pw,
                  const int* lvl_max_ph, const uint8_t* d_pyr, size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch,
-                 int32_t* d_n_cand, int n_levels, int n_img, int cpw_force, uint32_t level_mask, bool merge_masked) {
+                 int32_t* d_n_cand, int n_levels, int n_img, int cpw_force, uint32_t level_mask, bool merge_masked, int32_t* d_n_cand_sh, int n_shards) {
+  // d_n_cand_sh / n_shards > 1: the caller has checked fast_single_launch() -- only the one-launch form shards its lists
   // level_mask: the levels this call launches (bit l; ~0u: all) -- an experiment of r6 puts some levels' launches on a second stream (run_extract)
   // (the launches of the small levels on a second stream beside the large ones, or alternating levels on two streams, were measured in
   //  rounds 2-3 and dropped: profiles/NOTES_r1-r3.md)
@@ -618,7 +703,7 @@ void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, co
   }
   if ((long long)total_cells * n_img <= 16384 && max_pw > 6 && max_ph > 6 && level_mask == ~0u) {
     launch_fast_cells(s, d_lv, d_cells, max_pw, max_ph, d_pyr, img_pitch, t_hi, t_lo, d_cand, cand_pitch, d_n_cand, n_levels, 0, total_cells,
-                      n_img, cpw_force);
+                      n_img, cpw_force, d_n_cand_sh, n_shards);
     return;
   }
   if (merge_masked && level_mask != ~0u) {

@@ -361,8 +361,19 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
                                           unsigned long long* sortbuf, unsigned long long* bkey, uint32_t* bj,
                                           uint32_t* shared_ints, int batch_on, int node_cap, int need,
                                           int sort_cap, uint32_t* __restrict__ out_sel, int32_t* __restrict__ sel_count_out, int lane, int wv,
-                                          const uint16_t* __restrict__ qt_tabs, uint16_t* tot4_lds = nullptr) {
+                                          const uint16_t* __restrict__ qt_tabs, uint16_t* tot4_lds = nullptr, const uint32_t* shP = nullptr) {
   constexpr int NT = 64 * NW;
+  // record i of the level's candidate set.  A frame or two: k_fast leaves the set as ORBFE_FAST_SHARDS lists in equal parts of the level's
+  // region (k_fast.hip); shP = the exclusive prefix of their sizes in LDS, [ORBFE_FAST_SHARDS + 1] (shards without records share their
+  // successor's prefix and come before it: the LAST shard whose prefix is <= i holds record i)
+  auto A_at = [&](int i) __attribute__((always_inline)) -> uint32_t {
+    if (NW == 1 || !shP) return A[i];
+    int sh = 0;
+#pragma unroll
+    for (int step = ORBFE_FAST_SHARDS / 2; step; step >>= 1)
+      if ((int)shP[sh + step] <= i) sh += step;
+    return A[(size_t)sh * L.shard_cap + (size_t)(i - (int)shP[sh])];
+  };
   const int tid = wv * 64 + lane;
   const bool w0 = wv == 0;
   QTS_DECL
@@ -402,31 +413,48 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     // to cover the level ONCE with all waves (pu_eff, in uniform groups of four slots): 5087 candidates on eight waves are ten records a
     // lane on every wave -- with whole trips of sixteen, five waves took one trip each and three had nothing to do.
     constexpr int PU = NW == 1 ? 8 : 16;
-    const int pu_eff = NW == 1 ? PU : min(PU, max(1, (N + NT - 1) / NT));
+    // Sharded candidate lists (a frame or two, k_fast.hip): the set's order is free, so wave w simply takes shards [w SPW, (w + 1) SPW) back to
+    // back -- equal numbers of cells each, so the waves are balanced -- and no record needs the search of A_at: local index t -> shard k by
+    // SPW - 1 compares against wave-uniform prefixes.  (With the search in the loads the passes were 3.5 us longer per pair.)
+    constexpr int SPW = (NW > 1 && ORBFE_FAST_SHARDS / NW > 0) ? ORBFE_FAST_SHARDS / NW : 1;
+    static_assert(NW == 1 || NW > ORBFE_FAST_SHARDS || SPW * NW == ORBFE_FAST_SHARDS, "shards per wave");
+    const bool shw = NW > 1 && NW <= ORBFE_FAST_SHARDS && shP != nullptr;  // (uniform)
+    int lp[SPW + 1];  // this wave's shards: exclusive prefix of their sizes
+#pragma unroll
+    for (int k = 0; k <= SPW; ++k) lp[k] = shw ? (int)(shP[wv * SPW + k] - shP[wv * SPW]) : 0;
+    const int n_loc = lp[SPW];
+    const int pu_eff = NW == 1 ? PU : min(PU, max(1, shw ? (n_loc + 63) / 64 : (N + NT - 1) / NT));
     const int pch = 64 * pu_eff;
+    const int t_beg = shw ? 0 : wv * pch, t_end = shw ? n_loc : N, t_step = shw ? pch : NW * pch;  // this wave's trips: records [b0, b0 + pch)
 #define QT_SLOT_ON(u) (NW == 1 || ((u) & ~3) < pu_eff)  // (wave-uniform: a group of four slots is worked on or skipped as a whole)
-    // which record slot u of a lane holds: slot-major (a wave instruction's 64 records are consecutive: coalesced loads).  The experiment:
-    // LANE-major with helper waves -- the candidates arrive cell by cell (k_fast appends a cell's corners together), so 64 consecutive records
-    // fall into four to six groups of the pre-partition and the 64 lanes' LDS atomics on the group counters serialise a dozen deep; ten records
-    // apart the lanes of an instruction span some thirty cells.  (The order of the records inside a group is irrelevant.)
-#ifndef QT_LANE_MAJOR
-#define QT_LANE_MAJOR 0  // (measured with eight waves: pass 2 5.97 -> 5.1 k cycles, pass 1 8.8 -> 10.2 k -- its strided loads; left off)
-#endif
-#define QT_REC_AT(b0, u) ((NW > 1 && QT_LANE_MAJOR) ? (b0) + lane * pu_eff + (u) : (b0) + (u) * 64 + lane)
+#define QT_REC_AT(b0, u) ((b0) + (u) * 64 + lane)        // slot-major: a wave instruction's 64 records are consecutive (coalesced loads)
+    // (measured and dropped, eight waves: LANE-major slots -- the candidates arrive cell by cell, 64 consecutive records fall into four to six
+    //  groups of the pre-partition and the lanes' LDS atomics serialise a dozen deep -- pass 2 5.97 -> 5.1 k cycles, pass 1 8.8 -> 10.2 k: its
+    //  strided loads)
+    auto rec_fetch = [&](int i) __attribute__((always_inline)) -> uint32_t {  // record i of this wave's range (clamped by the caller)
+      if (!shw) return A[i];
+      int k = 0;
+#pragma unroll
+      for (int q = 1; q < SPW; ++q) k += i >= lp[q] ? 1 : 0;
+      int base = lp[0];
+#pragma unroll
+      for (int q = 1; q < SPW; ++q) base = k >= q ? lp[q] : base;
+      return A[(size_t)(wv * SPW + k) * L.shard_cap + (size_t)(i - base)];
+    };
     // pass 1: group sizes.  The next trip's records are requested before this trip's are classified: a lone wave sees every global round
     // trip, so the loads of trip k+1 fly under the work of trip k.
     auto load16 = [&](int b0, uint32_t* r) {
 #pragma unroll
       for (int u = 0; u < PU; ++u) {
         const int i = QT_REC_AT(b0, u);
-        r[u] = QT_SLOT_ON(u) ? A[max(min(i, N - 1), 0)] : 0u;  // (clamped: unconditional loads, validity is checked when the record is used)
+        r[u] = QT_SLOT_ON(u) ? rec_fetch(max(min(i, t_end - 1), 0)) : 0u;  // (clamped: unconditional loads, validity is checked when the record is used)
       }
     };
-    auto slot_off = [&](int b0, int u) -> bool { return u >= pu_eff || QT_REC_AT(b0, u) >= N; };  // not a record of this trip
+    auto slot_off = [&](int b0, int u) -> bool { return u >= pu_eff || QT_REC_AT(b0, u) >= t_end; };  // not a record of this trip
     // (r6) the first trip's records are requested HERE, before the tables are copied: a tree's first global round trip -- the candidates
     // k_fast has just written -- flies under the copy and its barrier instead of opening pass 1
     uint32_t nxt0[PU];
-    if (NW > 1) load16(wv * pch, nxt0);  // (the one-wave batch kernel keeps its request in pass 1: eight more live registers across the copy buy it nothing)
+    if (NW > 1) load16(t_beg, nxt0);  // (the one-wave batch kernel keeps its request in pass 1: eight more live registers across the copy buy it nothing)
     for (int g = tid; g < cur_words; g += NT) cur[g] = 0;
     // The coordinate -> code tables depend on the LEVEL's geometry alone (strip bounds, region height): the host builds them once per
     // context (quadtree_build_tables, the same fp64 operations) and a tree only copies its level's ~3 KB into LDS.  Built here, per tree,
@@ -471,13 +499,13 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
 #pragma unroll
         for (int u = 0; u < PU; ++u) nxt[u] = nxt0[u];
       } else {
-        load16(wv * pch, nxt);
+        load16(t_beg, nxt);
       }
-      for (int b0 = wv * pch; b0 < N; b0 += NW * pch) {
+      for (int b0 = t_beg; b0 < t_end; b0 += t_step) {
         uint32_t rec[PU];
 #pragma unroll
         for (int u = 0; u < PU; ++u) rec[u] = nxt[u];
-        if (b0 + NW * pch < N) load16(b0 + NW * pch, nxt);
+        if (b0 + t_step < t_end) load16(b0 + t_step, nxt);
         int g[PU];  // (all groups first, then the atomics: the table reads must not queue behind the atomics they may alias)
         // (classified UNCONDITIONALLY -- the loads are clamped, so every register holds a real record -- and masked afterwards: written as
         //  `i < N ? group_of(rec) : -1` each record became a branch of its own whose two table reads were waited for on the spot, eight
@@ -497,7 +525,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
 #endif
 #pragma unroll
         for (int u = 0; u < PU; ++u) g[u] |= -(int)slot_off(b0, u);
-        if (b0 == wv * pch) {  // wave-uniform
+        if (b0 == t_beg) {  // wave-uniform
 #pragma unroll
           for (int u = 0; u < PU; ++u) rec0[u] = rec[u], g0[u] = g[u];
         }
@@ -626,20 +654,20 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
     // pass 2: scatter
     {
       uint32_t nxt[PU];
-      if (wv * pch + NW * pch < N) load16(wv * pch + NW * pch, nxt);  // (the first trip's records are still in registers)
+      if (t_beg + t_step < t_end) load16(t_beg + t_step, nxt);  // (the first trip's records are still in registers)
       // (r5, measured and dropped: the groups of pass 1 kept in the bounce buffer for this pass instead of classifying every record a
       //  second time -- ~35 vector instructions per record saved here, one store and one load added: pass 1 45 k -> 59 k cycles, this
       //  pass 53 k -> 49 k on a level-0 tree: it is not the classification that bounds this pass)
-      for (int b0 = wv * pch; b0 < N; b0 += NW * pch) {
+      for (int b0 = t_beg; b0 < t_end; b0 += t_step) {
         uint32_t rec[PU];
         int g[PU];
-        if (b0 == wv * pch) {  // wave-uniform
+        if (b0 == t_beg) {  // wave-uniform
 #pragma unroll
           for (int u = 0; u < PU; ++u) rec[u] = rec0[u], g[u] = g0[u];
         } else {
 #pragma unroll
           for (int u = 0; u < PU; ++u) rec[u] = nxt[u];
-          if (b0 + NW * pch < N) load16(b0 + NW * pch, nxt);
+          if (b0 + t_step < t_end) load16(b0 + t_step, nxt);
           groups_of(rec, g, PU);
 #pragma unroll
           for (int u = 0; u < PU; ++u) g[u] |= -(int)slot_off(b0, u);
@@ -677,7 +705,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = b0 + u * 64 + lane;
-        rec[u] = (i < N) ? A[i] : 0u;
+        rec[u] = (i < N) ? A_at(i) : 0u;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -711,7 +739,7 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = b0 + u * 64 + lane;
-        rec[u] = (i < N) ? A[i] : 0u;
+        rec[u] = (i < N) ? A_at(i) : 0u;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -1493,7 +1521,8 @@ __device__ __forceinline__ void quadtree_levels(const LevelDev* __restrict__ lv,
                                                  uint32_t* __restrict__ sel, int32_t* __restrict__ sel_count, int n_features,
                                                  const int32_t* __restrict__ n_cand, int node_cap, int sort_cap, int rec_cap, int batch,
                                                  QtGroups groups, uint8_t* __restrict__ big_base, size_t big_pitch,
-                                                 const uint16_t* __restrict__ qt_tabs, int32_t* __restrict__ qt_next) {
+                                                 const uint16_t* __restrict__ qt_tabs, int32_t* __restrict__ qt_next,
+                                                 const int32_t* __restrict__ n_cand_sh = nullptr, int n_shards = 1) {
   extern __shared__ unsigned long long lds[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int img = blockIdx.y;
@@ -1542,7 +1571,30 @@ __device__ __forceinline__ void quadtree_levels(const LevelDev* __restrict__ lv,
   const int need = L.quota;
   // the level's candidate SET, appended by k_fast in arbitrary order
   const uint32_t* A = cand + (size_t)img * scratch_pitch + L.cand_base;
-  const int N = min(n_cand[(size_t)img * n_levels + level], (int)L.cand_cap);
+  int N;
+  const uint32_t* shP = nullptr;
+  if (NW > 1 && n_cand_sh && n_shards > 1) {
+    // a frame or two: the set arrives in shards (k_fast.hip); their sizes -> N and the exclusive prefix in LDS (the sort area: idle until the
+    // expansion, and tree_body reads its records before that)
+    const int32_t* cs = n_cand_sh + ((size_t)img * n_levels + level) * n_shards;
+    const int cnt = lane < n_shards ? min(max(cs[lane], 0), (int)L.shard_cap) : 0;
+    const int incl = wave_incl_scan(cnt, lane);
+    N = __builtin_amdgcn_readlane(incl, 63);
+    uint32_t* pfx = (uint32_t*)sortbuf;
+    if (wv == 0 && lane <= ORBFE_FAST_SHARDS) pfx[lane] = (uint32_t)(incl - cnt);
+    shP = pfx;
+    __syncthreads();
+  } else {
+    N = min(n_cand[(size_t)img * n_levels + level], (int)L.cand_cap);
+  }
+  auto A_rec = [&](int i) __attribute__((always_inline)) -> uint32_t {  // (tree_body's A_at, for the one-feature level below)
+    if (!shP) return A[i];
+    int sh = 0;
+#pragma unroll
+    for (int step = ORBFE_FAST_SHARDS / 2; step; step >>= 1)
+      if ((int)shP[sh + step] <= i) sh += step;
+    return A[(size_t)sh * L.shard_cap + (size_t)(i - (int)shP[sh])];
+  };
   const bool in_lds = N <= rec_cap;
   uint32_t* gb = scratch_b + (size_t)img * scratch_pitch + L.cand_base;
   uint32_t* gc = scratch_c + (size_t)img * scratch_pitch + L.cand_base;
@@ -1556,7 +1608,7 @@ __device__ __forceinline__ void quadtree_levels(const LevelDev* __restrict__ lv,
       unsigned long long bk = ~0ull;
       uint32_t brec = 0;
       for (int i = lane; i < N; i += 64) {
-        const uint32_t rec = A[i];
+        const uint32_t rec = A_rec(i);
         const uint32_t r = ORBFE_REC_R(rec);
         const unsigned long long k = order_key(rec, L);
         if (r > br || (r == br && k < bk)) {
@@ -1596,13 +1648,13 @@ __device__ __forceinline__ void quadtree_levels(const LevelDev* __restrict__ lv,
     uint2* g_bp = (uint2*)(g_key + cap);
     unsigned long long* g_sort = (unsigned long long*)(g_bp + cap);
     tree_body<false, NW, false>(L, A, N, gb, gc, g_key, g_bp, g_sort, bkey, bj, shared_ints, batch, (int)cap, need,
-                                L.qt_big_sort, out_sel, sel_count + (size_t)img * n_levels + level, lane, wv, qt_tabs);
+                                L.qt_big_sort, out_sel, sel_count + (size_t)img * n_levels + level, lane, wv, qt_tabs, nullptr, shP);
   } else if (in_lds)
     tree_body<true, NW>(L, A, N, lds_recs, gb, n_key, n_bp, sortbuf, bkey, bj, shared_ints, batch, node_cap, need, sort_cap,
-                        out_sel, sel_count + (size_t)img * n_levels + level, lane, wv, qt_tabs, tot4_lds);
+                        out_sel, sel_count + (size_t)img * n_levels + level, lane, wv, qt_tabs, tot4_lds, shP);
   else
     tree_body<false, NW>(L, A, N, gb, gc, n_key, n_bp, sortbuf, bkey, bj, shared_ints, batch, node_cap, need, sort_cap,
-                         out_sel, sel_count + (size_t)img * n_levels + level, lane, wv, qt_tabs, tot4_lds);
+                         out_sel, sel_count + (size_t)img * n_levels + level, lane, wv, qt_tabs, tot4_lds, shP);
   // the next tree reuses the LDS: the accesses of one wave execute in order, the fence only pins the compiler
   if (NW > 1) __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1639,6 +1691,8 @@ struct QtBlur {
   size_t img_pitch;
   BlurTaps taps;
   int n_groups;
+  const int32_t* n_cand_sh;  // != nullptr: the candidate sets arrive in n_shards lists per level (k_fast.hip, SH)
+  int n_shards;
 };
 #ifndef QT_SMALL_WAVES
 #define QT_SMALL_WAVES 8  // (a power of two: 4 -> 8 takes a pair's trees from 60 to 50 us, 16 -> 69; tools/exp/qt_waves.sh)
@@ -1652,7 +1706,7 @@ __global__ __launch_bounds__(64 * QT_SMALL_WAVES) void k_quadtree_w4(QT_KERNEL_A
       blur_tile<false>(lv, n_levels, bl.pyr, bl.blur, bl.img_pitch, bl.taps, (int)blockIdx.x - bl.n_groups, (int)blockIdx.y, (int)threadIdx.x);
     return;
   }
-  quadtree_levels<QT_SMALL_WAVES>(QT_KERNEL_PASS);
+  quadtree_levels<QT_SMALL_WAVES>(QT_KERNEL_PASS, bl.n_cand_sh, bl.n_shards);
 }
 
 // The pre-partition's coordinate -> code tables of one level (tree_body): x table [tab_w2] then y table [tab_h], uint16 codes as
@@ -1707,7 +1761,7 @@ void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const ui
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
                      int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree, uint8_t* d_big, size_t big_pitch,
                      const uint16_t* d_qt_tabs, const uint8_t* blur_pyr, uint8_t* blur_out, size_t img_pitch, const int* blur_taps, int blur_tiles,
-                     int32_t* d_qt_next, bool next_zeroed) {
+                     int32_t* d_qt_next, bool next_zeroed, const int32_t* d_n_cand_sh, int n_shards) {
   // d_qt_next != nullptr and groups.n_order > 0 (one-wave launches only): the image's waves pull levels from d_qt_next[img], zeroed here
   // unless the caller has had them zeroed already (next_zeroed: run_extract lets the resize kernel do it)
   // blur_pyr != nullptr (four-wave launches only): the blur of the same images rides in this launch, blur_tiles workgroups per image
@@ -1715,6 +1769,8 @@ void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const ui
   const size_t lds = quadtree_lds_bytes(node_cap, rec_cap, sort_cap);
   QtBlur bl{};
   bl.n_groups = n_groups;
+  bl.n_cand_sh = (waves_per_tree >= 4 && n_shards > 1) ? d_n_cand_sh : nullptr;  // (the caller shards only where this launch is the several-waves one)
+  bl.n_shards = bl.n_cand_sh ? n_shards : 1;
   if (waves_per_tree >= 4 && blur_pyr && blur_tiles > 0) {
     bl.pyr = blur_pyr, bl.blur = blur_out, bl.img_pitch = img_pitch;
     for (int i = 0; i < 7; ++i) bl.taps.t[i] = blur_taps[i];

@@ -63,6 +63,10 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
   }
   size_t plane_off = 0;
   uint32_t cand_base = 0;
+  {
+    const char* she = getenv("ORBFE_FAST_SHARDS");  // 1: one list per level everywhere (r5's layout)
+    c->fast_shards = (cfg.max_images <= 16 && !(she && atoi(she) <= 1)) ? ORBFE_FAST_SHARDS : 1;
+  }
   int cell_base = 0, quota_off = 0, rs_tiles = 0, bl_tiles = 0, max_quota = 0, max_ini = 4;
   c->cells.clear();
   c->taps.clear();
@@ -141,7 +145,9 @@ static orbfe_status build_geometry(orbfe_ctx* c) {
     cell_base += n_cells;
     L.cand_cap = (uint32_t)n_cells * (uint32_t)L.cell_cap;
     L.cand_base = cand_base;
-    cand_base += (uint32_t)align_up(L.cand_cap, 32);
+    // (a frame or two: the level's region as fast_shards equal parts, each large enough for the cells it can receive)
+    L.shard_cap = c->fast_shards > 1 ? (uint32_t)((n_cells + c->fast_shards - 1) / c->fast_shards) * (uint32_t)L.cell_cap : 0u;
+    cand_base += (uint32_t)align_up(std::max<uint32_t>(L.cand_cap, (uint32_t)c->fast_shards * L.shard_cap), 32);
     // root strips (Quadtree::initSplit)
     {
       const double w = (double)L.reg_w, h = (double)L.reg_h;
@@ -576,7 +582,7 @@ void orbfe_destroy(orbfe_ctx* c) {
   drain_timers(c);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_rs_tiles, c->d_pattern, c->d_pyr,     c->d_blur,
-                  c->d_scr_a, c->d_scr_c,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_kp,
+                  c->d_scr_a, c->d_scr_c,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_cand_sh, c->d_n_kp,
                   c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos, c->d_kx, c->d_kpl,   c->d_right_u, c->d_depth, c->d_n_match,
                   c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist, c->d_rowoff_slot, c->d_rowlist_slot, c->d_rs_regions, c->d_rg_xtaps, c->d_rg_ytaps, c->d_qt_big, c->d_qt_tabs, c->d_qt_next, c->d_mb_tx, c->d_mb_ty, c->st_rows.lrow_off, c->st_rows.lrow_list, c->st_rows.work, c->st_rows.work_n};
   for (void* p : ptrs)
@@ -745,6 +751,8 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
     }
   }
   ALLOC(c->d_n_cand, M * NL);
+  if (c->fast_shards > 1) ALLOC(c->d_n_cand_sh, M * NL * (size_t)c->fast_shards);
+  c->slot_sharded.assign((size_t)M, 0);
   ALLOC(c->d_n_kp, M);
   ALLOC(c->d_kps, M * NF);
   ALLOC(c->d_desc, M * NF * 32);
@@ -995,12 +1003,30 @@ orbfe_status orbfe_debug_candidates(orbfe_ctx* c, int32_t slot, int32_t level, f
   TRY(join_stereo(c));
   const LevelDev& L = c->lv[level];
   int32_t n = 0;
-  HIP_TRY(c, hipMemcpyAsync(&n, c->d_n_cand + (size_t)slot * c->cfg.n_levels + level, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  n = std::min<int32_t>(std::max(n, 0), (int32_t)L.cand_cap);
-  std::vector<uint32_t> rec((size_t)std::max(n, 1));
-  if (n) HIP_TRY(c, hipMemcpyAsync(rec.data(), c->d_scr_a + (size_t)slot * c->scratch_pitch + L.cand_base, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::vector<uint32_t> rec;
+  if (c->fast_shards > 1 && c->slot_sharded[(size_t)slot]) {  // the level's list in shards (a frame or two): gathered here
+    const int ns = c->fast_shards;
+    std::vector<int32_t> cnt((size_t)ns, 0);
+    HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->d_n_cand_sh + ((size_t)slot * c->cfg.n_levels + level) * ns, sizeof(int32_t) * ns, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < ns; ++s) {
+      const int32_t k = std::min<int32_t>(std::max(cnt[(size_t)s], 0), (int32_t)L.shard_cap);
+      if (!k) continue;
+      rec.resize((size_t)n + k);
+      HIP_TRY(c, hipMemcpyAsync(rec.data() + n, c->d_scr_a + (size_t)slot * c->scratch_pitch + L.cand_base + (size_t)s * L.shard_cap, sizeof(uint32_t) * k,
+                                hipMemcpyDeviceToHost, c->stream));
+      n += k;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (rec.empty()) rec.resize(1);
+  } else {
+    HIP_TRY(c, hipMemcpyAsync(&n, c->d_n_cand + (size_t)slot * c->cfg.n_levels + level, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    n = std::min<int32_t>(std::max(n, 0), (int32_t)L.cand_cap);
+    rec.resize((size_t)std::max(n, 1));
+    if (n) HIP_TRY(c, hipMemcpyAsync(rec.data(), c->d_scr_a + (size_t)slot * c->scratch_pitch + L.cand_base, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
   // reference order = (cell row, cell col, y, x)
   std::vector<std::pair<uint64_t, uint32_t>> keyed((size_t)n);
   for (int i = 0; i < n; ++i) {

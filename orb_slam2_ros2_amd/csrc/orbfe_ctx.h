@@ -48,7 +48,9 @@ void launch_load_level0(hipStream_t st, const uint8_t* d_src, const uint8_t* d_s
 // k_fast.hip
 void launch_fast(hipStream_t s, const LevelDev* d_lv, const CellDev* d_cells, const LevelDev* h_lv, const int* lvl_max_pw,
                  const int* lvl_max_ph, const uint8_t* d_pyr, size_t img_pitch, int t_hi, int t_lo, uint32_t* d_cand, size_t cand_pitch,
-                 int32_t* d_n_cand, int n_levels, int n_img, int cpw_force, uint32_t level_mask = ~0u, bool merge_masked = false);
+                 int32_t* d_n_cand, int n_levels, int n_img, int cpw_force, uint32_t level_mask = ~0u, bool merge_masked = false,
+                 int32_t* d_n_cand_sh = nullptr, int n_shards = 1);
+bool fast_single_launch(const LevelDev* h_lv, const int* lvl_max_pw, const int* lvl_max_ph, int n_levels, int n_img);  // launch_fast's one-launch rule
 // k_quadtree.hip
 size_t quadtree_lds_bytes(int node_cap, int rec_cap, int sort_cap);
 hipError_t quadtree_configure(size_t lds_bytes);
@@ -56,7 +58,7 @@ void launch_quadtree(hipStream_t s, const LevelDev* d_lv, int n_levels, const ui
                      size_t scratch_pitch, uint32_t* d_sel, int32_t* d_sel_count, int n_features, const int32_t* d_n_cand, int node_cap, int sort_cap,
                      int rec_cap, int n_img, int batch, const QtGroups& groups, int n_groups, int waves_per_tree, uint8_t* d_big, size_t big_pitch,
                      const uint16_t* d_qt_tabs, const uint8_t* blur_pyr, uint8_t* blur_out, size_t img_pitch, const int* blur_taps, int blur_tiles,
-                     int32_t* d_qt_next, bool next_zeroed = false);
+                     int32_t* d_qt_next, bool next_zeroed = false, const int32_t* d_n_cand_sh = nullptr, int n_shards = 1);
 bool quadtree_build_tables(const LevelDev& L, std::vector<uint16_t>& out);
 // k_brief.hip
 void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,
@@ -267,6 +269,11 @@ struct orbfe_ctx {
   size_t qt_big_pitch = 0;
   uint32_t* d_sel = nullptr;
   int32_t *d_sel_count = nullptr, *d_n_cand = nullptr, *d_n_kp = nullptr;
+  // a frame or two (contexts of <= 16 slots): FAST's candidate lists in fast_shards shards per level (k_fast.hip: the reservations of a pair's
+  // 2462 one-cell waves on sixteen counters were 20 of the launch's 32 us); [slot][level][shard] counters, which slots hold sharded lists
+  int fast_shards = 1;
+  int32_t* d_n_cand_sh = nullptr;
+  std::vector<uint8_t> slot_sharded;
   orbfe_keypoint* d_kps = nullptr;
   uint8_t* d_desc = nullptr;
   KpAux* d_aux = nullptr;

@@ -44,13 +44,21 @@ orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, hipE
   // FAST's candidate counters are zeroed by the resize kernel (block 0): a memset between the blur and FAST is one more launch in the
   // chain -- 4.6 us of a 0.2 ms frame
   const bool zeroed_by_resize = !c->rs_regions.empty();  // (empty: the geometry rules the region-driven resize out -- the per-class tile launches)
+  // A frame or two: FAST's candidate lists in shards (k_fast.hip, SH) -- where FAST is ONE launch of one-cell waves and the quadtree the
+  // several-waves-per-tree launch that reads shards (the same conditions as launch_fast / launch_quadtree below)
+  // (contexts of <= 16 slots never group levels: one tree per level, several waves each, when the launch has at most one tree per CU)
+  const bool sharded = c->fast_shards > 1 && c->d_n_cand_sh && fast_single_launch(c->lv.data(), c->lvl_max_pw, c->lvl_max_ph, nl, n_img) &&
+                       (long long)nl * n_img <= c->n_cu;
+  int32_t* const n_cand_sh = sharded ? c->d_n_cand_sh + i0 * nl * c->fast_shards : nullptr;
+  for (int i = 0; i < n_img; ++i) c->slot_sharded[(size_t)(i0 + i)] = sharded ? 1 : 0;
   {
     StageTimer t(c, ORBFE_STAGE_RESIZE, st, timing);
     if (zeroed_by_resize)
       launch_resize_regions(st, c->d_lv, nl, c->d_rs_regions, (int)c->rs_regions.size(), c->rg_tile_bytes, c->rg_xt_bytes, c->rg_yt_bytes,
                             c->d_rg_xtaps, c->d_rg_ytaps, pyr, c->img_pitch, n_img, ext ? ext->left : pyr + c->lv[0].plane_off,
                             ext ? ext->right : nullptr, ext ? ext->pitch : c->img_pitch, ext ? ext->stride : c->lv[0].stride,
-                            ext ? ext->bytes : 0xFFFFFFFFu, ext ? 1 : 0, n_cand, n_img * nl, c->rg_pq, c->d_qt_next + i0, n_img);
+                            ext ? ext->bytes : 0xFFFFFFFFu, ext ? 1 : 0, n_cand, n_img * nl, c->rg_pq, sharded ? n_cand_sh : c->d_qt_next + i0,
+                            sharded ? n_img * nl * c->fast_shards : n_img);
     else
       launch_resize(st, c->d_lv, c->d_rs_tiles, c->rs_n, c->rs_bytes, c->d_taps, pyr, c->img_pitch, n_img);
   }
@@ -91,7 +99,10 @@ orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, hipE
     else
       launch_blur(st, c->d_lv, nl, 0, c->bl_tiles, pyr, blur, c->img_pitch, c->blur_taps, n_img);
   }
-  if (!zeroed_by_resize) HIP_TRY(c, hipMemsetAsync(n_cand, 0, sizeof(int32_t) * (size_t)n_img * nl, st));
+  if (!zeroed_by_resize) {
+    HIP_TRY(c, hipMemsetAsync(n_cand, 0, sizeof(int32_t) * (size_t)n_img * nl, st));
+    if (sharded) HIP_TRY(c, hipMemsetAsync(n_cand_sh, 0, sizeof(int32_t) * (size_t)n_img * nl * c->fast_shards, st));
+  }
   {
     StageTimer t(c, ORBFE_STAGE_FAST, st, timing);
     // r6: the launches of the SMALL levels -- fewer than 131072 cell x images: one or four cells per wave, each launch little more than a ramp
@@ -121,7 +132,7 @@ orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, hipE
     }
     launch_fast(st, c->d_lv, c->d_cells, c->lv.data(), c->lvl_max_pw, c->lvl_max_ph, pyr, c->img_pitch, c->cfg.fast_hi, c->cfg.fast_lo,
                 c->d_scr_a + i0 * c->scratch_pitch, c->scratch_pitch, n_cand, nl, n_img,
-                c->fast_cpw, side ? ~side_mask : ~0u);
+                c->fast_cpw, side ? ~side_mask : ~0u, false, n_cand_sh, sharded ? c->fast_shards : 1);
     if (side) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_fast_side_done, 0));
   }
   if (overlap_blur && !blur_queued) {
@@ -162,7 +173,8 @@ orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, hipE
                     c->cfg.n_features, n_cand, c->node_cap, c->sort_cap, rec_cap, n_img, 1, qt_tab, n_groups,
                     // helper waves for the data-parallel phases of a tree where the launch leaves the chip empty (a frame or two)
                     (!grouped && trees * 4 <= c->n_cu * 4) ? 4 : 1, c->d_qt_big ? c->d_qt_big + i0 * c->qt_big_pitch : nullptr,
-                    c->qt_big_pitch, c->d_qt_tabs, blur_in_qt ? pyr : nullptr, blur, c->img_pitch, c->blur_taps, c->bl_tiles, c->d_qt_next + i0, zeroed_by_resize);
+                    c->qt_big_pitch, c->d_qt_tabs, blur_in_qt ? pyr : nullptr, blur, c->img_pitch, c->blur_taps, c->bl_tiles, c->d_qt_next + i0,
+                    zeroed_by_resize && !sharded, n_cand_sh, sharded ? c->fast_shards : 1);
   }
   {
     StageTimer t(c, ORBFE_STAGE_BRIEF, st, timing);

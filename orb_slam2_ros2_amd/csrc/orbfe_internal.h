@@ -74,6 +74,8 @@ struct QtGroups {
 };
 
 // Per pyramid level, resident in device memory (one table per context).
+// A frame or two: k_fast appends a level's candidates to ORBFE_FAST_SHARDS lists (cell index mod shards) instead of one -- see k_fast.hip
+#define ORBFE_FAST_SHARDS 16
 struct LevelDev {
   int32_t w, h, stride;  // plane size, row pitch in bytes (multiple of 16)
   uint32_t plane_off;    // byte offset of the plane inside one image's pyramid buffer
@@ -90,6 +92,7 @@ struct LevelDev {
   // candidate list / quadtree
   uint32_t cand_base;    // first record (uint32 units) of this level inside one image's candidate buffer
   uint32_t cand_cap;     // = n_cells * cell_cap
+  uint32_t shard_cap;    // contexts of a frame or two (ORBFE_FAST_SHARDS): records of ONE shard of the level's region, ceil(n_cells / shards) * cell_cap; else 0
   int32_t n_ini;         // root strips
   // a level whose quota does not fit the node table one CU's LDS can hold keeps its table (and sort buffer) in global memory:
   // qt_big_cap > 0 nodes at byte offset qt_big_off of the image's block of the context's d_qt_big buffer, qt_big_sort keys to sort
