@@ -51,6 +51,25 @@ def assert_image_parity(ctx, slot, ex, gk, gd, n_levels, check_planes=True):
     return ok, od
 
 
+
+@pytest.mark.parametrize("slots,env", [(2, "1"), (40, None), (2, None)])
+def test_a_pair_with_and_without_sharded_candidate_lists(orc, lib, monkeypatch, slots, env):
+    """A frame or two in a context of <= 16 slots: k_fast appends a level's candidates to sixteen shards and the small-launch quadtree reads
+    them (r6).  ORBFE_FAST_SHARDS=1, or a context of more slots, keeps one list per level on the same launches -- all three against the oracle,
+    candidate sets included (orbfe_debug_candidates gathers the shards)."""
+    if env is not None:
+        monkeypatch.setenv("ORBFE_FAST_SHARDS", env)
+    ctx = lib.Context(1241, 376, max_images=slots)
+    try:
+        L, R = synth.stereo_pair(11)
+        (lk, ld), (rk, rd) = ctx.extract_batch([L, R])
+        assert_image_parity(ctx, 0, orc.extractor(L), lk, ld, 8, check_planes=False)
+        assert_image_parity(ctx, 1, orc.extractor(R), rk, rd, 8, check_planes=False)
+        k1, d1 = ctx.extract(R)   # one image alone, into the slot the left image used
+        assert_image_parity(ctx, 0, orc.extractor(R), k1, d1, 8, check_planes=False)
+    finally:
+        ctx.close()
+
 @pytest.mark.parametrize("f", [0, 1, 7])
 def test_kitti_stereo_frame_bit_exact_and_golden(orc, kitti_ctx, f):
     L, R = synth.stereo_pair(f)
