@@ -849,7 +849,11 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
         n_act = 0;     // halves every point until it sits on a split line and returns the empty set (quirk Q3)
         break;
       }
-      uint32_t C = (mc >> 1) + 1;  // the head = every node with count >= C: a prefix of the pop order whatever C is
+      // (r6) several waves per tree: the head from a QUARTER of the largest count, not half -- a level-0 tree of the bench frames takes six
+      // batched steps instead of seven (a pair's trees 43.9 -> 42.0 us; an eighth: no fewer).  The one-wave batch kernel keeps half: same-box,
+      // rect 0.255 -> 0.250 ms but saturated (38 k candidates: larger heads of large ordinary nodes, more of them invalid) 0.432 -> 0.470.
+      constexpr int QT_HEAD_SHIFT = NW == 1 ? 1 : 2;
+      uint32_t C = max((mc >> QT_HEAD_SHIFT) + 1u, 2u);  // the head = every node with count >= C: a prefix of the pop order whatever C is
       int B;
       for (;;) {
         uint32_t cnt = 0;
