@@ -1237,6 +1237,60 @@ __device__ __forceinline__ void tree_body(const LevelDev& L, const uint32_t* __r
 
   QTS(-2)  // expansion done (single pops included in the last interval)
   // ---- nodes2kpoints (ORBExtractor.cc:182-192): keep the first min(need, size) nodes in map order ----
+  // (r6) The last pop overshoots the quota by at most three nodes.  Dropping them one at a time -- a scan of the whole table, two wave
+  // reductions and two waits each -- was 5.3 k of a level-0 tree's 94 k cycles, with every helper wave waiting.  Where counts and sequence
+  // numbers fit 16 bits each (always, on tables the batched steps handle) the keys are read ONCE as 32-bit surrogates count << 16 | ~seq
+  // (the same order), every drop is one lane-minimum over registers and one wave reduction, and the holes are filled from the table's
+  // tail at the end (any order: the selection below ranks by candidate order).
+  if (NODES_LDS && n_act > need && n_act - need <= 4 && n_act <= 512 && next_seq < 65536u && N <= 65535) {
+    const int d = n_act - need, new_n = need;
+    uint32_t k32[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = u * 64 + lane;
+      k32[u] = 0xFFFFFFFFu;
+      if (u * 64 < n_act && j < n_act) {
+        const unsigned long long key = n_key[j];
+        k32[u] = ((uint32_t)(key >> 32) << 16) | ((uint32_t)key & 0xFFFFu);
+      }
+    }
+    int hole[4] = {-1, -1, -1, -1};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q < d) {  // uniform
+        uint32_t lm = k32[0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) lm = min(lm, k32[u]);
+        const uint32_t m = wave_min_u32(lm);
+        int ju = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool hit = k32[u] == m;  // (keys are distinct: one register of one lane)
+          ju = hit ? u * 64 + lane : ju;
+          k32[u] = hit ? 0xFFFFFFFFu : k32[u];
+        }
+        const unsigned long long win = __ballot(lm == m);
+        hole[q] = __builtin_amdgcn_readlane(ju, __ffsll((long long)win) - 1);
+      }
+    }
+    // survivors of the tail [new_n, n_act) -> the holes below new_n (as many of the one as of the other)
+    int hi = 0;
+    for (int t = new_n; t < n_act; ++t) {  // d trips, everything uniform
+      const bool dropped = t == hole[0] || t == hole[1] || t == hole[2] || t == hole[3];
+      if (!dropped) {
+        int h = -1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (h < 0 && q >= hi && hole[q] >= 0 && hole[q] < new_n) h = hole[q], hi = q + 1;
+        if (lane == 0 && h >= 0) {
+          n_key[h] = n_key[t];
+          n_bp[h] = n_bp[t];
+        }
+      }
+    }
+    n_act = new_n;
+    qt_wsync<NW>();
+  }
   while (n_act > need) {
     // drop the last node in map order = arg-min of the key
     uint32_t bc = 0xFFFFFFFFu, bs = 0xFFFFFFFFu;
