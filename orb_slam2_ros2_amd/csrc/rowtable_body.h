@@ -22,10 +22,19 @@ __device__ __forceinline__ void rowtable_build(const KpAux* __restrict__ A, int 
     KpAux a[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) a[k] = A[min(i0 + 256 * k, nr - 1)];
+    // (r6) the eight bands of a thread are walked TOGETHER, one row of each per trip: eight independent LDS atomics in flight where a
+    // band after the other was eight chains of dependent ones -- the scatter pass below (returning atomics, a store behind each) was
+    // most of this workgroup's 14 us, and the workgroup the long pole of a pair's descriptor launch
+    int len = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (i0 + 256 * k < nr)
-        for (int y = a[k].row_min; y < a[k].row_max; ++y) atomicAdd(&cnt[y], 1u);  // (k_orient clips the band to [0, rows])
+    for (int k = 0; k < 8; ++k) len = max(len, (i0 + 256 * k < nr) ? (int)a[k].row_max - (int)a[k].row_min : 0);
+    for (int t = 0; t < len; ++t) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int y = (int)a[k].row_min + t;
+        if (i0 + 256 * k < nr && y < (int)a[k].row_max) atomicAdd(&cnt[y], 1u);  // (k_orient clips the band to [0, rows])
+      }
+    }
   }
   __syncthreads();
   // exclusive prefix sum over the rows: a run of rows per thread, the 256 run totals scanned in LDS
@@ -55,14 +64,19 @@ __device__ __forceinline__ void rowtable_build(const KpAux* __restrict__ A, int 
     KpAux a[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) a[k] = A[min(i0 + 256 * k, nr - 1)];
+    int len = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int i = i0 + 256 * k;
-      if (i < nr)
-        for (int y = a[k].row_min; y < a[k].row_max; ++y) {
-          const uint32_t p = atomicAdd(&cnt[y], 1u);
-          if (p < (uint32_t)list_cap) RL[p] = (uint16_t)i;  // (list_cap = n_features x the widest band: always true)
-        }
+    for (int k = 0; k < 8; ++k) len = max(len, (i0 + 256 * k < nr) ? (int)a[k].row_max - (int)a[k].row_min : 0);
+    for (int t = 0; t < len; ++t) {
+      uint32_t pos[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int y = (int)a[k].row_min + t;
+        pos[k] = (i0 + 256 * k < nr && y < (int)a[k].row_max) ? atomicAdd(&cnt[y], 1u) : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (pos[k] < (uint32_t)list_cap) RL[pos[k]] = (uint16_t)(i0 + 256 * k);  // (list_cap = n_features x the widest band: always true for a real position)
     }
   }
 }
