@@ -13,6 +13,8 @@
 //    the reference does (double product -> float, float add, round-half-even); one __ballot per group of
 //    64 tests yields 8 descriptor bytes already in the reference's LSB-first order.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
 
 #include "orb_math.h"
 #include "orbfe_internal.h"
@@ -205,7 +207,9 @@ __global__ __launch_bounds__(256) void k_orient(const LevelDev* __restrict__ lv,
     kp.octave = level;
     kp.class_id = -1;
     kps[o] = kp;
-    if (kps_host) kps_host[o] = kp;
+  #ifndef EXP_NO_KPS_HOST
+  if (kps_host) kps_host[o] = kp;
+#endif
     kx[o] = kpx_of(kp, L.sf);
     // createRowIndexDB band (ORBMatcher.cc:924-927), stored with the keypoint for the stereo matcher
     const float r = (float)(2.0 * (double)L.sf);
@@ -324,7 +328,9 @@ __global__ __launch_bounds__(256) void k_list_moments_orient(const LevelDev* __r
   kp.octave = level;
   kp.class_id = -1;
   kps[o] = kp;
+#ifndef EXP_NO_KPS_HOST
   if (kps_host) kps_host[o] = kp;
+#endif
   kx[o] = kpx_of(kp, L.sf);
   const float r = (float)(2.0 * (double)L.sf);
   const unsigned row = (unsigned)__float2int_rn(kp.y);
@@ -349,6 +355,16 @@ __global__ __launch_bounds__(256) void k_list_moments_orient(const LevelDev* __r
 #endif
 #ifndef BRIEF_KPW
 #define BRIEF_KPW 2  // consecutive keypoints per wave (measured: 2 and 3 equal, 4 and 8 slower -- fewer, longer waves balance worse)
+#endif
+#ifdef BRIEF_STAMPS  // diagnostic build only (tools/exp/brief_stamps.sh): start / end of every descriptor wave and of the row-table workgroups, 100 MHz ticks
+__device__ unsigned long long g_bs_rec[8192][6];  // [wave]: start, first window parked, end, kind (1 descriptor wave, 2 row-table workgroup), list entry arrived, window arrived
+#define BS_DECL const unsigned bs_w = ((blockIdx.y * 520u + blockIdx.x) * BRIEF_WAVES + (threadIdx.x >> 6)) & 8191u; const unsigned long long bs_t0 = __builtin_amdgcn_s_memrealtime(); unsigned long long bs_t1 = 0, bs_ta = 0, bs_tb = 0;
+#define BS_MID if (!bs_t1) bs_t1 = __builtin_amdgcn_s_memrealtime();
+#define BS_END(kind) if ((threadIdx.x & 63) == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g_bs_rec[bs_w][0] = bs_t0, g_bs_rec[bs_w][1] = bs_t1, g_bs_rec[bs_w][2] = __builtin_amdgcn_s_memrealtime(), g_bs_rec[bs_w][3] = kind, g_bs_rec[bs_w][4] = bs_ta, g_bs_rec[bs_w][5] = bs_tb; }
+#else
+#define BS_DECL
+#define BS_MID
+#define BS_END(kind)
 #endif
 struct BriefRowTable {  // rowoff == nullptr: descriptor blocks only
   const KpAux* aux;      // of the launch's first image
@@ -378,6 +394,7 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_e
                     (sizeof(double) * 40 * BRIEF_WAVES + sizeof(uint32_t) * (BRIEF_ROWS * BRIEF_WORDS + 1) * BRIEF_WAVES) % 512 != 0,
                 "rc[w] and rs[w] must not be reachable by one ds_read2(st64)_b64");
   __shared__ Lds lds;
+  BS_DECL
   if (rt.rowoff && (int)blockIdx.x >= rt.n_brief_blocks) {
     // A frame or two: the LAST eight workgroups of a row are not descriptor blocks; the first of them builds the row table of the image
     // (ORBMatcher::createRowIndexDB, ORBMatcher.cc:915-932: it needs the row bands k_orient left, nothing of this kernel) into the
@@ -390,6 +407,7 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_e
     if (threadIdx.x == 0) rt.n_match[slot >> 1] = 0;
     rowtable_build(rt.aux + (size_t)blockIdx.y * n_features, min(rt.n_kp[blockIdx.y], n_features), rt.rows, rt.list_cap,
                    rt.rowoff + (size_t)slot * (rt.rows + 1), rt.rowlist + (size_t)slot * rt.list_cap, cnt, cnt + rt.rows, (int)threadIdx.x);
+    BS_END(2)
     return;
   }
   const int lane = threadIdx.x & 63;
@@ -399,7 +417,11 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_e
   // XCD-aware block order: workgroups go round-robin to the 8 XCDs (own L2 each) and consecutive keypoints are spatial neighbours
   // (candidate order) whose 37x37 windows overlap; block b of the grid takes keypoint block (b % 8) * (grid / 8) + b / 8, so one XCD
   // works through one contiguous eighth of the list (gridDim.x is a multiple of 8).  Fetched bytes 2.69 -> 0.85 GB per 1024 images.
-  const int per_xcd = (rt.rowoff ? rt.n_brief_blocks : (int)gridDim.x) >> 3;
+  // (r6: the number of descriptor blocks is a kernel ARGUMENT in both forms.  It used to be gridDim.x for the batches -- and the compiler
+  //  derived that from the dispatch packet, which lives in the queue's ring buffer in HOST memory: every wave of the launch began with a
+  //  scalar load across PCIe that no cache holds.  A pair's 2000 waves queued for it -- first data after 13.6 us on average, 26.5 at worst,
+  //  whatever they asked for first (stamps build, tools/exp/brief_stamps.sh) -- and the launch took 18 - 31 us.)
+  const int per_xcd = rt.n_brief_blocks >> 3;
   const int kb = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
   const int k0 = (kb * BRIEF_WAVES + (threadIdx.x >> 6)) * BRIEF_KPW;
   const int img = blockIdx.y;
@@ -412,17 +434,27 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_e
   const double2* sc = sincos + (size_t)img * n_features;
   const uint8_t* W = blur + (size_t)img * img_pitch;  // wave-uniform base; the rest of the address is a 32-bit offset
   const int k_last = min(k0 + BRIEF_KPW, n_features) - 1;
-  uint32_t tp[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) tp[g] = *(const uint32_t*)(pattern + (g * 64 + lane) * 4);
+  const uint32_t tp0 = *(const uint32_t*)(pattern + (0 * 64 + lane) * 4), tp1 = *(const uint32_t*)(pattern + (1 * 64 + lane) * 4);
+  const uint32_t tp2 = *(const uint32_t*)(pattern + (2 * 64 + lane) * 4), tp3 = *(const uint32_t*)(pattern + (3 * 64 + lane) * 4);
+#ifdef BRIEF_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" :: "v"(tp0), "v"(tp1), "v"(tp2), "v"(tp3) : "memory");
+  bs_t1 = __builtin_amdgcn_s_memrealtime();  // (pattern arrived; the "first window parked" stamp is not taken in this build)
+#endif
   // window load: 5 rows x 11 words per pass over lanes 0..54 (lane = 11 r0 + c0), 8 passes; a pass adds a wave-uniform 5 * stride to
   // one address and parks its words at lane + 55 * pass -- one v_add per load where the flat index -> (row, word) split cost five
   constexpr int NIT = (BRIEF_ROWS + 4) / 5;
   const int ll = min(lane, 54);
   const int r0 = (ll * 373) >> 12, c0 = ll - r0 * BRIEF_WORDS;  // ll / 11 for ll < 64
   const int r_last = min(r0 + 5 * (NIT - 1), BRIEF_ROWS - 1);    // last pass: rows 35, 36 exist, the lanes of rows 37..39 re-read row 36
+  // (r6: the eight window words as two VECTORS, named component by component.  As an array `uint32_t wv[NIT]` the stage records that
+  //  rotate through the keypoint loop were private arrays the compiler moved to LDS, 32 bytes per thread addressed by the FLAT thread
+  //  number -- for which it reads the workgroup's y and z sizes from the dispatch packet, and that packet lives in the queue's ring
+  //  buffer in HOST memory: every wave of every launch of this kernel began with a scalar load across PCIe that no cache holds.  A pair's
+  //  2000 waves queued for theirs: first data after 13.6 us on average, 26.5 at worst, whatever they had asked for (stamps build,
+  //  tools/exp/brief_stamps.sh), a launch of 18 - 31 us.  No kernel of this library may touch blockDim / gridDim or keep a private array.)
+  static_assert(NIT == 8, "Stage holds eight window words");
   struct Stage {
-    uint32_t wv[NIT];
+    uint4 wa, wb;
     double2 scv;
   };
   // requests the window and sin / cos of the keypoint in entry e (an unused slot -- x = 0xFFFF -- reads row 0 of plane 0: harmless)
@@ -434,15 +466,25 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_e
     const int xa = (x - BRIEF_R) & ~3;
     const uint32_t step = 5u * (uint32_t)__builtin_amdgcn_readfirstlane(stride);
     const uint32_t a0 = plane + (uint32_t)mad24u(y - BRIEF_R + r0, stride, xa + 4 * c0);
-#pragma unroll
-    for (int it = 0; it < NIT - 1; ++it) st.wv[it] = *(const uint32_t*)(W + (a0 + (uint32_t)it * step));
-    st.wv[NIT - 1] = *(const uint32_t*)(W + (plane + (uint32_t)mad24u(y - BRIEF_R + r_last, stride, xa + 4 * c0)));
+#define BRIEF_WLD(it) (*(const uint32_t*)(W + (a0 + (uint32_t)(it) * step)))
+    st.wa.x = BRIEF_WLD(0), st.wa.y = BRIEF_WLD(1), st.wa.z = BRIEF_WLD(2), st.wa.w = BRIEF_WLD(3);
+    st.wb.x = BRIEF_WLD(4), st.wb.y = BRIEF_WLD(5), st.wb.z = BRIEF_WLD(6);
+#undef BRIEF_WLD
+    st.wb.w = *(const uint32_t*)(W + (plane + (uint32_t)mad24u(y - BRIEF_R + r_last, stride, xa + 4 * c0)));
     st.scv = sc[k];
   };
   uint4 e_cur = list[k0];
   uint4 e_nxt = list[min(k0 + 1, k_last)];
+#ifdef BRIEF_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bs_ta = __builtin_amdgcn_s_memrealtime();
+#endif
   Stage st_cur;
   request(e_cur, k0, st_cur);
+#ifdef BRIEF_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bs_tb = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
   for (int i = 0; i < BRIEF_KPW; ++i) {
     const int k = k0 + i;
@@ -455,9 +497,9 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_e
       const int x = (int)(e_cur.x & 0xFFFFu), y = (int)(e_cur.x >> 16);
       const int xa = (x - BRIEF_R) & ~3;
       if (lane < 55) {
-#pragma unroll
-        for (int it = 0; it < NIT - 1; ++it) win[lane + 55 * it] = st_cur.wv[it];
-        if (r0 + 5 * (NIT - 1) < BRIEF_ROWS) win[lane + 55 * (NIT - 1)] = st_cur.wv[NIT - 1];
+        win[lane] = st_cur.wa.x, win[lane + 55] = st_cur.wa.y, win[lane + 110] = st_cur.wa.z, win[lane + 165] = st_cur.wa.w;
+        win[lane + 220] = st_cur.wb.x, win[lane + 275] = st_cur.wb.y, win[lane + 330] = st_cur.wb.z;
+        if (r0 + 5 * (NIT - 1) < BRIEF_ROWS) win[lane + 385] = st_cur.wb.w;
       }
       const double sn = st_cur.scv.x, cs = st_cur.scv.y;
       // The rotation needs x cos, x sin, y cos, y sin in fp64 for 512 template points, but the coordinates are small integers:
@@ -472,6 +514,7 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_e
       // wave; the fence only pins the compiler
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      BS_MID
       const float px = (float)x, py = (float)y;
       // cvRound(float sum) and the window address without a subtraction.  Adding 1.5 * 2^23 rounds a float sum to an integer with ties to
       // even -- the unit in the last place of the result is 1 -- and leaves that integer in the low mantissa bits (0x4B400000 + n).  An
@@ -485,11 +528,9 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_e
       const int y0w = y - BRIEF_R;
       const float magic_y = (float)(12582912 - (y0w & ~1));
       const float magic_x = (float)(12582912 - xa + (int)(uint32_t)(uintptr_t)(lds_bytes_t)(const uint8_t*)win - (y0w & 1) * (BRIEF_WORDS * 4));
-      unsigned long long bits[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int x1 = (int)(int8_t)(tp[g] & 255u), y1 = (int)(int8_t)((tp[g] >> 8) & 255u);
-        const int x2 = (int)(int8_t)((tp[g] >> 16) & 255u), y2 = (int)(int8_t)(tp[g] >> 24);
+      auto tests = [&](const uint32_t tpg) __attribute__((always_inline)) -> unsigned long long {
+        const int x1 = (int)(int8_t)(tpg & 255u), y1 = (int)(int8_t)((tpg >> 8) & 255u);
+        const int x2 = (int)(int8_t)((tpg >> 16) & 255u), y2 = (int)(int8_t)(tpg >> 24);
         // float * double -> double, one rounding to float (rotateTemplate, ORBExtractor.cc:537-538)
         const float p1x = (float)(rc[x1 + BRIEF_R] - rs[y1 + BRIEF_R]);  // x1 cos - y1 sin
         const float p1y = (float)(rs[x1 + BRIEF_R] + rc[y1 + BRIEF_R]);  // x1 sin + y1 cos
@@ -499,14 +540,16 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_e
         const uint32_t a2 = (uint32_t)mad24u(__float_as_int((py + p2y) + magic_y), BRIEF_WORDS * 4, __float_as_int((px + p2x) + magic_x)) & 0xFFFFu;
         const int v1 = *(lds_bytes_t)(uintptr_t)a1;
         const int v2 = *(lds_bytes_t)(uintptr_t)a2;
-        bits[g] = __ballot(v1 < v2);
-      }
+        return __ballot(v1 < v2);
+      };
+      // (four named words, not an array: see Stage above)
+      const unsigned long long bits0 = tests(tp0), bits1 = tests(tp1), bits2 = tests(tp2), bits3 = tests(tp3);
       if (lane < 4) {
         unsigned long long* d64 = (unsigned long long*)(desc + ((size_t)img * n_features + k) * 32);
-        unsigned long long b = bits[0];
-        if (lane == 1) b = bits[1];
-        if (lane == 2) b = bits[2];
-        if (lane == 3) b = bits[3];
+        unsigned long long b = bits0;
+        if (lane == 1) b = bits1;
+        if (lane == 2) b = bits2;
+        if (lane == 3) b = bits3;
         d64[lane] = b;
         if (desc_host) ((unsigned long long*)(desc_host + ((size_t)img * n_features + k) * 32))[lane] = b;
       }
@@ -520,7 +563,39 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_e
       st_cur = st_nxt;
     }
   }
+  BS_END(1)
 }
+#ifdef BRIEF_STAMPS
+}  // namespace orbfe
+extern "C" void orbfe_debug_brief_stamps() {
+  static unsigned long long rec[8192][6];
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(rec, HIP_SYMBOL(orbfe::g_bs_rec), sizeof(rec));
+  unsigned long long first = ~0ull, last = 0, n = 0, sum = 0, mx = 0, mid = 0, rt0 = 0, rt1 = 0, dlast = 0, sa = 0, sb = 0, ma = 0, mb = 0, smax = 0;
+  for (int w = 0; w < 8192; ++w) {
+    if (!rec[w][3]) continue;
+    first = first < rec[w][0] ? first : rec[w][0], last = last > rec[w][2] ? last : rec[w][2];
+    if (rec[w][3] == 1) {
+      ++n, sum += rec[w][2] - rec[w][0], mx = mx > rec[w][2] - rec[w][0] ? mx : rec[w][2] - rec[w][0], mid += rec[w][1] ? rec[w][1] - rec[w][0] : 0;
+      dlast = dlast > rec[w][2] ? dlast : rec[w][2];
+      sa += rec[w][4] - rec[w][0], sb += rec[w][5] - rec[w][4];
+      ma = ma > rec[w][4] - rec[w][0] ? ma : rec[w][4] - rec[w][0], mb = mb > rec[w][5] - rec[w][4] ? mb : rec[w][5] - rec[w][4];
+    }
+  }
+  printf("BRIEF stamps (last launch): %llu descriptor waves, launch span %.2f us, last descriptor wave ends at %.2f us; wave mean %.2f max %.2f us, pattern words arrive after %.2f us (mean)\n",
+         n, (last - first) * 0.01, (dlast - first) * 0.01, n ? sum * 0.01 / n : 0.0, mx * 0.01, n ? mid * 0.01 / n : 0.0);
+  for (int w = 0; w < 8192; ++w)
+    if (rec[w][3] == 1) smax = smax > rec[w][0] - first ? smax : rec[w][0] - first;
+  printf("  pattern + list entries arrive after %.2f us (mean, max %.2f); window + sin/cos %.2f us later (mean, max %.2f); last descriptor wave starts at %.2f us\n",
+         n ? sa * 0.01 / n : 0.0, ma * 0.01, n ? sb * 0.01 / n : 0.0, mb * 0.01, smax * 0.01);
+  for (int w = 0; w < 8192; ++w)
+    if (rec[w][3] == 2 && (w & 3) == 0) printf("  row-table workgroup: starts %.2f us, ends %.2f us after the launch's first wave\n", (rec[w][0] - first) * 0.01, (rec[w][2] - first) * 0.01);
+  memset(rec, 0, sizeof(rec));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(orbfe::g_bs_rec), rec, sizeof(rec));
+  (void)rt0, (void)rt1;
+}
+namespace orbfe {
+#endif
 
 void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, const uint8_t* d_pyr, const uint8_t* d_blur,
                          size_t img_pitch, const uint32_t* d_sel, const int32_t* d_sel_count, int n_features,
@@ -540,10 +615,15 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
     if (before_brief) (void)hipStreamWaitEvent(s, before_brief, 0);
     const int nb = (((n_features + BRIEF_WAVES * BRIEF_KPW - 1) / (BRIEF_WAVES * BRIEF_KPW)) + 7) & ~7;
     BriefRowTable rt{};
+    rt.n_brief_blocks = nb;
     if (d_rowoff_slot && (size_t)(rt_rows + 4) * 4 <= 9000)
       rt = BriefRowTable{d_aux, d_n_kp, d_rowoff_slot, d_rowlist_slot, d_n_match, rt_rows, rt_list_cap, rt_slot0, nb};
     hipLaunchKernelGGL(k_brief, dim3(nb + (rt.rowoff ? 8 : 0), n_img), dim3(64 * BRIEF_WAVES), 0, s, d_blur, img_pitch, d_kpl, n_features, d_pattern,
                        d_sincos, d_desc, h_desc, rt);
+#ifdef EXP_BRIEF_TWICE
+    hipLaunchKernelGGL(k_brief, dim3(nb + (rt.rowoff ? 8 : 0), n_img), dim3(64 * BRIEF_WAVES), 0, s, d_blur, img_pitch, d_kpl, n_features, d_pattern,
+                       d_sincos, d_desc, h_desc, rt);
+#endif
     return;
   }
   // (measured and dropped: two or three groups of four keypoints per wave in k_ic_moments, all their loads in flight together -- the stage
@@ -561,8 +641,10 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
   hipLaunchKernelGGL(k_orient, dim3((n_features + 255) / 256, n_img), dim3(256), 0, s, d_lv, d_kpl, n_features, d_moments, d_sincos,
                      d_kps, d_aux, d_kx, d_theta, rows0, d_sel_count, n_levels, d_n_kp, h_kps, h_n_kp);
   if (before_brief) (void)hipStreamWaitEvent(s, before_brief, 0);  // the blurred planes come from another stream
-  hipLaunchKernelGGL(k_brief, dim3((((n_features + BRIEF_WAVES * BRIEF_KPW - 1) / (BRIEF_WAVES * BRIEF_KPW)) + 7) & ~7, n_img), dim3(64 * BRIEF_WAVES), 0, s,
-                     d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos, d_desc, h_desc, BriefRowTable{});
+  BriefRowTable rt_none{};
+  rt_none.n_brief_blocks = (((n_features + BRIEF_WAVES * BRIEF_KPW - 1) / (BRIEF_WAVES * BRIEF_KPW)) + 7) & ~7;  // (= the grid: no row-table blocks)
+  hipLaunchKernelGGL(k_brief, dim3(rt_none.n_brief_blocks, n_img), dim3(64 * BRIEF_WAVES), 0, s, d_blur, img_pitch, d_kpl, n_features, d_pattern, d_sincos, d_desc,
+                     h_desc, rt_none);
 }
 
 }  // namespace orbfe
