@@ -18,6 +18,11 @@
 
 #include "orb_math.h"
 #include "orbfe_internal.h"
+#ifdef BRIEF_STAMPS
+namespace orbfe { extern __device__ unsigned long long g_rt_t[4][8]; }
+#define RT_STAMP(k) { __syncthreads(); if (tid == 0 && blockIdx.y == 0) orbfe::g_rt_t[k][0] = __builtin_amdgcn_s_memrealtime(); }
+#define RTP_STAMP(k) { __syncthreads(); if (tid == 0 && blockIdx.y == 0) orbfe::g_rt_t[k][r] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 #include "rowtable_body.h"
 #include "wave_ops.h"
 
@@ -235,9 +240,12 @@ __global__ __launch_bounds__(256) void k_list_moments_orient(const LevelDev* __r
                                                              uint4* __restrict__ kpl, int2* __restrict__ moments, double2* __restrict__ sincos,
                                                              orbfe_keypoint* __restrict__ kps, KpAux* __restrict__ aux, KpX* __restrict__ kx,
                                                              double* __restrict__ theta_out, int rows0, int32_t* __restrict__ n_kp,
-                                                             orbfe_keypoint* __restrict__ kps_host, int32_t* __restrict__ n_kp_host) {
+                                                             orbfe_keypoint* __restrict__ kps_host, int32_t* __restrict__ n_kp_host,
+                                                             int32_t* __restrict__ rt_flags) {
 #pragma clang fp contract(off)
   __shared__ uint32_t s_mask[256];
+  // (rt_flags, nullable: the eight part totals of the row table the descriptor launch behind this one builds -- rowtable_build_part)
+  if (rt_flags && blockIdx.x == 0 && threadIdx.x < 8) rt_flags[blockIdx.y * 8 + threadIdx.x] = 0;
   {
     const int it = threadIdx.x >> 4, sb = threadIdx.x & 15;
     const int dy = (sb >> 3) + 2 * it - 15;
@@ -357,6 +365,7 @@ __global__ __launch_bounds__(256) void k_list_moments_orient(const LevelDev* __r
 #define BRIEF_KPW 2  // consecutive keypoints per wave (measured: 2 and 3 equal, 4 and 8 slower -- fewer, longer waves balance worse)
 #endif
 #ifdef BRIEF_STAMPS  // diagnostic build only (tools/exp/brief_stamps.sh): start / end of every descriptor wave and of the row-table workgroups, 100 MHz ticks
+__device__ unsigned long long g_rt_t[4][8];
 __device__ unsigned long long g_bs_rec[8192][6];  // [wave]: start, first window parked, end, kind (1 descriptor wave, 2 row-table workgroup), list entry arrived, window arrived
 #define BS_DECL const unsigned bs_w = ((blockIdx.y * 520u + blockIdx.x) * BRIEF_WAVES + (threadIdx.x >> 6)) & 8191u; const unsigned long long bs_t0 = __builtin_amdgcn_s_memrealtime(); unsigned long long bs_t1 = 0, bs_ta = 0, bs_tb = 0;
 #define BS_MID if (!bs_t1) bs_t1 = __builtin_amdgcn_s_memrealtime();
@@ -373,6 +382,8 @@ struct BriefRowTable {  // rowoff == nullptr: descriptor blocks only
   uint16_t* rowlist;
   int32_t* n_match;      // per pair
   int rows, list_cap, slot0, n_brief_blocks;
+  int stage_cap;  // entries of dynamic LDS the row-table workgroup may assemble its list in (0: none)
+  int32_t* flags;  // != nullptr: the table by all eight spare workgroups (rowtable_build_part): their totals, [image][8], zeroed by the launch before
 };
 __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_brief(const uint8_t* __restrict__ blur, size_t img_pitch,
                                               const uint4* __restrict__ kpl, int n_features, const int8_t* __restrict__ pattern,
@@ -400,13 +411,27 @@ __global__ __launch_bounds__(64 * BRIEF_WAVES) __attribute__((amdgpu_waves_per_e
     // (ORBMatcher::createRowIndexDB, ORBMatcher.cc:915-932: it needs the row bands k_orient left, nothing of this kernel) into the
     // slot's own table and zeroes the match counter of the slot's pair, so that an orbfe_stereo_match that follows launches k_stereo
     // alone -- 14 us of table building run beside the descriptors instead of in front of the match
-    if ((int)blockIdx.x != rt.n_brief_blocks) return;
+    // (r6) ... all EIGHT of them now, an eighth of the rows each (rowtable_build_part): one workgroup's 14 us were the launch's long pole.
     static_assert(sizeof(Lds) >= 9000, "the table's row counters borrow the descriptor kernel's LDS (launch_orient_brief checks the row count against 9000 bytes)");
     uint32_t* cnt = (uint32_t*)&lds;
     const int slot = rt.slot0 + (int)blockIdx.y;
+    const int r = (int)blockIdx.x - rt.n_brief_blocks;
+    if (rt.flags) {
+      if (r == 0 && threadIdx.x == 0) rt.n_match[slot >> 1] = 0;
+      const int rpw = (rt.rows + 7) >> 3;
+      extern __shared__ __attribute__((aligned(16))) uint2 brief_bands[];  // (dynamic LDS of the small launches: rt.stage_cap / 4 band records)
+      rowtable_build_part(rt.aux + (size_t)blockIdx.y * n_features, min(rt.n_kp[blockIdx.y], n_features), rt.rows, rt.list_cap,
+                          rt.rowoff + (size_t)slot * (rt.rows + 1), rt.rowlist + (size_t)slot * rt.list_cap, cnt, cnt + rpw + 12, (int)threadIdx.x, r,
+                          rt.flags + (size_t)blockIdx.y * 8, rt.stage_cap > 0 ? brief_bands : nullptr, rt.stage_cap / 4);
+      BS_END(2)
+      return;
+    }
+    if (r != 0) return;
     if (threadIdx.x == 0) rt.n_match[slot >> 1] = 0;
+    extern __shared__ __attribute__((aligned(16))) uint16_t brief_stage[];  // (dynamic LDS of the small launches: rt.stage_cap entries)
     rowtable_build(rt.aux + (size_t)blockIdx.y * n_features, min(rt.n_kp[blockIdx.y], n_features), rt.rows, rt.list_cap,
-                   rt.rowoff + (size_t)slot * (rt.rows + 1), rt.rowlist + (size_t)slot * rt.list_cap, cnt, cnt + rt.rows, (int)threadIdx.x);
+                   rt.rowoff + (size_t)slot * (rt.rows + 1), rt.rowlist + (size_t)slot * rt.list_cap, cnt, cnt + rt.rows, (int)threadIdx.x,
+                   rt.stage_cap > 0 ? brief_stage : nullptr, rt.stage_cap);
     BS_END(2)
     return;
   }
@@ -590,6 +615,13 @@ extern "C" void orbfe_debug_brief_stamps() {
          n ? sa * 0.01 / n : 0.0, ma * 0.01, n ? sb * 0.01 / n : 0.0, mb * 0.01, smax * 0.01);
   for (int w = 0; w < 8192; ++w)
     if (rec[w][3] == 2 && (w & 3) == 0) printf("  row-table workgroup: starts %.2f us, ends %.2f us after the launch's first wave\n", (rec[w][0] - first) * 0.01, (rec[w][2] - first) * 0.01);
+  {
+    unsigned long long rt[4][8];
+    (void)hipMemcpyFromSymbol(rt, HIP_SYMBOL(orbfe::g_rt_t), sizeof(rt));
+    for (int r = 0; r < 8; ++r)
+      printf("  row table part %d (image 0): zeroed %.2f | counted %.2f | lower parts known %.2f | scattered %.2f us after the launch's first wave\n", r,
+             (rt[0][r] - first) * 0.01, (rt[1][r] - first) * 0.01, (rt[2][r] - first) * 0.01, (rt[3][r] - first) * 0.01);
+  }
   memset(rec, 0, sizeof(rec));
   (void)hipMemcpyToSymbol(HIP_SYMBOL(orbfe::g_bs_rec), rec, sizeof(rec));
   (void)rt0, (void)rt1;
@@ -603,7 +635,7 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                          int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, KpX* d_kx,
                          uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief, hipEvent_t before_lists, orbfe_keypoint* h_kps,
                          uint8_t* h_desc, int32_t* h_n_kp, bool fuse_small, uint32_t* d_rowoff_slot, uint16_t* d_rowlist_slot, int32_t* d_n_match,
-                         int rt_rows, int rt_list_cap, int rt_slot0) {
+                         int rt_rows, int rt_list_cap, int rt_slot0, int32_t* d_rt_flags) {
   // d_rowoff_slot != nullptr (a frame or two): the launch of the descriptors also builds the row table of every image into the slot's table
   if (n_img <= 0 || n_features <= 0) return;
   UmaxPacked u = 0;
@@ -611,15 +643,20 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
   if (fuse_small && n_img <= 2) {  // list + moments + orientation in one launch (a frame or two: three launch floors of ~5 us become one)
     if (before_lists) (void)hipStreamWaitEvent(s, before_lists, 0);
     hipLaunchKernelGGL(k_list_moments_orient<true>, dim3((n_features + 15) / 16, n_img), dim3(256), 0, s, d_lv, n_levels, d_sel, d_sel_count, n_features,
-                       d_pyr, img_pitch, u, d_kpl, d_moments, d_sincos, d_kps, d_aux, d_kx, d_theta, rows0, d_n_kp, h_kps, h_n_kp);
+                       d_pyr, img_pitch, u, d_kpl, d_moments, d_sincos, d_kps, d_aux, d_kx, d_theta, rows0, d_n_kp, h_kps, h_n_kp,
+                       (d_rowoff_slot && d_rt_flags) ? d_rt_flags + (size_t)rt_slot0 * 8 : (int32_t*)nullptr);
     if (before_brief) (void)hipStreamWaitEvent(s, before_brief, 0);
     const int nb = (((n_features + BRIEF_WAVES * BRIEF_KPW - 1) / (BRIEF_WAVES * BRIEF_KPW)) + 7) & ~7;
     BriefRowTable rt{};
     rt.n_brief_blocks = nb;
     if (d_rowoff_slot && (size_t)(rt_rows + 4) * 4 <= 9000)
-      rt = BriefRowTable{d_aux, d_n_kp, d_rowoff_slot, d_rowlist_slot, d_n_match, rt_rows, rt_list_cap, rt_slot0, nb};
-    hipLaunchKernelGGL(k_brief, dim3(nb + (rt.rowoff ? 8 : 0), n_img), dim3(64 * BRIEF_WAVES), 0, s, d_blur, img_pitch, d_kpl, n_features, d_pattern,
-                       d_sincos, d_desc, h_desc, rt);
+      rt = BriefRowTable{d_aux, d_n_kp, d_rowoff_slot, d_rowlist_slot, d_n_match, rt_rows, rt_list_cap, rt_slot0, nb, 0,
+                         d_rt_flags ? d_rt_flags + (size_t)rt_slot0 * 8 : (int32_t*)nullptr};
+    // the row-table workgroup's list staging: 40 KB of dynamic LDS (20 k entries: ten rows a keypoint at 2000 features) where the list's
+    // alignment allows 16-byte copies; two descriptor workgroups per CU still fit beside it
+    if (rt.rowoff && (rt.flags || rt_list_cap % 8 == 0)) rt.stage_cap = rt.flags ? 4 * std::min(n_features, 4096) : std::min(rt_list_cap, 20480);  // (parts: a band record, 8 bytes, per keypoint)
+    hipLaunchKernelGGL(k_brief, dim3(nb + (rt.rowoff ? 8 : 0), n_img), dim3(64 * BRIEF_WAVES), (size_t)rt.stage_cap * 2, s, d_blur, img_pitch, d_kpl, n_features,
+                       d_pattern, d_sincos, d_desc, h_desc, rt);
 #ifdef EXP_BRIEF_TWICE
     hipLaunchKernelGGL(k_brief, dim3(nb + (rt.rowoff ? 8 : 0), n_img), dim3(64 * BRIEF_WAVES), 0, s, d_blur, img_pitch, d_kpl, n_features, d_pattern,
                        d_sincos, d_desc, h_desc, rt);

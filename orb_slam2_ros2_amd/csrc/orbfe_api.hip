@@ -584,7 +584,7 @@ void orbfe_destroy(orbfe_ctx* c) {
   void* ptrs[] = {c->d_lv,   c->d_cells,     c->d_taps,   c->d_rs_tiles, c->d_pattern, c->d_pyr,     c->d_blur,
                   c->d_scr_a, c->d_scr_c,   c->d_scr_b,  c->d_sel,     c->d_sel_count, c->d_n_cand, c->d_n_cand_sh, c->d_n_kp,
                   c->d_kps,  c->d_desc,      c->d_aux,    c->d_theta, c->d_moments, c->d_sincos, c->d_kx, c->d_kpl,   c->d_right_u, c->d_depth, c->d_n_match,
-                  c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist, c->d_rowoff_slot, c->d_rowlist_slot, c->d_rs_regions, c->d_rg_xtaps, c->d_rg_ytaps, c->d_qt_big, c->d_qt_tabs, c->d_qt_next, c->d_mb_tx, c->d_mb_ty, c->st_rows.lrow_off, c->st_rows.lrow_list, c->st_rows.work, c->st_rows.work_n};
+                  c->d_best_right, c->d_best_dist, c->d_tmp, c->d_rowoff, c->d_rowlist, c->d_rowoff_slot, c->d_rowlist_slot, c->d_rt_flags, c->d_rs_regions, c->d_rg_xtaps, c->d_rg_ytaps, c->d_qt_big, c->d_qt_tabs, c->d_qt_next, c->d_mb_tx, c->d_mb_ty, c->st_rows.lrow_off, c->st_rows.lrow_list, c->st_rows.work, c->st_rows.work_n};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -778,6 +778,7 @@ orbfe_status orbfe_create(const orbfe_config* cfg, orbfe_ctx** out) {
   for (size_t k = 0; k < M; ++k) c->grid_key[k] = 0;
   if (M <= 16 && ((size_t)c->cfg.height + 4) * 4 <= 9000) {  // (k_brief's table workgroup borrows 9000 bytes of the descriptor kernel's LDS)
     ALLOC(c->d_rowoff_slot, M * (size_t)(c->cfg.height + 1));
+    if (!getenv("ORBFE_ROWTABLE_ONE_WG")) ALLOC(c->d_rt_flags, M * 8);  // (1: r5's one-workgroup table in k_brief's small launches)
     ALLOC(c->d_rowlist_slot, M * (size_t)c->row_list_cap);
     c->slot_table_ok.reset(new std::atomic<uint8_t>[M]);
     c->pair_count_zero.reset(new std::atomic<uint8_t>[M]);

@@ -67,7 +67,7 @@ void launch_orient_brief(hipStream_t s, const LevelDev* d_lv, int n_levels, cons
                          int32_t* d_n_kp, double* d_theta, int2* d_moments, double2* d_sincos, KpX* d_kx,
                          uint4* d_kpl, int rows0, int n_img, hipEvent_t before_brief, hipEvent_t before_lists, orbfe_keypoint* h_kps, uint8_t* h_desc, int32_t* h_n_kp,
                          bool fuse_small, uint32_t* d_rowoff_slot = nullptr, uint16_t* d_rowlist_slot = nullptr,
-                         int32_t* d_n_match = nullptr, int rt_rows = 0, int rt_list_cap = 0, int rt_slot0 = 0);
+                         int32_t* d_n_match = nullptr, int rt_rows = 0, int rt_list_cap = 0, int rt_slot0 = 0, int32_t* d_rt_flags = nullptr);
 // k_match.hip
 void launch_match_bruteforce(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, const uint32_t* d_off,
                              const uint32_t* d_cand, int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second);
@@ -290,6 +290,7 @@ struct orbfe_ctx {
   // extraction of one or two images, so that orbfe_stereo_match launches k_stereo alone.  slot_table_ok[s]: slot s's table belongs to
   // its current features; pair_count_zero[p]: the match counter of pair p has not been counted into since an extraction zeroed it.
   uint32_t* d_rowoff_slot = nullptr;
+  int32_t* d_rt_flags = nullptr;  // [slot][8]: part totals of a slot's row table while k_brief's eight spare workgroups build it (rowtable_build_part)
   uint16_t* d_rowlist_slot = nullptr;
   std::unique_ptr<std::atomic<uint8_t>[]> slot_table_ok, pair_count_zero;
   // The frame grid of a slot (VirtualFrame::initGrid) is kept from one guided search to the next: Tracking searches the same frame two to

@@ -184,7 +184,7 @@ orbfe_status run_extract(orbfe_ctx* c, hipStream_t st, int img0, int n_img, hipE
                         c->d_kpl + i0 * NF, c->cfg.height, n_img,
                         overlap_blur ? c->ev_blur_done : nullptr, before_lists, mirror ? mirror->kps : nullptr, mirror ? mirror->desc : nullptr,
                         mirror ? mirror->n_kp : nullptr, true, n_img <= 2 ? c->d_rowoff_slot : nullptr, c->d_rowlist_slot, c->d_n_match, c->cfg.height,
-                        c->row_list_cap, img0);
+                        c->row_list_cap, img0, n_img <= 2 ? c->d_rt_flags : nullptr);
     // (the per-slot row tables: valid after an extraction of one or two images, stale after any other -- the flags are host state and
     //  this function also runs under graph CAPTURE, so the callers set them: extract_lane / note_slots_written)
   }
