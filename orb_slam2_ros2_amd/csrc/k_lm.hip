@@ -983,11 +983,18 @@ __global__ __launch_bounds__(256) void k_lm_update(int n_poses, int n_points, in
         double upd[6];
 #pragma unroll
         for (int a = 0; a < 6; ++a) upd[a] = x[6 * s + a];
+        // (every loop over these small arrays unrolled: left as loops the arrays stay private memory, the compiler moves them to LDS
+        //  addressed by the flat thread number and reads the workgroup sizes for that from the dispatch packet -- in HOST memory: a scalar
+        //  load across PCIe at the start of every wave; see k_brief.hip, r6)
         PoseDev T, R;
+#pragma unroll
         for (int a = 0; a < 4; ++a) T.q[a] = src[a];
+#pragma unroll
         for (int a = 0; a < 3; ++a) T.t[a] = src[4 + a];
         pose_oplus(T, upd, R);
+#pragma unroll
         for (int a = 0; a < 4; ++a) dst[a] = R.q[a];
+#pragma unroll
         for (int a = 0; a < 3; ++a) dst[4 + a] = R.t[a];
         const double* bp = B.bp[cur] + (size_t)k * 6;
 #pragma unroll

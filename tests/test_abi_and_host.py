@@ -163,3 +163,12 @@ def test_dropin_header_compiles_against_the_stand_in_opencv_and_fails_loudly_wit
         pytest.skip("a device is present: the run-time half is tests/test_gpu_dropin.py")
     r = subprocess.run([exe, "poseonly"], capture_output=True, text=True)
     assert r.returncode == 3 and r.stdout.strip() == "NO_DEVICE"
+
+
+def test_no_kernel_reads_the_dispatch_packet():
+    """A kernel with a private array the compiler cannot scalarise (or with blockDim / gridDim) gets the dispatch pointer: its waves then begin
+    with a scalar load from the queue's ring buffer in HOST memory (r6: 13.6 us per wave of a pair's descriptor launch).  tools/check_dispatch_ptr.py
+    compiles every kernel file for gfx950 and looks at the kernel descriptors."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dispatch_ptr.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
