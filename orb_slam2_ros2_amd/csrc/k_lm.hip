@@ -1043,7 +1043,7 @@ __device__ void lm_ctrl_body(LmState* __restrict__ st, const LmBuffers& B, int m
     s.finalized = 1;
   }
   if (s.need_chi) {
-    s.chi_of[s.cur] = sum_cur;
+    if (s.cur) s.chi_of[1] = sum_cur; else s.chi_of[0] = sum_cur;  // (selects, not a variable index: the state record stays in registers -- as an indexed array it lived in scratch memory)
     s.need_chi = 0;
   }
   // (a) a trial ran since the last control point: decide it
@@ -1061,7 +1061,7 @@ __device__ void lm_ctrl_body(LmState* __restrict__ st, const LmBuffers& B, int m
       s.lambda *= fmax(1. / 3., alpha);
       s.ni = 2;
       s.current_chi = temp_chi;
-      s.chi_of[s.cur ^ 1] = chi_trial;
+      if (s.cur) s.chi_of[0] = chi_trial; else s.chi_of[1] = chi_trial;
       s.cur ^= 1;  // accept: the trial's estimate AND its system become current (no pop)
     } else {
       s.lambda *= s.ni;
@@ -1082,11 +1082,11 @@ __device__ void lm_ctrl_body(LmState* __restrict__ st, const LmBuffers& B, int m
   s.run_step = 0;
   if (mode == 0) {  // (b) schedule: the trial kernels of this step follow
     if (s.phase == 0) {  // `for (it ...) { if (stopped) break; ++done; computeActiveErrors; buildSystem; ...` -- both already in the CURRENT buffers
-      if (s.it >= s.iters[s.round] || s.stopped) {
+      if (s.it >= (s.round ? s.iters[1] : s.iters[0]) || s.stopped) {
         s.phase = 2;
       } else {
-        ++s.done[s.round];
-        s.current_chi = s.chi_of[s.cur];
+        if (s.round) ++s.done[1]; else ++s.done[0];
+        s.current_chi = s.cur ? s.chi_of[1] : s.chi_of[0];
         if (s.it == 0) {
           s.lambda = 1e-5 * s.maxdiag;  // computeLambdaInit, tau = 1e-5
           s.ni = 2;
