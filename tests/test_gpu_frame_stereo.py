@@ -42,6 +42,27 @@ def two_calls(ctx, L, R):
     return l, r, nm, ru, dp
 
 
+@pytest.mark.parametrize("f", [3, 11])
+def test_row_table_by_one_workgroup_equals_the_eight_part_table(lib, monkeypatch, f):
+    """The right image's stereo row table rides in the descriptor launch of a frame or two: by the launch's eight spare workgroups (r6,
+    rowtable_build_part: an eighth of the rows each, totals through flags) or, with ORBFE_ROWTABLE_ONE_WG=1, by one (r5).  Same matches, bit
+    for bit, through both call shapes; a context is built per setting (the switch is read at orbfe_create)."""
+    L, R = synth.stereo_pair(f)
+    res = []
+    for one in (False, True):
+        if one:
+            monkeypatch.setenv("ORBFE_ROWTABLE_ONE_WG", "1")
+        ctx = lib.Context(1241, 376, max_images=2)
+        try:
+            a = two_calls(ctx, L, R)
+            b = ctx.frame_stereo(L, R, FX, BF)
+            assert_same(a, b)
+            res.append(a)
+        finally:
+            ctx.close()
+    assert_same(res[0], res[1])
+
+
 @pytest.mark.parametrize("f", [0, 1, 7])
 def test_one_call_frame_against_oracle_and_golden(orc, lib, f):
     L, R = synth.stereo_pair(f)
